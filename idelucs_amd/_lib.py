@@ -1,0 +1,80 @@
+"""ctypes binding of libidelucs_hip.so (the C ABI in include/idelucs_hip.h).
+
+There is no CPU fallback anywhere in this package: if the shared library is missing the import
+fails, and if no gfx950 device is usable every compute entry point raises RuntimeError.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libidelucs_hip.so")
+
+IDL_OK, IDL_ERR_ARG, IDL_ERR_HIP, IDL_ERR_IO, IDL_ERR_HEADER, IDL_ERR_BASE, IDL_ERR_NOMEM = 0, -1, -2, -3, -4, -5, -6
+MODE_KMER, MODE_CGR, MODE_CANONICAL = 0, 1, 2
+INIT_ZERO, INIT_ONE, INIT_FROM_OUT = 0, 1, 2
+OUT_COUNTS_I32, OUT_FREQ_F32, OUT_FREQ_F64 = 0, 1, 2
+MAX_K = 7
+
+_c = ctypes
+_vp, _i64, _i32, _int = _c.c_void_p, _c.c_int64, _c.c_int32, _c.c_int
+_pi64, _pu8 = _c.POINTER(_c.c_int64), _c.POINTER(_c.c_uint8)
+
+# name -> (restype, argtypes); kept in one table so tests can check every symbol the header declares
+SIGNATURES = {
+    "idl_last_error": (_c.c_char_p, []),
+    "idl_abi_version": (_int, []),
+    "idl_device_count": (_int, []),
+    "idl_row_len": (_i64, [_int, _int]),
+    "idl_kmer_counts": (_int, [_vp, _i64, _int, _vp]),
+    "idl_cgr": (_int, [_vp, _i64, _int, _vp]),
+    "idl_kmer_rev_comp": (_int, [_vp, _int, _vp]),
+    "idl_check_sequence": (_int, [_vp, _i64, _vp, _pi64, _pi64]),
+    "idl_pack": (_int, [_vp, _vp, _i64, _vp, _vp, _vp]),
+    "idl_fasta_open": (_int, [_c.c_char_p, _int, _c.POINTER(_vp)]),
+    "idl_fasta_close": (None, [_vp]),
+    "idl_fasta_sizes": (_int, [_vp, _pi64, _pi64, _pi64, _pi64]),
+    "idl_fasta_export": (_int, [_vp] + [_vp] * 8),
+    "idl_vectorise": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _int, _int, _int, _int, _vp, _vp, _vp, _i64, _vp]),
+    "idl_mimic_workspace": (_i64, [_int]),
+    "idl_mimic_edits": (_int, [_vp, _i64, _int, _vp, _vp, _vp, _c.c_uint64, _vp, _vp, _i64, _pi64, _vp, _vp]),
+    "idl_col_stats_workspace": (_i64, [_i64, _i64]),
+    "idl_col_stats": (_int, [_vp, _int, _i64, _i64, _vp, _vp, _vp, _vp]),
+    "idl_standardise": (_int, [_vp, _int, _i64, _i64, _vp, _vp, _vp, _vp]),
+    "idl_gather_pairs": (_int, [_vp, _i64, _i64, _i64, _vp, _i64, _vp, _vp, _vp, _vp]),
+}
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} is missing: build it with `make -C idelucs_amd/csrc` (or __graft_entry__.build()). "
+        "idelucs_amd has no CPU fallback.")
+
+lib = ctypes.CDLL(LIB_PATH)
+for _name, (_res, _args) in SIGNATURES.items():
+    _fn = getattr(lib, _name)
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+
+def last_error():
+    msg = lib.idl_last_error()
+    return msg.decode("utf-8", "replace") if msg else ""
+
+
+def check(rc):
+    """Map a C-ABI return code onto the exception the reference raises for the same condition."""
+    if rc == IDL_OK:
+        return
+    msg = last_error()
+    if rc in (IDL_ERR_HEADER, IDL_ERR_BASE, IDL_ERR_ARG):
+        raise ValueError(msg)              # reference: ValueError (utils.py:38,40,50)
+    if rc == IDL_ERR_IO:
+        raise FileNotFoundError(msg)       # reference: open() failure
+    if rc == IDL_ERR_NOMEM:
+        raise MemoryError(msg)
+    raise RuntimeError(msg or f"libidelucs_hip error {rc}")
+
+
+def require_gpu():
+    if lib.idl_device_count() < 1:
+        raise RuntimeError("idelucs_amd needs a gfx950 (MI355X) GPU: no usable HIP device found, "
+                           "and there is no CPU fallback")

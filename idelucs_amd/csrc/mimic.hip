@@ -1,0 +1,284 @@
+// mimic.hip -- "fast mode" mimic-mutation generator for gfx950: substitution edits drawn on the
+// device from a counter-based RNG, in the edit format the vectoriser consumes.
+//
+// What it replaces: the site selection of idelucs/utils.py:54-135 -- transition(p): every base
+// independently w.p. p (utils.py:69-70); transversion(p): likewise, target chosen uniformly between
+// the two transversions (utils.py:111-118); transition_transversion: both, sequentially
+// (utils.py:131-135); Random_N(n): n positions uniform with replacement (utils.py:93).
+// The reference draws these from numpy's global MT19937 and Python's `random`; that stream cannot
+// be reproduced on a GPU, so bit-parity with the reference lives in the host-RNG "compat" path
+// (idelucs_amd/utils.py) and THIS generator is statistically equivalent: identical per-base site
+// probabilities and target distributions, checked bit-for-bit against oracle/idelucs_oracle.c's
+// restatement of the spec below and statistically against the reference's rates.
+//
+// Spec (one wavefront per (sequence, view); lane l owns bases [l*seg, min(L,(l+1)*seg)), seg = ceil(L/64)):
+//   site views   q = 1-(1-p_ts)(1-p_tv).  Sites are placed by exact geometric gap sampling: draw
+//                r = Philox4x32-10(key = seed, ctr = (draw#, lane, seq, view)); gap-1 = the largest
+//                j <= J with r.x < T[j], T[j] = floor((1-q)^j * 2^32) (T[0] = +inf, J = 1024;
+//                j == J means "no site in the next J bases", resampled -- the geometric law is
+//                memoryless, so both the per-lane restart and the tail cut are exact).  Site type
+//                from r.y: < A transition only, < B transversion only, else both;
+//                transversion flavour = r.z & 1.  op = 2 | 1,3 | 3,1  (XOR on A0 C1 G2 T3).
+//   Random_N     lane i < n: pos = mulhi(Philox(ctr = (i, 0, seq, view | 1<<16)).x, L); positions are
+//                wave-sorted ascending (duplicates kept); op = 0 (N).  Nothing is emitted for L = 0.
+// Two passes (count, exclusive scan, fill) so that the caller sizes `edits` exactly.
+#include "common.h"
+
+namespace {
+
+constexpr int J = 1024;            // gap table length
+constexpr int MAX_VIEWS = 64;
+
+struct MimicParams {
+    double one_minus_q[MAX_VIEWS];
+    uint32_t thr_ts_only[MAX_VIEWS];   // A
+    uint32_t thr_tv_only[MAX_VIEWS];   // B (cumulative)
+    int32_t n_rand[MAX_VIEWS];
+    uint8_t has_sites[MAX_VIEWS];
+    uint8_t kind[MAX_VIEWS];           // 0 mixed (use A/B), 1 transition only, 2 transversion only
+};
+
+struct U4 { uint32_t x, y, z, w; };
+
+__host__ __device__ inline U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1)
+{
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        const uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return U4{c0, c1, c2, c3};
+}
+
+// T[v][0..J]: T[0] unused (+inf), T[j] = floor((1-q)^j * 2^32) by repeated float64 multiplication
+__global__ void mimic_table_kernel(MimicParams p, int n_views, uint32_t *tables)
+{
+    const int v = blockIdx.x;
+    if (threadIdx.x != 0 || v >= n_views) return;
+    uint32_t *T = tables + (size_t)v * (J + 1);
+    T[0] = 0xFFFFFFFFu;
+    if (!p.has_sites[v]) return;
+    double x = 1.0;
+    for (int j = 1; j <= J; ++j) {
+        x = x * p.one_minus_q[v];
+        T[j] = (uint32_t)(x * 4294967296.0);
+    }
+}
+
+__device__ __forceinline__ uint32_t wave_sort_u32(uint32_t key, int lane)
+{
+    // bitonic sort across the 64 lanes, ascending
+#pragma unroll
+    for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            const uint32_t other = __shfl_xor(key, j, 64);
+            const bool up = ((lane & k) == 0);
+            const bool lower = ((lane & j) == 0);
+            const uint32_t mn = key < other ? key : other, mx = key < other ? other : key;
+            key = (lower == up) ? mn : mx;
+        }
+    }
+    return key;
+}
+
+template <bool FILL>
+__global__ __launch_bounds__(64) void mimic_kernel(MimicParams p, int n_views, const int64_t *lengths, int64_t n, uint32_t k0,
+                                                   uint32_t k1, const uint32_t *tables, int64_t *counts_or_off, uint32_t *edits,
+                                                   int64_t capacity)
+{
+    __shared__ uint32_t T[J + 1];
+    const int lane = threadIdx.x;
+    const int64_t items = n * n_views;
+    int cur_view = -1;
+    for (int64_t it = blockIdx.x; it < items; it += gridDim.x) {
+        // view-major items keep the table resident: item = v * n + s
+        const int v = (int)(it / n);
+        const int64_t s = it - (int64_t)v * n;
+        const int64_t L = lengths[s];
+        uint32_t my_count = 0;
+        int64_t base = 0;
+        if (FILL) base = counts_or_off[it];
+
+        if (p.n_rand[v] > 0) {
+            uint32_t key = 0xFFFFFFFFu;
+            const int nr = L > 0 ? p.n_rand[v] : 0;
+            if (lane < nr) {
+                const U4 r = philox4x32_10((uint32_t)lane, 0u, (uint32_t)s, (uint32_t)v | (1u << 16), k0, k1);
+                key = (uint32_t)(((uint64_t)r.x * (uint64_t)(uint32_t)L) >> 32);
+            }
+            key = wave_sort_u32(key, lane);
+            if (FILL) { if (lane < nr && base + lane < capacity) edits[base + lane] = key; }       // op 0 = N
+            else if (lane == 0) counts_or_off[it] = nr;
+            continue;
+        }
+        if (!p.has_sites[v]) {
+            if (!FILL && lane == 0) counts_or_off[it] = 0;
+            continue;
+        }
+        if (cur_view != v) {
+            __syncthreads();
+            for (int j = lane; j <= J; j += 64) T[j] = tables[(size_t)v * (J + 1) + j];
+            __syncthreads();
+            cur_view = v;
+        }
+        const int64_t seg = (L + 63) / 64;
+        const int64_t lo = (int64_t)lane * seg;
+        int64_t hi = lo + seg;
+        if (hi > L) hi = L;
+        const uint32_t A = p.thr_ts_only[v], B = p.thr_tv_only[v];
+        const int kind = p.kind[v];
+
+        // in FILL mode each lane needs its output offset first: recount (same RNG) then prefix
+        uint32_t lane_off = 0;
+        if (FILL) {
+            uint32_t c = 0;
+            int64_t pos = lo - 1;
+            for (uint32_t d = 0; pos < hi; ++d) {
+                const U4 r = philox4x32_10(d, (uint32_t)lane, (uint32_t)s, (uint32_t)v, k0, k1);
+                int a = 0, b = J;                    // largest j in [0, J] with r.x < T[j]
+                while (a < b) { const int m = (a + b + 1) >> 1; if (r.x < T[m]) a = m; else b = m - 1; }
+                if (a == J) { pos += J; continue; }
+                pos += a + 1;
+                if (pos < hi) ++c;
+            }
+            uint32_t incl = c;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+            lane_off = incl - c;
+        }
+        {
+            int64_t pos = lo - 1;
+            for (uint32_t d = 0; pos < hi; ++d) {
+                const U4 r = philox4x32_10(d, (uint32_t)lane, (uint32_t)s, (uint32_t)v, k0, k1);
+                int a = 0, b = J;
+                while (a < b) { const int m = (a + b + 1) >> 1; if (r.x < T[m]) a = m; else b = m - 1; }
+                if (a == J) { pos += J; continue; }
+                pos += a + 1;
+                if (pos >= hi) break;
+                if (FILL) {
+                    const uint32_t flav = 1u | ((r.z & 1u) << 1);        // transversion: ^1 or ^3
+                    uint32_t op = (r.y < A) ? 2u : (r.y < B) ? flav : (2u ^ flav);
+                    if (kind == 1) op = 2u;
+                    if (kind == 2) op = flav;
+                    const int64_t o = base + lane_off + my_count;
+                    if (o < capacity) edits[o] = (uint32_t)pos | (op << 30);
+                }
+                ++my_count;
+            }
+        }
+        if (!FILL) {
+            uint32_t tot = my_count;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o, 64);
+            if (lane == 0) counts_or_off[it] = tot;
+        }
+    }
+}
+
+// in-place exclusive scan of m int64 counts (single workgroup); off[m] = total
+__global__ __launch_bounds__(1024) void scan_kernel(int64_t *off, int64_t m, int64_t *total)
+{
+    __shared__ int64_t part[1024];
+    const int t = threadIdx.x;
+    const int64_t per = (m + 1023) / 1024;
+    const int64_t a = (int64_t)t * per;
+    int64_t b = a + per;
+    if (b > m) b = m;
+    int64_t sum = 0;
+    for (int64_t i = a; i < b; ++i) sum += off[i];
+    part[t] = sum;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const int64_t x = (t >= o) ? part[t - o] : 0;
+        __syncthreads();
+        part[t] += x;
+        __syncthreads();
+    }
+    int64_t run = part[t] - sum;
+    for (int64_t i = a; i < b; ++i) { const int64_t c = off[i]; off[i] = run; run += c; }
+    if (t == 1023) { off[m] = part[1023]; *total = part[1023]; }
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t idl_mimic_workspace(int n_views)
+{
+    if (n_views < 1 || n_views > MAX_VIEWS) return -1;
+    return (int64_t)n_views * (J + 1) * 4 + 64;
+}
+
+int idl_mimic_edits(const int64_t *lengths, int64_t n, int n_views, const double *p_transition,
+                    const double *p_transversion, const int32_t *n_random_n, uint64_t seed,
+                    int64_t *edit_off, uint32_t *edits, int64_t edits_capacity, int64_t *total_edits,
+                    void *workspace, void *stream)
+{
+    IDL_REQUIRE(n >= 0 && n_views >= 1 && n_views <= MAX_VIEWS, "n < 0 or n_views outside 1..64");
+    IDL_REQUIRE(p_transition && p_transversion && n_random_n && edit_off && workspace, "NULL buffer");
+    IDL_REQUIRE(n < (1ll << 32), "more than 2^32 sequences");
+    MimicParams p{};
+    for (int v = 0; v < n_views; ++v) {
+        const double a = p_transition[v], b = p_transversion[v];
+        IDL_REQUIRE(a >= 0.0 && a < 1.0 && b >= 0.0 && b < 1.0, "probabilities must be in [0, 1)");
+        IDL_REQUIRE(n_random_n[v] >= 0 && n_random_n[v] <= 64, "n_random_n outside 0..64");
+        IDL_REQUIRE(!(n_random_n[v] > 0 && (a > 0.0 || b > 0.0)), "a view is either a site view or a Random_N view");
+        const double keep = (1.0 - a) * (1.0 - b);
+        const double q = 1.0 - keep;
+        p.one_minus_q[v] = keep;
+        p.n_rand[v] = n_random_n[v];
+        p.has_sites[v] = q > 0.0;
+        if (q > 0.0) {
+            const double fa = (a * (1.0 - b)) / q * 4294967296.0;
+            const double fb = ((1.0 - a) * b) / q * 4294967296.0;
+            const double A = fa >= 4294967295.0 ? 4294967295.0 : fa;
+            double B = A + fb;
+            if (B > 4294967295.0) B = 4294967295.0;
+            p.thr_ts_only[v] = (uint32_t)A;
+            p.thr_tv_only[v] = (uint32_t)B;
+            p.kind[v] = (b == 0.0) ? 1 : (a == 0.0) ? 2 : 0;
+        }
+    }
+    idl::DeviceInfo di;
+    int rc = idl::device_info(&di);
+    if (rc != IDL_OK) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    uint32_t *tables = (uint32_t *)workspace;
+    int64_t *d_total = (int64_t *)((uint8_t *)workspace + (size_t)n_views * (J + 1) * 4);
+    d_total = (int64_t *)(((uintptr_t)d_total + 7u) & ~(uintptr_t)7u);
+    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    const int64_t items = n * n_views;
+    if (items == 0) {
+        IDL_HIP_TRY(hipMemsetAsync(edit_off, 0, sizeof(int64_t), st));
+        if (total_edits) *total_edits = 0;
+        return IDL_OK;
+    }
+    int64_t grid = (int64_t)di.cus * 16;
+    if (grid > items) grid = items;
+    hipLaunchKernelGGL(mimic_table_kernel, dim3((unsigned)n_views), dim3(64), 0, st, p, n_views, tables);
+    if (edits == nullptr) {
+        hipLaunchKernelGGL(mimic_kernel<false>, dim3((unsigned)grid), dim3(64), 0, st, p, n_views, lengths, n, k0, k1, tables,
+                           edit_off, (uint32_t *)nullptr, (int64_t)0);
+        hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, st, edit_off, items, d_total);
+        IDL_HIP_TRY(hipGetLastError());
+        if (total_edits) {
+            IDL_HIP_TRY(hipMemcpyAsync(total_edits, d_total, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+            IDL_HIP_TRY(hipStreamSynchronize(st));
+        }
+        return IDL_OK;
+    }
+    // fill pass: edit_off must hold the offsets produced by the count pass with the same arguments
+    IDL_REQUIRE(edits_capacity >= 0, "negative capacity");
+    hipLaunchKernelGGL(mimic_kernel<true>, dim3((unsigned)grid), dim3(64), 0, st, p, n_views, lengths, n, k0, k1, tables,
+                       edit_off, edits, edits_capacity);
+    IDL_HIP_TRY(hipGetLastError());
+    return IDL_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,474 @@
+// vectorise.hip -- the k-mer / CGR / canonical vectoriser for gfx950 (MI355X).
+//
+// One wavefront (64 lanes) per sequence.  The wave walks the packed sequence in chunks of
+// 64 slots (= 4096 bases: one 16-byte code load + one 8-byte mask load per lane, fully
+// coalesced), applies the view's substitution edits through a 1.5 KiB LDS staging image,
+// and bumps a wave-private 4^k-bin uint32 histogram in LDS with ds_add_u32.  After the last
+// chunk the histogram is read back once, converted (pseudocount / normalise / CGR permutation /
+// reverse-complement collapse) and written to HBM with one coalesced pass -- the only global
+// write of the sequence.  All `n_views` mimic views of a sequence are produced back to back by
+// the same wave, so the packed bases are fetched from HBM once and re-read from L1/L2.
+//
+// Reference semantics restated here (not translated: the reference is a scalar byte loop):
+//   idelucs/kmers.pyx:2-50   kmer_counts  -> window = k consecutive valid bases, first base in
+//                                            the most significant 2-bit pair of the index
+//   idelucs/kmers.pyx:53-123 cgr          -> same windows, pixel index = fixed bit permutation
+//   idelucs/utils.py:191-221 kmer_rev_comp-> canonical collapse with int truncation
+//   idelucs/utils.py:242-250 ones-init, counts / sum(counts)
+//   idelucs/utils.py:54-135  transforms   -> substitution edits (XOR on 2-bit codes / set-N)
+#include "common.h"
+
+namespace {
+
+struct VecArgs {
+    const uint4 *codes;
+    const uint2 *mask;
+    const int64_t *slot_off;
+    const int64_t *lengths;
+    int64_t n;
+    int mode, init, out_kind, n_views;
+    const uint32_t *edits;
+    const int64_t *edit_off;
+    void *out;
+    int64_t view_stride;
+};
+
+constexpr int STAGE_DWORDS = 256 + 128;  // 64 lanes x (4 code words + 2 mask words)
+
+__device__ __forceinline__ uint32_t spread_bits(uint32_t x)
+{
+    x = (x | (x << 4)) & 0x0F0Fu;
+    x = (x | (x << 2)) & 0x3333u;
+    x = (x | (x << 1)) & 0x5555u;
+    return x;
+}
+
+// k-mer index (A0 C1 G2 T3, oldest base in the top pair) whose CGR pixel is `o` = (i << K) + j.
+// kmers.pyx:110-123: bit p of i/j belongs to the p-th (oldest first) base of the window;
+// (ibit, jbit): A(1,0) C(0,0) G(0,1) T(1,1)  =>  code = jbit<<1 | !(ibit ^ jbit).
+template <int K>
+__device__ __forceinline__ uint32_t cgr_pixel_to_kmer(uint32_t o)
+{
+    constexpr uint32_t M = (1u << K) - 1u;
+    uint32_t i = o >> K, j = o & M;
+    uint32_t ir = __brev(i) >> (32 - K), jr = __brev(j) >> (32 - K);  // base p -> bit K-1-p
+    uint32_t lo = ~(ir ^ jr) & M;
+    return (spread_bits(jr) << 1) | spread_bits(lo);
+}
+
+// reverse complement of a k-mer index (utils.py:191-206): complement every base (3 - code),
+// reverse the order of the 2-bit groups.
+template <int K>
+__device__ __forceinline__ uint32_t revcomp(uint32_t b)
+{
+    constexpr uint32_t KM = (1u << (2 * K)) - 1u;
+    uint32_t r = __brev(~b & KM) >> (32 - 2 * K);                  // reverses bits inside the pairs too
+    return ((r >> 1) & 0x55555555u) | ((r & 0x55555555u) << 1);   // ... so swap them back
+}
+
+__device__ __forceinline__ int64_t wave_sum_i64(int64_t v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// Count the 16 windows that END in `cur` (16 bases, first base in the top pair).
+//   prev : the 16 bases before `cur`
+//   M    : (invalid bits of prev's 16 bases) << 16 | invalid bits of cur's 16 bases, base j at bit 15-j
+template <int K>
+__device__ __forceinline__ uint32_t count_word(uint32_t *hist, uint32_t prev, uint32_t cur, uint32_t M)
+{
+    constexpr uint32_t KM = (1u << (2 * K)) - 1u;
+    // bit 15-j of `inv` is set when any of the K bases of the window ending at base j is invalid
+    uint32_t inv = M;
+#pragma unroll
+    for (int t = 1; t < K; ++t) inv |= (M >> t);
+    inv &= 0xFFFFu;
+    const uint64_t w = ((uint64_t)prev << 32) | cur;
+    if (__ballot(inv != 0u) == 0ull) {  // wave-uniform fast path: every window of every lane is valid
+#pragma unroll
+        for (int j = 0; j < 16; ++j) atomicAdd(&hist[(uint32_t)(w >> (30 - 2 * j)) & KM], 1u);
+        return 16u;
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        if (!((inv >> (15 - j)) & 1u)) atomicAdd(&hist[(uint32_t)(w >> (30 - 2 * j)) & KM], 1u);
+    }
+    return 16u - (uint32_t)__popc(inv);
+}
+
+template <int K>
+__global__ __launch_bounds__(64) void vectorise_kernel(VecArgs a)
+{
+    constexpr int F = 1 << (2 * K);
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    uint32_t *hist = lds;
+    uint32_t *st_codes = lds + F;
+    uint32_t *st_mask = st_codes + 256;
+    const int lane = threadIdx.x;
+    const int64_t row_len = (a.mode == IDL_MODE_CANONICAL)
+                                ? ((K % 2 == 0) ? (F + (1 << K)) / 2 : F / 2)
+                                : F;
+
+    for (int64_t s = blockIdx.x; s < a.n; s += gridDim.x) {
+        const int64_t slot0 = a.slot_off[s];
+        const int64_t nslots = a.slot_off[s + 1] - slot0;
+
+        for (int v = 0; v < a.n_views; ++v) {
+            const int64_t out_base = (int64_t)v * a.view_stride + s * row_len;
+
+            // ---------------- histogram init
+            if (a.init == IDL_INIT_FROM_OUT) {
+                const uint32_t *src = (const uint32_t *)a.out + out_base;
+                for (int i = lane; i < F; i += 64) hist[i] = src[i];
+            } else {
+                const uint32_t iv = (a.init == IDL_INIT_ONE) ? 1u : 0u;
+                for (int i = lane; i < F; i += 64) hist[i] = iv;
+            }
+            __syncthreads();
+
+            int64_t ecur = 0, eend = 0;
+            if (a.edits != nullptr) {
+                ecur = a.edit_off[(int64_t)v * a.n + s];
+                eend = a.edit_off[(int64_t)v * a.n + s + 1];
+            }
+
+            uint32_t carry_code = 0u, carry_mask = 0xFFFFFFFFu;  // nothing before the sequence: invalid
+            uint32_t cnt = 0u;
+
+            for (int64_t c0 = 0; c0 < nslots; c0 += 64) {
+                const int64_t slot = c0 + lane;
+                uint4 cw = make_uint4(0u, 0u, 0u, 0u);
+                uint2 mw = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+                if (slot < nslots) {
+                    cw = a.codes[slot0 + slot];
+                    mw = a.mask[slot0 + slot];
+                }
+
+                // ---------------- apply this view's edits that fall inside the chunk
+                if (ecur < eend) {
+                    const int64_t chunk_lo = c0 * 64, chunk_hi = chunk_lo + 4096;
+                    *(uint4 *)(st_codes + lane * 4) = cw;
+                    *(uint2 *)(st_mask + lane * 2) = mw;
+                    __syncthreads();
+                    while (ecur < eend) {
+                        const int64_t e = ecur + lane;
+                        bool act = false;
+                        if (e < eend) {
+                            const uint32_t ed = a.edits[e];
+                            const int64_t pos = (int64_t)(ed & 0x3FFFFFFFu);
+                            act = pos < chunk_hi;
+                            if (act && pos >= chunk_lo) {
+                                const uint32_t rel = (uint32_t)(pos - chunk_lo), op = ed >> 30;
+                                if (op == 0u) atomicOr(&st_mask[rel >> 5], 0x80000000u >> (rel & 31u));
+                                else atomicXor(&st_codes[rel >> 4], op << (30u - 2u * (rel & 15u)));
+                            }
+                        }
+                        const int na = __popcll(__ballot(act));
+                        ecur += na;
+                        if (na < 64) break;
+                    }
+                    __syncthreads();
+                    cw = *(uint4 *)(st_codes + lane * 4);
+                    mw = *(uint2 *)(st_mask + lane * 2);
+                    __syncthreads();
+                }
+
+                // ---------------- history of the previous 16 bases (previous lane / previous chunk)
+                uint32_t pc = __shfl_up(cw.w, 1, 64);
+                uint32_t pm = __shfl_up(mw.y, 1, 64);
+                if (lane == 0) { pc = carry_code; pm = carry_mask; }
+                carry_code = __shfl(cw.w, 63, 64);
+                carry_mask = __shfl(mw.y, 63, 64);
+
+                cnt += count_word<K>(hist, pc, cw.x, (pm << 16) | (mw.x >> 16));
+                cnt += count_word<K>(hist, cw.x, cw.y, mw.x);
+                cnt += count_word<K>(hist, cw.y, cw.z, (mw.x << 16) | (mw.y >> 16));
+                cnt += count_word<K>(hist, cw.z, cw.w, mw.y);
+            }
+            __syncthreads();
+
+            // ---------------- epilogue: one pass over the histogram, one coalesced global write
+            const int64_t windows = wave_sum_i64((int64_t)cnt);
+
+            if (a.mode == IDL_MODE_CANONICAL) {
+                // utils.py:208-221: canonical b (b <= rc): int32((h[b] + h[rc]) * 0.5); ascending order
+                int64_t part = 0;
+                if (a.out_kind != IDL_OUT_COUNTS_I32) {
+                    for (int b0 = 0; b0 < F; b0 += 64) {
+                        const uint32_t b = b0 + lane;
+                        if (b < (uint32_t)F) {
+                            const uint32_t rc = revcomp<K>(b);
+                            if (b <= rc) part += (int32_t)(hist[b] + hist[rc]) / 2;
+                        }
+                    }
+                }
+                const int64_t S = wave_sum_i64(part);
+                int rank0 = 0;
+                for (int b0 = 0; b0 < F; b0 += 64) {
+                    const uint32_t b = b0 + lane;
+                    bool canon = false;
+                    int32_t val = 0;
+                    if (b < (uint32_t)F) {
+                        const uint32_t rc = revcomp<K>(b);
+                        canon = b <= rc;
+                        if (canon) val = (int32_t)(hist[b] + hist[rc]) / 2;
+                    }
+                    const uint64_t bal = __ballot(canon);
+                    if (canon) {
+                        const int64_t o = out_base + rank0 + __popcll(bal & ((1ull << lane) - 1ull));
+                        if (a.out_kind == IDL_OUT_COUNTS_I32) ((int32_t *)a.out)[o] = val;
+                        else if (a.out_kind == IDL_OUT_FREQ_F64) ((double *)a.out)[o] = (double)val / (double)S;
+                        else ((float *)a.out)[o] = (float)((double)val / (double)S);
+                    }
+                    rank0 += __popcll(bal);
+                }
+            } else {
+                // row sum: every bin started at `init` (or at the caller's value) and got `windows` increments
+                int64_t S;
+                if (a.init == IDL_INIT_FROM_OUT) S = 0;  // counts only
+                else S = windows + ((a.init == IDL_INIT_ONE) ? (int64_t)F : 0);
+                const bool small = S < (1ll << 24);  // then int -> float32 is exact and f32 division == f64 division rounded
+                const float Sf = (float)S;
+                const double Sd = (double)S;
+                if (a.mode == IDL_MODE_KMER && F >= 256 && a.out_kind != IDL_OUT_FREQ_F64) {
+                    for (int i4 = lane; i4 < F / 4; i4 += 64) {
+                        const uint4 h = *(const uint4 *)(hist + i4 * 4);
+                        if (a.out_kind == IDL_OUT_COUNTS_I32) {
+                            *(uint4 *)((uint32_t *)a.out + out_base + i4 * 4) = h;
+                        } else {
+                            float4 f;
+                            if (small) {
+                                f.x = (float)h.x / Sf; f.y = (float)h.y / Sf;
+                                f.z = (float)h.z / Sf; f.w = (float)h.w / Sf;
+                            } else {
+                                f.x = (float)((double)h.x / Sd); f.y = (float)((double)h.y / Sd);
+                                f.z = (float)((double)h.z / Sd); f.w = (float)((double)h.w / Sd);
+                            }
+                            *(float4 *)((float *)a.out + out_base + i4 * 4) = f;
+                        }
+                    }
+                } else {
+                    for (int i = lane; i < F; i += 64) {
+                        const uint32_t src = (a.mode == IDL_MODE_CGR) ? cgr_pixel_to_kmer<K>((uint32_t)i) : (uint32_t)i;
+                        const uint32_t h = hist[src];
+                        if (a.out_kind == IDL_OUT_COUNTS_I32) ((uint32_t *)a.out)[out_base + i] = h;
+                        else if (a.out_kind == IDL_OUT_FREQ_F64) ((double *)a.out)[out_base + i] = (double)h / Sd;
+                        else ((float *)a.out)[out_base + i] = small ? (float)h / Sf : (float)((double)h / Sd);
+                    }
+                }
+            }
+            __syncthreads();  // the histogram is re-initialised for the next view
+        }
+    }
+}
+
+// collapse a host-provided histogram (idl_kmer_rev_comp): one wave, counts modified in place like utils.py:216-217
+template <int K>
+__global__ __launch_bounds__(64) void collapse_kernel(int32_t *counts, int32_t *out)
+{
+    constexpr int F = 1 << (2 * K);
+    const int lane = threadIdx.x;
+    int rank0 = 0;
+    for (int b0 = 0; b0 < F; b0 += 64) {
+        const uint32_t b = b0 + lane;
+        bool canon = false;
+        int32_t val = 0;
+        if (b < (uint32_t)F) {
+            const uint32_t rc = revcomp<K>(b);
+            canon = b <= rc;
+            if (canon) val = (int32_t)((uint32_t)counts[b] + (uint32_t)counts[rc]) / 2;
+        }
+        const uint64_t bal = __ballot(canon);
+        if (canon) {
+            out[rank0 + __popcll(bal & ((1ull << lane) - 1ull))] = val;
+            counts[b] = val;  // only canonical entries are written; reads of rc > b never race with them
+        }
+        rank0 += __popcll(bal);
+    }
+}
+
+template <int K>
+int launch_vectorise(const VecArgs &a, const idl::DeviceInfo &di, hipStream_t st)
+{
+    constexpr int F = 1 << (2 * K);
+    const size_t lds = (size_t)(F + STAGE_DWORDS) * 4;
+    if ((int)lds > di.max_dyn_lds) {
+        idl::set_error("k=%d needs %zu bytes of LDS per wavefront; device allows %d", K, lds, di.max_dyn_lds);
+        return IDL_ERR_ARG;
+    }
+    if (lds > 64 * 1024) {
+        IDL_HIP_TRY(hipFuncSetAttribute((const void *)vectorise_kernel<K>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    int per_cu = di.lds_per_cu / (int)lds;
+    if (per_cu > 16) per_cu = 16;
+    if (per_cu < 1) per_cu = 1;
+    int64_t grid = (int64_t)di.cus * per_cu;
+    if (grid > a.n) grid = a.n;
+    hipLaunchKernelGGL(vectorise_kernel<K>, dim3((unsigned)grid), dim3(64), lds, st, a);
+    IDL_HIP_TRY(hipGetLastError());
+    return IDL_OK;
+}
+
+int dispatch_vectorise(int k, const VecArgs &a, hipStream_t st)
+{
+    idl::DeviceInfo di;
+    int rc = idl::device_info(&di);
+    if (rc != IDL_OK) return rc;
+    switch (k) {
+    case 1: return launch_vectorise<1>(a, di, st);
+    case 2: return launch_vectorise<2>(a, di, st);
+    case 3: return launch_vectorise<3>(a, di, st);
+    case 4: return launch_vectorise<4>(a, di, st);
+    case 5: return launch_vectorise<5>(a, di, st);
+    case 6: return launch_vectorise<6>(a, di, st);
+    case 7: return launch_vectorise<7>(a, di, st);
+    }
+    idl::set_error("k=%d outside 1..%d", k, IDL_MAX_K);
+    return IDL_ERR_ARG;
+}
+
+struct DevBuf {  // RAII for the scalar host-pointer entry points
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+};
+
+int scalar_count(const uint8_t *seq, int64_t len, int k, int32_t *counts, int mode)
+{
+    IDL_REQUIRE(k >= 1 && k <= IDL_MAX_K, "k outside 1..IDL_MAX_K");
+    IDL_REQUIRE(len >= 0 && (len == 0 || seq != nullptr) && counts != nullptr, "NULL buffer");
+    IDL_REQUIRE(len < (1ll << 31), "sequence longer than 2^31 (kmers.pyx:16 int contiglength)");
+    idl::DeviceInfo di;
+    int rc = idl::device_info(&di);
+    if (rc != IDL_OK) return rc;
+    const int64_t F = 1ll << (2 * k);
+    const int64_t slots = (len + 63) / 64;
+    const int64_t byte_off[2] = {0, len};
+    int64_t slot_off[2];
+    uint8_t *h_codes = (uint8_t *)malloc((size_t)(slots > 0 ? slots : 1) * 24);
+    if (!h_codes) { idl::set_error("out of host memory"); return IDL_ERR_NOMEM; }
+    uint8_t *h_mask = h_codes + (size_t)(slots > 0 ? slots : 1) * 16;
+    rc = idl_pack(seq, byte_off, 1, h_codes, h_mask, slot_off);
+    if (rc != IDL_OK) { free(h_codes); return rc; }
+
+    DevBuf d_codes, d_mask, d_meta, d_out;
+    struct FreeHost { uint8_t *p; ~FreeHost() { free(p); } } fh{h_codes};
+    IDL_HIP_TRY(hipMalloc(&d_codes.p, (size_t)(slots > 0 ? slots : 1) * 16));
+    IDL_HIP_TRY(hipMalloc(&d_mask.p, (size_t)(slots > 0 ? slots : 1) * 8));
+    IDL_HIP_TRY(hipMalloc(&d_meta.p, 3 * sizeof(int64_t)));
+    IDL_HIP_TRY(hipMalloc(&d_out.p, (size_t)F * 4));
+    if (slots > 0) {
+        IDL_HIP_TRY(hipMemcpy(d_codes.p, h_codes, (size_t)slots * 16, hipMemcpyHostToDevice));
+        IDL_HIP_TRY(hipMemcpy(d_mask.p, h_mask, (size_t)slots * 8, hipMemcpyHostToDevice));
+    }
+    const int64_t meta[3] = {slot_off[0], slot_off[1], len};
+    IDL_HIP_TRY(hipMemcpy(d_meta.p, meta, sizeof(meta), hipMemcpyHostToDevice));
+    IDL_HIP_TRY(hipMemcpy(d_out.p, counts, (size_t)F * 4, hipMemcpyHostToDevice));
+
+    VecArgs a{};
+    a.codes = (const uint4 *)d_codes.p;
+    a.mask = (const uint2 *)d_mask.p;
+    a.slot_off = (const int64_t *)d_meta.p;
+    a.lengths = (const int64_t *)d_meta.p + 2;
+    a.n = 1;
+    a.mode = mode;
+    a.init = IDL_INIT_FROM_OUT;
+    a.out_kind = IDL_OUT_COUNTS_I32;
+    a.n_views = 1;
+    a.out = d_out.p;
+    a.view_stride = F;
+    rc = dispatch_vectorise(k, a, nullptr);
+    if (rc != IDL_OK) return rc;
+    IDL_HIP_TRY(hipMemcpy(counts, d_out.p, (size_t)F * 4, hipMemcpyDeviceToHost));
+    return IDL_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t idl_row_len(int mode, int k)
+{
+    if (k < 1 || k > 15) return -1;
+    const int64_t F = 1ll << (2 * k);
+    if (mode == IDL_MODE_CANONICAL) return (k % 2 == 0) ? (F + (1ll << k)) / 2 : F / 2;  // models.py:61-62
+    return F;
+}
+
+int idl_kmer_counts(const uint8_t *seq, int64_t len, int k, int32_t *counts)
+{
+    return scalar_count(seq, len, k, counts, IDL_MODE_KMER);
+}
+
+int idl_cgr(const uint8_t *seq, int64_t len, int k, int32_t *counts)
+{
+    return scalar_count(seq, len, k, counts, IDL_MODE_CGR);
+}
+
+int idl_kmer_rev_comp(int32_t *counts, int k, int32_t *out)
+{
+    IDL_REQUIRE(k >= 1 && k <= IDL_MAX_K, "k outside 1..IDL_MAX_K");
+    IDL_REQUIRE(counts != nullptr && out != nullptr, "NULL buffer");
+    idl::DeviceInfo di;
+    int rc = idl::device_info(&di);
+    if (rc != IDL_OK) return rc;
+    const int64_t F = 1ll << (2 * k), C = idl_row_len(IDL_MODE_CANONICAL, k);
+    DevBuf d_counts, d_out;
+    IDL_HIP_TRY(hipMalloc(&d_counts.p, (size_t)F * 4));
+    IDL_HIP_TRY(hipMalloc(&d_out.p, (size_t)C * 4));
+    IDL_HIP_TRY(hipMemcpy(d_counts.p, counts, (size_t)F * 4, hipMemcpyHostToDevice));
+    int32_t *dc = (int32_t *)d_counts.p, *dout = (int32_t *)d_out.p;
+    switch (k) {
+    case 1: hipLaunchKernelGGL(collapse_kernel<1>, dim3(1), dim3(64), 0, nullptr, dc, dout); break;
+    case 2: hipLaunchKernelGGL(collapse_kernel<2>, dim3(1), dim3(64), 0, nullptr, dc, dout); break;
+    case 3: hipLaunchKernelGGL(collapse_kernel<3>, dim3(1), dim3(64), 0, nullptr, dc, dout); break;
+    case 4: hipLaunchKernelGGL(collapse_kernel<4>, dim3(1), dim3(64), 0, nullptr, dc, dout); break;
+    case 5: hipLaunchKernelGGL(collapse_kernel<5>, dim3(1), dim3(64), 0, nullptr, dc, dout); break;
+    case 6: hipLaunchKernelGGL(collapse_kernel<6>, dim3(1), dim3(64), 0, nullptr, dc, dout); break;
+    case 7: hipLaunchKernelGGL(collapse_kernel<7>, dim3(1), dim3(64), 0, nullptr, dc, dout); break;
+    }
+    IDL_HIP_TRY(hipGetLastError());
+    IDL_HIP_TRY(hipMemcpy(counts, d_counts.p, (size_t)F * 4, hipMemcpyDeviceToHost));
+    IDL_HIP_TRY(hipMemcpy(out, d_out.p, (size_t)C * 4, hipMemcpyDeviceToHost));
+    return IDL_OK;
+}
+
+int idl_vectorise(const void *codes, const void *mask, const int64_t *slot_off, const int64_t *lengths,
+                  int64_t n, int k, int mode, int init, int out_kind,
+                  int n_views, const uint32_t *edits, const int64_t *edit_off,
+                  void *out, int64_t view_stride, void *stream)
+{
+    IDL_REQUIRE(k >= 1 && k <= IDL_MAX_K, "k outside 1..IDL_MAX_K");
+    IDL_REQUIRE(n >= 0 && n_views >= 1, "n < 0 or n_views < 1");
+    IDL_REQUIRE(mode == IDL_MODE_KMER || mode == IDL_MODE_CGR || mode == IDL_MODE_CANONICAL, "unknown mode");
+    IDL_REQUIRE(init == IDL_INIT_ZERO || init == IDL_INIT_ONE || init == IDL_INIT_FROM_OUT, "unknown init");
+    IDL_REQUIRE(out_kind == IDL_OUT_COUNTS_I32 || out_kind == IDL_OUT_FREQ_F32 || out_kind == IDL_OUT_FREQ_F64,
+                "unknown out_kind");
+    IDL_REQUIRE(!(init == IDL_INIT_FROM_OUT && (out_kind != IDL_OUT_COUNTS_I32 || mode == IDL_MODE_CANONICAL)),
+                "IDL_INIT_FROM_OUT needs IDL_OUT_COUNTS_I32 and a non-canonical mode");
+    IDL_REQUIRE((edits == nullptr) == (edit_off == nullptr), "edits and edit_off must both be given or both NULL");
+    IDL_REQUIRE(view_stride >= n * idl_row_len(mode, k) || n_views == 1, "view_stride smaller than one view");
+    if (n == 0) return IDL_OK;
+    IDL_REQUIRE(codes && mask && slot_off && lengths && out, "NULL buffer");
+    IDL_REQUIRE(((uintptr_t)codes & 15u) == 0 && ((uintptr_t)mask & 7u) == 0 && ((uintptr_t)out & 15u) == 0,
+                "codes/out must be 16-byte aligned, mask 8-byte aligned");
+    VecArgs a{};
+    a.codes = (const uint4 *)codes;
+    a.mask = (const uint2 *)mask;
+    a.slot_off = slot_off;
+    a.lengths = lengths;
+    a.n = n;
+    a.mode = mode;
+    a.init = init;
+    a.out_kind = out_kind;
+    a.n_views = n_views;
+    a.edits = edits;
+    a.edit_off = edit_off;
+    a.out = out;
+    a.view_stride = view_stride;
+    return dispatch_vectorise(k, a, (hipStream_t)stream);
+}
+
+}  // extern "C"

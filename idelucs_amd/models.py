@@ -1,0 +1,152 @@
+"""idelucs_amd.models -- IID_model: the training driver of the hot path on one MI355X.
+
+Same constructor dict keys and the same five methods as reference idelucs/models.py:46-195
+(IID_model.__init__, build_dataloader, contrastive_training_epoch, predict, calculate_probs).
+Differences are all below the interface: features live in HBM (utils.FeatureStore), batches are
+assembled by a HIP gather kernel instead of DataLoader workers, the two views go through the encoder
+as one [2B, F] batch, losses are mask-free device code, and no step synchronises with the host.
+"""
+import random
+import sys
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.optim as optim
+
+from . import _lib
+from . import utils
+from .LossFunctions import IID_loss, info_nce_loss
+from .PytorchUtils import NetLinear, myNet
+
+# Random seeds for reproducibility, at import, as the reference does (models.py:17-21): the
+# "compat" mimic RNG relies on numpy/random being seeded 0 exactly like a fresh `import idelucs`.
+torch.manual_seed(0)
+np.random.seed(0)
+random.seed(0)
+
+EPS = sys.float_info.epsilon
+
+
+def weights_init(m):
+    """Reference models.py:36-44: Kaiming-normal weights, zero biases, for every nn.Linear."""
+    if isinstance(m, nn.Linear):
+        torch.nn.init.kaiming_normal_(m.weight)
+        torch.nn.init.zeros_(m.bias)
+
+
+class IID_model():
+    def __init__(self, args: dict):
+        _lib.require_gpu()          # no CPU path: fail here, loudly, rather than train on the host
+        self.device = torch.device("cuda", torch.cuda.current_device())
+        self.sequence_file = args['sequence_file']
+        self.GT_file = args['GT_file']
+        self.n_clusters = args['n_clusters']
+        self.k = args['k']
+
+        if args['model_size'] == 'linear':                      # models.py:54-57
+            self.n_features = 4 ** self.k
+            self.net = NetLinear(self.n_features, args['n_clusters'])
+            self.reduce = False
+        elif args['model_size'] == 'small':                     # models.py:59-66
+            self.n_features = (4 ** self.k + 4 ** (self.k // 2)) // 2 if self.k % 2 == 0 else (4 ** self.k) // 2
+            self.net = myNet(self.n_features, args['n_clusters'])
+            self.reduce = True
+        else:
+            # 'full' builds a ResNet18 in the reference but then crashes in build_dataloader
+            # (models.py:68-69,111: n_features/reduce never set); 'conv' hits this same ValueError.
+            raise ValueError("Invalid Model Type")
+
+        self.net.apply(weights_init)
+        self.net.to(self.device)
+        self.epoch = 0
+        self.EPS = EPS
+        self.n_mimics = args['n_mimics']
+        self.batch_sz = args['batch_sz']
+        self.optimizer = args['optimizer']
+        self.l = args['lambda']
+        self.lr = args['lr']
+        self.weight = args['weight']
+        self.schedule = args['scheduler']
+        self.mutate = True
+        self.rng = args.get('rng')            # None -> $IDELUCS_RNG or "philox"
+        self.seed = args.get('seed', 0)
+
+        if self.optimizer == 'RMSprop':                         # models.py:87-94
+            self.optimizer = optim.RMSprop(self.net.parameters(), lr=self.lr, weight_decay=0.01)
+        elif self.optimizer == 'SGD':
+            self.optimizer = optim.SGD(self.net.parameters(), lr=self.lr, weight_decay=0.01, momentum=0.9)
+        elif self.optimizer == 'Adam':
+            self.optimizer = optim.Adam(self.net.parameters(), lr=self.lr)
+        else:
+            raise ValueError("Optimizer not supported")
+
+        if self.schedule == 'Plateau':                          # models.py:96-99
+            self.scheduler = optim.lr_scheduler.ReduceLROnPlateau(self.optimizer, 'min')
+        elif self.schedule == 'Triangle':
+            self.scheduler = optim.lr_scheduler.CyclicLR(self.optimizer, base_lr=0.001, max_lr=0.1, step_size_up=5,
+                                                         mode="triangular2")
+        self.store = None
+        self._fasta = None
+
+    # ------------------------------------------------------------------ data
+    def build_dataloader(self):
+        """Reference models.py:101-111: vectorise all mimic views + fit the scaler (one kernel launch
+        each, utils.build_feature_store) and expose an iterable of device batches."""
+        self.store = utils.build_feature_store(self.sequence_file, self.n_mimics, k=self.k, reduce=self.reduce,
+                                               rng=self.rng, seed=self.seed, device=self.device)
+        self.dataloader = utils.DeviceBatchLoader(self.store, self.batch_sz)
+
+    # ------------------------------------------------------------------ training
+    def _step(self, x):
+        """One optimizer step on a [2b, F] batch (rows [0,b) "true", [b,2b) "modified")."""
+        b = x.shape[0] // 2
+        self.optimizer.zero_grad(set_to_none=True)
+        z, h = self.net(x)                      # one pass for both views (independent dropout masks per row)
+        loss = (1 - self.weight) * info_nce_loss(h[:b], h[b:], 0.85) + self.weight * IID_loss(z[:b], z[b:], lamb=self.l)
+        loss.backward()
+        self.optimizer.step()
+        return loss.detach()
+
+    def contrastive_training_epoch(self):
+        """Reference models.py:113-143: one pass over the shuffled N*n_mimics pairs."""
+        self.net.train()
+        st = self.store
+        running_loss = torch.zeros((), device=self.device)
+        perm = torch.randperm(st.n_pairs, device=self.device)
+        i_batch = 0
+        for i_batch, i in enumerate(range(0, st.n_pairs, self.batch_sz)):
+            x = st.gather_pairs(perm[i:i + self.batch_sz])
+            running_loss += self._step(x)
+        running_loss = running_loss / i_batch      # models.py:135 divides by the LAST INDEX (n_batches-1): kept
+
+        if self.schedule == 'Plateau':
+            self.scheduler.step(running_loss)
+        elif self.schedule == 'Triangle':
+            self.scheduler.step()
+        self.epoch += 1
+        return running_loss.item()
+
+    # ------------------------------------------------------------------ inference
+    def _predict_outputs(self):
+        names, lengths, feats = utils.predict_features(self.sequence_file, k=self.k, reduce=self.reduce, device=self.device)
+        outs, lats = [], []
+        with torch.no_grad():
+            self.net.eval()
+            for i in range(0, feats.shape[0], self.batch_sz):
+                o, l = self.net(feats[i:i + self.batch_sz])
+                outs.append(o)
+                lats.append(l)
+        return torch.cat(outs), torch.cat(lats)
+
+    def predict(self, data=None):
+        """Reference models.py:145-172 -> (int64 y_pred[N], float64 probs[N], float64 latent[N,64])."""
+        outputs, latent = self._predict_outputs()
+        probs, predicted = torch.max(outputs, 1)
+        return (predicted.cpu().numpy().astype(np.int64), probs.double().cpu().numpy(),
+                latent.double().cpu().numpy())
+
+    def calculate_probs(self, data=None):
+        """Reference models.py:175-195 -> float64 [N, n_clusters] softmax outputs."""
+        outputs, _ = self._predict_outputs()
+        return outputs.double().cpu().numpy()

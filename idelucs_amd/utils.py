@@ -1,0 +1,540 @@
+"""idelucs_amd.utils -- the data layer of the hot path, behind the reference's names.
+
+Mirrors reference idelucs/utils.py:26-429 (check_sequence, SummaryFasta, reverse_complement,
+kmer_rev_comp, kmersFasta, cgrFasta, the four mimic transforms, AugmentFasta, AugmentedDataset,
+SequenceDataset, create_dataloader): same names, arguments, return types and errors.  What differs
+is where the work happens: the FASTA file is parsed and 2-bit packed ONCE by the C++ host reader in
+libidelucs_hip.so, every counting / collapsing / normalising / scaling step runs on the MI355X, and
+the feature matrix stays resident in HBM as a de-duplicated [views, N, F] store.
+
+Mimic RNG modes (argument `rng`, default from $IDELUCS_RNG, else "philox"):
+  "compat"  the host draws sites exactly like the reference (numpy global MT19937 + Python `random`,
+            same consumption order, utils.py:69-118 / survey D.2) and ships them to the device as
+            substitution edits -> outputs match the reference bit-for-bit up to the scaler's float64
+            summation order;
+  "philox"  sites are drawn on the device (idl_mimic_edits): statistically equivalent, ~1000x faster.
+"""
+import ctypes
+import os
+import random
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import lib as _L
+
+A, C, G, T, N = (ord(c) for c in "ACGTN")
+_CODE = np.full(256, 4, np.uint8)
+_CODE[[A, C, G, T]] = [0, 1, 2, 3]
+
+
+def _default_rng_mode():
+    return os.environ.get("IDELUCS_RNG", "philox")
+
+
+def _device(device=None):
+    _lib.require_gpu()
+    return torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+
+
+def _stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    if isinstance(t, torch.Tensor):
+        return ctypes.c_void_p(t.data_ptr())
+    return ctypes.c_void_p(t.ctypes.data)
+
+
+# ------------------------------------------------------------------------------------------------
+# check_sequence / FASTA reading (host C++)
+# ------------------------------------------------------------------------------------------------
+def check_sequence(header, seq):
+    """Reference idelucs/utils.py:26-51: validate the header, upper-case, U->T, IUPAC/'-' -> N,
+    delete whitespace, reject anything else.  Returns a new bytearray."""
+    if len(header) > 0 and (header[0] in (">", "#") or header[0].isspace()):
+        raise ValueError("Bad character in sequence header")
+    if "\t" in header:
+        raise ValueError("tab included in header")
+    src = np.frombuffer(bytes(seq), dtype=np.uint8)
+    out = np.empty(max(src.size, 1), np.uint8)
+    out_len, bad = ctypes.c_int64(0), ctypes.c_int64(-1)
+    rc = _L.idl_check_sequence(_ptr(src) if src.size else None, src.size, _ptr(out), ctypes.byref(out_len), ctypes.byref(bad))
+    if rc == _lib.IDL_ERR_BASE:
+        # utils.py:46-50 formats the first byte of the translated string that is not in ACGTN
+        raise ValueError("Invalid DNA byte in sequence {}: '{}'".format(header, chr(int(src[bad.value]))))
+    _lib.check(rc)
+    return bytearray(out[:out_len.value].tobytes())
+
+
+class FastaFile:
+    """One parse of a FASTA file by the C++ reader (idl_fasta_open): names, lengths, cleaned bytes
+    (optional) and the packed slot layout.  Replaces the reference's re-parsing of the file in every
+    pass (utils.py:137-188, :224-260, :279-317)."""
+
+    def __init__(self, fname, check=True, keep_bytes=False, pack=True):
+        h = ctypes.c_void_p()
+        _lib.check(_L.idl_fasta_open(os.fsencode(fname), 1 if check else 0, ctypes.byref(h)))
+        try:
+            n, tb, ts, nb = (ctypes.c_int64() for _ in range(4))
+            _lib.check(_L.idl_fasta_sizes(h, ctypes.byref(n), ctypes.byref(tb), ctypes.byref(ts), ctypes.byref(nb)))
+            self.n, self.total_bases, self.total_slots = n.value, tb.value, ts.value
+            names = np.empty(max(nb.value, 1), np.uint8)
+            name_off = np.empty(self.n + 1, np.int64)
+            self.lengths = np.empty(self.n, np.int64)
+            self.byte_off = np.empty(self.n + 1, np.int64)
+            self.bytes = np.empty(max(self.total_bases, 1), np.uint8) if keep_bytes else None
+            if pack:
+                self.codes = np.empty(max(self.total_slots, 1) * 16, np.uint8)
+                self.mask = np.empty(max(self.total_slots, 1) * 8, np.uint8)
+                self.slot_off = np.empty(self.n + 1, np.int64)
+            else:
+                self.codes = self.mask = self.slot_off = None
+            _lib.check(_L.idl_fasta_export(h, _ptr(names), _ptr(name_off), _ptr(self.lengths), _ptr(self.bytes),
+                                           _ptr(self.byte_off), _ptr(self.codes), _ptr(self.mask), _ptr(self.slot_off)))
+        finally:
+            _L.idl_fasta_close(h)
+        raw = names.tobytes()
+        self.names = [raw[name_off[i]:name_off[i + 1]].decode() for i in range(self.n)]   # utils.py:172 .decode()
+        if check:
+            for nm in self.names:   # unicode-whitespace first characters the byte-level check cannot see
+                if len(nm) > 0 and nm[0].isspace():
+                    raise ValueError("Bad character in sequence header")
+
+    def record(self, i):
+        return bytearray(self.bytes[self.byte_off[i]:self.byte_off[i + 1]].tobytes())
+
+
+def SummaryFasta(fname, GT_file=None):
+    """Reference idelucs/utils.py:137-188 -> (names, lengths, ground_truth | None, cluster_dis | None)."""
+    gt_dict = cluster_dis = ground_truth = None
+    if GT_file:
+        import pandas as pd
+        df = pd.read_csv(GT_file, sep="\t")
+        gt_dict = dict(zip(df.sequence_id, df.cluster_id))
+        cluster_dis = df["cluster_id"].value_counts().to_dict()
+    ff = FastaFile(fname, check=True, pack=False)
+    if GT_file:
+        ground_truth = []
+        for name in ff.names:
+            if name not in gt_dict:
+                raise ValueError("Check GT for sequence {}".format(name))
+            ground_truth.append(gt_dict[name])
+    return ff.names, ff.lengths.tolist(), ground_truth, cluster_dis
+
+
+# ------------------------------------------------------------------------------------------------
+# reverse complement helpers
+# ------------------------------------------------------------------------------------------------
+def reverse_complement(x, k):
+    """Reference idelucs/utils.py:191-206 (index of the reverse-complement k-mer, A0 C1 G2 T3)."""
+    x, rc = int(x), 0
+    for _ in range(k):
+        rc = (rc << 2) | (3 - (x & 3))
+        x >>= 2
+    return rc
+
+
+def kmer_rev_comp(kmer_counts, k):
+    """Reference idelucs/utils.py:208-221: canonical collapse with int truncation; `kmer_counts` is
+    modified in place like the reference and the canonical entries are returned (device kernel)."""
+    arr = np.asarray(kmer_counts)
+    if arr.dtype != np.int32 or not arr.flags.c_contiguous or arr.ndim != 1 or arr.size < 4 ** k:
+        raise ValueError("kmer_counts must be a contiguous int32 vector of 4**k entries")
+    _lib.require_gpu()
+    out = np.empty(_L.idl_row_len(_lib.MODE_CANONICAL, k), np.int32)
+    _lib.check(_L.idl_kmer_rev_comp(_ptr(arr), int(k), _ptr(out)))
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# mimic transforms: host-RNG ("compat") application + parameters for the device generator
+# ------------------------------------------------------------------------------------------------
+def _as_u8(seq):
+    return np.frombuffer(seq, dtype=np.uint8)   # writable view of a bytearray
+
+
+_TRANSITION_LUT = np.arange(256, dtype=np.uint8)
+_TRANSITION_LUT[[A, G, T, C]] = [G, A, C, T]
+_TRANSVERSION_TABLE = {A: [T, C], G: [T, C], T: [A, G], C: [A, G], N: [N]}
+
+
+class transition(object):
+    """Reference idelucs/utils.py:54-76: each base mutates w.p. `threshold`; A<->G, C<->T, N->N."""
+
+    def __init__(self, threshold):
+        self.threshold = threshold
+
+    def spec(self):
+        return (float(self.threshold), 0.0, 0)
+
+    def __call__(self, seq):
+        a = _as_u8(seq)
+        x = np.random.random(len(seq))
+        idx = np.flatnonzero(x < self.threshold)
+        bad = np.setdiff1d(a[idx], [A, C, G, T, N])
+        if bad.size:
+            raise KeyError(int(bad[0]))          # the reference's dict lookup (utils.py:76) raises KeyError
+        a[idx] = _TRANSITION_LUT[a[idx]]
+
+
+class transversion(object):
+    """Reference idelucs/utils.py:98-118: site w.p. `threshold`; purine -> T|C, pyrimidine -> A|G
+    via random.choice (an N site still consumes one choice)."""
+
+    def __init__(self, threshold):
+        self.threshold = threshold
+
+    def spec(self):
+        return (0.0, float(self.threshold), 0)
+
+    def __call__(self, seq):
+        x = np.random.random(len(seq))
+        for i in np.flatnonzero(x < self.threshold):
+            seq[i] = random.choice(_TRANSVERSION_TABLE.get(seq[i], [N]))
+
+
+class transition_transversion(object):
+    """Reference idelucs/utils.py:120-135: transition(threshold_1) then transversion(threshold_2)."""
+
+    def __init__(self, threshold_1, threshold_2):
+        self.tf1 = transition(threshold_1)
+        self.tf2 = transversion(threshold_2)
+
+    def spec(self):
+        return (float(self.tf1.threshold), float(self.tf2.threshold), 0)
+
+    def __call__(self, seq):
+        self.tf1(seq)
+        self.tf2(seq)
+
+
+class Random_N(object):
+    """Reference idelucs/utils.py:78-95: `n_bp` uniformly drawn positions (with replacement) -> N."""
+
+    def __init__(self, n_bp):
+        self.n_bp = n_bp
+
+    def spec(self):
+        return (0.0, 0.0, int(self.n_bp))
+
+    def __call__(self, seq):
+        a = _as_u8(seq)
+        a[np.random.randint(0, len(seq), self.n_bp)] = N
+
+
+def _edits_from_diff(orig, mutated):
+    """Substitution edits (pos | op<<30) that turn `orig` into `mutated` (equal-length ACGTN byte
+    arrays): op 0 = becomes N, else XOR of the 2-bit codes."""
+    pos = np.flatnonzero(orig != mutated)
+    if pos.size == 0:
+        return np.empty(0, np.uint32)
+    if pos[-1] >= (1 << 30):
+        raise ValueError("mutated sequences longer than 2^30 bases are not supported")
+    co, cm = _CODE[orig[pos]], _CODE[mutated[pos]]
+    if np.any(co == 4) or np.any((cm == 4) & (mutated[pos] != N)):
+        return None   # not expressible as edits (an invalid base became valid, or a non-ACGTN byte appeared)
+    op = np.where(cm == 4, 0, co ^ cm).astype(np.uint32)
+    return pos.astype(np.uint32) | (op << np.uint32(30))
+
+
+# ------------------------------------------------------------------------------------------------
+# device vectorisation of a parsed file
+# ------------------------------------------------------------------------------------------------
+class _DeviceInput:
+    """Packed bases of one FASTA file, resident in HBM."""
+
+    def __init__(self, ff, device):
+        self.n = ff.n
+        self.codes = torch.from_numpy(ff.codes).to(device)
+        self.mask = torch.from_numpy(ff.mask).to(device)
+        self.slot_off = torch.from_numpy(ff.slot_off).to(device)
+        self.lengths = torch.from_numpy(ff.lengths).to(device)
+
+
+def _vectorise(dev_in, k, mode, init, out_kind, n_views=1, edits=None, edit_off=None, out=None):
+    """idl_vectorise on torch-owned device buffers -> tensor [n_views, n, row_len]."""
+    row = _L.idl_row_len(mode, k)
+    if row < 0 or not 1 <= k <= _lib.MAX_K:
+        raise ValueError(f"k={k} is outside 1..{_lib.MAX_K}")
+    dtype = {_lib.OUT_COUNTS_I32: torch.int32, _lib.OUT_FREQ_F32: torch.float32, _lib.OUT_FREQ_F64: torch.float64}[out_kind]
+    if out is None:
+        out = torch.empty((n_views, dev_in.n, row), dtype=dtype, device=dev_in.codes.device)
+    assert out.is_contiguous() and out.dtype == dtype and tuple(out.shape) == (n_views, dev_in.n, row)
+    _lib.check(_L.idl_vectorise(_ptr(dev_in.codes), _ptr(dev_in.mask), _ptr(dev_in.slot_off), _ptr(dev_in.lengths),
+                                dev_in.n, k, mode, init, out_kind, n_views, _ptr(edits), _ptr(edit_off),
+                                _ptr(out), dev_in.n * row, _stream_ptr()))
+    return out
+
+
+def _compat_edits(ff, transforms):
+    """Host-RNG mimic sites for every (view, record), in the reference's consumption order
+    (pass-major, records in file order; survey D.2).  `transforms[v]` is None or a callable that
+    mutates a bytearray in place.  Returns (edits uint32, edit_off int64[n_views*n+1]) or raises if
+    a transform cannot be expressed as substitutions."""
+    chunks, counts = [], []
+    for tf in transforms:
+        for i in range(ff.n):
+            if tf is None:
+                counts.append(0)
+                continue
+            orig = ff.bytes[ff.byte_off[i]:ff.byte_off[i + 1]]
+            mut = bytearray(orig.tobytes())
+            tf(mut)
+            if len(mut) != orig.size:
+                raise ValueError("a transform changed the length of a sequence")
+            e = _edits_from_diff(orig, np.frombuffer(mut, np.uint8))
+            if e is None:
+                raise ValueError("a transform produced bytes that are not substitutions among ACGTN")
+            chunks.append(e)
+            counts.append(e.size)
+    edit_off = np.zeros(len(counts) + 1, np.int64)
+    np.cumsum(counts, out=edit_off[1:])
+    edits = np.concatenate(chunks) if chunks else np.empty(0, np.uint32)
+    return edits, edit_off
+
+
+def _philox_edits(dev_in, specs, seed):
+    """Device-drawn mimic sites (idl_mimic_edits, two-call protocol) -> (edits, edit_off) on device."""
+    P = len(specs)
+    p_ts = np.array([s[0] for s in specs], np.float64)
+    p_tv = np.array([s[1] for s in specs], np.float64)
+    n_rn = np.array([s[2] for s in specs], np.int32)
+    if np.any(n_rn > 0) and dev_in.n > 0 and int(dev_in.lengths.min().item()) <= 0:
+        raise ValueError("high <= 0")   # np.random.randint(0, 0, n) in the reference's Random_N (utils.py:93)
+    dev = dev_in.codes.device
+    ws = torch.empty(_L.idl_mimic_workspace(P), dtype=torch.uint8, device=dev)
+    edit_off = torch.empty(P * dev_in.n + 1, dtype=torch.int64, device=dev)
+    total = ctypes.c_int64(0)
+    args = (_ptr(dev_in.lengths), dev_in.n, P, _ptr(p_ts), _ptr(p_tv), _ptr(n_rn), ctypes.c_uint64(seed & (2 ** 64 - 1)))
+    _lib.check(_L.idl_mimic_edits(*args, _ptr(edit_off), None, 0, ctypes.byref(total), _ptr(ws), _stream_ptr()))
+    edits = torch.empty(max(total.value, 1), dtype=torch.int32, device=dev)
+    _lib.check(_L.idl_mimic_edits(*args, _ptr(edit_off), _ptr(edits), total.value, None, _ptr(ws), _stream_ptr()))
+    return edits, edit_off
+
+
+def _features_one_pass(fname, k, transform, mode, check, out_kind, device=None, rng=None, seed=0):
+    """One kmersFasta/cgrFasta-style pass: names + [N, row] device tensor."""
+    rng = rng or _default_rng_mode()
+    dev = _device(device)
+    spec = transform.spec() if hasattr(transform, "spec") else None
+    host_tf = transform is not None and (rng == "compat" or spec is None)
+    ff = FastaFile(fname, check=check, keep_bytes=host_tf)
+    edits = edit_off = None
+    if host_tf:
+        try:
+            e, eo = _compat_edits(ff, [transform])
+        except ValueError as err:
+            if "substitutions" not in str(err) and "length" not in str(err):
+                raise
+            # arbitrary user transform: re-pack the mutated bytes instead of shipping edits
+            return _features_user_transform(ff, fname, k, transform, mode, out_kind, dev)
+        edits = torch.from_numpy(e.view(np.int32)).to(dev) if e.size else torch.zeros(1, dtype=torch.int32, device=dev)
+        edit_off = torch.from_numpy(eo).to(dev)
+    din = _DeviceInput(ff, dev)
+    if transform is not None and not host_tf:
+        edits, edit_off = _philox_edits(din, [spec], seed)
+    out = _vectorise(din, k, mode, _lib.INIT_ONE, out_kind, 1, edits, edit_off)
+    return ff.names, out[0]
+
+
+def _features_user_transform(ff, fname, k, transform, mode, out_kind, dev):
+    raise NotImplementedError("transforms that are not base substitutions are not supported on the device path")
+
+
+def kmersFasta(fname, k=6, transform=None, reduce=False, rng=None, seed=0):
+    """Reference idelucs/utils.py:224-277 -> (names, float64 [N, 4^k or n_canonical])."""
+    mode = _lib.MODE_CANONICAL if reduce else _lib.MODE_KMER
+    names, feats = _features_one_pass(fname, k, transform, mode, True, _lib.OUT_FREQ_F64, rng=rng, seed=seed)
+    return names, feats.cpu().numpy()
+
+
+def cgrFasta(fname, k=6, transform=None, rng=None, seed=0):
+    """Reference idelucs/utils.py:279-317 (no check_sequence: lower-case bytes are skipped)."""
+    names, feats = _features_one_pass(fname, k, transform, _lib.MODE_CGR, False, _lib.OUT_FREQ_F64, rng=rng, seed=seed)
+    return names, feats.cpu().numpy()
+
+
+# ------------------------------------------------------------------------------------------------
+# the de-duplicated feature store (what AugmentFasta's [N*n_mimics, 2, F] array is a view of)
+# ------------------------------------------------------------------------------------------------
+def mimic_transforms(n_mimics):
+    """The passes of reference AugmentFasta (utils.py:330-351): view 0 = "true" view (itself mutated),
+    then transition, transversion, and max(n_mimics-2, 0) Random_N(20) views."""
+    return ([transition_transversion(1e-2, 0.5e-2), transition(1e-2), transversion(0.5e-2)]
+            + [Random_N(20) for _ in range(n_mimics - 2)])
+
+
+class FeatureStore:
+    """feats[P, N, F] float32 un-scaled frequencies (view 0 = "true") + the scaler fitted on view 0,
+    all resident in HBM.  Pair p of the reference's x_train (utils.py:353) is
+    (feats[0][p % N], feats[1 + p // N][p % N]), standardised."""
+
+    def __init__(self, names, lengths, feats, mean, scale, k, reduce):
+        self.names, self.lengths = names, lengths
+        self.feats, self.mean, self.scale = feats, mean, scale
+        self.k, self.reduce = k, reduce
+        self.n_views, self.n, self.f = feats.shape
+        self.n_pairs = (self.n_views - 1) * self.n
+
+    def gather_pairs(self, pair_idx, out=None):
+        """-> [2*B, F] float32: rows [0,B) 'true', [B,2B) 'modified' (AugmentedDataset.__getitem__)."""
+        b = pair_idx.numel()
+        if out is None:
+            out = torch.empty((2 * b, self.f), dtype=torch.float32, device=self.feats.device)
+        _lib.check(_L.idl_gather_pairs(_ptr(self.feats), self.n, self.f, self.n * self.f, _ptr(pair_idx), b,
+                                       _ptr(self.mean), _ptr(self.scale), _ptr(out), _stream_ptr()))
+        return out
+
+
+def col_stats(x):
+    """StandardScaler().fit statistics of a device matrix [n, f] (float32 or float64) -> (mean, scale) float64."""
+    n, f = x.shape
+    dev = x.device
+    ws = torch.empty(max(_L.idl_col_stats_workspace(n, f), 8), dtype=torch.uint8, device=dev)
+    mean = torch.empty(f, dtype=torch.float64, device=dev)
+    scale = torch.empty(f, dtype=torch.float64, device=dev)
+    _lib.check(_L.idl_col_stats(_ptr(x), 1 if x.dtype == torch.float64 else 0, n, f, _ptr(mean), _ptr(scale), _ptr(ws),
+                                _stream_ptr()))
+    return mean, scale
+
+
+def standardise(x, mean, scale, out=None):
+    """StandardScaler().transform of a device matrix -> float32."""
+    n, f = x.shape
+    if out is None:
+        out = torch.empty((n, f), dtype=torch.float32, device=x.device)
+    _lib.check(_L.idl_standardise(_ptr(x), 1 if x.dtype == torch.float64 else 0, n, f, _ptr(mean), _ptr(scale), _ptr(out),
+                                  _stream_ptr()))
+    return out
+
+
+def build_feature_store(sequence_file, n_mimics, k=6, reduce=False, rng=None, seed=0, device=None, fasta=None):
+    """Vectorise every mimic view of every sequence in one kernel launch and fit the scaler."""
+    rng = rng or _default_rng_mode()
+    dev = _device(device)
+    tfs = mimic_transforms(n_mimics)
+    ff = fasta if fasta is not None else FastaFile(sequence_file, check=True, keep_bytes=(rng == "compat"))
+    mode = _lib.MODE_CANONICAL if reduce else _lib.MODE_KMER
+    if rng == "compat":
+        if ff.bytes is None:
+            raise ValueError("compat RNG needs FastaFile(keep_bytes=True)")
+        e, eo = _compat_edits(ff, tfs)
+        edits = torch.from_numpy(e.view(np.int32)).to(dev) if e.size else torch.zeros(1, dtype=torch.int32, device=dev)
+        edit_off = torch.from_numpy(eo).to(dev)
+        din = _DeviceInput(ff, dev)
+    elif rng == "philox":
+        din = _DeviceInput(ff, dev)
+        edits, edit_off = _philox_edits(din, [t.spec() for t in tfs], seed)
+    else:
+        raise ValueError("rng must be 'compat' or 'philox'")
+    feats = _vectorise(din, k, mode, _lib.INIT_ONE, _lib.OUT_FREQ_F32, len(tfs), edits, edit_off)
+    mean, scale = col_stats(feats[0])
+    return FeatureStore(ff.names, ff.lengths, feats, mean, scale, k, reduce)
+
+
+def AugmentFasta(sequence_file, n_mimics, k=6, reduce=False, rng=None, seed=0):
+    """Reference idelucs/utils.py:321-368 -> float32 [N*max(n_mimics,2), 2, F] (host array), pairs
+    mimic-major, both halves standardised with the scaler fitted on the "true" view."""
+    st = build_feature_store(sequence_file, n_mimics, k=k, reduce=reduce, rng=rng, seed=seed)
+    scaled = standardise(st.feats.view(-1, st.f), st.mean, st.scale).view(st.n_views, st.n, st.f).cpu().numpy()
+    x = np.empty((st.n_pairs, 2, st.f), np.float32)
+    for m in range(st.n_views - 1):
+        x[m * st.n:(m + 1) * st.n, 0, :] = scaled[0]
+        x[m * st.n:(m + 1) * st.n, 1, :] = scaled[m + 1]
+    return x
+
+
+class AugmentedDataset(torch.utils.data.Dataset):
+    """Reference idelucs/utils.py:370-389."""
+
+    def __init__(self, data):
+        self.data = data
+
+    def __len__(self):
+        return self.data.shape[0]
+
+    def __getitem__(self, idx):
+        if torch.is_tensor(idx):
+            idx = idx.tolist()
+        return {"true": self.data[idx, 0, :], "modified": self.data[idx, 1, :]}
+
+
+def predict_features(sequence_file, k=6, reduce=False, device=None, fasta=None):
+    """What SequenceDataset feeds the network (utils.py:400-405 + models.py:163): un-mutated float64
+    frequencies, StandardScaler fit_transform in float64, rounded once to float32.  -> (names, lengths, [N,F] f32)."""
+    dev = _device(device)
+    ff = fasta if fasta is not None else FastaFile(sequence_file, check=True)
+    din = _DeviceInput(ff, dev)
+    mode = _lib.MODE_CANONICAL if reduce else _lib.MODE_KMER
+    f64 = _vectorise(din, k, mode, _lib.INIT_ONE, _lib.OUT_FREQ_F64)[0]
+    mean, scale = col_stats(f64)
+    return ff.names, ff.lengths, standardise(f64, mean, scale)
+
+
+class SequenceDataset(torch.utils.data.Dataset):
+    """Reference idelucs/utils.py:391-420: un-mutated k-mer vectors, own scaler (float64)."""
+
+    def __init__(self, fasta_file, k=6, transform=None, GT_file=None, reduce=False):
+        self.names, self.lengths, self.GT, self.cluster_dis = SummaryFasta(fasta_file, GT_file)
+        mode = _lib.MODE_CANONICAL if reduce else _lib.MODE_KMER
+        _, f64 = _features_one_pass(fasta_file, k, transform, mode, True, _lib.OUT_FREQ_F64)
+        mean, scale = col_stats(f64)
+        # StandardScaler on float64 keeps float64 (utils.py:404-405): (x - mean) / scale
+        self.kmers = ((f64 - mean) / scale).cpu().numpy()
+
+    def __len__(self):
+        return len(self.lengths)
+
+    def __getitem__(self, idx):
+        if torch.is_tensor(idx):
+            idx = idx.tolist()
+        if self.GT:
+            return {"kmer": self.kmers[idx, :], "name": self.names[idx], "cluster_id": self.GT[idx]}
+        return {"kmer": self.kmers[idx, :], "name": self.names[idx]}
+
+
+class DeviceBatchLoader:
+    """Stands in for the reference's DataLoader(AugmentedDataset, shuffle=True) (utils.py:422-429):
+    iterating yields {'true': [b,F], 'modified': [b,F]} float32 device tensors for a fresh random
+    permutation of the N*n_mimics pairs; the last batch is partial (no drop_last).  Batches are
+    assembled by idl_gather_pairs from the HBM-resident store -- no worker processes, no host copy."""
+
+    def __init__(self, store, batch_size, generator=None):
+        self.store, self.batch_size, self.generator = store, batch_size, generator
+
+    def __len__(self):
+        return (self.store.n_pairs + self.batch_size - 1) // self.batch_size
+
+    def __iter__(self):
+        perm = torch.randperm(self.store.n_pairs, device=self.store.feats.device, generator=self.generator)
+        for i in range(0, self.store.n_pairs, self.batch_size):
+            idx = perm[i:i + self.batch_size]
+            y = self.store.gather_pairs(idx)
+            b = idx.numel()
+            yield {"true": y[:b], "modified": y[b:]}
+
+
+def create_dataloader(sequence_file, n_mimics, k=6, batch_size=512, GT_file=None, reduce=False, rng=None, seed=0):
+    """Reference idelucs/utils.py:422-429."""
+    return DeviceBatchLoader(build_feature_store(sequence_file, n_mimics, k=k, reduce=reduce, rng=rng, seed=seed), batch_size)
+
+
+# ------------------------------------------------------------------------------------------------
+# post-hoc helpers kept for API compatibility (run once on [N] ints; sklearn/scipy on the host, as in the reference)
+# ------------------------------------------------------------------------------------------------
+def cluster_acc(y_true, y_pred):
+    """Reference idelucs/utils.py:489-508: best one-to-one label matching (Hungarian) accuracy."""
+    from scipy.optimize import linear_sum_assignment
+    y_true = np.asarray(y_true).astype(np.int64)
+    y_pred = np.asarray(y_pred).astype(np.int64)
+    d = max(y_pred.max(), y_true.max()) + 1
+    w = np.zeros((d, d), dtype=np.int64)
+    np.add.at(w, (y_pred, y_true), 1)
+    ind = linear_sum_assignment(w.max() - w)
+    ind = np.transpose(np.asarray(ind))
+    return ind, sum(w[i, j] for i, j in ind) * 1.0 / y_pred.size

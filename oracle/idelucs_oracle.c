@@ -180,18 +180,19 @@ void orc_apply_edits(uint8_t *seq, int64_t len, const uint32_t *edits, int64_t n
     }
 }
 
-/* Packed device layout: sequence s occupies slots [slot_off[s], slot_off[s+1]) of
- * 64 bases; per slot 16 bytes of 2-bit codes (base j of the slot at bits 2j..2j+1 of
- * the little-endian 128-bit word) and 8 bytes of invalid-mask (bit j).  Positions
- * past the sequence end are marked invalid. */
+/* Packed device layout (include/idelucs_hip.h): sequence s occupies slots of 64 bases; per slot
+ * four little-endian uint32 code words (base j of word w at bits 31-2j..30-2j: first base in the
+ * most significant pair) and two little-endian uint32 mask words (base j of word w at bit 31-j,
+ * 1 = not A/C/G/T).  Positions past the sequence end are marked invalid. */
 void orc_pack(const uint8_t *seq, int64_t len, uint8_t *codes, uint8_t *mask)
 {
     int64_t slots = (len + 63) / 64;
+    uint32_t *cw = (uint32_t *)codes, *mw = (uint32_t *)mask;
     memset(codes, 0, (size_t)slots * 16);
     memset(mask, 0, (size_t)slots * 8);
     for (int64_t i = 0; i < slots * 64; ++i) {
         unsigned c = (i < len) ? orc_code(seq[i]) : 4u;
-        if (c == 4u) mask[i >> 3] |= (uint8_t)(1u << (i & 7));
-        else codes[i >> 2] |= (uint8_t)(c << (2 * (i & 3)));
+        if (c == 4u) mw[i >> 5] |= 0x80000000u >> (i & 31);
+        else cw[i >> 4] |= (uint32_t)c << (30 - 2 * (i & 15));
     }
 }

@@ -1,0 +1,294 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP vectoriser, called through the C ABI,
+against (a) the golden vectors generated from the real reference and (b) the CPU oracle on seeded
+random inputs.  Integer/byte results must be bit-exact."""
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+
+from conftest import DATA, GOLDEN
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+KAT = json.load(open(os.path.join(GOLDEN, "kat.json")))
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+    import idelucs_amd
+    from idelucs_amd import _lib
+    _lib.require_gpu()
+    assert torch.cuda.is_available()
+    return idelucs_amd
+
+
+def test_scalar_api_kats(gpu):
+    for case in KAT["cases"]:
+        s, k = case["seq"].encode("latin1"), case["k"]
+        c = np.zeros(4 ** k, np.int32); gpu.kmer_counts(bytearray(s), k, c)
+        g = np.zeros(4 ** k, np.int32); gpu.cgr(bytearray(s), k, g)
+        assert np.flatnonzero(c).tolist() == case["kmer"] and c[c != 0].tolist() == case["kmer_v"], (s, k)
+        assert np.flatnonzero(g).tolist() == case["cgr"] and g[g != 0].tolist() == case["cgr_v"], (s, k)
+    c = np.full(16, 7, np.int32); gpu.kmer_counts(bytearray(b"ACGTNACGTTGCA"), 2, c)
+    assert c.tolist() == KAT["accumulate_k2_from7"]
+    # numpy uint8 arrays are accepted like bytearrays; seq is not modified
+    s = np.frombuffer(b"ACGTNACGTTGCA", np.uint8).copy(); keep = s.copy()
+    c = np.zeros(16, np.int32); gpu.kmer_counts(s, 2, c)
+    assert c.tolist() == [0, 2, 0, 0, 1, 0, 2, 0, 0, 1, 0, 2, 0, 0, 1, 1] and np.array_equal(s, keep)
+
+
+def test_scalar_api_random_vs_oracle(gpu):
+    rng = np.random.default_rng(11)
+    alphabet = np.frombuffer(b"ACGTNacgtX-", np.uint8)
+    for L in [1, 2, 5, 6, 7, 63, 64, 65, 127, 128, 129, 1000, 4095, 4096, 4097, 4102, 8191, 8192, 8200, 20000]:
+        for k in (1, 2, 3, 4, 5, 6, 7):
+            s = rng.choice(alphabet, size=L, p=[.23, .23, .23, .23, .03, .01, .01, .01, .01, .005, .005])
+            init = rng.integers(0, 5, 4 ** k).astype(np.int32)
+            want = init.copy(); O.kmer_counts(s, k, want)
+            got = init.copy(); gpu.kmer_counts(s.copy(), k, got)
+            assert np.array_equal(got, want), (L, k)
+            want = init.copy(); O.cgr(s, k, want)
+            got = init.copy(); gpu.cgr(s.copy(), k, got)
+            assert np.array_equal(got, want), (L, k)
+
+
+def test_kmer_rev_comp_api(gpu):
+    c = np.zeros(16, np.int32); c[0] = 3; c[15] = 2
+    assert gpu.kmer_rev_comp(c, 2).tolist() == KAT["kmer_rev_comp_k2_trunc"]
+    rng = np.random.default_rng(3)
+    for k in (1, 2, 3, 4, 5, 6, 7):
+        c = rng.integers(0, 1000, 4 ** k).astype(np.int32)
+        c2 = c.copy(); want = O.kmer_rev_comp(c2, k)
+        c3 = c.copy(); got = gpu.kmer_rev_comp(c3, k)
+        assert np.array_equal(got, want) and np.array_equal(c2, c3), k   # in-place side effect identical too
+
+
+@pytest.mark.parametrize("name", ["edge", "edge_nonl", "empty", "influenza_64", "actino_8"])
+def test_batched_vectoriser_vs_golden(gpu, name):
+    import torch
+    from idelucs_amd import _lib, utils as U
+    g = np.load(os.path.join(GOLDEN, f"counts_{name}.npz"))
+    fn = os.path.join(DATA, name + ".fas")
+    ff = U.FastaFile(fn)
+    din = U._DeviceInput(ff, torch.device("cuda"))
+    for k in (4, 5, 6):
+        c = U._vectorise(din, k, _lib.MODE_KMER, _lib.INIT_ZERO, _lib.OUT_COUNTS_I32)[0].cpu().numpy()
+        assert np.array_equal(c, g[f"kmer_k{k}"]), ("kmer", k)
+        c = U._vectorise(din, k, _lib.MODE_CGR, _lib.INIT_ZERO, _lib.OUT_COUNTS_I32)[0].cpu().numpy()
+        assert np.array_equal(c, g[f"cgr_k{k}"]), ("cgr", k)
+        c = U._vectorise(din, k, _lib.MODE_CANONICAL, _lib.INIT_ONE, _lib.OUT_COUNTS_I32)[0].cpu().numpy()
+        assert np.array_equal(c, g[f"canon_k{k}"]), ("canon", k)
+        # reference-level functions: float64 rows, bit-exact (exact ints divided in float64)
+        names, f = gpu.kmersFasta(fn, k=k)
+        assert names == g["names"].tolist() and f.dtype == np.float64 and np.array_equal(f, g[f"freq_k{k}"])
+        _, fr = gpu.kmersFasta(fn, k=k, reduce=True)
+        assert np.array_equal(fr, g[f"freq_canon_k{k}"])
+        if name != "empty":
+            _, cf = gpu.cgrFasta(fn, k=k)
+            assert np.array_equal(cf, g[f"cgrfreq_k{k}"])
+        # float32 output == float32(float64 division)  (what astype('float32') does at utils.py:353)
+        f32 = U._vectorise(din, k, _lib.MODE_KMER, _lib.INIT_ONE, _lib.OUT_FREQ_F32)[0].cpu().numpy()
+        assert np.array_equal(f32, g[f"freq_k{k}"].astype(np.float32))
+
+
+def test_full_influenza_hashes(gpu):
+    import hashlib
+    import torch
+    from idelucs_amd import _lib, utils as U
+    H = json.load(open(os.path.join(GOLDEN, "hashes.json")))
+    sha16 = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()[:16]
+    ff = U.FastaFile(os.path.join(DATA, "Influenza-A.fas"))
+    din = U._DeviceInput(ff, torch.device("cuda"))
+    for k in (4, 5, 6):
+        h = H[f"influenza_full_k{k}"]
+        km = U._vectorise(din, k, _lib.MODE_KMER, _lib.INIT_ZERO, _lib.OUT_COUNTS_I32)[0].cpu().numpy()
+        cg = U._vectorise(din, k, _lib.MODE_CGR, _lib.INIT_ZERO, _lib.OUT_COUNTS_I32)[0].cpu().numpy()
+        assert (int(km.sum()), int(km.max()), sha16(km), sha16(cg)) == (h["kmer_sum"], h["kmer_max"], h["kmer_sha16"], h["cgr_sha16"])
+        f64 = U._vectorise(din, k, _lib.MODE_KMER, _lib.INIT_ONE, _lib.OUT_FREQ_F64)[0].cpu().numpy()
+        f32 = U._vectorise(din, k, _lib.MODE_KMER, _lib.INIT_ONE, _lib.OUT_FREQ_F32)[0].cpu().numpy()
+        assert sha16(f64) == h["freq_sha16"] and sha16(f32) == h["freq_f32_sha16"]
+
+
+def _random_batch(rng, n, lmin, lmax, p_n=0.002):
+    seqs = []
+    for _ in range(n):
+        L = int(rng.integers(lmin, lmax + 1))
+        s = rng.choice(np.frombuffer(b"ACGTN", np.uint8), size=L, p=[(1 - p_n) / 4] * 4 + [p_n])
+        seqs.append(s)
+    return seqs
+
+
+def _pack_batch(seqs):
+    from idelucs_amd import _lib
+    import ctypes
+    n = len(seqs)
+    byte_off = np.zeros(n + 1, np.int64); np.cumsum([len(s) for s in seqs], out=byte_off[1:])
+    data = np.concatenate(seqs) if n else np.empty(0, np.uint8)
+    slots = int(sum((len(s) + 63) // 64 for s in seqs))
+    codes = np.zeros(max(slots, 1) * 16, np.uint8); mask = np.zeros(max(slots, 1) * 8, np.uint8)
+    slot_off = np.zeros(n + 1, np.int64)
+    p = lambda a: ctypes.c_void_p(a.ctypes.data)
+    _lib.check(_lib.lib.idl_pack(p(data), p(byte_off), n, p(codes), p(mask), p(slot_off)))
+    class FF: pass
+    ff = FF(); ff.n = n; ff.codes = codes; ff.mask = mask; ff.slot_off = slot_off
+    ff.lengths = np.array([len(s) for s in seqs], np.int64)
+    return ff
+
+
+def test_random_batches_with_edits_vs_oracle(gpu):
+    """Multi-view launch with explicit substitution edits (all four ops, chunk boundaries, duplicates)."""
+    import torch
+    from idelucs_amd import _lib, utils as U
+    rng = np.random.default_rng(2024)
+    seqs = _random_batch(rng, 40, 0, 300) + _random_batch(rng, 12, 3900, 4300) + _random_batch(rng, 6, 8000, 13000, 0.0) \
+        + [np.frombuffer(b"A" * 5000, np.uint8), np.frombuffer(b"ACGT" * 1024, np.uint8)]
+    n, P = len(seqs), 4
+    edits, counts, mutated = [], [], [[None] * n for _ in range(P)]
+    for v in range(P):
+        for i, s in enumerate(seqs):
+            L = len(s)
+            m = 0 if (v == 0 or L == 0) else int(rng.integers(0, max(2, L // 20)))
+            pos = np.sort(rng.integers(0, max(L, 1), m)).astype(np.uint32)     # duplicates allowed
+            op = rng.integers(0, 4, m).astype(np.uint32)
+            e = pos | (op << np.uint32(30))
+            edits.append(e); counts.append(m)
+            mutated[v][i] = O.apply_edits(s.tobytes(), e)
+    edit_off = np.zeros(P * n + 1, np.int64); np.cumsum(counts, out=edit_off[1:])
+    e_all = np.concatenate(edits)
+    dev = torch.device("cuda")
+    din = U._DeviceInput(_pack_batch(seqs), dev)
+    d_e = torch.from_numpy(e_all.view(np.int32)).to(dev); d_eo = torch.from_numpy(edit_off).to(dev)
+    for k in (3, 4, 6, 7):
+        for mode, fn in ((_lib.MODE_KMER, O.kmer_counts), (_lib.MODE_CGR, O.cgr)):
+            got = U._vectorise(din, k, mode, _lib.INIT_ZERO, _lib.OUT_COUNTS_I32, P, d_e, d_eo).cpu().numpy()
+            for v in range(P):
+                for i in range(n):
+                    want = np.zeros(4 ** k, np.int32); fn(mutated[v][i], k, want)
+                    assert np.array_equal(got[v, i], want), (k, mode, v, i, len(seqs[i]))
+        got = U._vectorise(din, k, _lib.MODE_CANONICAL, _lib.INIT_ONE, _lib.OUT_FREQ_F64, P, d_e, d_eo).cpu().numpy()
+        for v in (0, 3):
+            for i in range(0, n, 7):
+                c = np.ones(4 ** k, np.int32); O.kmer_counts(mutated[v][i], k, c)
+                c = O.kmer_rev_comp(c, k)
+                assert np.array_equal(got[v, i], c / np.sum(c)), (k, v, i)
+
+
+def _write_subset(tmp_path, n):
+    recs = list(O.fasta_records(os.path.join(DATA, "influenza_64.fas")))[:n]
+    p = tmp_path / "small.fas"
+    with open(p, "wb") as f:
+        for i, s in recs:
+            f.write(b">" + i.encode() + b"\n" + bytes(s) + b"\n")
+    return str(p)
+
+
+@pytest.mark.parametrize("n,m,k,r", [(16, 3, 4, False), (16, 1, 4, False), (16, 5, 4, True), (6, 3, 6, False), (6, 3, 6, True)])
+def test_augment_fasta_compat_vs_reference(gpu, tmp_path, n, m, k, r):
+    """Host-RNG compat mode: the device result equals the reference's AugmentFasta output
+    (golden, generated with numpy/random seeded 0 like a fresh import of the reference)."""
+    from idelucs_amd import utils as U
+    g = np.load(os.path.join(GOLDEN, "augment.npz"))[f"n{n}_m{m}_k{k}_r{int(r)}"]
+    np.random.seed(0); random.seed(0)
+    x = U.AugmentFasta(_write_subset(tmp_path, n), m, k=k, reduce=r, rng="compat")
+    assert x.dtype == np.float32 and x.shape == g.shape
+    # tolerance: the scaler's float64 column sums are reduced in a different order on the device
+    np.testing.assert_allclose(x, g, rtol=0, atol=2e-6)
+
+
+def test_augment_edge_file_and_error(gpu):
+    from idelucs_amd import utils as U
+    g = np.load(os.path.join(GOLDEN, "augment.npz"))["edge_m2_k4_r0"]
+    np.random.seed(0); random.seed(0)
+    x = U.AugmentFasta(os.path.join(DATA, "edge.fas"), 2, k=4, rng="compat")
+    np.testing.assert_allclose(x, g, rtol=0, atol=2e-6)
+    err = json.load(open(os.path.join(GOLDEN, "augment_errors.json")))["edge_m3_error"]
+    for mode in ("compat", "philox"):
+        np.random.seed(0); random.seed(0)
+        with pytest.raises(ValueError) as e:
+            U.AugmentFasta(os.path.join(DATA, "edge.fas"), 3, k=4, rng=mode)
+        assert str(e.value) == err
+
+
+def test_scaler_and_gather_vs_oracle(gpu):
+    import torch
+    from idelucs_amd import utils as U
+    rng = np.random.default_rng(9)
+    dev = torch.device("cuda")
+    for (n, f) in [(1, 4), (3, 10), (37, 136), (300, 256), (1000, 4096)]:
+        x32 = (rng.random((n, f)) * 1e-3).astype(np.float32)
+        x32[:, 0] = 0.25                                   # a zero-variance column -> scale 1
+        mean, scale = U.col_stats(torch.from_numpy(x32).to(dev))
+        m_ref, s_ref = O.scaler_fit(x32)
+        np.testing.assert_allclose(mean.cpu().numpy(), m_ref, rtol=1e-13, atol=0)
+        np.testing.assert_allclose(scale.cpu().numpy(), s_ref, rtol=1e-9, atol=0)
+        assert scale[0].item() == 1.0
+        # transform with the ORACLE's statistics uploaded: then float32 results must be bit-exact
+        dm, ds = torch.from_numpy(m_ref).to(dev), torch.from_numpy(s_ref).to(dev)
+        y = U.standardise(torch.from_numpy(x32).to(dev), dm, ds).cpu().numpy()
+        assert np.array_equal(y, O.scaler_transform(x32, m_ref, s_ref))
+        x64 = x32.astype(np.float64) * 1.0000001
+        m64, s64 = O.scaler_fit(x64)
+        y = U.standardise(torch.from_numpy(x64).to(dev), torch.from_numpy(m64).to(dev), torch.from_numpy(s64).to(dev)).cpu().numpy()
+        assert np.array_equal(y, O.scaler_transform(x64, m64, s64).astype(np.float32))
+    # gather_pairs == standardise + the reference's pair layout
+    P, n, f = 4, 50, 256
+    feats = (rng.random((P, n, f)) * 1e-3).astype(np.float32)
+    m_ref, s_ref = O.scaler_fit(feats[0])
+    st = U.FeatureStore(None, None, torch.from_numpy(feats).to(dev), torch.from_numpy(m_ref).to(dev),
+                        torch.from_numpy(s_ref).to(dev), 4, False)
+    idx = rng.permutation((P - 1) * n)[:70].astype(np.int64)
+    y = st.gather_pairs(torch.from_numpy(idx).to(dev)).cpu().numpy()
+    want_true = O.scaler_transform(feats[0][idx % n], m_ref, s_ref)
+    want_mod = O.scaler_transform(feats[1 + idx // n, idx % n], m_ref, s_ref)
+    assert np.array_equal(y[:70], want_true) and np.array_equal(y[70:], want_mod)
+
+
+def test_sequence_dataset_features(gpu, tmp_path):
+    from idelucs_amd import utils as U
+    g = np.load(os.path.join(GOLDEN, "seqdataset.npz"))
+    fn = _write_subset(tmp_path, 16)
+    ds = U.SequenceDataset(fn, k=4)
+    assert ds.kmers.dtype == np.float64 and len(ds) == 16
+    np.testing.assert_allclose(ds.kmers, g["n16_k4"], rtol=0, atol=1e-10)
+    _, _, f32 = U.predict_features(fn, k=4)
+    np.testing.assert_allclose(f32.cpu().numpy(), g["n16_k4_f32"], rtol=0, atol=2e-6)
+
+
+def test_size_independent_properties_at_full_size(gpu):
+    """cfg2-sized check (100k x 10 kbp is too slow for the scalar oracle): sum of counts ==
+    sum(L) - N*(k-1) for N-free input; CGR is a permutation of k-mer counts; rows of frequencies
+    sum to 1; canonical rows sum to the same totals."""
+    import torch
+    from idelucs_amd import _lib, utils as U
+    dev = torch.device("cuda")
+    n, L, k = 20000, 10000, 6
+    slots = (L + 63) // 64
+    g = torch.Generator(device=dev); g.manual_seed(1)
+    codes = torch.randint(-2 ** 31, 2 ** 31 - 1, (n * slots * 4,), dtype=torch.int32, device=dev, generator=g)
+    mask = torch.zeros(n * slots * 2, dtype=torch.int32, device=dev)
+    # mark the padding of the last slot invalid: bases [L % 64, 64) of the last slot
+    tail = L % 64
+    if tail:
+        lo = torch.tensor([0, 0], dtype=torch.int64)
+        for j in range(tail, 64):
+            lo[j // 32] |= (1 << (31 - (j % 32)))
+        m = mask.view(n, slots, 2)
+        m[:, -1, 0] = int(lo[0]) - (1 << 32) if int(lo[0]) >= 2 ** 31 else int(lo[0])
+        m[:, -1, 1] = int(lo[1]) - (1 << 32) if int(lo[1]) >= 2 ** 31 else int(lo[1])
+    class D: pass
+    din = D(); din.n = n; din.codes = codes; din.mask = mask
+    din.slot_off = torch.arange(0, (n + 1) * slots, slots, dtype=torch.int64, device=dev)
+    din.lengths = torch.full((n,), L, dtype=torch.int64, device=dev)
+    km = U._vectorise(din, k, _lib.MODE_KMER, _lib.INIT_ZERO, _lib.OUT_COUNTS_I32)[0]
+    assert torch.all(km.sum(1) == L - (k - 1))
+    cg = U._vectorise(din, k, _lib.MODE_CGR, _lib.INIT_ZERO, _lib.OUT_COUNTS_I32)[0]
+    assert torch.equal(torch.sort(km, dim=1).values, torch.sort(cg, dim=1).values)
+    fr = U._vectorise(din, k, _lib.MODE_KMER, _lib.INIT_ONE, _lib.OUT_FREQ_F32)[0]
+    assert torch.allclose(fr.double().sum(1), torch.ones(n, dtype=torch.float64, device=dev), atol=1e-6)
+    assert torch.equal(fr, ((km + 1).double() / float(L - (k - 1) + 4 ** k)).float())
+    ca = U._vectorise(din, k, _lib.MODE_CANONICAL, _lib.INIT_ZERO, _lib.OUT_COUNTS_I32)[0]
+    assert ca.shape[1] == 2080 and torch.all(ca.sum(1) <= (L - (k - 1)) // 2 + 64) and torch.all(ca.sum(1) >= (L - k + 1 - 2080) // 2)

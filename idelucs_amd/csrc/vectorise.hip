@@ -121,7 +121,9 @@ __global__ __launch_bounds__(64) void vectorise_kernel(VecArgs a)
             // ---------------- histogram init
             if (a.init == IDL_INIT_FROM_OUT) {
                 const uint32_t *src = (const uint32_t *)a.out + out_base;
-                for (int i = lane; i < F; i += 64) hist[i] = src[i];
+                // the histogram is kept in k-mer order; a CGR row is stored in pixel order
+                for (int i = lane; i < F; i += 64)
+                    hist[(a.mode == IDL_MODE_CGR) ? cgr_pixel_to_kmer<K>((uint32_t)i) : (uint32_t)i] = src[i];
             } else {
                 const uint32_t iv = (a.init == IDL_INIT_ONE) ? 1u : 0u;
                 for (int i = lane; i < F; i += 64) hist[i] = iv;

@@ -1,0 +1,65 @@
+"""world_size-2 tests of the multi-GPU plumbing on CPU (gloo): voter round-robin, all-gather of
+assignments / latent shards.  No GPU, no compute kernels."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _worker(rank, world_size, port, n_voters, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    from idelucs_amd import dist as D
+    n = 37
+    mine = D.voters_of_rank(n_voters)
+    local = {v: torch.full((n,), v, dtype=torch.int32) + torch.arange(n, dtype=torch.int32) % 3 for v in mine}
+    allp = D.gather_voter_predictions(local, n_voters, n)
+    want = torch.stack([torch.full((n,), v, dtype=torch.int32) + torch.arange(n, dtype=torch.int32) % 3 for v in range(n_voters)])
+    ok1 = torch.equal(allp, want)
+    g = D.all_gather_assignments(torch.full((n,), rank, dtype=torch.int32))
+    ok2 = g.shape == (world_size, n) and all(int(g[r, 0]) == r for r in range(world_size))
+    lo, hi = D.shard_bounds(n)
+    full = torch.arange(n * 4, dtype=torch.float32).view(n, 4)
+    ok3 = torch.equal(D.all_gather_rows(full[lo:hi].clone(), n), full)
+    q.put((rank, mine, bool(ok1), bool(ok2), bool(ok3)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_voters", [1, 2, 5])
+def test_voter_sharding_and_gathers_world2(n_voters):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_voters, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=60) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res[0][1] == [v for v in range(n_voters) if v % 2 == 0]
+    assert res[1][1] == [v for v in range(n_voters) if v % 2 == 1]
+    assert all(r[2] and r[3] and r[4] for r in res), res
+
+
+def test_single_process_paths():
+    from idelucs_amd import dist as D
+    assert D.world() == (0, 1)
+    assert D.voters_of_rank(5) == [0, 1, 2, 3, 4]
+    y = torch.arange(6, dtype=torch.int32)
+    assert D.all_gather_assignments(y).shape == (1, 6)
+    assert D.shard_bounds(10) == (0, 10)
+    assert [D.shard_bounds(10, r, 4) for r in range(4)] == [(0, 3), (3, 6), (6, 9), (9, 10)]

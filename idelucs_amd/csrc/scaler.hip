@@ -127,12 +127,12 @@ __global__ __launch_bounds__(256) void standardise_scalar(const T *x, int64_t to
 
 // one workgroup per output row; rows [0, batch) are the "true" halves, [batch, 2*batch) the "modified" ones
 __global__ __launch_bounds__(256) void gather_pairs_kernel(const float *feats, int64_t n, int64_t f, int64_t view_stride,
-                                                           const int64_t *pair_idx, int64_t batch, const double *mean,
-                                                           const double *scale, float *y)
+                                                           const int64_t *pair_idx, const int64_t *base, int64_t batch,
+                                                           const double *mean, const double *scale, float *y)
 {
     const int64_t row = blockIdx.x;
     const int64_t b = row < batch ? row : row - batch;
-    const int64_t pair = pair_idx[b];
+    const int64_t pair = pair_idx[(base ? *base : 0) + b];
     const int64_t m = pair / n, s = pair - m * n;
     const float *src = feats + (row < batch ? 0 : (m + 1) * view_stride) + s * f;
     float *dst = y + row * f;
@@ -220,9 +220,20 @@ int idl_standardise(const void *x, int is_f64, int64_t n, int64_t f, const doubl
     return IDL_OK;
 }
 
+int idl_gather_pairs_at(const float *feats, int64_t n, int64_t f, int64_t view_stride,
+                        const int64_t *pair_idx, const int64_t *base, int64_t batch, const double *mean,
+                        const double *scale, float *y, void *stream);
+
 int idl_gather_pairs(const float *feats, int64_t n, int64_t f, int64_t view_stride,
                      const int64_t *pair_idx, int64_t batch, const double *mean, const double *scale,
                      float *y, void *stream)
+{
+    return idl_gather_pairs_at(feats, n, f, view_stride, pair_idx, nullptr, batch, mean, scale, y, stream);
+}
+
+int idl_gather_pairs_at(const float *feats, int64_t n, int64_t f, int64_t view_stride,
+                        const int64_t *pair_idx, const int64_t *base, int64_t batch, const double *mean,
+                        const double *scale, float *y, void *stream)
 {
     IDL_REQUIRE(n >= 1 && f >= 1 && batch >= 0, "gather_pairs needs n >= 1, f >= 1, batch >= 0");
     if (batch == 0) return IDL_OK;
@@ -233,7 +244,7 @@ int idl_gather_pairs(const float *feats, int64_t n, int64_t f, int64_t view_stri
     int rc = idl::device_info(&di);
     if (rc != IDL_OK) return rc;
     hipLaunchKernelGGL(gather_pairs_kernel, dim3((unsigned)(2 * batch)), dim3(256), 0, (hipStream_t)stream, feats, n, f,
-                       view_stride, pair_idx, batch, mean, scale, y);
+                       view_stride, pair_idx, base, batch, mean, scale, y);
     IDL_HIP_TRY(hipGetLastError());
     return IDL_OK;
 }

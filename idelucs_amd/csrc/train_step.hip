@@ -1,0 +1,453 @@
+// train_step.hip -- the non-GEMM pieces of one contrastive-IIC optimizer step, fused for gfx950.
+//
+// The reference step (idelucs/models.py:117-133) is ~160 small PyTorch kernels around four dense
+// layers; on MI355X that is launch-bound (0.1 ms of GEMM inside a 1.8 ms step).  Here the step is an
+// explicit forward/backward: the dense products stay on hipBLASLt (MFMA) and every other piece is
+// one of the kernels below, so a step is ~20 launches that replay as a HIP graph.
+//
+//   relu_dropout_fwd      nn.ReLU + nn.Dropout(0.5) after Linear(F,512)        PytorchUtils.py:40-41
+//   head_fwd              latent -> L2-normalise (LossFunctions.py:79); ReLU + Dropout + Linear(64,C)
+//                         + Softmax (PytorchUtils.py:45-50)
+//   nce_lse / nce_esym    info_nce_loss forward and d/dS without masks         LossFunctions.py:65-98
+//   iic_core              IID_loss value and d/dP of the C x C joint           LossFunctions.py:20-62
+//   head_bwd              softmax/Linear/Dropout/ReLU backward + normalise backward, per row
+//   col_sum, relu_dropout_bwd_colsum   bias gradients, ReLU/Dropout backward
+//   rmsprop_step          torch.optim.RMSprop(lr, alpha=.99, eps=1e-8, weight_decay=.01) models.py:88
+//
+// Dropout uses Philox4x32-10 keyed by a seed with counter (element block, layer, step): the mask is
+// never stored -- a kept, active unit is exactly one whose output is > 0, which is all the backward
+// needs.  `ctl` is a small device-resident control block so that graph replays advance without
+// host involvement:  ctl[0] = optimizer-step counter, ctl[1] = offset of the next batch in the
+// shuffled pair list.
+#include "common.h"
+
+namespace {
+
+constexpr int H2 = 64;        // latent width of NetLinear == one wavefront
+constexpr int MAX_CPL = 4;    // classes per lane: n_clusters <= 256
+
+struct U4 { uint32_t x, y, z, w; };
+
+__device__ __forceinline__ U4 philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1)
+{
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return U4{c0, c1, c2, c3};
+}
+
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// ---------------------------------------------------------------- ReLU + Dropout(0.5), in place
+__global__ __launch_bounds__(256) void relu_dropout_fwd_kernel(float4 *a, int64_t n4, int train, uint64_t seed, const int64_t *ctl,
+                                                               uint32_t layer)
+{
+    const uint32_t step = (uint32_t)ctl[0];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        float4 v = a[i];
+        float s0 = 1.f, s1 = 1.f, s2 = 1.f, s3 = 1.f;
+        if (train) {
+            const U4 r = philox((uint32_t)i, layer, step, (uint32_t)(i >> 32), (uint32_t)seed, (uint32_t)(seed >> 32));
+            s0 = (r.x >> 31) ? 2.f : 0.f; s1 = (r.y >> 31) ? 2.f : 0.f;
+            s2 = (r.z >> 31) ? 2.f : 0.f; s3 = (r.w >> 31) ? 2.f : 0.f;
+        }
+        v.x = v.x > 0.f ? v.x * s0 : 0.f; v.y = v.y > 0.f ? v.y * s1 : 0.f;
+        v.z = v.z > 0.f ? v.z * s2 : 0.f; v.w = v.w > 0.f ? v.w * s3 : 0.f;
+        a[i] = v;
+    }
+}
+
+// ---------------------------------------------------------------- head forward: one wave per row
+// lat[m,64] -> f = lat/max(||lat||,1e-12), inv[m]; r2 = dropout(relu(lat)); z = softmax(r2 W3^T + b3)
+__global__ __launch_bounds__(256) void head_fwd_kernel(const float *lat, const float *W3, const float *b3, int m, int C, int train,
+                                                       uint64_t seed, const int64_t *ctl, float *f, float *inv, float *r2, float *z)
+{
+    __shared__ float sh[4][H2];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + w;
+    if (row >= m) return;
+    const float x = lat[(int64_t)row * H2 + lane];
+    const float nrm = fmaxf(sqrtf(wave_sum(x * x)), 1e-12f);       // F.normalize(dim=1), eps 1e-12
+    f[(int64_t)row * H2 + lane] = x / nrm;
+    if (lane == 0) inv[row] = 1.f / nrm;
+    float s = 1.f;
+    if (train) {
+        const U4 r = philox((uint32_t)row, 2u, (uint32_t)ctl[0], 0u, (uint32_t)seed, (uint32_t)(seed >> 32));
+        const uint32_t word = (lane < 32) ? r.x : r.y;
+        s = ((word >> (lane & 31)) & 1u) ? 2.f : 0.f;
+    }
+    const float a = x > 0.f ? x * s : 0.f;
+    r2[(int64_t)row * H2 + lane] = a;
+    sh[w][lane] = a;
+    __builtin_amdgcn_wave_barrier();
+    float lg[MAX_CPL];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < MAX_CPL; ++t) {
+        const int c = t * 64 + lane;
+        lg[t] = -INFINITY;
+        if (c < C) {
+            float acc = b3[c];
+            const float *wr = W3 + (int64_t)c * H2;
+#pragma unroll 8
+            for (int h = 0; h < H2; ++h) acc = fmaf(sh[w][h], wr[h], acc);
+            lg[t] = acc;
+            mx = fmaxf(mx, acc);
+        }
+    }
+    mx = wave_max(mx);
+    float den = 0.f;
+#pragma unroll
+    for (int t = 0; t < MAX_CPL; ++t) {
+        const int c = t * 64 + lane;
+        if (c < C) { lg[t] = __expf(lg[t] - mx); den += lg[t]; }
+    }
+    den = wave_sum(den);
+#pragma unroll
+    for (int t = 0; t < MAX_CPL; ++t) {
+        const int c = t * 64 + lane;
+        if (c < C) z[(int64_t)row * C + c] = lg[t] / den;
+    }
+}
+
+// ---------------------------------------------------------------- InfoNCE on S = f f^T (un-scaled)
+// per row r: lse_r = logsumexp_{j != r} S_rj / T;  loss_r = lse_r - S_r,pos(r) / T,  pos(r) = (r + m/2) mod m
+__global__ __launch_bounds__(256) void nce_lse_kernel(const float *S, int m, float inv_t, float *lse, float *loss_rows)
+{
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + w;
+    if (row >= m) return;
+    const float *s = S + (int64_t)row * m;
+    float mx = -INFINITY;
+    for (int j = lane; j < m; j += 64) if (j != row) mx = fmaxf(mx, s[j] * inv_t);
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int j = lane; j < m; j += 64) if (j != row) sum += __expf(s[j] * inv_t - mx);
+    sum = wave_sum(sum);
+    const float l = mx + __logf(sum);
+    if (lane == 0) {
+        lse[row] = l;
+        const int pos = (row + m / 2) % m;
+        loss_rows[row] = l - s[pos] * inv_t;
+    }
+}
+
+// S <- E + E^T with E_rj = exp(S_rj/T - lse_r) (j != r), 0 on the diagonal; S is symmetric
+__global__ __launch_bounds__(256) void nce_esym_kernel(float *S, int m, float inv_t, const float *lse)
+{
+    const int64_t total = (int64_t)m * m;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int r = (int)(i / m), j = (int)(i - (int64_t)r * m);
+        const float v = S[i] * inv_t;
+        S[i] = (r == j) ? 0.f : __expf(v - lse[r]) + __expf(v - lse[j]);
+    }
+}
+
+// ---------------------------------------------------------------- IIC on the C x C joint (one workgroup)
+// P0 = z1^T z2 (given).  Writes the step loss (w_nce * mean(loss_rows) + w_iic * IIC) to out[0], adds it
+// to out[1] (running epoch sum) and writes dP0 = w_iic * dIIC/dP0 into P0 in place.  scratch: C*C floats.
+__global__ __launch_bounds__(256) void iic_core_kernel(float *P0, int C, float lamb, float eps, float w_iic, float w_nce,
+                                                       const float *loss_rows, int m, float *scratch, float *rowsum, float *colsum,
+                                                       float *out)
+{
+    __shared__ double red[256];
+    __shared__ float bc[4];
+    const int t = threadIdx.x, n = C * C;
+    auto block_sum = [&](double v) -> double {
+        red[t] = v;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) { if (t < o) red[t] += red[t + o]; __syncthreads(); }
+        const double r = red[0];
+        __syncthreads();
+        return r;
+    };
+    // s = sum(P0); P = (P0 + P0^T) / 2 / s  -> scratch
+    double acc = 0.0;
+    for (int i = t; i < n; i += 256) acc += (double)P0[i];
+    const float s = (float)block_sum(acc);
+    for (int i = t; i < n; i += 256) {
+        const int r = i / C, c = i - r * C;
+        scratch[i] = ((P0[i] + P0[c * C + r]) * 0.5f) / s;
+    }
+    __syncthreads();
+    // marginals of the un-clamped joint (LossFunctions.py:32-33)
+    for (int r = t; r < C; r += 256) {
+        float a = 0.f, b = 0.f;
+        for (int c = 0; c < C; ++c) { a += scratch[r * C + c]; b += scratch[c * C + r]; }
+        rowsum[r] = a; colsum[r] = b;
+    }
+    __syncthreads();
+    // loss, and the clamped-row/col sums needed by the marginal terms of the gradient
+    acc = 0.0;
+    for (int i = t; i < n; i += 256) {
+        const int r = i / C, c = i - r * C;
+        const float p = fmaxf(scratch[i], eps), pi = fmaxf(rowsum[r], eps), pj = fmaxf(colsum[c], eps);
+        acc += (double)(-p * (__logf(p) - lamb * __logf(pj) - lamb * __logf(pi)));
+    }
+    const float iic = (float)block_sum(acc);
+    acc = 0.0;
+    for (int i = t; i < m; i += 256) acc += (double)loss_rows[i];
+    const float nce = (float)(block_sum(acc) / (double)m);
+    if (t == 0) { const float l = w_nce * nce + w_iic * iic; out[0] = l; out[1] += l; out[2] = nce; out[3] = iic; }
+    // clamped row / column sums: A_r = sum_c Pc[r,c], Bc_c = sum_r Pc[r,c]   (kept in P0's first 2C entries? no: reuse red-free arrays)
+    __shared__ float Ar[256], Bc[256];
+    for (int r = t; r < C; r += 256) {
+        float a = 0.f, b = 0.f;
+        for (int c = 0; c < C; ++c) { a += fmaxf(scratch[r * C + c], eps); b += fmaxf(scratch[c * C + r], eps); }
+        Ar[r] = a; Bc[r] = b;
+    }
+    __syncthreads();
+    // G = dL/dP (clamp-by-assignment: no gradient through clamped entries), staged in P0
+    acc = 0.0;
+    for (int i = t; i < n; i += 256) {
+        const int r = i / C, c = i - r * C;
+        const float pu = scratch[i], p = fmaxf(pu, eps);
+        const float piu = rowsum[r], pi = fmaxf(piu, eps), pju = colsum[c], pj = fmaxf(pju, eps);
+        float g = 0.f;
+        if (!(pu < eps)) g += -(__logf(p) - lamb * __logf(pj) - lamb * __logf(pi)) - 1.f;
+        if (!(piu < eps)) g += lamb * Ar[r] / pi;
+        if (!(pju < eps)) g += lamb * Bc[c] / pj;
+        P0[i] = g;
+        acc += (double)g * (double)pu;
+    }
+    const float gp = (float)block_sum(acc);       // sum(G * P)
+    // through P = Ps / sum(Ps):  dPs = (G - sum(G*P)) / s ; through Ps = (P0 + P0^T)/2: dP0 = (dPs + dPs^T)/2
+    for (int i = t; i < n; i += 256) scratch[i] = (P0[i] - gp) / s;
+    __syncthreads();
+    for (int i = t; i < n; i += 256) {
+        const int r = i / C, c = i - r * C;
+        P0[i] = w_iic * 0.5f * (scratch[i] + scratch[c * C + r]);
+    }
+    (void)bc;
+}
+
+// ---------------------------------------------------------------- head backward: one wave per row
+// inputs: z, r2, f, inv, G = (E + E^T) f, dP0 (scaled by w_iic), W3;  outputs: dlogits [m,C], dlat [m,64]
+__global__ __launch_bounds__(256) void head_bwd_kernel(const float *z, const float *r2, const float *f, const float *inv,
+                                                       const float *G, const float *dP0, const float *W3, int m, int C, int train,
+                                                       float nce_coef, float *dlogits, float *dlat)
+{
+    __shared__ float shz[4][256];
+    __shared__ float shd[4][256];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + w;
+    if (row >= m) return;
+    const int B = m / 2;
+    const bool first = row < B;
+    const int prow = first ? row + B : row - B;
+    for (int c = lane; c < C; c += 64) shz[w][c] = z[(int64_t)prow * C + c];
+    __builtin_amdgcn_wave_barrier();
+    // dz: rows of view 1: dz[c] = sum_c' dP0[c,c'] zp[c'];  rows of view 2: dz[c] = sum_c' zp[c'] dP0[c',c]
+    float zc[MAX_CPL], dz[MAX_CPL];
+    float dot = 0.f;
+#pragma unroll
+    for (int t = 0; t < MAX_CPL; ++t) {
+        const int c = t * 64 + lane;
+        zc[t] = 0.f; dz[t] = 0.f;
+        if (c < C) {
+            zc[t] = z[(int64_t)row * C + c];
+            float acc = 0.f;
+            if (first) for (int k = 0; k < C; ++k) acc = fmaf(dP0[c * C + k], shz[w][k], acc);
+            else for (int k = 0; k < C; ++k) acc = fmaf(shz[w][k], dP0[k * C + c], acc);
+            dz[t] = acc;
+            dot += acc * zc[t];
+        }
+    }
+    dot = wave_sum(dot);
+#pragma unroll
+    for (int t = 0; t < MAX_CPL; ++t) {
+        const int c = t * 64 + lane;
+        if (c < C) {
+            const float dl = zc[t] * (dz[t] - dot);       // softmax backward
+            dlogits[(int64_t)row * C + c] = dl;
+            shd[w][c] = dl;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // classifier branch: dr2[h] = sum_c dlogits[c] W3[c,h]; through Dropout+ReLU (kept & active <=> r2 > 0)
+    float dr = 0.f;
+    for (int c = 0; c < C; ++c) dr = fmaf(shd[w][c], W3[(int64_t)c * H2 + lane], dr);
+    const float a = r2[(int64_t)row * H2 + lane];
+    float dl_cls = a > 0.f ? dr * (train ? 2.f : 1.f) : 0.f;
+    // contrastive branch: df = nce_coef * (G_r - 2 f_pos); through f = lat / ||lat||
+    const float fr = f[(int64_t)row * H2 + lane];
+    const float df = nce_coef * (G[(int64_t)row * H2 + lane] - 2.f * f[(int64_t)prow * H2 + lane]);
+    const float proj = wave_sum(fr * df);
+    dlat[(int64_t)row * H2 + lane] = dl_cls + (df - fr * proj) * inv[row];
+}
+
+// ---------------------------------------------------------------- column sums (bias gradients)
+// out[c] = sum_r x[r, c]; block = 64 columns x 4 row-strided waves; deterministic
+template <bool RELU_BWD>
+__global__ __launch_bounds__(256) void col_sum_kernel(float *x, const float *act, int m, int n, float scale, float *out)
+{
+    __shared__ float sh[4][64];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int c = blockIdx.x * 64 + lane;
+    float acc = 0.f;
+    if (c < n) {
+        for (int r = w; r < m; r += 4) {
+            float v = x[(int64_t)r * n + c];
+            if (RELU_BWD) {   // x = d(out of dropout) -> d(pre-activation), in place
+                v = act[(int64_t)r * n + c] > 0.f ? v * scale : 0.f;
+                x[(int64_t)r * n + c] = v;
+            }
+            acc += v;
+        }
+    }
+    sh[w][lane] = acc;
+    __syncthreads();
+    if (w == 0 && c < n) out[c] = (sh[0][lane] + sh[1][lane]) + (sh[2][lane] + sh[3][lane]);
+}
+
+// ---------------------------------------------------------------- RMSprop over all parameter tensors
+struct RmsArgs {
+    float *p[8];
+    const float *g[8];
+    float *v[8];
+    int64_t n[8];
+    int count;
+};
+
+__global__ __launch_bounds__(256) void rmsprop_kernel(RmsArgs a, const float *hyper, int64_t *ctl, int64_t batch_advance)
+{
+    const int t = blockIdx.y;
+    const float lr = hyper[0], alpha = hyper[1], eps = hyper[2], wd = hyper[3], oma = hyper[4];
+    if (t < a.count) {
+        float *p = a.p[t]; const float *g = a.g[t]; float *v = a.v[t];
+        const int64_t n = a.n[t];
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+            const float pi = p[i];
+            const float gi = g[i] + wd * pi;                      // grad.add(param, alpha=weight_decay)
+            const float vi = v[i] * alpha + oma * gi * gi;  // square_avg.mul_(alpha).addcmul_(g, g, value=1-alpha)
+            v[i] = vi;
+            p[i] = pi - lr * (gi / (sqrtf(vi) + eps));           // param.addcdiv_(grad, sqrt(v)+eps, value=-lr)
+        }
+    }
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { ctl[0] += 1; ctl[1] += batch_advance; }
+}
+
+}  // namespace
+
+extern "C" {
+
+int idl_relu_dropout_fwd(float *a, int64_t n, int train, uint64_t seed, const int64_t *ctl, int layer, void *stream)
+{
+    IDL_REQUIRE(a && ctl && n >= 0 && (n & 3) == 0 && (((uintptr_t)a) & 15u) == 0, "relu_dropout_fwd: n % 4 == 0, 16-byte aligned");
+    if (n == 0) return IDL_OK;
+    int64_t g = (n / 4 + 255) / 256;
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(relu_dropout_fwd_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, (float4 *)a, n / 4, train, seed, ctl,
+                       (uint32_t)layer);
+    IDL_HIP_TRY(hipGetLastError());
+    return IDL_OK;
+}
+
+int idl_head_fwd(const float *lat, const float *W3, const float *b3, int m, int C, int train, uint64_t seed, const int64_t *ctl,
+                 float *f, float *inv, float *r2, float *z, void *stream)
+{
+    IDL_REQUIRE(lat && W3 && b3 && ctl && f && inv && r2 && z, "NULL buffer");
+    IDL_REQUIRE(m >= 1 && C >= 1 && C <= 64 * MAX_CPL, "head_fwd: n_clusters must be in 1..256");
+    hipLaunchKernelGGL(head_fwd_kernel, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, (hipStream_t)stream, lat, W3, b3, m, C, train, seed,
+                       ctl, f, inv, r2, z);
+    IDL_HIP_TRY(hipGetLastError());
+    return IDL_OK;
+}
+
+int idl_nce_rows(float *S, int m, float temperature, float *lse, float *loss_rows, void *stream)
+{
+    IDL_REQUIRE(S && lse && loss_rows && m >= 2 && (m % 2) == 0 && temperature > 0.f, "nce_rows: even m >= 2, T > 0");
+    const float inv_t = 1.f / temperature;
+    hipLaunchKernelGGL(nce_lse_kernel, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, (hipStream_t)stream, S, m, inv_t, lse, loss_rows);
+    int64_t g = ((int64_t)m * m + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(nce_esym_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, S, m, inv_t, lse);
+    IDL_HIP_TRY(hipGetLastError());
+    return IDL_OK;
+}
+
+int idl_iic_core(float *P0, int C, float lamb, float eps, float w_iic, float w_nce, const float *loss_rows, int m,
+                 float *scratch, float *out, void *stream)
+{
+    IDL_REQUIRE(P0 && loss_rows && scratch && out, "NULL buffer");
+    IDL_REQUIRE(C >= 1 && C <= 64 * MAX_CPL && m >= 1, "iic_core: n_clusters must be in 1..256");
+    // scratch layout: [C*C] joint, then [C] row sums, [C] column sums
+    float *rowsum = scratch + (size_t)C * C, *colsum = rowsum + C;
+    hipLaunchKernelGGL(iic_core_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, P0, C, lamb, eps, w_iic, w_nce, loss_rows, m, scratch,
+                       rowsum, colsum, out);
+    IDL_HIP_TRY(hipGetLastError());
+    return IDL_OK;
+}
+
+int idl_head_bwd(const float *z, const float *r2, const float *f, const float *inv, const float *G, const float *dP0,
+                 const float *W3, int m, int C, int train, float nce_coef, float *dlogits, float *dlat, void *stream)
+{
+    IDL_REQUIRE(z && r2 && f && inv && G && dP0 && W3 && dlogits && dlat, "NULL buffer");
+    IDL_REQUIRE(m >= 2 && (m % 2) == 0 && C >= 1 && C <= 64 * MAX_CPL, "head_bwd: even m, n_clusters in 1..256");
+    hipLaunchKernelGGL(head_bwd_kernel, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, (hipStream_t)stream, z, r2, f, inv, G, dP0, W3, m, C,
+                       train, nce_coef, dlogits, dlat);
+    IDL_HIP_TRY(hipGetLastError());
+    return IDL_OK;
+}
+
+int idl_col_sum(const float *x, int m, int n, float *out, void *stream)
+{
+    IDL_REQUIRE(x && out && m >= 1 && n >= 1, "col_sum: NULL buffer or empty");
+    hipLaunchKernelGGL(col_sum_kernel<false>, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, (hipStream_t)stream, (float *)x,
+                       (const float *)nullptr, m, n, 1.f, out);
+    IDL_HIP_TRY(hipGetLastError());
+    return IDL_OK;
+}
+
+int idl_relu_dropout_bwd_colsum(float *dx, const float *act, int m, int n, int train, float *out, void *stream)
+{
+    IDL_REQUIRE(dx && act && out && m >= 1 && n >= 1, "relu_dropout_bwd_colsum: NULL buffer or empty");
+    hipLaunchKernelGGL(col_sum_kernel<true>, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, (hipStream_t)stream, dx, act, m, n,
+                       train ? 2.f : 1.f, out);
+    IDL_HIP_TRY(hipGetLastError());
+    return IDL_OK;
+}
+
+int idl_rmsprop_step(int count, float *const *params, const float *const *grads, float *const *square_avg, const int64_t *sizes,
+                     const float *hyper, int64_t *ctl, int64_t batch_advance, void *stream)
+{
+    IDL_REQUIRE(count >= 1 && count <= 8 && params && grads && square_avg && sizes && hyper && ctl, "rmsprop_step: 1..8 tensors");
+    RmsArgs a{};
+    a.count = count;
+    int64_t mx = 0;
+    for (int i = 0; i < count; ++i) {
+        a.p[i] = params[i]; a.g[i] = grads[i]; a.v[i] = square_avg[i]; a.n[i] = sizes[i];
+        if (sizes[i] > mx) mx = sizes[i];
+    }
+    int64_t gx = (mx + 255) / 256;
+    if (gx > 1024) gx = 1024;
+    if (gx < 1) gx = 1;
+    hipLaunchKernelGGL(rmsprop_kernel, dim3((unsigned)gx, (unsigned)count), dim3(256), 0, (hipStream_t)stream, a, hyper, ctl, batch_advance);
+    IDL_HIP_TRY(hipGetLastError());
+    return IDL_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,185 @@
+"""idelucs_amd.fused -- the explicit, fused optimizer step for the default configuration
+(NetLinear encoder + RMSprop), replayed as a HIP graph.
+
+One step of reference idelucs/models.py:117-133 becomes ~20 launches: the dense products on
+hipBLASLt (torch.mm/addmm with out=, no allocation) and every other piece a fused HIP kernel from
+csrc/train_step.hip (C ABI: idl_relu_dropout_fwd, idl_head_fwd, idl_nce_rows, idl_iic_core,
+idl_head_bwd, idl_col_sum, idl_relu_dropout_bwd_colsum, idl_rmsprop_step).  The batch is assembled by
+idl_gather_pairs_at from the HBM feature store using a device-resident offset that the optimizer
+kernel advances, so an epoch is `n_batches` replays of one captured graph with no host work between.
+
+The parameters remain the nn.Parameters of model.net (state_dict / predict / weights_init unchanged).
+RMSprop state lives here and, like the reference's single optimizer object (models.py:87-88 +
+__main__.py:109), persists across voters.
+"""
+import ctypes
+import sys
+
+import torch
+
+from . import _lib
+from ._lib import lib as _L
+
+EPS = sys.float_info.epsilon
+TEMPERATURE = 0.85          # hard-coded at the reference call site, models.py:128
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class _Buffers:
+    """Activations / gradients of one batch shape (m = 2*B rows)."""
+
+    def __init__(self, m, F, H1, H2, C, dev):
+        f32 = dict(dtype=torch.float32, device=dev)
+        self.m = m
+        self.x = torch.empty((m, F), **f32)
+        self.r1 = torch.empty((m, H1), **f32)        # Linear1 output, then ReLU+Dropout in place
+        self.lat = torch.empty((m, H2), **f32)
+        self.f = torch.empty((m, H2), **f32)
+        self.inv = torch.empty((m,), **f32)
+        self.r2 = torch.empty((m, H2), **f32)
+        self.z = torch.empty((m, C), **f32)
+        self.S = torch.empty((m, m), **f32)
+        self.lse = torch.empty((m,), **f32)
+        self.loss_rows = torch.empty((m,), **f32)
+        self.G = torch.empty((m, H2), **f32)
+        self.P0 = torch.empty((C, C), **f32)
+        self.iic_scratch = torch.empty((C * C + 2 * C,), **f32)
+        self.dlogits = torch.empty((m, C), **f32)
+        self.dlat = torch.empty((m, H2), **f32)
+        self.dr1 = torch.empty((m, H1), **f32)
+
+
+class FusedLinearTrainer:
+    def __init__(self, net, lr, weight, lamb, weight_decay=0.01, alpha=0.99, eps=1e-8, seed=0):
+        lin1, lin2, lin3 = net.layers[0], net.layers[3], net.classifier[2]
+        self.net = net
+        self.W1, self.b1, self.W2, self.b2, self.W3, self.b3 = (lin1.weight, lin1.bias, lin2.weight, lin2.bias,
+                                                                  lin3.weight, lin3.bias)
+        self.params = [self.W1, self.b1, self.W2, self.b2, self.W3, self.b3]
+        self.dev = self.W1.device
+        self.F, self.H1, self.H2, self.C = lin1.in_features, lin1.out_features, lin2.out_features, lin3.out_features
+        if self.H2 != 64 or self.C > 256 or lin2.in_features != self.H1 or lin3.in_features != 64:
+            raise ValueError("FusedLinearTrainer needs NetLinear (latent 64) and n_clusters <= 256")
+        self.grads = [torch.zeros_like(p) for p in self.params]
+        self.square_avg = [torch.zeros_like(p) for p in self.params]
+        self.weight, self.lamb, self.seed = float(weight), float(lamb), int(seed) & (2 ** 64 - 1)
+        self.hyper = torch.tensor([lr, alpha, eps, weight_decay, 1.0 - alpha], dtype=torch.float32, device=self.dev)
+        self.ctl = torch.zeros(2, dtype=torch.int64, device=self.dev)        # [step counter, batch offset]
+        self.out = torch.zeros(4, dtype=torch.float32, device=self.dev)      # [step loss, running sum, nce, iic]
+        self._bufs = {}
+        self._graphs = {}
+        self._perm = None
+        n = len(self.params)
+        self._pp = (ctypes.c_void_p * n)(*[p.data_ptr() for p in self.params])
+        self._gp = (ctypes.c_void_p * n)(*[g.data_ptr() for g in self.grads])
+        self._vp = (ctypes.c_void_p * n)(*[v.data_ptr() for v in self.square_avg])
+        self._sz = (ctypes.c_int64 * n)(*[p.numel() for p in self.params])
+
+    def set_lr(self, lr):
+        self.hyper[0] = float(lr)
+
+    def buffers(self, m):
+        if m not in self._bufs:
+            self._bufs[m] = _Buffers(m, self.F, self.H1, self.H2, self.C, self.dev)
+        return self._bufs[m]
+
+    # ------------------------------------------------------------------ one step on a filled bf.x
+    @torch.no_grad()
+    def step_on_batch(self, bf, train=True, batch_advance=0):
+        """Forward, backward and RMSprop update for the [m, F] batch in bf.x (rows [0,m/2) "true",
+        [m/2,m) "modified").  Only enqueues work on the current stream."""
+        m, C, st, tr = bf.m, self.C, _stream(), 1 if train else 0
+        chk = _lib.check
+        # ---- forward
+        torch.addmm(self.b1, bf.x, self.W1.t(), out=bf.r1)
+        chk(_L.idl_relu_dropout_fwd(_p(bf.r1), bf.r1.numel(), tr, self.seed, _p(self.ctl), 1, st))
+        torch.addmm(self.b2, bf.r1, self.W2.t(), out=bf.lat)
+        chk(_L.idl_head_fwd(_p(bf.lat), _p(self.W3), _p(self.b3), m, C, tr, self.seed, _p(self.ctl),
+                            _p(bf.f), _p(bf.inv), _p(bf.r2), _p(bf.z), st))
+        # ---- losses and their gradients w.r.t. f and z
+        torch.mm(bf.f, bf.f.t(), out=bf.S)
+        chk(_L.idl_nce_rows(_p(bf.S), m, TEMPERATURE, _p(bf.lse), _p(bf.loss_rows), st))
+        torch.mm(bf.S, bf.f, out=bf.G)                                   # (E + E^T) f
+        torch.mm(bf.z[:m // 2].t(), bf.z[m // 2:], out=bf.P0)            # IIC joint, one [C,B]x[B,C] GEMM
+        chk(_L.idl_iic_core(_p(bf.P0), C, self.lamb, EPS, self.weight, 1.0 - self.weight, _p(bf.loss_rows), m,
+                            _p(bf.iic_scratch), _p(self.out), st))
+        nce_coef = (1.0 - self.weight) / (m * TEMPERATURE)
+        chk(_L.idl_head_bwd(_p(bf.z), _p(bf.r2), _p(bf.f), _p(bf.inv), _p(bf.G), _p(bf.P0), _p(self.W3), m, C, tr,
+                            nce_coef, _p(bf.dlogits), _p(bf.dlat), st))
+        # ---- parameter gradients
+        gW1, gb1, gW2, gb2, gW3, gb3 = self.grads
+        torch.mm(bf.dlogits.t(), bf.r2, out=gW3)
+        chk(_L.idl_col_sum(_p(bf.dlogits), m, C, _p(gb3), st))
+        torch.mm(bf.dlat.t(), bf.r1, out=gW2)
+        chk(_L.idl_col_sum(_p(bf.dlat), m, self.H2, _p(gb2), st))
+        torch.mm(bf.dlat, self.W2, out=bf.dr1)
+        chk(_L.idl_relu_dropout_bwd_colsum(_p(bf.dr1), _p(bf.r1), m, self.H1, tr, _p(gb1), st))
+        torch.mm(bf.dr1.t(), bf.x, out=gW1)
+        # ---- RMSprop (and advance the device-side step counter / batch offset)
+        chk(_L.idl_rmsprop_step(len(self.params), self._pp, self._gp, self._vp, self._sz, _p(self.hyper), _p(self.ctl),
+                                batch_advance, st))
+
+    def _gather(self, store, bf):
+        b = bf.m // 2
+        _lib.check(_L.idl_gather_pairs_at(_p(store.feats), store.n, store.f, store.n * store.f, _p(self._perm), _p(self.ctl[1:]),
+                                          b, _p(store.mean), _p(store.scale), _p(bf.x), _stream()))
+
+    def _full_step(self, store, bf, train=True):
+        self._gather(store, bf)
+        self.step_on_batch(bf, train=train, batch_advance=bf.m // 2)
+
+    # ------------------------------------------------------------------ one epoch over the store
+    @torch.no_grad()
+    def run_epoch(self, store, batch_sz, use_graph=True, generator=None):
+        """One pass over a fresh permutation of the N*n_mimics pairs (models.py:117-133).
+        Returns the device scalar sum of the per-step losses and the number of batches."""
+        n_pairs = store.n_pairs
+        if self._perm is None or self._perm.numel() != n_pairs:
+            self._perm = torch.empty(n_pairs, dtype=torch.int64, device=self.dev)
+            self._graphs.clear()
+        torch.randperm(n_pairs, device=self.dev, generator=generator, out=self._perm)
+        self.ctl[1] = 0
+        self.out[1] = 0.0
+        n_full, rem = divmod(n_pairs, batch_sz)
+        if n_full:
+            bf = self.buffers(2 * batch_sz)
+            key = (2 * batch_sz, store.feats.data_ptr(), store.mean.data_ptr(), store.n, store.f)
+            if use_graph and n_full >= 8:
+                g = self._graphs.get(key)
+                if g is None:
+                    g = self._capture(store, bf)
+                    self._graphs = {key: g}             # one store at a time: drop graphs of older stores
+                    n_done = 3                           # the warm-up + capture already ran real steps
+                else:
+                    n_done = 0
+                for _ in range(n_full - n_done):
+                    g.replay()
+            else:
+                for _ in range(n_full):
+                    self._full_step(store, bf)
+        if rem:
+            self._full_step(store, self.buffers(2 * rem))
+        return self.out[1], n_full + (1 if rem else 0)
+
+    @torch.no_grad()
+    def _capture(self, store, bf):
+        """Warm up on a side stream (2 real steps), then capture a third real step into a HIP graph.
+        Every launch is a genuine optimizer step on the next batch, so nothing is wasted or repeated."""
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(2):
+                self._full_step(store, bf)
+        torch.cuda.current_stream().wait_stream(s)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._full_step(store, bf)
+        g.replay()          # capture does not execute: run the captured (third) step once
+        return g

@@ -6,6 +6,7 @@ Differences are all below the interface: features live in HBM (utils.FeatureStor
 assembled by a HIP gather kernel instead of DataLoader workers, the two views go through the encoder
 as one [2B, F] batch, losses are mask-free device code, and no step synchronises with the host.
 """
+import os
 import random
 import sys
 
@@ -88,6 +89,10 @@ class IID_model():
                                                          mode="triangular2")
         self.store = None
         self._fasta = None
+        # default configuration (NetLinear + RMSprop): explicit fused step replayed as a HIP graph
+        self._fused = None
+        self._use_fused = (args['model_size'] == 'linear' and args['optimizer'] == 'RMSprop'
+                           and args['n_clusters'] <= 256 and os.environ.get("IDELUCS_FUSED", "1") != "0")
 
     # ------------------------------------------------------------------ data
     def build_dataloader(self):
@@ -112,6 +117,14 @@ class IID_model():
         """Reference models.py:113-143: one pass over the shuffled N*n_mimics pairs."""
         self.net.train()
         st = self.store
+        if self._use_fused:
+            from .fused import FusedLinearTrainer
+            if self._fused is None:
+                self._fused = FusedLinearTrainer(self.net, self.lr, self.weight, self.l, seed=self.seed)
+            self._fused.set_lr(self.optimizer.param_groups[0]['lr'])       # schedulers act on the torch optimizer
+            total, n_batches = self._fused.run_epoch(st, self.batch_sz)
+            running_loss = total / (n_batches - 1)                          # models.py:135 quirk (divide by last index)
+            return self._finish_epoch(running_loss)
         running_loss = torch.zeros((), device=self.device)
         perm = torch.randperm(st.n_pairs, device=self.device)
         i_batch = 0
@@ -119,7 +132,9 @@ class IID_model():
             x = st.gather_pairs(perm[i:i + self.batch_sz])
             running_loss += self._step(x)
         running_loss = running_loss / i_batch      # models.py:135 divides by the LAST INDEX (n_batches-1): kept
+        return self._finish_epoch(running_loss)
 
+    def _finish_epoch(self, running_loss):
         if self.schedule == 'Plateau':
             self.scheduler.step(running_loss)
         elif self.schedule == 'Triangle':

@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""ACC of the Influenza-A anchor (k=6, C=5, 10 epochs, 1 voter) over seeds, fused vs autograd step."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, pandas as pd, torch
+import idelucs_amd
+from idelucs_amd import models
+
+D = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "data")
+df = pd.read_csv(os.path.join(D, "Influenza-A_GT.tsv"), sep="\t")
+u = {v: i for i, v in enumerate(sorted(set(df.cluster_id)))}
+gt = np.array([u[v] for v in df.cluster_id])
+epochs = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+for fused in (0, 1):
+    accs = []
+    for seed in range(8):
+        torch.manual_seed(seed)
+        args = {'sequence_file': os.path.join(D, "Influenza-A.fas"), 'GT_file': None, 'n_clusters': 5, 'k': 6, 'model_size': 'linear',
+                'n_mimics': 3, 'batch_sz': 512, 'optimizer': 'RMSprop', 'lambda': 2.8, 'lr': 1e-3, 'weight': 0.25, 'scheduler': None,
+                'n_epochs': epochs, 'n_voters': 1, 'seed': seed}
+        m = models.IID_model(args)
+        m._use_fused = bool(fused)
+        m.build_dataloader()
+        m.net.apply(models.weights_init)
+        losses = [m.contrastive_training_epoch() for _ in range(epochs)]
+        y, _, _ = m.predict()
+        accs.append(idelucs_amd.cluster_acc(gt, y)[1])
+        print(f"fused={fused} seed={seed} acc={accs[-1]:.4f} loss0={losses[0]:.4f} lossN={losses[-1]:.4f}", flush=True)
+    print(f"== fused={fused}: mean {np.mean(accs):.4f} min {np.min(accs):.4f} max {np.max(accs):.4f}")

@@ -49,7 +49,8 @@ SIGNATURES = {
     "idl_head_bwd": (_int, [_vp] * 7 + [_int, _int, _int, _c.c_float, _vp, _vp, _vp]),
     "idl_col_sum": (_int, [_vp, _int, _int, _vp, _vp]),
     "idl_relu_dropout_bwd_colsum": (_int, [_vp, _vp, _int, _int, _int, _vp, _vp]),
-    "idl_rmsprop_step": (_int, [_int, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "idl_col_sum_parts": (_int, []),
+    "idl_rmsprop_step": (_int, [_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
 }
 
 if not os.path.exists(LIB_PATH):

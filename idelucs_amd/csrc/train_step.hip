@@ -300,18 +300,25 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float *z, const flo
 }
 
 // ---------------------------------------------------------------- column sums (bias gradients)
-// out[c] = sum_r x[r, c]; block = 64 columns x 4 row-strided waves; deterministic
+// partial[p, c] = sum over the rows of chunk p of x[r, c]  (p = blockIdx.y, COL_PARTS chunks); the chunks
+// are added up, in order, by rmsprop_kernel -- deterministic and without an extra launch.
+constexpr int COL_PARTS = 32;
+
 template <bool RELU_BWD>
-__global__ __launch_bounds__(256) void col_sum_kernel(float *x, const float *act, int m, int n, float scale, float *out)
+__global__ __launch_bounds__(256) void col_partial_kernel(float *x, const float *act, int m, int n, float scale, float *partial)
 {
     __shared__ float sh[4][64];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int c = blockIdx.x * 64 + lane;
+    const int rows = (m + COL_PARTS - 1) / COL_PARTS;
+    const int r0 = blockIdx.y * rows;
+    int r1 = r0 + rows;
+    if (r1 > m) r1 = m;
     float acc = 0.f;
     if (c < n) {
-        for (int r = w; r < m; r += 4) {
+        for (int r = r0 + w; r < r1; r += 4) {
             float v = x[(int64_t)r * n + c];
-            if (RELU_BWD) {   // x = d(out of dropout) -> d(pre-activation), in place
+            if (RELU_BWD) {   // x = d(output of Dropout) -> d(pre-activation), in place
                 v = act[(int64_t)r * n + c] > 0.f ? v * scale : 0.f;
                 x[(int64_t)r * n + c] = v;
             }
@@ -320,7 +327,7 @@ __global__ __launch_bounds__(256) void col_sum_kernel(float *x, const float *act
     }
     sh[w][lane] = acc;
     __syncthreads();
-    if (w == 0 && c < n) out[c] = (sh[0][lane] + sh[1][lane]) + (sh[2][lane] + sh[3][lane]);
+    if (w == 0 && c < n) partial[(int64_t)blockIdx.y * n + c] = (sh[0][lane] + sh[1][lane]) + (sh[2][lane] + sh[3][lane]);
 }
 
 // ---------------------------------------------------------------- RMSprop over all parameter tensors
@@ -329,6 +336,7 @@ struct RmsArgs {
     const float *g[8];
     float *v[8];
     int64_t n[8];
+    int parts[8];     // g[t] holds parts[t] stacked partial gradients [parts, n] (1 = a plain gradient)
     int count;
 };
 
@@ -341,7 +349,9 @@ __global__ __launch_bounds__(256) void rmsprop_kernel(RmsArgs a, const float *hy
         const int64_t n = a.n[t];
         for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
             const float pi = p[i];
-            const float gi = g[i] + wd * pi;                      // grad.add(param, alpha=weight_decay)
+            float gr = g[i];
+            for (int q = 1; q < a.parts[t]; ++q) gr += g[(int64_t)q * n + i];
+            const float gi = gr + wd * pi;                        // grad.add(param, alpha=weight_decay)
             const float vi = v[i] * alpha + oma * gi * gi;  // square_avg.mul_(alpha).addcmul_(g, g, value=1-alpha)
             v[i] = vi;
             p[i] = pi - lr * (gi / (sqrtf(vi) + eps));           // param.addcdiv_(grad, sqrt(v)+eps, value=-lr)
@@ -413,26 +423,29 @@ int idl_head_bwd(const float *z, const float *r2, const float *f, const float *i
     return IDL_OK;
 }
 
-int idl_col_sum(const float *x, int m, int n, float *out, void *stream)
+int idl_col_sum_parts(void) { return COL_PARTS; }
+
+int idl_col_sum(const float *x, int m, int n, float *partial, void *stream)
 {
-    IDL_REQUIRE(x && out && m >= 1 && n >= 1, "col_sum: NULL buffer or empty");
-    hipLaunchKernelGGL(col_sum_kernel<false>, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, (hipStream_t)stream, (float *)x,
-                       (const float *)nullptr, m, n, 1.f, out);
+    IDL_REQUIRE(x && partial && m >= 1 && n >= 1, "col_sum: NULL buffer or empty");
+    hipLaunchKernelGGL(col_partial_kernel<false>, dim3((unsigned)((n + 63) / 64), COL_PARTS), dim3(256), 0, (hipStream_t)stream,
+                       (float *)x, (const float *)nullptr, m, n, 1.f, partial);
     IDL_HIP_TRY(hipGetLastError());
     return IDL_OK;
 }
 
-int idl_relu_dropout_bwd_colsum(float *dx, const float *act, int m, int n, int train, float *out, void *stream)
+int idl_relu_dropout_bwd_colsum(float *dx, const float *act, int m, int n, int train, float *partial, void *stream)
 {
-    IDL_REQUIRE(dx && act && out && m >= 1 && n >= 1, "relu_dropout_bwd_colsum: NULL buffer or empty");
-    hipLaunchKernelGGL(col_sum_kernel<true>, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, (hipStream_t)stream, dx, act, m, n,
-                       train ? 2.f : 1.f, out);
+    IDL_REQUIRE(dx && act && partial && m >= 1 && n >= 1, "relu_dropout_bwd_colsum: NULL buffer or empty");
+    hipLaunchKernelGGL(col_partial_kernel<true>, dim3((unsigned)((n + 63) / 64), COL_PARTS), dim3(256), 0, (hipStream_t)stream, dx, act,
+                       m, n, train ? 2.f : 1.f, partial);
     IDL_HIP_TRY(hipGetLastError());
     return IDL_OK;
 }
 
-int idl_rmsprop_step(int count, float *const *params, const float *const *grads, float *const *square_avg, const int64_t *sizes,
-                     const float *hyper, int64_t *ctl, int64_t batch_advance, void *stream)
+int idl_rmsprop_step(int count, float *const *params, const float *const *grads, const int32_t *grad_parts,
+                     float *const *square_avg, const int64_t *sizes, const float *hyper, int64_t *ctl, int64_t batch_advance,
+                     void *stream)
 {
     IDL_REQUIRE(count >= 1 && count <= 8 && params && grads && square_avg && sizes && hyper && ctl, "rmsprop_step: 1..8 tensors");
     RmsArgs a{};
@@ -440,6 +453,8 @@ int idl_rmsprop_step(int count, float *const *params, const float *const *grads,
     int64_t mx = 0;
     for (int i = 0; i < count; ++i) {
         a.p[i] = params[i]; a.g[i] = grads[i]; a.v[i] = square_avg[i]; a.n[i] = sizes[i];
+        a.parts[i] = grad_parts ? grad_parts[i] : 1;
+        IDL_REQUIRE(a.parts[i] >= 1, "rmsprop_step: grad_parts must be >= 1");
         if (sizes[i] > mx) mx = sizes[i];
     }
     int64_t gx = (mx + 255) / 256;

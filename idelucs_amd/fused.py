@@ -67,7 +67,10 @@ class FusedLinearTrainer:
         self.F, self.H1, self.H2, self.C = lin1.in_features, lin1.out_features, lin2.out_features, lin3.out_features
         if self.H2 != 64 or self.C > 256 or lin2.in_features != self.H1 or lin3.in_features != 64:
             raise ValueError("FusedLinearTrainer needs NetLinear (latent 64) and n_clusters <= 256")
-        self.grads = [torch.zeros_like(p) for p in self.params]
+        # bias gradients are kept as COL_PARTS stacked partial column sums, added up inside idl_rmsprop_step
+        self.parts = [1 if p.dim() == 2 else _L.idl_col_sum_parts() for p in self.params]
+        self.grads = [torch.zeros((q,) + tuple(p.shape), dtype=p.dtype, device=p.device) if q > 1 else torch.zeros_like(p)
+                      for p, q in zip(self.params, self.parts)]
         self.square_avg = [torch.zeros_like(p) for p in self.params]
         self.weight, self.lamb, self.seed = float(weight), float(lamb), int(seed) & (2 ** 64 - 1)
         self.hyper = torch.tensor([lr, alpha, eps, weight_decay, 1.0 - alpha], dtype=torch.float32, device=self.dev)
@@ -81,6 +84,11 @@ class FusedLinearTrainer:
         self._gp = (ctypes.c_void_p * n)(*[g.data_ptr() for g in self.grads])
         self._vp = (ctypes.c_void_p * n)(*[v.data_ptr() for v in self.square_avg])
         self._sz = (ctypes.c_int64 * n)(*[p.numel() for p in self.params])
+        self._parts = (ctypes.c_int32 * n)(*self.parts)
+
+    def gradient(self, i):
+        """Gradient of parameter i as a tensor of the parameter's shape (sums the stacked partials)."""
+        return self.grads[i].sum(0) if self.parts[i] > 1 else self.grads[i]
 
     def set_lr(self, lr):
         self.hyper[0] = float(lr)
@@ -123,8 +131,8 @@ class FusedLinearTrainer:
         chk(_L.idl_relu_dropout_bwd_colsum(_p(bf.dr1), _p(bf.r1), m, self.H1, tr, _p(gb1), st))
         torch.mm(bf.dr1.t(), bf.x, out=gW1)
         # ---- RMSprop (and advance the device-side step counter / batch offset)
-        chk(_L.idl_rmsprop_step(len(self.params), self._pp, self._gp, self._vp, self._sz, _p(self.hyper), _p(self.ctl),
-                                batch_advance, st))
+        chk(_L.idl_rmsprop_step(len(self.params), self._pp, self._gp, self._parts, self._vp, self._sz, _p(self.hyper),
+                                _p(self.ctl), batch_advance, st))
 
     def _gather(self, store, bf):
         b = bf.m // 2

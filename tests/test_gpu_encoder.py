@@ -179,8 +179,8 @@ def test_fused_step_matches_reference(dev):
     ref = float(g["linear.step0.loss"])
     assert abs(tr.out[0].item() - ref) <= 2e-4 * abs(ref), (tr.out[0].item(), ref)
     names = ["layers.0.weight", "layers.0.bias", "layers.3.weight", "layers.3.bias", "classifier.2.weight", "classifier.2.bias"]
-    for n_, gr in zip(names, tr.grads):
-        np.testing.assert_allclose(gr.cpu().numpy(), g[f"linear.step0.g.{n_}"], rtol=2e-3, atol=2e-6, err_msg=n_)
+    for i, n_ in enumerate(names):
+        np.testing.assert_allclose(tr.gradient(i).cpu().numpy(), g[f"linear.step0.g.{n_}"], rtol=2e-3, atol=2e-6, err_msg=n_)
     # parameters after the update: all but the near-zero-gradient elements (first RMSprop step is lr*g/(0.1|g|+eps))
     for n_, p in zip(names, tr.params):
         got, want = p.detach().cpu().numpy(), g[f"linear.step0.p.{n_}"]
@@ -200,11 +200,15 @@ def test_fused_rmsprop_kernel_exact(dev):
     g = g5()
     net, tr = _fused_trainer(dev)
     names = ["layers.0.weight", "layers.0.bias", "layers.3.weight", "layers.3.bias", "classifier.2.weight", "classifier.2.bias"]
-    for n_, gr in zip(names, tr.grads):
-        gr.copy_(torch.from_numpy(g[f"linear.step0.g.{n_}"]).to(dev))
+    for n_, gr, parts in zip(names, tr.grads, tr.parts):
+        ref = torch.from_numpy(g[f"linear.step0.g.{n_}"]).to(dev)
+        if parts > 1:                       # spread a bias gradient over the stacked partials
+            gr.zero_(); gr[0].copy_(ref * 0.25); gr[parts - 1].copy_(ref * 0.75)
+        else:
+            gr.copy_(ref)
     from idelucs_amd import _lib
     from idelucs_amd.fused import _p, _stream
-    _lib.check(_lib.lib.idl_rmsprop_step(6, tr._pp, tr._gp, tr._vp, tr._sz, _p(tr.hyper), _p(tr.ctl), 7, _stream()))
+    _lib.check(_lib.lib.idl_rmsprop_step(6, tr._pp, tr._gp, tr._parts, tr._vp, tr._sz, _p(tr.hyper), _p(tr.ctl), 7, _stream()))
     for n_, p in zip(names, tr.params):
         np.testing.assert_allclose(p.detach().cpu().numpy(), g[f"linear.step0.p.{n_}"], rtol=1e-5, atol=1e-7, err_msg=n_)
     assert tr.ctl.tolist() == [1, 7]

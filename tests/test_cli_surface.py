@@ -1,0 +1,48 @@
+"""The CLI keeps the reference's flag surface (idelucs/__main__.py:275-308); CPU-only checks plus one GPU run."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import DATA
+
+
+def test_flag_surface_and_defaults():
+    from idelucs_amd.__main__ import build_parser
+    a = vars(build_parser().parse_args(["--sequence_file", "x.fas"]))
+    want = {"sequence_file": "x.fas", "n_clusters": 0, "n_epochs": 100, "n_mimics": 3, "batch_sz": 256, "GT_file": None, "k": 6,
+            "optimizer": "RMSprop", "scheduler": "None", "weight": 0.25, "lambda": 2.8, "lr": 1e-3, "n_voters": 5,
+            "model_size": "linear", "plot": False}
+    for k, v in want.items():
+        assert a[k] == v, k
+
+
+def test_relabel_and_ensemble_helpers():
+    from idelucs_amd import posthoc
+    y = np.array([3, 3, 1, 0, 1, 3, 7])
+    assert posthoc.relabel_first_occurrence(y).tolist() == [0, 0, 1, 2, 1, 0, 3]
+    rng = np.random.default_rng(0)
+    truth = rng.integers(0, 3, 300)
+    votes = np.stack([(truth + s) % 3 for s in (0, 1, 2)])       # three voters, same partition, permuted labels
+    flip = rng.random(votes.shape) < 0.05                         # (perfect agreement gives 1/0 distances -> NaN
+    votes = np.where(flip, (votes + 1) % 3, votes)                #  confidences, in the reference too: utils.py:597-599)
+    y, conf = posthoc.label_features(votes, 3)
+    from idelucs_amd.utils import cluster_acc
+    assert cluster_acc(truth, y)[1] >= 0.98 and conf.shape == (300,) and np.all(conf > 1 / 3)
+
+
+@pytest.mark.gpu
+def test_cli_end_to_end_writes_reference_outputs(tmp_path, monkeypatch):
+    import pandas as pd
+    from idelucs_amd.__main__ import main
+    monkeypatch.chdir(tmp_path)
+    out_dir = main(["--sequence_file", os.path.join(DATA, "Influenza-A.fas"), "--GT_file", os.path.join(DATA, "Influenza-A_GT.tsv"),
+                    "--n_clusters", "5", "--n_epochs", "12", "--n_voters", "3", "--batch_sz", "512", "--k", "6"])
+    for f in ("assignments.tsv", "metrics.tsv", "training_plots.jpg", "contingency_matrix.tsv"):
+        assert os.path.exists(os.path.join(out_dir, f)), f
+    assert os.path.exists(tmp_path / "ALL_RESULTS.tsv")
+    df = pd.read_csv(os.path.join(out_dir, "assignments.tsv"), sep="\t", index_col=0)
+    assert list(df.columns) == ["sequence_id", "assignment", "confidence_score"] and len(df) == 949
+    m = pd.read_csv(os.path.join(out_dir, "metrics.tsv"), sep="\t", index_col=0)
+    assert {"ACC", "ARI", "NMI", "Silhouette-Score", "Davies-Boulding"} <= set(m.index)
+    assert float(m.loc["ACC", "Value"]) > 0.85        # 3-voter ensemble

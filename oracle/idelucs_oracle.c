@@ -196,3 +196,87 @@ void orc_pack(const uint8_t *seq, int64_t len, uint8_t *codes, uint8_t *mask)
         else cw[i >> 4] |= (uint32_t)c << (30 - 2 * (i & 15));
     }
 }
+
+/* ------------------------------------------------------------------------
+ * Restatement of the "fast mode" mimic generator spec (idelucs_amd/csrc/mimic.hip header):
+ * Philox4x32-10, exact geometric gap sampling from an integer threshold table, per-lane segments
+ * of ceil(L/64) bases, Random_N by mulhi + sort.  Statistically equivalent to the reference's
+ * transforms (idelucs/utils.py:54-135); bit-exact with the device by construction of the spec.
+ * ------------------------------------------------------------------------ */
+#define ORC_J 1024
+
+static void orc_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4])
+{
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+/* site view: returns the number of edits written (sorted by position) */
+int64_t orc_mimic_sites(int64_t L, uint32_t seq_index, uint32_t view, double p_ts, double p_tv, uint64_t seed,
+                        uint32_t *out, int64_t cap)
+{
+    const double keep = (1.0 - p_ts) * (1.0 - p_tv);
+    const double q = 1.0 - keep;
+    if (!(q > 0.0)) return 0;
+    static uint32_t T[ORC_J + 1];
+    T[0] = 0xFFFFFFFFu;
+    double x = 1.0;
+    for (int j = 1; j <= ORC_J; ++j) { x = x * keep; T[j] = (uint32_t)(x * 4294967296.0); }
+    const double fa = (p_ts * (1.0 - p_tv)) / q * 4294967296.0;
+    const double fb = ((1.0 - p_ts) * p_tv) / q * 4294967296.0;
+    const double Ad = fa >= 4294967295.0 ? 4294967295.0 : fa;
+    double Bd = Ad + fb;
+    if (Bd > 4294967295.0) Bd = 4294967295.0;
+    const uint32_t A = (uint32_t)Ad, B = (uint32_t)Bd;
+    const int kind = (p_tv == 0.0) ? 1 : (p_ts == 0.0) ? 2 : 0;
+    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    const int64_t seg = (L + 63) / 64;
+    int64_t n = 0;
+    for (int lane = 0; lane < 64; ++lane) {
+        const int64_t lo = (int64_t)lane * seg;
+        int64_t hi = lo + seg;
+        if (hi > L) hi = L;
+        int64_t pos = lo - 1;
+        for (uint32_t d = 0; pos < hi; ++d) {
+            uint32_t r[4];
+            orc_philox(d, (uint32_t)lane, seq_index, view, k0, k1, r);
+            int a = 0, b = ORC_J;
+            while (a < b) { int m = (a + b + 1) >> 1; if (r[0] < T[m]) a = m; else b = m - 1; }
+            if (a == ORC_J) { pos += ORC_J; continue; }
+            pos += a + 1;
+            if (pos >= hi) break;
+            const uint32_t flav = 1u | ((r[2] & 1u) << 1);
+            uint32_t op = (r[1] < A) ? 2u : (r[1] < B) ? flav : (2u ^ flav);
+            if (kind == 1) op = 2u;
+            if (kind == 2) op = flav;
+            if (n < cap) out[n] = (uint32_t)pos | (op << 30);
+            ++n;
+        }
+    }
+    return n;
+}
+
+static int orc_cmp_u32(const void *a, const void *b)
+{
+    uint32_t x = *(const uint32_t *)a, y = *(const uint32_t *)b;
+    return x < y ? -1 : x > y;
+}
+
+/* Random_N view: n_rand <= 64 positions, ascending, op 0 */
+int64_t orc_mimic_random_n(int64_t L, uint32_t seq_index, uint32_t view, int n_rand, uint64_t seed, uint32_t *out)
+{
+    if (L <= 0) return 0;
+    for (int i = 0; i < n_rand; ++i) {
+        uint32_t r[4];
+        orc_philox((uint32_t)i, 0u, seq_index, view | (1u << 16), (uint32_t)seed, (uint32_t)(seed >> 32), r);
+        out[i] = (uint32_t)(((uint64_t)r[0] * (uint64_t)(uint32_t)L) >> 32);
+    }
+    qsort(out, (size_t)n_rand, sizeof(uint32_t), orc_cmp_u32);
+    return n_rand;
+}

@@ -54,6 +54,11 @@ def lib():
         L.orc_apply_edits.restype = None
         L.orc_pack.argtypes = [u8p, ctypes.c_int64, u8p, u8p]
         L.orc_pack.restype = None
+        L.orc_mimic_sites.argtypes = [ctypes.c_int64, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_double, ctypes.c_double,
+                                      ctypes.c_uint64, u32p, ctypes.c_int64]
+        L.orc_mimic_sites.restype = ctypes.c_int64
+        L.orc_mimic_random_n.argtypes = [ctypes.c_int64, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, ctypes.c_uint64, u32p]
+        L.orc_mimic_random_n.restype = ctypes.c_int64
         _LIB = L
     return _LIB
 
@@ -319,3 +324,18 @@ def pack(seq):
     if slots:
         lib().orc_pack(_u8(a), a.size, _u8(codes), _u8(mask))
     return codes, mask
+
+
+def mimic_edits(length, seq_index, view, spec, seed):
+    """Fast-mode (Philox) mimic edits of one (view, sequence): spec = (p_transition, p_transversion, n_random_n).
+    C-oracle restatement of the device generator's spec (idelucs_amd/csrc/mimic.hip)."""
+    p_ts, p_tv, n_rand = spec
+    u32p = ctypes.POINTER(ctypes.c_uint32)
+    if n_rand > 0:
+        out = np.empty(max(n_rand, 1), np.uint32)
+        n = lib().orc_mimic_random_n(int(length), int(seq_index), int(view), int(n_rand), int(seed), out.ctypes.data_as(u32p))
+        return out[:n].copy()
+    cap = int(length) + 64
+    out = np.empty(cap, np.uint32)
+    n = lib().orc_mimic_sites(int(length), int(seq_index), int(view), float(p_ts), float(p_tv), int(seed), out.ctypes.data_as(u32p), cap)
+    return out[:n].copy()

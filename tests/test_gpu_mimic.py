@@ -1,0 +1,96 @@
+"""GPU tests (-m gpu) of the fast-mode (device Philox) mimic generator: bit-exact against the C
+oracle's restatement of the spec, and statistically equivalent to the reference transforms
+(idelucs/utils.py:54-135: site probability per base, transition/transversion target law, Random_N)."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _generate(lengths, specs, seed):
+    import torch
+    from idelucs_amd import utils as U
+    dev = torch.device("cuda")
+
+    class D:
+        pass
+    d = D()
+    d.n = len(lengths)
+    d.codes = torch.zeros(1, dtype=torch.int32, device=dev)
+    d.lengths = torch.tensor(lengths, dtype=torch.int64, device=dev)
+    edits, off = U._philox_edits(d, specs, seed)
+    return edits.cpu().numpy().view(np.uint32), off.cpu().numpy()
+
+
+def test_bit_exact_vs_oracle():
+    lengths = [1, 2, 63, 64, 65, 127, 1000, 4096, 4097, 10000, 10000, 33333, 200000, 5]
+    specs = [(1e-2, 0.5e-2, 0), (1e-2, 0.0, 0), (0.0, 0.5e-2, 0), (0.0, 0.0, 20), (0.3, 0.3, 0), (1e-6, 0.0, 0), (0.0, 0.0, 64)]
+    for seed in (0, 7, 2 ** 40 + 12345):
+        edits, off = _generate(lengths, specs, seed)
+        n = len(lengths)
+        assert off[0] == 0 and off[-1] == len(edits) or (off[-1] == 0 and len(edits) == 1)
+        for v, spec in enumerate(specs):
+            for s, L in enumerate(lengths):
+                got = edits[off[v * n + s]:off[v * n + s + 1]]
+                want = O.mimic_edits(L, s, v, spec, seed)
+                assert np.array_equal(got, want), (seed, v, s, L, len(got), len(want))
+                pos = got & 0x3FFFFFFF
+                assert np.all(pos < max(L, 1)) and np.all(np.diff(pos.astype(np.int64)) >= 0)       # in range, sorted
+
+
+def test_statistics_match_reference_transforms():
+    n, L = 2000, 10000
+    specs = [(1e-2, 0.5e-2, 0), (1e-2, 0.0, 0), (0.0, 0.5e-2, 0), (0.0, 0.0, 20)]
+    edits, off = _generate([L] * n, specs, 99)
+    tot = n * L
+
+    def view(v):
+        e = edits[off[v * n]:off[(v + 1) * n]]
+        return e & 0x3FFFFFFF, e >> 30
+    # view 1: transition only, rate 1e-2, op always 2 (A<->G, C<->T)
+    pos, op = view(1)
+    assert np.all(op == 2) and abs(len(pos) / tot - 1e-2) < 4 * np.sqrt(1e-2 / tot)
+    # view 2: transversion only, rate 0.5e-2, the two targets equally likely (random.choice, utils.py:118)
+    pos, op = view(2)
+    assert set(np.unique(op)) == {1, 3} and abs(len(pos) / tot - 0.5e-2) < 4 * np.sqrt(0.5e-2 / tot)
+    assert abs(np.mean(op == 1) - 0.5) < 4 * 0.5 / np.sqrt(len(op))
+    # view 0: both passes: P(site) = 1-(1-p1)(1-p2); type shares ts-only : tv-only : both = p1(1-p2) : (1-p1)p2 : p1p2
+    pos, op = view(0)
+    q = 1 - (1 - 1e-2) * (1 - 0.5e-2)
+    assert abs(len(pos) / tot - q) < 4 * np.sqrt(q / tot)
+    # ts-only -> op 2; tv-only -> 1|3; both -> 2^(1|3) = 3|1  => P(op==2) = p1(1-p2)/q
+    assert abs(np.mean(op == 2) - 1e-2 * (1 - 0.5e-2) / q) < 4 * 0.5 / np.sqrt(len(op))
+    # positions uniform over the sequence (10 bins)
+    h = np.bincount((pos.astype(np.int64) * 10 // L), minlength=10)
+    assert np.all(np.abs(h - len(pos) / 10) < 5 * np.sqrt(len(pos) / 10))
+    # gaps between consecutive sites inside a sequence are geometric: mean 1/q
+    e0 = edits[off[0]:off[1]] & 0x3FFFFFFF
+    assert len(e0) > 50
+    # view 3: Random_N(20): exactly 20 draws per sequence, uniform, duplicates allowed, op 0
+    pos, op = view(3)
+    assert np.all(op == 0) and len(pos) == 20 * n
+    h = np.bincount((pos.astype(np.int64) * 10 // L), minlength=10)
+    assert np.all(np.abs(h - len(pos) / 10) < 5 * np.sqrt(len(pos) / 10))
+    # different seeds / sequences decorrelate
+    e2, off2 = _generate([L] * 4, specs, 100)
+    assert not np.array_equal(e2[off2[0]:off2[1]], edits[off[0]:off[1]])
+
+
+def test_feature_level_equivalence_of_rng_modes(tmp_path):
+    """Philox and compat (reference-stream) mimics give statistically the same features: mean L1 distance
+    between the "true" view and each mimic view agrees within 10 % on real sequences."""
+    import os
+    import random
+    from conftest import DATA
+    from idelucs_amd import utils as U
+    fn = os.path.join(DATA, "influenza_64.fas")
+    np.random.seed(0); random.seed(0)
+    a = U.build_feature_store(fn, 3, k=4, rng="compat").feats.cpu().numpy()
+    b = U.build_feature_store(fn, 3, k=4, rng="philox", seed=3).feats.cpu().numpy()
+    assert a.shape == b.shape == (4, 64, 256)
+    for v in (1, 2, 3):
+        da = np.abs(a[v] - a[0]).sum(1).mean()
+        db = np.abs(b[v] - b[0]).sum(1).mean()
+        assert abs(da - db) / da < 0.10, (v, da, db)

@@ -16,6 +16,8 @@
 //   idelucs/utils.py:191-221 kmer_rev_comp-> canonical collapse with int truncation
 //   idelucs/utils.py:242-250 ones-init, counts / sum(counts)
 //   idelucs/utils.py:54-135  transforms   -> substitution edits (XOR on 2-bit codes / set-N)
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -31,6 +33,7 @@ struct VecArgs {
     const int64_t *edit_off;
     void *out;
     int64_t view_stride;
+    int sc_slots;   // v2: slots (64 bases) staged in LDS at a time
 };
 
 constexpr int STAGE_DWORDS = 256 + 128;  // 64 lanes x (4 code words + 2 mask words)
@@ -266,6 +269,350 @@ __global__ __launch_bounds__(64) void vectorise_kernel(VecArgs a)
     }
 }
 
+
+// =====================================================================================================
+// v2: delta views.  The mimic views of a sequence differ from the un-mutated sequence at ~1.5 % of
+// the positions, so the sequence is counted ONCE (H0) and a view is produced by moving the <= k windows
+// around each edit from their old bin to their new bin.  Because every substitution is an XOR on a 2-bit
+// code (or "becomes N"), the mutated window is old_kmer ^ (the XORs of the edits inside the window) -- the
+// staged copy of the sequence is never modified -- and an N edit simply invalidates the window.  After the
+// view's row has been written the moves are undone (replayed from an LDS list when it fits).
+// The sequence is staged in LDS one "super-chunk" (sc_slots slots + a halo slot of history) at a time;
+// lanes own 16-base words (a 10 kbp sequence is 9.8 rounds of 64 lanes, not 2.4 rounds of 4096 bases);
+// invalid windows go to garbage bins instead of being branched around; the epilogue divides by
+// multiplying with the row's correctly rounded reciprocal plus one FMA correction (Markstein; verified
+// bit-identical to float32(float64 division) for all 1 <= c <= S < 2^24 by tools/markstein_check.c).
+// =====================================================================================================
+constexpr int V2_LIST_CAP = 768;   // (edit, window) pairs recorded per view for a replay-undo
+constexpr int V2_EDIT_CAP = 192;   // edits of a view preloaded into LDS
+constexpr int V2_WAVES = 4;        // wavefronts per sequence
+
+template <int K>
+struct V2 {
+    static constexpr int NT = 64 * V2_WAVES;   // threads (V2_WAVES wavefronts) that share one sequence and one LDS histogram
+    static constexpr int F = 1 << (2 * K);
+    static constexpr uint32_t KM = (1u << (2 * K)) - 1u;
+    static constexpr uint32_t VM = (1u << K) - 1u;
+
+    // (previous word : word D) of the staged codes and the matching 32 invalid bits
+    static __device__ __forceinline__ void fetch(const uint32_t *cod, const uint32_t *msk, int D, uint64_t &w, uint32_t &M)
+    {
+        w = ((uint64_t)cod[D - 1] << 32) | cod[D];
+        const uint32_t m0 = msk[(D >> 1) - 1], m1 = msk[D >> 1];
+        M = (D & 1) ? m1 : (uint32_t)((((uint64_t)m0 << 32) | m1) >> 16);
+    }
+
+    // global -> LDS: slots [sc_first - 1, sc_first + nloc); LDS slot 0 is the halo (history of 64 bases)
+    static __device__ __forceinline__ void stage(const VecArgs &a, int64_t slot0, int64_t sc_first, int nloc, uint32_t *cod,
+                                                 uint32_t *msk, int lane)
+    {
+        __syncthreads();
+        for (int i = lane; i < nloc + 1; i += NT) {
+            const int64_t g = sc_first - 1 + i;
+            uint4 c = make_uint4(0u, 0u, 0u, 0u);
+            uint2 m = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+            if (g >= 0) { c = a.codes[slot0 + g]; m = a.mask[slot0 + g]; }
+            *(uint4 *)(cod + i * 4) = c;
+            *(uint2 *)(msk + i * 2) = m;
+        }
+        __syncthreads();
+    }
+
+    // first edit index in [0, ne) whose position is >= pos (edits sorted); wave-uniform
+    template <typename EP>
+    static __device__ __forceinline__ int lower_bound(EP E, int ne, int64_t pos)
+    {
+        int lo = 0, hi = ne;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if ((int64_t)(E[mid] & 0x3FFFFFFFu) < pos) lo = mid + 1; else hi = mid;
+        }
+        return lo;
+    }
+
+    // One lane per (edit, window offset) pair.  Pair (e, t) is the window ending at w = p_e + t; it is owned by
+    // edit e iff w <= min(p_e + K - 1, p_{e+1} - 1) (the latest edit at or before w), and handled here iff it ends
+    // inside the staged range [lo, hi) and inside the sequence.  old = the window as staged; new = old ^ (XORs of
+    // all edits inside the window), invalid if one of them is an N edit.  hist[old] += s_old, hist[new] += s_new.
+    template <bool REC, typename EP>
+    static __device__ __forceinline__ int pair_pass(EP E, int ne, int i0, int64_t lo, int64_t hi, int64_t L, const uint32_t *cod,
+                                                    const uint32_t *msk, uint32_t *hist, uint16_t *list_old, uint16_t *list_new,
+                                                    uint32_t s_old, uint32_t s_new, int lane)
+    {
+        int dwin = 0;
+        const int npairs = (ne - i0) * K;
+        for (int q0 = 0; q0 < npairs; q0 += NT) {
+            const int q = q0 + lane;
+            bool inside = false;
+            uint32_t ko = 0xFFFFu, kn = 0xFFFFu;
+            if (q < npairs) {
+                const int ei = i0 + q / K, t = q % K;
+                const uint32_t ed = E[ei];
+                const int64_t p = (int64_t)(ed & 0x3FFFFFFFu);
+                inside = p < hi;
+                int64_t last = p + K - 1;
+                if (ei + 1 < ne) { const int64_t nx = (int64_t)(E[ei + 1] & 0x3FFFFFFFu) - 1; if (nx < last) last = nx; }
+                if (last > L - 1) last = L - 1;
+                if (last > hi - 1) last = hi - 1;
+                const int64_t w = p + t;
+                if (w <= last && w >= lo) {
+                    const uint32_t rel = (uint32_t)(w - lo) + 64u;
+                    const int D = (int)(rel >> 4), j = (int)(rel & 15u);
+                    uint64_t ww; uint32_t M;
+                    fetch(cod, msk, D, ww, M);
+                    if (((M >> (15 - j)) & VM) == 0u) {
+                        ko = (uint32_t)(ww >> (30 - 2 * j)) & KM;
+                        uint32_t xm = (ed >> 30) << (2 * t);
+                        bool dead = (ed >> 30) == 0u;
+                        for (int i = ei - 1; i >= 0; --i) {          // earlier edits that also lie inside this window (rare)
+                            const uint32_t e2 = E[i];
+                            const int64_t d = w - (int64_t)(e2 & 0x3FFFFFFFu);
+                            if (d >= K) break;
+                            dead |= (e2 >> 30) == 0u;
+                            xm ^= (e2 >> 30) << (2 * (int)d);
+                        }
+                        kn = dead ? 0xFFFFu : (ko ^ xm);
+                    }
+                }
+            }
+            if (REC) { if (q < npairs && q < V2_LIST_CAP) { list_old[q] = (uint16_t)ko; list_new[q] = (uint16_t)kn; } }
+            if (ko != kn) {
+                if (ko != 0xFFFFu) { atomicAdd(&hist[ko], s_old); --dwin; }
+                if (kn != 0xFFFFu) { atomicAdd(&hist[kn], s_new); ++dwin; }
+            }
+            if (__ballot(inside) == 0ull) break;      // sorted: every later edit lies beyond this super-chunk (per wave)
+        }
+        __syncthreads();
+        return dwin;
+    }
+
+    static __device__ __forceinline__ void replay(int npairs, uint32_t *hist, const uint16_t *list_old, const uint16_t *list_new, int lane)
+    {
+        for (int q = lane; q < npairs; q += NT) {
+            const uint32_t o = list_old[q], nw = list_new[q];
+            if (o != nw) {
+                if (nw != 0xFFFFu) atomicAdd(&hist[nw], 0xFFFFFFFFu);
+                if (o != 0xFFFFu) atomicAdd(&hist[o], 1u);
+            }
+        }
+        __syncthreads();
+    }
+
+    // count every window ending in the staged super-chunk (nloc slots = 4*nloc words)
+    static __device__ __forceinline__ uint32_t count_all(const uint32_t *cod, const uint32_t *msk, int nloc, uint32_t *hist, int lane)
+    {
+        uint32_t cnt = 0;
+        const int nd = nloc * 4;
+        for (int d0 = 0; d0 < nd; d0 += NT) {
+            const int d = d0 + lane;
+            if (d < nd) {
+                uint64_t w; uint32_t M;
+                fetch(cod, msk, 4 + d, w, M);
+                uint32_t inv = M;
+#pragma unroll
+                for (int t = 1; t < K; ++t) inv |= (M >> t);
+                inv &= 0xFFFFu;
+                if (__ballot(inv != 0u) == 0ull) {               // uniform over the active lanes
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) atomicAdd(&hist[(uint32_t)(w >> (30 - 2 * j)) & KM], 1u);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) {               // invalid windows land in a garbage bin past the histogram
+                        const uint32_t km = (uint32_t)(w >> (30 - 2 * j)) & KM;
+                        atomicAdd(&hist[((inv >> (15 - j)) & 1u) ? (uint32_t)F + (lane & 3) : km], 1u);
+                    }
+                }
+                cnt += 16u - (uint32_t)__popc(inv);
+            }
+        }
+        __syncthreads();
+        return cnt;
+    }
+
+    // all delta work of one view in one direction (forward: s_old = -1, s_new = +1)
+    template <bool REC, typename EP>
+    static __device__ __forceinline__ int view_pass(const VecArgs &a, EP E, int ne, int64_t slot0, int64_t nslots, int64_t nsc, int SC,
+                                                    int64_t L, uint32_t *cod, uint32_t *msk, uint32_t *hist, uint16_t *list_old,
+                                                    uint16_t *list_new, uint32_t s_old, uint32_t s_new, int lane)
+    {
+        if (nsc == 1) return pair_pass<REC>(E, ne, 0, 0, nslots * 64, L, cod, msk, hist, list_old, list_new, s_old, s_new, lane);
+        int dwin = 0;
+        for (int64_t sc = 0; sc < nsc; ++sc) {
+            const int nloc = (int)((nslots - sc * SC) < SC ? (nslots - sc * SC) : SC);
+            const int64_t lo = sc * SC * 64, hi = lo + (int64_t)nloc * 64;
+            stage(a, slot0, sc * SC, nloc, cod, msk, lane);
+            const int i0 = lower_bound(E, ne, lo - (K - 1));
+            dwin += pair_pass<false>(E, ne, i0, lo, hi, L, cod, msk, hist, list_old, list_new, s_old, s_new, lane);
+        }
+        return dwin;
+    }
+};
+
+template <int K>
+__global__ __launch_bounds__(64 * V2_WAVES) void vectorise2_kernel(VecArgs a)
+{
+    using T = V2<K>;
+    constexpr int F = T::F;
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    uint32_t *hist = lds;                       // F bins + 4 garbage bins
+    uint32_t *cod = lds + F + 4;                // (SC + 1) slots x 4 words, slot 0 = halo
+    const int SC = a.sc_slots;
+    uint32_t *msk = cod + (SC + 1) * 4;         // (SC + 1) slots x 2 words
+    uint32_t *ed_lds = msk + (SC + 1) * 2;      // V2_EDIT_CAP edits of the current view
+    uint16_t *list_old = (uint16_t *)(ed_lds + V2_EDIT_CAP);
+    uint16_t *list_new = list_old + V2_LIST_CAP;
+    int64_t *red = (int64_t *)(list_old + 2 * V2_LIST_CAP);   // V2_WAVES partial sums
+    constexpr int NT = T::NT;
+    const int lane = threadIdx.x;                             // thread index within the sequence's workgroup
+    auto block_sum = [&](int64_t v) -> int64_t {
+        v = wave_sum_i64(v);
+        __syncthreads();
+        if ((lane & 63) == 0) red[lane >> 6] = v;
+        __syncthreads();
+        int64_t t = 0;
+#pragma unroll
+        for (int w = 0; w < V2_WAVES; ++w) t += red[w];
+        return t;
+    };
+    const int64_t row_len = (a.mode == IDL_MODE_CANONICAL) ? ((K % 2 == 0) ? (F + (1 << K)) / 2 : F / 2) : F;
+    const uint32_t iv = (a.init == IDL_INIT_ONE) ? 1u : 0u;
+
+    for (int64_t s = blockIdx.x; s < a.n; s += gridDim.x) {
+        const int64_t slot0 = a.slot_off[s];
+        const int64_t nslots = a.slot_off[s + 1] - slot0;
+        const int64_t L = a.lengths[s];
+        const int64_t nsc = (nslots + SC - 1) / SC;
+
+        for (int i = lane; i < (F + 4) / 4; i += NT) *(uint4 *)(hist + i * 4) = make_uint4(iv, iv, iv, iv);
+
+        // ---------------- H0: the un-mutated sequence, counted once (sc 0 last, so a short sequence stays staged)
+        uint32_t cnt0 = 0;
+        for (int64_t sc = nsc - 1; sc >= 0; --sc) {
+            const int nloc = (int)((nslots - sc * SC) < SC ? (nslots - sc * SC) : SC);
+            T::stage(a, slot0, sc * SC, nloc, cod, msk, lane);
+            cnt0 += T::count_all(cod, msk, nloc, hist, lane);
+        }
+        const int64_t windows0 = block_sum((int64_t)cnt0);
+
+        // the view with the most edits goes last: nothing has to be undone (or recorded) after the last view
+        int vlast = a.n_views - 1;
+        if (a.edits != nullptr) {
+            int64_t best = -1;
+            for (int v = 0; v < a.n_views; ++v) {
+                const int64_t c = a.edit_off[(int64_t)v * a.n + s + 1] - a.edit_off[(int64_t)v * a.n + s];
+                if (c > best) { best = c; vlast = v; }
+            }
+        }
+        for (int vi = 0; vi < a.n_views; ++vi) {
+            const int v = (vi == a.n_views - 1) ? vlast : (vi < vlast ? vi : vi + 1);
+            const int64_t out_base = (int64_t)v * a.view_stride + s * row_len;
+            int64_t eb = 0, ee = 0;
+            if (a.edits != nullptr) { eb = a.edit_off[(int64_t)v * a.n + s]; ee = a.edit_off[(int64_t)v * a.n + s + 1]; }
+            const int ne = (int)(ee - eb);
+            const bool mutated = ne > 0 && nsc > 0;
+            const bool in_lds = ne <= V2_EDIT_CAP;      // edits preloaded into LDS
+            const bool rec = in_lds && nsc == 1 && ne * K <= V2_LIST_CAP && vi + 1 < a.n_views;
+            const uint32_t *eg = a.edits + eb;
+
+            // ---------------- forward: hist = H0 - (old windows) + (new windows)
+            int dwin = 0;
+            if (mutated) {
+                if (in_lds) {
+                    __syncthreads();
+                    for (int i = lane; i < ne; i += NT) ed_lds[i] = eg[i];
+                    __syncthreads();
+                    if (rec) dwin = T::template view_pass<true>(a, (const uint32_t *)ed_lds, ne, slot0, nslots, nsc, SC, L, cod, msk, hist, list_old, list_new, 0xFFFFFFFFu, 1u, lane);
+                    else dwin = T::template view_pass<false>(a, (const uint32_t *)ed_lds, ne, slot0, nslots, nsc, SC, L, cod, msk, hist, list_old, list_new, 0xFFFFFFFFu, 1u, lane);
+                } else {
+                    dwin = T::template view_pass<false>(a, eg, ne, slot0, nslots, nsc, SC, L, cod, msk, hist, list_old, list_new, 0xFFFFFFFFu, 1u, lane);
+                }
+            }
+            const int64_t windows = windows0 + block_sum((int64_t)dwin);
+            __syncthreads();
+
+            // ---------------- epilogue: one pass over the histogram, one coalesced global write
+            if (a.mode == IDL_MODE_CANONICAL) {
+              if (lane < 64) {          // ranks come from a running ballot prefix: one wavefront walks the bins in order
+                int64_t part = 0;
+                if (a.out_kind != IDL_OUT_COUNTS_I32) {
+                    for (int b0 = 0; b0 < F; b0 += 64) {
+                        const uint32_t b = b0 + lane;
+                        if (b < (uint32_t)F) {
+                            const uint32_t rc = revcomp<K>(b);
+                            if (b <= rc) part += (int32_t)(hist[b] + hist[rc]) / 2;
+                        }
+                    }
+                }
+                const int64_t S = wave_sum_i64(part);
+                int rank0 = 0;
+                for (int b0 = 0; b0 < F; b0 += 64) {
+                    const uint32_t b = b0 + lane;
+                    bool canon = false;
+                    int32_t val = 0;
+                    if (b < (uint32_t)F) {
+                        const uint32_t rc = revcomp<K>(b);
+                        canon = b <= rc;
+                        if (canon) val = (int32_t)(hist[b] + hist[rc]) / 2;
+                    }
+                    const uint64_t bal = __ballot(canon);
+                    if (canon) {
+                        const int64_t o = out_base + rank0 + __popcll(bal & ((1ull << lane) - 1ull));
+                        if (a.out_kind == IDL_OUT_COUNTS_I32) ((int32_t *)a.out)[o] = val;
+                        else if (a.out_kind == IDL_OUT_FREQ_F64) ((double *)a.out)[o] = (double)val / (double)S;
+                        else ((float *)a.out)[o] = (float)((double)val / (double)S);
+                    }
+                    rank0 += __popcll(bal);
+                }
+              }
+            } else {
+                const int64_t S = windows + (iv ? (int64_t)F : 0);
+                const bool small = S < (1ll << 24);   // ints exact in float32; Markstein division == float32(float64 division)
+                const float Sf = (float)S, rS = 1.0f / Sf;
+                const double Sd = (double)S;
+                if (a.mode == IDL_MODE_KMER && F >= 256 && a.out_kind != IDL_OUT_FREQ_F64) {
+                    for (int i4 = lane; i4 < F / 4; i4 += NT) {
+                        const uint4 h = *(const uint4 *)(hist + i4 * 4);
+                        if (a.out_kind == IDL_OUT_COUNTS_I32) {
+                            *(uint4 *)((uint32_t *)a.out + out_base + i4 * 4) = h;
+                        } else {
+                            float4 f;
+                            if (small) {
+                                const float c0 = (float)h.x, c1 = (float)h.y, c2 = (float)h.z, c3 = (float)h.w;
+                                const float q0 = c0 * rS, q1 = c1 * rS, q2 = c2 * rS, q3 = c3 * rS;
+                                f.x = __builtin_fmaf(__builtin_fmaf(-q0, Sf, c0), rS, q0);
+                                f.y = __builtin_fmaf(__builtin_fmaf(-q1, Sf, c1), rS, q1);
+                                f.z = __builtin_fmaf(__builtin_fmaf(-q2, Sf, c2), rS, q2);
+                                f.w = __builtin_fmaf(__builtin_fmaf(-q3, Sf, c3), rS, q3);
+                            } else {
+                                f.x = (float)((double)h.x / Sd); f.y = (float)((double)h.y / Sd);
+                                f.z = (float)((double)h.z / Sd); f.w = (float)((double)h.w / Sd);
+                            }
+                            *(float4 *)((float *)a.out + out_base + i4 * 4) = f;
+                        }
+                    }
+                } else {
+                    for (int i = lane; i < F; i += NT) {
+                        const uint32_t src = (a.mode == IDL_MODE_CGR) ? cgr_pixel_to_kmer<K>((uint32_t)i) : (uint32_t)i;
+                        const uint32_t h = hist[src];
+                        if (a.out_kind == IDL_OUT_COUNTS_I32) ((uint32_t *)a.out)[out_base + i] = h;
+                        else if (a.out_kind == IDL_OUT_FREQ_F64) ((double *)a.out)[out_base + i] = (double)h / Sd;
+                        else ((float *)a.out)[out_base + i] = small ? (float)h / Sf : (float)((double)h / Sd);
+                    }
+                }
+            }
+            __syncthreads();
+
+            // ---------------- undo: hist back to H0 for the next view (not needed after the last one)
+            if (mutated && vi + 1 < a.n_views) {
+                if (rec) T::replay(ne * K, hist, list_old, list_new, lane);
+                else if (in_lds) (void)T::template view_pass<false>(a, (const uint32_t *)ed_lds, ne, slot0, nslots, nsc, SC, L, cod, msk, hist, list_old, list_new, 1u, 0xFFFFFFFFu, lane);
+                else (void)T::template view_pass<false>(a, eg, ne, slot0, nslots, nsc, SC, L, cod, msk, hist, list_old, list_new, 1u, 0xFFFFFFFFu, lane);
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // collapse a host-provided histogram (idl_kmer_rev_comp): one wave, counts modified in place like utils.py:216-217
 template <int K>
 __global__ __launch_bounds__(64) void collapse_kernel(int32_t *counts, int32_t *out)
@@ -292,24 +639,28 @@ __global__ __launch_bounds__(64) void collapse_kernel(int32_t *counts, int32_t *
 }
 
 template <int K>
-int launch_vectorise(const VecArgs &a, const idl::DeviceInfo &di, hipStream_t st)
+int launch_vectorise(const VecArgs &a_in, const idl::DeviceInfo &di, hipStream_t st)
 {
     constexpr int F = 1 << (2 * K);
-    const size_t lds = (size_t)(F + STAGE_DWORDS) * 4;
+    VecArgs a = a_in;
+    const bool v1 = (a.init == IDL_INIT_FROM_OUT);      // accumulate-on-top needs a per-view start: single-pass kernel
+    int sc = 160;                                       // 10240 bases staged at a time (cfg2's 10 kbp in one super-chunk)
+    if (const char *e = getenv("IDELUCS_SC_SLOTS")) { const int t = atoi(e); if (t >= 1 && t <= 4096) sc = t; }
+    a.sc_slots = sc;
+    const size_t lds = v1 ? (size_t)(F + STAGE_DWORDS) * 4 : (size_t)(F + 4 + (sc + 1) * 6 + V2_EDIT_CAP + V2_LIST_CAP + 2 * V2_WAVES) * 4;
     if ((int)lds > di.max_dyn_lds) {
         idl::set_error("k=%d needs %zu bytes of LDS per wavefront; device allows %d", K, lds, di.max_dyn_lds);
         return IDL_ERR_ARG;
     }
-    if (lds > 64 * 1024) {
-        IDL_HIP_TRY(hipFuncSetAttribute((const void *)vectorise_kernel<K>,
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    }
+    const void *fn = v1 ? (const void *)vectorise_kernel<K> : (const void *)vectorise2_kernel<K>;
+    if (lds > 64 * 1024) IDL_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int per_cu = di.lds_per_cu / (int)lds;
     if (per_cu > 16) per_cu = 16;
     if (per_cu < 1) per_cu = 1;
     int64_t grid = (int64_t)di.cus * per_cu;
     if (grid > a.n) grid = a.n;
-    hipLaunchKernelGGL(vectorise_kernel<K>, dim3((unsigned)grid), dim3(64), lds, st, a);
+    if (v1) hipLaunchKernelGGL(vectorise_kernel<K>, dim3((unsigned)grid), dim3(64), lds, st, a);
+    else hipLaunchKernelGGL(vectorise2_kernel<K>, dim3((unsigned)grid), dim3(64 * V2_WAVES), lds, st, a);
     IDL_HIP_TRY(hipGetLastError());
     return IDL_OK;
 }

@@ -139,9 +139,14 @@ def _pack_batch(seqs):
     return ff
 
 
-def test_random_batches_with_edits_vs_oracle(gpu):
-    """Multi-view launch with explicit substitution edits (all four ops, chunk boundaries, duplicates)."""
+@pytest.mark.parametrize("sc_slots", [None, "1", "2", "5"])
+def test_random_batches_with_edits_vs_oracle(gpu, monkeypatch, sc_slots):
+    """Multi-view launch with explicit substitution edits (all four ops, chunk boundaries, duplicates).
+    sc_slots shrinks the LDS super-chunk of the delta-view kernel so that halo / boundary handling is
+    exercised on small inputs."""
     import torch
+    if sc_slots is not None:
+        monkeypatch.setenv("IDELUCS_SC_SLOTS", sc_slots)
     from idelucs_amd import _lib, utils as U
     rng = np.random.default_rng(2024)
     seqs = _random_batch(rng, 40, 0, 300) + _random_batch(rng, 12, 3900, 4300) + _random_batch(rng, 6, 8000, 13000, 0.0) \
@@ -175,6 +180,48 @@ def test_random_batches_with_edits_vs_oracle(gpu):
                 c = np.ones(4 ** k, np.int32); O.kmer_counts(mutated[v][i], k, c)
                 c = O.kmer_rev_comp(c, k)
                 assert np.array_equal(got[v, i], c / np.sum(c)), (k, v, i)
+
+
+@pytest.mark.parametrize("sc_slots", [None, "1", "3"])
+def test_adversarial_edits_at_boundaries(gpu, monkeypatch, sc_slots):
+    """Edits packed around slot / super-chunk boundaries, runs of adjacent edits (overlapping windows),
+    duplicates, N edits on top of XOR edits, edits in the last k bases and past-the-end positions."""
+    import torch
+    from idelucs_amd import _lib, utils as U
+    if sc_slots is not None:
+        monkeypatch.setenv("IDELUCS_SC_SLOTS", sc_slots)
+    rng = np.random.default_rng(77)
+    seqs = _random_batch(rng, 6, 380, 400, 0.01) + _random_batch(rng, 2, 64, 64, 0.0) + _random_batch(rng, 2, 128, 129, 0.0) \
+        + _random_batch(rng, 2, 17000, 17010, 0.001)
+    n, P = len(seqs), 3
+    edits, counts, mutated = [], [], [[None] * n for _ in range(P)]
+    for v in range(P):
+        for i, s in enumerate(seqs):
+            L = len(s)
+            cand = []
+            for b in (0, 63, 64, 65, 127, 128, 191, 192, 193, 16383, 16384, 16385, L - 1, L - 2, L - 6, L - 7):
+                cand += [b + d for d in range(-2, 3)]
+            cand += list(range(100, 100 + 12))                     # a dense run: every window overlaps several edits
+            cand += [150, 150, 150, 151]                            # duplicates
+            pos = np.array(sorted(c for c in cand if 0 <= c < L), np.uint32)
+            if v == 0:
+                pos = pos[::3]
+            op = rng.integers(0, 4, pos.size).astype(np.uint32)
+            e = pos | (op << np.uint32(30))
+            edits.append(e); counts.append(e.size)
+            mutated[v][i] = O.apply_edits(s.tobytes(), e)
+    edit_off = np.zeros(P * n + 1, np.int64); np.cumsum(counts, out=edit_off[1:])
+    dev = torch.device("cuda")
+    din = U._DeviceInput(_pack_batch(seqs), dev)
+    d_e = torch.from_numpy(np.concatenate(edits).view(np.int32)).to(dev); d_eo = torch.from_numpy(edit_off).to(dev)
+    for k in (1, 2, 4, 6, 7):
+        got = U._vectorise(din, k, _lib.MODE_KMER, _lib.INIT_ONE, _lib.OUT_COUNTS_I32, P, d_e, d_eo).cpu().numpy()
+        f32 = U._vectorise(din, k, _lib.MODE_KMER, _lib.INIT_ONE, _lib.OUT_FREQ_F32, P, d_e, d_eo).cpu().numpy()
+        for v in range(P):
+            for i in range(n):
+                want = np.ones(4 ** k, np.int32); O.kmer_counts(mutated[v][i], k, want)
+                assert np.array_equal(got[v, i], want), (k, v, i, len(seqs[i]))
+                assert np.array_equal(f32[v, i], (want / np.sum(want)).astype(np.float32)), (k, v, i)
 
 
 def _write_subset(tmp_path, n):

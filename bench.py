@@ -57,6 +57,7 @@ def synth_packed(n, L, dev, seed=12345):
     d.n, d.codes, d.mask = n, codes, mask.view(-1)
     d.slot_off = torch.arange(0, (n + 1) * slots, slots, dtype=torch.int64, device=dev)
     d.lengths = torch.full((n,), L, dtype=torch.int64, device=dev)
+    d.max_len = L
     return d
 
 

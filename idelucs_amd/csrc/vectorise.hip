@@ -34,6 +34,7 @@ struct VecArgs {
     void *out;
     int64_t view_stride;
     int sc_slots;   // v2: slots (64 bases) staged in LDS at a time
+    int64_t max_len; // upper bound on the sequence lengths, 0 = unknown
 };
 
 constexpr int STAGE_DWORDS = 256 + 128;  // 64 lanes x (4 code words + 2 mask words)
@@ -287,12 +288,25 @@ constexpr int V2_LIST_CAP = 768;   // (edit, window) pairs recorded per view for
 constexpr int V2_EDIT_CAP = 192;   // edits of a view preloaded into LDS
 constexpr int V2_WAVES = 4;        // wavefronts per sequence
 
-template <int K>
+// B16: two 16-bit bins per LDS word (valid while every count stays < 65536, i.e. sequences shorter than ~65 kbp):
+// half the histogram footprint -> more sequences resident per CU.
+template <int K, bool B16>
 struct V2 {
     static constexpr int NT = 64 * V2_WAVES;   // threads (V2_WAVES wavefronts) that share one sequence and one LDS histogram
     static constexpr int F = 1 << (2 * K);
     static constexpr uint32_t KM = (1u << (2 * K)) - 1u;
     static constexpr uint32_t VM = (1u << K) - 1u;
+    static constexpr int HD = B16 ? (F / 2 + 4) & ~3 : F + 4;      // histogram words incl. 4 garbage bins (kept a multiple of 4)
+
+    static __device__ __forceinline__ void bump(uint32_t *hist, uint32_t bin, uint32_t sign)   // sign = 1 or 0xFFFFFFFF (-1)
+    {
+        if (B16) atomicAdd(&hist[bin >> 1], sign << (16u * (bin & 1u)));
+        else atomicAdd(&hist[bin], sign);
+    }
+    static __device__ __forceinline__ uint32_t get(const uint32_t *hist, uint32_t bin)
+    {
+        return B16 ? (hist[bin >> 1] >> (16u * (bin & 1u))) & 0xFFFFu : hist[bin];
+    }
 
     // (previous word : word D) of the staged codes and the matching 32 invalid bits
     static __device__ __forceinline__ void fetch(const uint32_t *cod, const uint32_t *msk, int D, uint64_t &w, uint32_t &M)
@@ -377,8 +391,8 @@ struct V2 {
             }
             if (REC) { if (q < npairs && q < V2_LIST_CAP) { list_old[q] = (uint16_t)ko; list_new[q] = (uint16_t)kn; } }
             if (ko != kn) {
-                if (ko != 0xFFFFu) { atomicAdd(&hist[ko], s_old); --dwin; }
-                if (kn != 0xFFFFu) { atomicAdd(&hist[kn], s_new); ++dwin; }
+                if (ko != 0xFFFFu) { bump(hist, ko, s_old); --dwin; }
+                if (kn != 0xFFFFu) { bump(hist, kn, s_new); ++dwin; }
             }
             if (__ballot(inside) == 0ull) break;      // sorted: every later edit lies beyond this super-chunk (per wave)
         }
@@ -391,8 +405,8 @@ struct V2 {
         for (int q = lane; q < npairs; q += NT) {
             const uint32_t o = list_old[q], nw = list_new[q];
             if (o != nw) {
-                if (nw != 0xFFFFu) atomicAdd(&hist[nw], 0xFFFFFFFFu);
-                if (o != 0xFFFFu) atomicAdd(&hist[o], 1u);
+                if (nw != 0xFFFFu) bump(hist, nw, 0xFFFFFFFFu);
+                if (o != 0xFFFFu) bump(hist, o, 1u);
             }
         }
         __syncthreads();
@@ -414,12 +428,12 @@ struct V2 {
                 inv &= 0xFFFFu;
                 if (__ballot(inv != 0u) == 0ull) {               // uniform over the active lanes
 #pragma unroll
-                    for (int j = 0; j < 16; ++j) atomicAdd(&hist[(uint32_t)(w >> (30 - 2 * j)) & KM], 1u);
+                    for (int j = 0; j < 16; ++j) bump(hist, (uint32_t)(w >> (30 - 2 * j)) & KM, 1u);
                 } else {
 #pragma unroll
                     for (int j = 0; j < 16; ++j) {               // invalid windows land in a garbage bin past the histogram
                         const uint32_t km = (uint32_t)(w >> (30 - 2 * j)) & KM;
-                        atomicAdd(&hist[((inv >> (15 - j)) & 1u) ? (uint32_t)F + (lane & 3) : km], 1u);
+                        bump(hist, ((inv >> (15 - j)) & 1u) ? (uint32_t)F + (lane & 3) : km, 1u);
                     }
                 }
                 cnt += 16u - (uint32_t)__popc(inv);
@@ -448,20 +462,22 @@ struct V2 {
     }
 };
 
-template <int K>
-__global__ __launch_bounds__(64 * V2_WAVES) void vectorise2_kernel(VecArgs a)
+// second launch-bound argument = waves per SIMD wanted: 8 workgroups/CU with 16-bit bins (16 KB LDS each), 6 with 32-bit bins
+template <int K, bool B16>
+__global__ __launch_bounds__(64 * V2_WAVES, B16 ? 8 : 6) void vectorise2_kernel(VecArgs a)
 {
-    using T = V2<K>;
+    using T = V2<K, B16>;
     constexpr int F = T::F;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    uint32_t *hist = lds;                       // F bins + 4 garbage bins
-    uint32_t *cod = lds + F + 4;                // (SC + 1) slots x 4 words, slot 0 = halo
+    uint32_t *hist = lds;                       // F bins + 4 garbage bins (32- or 16-bit)
+    uint32_t *cod = lds + T::HD;                // (SC + 1) slots x 4 words, slot 0 = halo
     const int SC = a.sc_slots;
     uint32_t *msk = cod + (SC + 1) * 4;         // (SC + 1) slots x 2 words
     uint32_t *ed_lds = msk + (SC + 1) * 2;      // V2_EDIT_CAP edits of the current view
     uint16_t *list_old = (uint16_t *)(ed_lds + V2_EDIT_CAP);
     uint16_t *list_new = list_old + V2_LIST_CAP;
     int64_t *red = (int64_t *)(list_old + 2 * V2_LIST_CAP);   // V2_WAVES partial sums
+    int64_t *vrange = red + V2_WAVES;                         // [2 * n_views] edit ranges (begin, end) of the views
     constexpr int NT = T::NT;
     const int lane = threadIdx.x;                             // thread index within the sequence's workgroup
     auto block_sum = [&](int64_t v) -> int64_t {
@@ -476,6 +492,7 @@ __global__ __launch_bounds__(64 * V2_WAVES) void vectorise2_kernel(VecArgs a)
     };
     const int64_t row_len = (a.mode == IDL_MODE_CANONICAL) ? ((K % 2 == 0) ? (F + (1 << K)) / 2 : F / 2) : F;
     const uint32_t iv = (a.init == IDL_INIT_ONE) ? 1u : 0u;
+    const uint32_t ivw = B16 ? iv * 0x00010001u : iv;
 
     for (int64_t s = blockIdx.x; s < a.n; s += gridDim.x) {
         const int64_t slot0 = a.slot_off[s];
@@ -483,7 +500,7 @@ __global__ __launch_bounds__(64 * V2_WAVES) void vectorise2_kernel(VecArgs a)
         const int64_t L = a.lengths[s];
         const int64_t nsc = (nslots + SC - 1) / SC;
 
-        for (int i = lane; i < (F + 4) / 4; i += NT) *(uint4 *)(hist + i * 4) = make_uint4(iv, iv, iv, iv);
+        for (int i = lane; i < T::HD / 4; i += NT) *(uint4 *)(hist + i * 4) = make_uint4(ivw, ivw, ivw, ivw);
 
         // ---------------- H0: the un-mutated sequence, counted once (sc 0 last, so a short sequence stays staged)
         uint32_t cnt0 = 0;
@@ -494,20 +511,40 @@ __global__ __launch_bounds__(64 * V2_WAVES) void vectorise2_kernel(VecArgs a)
         }
         const int64_t windows0 = block_sum((int64_t)cnt0);
 
+        // the views' edit ranges, loaded once per sequence (one thread per view) while H0 is being counted
+        __syncthreads();
+        if (lane < a.n_views) {
+            int64_t b0 = 0, e0 = 0;
+            if (a.edits != nullptr) { b0 = a.edit_off[(int64_t)lane * a.n + s]; e0 = a.edit_off[(int64_t)lane * a.n + s + 1]; }
+            vrange[2 * lane] = b0;
+            vrange[2 * lane + 1] = e0;
+        }
+        __syncthreads();
         // the view with the most edits goes last: nothing has to be undone (or recorded) after the last view
         int vlast = a.n_views - 1;
-        if (a.edits != nullptr) {
+        {
             int64_t best = -1;
             for (int v = 0; v < a.n_views; ++v) {
-                const int64_t c = a.edit_off[(int64_t)v * a.n + s + 1] - a.edit_off[(int64_t)v * a.n + s];
+                const int64_t c = vrange[2 * v + 1] - vrange[2 * v];
                 if (c > best) { best = c; vlast = v; }
             }
         }
+        auto view_at = [&](int vi) -> int { return (vi == a.n_views - 1) ? vlast : (vi < vlast ? vi : vi + 1); };
+        // register prefetch of a view's edits (<= one per thread when the list fits the LDS cache)
+        uint32_t pre = 0u;
+        auto prefetch = [&](int vi) {
+            if (vi < a.n_views) {
+                const int v2 = view_at(vi);
+                const int64_t b2 = vrange[2 * v2], n2 = vrange[2 * v2 + 1] - b2;
+                if (n2 <= V2_EDIT_CAP && lane < n2) pre = a.edits[b2 + lane];
+            }
+        };
+        static_assert(V2_EDIT_CAP <= 64 * V2_WAVES, "one prefetched edit per thread");
+        prefetch(0);
         for (int vi = 0; vi < a.n_views; ++vi) {
-            const int v = (vi == a.n_views - 1) ? vlast : (vi < vlast ? vi : vi + 1);
+            const int v = view_at(vi);
             const int64_t out_base = (int64_t)v * a.view_stride + s * row_len;
-            int64_t eb = 0, ee = 0;
-            if (a.edits != nullptr) { eb = a.edit_off[(int64_t)v * a.n + s]; ee = a.edit_off[(int64_t)v * a.n + s + 1]; }
+            const int64_t eb = vrange[2 * v], ee = vrange[2 * v + 1];
             const int ne = (int)(ee - eb);
             const bool mutated = ne > 0 && nsc > 0;
             const bool in_lds = ne <= V2_EDIT_CAP;      // edits preloaded into LDS
@@ -519,7 +556,7 @@ __global__ __launch_bounds__(64 * V2_WAVES) void vectorise2_kernel(VecArgs a)
             if (mutated) {
                 if (in_lds) {
                     __syncthreads();
-                    for (int i = lane; i < ne; i += NT) ed_lds[i] = eg[i];
+                    if (lane < ne) ed_lds[lane] = pre;
                     __syncthreads();
                     if (rec) dwin = T::template view_pass<true>(a, (const uint32_t *)ed_lds, ne, slot0, nslots, nsc, SC, L, cod, msk, hist, list_old, list_new, 0xFFFFFFFFu, 1u, lane);
                     else dwin = T::template view_pass<false>(a, (const uint32_t *)ed_lds, ne, slot0, nslots, nsc, SC, L, cod, msk, hist, list_old, list_new, 0xFFFFFFFFu, 1u, lane);
@@ -527,6 +564,7 @@ __global__ __launch_bounds__(64 * V2_WAVES) void vectorise2_kernel(VecArgs a)
                     dwin = T::template view_pass<false>(a, eg, ne, slot0, nslots, nsc, SC, L, cod, msk, hist, list_old, list_new, 0xFFFFFFFFu, 1u, lane);
                 }
             }
+            prefetch(vi + 1);
             const int64_t windows = windows0 + block_sum((int64_t)dwin);
             __syncthreads();
 
@@ -539,7 +577,7 @@ __global__ __launch_bounds__(64 * V2_WAVES) void vectorise2_kernel(VecArgs a)
                         const uint32_t b = b0 + lane;
                         if (b < (uint32_t)F) {
                             const uint32_t rc = revcomp<K>(b);
-                            if (b <= rc) part += (int32_t)(hist[b] + hist[rc]) / 2;
+                            if (b <= rc) part += (int32_t)(T::get(hist, b) + T::get(hist, rc)) / 2;
                         }
                     }
                 }
@@ -552,7 +590,7 @@ __global__ __launch_bounds__(64 * V2_WAVES) void vectorise2_kernel(VecArgs a)
                     if (b < (uint32_t)F) {
                         const uint32_t rc = revcomp<K>(b);
                         canon = b <= rc;
-                        if (canon) val = (int32_t)(hist[b] + hist[rc]) / 2;
+                        if (canon) val = (int32_t)(T::get(hist, b) + T::get(hist, rc)) / 2;
                     }
                     const uint64_t bal = __ballot(canon);
                     if (canon) {
@@ -570,8 +608,7 @@ __global__ __launch_bounds__(64 * V2_WAVES) void vectorise2_kernel(VecArgs a)
                 const float Sf = (float)S, rS = 1.0f / Sf;
                 const double Sd = (double)S;
                 if (a.mode == IDL_MODE_KMER && F >= 256 && a.out_kind != IDL_OUT_FREQ_F64) {
-                    for (int i4 = lane; i4 < F / 4; i4 += NT) {
-                        const uint4 h = *(const uint4 *)(hist + i4 * 4);
+                    auto emit = [&](int i4, uint4 h) {         // four consecutive bins starting at 4*i4
                         if (a.out_kind == IDL_OUT_COUNTS_I32) {
                             *(uint4 *)((uint32_t *)a.out + out_base + i4 * 4) = h;
                         } else {
@@ -589,11 +626,20 @@ __global__ __launch_bounds__(64 * V2_WAVES) void vectorise2_kernel(VecArgs a)
                             }
                             *(float4 *)((float *)a.out + out_base + i4 * 4) = f;
                         }
+                    };
+                    if (B16) {
+                        for (int i8 = lane; i8 < F / 8; i8 += NT) {
+                            const uint4 h = *(const uint4 *)(hist + i8 * 4);
+                            emit(2 * i8, make_uint4(h.x & 0xFFFFu, h.x >> 16, h.y & 0xFFFFu, h.y >> 16));
+                            emit(2 * i8 + 1, make_uint4(h.z & 0xFFFFu, h.z >> 16, h.w & 0xFFFFu, h.w >> 16));
+                        }
+                    } else {
+                        for (int i4 = lane; i4 < F / 4; i4 += NT) emit(i4, *(const uint4 *)(hist + i4 * 4));
                     }
                 } else {
                     for (int i = lane; i < F; i += NT) {
                         const uint32_t src = (a.mode == IDL_MODE_CGR) ? cgr_pixel_to_kmer<K>((uint32_t)i) : (uint32_t)i;
-                        const uint32_t h = hist[src];
+                        const uint32_t h = T::get(hist, src);
                         if (a.out_kind == IDL_OUT_COUNTS_I32) ((uint32_t *)a.out)[out_base + i] = h;
                         else if (a.out_kind == IDL_OUT_FREQ_F64) ((double *)a.out)[out_base + i] = (double)h / Sd;
                         else ((float *)a.out)[out_base + i] = small ? (float)h / Sf : (float)((double)h / Sd);
@@ -647,20 +693,33 @@ int launch_vectorise(const VecArgs &a_in, const idl::DeviceInfo &di, hipStream_t
     int sc = 160;                                       // 10240 bases staged at a time (cfg2's 10 kbp in one super-chunk)
     if (const char *e = getenv("IDELUCS_SC_SLOTS")) { const int t = atoi(e); if (t >= 1 && t <= 4096) sc = t; }
     a.sc_slots = sc;
-    const size_t lds = v1 ? (size_t)(F + STAGE_DWORDS) * 4 : (size_t)(F + 4 + (sc + 1) * 6 + V2_EDIT_CAP + V2_LIST_CAP + 2 * V2_WAVES) * 4;
+    // 16-bit bins are possible while no count can reach 65536 (count <= max_len + 1).  Measured on MI355X (cfg2): 8
+    // workgroups/CU with 16-bit bins (64 VGPRs, 80 B/lane of spill) run 2.16 ms, 6 workgroups/CU with 32-bit bins
+    // (79 VGPRs) 1.98 ms -- so 32-bit is the default and 16-bit an opt-in experiment (IDELUCS_BINS=16).
+    bool b16 = false;
+    if (const char *e = getenv("IDELUCS_BINS")) b16 = atoi(e) == 16 && !v1 && a.max_len > 0 && a.max_len <= 65000;
+    const int hd = b16 ? (F / 2 + 4) & ~3 : F + 4;
+    const size_t lds = v1 ? (size_t)(F + STAGE_DWORDS) * 4
+                          : (size_t)(hd + (sc + 1) * 6 + V2_EDIT_CAP + V2_LIST_CAP + 2 * V2_WAVES + 4 * a.n_views) * 4;
     if ((int)lds > di.max_dyn_lds) {
         idl::set_error("k=%d needs %zu bytes of LDS per wavefront; device allows %d", K, lds, di.max_dyn_lds);
         return IDL_ERR_ARG;
     }
-    const void *fn = v1 ? (const void *)vectorise_kernel<K> : (const void *)vectorise2_kernel<K>;
+    const void *fn = v1 ? (const void *)vectorise_kernel<K>
+                        : (b16 ? (const void *)vectorise2_kernel<K, true> : (const void *)vectorise2_kernel<K, false>);
     if (lds > 64 * 1024) IDL_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    int per_cu = di.lds_per_cu / (int)lds;
+    int per_cu = 0;
+    IDL_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, v1 ? 64 : 64 * V2_WAVES, lds));
+    if (const char *e = getenv("IDELUCS_WG_PER_CU")) { const int t = atoi(e); if (t >= 1 && t <= 32) per_cu = t; }
     if (per_cu > 16) per_cu = 16;
     if (per_cu < 1) per_cu = 1;
+    if (getenv("IDELUCS_DEBUG"))
+        fprintf(stderr, "[idl] vectorise k=%d %s lds=%zu B -> %d workgroups/CU\n", K, v1 ? "v1" : (b16 ? "v2/16-bit bins" : "v2/32-bit bins"), lds, per_cu);
     int64_t grid = (int64_t)di.cus * per_cu;
     if (grid > a.n) grid = a.n;
     if (v1) hipLaunchKernelGGL(vectorise_kernel<K>, dim3((unsigned)grid), dim3(64), lds, st, a);
-    else hipLaunchKernelGGL(vectorise2_kernel<K>, dim3((unsigned)grid), dim3(64 * V2_WAVES), lds, st, a);
+    else if (b16) hipLaunchKernelGGL((vectorise2_kernel<K, true>), dim3((unsigned)grid), dim3(64 * V2_WAVES), lds, st, a);
+    else hipLaunchKernelGGL((vectorise2_kernel<K, false>), dim3((unsigned)grid), dim3(64 * V2_WAVES), lds, st, a);
     IDL_HIP_TRY(hipGetLastError());
     return IDL_OK;
 }
@@ -791,10 +850,10 @@ int idl_kmer_rev_comp(int32_t *counts, int k, int32_t *out)
 int idl_vectorise(const void *codes, const void *mask, const int64_t *slot_off, const int64_t *lengths,
                   int64_t n, int k, int mode, int init, int out_kind,
                   int n_views, const uint32_t *edits, const int64_t *edit_off,
-                  void *out, int64_t view_stride, void *stream)
+                  void *out, int64_t view_stride, int64_t max_len, void *stream)
 {
     IDL_REQUIRE(k >= 1 && k <= IDL_MAX_K, "k outside 1..IDL_MAX_K");
-    IDL_REQUIRE(n >= 0 && n_views >= 1, "n < 0 or n_views < 1");
+    IDL_REQUIRE(n >= 0 && n_views >= 1 && n_views <= 64, "n < 0 or n_views outside 1..64");
     IDL_REQUIRE(mode == IDL_MODE_KMER || mode == IDL_MODE_CGR || mode == IDL_MODE_CANONICAL, "unknown mode");
     IDL_REQUIRE(init == IDL_INIT_ZERO || init == IDL_INIT_ONE || init == IDL_INIT_FROM_OUT, "unknown init");
     IDL_REQUIRE(out_kind == IDL_OUT_COUNTS_I32 || out_kind == IDL_OUT_FREQ_F32 || out_kind == IDL_OUT_FREQ_F64,
@@ -821,6 +880,7 @@ int idl_vectorise(const void *codes, const void *mask, const int64_t *slot_off, 
     a.edit_off = edit_off;
     a.out = out;
     a.view_stride = view_stride;
+    a.max_len = max_len;
     return dispatch_vectorise(k, a, (hipStream_t)stream);
 }
 

@@ -254,6 +254,7 @@ class _DeviceInput:
         self.mask = torch.from_numpy(ff.mask).to(device)
         self.slot_off = torch.from_numpy(ff.slot_off).to(device)
         self.lengths = torch.from_numpy(ff.lengths).to(device)
+        self.max_len = int(ff.lengths.max()) if ff.n else 0
 
 
 def _vectorise(dev_in, k, mode, init, out_kind, n_views=1, edits=None, edit_off=None, out=None):
@@ -267,7 +268,7 @@ def _vectorise(dev_in, k, mode, init, out_kind, n_views=1, edits=None, edit_off=
     assert out.is_contiguous() and out.dtype == dtype and tuple(out.shape) == (n_views, dev_in.n, row)
     _lib.check(_L.idl_vectorise(_ptr(dev_in.codes), _ptr(dev_in.mask), _ptr(dev_in.slot_off), _ptr(dev_in.lengths),
                                 dev_in.n, k, mode, init, out_kind, n_views, _ptr(edits), _ptr(edit_off),
-                                _ptr(out), dev_in.n * row, _stream_ptr()))
+                                _ptr(out), dev_in.n * row, int(getattr(dev_in, "max_len", 0) or 0), _stream_ptr()))
     return out
 
 

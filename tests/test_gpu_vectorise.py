@@ -139,14 +139,16 @@ def _pack_batch(seqs):
     return ff
 
 
-@pytest.mark.parametrize("sc_slots", [None, "1", "2", "5"])
-def test_random_batches_with_edits_vs_oracle(gpu, monkeypatch, sc_slots):
+@pytest.mark.parametrize("sc_slots,bins", [(None, None), ("1", None), ("2", "16"), ("5", None), (None, "16")])
+def test_random_batches_with_edits_vs_oracle(gpu, monkeypatch, sc_slots, bins):
     """Multi-view launch with explicit substitution edits (all four ops, chunk boundaries, duplicates).
     sc_slots shrinks the LDS super-chunk of the delta-view kernel so that halo / boundary handling is
     exercised on small inputs."""
     import torch
     if sc_slots is not None:
         monkeypatch.setenv("IDELUCS_SC_SLOTS", sc_slots)
+    if bins is not None:
+        monkeypatch.setenv("IDELUCS_BINS", bins)          # opt-in 16-bit LDS bins (default: 32-bit)
     from idelucs_amd import _lib, utils as U
     rng = np.random.default_rng(2024)
     seqs = _random_batch(rng, 40, 0, 300) + _random_batch(rng, 12, 3900, 4300) + _random_batch(rng, 6, 8000, 13000, 0.0) \
@@ -182,8 +184,8 @@ def test_random_batches_with_edits_vs_oracle(gpu, monkeypatch, sc_slots):
                 assert np.array_equal(got[v, i], c / np.sum(c)), (k, v, i)
 
 
-@pytest.mark.parametrize("sc_slots", [None, "1", "3"])
-def test_adversarial_edits_at_boundaries(gpu, monkeypatch, sc_slots):
+@pytest.mark.parametrize("sc_slots,long_seq", [(None, False), ("1", False), ("3", False), (None, True)])
+def test_adversarial_edits_at_boundaries(gpu, monkeypatch, sc_slots, long_seq):
     """Edits packed around slot / super-chunk boundaries, runs of adjacent edits (overlapping windows),
     duplicates, N edits on top of XOR edits, edits in the last k bases and past-the-end positions."""
     import torch
@@ -193,6 +195,8 @@ def test_adversarial_edits_at_boundaries(gpu, monkeypatch, sc_slots):
     rng = np.random.default_rng(77)
     seqs = _random_batch(rng, 6, 380, 400, 0.01) + _random_batch(rng, 2, 64, 64, 0.0) + _random_batch(rng, 2, 128, 129, 0.0) \
         + _random_batch(rng, 2, 17000, 17010, 0.001)
+    if long_seq:                     # > 65000 bases: counts may exceed 16 bits -> the launcher must pick 32-bit bins
+        seqs += [np.frombuffer(b"AC" * 40000, np.uint8), rng.choice(np.frombuffer(b"ACGT", np.uint8), size=70001)]
     n, P = len(seqs), 3
     edits, counts, mutated = [], [], [[None] * n for _ in range(P)]
     for v in range(P):

@@ -29,6 +29,7 @@ def synth_input(n, L, dev, seed=12345):
     d = D(); d.n = n; d.codes = codes; d.mask = mask.view(-1)
     d.slot_off = torch.arange(0, (n + 1) * slots, slots, dtype=torch.int64, device=dev)
     d.lengths = torch.full((n,), L, dtype=torch.int64, device=dev)
+    d.max_len = L
     return d
 
 

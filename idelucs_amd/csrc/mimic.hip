@@ -90,7 +90,7 @@ __device__ __forceinline__ uint32_t wave_sort_u32(uint32_t key, int lane)
 template <bool FILL>
 __global__ __launch_bounds__(64) void mimic_kernel(MimicParams p, int n_views, const int64_t *lengths, int64_t n, uint32_t k0,
                                                    uint32_t k1, const uint32_t *tables, int64_t *counts_or_off, uint32_t *edits,
-                                                   int64_t capacity)
+                                                   int64_t capacity, uint16_t *lane_counts)
 {
     __shared__ uint32_t T[J + 1];
     const int lane = threadIdx.x;
@@ -134,19 +134,10 @@ __global__ __launch_bounds__(64) void mimic_kernel(MimicParams p, int n_views, c
         const uint32_t A = p.thr_ts_only[v], B = p.thr_tv_only[v];
         const int kind = p.kind[v];
 
-        // in FILL mode each lane needs its output offset first: recount (same RNG) then prefix
+        // in FILL mode each lane needs its output offset: the per-lane counts were saved by the count pass
         uint32_t lane_off = 0;
         if (FILL) {
-            uint32_t c = 0;
-            int64_t pos = lo - 1;
-            for (uint32_t d = 0; pos < hi; ++d) {
-                const U4 r = philox4x32_10(d, (uint32_t)lane, (uint32_t)s, (uint32_t)v, k0, k1);
-                int a = 0, b = J;                    // largest j in [0, J] with r.x < T[j]
-                while (a < b) { const int m = (a + b + 1) >> 1; if (r.x < T[m]) a = m; else b = m - 1; }
-                if (a == J) { pos += J; continue; }
-                pos += a + 1;
-                if (pos < hi) ++c;
-            }
+            const uint32_t c = lane_counts[it * 64 + lane];
             uint32_t incl = c;
 #pragma unroll
             for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
@@ -173,6 +164,7 @@ __global__ __launch_bounds__(64) void mimic_kernel(MimicParams p, int n_views, c
             }
         }
         if (!FILL) {
+            lane_counts[it * 64 + lane] = (uint16_t)my_count;      // a lane owns <= ceil(L/64) <= 2^24 bases; sites/lane << 65536 for p < 1
             uint32_t tot = my_count;
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o, 64);
@@ -181,17 +173,18 @@ __global__ __launch_bounds__(64) void mimic_kernel(MimicParams p, int n_views, c
     }
 }
 
-// in-place exclusive scan of m int64 counts (single workgroup); off[m] = total
-__global__ __launch_bounds__(1024) void scan_kernel(int64_t *off, int64_t m, int64_t *total)
+// in-place exclusive scan of m int64 counts in three launches: per-block scan (1024 x SCAN_PER elements per block) ->
+// scan of the block totals (one workgroup) -> add the block offsets; off[m] = total
+constexpr int SCAN_PER = 4;
+
+__global__ __launch_bounds__(1024) void scan_block_kernel(int64_t *off, int64_t m, int64_t *block_tot)
 {
     __shared__ int64_t part[1024];
     const int t = threadIdx.x;
-    const int64_t per = (m + 1023) / 1024;
-    const int64_t a = (int64_t)t * per;
-    int64_t b = a + per;
-    if (b > m) b = m;
-    int64_t sum = 0;
-    for (int64_t i = a; i < b; ++i) sum += off[i];
+    const int64_t a = ((int64_t)blockIdx.x * 1024 + t) * SCAN_PER;
+    int64_t v[SCAN_PER], sum = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_PER; ++i) { v[i] = (a + i < m) ? off[a + i] : 0; sum += v[i]; }
     part[t] = sum;
     __syncthreads();
     for (int o = 1; o < 1024; o <<= 1) {
@@ -201,18 +194,58 @@ __global__ __launch_bounds__(1024) void scan_kernel(int64_t *off, int64_t m, int
         __syncthreads();
     }
     int64_t run = part[t] - sum;
-    for (int64_t i = a; i < b; ++i) { const int64_t c = off[i]; off[i] = run; run += c; }
-    if (t == 1023) { off[m] = part[1023]; *total = part[1023]; }
+#pragma unroll
+    for (int i = 0; i < SCAN_PER; ++i) { if (a + i < m) off[a + i] = run; run += v[i]; }
+    if (t == 1023) block_tot[blockIdx.x] = part[1023];
+}
+
+__global__ __launch_bounds__(1024) void scan_tops_kernel(int64_t *block_tot, int64_t nb, int64_t *off_last, int64_t *total)
+{
+    // nb <= 1024 * 1024 block totals, scanned by one workgroup in chunks of 1024
+    __shared__ int64_t part[1024];
+    __shared__ int64_t carry;
+    const int t = threadIdx.x;
+    if (t == 0) carry = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < nb; base += 1024) {
+        const int64_t x0 = (base + t < nb) ? block_tot[base + t] : 0;
+        part[t] = x0;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {
+            const int64_t x = (t >= o) ? part[t - o] : 0;
+            __syncthreads();
+            part[t] += x;
+            __syncthreads();
+        }
+        if (base + t < nb) block_tot[base + t] = carry + part[t] - x0;
+        __syncthreads();
+        if (t == 1023) carry += part[1023];
+        __syncthreads();
+    }
+    if (t == 0) { *off_last = carry; *total = carry; }
+}
+
+__global__ __launch_bounds__(1024) void scan_add_kernel(int64_t *off, int64_t m, const int64_t *block_tot)
+{
+    const int64_t a = ((int64_t)blockIdx.x * 1024 + threadIdx.x) * SCAN_PER;
+    const int64_t add = block_tot[blockIdx.x];
+#pragma unroll
+    for (int i = 0; i < SCAN_PER; ++i) if (a + i < m) off[a + i] += add;
 }
 
 }  // namespace
 
 extern "C" {
 
-int64_t idl_mimic_workspace(int n_views)
+// workspace: gap tables | total | block totals of the scan | per-lane counts (uint16 x 64 per (view, sequence))
+static int64_t ws_tables(int n_views) { return (((int64_t)n_views * (J + 1) * 4 + 15) / 16) * 16; }
+static int64_t ws_scan_blocks(int64_t items) { return (items + 1024 * SCAN_PER - 1) / (1024 * SCAN_PER); }
+
+int64_t idl_mimic_workspace(int64_t n, int n_views)
 {
-    if (n_views < 1 || n_views > MAX_VIEWS) return -1;
-    return (int64_t)n_views * (J + 1) * 4 + 64;
+    if (n < 0 || n_views < 1 || n_views > MAX_VIEWS) return -1;
+    const int64_t items = n * n_views;
+    return ws_tables(n_views) + 16 + (ws_scan_blocks(items) + 1) * 8 + items * 64 * 2 + 64;
 }
 
 int idl_mimic_edits(const int64_t *lengths, int64_t n, int n_views, const double *p_transition,
@@ -249,11 +282,14 @@ int idl_mimic_edits(const int64_t *lengths, int64_t n, int n_views, const double
     int rc = idl::device_info(&di);
     if (rc != IDL_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
-    uint32_t *tables = (uint32_t *)workspace;
-    int64_t *d_total = (int64_t *)((uint8_t *)workspace + (size_t)n_views * (J + 1) * 4);
-    d_total = (int64_t *)(((uintptr_t)d_total + 7u) & ~(uintptr_t)7u);
+    IDL_REQUIRE((((uintptr_t)workspace) & 15u) == 0, "workspace must be 16-byte aligned");
     const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
     const int64_t items = n * n_views;
+    const int64_t nb = ws_scan_blocks(items);
+    uint32_t *tables = (uint32_t *)workspace;
+    int64_t *d_total = (int64_t *)((uint8_t *)workspace + ws_tables(n_views));
+    int64_t *block_tot = d_total + 2;
+    uint16_t *lane_counts = (uint16_t *)(block_tot + nb + 1);
     if (items == 0) {
         IDL_HIP_TRY(hipMemsetAsync(edit_off, 0, sizeof(int64_t), st));
         if (total_edits) *total_edits = 0;
@@ -264,8 +300,10 @@ int idl_mimic_edits(const int64_t *lengths, int64_t n, int n_views, const double
     hipLaunchKernelGGL(mimic_table_kernel, dim3((unsigned)n_views), dim3(64), 0, st, p, n_views, tables);
     if (edits == nullptr) {
         hipLaunchKernelGGL(mimic_kernel<false>, dim3((unsigned)grid), dim3(64), 0, st, p, n_views, lengths, n, k0, k1, tables,
-                           edit_off, (uint32_t *)nullptr, (int64_t)0);
-        hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, st, edit_off, items, d_total);
+                           edit_off, (uint32_t *)nullptr, (int64_t)0, lane_counts);
+        hipLaunchKernelGGL(scan_block_kernel, dim3((unsigned)nb), dim3(1024), 0, st, edit_off, items, block_tot);
+        hipLaunchKernelGGL(scan_tops_kernel, dim3(1), dim3(1024), 0, st, block_tot, nb, edit_off + items, d_total);
+        hipLaunchKernelGGL(scan_add_kernel, dim3((unsigned)nb), dim3(1024), 0, st, edit_off, items, block_tot);
         IDL_HIP_TRY(hipGetLastError());
         if (total_edits) {
             IDL_HIP_TRY(hipMemcpyAsync(total_edits, d_total, sizeof(int64_t), hipMemcpyDeviceToHost, st));
@@ -276,7 +314,7 @@ int idl_mimic_edits(const int64_t *lengths, int64_t n, int n_views, const double
     // fill pass: edit_off must hold the offsets produced by the count pass with the same arguments
     IDL_REQUIRE(edits_capacity >= 0, "negative capacity");
     hipLaunchKernelGGL(mimic_kernel<true>, dim3((unsigned)grid), dim3(64), 0, st, p, n_views, lengths, n, k0, k1, tables,
-                       edit_off, edits, edits_capacity);
+                       edit_off, edits, edits_capacity, lane_counts);
     IDL_HIP_TRY(hipGetLastError());
     return IDL_OK;
 }

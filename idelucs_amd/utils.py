@@ -308,7 +308,7 @@ def _philox_edits(dev_in, specs, seed):
     if np.any(n_rn > 0) and dev_in.n > 0 and int(dev_in.lengths.min().item()) <= 0:
         raise ValueError("high <= 0")   # np.random.randint(0, 0, n) in the reference's Random_N (utils.py:93)
     dev = dev_in.codes.device
-    ws = torch.empty(_L.idl_mimic_workspace(P), dtype=torch.uint8, device=dev)
+    ws = torch.empty(_L.idl_mimic_workspace(dev_in.n, P), dtype=torch.uint8, device=dev)
     edit_off = torch.empty(P * dev_in.n + 1, dtype=torch.int64, device=dev)
     total = ctypes.c_int64(0)
     args = (_ptr(dev_in.lengths), dev_in.n, P, _ptr(p_ts), _ptr(p_tv), _ptr(n_rn), ctypes.c_uint64(seed & (2 ** 64 - 1)))

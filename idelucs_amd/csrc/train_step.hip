@@ -141,17 +141,32 @@ __global__ __launch_bounds__(256) void nce_lse_kernel(const float *S, int m, flo
     const int row = blockIdx.x * 4 + w;
     if (row >= m) return;
     const float *s = S + (int64_t)row * m;
-    float mx = -INFINITY;
-    for (int j = lane; j < m; j += 64) if (j != row) mx = fmaxf(mx, s[j] * inv_t);
-    mx = wave_max(mx);
-    float sum = 0.f;
-    for (int j = lane; j < m; j += 64) if (j != row) sum += __expf(s[j] * inv_t - mx);
-    sum = wave_sum(sum);
-    const float l = mx + __logf(sum);
+    float l;
+    if (m <= 1024) {                    // one pass over the row: 16 values per lane stay in registers
+        float v[16];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int j = lane + 64 * i;
+            v[i] = (j < m && j != row) ? s[j] * inv_t : -INFINITY;
+            mx = fmaxf(mx, v[i]);
+        }
+        mx = wave_max(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sum += __expf(v[i] - mx);      // exp(-inf) = 0 for the masked entries
+        l = mx + __logf(wave_sum(sum));
+    } else {
+        float mx = -INFINITY;
+        for (int j = lane; j < m; j += 64) if (j != row) mx = fmaxf(mx, s[j] * inv_t);
+        mx = wave_max(mx);
+        float sum = 0.f;
+        for (int j = lane; j < m; j += 64) if (j != row) sum += __expf(s[j] * inv_t - mx);
+        l = mx + __logf(wave_sum(sum));
+    }
     if (lane == 0) {
         lse[row] = l;
-        const int pos = (row + m / 2) % m;
-        loss_rows[row] = l - s[pos] * inv_t;
+        loss_rows[row] = l - s[(row + m / 2) % m] * inv_t;
     }
 }
 
@@ -167,22 +182,19 @@ __global__ __launch_bounds__(256) void nce_esym_kernel(float *S, int m, float in
 }
 
 // ---------------------------------------------------------------- IIC on the C x C joint (one workgroup)
-// P0 = z1^T z2 (given).  Writes the step loss (w_nce * mean(loss_rows) + w_iic * IIC) to out[0], adds it
-// to out[1] (running epoch sum) and writes dP0 = w_iic * dIIC/dP0 into P0 in place.  scratch: C*C floats.
-__global__ __launch_bounds__(256) void iic_core_kernel(float *P0, int C, float lamb, float eps, float w_iic, float w_nce,
-                                                       const float *loss_rows, int m, float *scratch, float *rowsum, float *colsum,
-                                                       float *out)
+// P0 = z1^T z2 (given).  Writes IIC to out[3] and dP0 = w_iic * dIIC/dP0 into P0 in place.  scratch: C*C floats.
+// (The step loss is assembled by head_bwd_kernel, so that this kernel does not depend on the InfoNCE branch.)
+__global__ __launch_bounds__(256) void iic_core_kernel(float *P0, int C, float lamb, float eps, float w_iic, float *scratch,
+                                                       float *rowsum, float *colsum, float *out)
 {
-    __shared__ double red[256];
-    __shared__ float bc[4];
+    __shared__ double red[4];
     const int t = threadIdx.x, n = C * C;
     auto block_sum = [&](double v) -> double {
-        red[t] = v;
+        v = wave_sum_d(v);
         __syncthreads();
-        for (int o = 128; o > 0; o >>= 1) { if (t < o) red[t] += red[t + o]; __syncthreads(); }
-        const double r = red[0];
+        if ((t & 63) == 0) red[t >> 6] = v;
         __syncthreads();
-        return r;
+        return (red[0] + red[1]) + (red[2] + red[3]);
     };
     // s = sum(P0); P = (P0 + P0^T) / 2 / s  -> scratch
     double acc = 0.0;
@@ -208,10 +220,7 @@ __global__ __launch_bounds__(256) void iic_core_kernel(float *P0, int C, float l
         acc += (double)(-p * (__logf(p) - lamb * __logf(pj) - lamb * __logf(pi)));
     }
     const float iic = (float)block_sum(acc);
-    acc = 0.0;
-    for (int i = t; i < m; i += 256) acc += (double)loss_rows[i];
-    const float nce = (float)(block_sum(acc) / (double)m);
-    if (t == 0) { const float l = w_nce * nce + w_iic * iic; out[0] = l; out[1] += l; out[2] = nce; out[3] = iic; }
+    if (t == 0) out[3] = iic;
     // clamped row / column sums: A_r = sum_c Pc[r,c], Bc_c = sum_r Pc[r,c]   (kept in P0's first 2C entries? no: reuse red-free arrays)
     __shared__ float Ar[256], Bc[256];
     for (int r = t; r < C; r += 256) {
@@ -241,18 +250,25 @@ __global__ __launch_bounds__(256) void iic_core_kernel(float *P0, int C, float l
         const int r = i / C, c = i - r * C;
         P0[i] = w_iic * 0.5f * (scratch[i] + scratch[c * C + r]);
     }
-    (void)bc;
 }
 
 // ---------------------------------------------------------------- head backward: one wave per row
 // inputs: z, r2, f, inv, G = (E + E^T) f, dP0 (scaled by w_iic), W3;  outputs: dlogits [m,C], dlat [m,64]
 __global__ __launch_bounds__(256) void head_bwd_kernel(const float *z, const float *r2, const float *f, const float *inv,
                                                        const float *G, const float *dP0, const float *W3, int m, int C, int train,
-                                                       float nce_coef, float *dlogits, float *dlat)
+                                                       float nce_coef, float *dlogits, float *dlat, const float *loss_rows,
+                                                       float w_nce, float w_iic, float *out)
 {
     __shared__ float shz[4][256];
     __shared__ float shd[4][256];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (blockIdx.x == 0 && w == 0 && out != nullptr) {
+        // step loss = w_nce * mean(loss_rows) + w_iic * IIC (IIC was left in out[3] by iic_core_kernel); out[1] = running sum
+        float acc = 0.f;
+        for (int i = lane; i < m; i += 64) acc += loss_rows[i];
+        acc = wave_sum(acc) / (float)m;
+        if (lane == 0) { const float l = w_nce * acc + w_iic * out[3]; out[0] = l; out[1] += l; out[2] = acc; }
+    }
     const int row = blockIdx.x * 4 + w;
     if (row >= m) return;
     const int B = m / 2;
@@ -304,12 +320,18 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float *z, const flo
 // are added up, in order, by rmsprop_kernel -- deterministic and without an extra launch.
 constexpr int COL_PARTS = 32;
 
-template <bool RELU_BWD>
-__global__ __launch_bounds__(256) void col_partial_kernel(float *x, const float *act, int m, int n, float scale, float *partial)
+struct ColJob { float *x; const float *act; float *partial; int n; float scale; };   // act != NULL: ReLU/Dropout backward in place
+struct ColJobs { ColJob j[3]; int first_block[4]; int m; };
+
+__global__ __launch_bounds__(256) void col_partial_kernel(ColJobs jobs)
 {
     __shared__ float sh[4][64];
+    int k = 0;
+    while (k < 2 && (int)blockIdx.x >= jobs.first_block[k + 1]) ++k;
+    const ColJob job = jobs.j[k];
+    const int m = jobs.m, n = job.n;
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int c = blockIdx.x * 64 + lane;
+    const int c = ((int)blockIdx.x - jobs.first_block[k]) * 64 + lane;
     const int rows = (m + COL_PARTS - 1) / COL_PARTS;
     const int r0 = blockIdx.y * rows;
     int r1 = r0 + rows;
@@ -317,17 +339,17 @@ __global__ __launch_bounds__(256) void col_partial_kernel(float *x, const float 
     float acc = 0.f;
     if (c < n) {
         for (int r = r0 + w; r < r1; r += 4) {
-            float v = x[(int64_t)r * n + c];
-            if (RELU_BWD) {   // x = d(output of Dropout) -> d(pre-activation), in place
-                v = act[(int64_t)r * n + c] > 0.f ? v * scale : 0.f;
-                x[(int64_t)r * n + c] = v;
+            float v = job.x[(int64_t)r * n + c];
+            if (job.act != nullptr) {   // x = d(output of Dropout) -> d(pre-activation), in place
+                v = job.act[(int64_t)r * n + c] > 0.f ? v * job.scale : 0.f;
+                job.x[(int64_t)r * n + c] = v;
             }
             acc += v;
         }
     }
     sh[w][lane] = acc;
     __syncthreads();
-    if (w == 0 && c < n) partial[(int64_t)blockIdx.y * n + c] = (sh[0][lane] + sh[1][lane]) + (sh[2][lane] + sh[3][lane]);
+    if (w == 0 && c < n) job.partial[(int64_t)blockIdx.y * n + c] = (sh[0][lane] + sh[1][lane]) + (sh[2][lane] + sh[3][lane]);
 }
 
 // ---------------------------------------------------------------- RMSprop over all parameter tensors
@@ -347,6 +369,19 @@ __global__ __launch_bounds__(256) void rmsprop_kernel(RmsArgs a, const float *hy
     if (t < a.count) {
         float *p = a.p[t]; const float *g = a.g[t]; float *v = a.v[t];
         const int64_t n = a.n[t];
+        if (a.parts[t] == 1 && (n & 3) == 0 && ((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)v)) & 15u) == 0) {
+            float4 *p4 = (float4 *)p; const float4 *g4 = (const float4 *)g; float4 *v4 = (float4 *)v;
+            for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n / 4; i += (int64_t)gridDim.x * blockDim.x) {
+                float4 pi = p4[i], vi = v4[i];
+                const float4 gr = g4[i];
+                const float g0 = gr.x + wd * pi.x, g1 = gr.y + wd * pi.y, g2 = gr.z + wd * pi.z, g3 = gr.w + wd * pi.w;
+                vi.x = vi.x * alpha + oma * g0 * g0; vi.y = vi.y * alpha + oma * g1 * g1;
+                vi.z = vi.z * alpha + oma * g2 * g2; vi.w = vi.w * alpha + oma * g3 * g3;
+                pi.x -= lr * (g0 / (sqrtf(vi.x) + eps)); pi.y -= lr * (g1 / (sqrtf(vi.y) + eps));
+                pi.z -= lr * (g2 / (sqrtf(vi.z) + eps)); pi.w -= lr * (g3 / (sqrtf(vi.w) + eps));
+                v4[i] = vi; p4[i] = pi;
+            }
+        } else
         for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
             const float pi = p[i];
             float gr = g[i];
@@ -399,48 +434,73 @@ int idl_nce_rows(float *S, int m, float temperature, float *lse, float *loss_row
     return IDL_OK;
 }
 
-int idl_iic_core(float *P0, int C, float lamb, float eps, float w_iic, float w_nce, const float *loss_rows, int m,
-                 float *scratch, float *out, void *stream)
+int idl_iic_core(float *P0, int C, float lamb, float eps, float w_iic, float *scratch, float *out, void *stream)
 {
-    IDL_REQUIRE(P0 && loss_rows && scratch && out, "NULL buffer");
-    IDL_REQUIRE(C >= 1 && C <= 64 * MAX_CPL && m >= 1, "iic_core: n_clusters must be in 1..256");
+    IDL_REQUIRE(P0 && scratch && out, "NULL buffer");
+    IDL_REQUIRE(C >= 1 && C <= 64 * MAX_CPL, "iic_core: n_clusters must be in 1..256");
     // scratch layout: [C*C] joint, then [C] row sums, [C] column sums
     float *rowsum = scratch + (size_t)C * C, *colsum = rowsum + C;
-    hipLaunchKernelGGL(iic_core_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, P0, C, lamb, eps, w_iic, w_nce, loss_rows, m, scratch,
-                       rowsum, colsum, out);
+    hipLaunchKernelGGL(iic_core_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, P0, C, lamb, eps, w_iic, scratch, rowsum, colsum, out);
     IDL_HIP_TRY(hipGetLastError());
     return IDL_OK;
 }
 
 int idl_head_bwd(const float *z, const float *r2, const float *f, const float *inv, const float *G, const float *dP0,
-                 const float *W3, int m, int C, int train, float nce_coef, float *dlogits, float *dlat, void *stream)
+                 const float *W3, int m, int C, int train, float nce_coef, float *dlogits, float *dlat,
+                 const float *loss_rows, float w_nce, float w_iic, float *out, void *stream)
 {
     IDL_REQUIRE(z && r2 && f && inv && G && dP0 && W3 && dlogits && dlat, "NULL buffer");
     IDL_REQUIRE(m >= 2 && (m % 2) == 0 && C >= 1 && C <= 64 * MAX_CPL, "head_bwd: even m, n_clusters in 1..256");
     hipLaunchKernelGGL(head_bwd_kernel, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, (hipStream_t)stream, z, r2, f, inv, G, dP0, W3, m, C,
-                       train, nce_coef, dlogits, dlat);
+                       train, nce_coef, dlogits, dlat, loss_rows, w_nce, w_iic, out);
     IDL_HIP_TRY(hipGetLastError());
     return IDL_OK;
 }
 
 int idl_col_sum_parts(void) { return COL_PARTS; }
 
+static int launch_col_jobs(ColJobs &jobs, int njobs, void *stream)
+{
+    int nb = 0;
+    for (int k = 0; k < 3; ++k) {
+        jobs.first_block[k] = nb;
+        if (k < njobs) nb += (jobs.j[k].n + 63) / 64;
+    }
+    jobs.first_block[3] = nb;
+    hipLaunchKernelGGL(col_partial_kernel, dim3((unsigned)nb, COL_PARTS), dim3(256), 0, (hipStream_t)stream, jobs);
+    IDL_HIP_TRY(hipGetLastError());
+    return IDL_OK;
+}
+
 int idl_col_sum(const float *x, int m, int n, float *partial, void *stream)
 {
     IDL_REQUIRE(x && partial && m >= 1 && n >= 1, "col_sum: NULL buffer or empty");
-    hipLaunchKernelGGL(col_partial_kernel<false>, dim3((unsigned)((n + 63) / 64), COL_PARTS), dim3(256), 0, (hipStream_t)stream,
-                       (float *)x, (const float *)nullptr, m, n, 1.f, partial);
-    IDL_HIP_TRY(hipGetLastError());
-    return IDL_OK;
+    ColJobs jobs{};
+    jobs.m = m;
+    jobs.j[0] = ColJob{(float *)x, nullptr, partial, n, 1.f};
+    return launch_col_jobs(jobs, 1, stream);
 }
 
 int idl_relu_dropout_bwd_colsum(float *dx, const float *act, int m, int n, int train, float *partial, void *stream)
 {
     IDL_REQUIRE(dx && act && partial && m >= 1 && n >= 1, "relu_dropout_bwd_colsum: NULL buffer or empty");
-    hipLaunchKernelGGL(col_partial_kernel<true>, dim3((unsigned)((n + 63) / 64), COL_PARTS), dim3(256), 0, (hipStream_t)stream, dx, act,
-                       m, n, train ? 2.f : 1.f, partial);
-    IDL_HIP_TRY(hipGetLastError());
-    return IDL_OK;
+    ColJobs jobs{};
+    jobs.m = m;
+    jobs.j[0] = ColJob{dx, act, partial, n, train ? 2.f : 1.f};
+    return launch_col_jobs(jobs, 1, stream);
+}
+
+int idl_bias_grads(float *dx1, const float *act1, int n1, float *partial1, const float *x2, int n2, float *partial2,
+                   const float *x3, int n3, float *partial3, int m, int train, void *stream)
+{
+    IDL_REQUIRE(dx1 && act1 && partial1 && x2 && partial2 && x3 && partial3 && m >= 1 && n1 >= 1 && n2 >= 1 && n3 >= 1,
+                "bias_grads: NULL buffer or empty");
+    ColJobs jobs{};
+    jobs.m = m;
+    jobs.j[0] = ColJob{dx1, act1, partial1, n1, train ? 2.f : 1.f};
+    jobs.j[1] = ColJob{(float *)x2, nullptr, partial2, n2, 1.f};
+    jobs.j[2] = ColJob{(float *)x3, nullptr, partial3, n3, 1.f};
+    return launch_col_jobs(jobs, 3, stream);
 }
 
 int idl_rmsprop_step(int count, float *const *params, const float *const *grads, const int32_t *grad_parts,

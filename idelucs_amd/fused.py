@@ -13,6 +13,7 @@ RMSprop state lives here and, like the reference's single optimizer object (mode
 __main__.py:109), persists across voters.
 """
 import ctypes
+import os
 import sys
 
 import torch
@@ -78,6 +79,8 @@ class FusedLinearTrainer:
         self.out = torch.zeros(4, dtype=torch.float32, device=self.dev)      # [step loss, running sum, nce, iic]
         self._bufs = {}
         self._graphs = {}
+        self._side = torch.cuda.Stream(device=self.dev)     # second branch of the step (see step_on_batch)
+        self._overlap = os.environ.get("IDELUCS_OVERLAP", "0") != "0"   # measured: no gain inside a HIP graph on ROCm 7.2
         self._perm = None
         n = len(self.params)
         self._pp = (ctypes.c_void_p * n)(*[p.data_ptr() for p in self.params])
@@ -103,36 +106,43 @@ class FusedLinearTrainer:
     def step_on_batch(self, bf, train=True, batch_advance=0):
         """Forward, backward and RMSprop update for the [m, F] batch in bf.x (rows [0,m/2) "true",
         [m/2,m) "modified").  Only enqueues work on the current stream."""
-        m, C, st, tr = bf.m, self.C, _stream(), 1 if train else 0
+        m, C, tr = bf.m, self.C, 1 if train else 0
         chk = _lib.check
+        main = torch.cuda.current_stream()
+        side = self._side if self._overlap else main
         # ---- forward
         torch.addmm(self.b1, bf.x, self.W1.t(), out=bf.r1)
-        chk(_L.idl_relu_dropout_fwd(_p(bf.r1), bf.r1.numel(), tr, self.seed, _p(self.ctl), 1, st))
+        chk(_L.idl_relu_dropout_fwd(_p(bf.r1), bf.r1.numel(), tr, self.seed, _p(self.ctl), 1, _stream()))
         torch.addmm(self.b2, bf.r1, self.W2.t(), out=bf.lat)
         chk(_L.idl_head_fwd(_p(bf.lat), _p(self.W3), _p(self.b3), m, C, tr, self.seed, _p(self.ctl),
-                            _p(bf.f), _p(bf.inv), _p(bf.r2), _p(bf.z), st))
-        # ---- losses and their gradients w.r.t. f and z
+                            _p(bf.f), _p(bf.inv), _p(bf.r2), _p(bf.z), _stream()))
+        # ---- the two losses are independent branches: IIC on the side stream, InfoNCE on the main one
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            torch.mm(bf.z[:m // 2].t(), bf.z[m // 2:], out=bf.P0)        # IIC joint, one [C,B]x[B,C] GEMM
+            chk(_L.idl_iic_core(_p(bf.P0), C, self.lamb, EPS, self.weight, _p(bf.iic_scratch), _p(self.out), _stream()))
         torch.mm(bf.f, bf.f.t(), out=bf.S)
-        chk(_L.idl_nce_rows(_p(bf.S), m, TEMPERATURE, _p(bf.lse), _p(bf.loss_rows), st))
+        chk(_L.idl_nce_rows(_p(bf.S), m, TEMPERATURE, _p(bf.lse), _p(bf.loss_rows), _stream()))
         torch.mm(bf.S, bf.f, out=bf.G)                                   # (E + E^T) f
-        torch.mm(bf.z[:m // 2].t(), bf.z[m // 2:], out=bf.P0)            # IIC joint, one [C,B]x[B,C] GEMM
-        chk(_L.idl_iic_core(_p(bf.P0), C, self.lamb, EPS, self.weight, 1.0 - self.weight, _p(bf.loss_rows), m,
-                            _p(bf.iic_scratch), _p(self.out), st))
+        main.wait_stream(side)
         nce_coef = (1.0 - self.weight) / (m * TEMPERATURE)
         chk(_L.idl_head_bwd(_p(bf.z), _p(bf.r2), _p(bf.f), _p(bf.inv), _p(bf.G), _p(bf.P0), _p(self.W3), m, C, tr,
-                            nce_coef, _p(bf.dlogits), _p(bf.dlat), st))
-        # ---- parameter gradients
+                            nce_coef, _p(bf.dlogits), _p(bf.dlat), _p(bf.loss_rows), 1.0 - self.weight, self.weight,
+                            _p(self.out), _stream()))
+        # ---- parameter gradients (one launch for the three bias gradients + the ReLU/Dropout backward of layer 1)
         gW1, gb1, gW2, gb2, gW3, gb3 = self.grads
-        torch.mm(bf.dlogits.t(), bf.r2, out=gW3)
-        chk(_L.idl_col_sum(_p(bf.dlogits), m, C, _p(gb3), st))
-        torch.mm(bf.dlat.t(), bf.r1, out=gW2)
-        chk(_L.idl_col_sum(_p(bf.dlat), m, self.H2, _p(gb2), st))
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            torch.mm(bf.dlogits.t(), bf.r2, out=gW3)
+            torch.mm(bf.dlat.t(), bf.r1, out=gW2)
         torch.mm(bf.dlat, self.W2, out=bf.dr1)
-        chk(_L.idl_relu_dropout_bwd_colsum(_p(bf.dr1), _p(bf.r1), m, self.H1, tr, _p(gb1), st))
+        chk(_L.idl_bias_grads(_p(bf.dr1), _p(bf.r1), self.H1, _p(gb1), _p(bf.dlat), self.H2, _p(gb2), _p(bf.dlogits), C, _p(gb3),
+                              m, tr, _stream()))
         torch.mm(bf.dr1.t(), bf.x, out=gW1)
+        main.wait_stream(side)
         # ---- RMSprop (and advance the device-side step counter / batch offset)
         chk(_L.idl_rmsprop_step(len(self.params), self._pp, self._gp, self._parts, self._vp, self._sz, _p(self.hyper),
-                                _p(self.ctl), batch_advance, st))
+                                _p(self.ctl), batch_advance, _stream()))
 
     def _gather(self, store, bf):
         b = bf.m // 2

@@ -242,7 +242,7 @@ def test_fused_loss_kernels_vs_reference(dev, B, C):
     z1, z2 = torch.softmax(a, 1), torch.softmax(b, 1)
     P0 = (z1.t() @ z2).contiguous()
     scratch = torch.empty(C * C + 2 * C, device=dev); out = torch.zeros(4, device=dev)
-    _lib.check(L.idl_iic_core(_p(P0), C, 2.8, EPS, 1.0, 0.0, _p(rows), m, _p(scratch), _p(out), _stream()))
+    _lib.check(L.idl_iic_core(_p(P0), C, 2.8, EPS, 1.0, _p(scratch), _p(out), _stream()))
     ref = float(g[f"iic.B{B}.C{C}.loss"])
     assert abs(out[3].item() - ref) <= 1e-4 * abs(ref), (out[3].item(), ref)
     dz1, dz2 = z2 @ P0.t(), z1 @ P0

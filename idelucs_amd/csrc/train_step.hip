@@ -256,19 +256,11 @@ __global__ __launch_bounds__(256) void iic_core_kernel(float *P0, int C, float l
 // inputs: z, r2, f, inv, G = (E + E^T) f, dP0 (scaled by w_iic), W3;  outputs: dlogits [m,C], dlat [m,64]
 __global__ __launch_bounds__(256) void head_bwd_kernel(const float *z, const float *r2, const float *f, const float *inv,
                                                        const float *G, const float *dP0, const float *W3, int m, int C, int train,
-                                                       float nce_coef, float *dlogits, float *dlat, const float *loss_rows,
-                                                       float w_nce, float w_iic, float *out)
+                                                       float nce_coef, float *dlogits, float *dlat)
 {
     __shared__ float shz[4][256];
     __shared__ float shd[4][256];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (blockIdx.x == 0 && w == 0 && out != nullptr) {
-        // step loss = w_nce * mean(loss_rows) + w_iic * IIC (IIC was left in out[3] by iic_core_kernel); out[1] = running sum
-        float acc = 0.f;
-        for (int i = lane; i < m; i += 64) acc += loss_rows[i];
-        acc = wave_sum(acc) / (float)m;
-        if (lane == 0) { const float l = w_nce * acc + w_iic * out[3]; out[0] = l; out[1] += l; out[2] = acc; }
-    }
     const int row = blockIdx.x * 4 + w;
     if (row >= m) return;
     const int B = m / 2;
@@ -354,6 +346,10 @@ __global__ __launch_bounds__(256) void col_partial_kernel(ColJobs jobs)
 
 // ---------------------------------------------------------------- RMSprop over all parameter tensors
 struct RmsArgs {
+    const float *loss_rows;   // optional step-loss assembly (models.py:128): see idl_rmsprop_step
+    float *out;
+    int loss_m;
+    float w_nce, w_iic;
     float *p[8];
     const float *g[8];
     float *v[8];
@@ -384,8 +380,18 @@ __global__ __launch_bounds__(256) void rmsprop_kernel(RmsArgs a, const float *hy
         } else
         for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
             const float pi = p[i];
-            float gr = g[i];
-            for (int q = 1; q < a.parts[t]; ++q) gr += g[(int64_t)q * n + i];
+            float gr;
+            if (a.parts[t] == COL_PARTS) {          // 32 independent loads in flight, summed in a fixed order
+                float part[COL_PARTS];
+#pragma unroll
+                for (int q = 0; q < COL_PARTS; ++q) part[q] = g[(int64_t)q * n + i];
+                gr = part[0];
+#pragma unroll
+                for (int q = 1; q < COL_PARTS; ++q) gr += part[q];
+            } else {
+                gr = g[i];
+                for (int q = 1; q < a.parts[t]; ++q) gr += g[(int64_t)q * n + i];
+            }
             const float gi = gr + wd * pi;                        // grad.add(param, alpha=weight_decay)
             const float vi = v[i] * alpha + oma * gi * gi;  // square_avg.mul_(alpha).addcmul_(g, g, value=1-alpha)
             v[i] = vi;
@@ -393,6 +399,13 @@ __global__ __launch_bounds__(256) void rmsprop_kernel(RmsArgs a, const float *hy
         }
     }
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { ctl[0] += 1; ctl[1] += batch_advance; }
+    if (a.out != nullptr && blockIdx.x == gridDim.x - 1 && blockIdx.y == gridDim.y - 1 && threadIdx.x < 64) {
+        // step loss = w_nce * mean(loss_rows) + w_iic * IIC (left in out[3] by iic_core_kernel); out[1] = running sum
+        float acc = 0.f;
+        for (int i = threadIdx.x; i < a.loss_m; i += 64) acc += a.loss_rows[i];
+        acc = wave_sum(acc) / (float)a.loss_m;
+        if (threadIdx.x == 0) { const float l = a.w_nce * acc + a.w_iic * a.out[3]; a.out[0] = l; a.out[1] += l; a.out[2] = acc; }
+    }
 }
 
 }  // namespace
@@ -446,13 +459,12 @@ int idl_iic_core(float *P0, int C, float lamb, float eps, float w_iic, float *sc
 }
 
 int idl_head_bwd(const float *z, const float *r2, const float *f, const float *inv, const float *G, const float *dP0,
-                 const float *W3, int m, int C, int train, float nce_coef, float *dlogits, float *dlat,
-                 const float *loss_rows, float w_nce, float w_iic, float *out, void *stream)
+                 const float *W3, int m, int C, int train, float nce_coef, float *dlogits, float *dlat, void *stream)
 {
     IDL_REQUIRE(z && r2 && f && inv && G && dP0 && W3 && dlogits && dlat, "NULL buffer");
     IDL_REQUIRE(m >= 2 && (m % 2) == 0 && C >= 1 && C <= 64 * MAX_CPL, "head_bwd: even m, n_clusters in 1..256");
     hipLaunchKernelGGL(head_bwd_kernel, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, (hipStream_t)stream, z, r2, f, inv, G, dP0, W3, m, C,
-                       train, nce_coef, dlogits, dlat, loss_rows, w_nce, w_iic, out);
+                       train, nce_coef, dlogits, dlat);
     IDL_HIP_TRY(hipGetLastError());
     return IDL_OK;
 }
@@ -505,11 +517,12 @@ int idl_bias_grads(float *dx1, const float *act1, int n1, float *partial1, const
 
 int idl_rmsprop_step(int count, float *const *params, const float *const *grads, const int32_t *grad_parts,
                      float *const *square_avg, const int64_t *sizes, const float *hyper, int64_t *ctl, int64_t batch_advance,
-                     void *stream)
+                     const float *loss_rows, int loss_m, float w_nce, float w_iic, float *out, void *stream)
 {
     IDL_REQUIRE(count >= 1 && count <= 8 && params && grads && square_avg && sizes && hyper && ctl, "rmsprop_step: 1..8 tensors");
     RmsArgs a{};
     a.count = count;
+    a.loss_rows = loss_rows; a.out = (loss_rows != nullptr && loss_m > 0) ? out : nullptr; a.loss_m = loss_m; a.w_nce = w_nce; a.w_iic = w_iic;
     int64_t mx = 0;
     for (int i = 0; i < count; ++i) {
         a.p[i] = params[i]; a.g[i] = grads[i]; a.v[i] = square_avg[i]; a.n[i] = sizes[i];

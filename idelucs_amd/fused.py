@@ -127,8 +127,7 @@ class FusedLinearTrainer:
         main.wait_stream(side)
         nce_coef = (1.0 - self.weight) / (m * TEMPERATURE)
         chk(_L.idl_head_bwd(_p(bf.z), _p(bf.r2), _p(bf.f), _p(bf.inv), _p(bf.G), _p(bf.P0), _p(self.W3), m, C, tr,
-                            nce_coef, _p(bf.dlogits), _p(bf.dlat), _p(bf.loss_rows), 1.0 - self.weight, self.weight,
-                            _p(self.out), _stream()))
+                            nce_coef, _p(bf.dlogits), _p(bf.dlat), _stream()))
         # ---- parameter gradients (one launch for the three bias gradients + the ReLU/Dropout backward of layer 1)
         gW1, gb1, gW2, gb2, gW3, gb3 = self.grads
         side.wait_stream(main)
@@ -142,7 +141,8 @@ class FusedLinearTrainer:
         main.wait_stream(side)
         # ---- RMSprop (and advance the device-side step counter / batch offset)
         chk(_L.idl_rmsprop_step(len(self.params), self._pp, self._gp, self._parts, self._vp, self._sz, _p(self.hyper),
-                                _p(self.ctl), batch_advance, _stream()))
+                                _p(self.ctl), batch_advance, _p(bf.loss_rows), m, 1.0 - self.weight, self.weight, _p(self.out),
+                                _stream()))
 
     def _gather(self, store, bf):
         b = bf.m // 2

@@ -208,7 +208,8 @@ def test_fused_rmsprop_kernel_exact(dev):
             gr.copy_(ref)
     from idelucs_amd import _lib
     from idelucs_amd.fused import _p, _stream
-    _lib.check(_lib.lib.idl_rmsprop_step(6, tr._pp, tr._gp, tr._parts, tr._vp, tr._sz, _p(tr.hyper), _p(tr.ctl), 7, _stream()))
+    _lib.check(_lib.lib.idl_rmsprop_step(6, tr._pp, tr._gp, tr._parts, tr._vp, tr._sz, _p(tr.hyper), _p(tr.ctl), 7, None, 0, 0.0, 0.0, None,
+                                         _stream()))
     for n_, p in zip(names, tr.params):
         np.testing.assert_allclose(p.detach().cpu().numpy(), g[f"linear.step0.p.{n_}"], rtol=1e-5, atol=1e-7, err_msg=n_)
     assert tr.ctl.tolist() == [1, 7]

@@ -202,9 +202,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    from idelucs_amd import _lib
+    from idelucs_amd import _lib, gemm_tuning
     _lib.require_gpu()
     torch.cuda.set_device(local_rank)
+    os.environ.setdefault("IDELUCS_TUNABLEOP", "1")      # GEMM solution selection (PyTorch TunableOp), done in the warm-up step
+    gemm_tuning.maybe_enable()
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

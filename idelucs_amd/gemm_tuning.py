@@ -1,0 +1,47 @@
+"""GEMM solution selection for the dense layers of the training step.
+
+The step's seven skinny fp32 GEMMs (K or N = 64, or C x C outputs) are latency-bound; hipBLASLt's
+default heuristic runs them in 8-12 us each, while the best rocBLAS/hipBLASLt solution found by
+PyTorch's TunableOp needs 5-7 us (measured on MI355X: epoch 120.5 -> 108.1 ms).  This module turns
+TunableOp on, seeds it with the solutions tuned for the default shapes (k=6, batch 512, NetLinear,
+n_clusters=20 -- idelucs_amd/tunableop_gfx950.csv, valid for this image's PyTorch/rocBLAS/hipBLASLt
+versions, re-tuned automatically when TunableOp's validators do not match) and leaves online tuning
+enabled for any other shape (a few hundred ms per new GEMM shape, once per process).
+
+IDELUCS_TUNABLEOP=0 disables it; =1 forces it on.  By default it is enabled for jobs with at least
+MIN_STEPS optimizer steps (tuning unseen shapes costs more than it saves on tiny jobs).
+"""
+import os
+import shutil
+import tempfile
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SEED_FILE = os.path.join(_HERE, "tunableop_gfx950.csv")
+MIN_STEPS = 3000
+_enabled = False
+
+
+def maybe_enable(total_steps=None):
+    global _enabled
+    mode = os.environ.get("IDELUCS_TUNABLEOP", "auto")
+    if _enabled or mode == "0":
+        return _enabled
+    if mode != "1" and (total_steps is None or total_steps < MIN_STEPS):
+        return False
+    try:
+        import torch.cuda.tunable as tn
+    except ImportError:
+        return False
+    # one result file per process (ranks of a multi-GPU job must not share one), seeded from the shipped solutions
+    path = os.path.join(tempfile.gettempdir(), f"idelucs_tunableop_{os.getpid()}.csv")
+    if os.path.exists(SEED_FILE):
+        shutil.copyfile(SEED_FILE, path)
+    tn.set_filename(path, insert_device_ordinal=False)
+    tn.enable(True)
+    tn.tuning_enable(True)
+    if hasattr(tn, "write_file_on_exit"):
+        tn.write_file_on_exit(False)
+    _enabled = True
+    return True

@@ -70,6 +70,8 @@ class IID_model():
         self.weight = args['weight']
         self.schedule = args['scheduler']
         self.mutate = True
+        self.n_epochs = args.get('n_epochs', 1)
+        self.n_voters = args.get('n_voters', 1)
         self.rng = args.get('rng')            # None -> $IDELUCS_RNG or "philox"
         self.seed = args.get('seed', 0)
 
@@ -120,6 +122,9 @@ class IID_model():
         if self._use_fused:
             from .fused import FusedLinearTrainer
             if self._fused is None:
+                from . import gemm_tuning
+                n_batches = (st.n_pairs + self.batch_sz - 1) // self.batch_sz
+                gemm_tuning.maybe_enable(n_batches * self.n_epochs * self.n_voters)
                 self._fused = FusedLinearTrainer(self.net, self.lr, self.weight, self.l, seed=self.seed)
             self._fused.set_lr(self.optimizer.param_groups[0]['lr'])       # schedulers act on the torch optimizer
             total, n_batches = self._fused.run_epoch(st, self.batch_sz)

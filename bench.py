@@ -120,6 +120,17 @@ class HotPath:
         return sum(s.elapsed_time(e) for s, e in ev) / max(len(ev), 1)
 
 
+def pmc_traffic_gb():
+    """HBM traffic of one vectorise launch at cfg2, GB, from the committed rocprofv3 PMC passes
+    (profiles/r01_c_vectorise_pmc.json: WRITE_SIZE exact for 16-B stores, FETCH_SIZE as reported -- see DESIGN.md 4.1);
+    None when the profile is not present or the workload is not cfg2."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_c_vectorise_pmc.json")) as fh:
+            return json.load(fh)["traffic_gb_per_launch"]
+    except Exception:
+        return None
+
+
 def cpu_baseline(args):
     """The oracle (CPU restatement of the reference algorithm) timed on this box's host cores, in the
     reference's shape: single-threaded per-record vectorise passes with numpy/random mimics
@@ -195,7 +206,7 @@ def main():
     ap.add_argument("--batch-sz", dest="batch_sz", type=int, default=512)
     ap.add_argument("--with-predict", dest="with_predict", type=int, default=1,
                     help="include predict + all-gather of assignments in the timed region (default 1)")
-    ap.add_argument("--cpu-sample", dest="cpu_sample", type=int, default=4000)
+    ap.add_argument("--cpu-sample", dest="cpu_sample", type=int, default=24000)
     ap.add_argument("--no-cpu-baseline", dest="cpu_base", action="store_false")
     args = ap.parse_args()
 
@@ -267,9 +278,9 @@ def main():
                        "n_sequences": args.n, "seq_len": args.len, "k": args.k, "batch_sz": args.batch_sz,
                        "optimizer_steps_per_epoch": (args.n * args.n_mimics + args.batch_sz - 1) // args.batch_sz,
                        "parallelism": f"voters x{world}"},
-            "roofline": {"kernel": "vectorise_kernel<6> (hand-written HIP: counts + mimic edits + normalise, all views)",
+            "roofline": {"kernel": "vectorise2_kernel<6> (hand-written HIP: one count + per-view window deltas + normalise, all views)",
                          "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                         "traffic": None, "ms_per_launch": t_vec, "bytes_per_seq_algorithmic": b_vec,
+                         "traffic": pmc_traffic_gb(), "ms_per_launch": t_vec, "bytes_per_seq_algorithmic": b_vec,
                          "share_of_step": t_vec / ms_step},
             "roofline_epoch": {"kernel": "training epoch (hipBLASLt fp32 GEMMs + gather + losses + RMSprop)", "bound": "mfma",
                                "achieved": ach_ep, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach_ep / MFMA_F32_PEAK_TFLOPS,

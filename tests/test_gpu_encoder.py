@@ -301,3 +301,59 @@ def test_fused_graph_replay_equals_eager(dev):
         assert torch.allclose(a, b, rtol=1e-5, atol=1e-7)
     assert abs(results[0][1] - results[1][1]) <= 1e-4 * abs(results[0][1])
     assert np.isfinite(results[0][1])
+
+
+# ------------------------------------------------------------------------------------------------
+# the other configurations of the reference surface
+# ------------------------------------------------------------------------------------------------
+def _args(**kw):
+    a = {'sequence_file': os.path.join(DATA, "Influenza-A.fas"), 'GT_file': None, 'n_clusters': 5, 'k': 4, 'model_size': 'linear',
+         'n_mimics': 3, 'batch_sz': 256, 'optimizer': 'RMSprop', 'lambda': 2.8, 'lr': 1e-3, 'weight': 0.25, 'scheduler': None,
+         'n_epochs': 3, 'n_voters': 1}
+    a.update(kw)
+    return a
+
+
+@pytest.mark.parametrize("kw", [dict(model_size='small', k=4), dict(model_size='small', k=5), dict(optimizer='SGD'), dict(optimizer='Adam'),
+                                dict(scheduler='Plateau'), dict(scheduler='Triangle'), dict(n_mimics=1), dict(n_mimics=5, k=5),
+                                dict(n_clusters=200, k=4)])
+def test_all_reference_configurations_train_and_predict(dev, kw):
+    """model_size small (canonical k-mers + myNet, reference models.py:59-66), the three optimizers
+    (:87-94), both schedulers (:96-99), n_mimics < 2 (still two mimic passes, utils.py:336-344) and the
+    n_clusters=0 head width (200): every one trains on the GPU, loss decreases, outputs have the
+    reference's shapes/dtypes."""
+    import torch
+    from idelucs_amd import models
+    torch.manual_seed(1)
+    m = models.IID_model(_args(**kw))
+    m.build_dataloader()
+    assert m.store.n_pairs == 949 * max(m.n_mimics, 2)
+    if kw.get('model_size') == 'small':
+        assert m.store.f == {4: 136, 5: 512}[m.k] and m._use_fused is False
+    losses = [m.contrastive_training_epoch() for _ in range(3)]
+    assert all(np.isfinite(l) for l in losses)
+    if kw.get('scheduler') != 'Triangle':          # CyclicLR ramps the LR from 1e-3 towards 0.1 (models.py:99): the loss rises
+        assert losses[-1] < losses[0]
+    else:
+        assert m.optimizer.param_groups[0]['lr'] > 1e-3 and losses[-1] != losses[0]
+    y, p, lat = m.predict()
+    assert y.dtype == np.int64 and y.shape == (949,) and p.dtype == np.float64 and lat.shape == (949, 64) and lat.dtype == np.float64
+    probs = m.calculate_probs()
+    assert probs.shape == (949, m.n_clusters) and np.allclose(probs.sum(1), 1.0, atol=1e-5)
+
+
+def test_invalid_configurations_raise_like_the_reference(dev):
+    from idelucs_amd import models
+    with pytest.raises(ValueError, match="Invalid Model Type"):
+        models.IID_model(_args(model_size='conv'))
+    with pytest.raises(ValueError, match="Optimizer not supported"):
+        models.IID_model(_args(optimizer='LBFGS'))
+
+
+def test_single_batch_epoch_returns_inf_like_the_reference(dev, tmp_path):
+    """models.py:135 divides the summed loss by the LAST batch index: one batch -> division by zero -> inf."""
+    from idelucs_amd import models
+    m = models.IID_model(_args(sequence_file=os.path.join(DATA, "influenza_64.fas"), batch_sz=512))
+    m.build_dataloader()
+    assert m.store.n_pairs == 192
+    assert np.isinf(m.contrastive_training_epoch())

@@ -183,73 +183,63 @@ __global__ __launch_bounds__(256) void nce_esym_kernel(float *S, int m, float in
 
 // ---------------------------------------------------------------- IIC on the C x C joint (one workgroup)
 // P0 = z1^T z2 (given).  Writes IIC to out[3] and dP0 = w_iic * dIIC/dP0 into P0 in place.  scratch: C*C floats.
-// (The step loss is assembled by head_bwd_kernel, so that this kernel does not depend on the InfoNCE branch.)
-__global__ __launch_bounds__(256) void iic_core_kernel(float *P0, int C, float lamb, float eps, float w_iic, float *scratch,
-                                                       float *rowsum, float *colsum, float *out)
+// (The step loss is assembled by rmsprop_kernel, so that this kernel does not depend on the InfoNCE branch.)
+// The joint P = (P0 + P0^T) / (2 sum P0) is symmetric bit-for-bit ((a+b) == (b+a)), so its column sums equal its
+// row sums and dL/dP is symmetric too: the reference's two marginals (LossFunctions.py:32-33) and its
+// symmetrisation backward collapse to one coalesced wave-per-row pass and no transpose.
+template <int NT>
+__global__ __launch_bounds__(NT) void iic_core_kernel(float *P0, int C, float lamb, float eps, float w_iic, float *scratch,
+                                                      float *out)
 {
-    __shared__ double red[4];
-    const int t = threadIdx.x, n = C * C;
+    constexpr int NW = NT / 64;
+    __shared__ double red[NW];
+    __shared__ float rs[256], ar[256];          // row sums of P and of the clamped P
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6, n = C * C;
     auto block_sum = [&](double v) -> double {
         v = wave_sum_d(v);
         __syncthreads();
-        if ((t & 63) == 0) red[t >> 6] = v;
+        if (lane == 0) red[wv] = v;
         __syncthreads();
-        return (red[0] + red[1]) + (red[2] + red[3]);
+        double r = 0.0;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) r += red[i];
+        return r;
     };
-    // s = sum(P0); P = (P0 + P0^T) / 2 / s  -> scratch
     double acc = 0.0;
-    for (int i = t; i < n; i += 256) acc += (double)P0[i];
+    for (int i = t; i < n; i += NT) acc += (double)P0[i];
     const float s = (float)block_sum(acc);
-    for (int i = t; i < n; i += 256) {
+    for (int i = t; i < n; i += NT) {
         const int r = i / C, c = i - r * C;
         scratch[i] = ((P0[i] + P0[c * C + r]) * 0.5f) / s;
     }
     __syncthreads();
-    // marginals of the un-clamped joint (LossFunctions.py:32-33)
-    for (int r = t; r < C; r += 256) {
+    for (int r = wv; r < C; r += NW) {          // one wave per row, coalesced
         float a = 0.f, b = 0.f;
-        for (int c = 0; c < C; ++c) { a += scratch[r * C + c]; b += scratch[c * C + r]; }
-        rowsum[r] = a; colsum[r] = b;
+        for (int c = lane; c < C; c += 64) { const float p = scratch[r * C + c]; a += p; b += fmaxf(p, eps); }
+        a = wave_sum(a); b = wave_sum(b);
+        if (lane == 0) { rs[r] = a; ar[r] = b; }
     }
     __syncthreads();
-    // loss, and the clamped-row/col sums needed by the marginal terms of the gradient
-    acc = 0.0;
-    for (int i = t; i < n; i += 256) {
-        const int r = i / C, c = i - r * C;
-        const float p = fmaxf(scratch[i], eps), pi = fmaxf(rowsum[r], eps), pj = fmaxf(colsum[c], eps);
-        acc += (double)(-p * (__logf(p) - lamb * __logf(pj) - lamb * __logf(pi)));
-    }
-    const float iic = (float)block_sum(acc);
-    if (t == 0) out[3] = iic;
-    // clamped row / column sums: A_r = sum_c Pc[r,c], Bc_c = sum_r Pc[r,c]   (kept in P0's first 2C entries? no: reuse red-free arrays)
-    __shared__ float Ar[256], Bc[256];
-    for (int r = t; r < C; r += 256) {
-        float a = 0.f, b = 0.f;
-        for (int c = 0; c < C; ++c) { a += fmaxf(scratch[r * C + c], eps); b += fmaxf(scratch[c * C + r], eps); }
-        Ar[r] = a; Bc[r] = b;
-    }
-    __syncthreads();
-    // G = dL/dP (clamp-by-assignment: no gradient through clamped entries), staged in P0
-    acc = 0.0;
-    for (int i = t; i < n; i += 256) {
+    // loss, G = dL/dP (clamp-by-assignment: no gradient through clamped entries) and sum(G * P) in one pass
+    double lacc = 0.0, gacc = 0.0;
+    for (int i = t; i < n; i += NT) {
         const int r = i / C, c = i - r * C;
         const float pu = scratch[i], p = fmaxf(pu, eps);
-        const float piu = rowsum[r], pi = fmaxf(piu, eps), pju = colsum[c], pj = fmaxf(pju, eps);
+        const float piu = rs[r], pi = fmaxf(piu, eps), pju = rs[c], pj = fmaxf(pju, eps);
+        const float lg = __logf(p) - lamb * __logf(pj) - lamb * __logf(pi);
+        lacc += (double)(-p * lg);
         float g = 0.f;
-        if (!(pu < eps)) g += -(__logf(p) - lamb * __logf(pj) - lamb * __logf(pi)) - 1.f;
-        if (!(piu < eps)) g += lamb * Ar[r] / pi;
-        if (!(pju < eps)) g += lamb * Bc[c] / pj;
+        if (!(pu < eps)) g += -lg - 1.f;
+        if (!(piu < eps)) g += lamb * ar[r] / pi;
+        if (!(pju < eps)) g += lamb * ar[c] / pj;
         P0[i] = g;
-        acc += (double)g * (double)pu;
+        gacc += (double)g * (double)pu;
     }
-    const float gp = (float)block_sum(acc);       // sum(G * P)
-    // through P = Ps / sum(Ps):  dPs = (G - sum(G*P)) / s ; through Ps = (P0 + P0^T)/2: dP0 = (dPs + dPs^T)/2
-    for (int i = t; i < n; i += 256) scratch[i] = (P0[i] - gp) / s;
-    __syncthreads();
-    for (int i = t; i < n; i += 256) {
-        const int r = i / C, c = i - r * C;
-        P0[i] = w_iic * 0.5f * (scratch[i] + scratch[c * C + r]);
-    }
+    const float iic = (float)block_sum(lacc);
+    const float gp = (float)block_sum(gacc);
+    if (t == 0) out[3] = iic;
+    // through P = Ps / sum(Ps): dPs = (G - sum(G P)) / s; G is symmetric, so (dPs + dPs^T)/2 = dPs
+    for (int i = t; i < n; i += NT) P0[i] = w_iic * (P0[i] - gp) / s;
 }
 
 // ---------------------------------------------------------------- head backward: one wave per row
@@ -268,7 +258,8 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float *z, const flo
     const int prow = first ? row + B : row - B;
     for (int c = lane; c < C; c += 64) shz[w][c] = z[(int64_t)prow * C + c];
     __builtin_amdgcn_wave_barrier();
-    // dz: rows of view 1: dz[c] = sum_c' dP0[c,c'] zp[c'];  rows of view 2: dz[c] = sum_c' zp[c'] dP0[c',c]
+    // dz[c] = sum_c' zp[c'] dP0[c',c] for both views: dP0 is symmetric (see iic_core_kernel), so view 1's
+    // dP0[c,c'] is read as dP0[c',c] -- coalesced across the lanes
     float zc[MAX_CPL], dz[MAX_CPL];
     float dot = 0.f;
 #pragma unroll
@@ -278,8 +269,8 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float *z, const flo
         if (c < C) {
             zc[t] = z[(int64_t)row * C + c];
             float acc = 0.f;
-            if (first) for (int k = 0; k < C; ++k) acc = fmaf(dP0[c * C + k], shz[w][k], acc);
-            else for (int k = 0; k < C; ++k) acc = fmaf(shz[w][k], dP0[k * C + c], acc);
+#pragma unroll 4
+            for (int k = 0; k < C; ++k) acc = fmaf(shz[w][k], dP0[k * C + c], acc);
             dz[t] = acc;
             dot += acc * zc[t];
         }
@@ -451,9 +442,8 @@ int idl_iic_core(float *P0, int C, float lamb, float eps, float w_iic, float *sc
 {
     IDL_REQUIRE(P0 && scratch && out, "NULL buffer");
     IDL_REQUIRE(C >= 1 && C <= 64 * MAX_CPL, "iic_core: n_clusters must be in 1..256");
-    // scratch layout: [C*C] joint, then [C] row sums, [C] column sums
-    float *rowsum = scratch + (size_t)C * C, *colsum = rowsum + C;
-    hipLaunchKernelGGL(iic_core_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, P0, C, lamb, eps, w_iic, scratch, rowsum, colsum, out);
+    if (C <= 48) hipLaunchKernelGGL(iic_core_kernel<256>, dim3(1), dim3(256), 0, (hipStream_t)stream, P0, C, lamb, eps, w_iic, scratch, out);
+    else hipLaunchKernelGGL(iic_core_kernel<1024>, dim3(1), dim3(1024), 0, (hipStream_t)stream, P0, C, lamb, eps, w_iic, scratch, out);
     IDL_HIP_TRY(hipGetLastError());
     return IDL_OK;
 }

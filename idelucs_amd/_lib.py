@@ -46,7 +46,10 @@ SIGNATURES = {
     "idl_head_fwd": (_int, [_vp, _vp, _vp, _int, _int, _int, _c.c_uint64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "idl_nce_rows": (_int, [_vp, _int, _c.c_float, _vp, _vp, _vp]),
     "idl_iic_core": (_int, [_vp, _int, _c.c_float, _c.c_float, _c.c_float, _vp, _vp, _vp]),
-    "idl_head_bwd": (_int, [_vp] * 7 + [_int, _int, _int, _c.c_float, _vp, _vp, _vp]),
+    "idl_head_bwd": (_int, [_vp] * 5 + [_int, _vp, _vp, _int, _int, _int, _c.c_float, _vp, _vp, _vp]),
+    "idl_nce_fused_workspace": (_i64, [_int]),
+    "idl_nce_fused_parts": (_int, []),
+    "idl_nce_fused": (_int, [_vp, _int, _c.c_float, _vp, _vp, _vp, _vp, _vp]),
     "idl_col_sum": (_int, [_vp, _int, _int, _vp, _vp]),
     "idl_relu_dropout_bwd_colsum": (_int, [_vp, _vp, _int, _int, _int, _vp, _vp]),
     "idl_col_sum_parts": (_int, []),

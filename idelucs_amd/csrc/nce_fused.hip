@@ -1,0 +1,161 @@
+// nce_fused.hip -- info_nce_loss (reference idelucs/LossFunctions.py:65-98) forward + gradient w.r.t. the
+// normalised latents, fused on the fp32 matrix cores of gfx950; the [2B, 2B] similarity matrix is never
+// written to memory.
+//
+//   f [m, 64]  rows L2-normalised (m = 2B; rows [0,B) view 1, [B,2B) view 2), S = f f^T
+//   pass 1     rowsum_r = sum_{j != r} exp(S_rj / T)        (|S/T| <= 1/T: no max subtraction needed)
+//              pos_r    = S_{r,(r+B) mod m} / T
+//   pass 2     lse_r = log rowsum_r, loss_r = lse_r - pos_r,
+//              G_r  = sum_{j != r} (exp(S_rj/T - lse_r) + exp(S_rj/T - lse_j)) f_j      == ((E + E^T) f)_r
+//   so that d(mean loss)/df = (G - 2 f_pos) / (m T)  (consumed by head_bwd_kernel).
+//
+// Tiling: a workgroup owns 16 rows r and a quarter of the columns j; each of its 4 wavefronts walks 16-column
+// tiles.  A tile is computed TRANSPOSED, S'[j][r] = sum_k f[j0+j][k] f[r0+r][k], with 16
+// v_mfma_f32_16x16x4_f32 (exact fp32 FMA chains).  In the C/D layout a lane then holds S'[j = 4q+reg][r = l]
+// (q = lane>>4, l = lane&15), which is exactly the A operand of the second product G[r][c] += E[r][j] f[j][c]
+// when its four k-steps are taken as j = 4q + reg -- no cross-lane movement, no LDS round trip.  The k order
+// of both products is permuted the same way on the A and the B side (lane q owns k = 16q..16q+15 of the first
+// product), which MFMA permits because it only sums over k.
+#include "common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int NCE_SPLIT = 4;     // column quarters -> (m/16) * 4 workgroups
+constexpr int NCE_MAX_M = 2048;  // rows (2 * batch) whose lse fit the LDS table
+
+
+// S'[j][r] tile: rows j = j0..j0+15 (A operand), columns r = r0..r0+15 (B operand, preloaded in rb[])
+__device__ __forceinline__ f32x4 sim_tile(const float *f, int j0, const float (&rb)[16], int l, int q)
+{
+    const float4 *src = (const float4 *)(f + (int64_t)(j0 + l) * 64 + 16 * q);
+    const float4 a0 = src[0], a1 = src[1], a2 = src[2], a3 = src[3];
+    const float a[16] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x, a2.y, a2.z, a2.w, a3.x, a3.y, a3.z, a3.w};
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks], rb[ks], acc, 0, 0, 0);
+    return acc;
+}
+
+__device__ __forceinline__ void load_rows(const float *f, int r0, int l, int q, float (&rb)[16])
+{
+    const float4 *src = (const float4 *)(f + (int64_t)(r0 + l) * 64 + 16 * q);
+    const float4 b0 = src[0], b1 = src[1], b2 = src[2], b3 = src[3];
+    rb[0] = b0.x; rb[1] = b0.y; rb[2] = b0.z; rb[3] = b0.w; rb[4] = b1.x; rb[5] = b1.y; rb[6] = b1.z; rb[7] = b1.w;
+    rb[8] = b2.x; rb[9] = b2.y; rb[10] = b2.z; rb[11] = b2.w; rb[12] = b3.x; rb[13] = b3.y; rb[14] = b3.z; rb[15] = b3.w;
+}
+
+// pass 1: partial row sums [NCE_SPLIT][m] and the positive logits pos[m]
+__global__ __launch_bounds__(256) void nce_pass1_kernel(const float *f, int m, float inv_t, float *rowsum_part, float *pos)
+{
+    __shared__ float sh[4][16];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, l = lane & 15, q = lane >> 4;
+    const int r0 = blockIdx.x * 16, ntiles = m / 16;
+    const int t0 = (int)((int64_t)blockIdx.y * ntiles / NCE_SPLIT), t1 = (int)((int64_t)(blockIdx.y + 1) * ntiles / NCE_SPLIT);
+    float rb[16];
+    load_rows(f, r0, l, q, rb);
+    const int r = r0 + l, pr = (r + m / 2) % m;
+    float sum = 0.f;
+    for (int t = t0 + wv; t < t1; t += 4) {
+        const f32x4 s = sim_tile(f, t * 16, rb, l, q);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int j = t * 16 + 4 * q + g;
+            const float x = s[g] * inv_t;
+            if (j != r) sum += __expf(x);
+            if (j == pr) pos[r] = x;
+        }
+    }
+    // this lane holds the partial of row r over its j's (q, reg); add the four q groups, then the four waves
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    if (q == 0) sh[wv][l] = sum;
+    __syncthreads();
+    if (threadIdx.x < 16) rowsum_part[(int64_t)blockIdx.y * m + r0 + threadIdx.x] = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+}
+
+// pass 2: lse / loss rows, and the partial products G_part[NCE_SPLIT][m][64]
+__global__ __launch_bounds__(256) void nce_pass2_kernel(const float *f, int m, float inv_t, const float *rowsum_part, const float *pos,
+                                                        float *lse, float *loss_rows, float *G_part)
+{
+    __shared__ float red[4][16][64];     // per-wave G tiles [row][c]
+    __shared__ float lse_sh[NCE_MAX_M];  // lse of every row (each workgroup needs all of them for E^T)
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, l = lane & 15, q = lane >> 4;
+    const int r0 = blockIdx.x * 16, ntiles = m / 16;
+    const int t0 = (int)((int64_t)blockIdx.y * ntiles / NCE_SPLIT), t1 = (int)((int64_t)(blockIdx.y + 1) * ntiles / NCE_SPLIT);
+    for (int i = threadIdx.x; i < m; i += 256) {
+        float sm = 0.f;
+#pragma unroll
+        for (int p = 0; p < NCE_SPLIT; ++p) sm += rowsum_part[(int64_t)p * m + i];
+        lse_sh[i] = __logf(sm);
+    }
+    float rb[16];
+    load_rows(f, r0, l, q, rb);
+    const int r = r0 + l;
+    __syncthreads();
+    const float lse_r = lse_sh[r];
+    if (blockIdx.y == 0 && wv == 0 && q == 0) { lse[r] = lse_r; loss_rows[r] = lse_r - pos[r]; }
+    f32x4 g[4];                           // G[r = 4q+reg][c = 16*ct + l] for ct = 0..3
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) g[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = t0 + wv; t < t1; t += 4) {
+        const int j0 = t * 16;
+        const f32x4 s = sim_tile(f, j0, rb, l, q);
+        float e[4];
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            const int j = j0 + 4 * q + gq;
+            const float x = s[gq] * inv_t;
+            e[gq] = (j == r) ? 0.f : __expf(x - lse_r) + __expf(x - lse_sh[j]);
+        }
+        // G[r][c] += sum_j E[r][j] f[j][c]: A = E[r = l][k -> j = 4q + step], B = f[j0 + 4q + step][16 ct + l]
+#pragma unroll
+        for (int step = 0; step < 4; ++step) {
+            const float *frow = f + (int64_t)(j0 + 4 * q + step) * 64 + l;
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) g[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(e[step], frow[16 * ct], g[ct], 0, 0, 0);
+        }
+    }
+    // C/D layout of g[ct]: row = 4q + reg, col = l  ->  add the four waves through LDS, write [16][64]
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) red[wv][4 * q + reg][16 * ct + l] = g[ct][reg];
+    __syncthreads();
+    float *dst = G_part + ((int64_t)blockIdx.y * m + r0) * 64;
+    for (int i = threadIdx.x; i < 16 * 64; i += 256) {
+        const int rr = i >> 6, c = i & 63;
+        dst[i] = (red[0][rr][c] + red[1][rr][c]) + (red[2][rr][c] + red[3][rr][c]);
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t idl_nce_fused_workspace(int m)
+{
+    if (m < 32 || (m % 32) != 0 || m > NCE_MAX_M) return -1;     // unsupported shape: use idl_nce_rows + GEMMs
+    return ((int64_t)NCE_SPLIT * m + m) * 4;          // partial row sums + positive logits
+}
+
+int idl_nce_fused_parts(void) { return NCE_SPLIT; }
+
+int idl_nce_fused(const float *f, int m, float temperature, float *lse, float *loss_rows, float *G_part, void *workspace,
+                  void *stream)
+{
+    IDL_REQUIRE(f && lse && loss_rows && G_part && workspace, "NULL buffer");
+    IDL_REQUIRE(m >= 32 && (m % 32) == 0 && m <= NCE_MAX_M && temperature > 0.f, "nce_fused: m must be a multiple of 32 in 32..2048, T > 0");
+    IDL_REQUIRE((((uintptr_t)f) & 15u) == 0, "f must be 16-byte aligned");
+    float *rowsum_part = (float *)workspace, *pos = rowsum_part + (size_t)NCE_SPLIT * m;
+    const float inv_t = 1.f / temperature;
+    const dim3 grid((unsigned)(m / 16), NCE_SPLIT);
+    hipLaunchKernelGGL(nce_pass1_kernel, grid, dim3(256), 0, (hipStream_t)stream, f, m, inv_t, rowsum_part, pos);
+    hipLaunchKernelGGL(nce_pass2_kernel, grid, dim3(256), 0, (hipStream_t)stream, f, m, inv_t, (const float *)rowsum_part,
+                       (const float *)pos, lse, loss_rows, G_part);
+    IDL_HIP_TRY(hipGetLastError());
+    return IDL_OK;
+}
+
+}  // extern "C"

@@ -245,8 +245,8 @@ __global__ __launch_bounds__(NT) void iic_core_kernel(float *P0, int C, float la
 // ---------------------------------------------------------------- head backward: one wave per row
 // inputs: z, r2, f, inv, G = (E + E^T) f, dP0 (scaled by w_iic), W3;  outputs: dlogits [m,C], dlat [m,64]
 __global__ __launch_bounds__(256) void head_bwd_kernel(const float *z, const float *r2, const float *f, const float *inv,
-                                                       const float *G, const float *dP0, const float *W3, int m, int C, int train,
-                                                       float nce_coef, float *dlogits, float *dlat)
+                                                       const float *G, int g_parts, const float *dP0, const float *W3, int m, int C,
+                                                       int train, float nce_coef, float *dlogits, float *dlat)
 {
     __shared__ float shz[4][256];
     __shared__ float shd[4][256];
@@ -293,7 +293,9 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float *z, const flo
     float dl_cls = a > 0.f ? dr * (train ? 2.f : 1.f) : 0.f;
     // contrastive branch: df = nce_coef * (G_r - 2 f_pos); through f = lat / ||lat||
     const float fr = f[(int64_t)row * H2 + lane];
-    const float df = nce_coef * (G[(int64_t)row * H2 + lane] - 2.f * f[(int64_t)prow * H2 + lane]);
+    float gsum = G[(int64_t)row * H2 + lane];
+    for (int p = 1; p < g_parts; ++p) gsum += G[((int64_t)p * m + row) * H2 + lane];      // partial slabs of idl_nce_fused
+    const float df = nce_coef * (gsum - 2.f * f[(int64_t)prow * H2 + lane]);
     const float proj = wave_sum(fr * df);
     dlat[(int64_t)row * H2 + lane] = dl_cls + (df - fr * proj) * inv[row];
 }
@@ -448,12 +450,13 @@ int idl_iic_core(float *P0, int C, float lamb, float eps, float w_iic, float *sc
     return IDL_OK;
 }
 
-int idl_head_bwd(const float *z, const float *r2, const float *f, const float *inv, const float *G, const float *dP0,
+int idl_head_bwd(const float *z, const float *r2, const float *f, const float *inv, const float *G, int g_parts, const float *dP0,
                  const float *W3, int m, int C, int train, float nce_coef, float *dlogits, float *dlat, void *stream)
 {
+    IDL_REQUIRE(g_parts >= 1 && g_parts <= 16, "head_bwd: g_parts outside 1..16");
     IDL_REQUIRE(z && r2 && f && inv && G && dP0 && W3 && dlogits && dlat, "NULL buffer");
     IDL_REQUIRE(m >= 2 && (m % 2) == 0 && C >= 1 && C <= 64 * MAX_CPL, "head_bwd: even m, n_clusters in 1..256");
-    hipLaunchKernelGGL(head_bwd_kernel, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, (hipStream_t)stream, z, r2, f, inv, G, dP0, W3, m, C,
+    hipLaunchKernelGGL(head_bwd_kernel, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, (hipStream_t)stream, z, r2, f, inv, G, g_parts, dP0, W3, m, C,
                        train, nce_coef, dlogits, dlat);
     IDL_HIP_TRY(hipGetLastError());
     return IDL_OK;

@@ -353,6 +353,10 @@ struct V2 {
                                                     const uint32_t *msk, uint32_t *hist, uint16_t *list_old, uint16_t *list_new,
                                                     uint32_t s_old, uint32_t s_new, int lane)
     {
+        // all positions are taken relative to `lo` and fit 32 bits (edit positions are < 2^30)
+        const int hi_r = (int)(hi - lo);
+        const int end_r = (int)((L < hi ? L : hi) - lo) - 1;       // last window end handled here
+        const int lo32 = (int)(lo > 0x3FFFFFFF ? 0x3FFFFFFF : lo); // an edit at p has p - lo = p - lo32 whenever it can matter
         int dwin = 0;
         const int npairs = (ne - i0) * K;
         for (int q0 = 0; q0 < npairs; q0 += NT) {
@@ -362,15 +366,14 @@ struct V2 {
             if (q < npairs) {
                 const int ei = i0 + q / K, t = q % K;
                 const uint32_t ed = E[ei];
-                const int64_t p = (int64_t)(ed & 0x3FFFFFFFu);
-                inside = p < hi;
-                int64_t last = p + K - 1;
-                if (ei + 1 < ne) { const int64_t nx = (int64_t)(E[ei + 1] & 0x3FFFFFFFu) - 1; if (nx < last) last = nx; }
-                if (last > L - 1) last = L - 1;
-                if (last > hi - 1) last = hi - 1;
-                const int64_t w = p + t;
-                if (w <= last && w >= lo) {
-                    const uint32_t rel = (uint32_t)(w - lo) + 64u;
+                const int p = (int)(ed & 0x3FFFFFFFu) - lo32;           // relative edit position (may be slightly negative)
+                inside = p < hi_r;
+                int last = p + K - 1;
+                if (ei + 1 < ne) { const int nx = (int)(E[ei + 1] & 0x3FFFFFFFu) - lo32 - 1; if (nx < last) last = nx; }
+                if (last > end_r) last = end_r;
+                const int w = p + t;
+                if (w <= last && w >= 0) {
+                    const uint32_t rel = (uint32_t)w + 64u;
                     const int D = (int)(rel >> 4), j = (int)(rel & 15u);
                     uint64_t ww; uint32_t M;
                     fetch(cod, msk, D, ww, M);
@@ -380,10 +383,10 @@ struct V2 {
                         bool dead = (ed >> 30) == 0u;
                         for (int i = ei - 1; i >= 0; --i) {          // earlier edits that also lie inside this window (rare)
                             const uint32_t e2 = E[i];
-                            const int64_t d = w - (int64_t)(e2 & 0x3FFFFFFFu);
+                            const int d = w - ((int)(e2 & 0x3FFFFFFFu) - lo32);
                             if (d >= K) break;
                             dead |= (e2 >> 30) == 0u;
-                            xm ^= (e2 >> 30) << (2 * (int)d);
+                            xm ^= (e2 >> 30) << (2 * d);
                         }
                         kn = dead ? 0xFFFFu : (ko ^ xm);
                     }
@@ -608,18 +611,19 @@ __global__ __launch_bounds__(64 * V2_WAVES, B16 ? 8 : 6) void vectorise2_kernel(
                 const float Sf = (float)S, rS = 1.0f / Sf;
                 const double Sd = (double)S;
                 if (a.mode == IDL_MODE_KMER && F >= 256 && a.out_kind != IDL_OUT_FREQ_F64) {
+                    typedef float f32x2 __attribute__((ext_vector_type(2)));
+                    const f32x2 rS2 = {rS, rS}, nS2 = {-Sf, -Sf};
                     auto emit = [&](int i4, uint4 h) {         // four consecutive bins starting at 4*i4
                         if (a.out_kind == IDL_OUT_COUNTS_I32) {
                             *(uint4 *)((uint32_t *)a.out + out_base + i4 * 4) = h;
                         } else {
                             float4 f;
-                            if (small) {
-                                const float c0 = (float)h.x, c1 = (float)h.y, c2 = (float)h.z, c3 = (float)h.w;
-                                const float q0 = c0 * rS, q1 = c1 * rS, q2 = c2 * rS, q3 = c3 * rS;
-                                f.x = __builtin_fmaf(__builtin_fmaf(-q0, Sf, c0), rS, q0);
-                                f.y = __builtin_fmaf(__builtin_fmaf(-q1, Sf, c1), rS, q1);
-                                f.z = __builtin_fmaf(__builtin_fmaf(-q2, Sf, c2), rS, q2);
-                                f.w = __builtin_fmaf(__builtin_fmaf(-q3, Sf, c3), rS, q3);
+                            if (small) {                           // q = c * r; q' = fma(fma(-q, S, c), r, q), two bins per packed op
+                                const f32x2 c01 = {(float)h.x, (float)h.y}, c23 = {(float)h.z, (float)h.w};
+                                const f32x2 q01 = c01 * rS2, q23 = c23 * rS2;
+                                const f32x2 o01 = __builtin_elementwise_fma(__builtin_elementwise_fma(q01, nS2, c01), rS2, q01);
+                                const f32x2 o23 = __builtin_elementwise_fma(__builtin_elementwise_fma(q23, nS2, c23), rS2, q23);
+                                f.x = o01.x; f.y = o01.y; f.z = o23.x; f.w = o23.y;
                             } else {
                                 f.x = (float)((double)h.x / Sd); f.y = (float)((double)h.y / Sd);
                                 f.z = (float)((double)h.z / Sd); f.w = (float)((double)h.w / Sd);

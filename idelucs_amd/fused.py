@@ -46,10 +46,14 @@ class _Buffers:
         self.inv = torch.empty((m,), **f32)
         self.r2 = torch.empty((m, H2), **f32)
         self.z = torch.empty((m, C), **f32)
-        self.S = torch.empty((m, m), **f32)
+        self.S = torch.empty((m, m) if not (_L.idl_nce_fused_workspace(m) > 0 and os.environ.get("IDELUCS_NCE_FUSED", "1") != "0") else (1, 1), **f32)
         self.lse = torch.empty((m,), **f32)
         self.loss_rows = torch.empty((m,), **f32)
-        self.G = torch.empty((m, H2), **f32)
+        self.nce_parts = _L.idl_nce_fused_parts()
+        self.nce_ws_bytes = _L.idl_nce_fused_workspace(m)            # -1: shape not supported by the fused InfoNCE kernels
+        self.nce_fused = self.nce_ws_bytes > 0 and os.environ.get("IDELUCS_NCE_FUSED", "1") != "0"
+        self.G = torch.empty((self.nce_parts if self.nce_fused else 1, m, H2), **f32)
+        self.nce_ws = torch.empty(max(self.nce_ws_bytes, 4) // 4, **f32)
         self.P0 = torch.empty((C, C), **f32)
         self.iic_scratch = torch.empty((C * C + 2 * C,), **f32)
         self.dlogits = torch.empty((m, C), **f32)
@@ -121,12 +125,15 @@ class FusedLinearTrainer:
         with torch.cuda.stream(side):
             torch.mm(bf.z[:m // 2].t(), bf.z[m // 2:], out=bf.P0)        # IIC joint, one [C,B]x[B,C] GEMM
             chk(_L.idl_iic_core(_p(bf.P0), C, self.lamb, EPS, self.weight, _p(bf.iic_scratch), _p(self.out), _stream()))
-        torch.mm(bf.f, bf.f.t(), out=bf.S)
-        chk(_L.idl_nce_rows(_p(bf.S), m, TEMPERATURE, _p(bf.lse), _p(bf.loss_rows), _stream()))
-        torch.mm(bf.S, bf.f, out=bf.G)                                   # (E + E^T) f
+        if bf.nce_fused:       # S = f f^T, lse, E + E^T and (E + E^T) f in two MFMA kernels, S never written
+            chk(_L.idl_nce_fused(_p(bf.f), m, TEMPERATURE, _p(bf.lse), _p(bf.loss_rows), _p(bf.G), _p(bf.nce_ws), _stream()))
+        else:
+            torch.mm(bf.f, bf.f.t(), out=bf.S)
+            chk(_L.idl_nce_rows(_p(bf.S), m, TEMPERATURE, _p(bf.lse), _p(bf.loss_rows), _stream()))
+            torch.mm(bf.S, bf.f, out=bf.G[0])                            # (E + E^T) f
         main.wait_stream(side)
         nce_coef = (1.0 - self.weight) / (m * TEMPERATURE)
-        chk(_L.idl_head_bwd(_p(bf.z), _p(bf.r2), _p(bf.f), _p(bf.inv), _p(bf.G), _p(bf.P0), _p(self.W3), m, C, tr,
+        chk(_L.idl_head_bwd(_p(bf.z), _p(bf.r2), _p(bf.f), _p(bf.inv), _p(bf.G), bf.G.shape[0], _p(bf.P0), _p(self.W3), m, C, tr,
                             nce_coef, _p(bf.dlogits), _p(bf.dlat), _stream()))
         # ---- parameter gradients (one launch for the three bias gradients + the ReLU/Dropout backward of layer 1)
         gW1, gb1, gW2, gb2, gW3, gb3 = self.grads

@@ -357,3 +357,34 @@ def test_single_batch_epoch_returns_inf_like_the_reference(dev, tmp_path):
     m.build_dataloader()
     assert m.store.n_pairs == 192
     assert np.isinf(m.contrastive_training_epoch())
+
+
+@pytest.mark.parametrize("B", [16, 64, 512, 480])
+def test_fused_infonce_kernels_vs_torch(dev, B):
+    """idl_nce_fused (fp32 MFMA, S never materialised) against the mask-free torch formulation, which the
+    tests above tie to the reference: loss rows, lse and (E + E^T) f."""
+    import torch
+    from idelucs_amd import _lib
+    from idelucs_amd.fused import _p, _stream
+    L = _lib.lib
+    m = 2 * B
+    torch.manual_seed(B)
+    h = torch.randn(m, 64, device=dev)
+    h[B:] = h[:B] + 0.3 * torch.randn(B, 64, device=dev)           # positives are correlated, like real pairs
+    f = torch.nn.functional.normalize(h, dim=1).contiguous()
+    T = 0.85
+    S = (f.double() @ f.double().t()) / T
+    eye = torch.eye(m, dtype=torch.bool, device=dev)
+    lse_ref = torch.logsumexp(S.masked_fill(eye, float("-inf")), dim=1)
+    pos = (torch.arange(m, device=dev) + B) % m
+    loss_ref = lse_ref - S[torch.arange(m, device=dev), pos]
+    E = torch.exp(S - lse_ref[:, None]).masked_fill(eye, 0.0)
+    G_ref = (E + E.t()) @ f.double()
+    parts = L.idl_nce_fused_parts()
+    ws = torch.empty(L.idl_nce_fused_workspace(m) // 4, device=dev)
+    lse = torch.empty(m, device=dev); rows = torch.empty(m, device=dev); G = torch.empty((parts, m, 64), device=dev)
+    _lib.check(L.idl_nce_fused(_p(f), m, T, _p(lse), _p(rows), _p(G), _p(ws), _stream()))
+    np.testing.assert_allclose(lse.cpu().numpy(), lse_ref.float().cpu().numpy(), rtol=2e-6, atol=2e-6)
+    np.testing.assert_allclose(rows.cpu().numpy(), loss_ref.float().cpu().numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(G.sum(0).cpu().numpy(), G_ref.float().cpu().numpy(), rtol=1e-4, atol=2e-6)
+    assert L.idl_nce_fused_workspace(574) == -1 and L.idl_nce_fused_workspace(4096) == -1      # fallback shapes

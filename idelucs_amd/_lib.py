@@ -44,6 +44,7 @@ SIGNATURES = {
     "idl_gather_pairs_at": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "idl_relu_dropout_fwd": (_int, [_vp, _i64, _int, _c.c_uint64, _vp, _int, _vp]),
     "idl_head_fwd": (_int, [_vp, _vp, _vp, _int, _int, _int, _c.c_uint64, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "idl_mid_fwd": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _int, _c.c_uint64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "idl_nce_rows": (_int, [_vp, _int, _c.c_float, _vp, _vp, _vp]),
     "idl_iic_core": (_int, [_vp, _int, _c.c_float, _c.c_float, _c.c_float, _vp, _vp, _vp]),
     "idl_head_bwd": (_int, [_vp] * 5 + [_int, _vp, _vp, _int, _int, _int, _c.c_float, _vp, _vp, _vp]),

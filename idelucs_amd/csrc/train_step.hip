@@ -81,27 +81,23 @@ __global__ __launch_bounds__(256) void relu_dropout_fwd_kernel(float4 *a, int64_
 }
 
 // ---------------------------------------------------------------- head forward: one wave per row
-// lat[m,64] -> f = lat/max(||lat||,1e-12), inv[m]; r2 = dropout(relu(lat)); z = softmax(r2 W3^T + b3)
-__global__ __launch_bounds__(256) void head_fwd_kernel(const float *lat, const float *W3, const float *b3, int m, int C, int train,
-                                                       uint64_t seed, const int64_t *ctl, float *f, float *inv, float *r2, float *z)
+// x = this lane's latent value lat[row][lane]  ->  f = lat/max(||lat||,1e-12), inv; r2 = dropout(relu(lat));
+// z = softmax(r2 W3^T + b3).  `sh` = 64 floats of LDS private to the calling wave.
+__device__ __forceinline__ void head_row(float x, int row, int lane, float *sh, const float *W3, const float *b3, int C, int train,
+                                         uint64_t seed, uint32_t step, float *f, float *inv, float *r2, float *z)
 {
-    __shared__ float sh[4][H2];
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + w;
-    if (row >= m) return;
-    const float x = lat[(int64_t)row * H2 + lane];
     const float nrm = fmaxf(sqrtf(wave_sum(x * x)), 1e-12f);       // F.normalize(dim=1), eps 1e-12
     f[(int64_t)row * H2 + lane] = x / nrm;
     if (lane == 0) inv[row] = 1.f / nrm;
     float s = 1.f;
     if (train) {
-        const U4 r = philox((uint32_t)row, 2u, (uint32_t)ctl[0], 0u, (uint32_t)seed, (uint32_t)(seed >> 32));
+        const U4 r = philox((uint32_t)row, 2u, step, 0u, (uint32_t)seed, (uint32_t)(seed >> 32));
         const uint32_t word = (lane < 32) ? r.x : r.y;
         s = ((word >> (lane & 31)) & 1u) ? 2.f : 0.f;
     }
     const float a = x > 0.f ? x * s : 0.f;
     r2[(int64_t)row * H2 + lane] = a;
-    sh[w][lane] = a;
+    sh[lane] = a;
     __builtin_amdgcn_wave_barrier();
     float lg[MAX_CPL];
     float mx = -INFINITY;
@@ -113,7 +109,7 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float *lat, const f
             float acc = b3[c];
             const float *wr = W3 + (int64_t)c * H2;
 #pragma unroll 8
-            for (int h = 0; h < H2; ++h) acc = fmaf(sh[w][h], wr[h], acc);
+            for (int h = 0; h < H2; ++h) acc = fmaf(sh[h], wr[h], acc);
             lg[t] = acc;
             mx = fmaxf(mx, acc);
         }
@@ -130,6 +126,82 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float *lat, const f
     for (int t = 0; t < MAX_CPL; ++t) {
         const int c = t * 64 + lane;
         if (c < C) z[(int64_t)row * C + c] = lg[t] / den;
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+__global__ __launch_bounds__(256) void head_fwd_kernel(const float *lat, const float *W3, const float *b3, int m, int C, int train,
+                                                       uint64_t seed, const int64_t *ctl, float *f, float *inv, float *r2, float *z)
+{
+    __shared__ float sh[4][H2];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + w;
+    if (row >= m) return;
+    head_row(lat[(int64_t)row * H2 + lane], row, lane, sh[w], W3, b3, C, train, seed, (uint32_t)ctl[0], f, inv, r2, z);
+}
+
+// ---------------------------------------------------------------- fused middle of the forward pass (fp32 MFMA)
+// a1[m,512] = Linear(F,512) output (bias included).  Per 16-row tile, in one kernel:
+//   r1 = Dropout(ReLU(a1))  (written back in place: the backward needs it)
+//   lat = r1 W2^T + b2      (v_mfma_f32_16x16x4_f32; the four waves split K = 512, partial tiles added through LDS)
+//   head_row() on every row (normalise, ReLU/Dropout, Linear(64,C), softmax)
+// replacing relu_dropout_fwd + one hipBLASLt GEMM + head_fwd.  Same dropout streams as those kernels.
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+constexpr int H1 = 512;
+
+__global__ __launch_bounds__(256) void mid_fwd_kernel(float *a1, const float *W2, const float *b2, const float *W3, const float *b3, int m,
+                                                      int C, int train, uint64_t seed, const int64_t *ctl, float *f, float *inv,
+                                                      float *r2, float *z)
+{
+    __shared__ float part[4][16][H2 + 1];    // per-wave partial lat tiles; +1 breaks the 64-float row stride for the column reads
+    __shared__ float sh[4][H2];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, l = lane & 15, q = lane >> 4;
+    const int r0 = blockIdx.x * 16;
+    const uint32_t step = (uint32_t)ctl[0];
+    // this lane's 32 consecutive k of row r0 + l: k = 128 wv + 32 q + ks
+    const int k0 = 128 * wv + 32 * q;
+    float a[32];
+    {
+        float4 *src = (float4 *)(a1 + (int64_t)(r0 + l) * H1 + k0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float4 v = src[i];
+            float s0 = 1.f, s1 = 1.f, s2 = 1.f, s3 = 1.f;
+            if (train) {                         // identical stream to relu_dropout_fwd_kernel: counter = float4 index of the flat array
+                const int64_t idx4 = ((int64_t)(r0 + l) * H1 + k0) / 4 + i;
+                const U4 r = philox((uint32_t)idx4, 1u, step, (uint32_t)(idx4 >> 32), (uint32_t)seed, (uint32_t)(seed >> 32));
+                s0 = (r.x >> 31) ? 2.f : 0.f; s1 = (r.y >> 31) ? 2.f : 0.f;
+                s2 = (r.z >> 31) ? 2.f : 0.f; s3 = (r.w >> 31) ? 2.f : 0.f;
+            }
+            v.x = v.x > 0.f ? v.x * s0 : 0.f; v.y = v.y > 0.f ? v.y * s1 : 0.f;
+            v.z = v.z > 0.f ? v.z * s2 : 0.f; v.w = v.w > 0.f ? v.w * s3 : 0.f;
+            src[i] = v;
+            a[4 * i] = v.x; a[4 * i + 1] = v.y; a[4 * i + 2] = v.z; a[4 * i + 3] = v.w;
+        }
+    }
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {             // lat[:, 16 ct .. 16 ct + 15]: B[k][c] = W2[16 ct + c][k]
+        const float4 *wsrc = (const float4 *)(W2 + (int64_t)(16 * ct + l) * H1 + k0);
+        f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float4 b = wsrc[i];
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4 * i], b.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4 * i + 1], b.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4 * i + 2], b.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4 * i + 3], b.w, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) part[wv][4 * q + reg][16 * ct + l] = acc[reg];   // C/D: row = 4q+reg, col = l
+    }
+    __syncthreads();
+    // rows 4 wv .. 4 wv + 3 of the tile: add the four K-quarters and the bias, then the per-row head
+    for (int rr = 0; rr < 4; ++rr) {
+        const int row = r0 + 4 * wv + rr, tr = 4 * wv + rr;
+        if (row < m) {
+            const float x = (part[0][tr][lane] + part[1][tr][lane]) + (part[2][tr][lane] + part[3][tr][lane]) + b2[lane];
+            head_row(x, row, lane, sh[wv], W3, b3, C, train, seed, step, f, inv, r2, z);
+        }
     }
 }
 
@@ -423,6 +495,18 @@ int idl_head_fwd(const float *lat, const float *W3, const float *b3, int m, int 
     IDL_REQUIRE(lat && W3 && b3 && ctl && f && inv && r2 && z, "NULL buffer");
     IDL_REQUIRE(m >= 1 && C >= 1 && C <= 64 * MAX_CPL, "head_fwd: n_clusters must be in 1..256");
     hipLaunchKernelGGL(head_fwd_kernel, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, (hipStream_t)stream, lat, W3, b3, m, C, train, seed,
+                       ctl, f, inv, r2, z);
+    IDL_HIP_TRY(hipGetLastError());
+    return IDL_OK;
+}
+
+int idl_mid_fwd(float *a1, const float *W2, const float *b2, const float *W3, const float *b3, int m, int C, int train,
+                uint64_t seed, const int64_t *ctl, float *f, float *inv, float *r2, float *z, void *stream)
+{
+    IDL_REQUIRE(a1 && W2 && b2 && W3 && b3 && ctl && f && inv && r2 && z, "NULL buffer");
+    IDL_REQUIRE(m >= 16 && (m % 16) == 0 && C >= 1 && C <= 64 * MAX_CPL, "mid_fwd: m must be a multiple of 16, n_clusters in 1..256");
+    IDL_REQUIRE((((uintptr_t)a1 | (uintptr_t)W2) & 15u) == 0, "a1 / W2 must be 16-byte aligned");
+    hipLaunchKernelGGL(mid_fwd_kernel, dim3((unsigned)(m / 16)), dim3(256), 0, (hipStream_t)stream, a1, W2, b2, W3, b3, m, C, train, seed,
                        ctl, f, inv, r2, z);
     IDL_HIP_TRY(hipGetLastError());
     return IDL_OK;

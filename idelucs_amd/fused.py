@@ -84,6 +84,9 @@ class FusedLinearTrainer:
         self._bufs = {}
         self._graphs = {}
         self._side = torch.cuda.Stream(device=self.dev)     # second branch of the step (see step_on_batch)
+        # measured on MI355X: correct (tests) but 2 % slower than the three separate kernels (64 workgroups, 4 rows of head
+        # work serialised per wave) -> opt-in only
+        self._mid_fused = self.H1 == 512 and os.environ.get("IDELUCS_MID_FUSED", "0") == "1"
         self._overlap = os.environ.get("IDELUCS_OVERLAP", "0") != "0"   # measured: no gain inside a HIP graph on ROCm 7.2
         self._perm = None
         n = len(self.params)
@@ -116,10 +119,14 @@ class FusedLinearTrainer:
         side = self._side if self._overlap else main
         # ---- forward
         torch.addmm(self.b1, bf.x, self.W1.t(), out=bf.r1)
-        chk(_L.idl_relu_dropout_fwd(_p(bf.r1), bf.r1.numel(), tr, self.seed, _p(self.ctl), 1, _stream()))
-        torch.addmm(self.b2, bf.r1, self.W2.t(), out=bf.lat)
-        chk(_L.idl_head_fwd(_p(bf.lat), _p(self.W3), _p(self.b3), m, C, tr, self.seed, _p(self.ctl),
-                            _p(bf.f), _p(bf.inv), _p(bf.r2), _p(bf.z), _stream()))
+        if self._mid_fused and m % 16 == 0:     # ReLU/Dropout + Linear(512,64) + head in one MFMA kernel
+            chk(_L.idl_mid_fwd(_p(bf.r1), _p(self.W2), _p(self.b2), _p(self.W3), _p(self.b3), m, C, tr, self.seed, _p(self.ctl),
+                               _p(bf.f), _p(bf.inv), _p(bf.r2), _p(bf.z), _stream()))
+        else:
+            chk(_L.idl_relu_dropout_fwd(_p(bf.r1), bf.r1.numel(), tr, self.seed, _p(self.ctl), 1, _stream()))
+            torch.addmm(self.b2, bf.r1, self.W2.t(), out=bf.lat)
+            chk(_L.idl_head_fwd(_p(bf.lat), _p(self.W3), _p(self.b3), m, C, tr, self.seed, _p(self.ctl),
+                                _p(bf.f), _p(bf.inv), _p(bf.r2), _p(bf.z), _stream()))
         # ---- the two losses are independent branches: IIC on the side stream, InfoNCE on the main one
         side.wait_stream(main)
         with torch.cuda.stream(side):

@@ -388,3 +388,35 @@ def test_fused_infonce_kernels_vs_torch(dev, B):
     np.testing.assert_allclose(rows.cpu().numpy(), loss_ref.float().cpu().numpy(), rtol=1e-5, atol=1e-5)
     np.testing.assert_allclose(G.sum(0).cpu().numpy(), G_ref.float().cpu().numpy(), rtol=1e-4, atol=2e-6)
     assert L.idl_nce_fused_workspace(574) == -1 and L.idl_nce_fused_workspace(4096) == -1      # fallback shapes
+
+
+@pytest.mark.parametrize("m,C,train", [(16, 5, 0), (1024, 20, 0), (960, 20, 1), (64, 200, 1)])
+def test_fused_mid_forward_equals_separate_kernels(dev, m, C, train):
+    """idl_mid_fwd (ReLU/Dropout + Linear(512,64) on fp32 MFMA + head) == idl_relu_dropout_fwd + addmm + idl_head_fwd,
+    including the dropout masks (same Philox streams)."""
+    import torch
+    from idelucs_amd import _lib
+    from idelucs_amd.fused import _p, _stream
+    L = _lib.lib
+    torch.manual_seed(m + C)
+    a1 = torch.randn(m, 512, device=dev)
+    W2 = torch.randn(64, 512, device=dev) * 0.06; b2 = torch.randn(64, device=dev) * 0.1
+    W3 = torch.randn(C, 64, device=dev) * 0.2; b3 = torch.randn(C, device=dev) * 0.1
+    ctl = torch.tensor([3, 0], dtype=torch.int64, device=dev)
+    seed = 12345
+    def outs():
+        return [torch.empty(m, 64, device=dev), torch.empty(m, device=dev), torch.empty(m, 64, device=dev), torch.empty(m, C, device=dev)]
+    # separate kernels
+    r1a = a1.clone()
+    _lib.check(L.idl_relu_dropout_fwd(_p(r1a), r1a.numel(), train, seed, _p(ctl), 1, _stream()))
+    lat = torch.addmm(b2, r1a, W2.t())
+    fa, ia, r2a, za = outs()
+    _lib.check(L.idl_head_fwd(_p(lat), _p(W3), _p(b3), m, C, train, seed, _p(ctl), _p(fa), _p(ia), _p(r2a), _p(za), _stream()))
+    # fused
+    r1b = a1.clone()
+    fb, ib, r2b, zb = outs()
+    _lib.check(L.idl_mid_fwd(_p(r1b), _p(W2), _p(b2), _p(W3), _p(b3), m, C, train, seed, _p(ctl), _p(fb), _p(ib), _p(r2b), _p(zb), _stream()))
+    assert torch.equal(r1a, r1b)                                        # same ReLU/Dropout result, bit for bit
+    assert torch.equal(r2a != 0, r2b != 0) or (r2a != 0).ne(r2b != 0).float().mean() < 1e-3   # same latent dropout mask (sign flips at ~0 aside)
+    for x, y, tol in ((fa, fb, 2e-5), (ia, ib, 2e-5), (r2a, r2b, 2e-4), (za, zb, 2e-5)):
+        np.testing.assert_allclose(y.cpu().numpy(), x.cpu().numpy(), rtol=2e-4, atol=tol)

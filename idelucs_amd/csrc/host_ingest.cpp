@@ -65,13 +65,127 @@ void pack_one(const uint8_t *seq, int64_t len, uint8_t *codes, uint8_t *mask)
 
 }  // namespace
 
+// ------------------------------------------------------------------------------------------------
+// FASTA reader.  The reference walks the file line by line in Python (utils.py:137-188, :224-260); here
+// the file is read once, header lines are located by a parallel newline scan, the record table is built
+// by the reference's state machine applied to the header lines only, and records are validated / counted
+// and later translated + packed by a pool of threads straight from the raw bytes (no cleaned copy
+// unless the caller asks for one).  Semantics kept exactly, including the quirks: sequence lines seen
+// before a record id is set (file start, or after an empty-id header) roll into the next flushed record
+// (`lines` is only reset on a flush, utils.py:184/257); the first failing record in file order decides
+// the error.
+// ------------------------------------------------------------------------------------------------
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <thread>
+
+namespace {
+
+struct Rec {
+    size_t id_b, id_e;       // id bytes in buf (line[1:-1])
+    size_t data_b, data_e;   // file range whose non-'#', non-'>' lines are this record's sequence
+    int64_t len;             // cleaned length
+};
+
+int n_threads()
+{
+    if (const char *e = getenv("IDELUCS_THREADS")) { const int t = atoi(e); if (t >= 1 && t <= 256) return t; }
+    unsigned hc = std::thread::hardware_concurrency();
+    if (hc == 0) hc = 1;
+    return (int)(hc > 16 ? 16 : hc);
+}
+
+size_t par_min_bytes()                  // files smaller than this are handled by one thread
+{
+    if (const char *e = getenv("IDELUCS_PAR_MIN")) return (size_t)atoll(e);
+    return (size_t)1 << 22;
+}
+
+template <typename F>
+void parallel_for(int nt, F &&fn)       // fn(thread index)
+{
+    if (nt <= 1) { fn(0); return; }
+    std::vector<std::thread> th;
+    for (int t = 1; t < nt; ++t) th.emplace_back([&fn, t]() { fn(t); });
+    fn(0);
+    for (auto &x : th) x.join();
+}
+
+// streaming 2-bit packer (first base in the top pair of each word; invalid-mask bit 31-j per base)
+struct Packer {
+    uint32_t *cw, *mw;
+    uint32_t c = 0, m = 0;
+    int j = 0;
+    int64_t w = 0;
+    inline void push(unsigned code)
+    {
+        if (code == 4u) m |= 0x8000u >> j;
+        else c |= (uint32_t)code << (30 - 2 * j);
+        if (++j == 16) flush_word();
+    }
+    inline void flush_word()
+    {
+        cw[w] = c;
+        if ((w & 1) == 0) mw[w >> 1] = m << 16; else mw[w >> 1] |= m;
+        ++w; c = 0; m = 0; j = 0;
+    }
+    void finish(int64_t slots)
+    {
+        if (j > 0) { for (int t = j; t < 16; ++t) m |= 0x8000u >> t; j = 16; flush_word(); }
+        while (w < slots * 4) { c = 0; m = 0xFFFFu; flush_word(); }
+    }
+};
+
+enum { REC_OK = 0, REC_BAD_HEADER = 1, REC_TAB = 2, REC_BAD_BASE = 3 };
+
+// Walk the sequence bytes of one record.  emit(byte) is called for every byte that survives strip (+ check_sequence's
+// delete table when `check`); returns REC_BAD_BASE with *bad = offending byte when `check` finds an invalid one.
+template <typename Emit>
+inline int walk_record(const uint8_t *buf, const Rec &r, int check, Emit &&emit, uint8_t *bad)
+{
+    const uint8_t *p = buf + r.data_b, *end = buf + r.data_e;
+    while (p < end) {
+        const uint8_t *nl = (const uint8_t *)memchr(p, '\n', (size_t)(end - p));
+        const uint8_t *le = nl ? nl + 1 : end;
+        if (*p != '#' && *p != '>') {
+            const uint8_t *a = p, *b = le;
+            while (a < b && py_bytes_space(*a)) ++a;
+            while (b > a && py_bytes_space(b[-1])) --b;
+            if (check) {
+                for (; a < b; ++a) {
+                    const uint8_t t = T.translate[*a];
+                    if (t == 0) continue;
+                    if (t == 1) { *bad = *a; return REC_BAD_BASE; }
+                    emit(t);
+                }
+            } else {
+                for (; a < b; ++a) emit(*a);
+            }
+        }
+        p = le;
+    }
+    return REC_OK;
+}
+
+}  // namespace
+
+struct FileMap {                  // read-only view of the whole file (mmap; empty files map to nothing)
+    const uint8_t *p = nullptr;
+    size_t n = 0;
+    const uint8_t *data() const { return p; }
+    size_t size() const { return n; }
+    ~FileMap() { if (p && n) munmap((void *)p, n); }
+};
+
 struct idl_fasta {
-    std::vector<uint8_t> names;
-    std::vector<int64_t> name_off{0};
-    std::vector<int64_t> lengths;
-    std::vector<uint8_t> bytes;
-    std::vector<int64_t> byte_off{0};
-    int64_t total_slots = 0;
+    FileMap buf;
+    std::vector<Rec> recs;
+    int check = 1;
+    int64_t total_bases = 0, total_slots = 0, names_bytes = 0;
 };
 
 extern "C" {
@@ -103,13 +217,17 @@ int idl_pack(const uint8_t *bytes, const int64_t *byte_off, int64_t n, uint8_t *
         const int64_t len = byte_off[s + 1] - byte_off[s];
         IDL_REQUIRE(len >= 0, "byte_off not ascending");
         slot_off[s] = slot;
-        if (len > 0) {
-            IDL_REQUIRE(bytes && codes && mask, "NULL buffer");
-            pack_one(bytes + byte_off[s], len, codes + slot * 16, mask + slot * 8);
-        }
         slot += (len + 63) / 64;
     }
     slot_off[n] = slot;
+    if (slot > 0) IDL_REQUIRE(bytes && codes && mask, "NULL buffer");
+    const int nt = (n >= 64) ? n_threads() : 1;
+    parallel_for(nt, [&](int t) {
+        for (int64_t s = n * t / nt; s < n * (t + 1) / nt; ++s) {
+            const int64_t len = byte_off[s + 1] - byte_off[s];
+            if (len > 0) pack_one(bytes + byte_off[s], len, codes + slot_off[s] * 16, mask + slot_off[s] * 8);
+        }
+    });
     return IDL_OK;
 }
 
@@ -117,92 +235,114 @@ int idl_fasta_open(const char *path, int check, idl_fasta **out)
 {
     IDL_REQUIRE(path && out, "NULL argument");
     *out = nullptr;
-    FILE *fp = fopen(path, "rb");
-    if (!fp) { idl::set_error("cannot open %s", path); return IDL_ERR_IO; }
-    std::vector<uint8_t> buf;
-    {
-        fseek(fp, 0, SEEK_END);
-        const long sz = ftell(fp);
-        fseek(fp, 0, SEEK_SET);
-        if (sz < 0) { fclose(fp); idl::set_error("cannot size %s", path); return IDL_ERR_IO; }
-        buf.resize((size_t)sz);
-        if (sz > 0 && fread(buf.data(), 1, (size_t)sz, fp) != (size_t)sz) {
-            fclose(fp); idl::set_error("short read on %s", path); return IDL_ERR_IO;
-        }
-        fclose(fp);
-    }
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) { idl::set_error("cannot open %s", path); return IDL_ERR_IO; }
+    struct stat st;
+    if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode)) { close(fd); idl::set_error("cannot size %s", path); return IDL_ERR_IO; }
     idl_fasta *f = new idl_fasta();
-    std::vector<uint8_t> cur;          // joined, stripped lines of the current record ("lines" in the reference)
-    std::string seq_id;                // raw bytes of the id ("" = none yet)
-    int rc = IDL_OK;
+    f->check = check;
+    if (st.st_size > 0) {
+        void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (m == MAP_FAILED) { close(fd); delete f; idl::set_error("cannot map %s", path); return IDL_ERR_IO; }
+        (void)madvise(m, (size_t)st.st_size, MADV_SEQUENTIAL);
+        f->buf.p = (const uint8_t *)m;
+        f->buf.n = (size_t)st.st_size;
+    }
+    close(fd);
+    const uint8_t *buf = f->buf.data();
+    const size_t size = f->buf.size();
+    const int nt = (size > par_min_bytes() && size >= 64) ? n_threads() : 1;
 
-    auto flush = [&]() -> int {
-        // utils.py:37-40 header checks (check_sequence is only called when check != 0)
-        if (check) {
-            if (!seq_id.empty()) {
-                const uint8_t h0 = (uint8_t)seq_id[0];
-                if (h0 == '>' || h0 == '#' || py_bytes_space(h0) || (h0 >= 0x1c && h0 <= 0x1f)) {
-                    idl::set_error("Bad character in sequence header");
-                    return IDL_ERR_HEADER;
-                }
-            }
-            if (seq_id.find('\t') != std::string::npos) {
-                idl::set_error("tab included in header");
-                return IDL_ERR_HEADER;
-            }
+    // 1. header lines ('>' at a line start), found by a parallel newline scan
+    std::vector<std::vector<size_t>> hdr((size_t)nt);
+    parallel_for(nt, [&](int t) {
+        const size_t b = size * (size_t)t / (size_t)nt, e = size * (size_t)(t + 1) / (size_t)nt;
+        size_t p = b;
+        if (b == 0) { if (size > 0 && buf[0] == '>') hdr[t].push_back(0); }
+        while (p < e) {
+            const uint8_t *nl = (const uint8_t *)memchr(buf + p, '\n', e - p);
+            if (!nl) break;
+            p = (size_t)(nl - buf) + 1;
+            if (p < size && buf[p] == '>') hdr[t].push_back(p);
         }
-        const size_t start = f->bytes.size();
-        if (check) {
-            f->bytes.resize(start + cur.size());
-            int64_t n = 0;
-            uint8_t *dst = f->bytes.data() + start;
-            for (size_t i = 0; i < cur.size(); ++i) {
-                const uint8_t t = T.translate[cur[i]];
-                if (t == 0) continue;
-                if (t == 1) {
-                    idl::set_error("Invalid DNA byte in sequence %s: '%s'", seq_id.c_str(), chr_utf8(cur[i]).c_str());
-                    return IDL_ERR_BASE;
-                }
-                dst[n++] = t;
-            }
-            f->bytes.resize(start + (size_t)n);
-        } else {
-            f->bytes.insert(f->bytes.end(), cur.begin(), cur.end());
-        }
-        const int64_t len = (int64_t)(f->bytes.size() - start);
-        f->names.insert(f->names.end(), seq_id.begin(), seq_id.end());
-        f->name_off.push_back((int64_t)f->names.size());
-        f->lengths.push_back(len);
-        f->byte_off.push_back((int64_t)f->bytes.size());
-        f->total_slots += (len + 63) / 64;
-        return IDL_OK;
+    });
+
+    // 2. the reference's state machine over the header lines
+    std::string dummy;
+    size_t cur_b = 0;
+    bool have_id = false;
+    size_t id_b = 0, id_e = 0;
+    auto line_end = [&](size_t hs) -> size_t {
+        const uint8_t *nl = (const uint8_t *)memchr(buf + hs, '\n', size - hs);
+        return nl ? (size_t)(nl - buf) + 1 : size;
     };
-
-    const uint8_t *p = buf.data(), *end = p + buf.size();
-    while (p < end) {
-        const uint8_t *nl = (const uint8_t *)memchr(p, '\n', (size_t)(end - p));
-        const uint8_t *le = nl ? nl + 1 : end;  // line = [p, le), includes the '\n' when present
-        if (*p == '#') {
-            // ignored
-        } else if (*p == '>') {
-            if (!seq_id.empty()) {
-                rc = flush();
-                if (rc != IDL_OK) break;
-                cur.clear();  // NB utils.py:184/257: `lines` is reset only on a flush
+    for (int t = 0; t < nt; ++t) {
+        for (size_t hs : hdr[t]) {
+            const size_t he = line_end(hs);
+            if (have_id && id_e > id_b) {            // seq_id != "": flush, `lines` restart after this header
+                f->recs.push_back(Rec{id_b, id_e, cur_b, hs, 0});
+                cur_b = he;
             }
             // id = line[1:-1]: drops exactly one trailing byte whatever it is
-            const int64_t l = le - p;
-            seq_id.assign((const char *)p + 1, (size_t)(l >= 2 ? l - 2 : 0));
-        } else {
-            const uint8_t *a = p, *b = le;
-            while (a < b && py_bytes_space(*a)) ++a;
-            while (b > a && py_bytes_space(b[-1])) --b;
-            cur.insert(cur.end(), a, b);
+            id_b = hs + 1;
+            id_e = (he - hs >= 2) ? he - 1 : id_b;
+            if (id_e < id_b) id_e = id_b;
+            have_id = true;
         }
-        p = le;
     }
-    if (rc == IDL_OK) rc = flush();  // unconditional flush at EOF (an empty file yields one empty record with id "")
-    if (rc != IDL_OK) { delete f; return rc; }
+    f->recs.push_back(Rec{have_id ? id_b : 0, have_id ? id_e : 0, cur_b, size, 0});   // unconditional flush at EOF
+
+    // 3. validate + count, in parallel; the first failing record in file order decides the error
+    const int64_t n = (int64_t)f->recs.size();
+    const int nt2 = (size > par_min_bytes() && n >= 2) ? n_threads() : 1;
+    std::vector<int64_t> first_bad((size_t)nt2, -1);
+    std::vector<int> bad_kind((size_t)nt2, REC_OK);
+    std::vector<uint8_t> bad_byte((size_t)nt2, 0);
+    // balance by bytes: thread t takes the records whose data starts in its slice of the file
+    std::vector<int64_t> cut((size_t)nt2 + 1, n);
+    cut[0] = 0;
+    {
+        int t = 1;
+        for (int64_t i = 0; i < n && t < nt2; ++i)
+            while (t < nt2 && f->recs[(size_t)i].data_b >= size * (size_t)t / (size_t)nt2) cut[(size_t)t++] = i;
+    }
+    parallel_for(nt2, [&](int t) {
+        for (int64_t i = cut[(size_t)t]; i < cut[(size_t)t + 1]; ++i) {
+            Rec &r = f->recs[(size_t)i];
+            int kind = REC_OK;
+            uint8_t bb = 0;
+            if (check) {                             // utils.py:37-40 header checks
+                if (r.id_e > r.id_b) {
+                    const uint8_t h0 = buf[r.id_b];
+                    if (h0 == '>' || h0 == '#' || py_bytes_space(h0) || (h0 >= 0x1c && h0 <= 0x1f)) kind = REC_BAD_HEADER;
+                }
+                if (kind == REC_OK && memchr(buf + r.id_b, '\t', r.id_e - r.id_b)) kind = REC_TAB;
+            }
+            if (kind == REC_OK) {
+                int64_t cnt = 0;
+                kind = walk_record(buf, r, check, [&](uint8_t) { ++cnt; }, &bb);
+                r.len = cnt;
+            }
+            if (kind != REC_OK) { first_bad[(size_t)t] = i; bad_kind[(size_t)t] = kind; bad_byte[(size_t)t] = bb; break; }
+        }
+    });
+    for (int t = 0; t < nt2; ++t) {
+        if (first_bad[(size_t)t] >= 0) {
+            const Rec &r = f->recs[(size_t)first_bad[(size_t)t]];
+            const std::string id((const char *)buf + r.id_b, r.id_e - r.id_b);
+            int rc = IDL_ERR_HEADER;
+            if (bad_kind[(size_t)t] == REC_BAD_HEADER) idl::set_error("Bad character in sequence header");
+            else if (bad_kind[(size_t)t] == REC_TAB) idl::set_error("tab included in header");
+            else { idl::set_error("Invalid DNA byte in sequence %s: '%s'", id.c_str(), chr_utf8(bad_byte[(size_t)t]).c_str()); rc = IDL_ERR_BASE; }
+            delete f;
+            return rc;
+        }
+    }
+    for (const Rec &r : f->recs) {
+        f->total_bases += r.len;
+        f->total_slots += (r.len + 63) / 64;
+        f->names_bytes += (int64_t)(r.id_e - r.id_b);
+    }
     *out = f;
     return IDL_OK;
 }
@@ -213,10 +353,10 @@ int idl_fasta_sizes(const idl_fasta *f, int64_t *n_records, int64_t *total_bases
                     int64_t *names_bytes)
 {
     IDL_REQUIRE(f, "NULL handle");
-    if (n_records) *n_records = (int64_t)f->lengths.size();
-    if (total_bases) *total_bases = (int64_t)f->bytes.size();
+    if (n_records) *n_records = (int64_t)f->recs.size();
+    if (total_bases) *total_bases = f->total_bases;
     if (total_slots) *total_slots = f->total_slots;
-    if (names_bytes) *names_bytes = (int64_t)f->names.size();
+    if (names_bytes) *names_bytes = f->names_bytes;
     return IDL_OK;
 }
 
@@ -224,16 +364,46 @@ int idl_fasta_export(const idl_fasta *f, uint8_t *names, int64_t *name_off, int6
                      uint8_t *bytes, int64_t *byte_off, uint8_t *codes, uint8_t *mask, int64_t *slot_off)
 {
     IDL_REQUIRE(f, "NULL handle");
-    const int64_t n = (int64_t)f->lengths.size();
-    if (names && !f->names.empty()) memcpy(names, f->names.data(), f->names.size());
-    if (name_off) memcpy(name_off, f->name_off.data(), (size_t)(n + 1) * sizeof(int64_t));
-    if (lengths && n) memcpy(lengths, f->lengths.data(), (size_t)n * sizeof(int64_t));
-    if (bytes && !f->bytes.empty()) memcpy(bytes, f->bytes.data(), f->bytes.size());
-    if (byte_off) memcpy(byte_off, f->byte_off.data(), (size_t)(n + 1) * sizeof(int64_t));
-    if (codes) {
-        IDL_REQUIRE(mask && slot_off, "codes given without mask/slot_off");
-        return idl_pack(f->bytes.data(), f->byte_off.data(), n, codes, mask, slot_off);
+    IDL_REQUIRE(!codes || (mask && slot_off), "codes given without mask/slot_off");
+    const int64_t n = (int64_t)f->recs.size();
+    const uint8_t *buf = f->buf.data();
+    std::vector<int64_t> boff((size_t)n + 1, 0), soff((size_t)n + 1, 0);
+    int64_t noff = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        const Rec &r = f->recs[(size_t)i];
+        if (name_off) name_off[i] = noff;
+        if (names && r.id_e > r.id_b) memcpy(names + noff, buf + r.id_b, r.id_e - r.id_b);
+        noff += (int64_t)(r.id_e - r.id_b);
+        if (lengths) lengths[i] = r.len;
+        boff[(size_t)i + 1] = boff[(size_t)i] + r.len;
+        soff[(size_t)i + 1] = soff[(size_t)i] + (r.len + 63) / 64;
     }
+    if (name_off) name_off[n] = noff;
+    if (byte_off) memcpy(byte_off, boff.data(), (size_t)(n + 1) * sizeof(int64_t));
+    if (slot_off) memcpy(slot_off, soff.data(), (size_t)(n + 1) * sizeof(int64_t));
+    if (!bytes && !codes) return IDL_OK;
+    const int nt = (f->buf.size() > par_min_bytes() && n >= 2) ? n_threads() : 1;
+    const int64_t total = boff[(size_t)n];
+    parallel_for(nt, [&](int t) {
+        // balance by cleaned bases
+        const int64_t lo = total * t / nt, hi = total * (t + 1) / nt;
+        int64_t i0 = std::lower_bound(boff.begin(), boff.begin() + n, lo) - boff.begin();
+        int64_t i1 = (t == nt - 1) ? n : std::lower_bound(boff.begin(), boff.begin() + n, hi) - boff.begin();
+        if (t == 0) i0 = 0;
+        for (int64_t i = i0; i < i1; ++i) {
+            const Rec &r = f->recs[(size_t)i];
+            uint8_t bb = 0;
+            uint8_t *bdst = bytes ? bytes + boff[(size_t)i] : nullptr;
+            if (codes) {
+                Packer pk{(uint32_t *)(codes + soff[(size_t)i] * 16), (uint32_t *)(mask + soff[(size_t)i] * 8)};
+                if (bdst) (void)walk_record(buf, r, f->check, [&](uint8_t c) { *bdst++ = c; pk.push(T.code[c]); }, &bb);
+                else (void)walk_record(buf, r, f->check, [&](uint8_t c) { pk.push(T.code[c]); }, &bb);
+                pk.finish((r.len + 63) / 64);
+            } else {
+                (void)walk_record(buf, r, f->check, [&](uint8_t c) { *bdst++ = c; }, &bb);
+            }
+        }
+    });
     return IDL_OK;
 }
 

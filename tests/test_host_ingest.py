@@ -148,3 +148,76 @@ def test_compute_entry_points_fail_loudly_without_gpu():
     with pytest.raises(ValueError) as e:
         idelucs_amd.kmer_counts(bytearray(b"ACGT"), 2, np.zeros(16, np.int64))
     assert "expected 'int' but got 'long'" in str(e.value)
+
+
+def _random_fasta(path, rng, n, with_noise=True):
+    alpha = np.frombuffer(b"ACGTacgtNnRYKM-Uu", np.uint8)
+    with open(path, "wb") as f:
+        for i in range(n):
+            L = int(rng.integers(0, 400))
+            pr = np.array([.2, .2, .2, .2, .03, .03, .03, .03, .01, .01, .01, .01, .01, .01, .01, .01, .01]); pr /= pr.sum()
+            s = rng.choice(alpha, size=L, p=pr).tobytes()
+            if with_noise and i % 7 == 3:
+                f.write(b"# a comment between records\n")
+            f.write(b">rec%d some description %d\n" % (i, i * i))
+            w_ = int(rng.integers(20, 90))
+            for a in range(0, L, w_):
+                eol = b"\r\n" if (with_noise and i % 5 == 2) else b"\n"
+                pad = b"  " if (with_noise and i % 11 == 4) else b""
+                f.write(pad + s[a:a + w_] + pad + eol)
+
+
+@pytest.mark.parametrize("threads", ["1", "3", "8"])
+def test_threaded_reader_equals_oracle(tmp_path, monkeypatch, threads):
+    """The parallel reader (forced on for small files) reproduces the reference's sequential state machine:
+    wrapped lines, CRLF, padded lines, comments, lower case / IUPAC / gaps, empty records."""
+    monkeypatch.setenv("IDELUCS_THREADS", threads)
+    monkeypatch.setenv("IDELUCS_PAR_MIN", "0")
+    rng = np.random.default_rng(int(threads))
+    p = str(tmp_path / "r.fas")
+    _random_fasta(p, rng, 300)
+    for check in (True, False):
+        ff = U.FastaFile(p, check=check, keep_bytes=True)
+        recs = list(O.fasta_records(p, check=check))
+        assert ff.names == [r[0] for r in recs] and ff.lengths.tolist() == [len(r[1]) for r in recs]
+        assert [bytes(ff.record(i)) for i in range(ff.n)] == [bytes(r[1]) for r in recs]
+        for i, (_, s) in enumerate(recs):
+            codes, mask = O.pack(s)
+            a, b = ff.slot_off[i], ff.slot_off[i + 1]
+            assert np.array_equal(ff.codes[a * 16:b * 16], codes) and np.array_equal(ff.mask[a * 8:b * 8], mask), i
+
+
+@pytest.mark.parametrize("content", [
+    b"ACGT\nAC\n>first\nGGGG\n>second\nTT\n",              # sequence lines before the first header join the first record
+    b">a\nAC\n>\nGG\n>b\nTT\n>c\nAA\n",                    # an empty-id header: its lines roll into the next flushed record
+    b">\nAC\n",                                                # only an empty id: one record "" at EOF
+    b">x\n>y\n>z\nACGT",                                       # empty records, no trailing newline
+    b"\n\n>q\n\nAC\n\n\nGT\n\n",                              # blank lines
+    b">only header no newline",                                 # id loses its last byte (line[1:-1])
+])
+def test_reader_quirks_match_reference_state_machine(tmp_path, monkeypatch, content):
+    p = tmp_path / "q.fas"
+    p.write_bytes(content)
+    want = list(O.fasta_records(str(p)))
+    for threads, par_min in (("1", None), ("4", "0")):
+        monkeypatch.setenv("IDELUCS_THREADS", threads)
+        if par_min is not None:
+            monkeypatch.setenv("IDELUCS_PAR_MIN", par_min)
+        ff = U.FastaFile(str(p), keep_bytes=True)
+        assert ff.names == [r[0] for r in want], (threads, ff.names)
+        assert [bytes(ff.record(i)) for i in range(ff.n)] == [bytes(r[1]) for r in want]
+
+
+def test_first_error_in_file_order_wins(tmp_path, monkeypatch):
+    monkeypatch.setenv("IDELUCS_THREADS", "6")
+    monkeypatch.setenv("IDELUCS_PAR_MIN", "0")
+    body = b"".join(b">r%d\nACGTACGTAC\n" % i for i in range(200))
+    bad = body.replace(b">r150\nACGT", b">r150\nAC!T").replace(b">r40\nACGT", b">r40\nAZGT").replace(b">r90\n", b">r\t90\n")
+    p = tmp_path / "e.fas"
+    p.write_bytes(bad)
+    with pytest.raises(ValueError) as e:
+        U.FastaFile(str(p))
+    assert str(e.value) == "Invalid DNA byte in sequence r40: 'Z'"
+    with pytest.raises(ValueError) as e2:
+        list(O.fasta_records(str(p)))
+    assert str(e2.value) == str(e.value)

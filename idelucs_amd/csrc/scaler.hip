@@ -96,6 +96,15 @@ __device__ __forceinline__ float std_f32(float x, double m, double s)
     return (float)((double)t / s);
 }
 
+// same result with a precomputed r = RN(1/s): q = t r, q' = fma(fma(-q, s, t), r, q) is the correctly rounded float64
+// quotient (Markstein; 3.8e9 random (t, s) pairs checked against IEEE division, tools/markstein_check_f64.c)
+__device__ __forceinline__ float std_f32_rcp(float x, double m, double s, double r)
+{
+    const double t = (double)(float)((double)x - m);
+    const double q = t * r;
+    return (float)fma(fma(-q, s, t), r, q);
+}
+
 // float64 in: float64 arithmetic throughout, one final rounding to float32 (models.py:163 .type(dtype))
 __device__ __forceinline__ float std_f64(double x, double m, double s) { return (float)((x - m) / s); }
 
@@ -128,7 +137,8 @@ __global__ __launch_bounds__(256) void standardise_scalar(const T *x, int64_t to
 // one workgroup per output row; rows [0, batch) are the "true" halves, [batch, 2*batch) the "modified" ones
 __global__ __launch_bounds__(256) void gather_pairs_kernel(const float *feats, int64_t n, int64_t f, int64_t view_stride,
                                                            const int64_t *pair_idx, const int64_t *base, int64_t batch,
-                                                           const double *mean, const double *scale, float *y)
+                                                           const double *mean, const double *scale, const double *inv_scale,
+                                                           float *y)
 {
     const int64_t row = blockIdx.x;
     const int64_t b = row < batch ? row : row - batch;
@@ -143,10 +153,17 @@ __global__ __launch_bounds__(256) void gather_pairs_kernel(const float *feats, i
             const float4 v = src4[i];
             const int64_t c = i * 4;
             float4 o;
-            o.x = std_f32(v.x, mean[c + 0], scale[c + 0]);
-            o.y = std_f32(v.y, mean[c + 1], scale[c + 1]);
-            o.z = std_f32(v.z, mean[c + 2], scale[c + 2]);
-            o.w = std_f32(v.w, mean[c + 3], scale[c + 3]);
+            if (inv_scale != nullptr) {
+                o.x = std_f32_rcp(v.x, mean[c + 0], scale[c + 0], inv_scale[c + 0]);
+                o.y = std_f32_rcp(v.y, mean[c + 1], scale[c + 1], inv_scale[c + 1]);
+                o.z = std_f32_rcp(v.z, mean[c + 2], scale[c + 2], inv_scale[c + 2]);
+                o.w = std_f32_rcp(v.w, mean[c + 3], scale[c + 3], inv_scale[c + 3]);
+            } else {
+                o.x = std_f32(v.x, mean[c + 0], scale[c + 0]);
+                o.y = std_f32(v.y, mean[c + 1], scale[c + 1]);
+                o.z = std_f32(v.z, mean[c + 2], scale[c + 2]);
+                o.w = std_f32(v.w, mean[c + 3], scale[c + 3]);
+            }
             dst4[i] = o;
         }
     } else {
@@ -222,18 +239,18 @@ int idl_standardise(const void *x, int is_f64, int64_t n, int64_t f, const doubl
 
 int idl_gather_pairs_at(const float *feats, int64_t n, int64_t f, int64_t view_stride,
                         const int64_t *pair_idx, const int64_t *base, int64_t batch, const double *mean,
-                        const double *scale, float *y, void *stream);
+                        const double *scale, const double *inv_scale, float *y, void *stream);
 
 int idl_gather_pairs(const float *feats, int64_t n, int64_t f, int64_t view_stride,
                      const int64_t *pair_idx, int64_t batch, const double *mean, const double *scale,
                      float *y, void *stream)
 {
-    return idl_gather_pairs_at(feats, n, f, view_stride, pair_idx, nullptr, batch, mean, scale, y, stream);
+    return idl_gather_pairs_at(feats, n, f, view_stride, pair_idx, nullptr, batch, mean, scale, nullptr, y, stream);
 }
 
 int idl_gather_pairs_at(const float *feats, int64_t n, int64_t f, int64_t view_stride,
                         const int64_t *pair_idx, const int64_t *base, int64_t batch, const double *mean,
-                        const double *scale, float *y, void *stream)
+                        const double *scale, const double *inv_scale, float *y, void *stream)
 {
     IDL_REQUIRE(n >= 1 && f >= 1 && batch >= 0, "gather_pairs needs n >= 1, f >= 1, batch >= 0");
     if (batch == 0) return IDL_OK;
@@ -244,7 +261,7 @@ int idl_gather_pairs_at(const float *feats, int64_t n, int64_t f, int64_t view_s
     int rc = idl::device_info(&di);
     if (rc != IDL_OK) return rc;
     hipLaunchKernelGGL(gather_pairs_kernel, dim3((unsigned)(2 * batch)), dim3(256), 0, (hipStream_t)stream, feats, n, f,
-                       view_stride, pair_idx, base, batch, mean, scale, y);
+                       view_stride, pair_idx, base, batch, mean, scale, inv_scale, y);
     IDL_HIP_TRY(hipGetLastError());
     return IDL_OK;
 }

@@ -1,13 +1,13 @@
 // vectorise.hip -- the k-mer / CGR / canonical vectoriser for gfx950 (MI355X).
 //
-// One wavefront (64 lanes) per sequence.  The wave walks the packed sequence in chunks of
-// 64 slots (= 4096 bases: one 16-byte code load + one 8-byte mask load per lane, fully
-// coalesced), applies the view's substitution edits through a 1.5 KiB LDS staging image,
-// and bumps a wave-private 4^k-bin uint32 histogram in LDS with ds_add_u32.  After the last
-// chunk the histogram is read back once, converted (pseudocount / normalise / CGR permutation /
-// reverse-complement collapse) and written to HBM with one coalesced pass -- the only global
-// write of the sequence.  All `n_views` mimic views of a sequence are produced back to back by
-// the same wave, so the packed bases are fetched from HBM once and re-read from L1/L2.
+// Two kernels share this file:
+//   vectorise2_kernel (default): four wavefronts per sequence around one LDS histogram; the un-mutated sequence is
+//       counted once and every mimic view is produced as window deltas (see the "v2" block comment below);
+//   vectorise_kernel  (v1): one wavefront per sequence, 4096-base chunks, a full recount per view with the edits
+//       applied through an LDS staging image.  Kept for IDL_INIT_FROM_OUT (the accumulate-on-top scalar API), where
+//       every view starts from a caller-provided row.
+// Both finish a view with ONE pass over the histogram (pseudocount / normalise / CGR permutation / reverse-complement
+// collapse) and one coalesced row store -- the only global write of the sequence.
 //
 // Reference semantics restated here (not translated: the reference is a scalar byte loop):
 //   idelucs/kmers.pyx:2-50   kmer_counts  -> window = k consecutive valid bases, first base in

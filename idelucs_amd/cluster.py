@@ -1,34 +1,23 @@
-"""idelucs_amd.cluster -- library entry point, same signature as reference idelucs/cluster.py:9-52."""
-import sys
+"""idelucs_amd.cluster -- the scikit-learn-like entry point, `iDeLUCS_cluster(...).fit_predict()`, with the
+constructor signature and return values of reference idelucs/cluster.py:9-52."""
+from .training import prepare_model, train_voter
 
-from .utils import SummaryFasta
-from . import models
+# what the reference hard-codes for this entry point (cluster.py:20-30)
+_PINNED = {"GT_file": None, "optimizer": "RMSprop", "lambda": 2.8, "lr": 1e-3, "model_size": "linear", "scheduler": None}
 
 
 class iDeLUCS_cluster():
-    def __init__(self, sequence_file, n_clusters=4, n_epochs=500, n_mimics=3, batch_sz=512, k=4, weight=0.25,
-                 n_voters=1):
-        self.args = {
-            'sequence_file': sequence_file, 'n_clusters': n_clusters, 'n_epochs': n_epochs, 'n_mimics': n_mimics,
-            'batch_sz': batch_sz, 'GT_file': None, 'k': k,
-            # hard-coded in the reference (cluster.py:24-30)
-            'optimizer': "RMSprop", 'lambda': 2.8, 'weight': weight, 'n_voters': n_voters, 'lr': 1e-3,
-            'model_size': "linear", 'scheduler': None,
-        }
+    def __init__(self, sequence_file, n_clusters=4, n_epochs=500, n_mimics=3, batch_sz=512, k=4, weight=0.25, n_voters=1):
+        chosen = dict(sequence_file=sequence_file, n_clusters=n_clusters, n_epochs=n_epochs, n_mimics=n_mimics,
+                      batch_sz=batch_sz, k=k, weight=weight, n_voters=n_voters)
+        self.args = {**chosen, **_PINNED}
 
     def fit_predict(self, kmers=None):
-        """Returns (y_pred int64 [N], latent float64 [N, 64]) of the LAST voter (cluster.py:32-52);
-        the positional argument is ignored, as in the reference."""
-        model = models.IID_model(self.args)
-        model.names, model.lengths, model.GT, model.cluster_dis = SummaryFasta(model.sequence_file, model.GT_file)
-        model.build_dataloader()
-        y_pred = latent = None
-        for voter in range(self.args['n_voters']):
-            sys.stdout.write(f"\r........... Training Model ({voter + 1}/{self.args['n_voters']})................")
-            sys.stdout.flush()
-            model.net.apply(models.weights_init)
-            model.epoch = 0
-            for _ in range(self.args['n_epochs']):
-                model.contrastive_training_epoch()
-            y_pred, _, latent = model.predict()
+        """(y_pred int64 [N], latent float64 [N, 64]) of the LAST voter; no ensembling here, and the
+        positional argument is ignored -- both as in the reference (cluster.py:32,47-52)."""
+        model = prepare_model(self.args)
+        result = None
+        for v in range(self.args["n_voters"]):
+            result = train_voter(model, self.args["n_epochs"], v, self.args["n_voters"])
+        _, y_pred, _, latent = result
         return y_pred, latent

@@ -6,14 +6,16 @@ workload : BASELINE.json configs[1] -- synthetic 100 000 sequences x 10 kbp (iid
            k=6, n_clusters=20, n_mimics=3 (CLI default), batch_sz=512, NetLinear, RMSprop, fp32.
 step     : ONE pass of the hot path over the whole synthetic batch, with the packed bases already
            resident in HBM: device mimic-site generation + vectorisation of all 4 views + scaler fit
-           + one full training epoch (586 optimizer steps) [+ predict + all-gather of assignments,
-           see --with-predict].  Nothing is cached across steps (features are recomputed, weights
-           re-initialised each step -- one step == one voter of the reference's voter loop,
-           idelucs/__main__.py:106-146).
+           + one full training epoch (586 optimizer steps), i.e. BASELINE.md section 3's timed region
+           ("... to the optimizer.step() of the last batch of epoch 1; excludes predict, ensemble, TSV").
+           Nothing is cached across steps (features are recomputed, weights re-initialised each step
+           -- one step == one voter of the reference's voter loop, idelucs/__main__.py:106-146).
+           --with-predict 1 adds predict (+ the all-gather) to the timed region.
 N > 1    : one process per GPU (torch.distributed, backend nccl == RCCL); every rank runs its own
            voter on the full data set (the n_voters loop sharded over GPUs; weak scaling, no
-           data-path collective inside the epoch), then one all-gather of the int32 assignments.
-           value = (N_seq x ranks) / max-over-ranks time.
+           data-path collective inside the epoch).  value = (N_seq x ranks) / max-over-ranks time.
+           The path's one exchange step -- predict + all-gather of the int32 assignments [V, N] over
+           RCCL -- runs once after the timed loop at every N (reported as "exchange_ms").
 
 Prints ONE JSON line (rank 0).  Extra objects: "roofline" (the hand-written vectoriser kernel, HBM
 bound), "roofline_epoch" (the encoder epoch, MFMA fp32 bound), "cpu_baseline" (oracle port on the
@@ -204,8 +206,8 @@ def main():
     ap.add_argument("--n-clusters", dest="n_clusters", type=int, default=20)
     ap.add_argument("--n-mimics", dest="n_mimics", type=int, default=3)
     ap.add_argument("--batch-sz", dest="batch_sz", type=int, default=512)
-    ap.add_argument("--with-predict", dest="with_predict", type=int, default=1,
-                    help="include predict + all-gather of assignments in the timed region (default 1)")
+    ap.add_argument("--with-predict", dest="with_predict", type=int, default=0,
+                    help="1: include predict + all-gather of assignments in the timed region (default 0 = BASELINE.md's region)")
     ap.add_argument("--cpu-sample", dest="cpu_sample", type=int, default=24000)
     ap.add_argument("--no-cpu-baseline", dest="cpu_base", action="store_false")
     args = ap.parse_args()
@@ -252,6 +254,14 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
+    # the exchange step of the path (untimed unless --with-predict 1): this rank's voter predicts, assignments are all-gathered
+    from idelucs_amd.dist import all_gather_assignments
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    gathered = all_gather_assignments(hp.predict())
+    torch.cuda.synchronize()
+    exchange_ms = 1e3 * (time.perf_counter() - t1)
+    assert tuple(gathered.shape) == (world, args.n)
 
     if rank == 0:
         ms_step = 1e3 * elapsed / args.steps
@@ -274,7 +284,8 @@ def main():
             "config": {"workload": f"BASELINE configs[1]: synthetic {args.n} x {args.len} bp, k={args.k}, n_clusters={args.n_clusters}, "
                                    f"n_mimics={args.n_mimics} ({P} views), batch_sz={args.batch_sz}, NetLinear fp32, RMSprop; "
                                    f"one voter per GPU; timed = device mimic sites + vectorise + scaler fit + 1 epoch"
-                                   + (" + predict + all-gather of assignments" if args.with_predict else ""),
+                                   + (" + predict + all-gather of assignments" if args.with_predict
+                                      else " (BASELINE.md section 3 region; predict + RCCL all-gather of assignments run once after it)"),
                        "n_sequences": args.n, "seq_len": args.len, "k": args.k, "batch_sz": args.batch_sz,
                        "optimizer_steps_per_epoch": (args.n * args.n_mimics + args.batch_sz - 1) // args.batch_sz,
                        "parallelism": f"voters x{world}"},
@@ -286,6 +297,7 @@ def main():
                                "achieved": ach_ep, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach_ep / MFMA_F32_PEAK_TFLOPS,
                                "ms": t_ep, "flop_per_seq_algorithmic": f_ep, "share_of_step": t_ep / ms_step},
             "stage_ms": {k: hp.mean_ms(k, args.warmup) for k in hp.ev if hp.ev[k]},
+            "exchange_ms": exchange_ms,
         }
         if world == 1 and args.cpu_base:
             out["cpu_baseline"] = cpu_baseline(args)

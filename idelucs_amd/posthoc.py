@@ -31,6 +31,61 @@ def label_features(predictions, n_clusters):
     return np.array(y), d.max(axis=1)
 
 
+def label_features_device(predictions, n_clusters, device=None, n_init=10, max_iter=300, seed=None):
+    """label_features (reference utils.py:582-602) on the GPU: the same centred one-hot vote matrix
+    [N, V*C], k-means++ seeding + Lloyd iterations as dense torch ops, best of `n_init` restarts by
+    inertia, and the same inverse-squared-distance confidence.  KMeans is unseeded in the reference, so
+    parity is at partition level (ARI vs sklearn on the same votes, tests/test_cli_surface.py).
+    predictions: [V, N] integer tensor/array of per-voter labels in [0, n_clusters)."""
+    import torch
+    dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+    pred = torch.as_tensor(np.asarray(predictions) if not torch.is_tensor(predictions) else predictions).to(dev).long()
+    v, n = pred.shape
+    g = torch.Generator(device=dev)
+    g.manual_seed(int(seed) if seed is not None else int(torch.seed() % (2 ** 31)))
+    x = torch.zeros((n, v * n_clusters), dtype=torch.float32, device=dev)
+    x.scatter_(1, (pred.t() + torch.arange(v, device=dev) * n_clusters), 1.0)
+    x = x - x.sum(0, keepdim=True) / n                                  # utils.py:592-594
+    x2 = (x * x).sum(1)
+
+    def sqdist(c):                                                       # [N, K] squared distances to centres c [K, D]
+        return (x2[:, None] - 2.0 * (x @ c.t()) + (c * c).sum(1)[None, :]).clamp_min_(0.0)
+
+    best = None
+    for _ in range(n_init):
+        # k-means++ seeding
+        idx = torch.randint(0, n, (1,), device=dev, generator=g)
+        centres = x[idx].clone()
+        d = sqdist(centres).squeeze(1)
+        for _k in range(1, n_clusters):
+            tot = d.sum()
+            if float(tot) <= 0.0:                                        # fewer distinct rows than clusters
+                nxt = torch.randint(0, n, (1,), device=dev, generator=g)
+            else:
+                nxt = torch.multinomial(d / tot, 1, generator=g)
+            centres = torch.cat([centres, x[nxt]], 0)
+            d = torch.minimum(d, sqdist(x[nxt]).squeeze(1))
+        # Lloyd
+        labels = None
+        for _it in range(max_iter):
+            new_labels = sqdist(centres).argmin(1)
+            if labels is not None and torch.equal(new_labels, labels):
+                break
+            labels = new_labels
+            sums = torch.zeros_like(centres).index_add_(0, labels, x)
+            cnt = torch.bincount(labels, minlength=n_clusters).to(x.dtype)
+            keep = cnt > 0
+            centres = torch.where(keep[:, None], sums / cnt.clamp_min(1.0)[:, None], centres)
+        dist = sqdist(centres)
+        inertia = float(dist.gather(1, labels[:, None]).sum())
+        if best is None or inertia < best[0]:
+            best = (inertia, labels.clone(), dist.clone())
+    _, labels, dist = best
+    w = 1.0 / dist                                                       # utils.py:597-600 (inf where a point sits on a centre, as in the reference)
+    w = w / w.sum(1, keepdim=True)
+    return labels.cpu().numpy(), w.max(1).values.double().cpu().numpy()
+
+
 def compute_results(y_pred, data, y_true=None):
     """Reference utils.py:606-623."""
     import sklearn.metrics.cluster as metrics

@@ -62,3 +62,32 @@ def test_cli_fine_grained_mode_n_clusters_0(tmp_path, monkeypatch):
     assert ((df["confidence_score"] >= 0) & (df["confidence_score"] <= 1)).all()
     m = pd.read_csv(os.path.join(out_dir, "metrics.tsv"), sep="\t", index_col=0)
     assert "ACC" in m.index and os.path.exists(os.path.join(out_dir, "contingency_matrix.tsv"))
+
+
+@pytest.mark.gpu
+def test_device_ensemble_matches_sklearn_partition():
+    """label_features on the GPU vs the sklearn restatement of the reference (utils.py:582-602): the KMeans there is
+    unseeded, so the bar is partition-level -- ARI >= 0.98 between the two and against the planted truth."""
+    import time
+    import torch
+    from sklearn.metrics import adjusted_rand_score
+    from idelucs_amd import posthoc
+    rng = np.random.default_rng(4)
+    n, C, V = 20000, 6, 5
+    truth = rng.integers(0, C, n)
+    votes = []
+    for v in range(V):
+        perm = rng.permutation(C)
+        y = perm[truth]
+        flip = rng.random(n) < 0.08
+        y = np.where(flip, rng.integers(0, C, n), y)
+        votes.append(posthoc.relabel_first_occurrence(y))
+    votes = np.stack(votes)
+    t0 = time.time(); y_sk, conf_sk = posthoc.label_features(votes, C); t_sk = time.time() - t0
+    torch.cuda.synchronize(); t0 = time.time()
+    y_dev, conf_dev = posthoc.label_features_device(votes, C, seed=1); t_dev = time.time() - t0
+    print(f"ensemble of {V} voters x {n}: sklearn {t_sk:.2f} s, device {t_dev:.2f} s")
+    assert adjusted_rand_score(truth, y_dev) >= 0.98 and adjusted_rand_score(y_sk, y_dev) >= 0.98
+    assert conf_dev.shape == (n,) and np.all(conf_dev[np.isfinite(conf_dev)] > 1.0 / C - 1e-6)
+    agree = (np.abs(conf_dev - conf_sk) < 0.05) | ~np.isfinite(conf_sk) | ~np.isfinite(conf_dev)
+    assert agree.mean() > 0.95

@@ -693,7 +693,8 @@ int launch_vectorise(const VecArgs &a_in, const idl::DeviceInfo &di, hipStream_t
 {
     constexpr int F = 1 << (2 * K);
     VecArgs a = a_in;
-    const bool v1 = (a.init == IDL_INIT_FROM_OUT);      // accumulate-on-top needs a per-view start: single-pass kernel
+    bool v1 = (a.init == IDL_INIT_FROM_OUT);            // accumulate-on-top needs a per-view start: single-pass kernel
+    if (const char *e = getenv("IDELUCS_VEC")) { if (atoi(e) == 1) v1 = true; }   // force the v1 kernel (cross-check tests)
     int sc = 160;                                       // 10240 bases staged at a time (cfg2's 10 kbp in one super-chunk)
     if (const char *e = getenv("IDELUCS_SC_SLOTS")) { const int t = atoi(e); if (t >= 1 && t <= 4096) sc = t; }
     a.sc_slots = sc;

@@ -351,3 +351,28 @@ def test_size_independent_properties_at_full_size(gpu):
     assert torch.equal(fr, ((km + 1).double() / float(L - (k - 1) + 4 ** k)).float())
     ca = U._vectorise(din, k, _lib.MODE_CANONICAL, _lib.INIT_ZERO, _lib.OUT_COUNTS_I32)[0]
     assert ca.shape[1] == 2080 and torch.all(ca.sum(1) <= (L - (k - 1)) // 2 + 64) and torch.all(ca.sum(1) >= (L - k + 1 - 2080) // 2)
+
+
+def test_full_size_v1_and_v2_kernels_agree_bitwise(gpu, monkeypatch):
+    """cfg2-shaped batch (20 000 x 10 kbp, 4 views, device-drawn mimic edits): the single-pass kernel (full recount per
+    view, edits applied to a staged copy) and the delta-view kernel (one count + XOR-mask window moves) are independent
+    implementations and must produce identical bits -- counts and float32 frequencies."""
+    import torch
+    from idelucs_amd import _lib, utils as U
+    sys_path_tools = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools")
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_vectorise", os.path.join(sys_path_tools, "bench_vectorise.py"))
+    bv = importlib.util.module_from_spec(spec); spec.loader.exec_module(bv)
+    dev = torch.device("cuda")
+    din = bv.synth_input(20000, 10000, dev)
+    specs = [t.spec() for t in U.mimic_transforms(3)]
+    edits, edit_off = U._philox_edits(din, specs, 11)
+    outs = {}
+    for which in ("2", "1"):
+        monkeypatch.setenv("IDELUCS_VEC", which)
+        outs[which] = (U._vectorise(din, 6, _lib.MODE_KMER, _lib.INIT_ONE, _lib.OUT_FREQ_F32, 4, edits, edit_off).clone(),
+                       U._vectorise(din, 6, _lib.MODE_KMER, _lib.INIT_ZERO, _lib.OUT_COUNTS_I32, 4, edits, edit_off).clone())
+    assert torch.equal(outs["1"][1], outs["2"][1])
+    assert torch.equal(outs["1"][0], outs["2"][0])
+    c = outs["2"][1]
+    assert not torch.equal(c[0], c[1]) and int(c[3].sum(1).min()) >= 10000 - 5 - 20 * 6       # the views differ; Random_N kills <= 20*k windows

@@ -451,6 +451,18 @@ def AugmentFasta(sequence_file, n_mimics, k=6, reduce=False, rng=None, seed=0):
     return x
 
 
+def project_kernel(features, kernel):
+    """The compositional projection the reference keeps commented out in kmersFasta (utils.py:272-275):
+    `np.dot(kmers, KERNEL)` with KERNEL = kernels/kernel{k}.npz['arr_0'] ([4^k, d], d = 135/511/2079).
+    features: [N, 4^k] tensor or array -> [N, d] on the device, one GEMM (float64 like the reference's rows)."""
+    dev = _device()
+    x = torch.as_tensor(features).to(dev).double()
+    kern = torch.as_tensor(np.load(kernel)["arr_0"] if isinstance(kernel, (str, os.PathLike)) else kernel).to(dev).double()
+    if x.shape[1] != kern.shape[0]:
+        raise ValueError(f"kernel has {kern.shape[0]} rows, features have {x.shape[1]} columns")
+    return x @ kern
+
+
 class AugmentedDataset(torch.utils.data.Dataset):
     """Reference idelucs/utils.py:370-389."""
 

@@ -56,7 +56,7 @@ def synth_packed(n, L, dev, seed=12345):
     class DeviceInput:
         pass
     d = DeviceInput()
-    d.n, d.codes, d.mask = n, codes, mask.view(-1)
+    d.n, d.codes, d.mask, d.min_len = n, codes, mask.view(-1), L
     d.slot_off = torch.arange(0, (n + 1) * slots, slots, dtype=torch.int64, device=dev)
     d.lengths = torch.full((n,), L, dtype=torch.int64, device=dev)
     d.max_len = L
@@ -78,6 +78,11 @@ class HotPath:
             'n_mimics': args.n_mimics, 'batch_sz': args.batch_sz, 'optimizer': 'RMSprop', 'lambda': 2.8, 'lr': 1e-3,
             'weight': 0.25, 'scheduler': None, 'n_epochs': 1, 'n_voters': 1})
         self.feats = torch.empty((self.P, din.n, self.F), dtype=torch.float32, device=dev)   # 6.55 GB at cfg2
+        # mimic-site buffer sized by a safe bound (expected + 25 % + slack) instead of a host round trip per step; the
+        # device-side totals are checked against it after the run (overflow flag, no sync inside the step)
+        expect = sum(din.n * (args.len * (1.0 - (1.0 - s[0]) * (1.0 - s[1])) + s[2]) for s in self.specs)
+        self.edit_capacity = int(1.25 * expect + 64 * din.n * self.P + 1024)
+        self.edit_overflow = torch.zeros((), dtype=torch.bool, device=dev)
         self.ev = {k: [] for k in ("edits", "vectorise", "stats", "epoch", "predict")}
         self.y_pred = None
 
@@ -91,7 +96,8 @@ class HotPath:
 
     def step(self, seed):
         U, _lib, m = self.U, self._lib, self.model
-        edits, edit_off = self._timed("edits", lambda: U._philox_edits(self.din, self.specs, seed))
+        edits, edit_off = self._timed("edits", lambda: U._philox_edits(self.din, self.specs, seed, capacity=self.edit_capacity))
+        self.edit_overflow |= edit_off[-1] > self.edit_capacity
         self._timed("vectorise", lambda: U._vectorise(self.din, self.a.k, _lib.MODE_KMER, _lib.INIT_ONE, _lib.OUT_FREQ_F32,
                                                       self.P, edits, edit_off, self.feats))
         mean, scale = self._timed("stats", lambda: U.col_stats(self.feats[0]))
@@ -262,6 +268,7 @@ def main():
     torch.cuda.synchronize()
     exchange_ms = 1e3 * (time.perf_counter() - t1)
     assert tuple(gathered.shape) == (world, args.n)
+    assert not bool(hp.edit_overflow.item()), "mimic edit buffer bound exceeded: the run is invalid"
 
     if rank == 0:
         ms_step = 1e3 * elapsed / args.steps

@@ -299,22 +299,31 @@ def _compat_edits(ff, transforms):
     return edits, edit_off
 
 
-def _philox_edits(dev_in, specs, seed):
-    """Device-drawn mimic sites (idl_mimic_edits, two-call protocol) -> (edits, edit_off) on device."""
+def _philox_edits(dev_in, specs, seed, capacity=None):
+    """Device-drawn mimic sites (idl_mimic_edits, two-call protocol) -> (edits, edit_off) on device.
+    capacity=None: exact sizing (one host round trip to read the total).  With a capacity (an upper bound chosen by
+    the caller) nothing synchronises; edit_off[-1] holds the true total and the caller must check it against the
+    capacity afterwards (the fill kernel never writes past it)."""
     P = len(specs)
     p_ts = np.array([s[0] for s in specs], np.float64)
     p_tv = np.array([s[1] for s in specs], np.float64)
     n_rn = np.array([s[2] for s in specs], np.int32)
-    if np.any(n_rn > 0) and dev_in.n > 0 and int(dev_in.lengths.min().item()) <= 0:
+    if np.any(n_rn > 0) and dev_in.n > 0 and getattr(dev_in, "min_len", None) is None:
+        dev_in.min_len = int(dev_in.lengths.min().item())
+    if np.any(n_rn > 0) and dev_in.n > 0 and dev_in.min_len <= 0:
         raise ValueError("high <= 0")   # np.random.randint(0, 0, n) in the reference's Random_N (utils.py:93)
     dev = dev_in.codes.device
     ws = torch.empty(_L.idl_mimic_workspace(dev_in.n, P), dtype=torch.uint8, device=dev)
     edit_off = torch.empty(P * dev_in.n + 1, dtype=torch.int64, device=dev)
-    total = ctypes.c_int64(0)
     args = (_ptr(dev_in.lengths), dev_in.n, P, _ptr(p_ts), _ptr(p_tv), _ptr(n_rn), ctypes.c_uint64(seed & (2 ** 64 - 1)))
-    _lib.check(_L.idl_mimic_edits(*args, _ptr(edit_off), None, 0, ctypes.byref(total), _ptr(ws), _stream_ptr()))
-    edits = torch.empty(max(total.value, 1), dtype=torch.int32, device=dev)
-    _lib.check(_L.idl_mimic_edits(*args, _ptr(edit_off), _ptr(edits), total.value, None, _ptr(ws), _stream_ptr()))
+    if capacity is None:
+        total = ctypes.c_int64(0)
+        _lib.check(_L.idl_mimic_edits(*args, _ptr(edit_off), None, 0, ctypes.byref(total), _ptr(ws), _stream_ptr()))
+        capacity = total.value
+    else:
+        _lib.check(_L.idl_mimic_edits(*args, _ptr(edit_off), None, 0, None, _ptr(ws), _stream_ptr()))
+    edits = torch.empty(max(int(capacity), 1), dtype=torch.int32, device=dev)
+    _lib.check(_L.idl_mimic_edits(*args, _ptr(edit_off), _ptr(edits), int(capacity), None, _ptr(ws), _stream_ptr()))
     return edits, edit_off
 
 

@@ -13,6 +13,7 @@
 // Threads own columns (lane i -> column i, 16-byte vectors where f % 4 == 0), so every row read
 // is a contiguous, coalesced segment.
 #include "common.h"
+#include "scaler_device.h"
 
 namespace {
 
@@ -88,22 +89,7 @@ __global__ __launch_bounds__(STAT_THREADS) void col_scale_kernel(const double *p
     scale[c] = s;
 }
 
-// float32 in -> float32 out: both ops in float64, rounded to float32 after each (numpy in-place
-// ufunc on a float32 array with a float64 operand).
-__device__ __forceinline__ float std_f32(float x, double m, double s)
-{
-    const float t = (float)((double)x - m);
-    return (float)((double)t / s);
-}
-
-// same result with a precomputed r = RN(1/s): q = t r, q' = fma(fma(-q, s, t), r, q) is the correctly rounded float64
-// quotient (Markstein; 3.8e9 random (t, s) pairs checked against IEEE division, tools/markstein_check_f64.c)
-__device__ __forceinline__ float std_f32_rcp(float x, double m, double s, double r)
-{
-    const double t = (double)(float)((double)x - m);
-    const double q = t * r;
-    return (float)fma(fma(-q, s, t), r, q);
-}
+using idl_dev::std_f32;
 
 // float64 in: float64 arithmetic throughout, one final rounding to float32 (models.py:163 .type(dtype))
 __device__ __forceinline__ float std_f64(double x, double m, double s) { return (float)((x - m) / s); }
@@ -134,41 +120,9 @@ __global__ __launch_bounds__(256) void standardise_scalar(const T *x, int64_t to
     }
 }
 
-// one workgroup per output row; rows [0, batch) are the "true" halves, [batch, 2*batch) the "modified" ones
-__global__ __launch_bounds__(256) void gather_pairs_kernel(const float *feats, int64_t n, int64_t f, int64_t view_stride,
-                                                           const int64_t *pair_idx, const int64_t *base, int64_t batch,
-                                                           const double *mean, const double *scale, const double *inv_scale,
-                                                           float *y)
+__global__ __launch_bounds__(256) void gather_pairs_kernel(idl_dev::GatherArgs g)
 {
-    const int64_t row = blockIdx.x;
-    const int64_t b = row < batch ? row : row - batch;
-    const int64_t pair = pair_idx[(base ? *base : 0) + b];
-    const int64_t m = pair / n, s = pair - m * n;
-    const float *src = feats + (row < batch ? 0 : (m + 1) * view_stride) + s * f;
-    float *dst = y + row * f;
-    if ((f & 3) == 0) {
-        const float4 *src4 = (const float4 *)src;
-        float4 *dst4 = (float4 *)dst;
-        for (int64_t i = threadIdx.x; i < f / 4; i += blockDim.x) {
-            const float4 v = src4[i];
-            const int64_t c = i * 4;
-            float4 o;
-            if (inv_scale != nullptr) {
-                o.x = std_f32_rcp(v.x, mean[c + 0], scale[c + 0], inv_scale[c + 0]);
-                o.y = std_f32_rcp(v.y, mean[c + 1], scale[c + 1], inv_scale[c + 1]);
-                o.z = std_f32_rcp(v.z, mean[c + 2], scale[c + 2], inv_scale[c + 2]);
-                o.w = std_f32_rcp(v.w, mean[c + 3], scale[c + 3], inv_scale[c + 3]);
-            } else {
-                o.x = std_f32(v.x, mean[c + 0], scale[c + 0]);
-                o.y = std_f32(v.y, mean[c + 1], scale[c + 1]);
-                o.z = std_f32(v.z, mean[c + 2], scale[c + 2]);
-                o.w = std_f32(v.w, mean[c + 3], scale[c + 3]);
-            }
-            dst4[i] = o;
-        }
-    } else {
-        for (int64_t i = threadIdx.x; i < f; i += blockDim.x) dst[i] = std_f32(src[i], mean[i], scale[i]);
-    }
+    idl_dev::gather_row(g, blockIdx.x, threadIdx.x, blockDim.x);
 }
 
 }  // namespace
@@ -260,8 +214,8 @@ int idl_gather_pairs_at(const float *feats, int64_t n, int64_t f, int64_t view_s
     idl::DeviceInfo di;
     int rc = idl::device_info(&di);
     if (rc != IDL_OK) return rc;
-    hipLaunchKernelGGL(gather_pairs_kernel, dim3((unsigned)(2 * batch)), dim3(256), 0, (hipStream_t)stream, feats, n, f,
-                       view_stride, pair_idx, base, batch, mean, scale, inv_scale, y);
+    idl_dev::GatherArgs g{feats, n, f, view_stride, pair_idx, base, batch, (int64_t)-1, mean, scale, inv_scale, y};
+    hipLaunchKernelGGL(gather_pairs_kernel, dim3((unsigned)(2 * batch)), dim3(256), 0, (hipStream_t)stream, g);
     IDL_HIP_TRY(hipGetLastError());
     return IDL_OK;
 }

@@ -1,0 +1,71 @@
+// scaler_device.h -- device code shared by scaler.hip (idl_gather_pairs*) and train_step.hip (the optimizer launch that
+// also assembles the NEXT batch): StandardScaler.transform arithmetic and the row gather.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace idl_dev {
+
+// float32 in -> float32 out: both ops in float64, rounded to float32 after each (numpy in-place ufunc on a float32 array
+// with a float64 operand; reference idelucs/utils.py:361-366).
+__device__ __forceinline__ float std_f32(float x, double m, double s)
+{
+    const float t = (float)((double)x - m);
+    return (float)((double)t / s);
+}
+
+// same result with a precomputed r = RN(1/s): q = t r, q' = fma(fma(-q, s, t), r, q) is the correctly rounded float64
+// quotient (Markstein; 3.8e9 random (t, s) pairs checked against IEEE division, tools/markstein_check_f64.c)
+__device__ __forceinline__ float std_f32_rcp(float x, double m, double s, double r)
+{
+    const double t = (double)(float)((double)x - m);
+    const double q = t * r;
+    return (float)fma(fma(-q, s, t), r, q);
+}
+
+struct GatherArgs {
+    const float *feats;
+    int64_t n, f, view_stride;
+    const int64_t *pair_idx;
+    const int64_t *base;        // device int64 offset into pair_idx (may be NULL = 0)
+    int64_t batch, n_pairs;     // rows whose pair index falls at or beyond n_pairs are skipped (n_pairs < 0: no limit)
+    const double *mean, *scale, *inv_scale;
+    float *y;
+};
+
+// one workgroup copies + standardises one output row; rows [0, batch) are the "true" halves, [batch, 2*batch) the "modified" ones
+__device__ __forceinline__ void gather_row(const GatherArgs &g, int64_t row, int tid, int nthreads)
+{
+    const int64_t b = row < g.batch ? row : row - g.batch;
+    const int64_t at = (g.base ? *g.base : 0) + b;
+    if (g.n_pairs >= 0 && at >= g.n_pairs) return;
+    const int64_t pair = g.pair_idx[at];
+    const int64_t m = pair / g.n, s = pair - m * g.n;
+    const float *src = g.feats + (row < g.batch ? 0 : (m + 1) * g.view_stride) + s * g.f;
+    float *dst = g.y + row * g.f;
+    if ((g.f & 3) == 0) {
+        const float4 *src4 = (const float4 *)src;
+        float4 *dst4 = (float4 *)dst;
+        for (int64_t i = tid; i < g.f / 4; i += nthreads) {
+            const float4 v = src4[i];
+            const int64_t c = i * 4;
+            float4 o;
+            if (g.inv_scale != nullptr) {
+                o.x = std_f32_rcp(v.x, g.mean[c + 0], g.scale[c + 0], g.inv_scale[c + 0]);
+                o.y = std_f32_rcp(v.y, g.mean[c + 1], g.scale[c + 1], g.inv_scale[c + 1]);
+                o.z = std_f32_rcp(v.z, g.mean[c + 2], g.scale[c + 2], g.inv_scale[c + 2]);
+                o.w = std_f32_rcp(v.w, g.mean[c + 3], g.scale[c + 3], g.inv_scale[c + 3]);
+            } else {
+                o.x = std_f32(v.x, g.mean[c + 0], g.scale[c + 0]);
+                o.y = std_f32(v.y, g.mean[c + 1], g.scale[c + 1]);
+                o.z = std_f32(v.z, g.mean[c + 2], g.scale[c + 2]);
+                o.w = std_f32(v.w, g.mean[c + 3], g.scale[c + 3]);
+            }
+            dst4[i] = o;
+        }
+    } else {
+        for (int64_t i = tid; i < g.f; i += nthreads) dst[i] = std_f32(src[i], g.mean[i], g.scale[i]);
+    }
+}
+
+}  // namespace idl_dev

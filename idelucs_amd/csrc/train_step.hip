@@ -20,6 +20,7 @@
 // host involvement:  ctl[0] = optimizer-step counter, ctl[1] = offset of the next batch in the
 // shuffled pair list.
 #include "common.h"
+#include "scaler_device.h"
 
 namespace {
 
@@ -378,11 +379,12 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float *z, const flo
 constexpr int COL_PARTS = 32;
 
 struct ColJob { float *x; const float *act; float *partial; int n; float scale; };   // act != NULL: ReLU/Dropout backward in place
-struct ColJobs { ColJob j[3]; int first_block[4]; int m; };
+struct ColJobs { ColJob j[3]; int first_block[4]; int m; int64_t *ctl; int64_t batch_advance; };   // ctl != NULL: ctl[1] += batch_advance
 
 __global__ __launch_bounds__(256) void col_partial_kernel(ColJobs jobs)
 {
     __shared__ float sh[4][64];
+    if (jobs.ctl != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) jobs.ctl[1] += jobs.batch_advance;
     int k = 0;
     while (k < 2 && (int)blockIdx.x >= jobs.first_block[k + 1]) ++k;
     const ColJob job = jobs.j[k];
@@ -423,16 +425,25 @@ struct RmsArgs {
     int count;
 };
 
-__global__ __launch_bounds__(256) void rmsprop_kernel(RmsArgs a, const float *hyper, int64_t *ctl, int64_t batch_advance)
+// Grid: blockIdx.x in [0, gx * count) are optimizer blocks (tensor = blockIdx.x / gx); the following 2 * g.batch blocks, when
+// g.y != NULL, assemble the NEXT batch (nothing in this launch writes what they read: the batch offset ctl[1] was already
+// advanced by the bias-gradient launch of this step, and x is no longer read by this step's GEMMs).
+__global__ __launch_bounds__(256) void rmsprop_kernel(RmsArgs a, const float *hyper, int64_t *ctl, int64_t batch_advance, int gx,
+                                                      idl_dev::GatherArgs g)
 {
-    const int t = blockIdx.y;
+    if ((int)blockIdx.x >= gx * a.count) {
+        idl_dev::gather_row(g, (int64_t)blockIdx.x - (int64_t)gx * a.count, threadIdx.x, 256);
+        return;
+    }
+    const int t = (int)blockIdx.x / gx;
+    const int bx = (int)blockIdx.x - t * gx;
     const float lr = hyper[0], alpha = hyper[1], eps = hyper[2], wd = hyper[3], oma = hyper[4];
     if (t < a.count) {
         float *p = a.p[t]; const float *g = a.g[t]; float *v = a.v[t];
         const int64_t n = a.n[t];
         if (a.parts[t] == 1 && (n & 3) == 0 && ((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)v)) & 15u) == 0) {
             float4 *p4 = (float4 *)p; const float4 *g4 = (const float4 *)g; float4 *v4 = (float4 *)v;
-            for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n / 4; i += (int64_t)gridDim.x * blockDim.x) {
+            for (int64_t i = (int64_t)bx * blockDim.x + threadIdx.x; i < n / 4; i += (int64_t)gx * blockDim.x) {
                 float4 pi = p4[i], vi = v4[i];
                 const float4 gr = g4[i];
                 const float g0 = gr.x + wd * pi.x, g1 = gr.y + wd * pi.y, g2 = gr.z + wd * pi.z, g3 = gr.w + wd * pi.w;
@@ -443,7 +454,7 @@ __global__ __launch_bounds__(256) void rmsprop_kernel(RmsArgs a, const float *hy
                 v4[i] = vi; p4[i] = pi;
             }
         } else
-        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        for (int64_t i = (int64_t)bx * blockDim.x + threadIdx.x; i < n; i += (int64_t)gx * blockDim.x) {
             const float pi = p[i];
             float gr;
             if (a.parts[t] == COL_PARTS) {          // 32 independent loads in flight, summed in a fixed order
@@ -463,8 +474,8 @@ __global__ __launch_bounds__(256) void rmsprop_kernel(RmsArgs a, const float *hy
             p[i] = pi - lr * (gi / (sqrtf(vi) + eps));           // param.addcdiv_(grad, sqrt(v)+eps, value=-lr)
         }
     }
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { ctl[0] += 1; ctl[1] += batch_advance; }
-    if (a.out != nullptr && blockIdx.x == gridDim.x - 1 && blockIdx.y == gridDim.y - 1 && threadIdx.x < 64) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) { ctl[0] += 1; ctl[1] += batch_advance; }
+    if (a.out != nullptr && (int)blockIdx.x == gx * a.count - 1 && threadIdx.x < 64) {
         // step loss = w_nce * mean(loss_rows) + w_iic * IIC (left in out[3] by iic_core_kernel); out[1] = running sum
         float acc = 0.f;
         for (int i = threadIdx.x; i < a.loss_m; i += 64) acc += a.loss_rows[i];
@@ -580,7 +591,7 @@ int idl_relu_dropout_bwd_colsum(float *dx, const float *act, int m, int n, int t
 }
 
 int idl_bias_grads(float *dx1, const float *act1, int n1, float *partial1, const float *x2, int n2, float *partial2,
-                   const float *x3, int n3, float *partial3, int m, int train, void *stream)
+                   const float *x3, int n3, float *partial3, int m, int train, int64_t *ctl, int64_t batch_advance, void *stream)
 {
     IDL_REQUIRE(dx1 && act1 && partial1 && x2 && partial2 && x3 && partial3 && m >= 1 && n1 >= 1 && n2 >= 1 && n3 >= 1,
                 "bias_grads: NULL buffer or empty");
@@ -589,12 +600,15 @@ int idl_bias_grads(float *dx1, const float *act1, int n1, float *partial1, const
     jobs.j[0] = ColJob{dx1, act1, partial1, n1, train ? 2.f : 1.f};
     jobs.j[1] = ColJob{(float *)x2, nullptr, partial2, n2, 1.f};
     jobs.j[2] = ColJob{(float *)x3, nullptr, partial3, n3, 1.f};
+    jobs.ctl = ctl;
+    jobs.batch_advance = batch_advance;
     return launch_col_jobs(jobs, 3, stream);
 }
 
-int idl_rmsprop_step(int count, float *const *params, const float *const *grads, const int32_t *grad_parts,
-                     float *const *square_avg, const int64_t *sizes, const float *hyper, int64_t *ctl, int64_t batch_advance,
-                     const float *loss_rows, int loss_m, float w_nce, float w_iic, float *out, void *stream)
+static int rmsprop_launch(int count, float *const *params, const float *const *grads, const int32_t *grad_parts,
+                          float *const *square_avg, const int64_t *sizes, const float *hyper, int64_t *ctl, int64_t batch_advance,
+                          const float *loss_rows, int loss_m, float w_nce, float w_iic, float *out, const idl_dev::GatherArgs &g,
+                          void *stream)
 {
     IDL_REQUIRE(count >= 1 && count <= 8 && params && grads && square_avg && sizes && hyper && ctl, "rmsprop_step: 1..8 tensors");
     RmsArgs a{};
@@ -610,9 +624,31 @@ int idl_rmsprop_step(int count, float *const *params, const float *const *grads,
     int64_t gx = (mx + 255) / 256;
     if (gx > 1024) gx = 1024;
     if (gx < 1) gx = 1;
-    hipLaunchKernelGGL(rmsprop_kernel, dim3((unsigned)gx, (unsigned)count), dim3(256), 0, (hipStream_t)stream, a, hyper, ctl, batch_advance);
+    const int64_t extra = g.y != nullptr ? 2 * g.batch : 0;
+    hipLaunchKernelGGL(rmsprop_kernel, dim3((unsigned)(gx * count + extra)), dim3(256), 0, (hipStream_t)stream, a, hyper, ctl, batch_advance,
+                       (int)gx, g);
     IDL_HIP_TRY(hipGetLastError());
     return IDL_OK;
+}
+
+int idl_rmsprop_step(int count, float *const *params, const float *const *grads, const int32_t *grad_parts,
+                     float *const *square_avg, const int64_t *sizes, const float *hyper, int64_t *ctl, int64_t batch_advance,
+                     const float *loss_rows, int loss_m, float w_nce, float w_iic, float *out, void *stream)
+{
+    idl_dev::GatherArgs g{};
+    return rmsprop_launch(count, params, grads, grad_parts, square_avg, sizes, hyper, ctl, batch_advance, loss_rows, loss_m, w_nce, w_iic,
+                          out, g, stream);
+}
+
+int idl_rmsprop_step_gather(int count, float *const *params, const float *const *grads, const int32_t *grad_parts,
+                            float *const *square_avg, const int64_t *sizes, const float *hyper, int64_t *ctl,
+                            const float *loss_rows, int loss_m, float w_nce, float w_iic, float *out,
+                            const float *feats, int64_t n, int64_t f, int64_t view_stride, const int64_t *pair_idx, int64_t n_pairs,
+                            int64_t batch, const double *mean, const double *scale, const double *inv_scale, float *y, void *stream)
+{
+    IDL_REQUIRE(feats && pair_idx && mean && scale && y && n >= 1 && f >= 1 && batch >= 1 && n_pairs >= 0, "rmsprop_step_gather: bad gather arguments");
+    idl_dev::GatherArgs g{feats, n, f, view_stride, pair_idx, ctl + 1, batch, n_pairs, mean, scale, inv_scale, y};
+    return rmsprop_launch(count, params, grads, grad_parts, square_avg, sizes, hyper, ctl, 0, loss_rows, loss_m, w_nce, w_iic, out, g, stream);
 }
 
 }  // extern "C"

@@ -87,6 +87,7 @@ class FusedLinearTrainer:
         # measured on MI355X: correct (tests) but 2 % slower than the three separate kernels (64 workgroups, 4 rows of head
         # work serialised per wave) -> opt-in only
         self._mid_fused = self.H1 == 512 and os.environ.get("IDELUCS_MID_FUSED", "0") == "1"
+        self._pipeline = os.environ.get("IDELUCS_PIPELINE", "1") != "0"   # optimizer launch also assembles the next batch
         self._overlap = os.environ.get("IDELUCS_OVERLAP", "0") != "0"   # measured: no gain inside a HIP graph on ROCm 7.2
         self._perm = None
         n = len(self.params)
@@ -110,9 +111,11 @@ class FusedLinearTrainer:
 
     # ------------------------------------------------------------------ one step on a filled bf.x
     @torch.no_grad()
-    def step_on_batch(self, bf, train=True, batch_advance=0):
+    def step_on_batch(self, bf, train=True, batch_advance=0, next_from=None):
         """Forward, backward and RMSprop update for the [m, F] batch in bf.x (rows [0,m/2) "true",
-        [m/2,m) "modified").  Only enqueues work on the current stream."""
+        [m/2,m) "modified").  Only enqueues work on the current stream.  next_from = a FeatureStore: the batch
+        offset is advanced in the middle of the step and the optimizer launch also assembles the NEXT batch into
+        bf.x (both are memory-bound and independent: one launch instead of two)."""
         m, C, tr = bf.m, self.C, 1 if train else 0
         chk = _lib.check
         main = torch.cuda.current_stream()
@@ -150,22 +153,35 @@ class FusedLinearTrainer:
             torch.mm(bf.dlat.t(), bf.r1, out=gW2)
         torch.mm(bf.dlat, self.W2, out=bf.dr1)
         chk(_L.idl_bias_grads(_p(bf.dr1), _p(bf.r1), self.H1, _p(gb1), _p(bf.dlat), self.H2, _p(gb2), _p(bf.dlogits), C, _p(gb3),
-                              m, tr, _stream()))
+                              m, tr, _p(self.ctl) if next_from is not None else None, batch_advance if next_from is not None else 0,
+                              _stream()))
         torch.mm(bf.dr1.t(), bf.x, out=gW1)
         main.wait_stream(side)
         # ---- RMSprop (and advance the device-side step counter / batch offset)
-        chk(_L.idl_rmsprop_step(len(self.params), self._pp, self._gp, self._parts, self._vp, self._sz, _p(self.hyper),
-                                _p(self.ctl), batch_advance, _p(bf.loss_rows), m, 1.0 - self.weight, self.weight, _p(self.out),
-                                _stream()))
+        if next_from is not None:
+            st = next_from
+            chk(_L.idl_rmsprop_step_gather(len(self.params), self._pp, self._gp, self._parts, self._vp, self._sz, _p(self.hyper),
+                                           _p(self.ctl), _p(bf.loss_rows), m, 1.0 - self.weight, self.weight, _p(self.out),
+                                           _p(st.feats), st.n, st.f, st.n * st.f, _p(self._perm), st.n_pairs, m // 2,
+                                           _p(st.mean), _p(st.scale), _p(st.inv_scale), _p(bf.x), _stream()))
+        else:
+            chk(_L.idl_rmsprop_step(len(self.params), self._pp, self._gp, self._parts, self._vp, self._sz, _p(self.hyper),
+                                    _p(self.ctl), batch_advance, _p(bf.loss_rows), m, 1.0 - self.weight, self.weight, _p(self.out),
+                                    _stream()))
 
     def _gather(self, store, bf):
         b = bf.m // 2
         _lib.check(_L.idl_gather_pairs_at(_p(store.feats), store.n, store.f, store.n * store.f, _p(self._perm), _p(self.ctl[1:]),
                                           b, _p(store.mean), _p(store.scale), _p(store.inv_scale), _p(bf.x), _stream()))
 
-    def _full_step(self, store, bf, train=True):
-        self._gather(store, bf)
-        self.step_on_batch(bf, train=train, batch_advance=bf.m // 2)
+    def _full_step(self, store, bf, train=True, pipelined=False):
+        """pipelined: bf.x already holds this batch (assembled by the previous step's optimizer launch, or by the
+        prologue gather); this step assembles the next one."""
+        if pipelined:
+            self.step_on_batch(bf, train=train, batch_advance=bf.m // 2, next_from=store)
+        else:
+            self._gather(store, bf)
+            self.step_on_batch(bf, train=train, batch_advance=bf.m // 2)
 
     # ------------------------------------------------------------------ one epoch over the store
     @torch.no_grad()
@@ -180,13 +196,16 @@ class FusedLinearTrainer:
         self.ctl[1] = 0
         self.out[1] = 0.0
         n_full, rem = divmod(n_pairs, batch_sz)
+        pipe = self._pipeline
         if n_full:
             bf = self.buffers(2 * batch_sz)
-            key = (2 * batch_sz, store.feats.data_ptr(), store.mean.data_ptr(), store.n, store.f)
+            if pipe:
+                self._gather(store, bf)         # prologue: batch 0; every later batch is assembled by the previous step
+            key = (2 * batch_sz, store.feats.data_ptr(), store.mean.data_ptr(), store.n, store.f, pipe)
             if use_graph and n_full >= 8:
                 g = self._graphs.get(key)
                 if g is None:
-                    g = self._capture(store, bf)
+                    g = self._capture(store, bf, pipe)
                     self._graphs = {key: g}             # one store at a time: drop graphs of older stores
                     n_done = 3                           # the warm-up + capture already ran real steps
                 else:
@@ -195,23 +214,23 @@ class FusedLinearTrainer:
                     g.replay()
             else:
                 for _ in range(n_full):
-                    self._full_step(store, bf)
+                    self._full_step(store, bf, pipelined=pipe)
         if rem:
             self._full_step(store, self.buffers(2 * rem))
         return self.out[1], n_full + (1 if rem else 0)
 
     @torch.no_grad()
-    def _capture(self, store, bf):
+    def _capture(self, store, bf, pipe):
         """Warm up on a side stream (2 real steps), then capture a third real step into a HIP graph.
         Every launch is a genuine optimizer step on the next batch, so nothing is wasted or repeated."""
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             for _ in range(2):
-                self._full_step(store, bf)
+                self._full_step(store, bf, pipelined=pipe)
         torch.cuda.current_stream().wait_stream(s)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
-            self._full_step(store, bf)
+            self._full_step(store, bf, pipelined=pipe)
         g.replay()          # capture does not execute: run the captured (third) step once
         return g

@@ -1,0 +1,81 @@
+// iic_device.h -- the IIC core as a device function, shared by train_step.hip (its own launch) and nce_fused.hip (where
+// it rides along as one extra workgroup of InfoNCE pass 1: the two loss branches are independent).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace idl_dev {
+__device__ __forceinline__ float wsum_f(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wsum_d(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+}  // namespace idl_dev
+
+// ---------------------------------------------------------------- IIC on the C x C joint (one workgroup)
+// P0 = z1^T z2 (given).  Writes IIC to out[3] and dP0 = w_iic * dIIC/dP0 into P0 in place.  scratch: C*C floats.
+// (The step loss is assembled by rmsprop_kernel, so that this kernel does not depend on the InfoNCE branch.)
+// The joint P = (P0 + P0^T) / (2 sum P0) is symmetric bit-for-bit ((a+b) == (b+a)), so its column sums equal its
+// row sums and dL/dP is symmetric too: the reference's two marginals (LossFunctions.py:32-33) and its
+// symmetrisation backward collapse to one coalesced wave-per-row pass and no transpose.
+template <int NT>
+__device__ __forceinline__ void iic_core_body(float *P0, int C, float lamb, float eps, float w_iic, float *scratch, float *out)
+{
+    constexpr int NW = NT / 64;
+    __shared__ double red[NW];
+    __shared__ float rs[256], ar[256];          // row sums of P and of the clamped P
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6, n = C * C;
+    auto block_sum = [&](double v) -> double {
+        v = idl_dev::wsum_d(v);
+        __syncthreads();
+        if (lane == 0) red[wv] = v;
+        __syncthreads();
+        double r = 0.0;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) r += red[i];
+        return r;
+    };
+    double acc = 0.0;
+    for (int i = t; i < n; i += NT) acc += (double)P0[i];
+    const float s = (float)block_sum(acc);
+    for (int i = t; i < n; i += NT) {
+        const int r = i / C, c = i - r * C;
+        scratch[i] = ((P0[i] + P0[c * C + r]) * 0.5f) / s;
+    }
+    __syncthreads();
+    for (int r = wv; r < C; r += NW) {          // one wave per row, coalesced
+        float a = 0.f, b = 0.f;
+        for (int c = lane; c < C; c += 64) { const float p = scratch[r * C + c]; a += p; b += fmaxf(p, eps); }
+        a = idl_dev::wsum_f(a); b = idl_dev::wsum_f(b);
+        if (lane == 0) { rs[r] = a; ar[r] = b; }
+    }
+    __syncthreads();
+    // loss, G = dL/dP (clamp-by-assignment: no gradient through clamped entries) and sum(G * P) in one pass
+    double lacc = 0.0, gacc = 0.0;
+    for (int i = t; i < n; i += NT) {
+        const int r = i / C, c = i - r * C;
+        const float pu = scratch[i], p = fmaxf(pu, eps);
+        const float piu = rs[r], pi = fmaxf(piu, eps), pju = rs[c], pj = fmaxf(pju, eps);
+        const float lg = __logf(p) - lamb * __logf(pj) - lamb * __logf(pi);
+        lacc += (double)(-p * lg);
+        float g = 0.f;
+        if (!(pu < eps)) g += -lg - 1.f;
+        if (!(piu < eps)) g += lamb * ar[r] / pi;
+        if (!(pju < eps)) g += lamb * ar[c] / pj;
+        P0[i] = g;
+        gacc += (double)g * (double)pu;
+    }
+    const float iic = (float)block_sum(lacc);
+    const float gp = (float)block_sum(gacc);
+    if (t == 0) out[3] = iic;
+    // through P = Ps / sum(Ps): dPs = (G - sum(G P)) / s; G is symmetric, so (dPs + dPs^T)/2 = dPs
+    for (int i = t; i < n; i += NT) P0[i] = w_iic * (P0[i] - gp) / s;
+}
+

@@ -17,6 +17,7 @@
 // of both products is permuted the same way on the A and the B side (lane q owns k = 16q..16q+15 of the first
 // product), which MFMA permits because it only sums over k.
 #include "common.h"
+#include "iic_device.h"
 
 namespace {
 
@@ -46,9 +47,17 @@ __device__ __forceinline__ void load_rows(const float *f, int r0, int l, int q, 
     rb[8] = b2.x; rb[9] = b2.y; rb[10] = b2.z; rb[11] = b2.w; rb[12] = b3.x; rb[13] = b3.y; rb[14] = b3.z; rb[15] = b3.w;
 }
 
+// The IIC core is a single-workgroup computation that is independent of the InfoNCE branch: when asked (P0 != NULL) it
+// rides along as ONE extra workgroup (blockIdx.x == m/16, blockIdx.y == 0) of pass 1 instead of a launch of its own.
+struct IicJob { float *P0; int C; float lamb, eps, w_iic; float *scratch; float *out; };
+
 // pass 1: partial row sums [NCE_SPLIT][m] and the positive logits pos[m]
-__global__ __launch_bounds__(256) void nce_pass1_kernel(const float *f, int m, float inv_t, float *rowsum_part, float *pos)
+__global__ __launch_bounds__(256) void nce_pass1_kernel(const float *f, int m, float inv_t, float *rowsum_part, float *pos, IicJob iic)
 {
+    if ((int)blockIdx.x == m / 16) {
+        if (blockIdx.y == 0 && iic.P0 != nullptr) iic_core_body<256>(iic.P0, iic.C, iic.lamb, iic.eps, iic.w_iic, iic.scratch, iic.out);
+        return;
+    }
     __shared__ float sh[4][16];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, l = lane & 15, q = lane >> 4;
     const int r0 = blockIdx.x * 16, ntiles = m / 16;
@@ -142,8 +151,8 @@ int64_t idl_nce_fused_workspace(int m)
 
 int idl_nce_fused_parts(void) { return NCE_SPLIT; }
 
-int idl_nce_fused(const float *f, int m, float temperature, float *lse, float *loss_rows, float *G_part, void *workspace,
-                  void *stream)
+static int nce_launch(const float *f, int m, float temperature, float *lse, float *loss_rows, float *G_part, void *workspace,
+                      const IicJob &iic, void *stream)
 {
     IDL_REQUIRE(f && lse && loss_rows && G_part && workspace, "NULL buffer");
     IDL_REQUIRE(m >= 32 && (m % 32) == 0 && m <= NCE_MAX_M && temperature > 0.f, "nce_fused: m must be a multiple of 32 in 32..2048, T > 0");
@@ -151,11 +160,25 @@ int idl_nce_fused(const float *f, int m, float temperature, float *lse, float *l
     float *rowsum_part = (float *)workspace, *pos = rowsum_part + (size_t)NCE_SPLIT * m;
     const float inv_t = 1.f / temperature;
     const dim3 grid((unsigned)(m / 16), NCE_SPLIT);
-    hipLaunchKernelGGL(nce_pass1_kernel, grid, dim3(256), 0, (hipStream_t)stream, f, m, inv_t, rowsum_part, pos);
+    const dim3 grid1((unsigned)(m / 16 + (iic.P0 != nullptr ? 1 : 0)), NCE_SPLIT);
+    hipLaunchKernelGGL(nce_pass1_kernel, grid1, dim3(256), 0, (hipStream_t)stream, f, m, inv_t, rowsum_part, pos, iic);
     hipLaunchKernelGGL(nce_pass2_kernel, grid, dim3(256), 0, (hipStream_t)stream, f, m, inv_t, (const float *)rowsum_part,
                        (const float *)pos, lse, loss_rows, G_part);
     IDL_HIP_TRY(hipGetLastError());
     return IDL_OK;
+}
+
+int idl_nce_fused(const float *f, int m, float temperature, float *lse, float *loss_rows, float *G_part, void *workspace,
+                  void *stream)
+{
+    return nce_launch(f, m, temperature, lse, loss_rows, G_part, workspace, IicJob{}, stream);
+}
+
+int idl_nce_fused_iic(const float *f, int m, float temperature, float *lse, float *loss_rows, float *G_part, void *workspace,
+                      float *P0, int C, float lamb, float eps, float w_iic, float *iic_scratch, float *out, void *stream)
+{
+    IDL_REQUIRE(P0 && iic_scratch && out && C >= 1 && C <= 48, "nce_fused_iic: n_clusters must be in 1..48 (larger: idl_iic_core)");
+    return nce_launch(f, m, temperature, lse, loss_rows, G_part, workspace, IicJob{P0, C, lamb, eps, w_iic, iic_scratch, out}, stream);
 }
 
 }  // extern "C"

@@ -130,17 +130,22 @@ class FusedLinearTrainer:
             torch.addmm(self.b2, bf.r1, self.W2.t(), out=bf.lat)
             chk(_L.idl_head_fwd(_p(bf.lat), _p(self.W3), _p(self.b3), m, C, tr, self.seed, _p(self.ctl),
                                 _p(bf.f), _p(bf.inv), _p(bf.r2), _p(bf.z), _stream()))
-        # ---- the two losses are independent branches: IIC on the side stream, InfoNCE on the main one
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            torch.mm(bf.z[:m // 2].t(), bf.z[m // 2:], out=bf.P0)        # IIC joint, one [C,B]x[B,C] GEMM
-            chk(_L.idl_iic_core(_p(bf.P0), C, self.lamb, EPS, self.weight, _p(bf.iic_scratch), _p(self.out), _stream()))
-        if bf.nce_fused:       # S = f f^T, lse, E + E^T and (E + E^T) f in two MFMA kernels, S never written
-            chk(_L.idl_nce_fused(_p(bf.f), m, TEMPERATURE, _p(bf.lse), _p(bf.loss_rows), _p(bf.G), _p(bf.nce_ws), _stream()))
+        # ---- the two losses are independent: with the fused InfoNCE kernels the IIC core rides along as one extra workgroup
+        if bf.nce_fused and C <= 48 and not self._overlap:
+            torch.mm(bf.z[:m // 2].t(), bf.z[m // 2:], out=bf.P0)            # IIC joint, one [C,B]x[B,C] GEMM
+            chk(_L.idl_nce_fused_iic(_p(bf.f), m, TEMPERATURE, _p(bf.lse), _p(bf.loss_rows), _p(bf.G), _p(bf.nce_ws),
+                                     _p(bf.P0), C, self.lamb, EPS, self.weight, _p(bf.iic_scratch), _p(self.out), _stream()))
         else:
-            torch.mm(bf.f, bf.f.t(), out=bf.S)
-            chk(_L.idl_nce_rows(_p(bf.S), m, TEMPERATURE, _p(bf.lse), _p(bf.loss_rows), _stream()))
-            torch.mm(bf.S, bf.f, out=bf.G[0])                            # (E + E^T) f
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                torch.mm(bf.z[:m // 2].t(), bf.z[m // 2:], out=bf.P0)
+                chk(_L.idl_iic_core(_p(bf.P0), C, self.lamb, EPS, self.weight, _p(bf.iic_scratch), _p(self.out), _stream()))
+            if bf.nce_fused:       # S = f f^T, lse, E + E^T and (E + E^T) f in two MFMA kernels, S never written
+                chk(_L.idl_nce_fused(_p(bf.f), m, TEMPERATURE, _p(bf.lse), _p(bf.loss_rows), _p(bf.G), _p(bf.nce_ws), _stream()))
+            else:
+                torch.mm(bf.f, bf.f.t(), out=bf.S)
+                chk(_L.idl_nce_rows(_p(bf.S), m, TEMPERATURE, _p(bf.lse), _p(bf.loss_rows), _stream()))
+                torch.mm(bf.S, bf.f, out=bf.G[0])                            # (E + E^T) f
         main.wait_stream(side)
         nce_coef = (1.0 - self.weight) / (m * TEMPERATURE)
         chk(_L.idl_head_bwd(_p(bf.z), _p(bf.r2), _p(bf.f), _p(bf.inv), _p(bf.G), bf.G.shape[0], _p(bf.P0), _p(self.W3), m, C, tr,

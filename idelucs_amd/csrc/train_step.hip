@@ -321,12 +321,50 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float *z, const flo
 constexpr int COL_PARTS = 32;
 
 struct ColJob { float *x; const float *act; float *partial; int n; float scale; };   // act != NULL: ReLU/Dropout backward in place
-struct ColJobs { ColJob j[3]; int first_block[4]; int m; int64_t *ctl; int64_t batch_advance; };   // ctl != NULL: ctl[1] += batch_advance
+struct ColJobs {
+    ColJob j[3]; int first_block[4]; int m; int64_t *ctl; int64_t batch_advance;   // ctl != NULL: ctl[1] += batch_advance
+    // optional 4th job (blockIdx.x == first_block[3]): partial weight gradient of the last layer, dW3_part[p][c][h] =
+    // sum over row chunk p of dlogits[r][c] * r2[r][h]  (C x 64 outputs, reduced over the chunks by rmsprop_kernel)
+    const float *dlogits; const float *r2; float *dW3_part; int C;
+};
 
 __global__ __launch_bounds__(256) void col_partial_kernel(ColJobs jobs)
 {
     __shared__ float sh[4][64];
     if (jobs.ctl != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) jobs.ctl[1] += jobs.batch_advance;
+    if ((int)blockIdx.x == jobs.first_block[3]) {              // dW3 partial of row chunk blockIdx.y
+        __shared__ float dl[32][48], rr[32][H2];
+        const int m = jobs.m, C = jobs.C;
+        const int rows = (m + COL_PARTS - 1) / COL_PARTS;
+        const int r0 = blockIdx.y * rows;
+        const int r1 = (r0 + rows < m) ? r0 + rows : m;
+        float acc[12];                                          // ceil(48 * 64 / 256) outputs per thread
+#pragma unroll
+        for (int i = 0; i < 12; ++i) acc[i] = 0.f;
+        for (int t0 = r0; t0 < r1; t0 += 32) {
+            const int nr = (r1 - t0 < 32) ? r1 - t0 : 32;
+            __syncthreads();
+            for (int i = threadIdx.x; i < nr * C; i += 256) { const int r = i / C, c = i - r * C; dl[r][c] = jobs.dlogits[(int64_t)(t0 + r) * C + c]; }
+            for (int i = threadIdx.x; i < nr * H2; i += 256) rr[i >> 6][i & 63] = jobs.r2[(int64_t)t0 * H2 + i];
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 12; ++i) {
+                const int o = threadIdx.x + 256 * i;            // o = c * 64 + h
+                if (o < C * H2) {
+                    const int c = o >> 6, h = o & 63;
+                    float a = acc[i];
+                    for (int r = 0; r < nr; ++r) a = fmaf(dl[r][c], rr[r][h], a);
+                    acc[i] = a;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+            const int o = threadIdx.x + 256 * i;
+            if (o < C * H2) jobs.dW3_part[(int64_t)blockIdx.y * C * H2 + o] = acc[i];
+        }
+        return;
+    }
     int k = 0;
     while (k < 2 && (int)blockIdx.x >= jobs.first_block[k + 1]) ++k;
     const ColJob job = jobs.j[k];
@@ -509,6 +547,7 @@ static int launch_col_jobs(ColJobs &jobs, int njobs, void *stream)
         if (k < njobs) nb += (jobs.j[k].n + 63) / 64;
     }
     jobs.first_block[3] = nb;
+    if (jobs.dW3_part != nullptr) nb += 1;
     hipLaunchKernelGGL(col_partial_kernel, dim3((unsigned)nb, COL_PARTS), dim3(256), 0, (hipStream_t)stream, jobs);
     IDL_HIP_TRY(hipGetLastError());
     return IDL_OK;
@@ -533,8 +572,10 @@ int idl_relu_dropout_bwd_colsum(float *dx, const float *act, int m, int n, int t
 }
 
 int idl_bias_grads(float *dx1, const float *act1, int n1, float *partial1, const float *x2, int n2, float *partial2,
-                   const float *x3, int n3, float *partial3, int m, int train, int64_t *ctl, int64_t batch_advance, void *stream)
+                   const float *x3, int n3, float *partial3, int m, int train, int64_t *ctl, int64_t batch_advance,
+                   const float *r2, float *dW3_partial, void *stream)
 {
+    IDL_REQUIRE(dW3_partial == nullptr || (r2 != nullptr && n2 == H2 && n3 <= 48), "bias_grads: dW3 partials need r2, latent width 64, n_clusters <= 48");
     IDL_REQUIRE(dx1 && act1 && partial1 && x2 && partial2 && x3 && partial3 && m >= 1 && n1 >= 1 && n2 >= 1 && n3 >= 1,
                 "bias_grads: NULL buffer or empty");
     ColJobs jobs{};
@@ -544,6 +585,7 @@ int idl_bias_grads(float *dx1, const float *act1, int n1, float *partial1, const
     jobs.j[2] = ColJob{(float *)x3, nullptr, partial3, n3, 1.f};
     jobs.ctl = ctl;
     jobs.batch_advance = batch_advance;
+    jobs.dlogits = x3; jobs.r2 = r2; jobs.dW3_part = dW3_partial; jobs.C = n3;
     return launch_col_jobs(jobs, 3, stream);
 }
 

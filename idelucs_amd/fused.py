@@ -74,6 +74,10 @@ class FusedLinearTrainer:
             raise ValueError("FusedLinearTrainer needs NetLinear (latent 64) and n_clusters <= 256")
         # bias gradients are kept as COL_PARTS stacked partial column sums, added up inside idl_rmsprop_step
         self.parts = [1 if p.dim() == 2 else _L.idl_col_sum_parts() for p in self.params]
+        # the last layer's weight gradient (C x 64) is produced as partials by the bias-gradient launch when C <= 48
+        self._dw3_partial = self.C <= 48 and os.environ.get("IDELUCS_DW3_PARTIAL", "1") != "0"
+        if self._dw3_partial:
+            self.parts[4] = _L.idl_col_sum_parts()
         self.grads = [torch.zeros((q,) + tuple(p.shape), dtype=p.dtype, device=p.device) if q > 1 else torch.zeros_like(p)
                       for p, q in zip(self.params, self.parts)]
         self.square_avg = [torch.zeros_like(p) for p in self.params]
@@ -154,12 +158,13 @@ class FusedLinearTrainer:
         gW1, gb1, gW2, gb2, gW3, gb3 = self.grads
         side.wait_stream(main)
         with torch.cuda.stream(side):
-            torch.mm(bf.dlogits.t(), bf.r2, out=gW3)
+            if not self._dw3_partial:
+                torch.mm(bf.dlogits.t(), bf.r2, out=gW3)
             torch.mm(bf.dlat.t(), bf.r1, out=gW2)
         torch.mm(bf.dlat, self.W2, out=bf.dr1)
         chk(_L.idl_bias_grads(_p(bf.dr1), _p(bf.r1), self.H1, _p(gb1), _p(bf.dlat), self.H2, _p(gb2), _p(bf.dlogits), C, _p(gb3),
                               m, tr, _p(self.ctl) if next_from is not None else None, batch_advance if next_from is not None else 0,
-                              _stream()))
+                              _p(bf.r2) if self._dw3_partial else None, _p(gW3) if self._dw3_partial else None, _stream()))
         torch.mm(bf.dr1.t(), bf.x, out=gW1)
         main.wait_stream(side)
         # ---- RMSprop (and advance the device-side step counter / batch offset)

@@ -55,6 +55,7 @@ SIGNATURES = {
     "idl_col_sum": (_int, [_vp, _int, _int, _vp, _vp]),
     "idl_relu_dropout_bwd_colsum": (_int, [_vp, _vp, _int, _int, _int, _vp, _vp]),
     "idl_col_sum_parts": (_int, []),
+    "idl_mid_bwd": (_int, [_vp] * 5 + [_int] + [_vp] * 4 + [_int, _int, _int, _c.c_float] + [_vp] * 8 + [_i64, _vp]),
     "idl_bias_grads": (_int, [_vp, _vp, _int, _vp, _vp, _int, _vp, _vp, _int, _vp, _int, _int, _vp, _i64, _vp, _vp, _vp]),
     "idl_rmsprop_step_gather": (_int, [_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _c.c_float, _c.c_float, _vp,
                                        _vp, _i64, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),

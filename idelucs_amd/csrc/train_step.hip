@@ -27,6 +27,7 @@ namespace {
 
 constexpr int H2 = 64;        // latent width of NetLinear == one wavefront
 constexpr int MAX_CPL = 4;    // classes per lane: n_clusters <= 256
+constexpr int COL_PARTS = 64; // row chunks of the partial column sums (bias gradients); 16 rows each at m = 1024
 
 struct U4 { uint32_t x, y, z, w; };
 
@@ -137,30 +138,31 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float *lat, const f
 }
 
 // ---------------------------------------------------------------- fused middle of the forward pass (fp32 MFMA)
-// a1[m,512] = Linear(F,512) output (bias included).  Per 16-row tile, in one kernel:
+// a1[m,512] = Linear(F,512) output (bias included).  One 1024-thread workgroup per 16-row tile:
 //   r1 = Dropout(ReLU(a1))  (written back in place: the backward needs it)
-//   lat = r1 W2^T + b2      (v_mfma_f32_16x16x4_f32; the four waves split K = 512, partial tiles added through LDS)
-//   head_row() on every row (normalise, ReLU/Dropout, Linear(64,C), softmax)
+//   lat = r1 W2^T + b2      (v_mfma_f32_16x16x4_f32; the 16 waves split K = 512 into 32-wide slices -- each lane owns 8
+//                            consecutive k of one row, so A is read and masked exactly once -- partial tiles added through LDS)
+//   head_row() one row per wave (normalise, ReLU/Dropout, Linear(64,C), softmax)
 // replacing relu_dropout_fwd + one hipBLASLt GEMM + head_fwd.  Same dropout streams as those kernels.
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 constexpr int H1 = 512;
+constexpr int MID_WAVES = 16;
 
-__global__ __launch_bounds__(256) void mid_fwd_kernel(float *a1, const float *W2, const float *b2, const float *W3, const float *b3, int m,
-                                                      int C, int train, uint64_t seed, const int64_t *ctl, float *f, float *inv,
-                                                      float *r2, float *z)
+__global__ __launch_bounds__(64 * MID_WAVES) void mid_fwd_kernel(float *a1, const float *W2, const float *b2, const float *W3,
+                                                                  const float *b3, int m, int C, int train, uint64_t seed,
+                                                                  const int64_t *ctl, float *f, float *inv, float *r2, float *z)
 {
-    __shared__ float part[4][16][H2 + 1];    // per-wave partial lat tiles; +1 breaks the 64-float row stride for the column reads
-    __shared__ float sh[4][H2];
+    // part[wave][row][col'], col' = (col + 16 (row >> 2)) & 63: the four row-quads of one MFMA store hit disjoint banks
+    __shared__ float part[MID_WAVES][16][H2];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, l = lane & 15, q = lane >> 4;
     const int r0 = blockIdx.x * 16;
     const uint32_t step = (uint32_t)ctl[0];
-    // this lane's 32 consecutive k of row r0 + l: k = 128 wv + 32 q + ks
-    const int k0 = 128 * wv + 32 * q;
-    float a[32];
+    const int k0 = 32 * wv + 8 * q;              // this lane's 8 consecutive k of row r0 + l
+    float a[8];
     {
         float4 *src = (float4 *)(a1 + (int64_t)(r0 + l) * H1 + k0);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < 2; ++i) {
             float4 v = src[i];
             float s0 = 1.f, s1 = 1.f, s2 = 1.f, s3 = 1.f;
             if (train) {                         // identical stream to relu_dropout_fwd_kernel: counter = float4 index of the flat array
@@ -175,30 +177,34 @@ __global__ __launch_bounds__(256) void mid_fwd_kernel(float *a1, const float *W2
             a[4 * i] = v.x; a[4 * i + 1] = v.y; a[4 * i + 2] = v.z; a[4 * i + 3] = v.w;
         }
     }
+    float4 bw[4][2];
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) {             // lat[:, 16 ct .. 16 ct + 15]: B[k][c] = W2[16 ct + c][k]
         const float4 *wsrc = (const float4 *)(W2 + (int64_t)(16 * ct + l) * H1 + k0);
+        bw[ct][0] = wsrc[0]; bw[ct][1] = wsrc[1];
+    }
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
         f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const float4 b = wsrc[i];
+        for (int i = 0; i < 2; ++i) {
+            const float4 b = bw[ct][i];
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4 * i], b.x, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4 * i + 1], b.y, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4 * i + 2], b.z, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4 * i + 3], b.w, acc, 0, 0, 0);
         }
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) part[wv][4 * q + reg][16 * ct + l] = acc[reg];   // C/D: row = 4q+reg, col = l
+        for (int reg = 0; reg < 4; ++reg) part[wv][4 * q + reg][(16 * ct + l + 16 * q) & 63] = acc[reg];   // C/D: row = 4q+reg, col = l
     }
     __syncthreads();
-    // rows 4 wv .. 4 wv + 3 of the tile: add the four K-quarters and the bias, then the per-row head
-    for (int rr = 0; rr < 4; ++rr) {
-        const int row = r0 + 4 * wv + rr, tr = 4 * wv + rr;
-        if (row < m) {
-            const float x = (part[0][tr][lane] + part[1][tr][lane]) + (part[2][tr][lane] + part[3][tr][lane]) + b2[lane];
-            head_row(x, row, lane, sh[wv], W3, b3, C, train, seed, step, f, inv, r2, z);
-        }
-    }
+    // wave wv owns row wv of the tile: add the 16 K-slices and the bias, then the per-row head
+    const int row = r0 + wv, cs = (lane + 16 * (wv >> 2)) & 63;
+    float x = b2[lane];
+#pragma unroll
+    for (int w = 0; w < MID_WAVES; ++w) x += part[w][wv][cs];
+    __syncthreads();                             // part is dead: its first rows become the waves' private head scratch
+    if (row < m) head_row(x, row, lane, &part[0][wv][0], W3, b3, C, train, seed, step, f, inv, r2, z);
 }
 
 // ---------------------------------------------------------------- InfoNCE on S = f f^T (un-scaled)
@@ -318,7 +324,6 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float *z, const flo
 // ---------------------------------------------------------------- column sums (bias gradients)
 // partial[p, c] = sum over the rows of chunk p of x[r, c]  (p = blockIdx.y, COL_PARTS chunks); the chunks
 // are added up, in order, by rmsprop_kernel -- deterministic and without an extra launch.
-constexpr int COL_PARTS = 32;
 
 struct ColJob { float *x; const float *act; float *partial; int n; float scale; };   // act != NULL: ReLU/Dropout backward in place
 struct ColJobs {
@@ -389,6 +394,158 @@ __global__ __launch_bounds__(256) void col_partial_kernel(ColJobs jobs)
     sh[w][lane] = acc;
     __syncthreads();
     if (w == 0 && c < n) job.partial[(int64_t)blockIdx.y * n + c] = (sh[0][lane] + sh[1][lane]) + (sh[2][lane] + sh[3][lane]);
+}
+
+// ---------------------------------------------------------------- fused middle of the backward pass (fp32 MFMA)
+// One 1024-thread workgroup per row chunk p of the partial sums (16 rows at m = 1024), replacing head_bwd + the hipBLASLt GEMM
+// dr1 = dlat W2 + bias_grads:
+//   1. head backward, one row per wave (as head_bwd_kernel): dlogits, dlat -> global and LDS
+//   2. dr1 = (dlat W2) masked by the layer-1 ReLU/Dropout (act1 > 0, x2 in training): v_mfma_f32_16x16x4_f32, K = 64, each wave
+//      two of the 32 column tiles (its W2 fragments are loaded once, before phase 1); column sums -> partial1[p]
+//   3. partial2[p] = column sums of dlat, partial3[p] = column sums of dlogits, dW3_part[p] = dlogits^T r2 over the chunk's rows
+struct MidBwdArgs {
+    const float *z, *r2, *f, *inv, *G, *dP0, *W3, *W2, *act1;
+    float *dlogits, *dlat, *dr1, *partial1, *partial2, *partial3, *dW3_part;
+    int64_t *ctl; int64_t batch_advance;
+    int g_parts, m, C, train; float nce_coef;
+};
+
+__global__ __launch_bounds__(64 * MID_WAVES) void mid_bwd_kernel(MidBwdArgs a)
+{
+    __shared__ float DL[16][H2 + 4];      // dlat rows of the tile; +4: the 16 rows of an A-fragment read hit disjoint banks
+    __shared__ float R2s[16][H2];
+    __shared__ float DLG[16][64 * MAX_CPL];
+    __shared__ float shz[MID_WAVES][64 * MAX_CPL];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, l = lane & 15, q = lane >> 4, tid = threadIdx.x;
+    const int m = a.m, C = a.C, B = m / 2;
+    const int rows = (m + COL_PARTS - 1) / COL_PARTS;
+    const int r0 = blockIdx.x * rows;
+    const int r1 = (r0 + rows < m) ? r0 + rows : m;
+    if (a.ctl != nullptr && blockIdx.x == 0 && tid == 0) a.ctl[1] += a.batch_advance;
+    // B fragments of this wave's two column tiles: B[k = 16 q + s][c = l] = W2[k][16 ct + l]
+    float bw[2][16];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int s = 0; s < 16; ++s) bw[j][s] = a.W2[(int64_t)(16 * q + s) * H1 + 16 * (2 * wv + j) + l];
+    const float scale = a.train ? 2.f : 1.f;
+    float cs1[2] = {0.f, 0.f}, s23 = 0.f, acc3[3] = {0.f, 0.f, 0.f};
+    for (int t0 = r0; t0 < r1; t0 += 16) {
+        const int nr = (r1 - t0 < 16) ? r1 - t0 : 16;
+        __syncthreads();
+        // ---- 1. head backward of row t0 + wv
+        if (wv < nr) {
+            const int row = t0 + wv;
+            const int prow = row < B ? row + B : row - B;
+            for (int c = lane; c < C; c += 64) shz[wv][c] = a.z[(int64_t)prow * C + c];
+            __builtin_amdgcn_wave_barrier();
+            float zc[MAX_CPL], dz[MAX_CPL];
+            float dot = 0.f;
+#pragma unroll
+            for (int t = 0; t < MAX_CPL; ++t) {
+                const int c = t * 64 + lane;
+                zc[t] = 0.f; dz[t] = 0.f;
+                if (c < C) {
+                    zc[t] = a.z[(int64_t)row * C + c];
+                    float acc = 0.f;
+#pragma unroll 4
+                    for (int k = 0; k < C; ++k) acc = fmaf(shz[wv][k], a.dP0[k * C + c], acc);
+                    dz[t] = acc;
+                    dot += acc * zc[t];
+                }
+            }
+            dot = wave_sum(dot);
+#pragma unroll
+            for (int t = 0; t < MAX_CPL; ++t) {
+                const int c = t * 64 + lane;
+                if (c < C) {
+                    const float dl = zc[t] * (dz[t] - dot);       // softmax backward
+                    a.dlogits[(int64_t)row * C + c] = dl;
+                    DLG[wv][c] = dl;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            float dr = 0.f;
+            for (int c = 0; c < C; ++c) dr = fmaf(DLG[wv][c], a.W3[(int64_t)c * H2 + lane], dr);
+            const float act = a.r2[(int64_t)row * H2 + lane];
+            const float dl_cls = act > 0.f ? dr * scale : 0.f;
+            const float fr = a.f[(int64_t)row * H2 + lane];
+            float gsum = a.G[(int64_t)row * H2 + lane];
+            for (int pp = 1; pp < a.g_parts; ++pp) gsum += a.G[((int64_t)pp * m + row) * H2 + lane];
+            const float df = a.nce_coef * (gsum - 2.f * a.f[(int64_t)prow * H2 + lane]);
+            const float proj = wave_sum(fr * df);
+            const float d = dl_cls + (df - fr * proj) * a.inv[row];
+            a.dlat[(int64_t)row * H2 + lane] = d;
+            DL[wv][lane] = d;
+            R2s[wv][lane] = act;
+        } else {
+            DL[wv][lane] = 0.f;
+            R2s[wv][lane] = 0.f;
+            for (int c = lane; c < C; c += 64) DLG[wv][c] = 0.f;
+        }
+        __syncthreads();
+        // ---- 2. dr1 tile = DL[16 x 64] W2[64 x 512]
+        float av[16];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float4 t = *(const float4 *)&DL[l][16 * q + 4 * i];
+            av[4 * i] = t.x; av[4 * i + 1] = t.y; av[4 * i + 2] = t.z; av[4 * i + 3] = t.w;
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bw[j][s], acc, 0, 0, 0);
+            const int col = 16 * (2 * wv + j) + l;
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int rl = 4 * q + reg;                        // C/D: row = 4q + reg, col = l
+                if (rl < nr) {
+                    const int64_t idx = (int64_t)(t0 + rl) * H1 + col;
+                    const float v = a.act1[idx] > 0.f ? acc[reg] * scale : 0.f;
+                    a.dr1[idx] = v;
+                    cs1[j] += v;
+                }
+            }
+        }
+        // ---- 3. the small partial sums, from LDS (rows >= nr are zero)
+        if (tid < H2) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s23 += DL[r][tid];
+        } else if (tid < H2 + C) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s23 += DLG[r][tid - H2];
+        }
+        if (a.dW3_part != nullptr) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int o = tid + 1024 * i;                      // o = c * 64 + h, C <= 48
+                if (o < C * H2) {
+                    const int c = o >> 6, h = o & 63;
+                    float x = acc3[i];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) x = fmaf(DLG[r][c], R2s[r][h], x);
+                    acc3[i] = x;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        float v = cs1[j];
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        if (q == 0) a.partial1[(int64_t)blockIdx.x * H1 + 16 * (2 * wv + j) + l] = v;
+    }
+    if (tid < H2) a.partial2[(int64_t)blockIdx.x * H2 + tid] = s23;
+    else if (tid < H2 + C) a.partial3[(int64_t)blockIdx.x * C + tid - H2] = s23;
+    if (a.dW3_part != nullptr) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int o = tid + 1024 * i;
+            if (o < C * H2) a.dW3_part[(int64_t)blockIdx.x * C * H2 + o] = acc3[i];
+        }
+    }
 }
 
 // ---------------------------------------------------------------- RMSprop over all parameter tensors
@@ -497,7 +654,7 @@ int idl_mid_fwd(float *a1, const float *W2, const float *b2, const float *W3, co
     IDL_REQUIRE(a1 && W2 && b2 && W3 && b3 && ctl && f && inv && r2 && z, "NULL buffer");
     IDL_REQUIRE(m >= 16 && (m % 16) == 0 && C >= 1 && C <= 64 * MAX_CPL, "mid_fwd: m must be a multiple of 16, n_clusters in 1..256");
     IDL_REQUIRE((((uintptr_t)a1 | (uintptr_t)W2) & 15u) == 0, "a1 / W2 must be 16-byte aligned");
-    hipLaunchKernelGGL(mid_fwd_kernel, dim3((unsigned)(m / 16)), dim3(256), 0, (hipStream_t)stream, a1, W2, b2, W3, b3, m, C, train, seed,
+    hipLaunchKernelGGL(mid_fwd_kernel, dim3((unsigned)(m / 16)), dim3(64 * MID_WAVES), 0, (hipStream_t)stream, a1, W2, b2, W3, b3, m, C, train, seed,
                        ctl, f, inv, r2, z);
     IDL_HIP_TRY(hipGetLastError());
     return IDL_OK;
@@ -533,6 +690,25 @@ int idl_head_bwd(const float *z, const float *r2, const float *f, const float *i
     IDL_REQUIRE(m >= 2 && (m % 2) == 0 && C >= 1 && C <= 64 * MAX_CPL, "head_bwd: even m, n_clusters in 1..256");
     hipLaunchKernelGGL(head_bwd_kernel, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, (hipStream_t)stream, z, r2, f, inv, G, g_parts, dP0, W3, m, C,
                        train, nce_coef, dlogits, dlat);
+    IDL_HIP_TRY(hipGetLastError());
+    return IDL_OK;
+}
+
+int idl_mid_bwd(const float *z, const float *r2, const float *f, const float *inv, const float *G, int g_parts, const float *dP0,
+                const float *W3, const float *W2, const float *act1, int m, int C, int train, float nce_coef, float *dlogits, float *dlat,
+                float *dr1, float *partial1, float *partial2, float *partial3, float *dW3_partial, int64_t *ctl, int64_t batch_advance,
+                void *stream)
+{
+    IDL_REQUIRE(g_parts >= 1 && g_parts <= 16, "mid_bwd: g_parts outside 1..16");
+    IDL_REQUIRE(z && r2 && f && inv && G && dP0 && W3 && W2 && act1 && dlogits && dlat && dr1 && partial1 && partial2 && partial3, "NULL buffer");
+    IDL_REQUIRE(m >= 2 && (m % 2) == 0 && C >= 1 && C <= 64 * MAX_CPL, "mid_bwd: even m, n_clusters in 1..256");
+    IDL_REQUIRE(dW3_partial == nullptr || C <= 48, "mid_bwd: dW3 partials need n_clusters <= 48");
+    MidBwdArgs a{};
+    a.z = z; a.r2 = r2; a.f = f; a.inv = inv; a.G = G; a.dP0 = dP0; a.W3 = W3; a.W2 = W2; a.act1 = act1;
+    a.dlogits = dlogits; a.dlat = dlat; a.dr1 = dr1; a.partial1 = partial1; a.partial2 = partial2; a.partial3 = partial3;
+    a.dW3_part = dW3_partial; a.ctl = ctl; a.batch_advance = batch_advance;
+    a.g_parts = g_parts; a.m = m; a.C = C; a.train = train; a.nce_coef = nce_coef;
+    hipLaunchKernelGGL(mid_bwd_kernel, dim3(COL_PARTS), dim3(64 * MID_WAVES), 0, (hipStream_t)stream, a);
     IDL_HIP_TRY(hipGetLastError());
     return IDL_OK;
 }

@@ -1,10 +1,11 @@
 """idelucs_amd.fused -- the explicit, fused optimizer step for the default configuration
 (NetLinear encoder + RMSprop), replayed as a HIP graph.
 
-One step of reference idelucs/models.py:117-133 becomes ~20 launches: the dense products on
+One step of reference idelucs/models.py:117-133 becomes ~10 launches: the large dense products on
 hipBLASLt (torch.mm/addmm with out=, no allocation) and every other piece a fused HIP kernel from
-csrc/train_step.hip (C ABI: idl_relu_dropout_fwd, idl_head_fwd, idl_nce_rows, idl_iic_core,
-idl_head_bwd, idl_col_sum, idl_relu_dropout_bwd_colsum, idl_rmsprop_step).  The batch is assembled by
+csrc/train_step.hip + nce_fused.hip (C ABI: idl_mid_fwd, idl_nce_fused_iic, idl_mid_bwd, idl_rmsprop_step_gather;
+the unfused building blocks idl_relu_dropout_fwd, idl_head_fwd, idl_nce_rows, idl_iic_core, idl_head_bwd,
+idl_bias_grads remain for shapes the fused kernels do not take and as their test references).  The batch is assembled by
 idl_gather_pairs_at from the HBM feature store using a device-resident offset that the optimizer
 kernel advances, so an epoch is `n_batches` replays of one captured graph with no host work between.
 
@@ -88,9 +89,8 @@ class FusedLinearTrainer:
         self._bufs = {}
         self._graphs = {}
         self._side = torch.cuda.Stream(device=self.dev)     # second branch of the step (see step_on_batch)
-        # measured on MI355X: correct (tests) but 2 % slower than the three separate kernels (64 workgroups, 4 rows of head
-        # work serialised per wave) -> opt-in only
-        self._mid_fused = self.H1 == 512 and os.environ.get("IDELUCS_MID_FUSED", "0") == "1"
+        # the layers between the two big GEMMs as one 1024-thread MFMA kernel per direction (idl_mid_fwd / idl_mid_bwd)
+        self._mid_fused = self.H1 == 512 and os.environ.get("IDELUCS_MID_FUSED", "1") != "0"
         self._pipeline = os.environ.get("IDELUCS_PIPELINE", "1") != "0"   # optimizer launch also assembles the next batch
         self._overlap = os.environ.get("IDELUCS_OVERLAP", "0") != "0"   # measured: no gain inside a HIP graph on ROCm 7.2
         self._perm = None
@@ -152,19 +152,30 @@ class FusedLinearTrainer:
                 torch.mm(bf.S, bf.f, out=bf.G[0])                            # (E + E^T) f
         main.wait_stream(side)
         nce_coef = (1.0 - self.weight) / (m * TEMPERATURE)
-        chk(_L.idl_head_bwd(_p(bf.z), _p(bf.r2), _p(bf.f), _p(bf.inv), _p(bf.G), bf.G.shape[0], _p(bf.P0), _p(self.W3), m, C, tr,
-                            nce_coef, _p(bf.dlogits), _p(bf.dlat), _stream()))
-        # ---- parameter gradients (one launch for the three bias gradients + the ReLU/Dropout backward of layer 1)
         gW1, gb1, gW2, gb2, gW3, gb3 = self.grads
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
+        adv_ctl = _p(self.ctl) if next_from is not None else None
+        adv = batch_advance if next_from is not None else 0
+        if self._mid_fused:
+            # ---- head backward + dr1 = dlat W2 (MFMA) + ReLU/Dropout backward + every bias gradient (+ dW3) in one launch
+            chk(_L.idl_mid_bwd(_p(bf.z), _p(bf.r2), _p(bf.f), _p(bf.inv), _p(bf.G), bf.G.shape[0], _p(bf.P0), _p(self.W3), _p(self.W2),
+                               _p(bf.r1), m, C, tr, nce_coef, _p(bf.dlogits), _p(bf.dlat), _p(bf.dr1), _p(gb1), _p(gb2), _p(gb3),
+                               _p(gW3) if self._dw3_partial else None, adv_ctl, adv, _stream()))
             if not self._dw3_partial:
                 torch.mm(bf.dlogits.t(), bf.r2, out=gW3)
             torch.mm(bf.dlat.t(), bf.r1, out=gW2)
-        torch.mm(bf.dlat, self.W2, out=bf.dr1)
-        chk(_L.idl_bias_grads(_p(bf.dr1), _p(bf.r1), self.H1, _p(gb1), _p(bf.dlat), self.H2, _p(gb2), _p(bf.dlogits), C, _p(gb3),
-                              m, tr, _p(self.ctl) if next_from is not None else None, batch_advance if next_from is not None else 0,
-                              _p(bf.r2) if self._dw3_partial else None, _p(gW3) if self._dw3_partial else None, _stream()))
+        else:
+            chk(_L.idl_head_bwd(_p(bf.z), _p(bf.r2), _p(bf.f), _p(bf.inv), _p(bf.G), bf.G.shape[0], _p(bf.P0), _p(self.W3), m, C, tr,
+                                nce_coef, _p(bf.dlogits), _p(bf.dlat), _stream()))
+            # ---- parameter gradients (one launch for the three bias gradients + the ReLU/Dropout backward of layer 1)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                if not self._dw3_partial:
+                    torch.mm(bf.dlogits.t(), bf.r2, out=gW3)
+                torch.mm(bf.dlat.t(), bf.r1, out=gW2)
+            torch.mm(bf.dlat, self.W2, out=bf.dr1)
+            chk(_L.idl_bias_grads(_p(bf.dr1), _p(bf.r1), self.H1, _p(gb1), _p(bf.dlat), self.H2, _p(gb2), _p(bf.dlogits), C, _p(gb3),
+                                  m, tr, adv_ctl, adv, _p(bf.r2) if self._dw3_partial else None,
+                                  _p(gW3) if self._dw3_partial else None, _stream()))
         torch.mm(bf.dr1.t(), bf.x, out=gW1)
         main.wait_stream(side)
         # ---- RMSprop (and advance the device-side step counter / batch offset)

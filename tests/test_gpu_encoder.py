@@ -420,3 +420,52 @@ def test_fused_mid_forward_equals_separate_kernels(dev, m, C, train):
     assert torch.equal(r2a != 0, r2b != 0) or (r2a != 0).ne(r2b != 0).float().mean() < 1e-3   # same latent dropout mask (sign flips at ~0 aside)
     for x, y, tol in ((fa, fb, 2e-5), (ia, ib, 2e-5), (r2a, r2b, 2e-4), (za, zb, 2e-5)):
         np.testing.assert_allclose(y.cpu().numpy(), x.cpu().numpy(), rtol=2e-4, atol=tol)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("m,C,train,dw3", [(32, 5, 0, 1), (1024, 20, 1, 1), (960, 20, 1, 1), (14, 7, 1, 1), (64, 200, 1, 0), (2080, 20, 1, 1)])
+def test_fused_mid_backward_equals_separate_kernels(dev, m, C, train, dw3):
+    """idl_mid_bwd (head backward + dr1 = dlat W2 on fp32 MFMA + ReLU/Dropout backward + all partial bias sums + dW3 partials)
+    == idl_head_bwd + torch.mm + idl_bias_grads, on ragged / empty row chunks too."""
+    import torch
+    from idelucs_amd import _lib
+    from idelucs_amd.fused import _p, _stream
+    L = _lib.lib
+    parts = L.idl_col_sum_parts()
+    torch.manual_seed(m * 7 + C)
+    z = torch.softmax(torch.randn(m, C, device=dev), 1)
+    r2 = torch.relu(torch.randn(m, 64, device=dev)) * (torch.rand(m, 64, device=dev) > 0.5) * 2
+    lat = torch.randn(m, 64, device=dev)
+    nrm = lat.norm(dim=1).clamp_min(1e-12)
+    f = lat / nrm[:, None]; inv = 1.0 / nrm
+    gp = 4
+    G = torch.randn(gp, m, 64, device=dev) * 0.3
+    dP0 = torch.randn(C, C, device=dev) * 0.1; dP0 = dP0 + dP0.t()
+    W3 = torch.randn(C, 64, device=dev) * 0.2
+    W2 = torch.randn(64, 512, device=dev) * 0.06
+    act1 = torch.relu(torch.randn(m, 512, device=dev)) * (torch.rand(m, 512, device=dev) > 0.5)
+    coef = 0.75 / (m * 0.85)
+    # separate kernels
+    dlg_a = torch.empty(m, C, device=dev); dlat_a = torch.empty(m, 64, device=dev)
+    _lib.check(L.idl_head_bwd(_p(z), _p(r2), _p(f), _p(inv), _p(G), gp, _p(dP0), _p(W3), m, C, train, coef, _p(dlg_a), _p(dlat_a), _stream()))
+    dr1_a = dlat_a @ W2
+    p1a = torch.zeros(parts, 512, device=dev); p2a = torch.zeros(parts, 64, device=dev); p3a = torch.zeros(parts, C, device=dev)
+    w3a = torch.zeros(parts, C, 64, device=dev)
+    ctl_a = torch.tensor([3, 100], dtype=torch.int64, device=dev)
+    _lib.check(L.idl_bias_grads(_p(dr1_a), _p(act1), 512, _p(p1a), _p(dlat_a), 64, _p(p2a), _p(dlg_a), C, _p(p3a), m, train,
+                                _p(ctl_a), 7, _p(r2) if dw3 else None, _p(w3a) if dw3 else None, _stream()))
+    # fused
+    dlg_b = torch.empty(m, C, device=dev); dlat_b = torch.empty(m, 64, device=dev); dr1_b = torch.full((m, 512), float('nan'), device=dev)
+    p1b = torch.full((parts, 512), float('nan'), device=dev); p2b = torch.full((parts, 64), float('nan'), device=dev)
+    p3b = torch.full((parts, C), float('nan'), device=dev); w3b = torch.full((parts, C, 64), float('nan'), device=dev)
+    ctl_b = torch.tensor([3, 100], dtype=torch.int64, device=dev)
+    _lib.check(L.idl_mid_bwd(_p(z), _p(r2), _p(f), _p(inv), _p(G), gp, _p(dP0), _p(W3), _p(W2), _p(act1), m, C, train, coef,
+                             _p(dlg_b), _p(dlat_b), _p(dr1_b), _p(p1b), _p(p2b), _p(p3b), _p(w3b) if dw3 else None, _p(ctl_b), 7, _stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(ctl_a, ctl_b) and int(ctl_b[1]) == 107
+    assert torch.equal(dlg_a, dlg_b) and torch.equal(dlat_a, dlat_b)          # same per-row arithmetic
+    assert torch.equal(dr1_a == 0, dr1_b == 0) or ((dr1_a == 0) != (dr1_b == 0)).float().mean() < 1e-4
+    np.testing.assert_allclose(dr1_b.cpu().numpy(), dr1_a.cpu().numpy(), rtol=2e-4, atol=2e-6)
+    for x, y in ((p1a, p1b), (p2a, p2b), (p3a, p3b)) + (((w3a, w3b),) if dw3 else ()):
+        np.testing.assert_allclose(y.sum(0).cpu().numpy(), x.sum(0).cpu().numpy(), rtol=2e-4, atol=2e-5)
+        assert torch.isfinite(y).all()                                          # every chunk slab written, empty chunks as zeros

@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void standardise_scalar(const T *x, int64_t to
 
 __global__ __launch_bounds__(256) void gather_pairs_kernel(idl_dev::GatherArgs g)
 {
-    idl_dev::gather_row(g, blockIdx.x, threadIdx.x, blockDim.x);
+    idl_dev::gather_block(g, blockIdx.x, threadIdx.x);
 }
 
 }  // namespace
@@ -215,7 +215,7 @@ int idl_gather_pairs_at(const float *feats, int64_t n, int64_t f, int64_t view_s
     int rc = idl::device_info(&di);
     if (rc != IDL_OK) return rc;
     idl_dev::GatherArgs g{feats, n, f, view_stride, pair_idx, base, batch, (int64_t)-1, mean, scale, inv_scale, y};
-    hipLaunchKernelGGL(gather_pairs_kernel, dim3((unsigned)(2 * batch)), dim3(256), 0, (hipStream_t)stream, g);
+    hipLaunchKernelGGL(gather_pairs_kernel, dim3((unsigned)idl_dev::gather_blocks(f, batch)), dim3(256), 0, (hipStream_t)stream, g);
     IDL_HIP_TRY(hipGetLastError());
     return IDL_OK;
 }

@@ -46,25 +46,93 @@ __device__ __forceinline__ void gather_row(const GatherArgs &g, int64_t row, int
     if ((g.f & 3) == 0) {
         const float4 *src4 = (const float4 *)src;
         float4 *dst4 = (float4 *)dst;
-        for (int64_t i = tid; i < g.f / 4; i += nthreads) {
-            const float4 v = src4[i];
-            const int64_t c = i * 4;
-            float4 o;
-            if (g.inv_scale != nullptr) {
-                o.x = std_f32_rcp(v.x, g.mean[c + 0], g.scale[c + 0], g.inv_scale[c + 0]);
-                o.y = std_f32_rcp(v.y, g.mean[c + 1], g.scale[c + 1], g.inv_scale[c + 1]);
-                o.z = std_f32_rcp(v.z, g.mean[c + 2], g.scale[c + 2], g.inv_scale[c + 2]);
-                o.w = std_f32_rcp(v.w, g.mean[c + 3], g.scale[c + 3], g.inv_scale[c + 3]);
-            } else {
-                o.x = std_f32(v.x, g.mean[c + 0], g.scale[c + 0]);
-                o.y = std_f32(v.y, g.mean[c + 1], g.scale[c + 1]);
-                o.z = std_f32(v.z, g.mean[c + 2], g.scale[c + 2]);
-                o.w = std_f32(v.w, g.mean[c + 3], g.scale[c + 3]);
+        // the row is a random 4^k * 4 B read from HBM: put four independent 16-byte loads per thread in flight before any arithmetic
+        const int64_t n4 = g.f / 4;
+        for (int64_t i0 = tid; i0 < n4; i0 += 4 * (int64_t)nthreads) {
+            float4 vv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t i = i0 + (int64_t)u * nthreads;
+                if (i < n4) vv[u] = src4[i];
             }
-            dst4[i] = o;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t i = i0 + (int64_t)u * nthreads;
+                if (i >= n4) continue;
+                const float4 v = vv[u];
+                const int64_t c = i * 4;
+                float4 o;
+                if (g.inv_scale != nullptr) {
+                    o.x = std_f32_rcp(v.x, g.mean[c + 0], g.scale[c + 0], g.inv_scale[c + 0]);
+                    o.y = std_f32_rcp(v.y, g.mean[c + 1], g.scale[c + 1], g.inv_scale[c + 1]);
+                    o.z = std_f32_rcp(v.z, g.mean[c + 2], g.scale[c + 2], g.inv_scale[c + 2]);
+                    o.w = std_f32_rcp(v.w, g.mean[c + 3], g.scale[c + 3], g.inv_scale[c + 3]);
+                } else {
+                    o.x = std_f32(v.x, g.mean[c + 0], g.scale[c + 0]);
+                    o.y = std_f32(v.y, g.mean[c + 1], g.scale[c + 1]);
+                    o.z = std_f32(v.z, g.mean[c + 2], g.scale[c + 2]);
+                    o.w = std_f32(v.w, g.mean[c + 3], g.scale[c + 3]);
+                }
+                dst4[i] = o;
+            }
         }
     } else {
         for (int64_t i = tid; i < g.f; i += nthreads) dst[i] = std_f32(src[i], g.mean[i], g.scale[i]);
+    }
+}
+
+// Tiled form of the same copy for 4 | f (used by every launcher): one 256-thread workgroup owns GATHER_ROWS output rows x 1024
+// columns.  A thread reads its 4 columns' (mean, scale, 1/scale) once for all the rows -- per element those tables are 6x the
+// feature bytes -- and has GATHER_ROWS independent 16-byte row reads in flight.
+constexpr int GATHER_ROWS = 8;
+
+__host__ __device__ inline int64_t gather_blocks(int64_t f, int64_t batch)
+{
+    if (f & 3) return 2 * batch;
+    return ((2 * batch + GATHER_ROWS - 1) / GATHER_ROWS) * ((f / 4 + 255) / 256);
+}
+
+__device__ __forceinline__ void gather_block(const GatherArgs &g, int64_t blk, int tid)
+{
+    if (g.f & 3) { gather_row(g, blk, tid, 256); return; }
+    const int64_t n4 = g.f / 4, slices = (n4 + 255) / 256;
+    const int64_t rg = blk / slices, i = (blk - rg * slices) * 256 + tid;
+    if (i >= n4) return;
+    const int64_t base = g.base ? *g.base : 0;
+    const float4 *src4[GATHER_ROWS];
+    float4 vv[GATHER_ROWS];
+#pragma unroll
+    for (int u = 0; u < GATHER_ROWS; ++u) {
+        const int64_t row = rg * GATHER_ROWS + u;
+        const int64_t b = row < g.batch ? row : row - g.batch;
+        const int64_t at = base + b;
+        src4[u] = nullptr;
+        if (row < 2 * g.batch && (g.n_pairs < 0 || at < g.n_pairs)) {
+            const int64_t pair = g.pair_idx[at];
+            const int64_t m = pair / g.n, s = pair - m * g.n;
+            src4[u] = (const float4 *)(g.feats + (row < g.batch ? 0 : (m + 1) * g.view_stride) + s * g.f);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < GATHER_ROWS; ++u)
+        if (src4[u] != nullptr) vv[u] = src4[u][i];
+    const int64_t c = i * 4;
+    double mu[4], sc[4], rc[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { mu[e] = g.mean[c + e]; sc[e] = g.scale[c + e]; rc[e] = g.inv_scale ? g.inv_scale[c + e] : 0.0; }
+#pragma unroll
+    for (int u = 0; u < GATHER_ROWS; ++u) {
+        if (src4[u] == nullptr) continue;
+        const float4 v = vv[u];
+        float4 o;
+        if (g.inv_scale != nullptr) {
+            o.x = std_f32_rcp(v.x, mu[0], sc[0], rc[0]); o.y = std_f32_rcp(v.y, mu[1], sc[1], rc[1]);
+            o.z = std_f32_rcp(v.z, mu[2], sc[2], rc[2]); o.w = std_f32_rcp(v.w, mu[3], sc[3], rc[3]);
+        } else {
+            o.x = std_f32(v.x, mu[0], sc[0]); o.y = std_f32(v.y, mu[1], sc[1]);
+            o.z = std_f32(v.z, mu[2], sc[2]); o.w = std_f32(v.w, mu[3], sc[3]);
+        }
+        ((float4 *)(g.y + (rg * GATHER_ROWS + u) * g.f))[i] = o;
     }
 }
 

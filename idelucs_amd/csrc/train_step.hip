@@ -562,33 +562,44 @@ struct RmsArgs {
     int count;
 };
 
-// Grid: blockIdx.x in [0, gx * count) are optimizer blocks (tensor = blockIdx.x / gx); the following 2 * g.batch blocks, when
-// g.y != NULL, assemble the NEXT batch (nothing in this launch writes what they read: the batch offset ctl[1] was already
-// advanced by the bias-gradient launch of this step, and x is no longer read by this step's GEMMs).
+// Grid: when g.y != NULL the first n_gather = gather_blocks() blocks assemble the NEXT batch (nothing in this launch writes what they
+// read: the batch offset ctl[1] was already advanced by the bias-gradient launch of this step, and x is no longer read by this
+// step's GEMMs); they go first because a gathered row is a dependent chain of HBM latencies that the streaming optimizer blocks
+// behind them hide.  The following gx * count blocks are optimizer blocks (tensor = block / gx).
 __global__ __launch_bounds__(256) void rmsprop_kernel(RmsArgs a, const float *hyper, int64_t *ctl, int64_t batch_advance, int gx,
-                                                      idl_dev::GatherArgs g)
+                                                      int n_gather, idl_dev::GatherArgs g)
 {
-    if ((int)blockIdx.x >= gx * a.count) {
-        idl_dev::gather_row(g, (int64_t)blockIdx.x - (int64_t)gx * a.count, threadIdx.x, 256);
+    if ((int)blockIdx.x < n_gather) {
+        idl_dev::gather_block(g, (int64_t)blockIdx.x, threadIdx.x);
         return;
     }
-    const int t = (int)blockIdx.x / gx;
-    const int bx = (int)blockIdx.x - t * gx;
+    const int bid = (int)blockIdx.x - n_gather;
+    const int t = bid / gx;
+    const int bx = bid - t * gx;
     const float lr = hyper[0], alpha = hyper[1], eps = hyper[2], wd = hyper[3], oma = hyper[4];
     if (t < a.count) {
         float *p = a.p[t]; const float *g = a.g[t]; float *v = a.v[t];
         const int64_t n = a.n[t];
         if (a.parts[t] == 1 && (n & 3) == 0 && ((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)v)) & 15u) == 0) {
             float4 *p4 = (float4 *)p; const float4 *g4 = (const float4 *)g; float4 *v4 = (float4 *)v;
-            for (int64_t i = (int64_t)bx * blockDim.x + threadIdx.x; i < n / 4; i += (int64_t)gx * blockDim.x) {
-                float4 pi = p4[i], vi = v4[i];
-                const float4 gr = g4[i];
+            auto upd = [&](float4 &pi, float4 &vi, const float4 gr) {
                 const float g0 = gr.x + wd * pi.x, g1 = gr.y + wd * pi.y, g2 = gr.z + wd * pi.z, g3 = gr.w + wd * pi.w;
                 vi.x = vi.x * alpha + oma * g0 * g0; vi.y = vi.y * alpha + oma * g1 * g1;
                 vi.z = vi.z * alpha + oma * g2 * g2; vi.w = vi.w * alpha + oma * g3 * g3;
                 pi.x -= lr * (g0 / (sqrtf(vi.x) + eps)); pi.y -= lr * (g1 / (sqrtf(vi.y) + eps));
                 pi.z -= lr * (g2 / (sqrtf(vi.z) + eps)); pi.w -= lr * (g3 / (sqrtf(vi.w) + eps));
+            };
+            const int64_t n4 = n / 4, stride = (int64_t)gx * blockDim.x;
+            for (int64_t i = (int64_t)bx * blockDim.x + threadIdx.x; i < n4; i += 2 * stride) {      // two elements' loads in flight
+                const int64_t i2 = i + stride;
+                const bool two = i2 < n4;
+                float4 pi = p4[i], vi = v4[i];
+                const float4 gr = g4[i];
+                float4 pj = pi, vj = vi, gj = gr;
+                if (two) { pj = p4[i2]; vj = v4[i2]; gj = g4[i2]; }
+                upd(pi, vi, gr);
                 v4[i] = vi; p4[i] = pi;
+                if (two) { upd(pj, vj, gj); v4[i2] = vj; p4[i2] = pj; }
             }
         } else
         for (int64_t i = (int64_t)bx * blockDim.x + threadIdx.x; i < n; i += (int64_t)gx * blockDim.x) {
@@ -611,8 +622,8 @@ __global__ __launch_bounds__(256) void rmsprop_kernel(RmsArgs a, const float *hy
             p[i] = pi - lr * (gi / (sqrtf(vi) + eps));           // param.addcdiv_(grad, sqrt(v)+eps, value=-lr)
         }
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) { ctl[0] += 1; ctl[1] += batch_advance; }
-    if (a.out != nullptr && (int)blockIdx.x == gx * a.count - 1 && threadIdx.x < 64) {
+    if (bid == 0 && threadIdx.x == 0) { ctl[0] += 1; ctl[1] += batch_advance; }
+    if (a.out != nullptr && bid == gx * a.count - 1 && threadIdx.x < 64) {
         // step loss = w_nce * mean(loss_rows) + w_iic * IIC (left in out[3] by iic_core_kernel); out[1] = running sum
         float acc = 0.f;
         for (int i = threadIdx.x; i < a.loss_m; i += 64) acc += a.loss_rows[i];
@@ -784,9 +795,9 @@ static int rmsprop_launch(int count, float *const *params, const float *const *g
     int64_t gx = (mx + 255) / 256;
     if (gx > 1024) gx = 1024;
     if (gx < 1) gx = 1;
-    const int64_t extra = g.y != nullptr ? 2 * g.batch : 0;
+    const int64_t extra = g.y != nullptr ? idl_dev::gather_blocks(g.f, g.batch) : 0;
     hipLaunchKernelGGL(rmsprop_kernel, dim3((unsigned)(gx * count + extra)), dim3(256), 0, (hipStream_t)stream, a, hyper, ctl, batch_advance,
-                       (int)gx, g);
+                       (int)gx, (int)extra, g);
     IDL_HIP_TRY(hipGetLastError());
     return IDL_OK;
 }

@@ -3,14 +3,10 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "wave_ops.h"
 
 namespace idl_dev {
-__device__ __forceinline__ float wsum_f(float v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
+__device__ __forceinline__ float wsum_f(float v) { return wave_sum_f(v); }
 __device__ __forceinline__ double wsum_d(double v)
 {
 #pragma unroll

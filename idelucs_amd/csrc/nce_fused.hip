@@ -77,8 +77,7 @@ __global__ __launch_bounds__(256) void nce_pass1_kernel(const float *f, int m, f
         }
     }
     // this lane holds the partial of row r over its j's (q, reg); add the four q groups, then the four waves
-    sum += __shfl_xor(sum, 16, 64);
-    sum += __shfl_xor(sum, 32, 64);
+    sum = idl_dev::add_xor32(idl_dev::add_xor16(sum));
     if (q == 0) sh[wv][l] = sum;
     __syncthreads();
     if (threadIdx.x < 16) rowsum_part[(int64_t)blockIdx.y * m + r0 + threadIdx.x] = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);

@@ -22,6 +22,7 @@
 #include "common.h"
 #include "iic_device.h"
 #include "scaler_device.h"
+#include "wave_ops.h"
 
 namespace {
 
@@ -45,18 +46,8 @@ __device__ __forceinline__ U4 philox(uint32_t c0, uint32_t c1, uint32_t c2, uint
     return U4{c0, c1, c2, c3};
 }
 
-__device__ __forceinline__ float wave_sum(float v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-__device__ __forceinline__ float wave_max(float v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
-}
+__device__ __forceinline__ float wave_sum(float v) { return idl_dev::wave_sum_f(v); }
+__device__ __forceinline__ float wave_max(float v) { return idl_dev::wave_max_f(v); }
 
 // ---------------------------------------------------------------- ReLU + Dropout(0.5), in place
 __global__ __launch_bounds__(256) void relu_dropout_fwd_kernel(float4 *a, int64_t n4, int train, uint64_t seed, const int64_t *ctl,
@@ -148,41 +139,59 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 constexpr int H1 = 512;
 constexpr int MID_WAVES = 16;
 
-__global__ __launch_bounds__(64 * MID_WAVES) void mid_fwd_kernel(float *a1, const float *W2, const float *b2, const float *W3,
-                                                                  const float *b3, int m, int C, int train, uint64_t seed,
-                                                                  const int64_t *ctl, float *f, float *inv, float *r2, float *z)
+__global__ __launch_bounds__(64 * MID_WAVES) void mid_fwd_kernel(float *__restrict__ a1, const float *__restrict__ W2,
+                                                                  const float *__restrict__ b2, const float *__restrict__ W3,
+                                                                  const float *__restrict__ b3, int m, int C, int train, uint64_t seed,
+                                                                  const int64_t *__restrict__ ctl, float *__restrict__ f,
+                                                                  float *__restrict__ inv, float *__restrict__ r2, float *__restrict__ z)
 {
-    // part[wave][row][col'], col' = (col + 16 (row >> 2)) & 63: the four row-quads of one MFMA store hit disjoint banks
+    // part[wave][row][col'], col' = (col + 16 (row >> 2)) & 63: the four row-quads of one MFMA store hit disjoint banks.
+    // Once the K-slices are added up the same memory holds the r2 tile (A operand of the logits) and the logits tile.
     __shared__ float part[MID_WAVES][16][H2];
+    float (*R2t)[H2 + 4] = (float (*)[H2 + 4])&part[0][0][0];               // [16][68]
+    float (*LG)[64 * MAX_CPL + 1] = (float (*)[64 * MAX_CPL + 1])&part[2][0][0];   // [16][257]
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, l = lane & 15, q = lane >> 4;
     const int r0 = blockIdx.x * 16;
-    const uint32_t step = (uint32_t)ctl[0];
     const int k0 = 32 * wv + 8 * q;              // this lane's 8 consecutive k of row r0 + l
-    float a[8];
-    {
-        float4 *src = (float4 *)(a1 + (int64_t)(r0 + l) * H1 + k0);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            float4 v = src[i];
-            float s0 = 1.f, s1 = 1.f, s2 = 1.f, s3 = 1.f;
-            if (train) {                         // identical stream to relu_dropout_fwd_kernel: counter = float4 index of the flat array
-                const int64_t idx4 = ((int64_t)(r0 + l) * H1 + k0) / 4 + i;
-                const U4 r = philox((uint32_t)idx4, 1u, step, (uint32_t)(idx4 >> 32), (uint32_t)seed, (uint32_t)(seed >> 32));
-                s0 = (r.x >> 31) ? 2.f : 0.f; s1 = (r.y >> 31) ? 2.f : 0.f;
-                s2 = (r.z >> 31) ? 2.f : 0.f; s3 = (r.w >> 31) ? 2.f : 0.f;
-            }
-            v.x = v.x > 0.f ? v.x * s0 : 0.f; v.y = v.y > 0.f ? v.y * s1 : 0.f;
-            v.z = v.z > 0.f ? v.z * s2 : 0.f; v.w = v.w > 0.f ? v.w * s3 : 0.f;
-            src[i] = v;
-            a[4 * i] = v.x; a[4 * i + 1] = v.y; a[4 * i + 2] = v.z; a[4 * i + 3] = v.w;
-        }
-    }
+    // ---- every global read of the kernel is issued here, before the first dependent instruction
+    float4 *src = (float4 *)(a1 + (int64_t)(r0 + l) * H1 + k0);
+    float4 av[2] = {src[0], src[1]};
     float4 bw[4][2];
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) {             // lat[:, 16 ct .. 16 ct + 15]: B[k][c] = W2[16 ct + c][k]
         const float4 *wsrc = (const float4 *)(W2 + (int64_t)(16 * ct + l) * H1 + k0);
         bw[ct][0] = wsrc[0]; bw[ct][1] = wsrc[1];
     }
+    const int nct = (C + 15) / 16;               // column tiles of the logits; wave wv < nct owns tile wv
+    float4 w3f[4];                               // B[k = 16 q + s][c = l] = W3[16 wv + l][16 q + s]
+    float b3v = 0.f;
+    if (wv < nct) {
+        const int c = min(16 * wv + l, C - 1);
+        const float4 *wsrc = (const float4 *)(W3 + (int64_t)c * H2 + 16 * q);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w3f[i] = wsrc[i];
+        b3v = b3[c];
+    }
+    const float b2v = b2[lane];
+    const uint32_t step = (uint32_t)ctl[0];
+    // ---- ReLU + Dropout of layer 1, in place
+    float a[8];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        float4 v = av[i];
+        float s0 = 1.f, s1 = 1.f, s2 = 1.f, s3 = 1.f;
+        if (train) {                             // identical stream to relu_dropout_fwd_kernel: counter = float4 index of the flat array
+            const int64_t idx4 = ((int64_t)(r0 + l) * H1 + k0) / 4 + i;
+            const U4 r = philox((uint32_t)idx4, 1u, step, (uint32_t)(idx4 >> 32), (uint32_t)seed, (uint32_t)(seed >> 32));
+            s0 = (r.x >> 31) ? 2.f : 0.f; s1 = (r.y >> 31) ? 2.f : 0.f;
+            s2 = (r.z >> 31) ? 2.f : 0.f; s3 = (r.w >> 31) ? 2.f : 0.f;
+        }
+        v.x = v.x > 0.f ? v.x * s0 : 0.f; v.y = v.y > 0.f ? v.y * s1 : 0.f;
+        v.z = v.z > 0.f ? v.z * s2 : 0.f; v.w = v.w > 0.f ? v.w * s3 : 0.f;
+        src[i] = v;
+        a[4 * i] = v.x; a[4 * i + 1] = v.y; a[4 * i + 2] = v.z; a[4 * i + 3] = v.w;
+    }
+    // ---- lat = r1 W2^T: this wave's K-slice
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) {
         f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
@@ -198,13 +207,66 @@ __global__ __launch_bounds__(64 * MID_WAVES) void mid_fwd_kernel(float *a1, cons
         for (int reg = 0; reg < 4; ++reg) part[wv][4 * q + reg][(16 * ct + l + 16 * q) & 63] = acc[reg];   // C/D: row = 4q+reg, col = l
     }
     __syncthreads();
-    // wave wv owns row wv of the tile: add the 16 K-slices and the bias, then the per-row head
+    // ---- wave wv owns row wv of the tile: add the 16 K-slices and the bias; normalise; ReLU + Dropout of the latent
     const int row = r0 + wv, cs = (lane + 16 * (wv >> 2)) & 63;
-    float x = b2[lane];
+    float x = b2v;
 #pragma unroll
     for (int w = 0; w < MID_WAVES; ++w) x += part[w][wv][cs];
-    __syncthreads();                             // part is dead: its first rows become the waves' private head scratch
-    if (row < m) head_row(x, row, lane, &part[0][wv][0], W3, b3, C, train, seed, step, f, inv, r2, z);
+    const float nrm = fmaxf(sqrtf(wave_sum(x * x)), 1e-12f);       // F.normalize(dim=1), eps 1e-12
+    float sc = 1.f;
+    if (train) {                                 // as head_row
+        const U4 r = philox((uint32_t)row, 2u, step, 0u, (uint32_t)seed, (uint32_t)(seed >> 32));
+        const uint32_t word = (lane < 32) ? r.x : r.y;
+        sc = ((word >> (lane & 31)) & 1u) ? 2.f : 0.f;
+    }
+    const float ar = x > 0.f ? x * sc : 0.f;
+    if (row < m) {
+        f[(int64_t)row * H2 + lane] = x / nrm;
+        if (lane == 0) inv[row] = 1.f / nrm;
+        r2[(int64_t)row * H2 + lane] = ar;
+    }
+    __syncthreads();                             // part is dead
+    R2t[wv][lane] = ar;
+    __syncthreads();
+    // ---- logits tile wv = r2[16 x 64] W3[16 wv .. 16 wv + 15]^T + b3
+    if (wv < nct) {
+        f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float4 t = *(const float4 *)&R2t[l][16 * q + 4 * i];
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(t.x, w3f[i].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(t.y, w3f[i].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(t.z, w3f[i].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(t.w, w3f[i].w, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) LG[4 * q + reg][16 * wv + l] = acc[reg] + b3v;
+    }
+    __syncthreads();
+    // ---- softmax of row wv
+    float lg[MAX_CPL];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < MAX_CPL; ++t) {
+        const int c = t * 64 + lane;
+        lg[t] = c < C ? LG[wv][c] : -INFINITY;
+        mx = fmaxf(mx, lg[t]);
+    }
+    mx = wave_max(mx);
+    float den = 0.f;
+#pragma unroll
+    for (int t = 0; t < MAX_CPL; ++t) {
+        const int c = t * 64 + lane;
+        if (c < C) { lg[t] = __expf(lg[t] - mx); den += lg[t]; }
+    }
+    den = wave_sum(den);
+    if (row < m) {
+#pragma unroll
+        for (int t = 0; t < MAX_CPL; ++t) {
+            const int c = t * 64 + lane;
+            if (c < C) z[(int64_t)row * C + c] = lg[t] / den;
+        }
+    }
 }
 
 // ---------------------------------------------------------------- InfoNCE on S = f f^T (un-scaled)
@@ -533,8 +595,7 @@ __global__ __launch_bounds__(64 * MID_WAVES) void mid_bwd_kernel(MidBwdArgs a)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         float v = cs1[j];
-        v += __shfl_xor(v, 16, 64);
-        v += __shfl_xor(v, 32, 64);
+        v = idl_dev::add_xor32(idl_dev::add_xor16(v));
         if (q == 0) a.partial1[(int64_t)blockIdx.x * H1 + 16 * (2 * wv + j) + l] = v;
     }
     if (tid < H2) a.partial2[(int64_t)blockIdx.x * H2 + tid] = s23;
@@ -664,7 +725,7 @@ int idl_mid_fwd(float *a1, const float *W2, const float *b2, const float *W3, co
 {
     IDL_REQUIRE(a1 && W2 && b2 && W3 && b3 && ctl && f && inv && r2 && z, "NULL buffer");
     IDL_REQUIRE(m >= 16 && (m % 16) == 0 && C >= 1 && C <= 64 * MAX_CPL, "mid_fwd: m must be a multiple of 16, n_clusters in 1..256");
-    IDL_REQUIRE((((uintptr_t)a1 | (uintptr_t)W2) & 15u) == 0, "a1 / W2 must be 16-byte aligned");
+    IDL_REQUIRE((((uintptr_t)a1 | (uintptr_t)W2 | (uintptr_t)W3) & 15u) == 0, "a1 / W2 / W3 must be 16-byte aligned");
     hipLaunchKernelGGL(mid_fwd_kernel, dim3((unsigned)(m / 16)), dim3(64 * MID_WAVES), 0, (hipStream_t)stream, a1, W2, b2, W3, b3, m, C, train, seed,
                        ctl, f, inv, r2, z);
     IDL_HIP_TRY(hipGetLastError());

@@ -1,0 +1,61 @@
+// wave_ops.h -- wave64 all-reduces on the VALU only (gfx950): four DPP steps inside each row of 16 lanes, then
+// v_permlane16_swap / v_permlane32_swap (new in gfx950) across the rows -- 8 instructions, against six ds_bpermute round
+// trips through the LDS crossbar for the __shfl_xor butterfly.  Every lane ends with the same value (each step combines a
+// lane with its mirror partner, and a + b == b + a bit for bit).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace idl_dev {
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+constexpr int DPP_XOR1 = 0xB1;          // quad_perm:[1,0,3,2]
+constexpr int DPP_XOR2 = 0x4E;          // quad_perm:[2,3,0,1]
+constexpr int DPP_HALF_MIRROR = 0x141;  // lane i <-> 7 - i inside each 8
+constexpr int DPP_MIRROR = 0x140;       // lane i <-> 15 - i inside each row
+
+// value of the lane 16 (32) positions away, as a pair with this lane's own: r[0], r[1] hold {own, partner} in some order
+__device__ __forceinline__ float add_xor16(float v)
+{
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float add_xor32(float v)
+{
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float max_xor16(float v)
+{
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float max_xor32(float v)
+{
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+
+__device__ __forceinline__ float row_sum16(float v)      // sum over the 16 lanes of this lane's row
+{
+    v += dpp_f<DPP_XOR1>(v);
+    v += dpp_f<DPP_XOR2>(v);
+    v += dpp_f<DPP_HALF_MIRROR>(v);
+    v += dpp_f<DPP_MIRROR>(v);
+    return v;
+}
+__device__ __forceinline__ float wave_sum_f(float v) { return add_xor32(add_xor16(row_sum16(v))); }
+__device__ __forceinline__ float wave_max_f(float v)
+{
+    v = fmaxf(v, dpp_f<DPP_XOR1>(v));
+    v = fmaxf(v, dpp_f<DPP_XOR2>(v));
+    v = fmaxf(v, dpp_f<DPP_HALF_MIRROR>(v));
+    v = fmaxf(v, dpp_f<DPP_MIRROR>(v));
+    return max_xor32(max_xor16(v));
+}
+
+}  // namespace idl_dev

@@ -155,7 +155,7 @@ class FusedLinearTrainer:
         gW1, gb1, gW2, gb2, gW3, gb3 = self.grads
         adv_ctl = _p(self.ctl) if next_from is not None else None
         adv = batch_advance if next_from is not None else 0
-        if self._mid_fused:
+        if self._mid_fused and C <= 48:       # (at n_clusters = 200 the per-row C x C products want all 256 CUs: separate kernels)
             # ---- head backward + dr1 = dlat W2 (MFMA) + ReLU/Dropout backward + every bias gradient (+ dW3) in one launch
             chk(_L.idl_mid_bwd(_p(bf.z), _p(bf.r2), _p(bf.f), _p(bf.inv), _p(bf.G), bf.G.shape[0], _p(bf.P0), _p(self.W3), _p(self.W2),
                                _p(bf.r1), m, C, tr, nce_coef, _p(bf.dlogits), _p(bf.dlat), _p(bf.dr1), _p(gb1), _p(gb2), _p(gb3),

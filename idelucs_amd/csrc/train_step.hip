@@ -621,7 +621,52 @@ struct RmsArgs {
     int64_t n[8];
     int parts[8];     // g[t] holds parts[t] stacked partial gradients [parts, n] (1 = a plain gradient)
     int count;
+    // optional: the gradient of tensor wg_t is not read but computed here as wg_dy^T wg_x ([wg_m, n_out]^T [wg_m, n_in]) by
+    // wg_tiles extra workgroups, one 16 x 16 tile each, which also apply the update to their tile (a.n[wg_t] is 0 then)
+    const float *wg_dy, *wg_x; float *wg_grad;
+    int wg_t, wg_m, wg_n_out, wg_n_in, wg_tiles;
 };
+
+// One 16 x 16 tile of dy^T x on the fp32 matrix cores (v_mfma_f32_16x16x4_f32): the four waves split the contraction index m,
+// the partial tiles are added through LDS in a fixed order, then RMSprop on the tile.  red: 1024 floats of LDS.
+__device__ __forceinline__ void wgrad_tile_rms(const RmsArgs &a, int tile, float lr, float alpha, float eps, float wd, float oma, float *red)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l = lane & 15, q = lane >> 4;
+    const int tn = a.wg_n_in / 16;
+    const int i0 = (tile / tn) * 16, j0 = (tile % tn) * 16;
+    const int lda = a.wg_n_out, ldb = a.wg_n_in, m = a.wg_m;
+    const int per = ((m + 15) / 16) * 4;                     // rows per wave, a multiple of 4
+    const int kb = wv * per, ke = (kb + per < m) ? kb + per : m;
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+    const float *pa = a.wg_dy + i0 + l, *pb = a.wg_x + j0 + l;    // A[i = l][k = q] = dy[k][i0 + l], B[k = q][j = l] = x[k][j0 + l]
+    for (int k0 = kb; k0 < ke; k0 += 128) {                  // 64 independent loads in flight per lane, then 32 MFMAs
+        float av[32], bv[32];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) {
+            const int k = k0 + 4 * u + q;
+            const bool ok = k < ke;
+            const int kc = ok ? k : ke - 1;
+            const float ta = pa[kc * lda], tb = pb[kc * ldb];
+            av[u] = ok ? ta : 0.f;
+            bv[u] = ok ? tb : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 32; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wv * 256 + (4 * q + r) * 16 + l] = acc[r];          // C/D: row = 4 q + reg, col = l
+    __syncthreads();
+    const int i = tid >> 4, j = tid & 15;
+    const float g = (red[tid] + red[256 + tid]) + (red[512 + tid] + red[768 + tid]);
+    const int o = (i0 + i) * ldb + j0 + j;
+    if (a.wg_grad != nullptr) a.wg_grad[o] = g;
+    float *p = a.p[a.wg_t], *v = a.v[a.wg_t];
+    const float pi = p[o];
+    const float gi = g + wd * pi;
+    const float vi = v[o] * alpha + oma * gi * gi;
+    v[o] = vi;
+    p[o] = pi - lr * (gi / (sqrtf(vi) + eps));
+}
 
 // Grid: when g.y != NULL the first n_gather = gather_blocks() blocks assemble the NEXT batch (nothing in this launch writes what they
 // read: the batch offset ctl[1] was already advanced by the bias-gradient launch of this step, and x is no longer read by this
@@ -630,14 +675,22 @@ struct RmsArgs {
 __global__ __launch_bounds__(256) void rmsprop_kernel(RmsArgs a, const float *hyper, int64_t *ctl, int64_t batch_advance, int gx,
                                                       int n_gather, idl_dev::GatherArgs g)
 {
-    if ((int)blockIdx.x < n_gather) {
-        idl_dev::gather_block(g, (int64_t)blockIdx.x, threadIdx.x);
+    // grid order: weight-gradient tiles (dependent chains of strided loads: first, so that the streaming blocks behind them hide
+    // their latency), then the gather blocks, then the optimizer blocks
+    const float lr = hyper[0], alpha = hyper[1], eps = hyper[2], wd = hyper[3], oma = hyper[4];
+    if ((int)blockIdx.x < a.wg_tiles) {
+        __shared__ float red[1024];
+        wgrad_tile_rms(a, (int)blockIdx.x, lr, alpha, eps, wd, oma, red);
         return;
     }
-    const int bid = (int)blockIdx.x - n_gather;
+    const int b0 = (int)blockIdx.x - a.wg_tiles;
+    if (b0 < n_gather) {
+        idl_dev::gather_block(g, (int64_t)b0, threadIdx.x);
+        return;
+    }
+    const int bid = b0 - n_gather;
     const int t = bid / gx;
     const int bx = bid - t * gx;
-    const float lr = hyper[0], alpha = hyper[1], eps = hyper[2], wd = hyper[3], oma = hyper[4];
     if (t < a.count) {
         float *p = a.p[t]; const float *g = a.g[t]; float *v = a.v[t];
         const int64_t n = a.n[t];
@@ -840,7 +893,8 @@ int idl_bias_grads(float *dx1, const float *act1, int n1, float *partial1, const
 static int rmsprop_launch(int count, float *const *params, const float *const *grads, const int32_t *grad_parts,
                           float *const *square_avg, const int64_t *sizes, const float *hyper, int64_t *ctl, int64_t batch_advance,
                           const float *loss_rows, int loss_m, float w_nce, float w_iic, float *out, const idl_dev::GatherArgs &g,
-                          void *stream)
+                          void *stream, int wg_index = -1, const float *wg_dy = nullptr, const float *wg_x = nullptr, int wg_m = 0,
+                          int wg_n_out = 0, int wg_n_in = 0, float *wg_grad = nullptr)
 {
     IDL_REQUIRE(count >= 1 && count <= 8 && params && grads && square_avg && sizes && hyper && ctl, "rmsprop_step: 1..8 tensors");
     RmsArgs a{};
@@ -853,12 +907,22 @@ static int rmsprop_launch(int count, float *const *params, const float *const *g
         IDL_REQUIRE(a.parts[i] >= 1, "rmsprop_step: grad_parts must be >= 1");
         if (sizes[i] > mx) mx = sizes[i];
     }
+    if (wg_index >= 0) {
+        IDL_REQUIRE(wg_index < count && wg_dy && wg_x && wg_m >= 1 && wg_n_out >= 16 && (wg_n_out % 16) == 0 && wg_n_in >= 16 &&
+                    (wg_n_in % 16) == 0 && sizes[wg_index] == (int64_t)wg_n_out * wg_n_in && (int64_t)wg_m * wg_n_in < (1ll << 31),
+                    "rmsprop_step: in-launch weight gradient needs n_out, n_in multiples of 16 and sizes[wg_index] == n_out * n_in");
+        a.wg_t = wg_index; a.wg_dy = wg_dy; a.wg_x = wg_x; a.wg_grad = wg_grad; a.wg_m = wg_m; a.wg_n_out = wg_n_out; a.wg_n_in = wg_n_in;
+        a.wg_tiles = (wg_n_out / 16) * (wg_n_in / 16);
+        a.n[wg_index] = 0;                  // its optimizer blocks have nothing to do: the tile workgroups update it
+        mx = 0;
+        for (int i = 0; i < count; ++i) if (a.n[i] > mx) mx = a.n[i];
+    }
     int64_t gx = (mx + 255) / 256;
     if (gx > 1024) gx = 1024;
     if (gx < 1) gx = 1;
     const int64_t extra = g.y != nullptr ? idl_dev::gather_blocks(g.f, g.batch) : 0;
-    hipLaunchKernelGGL(rmsprop_kernel, dim3((unsigned)(gx * count + extra)), dim3(256), 0, (hipStream_t)stream, a, hyper, ctl, batch_advance,
-                       (int)gx, (int)extra, g);
+    hipLaunchKernelGGL(rmsprop_kernel, dim3((unsigned)(gx * count + extra + a.wg_tiles)), dim3(256), 0, (hipStream_t)stream, a, hyper, ctl,
+                       batch_advance, (int)gx, (int)extra, g);
     IDL_HIP_TRY(hipGetLastError());
     return IDL_OK;
 }
@@ -881,6 +945,23 @@ int idl_rmsprop_step_gather(int count, float *const *params, const float *const 
     IDL_REQUIRE(feats && pair_idx && mean && scale && y && n >= 1 && f >= 1 && batch >= 1 && n_pairs >= 0, "rmsprop_step_gather: bad gather arguments");
     idl_dev::GatherArgs g{feats, n, f, view_stride, pair_idx, ctl + 1, batch, n_pairs, mean, scale, inv_scale, y};
     return rmsprop_launch(count, params, grads, grad_parts, square_avg, sizes, hyper, ctl, 0, loss_rows, loss_m, w_nce, w_iic, out, g, stream);
+}
+
+int idl_rmsprop_step_gather_wgrad(int count, float *const *params, const float *const *grads, const int32_t *grad_parts,
+                                  float *const *square_avg, const int64_t *sizes, const float *hyper, int64_t *ctl,
+                                  const float *loss_rows, int loss_m, float w_nce, float w_iic, float *out,
+                                  const float *feats, int64_t n, int64_t f, int64_t view_stride, const int64_t *pair_idx, int64_t n_pairs,
+                                  int64_t batch, const double *mean, const double *scale, const double *inv_scale, float *y,
+                                  int wg_index, const float *wg_dy, const float *wg_x, int wg_m, int wg_n_out, int wg_n_in, float *wg_grad,
+                                  void *stream)
+{
+    idl_dev::GatherArgs g{};
+    if (feats != nullptr) {
+        IDL_REQUIRE(pair_idx && mean && scale && y && n >= 1 && f >= 1 && batch >= 1 && n_pairs >= 0, "rmsprop_step_gather_wgrad: bad gather arguments");
+        g = idl_dev::GatherArgs{feats, n, f, view_stride, pair_idx, ctl + 1, batch, n_pairs, mean, scale, inv_scale, y};
+    }
+    return rmsprop_launch(count, params, grads, grad_parts, square_avg, sizes, hyper, ctl, 0, loss_rows, loss_m, w_nce, w_iic, out, g, stream,
+                          wg_index, wg_dy, wg_x, wg_m, wg_n_out, wg_n_in, wg_grad);
 }
 
 }  // extern "C"

@@ -92,7 +92,12 @@ class FusedLinearTrainer:
         # the layers between the two big GEMMs as one 1024-thread MFMA kernel per direction (idl_mid_fwd / idl_mid_bwd)
         self._mid_fused = self.H1 == 512 and os.environ.get("IDELUCS_MID_FUSED", "1") != "0"
         self._pipeline = os.environ.get("IDELUCS_PIPELINE", "1") != "0"   # optimizer launch also assembles the next batch
+        # dW2 = dlat^T r1 as 16 x 16 MFMA tiles inside the optimizer launch (idl_rmsprop_step_gather_wgrad) instead of a GEMM launch
+        self._dw2_inlaunch = self.H1 % 16 == 0 and os.environ.get("IDELUCS_DW2_INLAUNCH", "1") != "0"
         self._overlap = os.environ.get("IDELUCS_OVERLAP", "0") != "0"   # measured: no gain inside a HIP graph on ROCm 7.2
+        # opt-in: dW1 on this package's own MFMA kernel with RMSprop in its epilogue (csrc/wgrad.hip; measured a wash against
+        # hipBLASLt + the optimizer launch, so off by default)
+        self._wgrad_fused = os.environ.get("IDELUCS_WGRAD_FUSED", "0") != "0"
         self._perm = None
         n = len(self.params)
         self._pp = (ctypes.c_void_p * n)(*[p.data_ptr() for p in self.params])
@@ -100,6 +105,7 @@ class FusedLinearTrainer:
         self._vp = (ctypes.c_void_p * n)(*[v.data_ptr() for v in self.square_avg])
         self._sz = (ctypes.c_int64 * n)(*[p.numel() for p in self.params])
         self._parts = (ctypes.c_int32 * n)(*self.parts)
+        self._sz_no_w1 = (ctypes.c_int64 * n)(*([0] + [p.numel() for p in self.params[1:]]))     # W1 updated by idl_wgrad_rmsprop
 
     def gradient(self, i):
         """Gradient of parameter i as a tensor of the parameter's shape (sums the stacked partials)."""
@@ -162,7 +168,8 @@ class FusedLinearTrainer:
                                _p(gW3) if self._dw3_partial else None, adv_ctl, adv, _stream()))
             if not self._dw3_partial:
                 torch.mm(bf.dlogits.t(), bf.r2, out=gW3)
-            torch.mm(bf.dlat.t(), bf.r1, out=gW2)
+            if not (self._dw2_inlaunch and next_from is not None):
+                torch.mm(bf.dlat.t(), bf.r1, out=gW2)
         else:
             chk(_L.idl_head_bwd(_p(bf.z), _p(bf.r2), _p(bf.f), _p(bf.inv), _p(bf.G), bf.G.shape[0], _p(bf.P0), _p(self.W3), m, C, tr,
                                 nce_coef, _p(bf.dlogits), _p(bf.dlat), _stream()))
@@ -171,22 +178,36 @@ class FusedLinearTrainer:
             with torch.cuda.stream(side):
                 if not self._dw3_partial:
                     torch.mm(bf.dlogits.t(), bf.r2, out=gW3)
-                torch.mm(bf.dlat.t(), bf.r1, out=gW2)
+                if not (self._dw2_inlaunch and next_from is not None):
+                    torch.mm(bf.dlat.t(), bf.r1, out=gW2)
             torch.mm(bf.dlat, self.W2, out=bf.dr1)
             chk(_L.idl_bias_grads(_p(bf.dr1), _p(bf.r1), self.H1, _p(gb1), _p(bf.dlat), self.H2, _p(gb2), _p(bf.dlogits), C, _p(gb3),
                                   m, tr, adv_ctl, adv, _p(bf.r2) if self._dw3_partial else None,
                                   _p(gW3) if self._dw3_partial else None, _stream()))
-        torch.mm(bf.dr1.t(), bf.x, out=gW1)
+        w1_done = self._wgrad_fused and bool(_L.idl_wgrad_supported(m, self.H1, self.F))
+        if w1_done:
+            chk(_L.idl_wgrad_rmsprop(_p(bf.dr1), _p(bf.x), m, self.H1, self.F, None, _p(self.W1), _p(self.square_avg[0]), _p(self.hyper),
+                                     _stream()))
+        else:
+            torch.mm(bf.dr1.t(), bf.x, out=gW1)
+        sz = self._sz_no_w1 if w1_done else self._sz
         main.wait_stream(side)
         # ---- RMSprop (and advance the device-side step counter / batch offset)
-        if next_from is not None:
+        if next_from is not None and self._dw2_inlaunch:
             st = next_from
-            chk(_L.idl_rmsprop_step_gather(len(self.params), self._pp, self._gp, self._parts, self._vp, self._sz, _p(self.hyper),
+            chk(_L.idl_rmsprop_step_gather_wgrad(len(self.params), self._pp, self._gp, self._parts, self._vp, sz, _p(self.hyper),
+                                                 _p(self.ctl), _p(bf.loss_rows), m, 1.0 - self.weight, self.weight, _p(self.out),
+                                                 _p(st.feats), st.n, st.f, st.n * st.f, _p(self._perm), st.n_pairs, m // 2,
+                                                 _p(st.mean), _p(st.scale), _p(st.inv_scale), _p(bf.x),
+                                                 2, _p(bf.dlat), _p(bf.r1), m, self.H2, self.H1, _p(gW2), _stream()))
+        elif next_from is not None:
+            st = next_from
+            chk(_L.idl_rmsprop_step_gather(len(self.params), self._pp, self._gp, self._parts, self._vp, sz, _p(self.hyper),
                                            _p(self.ctl), _p(bf.loss_rows), m, 1.0 - self.weight, self.weight, _p(self.out),
                                            _p(st.feats), st.n, st.f, st.n * st.f, _p(self._perm), st.n_pairs, m // 2,
                                            _p(st.mean), _p(st.scale), _p(st.inv_scale), _p(bf.x), _stream()))
         else:
-            chk(_L.idl_rmsprop_step(len(self.params), self._pp, self._gp, self._parts, self._vp, self._sz, _p(self.hyper),
+            chk(_L.idl_rmsprop_step(len(self.params), self._pp, self._gp, self._parts, self._vp, sz, _p(self.hyper),
                                     _p(self.ctl), batch_advance, _p(bf.loss_rows), m, 1.0 - self.weight, self.weight, _p(self.out),
                                     _stream()))
 

@@ -469,3 +469,73 @@ def test_fused_mid_backward_equals_separate_kernels(dev, m, C, train, dw3):
     for x, y in ((p1a, p1b), (p2a, p2b), (p3a, p3b)) + (((w3a, w3b),) if dw3 else ()):
         np.testing.assert_allclose(y.sum(0).cpu().numpy(), x.sum(0).cpu().numpy(), rtol=2e-4, atol=2e-5)
         assert torch.isfinite(y).all()                                          # every chunk slab written, empty chunks as zeros
+
+
+@pytest.mark.parametrize("m", [1024, 960, 70])
+def test_dw2_inside_the_optimizer_launch(dev, m):
+    """idl_rmsprop_step_gather_wgrad: the gradient of one tensor computed in the launch as dy^T x (MFMA tiles) and applied
+    there equals torch's product followed by the RMSprop formula; the other tensors are updated as by idl_rmsprop_step."""
+    import ctypes
+    import torch
+    from idelucs_amd import _lib
+    from idelucs_amd.fused import _p, _stream
+    L = _lib.lib
+    torch.manual_seed(m)
+    dy = torch.randn(m, 64, device=dev); x = torch.relu(torch.randn(m, 512, device=dev))
+    W = [torch.randn(64, 512, device=dev) * 0.05, torch.randn(512, device=dev) * 0.1]
+    V = [torch.rand(64, 512, device=dev) * 1e-3, torch.rand(512, device=dev) * 1e-3]
+    gb = torch.randn(512, device=dev)
+    grads = [torch.zeros(64, 512, device=dev), gb]
+    W0, V0 = [w.clone() for w in W], [v.clone() for v in V]
+    hyper = torch.tensor([1e-3, 0.99, 1e-8, 0.01, 0.01], device=dev)
+    ctl = torch.zeros(2, dtype=torch.int64, device=dev)
+    gout = torch.empty(64, 512, device=dev)
+    arr = lambda ts: (ctypes.c_void_p * 2)(*[t_.data_ptr() for t_ in ts])
+    _lib.check(L.idl_rmsprop_step_gather_wgrad(2, arr(W), arr(grads), (ctypes.c_int32 * 2)(1, 1), arr(V), (ctypes.c_int64 * 2)(64 * 512, 512),
+                                               _p(hyper), _p(ctl), None, 0, 0.0, 0.0, None,
+                                               None, 0, 0, 0, None, 0, 0, None, None, None, None,
+                                               0, _p(dy), _p(x), m, 64, 512, _p(gout), _stream()))
+    torch.cuda.synchronize()
+    g64 = (dy.double().t() @ x.double())
+    assert (gout.double() - g64).abs().max().item() <= 2e-6 * g64.abs().max().item() + 1e-5
+
+    def upd(w, v, g):
+        gi = g + 0.01 * w
+        v2 = v * 0.99 + 0.01 * gi * gi
+        return w - 1e-3 * (gi / (v2.sqrt() + 1e-8)), v2
+    for w, v, w0, v0, g in zip(W, V, W0, V0, [gout, gb]):
+        wr, vr = upd(w0, v0, g)
+        assert torch.allclose(w, wr, rtol=1e-5, atol=1e-7) and torch.allclose(v, vr, rtol=1e-5, atol=1e-9)
+    assert ctl.tolist() == [1, 0]
+
+
+@pytest.mark.parametrize("m,fused", [(1024, True), (960, True), (128, False)])
+def test_wgrad_kernel_vs_torch(dev, m, fused):
+    """idl_wgrad_rmsprop (opt-in dW1 kernel): dy^T x on the fp32 matrix cores within fp32 summation error of a float64 product,
+    and its fused RMSprop epilogue equals the formula applied to that gradient; unsupported shapes are refused."""
+    import torch
+    from idelucs_amd import _lib
+    from idelucs_amd.fused import _p, _stream
+    L = _lib.lib
+    torch.manual_seed(m)
+    H, F = 512, 1024
+    dy = torch.randn(m, H, device=dev) * (torch.rand(m, H, device=dev) < 0.25); x = torch.randn(m, F, device=dev)
+    W = torch.randn(H, F, device=dev) * 0.02; V = torch.rand(H, F, device=dev) * 1e-3
+    W0, V0 = W.clone(), V.clone()
+    hyper = torch.tensor([1e-3, 0.99, 1e-8, 0.01, 0.01], device=dev)
+    g = torch.empty(H, F, device=dev)
+    assert L.idl_wgrad_supported(m, H, F) == 1 and L.idl_wgrad_supported(m + 2, H, F) == 0 and L.idl_wgrad_supported(m, H + 64, F) == 0
+    with pytest.raises(ValueError):
+        _lib.check(L.idl_wgrad_rmsprop(_p(dy), _p(x), m + 2, H, F, _p(g), None, None, None, _stream()))
+    _lib.check(L.idl_wgrad_rmsprop(_p(dy), _p(x), m, H, F, _p(g), _p(W) if fused else None, _p(V) if fused else None,
+                                   _p(hyper) if fused else None, _stream()))
+    torch.cuda.synchronize()
+    g64 = dy.double().t() @ x.double()
+    assert (g.double() - g64).abs().max().item() <= 1e-6 * (dy.abs().double().t() @ x.abs().double()).max().item()
+    if fused:
+        gi = g + 0.01 * W0
+        vr = V0 * 0.99 + 0.01 * gi * gi
+        wr = W0 - 1e-3 * (gi / (vr.sqrt() + 1e-8))
+        assert torch.allclose(W, wr, rtol=1e-5, atol=1e-7) and torch.allclose(V, vr, rtol=1e-5, atol=1e-9)
+    else:
+        assert torch.equal(W, W0) and torch.equal(V, V0)

@@ -52,6 +52,7 @@ SIGNATURES = {
     "idl_nce_fused_parts": (_int, []),
     "idl_nce_fused": (_int, [_vp, _int, _c.c_float, _vp, _vp, _vp, _vp, _vp]),
     "idl_nce_fused_iic": (_int, [_vp, _int, _c.c_float, _vp, _vp, _vp, _vp, _vp, _int, _c.c_float, _c.c_float, _c.c_float, _vp, _vp, _vp]),
+    "idl_nce_fused_iic_z": (_int, [_vp, _int, _c.c_float, _vp, _vp, _vp, _vp, _vp, _vp, _int, _c.c_float, _c.c_float, _c.c_float, _vp, _vp, _vp]),
     "idl_col_sum": (_int, [_vp, _int, _int, _vp, _vp]),
     "idl_relu_dropout_bwd_colsum": (_int, [_vp, _vp, _int, _int, _int, _vp, _vp]),
     "idl_col_sum_parts": (_int, []),

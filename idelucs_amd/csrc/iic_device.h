@@ -75,3 +75,57 @@ __device__ __forceinline__ void iic_core_body(float *P0, int C, float lamb, floa
     for (int i = t; i < n; i += NT) P0[i] = w_iic * (P0[i] - gp) / s;
 }
 
+// ---------------------------------------------------------------- the same core for C <= 48, resident in LDS
+// One 256-thread workgroup.  The joint (<= 9 KB) is read from memory once and dP0 written once; everything between -- the
+// symmetrised normalised joint, its marginals, the loss and the gradient -- lives in LDS, and the three float64 block
+// reductions go through the VALU-only wave all-reduce.  Same arithmetic, element for element, as iic_core_body (the order of
+// the float64 additions inside a block sum differs, below float32 resolution of the results).
+constexpr int IIC_SMALL_C = 48;
+
+__device__ __forceinline__ void iic_core_small(float *P0, int C, float lamb, float eps, float w_iic, float *out)
+{
+    constexpr int NT = 256, NW = 4;
+    __shared__ float Pl[IIC_SMALL_C * IIC_SMALL_C], Ps[IIC_SMALL_C * IIC_SMALL_C];
+    __shared__ float rs[IIC_SMALL_C], ar[IIC_SMALL_C];
+    __shared__ double red[2][NW];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6, n = C * C;
+    double acc = 0.0;
+    for (int i = t; i < n; i += NT) { const float p = P0[i]; Pl[i] = p; acc += (double)p; }
+    acc = idl_dev::wave_sum_d(acc);
+    if (lane == 0) red[0][wv] = acc;
+    __syncthreads();
+    const float s = (float)((red[0][0] + red[0][1]) + (red[0][2] + red[0][3]));
+    for (int i = t; i < n; i += NT) {
+        const int r = i / C, c = i - r * C;
+        Ps[i] = ((Pl[i] + Pl[c * C + r]) * 0.5f) / s;
+    }
+    __syncthreads();
+    for (int r = wv; r < C; r += NW) {          // one wave per row
+        const float p = lane < C ? Ps[r * C + lane] : 0.f;
+        const float a = idl_dev::wave_sum_f(p), b = idl_dev::wave_sum_f(lane < C ? fmaxf(p, eps) : 0.f);
+        if (lane == 0) { rs[r] = a; ar[r] = b; }
+    }
+    __syncthreads();
+    double lacc = 0.0, gacc = 0.0;
+    for (int i = t; i < n; i += NT) {
+        const int r = i / C, c = i - r * C;
+        const float pu = Ps[i], p = fmaxf(pu, eps);
+        const float piu = rs[r], pi = fmaxf(piu, eps), pju = rs[c], pj = fmaxf(pju, eps);
+        const float lg = __logf(p) - lamb * __logf(pj) - lamb * __logf(pi);
+        lacc += (double)(-p * lg);
+        float g = 0.f;
+        if (!(pu < eps)) g += -lg - 1.f;
+        if (!(piu < eps)) g += lamb * ar[r] / pi;
+        if (!(pju < eps)) g += lamb * ar[c] / pj;
+        Pl[i] = g;
+        gacc += (double)g * (double)pu;
+    }
+    lacc = idl_dev::wave_sum_d(lacc); gacc = idl_dev::wave_sum_d(gacc);
+    if (lane == 0) { red[0][wv] = lacc; red[1][wv] = gacc; }       // (red[0] was last read before the two barriers above)
+    __syncthreads();
+    const float iic = (float)((red[0][0] + red[0][1]) + (red[0][2] + red[0][3]));
+    const float gp = (float)((red[1][0] + red[1][1]) + (red[1][2] + red[1][3]));
+    if (t == 0) out[3] = iic;
+    for (int i = t; i < n; i += NT) P0[i] = w_iic * (Pl[i] - gp) / s;
+}
+

@@ -49,13 +49,54 @@ __device__ __forceinline__ void load_rows(const float *f, int r0, int l, int q, 
 
 // The IIC core is a single-workgroup computation that is independent of the InfoNCE branch: when asked (P0 != NULL) it
 // rides along as ONE extra workgroup (blockIdx.x == m/16, blockIdx.y == 0) of pass 1 instead of a launch of its own.
-struct IicJob { float *P0; int C; float lamb, eps, w_iic; float *scratch; float *out; };
+struct IicJob { float *P0; int C; float lamb, eps, w_iic; float *scratch; float *out; const float *z; };
+
+// The IIC joint P0 = z1^T z2 ([C, B] x [B, C], z1 = rows [0, B) of z, z2 = rows [B, 2B); reference LossFunctions.py:57-58 as
+// one contraction) rides along too: a [C, C] product is far too small to be worth a GEMM launch of its own.  The spare
+// workgroups of pass 1 (column blockIdx.x == m/16) each take 16 x 16 output tiles (v_mfma_f32_16x16x4_f32), the four waves
+// splitting the batch, partial tiles added through LDS; the core then runs as the spare workgroup of PASS 2, when P0 is complete.
+// A[i = c1][k = b] = z[b][i0 + l], B[k = b][j = c2] = z[B + b][j0 + l]; classes >= C enter as zeros and are not stored.
+__device__ __forceinline__ void iic_joint_tiles(const float *z, int m, int C, float *P0, int first, int stride)
+{
+    __shared__ float red[4][256];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l = lane & 15, q = lane >> 4;
+    const int B = m / 2, ct = (C + 15) / 16;
+    const int per = ((B + 15) / 16) * 4;                     // rows per wave, a multiple of 4
+    const int kb = wv * per, ke = (kb + per < B) ? kb + per : B;
+    for (int tile = first; tile < ct * ct; tile += stride) {
+        const int i0 = (tile / ct) * 16, j0 = (tile % ct) * 16;
+        const bool ia = i0 + l < C, jb = j0 + l < C;
+        const float *pa = z + (ia ? i0 + l : 0), *pb = z + (int64_t)B * C + (jb ? j0 + l : 0);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int k0 = kb; k0 < ke; k0 += 128) {              // 64 independent loads in flight per lane, then 32 MFMAs
+            float av[32], bv[32];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) {
+                const int k = k0 + 4 * u + q;
+                const bool ok = k < ke;
+                const int kc = ok ? k : ke - 1;
+                const float ta = pa[kc * C], tb = pb[kc * C];
+                av[u] = (ok && ia) ? ta : 0.f;
+                bv[u] = (ok && jb) ? tb : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 32; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wv][(4 * q + r) * 16 + l] = acc[r];          // C/D: row = 4 q + reg, col = l
+        __syncthreads();
+        const int c1 = i0 + (tid >> 4), c2 = j0 + (tid & 15);
+        if (c1 < C && c2 < C) P0[c1 * C + c2] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+    }
+}
 
 // pass 1: partial row sums [NCE_SPLIT][m] and the positive logits pos[m]
 __global__ __launch_bounds__(256) void nce_pass1_kernel(const float *f, int m, float inv_t, float *rowsum_part, float *pos, IicJob iic)
 {
     if ((int)blockIdx.x == m / 16) {
-        if (blockIdx.y == 0 && iic.P0 != nullptr) iic_core_body<256>(iic.P0, iic.C, iic.lamb, iic.eps, iic.w_iic, iic.scratch, iic.out);
+        if (iic.z != nullptr) iic_joint_tiles(iic.z, m, iic.C, iic.P0, (int)blockIdx.y, NCE_SPLIT);     // core: pass 2
+        else if (blockIdx.y == 0 && iic.P0 != nullptr) iic_core_small(iic.P0, iic.C, iic.lamb, iic.eps, iic.w_iic, iic.out);
         return;
     }
     __shared__ float sh[4][16];
@@ -85,8 +126,12 @@ __global__ __launch_bounds__(256) void nce_pass1_kernel(const float *f, int m, f
 
 // pass 2: lse / loss rows, and the partial products G_part[NCE_SPLIT][m][64]
 __global__ __launch_bounds__(256) void nce_pass2_kernel(const float *f, int m, float inv_t, const float *rowsum_part, const float *pos,
-                                                        float *lse, float *loss_rows, float *G_part)
+                                                        float *lse, float *loss_rows, float *G_part, IicJob iic)
 {
+    if ((int)blockIdx.x == m / 16) {         // spare column (only launched when the joint was formed in pass 1): the IIC core
+        if (blockIdx.y == 0) iic_core_small(iic.P0, iic.C, iic.lamb, iic.eps, iic.w_iic, iic.out);
+        return;
+    }
     __shared__ float red[4][16][64];     // per-wave G tiles [row][c]
     __shared__ float lse_sh[NCE_MAX_M];  // lse of every row (each workgroup needs all of them for E^T)
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, l = lane & 15, q = lane >> 4;
@@ -161,8 +206,8 @@ static int nce_launch(const float *f, int m, float temperature, float *lse, floa
     const dim3 grid((unsigned)(m / 16), NCE_SPLIT);
     const dim3 grid1((unsigned)(m / 16 + (iic.P0 != nullptr ? 1 : 0)), NCE_SPLIT);
     hipLaunchKernelGGL(nce_pass1_kernel, grid1, dim3(256), 0, (hipStream_t)stream, f, m, inv_t, rowsum_part, pos, iic);
-    hipLaunchKernelGGL(nce_pass2_kernel, grid, dim3(256), 0, (hipStream_t)stream, f, m, inv_t, (const float *)rowsum_part,
-                       (const float *)pos, lse, loss_rows, G_part);
+    hipLaunchKernelGGL(nce_pass2_kernel, iic.z != nullptr ? grid1 : grid, dim3(256), 0, (hipStream_t)stream, f, m, inv_t,
+                       (const float *)rowsum_part, (const float *)pos, lse, loss_rows, G_part, iic);
     IDL_HIP_TRY(hipGetLastError());
     return IDL_OK;
 }
@@ -177,7 +222,14 @@ int idl_nce_fused_iic(const float *f, int m, float temperature, float *lse, floa
                       float *P0, int C, float lamb, float eps, float w_iic, float *iic_scratch, float *out, void *stream)
 {
     IDL_REQUIRE(P0 && iic_scratch && out && C >= 1 && C <= 48, "nce_fused_iic: n_clusters must be in 1..48 (larger: idl_iic_core)");
-    return nce_launch(f, m, temperature, lse, loss_rows, G_part, workspace, IicJob{P0, C, lamb, eps, w_iic, iic_scratch, out}, stream);
+    return nce_launch(f, m, temperature, lse, loss_rows, G_part, workspace, IicJob{P0, C, lamb, eps, w_iic, iic_scratch, out, nullptr}, stream);
+}
+
+int idl_nce_fused_iic_z(const float *f, int m, float temperature, float *lse, float *loss_rows, float *G_part, void *workspace,
+                        const float *z, float *P0, int C, float lamb, float eps, float w_iic, float *iic_scratch, float *out, void *stream)
+{
+    IDL_REQUIRE(z && P0 && iic_scratch && out && C >= 1 && C <= 48, "nce_fused_iic_z: n_clusters must be in 1..48 (larger: a GEMM + idl_iic_core)");
+    return nce_launch(f, m, temperature, lse, loss_rows, G_part, workspace, IicJob{P0, C, lamb, eps, w_iic, iic_scratch, out, z}, stream);
 }
 
 }  // extern "C"

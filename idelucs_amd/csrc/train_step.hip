@@ -322,7 +322,8 @@ template <int NT>
 __global__ __launch_bounds__(NT) void iic_core_kernel(float *P0, int C, float lamb, float eps, float w_iic, float *scratch,
                                                       float *out)
 {
-    iic_core_body<NT>(P0, C, lamb, eps, w_iic, scratch, out);
+    if (NT == 256) iic_core_small(P0, C, lamb, eps, w_iic, out);     // C <= 48 (launcher)
+    else iic_core_body<NT>(P0, C, lamb, eps, w_iic, scratch, out);
 }
 
 // ---------------------------------------------------------------- head backward: one wave per row

@@ -49,6 +49,35 @@ __device__ __forceinline__ float row_sum16(float v)      // sum over the 16 lane
     return v;
 }
 __device__ __forceinline__ float wave_sum_f(float v) { return add_xor32(add_xor16(row_sum16(v))); }
+
+// the same all-reduce for float64: the two 32-bit halves travel separately through the same DPP / permlane-swap steps
+template <int CTRL>
+__device__ __forceinline__ double dpp_d(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double add_xor16_d(double v)
+{
+    const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(v), (unsigned)__double2loint(v), false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(v), (unsigned)__double2hiint(v), false, false);
+    return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+}
+__device__ __forceinline__ double add_xor32_d(double v)
+{
+    const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(v), (unsigned)__double2loint(v), false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(v), (unsigned)__double2hiint(v), false, false);
+    return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+}
+__device__ __forceinline__ double wave_sum_d(double v)
+{
+    v += dpp_d<DPP_XOR1>(v);
+    v += dpp_d<DPP_XOR2>(v);
+    v += dpp_d<DPP_HALF_MIRROR>(v);
+    v += dpp_d<DPP_MIRROR>(v);
+    return add_xor32_d(add_xor16_d(v));
+}
 __device__ __forceinline__ float wave_max_f(float v)
 {
     v = fmaxf(v, dpp_f<DPP_XOR1>(v));

@@ -95,6 +95,7 @@ class FusedLinearTrainer:
         # dW2 = dlat^T r1 as 16 x 16 MFMA tiles inside the optimizer launch (idl_rmsprop_step_gather_wgrad) instead of a GEMM launch
         self._dw2_inlaunch = self.H1 % 16 == 0 and os.environ.get("IDELUCS_DW2_INLAUNCH", "1") != "0"
         self._overlap = os.environ.get("IDELUCS_OVERLAP", "0") != "0"   # measured: no gain inside a HIP graph on ROCm 7.2
+        self._joint_inlaunch = os.environ.get("IDELUCS_JOINT_INLAUNCH", "1") != "0"   # IIC joint inside the InfoNCE pass-1 launch
         # opt-in: dW1 on this package's own MFMA kernel with RMSprop in its epilogue (csrc/wgrad.hip; measured a wash against
         # hipBLASLt + the optimizer launch, so off by default)
         self._wgrad_fused = os.environ.get("IDELUCS_WGRAD_FUSED", "0") != "0"
@@ -141,7 +142,11 @@ class FusedLinearTrainer:
             chk(_L.idl_head_fwd(_p(bf.lat), _p(self.W3), _p(self.b3), m, C, tr, self.seed, _p(self.ctl),
                                 _p(bf.f), _p(bf.inv), _p(bf.r2), _p(bf.z), _stream()))
         # ---- the two losses are independent: with the fused InfoNCE kernels the IIC core rides along as one extra workgroup
-        if bf.nce_fused and C <= 48 and not self._overlap:
+        if bf.nce_fused and C <= 48 and not self._overlap and self._joint_inlaunch:
+            # the IIC workgroup of InfoNCE pass 1 forms the joint z1^T z2 itself (MFMA tiles) before the core
+            chk(_L.idl_nce_fused_iic_z(_p(bf.f), m, TEMPERATURE, _p(bf.lse), _p(bf.loss_rows), _p(bf.G), _p(bf.nce_ws), _p(bf.z),
+                                       _p(bf.P0), C, self.lamb, EPS, self.weight, _p(bf.iic_scratch), _p(self.out), _stream()))
+        elif bf.nce_fused and C <= 48 and not self._overlap:
             torch.mm(bf.z[:m // 2].t(), bf.z[m // 2:], out=bf.P0)            # IIC joint, one [C,B]x[B,C] GEMM
             chk(_L.idl_nce_fused_iic(_p(bf.f), m, TEMPERATURE, _p(bf.lse), _p(bf.loss_rows), _p(bf.G), _p(bf.nce_ws),
                                      _p(bf.P0), C, self.lamb, EPS, self.weight, _p(bf.iic_scratch), _p(self.out), _stream()))

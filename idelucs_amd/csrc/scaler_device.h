@@ -31,13 +31,14 @@ struct GatherArgs {
     int64_t batch, n_pairs;     // rows whose pair index falls at or beyond n_pairs are skipped (n_pairs < 0: no limit)
     const double *mean, *scale, *inv_scale;
     float *y;
+    int64_t base_add;           // added to *base (a launch that assembles the batch AFTER the one the offset points at)
 };
 
 // one workgroup copies + standardises one output row; rows [0, batch) are the "true" halves, [batch, 2*batch) the "modified" ones
 __device__ __forceinline__ void gather_row(const GatherArgs &g, int64_t row, int tid, int nthreads)
 {
     const int64_t b = row < g.batch ? row : row - g.batch;
-    const int64_t at = (g.base ? *g.base : 0) + b;
+    const int64_t at = (g.base ? *g.base : 0) + g.base_add + b;
     if (g.n_pairs >= 0 && at >= g.n_pairs) return;
     const int64_t pair = g.pair_idx[at];
     const int64_t m = pair / g.n, s = pair - m * g.n;
@@ -92,18 +93,25 @@ __host__ __device__ inline int64_t gather_blocks(int64_t f, int64_t batch)
     return ((2 * batch + GATHER_ROWS - 1) / GATHER_ROWS) * ((f / 4 + 255) / 256);
 }
 
-__device__ __forceinline__ void gather_block(const GatherArgs &g, int64_t blk, int tid)
+// R output rows x 1024 columns per 256-thread tile (R independent 16-byte row reads in flight per thread)
+template <int R>
+__host__ __device__ inline int64_t gather_tiles(int64_t f, int64_t batch)
 {
-    if (g.f & 3) { gather_row(g, blk, tid, 256); return; }
+    return ((2 * batch + R - 1) / R) * ((f / 4 + 255) / 256);
+}
+
+template <int R>
+__device__ __forceinline__ void gather_tile(const GatherArgs &g, int64_t blk, int tid)
+{
     const int64_t n4 = g.f / 4, slices = (n4 + 255) / 256;
     const int64_t rg = blk / slices, i = (blk - rg * slices) * 256 + tid;
     if (i >= n4) return;
-    const int64_t base = g.base ? *g.base : 0;
-    const float4 *src4[GATHER_ROWS];
-    float4 vv[GATHER_ROWS];
+    const int64_t base = (g.base ? *g.base : 0) + g.base_add;
+    const float4 *src4[R];
+    float4 vv[R];
 #pragma unroll
-    for (int u = 0; u < GATHER_ROWS; ++u) {
-        const int64_t row = rg * GATHER_ROWS + u;
+    for (int u = 0; u < R; ++u) {
+        const int64_t row = rg * R + u;
         const int64_t b = row < g.batch ? row : row - g.batch;
         const int64_t at = base + b;
         src4[u] = nullptr;
@@ -114,14 +122,14 @@ __device__ __forceinline__ void gather_block(const GatherArgs &g, int64_t blk, i
         }
     }
 #pragma unroll
-    for (int u = 0; u < GATHER_ROWS; ++u)
+    for (int u = 0; u < R; ++u)
         if (src4[u] != nullptr) vv[u] = src4[u][i];
     const int64_t c = i * 4;
     double mu[4], sc[4], rc[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) { mu[e] = g.mean[c + e]; sc[e] = g.scale[c + e]; rc[e] = g.inv_scale ? g.inv_scale[c + e] : 0.0; }
 #pragma unroll
-    for (int u = 0; u < GATHER_ROWS; ++u) {
+    for (int u = 0; u < R; ++u) {
         if (src4[u] == nullptr) continue;
         const float4 v = vv[u];
         float4 o;
@@ -132,8 +140,14 @@ __device__ __forceinline__ void gather_block(const GatherArgs &g, int64_t blk, i
             o.x = std_f32(v.x, mu[0], sc[0]); o.y = std_f32(v.y, mu[1], sc[1]);
             o.z = std_f32(v.z, mu[2], sc[2]); o.w = std_f32(v.w, mu[3], sc[3]);
         }
-        ((float4 *)(g.y + (rg * GATHER_ROWS + u) * g.f))[i] = o;
+        ((float4 *)(g.y + (rg * R + u) * g.f))[i] = o;
     }
+}
+
+__device__ __forceinline__ void gather_block(const GatherArgs &g, int64_t blk, int tid)
+{
+    if (g.f & 3) { gather_row(g, blk, tid, 256); return; }
+    gather_tile<GATHER_ROWS>(g, blk, tid);
 }
 
 }  // namespace idl_dev

@@ -138,13 +138,20 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float *lat, const f
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 constexpr int H1 = 512;
 constexpr int MID_WAVES = 16;
+constexpr int MID_GATHER_ROWS = 4;   // rows per 256-thread gather tile when the batch assembly rides in mid_fwd / mid_bwd
 
 __global__ __launch_bounds__(64 * MID_WAVES) void mid_fwd_kernel(float *__restrict__ a1, const float *__restrict__ W2,
                                                                   const float *__restrict__ b2, const float *__restrict__ W3,
                                                                   const float *__restrict__ b3, int m, int C, int train, uint64_t seed,
                                                                   const int64_t *__restrict__ ctl, float *__restrict__ f,
-                                                                  float *__restrict__ inv, float *__restrict__ r2, float *__restrict__ z)
+                                                                  float *__restrict__ inv, float *__restrict__ r2, float *__restrict__ z,
+                                                                  int n_rows_wg, int tile0, int tile1, idl_dev::GatherArgs gth)
 {
+    if ((int)blockIdx.x >= n_rows_wg) {          // spare workgroups: tiles [tile0, tile1) of the next batch (see mid_bwd_kernel)
+        const int blk = tile0 + ((int)blockIdx.x - n_rows_wg) * 4 + (int)(threadIdx.x >> 8);
+        if (blk < tile1) idl_dev::gather_tile<MID_GATHER_ROWS>(gth, (int64_t)blk, (int)(threadIdx.x & 255));
+        return;
+    }
     // part[wave][row][col'], col' = (col + 16 (row >> 2)) & 63: the four row-quads of one MFMA store hit disjoint banks.
     // Once the K-slices are added up the same memory holds the r2 tile (A operand of the logits) and the logits tile.
     __shared__ float part[MID_WAVES][16][H2];
@@ -473,8 +480,16 @@ struct MidBwdArgs {
     int g_parts, m, C, train; float nce_coef;
 };
 
-__global__ __launch_bounds__(64 * MID_WAVES) void mid_bwd_kernel(MidBwdArgs a)
+// (tile1 > tile0: the workgroups behind the COL_PARTS computing ones assemble tiles [tile0, tile1) of the NEXT batch into a
+// second x buffer, four 256-thread gather tiles of MID_GATHER_ROWS rows each -- this launch leaves three quarters of the CUs idle and is latency-bound, the gather is
+// pure streaming, and nothing in this step reads or writes what it touches.)
+__global__ __launch_bounds__(64 * MID_WAVES) void mid_bwd_kernel(MidBwdArgs a, int tile0, int tile1, idl_dev::GatherArgs gth)
 {
+    if ((int)blockIdx.x >= COL_PARTS) {
+        const int blk = tile0 + ((int)blockIdx.x - COL_PARTS) * 4 + (int)(threadIdx.x >> 8);
+        if (blk < tile1) idl_dev::gather_tile<MID_GATHER_ROWS>(gth, (int64_t)blk, (int)(threadIdx.x & 255));
+        return;
+    }
     __shared__ float DL[16][H2 + 4];      // dlat rows of the tile; +4: the 16 rows of an A-fragment read hit disjoint banks
     __shared__ float R2s[16][H2];
     __shared__ float DLG[16][64 * MAX_CPL];
@@ -781,7 +796,28 @@ int idl_mid_fwd(float *a1, const float *W2, const float *b2, const float *W3, co
     IDL_REQUIRE(m >= 16 && (m % 16) == 0 && C >= 1 && C <= 64 * MAX_CPL, "mid_fwd: m must be a multiple of 16, n_clusters in 1..256");
     IDL_REQUIRE((((uintptr_t)a1 | (uintptr_t)W2 | (uintptr_t)W3) & 15u) == 0, "a1 / W2 / W3 must be 16-byte aligned");
     hipLaunchKernelGGL(mid_fwd_kernel, dim3((unsigned)(m / 16)), dim3(64 * MID_WAVES), 0, (hipStream_t)stream, a1, W2, b2, W3, b3, m, C, train, seed,
-                       ctl, f, inv, r2, z);
+                       ctl, f, inv, r2, z, m / 16, 0, 0, idl_dev::GatherArgs{});
+    IDL_HIP_TRY(hipGetLastError());
+    return IDL_OK;
+}
+
+int idl_mid_fwd_gather(float *a1, const float *W2, const float *b2, const float *W3, const float *b3, int m, int C, int train,
+                       uint64_t seed, const int64_t *ctl, float *f, float *inv, float *r2, float *z,
+                       const float *feats, int64_t n, int64_t fdim, int64_t view_stride, const int64_t *pair_idx, const int64_t *base,
+                       int64_t base_add, int64_t n_pairs, int64_t batch, const double *mean, const double *scale,
+                       const double *inv_scale, float *y, int part, int parts, void *stream)
+{
+    IDL_REQUIRE(a1 && W2 && b2 && W3 && b3 && ctl && f && inv && r2 && z, "NULL buffer");
+    IDL_REQUIRE(m >= 16 && (m % 16) == 0 && C >= 1 && C <= 64 * MAX_CPL, "mid_fwd: m must be a multiple of 16, n_clusters in 1..256");
+    IDL_REQUIRE((((uintptr_t)a1 | (uintptr_t)W2 | (uintptr_t)W3) & 15u) == 0, "a1 / W2 / W3 must be 16-byte aligned");
+    IDL_REQUIRE(parts >= 1 && part >= 0 && part < parts, "mid_fwd_gather: part outside [0, parts)");
+    IDL_REQUIRE(feats && pair_idx && mean && scale && y && n >= 1 && fdim >= 4 && (fdim & 3) == 0 && batch >= 1 && n_pairs >= 0,
+                "mid_fwd_gather: bad gather arguments (4 | f)");
+    idl_dev::GatherArgs g{feats, n, fdim, view_stride, pair_idx, base, batch, n_pairs, mean, scale, inv_scale, y, base_add};
+    const int64_t ng = idl_dev::gather_tiles<MID_GATHER_ROWS>(fdim, batch);
+    const int64_t t0 = ng * part / parts, t1 = ng * (part + 1) / parts;
+    hipLaunchKernelGGL(mid_fwd_kernel, dim3((unsigned)(m / 16 + (t1 - t0 + 3) / 4)), dim3(64 * MID_WAVES), 0, (hipStream_t)stream, a1, W2, b2, W3, b3,
+                       m, C, train, seed, ctl, f, inv, r2, z, m / 16, (int)t0, (int)t1, g);
     IDL_HIP_TRY(hipGetLastError());
     return IDL_OK;
 }
@@ -834,7 +870,35 @@ int idl_mid_bwd(const float *z, const float *r2, const float *f, const float *in
     a.dlogits = dlogits; a.dlat = dlat; a.dr1 = dr1; a.partial1 = partial1; a.partial2 = partial2; a.partial3 = partial3;
     a.dW3_part = dW3_partial; a.ctl = ctl; a.batch_advance = batch_advance;
     a.g_parts = g_parts; a.m = m; a.C = C; a.train = train; a.nce_coef = nce_coef;
-    hipLaunchKernelGGL(mid_bwd_kernel, dim3(COL_PARTS), dim3(64 * MID_WAVES), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(mid_bwd_kernel, dim3(COL_PARTS), dim3(64 * MID_WAVES), 0, (hipStream_t)stream, a, 0, 0, idl_dev::GatherArgs{});
+    IDL_HIP_TRY(hipGetLastError());
+    return IDL_OK;
+}
+
+int idl_mid_bwd_gather(const float *z, const float *r2, const float *f, const float *inv, const float *G, int g_parts, const float *dP0,
+                       const float *W3, const float *W2, const float *act1, int m, int C, int train, float nce_coef, float *dlogits,
+                       float *dlat, float *dr1, float *partial1, float *partial2, float *partial3, float *dW3_partial,
+                       const float *feats, int64_t n, int64_t fdim, int64_t view_stride, const int64_t *pair_idx, const int64_t *base,
+                       int64_t base_add, int64_t n_pairs, int64_t batch, const double *mean, const double *scale,
+                       const double *inv_scale, float *y, int part, int parts, void *stream)
+{
+    IDL_REQUIRE(parts >= 1 && part >= 0 && part < parts, "mid_bwd_gather: part outside [0, parts)");
+    IDL_REQUIRE(g_parts >= 1 && g_parts <= 16, "mid_bwd: g_parts outside 1..16");
+    IDL_REQUIRE(z && r2 && f && inv && G && dP0 && W3 && W2 && act1 && dlogits && dlat && dr1 && partial1 && partial2 && partial3, "NULL buffer");
+    IDL_REQUIRE(m >= 2 && (m % 2) == 0 && C >= 1 && C <= 64 * MAX_CPL, "mid_bwd: even m, n_clusters in 1..256");
+    IDL_REQUIRE(dW3_partial == nullptr || C <= 48, "mid_bwd: dW3 partials need n_clusters <= 48");
+    IDL_REQUIRE(feats && pair_idx && mean && scale && y && n >= 1 && fdim >= 4 && (fdim & 3) == 0 && batch >= 1 && n_pairs >= 0,
+                "mid_bwd_gather: bad gather arguments (4 | f)");
+    MidBwdArgs a{};
+    a.z = z; a.r2 = r2; a.f = f; a.inv = inv; a.G = G; a.dP0 = dP0; a.W3 = W3; a.W2 = W2; a.act1 = act1;
+    a.dlogits = dlogits; a.dlat = dlat; a.dr1 = dr1; a.partial1 = partial1; a.partial2 = partial2; a.partial3 = partial3;
+    a.dW3_part = dW3_partial; a.ctl = nullptr; a.batch_advance = 0;
+    a.g_parts = g_parts; a.m = m; a.C = C; a.train = train; a.nce_coef = nce_coef;
+    idl_dev::GatherArgs g{feats, n, fdim, view_stride, pair_idx, base, batch, n_pairs, mean, scale, inv_scale, y, base_add};
+    const int64_t ng = idl_dev::gather_tiles<MID_GATHER_ROWS>(fdim, batch);
+    const int64_t t0 = ng * part / parts, t1 = ng * (part + 1) / parts;
+    hipLaunchKernelGGL(mid_bwd_kernel, dim3((unsigned)(COL_PARTS + (t1 - t0 + 3) / 4)), dim3(64 * MID_WAVES), 0, (hipStream_t)stream, a, (int)t0,
+                       (int)t1, g);
     IDL_HIP_TRY(hipGetLastError());
     return IDL_OK;
 }
@@ -954,15 +1018,15 @@ int idl_rmsprop_step_gather_wgrad(int count, float *const *params, const float *
                                   const float *feats, int64_t n, int64_t f, int64_t view_stride, const int64_t *pair_idx, int64_t n_pairs,
                                   int64_t batch, const double *mean, const double *scale, const double *inv_scale, float *y,
                                   int wg_index, const float *wg_dy, const float *wg_x, int wg_m, int wg_n_out, int wg_n_in, float *wg_grad,
-                                  void *stream)
+                                  int64_t batch_advance, void *stream)
 {
     idl_dev::GatherArgs g{};
     if (feats != nullptr) {
         IDL_REQUIRE(pair_idx && mean && scale && y && n >= 1 && f >= 1 && batch >= 1 && n_pairs >= 0, "rmsprop_step_gather_wgrad: bad gather arguments");
         g = idl_dev::GatherArgs{feats, n, f, view_stride, pair_idx, ctl + 1, batch, n_pairs, mean, scale, inv_scale, y};
     }
-    return rmsprop_launch(count, params, grads, grad_parts, square_avg, sizes, hyper, ctl, 0, loss_rows, loss_m, w_nce, w_iic, out, g, stream,
-                          wg_index, wg_dy, wg_x, wg_m, wg_n_out, wg_n_in, wg_grad);
+    return rmsprop_launch(count, params, grads, grad_parts, square_avg, sizes, hyper, ctl, batch_advance, loss_rows, loss_m, w_nce, w_iic, out, g,
+                          stream, wg_index, wg_dy, wg_x, wg_m, wg_n_out, wg_n_in, wg_grad);
 }
 
 }  // extern "C"

@@ -40,7 +40,8 @@ class _Buffers:
     def __init__(self, m, F, H1, H2, C, dev):
         f32 = dict(dtype=torch.float32, device=dev)
         self.m = m
-        self.x = torch.empty((m, F), **f32)
+        self.xs = [torch.empty((m, F), **f32), torch.empty((m, F), **f32)]   # the batch of this step / the next one being assembled
+        self.x = self.xs[0]
         self.r1 = torch.empty((m, H1), **f32)        # Linear1 output, then ReLU+Dropout in place
         self.lat = torch.empty((m, H2), **f32)
         self.f = torch.empty((m, H2), **f32)
@@ -95,6 +96,11 @@ class FusedLinearTrainer:
         # dW2 = dlat^T r1 as 16 x 16 MFMA tiles inside the optimizer launch (idl_rmsprop_step_gather_wgrad) instead of a GEMM launch
         self._dw2_inlaunch = self.H1 % 16 == 0 and os.environ.get("IDELUCS_DW2_INLAUNCH", "1") != "0"
         self._overlap = os.environ.get("IDELUCS_OVERLAP", "0") != "0"   # measured: no gain inside a HIP graph on ROCm 7.2
+        # the NEXT batch is assembled by spare workgroups of the mid-backward launch into a second x buffer (instead of by the
+        # optimizer launch, where it competed with RMSprop for HBM): needs the fused middle kernels and n_clusters <= 48
+        self._early_gather = (self._pipeline and self._mid_fused and self.C <= 48 and self.F % 4 == 0
+                              and os.environ.get("IDELUCS_EARLY_GATHER", "1") != "0")
+        self._early_split = os.environ.get("IDELUCS_EARLY_GATHER", "1") != "2"       # 2: all of it in the mid-backward launch
         self._joint_inlaunch = os.environ.get("IDELUCS_JOINT_INLAUNCH", "1") != "0"   # IIC joint inside the InfoNCE pass-1 launch
         # opt-in: dW1 on this package's own MFMA kernel with RMSprop in its epilogue (csrc/wgrad.hip; measured a wash against
         # hipBLASLt + the optimizer launch, so off by default)
@@ -122,18 +128,26 @@ class FusedLinearTrainer:
 
     # ------------------------------------------------------------------ one step on a filled bf.x
     @torch.no_grad()
-    def step_on_batch(self, bf, train=True, batch_advance=0, next_from=None):
+    def step_on_batch(self, bf, train=True, batch_advance=0, next_from=None, xi=0):
         """Forward, backward and RMSprop update for the [m, F] batch in bf.x (rows [0,m/2) "true",
         [m/2,m) "modified").  Only enqueues work on the current stream.  next_from = a FeatureStore: the batch
         offset is advanced in the middle of the step and the optimizer launch also assembles the NEXT batch into
         bf.x (both are memory-bound and independent: one launch instead of two)."""
         m, C, tr = bf.m, self.C, 1 if train else 0
+        x = bf.xs[xi]
+        early = next_from is not None and self._early_gather and m % 16 == 0   # next batch -> bf.xs[1 - xi] by the mid launches
         chk = _lib.check
         main = torch.cuda.current_stream()
         side = self._side if self._overlap else main
         # ---- forward
-        torch.addmm(self.b1, bf.x, self.W1.t(), out=bf.r1)
-        if self._mid_fused and m % 16 == 0:     # ReLU/Dropout + Linear(512,64) + head in one MFMA kernel
+        torch.addmm(self.b1, x, self.W1.t(), out=bf.r1)
+        if early and self._early_split:         # ... and the first half of the next batch's tiles in its spare workgroups
+            st = next_from
+            chk(_L.idl_mid_fwd_gather(_p(bf.r1), _p(self.W2), _p(self.b2), _p(self.W3), _p(self.b3), m, C, tr, self.seed, _p(self.ctl),
+                                      _p(bf.f), _p(bf.inv), _p(bf.r2), _p(bf.z),
+                                      _p(st.feats), st.n, st.f, st.n * st.f, _p(self._perm), _p(self.ctl[1:]), m // 2, st.n_pairs, m // 2,
+                                      _p(st.mean), _p(st.scale), _p(st.inv_scale), _p(bf.xs[1 - xi]), 0, 2, _stream()))
+        elif self._mid_fused and m % 16 == 0:   # ReLU/Dropout + Linear(512,64) + head in one MFMA kernel
             chk(_L.idl_mid_fwd(_p(bf.r1), _p(self.W2), _p(self.b2), _p(self.W3), _p(self.b3), m, C, tr, self.seed, _p(self.ctl),
                                _p(bf.f), _p(bf.inv), _p(bf.r2), _p(bf.z), _stream()))
         else:
@@ -164,9 +178,21 @@ class FusedLinearTrainer:
         main.wait_stream(side)
         nce_coef = (1.0 - self.weight) / (m * TEMPERATURE)
         gW1, gb1, gW2, gb2, gW3, gb3 = self.grads
-        adv_ctl = _p(self.ctl) if next_from is not None else None
-        adv = batch_advance if next_from is not None else 0
-        if self._mid_fused and C <= 48:       # (at n_clusters = 200 the per-row C x C products want all 256 CUs: separate kernels)
+        adv_ctl = _p(self.ctl) if (next_from is not None and not early) else None
+        adv = batch_advance if (next_from is not None and not early) else 0
+        if early:
+            st = next_from
+            chk(_L.idl_mid_bwd_gather(_p(bf.z), _p(bf.r2), _p(bf.f), _p(bf.inv), _p(bf.G), bf.G.shape[0], _p(bf.P0), _p(self.W3), _p(self.W2),
+                                      _p(bf.r1), m, C, tr, nce_coef, _p(bf.dlogits), _p(bf.dlat), _p(bf.dr1), _p(gb1), _p(gb2), _p(gb3),
+                                      _p(gW3) if self._dw3_partial else None,
+                                      _p(st.feats), st.n, st.f, st.n * st.f, _p(self._perm), _p(self.ctl[1:]), m // 2, st.n_pairs, m // 2,
+                                      _p(st.mean), _p(st.scale), _p(st.inv_scale), _p(bf.xs[1 - xi]), 1 if self._early_split else 0,
+                                      2 if self._early_split else 1, _stream()))
+            if not self._dw3_partial:
+                torch.mm(bf.dlogits.t(), bf.r2, out=gW3)
+            if not self._dw2_inlaunch:
+                torch.mm(bf.dlat.t(), bf.r1, out=gW2)
+        elif self._mid_fused and C <= 48:     # (at n_clusters = 200 the per-row C x C products want all 256 CUs: separate kernels)
             # ---- head backward + dr1 = dlat W2 (MFMA) + ReLU/Dropout backward + every bias gradient (+ dW3) in one launch
             chk(_L.idl_mid_bwd(_p(bf.z), _p(bf.r2), _p(bf.f), _p(bf.inv), _p(bf.G), bf.G.shape[0], _p(bf.P0), _p(self.W3), _p(self.W2),
                                _p(bf.r1), m, C, tr, nce_coef, _p(bf.dlogits), _p(bf.dlat), _p(bf.dr1), _p(gb1), _p(gb2), _p(gb3),
@@ -191,20 +217,28 @@ class FusedLinearTrainer:
                                   _p(gW3) if self._dw3_partial else None, _stream()))
         w1_done = self._wgrad_fused and bool(_L.idl_wgrad_supported(m, self.H1, self.F))
         if w1_done:
-            chk(_L.idl_wgrad_rmsprop(_p(bf.dr1), _p(bf.x), m, self.H1, self.F, None, _p(self.W1), _p(self.square_avg[0]), _p(self.hyper),
+            chk(_L.idl_wgrad_rmsprop(_p(bf.dr1), _p(x), m, self.H1, self.F, None, _p(self.W1), _p(self.square_avg[0]), _p(self.hyper),
                                      _stream()))
         else:
-            torch.mm(bf.dr1.t(), bf.x, out=gW1)
+            torch.mm(bf.dr1.t(), x, out=gW1)
         sz = self._sz_no_w1 if w1_done else self._sz
         main.wait_stream(side)
         # ---- RMSprop (and advance the device-side step counter / batch offset)
-        if next_from is not None and self._dw2_inlaunch:
+        if early and self._dw2_inlaunch:      # no batch assembly here; the offset moves on at the end of the step
+            chk(_L.idl_rmsprop_step_gather_wgrad(len(self.params), self._pp, self._gp, self._parts, self._vp, sz, _p(self.hyper),
+                                                 _p(self.ctl), _p(bf.loss_rows), m, 1.0 - self.weight, self.weight, _p(self.out),
+                                                 None, 0, 0, 0, None, 0, 0, None, None, None, None,
+                                                 2, _p(bf.dlat), _p(bf.r1), m, self.H2, self.H1, _p(gW2), m // 2, _stream()))
+        elif early:
+            chk(_L.idl_rmsprop_step(len(self.params), self._pp, self._gp, self._parts, self._vp, sz, _p(self.hyper),
+                                    _p(self.ctl), m // 2, _p(bf.loss_rows), m, 1.0 - self.weight, self.weight, _p(self.out), _stream()))
+        elif next_from is not None and self._dw2_inlaunch:
             st = next_from
             chk(_L.idl_rmsprop_step_gather_wgrad(len(self.params), self._pp, self._gp, self._parts, self._vp, sz, _p(self.hyper),
                                                  _p(self.ctl), _p(bf.loss_rows), m, 1.0 - self.weight, self.weight, _p(self.out),
                                                  _p(st.feats), st.n, st.f, st.n * st.f, _p(self._perm), st.n_pairs, m // 2,
                                                  _p(st.mean), _p(st.scale), _p(st.inv_scale), _p(bf.x),
-                                                 2, _p(bf.dlat), _p(bf.r1), m, self.H2, self.H1, _p(gW2), _stream()))
+                                                 2, _p(bf.dlat), _p(bf.r1), m, self.H2, self.H1, _p(gW2), 0, _stream()))
         elif next_from is not None:
             st = next_from
             chk(_L.idl_rmsprop_step_gather(len(self.params), self._pp, self._gp, self._parts, self._vp, sz, _p(self.hyper),
@@ -221,11 +255,11 @@ class FusedLinearTrainer:
         _lib.check(_L.idl_gather_pairs_at(_p(store.feats), store.n, store.f, store.n * store.f, _p(self._perm), _p(self.ctl[1:]),
                                           b, _p(store.mean), _p(store.scale), _p(store.inv_scale), _p(bf.x), _stream()))
 
-    def _full_step(self, store, bf, train=True, pipelined=False):
-        """pipelined: bf.x already holds this batch (assembled by the previous step's optimizer launch, or by the
-        prologue gather); this step assembles the next one."""
+    def _full_step(self, store, bf, train=True, pipelined=False, xi=0):
+        """pipelined: bf.xs[xi] already holds this batch (assembled by the previous step, or by the prologue gather);
+        this step assembles the next one (into bf.xs[1 - xi] when the mid-backward launch does it, else into bf.xs[xi])."""
         if pipelined:
-            self.step_on_batch(bf, train=train, batch_advance=bf.m // 2, next_from=store)
+            self.step_on_batch(bf, train=train, batch_advance=bf.m // 2, next_from=store, xi=xi if self._early_gather else 0)
         else:
             self._gather(store, bf)
             self.step_on_batch(bf, train=train, batch_advance=bf.m // 2)
@@ -248,36 +282,40 @@ class FusedLinearTrainer:
             bf = self.buffers(2 * batch_sz)
             if pipe:
                 self._gather(store, bf)         # prologue: batch 0; every later batch is assembled by the previous step
-            key = (2 * batch_sz, store.feats.data_ptr(), store.mean.data_ptr(), store.n, store.f, pipe)
+            key = (2 * batch_sz, store.feats.data_ptr(), store.mean.data_ptr(), store.n, store.f, pipe, self._early_gather)
+            per = 2 if (pipe and self._early_gather) else 1      # steps per graph replay (two x buffers alternate)
             if use_graph and n_full >= 8:
                 g = self._graphs.get(key)
                 if g is None:
-                    g = self._capture(store, bf, pipe)
+                    g = self._capture(store, bf, pipe, per)
                     self._graphs = {key: g}             # one store at a time: drop graphs of older stores
-                    n_done = 3                           # the warm-up + capture already ran real steps
+                    n_done = 2 + per                     # the warm-up + capture already ran real steps (an even number when per == 2)
                 else:
                     n_done = 0
-                for _ in range(n_full - n_done):
+                for _ in range((n_full - n_done) // per):
                     g.replay()
+                for i in range((n_full - n_done) % per):
+                    self._full_step(store, bf, pipelined=pipe, xi=i % 2)
             else:
-                for _ in range(n_full):
-                    self._full_step(store, bf, pipelined=pipe)
+                for i in range(n_full):
+                    self._full_step(store, bf, pipelined=pipe, xi=i % 2)
         if rem:
             self._full_step(store, self.buffers(2 * rem))
         return self.out[1], n_full + (1 if rem else 0)
 
     @torch.no_grad()
-    def _capture(self, store, bf, pipe):
-        """Warm up on a side stream (2 real steps), then capture a third real step into a HIP graph.
+    def _capture(self, store, bf, pipe, per=1):
+        """Warm up on a side stream (2 real steps), then capture the next `per` real steps into a HIP graph.
         Every launch is a genuine optimizer step on the next batch, so nothing is wasted or repeated."""
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
-            for _ in range(2):
-                self._full_step(store, bf, pipelined=pipe)
+            for i in range(2):
+                self._full_step(store, bf, pipelined=pipe, xi=i % 2)
         torch.cuda.current_stream().wait_stream(s)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
-            self._full_step(store, bf, pipelined=pipe)
-        g.replay()          # capture does not execute: run the captured (third) step once
+            for i in range(per):
+                self._full_step(store, bf, pipelined=pipe, xi=i % 2)
+        g.replay()          # capture does not execute: run the captured step(s) once
         return g

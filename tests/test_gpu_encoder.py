@@ -494,7 +494,7 @@ def test_dw2_inside_the_optimizer_launch(dev, m):
     _lib.check(L.idl_rmsprop_step_gather_wgrad(2, arr(W), arr(grads), (ctypes.c_int32 * 2)(1, 1), arr(V), (ctypes.c_int64 * 2)(64 * 512, 512),
                                                _p(hyper), _p(ctl), None, 0, 0.0, 0.0, None,
                                                None, 0, 0, 0, None, 0, 0, None, None, None, None,
-                                               0, _p(dy), _p(x), m, 64, 512, _p(gout), _stream()))
+                                               0, _p(dy), _p(x), m, 64, 512, _p(gout), 5, _stream()))
     torch.cuda.synchronize()
     g64 = (dy.double().t() @ x.double())
     assert (gout.double() - g64).abs().max().item() <= 2e-6 * g64.abs().max().item() + 1e-5
@@ -506,7 +506,7 @@ def test_dw2_inside_the_optimizer_launch(dev, m):
     for w, v, w0, v0, g in zip(W, V, W0, V0, [gout, gb]):
         wr, vr = upd(w0, v0, g)
         assert torch.allclose(w, wr, rtol=1e-5, atol=1e-7) and torch.allclose(v, vr, rtol=1e-5, atol=1e-9)
-    assert ctl.tolist() == [1, 0]
+    assert ctl.tolist() == [1, 5]
 
 
 @pytest.mark.parametrize("m,fused", [(1024, True), (960, True), (128, False)])

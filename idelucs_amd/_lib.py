@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libidelucs_hip.so")
+LIB_PATH = os.environ.get("IDELUCS_LIB_PATH") or os.path.join(_HERE, "csrc", "libidelucs_hip.so")   # (override: A/B of two builds)
 
 IDL_OK, IDL_ERR_ARG, IDL_ERR_HIP, IDL_ERR_IO, IDL_ERR_HEADER, IDL_ERR_BASE, IDL_ERR_NOMEM = 0, -1, -2, -3, -4, -5, -6
 MODE_KMER, MODE_CGR, MODE_CANONICAL = 0, 1, 2

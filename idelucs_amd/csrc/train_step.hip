@@ -641,6 +641,7 @@ struct RmsArgs {
     // wg_tiles extra workgroups, one 16 x 16 tile each, which also apply the update to their tile (a.n[wg_t] is 0 then)
     const float *wg_dy, *wg_x; float *wg_grad;
     int wg_t, wg_m, wg_n_out, wg_n_in, wg_tiles;
+    int first[9];     // optimizer blocks [first[t], first[t + 1]) belong to tensor t: as many as the tensor needs, not one grid row each
 };
 
 // One 16 x 16 tile of dy^T x on the fp32 matrix cores (v_mfma_f32_16x16x4_f32): the four waves split the contraction index m,
@@ -705,8 +706,10 @@ __global__ __launch_bounds__(256) void rmsprop_kernel(RmsArgs a, const float *hy
         return;
     }
     const int bid = b0 - n_gather;
-    const int t = bid / gx;
-    const int bx = bid - t * gx;
+    int t = 0;
+    while (t + 1 < a.count && bid >= a.first[t + 1]) ++t;
+    const int bx = bid - a.first[t];
+    gx = a.first[t + 1] - a.first[t];
     if (t < a.count) {
         float *p = a.p[t]; const float *g = a.g[t]; float *v = a.v[t];
         const int64_t n = a.n[t];
@@ -753,7 +756,7 @@ __global__ __launch_bounds__(256) void rmsprop_kernel(RmsArgs a, const float *hy
         }
     }
     if (bid == 0 && threadIdx.x == 0) { ctl[0] += 1; ctl[1] += batch_advance; }
-    if (a.out != nullptr && bid == gx * a.count - 1 && threadIdx.x < 64) {
+    if (a.out != nullptr && bid == a.first[a.count] - 1 && threadIdx.x < 64) {
         // step loss = w_nce * mean(loss_rows) + w_iic * IIC (left in out[3] by iic_core_kernel); out[1] = running sum
         float acc = 0.f;
         for (int i = threadIdx.x; i < a.loss_m; i += 64) acc += a.loss_rows[i];
@@ -982,12 +985,20 @@ static int rmsprop_launch(int count, float *const *params, const float *const *g
         mx = 0;
         for (int i = 0; i < count; ++i) if (a.n[i] > mx) mx = a.n[i];
     }
-    int64_t gx = (mx + 255) / 256;
-    if (gx > 1024) gx = 1024;
-    if (gx < 1) gx = 1;
+    (void)mx;
+    int nb_total = 0;
+    for (int i = 0; i < count; ++i) {
+        const bool vec = a.parts[i] == 1 && (a.n[i] & 3) == 0 && ((((uintptr_t)a.p[i]) | ((uintptr_t)a.g[i]) | ((uintptr_t)a.v[i])) & 15u) == 0;
+        int64_t nb = vec ? (a.n[i] / 4 + 511) / 512 : (a.n[i] + 255) / 256;     // float4 path: two 16-byte elements per thread
+        if (nb > 1024) nb = 1024;
+        a.first[i] = nb_total;
+        nb_total += (int)nb;
+    }
+    if (nb_total == 0) nb_total = 1;        // (step counter / loss assembly still need a block)
+    for (int i = count; i <= 8; ++i) a.first[i] = nb_total;
     const int64_t extra = g.y != nullptr ? idl_dev::gather_blocks(g.f, g.batch) : 0;
-    hipLaunchKernelGGL(rmsprop_kernel, dim3((unsigned)(gx * count + extra + a.wg_tiles)), dim3(256), 0, (hipStream_t)stream, a, hyper, ctl,
-                       batch_advance, (int)gx, (int)extra, g);
+    hipLaunchKernelGGL(rmsprop_kernel, dim3((unsigned)(nb_total + extra + a.wg_tiles)), dim3(256), 0, (hipStream_t)stream, a, hyper, ctl,
+                       batch_advance, 0, (int)extra, g);
     IDL_HIP_TRY(hipGetLastError());
     return IDL_OK;
 }

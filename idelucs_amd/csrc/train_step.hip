@@ -494,12 +494,18 @@ __global__ __launch_bounds__(64 * MID_WAVES) void mid_bwd_kernel(MidBwdArgs a, i
     __shared__ float R2s[16][H2];
     __shared__ float DLG[16][64 * MAX_CPL];
     __shared__ float shz[MID_WAVES][64 * MAX_CPL];
+    __shared__ float sP[48 * 48], sW3[48 * H2];      // dP0 and W3 for n_clusters <= 48: read once per workgroup, not once per row
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, l = lane & 15, q = lane >> 4, tid = threadIdx.x;
     const int m = a.m, C = a.C, B = m / 2;
+    const bool small = C <= 48;
     const int rows = (m + COL_PARTS - 1) / COL_PARTS;
     const int r0 = blockIdx.x * rows;
     const int r1 = (r0 + rows < m) ? r0 + rows : m;
     if (a.ctl != nullptr && blockIdx.x == 0 && tid == 0) a.ctl[1] += a.batch_advance;
+    if (small) {
+        for (int i = tid; i < C * C; i += 64 * MID_WAVES) sP[i] = a.dP0[i];
+        for (int i = tid; i < C * H2; i += 64 * MID_WAVES) sW3[i] = a.W3[i];
+    }
     // B fragments of this wave's two column tiles: B[k = 16 q + s][c = l] = W2[k][16 ct + l]
     float bw[2][16];
 #pragma unroll
@@ -510,9 +516,56 @@ __global__ __launch_bounds__(64 * MID_WAVES) void mid_bwd_kernel(MidBwdArgs a, i
     float cs1[2] = {0.f, 0.f}, s23 = 0.f, acc3[3] = {0.f, 0.f, 0.f};
     for (int t0 = r0; t0 < r1; t0 += 16) {
         const int nr = (r1 - t0 < 16) ? r1 - t0 : 16;
+        // the layer-1 activations this lane masks with in phase 2: requested now, needed after the head backward
+        float a1v[2][4];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int rl = 4 * q + reg;
+                a1v[j][reg] = rl < nr ? a.act1[(int64_t)(t0 + rl) * H1 + 16 * (2 * wv + j) + l] : 0.f;
+            }
         __syncthreads();
         // ---- 1. head backward of row t0 + wv
-        if (wv < nr) {
+        if (wv < nr && small) {
+            // every global read of the row first, then arithmetic on registers and LDS only
+            const int row = t0 + wv;
+            const int prow = row < B ? row + B : row - B;
+            const bool cl = lane < C;
+            const float zp = cl ? a.z[(int64_t)prow * C + lane] : 0.f;
+            const float zc = cl ? a.z[(int64_t)row * C + lane] : 0.f;
+            const float act = a.r2[(int64_t)row * H2 + lane];
+            const float fr = a.f[(int64_t)row * H2 + lane], fp = a.f[(int64_t)prow * H2 + lane];
+            float gp[16];
+#pragma unroll
+            for (int pp = 0; pp < 16; ++pp) gp[pp] = pp < a.g_parts ? a.G[((int64_t)pp * m + row) * H2 + lane] : 0.f;
+            const float invr = a.inv[row];
+            shz[wv][lane] = zp;
+            __builtin_amdgcn_wave_barrier();
+            float dz = 0.f;
+            if (cl) {
+#pragma unroll 4
+                for (int k = 0; k < C; ++k) dz = fmaf(shz[wv][k], sP[k * C + lane], dz);
+            }
+            const float dot = wave_sum(dz * zc);
+            const float dl = zc * (dz - dot);                     // softmax backward (0 for lanes >= C)
+            if (cl) a.dlogits[(int64_t)row * C + lane] = dl;
+            DLG[wv][lane] = dl;
+            __builtin_amdgcn_wave_barrier();
+            float dr = 0.f;
+#pragma unroll 4
+            for (int c = 0; c < C; ++c) dr = fmaf(DLG[wv][c], sW3[c * H2 + lane], dr);
+            const float dl_cls = act > 0.f ? dr * scale : 0.f;
+            float gsum = gp[0];
+#pragma unroll
+            for (int pp = 1; pp < 16; ++pp) if (pp < a.g_parts) gsum += gp[pp];
+            const float df = a.nce_coef * (gsum - 2.f * fp);
+            const float proj = wave_sum(fr * df);
+            const float d = dl_cls + (df - fr * proj) * invr;
+            a.dlat[(int64_t)row * H2 + lane] = d;
+            DL[wv][lane] = d;
+            R2s[wv][lane] = act;
+        } else if (wv < nr) {
             const int row = t0 + wv;
             const int prow = row < B ? row + B : row - B;
             for (int c = lane; c < C; c += 64) shz[wv][c] = a.z[(int64_t)prow * C + c];
@@ -580,7 +633,7 @@ __global__ __launch_bounds__(64 * MID_WAVES) void mid_bwd_kernel(MidBwdArgs a, i
                 const int rl = 4 * q + reg;                        // C/D: row = 4q + reg, col = l
                 if (rl < nr) {
                     const int64_t idx = (int64_t)(t0 + rl) * H1 + col;
-                    const float v = a.act1[idx] > 0.f ? acc[reg] * scale : 0.f;
+                    const float v = a1v[j][reg] > 0.f ? acc[reg] * scale : 0.f;
                     a.dr1[idx] = v;
                     cs1[j] += v;
                 }

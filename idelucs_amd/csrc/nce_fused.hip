@@ -23,7 +23,7 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int NCE_SPLIT = 4;     // column quarters -> (m/16) * 4 workgroups
+constexpr int NCE_SPLIT = 8;     // column quarters -> (m/16) * 4 workgroups
 constexpr int NCE_MAX_M = 2048;  // rows (2 * batch) whose lse fit the LDS table
 
 

@@ -31,6 +31,7 @@ def bench(name, fn, n=50):
     print(f"{name:52s} {e0.elapsed_time(e1) * 1000 / (5 * n):7.2f} us")
 
 bench("fwd  addmm(b, x, W.t())            [NT] (now)", lambda: torch.addmm(b, x, W.t(), out=o1))
+bench("fwd  mm(x, W.t())  no bias          [NT]", lambda: torch.mm(x, W.t(), out=o1))
 bench("fwd  mm(x, WT)                     [NN]", lambda: torch.mm(x, WT, out=o1))
 bench("fwd  mm(W, x.t()) -> r1^T          [NT']", lambda: torch.mm(W, x.t(), out=o1T))
 bench("fwd  mm(xT.t(), WT)                [TN]", lambda: torch.mm(xT.t(), WT, out=o1))

@@ -3,8 +3,10 @@
 // All three are HBM-streaming kernels over the row-major feature store [rows, f]:
 //   col_stats    : StandardScaler.fit as the reference uses it (idelucs/utils.py:357-359 on the
 //                  float32 "true" view, :404-405 on float64 un-mutated rows): float64 mean and
-//                  population variance per column, two passes (sum; centred sum + centred sum of
-//                  squares) exactly like sklearn's _incremental_mean_and_var, deterministic order.
+//                  population variance per column in ONE pass over the data -- sums of (x - x0) and
+//                  (x - x0)^2 with x0 = the column's first row, so the variance formula has nothing
+//                  to cancel -- within 1e-15 relative of sklearn's two-pass _incremental_mean_and_var
+//                  (exactly 0 -> scale 1 for a constant column), deterministic order.
 //   standardise  : StandardScaler.transform (utils.py:361-366): (x - mean) then / scale, each
 //                  evaluated in float64 and rounded to the array's type.
 //   gather_pairs : AugmentedDataset/DataLoader batch collation (utils.py:370-389, :422-429) on the
@@ -29,64 +31,70 @@ __host__ __device__ inline int64_t stat_row_blocks(int64_t n)
     return r;
 }
 
-template <typename T>
-__global__ __launch_bounds__(STAT_THREADS) void col_sum_kernel(const T *x, int64_t n, int64_t f, int64_t rows_per_block,
-                                                               double *partial)
+// one pass: partial sums of t = x - x0 and t^2 over a block of rows, V columns per thread (V = 4: 16-byte row reads)
+template <typename T, int V>
+__global__ __launch_bounds__(STAT_THREADS) void col_shifted_sums_kernel(const T *x, int64_t n, int64_t f, int64_t rows_per_block,
+                                                                        double *partial1, double *partial2)
 {
-    const int64_t c = (int64_t)blockIdx.x * STAT_THREADS + threadIdx.x;
+    const int64_t c = ((int64_t)blockIdx.x * STAT_THREADS + threadIdx.x) * V;
     if (c >= f) return;
     const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
     int64_t r1 = r0 + rows_per_block;
     if (r1 > n) r1 = n;
-    double acc = 0.0;
-    for (int64_t r = r0; r < r1; ++r) acc += (double)x[r * f + c];
-    partial[(int64_t)blockIdx.y * f + c] = acc;
+    typedef T vec_t __attribute__((ext_vector_type(V)));
+    double sh[V], a1[V], a2[V];
+    {
+        const vec_t v0 = *(const vec_t *)(x + c);
+#pragma unroll
+        for (int e = 0; e < V; ++e) { sh[e] = (double)v0[e]; a1[e] = 0.0; a2[e] = 0.0; }
+    }
+    int64_t r = r0;
+    for (; r + 4 <= r1; r += 4) {                             // four independent row reads in flight
+        vec_t v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *(const vec_t *)(x + (r + u) * f + c);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int e = 0; e < V; ++e) { const double t = (double)v[u][e] - sh[e]; a1[e] += t; a2[e] += t * t; }
+    }
+    for (; r < r1; ++r) {
+        const vec_t v = *(const vec_t *)(x + r * f + c);
+#pragma unroll
+        for (int e = 0; e < V; ++e) { const double t = (double)v[e] - sh[e]; a1[e] += t; a2[e] += t * t; }
+    }
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+        partial1[(int64_t)blockIdx.y * f + c + e] = a1[e];
+        partial2[(int64_t)blockIdx.y * f + c + e] = a2[e];
+    }
 }
 
-__global__ __launch_bounds__(STAT_THREADS) void col_mean_kernel(const double *partial, int64_t blocks, int64_t f, int64_t n,
-                                                                double *mean)
-{
-    const int64_t c = (int64_t)blockIdx.x * STAT_THREADS + threadIdx.x;
-    if (c >= f) return;
-    double acc = 0.0;
-    for (int64_t b = 0; b < blocks; ++b) acc += partial[b * f + c];
-    mean[c] = acc / (double)n;
-}
-
+// combine the row-block partials: 64 columns per workgroup, 16 groups of row blocks added through LDS in a fixed order
 template <typename T>
-__global__ __launch_bounds__(STAT_THREADS) void col_centred_kernel(const T *x, int64_t n, int64_t f, int64_t rows_per_block,
-                                                                   const double *mean, double *partial1, double *partial2)
+__global__ __launch_bounds__(1024) void col_finish_kernel(const T *x, const double *partial1, const double *partial2, int64_t blocks,
+                                                          int64_t f, int64_t n, double *mean, double *scale)
 {
-    const int64_t c = (int64_t)blockIdx.x * STAT_THREADS + threadIdx.x;
-    if (c >= f) return;
-    const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
-    int64_t r1 = r0 + rows_per_block;
-    if (r1 > n) r1 = n;
-    const double m = mean[c];
+    __shared__ double s1[16][64], s2[16][64];
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int64_t c = (int64_t)blockIdx.x * 64 + lane;
     double a1 = 0.0, a2 = 0.0;
-    for (int64_t r = r0; r < r1; ++r) {
-        const double t = (double)x[r * f + c] - m;
-        a1 += t;
-        a2 += t * t;
+    if (c < f)
+        for (int64_t b = grp; b < blocks; b += 16) { a1 += partial1[b * f + c]; a2 += partial2[b * f + c]; }
+    s1[grp][lane] = a1; s2[grp][lane] = a2;
+    __syncthreads();
+    if (grp == 0 && c < f) {
+        double t1 = 0.0, t2 = 0.0;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) { t1 += s1[g][lane]; t2 += s2[g][lane]; }
+        const double dn = (double)n;
+        mean[c] = (double)x[c] + t1 / dn;
+        double var = (t2 - t1 * t1 / dn) / dn;
+        if (var < 0.0) var = 0.0;
+        double s = sqrt(var);
+        if (s < 10.0 * 2.220446049250313e-16) s = 1.0;       // sklearn _handle_zeros_in_scale
+        scale[c] = s;
     }
-    partial1[(int64_t)blockIdx.y * f + c] = a1;
-    partial2[(int64_t)blockIdx.y * f + c] = a2;
-}
-
-__global__ __launch_bounds__(STAT_THREADS) void col_scale_kernel(const double *partial1, const double *partial2, int64_t blocks,
-                                                                 int64_t f, int64_t n, double *scale)
-{
-    const int64_t c = (int64_t)blockIdx.x * STAT_THREADS + threadIdx.x;
-    if (c >= f) return;
-    double corr = 0.0, ss = 0.0;
-    for (int64_t b = 0; b < blocks; ++b) {
-        corr += partial1[b * f + c];
-        ss += partial2[b * f + c];
-    }
-    const double var = (ss - corr * corr / (double)n) / (double)n;
-    double s = sqrt(var);
-    if (s < 10.0 * 2.220446049250313e-16) s = 1.0;  // sklearn _handle_zeros_in_scale
-    scale[c] = s;
 }
 
 using idl_dev::std_f32;
@@ -147,16 +155,19 @@ int idl_col_stats(const void *x, int is_f64, int64_t n, int64_t f, double *mean,
     const int64_t blocks = stat_row_blocks(n);
     const int64_t rpb = (n + blocks - 1) / blocks;
     double *p1 = (double *)workspace, *p2 = p1 + blocks * f;
-    const dim3 grid2((unsigned)((f + STAT_THREADS - 1) / STAT_THREADS), (unsigned)blocks);
-    const dim3 grid1((unsigned)((f + STAT_THREADS - 1) / STAT_THREADS));
-    if (is_f64) hipLaunchKernelGGL(col_sum_kernel<double>, grid2, dim3(STAT_THREADS), 0, st, (const double *)x, n, f, rpb, p1);
-    else hipLaunchKernelGGL(col_sum_kernel<float>, grid2, dim3(STAT_THREADS), 0, st, (const float *)x, n, f, rpb, p1);
-    hipLaunchKernelGGL(col_mean_kernel, grid1, dim3(STAT_THREADS), 0, st, p1, blocks, f, n, mean);
-    if (is_f64)
-        hipLaunchKernelGGL(col_centred_kernel<double>, grid2, dim3(STAT_THREADS), 0, st, (const double *)x, n, f, rpb, mean, p1, p2);
-    else
-        hipLaunchKernelGGL(col_centred_kernel<float>, grid2, dim3(STAT_THREADS), 0, st, (const float *)x, n, f, rpb, mean, p1, p2);
-    hipLaunchKernelGGL(col_scale_kernel, grid1, dim3(STAT_THREADS), 0, st, p1, p2, blocks, f, n, scale);
+    const bool vec4 = (f & 3) == 0 && (((uintptr_t)x) & (is_f64 ? 31u : 15u)) == 0;
+    const int64_t cols_per_block = (int64_t)STAT_THREADS * (vec4 ? 4 : 1);
+    const dim3 grid2((unsigned)((f + cols_per_block - 1) / cols_per_block), (unsigned)blocks);
+    const dim3 grid1((unsigned)((f + 63) / 64));
+    if (is_f64) {
+        if (vec4) hipLaunchKernelGGL((col_shifted_sums_kernel<double, 4>), grid2, dim3(STAT_THREADS), 0, st, (const double *)x, n, f, rpb, p1, p2);
+        else hipLaunchKernelGGL((col_shifted_sums_kernel<double, 1>), grid2, dim3(STAT_THREADS), 0, st, (const double *)x, n, f, rpb, p1, p2);
+        hipLaunchKernelGGL(col_finish_kernel<double>, grid1, dim3(1024), 0, st, (const double *)x, p1, p2, blocks, f, n, mean, scale);
+    } else {
+        if (vec4) hipLaunchKernelGGL((col_shifted_sums_kernel<float, 4>), grid2, dim3(STAT_THREADS), 0, st, (const float *)x, n, f, rpb, p1, p2);
+        else hipLaunchKernelGGL((col_shifted_sums_kernel<float, 1>), grid2, dim3(STAT_THREADS), 0, st, (const float *)x, n, f, rpb, p1, p2);
+        hipLaunchKernelGGL(col_finish_kernel<float>, grid1, dim3(1024), 0, st, (const float *)x, p1, p2, blocks, f, n, mean, scale);
+    }
     IDL_HIP_TRY(hipGetLastError());
     return IDL_OK;
 }

@@ -140,7 +140,8 @@ constexpr int H1 = 512;
 constexpr int MID_WAVES = 16;
 constexpr int MID_GATHER_ROWS = 4;   // rows per 256-thread gather tile when the batch assembly rides in mid_fwd / mid_bwd
 
-__global__ __launch_bounds__(64 * MID_WAVES) void mid_fwd_kernel(float *__restrict__ a1, const float *__restrict__ W2,
+template <bool TIN>       // TIN: a1 is stored transposed, [512, m] (the orientation hipBLASLt runs the layer-1 product fastest in)
+__global__ __launch_bounds__(64 * MID_WAVES) void mid_fwd_kernel(float *__restrict__ a1, const float *__restrict__ b1, const float *__restrict__ W2,
                                                                   const float *__restrict__ b2, const float *__restrict__ W3,
                                                                   const float *__restrict__ b3, int m, int C, int train, uint64_t seed,
                                                                   const int64_t *__restrict__ ctl, float *__restrict__ f,
@@ -162,7 +163,18 @@ __global__ __launch_bounds__(64 * MID_WAVES) void mid_fwd_kernel(float *__restri
     const int k0 = 32 * wv + 8 * q;              // this lane's 8 consecutive k of row r0 + l
     // ---- every global read of the kernel is issued here, before the first dependent instruction
     float4 *src = (float4 *)(a1 + (int64_t)(r0 + l) * H1 + k0);
-    float4 av[2] = {src[0], src[1]};
+    float *srcT = a1 + (int64_t)k0 * m + r0 + l;             // element (row r0 + l, column k0 + i) of the transposed image: srcT[i * m]
+    float4 av[2];
+    if (TIN) {
+        float t8[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t8[i] = srcT[(int64_t)i * m];
+        av[0] = make_float4(t8[0], t8[1], t8[2], t8[3]); av[1] = make_float4(t8[4], t8[5], t8[6], t8[7]);
+    } else {
+        av[0] = src[0]; av[1] = src[1];
+    }
+    float4 bb[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+    if (b1 != nullptr) { bb[0] = *(const float4 *)(b1 + k0); bb[1] = *(const float4 *)(b1 + k0 + 4); }
     float4 bw[4][2];
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) {             // lat[:, 16 ct .. 16 ct + 15]: B[k][c] = W2[16 ct + c][k]
@@ -186,6 +198,7 @@ __global__ __launch_bounds__(64 * MID_WAVES) void mid_fwd_kernel(float *__restri
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         float4 v = av[i];
+        v.x += bb[i].x; v.y += bb[i].y; v.z += bb[i].z; v.w += bb[i].w;      // Linear(F,512) bias when the product came without it
         float s0 = 1.f, s1 = 1.f, s2 = 1.f, s3 = 1.f;
         if (train) {                             // identical stream to relu_dropout_fwd_kernel: counter = float4 index of the flat array
             const int64_t idx4 = ((int64_t)(r0 + l) * H1 + k0) / 4 + i;
@@ -195,7 +208,8 @@ __global__ __launch_bounds__(64 * MID_WAVES) void mid_fwd_kernel(float *__restri
         }
         v.x = v.x > 0.f ? v.x * s0 : 0.f; v.y = v.y > 0.f ? v.y * s1 : 0.f;
         v.z = v.z > 0.f ? v.z * s2 : 0.f; v.w = v.w > 0.f ? v.w * s3 : 0.f;
-        src[i] = v;
+        if (TIN) { srcT[(int64_t)(4 * i) * m] = v.x; srcT[(int64_t)(4 * i + 1) * m] = v.y; srcT[(int64_t)(4 * i + 2) * m] = v.z; srcT[(int64_t)(4 * i + 3) * m] = v.w; }
+        else src[i] = v;
         a[4 * i] = v.x; a[4 * i + 1] = v.y; a[4 * i + 2] = v.z; a[4 * i + 3] = v.w;
     }
     // ---- lat = r1 W2^T: this wave's K-slice
@@ -478,6 +492,7 @@ struct MidBwdArgs {
     float *dlogits, *dlat, *dr1, *partial1, *partial2, *partial3, *dW3_part;
     int64_t *ctl; int64_t batch_advance;
     int g_parts, m, C, train; float nce_coef;
+    int act1_t;               // act1 is stored transposed, [512, m]
 };
 
 // (tile1 > tile0: the workgroups behind the COL_PARTS computing ones assemble tiles [tile0, tile1) of the NEXT batch into a
@@ -518,13 +533,22 @@ __global__ __launch_bounds__(64 * MID_WAVES) void mid_bwd_kernel(MidBwdArgs a, i
         const int nr = (r1 - t0 < 16) ? r1 - t0 : 16;
         // the layer-1 activations this lane masks with in phase 2: requested now, needed after the head backward
         float a1v[2][4];
+        if (a.act1_t && nr == 16 && (m & 3) == 0) {          // transposed image: this lane's four rows of a column are one 16-byte read
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                const int rl = 4 * q + reg;
-                a1v[j][reg] = rl < nr ? a.act1[(int64_t)(t0 + rl) * H1 + 16 * (2 * wv + j) + l] : 0.f;
+            for (int j = 0; j < 2; ++j) {
+                const float4 t4 = *(const float4 *)(a.act1 + (int64_t)(16 * (2 * wv + j) + l) * m + t0 + 4 * q);
+                a1v[j][0] = t4.x; a1v[j][1] = t4.y; a1v[j][2] = t4.z; a1v[j][3] = t4.w;
             }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int rl = 4 * q + reg;
+                    a1v[j][reg] = rl >= nr ? 0.f : a.act1_t ? a.act1[(int64_t)(16 * (2 * wv + j) + l) * m + t0 + rl]
+                                                            : a.act1[(int64_t)(t0 + rl) * H1 + 16 * (2 * wv + j) + l];
+                }
+        }
         __syncthreads();
         // ---- 1. head backward of row t0 + wv
         if (wv < nr && small) {
@@ -693,7 +717,7 @@ struct RmsArgs {
     // optional: the gradient of tensor wg_t is not read but computed here as wg_dy^T wg_x ([wg_m, n_out]^T [wg_m, n_in]) by
     // wg_tiles extra workgroups, one 16 x 16 tile each, which also apply the update to their tile (a.n[wg_t] is 0 then)
     const float *wg_dy, *wg_x; float *wg_grad;
-    int wg_t, wg_m, wg_n_out, wg_n_in, wg_tiles;
+    int wg_t, wg_m, wg_n_out, wg_n_in, wg_tiles, wg_xt;      // wg_xt: wg_x is stored transposed, [n_in, wg_m]
     int first[9];     // optimizer blocks [first[t], first[t + 1]) belong to tensor t: as many as the tensor needs, not one grid row each
 };
 
@@ -709,6 +733,30 @@ __device__ __forceinline__ void wgrad_tile_rms(const RmsArgs &a, int tile, float
     const int kb = wv * per, ke = (kb + per < m) ? kb + per : m;
     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
     const float *pa = a.wg_dy + i0 + l, *pb = a.wg_x + j0 + l;    // A[i = l][k = q] = dy[k][i0 + l], B[k = q][j = l] = x[k][j0 + l]
+    if (a.wg_xt && (per & 127) == 0 && kb + per <= m) {
+        // x stored transposed ([n_in, m]): lane (l, q) walks 32 consecutive k of ITS column per batch (16-byte reads), and MFMA step
+        // u takes k = k0 + 32 q + u on both operands -- any assignment of k to (step, q) is a valid order of the same sum
+        const float *pbt = a.wg_x + (int64_t)(j0 + l) * m;
+        for (int k0 = kb; k0 < ke; k0 += 128) {
+            float av[32], bv[32];
+#pragma unroll
+            for (int u4 = 0; u4 < 8; ++u4) {
+                const float4 t4 = *(const float4 *)(pbt + k0 + 32 * q + 4 * u4);
+                bv[4 * u4] = t4.x; bv[4 * u4 + 1] = t4.y; bv[4 * u4 + 2] = t4.z; bv[4 * u4 + 3] = t4.w;
+            }
+#pragma unroll
+            for (int u = 0; u < 32; ++u) av[u] = pa[(k0 + 32 * q + u) * lda];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
+        }
+    } else if (a.wg_xt) {
+        for (int k0 = kb; k0 < ke; k0 += 4) {
+            const int k = k0 + q;
+            const bool ok = k < ke;
+            const float ta = ok ? pa[k * lda] : 0.f, tb = ok ? a.wg_x[(int64_t)(j0 + l) * m + k] : 0.f;
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ta, tb, acc, 0, 0, 0);
+        }
+    } else
     for (int k0 = kb; k0 < ke; k0 += 128) {                  // 64 independent loads in flight per lane, then 32 MFMAs
         float av[32], bv[32];
 #pragma unroll
@@ -851,14 +899,14 @@ int idl_mid_fwd(float *a1, const float *W2, const float *b2, const float *W3, co
     IDL_REQUIRE(a1 && W2 && b2 && W3 && b3 && ctl && f && inv && r2 && z, "NULL buffer");
     IDL_REQUIRE(m >= 16 && (m % 16) == 0 && C >= 1 && C <= 64 * MAX_CPL, "mid_fwd: m must be a multiple of 16, n_clusters in 1..256");
     IDL_REQUIRE((((uintptr_t)a1 | (uintptr_t)W2 | (uintptr_t)W3) & 15u) == 0, "a1 / W2 / W3 must be 16-byte aligned");
-    hipLaunchKernelGGL(mid_fwd_kernel, dim3((unsigned)(m / 16)), dim3(64 * MID_WAVES), 0, (hipStream_t)stream, a1, W2, b2, W3, b3, m, C, train, seed,
-                       ctl, f, inv, r2, z, m / 16, 0, 0, idl_dev::GatherArgs{});
+    hipLaunchKernelGGL(mid_fwd_kernel<false>, dim3((unsigned)(m / 16)), dim3(64 * MID_WAVES), 0, (hipStream_t)stream, a1, (const float *)nullptr, W2, b2,
+                       W3, b3, m, C, train, seed, ctl, f, inv, r2, z, m / 16, 0, 0, idl_dev::GatherArgs{});
     IDL_HIP_TRY(hipGetLastError());
     return IDL_OK;
 }
 
-int idl_mid_fwd_gather(float *a1, const float *W2, const float *b2, const float *W3, const float *b3, int m, int C, int train,
-                       uint64_t seed, const int64_t *ctl, float *f, float *inv, float *r2, float *z,
+int idl_mid_fwd_gather(float *a1, const float *b1, int a1_transposed, const float *W2, const float *b2, const float *W3, const float *b3, int m,
+                       int C, int train, uint64_t seed, const int64_t *ctl, float *f, float *inv, float *r2, float *z,
                        const float *feats, int64_t n, int64_t fdim, int64_t view_stride, const int64_t *pair_idx, const int64_t *base,
                        int64_t base_add, int64_t n_pairs, int64_t batch, const double *mean, const double *scale,
                        const double *inv_scale, float *y, int part, int parts, void *stream)
@@ -867,13 +915,21 @@ int idl_mid_fwd_gather(float *a1, const float *W2, const float *b2, const float 
     IDL_REQUIRE(m >= 16 && (m % 16) == 0 && C >= 1 && C <= 64 * MAX_CPL, "mid_fwd: m must be a multiple of 16, n_clusters in 1..256");
     IDL_REQUIRE((((uintptr_t)a1 | (uintptr_t)W2 | (uintptr_t)W3) & 15u) == 0, "a1 / W2 / W3 must be 16-byte aligned");
     IDL_REQUIRE(parts >= 1 && part >= 0 && part < parts, "mid_fwd_gather: part outside [0, parts)");
-    IDL_REQUIRE(feats && pair_idx && mean && scale && y && n >= 1 && fdim >= 4 && (fdim & 3) == 0 && batch >= 1 && n_pairs >= 0,
-                "mid_fwd_gather: bad gather arguments (4 | f)");
-    idl_dev::GatherArgs g{feats, n, fdim, view_stride, pair_idx, base, batch, n_pairs, mean, scale, inv_scale, y, base_add};
-    const int64_t ng = idl_dev::gather_tiles<MID_GATHER_ROWS>(fdim, batch);
-    const int64_t t0 = ng * part / parts, t1 = ng * (part + 1) / parts;
-    hipLaunchKernelGGL(mid_fwd_kernel, dim3((unsigned)(m / 16 + (t1 - t0 + 3) / 4)), dim3(64 * MID_WAVES), 0, (hipStream_t)stream, a1, W2, b2, W3, b3,
-                       m, C, train, seed, ctl, f, inv, r2, z, m / 16, (int)t0, (int)t1, g);
+    IDL_REQUIRE(b1 == nullptr || (((uintptr_t)b1) & 15u) == 0, "mid_fwd_gather: b1 must be 16-byte aligned");
+    idl_dev::GatherArgs g{};
+    int64_t t0 = 0, t1 = 0;
+    if (feats != nullptr) {                  // (feats == NULL: no batch assembly in this launch)
+        IDL_REQUIRE(pair_idx && mean && scale && y && n >= 1 && fdim >= 4 && (fdim & 3) == 0 && batch >= 1 && n_pairs >= 0,
+                    "mid_fwd_gather: bad gather arguments (4 | f)");
+        g = idl_dev::GatherArgs{feats, n, fdim, view_stride, pair_idx, base, batch, n_pairs, mean, scale, inv_scale, y, base_add};
+        const int64_t ng = idl_dev::gather_tiles<MID_GATHER_ROWS>(fdim, batch);
+        t0 = ng * part / parts; t1 = ng * (part + 1) / parts;
+    }
+    const dim3 grid((unsigned)(m / 16 + (t1 - t0 + 3) / 4));
+    if (a1_transposed) hipLaunchKernelGGL(mid_fwd_kernel<true>, grid, dim3(64 * MID_WAVES), 0, (hipStream_t)stream, a1, b1, W2, b2, W3, b3,
+                                          m, C, train, seed, ctl, f, inv, r2, z, m / 16, (int)t0, (int)t1, g);
+    else hipLaunchKernelGGL(mid_fwd_kernel<false>, grid, dim3(64 * MID_WAVES), 0, (hipStream_t)stream, a1, b1, W2, b2, W3, b3,
+                            m, C, train, seed, ctl, f, inv, r2, z, m / 16, (int)t0, (int)t1, g);
     IDL_HIP_TRY(hipGetLastError());
     return IDL_OK;
 }
@@ -936,23 +992,27 @@ int idl_mid_bwd_gather(const float *z, const float *r2, const float *f, const fl
                        float *dlat, float *dr1, float *partial1, float *partial2, float *partial3, float *dW3_partial,
                        const float *feats, int64_t n, int64_t fdim, int64_t view_stride, const int64_t *pair_idx, const int64_t *base,
                        int64_t base_add, int64_t n_pairs, int64_t batch, const double *mean, const double *scale,
-                       const double *inv_scale, float *y, int part, int parts, void *stream)
+                       const double *inv_scale, float *y, int part, int parts, int act1_transposed, void *stream)
 {
     IDL_REQUIRE(parts >= 1 && part >= 0 && part < parts, "mid_bwd_gather: part outside [0, parts)");
     IDL_REQUIRE(g_parts >= 1 && g_parts <= 16, "mid_bwd: g_parts outside 1..16");
     IDL_REQUIRE(z && r2 && f && inv && G && dP0 && W3 && W2 && act1 && dlogits && dlat && dr1 && partial1 && partial2 && partial3, "NULL buffer");
     IDL_REQUIRE(m >= 2 && (m % 2) == 0 && C >= 1 && C <= 64 * MAX_CPL, "mid_bwd: even m, n_clusters in 1..256");
     IDL_REQUIRE(dW3_partial == nullptr || C <= 48, "mid_bwd: dW3 partials need n_clusters <= 48");
-    IDL_REQUIRE(feats && pair_idx && mean && scale && y && n >= 1 && fdim >= 4 && (fdim & 3) == 0 && batch >= 1 && n_pairs >= 0,
-                "mid_bwd_gather: bad gather arguments (4 | f)");
     MidBwdArgs a{};
     a.z = z; a.r2 = r2; a.f = f; a.inv = inv; a.G = G; a.dP0 = dP0; a.W3 = W3; a.W2 = W2; a.act1 = act1;
     a.dlogits = dlogits; a.dlat = dlat; a.dr1 = dr1; a.partial1 = partial1; a.partial2 = partial2; a.partial3 = partial3;
     a.dW3_part = dW3_partial; a.ctl = nullptr; a.batch_advance = 0;
-    a.g_parts = g_parts; a.m = m; a.C = C; a.train = train; a.nce_coef = nce_coef;
-    idl_dev::GatherArgs g{feats, n, fdim, view_stride, pair_idx, base, batch, n_pairs, mean, scale, inv_scale, y, base_add};
-    const int64_t ng = idl_dev::gather_tiles<MID_GATHER_ROWS>(fdim, batch);
-    const int64_t t0 = ng * part / parts, t1 = ng * (part + 1) / parts;
+    a.g_parts = g_parts; a.m = m; a.C = C; a.train = train; a.nce_coef = nce_coef; a.act1_t = act1_transposed ? 1 : 0;
+    idl_dev::GatherArgs g{};
+    int64_t t0 = 0, t1 = 0;
+    if (feats != nullptr) {                  // (feats == NULL: no batch assembly in this launch)
+        IDL_REQUIRE(pair_idx && mean && scale && y && n >= 1 && fdim >= 4 && (fdim & 3) == 0 && batch >= 1 && n_pairs >= 0,
+                    "mid_bwd_gather: bad gather arguments (4 | f)");
+        g = idl_dev::GatherArgs{feats, n, fdim, view_stride, pair_idx, base, batch, n_pairs, mean, scale, inv_scale, y, base_add};
+        const int64_t ng = idl_dev::gather_tiles<MID_GATHER_ROWS>(fdim, batch);
+        t0 = ng * part / parts; t1 = ng * (part + 1) / parts;
+    }
     hipLaunchKernelGGL(mid_bwd_kernel, dim3((unsigned)(COL_PARTS + (t1 - t0 + 3) / 4)), dim3(64 * MID_WAVES), 0, (hipStream_t)stream, a, (int)t0,
                        (int)t1, g);
     IDL_HIP_TRY(hipGetLastError());
@@ -1015,7 +1075,7 @@ static int rmsprop_launch(int count, float *const *params, const float *const *g
                           float *const *square_avg, const int64_t *sizes, const float *hyper, int64_t *ctl, int64_t batch_advance,
                           const float *loss_rows, int loss_m, float w_nce, float w_iic, float *out, const idl_dev::GatherArgs &g,
                           void *stream, int wg_index = -1, const float *wg_dy = nullptr, const float *wg_x = nullptr, int wg_m = 0,
-                          int wg_n_out = 0, int wg_n_in = 0, float *wg_grad = nullptr)
+                          int wg_n_out = 0, int wg_n_in = 0, float *wg_grad = nullptr, int wg_x_transposed = 0)
 {
     IDL_REQUIRE(count >= 1 && count <= 8 && params && grads && square_avg && sizes && hyper && ctl, "rmsprop_step: 1..8 tensors");
     RmsArgs a{};
@@ -1034,6 +1094,8 @@ static int rmsprop_launch(int count, float *const *params, const float *const *g
                     "rmsprop_step: in-launch weight gradient needs n_out, n_in multiples of 16 and sizes[wg_index] == n_out * n_in");
         a.wg_t = wg_index; a.wg_dy = wg_dy; a.wg_x = wg_x; a.wg_grad = wg_grad; a.wg_m = wg_m; a.wg_n_out = wg_n_out; a.wg_n_in = wg_n_in;
         a.wg_tiles = (wg_n_out / 16) * (wg_n_in / 16);
+        a.wg_xt = wg_x_transposed ? 1 : 0;
+        IDL_REQUIRE(!wg_x_transposed || ((wg_m & 3) == 0 && (((uintptr_t)wg_x) & 15u) == 0), "rmsprop_step: transposed wg_x needs 4 | m and 16-byte alignment");
         a.n[wg_index] = 0;                  // its optimizer blocks have nothing to do: the tile workgroups update it
         mx = 0;
         for (int i = 0; i < count; ++i) if (a.n[i] > mx) mx = a.n[i];
@@ -1081,8 +1143,8 @@ int idl_rmsprop_step_gather_wgrad(int count, float *const *params, const float *
                                   const float *loss_rows, int loss_m, float w_nce, float w_iic, float *out,
                                   const float *feats, int64_t n, int64_t f, int64_t view_stride, const int64_t *pair_idx, int64_t n_pairs,
                                   int64_t batch, const double *mean, const double *scale, const double *inv_scale, float *y,
-                                  int wg_index, const float *wg_dy, const float *wg_x, int wg_m, int wg_n_out, int wg_n_in, float *wg_grad,
-                                  int64_t batch_advance, void *stream)
+                                  int wg_index, const float *wg_dy, const float *wg_x, int wg_x_transposed, int wg_m, int wg_n_out, int wg_n_in,
+                                  float *wg_grad, int64_t batch_advance, void *stream)
 {
     idl_dev::GatherArgs g{};
     if (feats != nullptr) {
@@ -1090,7 +1152,7 @@ int idl_rmsprop_step_gather_wgrad(int count, float *const *params, const float *
         g = idl_dev::GatherArgs{feats, n, f, view_stride, pair_idx, ctl + 1, batch, n_pairs, mean, scale, inv_scale, y};
     }
     return rmsprop_launch(count, params, grads, grad_parts, square_avg, sizes, hyper, ctl, batch_advance, loss_rows, loss_m, w_nce, w_iic, out, g,
-                          stream, wg_index, wg_dy, wg_x, wg_m, wg_n_out, wg_n_in, wg_grad);
+                          stream, wg_index, wg_dy, wg_x, wg_m, wg_n_out, wg_n_in, wg_grad, wg_x_transposed);
 }
 
 }  // extern "C"

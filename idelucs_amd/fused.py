@@ -43,6 +43,7 @@ class _Buffers:
         self.xs = [torch.empty((m, F), **f32), torch.empty((m, F), **f32)]   # the batch of this step / the next one being assembled
         self.x = self.xs[0]
         self.r1 = torch.empty((m, H1), **f32)        # Linear1 output, then ReLU+Dropout in place
+        self.r1T = self.r1.view(H1, m)                # the same memory as the transposed image [H1, m] (one of the two is in use)
         self.lat = torch.empty((m, H2), **f32)
         self.f = torch.empty((m, H2), **f32)
         self.inv = torch.empty((m,), **f32)
@@ -101,6 +102,8 @@ class FusedLinearTrainer:
         self._early_gather = (self._pipeline and self._mid_fused and self.C <= 48 and self.F % 4 == 0
                               and os.environ.get("IDELUCS_EARLY_GATHER", "1") != "0")
         self._early_split = os.environ.get("IDELUCS_EARLY_GATHER", "1") != "2"       # 2: all of it in the mid-backward launch
+        # layer-1 activations kept transposed ([512, m]) between the layer-1 product and its consumers
+        self._transposed_l1 = os.environ.get("IDELUCS_TRANSPOSED_L1", "1") != "0"
         self._joint_inlaunch = os.environ.get("IDELUCS_JOINT_INLAUNCH", "1") != "0"   # IIC joint inside the InfoNCE pass-1 launch
         # opt-in: dW1 on this package's own MFMA kernel with RMSprop in its epilogue (csrc/wgrad.hip; measured a wash against
         # hipBLASLt + the optimizer launch, so off by default)
@@ -135,15 +138,21 @@ class FusedLinearTrainer:
         bf.x (both are memory-bound and independent: one launch instead of two)."""
         m, C, tr = bf.m, self.C, 1 if train else 0
         x = bf.xs[xi]
+        tl = (self._transposed_l1 and next_from is not None and self._early_gather and self._early_split and m % 16 == 0
+              and self._dw2_inlaunch)
         early = next_from is not None and self._early_gather and m % 16 == 0   # next batch -> bf.xs[1 - xi] by the mid launches
         chk = _lib.check
         main = torch.cuda.current_stream()
         side = self._side if self._overlap else main
         # ---- forward
-        torch.addmm(self.b1, x, self.W1.t(), out=bf.r1)
+        if tl:      # a1^T = W1 x^T: the orientation hipBLASLt runs this product fastest in; mid_fwd adds the bias
+            torch.mm(self.W1, x.t(), out=bf.r1T)
+        else:
+            torch.addmm(self.b1, x, self.W1.t(), out=bf.r1)
         if early and self._early_split:         # ... and the first half of the next batch's tiles in its spare workgroups
             st = next_from
-            chk(_L.idl_mid_fwd_gather(_p(bf.r1), _p(self.W2), _p(self.b2), _p(self.W3), _p(self.b3), m, C, tr, self.seed, _p(self.ctl),
+            chk(_L.idl_mid_fwd_gather(_p(bf.r1), _p(self.b1) if tl else None, 1 if tl else 0, _p(self.W2), _p(self.b2), _p(self.W3), _p(self.b3),
+                                      m, C, tr, self.seed, _p(self.ctl),
                                       _p(bf.f), _p(bf.inv), _p(bf.r2), _p(bf.z),
                                       _p(st.feats), st.n, st.f, st.n * st.f, _p(self._perm), _p(self.ctl[1:]), m // 2, st.n_pairs, m // 2,
                                       _p(st.mean), _p(st.scale), _p(st.inv_scale), _p(bf.xs[1 - xi]), 0, 2, _stream()))
@@ -187,7 +196,7 @@ class FusedLinearTrainer:
                                       _p(gW3) if self._dw3_partial else None,
                                       _p(st.feats), st.n, st.f, st.n * st.f, _p(self._perm), _p(self.ctl[1:]), m // 2, st.n_pairs, m // 2,
                                       _p(st.mean), _p(st.scale), _p(st.inv_scale), _p(bf.xs[1 - xi]), 1 if self._early_split else 0,
-                                      2 if self._early_split else 1, _stream()))
+                                      2 if self._early_split else 1, 1 if tl else 0, _stream()))
             if not self._dw3_partial:
                 torch.mm(bf.dlogits.t(), bf.r2, out=gW3)
             if not self._dw2_inlaunch:
@@ -228,7 +237,7 @@ class FusedLinearTrainer:
             chk(_L.idl_rmsprop_step_gather_wgrad(len(self.params), self._pp, self._gp, self._parts, self._vp, sz, _p(self.hyper),
                                                  _p(self.ctl), _p(bf.loss_rows), m, 1.0 - self.weight, self.weight, _p(self.out),
                                                  None, 0, 0, 0, None, 0, 0, None, None, None, None,
-                                                 2, _p(bf.dlat), _p(bf.r1), m, self.H2, self.H1, _p(gW2), m // 2, _stream()))
+                                                 2, _p(bf.dlat), _p(bf.r1), 1 if tl else 0, m, self.H2, self.H1, _p(gW2), m // 2, _stream()))
         elif early:
             chk(_L.idl_rmsprop_step(len(self.params), self._pp, self._gp, self._parts, self._vp, sz, _p(self.hyper),
                                     _p(self.ctl), m // 2, _p(bf.loss_rows), m, 1.0 - self.weight, self.weight, _p(self.out), _stream()))
@@ -238,7 +247,7 @@ class FusedLinearTrainer:
                                                  _p(self.ctl), _p(bf.loss_rows), m, 1.0 - self.weight, self.weight, _p(self.out),
                                                  _p(st.feats), st.n, st.f, st.n * st.f, _p(self._perm), st.n_pairs, m // 2,
                                                  _p(st.mean), _p(st.scale), _p(st.inv_scale), _p(bf.x),
-                                                 2, _p(bf.dlat), _p(bf.r1), m, self.H2, self.H1, _p(gW2), 0, _stream()))
+                                                 2, _p(bf.dlat), _p(bf.r1), 0, m, self.H2, self.H1, _p(gW2), 0, _stream()))
         elif next_from is not None:
             st = next_from
             chk(_L.idl_rmsprop_step_gather(len(self.params), self._pp, self._gp, self._parts, self._vp, sz, _p(self.hyper),

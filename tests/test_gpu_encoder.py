@@ -472,8 +472,59 @@ def test_fused_mid_backward_equals_separate_kernels(dev, m, C, train, dw3):
         assert torch.isfinite(y).all()                                          # every chunk slab written, empty chunks as zeros
 
 
-@pytest.mark.parametrize("m", [1024, 960, 70])
-def test_dw2_inside_the_optimizer_launch(dev, m):
+@pytest.mark.parametrize("m,C,train", [(1024, 20, 1), (96, 5, 0), (160, 48, 1)])
+def test_transposed_layer1_activations(dev, m, C, train):
+    """The layer-1 activations may live transposed ([512, m], the orientation hipBLASLt runs W1 x^T fastest in): idl_mid_fwd_gather
+    (bias added in the kernel) and idl_mid_bwd_gather on the transposed image give exactly what idl_mid_fwd / idl_mid_bwd give
+    on the row-major one, and leave the transposed image of the same masked activations behind."""
+    import torch
+    from idelucs_amd import _lib
+    from idelucs_amd.fused import _p, _stream
+    L = _lib.lib
+    torch.manual_seed(3 * m + C)
+    a1 = torch.randn(m, 512, device=dev); b1 = torch.randn(512, device=dev) * 0.1
+    W2 = torch.randn(64, 512, device=dev) * 0.06; b2 = torch.randn(64, device=dev) * 0.01
+    W3 = torch.randn(C, 64, device=dev) * 0.2; b3 = torch.randn(C, device=dev) * 0.01
+    ctl = torch.tensor([5, 0], dtype=torch.int64, device=dev)
+    outs = []
+    for tr_ in (0, 1):
+        buf = (a1.t().contiguous() if tr_ else (a1 + b1).contiguous())
+        f = torch.empty(m, 64, device=dev); inv = torch.empty(m, device=dev); r2 = torch.empty(m, 64, device=dev); z = torch.empty(m, C, device=dev)
+        if tr_:
+            _lib.check(L.idl_mid_fwd_gather(_p(buf), _p(b1), 1, _p(W2), _p(b2), _p(W3), _p(b3), m, C, train, 9, _p(ctl), _p(f), _p(inv), _p(r2), _p(z),
+                                            None, 0, 0, 0, None, None, 0, 0, 0, None, None, None, None, 0, 1, _stream()))
+        else:
+            _lib.check(L.idl_mid_fwd(_p(buf), _p(W2), _p(b2), _p(W3), _p(b3), m, C, train, 9, _p(ctl), _p(f), _p(inv), _p(r2), _p(z), _stream()))
+        torch.cuda.synchronize()
+        outs.append((buf.t().contiguous() if tr_ else buf, f, inv, r2, z))
+    for x, y in zip(outs[0], outs[1]):
+        assert torch.equal(x, y)
+    # backward: same tensors, act1 row-major vs transposed
+    r1, f, inv, r2, z = outs[0]
+    parts = L.idl_col_sum_parts(); gp = L.idl_nce_fused_parts()
+    G = torch.randn(gp, m, 64, device=dev) * 0.3
+    dP0 = torch.randn(C, C, device=dev) * 0.1; dP0 = dP0 + dP0.t()
+    res = []
+    for tr_ in (0, 1):
+        act = r1.t().contiguous() if tr_ else r1
+        dlg = torch.empty(m, C, device=dev); dlat = torch.empty(m, 64, device=dev); dr1 = torch.empty(m, 512, device=dev)
+        p1 = torch.empty(parts, 512, device=dev); p2 = torch.empty(parts, 64, device=dev); p3 = torch.empty(parts, C, device=dev)
+        w3 = torch.empty(parts, C, 64, device=dev)
+        if tr_:
+            _lib.check(L.idl_mid_bwd_gather(_p(z), _p(r2), _p(f), _p(inv), _p(G), gp, _p(dP0), _p(W3), _p(W2), _p(act), m, C, train, 1e-3,
+                                            _p(dlg), _p(dlat), _p(dr1), _p(p1), _p(p2), _p(p3), _p(w3),
+                                            None, 0, 0, 0, None, None, 0, 0, 0, None, None, None, None, 0, 1, 1, _stream()))
+        else:
+            _lib.check(L.idl_mid_bwd(_p(z), _p(r2), _p(f), _p(inv), _p(G), gp, _p(dP0), _p(W3), _p(W2), _p(act), m, C, train, 1e-3,
+                                     _p(dlg), _p(dlat), _p(dr1), _p(p1), _p(p2), _p(p3), _p(w3), None, 0, _stream()))
+        torch.cuda.synchronize()
+        res.append((dlg, dlat, dr1, p1, p2, p3, w3))
+    for x, y in zip(res[0], res[1]):
+        assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("m,xt", [(1024, 0), (960, 0), (70, 0), (1024, 1), (960, 1), (72, 1)])
+def test_dw2_inside_the_optimizer_launch(dev, m, xt):
     """idl_rmsprop_step_gather_wgrad: the gradient of one tensor computed in the launch as dy^T x (MFMA tiles) and applied
     there equals torch's product followed by the RMSprop formula; the other tensors are updated as by idl_rmsprop_step."""
     import ctypes
@@ -483,6 +534,7 @@ def test_dw2_inside_the_optimizer_launch(dev, m):
     L = _lib.lib
     torch.manual_seed(m)
     dy = torch.randn(m, 64, device=dev); x = torch.relu(torch.randn(m, 512, device=dev))
+    xarg = x.t().contiguous() if xt else x              # the product's second operand may be stored transposed, [512, m]
     W = [torch.randn(64, 512, device=dev) * 0.05, torch.randn(512, device=dev) * 0.1]
     V = [torch.rand(64, 512, device=dev) * 1e-3, torch.rand(512, device=dev) * 1e-3]
     gb = torch.randn(512, device=dev)
@@ -495,7 +547,7 @@ def test_dw2_inside_the_optimizer_launch(dev, m):
     _lib.check(L.idl_rmsprop_step_gather_wgrad(2, arr(W), arr(grads), (ctypes.c_int32 * 2)(1, 1), arr(V), (ctypes.c_int64 * 2)(64 * 512, 512),
                                                _p(hyper), _p(ctl), None, 0, 0.0, 0.0, None,
                                                None, 0, 0, 0, None, 0, 0, None, None, None, None,
-                                               0, _p(dy), _p(x), m, 64, 512, _p(gout), 5, _stream()))
+                                               0, _p(dy), _p(xarg), xt, m, 64, 512, _p(gout), 5, _stream()))
     torch.cuda.synchronize()
     g64 = (dy.double().t() @ x.double())
     assert (gout.double() - g64).abs().max().item() <= 2e-6 * g64.abs().max().item() + 1e-5

@@ -133,21 +133,25 @@ __global__ __launch_bounds__(256) void nce_pass2_kernel(const float *f, int m, f
         return;
     }
     __shared__ float red[4][16][64];     // per-wave G tiles [row][c]
-    __shared__ float lse_sh[NCE_MAX_M];  // lse of every row (each workgroup needs all of them for E^T)
+    __shared__ float lse_col[NCE_MAX_M / NCE_SPLIT + 16];   // lse of the columns this workgroup visits (for E^T) ...
+    __shared__ float lse_own[16];                            // ... and of its own 16 rows
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, l = lane & 15, q = lane >> 4;
     const int r0 = blockIdx.x * 16, ntiles = m / 16;
     const int t0 = (int)((int64_t)blockIdx.y * ntiles / NCE_SPLIT), t1 = (int)((int64_t)(blockIdx.y + 1) * ntiles / NCE_SPLIT);
-    for (int i = threadIdx.x; i < m; i += 256) {
+    const int c0 = 16 * t0, ncol = 16 * (t1 - t0);
+    for (int i = threadIdx.x; i < ncol + 16; i += 256) {     // only the rows this workgroup looks at, not all m of them
+        const int row = i < ncol ? c0 + i : r0 + (i - ncol);
         float sm = 0.f;
 #pragma unroll
-        for (int p = 0; p < NCE_SPLIT; ++p) sm += rowsum_part[(int64_t)p * m + i];
-        lse_sh[i] = __logf(sm);
+        for (int p = 0; p < NCE_SPLIT; ++p) sm += rowsum_part[(int64_t)p * m + row];
+        const float v = __logf(sm);
+        if (i < ncol) lse_col[i] = v; else lse_own[i - ncol] = v;
     }
     float rb[16];
     load_rows(f, r0, l, q, rb);
     const int r = r0 + l;
     __syncthreads();
-    const float lse_r = lse_sh[r];
+    const float lse_r = lse_own[l];
     if (blockIdx.y == 0 && wv == 0 && q == 0) { lse[r] = lse_r; loss_rows[r] = lse_r - pos[r]; }
     f32x4 g[4];                           // G[r = 4q+reg][c = 16*ct + l] for ct = 0..3
 #pragma unroll
@@ -160,7 +164,7 @@ __global__ __launch_bounds__(256) void nce_pass2_kernel(const float *f, int m, f
         for (int gq = 0; gq < 4; ++gq) {
             const int j = j0 + 4 * q + gq;
             const float x = s[gq] * inv_t;
-            e[gq] = (j == r) ? 0.f : __expf(x - lse_r) + __expf(x - lse_sh[j]);
+            e[gq] = (j == r) ? 0.f : __expf(x - lse_r) + __expf(x - lse_col[j - c0]);
         }
         // G[r][c] += sum_j E[r][j] f[j][c]: A = E[r = l][k -> j = 4q + step], B = f[j0 + 4q + step][16 ct + l]
 #pragma unroll

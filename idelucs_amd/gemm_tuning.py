@@ -35,13 +35,14 @@ def maybe_enable(total_steps=None):
     except ImportError:
         return False
     # one result file per process (ranks of a multi-GPU job must not share one), seeded from the shipped solutions
-    path = os.path.join(tempfile.gettempdir(), f"idelucs_tunableop_{os.getpid()}.csv")
+    dump = os.environ.get("IDELUCS_TUNABLEOP_DUMP")     # maintainers: write the tuned solutions there at exit (to refresh SEED_FILE)
+    path = dump or os.path.join(tempfile.gettempdir(), f"idelucs_tunableop_{os.getpid()}.csv")
     if os.path.exists(SEED_FILE):
         shutil.copyfile(SEED_FILE, path)
     tn.set_filename(path, insert_device_ordinal=False)
     tn.enable(True)
     tn.tuning_enable(True)
     if hasattr(tn, "write_file_on_exit"):
-        tn.write_file_on_exit(False)
+        tn.write_file_on_exit(bool(dump))
     _enabled = True
     return True

@@ -283,6 +283,10 @@ def main():
         f_ep = args.n_mimics * 2 * 3 * 2 * (F * H1 + H1 * H2 + H2 * C) + args.n_mimics * 3 * (2 * B) * H2 * 2 * 2
         t_ep = hp.mean_ms("epoch", args.warmup)
         ach_ep = args.n * f_ep / (t_ep * 1e-3) / 1e12
+        # what the step actually executes: layer 1 has no input gradient (x is data), so its backward is one product, not two
+        nce = args.n_mimics * 3 * (2 * B) * H2 * 2 * 2
+        f_exec = args.n_mimics * 2 * (2 * 2 * F * H1 + 3 * 2 * (H1 * H2 + H2 * C)) + nce
+        ach_exec = args.n * f_exec / (t_ep * 1e-3) / 1e12
         out = {
             "metric": "sequences/sec (k-mer vectorise + 1 epoch), k=6 batch 512",
             "value": value, "unit": "sequences/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -302,7 +306,10 @@ def main():
                          "share_of_step": t_vec / ms_step},
             "roofline_epoch": {"kernel": "training epoch (hipBLASLt fp32 GEMMs + gather + losses + RMSprop)", "bound": "mfma",
                                "achieved": ach_ep, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach_ep / MFMA_F32_PEAK_TFLOPS,
-                               "ms": t_ep, "flop_per_seq_algorithmic": f_ep, "share_of_step": t_ep / ms_step},
+                               "ms": t_ep, "flop_per_seq_algorithmic": f_ep, "share_of_step": t_ep / ms_step,
+                               "flop_per_seq_executed": f_exec, "achieved_executed": ach_exec, "frac_executed": ach_exec / MFMA_F32_PEAK_TFLOPS,
+                               "note": "algorithmic = SURVEY 8(d) (3 x forward for every layer); executed = without the input gradient of "
+                                       "layer 1, which is not computed; matrix-pipe busy time from PMC: profiles/r01_i_epoch_pmc_mfma.json"},
             "stage_ms": {k: hp.mean_ms(k, args.warmup) for k in hp.ev if hp.ev[k]},
             "exchange_ms": exchange_ms,
         }

@@ -129,3 +129,149 @@ __device__ __forceinline__ void iic_core_small(float *P0, int C, float lamb, flo
     for (int i = t; i < n; i += NT) P0[i] = w_iic * (Pl[i] - gp) / s;
 }
 
+// ---------------------------------------------------------------- the same core for 48 < C <= 256 (fine-grained mode, C = 200)
+// One 512-thread workgroup (2 waves per SIMD: 256 VGPRs each); row r of the joint belongs to two neighbouring lanes (r = t / 2),
+// each keeping its <= 128 elements in REGISTERS from the first read to the final write: P0 is read once (plus its transpose, for the symmetrisation) and written
+// once, the marginals are pair reductions (one DPP step), and only the C row sums go through LDS.  (iic_core_body walked the
+// 40 000 elements of a C = 200 joint four times through global memory behind float64 shuffles: 79 us; this: see DESIGN.md.)
+__device__ __forceinline__ void iic_core_rows(float *P0, int C, float lamb, float eps, float w_iic, float *out)
+{
+    constexpr int NW = 8, EPT = 128, G = 2;
+    __shared__ float rs[256], ar[256];
+    __shared__ double red[2][NW];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6, r = t / G, sub = t % G;
+    const bool live = r < C;
+    float p[EPT];
+    double acc = 0.0;
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) {
+        const int c = sub + G * j;
+        p[j] = 0.f;
+        if (live && c < C) { const float a = P0[r * C + c], b = P0[c * C + r]; p[j] = (a + b) * 0.5f; acc += (double)a; }
+        if ((j & 15) == 15) __builtin_amdgcn_sched_barrier(0);      // 32 loads in flight at a time, not 256 (register budget)
+    }
+    acc = idl_dev::wave_sum_d(acc);
+    if (lane == 0) red[0][wv] = acc;
+    __syncthreads();
+    double st = 0.0;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) st += red[0][i];
+    const float s = (float)st;
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) {
+        const int c = sub + G * j;
+        if (live && c < C) { p[j] = p[j] / s; a += p[j]; b += fmaxf(p[j], eps); }
+        if ((j & 15) == 15) __builtin_amdgcn_sched_barrier(0);
+    }
+    a += idl_dev::dpp_f<idl_dev::DPP_XOR1>(a);
+    b += idl_dev::dpp_f<idl_dev::DPP_XOR1>(b);
+    if (live && sub == 0) { rs[r] = a; ar[r] = b; }
+    __syncthreads();
+    double lacc = 0.0, gacc = 0.0;
+    if (live) {
+        const float piu = rs[r], pi = fmaxf(piu, eps), lpi = __logf(pi), ari = ar[r];
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) {
+            const int c = sub + G * j;
+            if (c < C) {
+                const float pu = p[j], pp = fmaxf(pu, eps);
+                const float pju = rs[c], pj = fmaxf(pju, eps);
+                const float lg = __logf(pp) - lamb * __logf(pj) - lamb * lpi;
+                lacc += (double)(-pp * lg);
+                float g = 0.f;
+                if (!(pu < eps)) g += -lg - 1.f;
+                if (!(piu < eps)) g += lamb * ari / pi;
+                if (!(pju < eps)) g += lamb * ar[c] / pj;
+                p[j] = g;
+                gacc += (double)g * (double)pu;
+            }
+            if ((j & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    lacc = idl_dev::wave_sum_d(lacc); gacc = idl_dev::wave_sum_d(gacc);
+    if (lane == 0) { red[0][wv] = lacc; red[1][wv] = gacc; }       // (red[0] was last read before the barrier above)
+    __syncthreads();
+    double l1 = 0.0, g1 = 0.0;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) { l1 += red[0][i]; g1 += red[1][i]; }
+    const float iic = (float)l1, gp = (float)g1;
+    if (t == 0) out[3] = iic;
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) {
+        const int c = sub + G * j;
+        if (live && c < C) P0[r * C + c] = w_iic * (p[j] - gp) / s;
+        if ((j & 15) == 15) __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// ---------------------------------------------------------------- ... and for C x C x 4 B <= ~158 KB (C <= 200: the fine-grained mode)
+// the whole joint in (dynamic) LDS, updated in place: read from memory once with coalesced 16-byte loads, symmetrised pair by pair
+// (the thread of element (r, c), r <= c, writes both (r, c) and (c, r)), row sums one wave per row, gradient in place, written
+// back once.  L: C * C floats of LDS.  NT threads.
+template <int NT>
+__device__ __forceinline__ void iic_core_lds(float *P0, int C, float lamb, float eps, float w_iic, float *out, float *L)
+{
+    constexpr int NW = NT / 64;
+    __shared__ float rs[256], ar[256];
+    __shared__ double red[2][NW];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6, n = C * C;
+    double acc = 0.0;
+    if ((n & 3) == 0 && ((uintptr_t)P0 & 15u) == 0) {
+        for (int i4 = t; i4 < n / 4; i4 += NT) {
+            const float4 v = ((const float4 *)P0)[i4];
+            *(float4 *)(L + 4 * i4) = v;
+            acc += ((double)v.x + (double)v.y) + ((double)v.z + (double)v.w);
+        }
+    } else {
+        for (int i = t; i < n; i += NT) { const float v = P0[i]; L[i] = v; acc += (double)v; }
+    }
+    acc = idl_dev::wave_sum_d(acc);
+    if (lane == 0) red[0][wv] = acc;
+    __syncthreads();
+    double st = 0.0;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) st += red[0][i];
+    const float s = (float)st;
+    // everything below walks the joint one wave per row (no integer divisions); the per-row terms of the loss and of the gradient
+    // -- log of the clamped marginal, lamb * ar / marginal -- are computed once per row, not once per element
+    for (int r = wv; r < C; r += NW)
+        for (int c = r + lane; c < C; c += 64) { const float v = ((L[r * C + c] + L[c * C + r]) * 0.5f) / s; L[r * C + c] = v; L[c * C + r] = v; }
+    __syncthreads();
+    for (int r = wv; r < C; r += NW) {
+        float a = 0.f, b = 0.f;
+        for (int c = lane; c < C; c += 64) { const float p = L[r * C + c]; a += p; b += fmaxf(p, eps); }
+        a = idl_dev::wave_sum_f(a); b = idl_dev::wave_sum_f(b);
+        if (lane == 0) {
+            const float pi = fmaxf(a, eps);
+            rs[r] = __logf(pi);                               // log of the clamped marginal
+            ar[r] = (a < eps) ? 0.f : lamb * b / pi;          // its share of dL/dP (none through a clamped marginal)
+        }
+    }
+    __syncthreads();
+    double lacc = 0.0, gacc = 0.0;
+    for (int r = wv; r < C; r += NW) {
+        const float lpi = rs[r], gri = ar[r];
+        for (int c = lane; c < C; c += 64) {
+            const float pu = L[r * C + c], p = fmaxf(pu, eps);
+            const float lg = __logf(p) - lamb * rs[c] - lamb * lpi;
+            lacc += (double)(-p * lg);
+            float g = 0.f;
+            if (!(pu < eps)) g += -lg - 1.f;
+            g += gri;
+            g += ar[c];
+            L[r * C + c] = g;
+            gacc += (double)g * (double)pu;
+        }
+    }
+    lacc = idl_dev::wave_sum_d(lacc); gacc = idl_dev::wave_sum_d(gacc);
+    if (lane == 0) { red[0][wv] = lacc; red[1][wv] = gacc; }       // (red[0] was last read two barriers ago)
+    __syncthreads();
+    double l1 = 0.0, g1 = 0.0;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) { l1 += red[0][i]; g1 += red[1][i]; }
+    const float gp = (float)g1;
+    if (t == 0) out[3] = (float)l1;
+    for (int i = t; i < n; i += NT) P0[i] = w_iic * (L[i] - gp) / s;      // (each thread re-reads only what it wrote)
+}
+

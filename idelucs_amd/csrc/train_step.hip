@@ -339,12 +339,18 @@ __global__ __launch_bounds__(256) void nce_esym_kernel(float *S, int m, float in
 }
 
 // ---------------------------------------------------------------- IIC on the C x C joint (one workgroup): iic_device.h
+__global__ __launch_bounds__(1024) void iic_core_lds_kernel(float *P0, int C, float lamb, float eps, float w_iic, float *out)
+{
+    extern __shared__ float iic_L[];
+    iic_core_lds<1024>(P0, C, lamb, eps, w_iic, out, iic_L);
+}
+
 template <int NT>
 __global__ __launch_bounds__(NT) void iic_core_kernel(float *P0, int C, float lamb, float eps, float w_iic, float *scratch,
                                                       float *out)
 {
     if (NT == 256) iic_core_small(P0, C, lamb, eps, w_iic, out);     // C <= 48 (launcher)
-    else iic_core_body<NT>(P0, C, lamb, eps, w_iic, scratch, out);
+    else iic_core_rows(P0, C, lamb, eps, w_iic, out);                // 48 < C <= 256
 }
 
 // ---------------------------------------------------------------- head backward: one wave per row
@@ -951,7 +957,18 @@ int idl_iic_core(float *P0, int C, float lamb, float eps, float w_iic, float *sc
     IDL_REQUIRE(P0 && scratch && out, "NULL buffer");
     IDL_REQUIRE(C >= 1 && C <= 64 * MAX_CPL, "iic_core: n_clusters must be in 1..256");
     if (C <= 48) hipLaunchKernelGGL(iic_core_kernel<256>, dim3(1), dim3(256), 0, (hipStream_t)stream, P0, C, lamb, eps, w_iic, scratch, out);
-    else hipLaunchKernelGGL(iic_core_kernel<1024>, dim3(1), dim3(1024), 0, (hipStream_t)stream, P0, C, lamb, eps, w_iic, scratch, out);
+    else if (C <= 200) {                     // the joint fits LDS (C * C * 4 + 2.3 KB <= 160 KB)
+        const int lds = C * C * 4;
+        static bool attr_set[64] = {};
+        int dev = 0;
+        IDL_HIP_TRY(hipGetDevice(&dev));
+        if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+            IDL_HIP_TRY(hipFuncSetAttribute((const void *)iic_core_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 200 * 200 * 4));
+            attr_set[dev] = true;
+        }
+        hipLaunchKernelGGL(iic_core_lds_kernel, dim3(1), dim3(1024), lds, (hipStream_t)stream, P0, C, lamb, eps, w_iic, out);
+    }
+    else hipLaunchKernelGGL(iic_core_kernel<512>, dim3(1), dim3(512), 0, (hipStream_t)stream, P0, C, lamb, eps, w_iic, scratch, out);
     IDL_HIP_TRY(hipGetLastError());
     return IDL_OK;
 }

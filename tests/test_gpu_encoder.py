@@ -592,3 +592,29 @@ def test_wgrad_kernel_vs_torch(dev, m, fused):
         assert torch.allclose(W, wr, rtol=1e-5, atol=1e-7) and torch.allclose(V, vr, rtol=1e-5, atol=1e-9)
     else:
         assert torch.equal(W, W0) and torch.equal(V, V0)
+
+
+@pytest.mark.parametrize("C", [49, 200, 256])
+def test_iic_core_large_joint_vs_torch(dev, C):
+    """idl_iic_core beyond the 48-class kernels (LDS-resident joint up to C = 200, register-resident rows up to 256): the loss and
+    d(loss)/dP0 equal torch autograd through the reference formula (LossFunctions.py:20-62 restated on the C x C joint)."""
+    import torch
+    from idelucs_amd import _lib
+    from idelucs_amd.fused import _p, _stream, EPS
+    torch.manual_seed(C)
+    B = 300
+    z1 = torch.softmax(torch.randn(B, C, device=dev) * 2, 1); z2 = torch.softmax(torch.randn(B, C, device=dev) * 2, 1)
+    P0 = (z1.t() @ z2).contiguous().requires_grad_(True)
+    P = (P0 + P0.t()) / 2.0
+    P = P / P.sum()
+    Pc = torch.where(P < EPS, torch.full_like(P, EPS), P)
+    pi = P.sum(1, keepdim=True).expand(C, C); pj = P.sum(0, keepdim=True).expand(C, C)
+    pic = torch.where(pi < EPS, torch.full_like(pi, EPS), pi); pjc = torch.where(pj < EPS, torch.full_like(pj, EPS), pj)
+    loss = -(Pc * (torch.log(Pc) - 2.8 * torch.log(pjc) - 2.8 * torch.log(pic))).sum()
+    loss.backward()
+    buf = P0.detach().clone(); scratch = torch.empty(C * C + 2 * C, device=dev); out = torch.zeros(4, device=dev)
+    _lib.check(_lib.lib.idl_iic_core(_p(buf), C, 2.8, EPS, 0.25, _p(scratch), _p(out), _stream()))
+    torch.cuda.synchronize()
+    assert abs(out[3].item() - loss.item()) <= 1e-4 * abs(loss.item())
+    want = 0.25 * P0.grad
+    assert torch.allclose(buf, want, rtol=2e-3, atol=2e-4 * want.abs().max().item())

@@ -357,8 +357,10 @@ __global__ __launch_bounds__(NT) void iic_core_kernel(float *P0, int C, float la
 // inputs: z, r2, f, inv, G = (E + E^T) f, dP0 (scaled by w_iic), W3;  outputs: dlogits [m,C], dlat [m,64]
 __global__ __launch_bounds__(256) void head_bwd_kernel(const float *z, const float *r2, const float *f, const float *inv,
                                                        const float *G, int g_parts, const float *dP0, const float *W3, int m, int C,
-                                                       int train, float nce_coef, float *dlogits, float *dlat)
+                                                       int train, float nce_coef, float *dlogits, float *dlat, const float *dzs)
 {
+    // dzs != NULL: dzs = z dP0 ([m, C], one GEMM by the caller -- at n_clusters = 200 the per-row product below is 40 000 FMAs
+    // behind global reads of a 160 KB matrix); row r then takes its partner's row of it.
     __shared__ float shz[4][256];
     __shared__ float shd[4][256];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -367,7 +369,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float *z, const flo
     const int B = m / 2;
     const bool first = row < B;
     const int prow = first ? row + B : row - B;
-    for (int c = lane; c < C; c += 64) shz[w][c] = z[(int64_t)prow * C + c];
+    if (dzs == nullptr) for (int c = lane; c < C; c += 64) shz[w][c] = z[(int64_t)prow * C + c];
     __builtin_amdgcn_wave_barrier();
     // dz[c] = sum_c' zp[c'] dP0[c',c] for both views: dP0 is symmetric (see iic_core_kernel), so view 1's
     // dP0[c,c'] is read as dP0[c',c] -- coalesced across the lanes
@@ -380,8 +382,11 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float *z, const flo
         if (c < C) {
             zc[t] = z[(int64_t)row * C + c];
             float acc = 0.f;
+            if (dzs != nullptr) acc = dzs[(int64_t)prow * C + c];
+            else {
 #pragma unroll 4
-            for (int k = 0; k < C; ++k) acc = fmaf(shz[w][k], dP0[k * C + c], acc);
+                for (int k = 0; k < C; ++k) acc = fmaf(shz[w][k], dP0[k * C + c], acc);
+            }
             dz[t] = acc;
             dot += acc * zc[t];
         }
@@ -980,7 +985,19 @@ int idl_head_bwd(const float *z, const float *r2, const float *f, const float *i
     IDL_REQUIRE(z && r2 && f && inv && G && dP0 && W3 && dlogits && dlat, "NULL buffer");
     IDL_REQUIRE(m >= 2 && (m % 2) == 0 && C >= 1 && C <= 64 * MAX_CPL, "head_bwd: even m, n_clusters in 1..256");
     hipLaunchKernelGGL(head_bwd_kernel, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, (hipStream_t)stream, z, r2, f, inv, G, g_parts, dP0, W3, m, C,
-                       train, nce_coef, dlogits, dlat);
+                       train, nce_coef, dlogits, dlat, (const float *)nullptr);
+    IDL_HIP_TRY(hipGetLastError());
+    return IDL_OK;
+}
+
+int idl_head_bwd_dz(const float *z, const float *r2, const float *f, const float *inv, const float *G, int g_parts, const float *dzs,
+                    const float *W3, int m, int C, int train, float nce_coef, float *dlogits, float *dlat, void *stream)
+{
+    IDL_REQUIRE(g_parts >= 1 && g_parts <= 16, "head_bwd_dz: g_parts outside 1..16");
+    IDL_REQUIRE(z && r2 && f && inv && G && dzs && W3 && dlogits && dlat, "NULL buffer");
+    IDL_REQUIRE(m >= 2 && (m % 2) == 0 && C >= 1 && C <= 64 * MAX_CPL, "head_bwd_dz: even m, n_clusters in 1..256");
+    hipLaunchKernelGGL(head_bwd_kernel, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, (hipStream_t)stream, z, r2, f, inv, G, g_parts,
+                       (const float *)nullptr, W3, m, C, train, nce_coef, dlogits, dlat, dzs);
     IDL_HIP_TRY(hipGetLastError());
     return IDL_OK;
 }

@@ -60,6 +60,7 @@ class _Buffers:
         self.P0 = torch.empty((C, C), **f32)
         self.iic_scratch = torch.empty((C * C + 2 * C,), **f32)
         self.dlogits = torch.empty((m, C), **f32)
+        self.dzs = torch.empty((m, C), **f32) if C > 64 else None       # z dP0 (fine-grained mode)
         self.dlat = torch.empty((m, H2), **f32)
         self.dr1 = torch.empty((m, H1), **f32)
 
@@ -211,8 +212,13 @@ class FusedLinearTrainer:
             if not (self._dw2_inlaunch and next_from is not None):
                 torch.mm(bf.dlat.t(), bf.r1, out=gW2)
         else:
-            chk(_L.idl_head_bwd(_p(bf.z), _p(bf.r2), _p(bf.f), _p(bf.inv), _p(bf.G), bf.G.shape[0], _p(bf.P0), _p(self.W3), m, C, tr,
-                                nce_coef, _p(bf.dlogits), _p(bf.dlat), _stream()))
+            if C > 64:      # fine-grained mode: z_partner dP0 for all rows as one GEMM instead of 40 000 FMAs per row inside the kernel
+                torch.mm(bf.z, bf.P0, out=bf.dzs)
+                chk(_L.idl_head_bwd_dz(_p(bf.z), _p(bf.r2), _p(bf.f), _p(bf.inv), _p(bf.G), bf.G.shape[0], _p(bf.dzs), _p(self.W3), m, C, tr,
+                                       nce_coef, _p(bf.dlogits), _p(bf.dlat), _stream()))
+            else:
+                chk(_L.idl_head_bwd(_p(bf.z), _p(bf.r2), _p(bf.f), _p(bf.inv), _p(bf.G), bf.G.shape[0], _p(bf.P0), _p(self.W3), m, C, tr,
+                                    nce_coef, _p(bf.dlogits), _p(bf.dlat), _stream()))
             # ---- parameter gradients (one launch for the three bias gradients + the ReLU/Dropout backward of layer 1)
             side.wait_stream(main)
             with torch.cuda.stream(side):

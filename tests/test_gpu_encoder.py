@@ -618,3 +618,29 @@ def test_iic_core_large_joint_vs_torch(dev, C):
     assert abs(out[3].item() - loss.item()) <= 1e-4 * abs(loss.item())
     want = 0.25 * P0.grad
     assert torch.allclose(buf, want, rtol=2e-3, atol=2e-4 * want.abs().max().item())
+
+
+def test_head_bwd_with_precomputed_product(dev):
+    """idl_head_bwd_dz (z dP0 as one GEMM by the caller, fine-grained mode) == idl_head_bwd with the per-row product inside."""
+    import torch
+    from idelucs_amd import _lib
+    from idelucs_amd.fused import _p, _stream
+    L = _lib.lib
+    torch.manual_seed(2)
+    m, C, gp = 256, 200, L.idl_nce_fused_parts()
+    z = torch.softmax(torch.randn(m, C, device=dev), 1)
+    lat = torch.randn(m, 64, device=dev); nrm = lat.norm(dim=1); f = lat / nrm[:, None]; inv = 1.0 / nrm
+    r2 = torch.relu(torch.randn(m, 64, device=dev)); G = torch.randn(gp, m, 64, device=dev) * 0.3
+    dP0 = torch.randn(C, C, device=dev) * 0.1; dP0 = (dP0 + dP0.t()).contiguous()
+    W3 = torch.randn(C, 64, device=dev) * 0.2
+    res = []
+    for pre in (False, True):
+        dlg = torch.empty(m, C, device=dev); dlat = torch.empty(m, 64, device=dev)
+        if pre:
+            dzs = z @ dP0
+            _lib.check(L.idl_head_bwd_dz(_p(z), _p(r2), _p(f), _p(inv), _p(G), gp, _p(dzs), _p(W3), m, C, 1, 1e-3, _p(dlg), _p(dlat), _stream()))
+        else:
+            _lib.check(L.idl_head_bwd(_p(z), _p(r2), _p(f), _p(inv), _p(G), gp, _p(dP0), _p(W3), m, C, 1, 1e-3, _p(dlg), _p(dlat), _stream()))
+        torch.cuda.synchronize()
+        res.append((dlg, dlat))
+    assert torch.allclose(res[0][0], res[1][0], rtol=1e-4, atol=1e-7) and torch.allclose(res[0][1], res[1][1], rtol=1e-4, atol=1e-7)

@@ -920,12 +920,12 @@ int idl_mid_fwd_gather(float *a1, const float *b1, int a1_transposed, const floa
                        int C, int train, uint64_t seed, const int64_t *ctl, float *f, float *inv, float *r2, float *z,
                        const float *feats, int64_t n, int64_t fdim, int64_t view_stride, const int64_t *pair_idx, const int64_t *base,
                        int64_t base_add, int64_t n_pairs, int64_t batch, const double *mean, const double *scale,
-                       const double *inv_scale, float *y, int part, int parts, void *stream)
+                       const double *inv_scale, float *y, int part, int part_end, int parts, void *stream)
 {
     IDL_REQUIRE(a1 && W2 && b2 && W3 && b3 && ctl && f && inv && r2 && z, "NULL buffer");
     IDL_REQUIRE(m >= 16 && (m % 16) == 0 && C >= 1 && C <= 64 * MAX_CPL, "mid_fwd: m must be a multiple of 16, n_clusters in 1..256");
     IDL_REQUIRE((((uintptr_t)a1 | (uintptr_t)W2 | (uintptr_t)W3) & 15u) == 0, "a1 / W2 / W3 must be 16-byte aligned");
-    IDL_REQUIRE(parts >= 1 && part >= 0 && part < parts, "mid_fwd_gather: part outside [0, parts)");
+    IDL_REQUIRE(parts >= 1 && part >= 0 && part <= part_end && part_end <= parts, "mid_fwd_gather: need 0 <= part <= part_end <= parts");
     IDL_REQUIRE(b1 == nullptr || (((uintptr_t)b1) & 15u) == 0, "mid_fwd_gather: b1 must be 16-byte aligned");
     idl_dev::GatherArgs g{};
     int64_t t0 = 0, t1 = 0;
@@ -934,7 +934,7 @@ int idl_mid_fwd_gather(float *a1, const float *b1, int a1_transposed, const floa
                     "mid_fwd_gather: bad gather arguments (4 | f)");
         g = idl_dev::GatherArgs{feats, n, fdim, view_stride, pair_idx, base, batch, n_pairs, mean, scale, inv_scale, y, base_add};
         const int64_t ng = idl_dev::gather_tiles<MID_GATHER_ROWS>(fdim, batch);
-        t0 = ng * part / parts; t1 = ng * (part + 1) / parts;
+        t0 = ng * part / parts; t1 = ng * part_end / parts;
     }
     const dim3 grid((unsigned)(m / 16 + (t1 - t0 + 3) / 4));
     if (a1_transposed) hipLaunchKernelGGL(mid_fwd_kernel<true>, grid, dim3(64 * MID_WAVES), 0, (hipStream_t)stream, a1, b1, W2, b2, W3, b3,
@@ -1026,9 +1026,9 @@ int idl_mid_bwd_gather(const float *z, const float *r2, const float *f, const fl
                        float *dlat, float *dr1, float *partial1, float *partial2, float *partial3, float *dW3_partial,
                        const float *feats, int64_t n, int64_t fdim, int64_t view_stride, const int64_t *pair_idx, const int64_t *base,
                        int64_t base_add, int64_t n_pairs, int64_t batch, const double *mean, const double *scale,
-                       const double *inv_scale, float *y, int part, int parts, int act1_transposed, void *stream)
+                       const double *inv_scale, float *y, int part, int part_end, int parts, int act1_transposed, void *stream)
 {
-    IDL_REQUIRE(parts >= 1 && part >= 0 && part < parts, "mid_bwd_gather: part outside [0, parts)");
+    IDL_REQUIRE(parts >= 1 && part >= 0 && part <= part_end && part_end <= parts, "mid_bwd_gather: need 0 <= part <= part_end <= parts");
     IDL_REQUIRE(g_parts >= 1 && g_parts <= 16, "mid_bwd: g_parts outside 1..16");
     IDL_REQUIRE(z && r2 && f && inv && G && dP0 && W3 && W2 && act1 && dlogits && dlat && dr1 && partial1 && partial2 && partial3, "NULL buffer");
     IDL_REQUIRE(m >= 2 && (m % 2) == 0 && C >= 1 && C <= 64 * MAX_CPL, "mid_bwd: even m, n_clusters in 1..256");
@@ -1045,7 +1045,7 @@ int idl_mid_bwd_gather(const float *z, const float *r2, const float *f, const fl
                     "mid_bwd_gather: bad gather arguments (4 | f)");
         g = idl_dev::GatherArgs{feats, n, fdim, view_stride, pair_idx, base, batch, n_pairs, mean, scale, inv_scale, y, base_add};
         const int64_t ng = idl_dev::gather_tiles<MID_GATHER_ROWS>(fdim, batch);
-        t0 = ng * part / parts; t1 = ng * (part + 1) / parts;
+        t0 = ng * part / parts; t1 = ng * part_end / parts;
     }
     hipLaunchKernelGGL(mid_bwd_kernel, dim3((unsigned)(COL_PARTS + (t1 - t0 + 3) / 4)), dim3(64 * MID_WAVES), 0, (hipStream_t)stream, a, (int)t0,
                        (int)t1, g);

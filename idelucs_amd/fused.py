@@ -103,6 +103,7 @@ class FusedLinearTrainer:
         self._early_gather = (self._pipeline and self._mid_fused and self.C <= 48 and self.F % 4 == 0
                               and os.environ.get("IDELUCS_EARLY_GATHER", "1") != "0")
         self._early_split = os.environ.get("IDELUCS_EARLY_GATHER", "1") != "2"       # 2: all of it in the mid-backward launch
+        self._gsplit = min(max(int(os.environ.get("IDELUCS_GATHER_SPLIT", "4")), 0), 8)   # eighths of the tiles the mid-forward launch takes
         # layer-1 activations kept transposed ([512, m]) between the layer-1 product and its consumers
         self._transposed_l1 = os.environ.get("IDELUCS_TRANSPOSED_L1", "1") != "0"
         self._joint_inlaunch = os.environ.get("IDELUCS_JOINT_INLAUNCH", "1") != "0"   # IIC joint inside the InfoNCE pass-1 launch
@@ -156,7 +157,7 @@ class FusedLinearTrainer:
                                       m, C, tr, self.seed, _p(self.ctl),
                                       _p(bf.f), _p(bf.inv), _p(bf.r2), _p(bf.z),
                                       _p(st.feats), st.n, st.f, st.n * st.f, _p(self._perm), _p(self.ctl[1:]), m // 2, st.n_pairs, m // 2,
-                                      _p(st.mean), _p(st.scale), _p(st.inv_scale), _p(bf.xs[1 - xi]), 0, 2, _stream()))
+                                      _p(st.mean), _p(st.scale), _p(st.inv_scale), _p(bf.xs[1 - xi]), 0, self._gsplit, 8, _stream()))
         elif self._mid_fused and m % 16 == 0:   # ReLU/Dropout + Linear(512,64) + head in one MFMA kernel
             chk(_L.idl_mid_fwd(_p(bf.r1), _p(self.W2), _p(self.b2), _p(self.W3), _p(self.b3), m, C, tr, self.seed, _p(self.ctl),
                                _p(bf.f), _p(bf.inv), _p(bf.r2), _p(bf.z), _stream()))
@@ -196,8 +197,8 @@ class FusedLinearTrainer:
                                       _p(bf.r1), m, C, tr, nce_coef, _p(bf.dlogits), _p(bf.dlat), _p(bf.dr1), _p(gb1), _p(gb2), _p(gb3),
                                       _p(gW3) if self._dw3_partial else None,
                                       _p(st.feats), st.n, st.f, st.n * st.f, _p(self._perm), _p(self.ctl[1:]), m // 2, st.n_pairs, m // 2,
-                                      _p(st.mean), _p(st.scale), _p(st.inv_scale), _p(bf.xs[1 - xi]), 1 if self._early_split else 0,
-                                      2 if self._early_split else 1, 1 if tl else 0, _stream()))
+                                      _p(st.mean), _p(st.scale), _p(st.inv_scale), _p(bf.xs[1 - xi]), self._gsplit if self._early_split else 0,
+                                      8, 8, 1 if tl else 0, _stream()))
             if not self._dw3_partial:
                 torch.mm(bf.dlogits.t(), bf.r2, out=gW3)
             if not self._dw2_inlaunch:

@@ -492,7 +492,7 @@ def test_transposed_layer1_activations(dev, m, C, train):
         f = torch.empty(m, 64, device=dev); inv = torch.empty(m, device=dev); r2 = torch.empty(m, 64, device=dev); z = torch.empty(m, C, device=dev)
         if tr_:
             _lib.check(L.idl_mid_fwd_gather(_p(buf), _p(b1), 1, _p(W2), _p(b2), _p(W3), _p(b3), m, C, train, 9, _p(ctl), _p(f), _p(inv), _p(r2), _p(z),
-                                            None, 0, 0, 0, None, None, 0, 0, 0, None, None, None, None, 0, 1, _stream()))
+                                            None, 0, 0, 0, None, None, 0, 0, 0, None, None, None, None, 0, 1, 1, _stream()))
         else:
             _lib.check(L.idl_mid_fwd(_p(buf), _p(W2), _p(b2), _p(W3), _p(b3), m, C, train, 9, _p(ctl), _p(f), _p(inv), _p(r2), _p(z), _stream()))
         torch.cuda.synchronize()
@@ -513,7 +513,7 @@ def test_transposed_layer1_activations(dev, m, C, train):
         if tr_:
             _lib.check(L.idl_mid_bwd_gather(_p(z), _p(r2), _p(f), _p(inv), _p(G), gp, _p(dP0), _p(W3), _p(W2), _p(act), m, C, train, 1e-3,
                                             _p(dlg), _p(dlat), _p(dr1), _p(p1), _p(p2), _p(p3), _p(w3),
-                                            None, 0, 0, 0, None, None, 0, 0, 0, None, None, None, None, 0, 1, 1, _stream()))
+                                            None, 0, 0, 0, None, None, 0, 0, 0, None, None, None, None, 0, 1, 1, 1, _stream()))
         else:
             _lib.check(L.idl_mid_bwd(_p(z), _p(r2), _p(f), _p(inv), _p(G), gp, _p(dP0), _p(W3), _p(W2), _p(act), m, C, train, 1e-3,
                                      _p(dlg), _p(dlat), _p(dr1), _p(p1), _p(p2), _p(p3), _p(w3), None, 0, _stream()))

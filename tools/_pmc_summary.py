@@ -9,5 +9,5 @@ for r in csv.DictReader(open(f)):
     key = (r['Dispatch_Id'], k)
     if key not in seen: seen.add(key); calls[k] += 1
 out = {k: dict(calls=calls[k], **{c: v for c, v in acc[k].items()}) for k in acc}
-top = sorted(out.items(), key=lambda kv: -kv[1].get('GRBM_GUI_ACTIVE', 0))[:12]
+top = sorted(out.items(), key=lambda kv: -(kv[1].get('GRBM_GUI_ACTIVE', 0) + kv[1].get('SQ_WAVE_CYCLES', 0)))[:14]
 print(json.dumps(dict(top), indent=1))

@@ -644,3 +644,41 @@ def test_head_bwd_with_precomputed_product(dev):
         torch.cuda.synchronize()
         res.append((dlg, dlat))
     assert torch.allclose(res[0][0], res[1][0], rtol=1e-4, atol=1e-7) and torch.allclose(res[0][1], res[1][1], rtol=1e-4, atol=1e-7)
+
+
+def test_opt_in_step_variants_agree_with_the_default(dev):
+    """The opt-in / fallback ways of running the step (own dW1 kernel with fused RMSprop, batch assembly in the optimizer launch,
+    row-major layer-1 activations, dW2 and the IIC joint as GEMM launches) train to the same parameters as the default launch
+    sequence -- same batches, same dropout streams; only the summation orders inside the products differ."""
+    import copy
+    import torch
+    from idelucs_amd import utils as U, models
+    from idelucs_amd.PytorchUtils import NetLinear
+    from idelucs_amd.fused import FusedLinearTrainer
+    torch.manual_seed(5)
+    P, n, F, B = 4, 1400, 256, 64            # m = 128: supported by idl_wgrad_rmsprop
+    feats = (torch.rand((P, n, F), device=dev) * 1e-2).contiguous()
+    mean, scale = U.col_stats(feats[0])
+    store = U.FeatureStore(None, None, feats, mean, scale, 4, False)
+    net0 = NetLinear(F, 6).to(dev); net0.apply(models.weights_init)
+
+    def run(**flags):
+        net = copy.deepcopy(net0)
+        tr = FusedLinearTrainer(net, lr=1e-3, weight=0.25, lamb=2.8, seed=11)
+        for k, v in flags.items():
+            assert hasattr(tr, k), k
+            setattr(tr, k, v)
+        gen = torch.Generator(device=dev); gen.manual_seed(77)
+        total, nb = tr.run_epoch(store, B, generator=gen)
+        torch.cuda.synchronize()
+        return [p.detach().clone() for p in tr.params], total.item()
+
+    ref_p, ref_l = run()
+    for flags in (dict(_wgrad_fused=True), dict(_early_gather=False), dict(_transposed_l1=False), dict(_dw2_inlaunch=False, _early_gather=False),
+                  dict(_joint_inlaunch=False), dict(_pipeline=False, _early_gather=False)):
+        p, l = run(**flags)
+        assert abs(l - ref_l) <= 2e-3 * abs(ref_l), (flags, l, ref_l)
+        for a, b in zip(p, ref_p):
+            # (RMSprop's first steps are sign-like, lr * g / (0.1 |g| + eps): rounding noise on a near-zero gradient moves a weight by
+            #  up to ~lr * 10, so the trajectories agree to a few 1e-3 absolute, not to rounding)
+            assert (a - b).abs().max().item() <= 5e-3 and (a - b).abs().mean().item() <= 2e-4, flags

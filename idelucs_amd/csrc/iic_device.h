@@ -275,3 +275,60 @@ __device__ __forceinline__ void iic_core_lds(float *P0, int C, float lamb, float
     for (int i = t; i < n; i += NT) P0[i] = w_iic * (L[i] - gp) / s;      // (each thread re-reads only what it wrote)
 }
 
+// ---------------------------------------------------------------- the C <= 48 core, from a read-only joint into LDS
+// For the fused InfoNCE-pass-2 + middle-backward kernel: every one of its workgroups needs w_iic * dIIC/dP0, and recomputing the
+// 400..2304-element core per workgroup is cheaper than a launch boundary.  P0: the joint in memory (not modified); Pl (C * C floats
+// of LDS) receives the gradient; Ps: C * C floats of LDS scratch; out (may be NULL): out[3] = IIC.  Ends with a barrier.
+template <int NT>
+__device__ __forceinline__ void iic_core_to_lds(const float *P0, int C, float lamb, float eps, float w_iic, float *out, float *Pl, float *Ps)
+{
+    constexpr int NW = NT / 64;
+    __shared__ float rs[IIC_SMALL_C], ar[IIC_SMALL_C];
+    __shared__ double red[2][NW];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6, n = C * C;
+    double acc = 0.0;
+    for (int i = t; i < n; i += NT) { const float p = P0[i]; Pl[i] = p; acc += (double)p; }
+    acc = idl_dev::wave_sum_d(acc);
+    if (lane == 0) red[0][wv] = acc;
+    __syncthreads();
+    double st = 0.0;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) st += red[0][i];
+    const float s = (float)st;
+    for (int i = t; i < n; i += NT) {
+        const int r = i / C, c = i - r * C;
+        Ps[i] = ((Pl[i] + Pl[c * C + r]) * 0.5f) / s;
+    }
+    __syncthreads();
+    for (int r = wv; r < C; r += NW) {          // one wave per row
+        const float p = lane < C ? Ps[r * C + lane] : 0.f;
+        const float a = idl_dev::wave_sum_f(p), b = idl_dev::wave_sum_f(lane < C ? fmaxf(p, eps) : 0.f);
+        if (lane == 0) { rs[r] = a; ar[r] = b; }
+    }
+    __syncthreads();
+    double lacc = 0.0, gacc = 0.0;
+    for (int i = t; i < n; i += NT) {
+        const int r = i / C, c = i - r * C;
+        const float pu = Ps[i], p = fmaxf(pu, eps);
+        const float piu = rs[r], pi = fmaxf(piu, eps), pju = rs[c], pj = fmaxf(pju, eps);
+        const float lg = __logf(p) - lamb * __logf(pj) - lamb * __logf(pi);
+        lacc += (double)(-p * lg);
+        float g = 0.f;
+        if (!(pu < eps)) g += -lg - 1.f;
+        if (!(piu < eps)) g += lamb * ar[r] / pi;
+        if (!(pju < eps)) g += lamb * ar[c] / pj;
+        Pl[i] = g;
+        gacc += (double)g * (double)pu;
+    }
+    lacc = idl_dev::wave_sum_d(lacc); gacc = idl_dev::wave_sum_d(gacc);
+    if (lane == 0) { red[0][wv] = lacc; red[1][wv] = gacc; }
+    __syncthreads();
+    double l1 = 0.0, g1 = 0.0;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) { l1 += red[0][i]; g1 += red[1][i]; }
+    const float gp = (float)g1;
+    if (out != nullptr && t == 0) out[3] = (float)l1;
+    for (int i = t; i < n; i += NT) Pl[i] = w_iic * (Pl[i] - gp) / s;
+    __syncthreads();
+}
+

@@ -18,34 +18,17 @@
 // product), which MFMA permits because it only sums over k.
 #include "common.h"
 #include "iic_device.h"
+#include "nce_device.h"
 
 namespace {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int NCE_SPLIT = 8;     // column quarters -> (m/16) * 4 workgroups
 constexpr int NCE_MAX_M = 2048;  // rows (2 * batch) whose lse fit the LDS table
 
 
-// S'[j][r] tile: rows j = j0..j0+15 (A operand), columns r = r0..r0+15 (B operand, preloaded in rb[])
-__device__ __forceinline__ f32x4 sim_tile(const float *f, int j0, const float (&rb)[16], int l, int q)
-{
-    const float4 *src = (const float4 *)(f + (int64_t)(j0 + l) * 64 + 16 * q);
-    const float4 a0 = src[0], a1 = src[1], a2 = src[2], a3 = src[3];
-    const float a[16] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x, a2.y, a2.z, a2.w, a3.x, a3.y, a3.z, a3.w};
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int ks = 0; ks < 16; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks], rb[ks], acc, 0, 0, 0);
-    return acc;
-}
-
-__device__ __forceinline__ void load_rows(const float *f, int r0, int l, int q, float (&rb)[16])
-{
-    const float4 *src = (const float4 *)(f + (int64_t)(r0 + l) * 64 + 16 * q);
-    const float4 b0 = src[0], b1 = src[1], b2 = src[2], b3 = src[3];
-    rb[0] = b0.x; rb[1] = b0.y; rb[2] = b0.z; rb[3] = b0.w; rb[4] = b1.x; rb[5] = b1.y; rb[6] = b1.z; rb[7] = b1.w;
-    rb[8] = b2.x; rb[9] = b2.y; rb[10] = b2.z; rb[11] = b2.w; rb[12] = b3.x; rb[13] = b3.y; rb[14] = b3.z; rb[15] = b3.w;
-}
+using nce_dev::f32x4;
+using nce_dev::sim_tile;
+using nce_dev::load_rows;
 
 // The IIC core is a single-workgroup computation that is independent of the InfoNCE branch: when asked (P0 != NULL) it
 // rides along as ONE extra workgroup (blockIdx.x == m/16, blockIdx.y == 0) of pass 1 instead of a launch of its own.
@@ -227,6 +210,19 @@ int idl_nce_fused_iic(const float *f, int m, float temperature, float *lse, floa
 {
     IDL_REQUIRE(P0 && iic_scratch && out && C >= 1 && C <= 48, "nce_fused_iic: n_clusters must be in 1..48 (larger: idl_iic_core)");
     return nce_launch(f, m, temperature, lse, loss_rows, G_part, workspace, IicJob{P0, C, lamb, eps, w_iic, iic_scratch, out, nullptr}, stream);
+}
+
+int idl_nce_pass1_joint(const float *f, int m, float temperature, void *workspace, const float *z, float *P0, int C, void *stream)
+{
+    IDL_REQUIRE(f && workspace && z && P0 && C >= 1 && C <= 48, "nce_pass1_joint: NULL buffer or n_clusters outside 1..48");
+    IDL_REQUIRE(m >= 32 && (m % 32) == 0 && m <= NCE_MAX_M && temperature > 0.f, "nce_pass1_joint: m must be a multiple of 32 in 32..2048, T > 0");
+    IDL_REQUIRE((((uintptr_t)f) & 15u) == 0, "f must be 16-byte aligned");
+    float *rowsum_part = (float *)workspace, *pos = rowsum_part + (size_t)NCE_SPLIT * m;
+    const dim3 grid1((unsigned)(m / 16 + 1), NCE_SPLIT);
+    hipLaunchKernelGGL(nce_pass1_kernel, grid1, dim3(256), 0, (hipStream_t)stream, f, m, 1.f / temperature, rowsum_part, pos,
+                       IicJob{P0, C, 0.f, 0.f, 0.f, nullptr, nullptr, z});
+    IDL_HIP_TRY(hipGetLastError());
+    return IDL_OK;
 }
 
 int idl_nce_fused_iic_z(const float *f, int m, float temperature, float *lse, float *loss_rows, float *G_part, void *workspace,

@@ -21,6 +21,7 @@
 // shuffled pair list.
 #include "common.h"
 #include "iic_device.h"
+#include "nce_device.h"
 #include "scaler_device.h"
 #include "wave_ops.h"
 
@@ -504,13 +505,25 @@ struct MidBwdArgs {
     int64_t *ctl; int64_t batch_advance;
     int g_parts, m, C, train; float nce_coef;
     int act1_t;               // act1 is stored transposed, [512, m]
+    // fused InfoNCE pass 2 + IIC core (mid_bwd_kernel<true>): pass-1 results, the joint, where lse / loss rows / IIC go
+    const float *rowsum_part, *pos, *P0joint;
+    float *lse, *loss_rows, *out;
+    float inv_t, lamb, eps, w_iic;
+    int nce_split;
 };
 
 // (tile1 > tile0: the workgroups behind the COL_PARTS computing ones assemble tiles [tile0, tile1) of the NEXT batch into a
 // second x buffer, four 256-thread gather tiles of MID_GATHER_ROWS rows each -- this launch leaves three quarters of the CUs idle and is latency-bound, the gather is
 // pure streaming, and nothing in this step reads or writes what it touches.)
+// NCE = true (m == 16 * COL_PARTS, n_clusters <= 48): the launch starts one step earlier in the chain -- it is InfoNCE pass 2 as
+// well.  A workgroup owns 16 rows here exactly as there; with all 16 waves walking the column tiles (four each) the rows' G = (E +
+// E^T) f is complete inside the workgroup (partials added through LDS in a fixed order) and never goes to memory, and the IIC
+// core (400..2304 elements) is recomputed by every workgroup from the joint into LDS instead of being waited for.  One launch
+// boundary and the G / dP0 round trips disappear.
+template <bool NCE>
 __global__ __launch_bounds__(64 * MID_WAVES) void mid_bwd_kernel(MidBwdArgs a, int tile0, int tile1, idl_dev::GatherArgs gth)
 {
+    extern __shared__ float mid_dyn[];        // NCE: Gred[16 waves][16][64] | lse_all[m] | Ps[48 * 48]
     if ((int)blockIdx.x >= COL_PARTS) {
         const int blk = tile0 + ((int)blockIdx.x - COL_PARTS) * 4 + (int)(threadIdx.x >> 8);
         if (blk < tile1) idl_dev::gather_tile<MID_GATHER_ROWS>(gth, (int64_t)blk, (int)(threadIdx.x & 255));
@@ -529,7 +542,7 @@ __global__ __launch_bounds__(64 * MID_WAVES) void mid_bwd_kernel(MidBwdArgs a, i
     const int r1 = (r0 + rows < m) ? r0 + rows : m;
     if (a.ctl != nullptr && blockIdx.x == 0 && tid == 0) a.ctl[1] += a.batch_advance;
     if (small) {
-        for (int i = tid; i < C * C; i += 64 * MID_WAVES) sP[i] = a.dP0[i];
+        if (!NCE) for (int i = tid; i < C * C; i += 64 * MID_WAVES) sP[i] = a.dP0[i];
         for (int i = tid; i < C * H2; i += 64 * MID_WAVES) sW3[i] = a.W3[i];
     }
     // B fragments of this wave's two column tiles: B[k = 16 q + s][c = l] = W2[k][16 ct + l]
@@ -540,6 +553,48 @@ __global__ __launch_bounds__(64 * MID_WAVES) void mid_bwd_kernel(MidBwdArgs a, i
         for (int s = 0; s < 16; ++s) bw[j][s] = a.W2[(int64_t)(16 * q + s) * H1 + 16 * (2 * wv + j) + l];
     const float scale = a.train ? 2.f : 1.f;
     float cs1[2] = {0.f, 0.f}, s23 = 0.f, acc3[3] = {0.f, 0.f, 0.f};
+    float gsum_nce = 0.f;                     // NCE: ((E + E^T) f)[row r0 + wv][lane]
+    if (NCE) {
+        float *Gred = mid_dyn, *lse_all = mid_dyn + MID_WAVES * 16 * H2, *Ps = lse_all + m;
+        float rb[16];
+        nce_dev::load_rows(a.f, r0, l, q, rb);
+        for (int i = tid; i < m; i += 64 * MID_WAVES) {
+            float sm = 0.f;
+            for (int p = 0; p < a.nce_split; ++p) sm += a.rowsum_part[(int64_t)p * m + i];
+            lse_all[i] = __logf(sm);
+        }
+        iic_core_to_lds<64 * MID_WAVES>(a.P0joint, C, a.lamb, a.eps, a.w_iic, blockIdx.x == 0 ? a.out : nullptr, sP, Ps);   // ends with a barrier
+        const int r = r0 + l;
+        const float lse_r = lse_all[r];
+        if (wv == 0 && q == 0) { a.lse[r] = lse_r; a.loss_rows[r] = lse_r - a.pos[r]; }
+        nce_dev::f32x4 g[4];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) g[ct] = nce_dev::f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int tc = wv; tc < m / 16; tc += MID_WAVES) {
+            const int j0 = tc * 16;
+            const nce_dev::f32x4 s = nce_dev::sim_tile(a.f, j0, rb, l, q);
+            float e[4];
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const int j = j0 + 4 * q + gq;
+                const float x = s[gq] * a.inv_t;
+                e[gq] = (j == r) ? 0.f : __expf(x - lse_r) + __expf(x - lse_all[j]);
+            }
+#pragma unroll
+            for (int step = 0; step < 4; ++step) {
+                const float *frow = a.f + (int64_t)(j0 + 4 * q + step) * H2 + l;
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) g[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(e[step], frow[16 * ct], g[ct], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) Gred[(wv * 16 + 4 * q + reg) * H2 + 16 * ct + l] = g[ct][reg];     // C/D: row = 4q + reg, col = l
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < MID_WAVES; ++w) gsum_nce += Gred[(w * 16 + wv) * H2 + lane];      // this thread's own (row wv, column lane)
+    }
     for (int t0 = r0; t0 < r1; t0 += 16) {
         const int nr = (r1 - t0 < 16) ? r1 - t0 : 16;
         // the layer-1 activations this lane masks with in phase 2: requested now, needed after the head backward
@@ -573,7 +628,7 @@ __global__ __launch_bounds__(64 * MID_WAVES) void mid_bwd_kernel(MidBwdArgs a, i
             const float fr = a.f[(int64_t)row * H2 + lane], fp = a.f[(int64_t)prow * H2 + lane];
             float gp[16];
 #pragma unroll
-            for (int pp = 0; pp < 16; ++pp) gp[pp] = pp < a.g_parts ? a.G[((int64_t)pp * m + row) * H2 + lane] : 0.f;
+            for (int pp = 0; pp < 16; ++pp) gp[pp] = (!NCE && pp < a.g_parts) ? a.G[((int64_t)pp * m + row) * H2 + lane] : 0.f;
             const float invr = a.inv[row];
             shz[wv][lane] = zp;
             __builtin_amdgcn_wave_barrier();
@@ -594,6 +649,7 @@ __global__ __launch_bounds__(64 * MID_WAVES) void mid_bwd_kernel(MidBwdArgs a, i
             float gsum = gp[0];
 #pragma unroll
             for (int pp = 1; pp < 16; ++pp) if (pp < a.g_parts) gsum += gp[pp];
+            if (NCE) gsum = gsum_nce;
             const float df = a.nce_coef * (gsum - 2.f * fp);
             const float proj = wave_sum(fr * df);
             const float d = dl_cls + (df - fr * proj) * invr;
@@ -1016,7 +1072,52 @@ int idl_mid_bwd(const float *z, const float *r2, const float *f, const float *in
     a.dlogits = dlogits; a.dlat = dlat; a.dr1 = dr1; a.partial1 = partial1; a.partial2 = partial2; a.partial3 = partial3;
     a.dW3_part = dW3_partial; a.ctl = ctl; a.batch_advance = batch_advance;
     a.g_parts = g_parts; a.m = m; a.C = C; a.train = train; a.nce_coef = nce_coef;
-    hipLaunchKernelGGL(mid_bwd_kernel, dim3(COL_PARTS), dim3(64 * MID_WAVES), 0, (hipStream_t)stream, a, 0, 0, idl_dev::GatherArgs{});
+    hipLaunchKernelGGL(mid_bwd_kernel<false>, dim3(COL_PARTS), dim3(64 * MID_WAVES), 0, (hipStream_t)stream, a, 0, 0, idl_dev::GatherArgs{});
+    IDL_HIP_TRY(hipGetLastError());
+    return IDL_OK;
+}
+
+int idl_nce_mid_bwd_gather(const float *z, const float *r2, const float *f, const float *inv, const void *nce_workspace, int nce_split,
+                           float temperature, const float *P0_joint, float lamb, float eps, float w_iic, float *lse, float *loss_rows,
+                           float *out, const float *W3, const float *W2, const float *act1, int m, int C, int train, float nce_coef,
+                           float *dlogits, float *dlat, float *dr1, float *partial1, float *partial2, float *partial3, float *dW3_partial,
+                           const float *feats, int64_t n, int64_t fdim, int64_t view_stride, const int64_t *pair_idx, const int64_t *base,
+                           int64_t base_add, int64_t n_pairs, int64_t batch, const double *mean, const double *scale,
+                           const double *inv_scale, float *y, int part, int part_end, int parts, int act1_transposed, void *stream)
+{
+    IDL_REQUIRE(parts >= 1 && part >= 0 && part <= part_end && part_end <= parts, "nce_mid_bwd_gather: need 0 <= part <= part_end <= parts");
+    IDL_REQUIRE(z && r2 && f && inv && nce_workspace && P0_joint && lse && loss_rows && out && W3 && W2 && act1 && dlogits && dlat && dr1 &&
+                partial1 && partial2 && partial3, "NULL buffer");
+    IDL_REQUIRE(m == 16 * COL_PARTS && C >= 1 && C <= 48 && nce_split >= 1 && nce_split <= 64 && temperature > 0.f,
+                "nce_mid_bwd_gather: m must be 1024 (16 rows per partial-sum chunk), n_clusters in 1..48");
+    IDL_REQUIRE((((uintptr_t)f) & 15u) == 0, "f must be 16-byte aligned");
+    MidBwdArgs a{};
+    a.z = z; a.r2 = r2; a.f = f; a.inv = inv; a.G = nullptr; a.dP0 = nullptr; a.W3 = W3; a.W2 = W2; a.act1 = act1;
+    a.dlogits = dlogits; a.dlat = dlat; a.dr1 = dr1; a.partial1 = partial1; a.partial2 = partial2; a.partial3 = partial3;
+    a.dW3_part = dW3_partial; a.ctl = nullptr; a.batch_advance = 0;
+    a.g_parts = 1; a.m = m; a.C = C; a.train = train; a.nce_coef = nce_coef; a.act1_t = act1_transposed ? 1 : 0;
+    a.rowsum_part = (const float *)nce_workspace; a.pos = a.rowsum_part + (size_t)nce_split * m; a.P0joint = P0_joint;
+    a.lse = lse; a.loss_rows = loss_rows; a.out = out; a.inv_t = 1.f / temperature; a.lamb = lamb; a.eps = eps; a.w_iic = w_iic;
+    a.nce_split = nce_split;
+    idl_dev::GatherArgs g{};
+    int64_t t0 = 0, t1 = 0;
+    if (feats != nullptr) {
+        IDL_REQUIRE(pair_idx && mean && scale && y && n >= 1 && fdim >= 4 && (fdim & 3) == 0 && batch >= 1 && n_pairs >= 0,
+                    "nce_mid_bwd_gather: bad gather arguments (4 | f)");
+        g = idl_dev::GatherArgs{feats, n, fdim, view_stride, pair_idx, base, batch, n_pairs, mean, scale, inv_scale, y, base_add};
+        const int64_t ng = idl_dev::gather_tiles<MID_GATHER_ROWS>(fdim, batch);
+        t0 = ng * part / parts; t1 = ng * part_end / parts;
+    }
+    const int lds = (MID_WAVES * 16 * H2 + m + 48 * 48) * 4;
+    static bool attr_set[64] = {};
+    int dev = 0;
+    IDL_HIP_TRY(hipGetDevice(&dev));
+    if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+        IDL_HIP_TRY(hipFuncSetAttribute((const void *)mid_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set[dev] = true;
+    }
+    hipLaunchKernelGGL(mid_bwd_kernel<true>, dim3((unsigned)(COL_PARTS + (t1 - t0 + 3) / 4)), dim3(64 * MID_WAVES), lds, (hipStream_t)stream, a, (int)t0,
+                       (int)t1, g);
     IDL_HIP_TRY(hipGetLastError());
     return IDL_OK;
 }
@@ -1047,7 +1148,7 @@ int idl_mid_bwd_gather(const float *z, const float *r2, const float *f, const fl
         const int64_t ng = idl_dev::gather_tiles<MID_GATHER_ROWS>(fdim, batch);
         t0 = ng * part / parts; t1 = ng * part_end / parts;
     }
-    hipLaunchKernelGGL(mid_bwd_kernel, dim3((unsigned)(COL_PARTS + (t1 - t0 + 3) / 4)), dim3(64 * MID_WAVES), 0, (hipStream_t)stream, a, (int)t0,
+    hipLaunchKernelGGL(mid_bwd_kernel<false>, dim3((unsigned)(COL_PARTS + (t1 - t0 + 3) / 4)), dim3(64 * MID_WAVES), 0, (hipStream_t)stream, a, (int)t0,
                        (int)t1, g);
     IDL_HIP_TRY(hipGetLastError());
     return IDL_OK;

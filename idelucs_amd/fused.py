@@ -106,6 +106,9 @@ class FusedLinearTrainer:
         self._gsplit = min(max(int(os.environ.get("IDELUCS_GATHER_SPLIT", "4")), 0), 8)   # eighths of the tiles the mid-forward launch takes
         # layer-1 activations kept transposed ([512, m]) between the layer-1 product and its consumers
         self._transposed_l1 = os.environ.get("IDELUCS_TRANSPOSED_L1", "1") != "0"
+        # opt-in: InfoNCE pass 2 + IIC core inside the mid-backward launch (one boundary less, but the InfoNCE tiles then run on
+        # the 64 CUs of that launch instead of 256: the fused launch takes 32.8 us against 9.5 + 13.5 -- measured +8 us per step)
+        self._nce_bwd_fused = os.environ.get("IDELUCS_NCE_BWD_FUSED", "0") != "0"
         self._joint_inlaunch = os.environ.get("IDELUCS_JOINT_INLAUNCH", "1") != "0"   # IIC joint inside the InfoNCE pass-1 launch
         # opt-in: dW1 on this package's own MFMA kernel with RMSprop in its epilogue (csrc/wgrad.hip; measured a wash against
         # hipBLASLt + the optimizer launch, so off by default)
@@ -167,7 +170,11 @@ class FusedLinearTrainer:
             chk(_L.idl_head_fwd(_p(bf.lat), _p(self.W3), _p(self.b3), m, C, tr, self.seed, _p(self.ctl),
                                 _p(bf.f), _p(bf.inv), _p(bf.r2), _p(bf.z), _stream()))
         # ---- the two losses are independent: with the fused InfoNCE kernels the IIC core rides along as one extra workgroup
-        if bf.nce_fused and C <= 48 and not self._overlap and self._joint_inlaunch:
+        # InfoNCE pass 2 + IIC core inside the mid-backward launch (m = 1024: a workgroup owns the same 16 rows in both)
+        nce_bwd = (early and self._nce_bwd_fused and bf.nce_fused and C <= 48 and m == 1024 and not self._overlap and self._joint_inlaunch)
+        if nce_bwd:
+            chk(_L.idl_nce_pass1_joint(_p(bf.f), m, TEMPERATURE, _p(bf.nce_ws), _p(bf.z), _p(bf.P0), C, _stream()))
+        elif bf.nce_fused and C <= 48 and not self._overlap and self._joint_inlaunch:
             # the IIC workgroup of InfoNCE pass 1 forms the joint z1^T z2 itself (MFMA tiles) before the core
             chk(_L.idl_nce_fused_iic_z(_p(bf.f), m, TEMPERATURE, _p(bf.lse), _p(bf.loss_rows), _p(bf.G), _p(bf.nce_ws), _p(bf.z),
                                        _p(bf.P0), C, self.lamb, EPS, self.weight, _p(bf.iic_scratch), _p(self.out), _stream()))
@@ -191,7 +198,20 @@ class FusedLinearTrainer:
         gW1, gb1, gW2, gb2, gW3, gb3 = self.grads
         adv_ctl = _p(self.ctl) if (next_from is not None and not early) else None
         adv = batch_advance if (next_from is not None and not early) else 0
-        if early:
+        if early and nce_bwd:
+            st = next_from
+            chk(_L.idl_nce_mid_bwd_gather(_p(bf.z), _p(bf.r2), _p(bf.f), _p(bf.inv), _p(bf.nce_ws), bf.nce_parts, TEMPERATURE, _p(bf.P0),
+                                          self.lamb, EPS, self.weight, _p(bf.lse), _p(bf.loss_rows), _p(self.out), _p(self.W3), _p(self.W2),
+                                          _p(bf.r1), m, C, tr, nce_coef, _p(bf.dlogits), _p(bf.dlat), _p(bf.dr1), _p(gb1), _p(gb2), _p(gb3),
+                                          _p(gW3) if self._dw3_partial else None,
+                                          _p(st.feats), st.n, st.f, st.n * st.f, _p(self._perm), _p(self.ctl[1:]), m // 2, st.n_pairs, m // 2,
+                                          _p(st.mean), _p(st.scale), _p(st.inv_scale), _p(bf.xs[1 - xi]),
+                                          self._gsplit if self._early_split else 0, 8, 8, 1 if tl else 0, _stream()))
+            if not self._dw3_partial:
+                torch.mm(bf.dlogits.t(), bf.r2, out=gW3)
+            if not self._dw2_inlaunch:
+                torch.mm(bf.dlat.t(), bf.r1, out=gW2)
+        elif early:
             st = next_from
             chk(_L.idl_mid_bwd_gather(_p(bf.z), _p(bf.r2), _p(bf.f), _p(bf.inv), _p(bf.G), bf.G.shape[0], _p(bf.P0), _p(self.W3), _p(self.W2),
                                       _p(bf.r1), m, C, tr, nce_coef, _p(bf.dlogits), _p(bf.dlat), _p(bf.dr1), _p(gb1), _p(gb2), _p(gb3),

@@ -66,7 +66,7 @@ def main():
     mn, av = timeit(lambda: U._vectorise(din, a.k, _lib.MODE_KMER, _lib.INIT_ZERO, _lib.OUT_COUNTS_I32, 1, None, None, out.view(torch.int32)[:1]), a.reps)
     print(f"vectorise i32 x1 view                 min {mn:8.3f} ms  avg {av:8.3f} ms  -> {a.n * ((a.len + 3) // 4 + F * 4) / mn / 1e6:8.1f} GB/s")
     mn, av = timeit(lambda: U.col_stats(out[0]), a.reps)
-    print(f"col_stats (2 passes over view 0)      min {mn:8.3f} ms  avg {av:8.3f} ms  -> {2 * a.n * F * 4 / mn / 1e6:8.1f} GB/s")
+    print(f"col_stats (one pass over view 0)        min {mn:8.3f} ms  avg {av:8.3f} ms  -> {2 * a.n * F * 4 / mn / 1e6:8.1f} GB/s")
     mean, scale = U.col_stats(out[0])
     st = U.FeatureStore(None, None, out, mean, scale, a.k, False)
     idx = torch.randperm(st.n_pairs, device=dev)[:512]

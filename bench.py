@@ -262,6 +262,7 @@ def main():
         elapsed = t.item()
     # the exchange step of the path (untimed unless --with-predict 1): this rank's voter predicts, assignments are all-gathered
     from idelucs_amd.dist import all_gather_assignments
+    all_gather_assignments(hp.predict())            # first call: library initialisation for the inference GEMM shapes (0.5 s), not the path
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     gathered = all_gather_assignments(hp.predict())

@@ -171,6 +171,149 @@ inline int walk_record(const uint8_t *buf, const Rec &r, int check, Emit &&emit,
     return REC_OK;
 }
 
+
+// ---- eight bases at a time (SWAR): the overwhelmingly common input is runs of upper-case A/C/G/T, for which neither the
+// translate table nor the per-base packer is needed.  Anything else falls back to the byte loop above, so the result is the same.
+inline uint64_t load8(const uint8_t *p) { uint64_t v; memcpy(&v, p, 8); return v; }      // byte 0 = first base (little endian)
+
+inline bool all_acgt8(uint64_t x)
+{
+    auto zero_bytes = [](uint64_t v) { const uint64_t L = 0x7F7F7F7F7F7F7F7FULL; return ~(((v & L) + L) | v | L); };               // exact: 0x80 in every byte of v that is 0
+    const uint64_t hit = zero_bytes(x ^ 0x4141414141414141ULL) | zero_bytes(x ^ 0x4343434343434343ULL) |
+                         zero_bytes(x ^ 0x4747474747474747ULL) | zero_bytes(x ^ 0x5454545454545454ULL);
+    return hit == 0x8080808080808080ULL;
+}
+
+inline uint32_t pack8(uint64_t x)           // 8 valid bases -> 16 bits, first base in the top pair, A0 C1 G2 T3
+{
+    uint64_t c = (x >> 1) & 0x0303030303030303ULL;                    // A0 C1 G3 T2
+    c ^= (c >> 1) & 0x0101010101010101ULL;                            // A0 C1 G2 T3
+    const uint64_t M = (1ull << 30) | (1ull << 20) | (1ull << 10) | 1ull;  // byte i of a 4-byte group -> bit pair 30 - 2 i (no two terms overlap)
+    const uint32_t p0 = (uint32_t)(((uint64_t)(uint32_t)c * M) >> 24) & 0xFFu;
+    const uint32_t p1 = (uint32_t)(((uint64_t)(uint32_t)(c >> 32) * M) >> 24) & 0xFFu;
+    return (p0 << 8) | p1;
+}
+
+// ---- the same with AVX2 where the host has it (runtime dispatch; the SWAR code above is the portable path)
+#if defined(__x86_64__)
+#include <immintrin.h>
+#define IDL_HAVE_AVX2_PATH 1
+inline bool host_has_avx2() { static const bool h = __builtin_cpu_supports("avx2"); return h; }
+
+__attribute__((target("avx2"))) inline bool all_acgt32_avx2(const uint8_t *p)
+{
+    const __m256i v = _mm256_loadu_si256((const __m256i *)p);
+    const __m256i ok = _mm256_or_si256(_mm256_or_si256(_mm256_cmpeq_epi8(v, _mm256_set1_epi8('A')), _mm256_cmpeq_epi8(v, _mm256_set1_epi8('C'))),
+                                       _mm256_or_si256(_mm256_cmpeq_epi8(v, _mm256_set1_epi8('G')), _mm256_cmpeq_epi8(v, _mm256_set1_epi8('T'))));
+    return (uint32_t)_mm256_movemask_epi8(ok) == 0xFFFFFFFFu;
+}
+
+// number of leading 32-byte blocks of [a, b) that are pure upper-case A/C/G/T
+__attribute__((target("avx2"))) inline int64_t acgt_run32_avx2(const uint8_t *a, const uint8_t *b)
+{
+    int64_t k = 0;
+    while (b - a >= 32 && all_acgt32_avx2(a)) { a += 32; ++k; }
+    return k;
+}
+
+// 32 valid bases -> two code words (16 bases each, first base in the top pair, A0 C1 G2 T3)
+__attribute__((target("avx2"))) inline void pack32_avx2(const uint8_t *p, uint32_t *w)
+{
+    const __m256i v = _mm256_loadu_si256((const __m256i *)p);
+    __m256i c = _mm256_and_si256(_mm256_srli_epi16(v, 1), _mm256_set1_epi8(3));                  // A0 C1 G3 T2
+    c = _mm256_xor_si256(c, _mm256_and_si256(_mm256_srli_epi16(c, 1), _mm256_set1_epi8(1)));     // A0 C1 G2 T3
+    const __m256i p2 = _mm256_maddubs_epi16(c, _mm256_set1_epi16(0x0104));      // bytes (b0, b1) -> b0 * 4 + b1 in a 16-bit lane
+    const __m256i p4 = _mm256_madd_epi16(p2, _mm256_set1_epi32(0x00010010));     // 16-bit (q0, q1) -> q0 * 16 + q1 in a 32-bit lane: 4 bases, first on top
+    // the low byte of each 32-bit lane is one packed byte; a word wants its 4 bytes with the FIRST one most significant
+    const __m256i sh = _mm256_setr_epi8(12, 8, 4, 0, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1,
+                                        12, 8, 4, 0, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1);
+    const __m256i g = _mm256_shuffle_epi8(p4, sh);
+    w[0] = (uint32_t)_mm256_extract_epi32(g, 0);
+    w[1] = (uint32_t)_mm256_extract_epi32(g, 4);
+}
+#else
+#define IDL_HAVE_AVX2_PATH 0
+#endif
+
+// walk_record specialised for counting the cleaned length (check mode)
+inline int walk_record_count(const uint8_t *buf, const Rec &r, int64_t *count, uint8_t *bad)
+{
+    const uint8_t *p = buf + r.data_b, *end = buf + r.data_e;
+    int64_t cnt = 0;
+    while (p < end) {
+        const uint8_t *nl = (const uint8_t *)memchr(p, '\n', (size_t)(end - p));
+        const uint8_t *le = nl ? nl + 1 : end;
+        if (*p != '#' && *p != '>') {
+            const uint8_t *a = p, *b = le;
+            while (a < b && py_bytes_space(*a)) ++a;
+            while (b > a && py_bytes_space(b[-1])) --b;
+            while (a < b) {
+#if IDL_HAVE_AVX2_PATH
+                if (b - a >= 32 && host_has_avx2()) { const int64_t k = acgt_run32_avx2(a, b); cnt += 32 * k; a += 32 * k; if (a >= b) break; }
+#endif
+                if (b - a >= 8 && all_acgt8(load8(a))) { cnt += 8; a += 8; continue; }
+                const uint8_t *stop = (b - a >= 8) ? a + 8 : b;
+                for (; a < stop; ++a) {
+                    const uint8_t t = T.translate[*a];
+                    if (t == 0) continue;
+                    if (t == 1) { *bad = *a; return REC_BAD_BASE; }
+                    ++cnt;
+                }
+            }
+        }
+        p = le;
+    }
+    *count = cnt;
+    return REC_OK;
+}
+
+// walk_record specialised for packing (check mode; bdst may be NULL): whole 16-base words straight from two 8-byte loads
+inline void walk_record_pack(const uint8_t *buf, const Rec &r, Packer &pk, uint8_t *&bdst)
+{
+    const uint8_t *p = buf + r.data_b, *end = buf + r.data_e;
+    while (p < end) {
+        const uint8_t *nl = (const uint8_t *)memchr(p, '\n', (size_t)(end - p));
+        const uint8_t *le = nl ? nl + 1 : end;
+        if (*p != '#' && *p != '>') {
+            const uint8_t *a = p, *b = le;
+            while (a < b && py_bytes_space(*a)) ++a;
+            while (b > a && py_bytes_space(b[-1])) --b;
+            while (a < b) {
+#if IDL_HAVE_AVX2_PATH
+                if (pk.j == 0 && b - a >= 32 && host_has_avx2()) {
+                    while (b - a >= 32 && all_acgt32_avx2(a)) {
+                        uint32_t w2[2];
+                        pack32_avx2(a, w2);
+                        pk.c = w2[0]; pk.m = 0; pk.j = 16; pk.flush_word();
+                        pk.c = w2[1]; pk.m = 0; pk.j = 16; pk.flush_word();
+                        if (bdst) { memcpy(bdst, a, 32); bdst += 32; }
+                        a += 32;
+                    }
+                    if (a >= b) break;
+                }
+#endif
+                if (pk.j == 0 && b - a >= 16) {
+                    const uint64_t x0 = load8(a), x1 = load8(a + 8);
+                    if (all_acgt8(x0) && all_acgt8(x1)) {
+                        pk.c = (pack8(x0) << 16) | pack8(x1); pk.m = 0; pk.j = 16; pk.flush_word();
+                        if (bdst) { memcpy(bdst, a, 16); bdst += 16; }
+                        a += 16;
+                        continue;
+                    }
+                }
+                const uint8_t *stop = (pk.j == 0 && b - a >= 16) ? a + 16 : ((b - a) > (16 - pk.j) ? a + (16 - pk.j) : b);
+                for (; a < stop; ++a) {
+                    const uint8_t t = T.translate[*a];
+                    if (t == 0 || t == 1) continue;          // (bad bytes were rejected when the file was opened)
+                    if (bdst) *bdst++ = t;
+                    pk.push(T.code[t]);
+                }
+            }
+        }
+        p = le;
+    }
+}
+
 }  // namespace
 
 struct FileMap {                  // read-only view of the whole file (mmap; empty files map to nothing)
@@ -320,7 +463,8 @@ int idl_fasta_open(const char *path, int check, idl_fasta **out)
             }
             if (kind == REC_OK) {
                 int64_t cnt = 0;
-                kind = walk_record(buf, r, check, [&](uint8_t) { ++cnt; }, &bb);
+                if (check) kind = walk_record_count(buf, r, &cnt, &bb);
+                else kind = walk_record(buf, r, check, [&](uint8_t) { ++cnt; }, &bb);
                 r.len = cnt;
             }
             if (kind != REC_OK) { first_bad[(size_t)t] = i; bad_kind[(size_t)t] = kind; bad_byte[(size_t)t] = bb; break; }
@@ -396,7 +540,8 @@ int idl_fasta_export(const idl_fasta *f, uint8_t *names, int64_t *name_off, int6
             uint8_t *bdst = bytes ? bytes + boff[(size_t)i] : nullptr;
             if (codes) {
                 Packer pk{(uint32_t *)(codes + soff[(size_t)i] * 16), (uint32_t *)(mask + soff[(size_t)i] * 8)};
-                if (bdst) (void)walk_record(buf, r, f->check, [&](uint8_t c) { *bdst++ = c; pk.push(T.code[c]); }, &bb);
+                if (f->check) walk_record_pack(buf, r, pk, bdst);
+                else if (bdst) (void)walk_record(buf, r, f->check, [&](uint8_t c) { *bdst++ = c; pk.push(T.code[c]); }, &bb);
                 else (void)walk_record(buf, r, f->check, [&](uint8_t c) { pk.push(T.code[c]); }, &bb);
                 pk.finish((r.len + 63) / 64);
             } else {

@@ -187,6 +187,35 @@ def test_threaded_reader_equals_oracle(tmp_path, monkeypatch, threads):
             assert np.array_equal(ff.codes[a * 16:b * 16], codes) and np.array_equal(ff.mask[a * 8:b * 8], mask), i
 
 
+@pytest.mark.parametrize("width", [0, 70, 33, 16])
+def test_reader_fast_paths_equal_oracle(tmp_path, width):
+    """Long runs of upper-case A/C/G/T take the 32-base (AVX2) / 8-base (SWAR) paths of the reader; mixed with N runs, lower case,
+    IUPAC codes and gaps at every alignment they must give exactly the bytes, lengths, codes and masks of the byte-wise walk."""
+    rng = np.random.default_rng(100 + width)
+    p = str(tmp_path / "fast.fas")
+    with open(p, "wb") as f:
+        for r in range(40):
+            L = int(rng.integers(0, 4000))
+            s = rng.choice(np.frombuffer(b"ACGT", np.uint8), size=L)
+            for _ in range(int(rng.integers(0, 6))):             # sprinkle short exceptional stretches at random offsets
+                if L == 0: break
+                a = int(rng.integers(0, L)); n_ = int(rng.integers(1, 40))
+                s[a:a + n_] = rng.choice(np.frombuffer(b"NnacgtRYK-u", np.uint8), size=len(s[a:a + n_]))
+            f.write(b">r%d\n" % r)
+            raw = s.tobytes()
+            if width == 0: f.write(raw + b"\n")
+            else:
+                for a in range(0, len(raw), width): f.write(raw[a:a + width] + b"\n")
+    ff = U.FastaFile(p, check=True, keep_bytes=True)
+    recs = list(O.fasta_records(p, check=True))
+    assert ff.lengths.tolist() == [len(r[1]) for r in recs]
+    assert [bytes(ff.record(i)) for i in range(ff.n)] == [bytes(r[1]) for r in recs]
+    for i, (_, s) in enumerate(recs):
+        codes, mask = O.pack(s)
+        a, b = ff.slot_off[i], ff.slot_off[i + 1]
+        assert np.array_equal(ff.codes[a * 16:b * 16], codes) and np.array_equal(ff.mask[a * 8:b * 8], mask), i
+
+
 @pytest.mark.parametrize("content", [
     b"ACGT\nAC\n>first\nGGGG\n>second\nTT\n",              # sequence lines before the first header join the first record
     b">a\nAC\n>\nGG\n>b\nTT\n>c\nAA\n",                    # an empty-id header: its lines roll into the next flushed record

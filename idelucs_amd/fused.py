@@ -1,13 +1,15 @@
 """idelucs_amd.fused -- the explicit, fused optimizer step for the default configuration
 (NetLinear encoder + RMSprop), replayed as a HIP graph.
 
-One step of reference idelucs/models.py:117-133 becomes ~10 launches: the large dense products on
-hipBLASLt (torch.mm/addmm with out=, no allocation) and every other piece a fused HIP kernel from
-csrc/train_step.hip + nce_fused.hip (C ABI: idl_mid_fwd, idl_nce_fused_iic, idl_mid_bwd, idl_rmsprop_step_gather;
-the unfused building blocks idl_relu_dropout_fwd, idl_head_fwd, idl_nce_rows, idl_iic_core, idl_head_bwd,
-idl_bias_grads remain for shapes the fused kernels do not take and as their test references).  The batch is assembled by
-idl_gather_pairs_at from the HBM feature store using a device-resident offset that the optimizer
-kernel advances, so an epoch is `n_batches` replays of one captured graph with no host work between.
+One step of reference idelucs/models.py:117-133 is 7 launches by default: the two large dense products on hipBLASLt
+(torch.mm with out=, no allocation) and five fused HIP kernels from csrc/train_step.hip + nce_fused.hip --
+    W1 x^T  ->  idl_mid_fwd_gather  ->  idl_nce_fused_iic_z (two launches)  ->  idl_mid_bwd_gather  ->  dr1^T x
+            ->  idl_rmsprop_step_gather_wgrad
+(DESIGN.md 4.4 has the table of what each launch carries).  The unfused building blocks idl_relu_dropout_fwd, idl_head_fwd,
+idl_nce_rows, idl_iic_core, idl_head_bwd, idl_bias_grads, idl_rmsprop_step remain for the shapes the fused kernels do not take
+(n_clusters > 48, partial batches) and as their test references.  Batches are assembled from the HBM feature store at a
+device-resident offset that the optimizer kernel advances, the next batch while the current step is between its two big GEMMs
+(two x buffers), so an epoch is n_batches / 2 replays of one captured two-step graph with no host work between.
 
 The parameters remain the nn.Parameters of model.net (state_dict / predict / weights_init unchanged).
 RMSprop state lives here and, like the reference's single optimizer object (models.py:87-88 +
@@ -98,8 +100,8 @@ class FusedLinearTrainer:
         # dW2 = dlat^T r1 as 16 x 16 MFMA tiles inside the optimizer launch (idl_rmsprop_step_gather_wgrad) instead of a GEMM launch
         self._dw2_inlaunch = self.H1 % 16 == 0 and os.environ.get("IDELUCS_DW2_INLAUNCH", "1") != "0"
         self._overlap = os.environ.get("IDELUCS_OVERLAP", "0") != "0"   # measured: no gain inside a HIP graph on ROCm 7.2
-        # the NEXT batch is assembled by spare workgroups of the mid-backward launch into a second x buffer (instead of by the
-        # optimizer launch, where it competed with RMSprop for HBM): needs the fused middle kernels and n_clusters <= 48
+        # the NEXT batch is assembled by spare workgroups of the mid-forward / mid-backward launches into a second x buffer (instead
+        # of by the optimizer launch, where it competed with RMSprop for HBM): needs the fused middle kernels and n_clusters <= 48
         self._early_gather = (self._pipeline and self._mid_fused and self.C <= 48 and self.F % 4 == 0
                               and os.environ.get("IDELUCS_EARLY_GATHER", "1") != "0")
         self._early_split = os.environ.get("IDELUCS_EARLY_GATHER", "1") != "2"       # 2: all of it in the mid-backward launch

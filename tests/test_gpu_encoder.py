@@ -725,3 +725,45 @@ def test_fused_nce_pass2_mid_backward_equals_separate_launches(dev, C, train):
     names = ("lse", "loss_rows", "iic", "dlogits", "dlat", "dr1", "partial1", "partial2", "partial3", "dW3_part")
     for nme, x, y in zip(names, res[0], res[1]):
         assert torch.allclose(x, y, rtol=2e-4, atol=1e-6 * max(1.0, x.abs().max().item())), (nme, (x - y).abs().max().item())
+
+
+def test_batch_assembly_riding_in_the_middle_launches_is_the_gather(dev):
+    """The tiles of the next batch assembled by the spare workgroups of idl_mid_fwd_gather (shares [0, 3) of 8) and
+    idl_mid_bwd_gather (shares [3, 8)) are bit for bit idl_gather_pairs_at's batch, including the offset (base + base_add) and the
+    rows past the end of the pair list, which are left alone."""
+    import torch
+    from idelucs_amd import _lib, utils as U
+    from idelucs_amd.fused import _p, _stream
+    L = _lib.lib
+    torch.manual_seed(9)
+    P, n, F, B, C, m = 4, 300, 1024, 512, 20, 1024
+    feats = (torch.rand((P, n, F), device=dev) * 1e-3).contiguous()
+    mean, scale = U.col_stats(feats[0]); inv_scale = (1.0 / scale).contiguous()
+    n_pairs = (P - 1) * n                                   # 900 pairs: the batch at offset 600 has only 300 of its 512 rows
+    # (the list is padded with valid indices: idl_gather_pairs_at, the reference here, has no end-of-list limit and reads 512 entries)
+    perm = torch.cat([torch.randperm(n_pairs, device=dev), torch.zeros(512, dtype=torch.int64, device=dev)])
+    ctl = torch.tensor([0, 88], dtype=torch.int64, device=dev)
+    want = torch.full((m, F), -7.0, device=dev)
+    base = ctl[1:].clone(); base += 512
+    _lib.check(L.idl_gather_pairs_at(_p(feats), n, F, n * F, _p(perm), _p(base), B, _p(mean), _p(scale), _p(inv_scale), _p(want), _stream()))
+    # (idl_gather_pairs_at has no pair-list limit: rows beyond it are compared only where the riding version writes)
+    got = torch.full((m, F), -7.0, device=dev)
+    a1 = torch.randn(m, 512, device=dev); W2 = torch.randn(64, 512, device=dev) * 0.06; b2 = torch.zeros(64, device=dev)
+    W3 = torch.randn(C, 64, device=dev) * 0.2; b3 = torch.zeros(C, device=dev)
+    f = torch.empty(m, 64, device=dev); inv = torch.empty(m, device=dev); r2 = torch.empty(m, 64, device=dev); z = torch.empty(m, C, device=dev)
+    g_args = lambda p0, p1: (_p(feats), n, F, n * F, _p(perm), _p(ctl[1:]), 512, n_pairs, B, _p(mean), _p(scale), _p(inv_scale), _p(got), p0, p1, 8)
+    _lib.check(L.idl_mid_fwd_gather(_p(a1), None, 0, _p(W2), _p(b2), _p(W3), _p(b3), m, C, 1, 3, _p(ctl), _p(f), _p(inv), _p(r2), _p(z),
+                                    *g_args(0, 3), _stream()))
+    parts = L.idl_col_sum_parts(); gp = L.idl_nce_fused_parts()
+    G = torch.randn(gp, m, 64, device=dev); dP0 = torch.randn(C, C, device=dev); dP0 = dP0 + dP0.t()
+    dlg = torch.empty(m, C, device=dev); dlat = torch.empty(m, 64, device=dev); dr1 = torch.empty(m, 512, device=dev)
+    p1 = torch.empty(parts, 512, device=dev); p2 = torch.empty(parts, 64, device=dev); p3 = torch.empty(parts, C, device=dev)
+    _lib.check(L.idl_mid_bwd_gather(_p(z), _p(r2), _p(f), _p(inv), _p(G), gp, _p(dP0), _p(W3), _p(W2), _p(a1), m, C, 1, 1e-3, _p(dlg), _p(dlat),
+                                    _p(dr1), _p(p1), _p(p2), _p(p3), None, *g_args(3, 8), 0, _stream()))
+    torch.cuda.synchronize()
+    live = n_pairs - (88 + 512)                               # rows of each half that exist in the pair list
+    assert 0 < live < B
+    for half in (0, B):
+        assert torch.equal(got[half:half + live], want[half:half + live])
+        assert torch.all(got[half + live:half + B] == -7.0)   # beyond the end of the list: untouched
+    assert ctl.tolist() == [0, 88]                            # the riding gather moves no offset

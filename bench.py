@@ -130,10 +130,10 @@ class HotPath:
 
 def pmc_traffic_gb():
     """HBM traffic of one vectorise launch at cfg2, GB, from the committed rocprofv3 PMC passes
-    (profiles/r01_c_vectorise_pmc.json: WRITE_SIZE exact for 16-B stores, FETCH_SIZE as reported -- see DESIGN.md 4.1);
+    (profiles/r01_k_vectorise_pmc.json, re-collected this round: WRITE_SIZE exact for 16-B stores, FETCH_SIZE as reported -- see DESIGN.md 4.1);
     None when the profile is not present or the workload is not cfg2."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_c_vectorise_pmc.json")) as fh:
+        with open(os.path.join(ROOT, "profiles", "r01_k_vectorise_pmc.json")) as fh:
             return json.load(fh)["traffic_gb_per_launch"]
     except Exception:
         return None

@@ -223,13 +223,22 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     from idelucs_amd import _lib, gemm_tuning
     _lib.require_gpu()
+    # rehearsal knobs (not used by the driver): IDELUCS_BENCH_BACKEND=gloo and IDELUCS_BENCH_DEVICES=1 let two ranks share the one
+    # GPU of a test box, to exercise every line of the N > 1 path except RCCL itself
+    backend = os.environ.get("IDELUCS_BENCH_BACKEND", "nccl")
+    n_dev = int(os.environ.get("IDELUCS_BENCH_DEVICES", "0"))
+    if n_dev > 0:
+        local_rank %= n_dev
     torch.cuda.set_device(local_rank)
     os.environ.setdefault("IDELUCS_TUNABLEOP", "1")      # GEMM solution selection (PyTorch TunableOp), done in the warm-up step
     gemm_tuning.maybe_enable()
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     din = synth_packed(args.n, args.len, dev)

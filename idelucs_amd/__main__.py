@@ -38,10 +38,16 @@ def run(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     if world > 1:
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        n_dev = int(os.environ.get("IDELUCS_BENCH_DEVICES", "0"))    # rehearsal on a box with fewer GPUs than ranks (with gloo)
+        torch.cuda.set_device(local % n_dev if n_dev > 0 else local)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", torch.cuda.current_device()))
+        backend = os.environ.get("IDELUCS_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", torch.cuda.current_device()))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     stamp = time.asctime().split(" ")
     stamp = [s for s in stamp if s]

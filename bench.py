@@ -2,24 +2,26 @@
 """bench.py -- the headline benchmark of BASELINE.json on MI355X.
 
 metric   : sequences/sec (k-mer vectorise + 1 epoch), k=6, batch 512
-workload : BASELINE.json configs[1] -- synthetic 100 000 sequences x 10 kbp (iid uniform ACGT),
-           k=6, n_clusters=20, n_mimics=3 (CLI default), batch_sz=512, NetLinear, RMSprop, fp32.
-step     : ONE pass of the hot path over the whole synthetic batch, with the packed bases already
-           resident in HBM: device mimic-site generation + vectorisation of all 4 views + scaler fit
-           + one full training epoch (586 optimizer steps), i.e. BASELINE.md section 3's timed region
-           ("... to the optimizer.step() of the last batch of epoch 1; excludes predict, ensemble, TSV").
-           Nothing is cached across steps (features are recomputed, weights re-initialised each step
-           -- one step == one voter of the reference's voter loop, idelucs/__main__.py:106-146).
-           --with-predict 1 adds predict (+ the all-gather) to the timed region.
-N > 1    : one process per GPU (torch.distributed, backend nccl == RCCL); every rank runs its own
-           voter on the full data set (the n_voters loop sharded over GPUs; weak scaling, no
-           data-path collective inside the epoch).  value = (N_seq x ranks) / max-over-ranks time.
-           The path's one exchange step -- predict + all-gather of the int32 assignments [V, N] over
-           RCCL -- runs once after the timed loop at every N (reported as "exchange_ms").
+workload : N = 1  -> BASELINE.json configs[1] ("cfg2"): synthetic 100 000 sequences x 10 kbp (iid uniform ACGT), k=6,
+                     n_clusters=20, n_mimics=3 (CLI default), batch_sz=512, NetLinear, RMSprop, fp32, ONE voter.
+           N > 1  -> configs[2] ("cfg3", BASELINE.md section 3 "Multi-GPU reporting"): the same data, a FIXED job of 8 voters
+                     sharded voter v -> rank v mod N (8/N voters per rank), predict + the RCCL all-gather of the int32
+                     assignments [V, N_seq] INSIDE the timed region.  value = N_seq * V / wall, "scaling": "strong".
+           --workload cfg5 -> configs[4]: 1 000 000 x 5 kbp, n_clusters=0 => 200 output units; voters as above, then the last
+                     voter's weights are broadcast, predict is sharded by sequence and the fp32 latent shards [N_seq/G, 64] are
+                     all-gathered (timed).  (HDBSCAN itself is post-hoc and not part of the metric.)
+step     : ONE pass of the hot path over the whole synthetic batch, packed bases already resident in HBM: device mimic-site
+           generation + vectorisation of all 4 views + scaler fit (once per step, as the reference builds x_train once,
+           idelucs/__main__.py:95) + one full training epoch per voter (586 optimizer steps at cfg2), i.e. BASELINE.md
+           section 3's timed region.  Nothing is cached across steps: features are recomputed and every voter starts from a
+           fresh Kaiming init (reference __main__.py:109).  --with-predict 1 adds predict at N = 1 too.
+checks   : the epoch loss of every timed step must be finite, and after the timed loop (untimed) the feature store of the last
+           step is validated (rows sum to 1, view 0 != view 1) and a checksum of it is printed ("validation").
+N > 1    : one process per GPU (torch.distributed, backend nccl == RCCL); no collective inside an epoch.
 
-Prints ONE JSON line (rank 0).  Extra objects: "roofline" (the hand-written vectoriser kernel, HBM
-bound), "roofline_epoch" (the encoder epoch, MFMA fp32 bound), "cpu_baseline" (oracle port on the
-host cores, bounded sample, rank 0 at N=1 only).
+Prints ONE JSON line (rank 0).  Extra objects: "roofline" (the hand-written vectoriser kernel, HBM bound), "roofline_epoch"
+(the encoder epoch, MFMA fp32 bound), "cpu_baseline" (oracle port on the host cores, bounded sample, rank 0 at N=1 only),
+"t_e2e" (FASTA text in the page cache -> last optimizer.step, N=1 only; never `value`).
 """
 import argparse
 import json
@@ -36,6 +38,7 @@ import torch.distributed as dist
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 matrix peak (v_mfma_f32_32x32x2_f32)
+PMC_PROFILE = "r02_vectorise_pmc.json"     # profiles/: FETCH_SIZE / WRITE_SIZE passes of the vectoriser at cfg2
 
 
 def synth_packed(n, L, dev, seed=12345):
@@ -43,7 +46,11 @@ def synth_packed(n, L, dev, seed=12345):
     slots = (L + 63) // 64
     g = torch.Generator(device=dev)
     g.manual_seed(seed)
-    codes = torch.randint(-2 ** 31, 2 ** 31 - 1, (n * slots * 4,), dtype=torch.int32, device=dev, generator=g)
+    codes = torch.empty(n * slots * 4, dtype=torch.int32, device=dev)
+    step = 1 << 28
+    for lo in range(0, codes.numel(), step):     # chunked: randint materialises an int64 temporary of the request
+        hi = min(lo + step, codes.numel())
+        codes[lo:hi] = torch.randint(-2 ** 31, 2 ** 31 - 1, (hi - lo,), dtype=torch.int32, device=dev, generator=g)
     mask = torch.zeros((n, slots, 2), dtype=torch.int32, device=dev)
     tail = L % 64
     if tail:                     # bases past the end of the sequence are marked invalid
@@ -64,27 +71,37 @@ def synth_packed(n, L, dev, seed=12345):
 
 
 class HotPath:
-    """The timed region: everything from packed bases in HBM to the last optimizer.step()."""
+    """The timed region: everything from packed bases in HBM to the last optimizer.step() (and, for a multi-voter job, to the
+    gathered assignments)."""
 
-    def __init__(self, din, args, dev):
-        from idelucs_amd import _lib, utils as U, models
-        self.U, self._lib, self.models = U, _lib, models
-        self.din, self.dev, self.a = din, dev, args
+    def __init__(self, din, args, dev, rank, world):
+        from idelucs_amd import _lib, utils as U, models, dist as D
+        self.U, self._lib, self.models, self.D = U, _lib, models, D
+        self.din, self.dev, self.a, self.rank, self.world = din, dev, args, rank, world
         self.specs = [t.spec() for t in U.mimic_transforms(args.n_mimics)]
         self.P = len(self.specs)
         self.F = 4 ** args.k
         self.model = models.IID_model({
             'sequence_file': None, 'GT_file': None, 'n_clusters': args.n_clusters, 'k': args.k, 'model_size': 'linear',
             'n_mimics': args.n_mimics, 'batch_sz': args.batch_sz, 'optimizer': 'RMSprop', 'lambda': 2.8, 'lr': 1e-3,
-            'weight': 0.25, 'scheduler': None, 'n_epochs': 1, 'n_voters': 1})
-        self.feats = torch.empty((self.P, din.n, self.F), dtype=torch.float32, device=dev)   # 6.55 GB at cfg2
+            'weight': 0.25, 'scheduler': None, 'n_epochs': 1, 'n_voters': args.voters})
+        self.feats = torch.empty((self.P, din.n, self.F), dtype=torch.float32, device=dev)   # 6.55 GB at cfg2, 65.5 GB at cfg5
+        # the scaler lives in persistent buffers refitted in place every step: the captured training-step graph (which bakes
+        # their addresses) is captured once, in the warm-up, and replayed afterwards
+        self.mean = torch.zeros(self.F, dtype=torch.float64, device=dev)
+        self.scale = torch.ones(self.F, dtype=torch.float64, device=dev)
+        self.store = U.FeatureStore(None, None, self.feats, self.mean, self.scale, args.k, False)
+        self.model.store = self.store
         # mimic-site buffer sized by a safe bound (expected + 25 % + slack) instead of a host round trip per step; the
         # device-side totals are checked against it after the run (overflow flag, no sync inside the step)
         expect = sum(din.n * (args.len * (1.0 - (1.0 - s[0]) * (1.0 - s[1])) + s[2]) for s in self.specs)
         self.edit_capacity = int(1.25 * expect + 64 * din.n * self.P + 1024)
         self.edit_overflow = torch.zeros((), dtype=torch.bool, device=dev)
-        self.ev = {k: [] for k in ("edits", "vectorise", "stats", "epoch", "predict")}
-        self.y_pred = None
+        self.ev = {k: [] for k in ("edits", "vectorise", "stats", "epoch", "predict", "exchange")}
+        self.my_voters = D.voters_of_rank(args.voters, rank, world)
+        self.losses = []            # device scalars, one per voter-epoch (checked after the timed loop)
+        self.gathered = None
+        self.latent = None
 
     def _timed(self, key, fn):
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -94,27 +111,45 @@ class HotPath:
         self.ev[key].append((s, e))
         return r
 
-    def step(self, seed):
-        U, _lib, m = self.U, self._lib, self.model
+    def features(self, seed):
+        U, _lib = self.U, self._lib
         edits, edit_off = self._timed("edits", lambda: U._philox_edits(self.din, self.specs, seed, capacity=self.edit_capacity))
         self.edit_overflow |= edit_off[-1] > self.edit_capacity
         self._timed("vectorise", lambda: U._vectorise(self.din, self.a.k, _lib.MODE_KMER, _lib.INIT_ONE, _lib.OUT_FREQ_F32,
                                                       self.P, edits, edit_off, self.feats))
-        mean, scale = self._timed("stats", lambda: U.col_stats(self.feats[0]))
-        m.store = U.FeatureStore(None, None, self.feats, mean, scale, self.a.k, False)
-        m.net.apply(self.models.weights_init)          # a fresh voter (reference __main__.py:109)
-        loss = self._timed("epoch", m.contrastive_training_epoch)
-        if self.a.with_predict:
-            self.y_pred = self._timed("predict", self.predict)
-        return loss
 
-    def predict(self):
-        """Un-mutated vectors, own float64 scaler, eval forward, argmax (reference models.py:145-172)."""
-        U, _lib, m = self.U, self._lib, self.model
+        def fit():
+            U.col_stats(self.feats[0], out=(self.mean, self.scale))
+            self.store.refresh()
+        self._timed("stats", fit)
+
+    def step(self, seed):
+        m, a = self.model, self.a
+        self.features(seed)
+        preds = {}
+        for v in self.my_voters:
+            m.begin_voter(v)                                   # fresh Kaiming init + this voter's RNG streams
+            self.losses.append(self._timed("epoch", lambda: m.contrastive_training_epoch(sync=False)))
+            if a.exchange and a.workload != "cfg5":
+                preds[v] = self._timed("predict", self.predict)
+        if a.exchange and a.workload != "cfg5":               # the path's one exchange step: [V, N] int32 assignments
+            self.gathered = self._timed("exchange", lambda: self.D.gather_voter_predictions(preds, a.voters, self.din.n, device=self.dev))
+        elif a.exchange:                                        # cfg5: last voter's model everywhere, predict sharded by sequence
+            self.latent = self._timed("exchange", self.sharded_latent)
+
+    def _predict_inputs(self, lo=0, hi=None):
+        """Un-mutated float64 vectors, own float64 scaler fitted on ALL rows (reference utils.py:400-405), rows [lo, hi)
+        standardised to float32."""
+        U, _lib = self.U, self._lib
         f64 = U._vectorise(self.din, self.a.k, _lib.MODE_KMER, _lib.INIT_ONE, _lib.OUT_FREQ_F64)[0]
         mean, scale = U.col_stats(f64)
-        x = U.standardise(f64, mean, scale)
-        del f64
+        hi = f64.shape[0] if hi is None else hi
+        return U.standardise(f64[lo:hi], mean, scale)
+
+    def predict(self):
+        """Eval forward, argmax (reference models.py:145-172) -> int32 [N]."""
+        m = self.model
+        x = self._predict_inputs()
         preds = []
         with torch.no_grad():
             m.net.eval()
@@ -123,20 +158,53 @@ class HotPath:
                 preds.append(o.argmax(1).to(torch.int32))
         return torch.cat(preds)
 
-    def mean_ms(self, key, skip):
-        ev = self.ev[key][skip:]
+    def sharded_latent(self):
+        """cfg5 (reference __main__.py:153-156 clusters ONE model's latent): the last voter's weights go to every rank, each
+        rank embeds its N/G sequences, the fp32 shards are all-gathered over RCCL."""
+        m, D = self.model, self.D
+        owner = (self.a.voters - 1) % self.world
+        if self.world > 1:
+            for p in m.net.parameters():
+                dist.broadcast(p.data, src=owner)
+        lo, hi = D.shard_bounds(self.din.n, self.rank, self.world)
+        x = self._predict_inputs(lo, hi)
+        lats = []
+        with torch.no_grad():
+            m.net.eval()
+            for i in range(0, x.shape[0], 8192):
+                lats.append(m.net(x[i:i + 8192])[1])
+        return D.all_gather_rows(torch.cat(lats) if lats else torch.empty((0, 64), device=self.dev), self.din.n)
+
+    def mean_ms(self, key, skip_steps):
+        per_step = {"epoch": len(self.my_voters), "predict": len(self.my_voters)}.get(key, 1)
+        ev = self.ev[key][skip_steps * per_step:]
         return sum(s.elapsed_time(e) for s, e in ev) / max(len(ev), 1)
+
+    def validate(self):
+        """Untimed checks of what the last timed step produced (the bench validated nothing it timed)."""
+        n = self.din.n
+        losses = torch.stack([l.reshape(()) for l in self.losses]).double().cpu().numpy()
+        assert np.all(np.isfinite(losses)), f"non-finite epoch loss in a timed step: {losses}"
+        rows = torch.arange(0, n, max(n // 4096, 1), device=self.dev)
+        sums = self.feats[:, rows].double().sum(2)
+        assert torch.allclose(sums, torch.ones_like(sums), atol=1e-6), "frequency rows of the timed store do not sum to 1"
+        assert not torch.equal(self.feats[0, rows], self.feats[1, rows]), "view 0 == view 1: the mimic views were not applied"
+        chk = [float(self.feats[v].sum(dtype=torch.float64).item()) for v in range(self.P)]      # == N for every view
+        assert all(abs(c - n) < 1e-3 * n for c in chk), chk
+        return {"epoch_loss_last_step": [float(x) for x in losses[-len(self.my_voters):]], "epoch_loss_first_timed": float(losses[0]),
+                "feats_checksum": chk, "rows_checked": int(rows.numel())}
 
 
 def pmc_traffic_gb():
-    """HBM traffic of one vectorise launch at cfg2, GB, from the committed rocprofv3 PMC passes
-    (profiles/r01_k_vectorise_pmc.json, re-collected this round: WRITE_SIZE exact for 16-B stores, FETCH_SIZE as reported -- see DESIGN.md 4.1);
-    None when the profile is not present or the workload is not cfg2."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_k_vectorise_pmc.json")) as fh:
-            return json.load(fh)["traffic_gb_per_launch"]
-    except Exception:
-        return None
+    """HBM traffic of one vectorise launch at cfg2, GB, from the committed rocprofv3 PMC passes (profiles/, WRITE_SIZE exact
+    for 16-B stores, FETCH_SIZE doubled per MI355X_MICROARCH.md: DESIGN.md 4.1); None when the profile is not present."""
+    for name in (PMC_PROFILE, "r01_k_vectorise_pmc.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as fh:
+                return json.load(fh)["traffic_gb_per_launch"]
+        except Exception:
+            continue
+    return None
 
 
 def cpu_baseline(args):
@@ -196,9 +264,52 @@ def cpu_baseline(args):
         loss.backward(); opt.step()
     t_all = time.perf_counter() - t0
     return {"value": n / t_all, "unit": "sequences/sec", "cores": threads, "kind": "port",
-            "sample": f"{n} of the 100000 x {L} bp sequences (same generator family), k={k}, n_mimics={args.n_mimics}, "
+            "sample": f"{n} of the {args.n} x {L} bp sequences (same generator family), k={k}, n_mimics={args.n_mimics}, "
                       f"B={args.batch_sz}: oracle vectorise single-threaded {t_vec:.1f} s + torch-CPU epoch "
                       f"({threads} threads of {cores} cores) {t_all - t_vec:.1f} s"}
+
+
+def t_e2e(args, dev, reps=2):
+    """SURVEY 8(d) / BASELINE.md section 3 T_e2e: the synthetic FASTA text (seed 12345, >seq%06d, one line per sequence,
+    ~1.0 GB at cfg2) is written to tmpfs once, untimed; timed = open (page cache) -> C++ parse/validate/2-bit pack in record
+    chunks, each chunk's H2D copy and vectorisation overlapped with the parsing of the next -> scaler fit -> the last
+    optimizer.step() of epoch 1, device-synchronised."""
+    from idelucs_amd import models, utils as U
+    d = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else "/tmp"
+    path = os.path.join(d, f"idelucs_synth_{args.n}x{args.len}_{os.getpid()}.fas")
+    rng = np.random.default_rng(12345)
+    with open(path, "wb") as f:
+        blk_n = 2000
+        for i0 in range(0, args.n, blk_n):
+            nb = min(blk_n, args.n - i0)
+            blk = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, size=(nb, args.len), dtype=np.uint8)]
+            rec = np.empty((nb, 11 + args.len + 1), np.uint8)       # ">seq%06d\n" is 11 bytes for i < 10^6
+            hdr = np.frombuffer(b"".join(b">seq%06d\n" % (i0 + j) for j in range(nb)), np.uint8).reshape(nb, 11)
+            rec[:, :11] = hdr; rec[:, 11:-1] = blk; rec[:, -1] = 10
+            f.write(rec.tobytes())
+    size = os.path.getsize(path)
+    margs = {'sequence_file': path, 'GT_file': None, 'n_clusters': args.n_clusters, 'k': args.k, 'model_size': 'linear',
+             'n_mimics': args.n_mimics, 'batch_sz': args.batch_sz, 'optimizer': 'RMSprop', 'lambda': 2.8, 'lr': 1e-3,
+             'weight': 0.25, 'scheduler': None, 'n_epochs': 1, 'n_voters': 1}
+    best = None
+    try:
+        m = models.IID_model(margs)
+        for rep in range(reps + 1):                      # rep 0 = warm-up (page cache, allocator, graph capture)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            m.store = None
+            m.store = U.build_feature_store(path, args.n_mimics, k=args.k, device=m.device, streamed=True)
+            torch.cuda.synchronize(); t1 = time.perf_counter()
+            m.begin_voter(0)
+            loss = m.contrastive_training_epoch()
+            torch.cuda.synchronize(); t2 = time.perf_counter()
+            assert np.isfinite(loss)
+            r = {"ms": 1e3 * (t2 - t0), "ingest_to_features_ms": 1e3 * (t1 - t0), "epoch_ms": 1e3 * (t2 - t1),
+                 "sequences_per_sec": args.n / (t2 - t0), "fasta_bytes": size, "host_threads": U.ingest_threads()}
+            if rep > 0 and (best is None or r["ms"] < best["ms"]):
+                best = r
+    finally:
+        os.unlink(path)
+    return best
 
 
 def main():
@@ -206,21 +317,32 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=100000)
-    ap.add_argument("--len", type=int, default=10000)
+    ap.add_argument("--workload", choices=["cfg2", "cfg5"], default="cfg2")
+    ap.add_argument("--n", type=int, default=None)
+    ap.add_argument("--len", type=int, default=None)
     ap.add_argument("--k", type=int, default=6)
-    ap.add_argument("--n-clusters", dest="n_clusters", type=int, default=20)
+    ap.add_argument("--n-clusters", dest="n_clusters", type=int, default=None)
     ap.add_argument("--n-mimics", dest="n_mimics", type=int, default=3)
     ap.add_argument("--batch-sz", dest="batch_sz", type=int, default=512)
-    ap.add_argument("--with-predict", dest="with_predict", type=int, default=0,
-                    help="1: include predict + all-gather of assignments in the timed region (default 0 = BASELINE.md's region)")
+    ap.add_argument("--voters", type=int, default=None,
+                    help="voters of the job (default: 1 on one GPU = cfg2; 8 on several GPUs = cfg3's fixed job)")
+    ap.add_argument("--with-predict", dest="with_predict", type=int, default=None,
+                    help="1: predict + all-gather inside the timed region (default: 0 at N=1 with one voter = BASELINE.md's region; 1 otherwise)")
     ap.add_argument("--cpu-sample", dest="cpu_sample", type=int, default=24000)
     ap.add_argument("--no-cpu-baseline", dest="cpu_base", action="store_false")
+    ap.add_argument("--no-e2e", dest="e2e", action="store_false")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    cfg5 = args.workload == "cfg5"
+    args.n = args.n or (1_000_000 if cfg5 else 100_000)
+    args.len = args.len or (5_000 if cfg5 else 10_000)
+    args.n_clusters = args.n_clusters or (200 if cfg5 else 20)
+    if args.voters is None:
+        args.voters = 1 if world == 1 else (world if cfg5 else 8)
+    args.exchange = bool(args.with_predict) if args.with_predict is not None else (world > 1 or args.voters > 1 or cfg5)
     from idelucs_amd import _lib, gemm_tuning
     _lib.require_gpu()
     # rehearsal knobs (not used by the driver): IDELUCS_BENCH_BACKEND=gloo and IDELUCS_BENCH_DEVICES=1 let two ranks share the one
@@ -241,25 +363,17 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
-    din = synth_packed(args.n, args.len, dev)
-    hp = HotPath(din, args, dev)
-    gathered = None
-
-    def one_step(i):
-        nonlocal gathered
-        hp.step(seed=1000 * rank + i)
-        if world > 1 and args.with_predict:
-            from idelucs_amd.dist import all_gather_assignments
-            gathered = all_gather_assignments(hp.y_pred)        # [world, N] int32 over RCCL/xGMI
+    din = synth_packed(args.n, args.len, dev, seed=54321 if cfg5 else 12345)
+    hp = HotPath(din, args, dev, rank, world)
 
     for i in range(args.warmup):
-        one_step(i)
+        hp.step(seed=i)                 # the data/mimic seed is shared by all ranks: every rank builds the same store
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        one_step(args.warmup + i)
+        hp.step(seed=args.warmup + i)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -269,20 +383,32 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
-    # the exchange step of the path (untimed unless --with-predict 1): this rank's voter predicts, assignments are all-gathered
-    from idelucs_amd.dist import all_gather_assignments
-    all_gather_assignments(hp.predict())            # first call: library initialisation for the inference GEMM shapes (0.5 s), not the path
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    gathered = all_gather_assignments(hp.predict())
-    torch.cuda.synchronize()
-    exchange_ms = 1e3 * (time.perf_counter() - t1)
-    assert tuple(gathered.shape) == (world, args.n)
     assert not bool(hp.edit_overflow.item()), "mimic edit buffer bound exceeded: the run is invalid"
+    validation = hp.validate()
+    exchange_ms = None
+    if args.exchange:
+        if cfg5:
+            assert tuple(hp.latent.shape) == (args.n, 64) and bool(torch.isfinite(hp.latent).all())
+        else:
+            assert tuple(hp.gathered.shape) == (args.voters, args.n)
+            assert int(hp.gathered.min()) >= 0 and int(hp.gathered.max()) < args.n_clusters
+            if args.voters > 1:      # voters are distinct runs (per-voter init / permutation / dropout streams), also across ranks
+                assert not torch.equal(hp.gathered[0], hp.gathered[1]), "voters 0 and 1 produced identical assignments"
+    else:
+        # the exchange step of the path, untimed at N = 1 with one voter: this rank's voter predicts, assignments are all-gathered
+        from idelucs_amd.dist import all_gather_assignments
+        all_gather_assignments(hp.predict())            # first call: library initialisation for the inference GEMM shapes (0.5 s)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        gathered = all_gather_assignments(hp.predict())
+        torch.cuda.synchronize()
+        exchange_ms = 1e3 * (time.perf_counter() - t1)
+        assert tuple(gathered.shape) == (world, args.n)
 
     if rank == 0:
         ms_step = 1e3 * elapsed / args.steps
-        value = args.n * world / (elapsed / args.steps)
+        V = args.voters
+        value = args.n * V / (elapsed / args.steps)
         P, F = hp.P, hp.F
         # B_vec = ceil(L/4) + P*F*4 bytes per sequence; one launch processes all N sequences
         b_vec = (args.len + 3) // 4 + P * F * 4
@@ -297,32 +423,44 @@ def main():
         nce = args.n_mimics * 3 * (2 * B) * H2 * 2 * 2
         f_exec = args.n_mimics * 2 * (2 * 2 * F * H1 + 3 * 2 * (H1 * H2 + H2 * C)) + nce
         ach_exec = args.n * f_exec / (t_ep * 1e-3) / 1e12
+        cfg_name = "configs[4] (cfg5)" if cfg5 else ("configs[1] (cfg2)" if V == 1 else "configs[2] (cfg3)")
+        region = "device mimic sites + vectorise + scaler fit + 1 epoch per voter"
+        if args.exchange:
+            region += (" + last voter's weights broadcast + predict sharded by sequence + all-gather of fp32 latent shards" if cfg5
+                       else " + predict + all-gather of the int32 assignments [V, N]")
+        else:
+            region += " (BASELINE.md section 3 region; predict + all-gather run once after it: exchange_ms)"
         out = {
             "metric": "sequences/sec (k-mer vectorise + 1 epoch), k=6 batch 512",
             "value": value, "unit": "sequences/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[1]: synthetic {args.n} x {args.len} bp, k={args.k}, n_clusters={args.n_clusters}, "
+            "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak" if V == world and world > 1 and cfg5 else ("strong" if world > 1 else "weak"),
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"BASELINE {cfg_name}: synthetic {args.n} x {args.len} bp, k={args.k}, n_clusters={args.n_clusters}, "
                                    f"n_mimics={args.n_mimics} ({P} views), batch_sz={args.batch_sz}, NetLinear fp32, RMSprop; "
-                                   f"one voter per GPU; timed = device mimic sites + vectorise + scaler fit + 1 epoch"
-                                   + (" + predict + all-gather of assignments" if args.with_predict
-                                      else " (BASELINE.md section 3 region; predict + RCCL all-gather of assignments run once after it)"),
-                       "n_sequences": args.n, "seq_len": args.len, "k": args.k, "batch_sz": args.batch_sz,
+                                   f"{V} voter(s) over {world} GPU(s), value = N_seq * voters / wall; timed = {region}",
+                       "n_sequences": args.n, "seq_len": args.len, "k": args.k, "batch_sz": args.batch_sz, "n_voters": V,
                        "optimizer_steps_per_epoch": (args.n * args.n_mimics + args.batch_sz - 1) // args.batch_sz,
-                       "parallelism": f"voters x{world}"},
-            "roofline": {"kernel": "vectorise2_kernel<6> (hand-written HIP: one count + per-view window deltas + normalise, all views)",
+                       "parallelism": f"{V} voters / {world} ranks"},
+            "roofline": {"kernel": "vectorise kernel (hand-written HIP: one count + per-view window deltas + normalise, all views)",
                          "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic_gb(), "ms_per_launch": t_vec, "bytes_per_seq_algorithmic": b_vec,
+                         "traffic": pmc_traffic_gb() if not cfg5 else None, "ms_per_launch": t_vec, "bytes_per_seq_algorithmic": b_vec,
                          "share_of_step": t_vec / ms_step},
             "roofline_epoch": {"kernel": "training epoch (hipBLASLt fp32 GEMMs + gather + losses + RMSprop)", "bound": "mfma",
                                "achieved": ach_ep, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach_ep / MFMA_F32_PEAK_TFLOPS,
-                               "ms": t_ep, "flop_per_seq_algorithmic": f_ep, "share_of_step": t_ep / ms_step,
+                               "ms": t_ep, "flop_per_seq_algorithmic": f_ep, "share_of_step": t_ep * len(hp.my_voters) / ms_step,
                                "flop_per_seq_executed": f_exec, "achieved_executed": ach_exec, "frac_executed": ach_exec / MFMA_F32_PEAK_TFLOPS,
                                "note": "algorithmic = SURVEY 8(d) (3 x forward for every layer); executed = without the input gradient of "
-                                       "layer 1, which is not computed; matrix-pipe busy time from PMC: profiles/r01_i_epoch_pmc_mfma.json"},
+                                       "layer 1, which is not computed"},
             "stage_ms": {k: hp.mean_ms(k, args.warmup) for k in hp.ev if hp.ev[k]},
-            "exchange_ms": exchange_ms,
+            "validation": validation,
         }
+        if exchange_ms is not None:
+            out["exchange_ms"] = exchange_ms
+        if world == 1 and args.e2e and not cfg5 and V == 1:
+            del hp.feats, hp.store.feats
+            hp.model.store = None
+            torch.cuda.empty_cache()
+            out["t_e2e"] = t_e2e(args, dev)
         if world == 1 and args.cpu_base:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out))

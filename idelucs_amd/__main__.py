@@ -37,6 +37,18 @@ def run(args):
     start_time = time.time()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+
+    # the output folder first (reference __main__.py:60-73), BEFORE any collective exists: a rank 0 that cannot create it fails
+    # here, alone, instead of leaving the other ranks waiting in a collective
+    stamp = time.asctime().split(" ")
+    stamp = [s for s in stamp if s]
+    stamp[3] = "-".join(stamp[3].split(":"))
+    time_stamp = "_".join(stamp[1:-1])
+    results_folder = os.path.join(os.getcwd(), "Results", os.path.basename(args["sequence_file"]).split(".")[0])
+    out_dir = os.path.join(results_folder, time_stamp)
+    if rank == 0:
+        os.makedirs(out_dir, exist_ok=False)
+
     if world > 1:
         local = int(os.environ.get("LOCAL_RANK", "0"))
         n_dev = int(os.environ.get("IDELUCS_BENCH_DEVICES", "0"))    # rehearsal on a box with fewer GPUs than ranks (with gloo)
@@ -48,15 +60,6 @@ def run(args):
                                     device_id=torch.device("cuda", torch.cuda.current_device()))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
-
-    stamp = time.asctime().split(" ")
-    stamp = [s for s in stamp if s]
-    stamp[3] = "-".join(stamp[3].split(":"))
-    time_stamp = "_".join(stamp[1:-1])
-    results_folder = os.path.join(os.getcwd(), "Results", os.path.basename(args["sequence_file"]).split(".")[0])
-    out_dir = os.path.join(results_folder, time_stamp)
-    if rank == 0:
-        os.makedirs(out_dir, exist_ok=False)
 
     use_hdbscan = False
     if args["n_clusters"] == 0:                                   # __main__.py:75-76
@@ -79,17 +82,27 @@ def run(args):
         local_preds[voter] = torch.from_numpy(posthoc.relabel_first_occurrence(y_pred)).to(model.device)
 
     preds = D.gather_voter_predictions(local_preds, args["n_voters"], n, device=model.device).cpu().numpy()
-    if world > 1:                                                  # ship the last voter's latent + loss curves to rank 0
+    if world > 1:
         owner = (args["n_voters"] - 1) % world
-        lat_t = torch.from_numpy(latent).to(model.device) if rank == owner else torch.empty((n, 64), dtype=torch.float64, device=model.device)
-        dist.broadcast(lat_t, src=owner)
-        latent = lat_t.cpu().numpy()
+        if use_hdbscan:
+            # n_clusters=0 clusters ONE model's latent (reference __main__.py:153-156, the last voter's): its weights go to every
+            # rank, predict is sharded by sequence, the fp32 latent shards [N/G, 64] are all-gathered over RCCL
+            for prm in model.net.parameters():
+                dist.broadcast(prm.data, src=owner)
+            lo, hi = D.shard_bounds(n, rank, world)
+            latent = D.all_gather_rows(model.predict_latent_shard(lo, hi), n).double().cpu().numpy()
+        else:                                                      # ship the last voter's latent to rank 0 (scores only)
+            lat_t = torch.from_numpy(latent).to(model.device) if rank == owner else torch.empty((n, 64), dtype=torch.float64, device=model.device)
+            dist.broadcast(lat_t, src=owner)
+            latent = lat_t.cpu().numpy()
         all_curves = [None] * world
         dist.all_gather_object(all_curves, curves)
         curves = {k: v for c in all_curves for k, v in c.items()}
     if rank != 0:
         dist.destroy_process_group()
         return
+    if os.environ.get("IDELUCS_DUMP_VOTES"):                      # tests: the [V, N] vote matrix as gathered from the ranks
+        np.save(os.environ["IDELUCS_DUMP_VOTES"], preds)
 
     import matplotlib
     matplotlib.use("Agg")
@@ -122,6 +135,11 @@ def run(args):
         w = np.zeros((len(unique_labels), max(max(y_pred) + 1, max(y) + 1)), dtype=np.int64)
         for i in range(y.shape[0]):
             w[y[i], d[y_pred[i]]] += 1
+        if args["n_clusters"] < 16:                               # reference __main__.py:176-180: a picture for small tables ...
+            fig, new_ax = plt.subplots(nrows=1, ncols=1)
+            posthoc.plot_confusion_matrix(w, unique_labels, ax=new_ax, normalize=False)
+            fig.savefig(os.path.join(out_dir, "contingency_matrix.jpg"))
+        # ... and the table itself always (the reference writes the .tsv only when n_clusters >= 16, :181-186)
         w_df = pd.DataFrame(w)
         w_df.index = unique_labels
         w_df.to_csv(os.path.join(out_dir, "contingency_matrix.tsv"), sep="\t")

@@ -34,6 +34,8 @@ SIGNATURES = {
     "idl_fasta_close": (None, [_vp]),
     "idl_fasta_sizes": (_int, [_vp, _pi64, _pi64, _pi64, _pi64]),
     "idl_fasta_export": (_int, [_vp] + [_vp] * 8),
+    "idl_fasta_pack_range": (_int, [_vp, _i64, _i64, _vp, _vp]),
+    "idl_ingest_threads": (_int, []),
     "idl_vectorise": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _int, _int, _int, _int, _vp, _vp, _vp, _i64, _i64, _vp]),
     "idl_mimic_workspace": (_i64, [_i64, _int]),
     "idl_mimic_edits": (_int, [_vp, _i64, _int, _vp, _vp, _vp, _c.c_uint64, _vp, _vp, _i64, _pi64, _vp, _vp]),

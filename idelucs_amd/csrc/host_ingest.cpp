@@ -552,4 +552,44 @@ int idl_fasta_export(const idl_fasta *f, uint8_t *names, int64_t *name_off, int6
     return IDL_OK;
 }
 
+int idl_ingest_threads(void) { return n_threads(); }
+
+int idl_fasta_pack_range(const idl_fasta *f, int64_t rec_lo, int64_t rec_hi, uint8_t *codes, uint8_t *mask)
+{
+    IDL_REQUIRE(f, "NULL handle");
+    const int64_t n = (int64_t)f->recs.size();
+    IDL_REQUIRE(rec_lo >= 0 && rec_lo <= rec_hi && rec_hi <= n, "record range outside the file");
+    if (rec_lo == rec_hi) return IDL_OK;
+    IDL_REQUIRE(codes && mask, "NULL buffer");
+    const uint8_t *buf = f->buf.data();
+    // slot offset of rec_lo in the whole-file layout, then a local prefix over the range (balanced by cleaned bases)
+    int64_t s0 = 0;
+    for (int64_t i = 0; i < rec_lo; ++i) s0 += (f->recs[(size_t)i].len + 63) / 64;
+    const int64_t m = rec_hi - rec_lo;
+    std::vector<int64_t> boff((size_t)m + 1, 0), soff((size_t)m + 1, s0);
+    for (int64_t i = 0; i < m; ++i) {
+        const Rec &r = f->recs[(size_t)(rec_lo + i)];
+        boff[(size_t)i + 1] = boff[(size_t)i] + r.len;
+        soff[(size_t)i + 1] = soff[(size_t)i] + (r.len + 63) / 64;
+    }
+    const int64_t total = boff[(size_t)m];
+    const int nt = (total > (int64_t)par_min_bytes() && m >= 2) ? n_threads() : 1;
+    parallel_for(nt, [&](int t) {
+        const int64_t lo = total * t / nt, hi = total * (t + 1) / nt;
+        int64_t i0 = std::lower_bound(boff.begin(), boff.begin() + m, lo) - boff.begin();
+        int64_t i1 = (t == nt - 1) ? m : std::lower_bound(boff.begin(), boff.begin() + m, hi) - boff.begin();
+        if (t == 0) i0 = 0;
+        for (int64_t i = i0; i < i1; ++i) {
+            const Rec &r = f->recs[(size_t)(rec_lo + i)];
+            uint8_t bb = 0;
+            uint8_t *bdst = nullptr;
+            Packer pk{(uint32_t *)(codes + soff[(size_t)i] * 16), (uint32_t *)(mask + soff[(size_t)i] * 8)};
+            if (f->check) walk_record_pack(buf, r, pk, bdst);
+            else (void)walk_record(buf, r, f->check, [&](uint8_t c) { pk.push(T.code[c]); }, &bb);
+            pk.finish((r.len + 63) / 64);
+        }
+    });
+    return IDL_OK;
+}
+
 }  // extern "C"

@@ -35,6 +35,7 @@ struct VecArgs {
     int64_t view_stride;
     int sc_slots;   // v2: slots (64 bases) staged in LDS at a time
     int64_t max_len; // upper bound on the sequence lengths, 0 = unknown
+    int ablate;      // diagnostic builds only (IDELUCS_VEC_ABLATE): 1 no row stores, 2 no H0 count, 4 no deltas, 8 raw epilogue
 };
 
 constexpr int STAGE_DWORDS = 256 + 128;  // 64 lanes x (4 code words + 2 mask words)
@@ -510,7 +511,7 @@ __global__ __launch_bounds__(64 * V2_WAVES, B16 ? 8 : 6) void vectorise2_kernel(
         for (int64_t sc = nsc - 1; sc >= 0; --sc) {
             const int nloc = (int)((nslots - sc * SC) < SC ? (nslots - sc * SC) : SC);
             T::stage(a, slot0, sc * SC, nloc, cod, msk, lane);
-            cnt0 += T::count_all(cod, msk, nloc, hist, lane);
+            if (!(a.ablate & 2)) cnt0 += T::count_all(cod, msk, nloc, hist, lane);
         }
         const int64_t windows0 = block_sum((int64_t)cnt0);
 
@@ -548,7 +549,7 @@ __global__ __launch_bounds__(64 * V2_WAVES, B16 ? 8 : 6) void vectorise2_kernel(
             const int v = view_at(vi);
             const int64_t out_base = (int64_t)v * a.view_stride + s * row_len;
             const int64_t eb = vrange[2 * v], ee = vrange[2 * v + 1];
-            const int ne = (int)(ee - eb);
+            const int ne = (a.ablate & 4) ? 0 : (int)(ee - eb);
             const bool mutated = ne > 0 && nsc > 0;
             const bool in_lds = ne <= V2_EDIT_CAP;      // edits preloaded into LDS
             const bool rec = in_lds && nsc == 1 && ne * K <= V2_LIST_CAP && vi + 1 < a.n_views;
@@ -614,7 +615,8 @@ __global__ __launch_bounds__(64 * V2_WAVES, B16 ? 8 : 6) void vectorise2_kernel(
                     typedef float f32x2 __attribute__((ext_vector_type(2)));
                     const f32x2 rS2 = {rS, rS}, nS2 = {-Sf, -Sf};
                     auto emit = [&](int i4, uint4 h) {         // four consecutive bins starting at 4*i4
-                        if (a.out_kind == IDL_OUT_COUNTS_I32) {
+                        if (a.ablate & 1) { if (h.x == 0xFFFFFFF0u) *(uint4 *)((uint32_t *)a.out + out_base + i4 * 4) = h; return; }
+                        if (a.out_kind == IDL_OUT_COUNTS_I32 || (a.ablate & 8)) {
                             *(uint4 *)((uint32_t *)a.out + out_base + i4 * 4) = h;
                         } else {
                             float4 f;
@@ -698,6 +700,7 @@ int launch_vectorise(const VecArgs &a_in, const idl::DeviceInfo &di, hipStream_t
     int sc = 160;                                       // 10240 bases staged at a time (cfg2's 10 kbp in one super-chunk)
     if (const char *e = getenv("IDELUCS_SC_SLOTS")) { const int t = atoi(e); if (t >= 1 && t <= 4096) sc = t; }
     a.sc_slots = sc;
+    if (const char *e = getenv("IDELUCS_VEC_ABLATE")) a.ablate = atoi(e);
     // 16-bit bins are possible while no count can reach 65536 (count <= max_len + 1).  Measured on MI355X (cfg2): 8
     // workgroups/CU with 16-bit bins (64 VGPRs, 80 B/lane of spill) run 2.16 ms, 6 workgroups/CU with 32-bit bins
     // (79 VGPRs) 1.98 ms -- so 32-bit is the default and 16-bit an opt-in experiment (IDELUCS_BINS=16).

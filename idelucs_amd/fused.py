@@ -124,6 +124,11 @@ class FusedLinearTrainer:
         self._parts = (ctypes.c_int32 * n)(*self.parts)
         self._sz_no_w1 = (ctypes.c_int64 * n)(*([0] + [p.numel() for p in self.params[1:]]))     # W1 updated by idl_wgrad_rmsprop
 
+    def begin_voter(self, voter):
+        """Dropout stream of voter v: the Philox counter word the kernels take from ctl[0] (its low 32 bits) starts at
+        v << 24, so voters never share masks whichever rank runs them (16.7 M optimizer steps per voter, 256 voters)."""
+        self.ctl[0] = (int(voter) & 0xFF) << 24
+
     def gradient(self, i):
         """Gradient of parameter i as a tensor of the parameter's shape (sums the stacked partials)."""
         return self.grads[i].sum(0) if self.parts[i] > 1 else self.grads[i]
@@ -320,7 +325,9 @@ class FusedLinearTrainer:
             bf = self.buffers(2 * batch_sz)
             if pipe:
                 self._gather(store, bf)         # prologue: batch 0; every later batch is assembled by the previous step
-            key = (2 * batch_sz, store.feats.data_ptr(), store.mean.data_ptr(), store.n, store.f, pipe, self._early_gather)
+            # every address the captured launches bake in is part of the key (a store refitted in place keeps its graph)
+            key = (2 * batch_sz, store.feats.data_ptr(), store.mean.data_ptr(), store.scale.data_ptr(), store.inv_scale.data_ptr(),
+                   self._perm.data_ptr(), store.n, store.f, store.n_views, pipe, self._early_gather)
             per = 2 if (pipe and self._early_gather) else 1      # steps per graph replay (two x buffers alternate)
             if use_graph and n_full >= 8:
                 g = self._graphs.get(key)

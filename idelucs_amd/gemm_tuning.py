@@ -11,8 +11,8 @@ enabled for any other shape (a few hundred ms per new GEMM shape, once per proce
 IDELUCS_TUNABLEOP=0 disables it; =1 forces it on.  By default it is enabled for jobs with at least
 MIN_STEPS optimizer steps (tuning unseen shapes costs more than it saves on tiny jobs).
 """
+import atexit
 import os
-import shutil
 import tempfile
 
 import torch
@@ -21,6 +21,13 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 SEED_FILE = os.path.join(_HERE, "tunableop_gfx950.csv")
 MIN_STEPS = 3000
 _enabled = False
+
+
+def _unlink_quietly(path):
+    try:
+        os.unlink(path)
+    except OSError:
+        pass
 
 
 def maybe_enable(total_steps=None):
@@ -36,9 +43,18 @@ def maybe_enable(total_steps=None):
         return False
     # one result file per process (ranks of a multi-GPU job must not share one), seeded from the shipped solutions
     dump = os.environ.get("IDELUCS_TUNABLEOP_DUMP")     # maintainers: write the tuned solutions there at exit (to refresh SEED_FILE)
-    path = dump or os.path.join(tempfile.gettempdir(), f"idelucs_tunableop_{os.getpid()}.csv")
-    if os.path.exists(SEED_FILE):
-        shutil.copyfile(SEED_FILE, path)
+    if dump:
+        path = dump
+        flags = os.O_WRONLY | os.O_CREAT | os.O_TRUNC | getattr(os, "O_NOFOLLOW", 0)
+        fd = os.open(path, flags, 0o600)
+    else:
+        # a fresh 0600 file of an unpredictable name (never an existing path or a symlink), removed at exit
+        fd, path = tempfile.mkstemp(prefix="idelucs_tunableop_", suffix=".csv")
+        atexit.register(_unlink_quietly, path)
+    with os.fdopen(fd, "wb") as out:
+        if os.path.exists(SEED_FILE):
+            with open(SEED_FILE, "rb") as src:
+                out.write(src.read())
     tn.set_filename(path, insert_device_ordinal=False)
     tn.enable(True)
     tn.tuning_enable(True)

@@ -91,6 +91,7 @@ class IID_model():
                                                          mode="triangular2")
         self.store = None
         self._fasta = None
+        self._voter = 0
         # default configuration (NetLinear + RMSprop): explicit fused step replayed as a HIP graph
         self._fused = None
         self._use_fused = (args['model_size'] == 'linear' and args['optimizer'] == 'RMSprop'
@@ -105,6 +106,18 @@ class IID_model():
         self.dataloader = utils.DeviceBatchLoader(self.store, self.batch_sz)
 
     # ------------------------------------------------------------------ training
+    def begin_voter(self, voter=0):
+        """A fresh voter (reference __main__.py:109: weights_init between voters).  The reference's voters differ because
+        its one process consumes the torch RNG sequentially; here voters may run on different ranks, so every stream a voter
+        draws from (Kaiming init, batch permutations, dropout) is a function of (seed, voter index) and voter v is the same
+        run whichever rank trains it.  The mimic/data seed stays shared: every rank builds the same feature store."""
+        self._voter = int(voter)
+        torch.manual_seed((int(self.seed) * 1000003 + 1 + self._voter) & (2 ** 63 - 1))     # CPU and every CUDA generator
+        self.net.apply(weights_init)
+        self.epoch = 0
+        if self._fused is not None:
+            self._fused.begin_voter(self._voter)
+
     def _step(self, x):
         """One optimizer step on a [2b, F] batch (rows [0,b) "true", [b,2b) "modified")."""
         b = x.shape[0] // 2
@@ -115,8 +128,9 @@ class IID_model():
         self.optimizer.step()
         return loss.detach()
 
-    def contrastive_training_epoch(self):
-        """Reference models.py:113-143: one pass over the shuffled N*n_mimics pairs."""
+    def contrastive_training_epoch(self, sync=True):
+        """Reference models.py:113-143: one pass over the shuffled N*n_mimics pairs -> the epoch loss as a Python float
+        (sync=False: as a device scalar, without waiting for the epoch to finish)."""
         self.net.train()
         st = self.store
         if self._use_fused:
@@ -126,10 +140,11 @@ class IID_model():
                 n_batches = (st.n_pairs + self.batch_sz - 1) // self.batch_sz
                 gemm_tuning.maybe_enable(n_batches * self.n_epochs * self.n_voters)
                 self._fused = FusedLinearTrainer(self.net, self.lr, self.weight, self.l, seed=self.seed)
+                self._fused.begin_voter(self._voter)
             self._fused.set_lr(self.optimizer.param_groups[0]['lr'])       # schedulers act on the torch optimizer
             total, n_batches = self._fused.run_epoch(st, self.batch_sz)
             running_loss = total / (n_batches - 1)                          # models.py:135 quirk (divide by last index)
-            return self._finish_epoch(running_loss)
+            return self._finish_epoch(running_loss, sync)
         running_loss = torch.zeros((), device=self.device)
         perm = torch.randperm(st.n_pairs, device=self.device)
         i_batch = 0
@@ -137,19 +152,19 @@ class IID_model():
             x = st.gather_pairs(perm[i:i + self.batch_sz])
             running_loss += self._step(x)
         running_loss = running_loss / i_batch      # models.py:135 divides by the LAST INDEX (n_batches-1): kept
-        return self._finish_epoch(running_loss)
+        return self._finish_epoch(running_loss, sync)
 
-    def _finish_epoch(self, running_loss):
+    def _finish_epoch(self, running_loss, sync=True):
         if self.schedule == 'Plateau':
             self.scheduler.step(running_loss)
         elif self.schedule == 'Triangle':
             self.scheduler.step()
         self.epoch += 1
-        return running_loss.item()
+        return running_loss.item() if sync else running_loss
 
     # ------------------------------------------------------------------ inference
-    def _predict_outputs(self):
-        names, lengths, feats = utils.predict_features(self.sequence_file, k=self.k, reduce=self.reduce, device=self.device)
+    def _predict_outputs(self, rows=None):
+        names, lengths, feats = utils.predict_features(self.sequence_file, k=self.k, reduce=self.reduce, device=self.device, rows=rows)
         outs, lats = [], []
         with torch.no_grad():
             self.net.eval()
@@ -165,6 +180,13 @@ class IID_model():
         probs, predicted = torch.max(outputs, 1)
         return (predicted.cpu().numpy().astype(np.int64), probs.double().cpu().numpy(),
                 latent.double().cpu().numpy())
+
+    def predict_latent_shard(self, lo, hi):
+        """Rows [lo, hi) of predict()'s latent as a float32 device tensor [hi-lo, 64] (n_clusters=0 mode on several GPUs:
+        predict is sharded by sequence and the shards are all-gathered, idelucs_amd.dist.all_gather_rows)."""
+        if hi <= lo:
+            return torch.empty((0, 64), dtype=torch.float32, device=self.device)
+        return self._predict_outputs(rows=(lo, hi))[1].float().contiguous()
 
     def calculate_probs(self, data=None):
         """Reference models.py:175-195 -> float64 [N, n_clusters] softmax outputs."""

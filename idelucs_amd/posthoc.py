@@ -103,6 +103,34 @@ def compute_results(y_pred, data, y_true=None):
     return d, ind
 
 
+def plot_confusion_matrix(cm, target_names, pairs=None, title="Confusion matrix", cmap=None, normalize=False, ax=None):
+    """The picture the reference CLI saves as contingency_matrix.jpg when n_clusters < 16 (utils.py:527-577, called at
+    __main__.py:178): the matrix as a 'Blues' heat map with one text cell per entry, class names on the y axis, accuracy
+    (trace, or the cells named by `pairs`) and misclassification rate under the x axis; tables with more than 16 classes are
+    replaced by a pointer to the .tsv."""
+    import matplotlib.pyplot as plt
+    cm = np.asarray(cm)
+    if len(target_names) > 16:
+        ax.text(0, 0.5, "The confusion matrix is too big to display, see .tsv file instead", fontsize=12)
+        ax.axis("off")
+        return
+    hits = np.trace(cm) if not isinstance(pairs, np.ndarray) else sum(cm[j][i] for i, j in pairs)
+    accuracy = hits / float(cm.sum())
+    ax.imshow(cm, interpolation="nearest", cmap=cmap if cmap is not None else plt.get_cmap("Blues"))
+    ax.set_title(title)
+    if target_names is not None:
+        ticks = np.arange(len(target_names))
+        ax.set_xticks(ticks); ax.set_xticklabels([""] * len(target_names))
+        ax.set_yticks(ticks); ax.set_yticklabels(target_names)
+    shown = cm.astype("float") / cm.sum(axis=1)[:, np.newaxis] if normalize else cm
+    thresh = shown.max() / (1.5 if normalize else 2)
+    fmt = "{:0.3f}" if normalize else "{:,}"
+    for (i, j), val in np.ndenumerate(shown):
+        ax.text(j, i, fmt.format(val), horizontalalignment="center", color="white" if val > thresh else "black")
+    ax.set_ylabel("True label")
+    ax.set_xlabel("Predicted label\naccuracy={:0.4f}; misclass={:0.4f}".format(accuracy, 1 - accuracy))
+
+
 def fine_grained_clusters(latent):
     """n_clusters=0 mode (reference __main__.py:82-83,153-156): HDBSCAN(min_cluster_size=N//100+1) on the
     last voter's latent; labels+1, probabilities.  `hdbscan` is used when importable, else

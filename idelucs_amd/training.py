@@ -20,7 +20,6 @@ def train_voter(model, n_epochs, voter=0, n_voters=1, progress=True):
     if progress:
         sys.stdout.write(f"\r........... Training Model ({voter + 1}/{n_voters})................")
         sys.stdout.flush()
-    model.net.apply(models.weights_init)
-    model.epoch = 0
+    model.begin_voter(voter)
     curve = [model.contrastive_training_epoch() for _ in range(n_epochs)]
     return (curve,) + tuple(model.predict())

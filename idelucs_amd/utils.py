@@ -77,8 +77,11 @@ class FastaFile:
     pass (utils.py:137-188, :224-260, :279-317)."""
 
     def __init__(self, fname, check=True, keep_bytes=False, pack=True):
+        """pack: True = packed codes/mask exported now; False = no packed data; "deferred" = the parsed file stays open and
+        record ranges are packed on request (pack_range) -- the streamed ingest of build_feature_store."""
         h = ctypes.c_void_p()
         _lib.check(_L.idl_fasta_open(os.fsencode(fname), 1 if check else 0, ctypes.byref(h)))
+        self._h = None
         try:
             n, tb, ts, nb = (ctypes.c_int64() for _ in range(4))
             _lib.check(_L.idl_fasta_sizes(h, ctypes.byref(n), ctypes.byref(tb), ctypes.byref(ts), ctypes.byref(nb)))
@@ -88,7 +91,7 @@ class FastaFile:
             self.lengths = np.empty(self.n, np.int64)
             self.byte_off = np.empty(self.n + 1, np.int64)
             self.bytes = np.empty(max(self.total_bases, 1), np.uint8) if keep_bytes else None
-            if pack:
+            if pack is True:
                 self.codes = np.empty(max(self.total_slots, 1) * 16, np.uint8)
                 self.mask = np.empty(max(self.total_slots, 1) * 8, np.uint8)
                 self.slot_off = np.empty(self.n + 1, np.int64)
@@ -96,14 +99,35 @@ class FastaFile:
                 self.codes = self.mask = self.slot_off = None
             _lib.check(_L.idl_fasta_export(h, _ptr(names), _ptr(name_off), _ptr(self.lengths), _ptr(self.bytes),
                                            _ptr(self.byte_off), _ptr(self.codes), _ptr(self.mask), _ptr(self.slot_off)))
+            if pack == "deferred":
+                self.slot_off = np.zeros(self.n + 1, np.int64)
+                np.cumsum((self.lengths + 63) // 64, out=self.slot_off[1:])
+                self._h, h = h, None
         finally:
-            _L.idl_fasta_close(h)
+            if h is not None:
+                _L.idl_fasta_close(h)
         raw = names.tobytes()
         self.names = [raw[name_off[i]:name_off[i + 1]].decode() for i in range(self.n)]   # utils.py:172 .decode()
         if check:
             for nm in self.names:   # unicode-whitespace first characters the byte-level check cannot see
                 if len(nm) > 0 and nm[0].isspace():
+                    self.close()
                     raise ValueError("Bad character in sequence header")
+
+    def pack_range(self, lo, hi, codes, mask):
+        """Translate + 2-bit pack records [lo, hi) into the whole-file buffers `codes` / `mask` (host uint8 tensors or arrays
+        of total_slots * 16 / * 8 bytes) at their slot offsets (idl_fasta_pack_range); needs pack="deferred"."""
+        if self._h is None:
+            raise ValueError("pack_range needs FastaFile(pack='deferred')")
+        _lib.check(_L.idl_fasta_pack_range(self._h, int(lo), int(hi), _ptr(codes), _ptr(mask)))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None:
+            _L.idl_fasta_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
 
     def record(self, i):
         return bytearray(self.bytes[self.byte_off[i]:self.byte_off[i + 1]].tobytes())
@@ -312,7 +336,17 @@ def _philox_edits(dev_in, specs, seed, capacity=None):
         dev_in.min_len = int(dev_in.lengths.min().item())
     if np.any(n_rn > 0) and dev_in.n > 0 and dev_in.min_len <= 0:
         raise ValueError("high <= 0")   # np.random.randint(0, 0, n) in the reference's Random_N (utils.py:93)
-    dev = dev_in.codes.device
+    # limits of the device generator (csrc/mimic.hip): positions are packed into 30 bits, per-lane site counts into 16
+    max_len = int(getattr(dev_in, "max_len", 0) or (dev_in.lengths.max().item() if dev_in.n else 0))
+    if max_len >= (1 << 30):
+        raise ValueError("mutated sequences longer than 2^30 bases are not supported")
+    per_lane = (max_len + 63) // 64
+    for a, b in zip(p_ts, p_tv):
+        mean = per_lane * (1.0 - (1.0 - a) * (1.0 - b))
+        if per_lane > 65535 and mean + 12.0 * mean ** 0.5 + 64.0 >= 65535.0:
+            raise ValueError(f"a {max_len}-base sequence at these mutation rates exceeds the device mimic generator's per-lane "
+                             "site counter; use rng='compat'")
+    dev = dev_in.lengths.device
     ws = torch.empty(_L.idl_mimic_workspace(dev_in.n, P), dtype=torch.uint8, device=dev)
     edit_off = torch.empty(P * dev_in.n + 1, dtype=torch.int64, device=dev)
     args = (_ptr(dev_in.lengths), dev_in.n, P, _ptr(p_ts), _ptr(p_tv), _ptr(n_rn), ctypes.c_uint64(seed & (2 ** 64 - 1)))
@@ -390,7 +424,14 @@ class FeatureStore:
         self.k, self.reduce = k, reduce
         self.n_views, self.n, self.f = feats.shape
         self.n_pairs = (self.n_views - 1) * self.n
-        self.inv_scale = 1.0 / scale            # correctly rounded float64 reciprocals (IEEE division on the device)
+        self.inv_scale = torch.empty_like(scale)
+        self.refresh()
+
+    def refresh(self):
+        """Recompute what is derived from `scale` IN PLACE (after col_stats(..., out=(mean, scale)) refitted the scaler into the
+        same buffers): the addresses a captured training-step graph holds stay valid."""
+        torch.div(1.0, self.scale, out=self.inv_scale)      # correctly rounded float64 reciprocals (IEEE division on the device)
+        return self
 
     def gather_pairs(self, pair_idx, out=None):
         """-> [2*B, F] float32: rows [0,B) 'true', [B,2B) 'modified' (AugmentedDataset.__getitem__)."""
@@ -402,13 +443,18 @@ class FeatureStore:
         return out
 
 
-def col_stats(x):
-    """StandardScaler().fit statistics of a device matrix [n, f] (float32 or float64) -> (mean, scale) float64."""
+def col_stats(x, out=None):
+    """StandardScaler().fit statistics of a device matrix [n, f] (float32 or float64) -> (mean, scale) float64.
+    out = (mean, scale): existing float64 [f] device buffers to refit in place."""
     n, f = x.shape
     dev = x.device
     ws = torch.empty(max(_L.idl_col_stats_workspace(n, f), 8), dtype=torch.uint8, device=dev)
-    mean = torch.empty(f, dtype=torch.float64, device=dev)
-    scale = torch.empty(f, dtype=torch.float64, device=dev)
+    if out is not None:
+        mean, scale = out
+        assert mean.dtype == scale.dtype == torch.float64 and mean.numel() == scale.numel() == f and mean.is_contiguous() and scale.is_contiguous()
+    else:
+        mean = torch.empty(f, dtype=torch.float64, device=dev)
+        scale = torch.empty(f, dtype=torch.float64, device=dev)
     _lib.check(_L.idl_col_stats(_ptr(x), 1 if x.dtype == torch.float64 else 0, n, f, _ptr(mean), _ptr(scale), _ptr(ws),
                                 _stream_ptr()))
     return mean, scale
@@ -424,11 +470,66 @@ def standardise(x, mean, scale, out=None):
     return out
 
 
-def build_feature_store(sequence_file, n_mimics, k=6, reduce=False, rng=None, seed=0, device=None, fasta=None):
-    """Vectorise every mimic view of every sequence in one kernel launch and fit the scaler."""
+def ingest_threads():
+    """Threads the C++ FASTA reader uses (IDELUCS_THREADS, default min(16, hardware threads))."""
+    return int(_L.idl_ingest_threads())
+
+
+class _StreamedInput:
+    """_DeviceInput filled chunk by chunk: the host reader translates + packs records [lo, hi) into pinned buffers while the
+    previous chunk's H2D copy is in flight on a copy stream (ingest overlapped with H2D).  The small arrays
+    (lengths, slot offsets) go first, so the device can draw the mimic sites while the bases are still being parsed."""
+
+    def __init__(self, ff, device, n_chunks=None):
+        self.n = ff.n
+        self.max_len = int(ff.lengths.max()) if ff.n else 0
+        self.min_len = int(ff.lengths.min()) if ff.n else 0
+        self.lengths = torch.from_numpy(ff.lengths).to(device, non_blocking=True)
+        self.slot_off = torch.from_numpy(ff.slot_off).to(device, non_blocking=True)
+        slots = max(ff.total_slots, 1)
+        self._hc = torch.empty(slots * 16, dtype=torch.uint8, pin_memory=True)
+        self._hm = torch.empty(slots * 8, dtype=torch.uint8, pin_memory=True)
+        self.codes = torch.empty(slots * 16, dtype=torch.uint8, device=device)
+        self.mask = torch.empty(slots * 8, dtype=torch.uint8, device=device)
+        self._ff, self._copy = ff, torch.cuda.Stream(device=device)
+        if n_chunks is None:
+            n_chunks = max(1, min(16, ff.total_slots * 24 // (32 << 20)))      # ~32 MB of packed data per chunk
+        cuts = np.searchsorted(ff.slot_off, np.linspace(0, ff.total_slots, n_chunks + 1)[1:-1]).tolist()
+        self._cuts = [0] + [int(c) for c in cuts] + [ff.n]
+
+    def fill(self):
+        ff = self._ff
+        for lo, hi in zip(self._cuts[:-1], self._cuts[1:]):
+            if hi <= lo:
+                continue
+            ff.pack_range(lo, hi, self._hc, self._hm)
+            a, b = int(ff.slot_off[lo]), int(ff.slot_off[hi])
+            with torch.cuda.stream(self._copy):
+                self.codes[a * 16:b * 16].copy_(self._hc[a * 16:b * 16], non_blocking=True)
+                self.mask[a * 8:b * 8].copy_(self._hm[a * 8:b * 8], non_blocking=True)
+        torch.cuda.current_stream().wait_stream(self._copy)
+        return self
+
+
+def build_feature_store(sequence_file, n_mimics, k=6, reduce=False, rng=None, seed=0, device=None, fasta=None, streamed=False):
+    """Vectorise every mimic view of every sequence in one kernel launch and fit the scaler.
+    streamed=True (device RNG only): parse once, pack record chunks into pinned memory and copy each chunk to the device
+    while the next is being packed; the mimic sites are drawn meanwhile (they need only the lengths)."""
     rng = rng or _default_rng_mode()
     dev = _device(device)
     tfs = mimic_transforms(n_mimics)
+    if streamed and rng == "philox" and fasta is None:
+        ff = FastaFile(sequence_file, check=True, pack="deferred")
+        try:
+            din = _StreamedInput(ff, dev)
+            edits, edit_off = _philox_edits(din, [t.spec() for t in tfs], seed)     # overlaps with the host packing below
+            din.fill()
+        finally:
+            ff.close()
+        mode = _lib.MODE_CANONICAL if reduce else _lib.MODE_KMER
+        feats = _vectorise(din, k, mode, _lib.INIT_ONE, _lib.OUT_FREQ_F32, len(tfs), edits, edit_off)
+        mean, scale = col_stats(feats[0])
+        return FeatureStore(ff.names, ff.lengths, feats, mean, scale, k, reduce)
     ff = fasta if fasta is not None else FastaFile(sequence_file, check=True, keep_bytes=(rng == "compat"))
     mode = _lib.MODE_CANONICAL if reduce else _lib.MODE_KMER
     if rng == "compat":
@@ -487,15 +588,19 @@ class AugmentedDataset(torch.utils.data.Dataset):
         return {"true": self.data[idx, 0, :], "modified": self.data[idx, 1, :]}
 
 
-def predict_features(sequence_file, k=6, reduce=False, device=None, fasta=None):
+def predict_features(sequence_file, k=6, reduce=False, device=None, fasta=None, rows=None):
     """What SequenceDataset feeds the network (utils.py:400-405 + models.py:163): un-mutated float64
-    frequencies, StandardScaler fit_transform in float64, rounded once to float32.  -> (names, lengths, [N,F] f32)."""
+    frequencies, StandardScaler fit_transform in float64, rounded once to float32.  -> (names, lengths, [N,F] f32).
+    rows=(lo, hi): the scaler is still fitted on ALL rows, only rows [lo, hi) are standardised and returned (sharded predict:
+    every rank recomputes the cheap statistics locally -- bit-identical everywhere, no collective -- and embeds its shard)."""
     dev = _device(device)
     ff = fasta if fasta is not None else FastaFile(sequence_file, check=True)
     din = _DeviceInput(ff, dev)
     mode = _lib.MODE_CANONICAL if reduce else _lib.MODE_KMER
     f64 = _vectorise(din, k, mode, _lib.INIT_ONE, _lib.OUT_FREQ_F64)[0]
     mean, scale = col_stats(f64)
+    if rows is not None:
+        f64 = f64[rows[0]:rows[1]]
     return ff.names, ff.lengths, standardise(f64, mean, scale)
 
 

@@ -303,6 +303,110 @@ def test_fused_graph_replay_equals_eager(dev):
     assert np.isfinite(results[0][1])
 
 
+def _cfg2_store_and_net(dev, n, seed=3, C=20):
+    """A feature store of cfg2's row shape (4 views x n x 4096, frequency-like rows) and a NetLinear(4096, C)."""
+    import torch
+    from idelucs_amd import utils as U, models
+    from idelucs_amd.PytorchUtils import NetLinear
+    g = torch.Generator(device=dev); g.manual_seed(seed)
+    P, F = 4, 4096
+    base = torch.rand((1, n, F), device=dev, generator=g) + 0.5
+    feats = base * (1.0 + 0.05 * torch.randn((P, n, F), device=dev, generator=g))       # mimic views = perturbed copies
+    feats = (feats / feats.sum(2, keepdim=True)).contiguous()
+    mean, scale = U.col_stats(feats[0])
+    store = U.FeatureStore(None, None, feats, mean, scale, 6, False)
+    torch.manual_seed(seed)
+    net = NetLinear(F, C).to(dev); net.apply(models.weights_init)
+    return store, net
+
+
+def test_default_fused_step_at_cfg2_shape_vs_autograd(dev):
+    """The launch sequence bench.py times -- FusedLinearTrainer._full_step(pipelined=True) with every default (transposed
+    layer-1 product -> mid_fwd_gather -> nce_fused_iic_z -> mid_bwd_gather -> dW1 GEMM -> rmsprop_step_gather_wgrad) at cfg2's
+    shape m=1024, F=4096, C=20 -- against torch autograd over idelucs_amd.LossFunctions (pinned to the reference goldens
+    above), dropout off: loss rel 2e-4, the six gradients rel 2e-3, parameters after RMSprop rel 1e-5 on identical
+    gradients; and the batch the step assembled for the NEXT step is the gather of the next 512 pairs."""
+    import copy
+    import torch
+    from idelucs_amd.fused import FusedLinearTrainer
+    from idelucs_amd.LossFunctions import IID_loss, info_nce_loss
+    store, net = _cfg2_store_and_net(dev, 2000)
+    ref_net = copy.deepcopy(net)
+    tr = FusedLinearTrainer(net, lr=1e-3, weight=0.25, lamb=2.8, seed=5)
+    assert tr._early_gather and tr._early_split and tr._transposed_l1 and tr._dw2_inlaunch and tr._mid_fused and tr._dw3_partial \
+        and tr._joint_inlaunch and not tr._nce_bwd_fused and not tr._wgrad_fused, "not the default launch sequence"
+    B = 512
+    gen = torch.Generator(device=dev); gen.manual_seed(9)
+    tr._perm = torch.randperm(store.n_pairs, device=dev, generator=gen)
+    tr.ctl[1] = 0; tr.out[1] = 0.0
+    bf = tr.buffers(2 * B)
+    assert bf.nce_fused
+    tr._gather(store, bf)                                       # prologue: batch 0 into bf.xs[0]
+    x = bf.xs[0].clone()
+    tr._full_step(store, bf, train=False, pipelined=True, xi=0)
+    torch.cuda.synchronize()
+    # --- autograd reference on the same batch, same initial parameters
+    ref_net.eval()
+    z, h = ref_net(x)
+    loss = 0.75 * info_nce_loss(h[:B], h[B:], 0.85) + 0.25 * IID_loss(z[:B], z[B:], lamb=2.8)
+    loss.backward()
+    assert abs(tr.out[0].item() - loss.item()) <= 2e-4 * abs(loss.item()), (tr.out[0].item(), loss.item())
+    ref_params = [ref_net.layers[0].weight, ref_net.layers[0].bias, ref_net.layers[3].weight, ref_net.layers[3].bias,
+                  ref_net.classifier[2].weight, ref_net.classifier[2].bias]
+    for i, p in enumerate(ref_params):
+        got, want = tr.gradient(i), p.grad
+        err = (got - want).abs().max().item()
+        assert err <= 2e-3 * want.abs().max().item() + 1e-9, (i, err, want.abs().max().item())
+        assert torch.allclose(got, want, rtol=2e-3, atol=2e-3 * want.abs().mean().item()), i
+    # --- RMSprop on IDENTICAL gradients (the trainer's own): torch.optim vs the fused optimizer launch
+    for i, p in enumerate(ref_params):
+        p.grad.copy_(tr.gradient(i))
+    torch.optim.RMSprop(ref_net.parameters(), lr=1e-3, weight_decay=0.01).step()
+    for i, (p, q) in enumerate(zip(tr.params, ref_params)):
+        bad = ~torch.isclose(p.detach(), q.detach(), rtol=1e-5, atol=1e-7)
+        # a first RMSprop step is lr * g / (0.1 |g| + eps): where the bias partials are summed in another order a near-zero
+        # gradient may flip; everything else must agree to 1e-5
+        assert bad.float().mean().item() < (2e-3 if p.dim() == 1 else 1e-5), (i, bad.float().mean().item())
+    assert tr.ctl.tolist() == [1, B]
+    # --- the next batch, assembled by spare workgroups of the two middle launches into the other x buffer
+    want_next = store.gather_pairs(tr._perm[B:2 * B])
+    assert torch.equal(bf.xs[1], want_next)
+
+
+def test_graph_replay_equals_eager_at_cfg2_shape(dev):
+    """A whole epoch at cfg2's step shape (F=4096, batch 512, C=20; 8 full batches + a partial one, dropout ON) replayed
+    from the captured two-step HIP graph vs launched eagerly: same permutation, same dropout stream, same start."""
+    import copy
+    import torch
+    from idelucs_amd.fused import FusedLinearTrainer
+    store, net0 = _cfg2_store_and_net(dev, 1500, seed=4)
+    B = 512
+    results = []
+    for use_graph in (False, True):
+        net = copy.deepcopy(net0)
+        tr = FusedLinearTrainer(net, lr=1e-3, weight=0.25, lamb=2.8, seed=11)
+        gen = torch.Generator(device=dev); gen.manual_seed(77)
+        total, nb = tr.run_epoch(store, B, use_graph=use_graph, generator=gen)
+        torch.cuda.synchronize()
+        assert nb == 9 and tr.ctl.tolist() == [9, store.n_pairs]
+        if use_graph:
+            assert len(tr._graphs) == 1, "the epoch did not go through a captured graph"
+        results.append(([p.detach().clone() for p in tr.params], total.item()))
+    for a, b in zip(results[0][0], results[1][0]):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-7)
+    assert np.isfinite(results[0][1]) and abs(results[0][1] - results[1][1]) <= 1e-4 * abs(results[0][1])
+    # a second epoch on the same store replays the SAME graph (nothing re-captured) ...
+    g_before = next(iter(tr._graphs.values()))
+    tr.run_epoch(store, B, generator=gen)
+    assert next(iter(tr._graphs.values())) is g_before
+    # ... also after the scaler was refitted IN PLACE (bench.py / a new voter): every baked address is unchanged
+    from idelucs_amd import utils as U
+    U.col_stats(store.feats[1], out=(store.mean, store.scale)); store.refresh()
+    tr.run_epoch(store, B, generator=gen)
+    torch.cuda.synchronize()
+    assert next(iter(tr._graphs.values())) is g_before and all(torch.isfinite(p).all() for p in tr.params)
+
+
 # ------------------------------------------------------------------------------------------------
 # the other configurations of the reference surface
 # ------------------------------------------------------------------------------------------------

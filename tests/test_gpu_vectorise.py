@@ -353,6 +353,41 @@ def test_size_independent_properties_at_full_size(gpu):
     assert ca.shape[1] == 2080 and torch.all(ca.sum(1) <= (L - (k - 1)) // 2 + 64) and torch.all(ca.sum(1) >= (L - k + 1 - 2080) // 2)
 
 
+def test_cfg2_full_size_store_properties(gpu):
+    """The exact workload bench.py times (BASELINE configs[1]: 100 000 x 10 kbp, k=6, 4 views, device-drawn mimic sites; byte
+    offsets of the 6.55 GB store pass 4 GiB), checked through size-independent properties: per view the counts sum to the
+    number of valid windows (XOR-only views keep all L-k+1, the Random_N view loses <= 20*k), every float32 row equals
+    (count + 1) / (windows + 4^k) recomputed from the integer counts, rows sum to 1, and the views differ."""
+    import torch
+    from idelucs_amd import _lib, utils as U
+    import importlib.util
+    tools = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools")
+    spec = importlib.util.spec_from_file_location("bench_vectorise", os.path.join(tools, "bench_vectorise.py"))
+    bv = importlib.util.module_from_spec(spec); spec.loader.exec_module(bv)
+    dev = torch.device("cuda")
+    n, L, k, P = 100000, 10000, 6, 4
+    F = 4 ** k
+    din = bv.synth_input(n, L, dev)
+    edits, edit_off = U._philox_edits(din, [t.spec() for t in U.mimic_transforms(P - 1)], 12345)
+    feats = U._vectorise(din, k, _lib.MODE_KMER, _lib.INIT_ONE, _lib.OUT_FREQ_F32, P, edits, edit_off)
+    counts = U._vectorise(din, k, _lib.MODE_KMER, _lib.INIT_ZERO, _lib.OUT_COUNTS_I32, P, edits, edit_off)
+    assert feats.numel() * 4 > 2 ** 32 and tuple(feats.shape) == (P, n, F)
+    for v in range(P):
+        S = counts[v].sum(1, dtype=torch.int64)
+        if v < 3:
+            assert torch.all(S == L - (k - 1)), v
+        else:
+            assert int(S.max()) <= L - (k - 1) and int(S.min()) >= L - (k - 1) - 20 * k, v
+        for lo in range(0, n, 25000):          # chunked: the float64 temporaries of 100 000 rows would be 3.3 GB each
+            c = counts[v, lo:lo + 25000]
+            want = ((c + 1).double() / (S[lo:lo + 25000] + F).double().unsqueeze(1)).float()
+            assert torch.equal(feats[v, lo:lo + 25000], want), (v, lo)
+            assert torch.allclose(feats[v, lo:lo + 25000].double().sum(1), torch.ones(c.shape[0], dtype=torch.float64, device=dev), atol=1e-6)
+    assert not torch.equal(counts[0, :1000], counts[1, :1000]) and not torch.equal(counts[1, :1000], counts[2, :1000])
+    # the last rows of the last view (highest addresses) are real rows, not left-overs
+    assert int(counts[P - 1, n - 1].sum()) >= L - (k - 1) - 20 * k
+
+
 def test_full_size_v1_and_v2_kernels_agree_bitwise(gpu, monkeypatch):
     """cfg2-shaped batch (20 000 x 10 kbp, 4 views, device-drawn mimic edits): the single-pass kernel (full recount per
     view, edits applied to a staged copy) and the delta-view kernel (one count + XOR-mask window moves) are independent

@@ -250,3 +250,30 @@ def test_first_error_in_file_order_wins(tmp_path, monkeypatch):
     with pytest.raises(ValueError) as e2:
         list(O.fasta_records(str(p)))
     assert str(e2.value) == str(e.value)
+
+
+@pytest.mark.parametrize("threads", ["1", "5"])
+def test_ranged_packing_equals_whole_file_export(tmp_path, monkeypatch, threads):
+    """idl_fasta_pack_range (the streamed ingest: record chunks packed into the whole-file buffers at their slot offsets)
+    gives the same bytes as idl_fasta_export, whatever the chunking, also on Influenza-A."""
+    monkeypatch.setenv("IDELUCS_THREADS", threads)
+    monkeypatch.setenv("IDELUCS_PAR_MIN", "0")
+    rng = np.random.default_rng(5)
+    fn = str(tmp_path / "r.fas")
+    _random_fasta(fn, rng, 41)
+    for path in (fn, os.path.join(DATA, "Influenza-A.fas")):
+        whole = U.FastaFile(path)
+        ff = U.FastaFile(path, pack="deferred")
+        assert np.array_equal(ff.slot_off, whole.slot_off) and ff.names == whole.names
+        codes = np.full(whole.codes.size, 0xAB, np.uint8); mask = np.full(whole.mask.size, 0xCD, np.uint8)
+        cuts = sorted(set([0, ff.n] + rng.integers(0, ff.n + 1, 6).tolist()))
+        for lo, hi in list(zip(cuts[:-1], cuts[1:]))[::-1]:         # any order
+            ff.pack_range(lo, hi, codes, mask)
+        ff.pack_range(3, 3, codes, mask)                             # empty range: no-op
+        assert np.array_equal(codes, whole.codes) and np.array_equal(mask, whole.mask)
+        with pytest.raises(ValueError):
+            ff.pack_range(0, ff.n + 1, codes, mask)
+        ff.close()
+        with pytest.raises(ValueError):
+            ff.pack_range(0, 1, codes, mask)
+    assert 1 <= U.ingest_threads() <= 256

@@ -18,6 +18,8 @@
 //   idelucs/utils.py:54-135  transforms   -> substitution edits (XOR on 2-bit codes / set-N)
 #include <stdlib.h>
 
+#include <vector>
+
 #include "common.h"
 
 namespace {
@@ -35,6 +37,11 @@ struct VecArgs {
     int64_t view_stride;
     int sc_slots;   // v2: slots (64 bases) staged in LDS at a time
     int64_t max_len; // upper bound on the sequence lengths, 0 = unknown
+    int *redo_count; // v3 -> v2 hand-over: number of sequences v3 left to the second pass (device word); v2 with redo != 0 takes exactly those
+    int redo, v3_sc; //   (a sequence is v3's iff its edits fit ecap, its pairs lcap and its slots v3_sc)
+    int blocked;     // v3: every workgroup owns a run of consecutive sequences (else: sequences dealt round-robin)
+    int ecap, lcap;  // v3: LDS capacity for the staged edits of all views / for the recorded (edit, window) pairs
+    unsigned long long *dbg;   // diagnostic (IDELUCS_VEC_DBG): per-workgroup cycle sums of the phases
     int ablate;      // diagnostic builds only (IDELUCS_VEC_ABLATE): 1 no row stores, 2 no H0 count, 4 no deltas, 8 raw epilogue
 };
 
@@ -498,11 +505,21 @@ __global__ __launch_bounds__(64 * V2_WAVES, B16 ? 8 : 6) void vectorise2_kernel(
     const uint32_t iv = (a.init == IDL_INIT_ONE) ? 1u : 0u;
     const uint32_t ivw = B16 ? iv * 0x00010001u : iv;
 
+    if (a.redo != 0 && *(const volatile int *)a.redo_count == 0) return;     // second pass after v3 with nothing left to do
     for (int64_t s = blockIdx.x; s < a.n; s += gridDim.x) {
         const int64_t slot0 = a.slot_off[s];
         const int64_t nslots = a.slot_off[s + 1] - slot0;
         const int64_t L = a.lengths[s];
         const int64_t nsc = (nslots + SC - 1) / SC;
+        if (a.redo != 0) {      // second pass: only the sequences v3 left alone (the predicate of vectorise3_kernel's stage_next, restated)
+            int64_t te = 0;
+            if (a.edits != nullptr)
+                for (int v = 0; v < a.n_views; ++v) {
+                    const int64_t d = a.edit_off[(int64_t)v * a.n + s + 1] - a.edit_off[(int64_t)v * a.n + s];
+                    te += d < 0 ? 0 : (d > 0x3FFFFFF ? 0x3FFFFFF : d);
+                }
+            if (te <= (int64_t)a.ecap && te * K <= (int64_t)a.lcap && nslots >= 0 && nslots <= (int64_t)a.v3_sc && L >= 0 && L <= nslots * 64) continue;
+        }
 
         for (int i = lane; i < T::HD / 4; i += NT) *(uint4 *)(hist + i * 4) = make_uint4(ivw, ivw, ivw, ivw);
 
@@ -665,6 +682,456 @@ __global__ __launch_bounds__(64 * V2_WAVES, B16 ? 8 : 6) void vectorise2_kernel(
     }
 }
 
+// =====================================================================================================
+// v3: the software-pipelined form of v2 for sequences that fit one staged super-chunk (the bench shape).
+// Measured on v2 (profiles/r02_a_vectorise_ablation.txt): with the row stores removed the launch still takes 1.62 of its
+// 1.96 ms, and with counting, deltas and stores ALL removed 0.77 ms remain -- a workgroup spends its time in dependent trips to
+// memory (slot range -> packed bases -> edit ranges -> edits), in 40 barriers per sequence, and, because vmcnt retires in
+// order, every wait for such a load also drains the row stores issued before it.  v3 removes those:
+//   * everything a sequence needs (slot range, length, edit ranges; then packed bases, invalid mask, every view's edits)
+//     arrives by LDS-DMA (global_load_lds) issued ONE sequence ahead (meta: two ahead) by wave 0 -- no register, no dependent
+//     round trip on the critical path, no ordinary global load in the loop at all; the DMA is retired by a COUNTED vmcnt placed
+//     in front of the last view's row stores, so no store is ever waited for;
+//   * ONE pass evaluates the (edit, window) pairs of ALL views from the pristine staged copy, while H0 is being counted
+//     (LDS atomics commute), and records them as (old bin, new bin) in LDS; a view change is then "undo list a + apply list b"
+//     in one phase; the histogram a thread owns is read into registers, so dividing / storing view a overlaps that phase;
+//   * 9 barriers per sequence instead of 40; window counts travel through LDS counters instead of block reductions.
+// A sequence whose edits / pairs do not fit the LDS tables takes a slower in-kernel path (per-view pair passes, like v2).
+// =====================================================================================================
+constexpr int V3_MAXV = 8;                      // views
+constexpr int V3_META = 8 + 4 * V3_MAXV;        // dwords of a meta ring entry: slot_off[s], slot_off[s+1], lengths[s], pad; per view edit_off[v*n+s], [..+1]
+constexpr int V3_VT = 4;                        // dwords of a view-table row: edits, first edit's index in LDS, first pair's index in the list, spare
+constexpr int V3_VTAB = (V3_MAXV + 1) * V3_VT;  // row 0 = header: flags (1 fast, 2 edits staged), total pairs, staged slots, clamped length
+
+__device__ __forceinline__ uint32_t lds_addr(const void *p) { return (uint32_t)(uintptr_t)p; }   // LDS byte offset = low half of the flat address
+
+// LDS-DMA, hidden from the compiler's vmcnt bookkeeping on purpose (cdna_hip_programming.md 5.7): destination = M0 + lane * size
+__device__ __forceinline__ void dma16(const void *gsrc, uint32_t lds_byte)
+{
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_byte) : "memory");
+}
+__device__ __forceinline__ void dma4(const void *gsrc, uint32_t lds_byte)
+{
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_byte) : "memory");
+}
+template <int N> __device__ __forceinline__ void vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+// wait until at most `younger` of this wave's vector-memory operations are outstanding (a smaller count is always safe)
+__device__ __forceinline__ void vm_wait_at_most(int younger)
+{
+    if (younger >= 48) vm_wait<48>();
+    else if (younger >= 32) vm_wait<32>();
+    else if (younger >= 16) vm_wait<16>();
+    else if (younger >= 12) vm_wait<12>();
+    else if (younger >= 8) vm_wait<8>();
+    else if (younger >= 4) vm_wait<4>();
+    else if (younger >= 3) vm_wait<3>();
+    else if (younger >= 2) vm_wait<2>();
+    else if (younger >= 1) vm_wait<1>();
+    else vm_wait<0>();
+}
+
+template <int K>
+struct V3 {
+    using T = V2<K, false>;
+    static constexpr int F = T::F, HD = T::HD;
+    static constexpr uint32_t KM = T::KM, VM = T::VM;
+
+    // (old bin, new bin) of pair q = (edit q / K, window offset q % K) of one view; 0xFFFF = no such window / invalid window
+    template <typename EP>
+    static __device__ __forceinline__ void pair_eval(EP E, int ne, int q, int end_r, const uint32_t *cod, const uint32_t *msk,
+                                                     uint32_t &ko, uint32_t &kn)
+    {
+        ko = 0xFFFFu; kn = 0xFFFFu;
+        const int ei = q / K, t = q - ei * K;
+        const uint32_t ed = E[ei];
+        const int p = (int)(ed & 0x3FFFFFFFu);
+        int last = p + K - 1;
+        if (ei + 1 < ne) { const int nx = (int)(E[ei + 1] & 0x3FFFFFFFu) - 1; if (nx < last) last = nx; }
+        if (last > end_r) last = end_r;
+        const int w = p + t;
+        if (w <= last) {
+            const uint32_t rel = (uint32_t)w + 64u;
+            const int D = (int)(rel >> 4), j = (int)(rel & 15u);
+            uint64_t ww; uint32_t M;
+            T::fetch(cod, msk, D, ww, M);
+            if (((M >> (15 - j)) & VM) == 0u) {
+                ko = (uint32_t)(ww >> (30 - 2 * j)) & KM;
+                uint32_t xm = (ed >> 30) << (2 * t);
+                bool dead = (ed >> 30) == 0u;
+                for (int i = ei - 1; i >= 0; --i) {          // earlier edits that also lie inside this window (rare)
+                    const uint32_t e2 = E[i];
+                    const int d = w - (int)(e2 & 0x3FFFFFFFu);
+                    if (d >= K) break;
+                    dead |= (e2 >> 30) == 0u;
+                    xm ^= (e2 >> 30) << (2 * d);
+                }
+                kn = dead ? 0xFFFFu : (ko ^ xm);
+            }
+        }
+    }
+
+    // All K windows of ONE edit: the windows ending at p .. p + K - 1 that this edit owns (it is the latest edit at or before
+    // their end: w <= min(p + K - 1, next edit - 1, last base)).  One 32-base fetch serves the K old bins; the XORs / N flags of
+    // the earlier edits that still reach into those windows (rare) are gathered once as X (2 bits per base back from p) and
+    // Dm (1 bit per base), so window t changes by (X << 2t) & KM and is dead when (Dm << t) & VM.  ko[t] | kn[t] << 16 per window,
+    // 0xFFFF = no such window / invalid window.
+    template <typename EP>
+    static __device__ __forceinline__ void edit_eval(EP E, int ne, int ei, int end_r, const uint32_t *cod, const uint32_t *msk, uint32_t (&pr)[K])
+    {
+        const uint32_t ed = E[ei];
+        const int p = (int)(ed & 0x3FFFFFFFu);
+        int last = p + K - 1;
+        if (ei + 1 < ne) { const int nx = (int)(E[ei + 1] & 0x3FFFFFFFu) - 1; if (nx < last) last = nx; }
+        if (last > end_r) last = end_r;
+        uint32_t X = ed >> 30, Dm = (ed >> 30) == 0u ? 1u : 0u;
+        for (int i = ei - 1; i >= 0; --i) {
+            const uint32_t e2 = E[i];
+            const int d = p - (int)(e2 & 0x3FFFFFFFu);
+            if (d >= K) break;
+            X ^= (e2 >> 30) << (2 * d);
+            Dm |= ((e2 >> 30) == 0u ? 1u : 0u) << d;
+        }
+        // 32 staged bases ending at the end of the word that holds base p + K - 1 (staged index = position + 64: slot 0 is the halo)
+        const int pt = (p + K - 1 < end_r) ? p + K - 1 : end_r;    // never fetch past the last base (positions are < L, so pt >= p)
+        const uint32_t top = (uint32_t)pt + 64u;
+        const int D = (int)(top >> 4);
+        uint64_t ww; uint32_t M;
+        T::fetch(cod, msk, D, ww, M);
+        const int e0 = 15 - (int)(top & 15u) + (pt - p);           // bases between p and the end of the fetched word
+#pragma unroll
+        for (int t = 0; t < K; ++t) {
+            uint32_t ko = 0xFFFFu, kn = 0xFFFFu;
+            const int sh = (e0 - t) & 31;                            // window t ends sh bases before the end of the word (negative only past `last`)
+            if (p + t <= last && ((M >> sh) & VM) == 0u) {
+                ko = (uint32_t)(ww >> (2 * sh)) & KM;
+                kn = ((Dm << t) & VM) ? 0xFFFFu : (ko ^ ((X << (2 * t)) & KM));
+            }
+            pr[t] = ko | (kn << 16);
+        }
+    }
+
+    static __device__ __forceinline__ void move(uint32_t *hist, uint32_t ko, uint32_t kn, uint32_t s_old, uint32_t s_new)
+    {
+        if (ko != kn) {
+            if (ko != 0xFFFFu) atomicAdd(&hist[ko], s_old);
+            if (kn != 0xFFFFu) atomicAdd(&hist[kn], s_new);
+        }
+    }
+
+    // every window ending in the staged sequence (v2's count_all without its barrier); returns this thread's valid windows
+    template <int NT>
+    static __device__ __forceinline__ uint32_t count_all(const uint32_t *cod, const uint32_t *msk, int nloc, uint32_t *hist, int tid)
+    {
+        uint32_t cnt = 0;
+        const int nd = nloc * 4;
+        for (int d0 = 0; d0 < nd; d0 += NT) {
+            const int d = d0 + tid;
+            if (d < nd) {
+                uint64_t w; uint32_t M;
+                T::fetch(cod, msk, 4 + d, w, M);
+                uint32_t inv = M;
+#pragma unroll
+                for (int t = 1; t < K; ++t) inv |= (M >> t);
+                inv &= 0xFFFFu;
+                if (__ballot(inv != 0u) == 0ull) {
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) atomicAdd(&hist[(uint32_t)(w >> (30 - 2 * j)) & KM], 1u);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) {
+                        const uint32_t km = (uint32_t)(w >> (30 - 2 * j)) & KM;
+                        atomicAdd(&hist[((inv >> (15 - j)) & 1u) ? (uint32_t)F + (tid & 3) : km], 1u);
+                    }
+                }
+                cnt += 16u - (uint32_t)__popc(inv);
+            }
+        }
+        return cnt;
+    }
+};
+
+// Workgroup = 4 COMPUTE waves (LDS only: counting, edit evaluation, list phases; they never issue a vector-memory instruction)
+// + 1 MEMORY wave (every LDS-DMA load of the next sequence and every row store: it reads the finished histogram into
+// registers between two barriers, then converts and stores while the compute waves are already moving the histogram to the
+// next view).  A full store queue -- the chip's write stream is the bound of this kernel -- therefore stalls only the wave that
+// has nothing else to do, and the DMA waits of that wave never queue behind another wave's work.
+constexpr int V3_NC = 256;                      // compute threads
+constexpr int V3_NT = V3_NC + 64;               // + the memory wave
+
+template <int K, bool DIAG>
+__global__ __launch_bounds__(V3_NT, 5) void vectorise3_kernel(VecArgs a)
+{
+    using W = V3<K>;
+    constexpr int F = W::F, HD = W::HD, NC = V3_NC, RP = (F / 4) / 64;      // RP: 16-byte pieces of a row per lane of the memory wave
+    static_assert((F / 4) % 64 == 0 && RP >= 1 && RP <= 16, "a row is held by one wave: 4^k in 256..4096");
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const int SC = a.sc_slots, P = a.n_views;
+    const int SET = (SC + 1) * 6 + a.ecap;                  // words of one staging set
+    uint32_t *hist = lds;                                   // F bins + 4 garbage bins
+    uint32_t *sets = hist + HD;                             // two staging sets (sequence it lives in set it & 1), each:
+    //   cod  (SC + 1) slots x 4 words, slot 0 = halo (zeros) | msk  (SC + 1) slots x 2 words, slot 0 = halo (all invalid) | edl  a.ecap edits of all views
+    uint32_t *list = sets + 2 * SET;                        // a.lcap pairs: old bin | new bin << 16
+    uint32_t *meta = list + a.lcap;                         // ring of 3 entries
+    uint32_t *vtab = meta + 3 * V3_META;                    // two view tables (this sequence / the next)
+    int32_t *ctr = (int32_t *)(vtab + 2 * V3_VTAB);         // [0] valid windows of the un-mutated sequence, [1 + v] window delta of view v
+    const int tid = threadIdx.x, lane = tid & 63;
+    const bool mem = __builtin_amdgcn_readfirstlane(tid >> 6) == NC / 64;      // the memory wave
+    const uint32_t iv = (a.init == IDL_INIT_ONE) ? 1u : 0u;
+    const bool has_edits = a.edits != nullptr;
+
+    // this workgroup's sequences: s_i = s_first + i * s_step, i < s_count (dealt round-robin; a.blocked: a run of consecutive ones)
+    int64_t s_first, s_step, s_count;
+    {
+        const int64_t G = gridDim.x, b = blockIdx.x;
+        if (a.blocked) {
+            const int64_t per = (a.n + G - 1) / G;
+            s_first = b * per; s_step = 1;
+            s_count = a.n - s_first < per ? a.n - s_first : per;
+            if (s_count < 0) s_count = 0;
+        } else {
+            s_first = b; s_step = G;
+            s_count = (a.n - b + G - 1) / G;
+        }
+    }
+
+    // ---------------- memory wave: slot range, length and edit ranges of sequence s -> meta ring entry r (one DMA instruction)
+    auto dma_meta = [&](int64_t s, int r) {
+        int l = lane;
+        asm volatile("" : "+v"(l));            // keeps the per-lane source address from being hoisted out of the sequence loop (and spilled there)
+        const uint32_t *src = nullptr;
+        if (l < 4) src = (const uint32_t *)(a.slot_off + s) + l;
+        else if (l < 6) src = (const uint32_t *)(a.lengths + s) + (l - 4);
+        else if (l >= 8 && l < 8 + 4 * P && has_edits) src = (const uint32_t *)(a.edit_off + (int64_t)((l - 8) >> 2) * a.n + s) + ((l - 8) & 3);
+        if (src != nullptr) dma4(src, __builtin_amdgcn_readfirstlane(lds_addr(meta + r * V3_META)));
+    };
+    // ---------------- memory wave: view table of the sequence described by ring entry r + the DMA of its packed bases, mask and
+    // edits into staging set `st`.  A sequence that does not fit the tables is only flagged (the launcher's second pass takes it).
+    auto stage_next = [&](int r, uint32_t *vt, uint32_t *st) {
+        int ln = lane;
+        asm volatile("" : "+v"(ln));           // per-lane source addresses are formed here, per call: hoisted out of the sequence loop they are spilled
+        uint32_t *cod = st, *msk = st + (SC + 1) * 4, *edl = st + (SC + 1) * 6;
+        const uint32_t *M = meta + r * V3_META;
+        const int64_t slot0 = (int64_t)(((uint64_t)M[1] << 32) | M[0]);
+        const int64_t nsl64 = (int64_t)(((uint64_t)M[3] << 32) | M[2]) - slot0;
+        const int64_t L64 = (int64_t)(((uint64_t)M[5] << 32) | M[4]);
+        int64_t eb = 0;
+        int ne = 0;
+        if (ln < P) {
+            eb = (int64_t)(((uint64_t)M[9 + 4 * ln] << 32) | M[8 + 4 * ln]);
+            const int64_t d = (int64_t)(((uint64_t)M[11 + 4 * ln] << 32) | M[10 + 4 * ln]) - eb;
+            ne = (int)(d < 0 ? 0 : (d > 0x3FFFFFF ? 0x3FFFFFF : d));
+        }
+        int incl = ne;
+#pragma unroll
+        for (int o = 1; o < V3_MAXV; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (ln >= o) incl += t; }
+        const int eoff = incl - ne;
+        const int total_e = __shfl(incl, P - 1, 64);
+        const bool fast = total_e <= a.ecap && (int64_t)total_e * K <= (int64_t)a.lcap && nsl64 >= 0 && nsl64 <= (int64_t)SC &&
+                          L64 >= 0 && L64 <= nsl64 * 64;
+        const int nslots = fast ? (int)nsl64 : 0;
+        if (ln < P) { vt[(1 + ln) * V3_VT] = (uint32_t)ne; vt[(1 + ln) * V3_VT + 1] = (uint32_t)eoff; vt[(1 + ln) * V3_VT + 2] = (uint32_t)(eoff * K); }
+        if (ln == 0) { vt[0] = fast ? 1u : 0u; vt[1] = (uint32_t)(total_e * K); vt[2] = (uint32_t)nslots; vt[3] = (uint32_t)(fast ? L64 : 0); }
+        if (!fast) return;
+        for (int i0 = 0; i0 < nslots; i0 += 64)
+            if (i0 + ln < nslots) dma16(a.codes + slot0 + i0 + ln, __builtin_amdgcn_readfirstlane(lds_addr(cod + 4 + i0 * 4)));
+        for (int i0 = 0; i0 < 2 * nslots; i0 += 64)
+            if (i0 + ln < 2 * nslots) dma4((const uint32_t *)(a.mask + slot0) + i0 + ln, __builtin_amdgcn_readfirstlane(lds_addr(msk + 2 + i0)));
+        for (int v = 0; v < P; ++v) {
+            const int nev = __shfl(ne, v, 64), eov = __shfl(eoff, v, 64);
+            const int64_t ebv = (int64_t)(((uint64_t)(uint32_t)__shfl((int)(eb >> 32), v, 64) << 32) | (uint32_t)__shfl((int)eb, v, 64));
+            for (int i0 = 0; i0 < nev; i0 += 64)
+                if (i0 + ln < nev) dma4(a.edits + ebv + i0 + ln, __builtin_amdgcn_readfirstlane(lds_addr(edl + eov + i0)));
+        }
+    };
+    // ---------------- compute waves
+    auto clear_hist = [&]() {
+        for (int i = tid; i < HD / 4; i += NC) *(uint4 *)(hist + i * 4) = make_uint4(iv, iv, iv, iv);
+        if (tid <= V3_MAXV) ctr[tid] = 0;
+    };
+
+    // ---------------- memory wave: a view's row, in registers between reading the histogram and storing it
+    struct Row { uint4 h[RP]; int64_t S, s; int v; };
+    auto row_load = [&](Row &rw, int v, int64_t s) {
+#pragma unroll
+        for (int j = 0; j < RP; ++j) rw.h[j] = *(const uint4 *)(hist + (lane + j * 64) * 4);
+        rw.S = (int64_t)ctr[0] + (int64_t)ctr[1 + v] + (iv ? (int64_t)F : 0);
+        rw.v = v; rw.s = s;
+    };
+    auto row_store = [&](const Row &rw) {
+        if (a.ablate & 1) { if (rw.h[0].x != 0xFFFFFFF0u) return; }
+        // one address, formed here (not where the row was loaded: sixteen 64-bit addresses held across the barrier cost 32 registers);
+        // the pieces are 1 KB apart
+        int l4 = lane * 4;
+        asm volatile("" : "+v"(l4));
+        float *dst = (float *)a.out + ((int64_t)rw.v * a.view_stride + rw.s * (int64_t)F) + l4;
+        if (a.out_kind == IDL_OUT_COUNTS_I32) {
+#pragma unroll
+            for (int j = 0; j < RP; ++j) *(uint4 *)((uint32_t *)dst + j * 256) = rw.h[j];
+            return;
+        }
+        // S <= max_len + 4^k < 2^24 in this kernel (the launcher bounds max_len): ints are exact in float32 and the Markstein form
+        // q = c * r; q' = fma(fma(-q, S, c), r, q) equals float32(float64 division) (tools/markstein_check.c); two bins per packed op
+        const float Sf = (float)rw.S, rS = 1.0f / Sf;
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        const f32x2 rS2 = {rS, rS}, nS2 = {-Sf, -Sf};
+#pragma unroll
+        for (int j = 0; j < RP; ++j) {
+            const uint4 h = rw.h[j];
+            const f32x2 c01 = {(float)h.x, (float)h.y}, c23 = {(float)h.z, (float)h.w};
+            const f32x2 q01 = c01 * rS2, q23 = c23 * rS2;
+            const f32x2 o01 = __builtin_elementwise_fma(__builtin_elementwise_fma(q01, nS2, c01), rS2, q01);
+            const f32x2 o23 = __builtin_elementwise_fma(__builtin_elementwise_fma(q23, nS2, c23), rS2, q23);
+            *(float4 *)(dst + j * 256) = make_float4(o01.x, o01.y, o23.x, o23.y);
+        }
+    };
+
+    // ---------------- prologue: halos, tables, the first two meta entries, the first sequence
+    if (tid < 8) sets[(tid >> 2) * SET + (tid & 3)] = 0u;
+    if (tid < 4) sets[(tid >> 1) * SET + (SC + 1) * 4 + (tid & 1)] = 0xFFFFFFFFu;
+    for (int i = tid; i < 3 * V3_META + 2 * V3_VTAB; i += V3_NT) meta[i] = 0u;
+    if (!mem) clear_hist();
+    __syncthreads();
+    if (mem && s_count > 0) {
+        dma_meta(s_first, 0);
+        if (s_count > 1) dma_meta(s_first + s_step, 1);
+        vm_wait<0>();
+    }
+    __syncthreads();
+    if (mem && s_count > 0) { stage_next(0, vtab, sets); vm_wait<0>(); }
+    __syncthreads();
+
+    // diagnostic stamps (DIAG build, a.dbg != NULL): cycles per phase, summed over this workgroup's sequences, compute wave 0 and the memory wave
+    unsigned long long tp[DIAG ? 10 : 1] = {0}, tl = 0;
+    const bool stamp = DIAG && a.dbg != nullptr && (tid < 64 || mem);
+    auto mark = [&](int k) { if constexpr (DIAG) { if (stamp) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tp[k] += t - tl; tl = t; } } };
+    if constexpr (DIAG) { if (stamp) tl = __builtin_amdgcn_s_memtime(); }
+
+    // what both roles read off the view table of the current sequence (the same values: the barrier schedule must match)
+    struct Seq { const uint32_t *vt; int TP, nslots, L, vlast; bool fast; };
+    auto seq_of = [&](int64_t it) -> Seq {
+        Seq q;
+        q.vt = vtab + (it & 1) * V3_VTAB;
+        q.fast = (q.vt[0] & 1u) != 0u;
+        q.TP = (a.ablate & 4) ? 0 : (int)q.vt[1]; q.nslots = (int)q.vt[2]; q.L = (int)q.vt[3];
+        q.vlast = P - 1;                       // the view with the most edits goes last: its list is applied once and never undone
+        int best = -1;
+        for (int v = 0; v < P; ++v) { const int c = (int)q.vt[(1 + v) * V3_VT]; if (c > best) { best = c; q.vlast = v; } }
+        return q;
+    };
+    auto view_at = [&](const Seq &q, int vi) -> int { return (vi == P - 1) ? q.vlast : (vi < q.vlast ? vi : vi + 1); };
+
+    // Barrier schedule of one sequence, identical in both roles: [P1 | stage the next sequence] B { [row load] B [lists | stores] B } x P;
+    // a sequence left to the second pass: [stage the next sequence] B.
+    if (mem) {
+        // =============================================================== the memory wave
+        int r = 0;
+        for (int64_t it = 0; it < s_count; ++it) {
+            const int64_t s = s_first + it * s_step;
+            const Seq q = seq_of(it);
+            const int r1 = (r + 1 == 3) ? 0 : r + 1, r2 = (r1 + 1 == 3) ? 0 : r1 + 1;
+            // while the compute waves count this sequence: the next sequence's data and the one after's meta leave for LDS (the other
+            // staging set was last read one sequence ago)
+            if (it + 1 < s_count) stage_next(r1, vtab + ((it + 1) & 1) * V3_VTAB, sets + ((it + 1) & 1) * SET);
+            if (it + 2 < s_count) dma_meta(s + 2 * s_step, r2);
+            mark(5);
+            if (q.fast) {
+                __syncthreads();                                // P1 of the compute waves is over
+                mark(2);
+                for (int vi = 0; vi < P; ++vi) {
+                    Row row;
+                    row_load(row, view_at(q, vi), s);
+                    mark(3);
+                    __syncthreads();
+                    mark(4);
+                    // before the last row goes out, retire the DMA issued above: the younger operations are the (P - 1) RP row stores
+                    // since, so no store is waited for
+                    if (vi + 1 == P) vm_wait_at_most((a.ablate & 1) ? 0 : (P - 1) * RP);
+                    row_store(row);
+                    mark(6);
+                    __syncthreads();
+                    mark(7);
+                }
+            } else {
+                if (lane == 0) atomicAdd(a.redo_count, 1);      // the launcher's second pass (v2) takes this sequence
+                vm_wait<0>();
+                __syncthreads();
+            }
+            r = r1;
+        }
+    } else {
+        // =============================================================== the compute waves
+        for (int64_t it = 0; it < s_count; ++it) {
+            const Seq q = seq_of(it);
+            if (!q.fast) { __syncthreads(); continue; }
+            const uint32_t *vt = q.vt;
+            const uint32_t *cod = sets + (it & 1) * SET, *msk = cod + (SC + 1) * 4, *edl = cod + (SC + 1) * 6;
+            // ---------------- P1: count the un-mutated sequence, evaluate every edit of every view
+            {
+                uint32_t c0 = (a.ablate & 2) ? 0u : W::template count_all<NC>(cod, msk, q.nslots, hist, tid);
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) c0 += __shfl_xor(c0, o, 64);
+                if (lane == 0) atomicAdd(&ctr[0], (int32_t)c0);
+            }
+            mark(0);
+            {
+                const int vfirst = view_at(q, 0);
+                const int TE = q.TP / K;                     // edits of all views; lane per edit, K list entries each
+                for (int e0 = 0; e0 < TE; e0 += NC) {
+                    const int e = e0 + tid;
+                    if (e < TE) {
+                        int v = 0;
+                        for (int u = 1; u < P; ++u) if (e >= (int)vt[(1 + u) * V3_VT + 1]) v = u;      // edit bases ascend with the view index
+                        const int ne = (int)vt[(1 + v) * V3_VT], eo = (int)vt[(1 + v) * V3_VT + 1];
+                        uint32_t pr[K];
+                        W::edit_eval((const uint32_t *)(edl + eo), ne, e - eo, q.L - 1, cod, msk, pr);
+                        int d = 0;
+#pragma unroll
+                        for (int t = 0; t < K; ++t) {
+                            list[e * K + t] = pr[t];
+                            d += (int)((pr[t] >> 16) != 0xFFFFu) - (int)((pr[t] & 0xFFFFu) != 0xFFFFu);
+                        }
+                        if (d != 0) atomicAdd(&ctr[1 + v], d);
+                        if (v == vfirst) {
+#pragma unroll
+                            for (int t = 0; t < K; ++t) W::move(hist, pr[t] & 0xFFFFu, pr[t] >> 16, 0xFFFFFFFFu, 1u);
+                        }
+                    }
+                }
+            }
+            mark(1);
+            __syncthreads();
+            mark(2);
+            for (int vi = 0; vi < P; ++vi) {
+                mark(3);
+                __syncthreads();            // the memory wave has the row of view vi in registers
+                mark(4);
+                if (vi + 1 < P) {           // hist: view v -> view v2 in one phase (LDS atomics commute)
+                    const int v = view_at(q, vi), v2 = view_at(q, vi + 1);
+                    const int na = (a.ablate & 4) ? 0 : (int)vt[(1 + v) * V3_VT] * K, pa = (int)vt[(1 + v) * V3_VT + 2];
+                    const int nb = (a.ablate & 4) ? 0 : (int)vt[(1 + v2) * V3_VT] * K, pb = (int)vt[(1 + v2) * V3_VT + 2];
+                    for (int x = tid; x < na; x += NC) { const uint32_t e = list[pa + x]; W::move(hist, e & 0xFFFFu, e >> 16, 1u, 0xFFFFFFFFu); }
+                    for (int x = tid; x < nb; x += NC) { const uint32_t e = list[pb + x]; W::move(hist, e & 0xFFFFu, e >> 16, 0xFFFFFFFFu, 1u); }
+                } else {
+                    clear_hist();
+                }
+                mark(6);
+                __syncthreads();
+                mark(7);
+            }
+        }
+    }
+    if constexpr (DIAG) {
+        if (stamp && lane == 0) {
+            unsigned long long *d = a.dbg + ((int64_t)blockIdx.x * 2 + (mem ? 1 : 0)) * 10;
+            for (int k = 0; k < 10; ++k) d[k] = tp[k];
+        }
+    }
+}
+
 // collapse a host-provided histogram (idl_kmer_rev_comp): one wave, counts modified in place like utils.py:216-217
 template <int K>
 __global__ __launch_bounds__(64) void collapse_kernel(int32_t *counts, int32_t *out)
@@ -690,10 +1157,115 @@ __global__ __launch_bounds__(64) void collapse_kernel(int32_t *counts, int32_t *
     }
 }
 
+// v3 takes the hot shape only: plain k-mer rows (float32 or int32), 4^k >= 1024, <= 8 views, every sequence within one staged
+// super-chunk (the host's length bound says so), fresh histograms.  Everything else stays on v2 / v1.
+template <int K>
+int launch_vectorise3_k(VecArgs &a, const idl::DeviceInfo &di, hipStream_t st, size_t lds, int per_cu)
+{
+    const bool dbg = getenv("IDELUCS_VEC_DBG") != nullptr;
+    const void *fn = dbg ? (const void *)vectorise3_kernel<K, true> : (const void *)vectorise3_kernel<K, false>;
+    if (lds > 64 * 1024) IDL_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int64_t grid = (int64_t)di.cus * per_cu;
+    if (grid > a.n) grid = a.n;
+    if (dbg) { IDL_HIP_TRY(hipMalloc((void **)&a.dbg, (size_t)grid * 20 * 8)); IDL_HIP_TRY(hipMemset(a.dbg, 0, (size_t)grid * 20 * 8)); }
+    if (dbg) hipLaunchKernelGGL((vectorise3_kernel<K, true>), dim3((unsigned)grid), dim3(V3_NT), lds, st, a);
+    else hipLaunchKernelGGL((vectorise3_kernel<K, false>), dim3((unsigned)grid), dim3(V3_NT), lds, st, a);
+    IDL_HIP_TRY(hipGetLastError());
+    if (dbg) {          // diagnostic only: synchronises, prints the mean cycles per sequence of each phase for compute wave 0 and the memory wave
+        std::vector<unsigned long long> h((size_t)grid * 20);
+        IDL_HIP_TRY(hipMemcpy(h.data(), a.dbg, h.size() * 8, hipMemcpyDeviceToHost));
+        (void)hipFree(a.dbg);
+        static const char *nm[10] = {"count", "edits|pending row", "barrier(P1)", "row load", "barrier(row)", "dma issue", "lists|stores", "barrier(lists)", "-", "-"};
+        for (int w = 0; w < 2; ++w) {
+            fprintf(stderr, "[idl] v3 cycles per sequence, %s wave:", w ? "memory" : "compute");
+            double tot = 0;
+            for (int k = 0; k < 8; ++k) { double sum = 0; for (int64_t b = 0; b < grid; ++b) sum += (double)h[(size_t)(b * 2 + w) * 10 + k]; fprintf(stderr, " %s %.0f", nm[k], sum / (double)a.n); tot += sum / (double)a.n; }
+            fprintf(stderr, " | total %.0f\n", tot);
+        }
+    }
+    return IDL_OK;
+}
+
+// v3 takes the hot shape only: plain k-mer rows (float32 or int32), 4^k >= 1024, <= 8 views, every sequence within one staged
+// super-chunk (the host's length bound says so), fresh histograms.  Everything else stays on v2 / v1.
+template <int K, int NT>
+int launch_vectorise3_nt(VecArgs &a, const idl::DeviceInfo &di, hipStream_t st, size_t lds, int per_cu)
+{
+    const void *fn = (const void *)vectorise3_kernel<K, NT>;
+    if (lds > 64 * 1024) IDL_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int64_t grid = (int64_t)di.cus * per_cu;
+    if (grid > a.n) grid = a.n;
+    const bool dbg = getenv("IDELUCS_VEC_DBG") != nullptr;
+    if (dbg) { IDL_HIP_TRY(hipMalloc((void **)&a.dbg, (size_t)grid * 20 * 8)); IDL_HIP_TRY(hipMemset(a.dbg, 0, (size_t)grid * 20 * 8)); }
+    hipLaunchKernelGGL((vectorise3_kernel<K, NT>), dim3((unsigned)grid), dim3(NT), lds, st, a);
+    IDL_HIP_TRY(hipGetLastError());
+    if (dbg) {          // diagnostic only: synchronises, prints the mean cycles per sequence of each phase for the first and the last wave
+        std::vector<unsigned long long> h((size_t)grid * 20);
+        IDL_HIP_TRY(hipMemcpy(h.data(), a.dbg, h.size() * 8, hipMemcpyDeviceToHost));
+        (void)hipFree(a.dbg);
+        static const char *nm[10] = {"count", "edits", "barrier(P1)", "dma issue", "row load", "barrier(row)", "lists+stores", "barrier(lists)", "-", "-"};
+        for (int w = 0; w < 2; ++w) {
+            fprintf(stderr, "[idl] v3 cycles per sequence, %s wave:", w ? "last" : "first");
+            double tot = 0;
+            for (int k = 0; k < 8; ++k) { double sum = 0; for (int64_t b = 0; b < grid; ++b) sum += (double)h[(size_t)(b * 2 + w) * 10 + k]; fprintf(stderr, " %s %.0f", nm[k], sum / (double)a.n); tot += sum / (double)a.n; }
+            fprintf(stderr, " | total %.0f\n", tot);
+        }
+    }
+    return IDL_OK;
+}
+
+// v3 takes the hot shape only: plain k-mer rows (float32 or int32), 4^k >= 1024, <= 8 views, every sequence within one staged
+// super-chunk (the host's length bound says so), fresh histograms.  Everything else stays on v2 / v1.
+template <int K>
+int launch_vectorise3(const VecArgs &a_in, const idl::DeviceInfo &di, hipStream_t st, bool *done)
+{
+    *done = false;
+    if constexpr (K >= 4 && K <= 6) {
+        constexpr int F = 1 << (2 * K);
+        VecArgs a = a_in;
+        int want = 3;
+        if (const char *e = getenv("IDELUCS_VEC")) want = atoi(e);
+        if (want != 3 || a.mode != IDL_MODE_KMER || a.init == IDL_INIT_FROM_OUT || a.out_kind == IDL_OUT_FREQ_F64 ||
+            a.n_views > V3_MAXV || a.max_len <= 0 || a.max_len > 64 * 2048)
+            return IDL_OK;
+        a.sc_slots = (int)((a.max_len + 63) / 64);
+        // LDS tables for the edits of all views (3.5 % of the bases + slack) and their K windows each; IDELUCS_V3_EC / _LC override
+        int ec = (int)(a.max_len * 35 / 1000) + 64, lc;
+        if (const char *e = getenv("IDELUCS_V3_EC")) { const int t = atoi(e); if (t >= 0 && t <= 16384) ec = t; }
+        ec = (ec + 63) & ~63;
+        lc = (ec - 64 > 0 ? ec - 64 : 0) * K;
+        if (const char *e = getenv("IDELUCS_V3_LC")) { const int t = atoi(e); if (t >= 0 && t <= 65536) lc = t; }
+        if (a.edits == nullptr) { ec = 0; lc = 0; }
+        a.ecap = ec; a.lcap = lc;
+        a.blocked = 0;
+        if (const char *e = getenv("IDELUCS_V3_BLOCKED")) a.blocked = atoi(e) != 0;
+        if (const char *e = getenv("IDELUCS_VEC_ABLATE")) a.ablate = atoi(e);
+        const size_t lds = (size_t)((F + 4) + (a.sc_slots + 1) * 6 + ec + lc + 3 * V3_META + 2 * V3_VTAB + 16) * 4;
+        if ((int)lds > di.max_dyn_lds || lds > 80 * 1024) return IDL_OK;                 // (fewer than two workgroups per CU: v2's chunked staging is the better fit)
+        // workgroups per CU by LDS, with 1 KB of slack each (measured: five 32 032-byte workgroups do NOT become resident
+        // together although 5 x 32 032 < 160 KB and the occupancy query says 5 -- the fifth ran after the others)
+        int per_cu = (int)((size_t)di.lds_per_cu / (lds + 1024));
+        if (per_cu > 4) per_cu = 4;                   // 5 waves per workgroup, 96 registers: 20 waves per CU
+        if (const char *e = getenv("IDELUCS_WG_PER_CU")) { const int t = atoi(e); if (t >= 1 && t <= 32) per_cu = t; }
+        if (per_cu < 1) per_cu = 1;
+        if (getenv("IDELUCS_DEBUG"))
+            fprintf(stderr, "[idl] vectorise k=%d v3 lds=%zu B (staged slots %d, edits %d, pairs %d) -> %d workgroups/CU\n", K, lds, a.sc_slots, ec, lc, per_cu);
+        const int rc = launch_vectorise3_k<K>(a, di, st, lds, per_cu);
+        if (rc != IDL_OK) return rc;
+        *done = true;
+    }
+    return IDL_OK;
+}
+
 template <int K>
 int launch_vectorise(const VecArgs &a_in, const idl::DeviceInfo &di, hipStream_t st)
 {
     constexpr int F = 1 << (2 * K);
+    {
+        bool done = false;
+        const int rc = launch_vectorise3<K>(a_in, di, st, &done);
+        if (rc != IDL_OK || done) return rc;
+    }
     VecArgs a = a_in;
     bool v1 = (a.init == IDL_INIT_FROM_OUT);            // accumulate-on-top needs a per-view start: single-pass kernel
     if (const char *e = getenv("IDELUCS_VEC")) { if (atoi(e) == 1) v1 = true; }   // force the v1 kernel (cross-check tests)

@@ -388,10 +388,11 @@ def test_cfg2_full_size_store_properties(gpu):
     assert int(counts[P - 1, n - 1].sum()) >= L - (k - 1) - 20 * k
 
 
-def test_full_size_v1_and_v2_kernels_agree_bitwise(gpu, monkeypatch):
-    """cfg2-shaped batch (20 000 x 10 kbp, 4 views, device-drawn mimic edits): the single-pass kernel (full recount per
-    view, edits applied to a staged copy) and the delta-view kernel (one count + XOR-mask window moves) are independent
-    implementations and must produce identical bits -- counts and float32 frequencies."""
+def test_full_size_v1_v2_v3_kernels_agree_bitwise(gpu, monkeypatch):
+    """cfg2-shaped batch (20 000 x 10 kbp, 4 views, device-drawn mimic edits): the single-pass kernel (v1: full recount per
+    view, edits applied to a staged copy), the delta-view kernel (v2: one count + XOR-mask window moves, per-view pair passes)
+    and the pipelined kernel (v3, the default here: LDS-DMA staging one sequence ahead, one pair pass for all views, recorded
+    pair lists) are independent code paths and must produce identical bits -- counts and float32 frequencies."""
     import torch
     from idelucs_amd import _lib, utils as U
     sys_path_tools = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools")
@@ -403,12 +404,17 @@ def test_full_size_v1_and_v2_kernels_agree_bitwise(gpu, monkeypatch):
     specs = [t.spec() for t in U.mimic_transforms(3)]
     edits, edit_off = U._philox_edits(din, specs, 11)
     outs = {}
-    for which in ("2", "1"):
+    for which in ("3", "2", "1"):
         monkeypatch.setenv("IDELUCS_VEC", which)
         outs[which] = (U._vectorise(din, 6, _lib.MODE_KMER, _lib.INIT_ONE, _lib.OUT_FREQ_F32, 4, edits, edit_off).clone(),
                        U._vectorise(din, 6, _lib.MODE_KMER, _lib.INIT_ZERO, _lib.OUT_COUNTS_I32, 4, edits, edit_off).clone())
-    assert torch.equal(outs["1"][1], outs["2"][1])
-    assert torch.equal(outs["1"][0], outs["2"][0])
+    assert torch.equal(outs["1"][1], outs["2"][1]) and torch.equal(outs["1"][1], outs["3"][1])
+    assert torch.equal(outs["1"][0], outs["2"][0]) and torch.equal(outs["1"][0], outs["3"][0])
+    # v3's slow path (tables too small for this sequence's edits / pairs) and its mixed fast/slow batches give the same bits
+    for ec, lc in (("0", "0"), ("320", "1800"), ("512", "1920")):
+        monkeypatch.setenv("IDELUCS_VEC", "3"); monkeypatch.setenv("IDELUCS_V3_EC", ec); monkeypatch.setenv("IDELUCS_V3_LC", lc)
+        assert torch.equal(U._vectorise(din, 6, _lib.MODE_KMER, _lib.INIT_ONE, _lib.OUT_FREQ_F32, 4, edits, edit_off), outs["1"][0]), (ec, lc)
+    monkeypatch.delenv("IDELUCS_V3_EC"); monkeypatch.delenv("IDELUCS_V3_LC")
     c = outs["2"][1]
     assert not torch.equal(c[0], c[1]) and int(c[3].sum(1).min()) >= 10000 - 5 - 20 * 6       # the views differ; Random_N kills <= 20*k windows
 

@@ -1157,8 +1157,16 @@ __global__ __launch_bounds__(64) void collapse_kernel(int32_t *counts, int32_t *
     }
 }
 
-// v3 takes the hot shape only: plain k-mer rows (float32 or int32), 4^k >= 1024, <= 8 views, every sequence within one staged
-// super-chunk (the host's length bound says so), fresh histograms.  Everything else stays on v2 / v1.
+// the device word through which v3 tells the second pass how many sequences it left alone (one per device, allocated on first use)
+int *redo_counter()
+{
+    static int *ptr[64] = {nullptr};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    if (ptr[dev] == nullptr) { if (hipMalloc((void **)&ptr[dev], 256) != hipSuccess) ptr[dev] = nullptr; }
+    return ptr[dev];
+}
+
 template <int K>
 int launch_vectorise3_k(VecArgs &a, const idl::DeviceInfo &di, hipStream_t st, size_t lds, int per_cu)
 {
@@ -1167,6 +1175,9 @@ int launch_vectorise3_k(VecArgs &a, const idl::DeviceInfo &di, hipStream_t st, s
     if (lds > 64 * 1024) IDL_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int64_t grid = (int64_t)di.cus * per_cu;
     if (grid > a.n) grid = a.n;
+    a.redo_count = redo_counter();
+    if (a.redo_count == nullptr) { idl::set_error("cannot allocate the v3 hand-over word"); return IDL_ERR_HIP; }
+    IDL_HIP_TRY(hipMemsetAsync(a.redo_count, 0, sizeof(int), st));
     if (dbg) { IDL_HIP_TRY(hipMalloc((void **)&a.dbg, (size_t)grid * 20 * 8)); IDL_HIP_TRY(hipMemset(a.dbg, 0, (size_t)grid * 20 * 8)); }
     if (dbg) hipLaunchKernelGGL((vectorise3_kernel<K, true>), dim3((unsigned)grid), dim3(V3_NT), lds, st, a);
     else hipLaunchKernelGGL((vectorise3_kernel<K, false>), dim3((unsigned)grid), dim3(V3_NT), lds, st, a);
@@ -1175,7 +1186,8 @@ int launch_vectorise3_k(VecArgs &a, const idl::DeviceInfo &di, hipStream_t st, s
         std::vector<unsigned long long> h((size_t)grid * 20);
         IDL_HIP_TRY(hipMemcpy(h.data(), a.dbg, h.size() * 8, hipMemcpyDeviceToHost));
         (void)hipFree(a.dbg);
-        static const char *nm[10] = {"count", "edits|pending row", "barrier(P1)", "row load", "barrier(row)", "dma issue", "lists|stores", "barrier(lists)", "-", "-"};
+        a.dbg = nullptr;
+        static const char *nm[10] = {"count", "edits", "barrier(P1)", "row load", "barrier(row)", "dma issue", "lists|stores", "barrier(lists)", "-", "-"};
         for (int w = 0; w < 2; ++w) {
             fprintf(stderr, "[idl] v3 cycles per sequence, %s wave:", w ? "memory" : "compute");
             double tot = 0;
@@ -1183,33 +1195,17 @@ int launch_vectorise3_k(VecArgs &a, const idl::DeviceInfo &di, hipStream_t st, s
             fprintf(stderr, " | total %.0f\n", tot);
         }
     }
-    return IDL_OK;
-}
-
-// v3 takes the hot shape only: plain k-mer rows (float32 or int32), 4^k >= 1024, <= 8 views, every sequence within one staged
-// super-chunk (the host's length bound says so), fresh histograms.  Everything else stays on v2 / v1.
-template <int K, int NT>
-int launch_vectorise3_nt(VecArgs &a, const idl::DeviceInfo &di, hipStream_t st, size_t lds, int per_cu)
-{
-    const void *fn = (const void *)vectorise3_kernel<K, NT>;
-    if (lds > 64 * 1024) IDL_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    int64_t grid = (int64_t)di.cus * per_cu;
-    if (grid > a.n) grid = a.n;
-    const bool dbg = getenv("IDELUCS_VEC_DBG") != nullptr;
-    if (dbg) { IDL_HIP_TRY(hipMalloc((void **)&a.dbg, (size_t)grid * 20 * 8)); IDL_HIP_TRY(hipMemset(a.dbg, 0, (size_t)grid * 20 * 8)); }
-    hipLaunchKernelGGL((vectorise3_kernel<K, NT>), dim3((unsigned)grid), dim3(NT), lds, st, a);
-    IDL_HIP_TRY(hipGetLastError());
-    if (dbg) {          // diagnostic only: synchronises, prints the mean cycles per sequence of each phase for the first and the last wave
-        std::vector<unsigned long long> h((size_t)grid * 20);
-        IDL_HIP_TRY(hipMemcpy(h.data(), a.dbg, h.size() * 8, hipMemcpyDeviceToHost));
-        (void)hipFree(a.dbg);
-        static const char *nm[10] = {"count", "edits", "barrier(P1)", "dma issue", "row load", "barrier(row)", "lists+stores", "barrier(lists)", "-", "-"};
-        for (int w = 0; w < 2; ++w) {
-            fprintf(stderr, "[idl] v3 cycles per sequence, %s wave:", w ? "last" : "first");
-            double tot = 0;
-            for (int k = 0; k < 8; ++k) { double sum = 0; for (int64_t b = 0; b < grid; ++b) sum += (double)h[(size_t)(b * 2 + w) * 10 + k]; fprintf(stderr, " %s %.0f", nm[k], sum / (double)a.n); tot += sum / (double)a.n; }
-            fprintf(stderr, " | total %.0f\n", tot);
-        }
+    // second pass: the v2 kernel on the sequences v3 left alone (their edits / pairs exceed the LDS tables); exits at once when there are none
+    {
+        VecArgs b = a;
+        b.redo = 1;
+        b.v3_sc = a.sc_slots;
+        b.sc_slots = 160;
+        const size_t lds2 = (size_t)((1 << (2 * K)) + 4 + (b.sc_slots + 1) * 6 + V2_EDIT_CAP + V2_LIST_CAP + 2 * V2_WAVES + 4 * b.n_views) * 4;
+        int64_t g2 = (int64_t)di.cus * 4;
+        if (g2 > a.n) g2 = a.n;
+        hipLaunchKernelGGL((vectorise2_kernel<K, false>), dim3((unsigned)g2), dim3(64 * V2_WAVES), lds2, st, b);
+        IDL_HIP_TRY(hipGetLastError());
     }
     return IDL_OK;
 }

@@ -1236,7 +1236,7 @@ int launch_vectorise3(const VecArgs &a_in, const idl::DeviceInfo &di, hipStream_
         a.blocked = 0;
         if (const char *e = getenv("IDELUCS_V3_BLOCKED")) a.blocked = atoi(e) != 0;
         if (const char *e = getenv("IDELUCS_VEC_ABLATE")) a.ablate = atoi(e);
-        const size_t lds = (size_t)((F + 4) + (a.sc_slots + 1) * 6 + ec + lc + 3 * V3_META + 2 * V3_VTAB + 16) * 4;
+        const size_t lds = (size_t)((F + 4) + 2 * ((a.sc_slots + 1) * 6 + ec) + lc + 3 * V3_META + 2 * V3_VTAB + 16) * 4;
         if ((int)lds > di.max_dyn_lds || lds > 80 * 1024) return IDL_OK;                 // (fewer than two workgroups per CU: v2's chunked staging is the better fit)
         // workgroups per CU by LDS, with 1 KB of slack each (measured: five 32 032-byte workgroups do NOT become resident
         // together although 5 x 32 032 < 160 KB and the occupancy query says 5 -- the fifth ran after the others)

@@ -898,18 +898,19 @@ __global__ __launch_bounds__(V3_NT, 5) void vectorise3_kernel(VecArgs a)
         }
     }
 
-    // ---------------- memory wave: slot range, length and edit ranges of sequence s -> meta ring entry r (one DMA instruction)
-    auto dma_meta = [&](int64_t s, int r) {
+    // ---------------- memory wave: slot range, length and edit ranges of sequence s -> meta ring entry r (one dword per lane)
+    auto load_meta = [&](int64_t s, int r) {
         int l = lane;
         asm volatile("" : "+v"(l));            // keeps the per-lane source address from being hoisted out of the sequence loop (and spilled there)
         const uint32_t *src = nullptr;
         if (l < 4) src = (const uint32_t *)(a.slot_off + s) + l;
         else if (l < 6) src = (const uint32_t *)(a.lengths + s) + (l - 4);
         else if (l >= 8 && l < 8 + 4 * P && has_edits) src = (const uint32_t *)(a.edit_off + (int64_t)((l - 8) >> 2) * a.n + s) + ((l - 8) & 3);
-        if (src != nullptr) dma4(src, __builtin_amdgcn_readfirstlane(lds_addr(meta + r * V3_META)));
+        if (src != nullptr) meta[r * V3_META + l] = *src;
     };
-    // ---------------- memory wave: view table of the sequence described by ring entry r + the DMA of its packed bases, mask and
-    // edits into staging set `st`.  A sequence that does not fit the tables is only flagged (the launcher's second pass takes it).
+    // ---------------- memory wave: view table of the sequence described by ring entry r, and its packed bases, mask and edits into
+    // staging set `st` (plain loads into this wave's free registers -- the row is not live here -- issued back to back, then
+    // written to LDS).  A sequence that does not fit the tables is only flagged (the launcher's second pass takes it).
     auto stage_next = [&](int r, uint32_t *vt, uint32_t *st) {
         int ln = lane;
         asm volatile("" : "+v"(ln));           // per-lane source addresses are formed here, per call: hoisted out of the sequence loop they are spilled
@@ -936,15 +937,50 @@ __global__ __launch_bounds__(V3_NT, 5) void vectorise3_kernel(VecArgs a)
         if (ln < P) { vt[(1 + ln) * V3_VT] = (uint32_t)ne; vt[(1 + ln) * V3_VT + 1] = (uint32_t)eoff; vt[(1 + ln) * V3_VT + 2] = (uint32_t)(eoff * K); }
         if (ln == 0) { vt[0] = fast ? 1u : 0u; vt[1] = (uint32_t)(total_e * K); vt[2] = (uint32_t)nslots; vt[3] = (uint32_t)(fast ? L64 : 0); }
         if (!fast) return;
-        for (int i0 = 0; i0 < nslots; i0 += 64)
-            if (i0 + ln < nslots) dma16(a.codes + slot0 + i0 + ln, __builtin_amdgcn_readfirstlane(lds_addr(cod + 4 + i0 * 4)));
-        for (int i0 = 0; i0 < 2 * nslots; i0 += 64)
-            if (i0 + ln < 2 * nslots) dma4((const uint32_t *)(a.mask + slot0) + i0 + ln, __builtin_amdgcn_readfirstlane(lds_addr(msk + 2 + i0)));
-        for (int v = 0; v < P; ++v) {
-            const int nev = __shfl(ne, v, 64), eov = __shfl(eoff, v, 64);
-            const int64_t ebv = (int64_t)(((uint64_t)(uint32_t)__shfl((int)(eb >> 32), v, 64) << 32) | (uint32_t)__shfl((int)eb, v, 64));
-            for (int i0 = 0; i0 < nev; i0 += 64)
-                if (i0 + ln < nev) dma4(a.edits + ebv + i0 + ln, __builtin_amdgcn_readfirstlane(lds_addr(edl + eov + i0)));
+        // packed bases + mask: four slots per lane in flight
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+        for (int i0 = 0; i0 < nslots; i0 += 256) {
+            u32x4 c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+            u32x2 m0 = 0, m1 = 0, m2 = 0, m3 = 0;
+            const int i = i0 + ln;
+            const u32x4 *gc = (const u32x4 *)a.codes + slot0 + i;
+            const u32x2 *gm = (const u32x2 *)a.mask + slot0 + i;
+            if (i < nslots) { c0 = gc[0]; m0 = gm[0]; }
+            if (i + 64 < nslots) { c1 = gc[64]; m1 = gm[64]; }
+            if (i + 128 < nslots) { c2 = gc[128]; m2 = gm[128]; }
+            if (i + 192 < nslots) { c3 = gc[192]; m3 = gm[192]; }
+            u32x4 *lc = (u32x4 *)(cod + 4) + i;
+            u32x2 *lm = (u32x2 *)(msk + 2) + i;
+            if (i < nslots) { lc[0] = c0; lm[0] = m0; }
+            if (i + 64 < nslots) { lc[64] = c1; lm[64] = m1; }
+            if (i + 128 < nslots) { lc[128] = c2; lm[128] = m2; }
+            if (i + 192 < nslots) { lc[192] = c3; lm[192] = m3; }
+        }
+        // the edits of all views, flat: LDS index x holds edit x - eoff[v] of the view v it falls in; eight per lane in flight
+        int eov[V3_MAXV]; int64_t ebv[V3_MAXV];            // per-view values (they sit in lanes 0..P-1) as wave-uniform scalars
+#pragma unroll
+        for (int v = 0; v < V3_MAXV; ++v) {
+            eov[v] = __builtin_amdgcn_readlane(eoff, v);
+            ebv[v] = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(eb >> 32), v) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)eb, v));
+        }
+        for (int x0 = 0; x0 < total_e; x0 += 512) {
+            uint32_t e[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int x = x0 + j * 64 + ln;
+                if (x < total_e) {
+                    int64_t src = 0;
+#pragma unroll
+                    for (int v = 0; v < V3_MAXV; ++v) if (v < P && x >= eov[v]) src = ebv[v] + (x - eov[v]);
+                    e[j] = a.edits[src];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int x = x0 + j * 64 + ln;
+                if (x < total_e) edl[x] = e[j];
+            }
         }
     };
     // ---------------- compute waves
@@ -996,12 +1032,11 @@ __global__ __launch_bounds__(V3_NT, 5) void vectorise3_kernel(VecArgs a)
     if (!mem) clear_hist();
     __syncthreads();
     if (mem && s_count > 0) {
-        dma_meta(s_first, 0);
-        if (s_count > 1) dma_meta(s_first + s_step, 1);
-        vm_wait<0>();
+        load_meta(s_first, 0);
+        if (s_count > 1) load_meta(s_first + s_step, 1);
     }
     __syncthreads();
-    if (mem && s_count > 0) { stage_next(0, vtab, sets); vm_wait<0>(); }
+    if (mem && s_count > 0) stage_next(0, vtab, sets);
     __syncthreads();
 
     // diagnostic stamps (DIAG build, a.dbg != NULL): cycles per phase, summed over this workgroup's sequences, compute wave 0 and the memory wave
@@ -1036,7 +1071,7 @@ __global__ __launch_bounds__(V3_NT, 5) void vectorise3_kernel(VecArgs a)
             // while the compute waves count this sequence: the next sequence's data and the one after's meta leave for LDS (the other
             // staging set was last read one sequence ago)
             if (it + 1 < s_count) stage_next(r1, vtab + ((it + 1) & 1) * V3_VTAB, sets + ((it + 1) & 1) * SET);
-            if (it + 2 < s_count) dma_meta(s + 2 * s_step, r2);
+            if (it + 2 < s_count) load_meta(s + 2 * s_step, r2);
             mark(5);
             if (q.fast) {
                 __syncthreads();                                // P1 of the compute waves is over
@@ -1047,9 +1082,6 @@ __global__ __launch_bounds__(V3_NT, 5) void vectorise3_kernel(VecArgs a)
                     mark(3);
                     __syncthreads();
                     mark(4);
-                    // before the last row goes out, retire the DMA issued above: the younger operations are the (P - 1) RP row stores
-                    // since, so no store is waited for
-                    if (vi + 1 == P) vm_wait_at_most((a.ablate & 1) ? 0 : (P - 1) * RP);
                     row_store(row);
                     mark(6);
                     __syncthreads();
@@ -1057,7 +1089,6 @@ __global__ __launch_bounds__(V3_NT, 5) void vectorise3_kernel(VecArgs a)
                 }
             } else {
                 if (lane == 0) atomicAdd(a.redo_count, 1);      // the launcher's second pass (v2) takes this sequence
-                vm_wait<0>();
                 __syncthreads();
             }
             r = r1;

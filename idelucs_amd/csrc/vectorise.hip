@@ -941,15 +941,13 @@ __global__ __launch_bounds__(V3_NT, 5) void vectorise3_kernel(VecArgs a)
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
         typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
         for (int i0 = 0; i0 < nslots; i0 += 256) {
-            u32x4 c0 = 0, c1 = 0, c2 = 0, c3 = 0;
-            u32x2 m0 = 0, m1 = 0, m2 = 0, m3 = 0;
-            const int i = i0 + ln;
-            const u32x4 *gc = (const u32x4 *)a.codes + slot0 + i;
-            const u32x2 *gm = (const u32x2 *)a.mask + slot0 + i;
-            if (i < nslots) { c0 = gc[0]; m0 = gm[0]; }
-            if (i + 64 < nslots) { c1 = gc[64]; m1 = gm[64]; }
-            if (i + 128 < nslots) { c2 = gc[128]; m2 = gm[128]; }
-            if (i + 192 < nslots) { c3 = gc[192]; m3 = gm[192]; }
+            // (every lane loads, from a clamped index: a load under a per-lane condition makes hipcc wait for each one in turn)
+            const int i = i0 + ln, last = nslots - 1;
+            const u32x4 *gc = (const u32x4 *)a.codes + slot0;
+            const u32x2 *gm = (const u32x2 *)a.mask + slot0;
+            const int j0 = i < last ? i : last, j1 = i + 64 < last ? i + 64 : last, j2 = i + 128 < last ? i + 128 : last, j3 = i + 192 < last ? i + 192 : last;
+            const u32x4 c0 = gc[j0], c1 = gc[j1], c2 = gc[j2], c3 = gc[j3];
+            const u32x2 m0 = gm[j0], m1 = gm[j1], m2 = gm[j2], m3 = gm[j3];
             u32x4 *lc = (u32x4 *)(cod + 4) + i;
             u32x2 *lm = (u32x2 *)(msk + 2) + i;
             if (i < nslots) { lc[0] = c0; lm[0] = m0; }
@@ -968,13 +966,12 @@ __global__ __launch_bounds__(V3_NT, 5) void vectorise3_kernel(VecArgs a)
             uint32_t e[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const int x = x0 + j * 64 + ln;
-                if (x < total_e) {
-                    int64_t src = 0;
+                int x = x0 + j * 64 + ln;
+                if (x > total_e - 1) x = total_e - 1;            // clamped, not predicated (see above)
+                int64_t src = 0;
 #pragma unroll
-                    for (int v = 0; v < V3_MAXV; ++v) if (v < P && x >= eov[v]) src = ebv[v] + (x - eov[v]);
-                    e[j] = a.edits[src];
-                }
+                for (int v = 0; v < V3_MAXV; ++v) if (v < P && x >= eov[v]) src = ebv[v] + (x - eov[v]);
+                e[j] = a.edits[src];
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {

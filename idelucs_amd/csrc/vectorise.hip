@@ -859,11 +859,11 @@ struct V3 {
 // registers between two barriers, then converts and stores while the compute waves are already moving the histogram to the
 // next view).  A full store queue -- the chip's write stream is the bound of this kernel -- therefore stalls only the wave that
 // has nothing else to do, and the DMA waits of that wave never queue behind another wave's work.
-constexpr int V3_NC = 256;                      // compute threads
+constexpr int V3_NC = 192;                      // compute threads
 constexpr int V3_NT = V3_NC + 64;               // + the memory wave
 
 template <int K, bool DIAG>
-__global__ __launch_bounds__(V3_NT, 5) void vectorise3_kernel(VecArgs a)
+__global__ __launch_bounds__(V3_NT, 4) void vectorise3_kernel(VecArgs a)
 {
     using W = V3<K>;
     constexpr int F = W::F, HD = W::HD, NC = V3_NC, RP = (F / 4) / 64;      // RP: 16-byte pieces of a row per lane of the memory wave
@@ -898,19 +898,18 @@ __global__ __launch_bounds__(V3_NT, 5) void vectorise3_kernel(VecArgs a)
         }
     }
 
-    // ---------------- memory wave: slot range, length and edit ranges of sequence s -> meta ring entry r (one dword per lane)
-    auto load_meta = [&](int64_t s, int r) {
+    // ---------------- memory wave: slot range, length and edit ranges of sequence s -> meta ring entry r (one DMA instruction)
+    auto dma_meta = [&](int64_t s, int r) {
         int l = lane;
         asm volatile("" : "+v"(l));            // keeps the per-lane source address from being hoisted out of the sequence loop (and spilled there)
         const uint32_t *src = nullptr;
         if (l < 4) src = (const uint32_t *)(a.slot_off + s) + l;
         else if (l < 6) src = (const uint32_t *)(a.lengths + s) + (l - 4);
         else if (l >= 8 && l < 8 + 4 * P && has_edits) src = (const uint32_t *)(a.edit_off + (int64_t)((l - 8) >> 2) * a.n + s) + ((l - 8) & 3);
-        if (src != nullptr) meta[r * V3_META + l] = *src;
+        if (src != nullptr) dma4(src, __builtin_amdgcn_readfirstlane(lds_addr(meta + r * V3_META)));
     };
-    // ---------------- memory wave: view table of the sequence described by ring entry r, and its packed bases, mask and edits into
-    // staging set `st` (plain loads into this wave's free registers -- the row is not live here -- issued back to back, then
-    // written to LDS).  A sequence that does not fit the tables is only flagged (the launcher's second pass takes it).
+    // ---------------- memory wave: view table of the sequence described by ring entry r + the DMA of its packed bases, mask and
+    // edits into staging set `st`.  A sequence that does not fit the tables is only flagged (the launcher's second pass takes it).
     auto stage_next = [&](int r, uint32_t *vt, uint32_t *st) {
         int ln = lane;
         asm volatile("" : "+v"(ln));           // per-lane source addresses are formed here, per call: hoisted out of the sequence loop they are spilled
@@ -937,47 +936,15 @@ __global__ __launch_bounds__(V3_NT, 5) void vectorise3_kernel(VecArgs a)
         if (ln < P) { vt[(1 + ln) * V3_VT] = (uint32_t)ne; vt[(1 + ln) * V3_VT + 1] = (uint32_t)eoff; vt[(1 + ln) * V3_VT + 2] = (uint32_t)(eoff * K); }
         if (ln == 0) { vt[0] = fast ? 1u : 0u; vt[1] = (uint32_t)(total_e * K); vt[2] = (uint32_t)nslots; vt[3] = (uint32_t)(fast ? L64 : 0); }
         if (!fast) return;
-        // packed bases + mask: four slots per lane in flight
-        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-        for (int i0 = 0; i0 < nslots; i0 += 256) {
-            // (every lane loads, from a clamped index: a load under a per-lane condition makes hipcc wait for each one in turn)
-            const int i = i0 + ln, last = nslots - 1;
-            const u32x4 *gc = (const u32x4 *)a.codes + slot0;
-            const u32x2 *gm = (const u32x2 *)a.mask + slot0;
-            const int j0 = i < last ? i : last, j1 = i + 64 < last ? i + 64 : last, j2 = i + 128 < last ? i + 128 : last, j3 = i + 192 < last ? i + 192 : last;
-            const u32x4 c0 = gc[j0], c1 = gc[j1], c2 = gc[j2], c3 = gc[j3];
-            const u32x2 m0 = gm[j0], m1 = gm[j1], m2 = gm[j2], m3 = gm[j3];
-            u32x4 *lc = (u32x4 *)(cod + 4) + i;
-            u32x2 *lm = (u32x2 *)(msk + 2) + i;
-            if (i < nslots) { lc[0] = c0; lm[0] = m0; }
-            if (i + 64 < nslots) { lc[64] = c1; lm[64] = m1; }
-            if (i + 128 < nslots) { lc[128] = c2; lm[128] = m2; }
-            if (i + 192 < nslots) { lc[192] = c3; lm[192] = m3; }
-        }
-        // the edits of all views, flat: LDS index x holds edit x - eoff[v] of the view v it falls in; eight per lane in flight
-        int eov[V3_MAXV]; int64_t ebv[V3_MAXV];            // per-view values (they sit in lanes 0..P-1) as wave-uniform scalars
-#pragma unroll
-        for (int v = 0; v < V3_MAXV; ++v) {
-            eov[v] = __builtin_amdgcn_readlane(eoff, v);
-            ebv[v] = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(eb >> 32), v) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)eb, v));
-        }
-        for (int x0 = 0; x0 < total_e; x0 += 512) {
-            uint32_t e[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                int x = x0 + j * 64 + ln;
-                if (x > total_e - 1) x = total_e - 1;            // clamped, not predicated (see above)
-                int64_t src = 0;
-#pragma unroll
-                for (int v = 0; v < V3_MAXV; ++v) if (v < P && x >= eov[v]) src = ebv[v] + (x - eov[v]);
-                e[j] = a.edits[src];
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int x = x0 + j * 64 + ln;
-                if (x < total_e) edl[x] = e[j];
-            }
+        for (int i0 = 0; i0 < nslots; i0 += 64)
+            if (i0 + ln < nslots) dma16(a.codes + slot0 + i0 + ln, __builtin_amdgcn_readfirstlane(lds_addr(cod + 4 + i0 * 4)));
+        for (int i0 = 0; i0 < 2 * nslots; i0 += 64)
+            if (i0 + ln < 2 * nslots) dma4((const uint32_t *)(a.mask + slot0) + i0 + ln, __builtin_amdgcn_readfirstlane(lds_addr(msk + 2 + i0)));
+        for (int v = 0; v < P; ++v) {
+            const int nev = __shfl(ne, v, 64), eov = __shfl(eoff, v, 64);
+            const int64_t ebv = (int64_t)(((uint64_t)(uint32_t)__shfl((int)(eb >> 32), v, 64) << 32) | (uint32_t)__shfl((int)eb, v, 64));
+            for (int i0 = 0; i0 < nev; i0 += 64)
+                if (i0 + ln < nev) dma4(a.edits + ebv + i0 + ln, __builtin_amdgcn_readfirstlane(lds_addr(edl + eov + i0)));
         }
     };
     // ---------------- compute waves
@@ -1029,11 +996,12 @@ __global__ __launch_bounds__(V3_NT, 5) void vectorise3_kernel(VecArgs a)
     if (!mem) clear_hist();
     __syncthreads();
     if (mem && s_count > 0) {
-        load_meta(s_first, 0);
-        if (s_count > 1) load_meta(s_first + s_step, 1);
+        dma_meta(s_first, 0);
+        if (s_count > 1) dma_meta(s_first + s_step, 1);
+        vm_wait<0>();
     }
     __syncthreads();
-    if (mem && s_count > 0) stage_next(0, vtab, sets);
+    if (mem && s_count > 0) { stage_next(0, vtab, sets); vm_wait<0>(); }
     __syncthreads();
 
     // diagnostic stamps (DIAG build, a.dbg != NULL): cycles per phase, summed over this workgroup's sequences, compute wave 0 and the memory wave
@@ -1068,7 +1036,7 @@ __global__ __launch_bounds__(V3_NT, 5) void vectorise3_kernel(VecArgs a)
             // while the compute waves count this sequence: the next sequence's data and the one after's meta leave for LDS (the other
             // staging set was last read one sequence ago)
             if (it + 1 < s_count) stage_next(r1, vtab + ((it + 1) & 1) * V3_VTAB, sets + ((it + 1) & 1) * SET);
-            if (it + 2 < s_count) load_meta(s + 2 * s_step, r2);
+            if (it + 2 < s_count) dma_meta(s + 2 * s_step, r2);
             mark(5);
             if (q.fast) {
                 __syncthreads();                                // P1 of the compute waves is over
@@ -1079,6 +1047,9 @@ __global__ __launch_bounds__(V3_NT, 5) void vectorise3_kernel(VecArgs a)
                     mark(3);
                     __syncthreads();
                     mark(4);
+                    // before the last row goes out, retire the DMA issued above: the younger operations are the (P - 1) RP row stores
+                    // since, so no store is waited for
+                    if (vi + 1 == P) vm_wait_at_most((a.ablate & 1) ? 0 : (P - 1) * RP);
                     row_store(row);
                     mark(6);
                     __syncthreads();
@@ -1086,6 +1057,7 @@ __global__ __launch_bounds__(V3_NT, 5) void vectorise3_kernel(VecArgs a)
                 }
             } else {
                 if (lane == 0) atomicAdd(a.redo_count, 1);      // the launcher's second pass (v2) takes this sequence
+                vm_wait<0>();
                 __syncthreads();
             }
             r = r1;

@@ -859,15 +859,16 @@ struct V3 {
 // registers between two barriers, then converts and stores while the compute waves are already moving the histogram to the
 // next view).  A full store queue -- the chip's write stream is the bound of this kernel -- therefore stalls only the wave that
 // has nothing else to do, and the DMA waits of that wave never queue behind another wave's work.
-constexpr int V3_NC = 192;                      // compute threads
-constexpr int V3_NT = V3_NC + 64;               // + the memory wave
+constexpr int V3_NC = 384;                      // compute threads (6 waves)
+constexpr int V3_MW = 2;                        // memory waves, each holding 1 / V3_MW of a row
+constexpr int V3_NT = V3_NC + 64 * V3_MW;
 
 template <int K, bool DIAG>
-__global__ __launch_bounds__(V3_NT, 4) void vectorise3_kernel(VecArgs a)
+__global__ __launch_bounds__(V3_NT, 8) void vectorise3_kernel(VecArgs a)
 {
     using W = V3<K>;
-    constexpr int F = W::F, HD = W::HD, NC = V3_NC, RP = (F / 4) / 64;      // RP: 16-byte pieces of a row per lane of the memory wave
-    static_assert((F / 4) % 64 == 0 && RP >= 1 && RP <= 16, "a row is held by one wave: 4^k in 256..4096");
+    constexpr int F = W::F, HD = W::HD, NC = V3_NC, RP = (F / 4) / 64 / V3_MW;      // RP: 16-byte pieces of a row per lane of a memory wave
+    static_assert((F / 4) % (64 * V3_MW) == 0 && RP >= 1 && RP <= 16, "a row is held by the memory waves: 4^k in 512..4096");
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int SC = a.sc_slots, P = a.n_views;
     const int SET = (SC + 1) * 6 + a.ecap;                  // words of one staging set
@@ -879,7 +880,8 @@ __global__ __launch_bounds__(V3_NT, 4) void vectorise3_kernel(VecArgs a)
     uint32_t *vtab = meta + 3 * V3_META;                    // two view tables (this sequence / the next)
     int32_t *ctr = (int32_t *)(vtab + 2 * V3_VTAB);         // [0] valid windows of the un-mutated sequence, [1 + v] window delta of view v
     const int tid = threadIdx.x, lane = tid & 63;
-    const bool mem = __builtin_amdgcn_readfirstlane(tid >> 6) == NC / 64;      // the memory wave
+    const int mw = __builtin_amdgcn_readfirstlane(tid >> 6) - NC / 64;         // >= 0: memory wave number
+    const bool mem = mw >= 0;
     const uint32_t iv = (a.init == IDL_INIT_ONE) ? 1u : 0u;
     const bool has_edits = a.edits != nullptr;
 
@@ -933,11 +935,16 @@ __global__ __launch_bounds__(V3_NT, 4) void vectorise3_kernel(VecArgs a)
         const bool fast = total_e <= a.ecap && (int64_t)total_e * K <= (int64_t)a.lcap && nsl64 >= 0 && nsl64 <= (int64_t)SC &&
                           L64 >= 0 && L64 <= nsl64 * 64;
         const int nslots = fast ? (int)nsl64 : 0;
-        if (ln < P) { vt[(1 + ln) * V3_VT] = (uint32_t)ne; vt[(1 + ln) * V3_VT + 1] = (uint32_t)eoff; vt[(1 + ln) * V3_VT + 2] = (uint32_t)(eoff * K); }
-        if (ln == 0) { vt[0] = fast ? 1u : 0u; vt[1] = (uint32_t)(total_e * K); vt[2] = (uint32_t)nslots; vt[3] = (uint32_t)(fast ? L64 : 0); }
+        if (mw == 0) {
+            if (ln < P) { vt[(1 + ln) * V3_VT] = (uint32_t)ne; vt[(1 + ln) * V3_VT + 1] = (uint32_t)eoff; vt[(1 + ln) * V3_VT + 2] = (uint32_t)(eoff * K); }
+            if (ln == 0) { vt[0] = fast ? 1u : 0u; vt[1] = (uint32_t)(total_e * K); vt[2] = (uint32_t)nslots; vt[3] = (uint32_t)(fast ? L64 : 0); }
+        }
         if (!fast) return;
-        for (int i0 = 0; i0 < nslots; i0 += 64)
-            if (i0 + ln < nslots) dma16(a.codes + slot0 + i0 + ln, __builtin_amdgcn_readfirstlane(lds_addr(cod + 4 + i0 * 4)));
+        if (mw == 0) {
+            for (int i0 = 0; i0 < nslots; i0 += 64)
+                if (i0 + ln < nslots) dma16(a.codes + slot0 + i0 + ln, __builtin_amdgcn_readfirstlane(lds_addr(cod + 4 + i0 * 4)));
+            if (V3_MW > 1) return;
+        }
         for (int i0 = 0; i0 < 2 * nslots; i0 += 64)
             if (i0 + ln < 2 * nslots) dma4((const uint32_t *)(a.mask + slot0) + i0 + ln, __builtin_amdgcn_readfirstlane(lds_addr(msk + 2 + i0)));
         for (int v = 0; v < P; ++v) {
@@ -957,7 +964,7 @@ __global__ __launch_bounds__(V3_NT, 4) void vectorise3_kernel(VecArgs a)
     struct Row { uint4 h[RP]; int64_t S, s; int v; };
     auto row_load = [&](Row &rw, int v, int64_t s) {
 #pragma unroll
-        for (int j = 0; j < RP; ++j) rw.h[j] = *(const uint4 *)(hist + (lane + j * 64) * 4);
+        for (int j = 0; j < RP; ++j) rw.h[j] = *(const uint4 *)(hist + (lane + (mw * RP + j) * 64) * 4);
         rw.S = (int64_t)ctr[0] + (int64_t)ctr[1 + v] + (iv ? (int64_t)F : 0);
         rw.v = v; rw.s = s;
     };
@@ -967,7 +974,7 @@ __global__ __launch_bounds__(V3_NT, 4) void vectorise3_kernel(VecArgs a)
         // the pieces are 1 KB apart
         int l4 = lane * 4;
         asm volatile("" : "+v"(l4));
-        float *dst = (float *)a.out + ((int64_t)rw.v * a.view_stride + rw.s * (int64_t)F) + l4;
+        float *dst = (float *)a.out + ((int64_t)rw.v * a.view_stride + rw.s * (int64_t)F) + mw * RP * 256 + l4;
         if (a.out_kind == IDL_OUT_COUNTS_I32) {
 #pragma unroll
             for (int j = 0; j < RP; ++j) *(uint4 *)((uint32_t *)dst + j * 256) = rw.h[j];
@@ -995,7 +1002,7 @@ __global__ __launch_bounds__(V3_NT, 4) void vectorise3_kernel(VecArgs a)
     for (int i = tid; i < 3 * V3_META + 2 * V3_VTAB; i += V3_NT) meta[i] = 0u;
     if (!mem) clear_hist();
     __syncthreads();
-    if (mem && s_count > 0) {
+    if (mw == 0 && s_count > 0) {
         dma_meta(s_first, 0);
         if (s_count > 1) dma_meta(s_first + s_step, 1);
         vm_wait<0>();
@@ -1006,7 +1013,7 @@ __global__ __launch_bounds__(V3_NT, 4) void vectorise3_kernel(VecArgs a)
 
     // diagnostic stamps (DIAG build, a.dbg != NULL): cycles per phase, summed over this workgroup's sequences, compute wave 0 and the memory wave
     unsigned long long tp[DIAG ? 10 : 1] = {0}, tl = 0;
-    const bool stamp = DIAG && a.dbg != nullptr && (tid < 64 || mem);
+    const bool stamp = DIAG && a.dbg != nullptr && (tid < 64 || mw == 0);
     auto mark = [&](int k) { if constexpr (DIAG) { if (stamp) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tp[k] += t - tl; tl = t; } } };
     if constexpr (DIAG) { if (stamp) tl = __builtin_amdgcn_s_memtime(); }
 
@@ -1036,7 +1043,7 @@ __global__ __launch_bounds__(V3_NT, 4) void vectorise3_kernel(VecArgs a)
             // while the compute waves count this sequence: the next sequence's data and the one after's meta leave for LDS (the other
             // staging set was last read one sequence ago)
             if (it + 1 < s_count) stage_next(r1, vtab + ((it + 1) & 1) * V3_VTAB, sets + ((it + 1) & 1) * SET);
-            if (it + 2 < s_count) dma_meta(s + 2 * s_step, r2);
+            if (mw == 0 && it + 2 < s_count) dma_meta(s + 2 * s_step, r2);
             mark(5);
             if (q.fast) {
                 __syncthreads();                                // P1 of the compute waves is over
@@ -1056,7 +1063,7 @@ __global__ __launch_bounds__(V3_NT, 4) void vectorise3_kernel(VecArgs a)
                     mark(7);
                 }
             } else {
-                if (lane == 0) atomicAdd(a.redo_count, 1);      // the launcher's second pass (v2) takes this sequence
+                if (lane == 0 && mw == 0) atomicAdd(a.redo_count, 1);      // the launcher's second pass (v2) takes this sequence
                 vm_wait<0>();
                 __syncthreads();
             }
@@ -1216,7 +1223,7 @@ template <int K>
 int launch_vectorise3(const VecArgs &a_in, const idl::DeviceInfo &di, hipStream_t st, bool *done)
 {
     *done = false;
-    if constexpr (K >= 4 && K <= 6) {
+    if constexpr (K >= 5 && K <= 6) {
         constexpr int F = 1 << (2 * K);
         VecArgs a = a_in;
         int want = 3;
@@ -1241,7 +1248,7 @@ int launch_vectorise3(const VecArgs &a_in, const idl::DeviceInfo &di, hipStream_
         // workgroups per CU by LDS, with 1 KB of slack each (measured: five 32 032-byte workgroups do NOT become resident
         // together although 5 x 32 032 < 160 KB and the occupancy query says 5 -- the fifth ran after the others)
         int per_cu = (int)((size_t)di.lds_per_cu / (lds + 1024));
-        if (per_cu > 4) per_cu = 4;                   // 5 waves per workgroup, 96 registers: 20 waves per CU
+        if (per_cu > 4) per_cu = 4;                   // 8 waves per workgroup, <= 64 registers: 32 waves per CU
         if (const char *e = getenv("IDELUCS_WG_PER_CU")) { const int t = atoi(e); if (t >= 1 && t <= 32) per_cu = t; }
         if (per_cu < 1) per_cu = 1;
         if (getenv("IDELUCS_DEBUG"))

@@ -33,6 +33,29 @@ __global__ __launch_bounds__(256) void rows_kernel(float *out, int64_t n, int P,
     }
 }
 
+// one wave of each workgroup stores the whole 16 KB row (16 pieces per lane), the others idle at the barrier: the memory-wave shape
+template <int NW>     // storing waves per workgroup (1, 2 or 4)
+__global__ __launch_bounds__(256) void rows_by_waves_kernel(float *out, int64_t n, int P, int64_t view_stride)
+{
+    __shared__ uint32_t junk[4096];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t G = gridDim.x;
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    for (int64_t s = blockIdx.x; s < n; s += G) {
+        for (int v = 0; v < P; ++v) {
+            if (wave < NW) {
+                f4 *row = (f4 *)(out + v * view_stride + s * 4096);
+                const f4 val = {(float)s, (float)v, 1.f, 2.f};
+#pragma unroll
+                for (int j = 0; j < 16 / NW; ++j) row[(wave * (16 / NW) + j) * 64 + lane] = val;
+            } else {
+                for (int r = 0; r < 40; ++r) atomicAdd(&junk[(tid * 17 + r * 97 + (int)s) & 4095], 1u);
+            }
+            __syncthreads();
+        }
+    }
+}
+
 __global__ void fill_kernel(float4 *out, int64_t n4)
 {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) out[i] = make_float4(1.f, 2.f, 3.f, 4.f);
@@ -61,6 +84,15 @@ int main()
     }
     time("one-shot workgroups, one 16 KB row each (400k WGs)", [&] { hipLaunchKernelGGL(rows_kernel<0>, dim3((unsigned)(n * P)), dim3(256), 0, 0, out, n * P, 1, (int64_t)0, 0, (int64_t)F); });
     time("one-shot workgroups, one sequence (4 views, view-major) each", [&] { hipLaunchKernelGGL(rows_kernel<0>, dim3((unsigned)n), dim3(256), 0, 0, out, n, P, n * F, 0, (int64_t)F); });
+    for (int wg : {3, 4, 6}) {
+        char nm[128];
+        snprintf(nm, sizeof nm, "rows stored by ONE wave of 4 (others: LDS work), %d WG/CU", wg);
+        time(nm, [&] { hipLaunchKernelGGL(rows_by_waves_kernel<1>, dim3(256 * wg), dim3(256), 0, 0, out, n, P, n * F); });
+        snprintf(nm, sizeof nm, "rows stored by TWO waves of 4 (others: LDS work), %d WG/CU", wg);
+        time(nm, [&] { hipLaunchKernelGGL(rows_by_waves_kernel<2>, dim3(256 * wg), dim3(256), 0, 0, out, n, P, n * F); });
+        snprintf(nm, sizeof nm, "rows stored by all FOUR waves, %d WG/CU", wg);
+        time(nm, [&] { hipLaunchKernelGGL(rows_by_waves_kernel<4>, dim3(256 * wg), dim3(256), 0, 0, out, n, P, n * F); });
+    }
     time("rows, nontemporal stores, 4 WG/CU, interleaved", [&] { hipLaunchKernelGGL(rows_kernel<1>, dim3(1024), dim3(256), 0, 0, out, n, P, n * F, 0); });
     for (int wg : {2, 4, 6}) {
         char nm[128];

@@ -740,47 +740,15 @@ struct V3 {
     static constexpr int F = T::F, HD = T::HD;
     static constexpr uint32_t KM = T::KM, VM = T::VM;
 
-    // (old bin, new bin) of pair q = (edit q / K, window offset q % K) of one view; 0xFFFF = no such window / invalid window
-    template <typename EP>
-    static __device__ __forceinline__ void pair_eval(EP E, int ne, int q, int end_r, const uint32_t *cod, const uint32_t *msk,
-                                                     uint32_t &ko, uint32_t &kn)
-    {
-        ko = 0xFFFFu; kn = 0xFFFFu;
-        const int ei = q / K, t = q - ei * K;
-        const uint32_t ed = E[ei];
-        const int p = (int)(ed & 0x3FFFFFFFu);
-        int last = p + K - 1;
-        if (ei + 1 < ne) { const int nx = (int)(E[ei + 1] & 0x3FFFFFFFu) - 1; if (nx < last) last = nx; }
-        if (last > end_r) last = end_r;
-        const int w = p + t;
-        if (w <= last) {
-            const uint32_t rel = (uint32_t)w + 64u;
-            const int D = (int)(rel >> 4), j = (int)(rel & 15u);
-            uint64_t ww; uint32_t M;
-            T::fetch(cod, msk, D, ww, M);
-            if (((M >> (15 - j)) & VM) == 0u) {
-                ko = (uint32_t)(ww >> (30 - 2 * j)) & KM;
-                uint32_t xm = (ed >> 30) << (2 * t);
-                bool dead = (ed >> 30) == 0u;
-                for (int i = ei - 1; i >= 0; --i) {          // earlier edits that also lie inside this window (rare)
-                    const uint32_t e2 = E[i];
-                    const int d = w - (int)(e2 & 0x3FFFFFFFu);
-                    if (d >= K) break;
-                    dead |= (e2 >> 30) == 0u;
-                    xm ^= (e2 >> 30) << (2 * d);
-                }
-                kn = dead ? 0xFFFFu : (ko ^ xm);
-            }
-        }
-    }
-
     // All K windows of ONE edit: the windows ending at p .. p + K - 1 that this edit owns (it is the latest edit at or before
     // their end: w <= min(p + K - 1, next edit - 1, last base)).  One 32-base fetch serves the K old bins; the XORs / N flags of
     // the earlier edits that still reach into those windows (rare) are gathered once as X (2 bits per base back from p) and
-    // Dm (1 bit per base), so window t changes by (X << 2t) & KM and is dead when (Dm << t) & VM.  ko[t] | kn[t] << 16 per window,
-    // 0xFFFF = no such window / invalid window.
+    // Dm (1 bit per base), so window t changes by (X << 2t) & KM and is dead when (Dm << t) & VM.  Per window: the BYTE offsets of
+    // the old and the new bin in the histogram, old | new << 16, a missing / invalid window pointing at a garbage bin behind the
+    // histogram (so a list entry is always two unconditional LDS adds); returns (valid new windows) - (valid old windows).
     template <typename EP>
-    static __device__ __forceinline__ void edit_eval(EP E, int ne, int ei, int end_r, const uint32_t *cod, const uint32_t *msk, uint32_t (&pr)[K])
+    static __device__ __forceinline__ int edit_eval(EP E, int ne, int ei, int end_r, const uint32_t *cod, const uint32_t *msk, uint32_t garbage,
+                                                    uint32_t (&pr)[K])
     {
         const uint32_t ed = E[ei];
         const int p = (int)(ed & 0x3FFFFFFFu);
@@ -795,31 +763,34 @@ struct V3 {
             X ^= (e2 >> 30) << (2 * d);
             Dm |= ((e2 >> 30) == 0u ? 1u : 0u) << d;
         }
-        // 32 staged bases ending at the end of the word that holds base p + K - 1 (staged index = position + 64: slot 0 is the halo)
+        // 32 staged bases ending at the end of the word that holds base min(p + K - 1, last base) (staged index = position + 64: slot 0 is the halo)
         const int pt = (p + K - 1 < end_r) ? p + K - 1 : end_r;    // never fetch past the last base (positions are < L, so pt >= p)
         const uint32_t top = (uint32_t)pt + 64u;
         const int D = (int)(top >> 4);
         uint64_t ww; uint32_t M;
         T::fetch(cod, msk, D, ww, M);
         const int e0 = 15 - (int)(top & 15u) + (pt - p);           // bases between p and the end of the fetched word
+        int dw = 0;
 #pragma unroll
         for (int t = 0; t < K; ++t) {
-            uint32_t ko = 0xFFFFu, kn = 0xFFFFu;
+            uint32_t ao = garbage, an = garbage;
             const int sh = (e0 - t) & 31;                            // window t ends sh bases before the end of the word (negative only past `last`)
             if (p + t <= last && ((M >> sh) & VM) == 0u) {
-                ko = (uint32_t)(ww >> (2 * sh)) & KM;
-                kn = ((Dm << t) & VM) ? 0xFFFFu : (ko ^ ((X << (2 * t)) & KM));
+                const uint32_t ko = (uint32_t)(ww >> (2 * sh)) & KM;
+                ao = ko << 2;
+                --dw;
+                if (((Dm << t) & VM) == 0u) { an = (ko ^ ((X << (2 * t)) & KM)) << 2; ++dw; }
             }
-            pr[t] = ko | (kn << 16);
+            pr[t] = ao | (an << 16);
         }
+        return dw;
     }
 
-    static __device__ __forceinline__ void move(uint32_t *hist, uint32_t ko, uint32_t kn, uint32_t s_old, uint32_t s_new)
+    // one list entry: the window leaves the bin at byte offset (e & 0xFFFF) and enters the one at (e >> 16) (sign = 1), or back
+    static __device__ __forceinline__ void move(uint32_t *hist, uint32_t e, uint32_t sign)
     {
-        if (ko != kn) {
-            if (ko != 0xFFFFu) atomicAdd(&hist[ko], s_old);
-            if (kn != 0xFFFFu) atomicAdd(&hist[kn], s_new);
-        }
+        atomicAdd((uint32_t *)((char *)hist + (e & 0xFFFFu)), 0u - sign);
+        atomicAdd((uint32_t *)((char *)hist + (e >> 16)), sign);
     }
 
     // every window ending in the staged sequence (v2's count_all without its barrier); returns this thread's valid windows
@@ -837,14 +808,21 @@ struct V3 {
 #pragma unroll
                 for (int t = 1; t < K; ++t) inv |= (M >> t);
                 inv &= 0xFFFFu;
+                // byte offset of window j's bin: ((prev:cur) >> (30 - 2j)) & KM, times 4 -- one funnel shift + one AND per window
+                const uint32_t hi = (uint32_t)(w >> 32), lo = (uint32_t)w;
+                constexpr uint32_t KM4 = KM << 2;
                 if (__ballot(inv != 0u) == 0ull) {
 #pragma unroll
-                    for (int j = 0; j < 16; ++j) atomicAdd(&hist[(uint32_t)(w >> (30 - 2 * j)) & KM], 1u);
+                    for (int j = 0; j < 16; ++j) {
+                        const uint32_t ad = (j < 15 ? __builtin_amdgcn_alignbit(hi, lo, 28 - 2 * (j < 15 ? j : 0)) : (lo << 2)) & KM4;
+                        atomicAdd((uint32_t *)((char *)hist + ad), 1u);
+                    }
                 } else {
+                    const uint32_t garbage = ((uint32_t)F + (tid & 3)) << 2;
 #pragma unroll
                     for (int j = 0; j < 16; ++j) {
-                        const uint32_t km = (uint32_t)(w >> (30 - 2 * j)) & KM;
-                        atomicAdd(&hist[((inv >> (15 - j)) & 1u) ? (uint32_t)F + (tid & 3) : km], 1u);
+                        const uint32_t ad = (j < 15 ? __builtin_amdgcn_alignbit(hi, lo, 28 - 2 * (j < 15 ? j : 0)) : (lo << 2)) & KM4;
+                        atomicAdd((uint32_t *)((char *)hist + (((inv >> (15 - j)) & 1u) ? garbage : ad)), 1u);
                     }
                 }
                 cnt += 16u - (uint32_t)__popc(inv);
@@ -937,7 +915,15 @@ __global__ __launch_bounds__(V3_NT, 8) void vectorise3_kernel(VecArgs a)
         const int nslots = fast ? (int)nsl64 : 0;
         if (mw == 0) {
             if (ln < P) { vt[(1 + ln) * V3_VT] = (uint32_t)ne; vt[(1 + ln) * V3_VT + 1] = (uint32_t)eoff; vt[(1 + ln) * V3_VT + 2] = (uint32_t)(eoff * K); }
-            if (ln == 0) { vt[0] = fast ? 1u : 0u; vt[1] = (uint32_t)(total_e * K); vt[2] = (uint32_t)nslots; vt[3] = (uint32_t)(fast ? L64 : 0); }
+            // the view with the most edits goes last (its list is applied once and never undone): found here, once per sequence
+            int best = ne, vl = ln < P ? ln : 0;
+            if (ln >= P) best = -1;
+#pragma unroll
+            for (int o = 1; o < V3_MAXV; o <<= 1) {
+                const int b2 = __shfl_xor(best, o, 64), v2 = __shfl_xor(vl, o, 64);
+                if (b2 > best || (b2 == best && v2 < vl)) { best = b2; vl = v2; }
+            }
+            if (ln == 0) { vt[0] = (fast ? 1u : 0u) | ((uint32_t)vl << 8); vt[1] = (uint32_t)(total_e * K); vt[2] = (uint32_t)nslots; vt[3] = (uint32_t)(fast ? L64 : 0); }
         }
         if (!fast) return;
         if (mw == 0) {
@@ -1024,9 +1010,7 @@ __global__ __launch_bounds__(V3_NT, 8) void vectorise3_kernel(VecArgs a)
         q.vt = vtab + (it & 1) * V3_VTAB;
         q.fast = (q.vt[0] & 1u) != 0u;
         q.TP = (a.ablate & 4) ? 0 : (int)q.vt[1]; q.nslots = (int)q.vt[2]; q.L = (int)q.vt[3];
-        q.vlast = P - 1;                       // the view with the most edits goes last: its list is applied once and never undone
-        int best = -1;
-        for (int v = 0; v < P; ++v) { const int c = (int)q.vt[(1 + v) * V3_VT]; if (c > best) { best = c; q.vlast = v; } }
+        q.vlast = (int)((q.vt[0] >> 8) & 0xFFu);      // the view with the most edits goes last (stage_next)
         return q;
     };
     auto view_at = [&](const Seq &q, int vi) -> int { return (vi == P - 1) ? q.vlast : (vi < q.vlast ? vi : vi + 1); };
@@ -1094,17 +1078,13 @@ __global__ __launch_bounds__(V3_NT, 8) void vectorise3_kernel(VecArgs a)
                         for (int u = 1; u < P; ++u) if (e >= (int)vt[(1 + u) * V3_VT + 1]) v = u;      // edit bases ascend with the view index
                         const int ne = (int)vt[(1 + v) * V3_VT], eo = (int)vt[(1 + v) * V3_VT + 1];
                         uint32_t pr[K];
-                        W::edit_eval((const uint32_t *)(edl + eo), ne, e - eo, q.L - 1, cod, msk, pr);
-                        int d = 0;
+                        const int d = W::edit_eval((const uint32_t *)(edl + eo), ne, e - eo, q.L - 1, cod, msk, ((uint32_t)F + (tid & 3)) << 2, pr);
 #pragma unroll
-                        for (int t = 0; t < K; ++t) {
-                            list[e * K + t] = pr[t];
-                            d += (int)((pr[t] >> 16) != 0xFFFFu) - (int)((pr[t] & 0xFFFFu) != 0xFFFFu);
-                        }
+                        for (int t = 0; t < K; ++t) list[e * K + t] = pr[t];
                         if (d != 0) atomicAdd(&ctr[1 + v], d);
                         if (v == vfirst) {
 #pragma unroll
-                            for (int t = 0; t < K; ++t) W::move(hist, pr[t] & 0xFFFFu, pr[t] >> 16, 0xFFFFFFFFu, 1u);
+                            for (int t = 0; t < K; ++t) W::move(hist, pr[t], 1u);
                         }
                     }
                 }
@@ -1120,8 +1100,8 @@ __global__ __launch_bounds__(V3_NT, 8) void vectorise3_kernel(VecArgs a)
                     const int v = view_at(q, vi), v2 = view_at(q, vi + 1);
                     const int na = (a.ablate & 4) ? 0 : (int)vt[(1 + v) * V3_VT] * K, pa = (int)vt[(1 + v) * V3_VT + 2];
                     const int nb = (a.ablate & 4) ? 0 : (int)vt[(1 + v2) * V3_VT] * K, pb = (int)vt[(1 + v2) * V3_VT + 2];
-                    for (int x = tid; x < na; x += NC) { const uint32_t e = list[pa + x]; W::move(hist, e & 0xFFFFu, e >> 16, 1u, 0xFFFFFFFFu); }
-                    for (int x = tid; x < nb; x += NC) { const uint32_t e = list[pb + x]; W::move(hist, e & 0xFFFFu, e >> 16, 0xFFFFFFFFu, 1u); }
+                    for (int x = tid; x < na; x += NC) W::move(hist, list[pa + x], 0xFFFFFFFFu);       // undo view v
+                    for (int x = tid; x < nb; x += NC) W::move(hist, list[pb + x], 1u);                // apply view v2
                 } else {
                     clear_hist();
                 }

@@ -505,13 +505,18 @@ __global__ __launch_bounds__(64 * V2_WAVES, B16 ? 8 : 6) void vectorise2_kernel(
     const uint32_t iv = (a.init == IDL_INIT_ONE) ? 1u : 0u;
     const uint32_t ivw = B16 ? iv * 0x00010001u : iv;
 
-    if (a.redo != 0 && *(const volatile int *)a.redo_count == 0) return;     // second pass after v3 with nothing left to do
-    for (int64_t s = blockIdx.x; s < a.n; s += gridDim.x) {
+    // second pass after v3: nothing left to do -> exit; a few sequences -> exactly those (v3 listed them); many -> scan all and skip v3's
+    const int redo_n = a.redo != 0 ? *(const volatile int *)a.redo_count : 0;
+    if (a.redo != 0 && redo_n == 0) return;
+    const bool redo_listed = a.redo != 0 && redo_n <= V3_REDO_CAP;
+    const int64_t loop_n = redo_listed ? (int64_t)redo_n : a.n;
+    for (int64_t si = blockIdx.x; si < loop_n; si += gridDim.x) {
+        const int64_t s = redo_listed ? ((const int64_t *)(a.redo_count + 2))[si] : si;
         const int64_t slot0 = a.slot_off[s];
         const int64_t nslots = a.slot_off[s + 1] - slot0;
         const int64_t L = a.lengths[s];
         const int64_t nsc = (nslots + SC - 1) / SC;
-        if (a.redo != 0) {      // second pass: only the sequences v3 left alone (the predicate of vectorise3_kernel's stage_next, restated)
+        if (a.redo != 0 && !redo_listed) {      // second pass without a list: only the sequences v3 left alone (the predicate of vectorise3_kernel's stage_next, restated)
             int64_t te = 0;
             if (a.edits != nullptr)
                 for (int v = 0; v < a.n_views; ++v) {
@@ -699,6 +704,7 @@ __global__ __launch_bounds__(64 * V2_WAVES, B16 ? 8 : 6) void vectorise2_kernel(
 // A sequence whose edits / pairs do not fit the LDS tables takes a slower in-kernel path (per-view pair passes, like v2).
 // =====================================================================================================
 constexpr int V3_MAXV = 8;                      // views
+constexpr int V3_REDO_CAP = 1023;               // sequences v3 can list for the second pass (beyond that the second pass scans)
 constexpr int V3_META = 8 + 4 * V3_MAXV;        // dwords of a meta ring entry: slot_off[s], slot_off[s+1], lengths[s], pad; per view edit_off[v*n+s], [..+1]
 constexpr int V3_VT = 4;                        // dwords of a view-table row: edits, first edit's index in LDS, first pair's index in the list, spare
 constexpr int V3_VTAB = (V3_MAXV + 1) * V3_VT;  // row 0 = header: flags (1 fast, 2 edits staged), total pairs, staged slots, clamped length
@@ -1047,7 +1053,10 @@ __global__ __launch_bounds__(V3_NT, 8) void vectorise3_kernel(VecArgs a)
                     mark(7);
                 }
             } else {
-                if (lane == 0 && mw == 0) atomicAdd(a.redo_count, 1);      // the launcher's second pass (v2) takes this sequence
+                if (lane == 0 && mw == 0) {                                   // the launcher's second pass (v2) takes this sequence
+                    const int slot = atomicAdd(a.redo_count, 1);
+                    if (slot < V3_REDO_CAP) ((int64_t *)(a.redo_count + 2))[slot] = s;
+                }
                 vm_wait<0>();
                 __syncthreads();
             }
@@ -1150,7 +1159,7 @@ int *redo_counter()
     static int *ptr[64] = {nullptr};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-    if (ptr[dev] == nullptr) { if (hipMalloc((void **)&ptr[dev], 256) != hipSuccess) ptr[dev] = nullptr; }
+    if (ptr[dev] == nullptr) { if (hipMalloc((void **)&ptr[dev], 8 + 8 * (size_t)V3_REDO_CAP) != hipSuccess) ptr[dev] = nullptr; }
     return ptr[dev];
 }
 
@@ -1212,10 +1221,17 @@ int launch_vectorise3(const VecArgs &a_in, const idl::DeviceInfo &di, hipStream_
             a.n_views > V3_MAXV || a.max_len <= 0 || a.max_len > 64 * 2048)
             return IDL_OK;
         a.sc_slots = (int)((a.max_len + 63) / 64);
-        // LDS tables for the edits of all views (3.5 % of the bases + slack) and their K windows each; IDELUCS_V3_EC / _LC override
+        // LDS tables for the edits of all views and their K windows each: at least 3.5 % of the bases + slack, and whatever else
+        // fits at four workgroups per CU (an edit costs 2 + K words: two staging sets and the list); IDELUCS_V3_EC / _LC override
         int ec = (int)(a.max_len * 35 / 1000) + 64, lc;
+        {
+            const int fixed = (F + 4) + 2 * (a.sc_slots + 1) * 6 + 3 * V3_META + 2 * V3_VTAB + 16;
+            const int budget = (di.lds_per_cu / 4 - 1024) / 4 - fixed - 64 * K;
+            const int fit = budget / (2 + K);
+            if (fit > ec) ec = fit > 4096 ? 4096 : fit;
+        }
         if (const char *e = getenv("IDELUCS_V3_EC")) { const int t = atoi(e); if (t >= 0 && t <= 16384) ec = t; }
-        ec = (ec + 63) & ~63;
+        ec &= ~63;
         lc = (ec - 64 > 0 ? ec - 64 : 0) * K;
         if (const char *e = getenv("IDELUCS_V3_LC")) { const int t = atoi(e); if (t >= 0 && t <= 65536) lc = t; }
         if (a.edits == nullptr) { ec = 0; lc = 0; }

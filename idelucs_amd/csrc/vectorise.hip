@@ -46,6 +46,7 @@ struct VecArgs {
 };
 
 constexpr int STAGE_DWORDS = 256 + 128;  // 64 lanes x (4 code words + 2 mask words)
+constexpr int V3_REDO_CAP = 1023;        // sequences the v3 kernel can list for the second pass on v2 (beyond that the second pass scans)
 
 __device__ __forceinline__ uint32_t spread_bits(uint32_t x)
 {
@@ -704,7 +705,6 @@ __global__ __launch_bounds__(64 * V2_WAVES, B16 ? 8 : 6) void vectorise2_kernel(
 // A sequence whose edits / pairs do not fit the LDS tables takes a slower in-kernel path (per-view pair passes, like v2).
 // =====================================================================================================
 constexpr int V3_MAXV = 8;                      // views
-constexpr int V3_REDO_CAP = 1023;               // sequences v3 can list for the second pass (beyond that the second pass scans)
 constexpr int V3_META = 8 + 4 * V3_MAXV;        // dwords of a meta ring entry: slot_off[s], slot_off[s+1], lengths[s], pad; per view edit_off[v*n+s], [..+1]
 constexpr int V3_VT = 4;                        // dwords of a view-table row: edits, first edit's index in LDS, first pair's index in the list, spare
 constexpr int V3_VTAB = (V3_MAXV + 1) * V3_VT;  // row 0 = header: flags (1 fast, 2 edits staged), total pairs, staged slots, clamped length

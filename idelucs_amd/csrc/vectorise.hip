@@ -1226,13 +1226,12 @@ int launch_vectorise3(const VecArgs &a_in, const idl::DeviceInfo &di, hipStream_
         int ec = (int)(a.max_len * 35 / 1000) + 64, lc;
         {
             const int fixed = (F + 4) + 2 * (a.sc_slots + 1) * 6 + 3 * V3_META + 2 * V3_VTAB + 16;
-            const int budget = (di.lds_per_cu / 4 - 1024) / 4 - fixed - 64 * K;
-            const int fit = budget / (2 + K);
+            const int fit = ((di.lds_per_cu / 4 - 1024) / 4 - fixed) / (2 + K);
             if (fit > ec) ec = fit > 4096 ? 4096 : fit;
         }
         if (const char *e = getenv("IDELUCS_V3_EC")) { const int t = atoi(e); if (t >= 0 && t <= 16384) ec = t; }
-        ec &= ~63;
-        lc = (ec - 64 > 0 ? ec - 64 : 0) * K;
+        ec &= ~7;
+        lc = ec * K;
         if (const char *e = getenv("IDELUCS_V3_LC")) { const int t = atoi(e); if (t >= 0 && t <= 65536) lc = t; }
         if (a.edits == nullptr) { ec = 0; lc = 0; }
         a.ecap = ec; a.lcap = lc;

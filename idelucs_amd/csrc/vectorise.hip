@@ -39,7 +39,7 @@ struct VecArgs {
     int64_t max_len; // upper bound on the sequence lengths, 0 = unknown
     int *redo_count; // v3 -> v2 hand-over: number of sequences v3 left to the second pass (device word); v2 with redo != 0 takes exactly those
     int redo, v3_sc; //   (a sequence is v3's iff its edits fit ecap, its pairs lcap and its slots v3_sc)
-    int blocked;     // v3: every workgroup owns a run of consecutive sequences (else: sequences dealt round-robin)
+    int chunk;       // v3: consecutive sequences per workgroup and round (chunks are dealt round-robin over the workgroups)
     int ecap, lcap;  // v3: LDS capacity for the staged edits of all views / for the recorded (edit, window) pairs
     unsigned long long *dbg;   // diagnostic (IDELUCS_VEC_DBG): per-workgroup cycle sums of the phases
     int ablate;      // diagnostic builds only (IDELUCS_VEC_ABLATE): 1 no row stores, 2 no H0 count, 4 no deltas, 8 raw epilogue
@@ -869,20 +869,19 @@ __global__ __launch_bounds__(V3_NT, 8) void vectorise3_kernel(VecArgs a)
     const uint32_t iv = (a.init == IDL_INIT_ONE) ? 1u : 0u;
     const bool has_edits = a.edits != nullptr;
 
-    // this workgroup's sequences: s_i = s_first + i * s_step, i < s_count (dealt round-robin; a.blocked: a run of consecutive ones)
-    int64_t s_first, s_step, s_count;
+    // this workgroup's sequences: chunks of a.chunk consecutive sequences dealt round-robin over the workgroups --
+    // s_i = ((i / C) G + b) C + i % C, i < s_count (each workgroup's row stores walk through C rows of every view in order and
+    // the rows being written chip-wide stay in a narrow window: + 10-15 % store rate, tools/store_pattern.hip)
+    const int64_t QG = gridDim.x, QB = blockIdx.x, QC = a.chunk > 0 ? a.chunk : 1;
+    auto seq_index = [&](int64_t i) -> int64_t { return ((i / QC) * QG + QB) * QC + i % QC; };
+    int64_t s_count;
     {
-        const int64_t G = gridDim.x, b = blockIdx.x;
-        if (a.blocked) {
-            const int64_t per = (a.n + G - 1) / G;
-            s_first = b * per; s_step = 1;
-            s_count = a.n - s_first < per ? a.n - s_first : per;
-            if (s_count < 0) s_count = 0;
-        } else {
-            s_first = b; s_step = G;
-            s_count = (a.n - b + G - 1) / G;
-        }
+        const int64_t q = a.n / (QG * QC);                         // complete rounds
+        const int64_t start = (q * QG + QB) * QC;                  // this workgroup's chunk of the last, partial round
+        const int64_t tail = a.n - start;
+        s_count = q * QC + (tail < 0 ? 0 : (tail > QC ? QC : tail));
     }
+    const int64_t s_first = seq_index(0);
 
     // ---------------- memory wave: slot range, length and edit ranges of sequence s -> meta ring entry r (one DMA instruction)
     auto dma_meta = [&](int64_t s, int r) {
@@ -996,7 +995,7 @@ __global__ __launch_bounds__(V3_NT, 8) void vectorise3_kernel(VecArgs a)
     __syncthreads();
     if (mw == 0 && s_count > 0) {
         dma_meta(s_first, 0);
-        if (s_count > 1) dma_meta(s_first + s_step, 1);
+        if (s_count > 1) dma_meta(seq_index(1), 1);
         vm_wait<0>();
     }
     __syncthreads();
@@ -1027,13 +1026,13 @@ __global__ __launch_bounds__(V3_NT, 8) void vectorise3_kernel(VecArgs a)
         // =============================================================== the memory wave
         int r = 0;
         for (int64_t it = 0; it < s_count; ++it) {
-            const int64_t s = s_first + it * s_step;
+            const int64_t s = seq_index(it);
             const Seq q = seq_of(it);
             const int r1 = (r + 1 == 3) ? 0 : r + 1, r2 = (r1 + 1 == 3) ? 0 : r1 + 1;
             // while the compute waves count this sequence: the next sequence's data and the one after's meta leave for LDS (the other
             // staging set was last read one sequence ago)
             if (it + 1 < s_count) stage_next(r1, vtab + ((it + 1) & 1) * V3_VTAB, sets + ((it + 1) & 1) * SET);
-            if (mw == 0 && it + 2 < s_count) dma_meta(s + 2 * s_step, r2);
+            if (mw == 0 && it + 2 < s_count) dma_meta(seq_index(it + 2), r2);
             mark(5);
             if (q.fast) {
                 __syncthreads();                                // P1 of the compute waves is over
@@ -1235,8 +1234,8 @@ int launch_vectorise3(const VecArgs &a_in, const idl::DeviceInfo &di, hipStream_
         if (const char *e = getenv("IDELUCS_V3_LC")) { const int t = atoi(e); if (t >= 0 && t <= 65536) lc = t; }
         if (a.edits == nullptr) { ec = 0; lc = 0; }
         a.ecap = ec; a.lcap = lc;
-        a.blocked = 0;
-        if (const char *e = getenv("IDELUCS_V3_BLOCKED")) a.blocked = atoi(e) != 0;
+        a.chunk = 4;
+        if (const char *e = getenv("IDELUCS_V3_CHUNK")) { const int t = atoi(e); if (t >= 1 && t <= 4096) a.chunk = t; }
         if (const char *e = getenv("IDELUCS_VEC_ABLATE")) a.ablate = atoi(e);
         const size_t lds = (size_t)((F + 4) + 2 * ((a.sc_slots + 1) * 6 + ec) + lc + 3 * V3_META + 2 * V3_VTAB + 16) * 4;
         if ((int)lds > di.max_dyn_lds || lds > 80 * 1024) return IDL_OK;                 // (fewer than two workgroups per CU: v2's chunked staging is the better fit)

@@ -56,6 +56,31 @@ __global__ __launch_bounds__(256) void rows_by_waves_kernel(float *out, int64_t 
     }
 }
 
+// persistent workgroups that take the next sequence (or chunk of C sequences) from a global counter instead of a fixed stride
+template <int C>
+__global__ __launch_bounds__(256) void rows_queue_kernel(float *out, int64_t n, int P, int64_t view_stride, unsigned long long *head)
+{
+    __shared__ unsigned long long base_s;
+    const int tid = threadIdx.x;
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    for (;;) {
+        if (tid == 0) base_s = atomicAdd(head, (unsigned long long)C);
+        __syncthreads();
+        const int64_t base = (int64_t)base_s;
+        __syncthreads();
+        if (base >= n) break;
+        for (int c = 0; c < C && base + c < n; ++c) {
+            const int64_t s = base + c;
+            for (int v = 0; v < P; ++v) {
+                f4 *row = (f4 *)(out + v * view_stride + s * 4096);
+                const f4 val = {(float)s, (float)v, 1.f, 2.f};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) row[tid + j * 256] = val;
+            }
+        }
+    }
+}
+
 __global__ void fill_kernel(float4 *out, int64_t n4)
 {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) out[i] = make_float4(1.f, 2.f, 3.f, 4.f);
@@ -92,6 +117,14 @@ int main()
         time(nm, [&] { hipLaunchKernelGGL(rows_by_waves_kernel<2>, dim3(256 * wg), dim3(256), 0, 0, out, n, P, n * F); });
         snprintf(nm, sizeof nm, "rows stored by all FOUR waves, %d WG/CU", wg);
         time(nm, [&] { hipLaunchKernelGGL(rows_by_waves_kernel<4>, dim3(256 * wg), dim3(256), 0, 0, out, n, P, n * F); });
+    }
+    unsigned long long *head; CK(hipMalloc(&head, 8));
+    for (int wg : {4, 8}) {
+        char nm[128];
+        snprintf(nm, sizeof nm, "rows, persistent WGs + global queue (1 sequence per grab), %d WG/CU", wg);
+        time(nm, [&] { (void)hipMemsetAsync(head, 0, 8, 0); hipLaunchKernelGGL(rows_queue_kernel<1>, dim3(256 * wg), dim3(256), 0, 0, out, n, P, n * F, head); });
+        snprintf(nm, sizeof nm, "rows, persistent WGs + global queue (4 sequences per grab), %d WG/CU", wg);
+        time(nm, [&] { (void)hipMemsetAsync(head, 0, 8, 0); hipLaunchKernelGGL(rows_queue_kernel<4>, dim3(256 * wg), dim3(256), 0, 0, out, n, P, n * F, head); });
     }
     time("rows, nontemporal stores, 4 WG/CU, interleaved", [&] { hipLaunchKernelGGL(rows_kernel<1>, dim3(1024), dim3(256), 0, 0, out, n, P, n * F, 0); });
     for (int wg : {2, 4, 6}) {

@@ -869,18 +869,17 @@ __global__ __launch_bounds__(V3_NT, 8) void vectorise3_kernel(VecArgs a)
     const uint32_t iv = (a.init == IDL_INIT_ONE) ? 1u : 0u;
     const bool has_edits = a.edits != nullptr;
 
-    // this workgroup's sequences: chunks of a.chunk consecutive sequences dealt round-robin over the workgroups --
-    // s_i = ((i / C) G + b) C + i % C, i < s_count (each workgroup's row stores walk through C rows of every view in order and
-    // the rows being written chip-wide stay in a narrow window: + 10-15 % store rate, tools/store_pattern.hip)
+    // this workgroup's sequences: chunks of a.chunk consecutive sequences dealt round-robin over the workgroups while whole
+    // rounds last -- s_i = ((i / C) G + b) C + i % C -- then the remaining < G C sequences one by one (s = rounds G C + j G + b), so
+    // that no workgroup ends more than one sequence after another.  (Each workgroup's row stores walk through C rows of every
+    // view in order and the rows being written chip-wide stay in a narrow window: + 10-15 % store rate, tools/store_pattern.hip.)
     const int64_t QG = gridDim.x, QB = blockIdx.x, QC = a.chunk > 0 ? a.chunk : 1;
-    auto seq_index = [&](int64_t i) -> int64_t { return ((i / QC) * QG + QB) * QC + i % QC; };
-    int64_t s_count;
-    {
-        const int64_t q = a.n / (QG * QC);                         // complete rounds
-        const int64_t start = (q * QG + QB) * QC;                  // this workgroup's chunk of the last, partial round
-        const int64_t tail = a.n - start;
-        s_count = q * QC + (tail < 0 ? 0 : (tail > QC ? QC : tail));
-    }
+    const int64_t q_rounds = a.n / (QG * QC), q_head = q_rounds * QC;      // iterations of this workgroup inside whole rounds
+    auto seq_index = [&](int64_t i) -> int64_t {
+        return i < q_head ? ((i / QC) * QG + QB) * QC + i % QC : q_rounds * QG * QC + (i - q_head) * QG + QB;
+    };
+    const int64_t n_tail = a.n - q_rounds * QG * QC;
+    const int64_t s_count = q_head + (QB < n_tail ? (n_tail - QB + QG - 1) / QG : 0);
     const int64_t s_first = seq_index(0);
 
     // ---------------- memory wave: slot range, length and edit ranges of sequence s -> meta ring entry r (one DMA instruction)

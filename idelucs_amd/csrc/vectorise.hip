@@ -37,7 +37,7 @@ struct VecArgs {
     int64_t view_stride;
     int sc_slots;   // v2: slots (64 bases) staged in LDS at a time
     int64_t max_len; // upper bound on the sequence lengths, 0 = unknown
-    int *redo_count; // v3 -> v2 hand-over: number of sequences v3 left to the second pass (device word); v2 with redo != 0 takes exactly those
+    int *redo_count; // v3 device scratch: [0] number of sequences v3 left to the second pass (v2 with redo != 0 takes exactly those), [1] head of v3's sequence queue, [2..] the list of those sequences
     int redo, v3_sc; //   (a sequence is v3's iff its edits fit ecap, its pairs lcap and its slots v3_sc)
     int chunk;       // v3: consecutive sequences per workgroup and round (chunks are dealt round-robin over the workgroups)
     int ecap, lcap;  // v3: LDS capacity for the staged edits of all views / for the recorded (edit, window) pairs
@@ -863,25 +863,21 @@ __global__ __launch_bounds__(V3_NT, 8) void vectorise3_kernel(VecArgs a)
     uint32_t *meta = list + a.lcap;                         // ring of 3 entries
     uint32_t *vtab = meta + 3 * V3_META;                    // two view tables (this sequence / the next)
     int32_t *ctr = (int32_t *)(vtab + 2 * V3_VTAB);         // [0] valid windows of the un-mutated sequence, [1 + v] window delta of view v
+    volatile int32_t *qb = ctr + 16;                        // first sequence of the last four batches this workgroup pulled
     const int tid = threadIdx.x, lane = tid & 63;
     const int mw = __builtin_amdgcn_readfirstlane(tid >> 6) - NC / 64;         // >= 0: memory wave number
     const bool mem = mw >= 0;
     const uint32_t iv = (a.init == IDL_INIT_ONE) ? 1u : 0u;
     const bool has_edits = a.edits != nullptr;
 
-    // this workgroup's sequences: chunks of a.chunk consecutive sequences dealt round-robin over the workgroups while whole
-    // rounds last -- s_i = ((i / C) G + b) C + i % C -- then the remaining < G C sequences one by one (s = rounds G C + j G + b), so
-    // that no workgroup ends more than one sequence after another.  (Each workgroup's row stores walk through C rows of every
-    // view in order and the rows being written chip-wide stay in a narrow window: + 10-15 % store rate, tools/store_pattern.hip.)
-    const int64_t QG = gridDim.x, QB = blockIdx.x, QC = a.chunk > 0 ? a.chunk : 1;
-    const int64_t q_rounds = a.n / (QG * QC), q_head = q_rounds * QC;      // iterations of this workgroup inside whole rounds
-    auto seq_index = [&](int64_t i) -> int64_t {
-        return i < q_head ? ((i / QC) * QG + QB) * QC + i % QC : q_rounds * QG * QC + (i - q_head) * QG + QB;
-    };
-    const int64_t n_tail = a.n - q_rounds * QG * QC;
-    const int64_t s_count = q_head + (QB < n_tail ? (n_tail - QB + QG - 1) / QG : 0);
-    const int64_t s_first = seq_index(0);
-
+    // this workgroup's sequences: batches of a.chunk consecutive sequences pulled from a global counter (one returning atomic per
+    // batch, issued by a compute wave -- they have no other vector-memory traffic -- three sequences before the batch is needed).
+    // Dynamic: the rows being written chip-wide stay in a narrow window, every workgroup's row stores walk through C rows of every
+    // view in order, and no workgroup ends more than a sequence after another (+ 10-15 % store rate over a fixed stride on
+    // boxes with slow HBM: tools/store_pattern.hip).  Iteration i of this workgroup is sequence qb[(i / C) & 3] + i % C.
+    const int QC = a.chunk > 0 ? a.chunk : 1;
+    int *qhead = a.redo_count + 1;
+    auto seq_index = [&](int64_t i) -> int64_t { return (int64_t)qb[(i / QC) & 3] + i % QC; };
     // ---------------- memory wave: slot range, length and edit ranges of sequence s -> meta ring entry r (one DMA instruction)
     auto dma_meta = [&](int64_t s, int r) {
         int l = lane;
@@ -991,14 +987,15 @@ __global__ __launch_bounds__(V3_NT, 8) void vectorise3_kernel(VecArgs a)
     if (tid < 4) sets[(tid >> 1) * SET + (SC + 1) * 4 + (tid & 1)] = 0xFFFFFFFFu;
     for (int i = tid; i < 3 * V3_META + 2 * V3_VTAB; i += V3_NT) meta[i] = 0u;
     if (!mem) clear_hist();
+    if (tid == 0) { qb[0] = atomicAdd(qhead, QC); qb[1] = atomicAdd(qhead, QC); qb[2] = 0x7FFFFFFF; qb[3] = 0x7FFFFFFF; }
     __syncthreads();
-    if (mw == 0 && s_count > 0) {
-        dma_meta(s_first, 0);
-        if (s_count > 1) dma_meta(seq_index(1), 1);
+    if (mw == 0 && seq_index(0) < a.n) {
+        dma_meta(seq_index(0), 0);
+        if (seq_index(1) < a.n) dma_meta(seq_index(1), 1);
         vm_wait<0>();
     }
     __syncthreads();
-    if (mem && s_count > 0) { stage_next(0, vtab, sets); vm_wait<0>(); }
+    if (mem && seq_index(0) < a.n) { stage_next(0, vtab, sets); vm_wait<0>(); }
     __syncthreads();
 
     // diagnostic stamps (DIAG build, a.dbg != NULL): cycles per phase, summed over this workgroup's sequences, compute wave 0 and the memory wave
@@ -1024,14 +1021,15 @@ __global__ __launch_bounds__(V3_NT, 8) void vectorise3_kernel(VecArgs a)
     if (mem) {
         // =============================================================== the memory wave
         int r = 0;
-        for (int64_t it = 0; it < s_count; ++it) {
+        for (int64_t it = 0;; ++it) {
             const int64_t s = seq_index(it);
+            if (s >= a.n) break;
             const Seq q = seq_of(it);
             const int r1 = (r + 1 == 3) ? 0 : r + 1, r2 = (r1 + 1 == 3) ? 0 : r1 + 1;
             // while the compute waves count this sequence: the next sequence's data and the one after's meta leave for LDS (the other
             // staging set was last read one sequence ago)
-            if (it + 1 < s_count) stage_next(r1, vtab + ((it + 1) & 1) * V3_VTAB, sets + ((it + 1) & 1) * SET);
-            if (mw == 0 && it + 2 < s_count) dma_meta(seq_index(it + 2), r2);
+            if (seq_index(it + 1) < a.n) stage_next(r1, vtab + ((it + 1) & 1) * V3_VTAB, sets + ((it + 1) & 1) * SET);
+            if (mw == 0) { const int64_t s2 = seq_index(it + 2); if (s2 < a.n) dma_meta(s2, r2); }
             mark(5);
             if (q.fast) {
                 __syncthreads();                                // P1 of the compute waves is over
@@ -1062,9 +1060,14 @@ __global__ __launch_bounds__(V3_NT, 8) void vectorise3_kernel(VecArgs a)
         }
     } else {
         // =============================================================== the compute waves
-        for (int64_t it = 0; it < s_count; ++it) {
+        for (int64_t it = 0;; ++it) {
+            if (seq_index(it) >= a.n) break;
             const Seq q = seq_of(it);
-            if (!q.fast) { __syncthreads(); continue; }
+            // the batch that iteration it + 3 starts is pulled now and published by this sequence's first barrier
+            const bool grab = tid == 0 && (it + 3) % QC == 0 && (it + 3) / QC >= 2;
+            int grabbed = 0;
+            if (grab) grabbed = atomicAdd(qhead, QC);
+            if (!q.fast) { if (grab) qb[((it + 3) / QC) & 3] = grabbed; __syncthreads(); continue; }
             const uint32_t *vt = q.vt;
             const uint32_t *cod = sets + (it & 1) * SET, *msk = cod + (SC + 1) * 4, *edl = cod + (SC + 1) * 6;
             // ---------------- P1: count the un-mutated sequence, evaluate every edit of every view
@@ -1096,6 +1099,7 @@ __global__ __launch_bounds__(V3_NT, 8) void vectorise3_kernel(VecArgs a)
                     }
                 }
             }
+            if (grab) qb[((it + 3) / QC) & 3] = grabbed;
             mark(1);
             __syncthreads();
             mark(2);
@@ -1171,7 +1175,7 @@ int launch_vectorise3_k(VecArgs &a, const idl::DeviceInfo &di, hipStream_t st, s
     if (grid > a.n) grid = a.n;
     a.redo_count = redo_counter();
     if (a.redo_count == nullptr) { idl::set_error("cannot allocate the v3 hand-over word"); return IDL_ERR_HIP; }
-    IDL_HIP_TRY(hipMemsetAsync(a.redo_count, 0, sizeof(int), st));
+    IDL_HIP_TRY(hipMemsetAsync(a.redo_count, 0, 2 * sizeof(int), st));      // [0] sequences left to the second pass, [1] head of the sequence queue
     if (dbg) { IDL_HIP_TRY(hipMalloc((void **)&a.dbg, (size_t)grid * 20 * 8)); IDL_HIP_TRY(hipMemset(a.dbg, 0, (size_t)grid * 20 * 8)); }
     if (dbg) hipLaunchKernelGGL((vectorise3_kernel<K, true>), dim3((unsigned)grid), dim3(V3_NT), lds, st, a);
     else hipLaunchKernelGGL((vectorise3_kernel<K, false>), dim3((unsigned)grid), dim3(V3_NT), lds, st, a);
@@ -1216,14 +1220,14 @@ int launch_vectorise3(const VecArgs &a_in, const idl::DeviceInfo &di, hipStream_
         int want = 3;
         if (const char *e = getenv("IDELUCS_VEC")) want = atoi(e);
         if (want != 3 || a.mode != IDL_MODE_KMER || a.init == IDL_INIT_FROM_OUT || a.out_kind == IDL_OUT_FREQ_F64 ||
-            a.n_views > V3_MAXV || a.max_len <= 0 || a.max_len > 64 * 2048)
+            a.n_views > V3_MAXV || a.max_len <= 0 || a.max_len > 64 * 2048 || a.n > 0x7F000000ll)
             return IDL_OK;
         a.sc_slots = (int)((a.max_len + 63) / 64);
         // LDS tables for the edits of all views and their K windows each: at least 3.5 % of the bases + slack, and whatever else
         // fits at four workgroups per CU (an edit costs 2 + K words: two staging sets and the list); IDELUCS_V3_EC / _LC override
         int ec = (int)(a.max_len * 35 / 1000) + 64, lc;
         {
-            const int fixed = (F + 4) + 2 * (a.sc_slots + 1) * 6 + 3 * V3_META + 2 * V3_VTAB + 16;
+            const int fixed = (F + 4) + 2 * (a.sc_slots + 1) * 6 + 3 * V3_META + 2 * V3_VTAB + 16 + 4;
             const int fit = ((di.lds_per_cu / 4 - 1024) / 4 - fixed) / (2 + K);
             if (fit > ec) ec = fit > 4096 ? 4096 : fit;
         }
@@ -1236,7 +1240,7 @@ int launch_vectorise3(const VecArgs &a_in, const idl::DeviceInfo &di, hipStream_
         a.chunk = 4;
         if (const char *e = getenv("IDELUCS_V3_CHUNK")) { const int t = atoi(e); if (t >= 1 && t <= 4096) a.chunk = t; }
         if (const char *e = getenv("IDELUCS_VEC_ABLATE")) a.ablate = atoi(e);
-        const size_t lds = (size_t)((F + 4) + 2 * ((a.sc_slots + 1) * 6 + ec) + lc + 3 * V3_META + 2 * V3_VTAB + 16) * 4;
+        const size_t lds = (size_t)((F + 4) + 2 * ((a.sc_slots + 1) * 6 + ec) + lc + 3 * V3_META + 2 * V3_VTAB + 16 + 4) * 4;
         if ((int)lds > di.max_dyn_lds || lds > 80 * 1024) return IDL_OK;                 // (fewer than two workgroups per CU: v2's chunked staging is the better fit)
         // workgroups per CU by LDS, with 1 KB of slack each (measured: five 32 032-byte workgroups do NOT become resident
         // together although 5 x 32 032 < 160 KB and the occupancy query says 5 -- the fifth ran after the others)

@@ -987,7 +987,8 @@ __global__ __launch_bounds__(V3_NT, 8) void vectorise3_kernel(VecArgs a)
     if (tid < 4) sets[(tid >> 1) * SET + (SC + 1) * 4 + (tid & 1)] = 0xFFFFFFFFu;
     for (int i = tid; i < 3 * V3_META + 2 * V3_VTAB; i += V3_NT) meta[i] = 0u;
     if (!mem) clear_hist();
-    if (tid == 0) { qb[0] = atomicAdd(qhead, QC); qb[1] = atomicAdd(qhead, QC); qb[2] = 0x7FFFFFFF; qb[3] = 0x7FFFFFFF; }
+    const int QPRO = QC == 1 ? 3 : 2;             // batches pulled up front: iterations 0..2 must be known before the loop starts
+    if (tid == 0) { for (int j = 0; j < 4; ++j) qb[j] = j < QPRO ? atomicAdd(qhead, QC) : 0x7FFFFFFF; }
     __syncthreads();
     if (mw == 0 && seq_index(0) < a.n) {
         dma_meta(seq_index(0), 0);
@@ -1064,7 +1065,7 @@ __global__ __launch_bounds__(V3_NT, 8) void vectorise3_kernel(VecArgs a)
             if (seq_index(it) >= a.n) break;
             const Seq q = seq_of(it);
             // the batch that iteration it + 3 starts is pulled now and published by this sequence's first barrier
-            const bool grab = tid == 0 && (it + 3) % QC == 0 && (it + 3) / QC >= 2;
+            const bool grab = tid == 0 && (it + 3) % QC == 0 && (it + 3) / QC >= QPRO;
             int grabbed = 0;
             if (grab) grabbed = atomicAdd(qhead, QC);
             if (!q.fast) { if (grab) qb[((it + 3) / QC) & 3] = grabbed; __syncthreads(); continue; }

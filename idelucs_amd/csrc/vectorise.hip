@@ -1238,7 +1238,7 @@ int launch_vectorise3(const VecArgs &a_in, const idl::DeviceInfo &di, hipStream_
         if (const char *e = getenv("IDELUCS_V3_LC")) { const int t = atoi(e); if (t >= 0 && t <= 65536) lc = t; }
         if (a.edits == nullptr) { ec = 0; lc = 0; }
         a.ecap = ec; a.lcap = lc;
-        a.chunk = 4;
+        a.chunk = 2;
         if (const char *e = getenv("IDELUCS_V3_CHUNK")) { const int t = atoi(e); if (t >= 1 && t <= 4096) a.chunk = t; }
         if (const char *e = getenv("IDELUCS_VEC_ABLATE")) a.ablate = atoi(e);
         const size_t lds = (size_t)((F + 4) + 2 * ((a.sc_slots + 1) * 6 + ec) + lc + 3 * V3_META + 2 * V3_VTAB + 16 + 4) * 4;

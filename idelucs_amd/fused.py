@@ -115,6 +115,7 @@ class FusedLinearTrainer:
         # opt-in: dW1 on this package's own MFMA kernel with RMSprop in its epilogue (csrc/wgrad.hip; measured a wash against
         # hipBLASLt + the optimizer launch, so off by default)
         self._wgrad_fused = os.environ.get("IDELUCS_WGRAD_FUSED", "0") != "0"
+        self._steps_per_graph = max(2, int(os.environ.get("IDELUCS_STEPS_PER_GRAPH", "8")) // 2 * 2)
         self._perm = None
         n = len(self.params)
         self._pp = (ctypes.c_void_p * n)(*[p.data_ptr() for p in self.params])
@@ -325,10 +326,14 @@ class FusedLinearTrainer:
             bf = self.buffers(2 * batch_sz)
             if pipe:
                 self._gather(store, bf)         # prologue: batch 0; every later batch is assembled by the previous step
+            # steps per graph replay: an even number when two x buffers alternate.  Between two replays the GPU idles ~9 us
+            # (profiles/r02_f: kernel trace), so a replay carries several steps
+            per = self._steps_per_graph if (pipe and self._early_gather) else 1
+            while per > 2 and n_full < 2 + 2 * per:      # short epochs: the capture itself runs 2 + per real steps
+                per = max(2, per // 4 * 2)
             # every address the captured launches bake in is part of the key (a store refitted in place keeps its graph)
             key = (2 * batch_sz, store.feats.data_ptr(), store.mean.data_ptr(), store.scale.data_ptr(), store.inv_scale.data_ptr(),
-                   self._perm.data_ptr(), store.n, store.f, store.n_views, pipe, self._early_gather)
-            per = 2 if (pipe and self._early_gather) else 1      # steps per graph replay (two x buffers alternate)
+                   self._perm.data_ptr(), store.n, store.f, store.n_views, pipe, self._early_gather, per)
             if use_graph and n_full >= 8:
                 g = self._graphs.get(key)
                 if g is None:

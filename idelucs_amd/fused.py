@@ -115,7 +115,7 @@ class FusedLinearTrainer:
         # opt-in: dW1 on this package's own MFMA kernel with RMSprop in its epilogue (csrc/wgrad.hip; measured a wash against
         # hipBLASLt + the optimizer launch, so off by default)
         self._wgrad_fused = os.environ.get("IDELUCS_WGRAD_FUSED", "0") != "0"
-        self._steps_per_graph = max(2, int(os.environ.get("IDELUCS_STEPS_PER_GRAPH", "8")) // 2 * 2)
+        self._steps_per_graph = max(2, int(os.environ.get("IDELUCS_STEPS_PER_GRAPH", "16")) // 2 * 2)
         self._perm = None
         n = len(self.params)
         self._pp = (ctypes.c_void_p * n)(*[p.data_ptr() for p in self.params])

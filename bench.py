@@ -318,7 +318,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", choices=["cfg2", "cfg5"], default="cfg2")
-    ap.add_argument("--n", type=int, default=None)
+    ap.add_argument("--n", "--n-sequences", dest="n", type=int, default=None)
     ap.add_argument("--len", type=int, default=None)
     ap.add_argument("--k", type=int, default=6)
     ap.add_argument("--n-clusters", dest="n_clusters", type=int, default=None)

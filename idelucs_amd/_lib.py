@@ -38,6 +38,7 @@ SIGNATURES = {
     "idl_ingest_threads": (_int, []),
     "idl_vectorise": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _int, _int, _int, _int, _vp, _vp, _vp, _i64, _i64, _vp]),
     "idl_mimic_workspace": (_i64, [_i64, _int]),
+    "idl_mimic_max_random_n": (_int, []),
     "idl_mimic_edits": (_int, [_vp, _i64, _int, _vp, _vp, _vp, _c.c_uint64, _vp, _vp, _i64, _pi64, _vp, _vp]),
     "idl_col_stats_workspace": (_i64, [_i64, _i64]),
     "idl_col_stats": (_int, [_vp, _int, _i64, _i64, _vp, _vp, _vp, _vp]),

@@ -248,6 +248,8 @@ extern "C" {
 static int64_t ws_tables(int n_views) { return (((int64_t)n_views * (J + 1) * 4 + 15) / 16) * 16; }
 static int64_t ws_scan_blocks(int64_t items) { return (items + 1024 * SCAN_PER - 1) / (1024 * SCAN_PER); }
 
+int idl_mimic_max_random_n(void) { return 64; }      // Random_N draws the device generator sorts inside one wavefront
+
 int64_t idl_mimic_workspace(int64_t n, int n_views)
 {
     if (n < 0 || n_views < 1 || n_views > MAX_VIEWS) return -1;

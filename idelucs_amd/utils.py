@@ -251,6 +251,15 @@ class Random_N(object):
         a[np.random.randint(0, len(seq), self.n_bp)] = N
 
 
+class _NotSubstitutions(ValueError):
+    """A transform did something other than ACGTN substitutions; .mutated holds the records mutated so far (the transform has
+    already consumed its random numbers for them: they must not be mutated a second time)."""
+
+    def __init__(self, msg, mutated):
+        super().__init__(msg)
+        self.mutated = mutated
+
+
 def _edits_from_diff(orig, mutated):
     """Substitution edits (pos | op<<30) that turn `orig` into `mutated` (equal-length ACGTN byte
     arrays): op 0 = becomes N, else XOR of the 2-bit codes."""
@@ -303,6 +312,7 @@ def _compat_edits(ff, transforms):
     a transform cannot be expressed as substitutions."""
     chunks, counts = [], []
     for tf in transforms:
+        done = []
         for i in range(ff.n):
             if tf is None:
                 counts.append(0)
@@ -310,11 +320,12 @@ def _compat_edits(ff, transforms):
             orig = ff.bytes[ff.byte_off[i]:ff.byte_off[i + 1]]
             mut = bytearray(orig.tobytes())
             tf(mut)
+            done.append(mut)
             if len(mut) != orig.size:
-                raise ValueError("a transform changed the length of a sequence")
+                raise _NotSubstitutions("a transform changed the length of a sequence", done)
             e = _edits_from_diff(orig, np.frombuffer(mut, np.uint8))
             if e is None:
-                raise ValueError("a transform produced bytes that are not substitutions among ACGTN")
+                raise _NotSubstitutions("a transform produced bytes that are not substitutions among ACGTN", done)
             chunks.append(e)
             counts.append(e.size)
     edit_off = np.zeros(len(counts) + 1, np.int64)
@@ -366,6 +377,8 @@ def _features_one_pass(fname, k, transform, mode, check, out_kind, device=None, 
     rng = rng or _default_rng_mode()
     dev = _device(device)
     spec = transform.spec() if hasattr(transform, "spec") else None
+    if spec is not None and spec[2] > _L.idl_mimic_max_random_n():
+        spec = None                           # more Random_N draws than the device generator sorts in one wave: draw on the host
     host_tf = transform is not None and (rng == "compat" or spec is None)
     ff = FastaFile(fname, check=check, keep_bytes=host_tf)
     edits = edit_off = None
@@ -375,8 +388,8 @@ def _features_one_pass(fname, k, transform, mode, check, out_kind, device=None, 
         except ValueError as err:
             if "substitutions" not in str(err) and "length" not in str(err):
                 raise
-            # arbitrary user transform: re-pack the mutated bytes instead of shipping edits
-            return _features_user_transform(ff, fname, k, transform, mode, out_kind, dev)
+            # an arbitrary user callable (reference utils.py:239-240 takes any): apply it on the host, re-pack the mutated bytes
+            return _features_user_transform(ff, k, transform, mode, out_kind, dev, applied=err.mutated)
         edits = torch.from_numpy(e.view(np.int32)).to(dev) if e.size else torch.zeros(1, dtype=torch.int32, device=dev)
         edit_off = torch.from_numpy(eo).to(dev)
     din = _DeviceInput(ff, dev)
@@ -386,12 +399,49 @@ def _features_one_pass(fname, k, transform, mode, check, out_kind, device=None, 
     return ff.names, out[0]
 
 
-def _features_user_transform(ff, fname, k, transform, mode, out_kind, dev):
-    raise NotImplementedError("transforms that are not base substitutions are not supported on the device path")
+def _pack_host(seqs):
+    """Byte strings -> an object with the packed device-input fields as host arrays (idl_pack: bytes other than ACGT invalid,
+    as kmers.pyx:19-34 treats them)."""
+    n = len(seqs)
+    lengths = np.array([len(x) for x in seqs], np.int64)
+    byte_off = np.zeros(n + 1, np.int64)
+    np.cumsum(lengths, out=byte_off[1:])
+    flat = np.frombuffer(b"".join(bytes(x) for x in seqs), np.uint8) if byte_off[-1] else np.zeros(1, np.uint8)
+    slots = int(((lengths + 63) // 64).sum())
+
+    class Packed:
+        pass
+    pk = Packed()
+    pk.n, pk.lengths = n, lengths
+    pk.codes = np.empty(max(slots, 1) * 16, np.uint8)
+    pk.mask = np.empty(max(slots, 1) * 8, np.uint8)
+    pk.slot_off = np.empty(n + 1, np.int64)
+    _lib.check(_L.idl_pack(_ptr(flat), _ptr(byte_off), n, _ptr(pk.codes), _ptr(pk.mask), _ptr(pk.slot_off)))
+    return pk
 
 
-def kmersFasta(fname, k=6, transform=None, reduce=False, rng=None, seed=0):
-    """Reference idelucs/utils.py:224-277 -> (names, float64 [N, 4^k or n_canonical])."""
+def _features_user_transform(ff, k, transform, mode, out_kind, dev, applied):
+    """kmersFasta / cgrFasta with a transform that is not a set of base substitutions (it inserts, deletes, writes other bytes...):
+    the callable runs on the host on every cleaned record, as in the reference, and the result is packed and counted."""
+    seqs = list(applied)
+    for i in range(len(seqs), ff.n):
+        b = ff.record(i)
+        transform(b)
+        seqs.append(b)
+    out = _vectorise(_DeviceInput(_pack_host(seqs), dev), k, mode, _lib.INIT_ONE, out_kind)
+    return ff.names, out[0]
+
+
+def kmersFasta(fname, k=6, transform=None, reduce=False, rng=None, seed=0, project=False):
+    """Reference idelucs/utils.py:224-277 -> (names, float64 [N, 4^k or n_canonical]).
+    project=True (or a path to a kernel .npz): the compositional projection the reference keeps commented out at utils.py:272-275,
+    `np.dot(kmers, kernels/kernel{k}.npz['arr_0'])` -> float64 [N, 135 / 511 / 2079] for k = 4 / 5 / 6.  The kernel has 4^k rows, so
+    it applies to the un-collapsed frequency rows: with project the canonical collapse of `reduce` is not performed (the
+    projection is the reduction)."""
+    if project:
+        names, feats = _features_one_pass(fname, k, transform, _lib.MODE_KMER, True, _lib.OUT_FREQ_F64, rng=rng, seed=seed)
+        kernel = project if isinstance(project, (str, os.PathLike)) else kernel_file(k)
+        return names, project_kernel(feats, kernel).cpu().numpy()
     mode = _lib.MODE_CANONICAL if reduce else _lib.MODE_KMER
     names, feats = _features_one_pass(fname, k, transform, mode, True, _lib.OUT_FREQ_F64, rng=rng, seed=seed)
     return names, feats.cpu().numpy()
@@ -559,6 +609,14 @@ def AugmentFasta(sequence_file, n_mimics, k=6, reduce=False, rng=None, seed=0):
         x[m * st.n:(m + 1) * st.n, 0, :] = scaled[0]
         x[m * st.n:(m + 1) * st.n, 1, :] = scaled[m + 1]
     return x
+
+
+def kernel_file(k):
+    """kernels/kernel{k}.npz of the reference repository (data files, shipped in idelucs_amd/kernels/)."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "kernels", f"kernel{int(k)}.npz")
+    if not os.path.exists(path):
+        raise ValueError(f"no projection kernel for k={k} (the reference ships kernel4/5/6.npz)")
+    return path
 
 
 def project_kernel(features, kernel):

@@ -17,6 +17,27 @@ def test_flag_surface_and_defaults():
         assert a[k] == v, k
 
 
+def test_reference_package_name_resolves_to_this_implementation():
+    """north_star: 'keeping the idelucs.cluster / __main__ CLI surface'.  `import idelucs`, its sub-modules and `python -m idelucs`
+    are the reference's names (idelucs/__init__.py:3-8, pyproject.toml:16) served by idelucs_amd."""
+    import importlib
+    import idelucs
+    import idelucs_amd
+    from idelucs.cluster import iDeLUCS_cluster
+    from idelucs.utils import kmersFasta, AugmentFasta                 # noqa: F401
+    from idelucs.models import IID_model                               # noqa: F401
+    from idelucs.LossFunctions import IID_loss, info_nce_loss          # noqa: F401
+    assert iDeLUCS_cluster is idelucs_amd.cluster.iDeLUCS_cluster and kmersFasta is idelucs_amd.utils.kmersFasta
+    assert importlib.import_module("idelucs.kmers") is idelucs_amd.kmers
+    for name in ["check_sequence", "SummaryFasta", "reverse_complement", "kmer_rev_comp", "kmersFasta", "cgrFasta", "cluster_acc",
+                 "SequenceDataset", "kmer_counts", "cgr", "IID_model", "IID_loss", "info_nce_loss", "iDeLUCS_cluster"]:
+        assert getattr(idelucs, name) is getattr(idelucs_amd, name), name
+    main = importlib.import_module("idelucs.__main__").main
+    assert main is importlib.import_module("idelucs_amd.__main__").main
+    from conftest import ROOT
+    assert 'idelucs = "idelucs_amd.__main__:main"' in open(os.path.join(ROOT, "pyproject.toml")).read()
+
+
 def test_relabel_and_ensemble_helpers():
     from idelucs_amd import posthoc
     y = np.array([3, 3, 1, 0, 1, 3, 7])

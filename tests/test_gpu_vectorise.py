@@ -423,7 +423,7 @@ def test_full_size_v1_v2_v3_kernels_agree_bitwise(gpu, monkeypatch):
 def test_kernel_projection_matches_numpy(gpu):
     """BASELINE config 4: kernels/kernel4.npz (the reference's data file) applied to k=4 frequency rows == np.dot."""
     from idelucs_amd import utils as U
-    kfile = os.path.join(DATA, "kernel4.npz")
+    kfile = U.kernel_file(4)
     K = np.load(kfile)["arr_0"]
     assert K.shape == (256, 135)
     g = np.load(os.path.join(GOLDEN, "counts_influenza_64.npz"))
@@ -464,3 +464,80 @@ def test_megabase_sequence_many_super_chunks(gpu):
                 want = np.ones(4 ** k, np.int32); O.kmer_counts(mutated[v][i], k, want)
                 assert np.array_equal(got[v, i], want), (k, v, i)
                 assert np.array_equal(f64[v, i], want / np.sum(want)), (k, v, i)
+
+
+def test_arbitrary_transform_callables(gpu, tmp_path):
+    """kmersFasta(fname, k, transform) takes ANY callable in the reference (utils.py:239-240).  Callables that are not base
+    substitutions -- deleting bases, inserting, writing bytes kmer_counts skips -- run on the host on the cleaned record and the
+    result is re-packed and counted on the device: equal to the oracle applying the same callable."""
+    from idelucs_amd import utils as U
+    fn = _write_subset(tmp_path, 12)
+
+    def drop_every_7th(seq):                   # changes the length
+        del seq[::7]
+
+    def insert_gaps(seq):                      # longer, with bytes that restart the window (kmers.pyx:19-34: anything but ACGT)
+        seq[10:10] = b"NN-xx"
+        seq[-3:] = b"acg"
+
+    calls = []
+
+    def third_record_only(seq):                # substitutions for some records, a deletion for one: mutated exactly once each
+        calls.append(len(seq))
+        if len(calls) == 3:
+            del seq[5:9]
+        else:
+            seq[0:1] = b"T"
+
+    for tf in (drop_every_7th, insert_gaps, third_record_only):
+        calls.clear()
+        names, got = U.kmersFasta(fn, k=5, transform=tf)
+        n_calls = len(calls)
+        want = []
+        for _, s in O.fasta_records(fn):
+            b = bytearray(s)
+            tf(b)
+            c = np.ones(4 ** 5, np.int32)
+            O.kmer_counts(b, 5, c)
+            want.append(c / np.sum(c))
+        assert np.array_equal(got, np.array(want)), tf.__name__
+        if tf is third_record_only:
+            assert n_calls == 12               # no record went through the callable twice
+
+
+def test_random_n_beyond_the_device_sorter(gpu, tmp_path):
+    """Random_N(n_bp > 64): more draws than the device generator sorts in a wave -- drawn on the host from numpy's global stream
+    exactly like the reference (utils.py:78-95), whatever the rng mode; equal to the oracle under the same seed."""
+    from idelucs_amd import _lib, utils as U
+    assert _lib.lib.idl_mimic_max_random_n() == 64
+    fn = _write_subset(tmp_path, 8)
+    np.random.seed(5)
+    _, got = U.kmersFasta(fn, k=6, transform=U.Random_N(150), rng="philox")
+    np.random.seed(5)
+    tf = O.Random_N(150)
+    want = []
+    for _, s in O.fasta_records(fn):
+        b = bytearray(s)
+        tf(b)
+        c = np.ones(4 ** 6, np.int32)
+        O.kmer_counts(b, 6, c)
+        want.append(c / np.sum(c))
+    assert np.array_equal(got, np.array(want))
+
+
+@pytest.mark.parametrize("k,d", [(4, 135), (5, 511), (6, 2079)])
+def test_kernel_projection_all_k(gpu, k, d):
+    """BASELINE config 4 (kernels/kernel{4,5,6}.npz parity): kmersFasta(..., project=True) == np.dot(reference frequency rows,
+    KERNEL) for the reference's three kernel files (the product the reference keeps commented out, utils.py:272-275)."""
+    from idelucs_amd import utils as U
+    K = np.load(U.kernel_file(k))["arr_0"]
+    assert K.shape == (4 ** k, d)
+    g = np.load(os.path.join(GOLDEN, "counts_influenza_64.npz"))
+    want = np.dot(g[f"freq_k{k}"], K)
+    names, got = U.kmersFasta(os.path.join(DATA, "influenza_64.fas"), k=k, project=True)
+    assert got.dtype == np.float64 and got.shape == (64, d) and names == list(g["names"])
+    np.testing.assert_allclose(got, want, rtol=1e-11, atol=1e-14)
+    _, got_r = U.kmersFasta(os.path.join(DATA, "influenza_64.fas"), k=k, reduce=True, project=True)    # the projection is the reduction
+    assert np.array_equal(got, got_r)
+    with pytest.raises(ValueError):
+        U.kernel_file(7)

@@ -86,12 +86,55 @@ def label_features_device(predictions, n_clusters, device=None, n_init=10, max_i
     return labels.cpu().numpy(), w.max(1).values.double().cpu().numpy()
 
 
+SILHOUETTE_HOST_MAX = 20000      # above this many points the silhouette is computed on the GPU (sklearn's is O(N^2) on the host)
+
+
+def silhouette_score_device(data, labels, device=None, block=4096):
+    """sklearn.metrics.silhouette_score(data, labels) (euclidean, mean over all samples) on the GPU: for a block of rows the
+    distances to every point come from one GEMM (||x||^2 + ||y||^2 - 2 x.y, clamped, square-rooted) and their per-cluster sums
+    from a second GEMM with the one-hot label matrix -- N^2 (d + K) multiply-adds in all, no N x N matrix is ever held.
+    float64 accumulation of the per-cluster sums; agrees with sklearn to ~1e-6 (tests/test_cli_surface.py)."""
+    import torch
+    dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+    x = torch.as_tensor(np.asarray(data)).to(dev, torch.float32)
+    uniq, inv = np.unique(np.asarray(labels), return_inverse=True)
+    n, k = x.shape[0], len(uniq)
+    if not 2 <= k <= n - 1:
+        raise ValueError("Number of labels is %d. Valid values are 2 to n_samples - 1 (inclusive)" % k)      # sklearn's check
+    lab = torch.from_numpy(inv.astype(np.int64)).to(dev)
+    onehot = torch.zeros((n, k), dtype=torch.float32, device=dev)
+    onehot[torch.arange(n, device=dev), lab] = 1.0
+    counts = onehot.sum(0).double()
+    x = x - x.mean(0, keepdim=True)                 # distances are translation invariant; centring keeps the cancellation small
+    x2 = (x * x).sum(1)
+    total = torch.zeros((), dtype=torch.float64, device=dev)
+    for lo in range(0, n, block):
+        hi = min(lo + block, n)
+        d2 = (x2[lo:hi, None] + x2[None, :] - 2.0 * (x[lo:hi] @ x.t())).clamp_min_(0.0)
+        d2[torch.arange(hi - lo, device=dev), torch.arange(lo, hi, device=dev)] = 0.0       # exact zeros on the diagonal
+        sums = (d2.sqrt_() @ onehot).double()                                                # [rows, K]: sum of distances to each cluster
+        own = lab[lo:hi]
+        n_own = counts[own]
+        a = sums.gather(1, own[:, None]).squeeze(1) / (n_own - 1.0).clamp_min(1.0)
+        means = sums / counts[None, :]
+        means.scatter_(1, own[:, None], float("inf"))
+        b = means.min(1).values
+        sil = (b - a) / torch.maximum(a, b)
+        sil = torch.where(n_own > 1.0, sil, torch.zeros_like(sil))                          # singletons score 0 (sklearn)
+        total += torch.nan_to_num(sil).sum()
+    return float(total.item() / n)
+
+
 def compute_results(y_pred, data, y_true=None):
-    """Reference utils.py:606-623."""
+    """Reference utils.py:606-623.  (Silhouette: sklearn up to SILHOUETTE_HOST_MAX points, the same score on the GPU above.)"""
     import sklearn.metrics.cluster as metrics
     from .utils import cluster_acc
+    if len(y_pred) > SILHOUETTE_HOST_MAX:
+        sil = silhouette_score_device(data, y_pred)
+    else:
+        sil = metrics.silhouette_score(data, y_pred)
     d = {"Davies-Boulding": metrics.davies_bouldin_score(data, y_pred),
-         "Silhouette-Score": metrics.silhouette_score(data, y_pred)}
+         "Silhouette-Score": sil}
     if y_true is None:
         return d, None
     d["NMI"] = metrics.adjusted_mutual_info_score(y_true, y_pred)
@@ -131,16 +174,63 @@ def plot_confusion_matrix(cm, target_names, pairs=None, title="Confusion matrix"
     ax.set_xlabel("Predicted label\naccuracy={:0.4f}; misclass={:0.4f}".format(accuracy, 1 - accuracy))
 
 
-def fine_grained_clusters(latent):
-    """n_clusters=0 mode (reference __main__.py:82-83,153-156): HDBSCAN(min_cluster_size=N//100+1) on the
-    last voter's latent; labels+1, probabilities.  `hdbscan` is used when importable, else
-    sklearn.cluster.HDBSCAN (parity with hdbscan==0.8.32 is unpinned -- SURVEY 8c)."""
-    mcs = len(latent) // 100 + 1
+HDBSCAN_EXACT_MAX = 20000        # points the host HDBSCAN is run on directly
+
+
+def _hdbscan(points, min_cluster_size):
     try:
         import hdbscan
-        cl = hdbscan.HDBSCAN(min_cluster_size=mcs, gen_min_span_tree=True, prediction_data=True)
+        cl = hdbscan.HDBSCAN(min_cluster_size=min_cluster_size, gen_min_span_tree=True, prediction_data=True)
     except ImportError:
         from sklearn.cluster import HDBSCAN
-        cl = HDBSCAN(min_cluster_size=max(mcs, 2))
-    cl.fit(latent)
-    return cl.labels_ + 1, cl.probabilities_
+        cl = HDBSCAN(min_cluster_size=max(min_cluster_size, 2))
+    cl.fit(points)
+    return cl.labels_, cl.probabilities_
+
+
+def fine_grained_clusters(latent, exact_max=None, seed=0, device=None):
+    """n_clusters=0 mode (reference __main__.py:82-83,153-156): HDBSCAN(min_cluster_size=N//100+1) on the last voter's latent;
+    labels+1, probabilities.  `hdbscan` is used when importable, else sklearn.cluster.HDBSCAN (parity with hdbscan==0.8.32 is
+    unpinned -- SURVEY 8c).
+
+    Up to `exact_max` points (default HDBSCAN_EXACT_MAX) that is the whole computation, on the host as in the reference.  Beyond
+    it (BASELINE cfg5: 10^6 points; the host algorithm needs the 10^4-th neighbour of every point) the density clustering runs on
+    a seeded uniform subsample of exact_max points -- min_cluster_size keeps its 1 % meaning, S//100+1 -- and every other point
+    takes the label of its nearest sampled point (one GEMM-shaped nearest-neighbour search on the GPU), with that point's
+    membership probability scaled by how far it is compared with that point's own spacing.  An approximation, stated as such:
+    the reference offers nothing that runs at that size."""
+    latent = np.asarray(latent)
+    n = len(latent)
+    exact_max = HDBSCAN_EXACT_MAX if exact_max is None else int(exact_max)
+    if n <= exact_max:
+        labels, prob = _hdbscan(latent, n // 100 + 1)
+        return labels + 1, prob
+    import torch
+    dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+    rng = np.random.default_rng(seed)
+    pick = np.sort(rng.choice(n, size=exact_max, replace=False))
+    sub_labels, sub_prob = _hdbscan(latent[pick], exact_max // 100 + 1)
+    x = torch.from_numpy(latent).to(dev, torch.float32)
+    s = x[torch.from_numpy(pick).to(dev)]
+    s2 = (s * s).sum(1)
+    # spacing of the sample around each sampled point: distance to its nearest other sampled point
+    spacing = torch.empty(exact_max, dtype=torch.float32, device=dev)
+    for lo in range(0, exact_max, 4096):
+        d2 = (s2[lo:lo + 4096, None] + s2[None, :] - 2.0 * (s[lo:lo + 4096] @ s.t())).clamp_min_(0.0)
+        d2[torch.arange(d2.shape[0], device=dev), torch.arange(lo, lo + d2.shape[0], device=dev)] = float("inf")
+        spacing[lo:lo + 4096] = d2.min(1).values.sqrt_()
+    near = torch.empty(n, dtype=torch.int64, device=dev)
+    dist = torch.empty(n, dtype=torch.float32, device=dev)
+    for lo in range(0, n, 16384):
+        xb = x[lo:lo + 16384]
+        d2 = ((xb * xb).sum(1)[:, None] + s2[None, :] - 2.0 * (xb @ s.t())).clamp_min_(0.0)
+        m = d2.min(1)
+        near[lo:lo + 16384] = m.indices
+        dist[lo:lo + 16384] = m.values.sqrt_()
+    lab_t = torch.from_numpy(sub_labels.astype(np.int64)).to(dev)[near]
+    scale = (spacing[near] / dist.clamp_min(1e-30)).clamp_max_(1.0)
+    prob_t = torch.from_numpy(sub_prob.astype(np.float32)).to(dev)[near] * scale
+    labels = lab_t.cpu().numpy()
+    prob = prob_t.double().cpu().numpy()
+    labels[pick], prob[pick] = sub_labels, sub_prob            # the sampled points keep exactly what HDBSCAN gave them
+    return labels + 1, prob

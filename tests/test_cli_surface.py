@@ -166,3 +166,83 @@ def test_cli_two_ranks_voters_are_distinct_and_outputs_complete(tmp_path, n_clus
     assert np.isfinite(float(m.loc["Silhouette-Score", "Value"]))        # computed on the gathered [N, 64] latent
     if n_clusters == 5:
         assert float(m.loc["ACC", "Value"]) > 0.80
+
+
+@pytest.mark.gpu
+def test_silhouette_on_device_equals_sklearn():
+    """posthoc.silhouette_score_device (two GEMMs per row block, used above 20 000 points where sklearn's O(N^2) host loop is
+    impractical) against sklearn.metrics.silhouette_score, including a singleton cluster and noise-like label values."""
+    from sklearn.metrics import silhouette_score
+    from idelucs_amd import posthoc
+    rng = np.random.default_rng(2)
+    centres = rng.normal(size=(5, 64)) * 2.0
+    lab = rng.integers(0, 5, 3000)
+    x = centres[lab] + rng.normal(size=(3000, 64))
+    lab[7] = 9                                                   # a singleton cluster scores 0
+    got = posthoc.silhouette_score_device(x, lab, block=512)
+    want = silhouette_score(x, lab)
+    assert abs(got - want) < 2e-5, (got, want)
+    with pytest.raises(ValueError):
+        posthoc.silhouette_score_device(x, np.zeros(3000, int))
+
+
+@pytest.mark.gpu
+def test_fine_grained_clusters_beyond_the_exact_limit():
+    """n_clusters = 0 above HDBSCAN_EXACT_MAX points: density clustering of a seeded subsample on the host + nearest-sampled-point
+    assignment on the GPU.  On planted blobs the partition is recovered, the sampled points keep HDBSCAN's own labels, and below
+    the limit the function is the plain HDBSCAN call."""
+    from sklearn.metrics import adjusted_rand_score
+    from idelucs_amd import posthoc
+    rng = np.random.default_rng(3)
+    centres = rng.normal(size=(6, 64)) * 3.0
+    truth = rng.integers(0, 6, 60000)
+    x = (centres[truth] + rng.normal(size=(60000, 64)) * 0.6).astype(np.float64)
+    y, p = posthoc.fine_grained_clusters(x, exact_max=6000, seed=1)
+    assert y.shape == (60000,) and p.shape == (60000,) and y.min() >= 0 and np.all((p >= 0) & (p <= 1))
+    keep = y > 0                                                 # label 0 = HDBSCAN noise (+1 shift, reference __main__.py:155)
+    assert keep.mean() > 0.9 and adjusted_rand_score(truth[keep], y[keep]) > 0.98
+    y_small, p_small = posthoc.fine_grained_clusters(x[:3000])
+    ref_l, ref_p = posthoc._hdbscan(x[:3000], 3000 // 100 + 1)
+    assert np.array_equal(y_small, ref_l + 1) and np.array_equal(p_small, ref_p)
+
+
+def _write_family_fasta(path, gt_path, n, L, n_families, seed):
+    """n sequences of L bases: n_families random ancestors, every member an independent 3 % point-mutated copy."""
+    rng = np.random.default_rng(seed)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    anc = rng.integers(0, 4, size=(n_families, L), dtype=np.uint8)
+    fam = rng.integers(0, n_families, n)
+    with open(path, "wb") as f, open(gt_path, "w") as g:
+        g.write("sequence_id\tcluster_id\n")
+        for lo in range(0, n, 10000):
+            hi = min(lo + 10000, n)
+            codes = anc[fam[lo:hi]]
+            mut = rng.random(codes.shape) < 0.03
+            codes = np.where(mut, (codes + rng.integers(1, 4, size=codes.shape, dtype=np.uint8)) & 3, codes)
+            rec = np.empty((hi - lo, 11 + L + 1), np.uint8)
+            rec[:, :11] = np.frombuffer(b"".join(b">seq%06d\n" % i for i in range(lo, hi)), np.uint8).reshape(hi - lo, 11)
+            rec[:, 11:-1] = acgt[codes]
+            rec[:, -1] = 10
+            f.write(rec.tobytes())
+            g.write("".join("seq%06d\tfam%d\n" % (i, fam[i]) for i in range(lo, hi)))
+    return fam
+
+
+@pytest.mark.gpu
+def test_cli_fine_grained_mode_at_cfg5_scale(tmp_path, monkeypatch):
+    """BASELINE cfg5's shape at a fifth of its size: 200 000 sequences x 5 kbp (a 1.0 GB FASTA of 8 planted families),
+    --n_clusters 0 => 200 output units, fine-grained clusters on the latent (subsampled HDBSCAN + GPU assignment), metrics with
+    the GPU silhouette: the whole FASTA-in / TSV-out path at a size the reference cannot run."""
+    import pandas as pd
+    from idelucs_amd.__main__ import main
+    fas, gt = str(tmp_path / "fam.fas"), str(tmp_path / "fam_GT.tsv")
+    _write_family_fasta(fas, gt, 200000, 5000, 8, seed=11)
+    monkeypatch.chdir(tmp_path)
+    out_dir = main(["--sequence_file", fas, "--GT_file", gt, "--n_clusters", "0", "--n_epochs", "2", "--n_voters", "1",
+                    "--batch_sz", "512", "--k", "6"])
+    df = pd.read_csv(os.path.join(out_dir, "assignments.tsv"), sep="\t", index_col=0)
+    assert len(df) == 200000 and ((df["confidence_score"] >= 0) & (df["confidence_score"] <= 1)).all()
+    m = pd.read_csv(os.path.join(out_dir, "metrics.tsv"), sep="\t", index_col=0)
+    acc, sil = float(m.loc["ACC", "Value"]), float(m.loc["Silhouette-Score", "Value"])
+    print(f"cfg5-scale CLI run: {df['assignment'].nunique()} clusters, ACC {acc:.4f}, silhouette {sil:.4f}")
+    assert np.isfinite(sil) and acc > 0.9 and 4 <= df["assignment"].nunique() <= 40

@@ -125,37 +125,39 @@ def test_training_step_matches_reference(dev, tag):
 
 
 def test_end_to_end_quality_anchor(dev):
-    """Reference on CPU: Influenza-A, k=6, C=5, 10 epochs, 1 voter, seed 0 -> ACC 0.99368
-    (tests/golden/anchor.json).  Dropout/shuffle streams differ on the GPU and a single voter is
-    noisy by nature (measured here over 8 seeds, autograd step AND fused step alike: mean 0.90,
-    range 0.72-0.99 -- the reason the reference ensembles n_voters=5), so the bar is statistical:
-    over 6 seeds mean ACC >= 0.82 and best ACC >= 0.96 (observed: mean 0.95, best 0.994 = the
-    reference's value; the margins absorb GEMM-solution / device differences)."""
+    """Statistical end-to-end anchor, pinned to the REFERENCE's own seed distribution (tests/golden/anchor_seeds.json, written by
+    tests/golden/make_anchor_seeds.py from the imported reference on CPU): Influenza-A, k=6, C=5, 10 epochs, ONE voter.  The
+    reference itself is noisy at one voter -- over its 10 seeds ACC = 0.80 .. 0.994, mean 0.948 (4 of 10 runs >= 0.99), which is
+    why it ensembles five -- so bit parity of a run is not definable (dropout / shuffle streams differ on the GPU); the bar is
+    that this implementation's distribution over 8 seeds is the reference's: mean within 0.05 of the reference's mean, best run
+    >= 0.985, worst run no more than 0.08 below the reference's worst."""
     import pandas as pd
     import torch
     import idelucs_amd
     from idelucs_amd import models
     anchor = json.load(open(os.path.join(GOLDEN, "anchor.json")))
+    ref = [r["acc"] for r in json.load(open(os.path.join(GOLDEN, "anchor_seeds.json")))["single"]]
+    assert len(ref) >= 8 and abs(ref[0] - anchor["acc"]) < 1e-12          # seed 0 of the sweep is the round-1 anchor run
     df = pd.read_csv(os.path.join(DATA, "Influenza-A_GT.tsv"), sep="\t")
     u = {v: i for i, v in enumerate(sorted(set(df.cluster_id)))}
     gt = np.array([u[v] for v in df.cluster_id])
     # API-level run (shapes / dtypes of the drop-in entry point)
-    torch.manual_seed(0)
     y, lat = idelucs_amd.iDeLUCS_cluster(os.path.join(DATA, "Influenza-A.fas"), n_clusters=5, n_epochs=10, n_mimics=3,
                                          batch_sz=512, k=6, weight=0.25, n_voters=1).fit_predict(None)
     assert y.dtype == np.int64 and y.shape == (949,) and lat.dtype == np.float64 and lat.shape == tuple(anchor["latent_shape"])
     accs = [idelucs_amd.cluster_acc(gt, y)[1]]
-    for seed in range(1, 6):
-        torch.manual_seed(seed)
+    for seed in range(1, 8):
         m = models.IID_model({'sequence_file': os.path.join(DATA, "Influenza-A.fas"), 'GT_file': None, 'n_clusters': 5, 'k': 6,
                               'model_size': 'linear', 'n_mimics': 3, 'batch_sz': 512, 'optimizer': 'RMSprop', 'lambda': 2.8,
                               'lr': 1e-3, 'weight': 0.25, 'scheduler': None, 'n_epochs': 10, 'n_voters': 1, 'seed': seed})
         m.build_dataloader()
+        m.begin_voter(0)
         for _ in range(10):
             m.contrastive_training_epoch()
         accs.append(idelucs_amd.cluster_acc(gt, m.predict()[0])[1])
-    print("ACC over seeds", np.round(accs, 4), "reference", anchor["acc"])
-    assert np.mean(accs) >= 0.82 and max(accs) >= 0.96
+    print("ACC over seeds", np.round(accs, 4), "| reference", np.round(ref, 4))
+    assert np.mean(accs) >= np.mean(ref) - 0.05, (np.mean(accs), np.mean(ref))
+    assert max(accs) >= 0.985 and min(accs) >= min(ref) - 0.08, (max(accs), min(accs), min(ref))
 
 
 # ------------------------------------------------------------------------------------------------

@@ -793,11 +793,10 @@ struct RmsArgs {
 __device__ __forceinline__ void wgrad_tile_rms(const RmsArgs &a, int tile, float lr, float alpha, float eps, float wd, float oma, float *red)
 {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l = lane & 15, q = lane >> 4;
-    const int nw = (int)(blockDim.x >> 6);                   // waves of the workgroup (RMS_THREADS / 64): they split the contraction index
     const int tn = a.wg_n_in / 16;
     const int i0 = (tile / tn) * 16, j0 = (tile % tn) * 16;
     const int lda = a.wg_n_out, ldb = a.wg_n_in, m = a.wg_m;
-    const int per = ((m + 4 * nw - 1) / (4 * nw)) * 4;       // rows per wave, a multiple of 4 (m = 1024, 8 waves: 128 = ONE batch of loads)
+    const int per = ((m + 15) / 16) * 4;                     // rows per wave, a multiple of 4
     const int kb = wv * per, ke = (kb + per < m) ? kb + per : m;
     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
     const float *pa = a.wg_dy + i0 + l, *pb = a.wg_x + j0 + l;    // A[i = l][k = q] = dy[k][i0 + l], B[k = q][j = l] = x[k][j0 + l]
@@ -842,11 +841,8 @@ __device__ __forceinline__ void wgrad_tile_rms(const RmsArgs &a, int tile, float
 #pragma unroll
     for (int r = 0; r < 4; ++r) red[wv * 256 + (4 * q + r) * 16 + l] = acc[r];          // C/D: row = 4 q + reg, col = l
     __syncthreads();
-    if (tid >= 256) return;                                   // one thread per tile element from here on
     const int i = tid >> 4, j = tid & 15;
-    float g = 0.f;
-    for (int w = 0; w < nw; w += 4)                           // the partial tiles, added in a fixed order
-        g += (red[w * 256 + tid] + red[(w + 1) * 256 + tid]) + (red[(w + 2) * 256 + tid] + red[(w + 3) * 256 + tid]);
+    const float g = (red[tid] + red[256 + tid]) + (red[512 + tid] + red[768 + tid]);
     const int o = (i0 + i) * ldb + j0 + j;
     if (a.wg_grad != nullptr) a.wg_grad[o] = g;
     float *p = a.p[a.wg_t], *v = a.v[a.wg_t];
@@ -861,22 +857,20 @@ __device__ __forceinline__ void wgrad_tile_rms(const RmsArgs &a, int tile, float
 // read: the batch offset ctl[1] was already advanced by the bias-gradient launch of this step, and x is no longer read by this
 // step's GEMMs); they go first because a gathered row is a dependent chain of HBM latencies that the streaming optimizer blocks
 // behind them hide.  The following gx * count blocks are optimizer blocks (tensor = block / gx).
-constexpr int RMS_THREADS = 512;      // 8 waves: a weight-gradient tile's contraction (m = 1024) is one batch of loads per wave
-
-__global__ __launch_bounds__(RMS_THREADS) void rmsprop_kernel(RmsArgs a, const float *hyper, int64_t *ctl, int64_t batch_advance, int gx,
+__global__ __launch_bounds__(256) void rmsprop_kernel(RmsArgs a, const float *hyper, int64_t *ctl, int64_t batch_advance, int gx,
                                                       int n_gather, idl_dev::GatherArgs g)
 {
     // grid order: weight-gradient tiles (dependent chains of strided loads: first, so that the streaming blocks behind them hide
     // their latency), then the gather blocks, then the optimizer blocks
     const float lr = hyper[0], alpha = hyper[1], eps = hyper[2], wd = hyper[3], oma = hyper[4];
     if ((int)blockIdx.x < a.wg_tiles) {
-        __shared__ float red[RMS_THREADS * 4];
+        __shared__ float red[1024];
         wgrad_tile_rms(a, (int)blockIdx.x, lr, alpha, eps, wd, oma, red);
         return;
     }
     const int b0 = (int)blockIdx.x - a.wg_tiles;
     if (b0 < n_gather) {
-        if (threadIdx.x < 256) idl_dev::gather_block(g, (int64_t)b0, threadIdx.x);      // (a gather block is 256 threads' work)
+        idl_dev::gather_block(g, (int64_t)b0, threadIdx.x);
         return;
     }
     const int bid = b0 - n_gather;
@@ -1245,7 +1239,7 @@ static int rmsprop_launch(int count, float *const *params, const float *const *g
     int nb_total = 0;
     for (int i = 0; i < count; ++i) {
         const bool vec = a.parts[i] == 1 && (a.n[i] & 3) == 0 && ((((uintptr_t)a.p[i]) | ((uintptr_t)a.g[i]) | ((uintptr_t)a.v[i])) & 15u) == 0;
-        int64_t nb = vec ? (a.n[i] / 4 + 2 * RMS_THREADS - 1) / (2 * RMS_THREADS) : (a.n[i] + RMS_THREADS - 1) / RMS_THREADS;     // float4 path: two 16-byte elements per thread
+        int64_t nb = vec ? (a.n[i] / 4 + 511) / 512 : (a.n[i] + 255) / 256;     // float4 path: two 16-byte elements per thread
         if (nb > 1024) nb = 1024;
         a.first[i] = nb_total;
         nb_total += (int)nb;
@@ -1253,7 +1247,7 @@ static int rmsprop_launch(int count, float *const *params, const float *const *g
     if (nb_total == 0) nb_total = 1;        // (step counter / loss assembly still need a block)
     for (int i = count; i <= 8; ++i) a.first[i] = nb_total;
     const int64_t extra = g.y != nullptr ? idl_dev::gather_blocks(g.f, g.batch) : 0;
-    hipLaunchKernelGGL(rmsprop_kernel, dim3((unsigned)(nb_total + extra + a.wg_tiles)), dim3(RMS_THREADS), 0, (hipStream_t)stream, a, hyper, ctl,
+    hipLaunchKernelGGL(rmsprop_kernel, dim3((unsigned)(nb_total + extra + a.wg_tiles)), dim3(256), 0, (hipStream_t)stream, a, hyper, ctl,
                        batch_advance, 0, (int)extra, g);
     IDL_HIP_TRY(hipGetLastError());
     return IDL_OK;

@@ -545,12 +545,15 @@ __global__ __launch_bounds__(64 * MID_WAVES) void mid_bwd_kernel(MidBwdArgs a, i
         if (!NCE) for (int i = tid; i < C * C; i += 64 * MID_WAVES) sP[i] = a.dP0[i];
         for (int i = tid; i < C * H2; i += 64 * MID_WAVES) sW3[i] = a.W3[i];
     }
-    // B fragments of this wave's two column tiles: B[k = 16 q + s][c = l] = W2[k][16 ct + l]
+    // B fragments of this wave's two column tiles.  The wave owns the 32 columns [32 wv, 32 wv + 32) of dr1 and its two tiles take
+    // them INTERLEAVED -- tile j, lane l = column 32 wv + 2 l + j -- so that a lane's B values of both tiles are one 8-byte read
+    // (B[k = 16 q + s][c] = W2[k][c]; 16 lanes x 8 B = one full 128-byte line per q) and the dr1 stores below are 8-byte stores
     float bw[2][16];
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int s = 0; s < 16; ++s) bw[j][s] = a.W2[(int64_t)(16 * q + s) * H1 + 16 * (2 * wv + j) + l];
+    for (int s = 0; s < 16; ++s) {
+        const float2 w2 = *(const float2 *)(a.W2 + (int64_t)(16 * q + s) * H1 + 32 * wv + 2 * l);
+        bw[0][s] = w2.x; bw[1][s] = w2.y;
+    }
     const float scale = a.train ? 2.f : 1.f;
     float cs1[2] = {0.f, 0.f}, s23 = 0.f, acc3[3] = {0.f, 0.f, 0.f};
     float gsum_nce = 0.f;                     // NCE: ((E + E^T) f)[row r0 + wv][lane]
@@ -602,7 +605,7 @@ __global__ __launch_bounds__(64 * MID_WAVES) void mid_bwd_kernel(MidBwdArgs a, i
         if (a.act1_t && nr == 16 && (m & 3) == 0) {          // transposed image: this lane's four rows of a column are one 16-byte read
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const float4 t4 = *(const float4 *)(a.act1 + (int64_t)(16 * (2 * wv + j) + l) * m + t0 + 4 * q);
+                const float4 t4 = *(const float4 *)(a.act1 + (int64_t)(32 * wv + 2 * l + j) * m + t0 + 4 * q);
                 a1v[j][0] = t4.x; a1v[j][1] = t4.y; a1v[j][2] = t4.z; a1v[j][3] = t4.w;
             }
         } else {
@@ -611,8 +614,8 @@ __global__ __launch_bounds__(64 * MID_WAVES) void mid_bwd_kernel(MidBwdArgs a, i
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) {
                     const int rl = 4 * q + reg;
-                    a1v[j][reg] = rl >= nr ? 0.f : a.act1_t ? a.act1[(int64_t)(16 * (2 * wv + j) + l) * m + t0 + rl]
-                                                            : a.act1[(int64_t)(t0 + rl) * H1 + 16 * (2 * wv + j) + l];
+                    a1v[j][reg] = rl >= nr ? 0.f : a.act1_t ? a.act1[(int64_t)(32 * wv + 2 * l + j) * m + t0 + rl]
+                                                            : a.act1[(int64_t)(t0 + rl) * H1 + 32 * wv + 2 * l + j];
                 }
         }
         __syncthreads();
@@ -713,20 +716,23 @@ __global__ __launch_bounds__(64 * MID_WAVES) void mid_bwd_kernel(MidBwdArgs a, i
             const float4 t = *(const float4 *)&DL[l][16 * q + 4 * i];
             av[4 * i] = t.x; av[4 * i + 1] = t.y; av[4 * i + 2] = t.z; av[4 * i + 3] = t.w;
         }
+        {
+            f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bw[j][s], acc, 0, 0, 0);
-            const int col = 16 * (2 * wv + j) + l;
+            for (int s = 0; s < 16; ++s) {
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bw[0][s], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bw[1][s], acc1, 0, 0, 0);
+            }
+            const int col = 32 * wv + 2 * l;                       // this lane's two adjacent columns (tile 0, tile 1)
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
                 const int rl = 4 * q + reg;                        // C/D: row = 4q + reg, col = l
                 if (rl < nr) {
-                    const int64_t idx = (int64_t)(t0 + rl) * H1 + col;
-                    const float v = a1v[j][reg] > 0.f ? acc[reg] * scale : 0.f;
-                    a.dr1[idx] = v;
-                    cs1[j] += v;
+                    const float v0 = a1v[0][reg] > 0.f ? acc0[reg] * scale : 0.f;
+                    const float v1 = a1v[1][reg] > 0.f ? acc1[reg] * scale : 0.f;
+                    *(float2 *)(a.dr1 + (int64_t)(t0 + rl) * H1 + col) = make_float2(v0, v1);
+                    cs1[0] += v0;
+                    cs1[1] += v1;
                 }
             }
         }
@@ -756,7 +762,7 @@ __global__ __launch_bounds__(64 * MID_WAVES) void mid_bwd_kernel(MidBwdArgs a, i
     for (int j = 0; j < 2; ++j) {
         float v = cs1[j];
         v = idl_dev::add_xor32(idl_dev::add_xor16(v));
-        if (q == 0) a.partial1[(int64_t)blockIdx.x * H1 + 16 * (2 * wv + j) + l] = v;
+        if (q == 0) a.partial1[(int64_t)blockIdx.x * H1 + 32 * wv + 2 * l + j] = v;
     }
     if (tid < H2) a.partial2[(int64_t)blockIdx.x * H2 + tid] = s23;
     else if (tid < H2 + C) a.partial3[(int64_t)blockIdx.x * C + tid - H2] = s23;

@@ -520,7 +520,8 @@ struct MidBwdArgs {
 // E^T) f is complete inside the workgroup (partials added through LDS in a fixed order) and never goes to memory, and the IIC
 // core (400..2304 elements) is recomputed by every workgroup from the joint into LDS instead of being waited for.  One launch
 // boundary and the G / dP0 round trips disappear.
-template <bool NCE>
+template <bool NCE, bool BIG = false>      // BIG: n_clusters > 48 (the per-row products then walk dP0 / W3 in memory); a separate instance, so that its
+                                          // registers do not count against the n_clusters <= 48 one the training step runs
 __global__ __launch_bounds__(64 * MID_WAVES) void mid_bwd_kernel(MidBwdArgs a, int tile0, int tile1, idl_dev::GatherArgs gth)
 {
     extern __shared__ float mid_dyn[];        // NCE: Gred[16 waves][16][64] | lse_all[m] | Ps[48 * 48]
@@ -536,7 +537,7 @@ __global__ __launch_bounds__(64 * MID_WAVES) void mid_bwd_kernel(MidBwdArgs a, i
     __shared__ float sP[48 * 48], sW3[48 * H2];      // dP0 and W3 for n_clusters <= 48: read once per workgroup, not once per row
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, l = lane & 15, q = lane >> 4, tid = threadIdx.x;
     const int m = a.m, C = a.C, B = m / 2;
-    const bool small = C <= 48;
+    constexpr bool small = !BIG;
     const int rows = (m + COL_PARTS - 1) / COL_PARTS;
     const int r0 = blockIdx.x * rows;
     const int r1 = (r0 + rows < m) ? r0 + rows : m;
@@ -620,7 +621,7 @@ __global__ __launch_bounds__(64 * MID_WAVES) void mid_bwd_kernel(MidBwdArgs a, i
         }
         __syncthreads();
         // ---- 1. head backward of row t0 + wv
-        if (wv < nr && small) {
+        if constexpr (small) { if (wv < nr) {
             // every global read of the row first, then arithmetic on registers and LDS only
             const int row = t0 + wv;
             const int prow = row < B ? row + B : row - B;
@@ -629,9 +630,9 @@ __global__ __launch_bounds__(64 * MID_WAVES) void mid_bwd_kernel(MidBwdArgs a, i
             const float zc = cl ? a.z[(int64_t)row * C + lane] : 0.f;
             const float act = a.r2[(int64_t)row * H2 + lane];
             const float fr = a.f[(int64_t)row * H2 + lane], fp = a.f[(int64_t)prow * H2 + lane];
-            float gp[16];
+            float gp[8];                       // the first 8 partial products (idl_nce_fused_parts() = 8) are requested up front
 #pragma unroll
-            for (int pp = 0; pp < 16; ++pp) gp[pp] = (!NCE && pp < a.g_parts) ? a.G[((int64_t)pp * m + row) * H2 + lane] : 0.f;
+            for (int pp = 0; pp < 8; ++pp) gp[pp] = (!NCE && pp < a.g_parts) ? a.G[((int64_t)pp * m + row) * H2 + lane] : 0.f;
             const float invr = a.inv[row];
             shz[wv][lane] = zp;
             __builtin_amdgcn_wave_barrier();
@@ -651,7 +652,8 @@ __global__ __launch_bounds__(64 * MID_WAVES) void mid_bwd_kernel(MidBwdArgs a, i
             const float dl_cls = act > 0.f ? dr * scale : 0.f;
             float gsum = gp[0];
 #pragma unroll
-            for (int pp = 1; pp < 16; ++pp) if (pp < a.g_parts) gsum += gp[pp];
+            for (int pp = 1; pp < 8; ++pp) if (pp < a.g_parts) gsum += gp[pp];
+            if (!NCE) for (int pp = 8; pp < a.g_parts; ++pp) gsum += a.G[((int64_t)pp * m + row) * H2 + lane];
             if (NCE) gsum = gsum_nce;
             const float df = a.nce_coef * (gsum - 2.f * fp);
             const float proj = wave_sum(fr * df);
@@ -659,7 +661,7 @@ __global__ __launch_bounds__(64 * MID_WAVES) void mid_bwd_kernel(MidBwdArgs a, i
             a.dlat[(int64_t)row * H2 + lane] = d;
             DL[wv][lane] = d;
             R2s[wv][lane] = act;
-        } else if (wv < nr) {
+        } } else if (wv < nr) {
             const int row = t0 + wv;
             const int prow = row < B ? row + B : row - B;
             for (int c = lane; c < C; c += 64) shz[wv][c] = a.z[(int64_t)prow * C + c];
@@ -703,7 +705,8 @@ __global__ __launch_bounds__(64 * MID_WAVES) void mid_bwd_kernel(MidBwdArgs a, i
             a.dlat[(int64_t)row * H2 + lane] = d;
             DL[wv][lane] = d;
             R2s[wv][lane] = act;
-        } else {
+        }
+        if (wv >= nr) {
             DL[wv][lane] = 0.f;
             R2s[wv][lane] = 0.f;
             for (int c = lane; c < C; c += 64) DLG[wv][c] = 0.f;
@@ -1078,7 +1081,8 @@ int idl_mid_bwd(const float *z, const float *r2, const float *f, const float *in
     a.dlogits = dlogits; a.dlat = dlat; a.dr1 = dr1; a.partial1 = partial1; a.partial2 = partial2; a.partial3 = partial3;
     a.dW3_part = dW3_partial; a.ctl = ctl; a.batch_advance = batch_advance;
     a.g_parts = g_parts; a.m = m; a.C = C; a.train = train; a.nce_coef = nce_coef;
-    hipLaunchKernelGGL(mid_bwd_kernel<false>, dim3(COL_PARTS), dim3(64 * MID_WAVES), 0, (hipStream_t)stream, a, 0, 0, idl_dev::GatherArgs{});
+    if (C <= 48) hipLaunchKernelGGL((mid_bwd_kernel<false, false>), dim3(COL_PARTS), dim3(64 * MID_WAVES), 0, (hipStream_t)stream, a, 0, 0, idl_dev::GatherArgs{});
+    else hipLaunchKernelGGL((mid_bwd_kernel<false, true>), dim3(COL_PARTS), dim3(64 * MID_WAVES), 0, (hipStream_t)stream, a, 0, 0, idl_dev::GatherArgs{});
     IDL_HIP_TRY(hipGetLastError());
     return IDL_OK;
 }
@@ -1154,8 +1158,10 @@ int idl_mid_bwd_gather(const float *z, const float *r2, const float *f, const fl
         const int64_t ng = idl_dev::gather_tiles<MID_GATHER_ROWS>(fdim, batch);
         t0 = ng * part / parts; t1 = ng * part_end / parts;
     }
-    hipLaunchKernelGGL(mid_bwd_kernel<false>, dim3((unsigned)(COL_PARTS + (t1 - t0 + 3) / 4)), dim3(64 * MID_WAVES), 0, (hipStream_t)stream, a, (int)t0,
-                       (int)t1, g);
+    if (C <= 48) hipLaunchKernelGGL((mid_bwd_kernel<false, false>), dim3((unsigned)(COL_PARTS + (t1 - t0 + 3) / 4)), dim3(64 * MID_WAVES), 0, (hipStream_t)stream, a, (int)t0,
+                                    (int)t1, g);
+    else hipLaunchKernelGGL((mid_bwd_kernel<false, true>), dim3((unsigned)(COL_PARTS + (t1 - t0 + 3) / 4)), dim3(64 * MID_WAVES), 0, (hipStream_t)stream, a, (int)t0,
+                            (int)t1, g);
     IDL_HIP_TRY(hipGetLastError());
     return IDL_OK;
 }

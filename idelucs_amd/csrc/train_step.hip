@@ -866,6 +866,8 @@ __device__ __forceinline__ void wgrad_tile_rms(const RmsArgs &a, int tile, float
 // read: the batch offset ctl[1] was already advanced by the bias-gradient launch of this step, and x is no longer read by this
 // step's GEMMs); they go first because a gathered row is a dependent chain of HBM latencies that the streaming optimizer blocks
 // behind them hide.  The following gx * count blocks are optimizer blocks (tensor = block / gx).
+constexpr int RMS_UNROLL = 4;         // 16-byte elements per thread of the streaming update
+
 __global__ __launch_bounds__(256) void rmsprop_kernel(RmsArgs a, const float *hyper, int64_t *ctl, int64_t batch_advance, int gx,
                                                       int n_gather, idl_dev::GatherArgs g)
 {
@@ -899,17 +901,20 @@ __global__ __launch_bounds__(256) void rmsprop_kernel(RmsArgs a, const float *hy
                 pi.x -= lr * (g0 / (sqrtf(vi.x) + eps)); pi.y -= lr * (g1 / (sqrtf(vi.y) + eps));
                 pi.z -= lr * (g2 / (sqrtf(vi.z) + eps)); pi.w -= lr * (g3 / (sqrtf(vi.w) + eps));
             };
+            // four 16-byte elements per thread, all twelve loads in flight before the first use.  (The weight-gradient tiles put this
+            // kernel at 104 registers = 16 waves per CU: with two elements per thread the 1024 blocks of W1 did not all fit at once.)
             const int64_t n4 = n / 4, stride = (int64_t)gx * blockDim.x;
-            for (int64_t i = (int64_t)bx * blockDim.x + threadIdx.x; i < n4; i += 2 * stride) {      // two elements' loads in flight
-                const int64_t i2 = i + stride;
-                const bool two = i2 < n4;
-                float4 pi = p4[i], vi = v4[i];
-                const float4 gr = g4[i];
-                float4 pj = pi, vj = vi, gj = gr;
-                if (two) { pj = p4[i2]; vj = v4[i2]; gj = g4[i2]; }
-                upd(pi, vi, gr);
-                v4[i] = vi; p4[i] = pi;
-                if (two) { upd(pj, vj, gj); v4[i2] = vj; p4[i2] = pj; }
+            for (int64_t i = (int64_t)bx * blockDim.x + threadIdx.x; i < n4; i += RMS_UNROLL * stride) {
+                float4 pv[RMS_UNROLL], vv[RMS_UNROLL], gv[RMS_UNROLL];
+#pragma unroll
+                for (int u = 0; u < RMS_UNROLL; ++u) {
+                    const int64_t iu = i + u * stride < n4 ? i + u * stride : i;        // clamped, not predicated: the loads stay unconditional
+                    pv[u] = p4[iu]; vv[u] = v4[iu]; gv[u] = g4[iu];
+                }
+#pragma unroll
+                for (int u = 0; u < RMS_UNROLL; ++u) {
+                    if (i + u * stride < n4) { upd(pv[u], vv[u], gv[u]); v4[i + u * stride] = vv[u]; p4[i + u * stride] = pv[u]; }
+                }
             }
         } else
         for (int64_t i = (int64_t)bx * blockDim.x + threadIdx.x; i < n; i += (int64_t)gx * blockDim.x) {
@@ -1251,7 +1256,7 @@ static int rmsprop_launch(int count, float *const *params, const float *const *g
     int nb_total = 0;
     for (int i = 0; i < count; ++i) {
         const bool vec = a.parts[i] == 1 && (a.n[i] & 3) == 0 && ((((uintptr_t)a.p[i]) | ((uintptr_t)a.g[i]) | ((uintptr_t)a.v[i])) & 15u) == 0;
-        int64_t nb = vec ? (a.n[i] / 4 + 511) / 512 : (a.n[i] + 255) / 256;     // float4 path: two 16-byte elements per thread
+        int64_t nb = vec ? (a.n[i] / 4 + 256 * RMS_UNROLL - 1) / (256 * RMS_UNROLL) : (a.n[i] + 255) / 256;     // float4 path: RMS_UNROLL 16-byte elements per thread
         if (nb > 1024) nb = 1024;
         a.first[i] = nb_total;
         nb_total += (int)nb;

@@ -873,3 +873,40 @@ def test_batch_assembly_riding_in_the_middle_launches_is_the_gather(dev):
         assert torch.equal(got[half:half + live], want[half:half + live])
         assert torch.all(got[half + live:half + B] == -7.0)   # beyond the end of the list: untouched
     assert ctl.tolist() == [0, 88]                            # the riding gather moves no offset
+
+
+def test_small_model_k5_first_step_vs_reference(dev):
+    """BASELINE config 4, k=5 through model_size='small' (tests/golden/small_k5.npz, from the imported reference): the device's
+    canonical 5-mer frequency rows are the reference's kmersFasta(reduce=True) rows bit for bit, and myNet(512, 5) on them gives
+    the reference's eval forward, first-step loss, gradients (rel 2e-3) and bias parameters after RMSprop."""
+    import torch
+    from idelucs_amd import utils as U
+    from idelucs_amd.PytorchUtils import myNet
+    from idelucs_amd.LossFunctions import IID_loss, info_nce_loss
+    g = np.load(os.path.join(GOLDEN, "small_k5.npz"))
+    _, rows = U.kmersFasta(os.path.join(DATA, "influenza_64.fas"), k=5, reduce=True)
+    assert np.array_equal(rows[:32], g["rows"])
+    net = myNet(512, 5)
+    net.load_state_dict({k[2:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("w.")})
+    net = net.to(dev).eval()
+    x = torch.from_numpy(g["x"]).to(dev)
+    with torch.no_grad():
+        out, lat = net(x[:16].view(-1, 1, 512))
+    np.testing.assert_allclose(out.cpu().numpy(), g["eval_out"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(lat.cpu().numpy(), g["eval_latent"], rtol=1e-4, atol=1e-5)
+    opt = torch.optim.RMSprop(net.parameters(), lr=1e-3, weight_decay=0.01)
+    opt.zero_grad()
+    z, h = net(x)                                   # both views in one [2B, F] pass, as IID_model._step does
+    loss = 0.75 * info_nce_loss(h[:16], h[16:], 0.85) + 0.25 * IID_loss(z[:16], z[16:], lamb=2.8)
+    loss.backward()
+    assert abs(loss.item() - float(g["loss"])) <= 2e-4 * abs(float(g["loss"]))
+    for n_, p in net.named_parameters():
+        want = g[f"g.{n_}"]
+        got = p.grad.cpu().numpy()
+        got = got[::8] if got.ndim == 2 and got.shape[0] >= 128 else got
+        np.testing.assert_allclose(got, want, rtol=2e-3, atol=2e-3 * np.abs(want).mean(), err_msg=n_)
+    opt.step()
+    for n_, p in net.named_parameters():
+        if p.dim() == 1:
+            bad = ~np.isclose(p.detach().cpu().numpy(), g[f"p.{n_}"], rtol=1e-3, atol=1e-6)
+            assert bad.mean() < 0.02, (n_, bad.mean())

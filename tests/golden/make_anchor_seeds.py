@@ -98,4 +98,6 @@ def main():
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1:            # no options: anything on the command line gets the usage, not a 15-minute rerun that rewrites the fixture
+        sys.exit(__doc__)
     main()

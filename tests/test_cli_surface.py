@@ -73,11 +73,17 @@ def test_confusion_matrix_picture(tmp_path):
 
 @pytest.mark.gpu
 def test_cli_end_to_end_writes_reference_outputs(tmp_path, monkeypatch):
+    """The run of Example/ALL_RESULTS.tsv:19 (Influenza-A, k=6, 5 clusters, 35 epochs x 5 voters, batch 512): the reference's
+    output files, and an ensemble accuracy inside the reference's own range for this run -- tests/golden/anchor_seeds.json holds
+    three 5-voter ensembles of the imported reference: 0.934, 0.928, 0.994 (the published 0.9947 is the lucky end of it)."""
+    import json
     import pandas as pd
+    from conftest import GOLDEN
     from idelucs_amd.__main__ import main
+    ref = [r["acc_ensemble"] for r in json.load(open(os.path.join(GOLDEN, "anchor_seeds.json")))["voters5"]]
     monkeypatch.chdir(tmp_path)
     out_dir = main(["--sequence_file", os.path.join(DATA, "Influenza-A.fas"), "--GT_file", os.path.join(DATA, "Influenza-A_GT.tsv"),
-                    "--n_clusters", "5", "--n_epochs", "12", "--n_voters", "3", "--batch_sz", "512", "--k", "6"])
+                    "--n_clusters", "5", "--n_epochs", "35", "--n_voters", "5", "--batch_sz", "512", "--k", "6"])
     for f in ("assignments.tsv", "metrics.tsv", "training_plots.jpg", "contingency_matrix.jpg", "contingency_matrix.tsv"):
         assert os.path.exists(os.path.join(out_dir, f)), f
     assert os.path.exists(tmp_path / "ALL_RESULTS.tsv")
@@ -85,7 +91,9 @@ def test_cli_end_to_end_writes_reference_outputs(tmp_path, monkeypatch):
     assert list(df.columns) == ["sequence_id", "assignment", "confidence_score"] and len(df) == 949
     m = pd.read_csv(os.path.join(out_dir, "metrics.tsv"), sep="\t", index_col=0)
     assert {"ACC", "ARI", "NMI", "Silhouette-Score", "Davies-Boulding"} <= set(m.index)
-    assert float(m.loc["ACC", "Value"]) > 0.80        # 3-voter ensemble (observed 0.96; KMeans in label_features is unseeded)
+    acc = float(m.loc["ACC", "Value"])
+    print("5-voter ensemble ACC", acc, "| reference ensembles", np.round(ref, 4))
+    assert acc >= min(ref) - 0.03
 
 
 @pytest.mark.gpu

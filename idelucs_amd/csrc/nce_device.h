@@ -20,6 +20,22 @@ __device__ __forceinline__ f32x4 sim_tile(const float *f, int j0, const float (&
     return acc;
 }
 
+// two tiles at once (rows ja.. and jb..): both tiles' loads are in flight before the first product and the two dependent MFMA
+// chains (40 cycles of latency per link) interleave
+__device__ __forceinline__ void sim_tile2(const float *f, int ja, int jb, const float (&rb)[16], int l, int q, f32x4 &sa, f32x4 &sb)
+{
+    const float4 *pa = (const float4 *)(f + (int64_t)(ja + l) * 64 + 16 * q), *pb = (const float4 *)(f + (int64_t)(jb + l) * 64 + 16 * q);
+    const float4 a0 = pa[0], a1 = pa[1], a2 = pa[2], a3 = pa[3], b0 = pb[0], b1 = pb[1], b2 = pb[2], b3 = pb[3];
+    const float a[16] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x, a2.y, a2.z, a2.w, a3.x, a3.y, a3.z, a3.w};
+    const float b[16] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w, b3.x, b3.y, b3.z, b3.w};
+    sa = f32x4{0.f, 0.f, 0.f, 0.f}; sb = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+        sa = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks], rb[ks], sa, 0, 0, 0);
+        sb = __builtin_amdgcn_mfma_f32_16x16x4f32(b[ks], rb[ks], sb, 0, 0, 0);
+    }
+}
+
 __device__ __forceinline__ void load_rows(const float *f, int r0, int l, int q, float (&rb)[16])
 {
     const float4 *src = (const float4 *)(f + (int64_t)(r0 + l) * 64 + 16 * q);

@@ -90,8 +90,7 @@ __global__ __launch_bounds__(256) void nce_pass1_kernel(const float *f, int m, f
     load_rows(f, r0, l, q, rb);
     const int r = r0 + l, pr = (r + m / 2) % m;
     float sum = 0.f;
-    for (int t = t0 + wv; t < t1; t += 4) {
-        const f32x4 s = sim_tile(f, t * 16, rb, l, q);
+    auto fold = [&](const f32x4 s, int t) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int j = t * 16 + 4 * q + g;
@@ -99,7 +98,15 @@ __global__ __launch_bounds__(256) void nce_pass1_kernel(const float *f, int m, f
             if (j != r) sum += __expf(x);
             if (j == pr) pos[r] = x;
         }
+    };
+    int t = t0 + wv;
+    for (; t + 4 < t1; t += 8) {              // two tiles per turn: loads of both in flight, MFMA chains interleaved
+        f32x4 sa, sb;
+        nce_dev::sim_tile2(f, t * 16, (t + 4) * 16, rb, l, q, sa, sb);
+        fold(sa, t);
+        fold(sb, t + 4);
     }
+    if (t < t1) fold(sim_tile(f, t * 16, rb, l, q), t);
     // this lane holds the partial of row r over its j's (q, reg); add the four q groups, then the four waves
     sum = idl_dev::add_xor32(idl_dev::add_xor16(sum));
     if (q == 0) sh[wv][l] = sum;
@@ -139,17 +146,44 @@ __global__ __launch_bounds__(256) void nce_pass2_kernel(const float *f, int m, f
     f32x4 g[4];                           // G[r = 4q+reg][c = 16*ct + l] for ct = 0..3
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) g[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int t = t0 + wv; t < t1; t += 4) {
-        const int j0 = t * 16;
-        const f32x4 s = sim_tile(f, j0, rb, l, q);
-        float e[4];
+    // G[r][c] += sum_j E[r][j] f[j][c]: A = E[r = l][k -> j = 4q + step], B = f[j0 + 4q + step][16 ct + l]
+    auto weights = [&](const f32x4 s, int j0, float (&e)[4]) {
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
             const int j = j0 + 4 * q + gq;
             const float x = s[gq] * inv_t;
             e[gq] = (j == r) ? 0.f : __expf(x - lse_r) + __expf(x - lse_col[j - c0]);
         }
-        // G[r][c] += sum_j E[r][j] f[j][c]: A = E[r = l][k -> j = 4q + step], B = f[j0 + 4q + step][16 ct + l]
+    };
+    int t = t0 + wv;
+    for (; t + 4 < t1; t += 8) {              // two tiles per turn: every load of both tiles is issued before the first product
+        const int ja = t * 16, jb = (t + 4) * 16;
+        float fa[4][4], fb[4][4];             // B operands of the second product, [step][ct]
+#pragma unroll
+        for (int step = 0; step < 4; ++step)
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+                fa[step][ct] = f[(int64_t)(ja + 4 * q + step) * 64 + l + 16 * ct];
+                fb[step][ct] = f[(int64_t)(jb + 4 * q + step) * 64 + l + 16 * ct];
+            }
+        f32x4 sa, sb;
+        nce_dev::sim_tile2(f, ja, jb, rb, l, q, sa, sb);
+        float ea[4], eb[4];
+        weights(sa, ja, ea);
+        weights(sb, jb, eb);
+#pragma unroll
+        for (int step = 0; step < 4; ++step)
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+                g[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(ea[step], fa[step][ct], g[ct], 0, 0, 0);
+                g[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(eb[step], fb[step][ct], g[ct], 0, 0, 0);
+            }
+    }
+    if (t < t1) {
+        const int j0 = t * 16;
+        const f32x4 s = sim_tile(f, j0, rb, l, q);
+        float e[4];
+        weights(s, j0, e);
 #pragma unroll
         for (int step = 0; step < 4; ++step) {
             const float *frow = f + (int64_t)(j0 + 4 * q + step) * 64 + l;

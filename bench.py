@@ -99,6 +99,12 @@ class HotPath:
         self.edit_overflow = torch.zeros((), dtype=torch.bool, device=dev)
         self.ev = {k: [] for k in ("edits", "vectorise", "stats", "epoch", "predict", "exchange")}
         self.my_voters = D.voters_of_rank(args.voters, rank, world)
+        # several voters of one rank train side by side, each on its own stream with its own network, buffers and captured
+        # graph (idelucs_amd.training.train_voters does the same for the CLI)
+        from idelucs_amd.training import voter_lanes
+        self.lanes = [self.model] + [self.model.lane() for _ in range(voter_lanes(len(self.my_voters)) - 1)]
+        self.streams = [torch.cuda.Stream(device=dev) for _ in self.lanes]
+        self.last_model = self.model
         self.losses = []            # device scalars, one per voter-epoch (checked after the timed loop)
         self.gathered = None
         self.latent = None
@@ -127,14 +133,35 @@ class HotPath:
         m, a = self.model, self.a
         self.features(seed)
         preds = {}
-        for v in self.my_voters:
-            m.begin_voter(v)                                   # fresh Kaiming init + this voter's RNG streams
-            self.losses.append(self._timed("epoch", lambda: m.contrastive_training_epoch(sync=False)))
-            if a.exchange and a.workload != "cfg5":
-                preds[v] = self._timed("predict", self.predict)
-        if a.exchange and a.workload != "cfg5":               # the path's one exchange step: [V, N] int32 assignments
+        with_predict = a.exchange and a.workload != "cfg5"
+        if len(self.lanes) == 1:
+            for v in self.my_voters:
+                m.begin_voter(v)                                   # fresh Kaiming init + this voter's RNG streams + optimizer state
+                self.losses.append(self._timed("epoch", lambda: m.contrastive_training_epoch(sync=False)))
+                if with_predict:
+                    preds[v] = self._timed("predict", lambda: self.predict(m, self._predict_inputs()))
+        else:
+            cur = torch.cuda.current_stream()
+            t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0.record()
+            x = self._predict_inputs() if with_predict else None   # a function of the input alone: once per job, not once per voter
+            L = len(self.lanes)
+            for w in range(0, len(self.my_voters), L):
+                for lm, s, v in zip(self.lanes, self.streams, self.my_voters[w:w + L]):
+                    s.wait_stream(cur)
+                    with torch.cuda.stream(s):
+                        lm.begin_voter(v)
+                        self.losses.append(lm.contrastive_training_epoch(sync=False))
+                        if with_predict:
+                            preds[v] = self.predict(lm, x)
+                    self.last_model = lm
+                for s in self.streams:
+                    cur.wait_stream(s)
+            t1.record()
+            self.ev["epoch"].append((t0, t1))
+        if with_predict:                                           # the path's one exchange step: [V, N] int32 assignments
             self.gathered = self._timed("exchange", lambda: self.D.gather_voter_predictions(preds, a.voters, self.din.n, device=self.dev))
-        elif a.exchange:                                        # cfg5: last voter's model everywhere, predict sharded by sequence
+        elif a.exchange:                                           # cfg5: last voter's model everywhere, predict sharded by sequence
             self.latent = self._timed("exchange", self.sharded_latent)
 
     def _predict_inputs(self, lo=0, hi=None):
@@ -146,10 +173,8 @@ class HotPath:
         hi = f64.shape[0] if hi is None else hi
         return U.standardise(f64[lo:hi], mean, scale)
 
-    def predict(self):
+    def predict(self, m, x):
         """Eval forward, argmax (reference models.py:145-172) -> int32 [N]."""
-        m = self.model
-        x = self._predict_inputs()
         preds = []
         with torch.no_grad():
             m.net.eval()
@@ -161,7 +186,7 @@ class HotPath:
     def sharded_latent(self):
         """cfg5 (reference __main__.py:153-156 clusters ONE model's latent): the last voter's weights go to every rank, each
         rank embeds its N/G sequences, the fp32 shards are all-gathered over RCCL."""
-        m, D = self.model, self.D
+        m, D = self.last_model, self.D
         owner = (self.a.voters - 1) % self.world
         if self.world > 1:
             for p in m.net.parameters():
@@ -176,9 +201,13 @@ class HotPath:
         return D.all_gather_rows(torch.cat(lats) if lats else torch.empty((0, 64), device=self.dev), self.din.n)
 
     def mean_ms(self, key, skip_steps):
-        per_step = {"epoch": len(self.my_voters), "predict": len(self.my_voters)}.get(key, 1)
+        """Mean duration of one stage; "epoch" is per voter-epoch (with lanes: the side-by-side region, predicts included,
+        divided by the voters it trained)."""
+        nv = len(self.my_voters)
+        per_step = {"epoch": nv if len(self.lanes) == 1 else 1, "predict": nv}.get(key, 1)
         ev = self.ev[key][skip_steps * per_step:]
-        return sum(s.elapsed_time(e) for s, e in ev) / max(len(ev), 1)
+        t = sum(s.elapsed_time(e) for s, e in ev) / max(len(ev), 1)
+        return t / nv if key == "epoch" and len(self.lanes) > 1 else t
 
     def validate(self):
         """Untimed checks of what the last timed step produced (the bench validated nothing it timed)."""
@@ -397,10 +426,10 @@ def main():
     else:
         # the exchange step of the path, untimed at N = 1 with one voter: this rank's voter predicts, assignments are all-gathered
         from idelucs_amd.dist import all_gather_assignments
-        all_gather_assignments(hp.predict())            # first call: library initialisation for the inference GEMM shapes (0.5 s)
+        all_gather_assignments(hp.predict(hp.model, hp._predict_inputs()))            # first call: library initialisation for the inference GEMM shapes (0.5 s)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        gathered = all_gather_assignments(hp.predict())
+        gathered = all_gather_assignments(hp.predict(hp.model, hp._predict_inputs()))
         torch.cuda.synchronize()
         exchange_ms = 1e3 * (time.perf_counter() - t1)
         assert tuple(gathered.shape) == (world, args.n)
@@ -440,7 +469,7 @@ def main():
                                    f"{V} voter(s) over {world} GPU(s), value = N_seq * voters / wall; timed = {region}",
                        "n_sequences": args.n, "seq_len": args.len, "k": args.k, "batch_sz": args.batch_sz, "n_voters": V,
                        "optimizer_steps_per_epoch": (args.n * args.n_mimics + args.batch_sz - 1) // args.batch_sz,
-                       "parallelism": f"{V} voters / {world} ranks"},
+                       "parallelism": f"{V} voters / {world} ranks" + (f", {len(hp.lanes)} side by side per rank" if len(hp.lanes) > 1 else "")},
             "roofline": {"kernel": "vectorise kernel (hand-written HIP: one count + per-view window deltas + normalise, all views)",
                          "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                          "traffic": pmc_traffic_gb() if not cfg5 else None, "ms_per_launch": t_vec, "bytes_per_seq_algorithmic": b_vec,

@@ -31,7 +31,7 @@ def run(args):
     import torch.distributed as dist
     from resource import getrusage, RUSAGE_SELF
     from . import posthoc, dist as D
-    from .training import prepare_model, train_voter
+    from .training import prepare_model, train_voters
     from . import models
 
     start_time = time.time()
@@ -75,8 +75,10 @@ def run(args):
     n = len(model.names)
 
     local_preds, curves, latent = {}, {}, None
-    for voter in D.voters_of_rank(args["n_voters"], rank, world):
-        curves[voter], y_pred, probabilities, lat = train_voter(model, args["n_epochs"], voter, args["n_voters"])
+    # this rank's voters, several at a time on their own HIP streams (training.train_voters)
+    trained = train_voters(model, D.voters_of_rank(args["n_voters"], rank, world), args["n_epochs"], args["n_voters"], progress=rank == 0)
+    for voter, (curve, y_pred, probabilities, lat) in trained.items():
+        curves[voter] = curve
         if voter == args["n_voters"] - 1:
             latent = lat                                          # the reference scores/clusters the LAST voter's latent
         local_preds[voter] = torch.from_numpy(posthoc.relabel_first_occurrence(y_pred)).to(model.device)

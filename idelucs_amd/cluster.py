@@ -16,8 +16,8 @@ class iDeLUCS_cluster():
         """(y_pred int64 [N], latent float64 [N, 64]) of the LAST voter; no ensembling here, and the
         positional argument is ignored -- both as in the reference (cluster.py:32,47-52)."""
         model = prepare_model(self.args)
-        result = None
-        for v in range(self.args["n_voters"]):
-            result = train_voter(model, self.args["n_epochs"], v, self.args["n_voters"])
-        _, y_pred, _, latent = result
+        # every voter is a function of (seed, voter index) alone (IID_model.begin_voter), so the voters the reference trains
+        # and then discards here need not be trained at all
+        last = self.args["n_voters"] - 1
+        _, y_pred, _, latent = train_voter(model, self.args["n_epochs"], last, self.args["n_voters"])
         return y_pred, latent

@@ -129,6 +129,8 @@ class FusedLinearTrainer:
         """Dropout stream of voter v: the Philox counter word the kernels take from ctl[0] (its low 32 bits) starts at
         v << 24, so voters never share masks whichever rank runs them (16.7 M optimizer steps per voter, 256 voters)."""
         self.ctl[0] = (int(voter) & 0xFF) << 24
+        for v in self.square_avg:               # a voter starts with fresh optimizer state (models.IID_model.begin_voter)
+            v.zero_()
 
     def gradient(self, i):
         """Gradient of parameter i as a tensor of the parameter's shape (sums the stacked partials)."""

@@ -29,10 +29,13 @@ random.seed(0)
 EPS = sys.float_info.epsilon
 
 
-def weights_init(m):
+PREDICT_CACHE_BYTES = 32 << 30      # standardised un-mutated vectors kept between the voters' predicts (1.6 GB at 100k x 4^6)
+
+
+def weights_init(m, generator=None):
     """Reference models.py:36-44: Kaiming-normal weights, zero biases, for every nn.Linear."""
     if isinstance(m, nn.Linear):
-        torch.nn.init.kaiming_normal_(m.weight)
+        torch.nn.init.kaiming_normal_(m.weight, generator=generator)
         torch.nn.init.zeros_(m.bias)
 
 
@@ -84,18 +87,35 @@ class IID_model():
         else:
             raise ValueError("Optimizer not supported")
 
-        if self.schedule == 'Plateau':                          # models.py:96-99
-            self.scheduler = optim.lr_scheduler.ReduceLROnPlateau(self.optimizer, 'min')
-        elif self.schedule == 'Triangle':
-            self.scheduler = optim.lr_scheduler.CyclicLR(self.optimizer, base_lr=0.001, max_lr=0.1, step_size_up=5,
-                                                         mode="triangular2")
+        self._make_scheduler()
         self.store = None
-        self._fasta = None
+        self._args = dict(args)
+        self._shared = {}           # what the lanes of one ensemble share besides the store (see lane()): the predict inputs
+        self._gen = None            # this voter's private device generator (begin_voter)
         self._voter = 0
         # default configuration (NetLinear + RMSprop): explicit fused step replayed as a HIP graph
         self._fused = None
         self._use_fused = (args['model_size'] == 'linear' and args['optimizer'] == 'RMSprop'
                            and args['n_clusters'] <= 256 and os.environ.get("IDELUCS_FUSED", "1") != "0")
+
+    def _make_scheduler(self):
+        if self.schedule == 'Plateau':                          # models.py:96-99
+            self.scheduler = optim.lr_scheduler.ReduceLROnPlateau(self.optimizer, 'min')
+        elif self.schedule == 'Triangle':
+            self.scheduler = optim.lr_scheduler.CyclicLR(self.optimizer, base_lr=0.001, max_lr=0.1, step_size_up=5,
+                                                         mode="triangular2")
+
+    def lane(self):
+        """A sibling model for training another voter of the same ensemble AT THE SAME TIME on this GPU (training.train_voters):
+        its own network, optimizer state, step buffers and captured graph; the feature store, the FASTA summary and the
+        predict inputs are shared, read-only."""
+        other = IID_model(self._args)
+        other.store, other._shared = self.store, self._shared
+        other.dataloader = getattr(self, "dataloader", None)
+        for name in ("names", "lengths", "GT", "cluster_dis"):
+            if hasattr(self, name):
+                setattr(other, name, getattr(self, name))
+        return other
 
     # ------------------------------------------------------------------ data
     def build_dataloader(self):
@@ -104,17 +124,27 @@ class IID_model():
         self.store = utils.build_feature_store(self.sequence_file, self.n_mimics, k=self.k, reduce=self.reduce,
                                                rng=self.rng, seed=self.seed, device=self.device)
         self.dataloader = utils.DeviceBatchLoader(self.store, self.batch_sz)
+        self._shared.clear()
 
     # ------------------------------------------------------------------ training
     def begin_voter(self, voter=0):
         """A fresh voter (reference __main__.py:109: weights_init between voters).  The reference's voters differ because
-        its one process consumes the torch RNG sequentially; here voters may run on different ranks, so every stream a voter
-        draws from (Kaiming init, batch permutations, dropout) is a function of (seed, voter index) and voter v is the same
-        run whichever rank trains it.  The mimic/data seed stays shared: every rank builds the same feature store."""
+        its one process consumes the torch RNG sequentially; here voters may run on different ranks, or side by side on one GPU,
+        so every stream a voter draws from (Kaiming init, batch permutations, dropout) is a function of (seed, voter index) and
+        voter v is the same run wherever and whenever it trains.  For the same reason the optimizer and scheduler state start
+        from scratch: the reference carries RMSprop's running averages (and the scheduler's counters) from voter v-1 into voter
+        v, which a sharded ensemble cannot do; every voter here starts where the reference's FIRST voter starts.  The
+        mimic/data seed stays shared: every rank builds the same feature store."""
         self._voter = int(voter)
-        torch.manual_seed((int(self.seed) * 1000003 + 1 + self._voter) & (2 ** 63 - 1))     # CPU and every CUDA generator
-        self.net.apply(weights_init)
+        vseed = (int(self.seed) * 1000003 + 1 + self._voter) & (2 ** 63 - 1)
+        torch.manual_seed(vseed)                                  # CPU and every CUDA generator (the unfused paths draw from these)
+        self._gen = torch.Generator(device=self.device).manual_seed(vseed)
+        self.net.apply(lambda mod: weights_init(mod, self._gen))
         self.epoch = 0
+        self.optimizer.state.clear()
+        for grp in self.optimizer.param_groups:
+            grp['lr'] = self.lr
+        self._make_scheduler()
         if self._fused is not None:
             self._fused.begin_voter(self._voter)
 
@@ -131,6 +161,11 @@ class IID_model():
     def contrastive_training_epoch(self, sync=True):
         """Reference models.py:113-143: one pass over the shuffled N*n_mimics pairs -> the epoch loss as a Python float
         (sync=False: as a device scalar, without waiting for the epoch to finish)."""
+        return self._finish_epoch(self.enqueue_epoch(), sync)
+
+    def enqueue_epoch(self):
+        """The epoch's launches on the current stream -> its loss as a device scalar (scheduler step and epoch counter:
+        _finish_epoch)."""
         self.net.train()
         st = self.store
         if self._use_fused:
@@ -142,17 +177,15 @@ class IID_model():
                 self._fused = FusedLinearTrainer(self.net, self.lr, self.weight, self.l, seed=self.seed)
                 self._fused.begin_voter(self._voter)
             self._fused.set_lr(self.optimizer.param_groups[0]['lr'])       # schedulers act on the torch optimizer
-            total, n_batches = self._fused.run_epoch(st, self.batch_sz)
-            running_loss = total / (n_batches - 1)                          # models.py:135 quirk (divide by last index)
-            return self._finish_epoch(running_loss, sync)
+            total, n_batches = self._fused.run_epoch(st, self.batch_sz, generator=self._gen)
+            return total / (n_batches - 1)                                  # models.py:135 quirk (divide by last index)
         running_loss = torch.zeros((), device=self.device)
-        perm = torch.randperm(st.n_pairs, device=self.device)
+        perm = torch.randperm(st.n_pairs, device=self.device, generator=self._gen)
         i_batch = 0
         for i_batch, i in enumerate(range(0, st.n_pairs, self.batch_sz)):
             x = st.gather_pairs(perm[i:i + self.batch_sz])
             running_loss += self._step(x)
-        running_loss = running_loss / i_batch      # models.py:135 divides by the LAST INDEX (n_batches-1): kept
-        return self._finish_epoch(running_loss, sync)
+        return running_loss / i_batch              # models.py:135 divides by the LAST INDEX (n_batches-1): kept
 
     def _finish_epoch(self, running_loss, sync=True):
         if self.schedule == 'Plateau':
@@ -163,8 +196,24 @@ class IID_model():
         return running_loss.item() if sync else running_loss
 
     # ------------------------------------------------------------------ inference
+    def _predict_inputs(self, rows=None):
+        """utils.predict_features of this model's file.  The reference re-reads and re-vectorises the file for every voter's
+        predict (models.py:147-163); the result is a pure function of the file, so one ensemble computes it once (kept while it
+        fits PREDICT_CACHE_BYTES, shared between lanes)."""
+        key = (self.sequence_file, self.k, self.reduce, rows)
+        hit = self._shared.get("predict_inputs")
+        if hit is not None and hit[0] == key:
+            torch.cuda.current_stream().wait_event(hit[2])
+            return hit[1]
+        feats = utils.predict_features(self.sequence_file, k=self.k, reduce=self.reduce, device=self.device, rows=rows)[2]
+        if feats.numel() * 4 <= PREDICT_CACHE_BYTES:
+            ready = torch.cuda.Event()
+            ready.record()
+            self._shared["predict_inputs"] = (key, feats, ready)
+        return feats
+
     def _predict_outputs(self, rows=None):
-        names, lengths, feats = utils.predict_features(self.sequence_file, k=self.k, reduce=self.reduce, device=self.device, rows=rows)
+        feats = self._predict_inputs(rows)
         outs, lats = [], []
         with torch.no_grad():
             self.net.eval()

@@ -1,5 +1,6 @@
 """The CLI keeps the reference's flag surface (idelucs/__main__.py:275-308); CPU-only checks plus one GPU run."""
 import os
+import time
 
 import numpy as np
 import pytest
@@ -142,7 +143,29 @@ def test_device_ensemble_matches_sklearn_partition():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n_clusters,n_voters", [(5, 2), (0, 3)])
+def test_voters_are_the_same_runs_side_by_side_or_one_after_the_other(tmp_path, monkeypatch):
+    """Several voters per GPU train side by side on their own streams (training.train_voters).  Every voter draws from its own
+    RNG streams and starts from fresh optimizer state, so the vote matrix must not depend on how many lanes there are."""
+    from idelucs_amd.__main__ import main
+    monkeypatch.chdir(tmp_path)
+    votes = {}
+    for lanes in (1, 3, 2):
+        monkeypatch.setenv("IDELUCS_VOTER_LANES", str(lanes))
+        monkeypatch.setenv("IDELUCS_DUMP_VOTES", str(tmp_path / f"votes{lanes}.npy"))
+        main(["--sequence_file", os.path.join(DATA, "Influenza-A.fas"), "--GT_file", os.path.join(DATA, "Influenza-A_GT.tsv"),
+              "--n_clusters", "5", "--n_epochs", "8", "--n_voters", "3", "--batch_sz", "512", "--k", "6"])
+        votes[lanes] = np.load(tmp_path / f"votes{lanes}.npy")
+        time.sleep(1.1)                                       # the results folder is stamped to the second
+    assert votes[1].shape == (3, 949)
+    assert not np.array_equal(votes[1][0], votes[1][1])
+    for lanes in (3, 2):
+        agree = (votes[lanes] == votes[1]).mean(axis=1)
+        print(f"{lanes} lanes vs 1: per-voter agreement {agree}")
+        assert np.array_equal(votes[lanes], votes[1]), agree
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_clusters,n_voters", [(5, 3), (0, 3)])
 def test_cli_two_ranks_voters_are_distinct_and_outputs_complete(tmp_path, n_clusters, n_voters):
     """`python -m torch.distributed.run --nproc-per-node 2 -m idelucs_amd ...`: the voter loop sharded over two ranks (both on
     this box's one GPU, collectives over gloo -- every line of the multi-GPU path except RCCL itself).  Voters on different
@@ -174,6 +197,19 @@ def test_cli_two_ranks_voters_are_distinct_and_outputs_complete(tmp_path, n_clus
     assert np.isfinite(float(m.loc["Silhouette-Score", "Value"]))        # computed on the gathered [N, 64] latent
     if n_clusters == 5:
         assert float(m.loc["ACC", "Value"]) > 0.80
+        # voter v is the same run whichever rank trains it: the same job in ONE process gives the same vote matrix
+        from idelucs_amd.__main__ import main
+        one = str(tmp_path / "votes_one_process.npy")
+        os.environ["IDELUCS_DUMP_VOTES"] = one
+        cwd = os.getcwd()
+        try:
+            os.chdir(tmp_path)
+            time.sleep(1.1)
+            main(cmd[cmd.index("idelucs_amd") + 1:])
+        finally:
+            os.chdir(cwd)
+            del os.environ["IDELUCS_DUMP_VOTES"]
+        assert np.array_equal(np.load(one), v), (np.load(one) == v).mean(axis=1)
 
 
 @pytest.mark.gpu

@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Do several voters' epochs overlap when each runs its own captured step graph on its own HIP stream?
+
+The small launches of one training step (InfoNCE passes, middle layers, optimizer) occupy a fraction of the 256 CUs each,
+so a second voter's step could fill the rest.  Times V voter-epochs back to back on one stream against the same V epochs on
+V streams (one model, one trainer and one graph per voter; the feature store is shared and read-only).
+
+  python tools/concurrent_voters.py [--n 100000] [--voters 4]
+"""
+import argparse
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=100000)
+    ap.add_argument("--voters", type=int, default=4)
+    ap.add_argument("--k", type=int, default=6)
+    ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--n-clusters", dest="n_clusters", type=int, default=20)
+    a = ap.parse_args()
+    from idelucs_amd import models, utils as U
+    dev = torch.device("cuda:0")
+    P, F = 3, 4 ** a.k
+    g = torch.Generator(device=dev).manual_seed(1)
+    feats = torch.rand((P, a.n, F), device=dev, generator=g) * 1e-3
+    mean, scale = U.col_stats(feats[0])
+    store = U.FeatureStore(None, None, feats, mean, scale, a.k, False)
+
+    def make(v):
+        m = models.IID_model({'sequence_file': None, 'GT_file': None, 'n_clusters': a.n_clusters, 'k': a.k, 'model_size': 'linear',
+                              'n_mimics': 3, 'batch_sz': 512, 'optimizer': 'RMSprop', 'lambda': 2.8, 'lr': 1e-3, 'weight': 0.25,
+                              'scheduler': None, 'n_epochs': 1, 'n_voters': a.voters})
+        m.store = store
+        m.begin_voter(v)
+        return m
+
+    ms = [make(v) for v in range(a.voters)]
+    streams = [torch.cuda.Stream() for _ in ms]
+    for m in ms:                                   # capture every voter's graph
+        m.contrastive_training_epoch(sync=False)
+    torch.cuda.synchronize()
+
+    def seq():
+        return [m.contrastive_training_epoch(sync=False) for m in ms]
+
+    def conc():
+        cur = torch.cuda.current_stream()
+        out = []
+        for m, s in zip(ms, streams):
+            s.wait_stream(cur)
+            with torch.cuda.stream(s):
+                out.append(m.contrastive_training_epoch(sync=False))
+        for s in streams:
+            cur.wait_stream(s)
+        return out
+
+    for name, fn in (("sequential", seq), ("concurrent", conc), ("sequential", seq), ("concurrent", conc)):
+        ts = []
+        for _ in range(a.reps):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            losses = fn()
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        print(f"{name}: {a.voters} voter-epochs in {min(ts) * 1e3:.1f} ms (min of {a.reps}); losses {[round(float(x), 4) for x in losses]}", flush=True)
+
+
+if __name__ == "__main__":
+    main()

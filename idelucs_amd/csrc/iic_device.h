@@ -205,26 +205,59 @@ __device__ __forceinline__ void iic_core_rows(float *P0, int C, float lamb, floa
     }
 }
 
-// ---------------------------------------------------------------- ... and for C x C x 4 B <= ~158 KB (C <= 200: the fine-grained mode)
-// the whole joint in (dynamic) LDS, updated in place: read from memory once with coalesced 16-byte loads, symmetrised pair by pair
-// (the thread of element (r, c), r <= c, writes both (r, c) and (c, r)), row sums one wave per row, gradient in place, written
-// back once.  L: C * C floats of LDS.  NT threads.
-template <int NT>
-__device__ __forceinline__ void iic_core_lds(float *P0, int C, float lamb, float eps, float w_iic, float *out, float *L)
+// ---------------------------------------------------------------- ... and for 48 < C <= 200 (the fine-grained mode): two launches
+// One workgroup took 32 us for the 40 000 elements of a C = 200 joint (s_memtime stamps: 8 us for the row marginals, 10 us for the
+// elementwise pass, 5 us each for the first read and the last write -- serial chains on the 4 SIMDs of ONE CU).  A single launch
+// on several CUs with a last-workgroup-done counter was no faster: the two agent-scope fences it needs cost 4-8 us EACH on this
+// GPU (its L2s are per XCD: a release writes the L2 back, an acquire invalidates it).  So the launch boundary is the barrier:
+//   iic_core_rows_multi, ceil(C / 8) workgroups: every one keeps the whole joint in (dynamic) LDS -- one coalesced read of the
+//     160 KB, rows padded to an odd stride so that the transposed reads of the symmetrisation are conflict-free -- and repeats the
+//     cheap parts (total, the C row marginals) for itself, so no workgroup waits for another; the expensive elementwise pass (loss
+//     terms + gradient) is done for IIC_RPW rows per workgroup, two waves per row.  The rows go to `grad` unshifted, with two
+//     partial sums per workgroup (and the total s) in `part`.
+//   iic_core_shift: the gradient needs the global sum gp = sum g p: every workgroup adds the partials up in workgroup order and
+//     writes w_iic (g - gp) / s over its slice of P0; workgroup 0 writes the loss.
+// L: C * (C | 1) floats of LDS.  part: 2 * gridDim.x + 1 doubles.  1024 threads.
+constexpr int IIC_RPW = 8;
+constexpr int IIC_U = 10;      // loads in flight per thread (a C = 200 joint is 9.8 float4 per thread)
+
+__device__ __forceinline__ void iic_core_rows_multi(const float *P0, int C, float lamb, float eps, float *grad, double *part, float *L)
 {
-    constexpr int NW = NT / 64;
-    __shared__ float rs[256], ar[256];
+    constexpr int NT = 1024, NW = NT / 64;
+    __shared__ float rs[200], ar[200];
     __shared__ double red[2][NW];
-    const int t = threadIdx.x, lane = t & 63, wv = t >> 6, n = C * C;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6, n = C * C, G = gridDim.x;
+    const int CP = C | 1;
+    const bool vec = (C & 3) == 0 && (((uintptr_t)P0) & 15u) == 0;
+    // (loads issued IIC_U at a time before the first use: a loop of load -> wait -> use pays the memory latency once per element)
     double acc = 0.0;
-    if ((n & 3) == 0 && ((uintptr_t)P0 & 15u) == 0) {
-        for (int i4 = t; i4 < n / 4; i4 += NT) {
-            const float4 v = ((const float4 *)P0)[i4];
-            *(float4 *)(L + 4 * i4) = v;
-            acc += ((double)v.x + (double)v.y) + ((double)v.z + (double)v.w);
+    if (vec) {
+        for (int b4 = 0; b4 < n / 4; b4 += IIC_U * NT) {
+            float4 v[IIC_U];
+#pragma unroll
+            for (int j = 0; j < IIC_U; ++j) { const int i4 = b4 + j * NT + t; v[j] = ((const float4 *)P0)[i4 < n / 4 ? i4 : 0]; }
+#pragma unroll
+            for (int j = 0; j < IIC_U; ++j) {
+                const int i4 = b4 + j * NT + t;
+                if (i4 < n / 4) {
+                    const int r = (4 * i4) / C, c = 4 * i4 - r * C;
+                    float *d = L + r * CP + c;
+                    d[0] = v[j].x; d[1] = v[j].y; d[2] = v[j].z; d[3] = v[j].w;
+                    acc += ((double)v[j].x + (double)v[j].y) + ((double)v[j].z + (double)v[j].w);
+                }
+            }
         }
     } else {
-        for (int i = t; i < n; i += NT) { const float v = P0[i]; L[i] = v; acc += (double)v; }
+        for (int b = 0; b < n; b += IIC_U * NT) {
+            float v[IIC_U];
+#pragma unroll
+            for (int j = 0; j < IIC_U; ++j) { const int i = b + j * NT + t; v[j] = P0[i < n ? i : 0]; }
+#pragma unroll
+            for (int j = 0; j < IIC_U; ++j) {
+                const int i = b + j * NT + t;
+                if (i < n) { const int r = i / C; L[r * CP + (i - r * C)] = v[j]; acc += (double)v[j]; }
+            }
+        }
     }
     acc = idl_dev::wave_sum_d(acc);
     if (lane == 0) red[0][wv] = acc;
@@ -232,47 +265,80 @@ __device__ __forceinline__ void iic_core_lds(float *P0, int C, float lamb, float
     double st = 0.0;
 #pragma unroll
     for (int i = 0; i < NW; ++i) st += red[0][i];
-    const float s = (float)st;
-    // everything below walks the joint one wave per row (no integer divisions); the per-row terms of the loss and of the gradient
-    // -- log of the clamped marginal, lamb * ar / marginal -- are computed once per row, not once per element
-    for (int r = wv; r < C; r += NW)
-        for (int c = r + lane; c < C; c += 64) { const float v = ((L[r * C + c] + L[c * C + r]) * 0.5f) / s; L[r * C + c] = v; L[c * C + r] = v; }
-    __syncthreads();
-    for (int r = wv; r < C; r += NW) {
-        float a = 0.f, b = 0.f;
-        for (int c = lane; c < C; c += 64) { const float p = L[r * C + c]; a += p; b += fmaxf(p, eps); }
-        a = idl_dev::wave_sum_f(a); b = idl_dev::wave_sum_f(b);
-        if (lane == 0) {
-            const float pi = fmaxf(a, eps);
-            rs[r] = __logf(pi);                               // log of the clamped marginal
-            ar[r] = (a < eps) ? 0.f : lamb * b / pi;          // its share of dL/dP (none through a clamped marginal)
+    const float s = (float)st;                                // the same value in every workgroup (same data, same order)
+    // the marginals of ALL rows (this pass is repeated by every workgroup: a reciprocal instead of 40 000 divisions), one wave per
+    // row, four rows in flight per wave (one row at a time is a serial chain of LDS latency, two wave reductions and a log)
+    const float half_inv_s = 0.5f / s;
+    for (int r0 = 4 * wv; r0 < C; r0 += 4 * NW) {
+        float a[4] = {0.f, 0.f, 0.f, 0.f}, b[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int c = lane; c < C; c += 64) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = min(r0 + j, C - 1);
+                const float p = (L[r * CP + c] + L[c * CP + r]) * half_inv_s;
+                a[j] += p; b[j] += fmaxf(p, eps);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { a[j] = idl_dev::wave_sum_f(a[j]); b[j] = idl_dev::wave_sum_f(b[j]); }
+        if (lane < 4 && r0 + lane < C) {
+            const float al = lane == 0 ? a[0] : lane == 1 ? a[1] : lane == 2 ? a[2] : a[3];
+            const float bl = lane == 0 ? b[0] : lane == 1 ? b[1] : lane == 2 ? b[2] : b[3];
+            const float pi = fmaxf(al, eps);
+            rs[r0 + lane] = __logf(pi);                             // log of the clamped marginal
+            ar[r0 + lane] = (al < eps) ? 0.f : lamb * bl / pi;      // its share of dL/dP (none through a clamped marginal)
         }
     }
     __syncthreads();
+    // loss terms and gradient of this workgroup's rows: two waves per row
     double lacc = 0.0, gacc = 0.0;
-    for (int r = wv; r < C; r += NW) {
+    const int r = blockIdx.x * IIC_RPW + (wv >> 1);
+    if (r < C && (wv >> 1) < IIC_RPW) {
         const float lpi = rs[r], gri = ar[r];
-        for (int c = lane; c < C; c += 64) {
-            const float pu = L[r * C + c], p = fmaxf(pu, eps);
+        for (int c = (wv & 1) * 64 + lane; c < C; c += 128) {
+            const float pu = ((L[r * CP + c] + L[c * CP + r]) * 0.5f) / s, p = fmaxf(pu, eps);
             const float lg = __logf(p) - lamb * rs[c] - lamb * lpi;
             lacc += (double)(-p * lg);
             float g = 0.f;
             if (!(pu < eps)) g += -lg - 1.f;
             g += gri;
             g += ar[c];
-            L[r * C + c] = g;
+            grad[r * C + c] = g;
             gacc += (double)g * (double)pu;
         }
     }
     lacc = idl_dev::wave_sum_d(lacc); gacc = idl_dev::wave_sum_d(gacc);
-    if (lane == 0) { red[0][wv] = lacc; red[1][wv] = gacc; }       // (red[0] was last read two barriers ago)
+    if (lane == 0) { red[0][wv] = lacc; red[1][wv] = gacc; }       // (red[0] was last read before the barrier above)
     __syncthreads();
-    double l1 = 0.0, g1 = 0.0;
+    if (t == 0) {
+        double l1 = 0.0, g1 = 0.0;
 #pragma unroll
-    for (int i = 0; i < NW; ++i) { l1 += red[0][i]; g1 += red[1][i]; }
-    const float gp = (float)g1;
-    if (t == 0) out[3] = (float)l1;
-    for (int i = t; i < n; i += NT) P0[i] = w_iic * (L[i] - gp) / s;      // (each thread re-reads only what it wrote)
+        for (int i = 0; i < NW; ++i) { l1 += red[0][i]; g1 += red[1][i]; }
+        part[2 * blockIdx.x] = l1; part[2 * blockIdx.x + 1] = g1;
+        if (blockIdx.x == 0) part[2 * G] = (double)s;
+    }
+}
+
+// P0[i] = w_iic (grad[i] - gp) / s for the 4 * blockDim.x elements of this workgroup; n_part = the grid of iic_core_rows_multi
+__device__ __forceinline__ void iic_core_shift(float *P0, int C, float w_iic, float *out, const float *grad, const double *part, int n_part)
+{
+    const int n = C * C, i0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    float g[4];
+    const bool vec = (n & 3) == 0 && ((((uintptr_t)P0) | ((uintptr_t)grad)) & 15u) == 0;
+    if (vec && i0 < n) { const float4 v = *(const float4 *)(grad + i0); g[0] = v.x; g[1] = v.y; g[2] = v.z; g[3] = v.w; }
+    else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) g[j] = grad[min(i0 + j, n - 1)];
+    }
+    double l1 = 0.0, g1 = 0.0;
+    for (int i = 0; i < n_part; ++i) { l1 += part[2 * i]; g1 += part[2 * i + 1]; }
+    const float gp = (float)g1, s = (float)part[2 * n_part];
+    if (blockIdx.x == 0 && threadIdx.x == 0) out[3] = (float)l1;
+    if (vec && i0 < n) *(float4 *)(P0 + i0) = float4{w_iic * (g[0] - gp) / s, w_iic * (g[1] - gp) / s, w_iic * (g[2] - gp) / s, w_iic * (g[3] - gp) / s};
+    else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (i0 + j < n) P0[i0 + j] = w_iic * (g[j] - gp) / s;
+    }
 }
 
 // ---------------------------------------------------------------- the C <= 48 core, from a read-only joint into LDS

@@ -340,10 +340,15 @@ __global__ __launch_bounds__(256) void nce_esym_kernel(float *S, int m, float in
 }
 
 // ---------------------------------------------------------------- IIC on the C x C joint (one workgroup): iic_device.h
-__global__ __launch_bounds__(1024) void iic_core_lds_kernel(float *P0, int C, float lamb, float eps, float w_iic, float *out)
+__global__ __launch_bounds__(1024) void iic_core_rows_kernel(const float *P0, int C, float lamb, float eps, float *grad, double *part)
 {
     extern __shared__ float iic_L[];
-    iic_core_lds<1024>(P0, C, lamb, eps, w_iic, out, iic_L);
+    iic_core_rows_multi(P0, C, lamb, eps, grad, part, iic_L);
+}
+
+__global__ __launch_bounds__(256) void iic_core_shift_kernel(float *P0, int C, float w_iic, float *out, const float *grad, const double *part, int n_part)
+{
+    iic_core_shift(P0, C, w_iic, out, grad, part, n_part);
 }
 
 template <int NT>
@@ -1032,16 +1037,21 @@ int idl_iic_core(float *P0, int C, float lamb, float eps, float w_iic, float *sc
     IDL_REQUIRE(P0 && scratch && out, "NULL buffer");
     IDL_REQUIRE(C >= 1 && C <= 64 * MAX_CPL, "iic_core: n_clusters must be in 1..256");
     if (C <= 48) hipLaunchKernelGGL(iic_core_kernel<256>, dim3(1), dim3(256), 0, (hipStream_t)stream, P0, C, lamb, eps, w_iic, scratch, out);
-    else if (C <= 200) {                     // the joint fits LDS (C * C * 4 + 2.3 KB <= 160 KB)
-        const int lds = C * C * 4;
+    else if (C <= 200) {                     // the joint fits LDS (rows padded to an odd stride: C * (C | 1) * 4 + 1.9 KB <= 160 KB)
+        const int lds = C * (C | 1) * 4;
         static bool attr_set[64] = {};
         int dev = 0;
         IDL_HIP_TRY(hipGetDevice(&dev));
         if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-            IDL_HIP_TRY(hipFuncSetAttribute((const void *)iic_core_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 200 * 200 * 4));
+            IDL_HIP_TRY(hipFuncSetAttribute((const void *)iic_core_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 200 * 201 * 4));
             attr_set[dev] = true;
         }
-        hipLaunchKernelGGL(iic_core_lds_kernel, dim3(1), dim3(1024), lds, (hipStream_t)stream, P0, C, lamb, eps, w_iic, out);
+        // scratch: [0, C*C) the unshifted gradient; then (16-byte aligned) 2 doubles per workgroup of the first launch + the total
+        const int G = (C + IIC_RPW - 1) / IIC_RPW;
+        IDL_REQUIRE((((uintptr_t)scratch) & 15u) == 0, "iic_core: scratch must be 16-byte aligned");
+        double *part = (double *)(scratch + ((C * C + 3) & ~3));           // 4 G + 2 <= 2 C - 3 floats for C >= 49
+        hipLaunchKernelGGL(iic_core_rows_kernel, dim3(G), dim3(1024), lds, (hipStream_t)stream, P0, C, lamb, eps, scratch, part);
+        hipLaunchKernelGGL(iic_core_shift_kernel, dim3((C * C + 1023) / 1024), dim3(256), 0, (hipStream_t)stream, P0, C, w_iic, out, scratch, part, G);
     }
     else hipLaunchKernelGGL(iic_core_kernel<512>, dim3(1), dim3(512), 0, (hipStream_t)stream, P0, C, lamb, eps, w_iic, scratch, out);
     IDL_HIP_TRY(hipGetLastError());

@@ -105,6 +105,10 @@ class FusedLinearTrainer:
         self._early_gather = (self._pipeline and self._mid_fused and self.C <= 48 and self.F % 4 == 0
                               and os.environ.get("IDELUCS_EARLY_GATHER", "1") != "0")
         self._early_split = os.environ.get("IDELUCS_EARLY_GATHER", "1") != "2"       # 2: all of it in the mid-backward launch
+        # n_clusters > 48 (fine-grained mode, 200 outputs): the backward runs as separate kernels, so ALL of the next batch's tiles ride
+        # in the mid-forward launch
+        self._early_fwd = (self._pipeline and self._mid_fused and self.C > 48 and self.F % 4 == 0 and self._dw2_inlaunch
+                           and os.environ.get("IDELUCS_EARLY_GATHER", "1") != "0")
         self._gsplit = min(max(int(os.environ.get("IDELUCS_GATHER_SPLIT", "4")), 0), 8)   # eighths of the tiles the mid-forward launch takes
         # layer-1 activations kept transposed ([512, m]) between the layer-1 product and its consumers
         self._transposed_l1 = os.environ.get("IDELUCS_TRANSPOSED_L1", "1") != "0"
@@ -156,6 +160,7 @@ class FusedLinearTrainer:
         tl = (self._transposed_l1 and next_from is not None and self._early_gather and self._early_split and m % 16 == 0
               and self._dw2_inlaunch)
         early = next_from is not None and self._early_gather and m % 16 == 0   # next batch -> bf.xs[1 - xi] by the mid launches
+        early_f = next_from is not None and self._early_fwd and m % 16 == 0    # ... by the mid-forward launch alone
         chk = _lib.check
         main = torch.cuda.current_stream()
         side = self._side if self._overlap else main
@@ -171,6 +176,13 @@ class FusedLinearTrainer:
                                       _p(bf.f), _p(bf.inv), _p(bf.r2), _p(bf.z),
                                       _p(st.feats), st.n, st.f, st.n * st.f, _p(self._perm), _p(self.ctl[1:]), m // 2, st.n_pairs, m // 2,
                                       _p(st.mean), _p(st.scale), _p(st.inv_scale), _p(bf.xs[1 - xi]), 0, self._gsplit, 8, _stream()))
+        elif early_f:
+            st = next_from
+            chk(_L.idl_mid_fwd_gather(_p(bf.r1), None, 0, _p(self.W2), _p(self.b2), _p(self.W3), _p(self.b3),
+                                      m, C, tr, self.seed, _p(self.ctl),
+                                      _p(bf.f), _p(bf.inv), _p(bf.r2), _p(bf.z),
+                                      _p(st.feats), st.n, st.f, st.n * st.f, _p(self._perm), _p(self.ctl[1:]), m // 2, st.n_pairs, m // 2,
+                                      _p(st.mean), _p(st.scale), _p(st.inv_scale), _p(bf.xs[1 - xi]), 0, 8, 8, _stream()))
         elif self._mid_fused and m % 16 == 0:   # ReLU/Dropout + Linear(512,64) + head in one MFMA kernel
             chk(_L.idl_mid_fwd(_p(bf.r1), _p(self.W2), _p(self.b2), _p(self.W3), _p(self.b3), m, C, tr, self.seed, _p(self.ctl),
                                _p(bf.f), _p(bf.inv), _p(bf.r2), _p(bf.z), _stream()))
@@ -206,8 +218,8 @@ class FusedLinearTrainer:
         main.wait_stream(side)
         nce_coef = (1.0 - self.weight) / (m * TEMPERATURE)
         gW1, gb1, gW2, gb2, gW3, gb3 = self.grads
-        adv_ctl = _p(self.ctl) if (next_from is not None and not early) else None
-        adv = batch_advance if (next_from is not None and not early) else 0
+        adv_ctl = _p(self.ctl) if (next_from is not None and not early and not early_f) else None
+        adv = batch_advance if (next_from is not None and not early and not early_f) else 0
         if early and nce_bwd:
             st = next_from
             chk(_L.idl_nce_mid_bwd_gather(_p(bf.z), _p(bf.r2), _p(bf.f), _p(bf.inv), _p(bf.nce_ws), bf.nce_parts, TEMPERATURE, _p(bf.P0),
@@ -270,7 +282,7 @@ class FusedLinearTrainer:
         sz = self._sz_no_w1 if w1_done else self._sz
         main.wait_stream(side)
         # ---- RMSprop (and advance the device-side step counter / batch offset)
-        if early and self._dw2_inlaunch:      # no batch assembly here; the offset moves on at the end of the step
+        if (early or early_f) and self._dw2_inlaunch:      # no batch assembly here; the offset moves on at the end of the step
             chk(_L.idl_rmsprop_step_gather_wgrad(len(self.params), self._pp, self._gp, self._parts, self._vp, sz, _p(self.hyper),
                                                  _p(self.ctl), _p(bf.loss_rows), m, 1.0 - self.weight, self.weight, _p(self.out),
                                                  None, 0, 0, 0, None, 0, 0, None, None, None, None,
@@ -305,7 +317,8 @@ class FusedLinearTrainer:
         """pipelined: bf.xs[xi] already holds this batch (assembled by the previous step, or by the prologue gather);
         this step assembles the next one (into bf.xs[1 - xi] when the mid-backward launch does it, else into bf.xs[xi])."""
         if pipelined:
-            self.step_on_batch(bf, train=train, batch_advance=bf.m // 2, next_from=store, xi=xi if self._early_gather else 0)
+            self.step_on_batch(bf, train=train, batch_advance=bf.m // 2, next_from=store,
+                               xi=xi if (self._early_gather or self._early_fwd) else 0)
         else:
             self._gather(store, bf)
             self.step_on_batch(bf, train=train, batch_advance=bf.m // 2)
@@ -330,12 +343,12 @@ class FusedLinearTrainer:
                 self._gather(store, bf)         # prologue: batch 0; every later batch is assembled by the previous step
             # steps per graph replay: an even number when two x buffers alternate.  Between two replays the GPU idles ~9 us
             # (profiles/r02_f: kernel trace), so a replay carries several steps
-            per = self._steps_per_graph if (pipe and self._early_gather) else 1
+            per = self._steps_per_graph if pipe else 1
             while per > 2 and n_full < 2 + 2 * per:      # short epochs: the capture itself runs 2 + per real steps
                 per = max(2, per // 4 * 2)
             # every address the captured launches bake in is part of the key (a store refitted in place keeps its graph)
             key = (2 * batch_sz, store.feats.data_ptr(), store.mean.data_ptr(), store.scale.data_ptr(), store.inv_scale.data_ptr(),
-                   self._perm.data_ptr(), store.n, store.f, store.n_views, pipe, self._early_gather, per)
+                   self._perm.data_ptr(), store.n, store.f, store.n_views, pipe, self._early_gather, self._early_fwd, per)
             if use_graph and n_full >= 8:
                 g = self._graphs.get(key)
                 if g is None:

@@ -245,7 +245,7 @@ def test_fused_loss_kernels_vs_reference(dev, B, C):
     a = torch.from_numpy(g[f"iic.B{B}.C{C}.a"]).to(dev); b = torch.from_numpy(g[f"iic.B{B}.C{C}.b"]).to(dev)
     z1, z2 = torch.softmax(a, 1), torch.softmax(b, 1)
     P0 = (z1.t() @ z2).contiguous()
-    scratch = torch.empty(C * C + 2 * C, device=dev); out = torch.zeros(4, device=dev)
+    scratch = torch.zeros(C * C + 2 * C, device=dev); out = torch.zeros(4, device=dev)
     _lib.check(L.idl_iic_core(_p(P0), C, 2.8, EPS, 1.0, _p(scratch), _p(out), _stream()))
     ref = float(g[f"iic.B{B}.C{C}.loss"])
     assert abs(out[3].item() - ref) <= 1e-4 * abs(ref), (out[3].item(), ref)
@@ -323,21 +323,28 @@ def _cfg2_store_and_net(dev, n, seed=3, C=20):
     return store, net
 
 
-def test_default_fused_step_at_cfg2_shape_vs_autograd(dev):
-    """The launch sequence bench.py times -- FusedLinearTrainer._full_step(pipelined=True) with every default (transposed
+@pytest.mark.parametrize("C", [20, 200])
+def test_default_fused_step_at_cfg2_shape_vs_autograd(dev, C):
+    """C = 20: the launch sequence bench.py times -- FusedLinearTrainer._full_step(pipelined=True) with every default (transposed
     layer-1 product -> mid_fwd_gather -> nce_fused_iic_z -> mid_bwd_gather -> dW1 GEMM -> rmsprop_step_gather_wgrad) at cfg2's
     shape m=1024, F=4096, C=20 -- against torch autograd over idelucs_amd.LossFunctions (pinned to the reference goldens
     above), dropout off: loss rel 2e-4, the six gradients rel 2e-3, parameters after RMSprop rel 1e-5 on identical
-    gradients; and the batch the step assembled for the NEXT step is the gather of the next 512 pairs."""
+    gradients; and the batch the step assembled for the NEXT step is the gather of the next 512 pairs.
+    C = 200: the fine-grained mode's sequence (cfg5, --n_clusters 0): layer-1 product -> mid_fwd_gather carrying ALL of the next
+    batch's tiles -> joint GEMM + idl_iic_core -> idl_nce_fused -> z dP0 GEMM -> head_bwd_dz -> dW3 / dr1 GEMMs -> bias_grads ->
+    dW1 GEMM -> rmsprop_step_gather_wgrad."""
     import copy
     import torch
     from idelucs_amd.fused import FusedLinearTrainer
     from idelucs_amd.LossFunctions import IID_loss, info_nce_loss
-    store, net = _cfg2_store_and_net(dev, 2000)
+    store, net = _cfg2_store_and_net(dev, 2000, C=C)
     ref_net = copy.deepcopy(net)
     tr = FusedLinearTrainer(net, lr=1e-3, weight=0.25, lamb=2.8, seed=5)
-    assert tr._early_gather and tr._early_split and tr._transposed_l1 and tr._dw2_inlaunch and tr._mid_fused and tr._dw3_partial \
-        and tr._joint_inlaunch and not tr._nce_bwd_fused and not tr._wgrad_fused, "not the default launch sequence"
+    if C == 20:
+        assert tr._early_gather and tr._early_split and tr._transposed_l1 and tr._dw2_inlaunch and tr._mid_fused and tr._dw3_partial \
+            and tr._joint_inlaunch and not tr._nce_bwd_fused and not tr._wgrad_fused, "not the default launch sequence"
+    else:
+        assert tr._early_fwd and not tr._early_gather and tr._dw2_inlaunch and tr._mid_fused and not tr._dw3_partial
     B = 512
     gen = torch.Generator(device=dev); gen.manual_seed(9)
     tr._perm = torch.randperm(store.n_pairs, device=dev, generator=gen)
@@ -376,14 +383,17 @@ def test_default_fused_step_at_cfg2_shape_vs_autograd(dev):
     assert torch.equal(bf.xs[1], want_next)
 
 
-def test_graph_replay_equals_eager_at_cfg2_shape(dev):
-    """A whole epoch at cfg2's step shape (F=4096, batch 512, C=20; 8 full batches + a partial one, dropout ON) replayed
-    from the captured two-step HIP graph vs launched eagerly: same permutation, same dropout stream, same start."""
+@pytest.mark.parametrize("C,n", [(20, 1500), (200, 1500), (20, 4200), (200, 4200)])
+def test_graph_replay_equals_eager_at_cfg2_shape(dev, C, n):
+    """A whole epoch at cfg2's step shape (F=4096, batch 512; n = 1500: 8 full batches + a partial one, replayed two steps per graph;
+    n = 4200: 24 full batches + a partial one, eight steps per graph; dropout ON) replayed from the captured HIP graph vs launched
+    eagerly: same permutation, same dropout stream, same start.  C = 200: the fine-grained mode's launch sequence."""
     import copy
     import torch
     from idelucs_amd.fused import FusedLinearTrainer
-    store, net0 = _cfg2_store_and_net(dev, 1500, seed=4)
+    store, net0 = _cfg2_store_and_net(dev, n, seed=4, C=C)
     B = 512
+    nb_want = (store.n_pairs + B - 1) // B
     results = []
     for use_graph in (False, True):
         net = copy.deepcopy(net0)
@@ -391,9 +401,10 @@ def test_graph_replay_equals_eager_at_cfg2_shape(dev):
         gen = torch.Generator(device=dev); gen.manual_seed(77)
         total, nb = tr.run_epoch(store, B, use_graph=use_graph, generator=gen)
         torch.cuda.synchronize()
-        assert nb == 9 and tr.ctl.tolist() == [9, store.n_pairs]
+        assert nb == nb_want and tr.ctl.tolist() == [nb_want, store.n_pairs]
         if use_graph:
             assert len(tr._graphs) == 1, "the epoch did not go through a captured graph"
+            assert next(iter(tr._graphs))[-1] == (2 if n == 1500 else 8)
         results.append(([p.detach().clone() for p in tr.params], total.item()))
     for a, b in zip(results[0][0], results[1][0]):
         assert torch.allclose(a, b, rtol=1e-5, atol=1e-7)
@@ -701,10 +712,11 @@ def test_wgrad_kernel_vs_torch(dev, m, fused):
         assert torch.equal(W, W0) and torch.equal(V, V0)
 
 
-@pytest.mark.parametrize("C", [49, 200, 256])
+@pytest.mark.parametrize("C", [49, 77, 120, 200, 256])
 def test_iic_core_large_joint_vs_torch(dev, C):
-    """idl_iic_core beyond the 48-class kernels (LDS-resident joint up to C = 200, register-resident rows up to 256): the loss and
-    d(loss)/dP0 equal torch autograd through the reference formula (LossFunctions.py:20-62 restated on the C x C joint)."""
+    """idl_iic_core beyond the 48-class kernels (joint in LDS on ceil(C/8) workgroups up to C = 200, register-resident rows up to
+    256): the loss and d(loss)/dP0 equal torch autograd through the reference formula (LossFunctions.py:20-62 restated on the
+    C x C joint); a second call on the same scratch gives the same answer (the completion counter was left at zero)."""
     import torch
     from idelucs_amd import _lib
     from idelucs_amd.fused import _p, _stream, EPS
@@ -719,12 +731,17 @@ def test_iic_core_large_joint_vs_torch(dev, C):
     pic = torch.where(pi < EPS, torch.full_like(pi, EPS), pi); pjc = torch.where(pj < EPS, torch.full_like(pj, EPS), pj)
     loss = -(Pc * (torch.log(Pc) - 2.8 * torch.log(pjc) - 2.8 * torch.log(pic))).sum()
     loss.backward()
-    buf = P0.detach().clone(); scratch = torch.empty(C * C + 2 * C, device=dev); out = torch.zeros(4, device=dev)
-    _lib.check(_lib.lib.idl_iic_core(_p(buf), C, 2.8, EPS, 0.25, _p(scratch), _p(out), _stream()))
-    torch.cuda.synchronize()
-    assert abs(out[3].item() - loss.item()) <= 1e-4 * abs(loss.item())
+    scratch = torch.zeros(C * C + 2 * C, device=dev)
     want = 0.25 * P0.grad
-    assert torch.allclose(buf, want, rtol=2e-3, atol=2e-4 * want.abs().max().item())
+    first = None
+    for _ in range(3):
+        buf = P0.detach().clone(); out = torch.zeros(4, device=dev)
+        _lib.check(_lib.lib.idl_iic_core(_p(buf), C, 2.8, EPS, 0.25, _p(scratch), _p(out), _stream()))
+        torch.cuda.synchronize()
+        assert abs(out[3].item() - loss.item()) <= 1e-4 * abs(loss.item())
+        assert torch.allclose(buf, want, rtol=2e-3, atol=2e-4 * want.abs().max().item())
+        first = buf if first is None else first
+        assert torch.equal(buf, first)
 
 
 def test_head_bwd_with_precomputed_product(dev):

@@ -20,7 +20,7 @@ G = torch.randn(gp, m, 64, device=dev); P0 = torch.randn(C, C, device=dev); P0 =
 dlg = torch.empty(m, C, device=dev); dlat = torch.empty(m, 64, device=dev); dr1 = torch.empty(m, 512, device=dev)
 p1 = torch.empty(parts, 512, device=dev); p2 = torch.empty(parts, 64, device=dev); p3 = torch.empty(parts, C, device=dev); w3p = torch.empty(parts, C, 64, device=dev)
 lse = torch.empty(m, device=dev); rows = torch.empty(m, device=dev); ws = torch.empty(max(L.idl_nce_fused_workspace(m), 4) // 4, device=dev)
-scr = torch.empty(C * C + 2 * C, device=dev); out = torch.zeros(4, device=dev)
+scr = torch.zeros(C * C + 2 * C, device=dev); out = torch.zeros(4, device=dev)
 lat = torch.randn(m, 64, device=dev)
 
 def k_mid_fwd():

@@ -106,13 +106,22 @@ class FastaFile:
         finally:
             if h is not None:
                 _L.idl_fasta_close(h)
-        raw = names.tobytes()
-        self.names = [raw[name_off[i]:name_off[i + 1]].decode() for i in range(self.n)]   # utils.py:172 .decode()
-        if check:
-            for nm in self.names:   # unicode-whitespace first characters the byte-level check cannot see
-                if len(nm) > 0 and nm[0].isspace():
-                    self.close()
-                    raise ValueError("Bad character in sequence header")
+        # names as Python strings (utils.py:172 .decode()) are built on first use: 100 000 decodes cost 12 ms, and the training
+        # path needs them only when results are written.  The checks that need decoded text run now, on the few names concerned.
+        self._names_raw, self._name_off, self._names = names, name_off, None
+        if self.n and int(names[:nb.value].max(initial=0)) >= 0x80:
+            # non-ASCII names: decode now, so that invalid UTF-8 fails here as in the reference, and apply the one header check the
+            # byte-level reader cannot do (unicode whitespace as first character)
+            if check and any(len(nm) > 0 and nm[0].isspace() for nm in self.names):
+                self.close()
+                raise ValueError("Bad character in sequence header")
+
+    @property
+    def names(self):
+        if self._names is None:
+            raw, off = self._names_raw.tobytes(), self._name_off
+            self._names = [raw[off[i]:off[i + 1]].decode() for i in range(self.n)]
+        return self._names
 
     def pack_range(self, lo, hi, codes, mask):
         """Translate + 2-bit pack records [lo, hi) into the whole-file buffers `codes` / `mask` (host uint8 tensors or arrays
@@ -469,13 +478,17 @@ class FeatureStore:
     (feats[0][p % N], feats[1 + p // N][p % N]), standardised."""
 
     def __init__(self, names, lengths, feats, mean, scale, k, reduce):
-        self.names, self.lengths = names, lengths
+        self._names, self.lengths = names, lengths           # names: a list, or a FastaFile (its names are decoded on first use)
         self.feats, self.mean, self.scale = feats, mean, scale
         self.k, self.reduce = k, reduce
         self.n_views, self.n, self.f = feats.shape
         self.n_pairs = (self.n_views - 1) * self.n
         self.inv_scale = torch.empty_like(scale)
         self.refresh()
+
+    @property
+    def names(self):
+        return self._names.names if isinstance(self._names, FastaFile) else self._names
 
     def refresh(self):
         """Recompute what is derived from `scale` IN PLACE (after col_stats(..., out=(mean, scale)) refitted the scaler into the
@@ -579,7 +592,7 @@ def build_feature_store(sequence_file, n_mimics, k=6, reduce=False, rng=None, se
         mode = _lib.MODE_CANONICAL if reduce else _lib.MODE_KMER
         feats = _vectorise(din, k, mode, _lib.INIT_ONE, _lib.OUT_FREQ_F32, len(tfs), edits, edit_off)
         mean, scale = col_stats(feats[0])
-        return FeatureStore(ff.names, ff.lengths, feats, mean, scale, k, reduce)
+        return FeatureStore(ff, ff.lengths, feats, mean, scale, k, reduce)
     ff = fasta if fasta is not None else FastaFile(sequence_file, check=True, keep_bytes=(rng == "compat"))
     mode = _lib.MODE_CANONICAL if reduce else _lib.MODE_KMER
     if rng == "compat":

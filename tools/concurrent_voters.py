@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--k", type=int, default=6)
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--n-clusters", dest="n_clusters", type=int, default=20)
+    ap.add_argument("--cu-mask", dest="cu_mask", default="", help="block | strided: one slice of the CUs per lane")
     a = ap.parse_args()
     from idelucs_amd import models, utils as U
     dev = torch.device("cuda:0")
@@ -41,7 +42,29 @@ def main():
         return m
 
     ms = [make(v) for v in range(a.voters)]
-    streams = [torch.cuda.Stream() for _ in ms]
+    if a.cu_mask:
+        # each lane on its own slice of the CUs (hipExtStreamCreateWithCUMask): the GEMMs of the lanes then run side by side instead
+        # of each one taking every CU in turn
+        import ctypes
+        hip = ctypes.CDLL("libamdhip64.so")
+        n_cu = torch.cuda.get_device_properties(0).multi_processor_count
+        words = (n_cu + 31) // 32
+        streams = []
+        for i in range(len(ms)):
+            bits = 0
+            if a.cu_mask == "block":
+                for cu in range(i * n_cu // len(ms), (i + 1) * n_cu // len(ms)):
+                    bits |= 1 << cu
+            else:                                       # strided: CU j belongs to lane j mod L
+                for cu in range(i, n_cu, len(ms)):
+                    bits |= 1 << cu
+            mask = (ctypes.c_uint32 * words)(*[(bits >> (32 * w)) & 0xFFFFFFFF for w in range(words)])
+            h = ctypes.c_void_p()
+            rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(h), words, mask)
+            assert rc == 0, rc
+            streams.append(torch.cuda.ExternalStream(h.value))
+    else:
+        streams = [torch.cuda.Stream() for _ in ms]
     for m in ms:                                   # capture every voter's graph
         m.contrastive_training_epoch(sync=False)
     torch.cuda.synchronize()

@@ -97,13 +97,20 @@ class HotPath:
         expect = sum(din.n * (args.len * (1.0 - (1.0 - s[0]) * (1.0 - s[1])) + s[2]) for s in self.specs)
         self.edit_capacity = int(1.25 * expect + 64 * din.n * self.P + 1024)
         self.edit_overflow = torch.zeros((), dtype=torch.bool, device=dev)
-        self.ev = {k: [] for k in ("edits", "vectorise", "stats", "epoch", "predict", "exchange")}
+        self.ev = {k: [] for k in ("edits", "vectorise", "stats", "epoch", "predict_inputs", "predict", "exchange")}
         self.my_voters = D.voters_of_rank(args.voters, rank, world)
-        # several voters of one rank train side by side, each on its own stream with its own network, buffers and captured
-        # graph (idelucs_amd.training.train_voters does the same for the CLI)
-        from idelucs_amd.training import voter_lanes
-        self.lanes = [self.model] + [self.model.lane() for _ in range(voter_lanes(len(self.my_voters)) - 1)]
-        self.streams = [torch.cuda.Stream(device=dev) for _ in self.lanes]
+        # several voters of one rank train in lockstep as one batch (idelucs_amd.training.train_voters does the same for the CLI):
+        # one launch sequence for all of them, each on its own network / permutation / dropout stream / optimizer state
+        from idelucs_amd.training import voter_lanes, can_batch
+        from idelucs_amd.fused import BatchedLinearTrainer
+        L = voter_lanes(len(self.my_voters)) if can_batch(self.model) else 1
+        self.lanes = [self.model]
+        self.batched = None
+        if L > 1:
+            self.lanes = [self.model.lane() for _ in range(L)]
+            self.batched = BatchedLinearTrainer([lm.net for lm in self.lanes], 1e-3, 0.25, 2.8, seed=self.model.seed)
+            for lm, t in zip(self.lanes, self.batched.trainers):
+                lm._fused = t
         self.last_model = self.model
         self.losses = []            # device scalars, one per voter-epoch (checked after the timed loop)
         self.gathered = None
@@ -135,30 +142,37 @@ class HotPath:
         preds = {}
         with_predict = a.exchange and a.workload != "cfg5"
         if len(self.lanes) == 1:
+            # the predict inputs are a function of the input alone: once per job, not once per voter (IID_model._predict_inputs)
+            x = self._timed("predict_inputs", self._predict_inputs) if with_predict else None
             for v in self.my_voters:
                 m.begin_voter(v)                                   # fresh Kaiming init + this voter's RNG streams + optimizer state
                 self.losses.append(self._timed("epoch", lambda: m.contrastive_training_epoch(sync=False)))
                 if with_predict:
-                    preds[v] = self._timed("predict", lambda: self.predict(m, self._predict_inputs()))
+                    preds[v] = self._timed("predict", lambda: self.predict(m, x))
         else:
-            cur = torch.cuda.current_stream()
-            t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            t0.record()
-            x = self._predict_inputs() if with_predict else None   # a function of the input alone: once per job, not once per voter
+            # (the predict inputs are a function of the input alone: once per job, not once per voter)
+            x = self._timed("predict_inputs", self._predict_inputs) if with_predict else None
             L = len(self.lanes)
             for w in range(0, len(self.my_voters), L):
-                for lm, s, v in zip(self.lanes, self.streams, self.my_voters[w:w + L]):
-                    s.wait_stream(cur)
-                    with torch.cuda.stream(s):
-                        lm.begin_voter(v)
-                        self.losses.append(lm.contrastive_training_epoch(sync=False))
+                wave = self.my_voters[w:w + L]
+                if len(wave) < L:                                   # a short last batch: one voter after the other
+                    for v in wave:
+                        m.begin_voter(v)
+                        self.losses.append(self._timed("epoch", lambda: m.contrastive_training_epoch(sync=False)))
                         if with_predict:
-                            preds[v] = self.predict(lm, x)
+                            preds[v] = self._timed("predict", lambda: self.predict(m, x))
+                        self.last_model = m
+                    continue
+                for lm, v in zip(self.lanes, wave):
+                    lm.begin_voter(v)
+                    lm.net.train()
+                res = self._timed("epoch", lambda: self.batched.run_epoch(self.store, a.batch_sz, [lm._gen for lm in self.lanes]))
+                self.epochs_timed_as_batches = True
+                for lm, v, (total, nb) in zip(self.lanes, wave, res):
+                    self.losses.append(total / (nb - 1))
+                    if with_predict:
+                        preds[v] = self._timed("predict", lambda: self.predict(lm, x))
                     self.last_model = lm
-                for s in self.streams:
-                    cur.wait_stream(s)
-            t1.record()
-            self.ev["epoch"].append((t0, t1))
         if with_predict:                                           # the path's one exchange step: [V, N] int32 assignments
             self.gathered = self._timed("exchange", lambda: self.D.gather_voter_predictions(preds, a.voters, self.din.n, device=self.dev))
         elif a.exchange:                                           # cfg5: last voter's model everywhere, predict sharded by sequence
@@ -201,13 +215,16 @@ class HotPath:
         return D.all_gather_rows(torch.cat(lats) if lats else torch.empty((0, 64), device=self.dev), self.din.n)
 
     def mean_ms(self, key, skip_steps):
-        """Mean duration of one stage; "epoch" is per voter-epoch (with lanes: the side-by-side region, predicts included,
-        divided by the voters it trained)."""
+        """Mean duration of one stage; "epoch" is per voter-epoch (voters batched: the batch's epoch divided by its voters)."""
         nv = len(self.my_voters)
-        per_step = {"epoch": nv if len(self.lanes) == 1 else 1, "predict": nv}.get(key, 1)
-        ev = self.ev[key][skip_steps * per_step:]
-        t = sum(s.elapsed_time(e) for s, e in ev) / max(len(ev), 1)
-        return t / nv if key == "epoch" and len(self.lanes) > 1 else t
+        ev = self.ev[key]
+        if key in ("epoch", "predict"):
+            per_step = len(ev) // max(len(self.ev["vectorise"]), 1)
+            ev = ev[skip_steps * per_step:]
+            t = sum(s.elapsed_time(e) for s, e in ev) / max(len(ev), 1)
+            return t * per_step / nv if key == "epoch" else t
+        ev = ev[skip_steps:]
+        return sum(s.elapsed_time(e) for s, e in ev) / max(len(ev), 1)
 
     def validate(self):
         """Untimed checks of what the last timed step produced (the bench validated nothing it timed)."""
@@ -469,7 +486,7 @@ def main():
                                    f"{V} voter(s) over {world} GPU(s), value = N_seq * voters / wall; timed = {region}",
                        "n_sequences": args.n, "seq_len": args.len, "k": args.k, "batch_sz": args.batch_sz, "n_voters": V,
                        "optimizer_steps_per_epoch": (args.n * args.n_mimics + args.batch_sz - 1) // args.batch_sz,
-                       "parallelism": f"{V} voters / {world} ranks" + (f", {len(hp.lanes)} side by side per rank" if len(hp.lanes) > 1 else "")},
+                       "parallelism": f"{V} voters / {world} ranks" + (f", batches of {len(hp.lanes)} voters in lockstep" if len(hp.lanes) > 1 else "")},
             "roofline": {"kernel": "vectorise kernel (hand-written HIP: one count + per-view window deltas + normalise, all views)",
                          "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                          "traffic": pmc_traffic_gb() if not cfg5 else None, "ms_per_launch": t_vec, "bytes_per_seq_algorithmic": b_vec,

@@ -16,6 +16,8 @@
 // when its four k-steps are taken as j = 4q + reg -- no cross-lane movement, no LDS round trip.  The k order
 // of both products is permuted the same way on the A and the B side (lane q owns k = 16q..16q+15 of the first
 // product), which MFMA permits because it only sums over k.
+#include <string.h>
+
 #include "common.h"
 #include "iic_device.h"
 #include "nce_device.h"
@@ -75,7 +77,7 @@ __device__ __forceinline__ void iic_joint_tiles(const float *z, int m, int C, fl
 }
 
 // pass 1: partial row sums [NCE_SPLIT][m] and the positive logits pos[m]
-__global__ __launch_bounds__(256) void nce_pass1_kernel(const float *f, int m, float inv_t, float *rowsum_part, float *pos, IicJob iic)
+__device__ __forceinline__ void nce_pass1_body(const float *f, int m, float inv_t, float *rowsum_part, float *pos, const IicJob &iic)
 {
     if ((int)blockIdx.x == m / 16) {
         if (iic.z != nullptr) iic_joint_tiles(iic.z, m, iic.C, iic.P0, (int)blockIdx.y, NCE_SPLIT);     // core: pass 2
@@ -115,8 +117,8 @@ __global__ __launch_bounds__(256) void nce_pass1_kernel(const float *f, int m, f
 }
 
 // pass 2: lse / loss rows, and the partial products G_part[NCE_SPLIT][m][64]
-__global__ __launch_bounds__(256) void nce_pass2_kernel(const float *f, int m, float inv_t, const float *rowsum_part, const float *pos,
-                                                        float *lse, float *loss_rows, float *G_part, IicJob iic)
+__device__ __forceinline__ void nce_pass2_body(const float *f, int m, float inv_t, const float *rowsum_part, const float *pos,
+                                               float *lse, float *loss_rows, float *G_part, const IicJob &iic)
 {
     if ((int)blockIdx.x == m / 16) {         // spare column (only launched when the joint was formed in pass 1): the IIC core
         if (blockIdx.y == 0) iic_core_small(iic.P0, iic.C, iic.lamb, iic.eps, iic.w_iic, iic.out);
@@ -204,6 +206,33 @@ __global__ __launch_bounds__(256) void nce_pass2_kernel(const float *f, int m, f
     }
 }
 
+__global__ __launch_bounds__(256) void nce_pass1_kernel(const float *f, int m, float inv_t, float *rowsum_part, float *pos, IicJob iic)
+{
+    nce_pass1_body(f, m, inv_t, rowsum_part, pos, iic);
+}
+
+__global__ __launch_bounds__(256) void nce_pass2_kernel(const float *f, int m, float inv_t, const float *rowsum_part, const float *pos,
+                                                        float *lse, float *loss_rows, float *G_part, IicJob iic)
+{
+    nce_pass2_body(f, m, inv_t, rowsum_part, pos, lse, loss_rows, G_part, iic);
+}
+
+// several voters in one launch: voter blockIdx.z takes its arguments from its plan record (common.h)
+struct NceParams { const float *f; int m; float inv_t; float *rowsum_part, *pos, *lse, *loss_rows, *G_part; IicJob iic; };
+static_assert(sizeof(NceParams) + idl::PLAN_PARAMS <= idl::PLAN_BYTES, "NceParams does not fit a plan record");
+
+__global__ __launch_bounds__(256) void nce_pass1_batched_kernel(const unsigned char *__restrict__ plans)
+{
+    const NceParams &p = *(const NceParams *)(plans + (size_t)blockIdx.z * idl::PLAN_BYTES + idl::PLAN_PARAMS);
+    nce_pass1_body(p.f, p.m, p.inv_t, p.rowsum_part, p.pos, p.iic);
+}
+
+__global__ __launch_bounds__(256) void nce_pass2_batched_kernel(const unsigned char *__restrict__ plans)
+{
+    const NceParams &p = *(const NceParams *)(plans + (size_t)blockIdx.z * idl::PLAN_BYTES + idl::PLAN_PARAMS);
+    nce_pass2_body(p.f, p.m, p.inv_t, p.rowsum_part, p.pos, p.lse, p.loss_rows, p.G_part, p.iic);
+}
+
 }  // namespace
 
 extern "C" {
@@ -226,6 +255,16 @@ static int nce_launch(const float *f, int m, float temperature, float *lse, floa
     const float inv_t = 1.f / temperature;
     const dim3 grid((unsigned)(m / 16), NCE_SPLIT);
     const dim3 grid1((unsigned)(m / 16 + (iic.P0 != nullptr ? 1 : 0)), NCE_SPLIT);
+    if (void *plan = idl::take_plan()) {          // recorded, not launched (idl_plan_begin): both passes in one record
+        const dim3 g2 = iic.z != nullptr ? grid1 : grid;
+        idl::PlanHead h{};
+        h.kind = idl::PLAN_NCE; h.grid[0] = grid1.x; h.grid[1] = grid1.y; h.grid[2] = 1; h.block = 256;
+        h.grid2[0] = g2.x; h.grid2[1] = g2.y; h.grid2[2] = 1;
+        memcpy(plan, &h, sizeof(h));
+        const NceParams p{f, m, inv_t, rowsum_part, pos, lse, loss_rows, G_part, iic};
+        memcpy((unsigned char *)plan + idl::PLAN_PARAMS, &p, sizeof(p));
+        return IDL_OK;
+    }
     hipLaunchKernelGGL(nce_pass1_kernel, grid1, dim3(256), 0, (hipStream_t)stream, f, m, inv_t, rowsum_part, pos, iic);
     hipLaunchKernelGGL(nce_pass2_kernel, iic.z != nullptr ? grid1 : grid, dim3(256), 0, (hipStream_t)stream, f, m, inv_t,
                        (const float *)rowsum_part, (const float *)pos, lse, loss_rows, G_part, iic);
@@ -267,3 +306,12 @@ int idl_nce_fused_iic_z(const float *f, int m, float temperature, float *lse, fl
 }
 
 }  // extern "C"
+
+int idl::nce_plan_launch(const idl::PlanHead &h, const void *dev_plans, int n_voters, hipStream_t stream)
+{
+    const unsigned char *dp = (const unsigned char *)dev_plans;
+    hipLaunchKernelGGL(nce_pass1_batched_kernel, dim3(h.grid[0], h.grid[1], (unsigned)n_voters), dim3(h.block), 0, stream, dp);
+    hipLaunchKernelGGL(nce_pass2_batched_kernel, dim3(h.grid2[0], h.grid2[1], (unsigned)n_voters), dim3(h.block), 0, stream, dp);
+    IDL_HIP_TRY(hipGetLastError());
+    return IDL_OK;
+}

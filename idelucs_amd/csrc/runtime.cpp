@@ -58,11 +58,43 @@ int device_info(DeviceInfo *out)
     return IDL_OK;
 }
 
+namespace {
+thread_local void *g_plan = nullptr;
+thread_local bool g_plan_filled = false;
+}
+void *take_plan()
+{
+    void *p = g_plan;
+    g_plan = nullptr;
+    if (p) g_plan_filled = true;
+    return p;
+}
+
 }  // namespace idl
 
 extern "C" {
 
 const char *idl_last_error(void) { return idl::get_error(); }
+
+int64_t idl_plan_bytes(void) { return idl::PLAN_BYTES; }
+
+int idl_plan_begin(void *host_plan)
+{
+    IDL_REQUIRE(host_plan, "plan_begin: NULL record");
+    memset(host_plan, 0, idl::PLAN_BYTES);
+    idl::g_plan = host_plan;
+    idl::g_plan_filled = false;
+    return IDL_OK;
+}
+
+int idl_plan_end(void)
+{
+    const bool pending = idl::g_plan != nullptr, filled = idl::g_plan_filled;
+    idl::g_plan = nullptr;
+    idl::g_plan_filled = false;
+    IDL_REQUIRE(!pending && filled, "plan_end: the call after idl_plan_begin was not a launcher that can be recorded (or failed)");
+    return IDL_OK;
+}
 
 int idl_abi_version(void) { return 1; }
 

@@ -19,6 +19,8 @@
 // needs.  `ctl` is a small device-resident control block so that graph replays advance without
 // host involvement:  ctl[0] = optimizer-step counter, ctl[1] = offset of the next batch in the
 // shuffled pair list.
+#include <string.h>
+
 #include "common.h"
 #include "iic_device.h"
 #include "nce_device.h"
@@ -142,15 +144,15 @@ constexpr int MID_WAVES = 16;
 constexpr int MID_GATHER_ROWS = 4;   // rows per 256-thread gather tile when the batch assembly rides in mid_fwd / mid_bwd
 
 template <bool TIN>       // TIN: a1 is stored transposed, [512, m] (the orientation hipBLASLt runs the layer-1 product fastest in)
-__global__ __launch_bounds__(64 * MID_WAVES) void mid_fwd_kernel(float *__restrict__ a1, const float *__restrict__ b1, const float *__restrict__ W2,
+__device__ __forceinline__ void mid_fwd_body(float *__restrict__ a1, const float *__restrict__ b1, const float *__restrict__ W2,
                                                                   const float *__restrict__ b2, const float *__restrict__ W3,
                                                                   const float *__restrict__ b3, int m, int C, int train, uint64_t seed,
                                                                   const int64_t *__restrict__ ctl, float *__restrict__ f,
                                                                   float *__restrict__ inv, float *__restrict__ r2, float *__restrict__ z,
-                                                                  int n_rows_wg, int tile0, int tile1, idl_dev::GatherArgs gth)
+                                                                  int n_rows_wg, int tile0, int tile1, const idl_dev::GatherArgs &gth, const int bid)
 {
-    if ((int)blockIdx.x >= n_rows_wg) {          // spare workgroups: tiles [tile0, tile1) of the next batch (see mid_bwd_kernel)
-        const int blk = tile0 + ((int)blockIdx.x - n_rows_wg) * 4 + (int)(threadIdx.x >> 8);
+    if (bid >= n_rows_wg) {          // spare workgroups: tiles [tile0, tile1) of the next batch (see mid_bwd_kernel)
+        const int blk = tile0 + (bid - n_rows_wg) * 4 + (int)(threadIdx.x >> 8);
         if (blk < tile1) idl_dev::gather_tile<MID_GATHER_ROWS>(gth, (int64_t)blk, (int)(threadIdx.x & 255));
         return;
     }
@@ -160,7 +162,7 @@ __global__ __launch_bounds__(64 * MID_WAVES) void mid_fwd_kernel(float *__restri
     float (*R2t)[H2 + 4] = (float (*)[H2 + 4])&part[0][0][0];               // [16][68]
     float (*LG)[64 * MAX_CPL + 1] = (float (*)[64 * MAX_CPL + 1])&part[2][0][0];   // [16][257]
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, l = lane & 15, q = lane >> 4;
-    const int r0 = blockIdx.x * 16;
+    const int r0 = bid * 16;
     const int k0 = 32 * wv + 8 * q;              // this lane's 8 consecutive k of row r0 + l
     // ---- every global read of the kernel is issued here, before the first dependent instruction
     float4 *src = (float4 *)(a1 + (int64_t)(r0 + l) * H1 + k0);
@@ -289,6 +291,34 @@ __global__ __launch_bounds__(64 * MID_WAVES) void mid_fwd_kernel(float *__restri
             if (c < C) z[(int64_t)row * C + c] = lg[t] / den;
         }
     }
+}
+struct MidFwdParams {
+    float *a1; const float *b1, *W2, *b2, *W3, *b3; int m, C, train; uint64_t seed; const int64_t *ctl; float *f, *inv, *r2, *z;
+    int n_rows_wg, tile0, tile1; idl_dev::GatherArgs gth;
+};
+static_assert(sizeof(MidFwdParams) + idl::PLAN_PARAMS <= idl::PLAN_BYTES, "MidFwdParams does not fit a plan record");
+
+template <bool TIN>
+__global__ __launch_bounds__(64 * MID_WAVES) void mid_fwd_kernel(float *__restrict__ a1, const float *__restrict__ b1, const float *__restrict__ W2,
+                                                                  const float *__restrict__ b2, const float *__restrict__ W3,
+                                                                  const float *__restrict__ b3, int m, int C, int train, uint64_t seed,
+                                                                  const int64_t *__restrict__ ctl, float *__restrict__ f,
+                                                                  float *__restrict__ inv, float *__restrict__ r2, float *__restrict__ z,
+                                                                  int n_rows_wg, int tile0, int tile1, idl_dev::GatherArgs gth)
+{
+    mid_fwd_body<TIN>(a1, b1, W2, b2, W3, b3, m, C, train, seed, ctl, f, inv, r2, z, n_rows_wg, tile0, tile1, gth, (int)blockIdx.x);
+}
+
+// the same for several voters in one launch: the grid is (voters, workgroups of one voter) -- the VOTER index runs fastest, so the
+// computing workgroups of every voter are dispatched before anybody's batch-assembly workgroups (a workgroup of this kernel fills a
+// CU: voter by voter, the second half of the voters would wait behind the first half's streaming workgroups); each voter takes its
+// arguments from its plan record (common.h)
+template <bool TIN>
+__global__ __launch_bounds__(64 * MID_WAVES) void mid_fwd_batched_kernel(const unsigned char *__restrict__ plans)
+{
+    const MidFwdParams &p = *(const MidFwdParams *)(plans + (size_t)blockIdx.x * idl::PLAN_BYTES + idl::PLAN_PARAMS);
+    mid_fwd_body<TIN>(p.a1, p.b1, p.W2, p.b2, p.W3, p.b3, p.m, p.C, p.train, p.seed, p.ctl, p.f, p.inv, p.r2, p.z, p.n_rows_wg, p.tile0, p.tile1, p.gth,
+                      (int)blockIdx.y);
 }
 
 // ---------------------------------------------------------------- InfoNCE on S = f f^T (un-scaled)
@@ -527,11 +557,11 @@ struct MidBwdArgs {
 // boundary and the G / dP0 round trips disappear.
 template <bool NCE, bool BIG = false>      // BIG: n_clusters > 48 (the per-row products then walk dP0 / W3 in memory); a separate instance, so that its
                                           // registers do not count against the n_clusters <= 48 one the training step runs
-__global__ __launch_bounds__(64 * MID_WAVES) void mid_bwd_kernel(MidBwdArgs a, int tile0, int tile1, idl_dev::GatherArgs gth)
+__device__ __forceinline__ void mid_bwd_body(const MidBwdArgs &a, int tile0, int tile1, const idl_dev::GatherArgs &gth, const int bid)
 {
     extern __shared__ float mid_dyn[];        // NCE: Gred[16 waves][16][64] | lse_all[m] | Ps[48 * 48]
-    if ((int)blockIdx.x >= COL_PARTS) {
-        const int blk = tile0 + ((int)blockIdx.x - COL_PARTS) * 4 + (int)(threadIdx.x >> 8);
+    if (bid >= COL_PARTS) {
+        const int blk = tile0 + (bid - COL_PARTS) * 4 + (int)(threadIdx.x >> 8);
         if (blk < tile1) idl_dev::gather_tile<MID_GATHER_ROWS>(gth, (int64_t)blk, (int)(threadIdx.x & 255));
         return;
     }
@@ -544,9 +574,9 @@ __global__ __launch_bounds__(64 * MID_WAVES) void mid_bwd_kernel(MidBwdArgs a, i
     const int m = a.m, C = a.C, B = m / 2;
     constexpr bool small = !BIG;
     const int rows = (m + COL_PARTS - 1) / COL_PARTS;
-    const int r0 = blockIdx.x * rows;
+    const int r0 = bid * rows;
     const int r1 = (r0 + rows < m) ? r0 + rows : m;
-    if (a.ctl != nullptr && blockIdx.x == 0 && tid == 0) a.ctl[1] += a.batch_advance;
+    if (a.ctl != nullptr && bid == 0 && tid == 0) a.ctl[1] += a.batch_advance;
     if (small) {
         if (!NCE) for (int i = tid; i < C * C; i += 64 * MID_WAVES) sP[i] = a.dP0[i];
         for (int i = tid; i < C * H2; i += 64 * MID_WAVES) sW3[i] = a.W3[i];
@@ -572,7 +602,7 @@ __global__ __launch_bounds__(64 * MID_WAVES) void mid_bwd_kernel(MidBwdArgs a, i
             for (int p = 0; p < a.nce_split; ++p) sm += a.rowsum_part[(int64_t)p * m + i];
             lse_all[i] = __logf(sm);
         }
-        iic_core_to_lds<64 * MID_WAVES>(a.P0joint, C, a.lamb, a.eps, a.w_iic, blockIdx.x == 0 ? a.out : nullptr, sP, Ps);   // ends with a barrier
+        iic_core_to_lds<64 * MID_WAVES>(a.P0joint, C, a.lamb, a.eps, a.w_iic, bid == 0 ? a.out : nullptr, sP, Ps);   // ends with a barrier
         const int r = r0 + l;
         const float lse_r = lse_all[r];
         if (wv == 0 && q == 0) { a.lse[r] = lse_r; a.loss_rows[r] = lse_r - a.pos[r]; }
@@ -770,17 +800,33 @@ __global__ __launch_bounds__(64 * MID_WAVES) void mid_bwd_kernel(MidBwdArgs a, i
     for (int j = 0; j < 2; ++j) {
         float v = cs1[j];
         v = idl_dev::add_xor32(idl_dev::add_xor16(v));
-        if (q == 0) a.partial1[(int64_t)blockIdx.x * H1 + 32 * wv + 2 * l + j] = v;
+        if (q == 0) a.partial1[(int64_t)bid * H1 + 32 * wv + 2 * l + j] = v;
     }
-    if (tid < H2) a.partial2[(int64_t)blockIdx.x * H2 + tid] = s23;
-    else if (tid < H2 + C) a.partial3[(int64_t)blockIdx.x * C + tid - H2] = s23;
+    if (tid < H2) a.partial2[(int64_t)bid * H2 + tid] = s23;
+    else if (tid < H2 + C) a.partial3[(int64_t)bid * C + tid - H2] = s23;
     if (a.dW3_part != nullptr) {
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const int o = tid + 1024 * i;
-            if (o < C * H2) a.dW3_part[(int64_t)blockIdx.x * C * H2 + o] = acc3[i];
+            if (o < C * H2) a.dW3_part[(int64_t)bid * C * H2 + o] = acc3[i];
         }
     }
+}
+struct MidBwdParams { MidBwdArgs a; int tile0, tile1; idl_dev::GatherArgs gth; };
+static_assert(sizeof(MidBwdParams) + idl::PLAN_PARAMS <= idl::PLAN_BYTES, "MidBwdParams does not fit a plan record");
+
+template <bool NCE, bool BIG = false>
+__global__ __launch_bounds__(64 * MID_WAVES) void mid_bwd_kernel(MidBwdArgs a, int tile0, int tile1, idl_dev::GatherArgs gth)
+{
+    mid_bwd_body<NCE, BIG>(a, tile0, tile1, gth, (int)blockIdx.x);
+}
+
+// several voters in one launch, grid (voters, workgroups of one voter) as in mid_fwd_batched_kernel (n_clusters <= 48, separate
+// InfoNCE passes)
+__global__ __launch_bounds__(64 * MID_WAVES) void mid_bwd_batched_kernel(const unsigned char *__restrict__ plans)
+{
+    const MidBwdParams &p = *(const MidBwdParams *)(plans + (size_t)blockIdx.x * idl::PLAN_BYTES + idl::PLAN_PARAMS);
+    mid_bwd_body<false, false>(p.a, p.tile0, p.tile1, p.gth, (int)blockIdx.y);
 }
 
 // ---------------------------------------------------------------- RMSprop over all parameter tensors
@@ -873,8 +919,8 @@ __device__ __forceinline__ void wgrad_tile_rms(const RmsArgs &a, int tile, float
 // behind them hide.  The following gx * count blocks are optimizer blocks (tensor = block / gx).
 constexpr int RMS_UNROLL = 4;         // 16-byte elements per thread of the streaming update
 
-__global__ __launch_bounds__(256) void rmsprop_kernel(RmsArgs a, const float *hyper, int64_t *ctl, int64_t batch_advance, int gx,
-                                                      int n_gather, idl_dev::GatherArgs g)
+__device__ __forceinline__ void rmsprop_body(const RmsArgs &a, const float *hyper, int64_t *ctl, int64_t batch_advance, int gx,
+                                             int n_gather, const idl_dev::GatherArgs &g)
 {
     // grid order: weight-gradient tiles (dependent chains of strided loads: first, so that the streaming blocks behind them hide
     // their latency), then the gather blocks, then the optimizer blocks
@@ -952,6 +998,22 @@ __global__ __launch_bounds__(256) void rmsprop_kernel(RmsArgs a, const float *hy
     }
 }
 
+struct RmsParams { RmsArgs a; const float *hyper; int64_t *ctl; int64_t batch_advance; int n_gather; idl_dev::GatherArgs g; };
+static_assert(sizeof(RmsParams) + idl::PLAN_PARAMS <= idl::PLAN_BYTES, "RmsParams does not fit a plan record");
+
+__global__ __launch_bounds__(256) void rmsprop_kernel(RmsArgs a, const float *hyper, int64_t *ctl, int64_t batch_advance, int gx,
+                                                      int n_gather, idl_dev::GatherArgs g)
+{
+    rmsprop_body(a, hyper, ctl, batch_advance, gx, n_gather, g);
+}
+
+// several voters in one launch: voter blockIdx.y takes its arguments from its plan record
+__global__ __launch_bounds__(256) void rmsprop_batched_kernel(const unsigned char *__restrict__ plans)
+{
+    const RmsParams &p = *(const RmsParams *)(plans + (size_t)blockIdx.y * idl::PLAN_BYTES + idl::PLAN_PARAMS);
+    rmsprop_body(p.a, p.hyper, p.ctl, p.batch_advance, 0, p.n_gather, p.g);
+}
+
 }  // namespace
 
 extern "C" {
@@ -1012,6 +1074,14 @@ int idl_mid_fwd_gather(float *a1, const float *b1, int a1_transposed, const floa
         t0 = ng * part / parts; t1 = ng * part_end / parts;
     }
     const dim3 grid((unsigned)(m / 16 + (t1 - t0 + 3) / 4));
+    if (void *plan = idl::take_plan()) {          // recorded, not launched (idl_plan_begin)
+        idl::PlanHead h{};
+        h.kind = idl::PLAN_MID_FWD; h.variant = a1_transposed ? 1 : 0; h.grid[0] = grid.x; h.grid[1] = 1; h.grid[2] = 1; h.block = 64 * MID_WAVES;
+        memcpy(plan, &h, sizeof(h));
+        const MidFwdParams p{a1, b1, W2, b2, W3, b3, m, C, train, seed, ctl, f, inv, r2, z, m / 16, (int)t0, (int)t1, g};
+        memcpy((unsigned char *)plan + idl::PLAN_PARAMS, &p, sizeof(p));
+        return IDL_OK;
+    }
     if (a1_transposed) hipLaunchKernelGGL(mid_fwd_kernel<true>, grid, dim3(64 * MID_WAVES), 0, (hipStream_t)stream, a1, b1, W2, b2, W3, b3,
                                           m, C, train, seed, ctl, f, inv, r2, z, m / 16, (int)t0, (int)t1, g);
     else hipLaunchKernelGGL(mid_fwd_kernel<false>, grid, dim3(64 * MID_WAVES), 0, (hipStream_t)stream, a1, b1, W2, b2, W3, b3,
@@ -1173,6 +1243,15 @@ int idl_mid_bwd_gather(const float *z, const float *r2, const float *f, const fl
         const int64_t ng = idl_dev::gather_tiles<MID_GATHER_ROWS>(fdim, batch);
         t0 = ng * part / parts; t1 = ng * part_end / parts;
     }
+    if (void *plan = idl::take_plan()) {          // recorded, not launched (idl_plan_begin)
+        IDL_REQUIRE(C <= 48, "mid_bwd_gather: only the n_clusters <= 48 form can be recorded");
+        idl::PlanHead h{};
+        h.kind = idl::PLAN_MID_BWD; h.grid[0] = (unsigned)(COL_PARTS + (t1 - t0 + 3) / 4); h.grid[1] = 1; h.grid[2] = 1; h.block = 64 * MID_WAVES;
+        memcpy(plan, &h, sizeof(h));
+        const MidBwdParams p{a, (int)t0, (int)t1, g};
+        memcpy((unsigned char *)plan + idl::PLAN_PARAMS, &p, sizeof(p));
+        return IDL_OK;
+    }
     if (C <= 48) hipLaunchKernelGGL((mid_bwd_kernel<false, false>), dim3((unsigned)(COL_PARTS + (t1 - t0 + 3) / 4)), dim3(64 * MID_WAVES), 0, (hipStream_t)stream, a, (int)t0,
                                     (int)t1, g);
     else hipLaunchKernelGGL((mid_bwd_kernel<false, true>), dim3((unsigned)(COL_PARTS + (t1 - t0 + 3) / 4)), dim3(64 * MID_WAVES), 0, (hipStream_t)stream, a, (int)t0,
@@ -1274,6 +1353,14 @@ static int rmsprop_launch(int count, float *const *params, const float *const *g
     if (nb_total == 0) nb_total = 1;        // (step counter / loss assembly still need a block)
     for (int i = count; i <= 8; ++i) a.first[i] = nb_total;
     const int64_t extra = g.y != nullptr ? idl_dev::gather_blocks(g.f, g.batch) : 0;
+    if (void *plan = idl::take_plan()) {          // recorded, not launched (idl_plan_begin)
+        idl::PlanHead h{};
+        h.kind = idl::PLAN_RMSPROP; h.grid[0] = (unsigned)(nb_total + extra + a.wg_tiles); h.grid[1] = 1; h.grid[2] = 1; h.block = 256;
+        memcpy(plan, &h, sizeof(h));
+        const RmsParams p{a, hyper, ctl, batch_advance, (int)extra, g};
+        memcpy((unsigned char *)plan + idl::PLAN_PARAMS, &p, sizeof(p));
+        return IDL_OK;
+    }
     hipLaunchKernelGGL(rmsprop_kernel, dim3((unsigned)(nb_total + extra + a.wg_tiles)), dim3(256), 0, (hipStream_t)stream, a, hyper, ctl,
                        batch_advance, 0, (int)extra, g);
     IDL_HIP_TRY(hipGetLastError());
@@ -1315,6 +1402,36 @@ int idl_rmsprop_step_gather_wgrad(int count, float *const *params, const float *
     }
     return rmsprop_launch(count, params, grads, grad_parts, square_avg, sizes, hyper, ctl, batch_advance, loss_rows, loss_m, w_nce, w_iic, out, g,
                           stream, wg_index, wg_dy, wg_x, wg_m, wg_n_out, wg_n_in, wg_grad, wg_x_transposed);
+}
+
+int idl_plan_launch(const void *host_plans, const void *dev_plans, int n_voters, void *stream)
+{
+    IDL_REQUIRE(host_plans && dev_plans && n_voters >= 1 && n_voters <= 65535, "plan_launch: NULL records or n_voters outside 1..65535");
+    idl::PlanHead h;
+    memcpy(&h, host_plans, sizeof(h));
+    for (int v = 1; v < n_voters; ++v)        // one launch serves every voter: their launches must have the same shape
+        IDL_REQUIRE(memcmp((const unsigned char *)host_plans + (size_t)v * idl::PLAN_BYTES, &h, sizeof(h)) == 0,
+                    "plan_launch: the voters' records differ in kind or launch shape");
+    const unsigned char *dp = (const unsigned char *)dev_plans;
+    const hipStream_t st = (hipStream_t)stream;
+    switch (h.kind) {
+    case idl::PLAN_MID_FWD:
+        if (h.variant) hipLaunchKernelGGL(mid_fwd_batched_kernel<true>, dim3((unsigned)n_voters, h.grid[0]), dim3(h.block), 0, st, dp);
+        else hipLaunchKernelGGL(mid_fwd_batched_kernel<false>, dim3((unsigned)n_voters, h.grid[0]), dim3(h.block), 0, st, dp);
+        break;
+    case idl::PLAN_MID_BWD:
+        hipLaunchKernelGGL(mid_bwd_batched_kernel, dim3((unsigned)n_voters, h.grid[0]), dim3(h.block), 0, st, dp);
+        break;
+    case idl::PLAN_RMSPROP:
+        hipLaunchKernelGGL(rmsprop_batched_kernel, dim3(h.grid[0], (unsigned)n_voters), dim3(h.block), 0, st, dp);
+        break;
+    case idl::PLAN_NCE:
+        return idl::nce_plan_launch(h, dev_plans, n_voters, st);
+    default:
+        IDL_REQUIRE(false, "plan_launch: not a recorded launch");
+    }
+    IDL_HIP_TRY(hipGetLastError());
+    return IDL_OK;
 }
 
 }  // extern "C"

@@ -12,8 +12,12 @@ device-resident offset that the optimizer kernel advances, the next batch while 
 (two x buffers), so an epoch is n_batches / 2 replays of one captured two-step graph with no host work between.
 
 The parameters remain the nn.Parameters of model.net (state_dict / predict / weights_init unchanged).
-RMSprop state lives here and, like the reference's single optimizer object (models.py:87-88 +
-__main__.py:109), persists across voters.
+RMSprop state lives here; begin_voter() clears it (every voter is an independent run, models.IID_model.begin_voter).
+
+BatchedLinearTrainer steps several voters of one ensemble in lockstep: the two big products become batched GEMMs and each of
+the five kernels becomes ONE launch with the voter index in its grid (recorded launches, idl_plan_*), so the latency-bound
+launches -- 51 of the 116 us of a step, mostly launch boundaries and dependent-load chains on a quarter of the CUs -- are paid
+once per step of the whole batch of voters instead of once per voter.
 """
 import ctypes
 import os
@@ -39,12 +43,15 @@ def _stream():
 class _Buffers:
     """Activations / gradients of one batch shape (m = 2*B rows)."""
 
-    def __init__(self, m, F, H1, H2, C, dev):
+    def __init__(self, m, F, H1, H2, C, dev, shared=None):
+        """shared: {'xs0', 'xs1', 'r1', 'dr1'} = this voter's slices of a BatchedLinearTrainer's stacked GEMM operands."""
         f32 = dict(dtype=torch.float32, device=dev)
+        sh = shared or {}
         self.m = m
-        self.xs = [torch.empty((m, F), **f32), torch.empty((m, F), **f32)]   # the batch of this step / the next one being assembled
+        # the batch of this step / the next one being assembled
+        self.xs = [sh['xs0'] if 'xs0' in sh else torch.empty((m, F), **f32), sh['xs1'] if 'xs1' in sh else torch.empty((m, F), **f32)]
         self.x = self.xs[0]
-        self.r1 = torch.empty((m, H1), **f32)        # Linear1 output, then ReLU+Dropout in place
+        self.r1 = sh['r1'] if 'r1' in sh else torch.empty((m, H1), **f32)        # Linear1 output, then ReLU+Dropout in place
         self.r1T = self.r1.view(H1, m)                # the same memory as the transposed image [H1, m] (one of the two is in use)
         self.lat = torch.empty((m, H2), **f32)
         self.f = torch.empty((m, H2), **f32)
@@ -64,11 +71,29 @@ class _Buffers:
         self.dlogits = torch.empty((m, C), **f32)
         self.dzs = torch.empty((m, C), **f32) if C > 64 else None       # z dP0 (fine-grained mode)
         self.dlat = torch.empty((m, H2), **f32)
-        self.dr1 = torch.empty((m, H1), **f32)
+        self.dr1 = sh['dr1'] if 'dr1' in sh else torch.empty((m, H1), **f32)
+
+
+class _Recorder:
+    """step_on_batch in record mode: the big products are skipped (the batched trainer runs them as batched GEMMs) and every
+    kernel launch is recorded as a plan (idl_plan_begin / idl_plan_end) instead of being performed."""
+
+    def __init__(self):
+        self.plans = []          # uint8 host tensors [PLAN_BYTES], in launch order
+        self.mms = 0
+
+    def launch(self, fn, *args):
+        blob = torch.zeros(int(_L.idl_plan_bytes()), dtype=torch.uint8)
+        _lib.check(_L.idl_plan_begin(ctypes.c_void_p(blob.data_ptr())))
+        rc = fn(*args)
+        end = _L.idl_plan_end()
+        _lib.check(rc)
+        _lib.check(end)
+        self.plans.append(blob)
 
 
 class FusedLinearTrainer:
-    def __init__(self, net, lr, weight, lamb, weight_decay=0.01, alpha=0.99, eps=1e-8, seed=0):
+    def __init__(self, net, lr, weight, lamb, weight_decay=0.01, alpha=0.99, eps=1e-8, seed=0, grad_w1=None, shared_buffers=None):
         lin1, lin2, lin3 = net.layers[0], net.layers[3], net.classifier[2]
         self.net = net
         self.W1, self.b1, self.W2, self.b2, self.W3, self.b3 = (lin1.weight, lin1.bias, lin2.weight, lin2.bias,
@@ -86,6 +111,11 @@ class FusedLinearTrainer:
             self.parts[4] = _L.idl_col_sum_parts()
         self.grads = [torch.zeros((q,) + tuple(p.shape), dtype=p.dtype, device=p.device) if q > 1 else torch.zeros_like(p)
                       for p, q in zip(self.params, self.parts)]
+        if grad_w1 is not None:                  # this voter's slice of a BatchedLinearTrainer's stacked dW1
+            assert tuple(grad_w1.shape) == tuple(self.W1.shape) and grad_w1.is_contiguous()
+            self.grads[0] = grad_w1
+        self._shared_buffers = shared_buffers    # {m: {...}} views handed to _Buffers
+        self._rec = None                         # a _Recorder while a BatchedLinearTrainer records this voter's launches
         self.square_avg = [torch.zeros_like(p) for p in self.params]
         self.weight, self.lamb, self.seed = float(weight), float(lamb), int(seed) & (2 ** 64 - 1)
         self.hyper = torch.tensor([lr, alpha, eps, weight_decay, 1.0 - alpha], dtype=torch.float32, device=self.dev)
@@ -145,8 +175,21 @@ class FusedLinearTrainer:
 
     def buffers(self, m):
         if m not in self._bufs:
-            self._bufs[m] = _Buffers(m, self.F, self.H1, self.H2, self.C, self.dev)
+            self._bufs[m] = _Buffers(m, self.F, self.H1, self.H2, self.C, self.dev, shared=(self._shared_buffers or {}).get(m))
         return self._bufs[m]
+
+    def _k(self, fn, *args):
+        """One kernel launch of the step: performed, or recorded while a BatchedLinearTrainer is recording."""
+        if self._rec is not None:
+            self._rec.launch(fn, *args)
+        else:
+            _lib.check(fn(*args))
+
+    def _mm(self, a, b, out):
+        if self._rec is not None:
+            self._rec.mms += 1                   # the batched trainer runs the big products as batched GEMMs
+        else:
+            torch.mm(a, b, out=out)
 
     # ------------------------------------------------------------------ one step on a filled bf.x
     @torch.no_grad()
@@ -166,16 +209,16 @@ class FusedLinearTrainer:
         side = self._side if self._overlap else main
         # ---- forward
         if tl:      # a1^T = W1 x^T: the orientation hipBLASLt runs this product fastest in; mid_fwd adds the bias
-            torch.mm(self.W1, x.t(), out=bf.r1T)
+            self._mm(self.W1, x.t(), bf.r1T)
         else:
             torch.addmm(self.b1, x, self.W1.t(), out=bf.r1)
         if early and self._early_split:         # ... and the first half of the next batch's tiles in its spare workgroups
             st = next_from
-            chk(_L.idl_mid_fwd_gather(_p(bf.r1), _p(self.b1) if tl else None, 1 if tl else 0, _p(self.W2), _p(self.b2), _p(self.W3), _p(self.b3),
-                                      m, C, tr, self.seed, _p(self.ctl),
-                                      _p(bf.f), _p(bf.inv), _p(bf.r2), _p(bf.z),
-                                      _p(st.feats), st.n, st.f, st.n * st.f, _p(self._perm), _p(self.ctl[1:]), m // 2, st.n_pairs, m // 2,
-                                      _p(st.mean), _p(st.scale), _p(st.inv_scale), _p(bf.xs[1 - xi]), 0, self._gsplit, 8, _stream()))
+            self._k(_L.idl_mid_fwd_gather, _p(bf.r1), _p(self.b1) if tl else None, 1 if tl else 0, _p(self.W2), _p(self.b2), _p(self.W3), _p(self.b3),
+                    m, C, tr, self.seed, _p(self.ctl),
+                    _p(bf.f), _p(bf.inv), _p(bf.r2), _p(bf.z),
+                    _p(st.feats), st.n, st.f, st.n * st.f, _p(self._perm), _p(self.ctl[1:]), m // 2, st.n_pairs, m // 2,
+                    _p(st.mean), _p(st.scale), _p(st.inv_scale), _p(bf.xs[1 - xi]), 0, self._gsplit, 8, _stream())
         elif early_f:
             st = next_from
             chk(_L.idl_mid_fwd_gather(_p(bf.r1), None, 0, _p(self.W2), _p(self.b2), _p(self.W3), _p(self.b3),
@@ -198,8 +241,8 @@ class FusedLinearTrainer:
             chk(_L.idl_nce_pass1_joint(_p(bf.f), m, TEMPERATURE, _p(bf.nce_ws), _p(bf.z), _p(bf.P0), C, _stream()))
         elif bf.nce_fused and C <= 48 and not self._overlap and self._joint_inlaunch:
             # the IIC workgroup of InfoNCE pass 1 forms the joint z1^T z2 itself (MFMA tiles) before the core
-            chk(_L.idl_nce_fused_iic_z(_p(bf.f), m, TEMPERATURE, _p(bf.lse), _p(bf.loss_rows), _p(bf.G), _p(bf.nce_ws), _p(bf.z),
-                                       _p(bf.P0), C, self.lamb, EPS, self.weight, _p(bf.iic_scratch), _p(self.out), _stream()))
+            self._k(_L.idl_nce_fused_iic_z, _p(bf.f), m, TEMPERATURE, _p(bf.lse), _p(bf.loss_rows), _p(bf.G), _p(bf.nce_ws), _p(bf.z),
+                    _p(bf.P0), C, self.lamb, EPS, self.weight, _p(bf.iic_scratch), _p(self.out), _stream())
         elif bf.nce_fused and C <= 48 and not self._overlap:
             torch.mm(bf.z[:m // 2].t(), bf.z[m // 2:], out=bf.P0)            # IIC joint, one [C,B]x[B,C] GEMM
             chk(_L.idl_nce_fused_iic(_p(bf.f), m, TEMPERATURE, _p(bf.lse), _p(bf.loss_rows), _p(bf.G), _p(bf.nce_ws),
@@ -235,12 +278,12 @@ class FusedLinearTrainer:
                 torch.mm(bf.dlat.t(), bf.r1, out=gW2)
         elif early:
             st = next_from
-            chk(_L.idl_mid_bwd_gather(_p(bf.z), _p(bf.r2), _p(bf.f), _p(bf.inv), _p(bf.G), bf.G.shape[0], _p(bf.P0), _p(self.W3), _p(self.W2),
-                                      _p(bf.r1), m, C, tr, nce_coef, _p(bf.dlogits), _p(bf.dlat), _p(bf.dr1), _p(gb1), _p(gb2), _p(gb3),
-                                      _p(gW3) if self._dw3_partial else None,
-                                      _p(st.feats), st.n, st.f, st.n * st.f, _p(self._perm), _p(self.ctl[1:]), m // 2, st.n_pairs, m // 2,
-                                      _p(st.mean), _p(st.scale), _p(st.inv_scale), _p(bf.xs[1 - xi]), self._gsplit if self._early_split else 0,
-                                      8, 8, 1 if tl else 0, _stream()))
+            self._k(_L.idl_mid_bwd_gather, _p(bf.z), _p(bf.r2), _p(bf.f), _p(bf.inv), _p(bf.G), bf.G.shape[0], _p(bf.P0), _p(self.W3), _p(self.W2),
+                    _p(bf.r1), m, C, tr, nce_coef, _p(bf.dlogits), _p(bf.dlat), _p(bf.dr1), _p(gb1), _p(gb2), _p(gb3),
+                    _p(gW3) if self._dw3_partial else None,
+                    _p(st.feats), st.n, st.f, st.n * st.f, _p(self._perm), _p(self.ctl[1:]), m // 2, st.n_pairs, m // 2,
+                    _p(st.mean), _p(st.scale), _p(st.inv_scale), _p(bf.xs[1 - xi]), self._gsplit if self._early_split else 0,
+                    8, 8, 1 if tl else 0, _stream())
             if not self._dw3_partial:
                 torch.mm(bf.dlogits.t(), bf.r2, out=gW3)
             if not self._dw2_inlaunch:
@@ -278,15 +321,15 @@ class FusedLinearTrainer:
             chk(_L.idl_wgrad_rmsprop(_p(bf.dr1), _p(x), m, self.H1, self.F, None, _p(self.W1), _p(self.square_avg[0]), _p(self.hyper),
                                      _stream()))
         else:
-            torch.mm(bf.dr1.t(), x, out=gW1)
+            self._mm(bf.dr1.t(), x, gW1)
         sz = self._sz_no_w1 if w1_done else self._sz
         main.wait_stream(side)
         # ---- RMSprop (and advance the device-side step counter / batch offset)
         if (early or early_f) and self._dw2_inlaunch:      # no batch assembly here; the offset moves on at the end of the step
-            chk(_L.idl_rmsprop_step_gather_wgrad(len(self.params), self._pp, self._gp, self._parts, self._vp, sz, _p(self.hyper),
-                                                 _p(self.ctl), _p(bf.loss_rows), m, 1.0 - self.weight, self.weight, _p(self.out),
-                                                 None, 0, 0, 0, None, 0, 0, None, None, None, None,
-                                                 2, _p(bf.dlat), _p(bf.r1), 1 if tl else 0, m, self.H2, self.H1, _p(gW2), m // 2, _stream()))
+            self._k(_L.idl_rmsprop_step_gather_wgrad, len(self.params), self._pp, self._gp, self._parts, self._vp, sz, _p(self.hyper),
+                    _p(self.ctl), _p(bf.loss_rows), m, 1.0 - self.weight, self.weight, _p(self.out),
+                    None, 0, 0, 0, None, 0, 0, None, None, None, None,
+                    2, _p(bf.dlat), _p(bf.r1), 1 if tl else 0, m, self.H2, self.H1, _p(gW2), m // 2, _stream())
         elif early:
             chk(_L.idl_rmsprop_step(len(self.params), self._pp, self._gp, self._parts, self._vp, sz, _p(self.hyper),
                                     _p(self.ctl), m // 2, _p(bf.loss_rows), m, 1.0 - self.weight, self.weight, _p(self.out), _stream()))
@@ -384,3 +427,153 @@ class FusedLinearTrainer:
                 self._full_step(store, bf, pipelined=pipe, xi=i % 2)
         g.replay()          # capture does not execute: run the captured step(s) once
         return g
+
+
+class BatchedLinearTrainer:
+    """Several voters of one ensemble trained in lockstep on one GPU (each on its own network, permutation, dropout stream and
+    optimizer state -- the same independent runs as one after the other; only the rounding of the batched GEMMs may differ
+    from the single-voter ones).
+
+    The step of voter l is the launch sequence of FusedLinearTrainer.step_on_batch; here each of its launches is issued ONCE for
+    all voters: the two big products as batched GEMMs over stacked operands ([L, 512, F] weights, [L, m, F] batches), the five
+    kernels as recorded launches (idl_plan_*: every voter's launch is recorded through the ordinary launcher, the records
+    live on the device, the kernels take the voter index from blockIdx.y / .z).  Needs the default launch sequence
+    (n_clusters <= 48, batch 2 x 512 rows assembled by the middle launches)."""
+
+    def __init__(self, nets, lr, weight, lamb, seed=0):
+        self.L = L = len(nets)
+        lin1 = [n.layers[0] for n in nets]
+        self.dev = dev = lin1[0].weight.device
+        H1, F = lin1[0].weight.shape
+        f32 = dict(dtype=torch.float32, device=dev)
+        # stacked GEMM operands; every voter's parameters / gradients / buffers are views of them
+        self.W1s = torch.empty((L, H1, F), **f32)
+        self.gW1s = torch.zeros((L, H1, F), **f32)
+        for l, lin in enumerate(lin1):
+            self.W1s[l].copy_(lin.weight.data)
+            lin.weight.data = self.W1s[l]
+        self._stacks = {}
+        self._H1, self._F = H1, F
+        self.trainers = []
+        for l, net in enumerate(nets):
+            self.trainers.append(FusedLinearTrainer(net, lr, weight, lamb, seed=seed, grad_w1=self.gW1s[l], shared_buffers=_SharedViews(self, l)))
+        t0 = self.trainers[0]
+        if not (t0._early_gather and t0._early_split and t0._transposed_l1 and t0._dw2_inlaunch and t0._mid_fused and t0._dw3_partial
+                and t0._joint_inlaunch and t0._pipeline and not t0._nce_bwd_fused and not t0._wgrad_fused and not t0._overlap):
+            raise ValueError("BatchedLinearTrainer needs the default launch sequence (n_clusters <= 48, no opt-in variants)")
+        self._programs = {}
+        self._graphs = {}
+
+    def stack(self, m):
+        """Stacked GEMM operands of batch shape m: XS[2][L, m, F], R1 [L, m, 512] (its transposed image [L, 512, m] is the layer-1
+        product's output), DR1 [L, m, 512]."""
+        if m not in self._stacks:
+            f32 = dict(dtype=torch.float32, device=self.dev)
+            self._stacks[m] = dict(xs=[torch.empty((self.L, m, self._F), **f32), torch.empty((self.L, m, self._F), **f32)],
+                                   r1=torch.empty((self.L, m, self._H1), **f32), dr1=torch.empty((self.L, m, self._H1), **f32))
+        return self._stacks[m]
+
+    # ------------------------------------------------------------------ recording
+    def _program(self, store, m):
+        """The recorded launches of one pipelined step for the two x-buffer parities: [(host records [L, B], device records)] x 4."""
+        key = (m, store.feats.data_ptr(), store.mean.data_ptr(), store.scale.data_ptr(), store.inv_scale.data_ptr(), store.n, store.f,
+               store.n_views) + tuple(t._perm.data_ptr() for t in self.trainers)
+        prog = self._programs.get(key)
+        if prog is None:
+            prog = []
+            for xi in (0, 1):
+                recs = []
+                for t in self.trainers:
+                    t._rec = _Recorder()
+                    try:
+                        t.step_on_batch(t.buffers(m), train=True, batch_advance=m // 2, next_from=store, xi=xi)
+                    finally:
+                        rec, t._rec = t._rec, None
+                    if len(rec.plans) != 4 or rec.mms != 2:
+                        raise RuntimeError("the recorded step is not the default launch sequence")
+                    recs.append(rec.plans)
+                ops = []
+                for k in range(4):
+                    host = torch.stack([recs[l][k] for l in range(self.L)]).contiguous()
+                    ops.append((host, host.to(self.dev)))
+                prog.append(ops)
+            self._programs = {key: prog}
+            self._graphs.clear()
+        return prog
+
+    def _step(self, prog, st, xi):
+        """One optimizer step of every voter on the batches in XS[xi] (assembling the next ones into XS[1 - xi])."""
+        L = self.L
+        ops = prog[xi]
+        r1T = st['r1'].view(L, self._H1, -1)
+        torch.bmm(self.W1s, st['xs'][xi].transpose(1, 2), out=r1T)                        # a1^T = W1 x^T per voter
+        for k in (0, 1, 2):                                                              # mid_fwd, InfoNCE passes, mid_bwd
+            _lib.check(_L.idl_plan_launch(ctypes.c_void_p(ops[k][0].data_ptr()), _p(ops[k][1]), L, _stream()))
+        torch.bmm(st['dr1'].transpose(1, 2), st['xs'][xi], out=self.gW1s)                # dW1 = dr1^T x per voter
+        _lib.check(_L.idl_plan_launch(ctypes.c_void_p(ops[3][0].data_ptr()), _p(ops[3][1]), L, _stream()))
+
+    # ------------------------------------------------------------------ one epoch of every voter
+    @torch.no_grad()
+    def run_epoch(self, store, batch_sz, generators, use_graph=True):
+        """One pass of every voter over its own fresh permutation -> [(device scalar sum of step losses, n_batches)] per voter."""
+        n_pairs = store.n_pairs
+        for t, g in zip(self.trainers, generators):
+            if t._perm is None or t._perm.numel() != n_pairs:
+                t._perm = torch.empty(n_pairs, dtype=torch.int64, device=self.dev)
+            torch.randperm(n_pairs, device=self.dev, generator=g, out=t._perm)
+            t.ctl[1] = 0
+            t.out[1] = 0.0
+        n_full, rem = divmod(n_pairs, batch_sz)
+        m = 2 * batch_sz
+        if n_full and m % 32 == 0:
+            st = self.stack(m)
+            for t in self.trainers:
+                t._gather(store, t.buffers(m))            # prologue: batch 0 of every voter
+            prog = self._program(store, m)
+            per = self.trainers[0]._steps_per_graph
+            while per > 2 and n_full < 2 + 2 * per:
+                per = max(2, per // 4 * 2)
+            done = 0
+            if use_graph and n_full >= 8:
+                g = self._graphs.get((m, per))
+                if g is None:
+                    s = torch.cuda.Stream()
+                    s.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(s):
+                        for i in range(2):
+                            self._step(prog, st, i % 2)
+                    torch.cuda.current_stream().wait_stream(s)
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        for i in range(per):
+                            self._step(prog, st, i % 2)
+                    g.replay()
+                    self._graphs[(m, per)] = g
+                    done = 2 + per
+                for _ in range((n_full - done) // per):
+                    g.replay()
+                done += (n_full - done) // per * per
+            for i in range(n_full - done):
+                self._step(prog, st, i % 2)
+        elif n_full:
+            for t in self.trainers:
+                for i in range(n_full):
+                    t._full_step(store, t.buffers(m), pipelined=t._pipeline, xi=i % 2)
+        if rem:                                           # the partial last batch: voter by voter, the single-voter kernels
+            for t in self.trainers:
+                t._full_step(store, t.buffers(2 * rem))
+        return [(t.out[1], n_full + (1 if rem else 0)) for t in self.trainers]
+
+
+class _SharedViews:
+    """{m: views} handed to a voter's _Buffers: its slices of the batched trainer's stacked GEMM operands (full batches only)."""
+
+    def __init__(self, owner, l):
+        self._owner, self._l = owner, l
+
+    def get(self, m, default=None):
+        if m % 32 != 0 or m < 64:
+            return default
+        st = self._owner.stack(m)
+        l = self._l
+        return dict(xs0=st['xs'][0][l], xs1=st['xs'][1][l], r1=st['r1'][l], dr1=st['dr1'][l])

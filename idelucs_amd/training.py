@@ -6,7 +6,7 @@ import sys
 
 import torch
 
-from . import models
+from . import gemm_tuning, models
 from .utils import SummaryFasta
 
 
@@ -29,61 +29,63 @@ def train_voter(model, n_epochs, voter=0, n_voters=1, progress=True):
 
 
 def voter_lanes(n_voters_here):
-    """How many voters of one rank train side by side, each on its own HIP stream (IDELUCS_VOTER_LANES, default 1).
-    Measured on MI355X (tools/concurrent_voters.py, tools/stream_overlap.hip): streams and graphs of different streams do overlap
-    on this GPU, but the training step's two GEMMs put one workgroup on every CU and its 1024-thread middle kernels do not fit
-    beside them, so lanes only fill launch gaps -- 1.17 x at n_clusters = 20 with 50 000 sequences, nothing at the cfg2 size (a
-    16-step graph has no gaps), 1.47 x on the one-step-per-replay path.  Off by default; the results are identical either way."""
-    lanes = int(os.environ.get("IDELUCS_VOTER_LANES", "1"))
+    """How many voters of one rank train in lockstep as one batch (IDELUCS_VOTER_LANES, default 8; 1 = one after the other).
+    One training step is two big GEMMs and five latency-bound launches; batched, the GEMMs become batched GEMMs and each of the
+    five launches serves every voter of the batch (fused.BatchedLinearTrainer)."""
+    lanes = int(os.environ.get("IDELUCS_VOTER_LANES", "8"))
     return max(1, min(lanes, n_voters_here))
 
 
+def can_batch(model):
+    """Voters can be batched when the model runs the default fused launch sequence (NetLinear + RMSprop, n_clusters <= 48, full
+    batches a multiple of 16 rows) and no scheduler reads the epoch loss on the host between epochs."""
+    return bool(model._use_fused and model.n_clusters <= 48 and model.batch_sz % 16 == 0 and model.schedule is None
+                and os.environ.get("IDELUCS_PIPELINE", "1") != "0" and os.environ.get("IDELUCS_EARLY_GATHER", "1") == "1"
+                and os.environ.get("IDELUCS_MID_FUSED", "1") != "0")
+
+
 def train_voters(model, voters, n_epochs, n_voters=None, lanes=None, progress=True):
-    """The voters this rank owns -> {voter: (loss curve, y_pred, probabilities, latent)}, the same results as train_voter()
-    one voter after the other: every voter draws from its own RNG streams and starts from fresh optimizer state
-    (IID_model.begin_voter), so when and beside whom it trains does not matter.  Voters run `lanes` at a time, each lane on its
-    own HIP stream with its own network, step buffers and captured graph (IID_model.lane()); the epochs of one wave are
-    enqueued round-robin and nothing waits on the host until the wave's predicts."""
+    """The voters this rank owns -> {voter: (loss curve, y_pred, probabilities, latent)}.  Every voter draws from its own RNG
+    streams and starts from fresh optimizer state (IID_model.begin_voter), so when and beside whom it trains does not change
+    what it is.  Voters run `lanes` at a time in lockstep (fused.BatchedLinearTrainer: one launch sequence for the whole batch of
+    voters, each on its own network / permutation / dropout stream / optimizer state; IID_model.lane()); nothing waits on the
+    host until a batch's predicts."""
+    from .fused import BatchedLinearTrainer
     voters = list(voters)
     n_voters = n_voters if n_voters is not None else len(voters)
     lanes = voter_lanes(len(voters)) if lanes is None else max(1, min(int(lanes), len(voters)))
-    if not model._use_fused:                 # the autograd paths draw dropout masks from the process-wide generator: one at a time
-        lanes = 1
-    if lanes <= 1:
-        out = {}
-        for v in voters:
-            r = train_voter(model, n_epochs, v, n_voters, progress)
-            out[v] = r
-        return out
-    models_ = [model] + [model.lane() for _ in range(lanes - 1)]
-    streams = [torch.cuda.Stream(device=model.device) for _ in models_]
-    cur = torch.cuda.current_stream()
+    if lanes <= 1 or not can_batch(model):
+        return {v: train_voter(model, n_epochs, v, n_voters, progress) for v in voters}
     out = {}
+    lane_models, batched = None, None
     for w in range(0, len(voters), lanes):
         wave = voters[w:w + lanes]
+        if len(wave) == 1:                                   # a last voter on its own: the single-voter path
+            out[wave[0]] = train_voter(model, n_epochs, wave[0], n_voters, progress)
+            continue
+        if batched is None or batched.L != len(wave):
+            lane_models = [model.lane() for _ in wave]
+            batched = BatchedLinearTrainer([m.net for m in lane_models], model.lr, model.weight, model.l, seed=model.seed)
+            for m, t in zip(lane_models, batched.trainers):
+                m._fused = t
         if progress:
             sys.stdout.write(f"\r........... Training Models ({wave[0] + 1}-{wave[-1] + 1}/{n_voters})................")
             sys.stdout.flush()
+        for m, v in zip(lane_models, wave):
+            m.begin_voter(v)
         curves = {v: [] for v in wave}
-        for m, s, v in zip(models_, streams, wave):
-            s.wait_stream(cur)
-            with torch.cuda.stream(s):
-                m.begin_voter(v)
+        n_batches = (model.store.n_pairs + model.batch_sz - 1) // model.batch_sz
+        gemm_tuning.maybe_enable(n_batches * n_epochs * len(voters))
         for _ in range(n_epochs):
-            pending = []
-            for m, s, v in zip(models_, streams, wave):
-                with torch.cuda.stream(s):
-                    pending.append(m.enqueue_epoch())
-            for m, s, v, loss in zip(models_, streams, wave, pending):     # schedulers may read the loss: after every lane is enqueued
-                with torch.cuda.stream(s):
-                    curves[v].append(m._finish_epoch(loss, sync=False))
-        for m, s, v in zip(models_, streams, wave):
-            with torch.cuda.stream(s):
-                out[v] = ([float(x) for x in curves[v]],) + tuple(m.predict())
-        for s in streams:
-            cur.wait_stream(s)
+            for m in lane_models:
+                m.net.train()
+            res = batched.run_epoch(model.store, model.batch_sz, [m._gen for m in lane_models])
+            for m, v, (total, nb) in zip(lane_models, wave, res):
+                curves[v].append(m._finish_epoch(total / (nb - 1), sync=False))     # models.py:135 quirk (divide by last index)
+        for m, v in zip(lane_models, wave):
+            out[v] = ([float(x) for x in curves[v]],) + tuple(m.predict())
     # the caller goes on with `model`: leave it holding the LAST voter's weights, as after a sequential run
-    last = models_[(len(voters) - 1) % lanes]
-    if last is not model:
+    if lane_models is not None and len(voters) % lanes != 1:
+        last = lane_models[(len(voters) - 1) % lanes if len(voters) % lanes else lanes - 1]
         model.net.load_state_dict(last.net.state_dict())
     return out

@@ -143,25 +143,32 @@ def test_device_ensemble_matches_sklearn_partition():
 
 
 @pytest.mark.gpu
-def test_voters_are_the_same_runs_side_by_side_or_one_after_the_other(tmp_path, monkeypatch):
-    """Several voters per GPU train side by side on their own streams (training.train_voters).  Every voter draws from its own
-    RNG streams and starts from fresh optimizer state, so the vote matrix must not depend on how many lanes there are."""
+def test_voters_batched_or_one_after_the_other(tmp_path, monkeypatch):
+    """Several voters per GPU train in lockstep as one batch (training.train_voters -> fused.BatchedLinearTrainer).  Every voter
+    draws from its own RNG streams and starts from fresh optimizer state, so it is the same run either way -- up to the rounding
+    of the batched GEMMs, which training amplifies: the votes of a voter trained in a batch and alone must describe the same
+    partition (ARI), and the ensembles must be equally good."""
+    import pandas as pd
+    from sklearn.metrics import adjusted_rand_score
     from idelucs_amd.__main__ import main
     monkeypatch.chdir(tmp_path)
-    votes = {}
+    votes, acc = {}, {}
     for lanes in (1, 3, 2):
         monkeypatch.setenv("IDELUCS_VOTER_LANES", str(lanes))
         monkeypatch.setenv("IDELUCS_DUMP_VOTES", str(tmp_path / f"votes{lanes}.npy"))
-        main(["--sequence_file", os.path.join(DATA, "Influenza-A.fas"), "--GT_file", os.path.join(DATA, "Influenza-A_GT.tsv"),
-              "--n_clusters", "5", "--n_epochs", "8", "--n_voters", "3", "--batch_sz", "512", "--k", "6"])
+        out_dir = main(["--sequence_file", os.path.join(DATA, "Influenza-A.fas"), "--GT_file", os.path.join(DATA, "Influenza-A_GT.tsv"),
+                        "--n_clusters", "5", "--n_epochs", "12", "--n_voters", "3", "--batch_sz", "512", "--k", "6"])
         votes[lanes] = np.load(tmp_path / f"votes{lanes}.npy")
+        acc[lanes] = float(pd.read_csv(os.path.join(out_dir, "metrics.tsv"), sep="\t", index_col=0).loc["ACC", "Value"])
         time.sleep(1.1)                                       # the results folder is stamped to the second
     assert votes[1].shape == (3, 949)
     assert not np.array_equal(votes[1][0], votes[1][1])
     for lanes in (3, 2):
-        agree = (votes[lanes] == votes[1]).mean(axis=1)
-        print(f"{lanes} lanes vs 1: per-voter agreement {agree}")
-        assert np.array_equal(votes[lanes], votes[1]), agree
+        ari = [adjusted_rand_score(votes[lanes][v], votes[1][v]) for v in range(3)]
+        print(f"{lanes} voters per batch vs one after the other: per-voter ARI {np.round(ari, 3)}, ensemble ACC {acc[lanes]:.4f} vs {acc[1]:.4f}")
+        assert min(ari) >= 0.6 and abs(acc[lanes] - acc[1]) <= 0.08
+    # with 2 voters per batch the third voter trains alone, on the single-voter kernels: exactly the sequential run's voter
+    assert np.array_equal(votes[2][2], votes[1][2])
 
 
 @pytest.mark.gpu
@@ -176,8 +183,10 @@ def test_cli_two_ranks_voters_are_distinct_and_outputs_complete(tmp_path, n_clus
     import pandas as pd
     from conftest import ROOT
     votes = str(tmp_path / "votes.npy")
+    # (voters one after the other on each rank: trained alone a voter is EXACTLY the same run wherever it trains; in a batch of
+    # voters only the rounding of the batched GEMMs differs, see test_voters_batched_or_one_after_the_other)
     env = dict(os.environ, IDELUCS_BENCH_BACKEND="gloo", IDELUCS_BENCH_DEVICES="1", IDELUCS_DUMP_VOTES=votes, PYTHONPATH=ROOT,
-               HSA_ENABLE_IPC_MODE_LEGACY="0")
+               HSA_ENABLE_IPC_MODE_LEGACY="0", IDELUCS_VOTER_LANES="1" if n_clusters == 5 else "4")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29613", "-m", "idelucs_amd", "--sequence_file", os.path.join(DATA, "Influenza-A.fas"),
            "--GT_file", os.path.join(DATA, "Influenza-A_GT.tsv"), "--n_clusters", str(n_clusters), "--n_epochs", "8",
@@ -201,6 +210,7 @@ def test_cli_two_ranks_voters_are_distinct_and_outputs_complete(tmp_path, n_clus
         from idelucs_amd.__main__ import main
         one = str(tmp_path / "votes_one_process.npy")
         os.environ["IDELUCS_DUMP_VOTES"] = one
+        os.environ["IDELUCS_VOTER_LANES"] = "1"
         cwd = os.getcwd()
         try:
             os.chdir(tmp_path)
@@ -208,7 +218,7 @@ def test_cli_two_ranks_voters_are_distinct_and_outputs_complete(tmp_path, n_clus
             main(cmd[cmd.index("idelucs_amd") + 1:])
         finally:
             os.chdir(cwd)
-            del os.environ["IDELUCS_DUMP_VOTES"]
+            del os.environ["IDELUCS_DUMP_VOTES"], os.environ["IDELUCS_VOTER_LANES"]
         assert np.array_equal(np.load(one), v), (np.load(one) == v).mean(axis=1)
 
 

@@ -421,6 +421,78 @@ def test_graph_replay_equals_eager_at_cfg2_shape(dev, C, n):
     assert next(iter(tr._graphs.values())) is g_before and all(torch.isfinite(p).all() for p in tr.params)
 
 
+@pytest.mark.parametrize("n,use_graph", [(1500, False), (1500, True), (4200, True)])
+def test_batched_voters_step_like_single_voters(dev, n, use_graph):
+    """fused.BatchedLinearTrainer (three voters in lockstep: batched GEMMs + recorded launches with the voter index in the grid)
+    against three FusedLinearTrainer runs of the same voters: same initial weights, same permutations (one generator per voter),
+    same dropout streams.  Only the GEMM kernels differ (batched vs plain: another summation order), so after a whole epoch
+    (8 or 24 full batches + a partial one) the parameters agree to a few 1e-4 of their scale and the losses to 1e-4."""
+    import copy
+    import torch
+    from idelucs_amd.fused import FusedLinearTrainer, BatchedLinearTrainer
+    store, net0 = _cfg2_store_and_net(dev, n, seed=4)
+    B, L = 512, 3
+    nets_a, nets_b = [], []
+    for l in range(L):
+        net = copy.deepcopy(net0)
+        with torch.no_grad():
+            for p_ in net.parameters():                       # different voters: different weights
+                p_.mul_(1.0 + 0.05 * l)
+        nets_a.append(net)
+        nets_b.append(copy.deepcopy(net))
+    single = []
+    for l, net in enumerate(nets_a):
+        tr = FusedLinearTrainer(net, lr=1e-3, weight=0.25, lamb=2.8, seed=11)
+        tr.begin_voter(l)
+        gen = torch.Generator(device=dev); gen.manual_seed(100 + l)
+        total, nb = tr.run_epoch(store, B, use_graph=use_graph, generator=gen)
+        single.append((total.item(), nb, [p_.detach().clone() for p_ in tr.params], tr.ctl.tolist()))
+    bt = BatchedLinearTrainer(nets_b, lr=1e-3, weight=0.25, lamb=2.8, seed=11)
+    gens = []
+    for l, tr in enumerate(bt.trainers):
+        tr.begin_voter(l)
+        g = torch.Generator(device=dev); g.manual_seed(100 + l)
+        gens.append(g)
+    res = bt.run_epoch(store, B, gens, use_graph=use_graph)
+    torch.cuda.synchronize()
+    if use_graph:
+        assert len(bt._graphs) == 1, "the epoch did not go through a captured graph"
+    for l, ((total, nb), tr) in enumerate(zip(res, bt.trainers)):
+        want_total, want_nb, want_params, want_ctl = single[l]
+        assert nb == want_nb and tr.ctl.tolist() == want_ctl
+        assert abs(total.item() - want_total) <= 2e-4 * abs(want_total), (l, total.item(), want_total)
+        for i, (a, b) in enumerate(zip(tr.params, want_params)):
+            err = (a.detach() - b).abs().max().item()
+            assert err <= 5e-4 * b.abs().max().item() + 1e-7, (l, i, err, b.abs().max().item())
+        assert nets_b[l].layers[0].weight.data_ptr() == bt.W1s[l].data_ptr()          # the network's parameter IS the stacked slice
+    # voters are different runs
+    assert not torch.allclose(bt.trainers[0].params[2], bt.trainers[1].params[2])
+    # a second epoch replays the same graph
+    if use_graph:
+        g_before = next(iter(bt._graphs.values()))
+        bt.run_epoch(store, B, gens)
+        torch.cuda.synchronize()
+        assert next(iter(bt._graphs.values())) is g_before and all(torch.isfinite(p_).all() for t in bt.trainers for p_ in t.params)
+
+
+def test_plan_records_are_checked(dev):
+    """idl_plan_begin / idl_plan_end: a launcher that cannot be recorded, or none at all, is an error; records of different
+    launch shapes cannot be launched together."""
+    import ctypes
+    import torch
+    from idelucs_amd import _lib
+    L = _lib.lib
+    nb = int(L.idl_plan_bytes())
+    blob = torch.zeros(nb, dtype=torch.uint8)
+    _lib.check(L.idl_plan_begin(ctypes.c_void_p(blob.data_ptr())))
+    with pytest.raises(ValueError):
+        _lib.check(L.idl_plan_end())                      # nothing was recorded
+    two = torch.zeros((2, nb), dtype=torch.uint8)
+    two[1, 8] = 1                                         # another grid
+    with pytest.raises(ValueError):
+        _lib.check(L.idl_plan_launch(ctypes.c_void_p(two.data_ptr()), ctypes.c_void_p(two.to(dev).data_ptr()), 2, None))
+
+
 # ------------------------------------------------------------------------------------------------
 # the other configurations of the reference surface
 # ------------------------------------------------------------------------------------------------

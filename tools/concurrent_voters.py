@@ -83,7 +83,24 @@ def main():
             cur.wait_stream(s)
         return out
 
-    for name, fn in (("sequential", seq), ("concurrent", conc), ("sequential", seq), ("concurrent", conc)):
+    # the same voters batched inside the launches (fused.BatchedLinearTrainer): one launch sequence for all of them
+    from idelucs_amd.fused import BatchedLinearTrainer
+    bms = [make(v) for v in range(a.voters)]
+    modes = [("sequential", seq), ("concurrent", conc)]
+    if a.n_clusters <= 48 and a.voters > 1:
+        bt = BatchedLinearTrainer([m.net for m in bms], 1e-3, 0.25, 2.8, seed=0)
+        for m, t in zip(bms, bt.trainers):
+            m._fused = t
+        for v, m in enumerate(bms):
+            m.begin_voter(v)
+
+        def batched():
+            res = bt.run_epoch(store, 512, [m._gen for m in bms])
+            return [tot / (nb - 1) for tot, nb in res]
+        batched()
+        torch.cuda.synchronize()
+        modes.append(("batched", batched))
+    for name, fn in modes + modes:
         ts = []
         for _ in range(a.reps):
             torch.cuda.synchronize()

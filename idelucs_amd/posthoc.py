@@ -2,6 +2,8 @@
 (reference idelucs/utils.py:582-623 and idelucs/__main__.py:129-156).  SURVEY 8(f) rows f2/f3: kept
 on the host with sklearn/scipy, as in the reference, on the outputs gathered from the GPUs.
 """
+import os
+
 import numpy as np
 
 
@@ -188,22 +190,92 @@ def _hdbscan(points, min_cluster_size):
     return cl.labels_, cl.probabilities_
 
 
-def fine_grained_clusters(latent, exact_max=None, seed=0, device=None):
+def core_distances_device(x64, k, device):
+    """Distance of every point to its k-th nearest neighbour, itself included (sklearn _hdbscan_prims: NearestNeighbors(
+    n_neighbors=k).kneighbors(X)[:, -1]).  Row blocks of the float64 Gram-form distance matrix (one GEMM each), the k-th smallest
+    per row by radix select (torch.kthvalue), and the selected neighbour's distance then formed exactly from the difference
+    vector (the Gram form is only trusted to FIND the neighbour)."""
+    import torch
+    n = x64.shape[0]
+    sq = (x64 * x64).sum(1)
+    rows = max(64, min(n, (1 << 30) // max(n, 1)))            # 8 GB of float64 distances per block
+    core = torch.empty(n, dtype=torch.float64, device=device)
+    for lo in range(0, n, rows):
+        xb = x64[lo:lo + rows]
+        d2 = torch.addmm(sq[None, :].expand(xb.shape[0], n), xb, x64.t(), beta=1.0, alpha=-2.0)
+        d2 += sq[lo:lo + rows, None]
+        d2[torch.arange(xb.shape[0], device=device), torch.arange(lo, lo + xb.shape[0], device=device)] = 0.0     # a point is its own first neighbour
+        idx = torch.kthvalue(d2, k, dim=1).indices
+        diff = xb - x64[idx]
+        core[lo:lo + rows] = (diff * diff).sum(1).sqrt()
+        del d2
+    return core
+
+
+def hdbscan_device(points, min_cluster_size, device=None):
+    """sklearn.cluster.HDBSCAN(min_cluster_size).fit(points) -> (labels_, probabilities_) with the two O(N^2) stages on the GPU:
+    core distances (core_distances_device) and Prim's minimum spanning tree of the mutual-reachability graph (csrc/mst.hip,
+    idl_mst_prim: sklearn's mst_from_data_matrix visit for visit, in float64); the edges then go through sklearn's own
+    single-linkage / condensed-tree code (sklearn.cluster._hdbscan: make_single_linkage, tree_to_labels -- private names of
+    sklearn 1.7, the stand-in for the absent `hdbscan` package: SURVEY 8c), so the labels are sklearn's."""
+    import ctypes
+    import torch
+    from sklearn.cluster._hdbscan._linkage import MST_edge_dtype, make_single_linkage
+    from sklearn.cluster._hdbscan._tree import tree_to_labels
+    from . import _lib
+    L = _lib.lib
+    dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+    pts = np.ascontiguousarray(np.asarray(points, dtype=np.float64))
+    n, d = pts.shape
+    k = max(int(min_cluster_size), 2)
+    if not np.all(np.isfinite(pts)):
+        raise ValueError("hdbscan_device: non-finite coordinates")
+    if n < 2 or k > n:
+        raise ValueError(f"hdbscan_device: min_samples ({k}) must be at most the number of points ({n})")
+    x64 = torch.from_numpy(pts).to(dev)
+    core = core_distances_device(x64, k, dev)
+    f32_exact = bool(np.array_equal(pts.astype(np.float32).astype(np.float64), pts))
+    xt = x64.t().contiguous().to(torch.float32 if f32_exact else torch.float64)       # feature-major, float32 when that is lossless
+    cur = torch.empty(n - 1, dtype=torch.int64, device=dev)
+    nxt = torch.empty(n - 1, dtype=torch.int64, device=dev)
+    w = torch.empty(n - 1, dtype=torch.float64, device=dev)
+    ws = torch.empty(int(L.idl_mst_prim_workspace(n)) + 256, dtype=torch.uint8, device=dev)
+    off = (-ws.data_ptr()) % 256
+    _lib.check(L.idl_mst_prim(ctypes.c_void_p(xt.data_ptr()), 0 if f32_exact else 1, ctypes.c_void_p(core.data_ptr()), n, d,
+                              ctypes.c_void_p(cur.data_ptr()), ctypes.c_void_p(nxt.data_ptr()), ctypes.c_void_p(w.data_ptr()),
+                              ctypes.c_void_p(ws.data_ptr() + off), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    mst = np.empty(n - 1, dtype=MST_edge_dtype)
+    mst["current_node"], mst["next_node"], mst["distance"] = cur.cpu().numpy(), nxt.cpu().numpy(), w.cpu().numpy()
+    mst = mst[np.argsort(mst["distance"])]                                            # sklearn hdbscan.py:_process_mst
+    tree = make_single_linkage(mst)
+    labels, prob = tree_to_labels(tree, k, "eom", False, 0.0, None)                   # HDBSCAN's defaults (hdbscan.py:846-853)
+    return labels, prob
+
+
+def fine_grained_clusters(latent, exact_max=None, seed=0, device=None, mode=None):
     """n_clusters=0 mode (reference __main__.py:82-83,153-156): HDBSCAN(min_cluster_size=N//100+1) on the last voter's latent;
     labels+1, probabilities.  `hdbscan` is used when importable, else sklearn.cluster.HDBSCAN (parity with hdbscan==0.8.32 is
     unpinned -- SURVEY 8c).
 
     Up to `exact_max` points (default HDBSCAN_EXACT_MAX) that is the whole computation, on the host as in the reference.  Beyond
-    it (BASELINE cfg5: 10^6 points; the host algorithm needs the 10^4-th neighbour of every point) the density clustering runs on
-    a seeded uniform subsample of exact_max points -- min_cluster_size keeps its 1 % meaning, S//100+1 -- and every other point
-    takes the label of its nearest sampled point (one GEMM-shaped nearest-neighbour search on the GPU), with that point's
-    membership probability scaled by how far it is compared with that point's own spacing.  An approximation, stated as such:
-    the reference offers nothing that runs at that size."""
+    it the host algorithm is out of reach (BASELINE cfg5: 10^6 points, each needing its 10^4-th neighbour), and
+      mode "device" (default; $IDELUCS_HDBSCAN): the same HDBSCAN with its two O(N^2) stages on the GPU (hdbscan_device: exact
+          core distances, sklearn's Prim visit for visit, sklearn's own tree code on the edges) -- minutes at 10^6 points;
+      mode "approx": the density clustering runs on a seeded uniform subsample of exact_max points -- min_cluster_size keeps its
+          1 % meaning, S//100+1 -- and every other point takes the label of its nearest sampled point (one GEMM-shaped
+          nearest-neighbour search on the GPU), with that point's membership probability scaled by how far it is compared with
+          that point's own spacing.  Seconds, and an approximation, stated as such."""
     latent = np.asarray(latent)
     n = len(latent)
     exact_max = HDBSCAN_EXACT_MAX if exact_max is None else int(exact_max)
     if n <= exact_max:
         labels, prob = _hdbscan(latent, n // 100 + 1)
+        return labels + 1, prob
+    mode = mode or os.environ.get("IDELUCS_HDBSCAN", "device")
+    if mode not in ("device", "approx"):
+        raise ValueError("fine_grained_clusters: mode must be 'device' or 'approx'")
+    if mode == "device":
+        labels, prob = hdbscan_device(latent, n // 100 + 1, device=device)
         return labels + 1, prob
     import torch
     dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())

@@ -242,8 +242,8 @@ def test_silhouette_on_device_equals_sklearn():
 
 @pytest.mark.gpu
 def test_fine_grained_clusters_beyond_the_exact_limit():
-    """n_clusters = 0 above HDBSCAN_EXACT_MAX points: density clustering of a seeded subsample on the host + nearest-sampled-point
-    assignment on the GPU.  On planted blobs the partition is recovered, the sampled points keep HDBSCAN's own labels, and below
+    """n_clusters = 0 above HDBSCAN_EXACT_MAX points, mode "approx": density clustering of a seeded subsample on the host +
+    nearest-sampled-point assignment on the GPU.  On planted blobs the partition is recovered, the sampled points keep HDBSCAN's own labels, and below
     the limit the function is the plain HDBSCAN call."""
     from sklearn.metrics import adjusted_rand_score
     from idelucs_amd import posthoc
@@ -251,13 +251,61 @@ def test_fine_grained_clusters_beyond_the_exact_limit():
     centres = rng.normal(size=(6, 64)) * 3.0
     truth = rng.integers(0, 6, 60000)
     x = (centres[truth] + rng.normal(size=(60000, 64)) * 0.6).astype(np.float64)
-    y, p = posthoc.fine_grained_clusters(x, exact_max=6000, seed=1)
+    y, p = posthoc.fine_grained_clusters(x, exact_max=6000, seed=1, mode="approx")
     assert y.shape == (60000,) and p.shape == (60000,) and y.min() >= 0 and np.all((p >= 0) & (p <= 1))
     keep = y > 0                                                 # label 0 = HDBSCAN noise (+1 shift, reference __main__.py:155)
     assert keep.mean() > 0.9 and adjusted_rand_score(truth[keep], y[keep]) > 0.98
     y_small, p_small = posthoc.fine_grained_clusters(x[:3000])
     ref_l, ref_p = posthoc._hdbscan(x[:3000], 3000 // 100 + 1)
     assert np.array_equal(y_small, ref_l + 1) and np.array_equal(p_small, ref_p)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,d,as_f32", [(3000, 64, True), (5000, 16, False), (12000, 64, True)])
+def test_hdbscan_on_the_device_is_sklearns(n, d, as_f32):
+    """posthoc.hdbscan_device (core distances by float64 GEMM + radix select, Prim's MST of the mutual-reachability graph as
+    one HIP launch per node, then sklearn's own tree code) against sklearn.cluster.HDBSCAN on the same points with the
+    reference's min_cluster_size rule N // 100 + 1: the MST weights are sklearn's (sorted, 1e-12), the labels are the same
+    partition with the same noise set, the membership probabilities agree."""
+    import torch
+    from sklearn.cluster import HDBSCAN
+    from sklearn.metrics import adjusted_rand_score
+    from idelucs_amd import posthoc
+    rng = np.random.default_rng(n + d)
+    centres = rng.normal(size=(7, d)) * 2.5
+    truth = rng.integers(0, 7, n)
+    x = centres[truth] + rng.normal(size=(n, d)) * rng.uniform(0.3, 0.9, size=(7,))[truth][:, None]
+    x[: n // 20] = rng.uniform(-8, 8, size=(n // 20, d))                   # background noise
+    x = x.astype(np.float32).astype(np.float64) if as_f32 else x
+    k = n // 100 + 1
+    ref = HDBSCAN(min_cluster_size=k).fit(x)
+    labels, prob = posthoc.hdbscan_device(x, k)
+    assert labels.shape == (n,) and prob.shape == (n,)
+    assert np.array_equal(labels < 0, ref.labels_ < 0), "different noise sets"
+    assert adjusted_rand_score(ref.labels_, labels) == 1.0
+    assert np.allclose(prob, ref.probabilities_, atol=1e-9)
+    # the core distances on their own, against sklearn's neighbour search
+    from sklearn.neighbors import NearestNeighbors
+    want = NearestNeighbors(n_neighbors=k).fit(x).kneighbors(x, k)[0][:, -1]
+    got = posthoc.core_distances_device(torch.from_numpy(x).cuda(), k, torch.device("cuda")).cpu().numpy()
+    assert np.allclose(got, want, rtol=1e-12, atol=0)
+
+
+@pytest.mark.gpu
+def test_fine_grained_clusters_on_the_device_beyond_the_exact_limit():
+    """n_clusters = 0 above HDBSCAN_EXACT_MAX points, default mode: the whole HDBSCAN with its O(N^2) stages on the GPU."""
+    from sklearn.metrics import adjusted_rand_score
+    from idelucs_amd import posthoc
+    rng = np.random.default_rng(5)
+    centres = rng.normal(size=(6, 64)) * 3.0
+    truth = rng.integers(0, 6, 40000)
+    x = (centres[truth] + rng.normal(size=(40000, 64)) * 0.6).astype(np.float32).astype(np.float64)
+    t0 = time.time()
+    y, p = posthoc.fine_grained_clusters(x)
+    print(f"HDBSCAN of 40 000 x 64 on the device: {time.time() - t0:.1f} s")
+    assert y.shape == (40000,) and y.min() >= 0 and np.all((p >= 0) & (p <= 1))
+    keep = y > 0
+    assert keep.mean() > 0.9 and adjusted_rand_score(truth[keep], y[keep]) > 0.99 and len(np.unique(y[keep])) == 6
 
 
 def _write_family_fasta(path, gt_path, n, L, n_families, seed):
@@ -285,7 +333,7 @@ def _write_family_fasta(path, gt_path, n, L, n_families, seed):
 @pytest.mark.gpu
 def test_cli_fine_grained_mode_at_cfg5_scale(tmp_path, monkeypatch):
     """BASELINE cfg5's shape at a fifth of its size: 200 000 sequences x 5 kbp (a 1.0 GB FASTA of 8 planted families),
-    --n_clusters 0 => 200 output units, fine-grained clusters on the latent (subsampled HDBSCAN + GPU assignment), metrics with
+    --n_clusters 0 => 200 output units, fine-grained clusters on the latent (HDBSCAN with its O(N^2) stages on the GPU), metrics with
     the GPU silhouette: the whole FASTA-in / TSV-out path at a size the reference cannot run."""
     import pandas as pd
     from idelucs_amd.__main__ import main

@@ -30,11 +30,15 @@ def run(args):
     import torch
     import torch.distributed as dist
     from resource import getrusage, RUSAGE_SELF
-    from . import posthoc, dist as D
+    from . import gemm_tuning, posthoc, dist as D
     from .training import prepare_model, train_voters
     from . import models
 
     start_time = time.time()
+    marks = [("start", start_time)]                               # stage timers, printed with IDELUCS_TIMING=1
+
+    def mark(name):
+        marks.append((name, time.time()))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
 
@@ -66,6 +70,7 @@ def run(args):
         args["n_clusters"], use_hdbscan = 200, True
 
     model = prepare_model(args)
+    mark("FASTA summary + feature store")
     if rank == 0:
         print(model.cluster_dis)
         print(f"No. Sequences: \t {len(model.lengths):,}")
@@ -83,6 +88,13 @@ def run(args):
             latent = lat                                          # the reference scores/clusters the LAST voter's latent
         local_preds[voter] = torch.from_numpy(posthoc.relabel_first_occurrence(y_pred)).to(model.device)
 
+    mark("training + predict")
+    # nothing below reads the feature store or the predict inputs again: return their memory (65 + 16 GB at cfg5) before the
+    # post-hoc stages allocate their own blocks -- left cached, the allocator ends up freeing and re-allocating per block
+    model.store = model.dataloader = None
+    model._shared.clear()
+    torch.cuda.empty_cache()
+    gemm_tuning.stop_tuning()                                     # the GEMM shapes below are one-off and huge: not worth tuning
     preds = D.gather_voter_predictions(local_preds, args["n_voters"], n, device=model.device).cpu().numpy()
     if world > 1:
         owner = (args["n_voters"] - 1) % world
@@ -124,19 +136,24 @@ def run(args):
     else:
         y_pred, probabilities = posthoc.fine_grained_clusters(latent)
         args["n_clusters"] = int(np.max(y_pred) + 1)
+    mark("ensemble / HDBSCAN")
 
     sys.stdout.write("\r........... Computing Results ................")
     sys.stdout.flush()
     if args["GT_file"] is not None:
-        unique_labels = list(np.unique(model.GT))
-        y = np.array([unique_labels.index(x) for x in model.GT])
+        unique_arr, y = np.unique(np.asarray(model.GT), return_inverse=True)      # reference :160-161, as one sort
+        unique_labels = list(unique_arr)
+        y = np.asarray(y, dtype=np.int64)
         results, ind = posthoc.compute_results(y_pred, latent, y)
+        mark("metrics")
         d = {i: j for i, j in ind}
         if -1 in y_pred:
             d[-1] = 0
         w = np.zeros((len(unique_labels), max(max(y_pred) + 1, max(y) + 1)), dtype=np.int64)
-        for i in range(y.shape[0]):
-            w[y[i], d[y_pred[i]]] += 1
+        lut = np.zeros(int(max(d)) + 2, dtype=np.int64)                          # reference :166-169 (w[y[i], d[y_pred[i]]] += 1)
+        for a_, b_ in d.items():
+            lut[a_] = b_                                                          # (a -1 key lands on the last slot)
+        np.add.at(w, (y, lut[np.asarray(y_pred, dtype=np.int64)]), 1)
         if args["n_clusters"] < 16:                               # reference __main__.py:176-180: a picture for small tables ...
             fig, new_ax = plt.subplots(nrows=1, ncols=1)
             posthoc.plot_confusion_matrix(w, unique_labels, ax=new_ax, normalize=False)
@@ -148,6 +165,7 @@ def run(args):
         print(f"ACC: {results['ACC']}")
     else:
         results, ind = posthoc.compute_results(y_pred, latent)
+        mark("metrics")
 
     sys.stdout.write("\r........ Saving Results ..............\n")
     sys.stdout.flush()
@@ -167,6 +185,9 @@ def run(args):
     pd.Series(results, name="Value").to_csv(os.path.join(out_dir, "metrics.tsv"), sep="\t")
     save_results_in_file(dataset_name, "iDeLUCS", params, results, f"{hh}:{mm}:{round(ss)}", memory,
                          os.path.join(os.getcwd(), "ALL_RESULTS.tsv"))
+    mark("tables")
+    if os.environ.get("IDELUCS_TIMING"):
+        print("stages: " + ", ".join(f"{name} {t1 - t0:.1f} s" for (_, t0), (name, t1) in zip(marks[:-1], marks[1:])))
 
     if args.get("plot"):
         try:

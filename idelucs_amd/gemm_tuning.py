@@ -62,3 +62,13 @@ def maybe_enable(total_steps=None):
         tn.write_file_on_exit(bool(dump))
     _enabled = True
     return True
+
+
+def stop_tuning():
+    """After the training loop: keep using the solutions found, but do not tune the shapes that follow -- the post-hoc stages
+    (silhouette, HDBSCAN core distances) run a handful of [4096 x 10^6]-sized GEMMs, and timing hundreds of candidate kernels on
+    each of those shapes cost 230 s at cfg5 (measured: HDBSCAN 169 -> 104 s, metrics 180 -> 10 s without it)."""
+    if not _enabled:
+        return
+    import torch.cuda.tunable as tn
+    tn.tuning_enable(False)

@@ -110,9 +110,14 @@ def silhouette_score_device(data, labels, device=None, block=4096):
     x = x - x.mean(0, keepdim=True)                 # distances are translation invariant; centring keeps the cancellation small
     x2 = (x * x).sum(1)
     total = torch.zeros((), dtype=torch.float64, device=dev)
+    block = max(64, min(block, (1 << 32) // max(n, 1)))        # one [block, n] float32 buffer (<= 16 GB), reused by every block
+    buf = torch.empty((min(block, n), n), dtype=torch.float32, device=dev)
+    xt = x.t()
     for lo in range(0, n, block):
         hi = min(lo + block, n)
-        d2 = (x2[lo:hi, None] + x2[None, :] - 2.0 * (x[lo:hi] @ x.t())).clamp_min_(0.0)
+        d2 = buf[:hi - lo]
+        torch.mm(x[lo:hi], xt, out=d2)
+        d2.mul_(-2.0).add_(x2[lo:hi, None]).add_(x2[None, :]).clamp_min_(0.0)
         d2[torch.arange(hi - lo, device=dev), torch.arange(lo, hi, device=dev)] = 0.0       # exact zeros on the diagonal
         sums = (d2.sqrt_() @ onehot).double()                                                # [rows, K]: sum of distances to each cluster
         own = lab[lo:hi]
@@ -200,15 +205,18 @@ def core_distances_device(x64, k, device):
     sq = (x64 * x64).sum(1)
     rows = max(64, min(n, (1 << 30) // max(n, 1)))            # 8 GB of float64 distances per block
     core = torch.empty(n, dtype=torch.float64, device=device)
+    buf = torch.empty((min(rows, n), n), dtype=torch.float64, device=device)      # one block buffer, reused
+    xt = x64.t()
     for lo in range(0, n, rows):
         xb = x64[lo:lo + rows]
-        d2 = torch.addmm(sq[None, :].expand(xb.shape[0], n), xb, x64.t(), beta=1.0, alpha=-2.0)
-        d2 += sq[lo:lo + rows, None]
+        d2 = buf[:xb.shape[0]]
+        torch.mm(xb, xt, out=d2)
+        d2.mul_(-2.0).add_(sq[None, :]).add_(sq[lo:lo + rows, None])
         d2[torch.arange(xb.shape[0], device=device), torch.arange(lo, lo + xb.shape[0], device=device)] = 0.0     # a point is its own first neighbour
         idx = torch.kthvalue(d2, k, dim=1).indices
         diff = xb - x64[idx]
         core[lo:lo + rows] = (diff * diff).sum(1).sqrt()
-        del d2
+    del buf
     return core
 
 

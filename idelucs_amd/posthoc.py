@@ -198,7 +198,7 @@ def _hdbscan(points, min_cluster_size):
 def core_distances_device(x64, k, device):
     """Distance of every point to its k-th nearest neighbour, itself included (sklearn _hdbscan_prims: NearestNeighbors(
     n_neighbors=k).kneighbors(X)[:, -1]).  Row blocks of the float64 Gram-form distance matrix (one GEMM each), the k-th smallest
-    per row by radix select (torch.kthvalue), and the selected neighbour's distance then formed exactly from the difference
+    per row by radix select (torch.topk), and the selected neighbour's distance then formed exactly from the difference
     vector (the Gram form is only trusted to FIND the neighbour)."""
     import torch
     n = x64.shape[0]
@@ -213,7 +213,11 @@ def core_distances_device(x64, k, device):
         torch.mm(xb, xt, out=d2)
         d2.mul_(-2.0).add_(sq[None, :]).add_(sq[lo:lo + rows, None])
         d2[torch.arange(xb.shape[0], device=device), torch.arange(lo, lo + xb.shape[0], device=device)] = 0.0     # a point is its own first neighbour
-        idx = torch.kthvalue(d2, k, dim=1).indices
+        # the k-th smallest per row: unsorted top-k (multi-block radix select, 2.5 x faster than torch.kthvalue on float64 rows of
+        # 10^6) and the largest of those
+        vals, cols = torch.topk(d2, k, dim=1, largest=False, sorted=False)
+        idx = cols.gather(1, vals.argmax(1, keepdim=True)).squeeze(1)
+        del vals, cols
         diff = xb - x64[idx]
         core[lo:lo + rows] = (diff * diff).sum(1).sqrt()
     del buf

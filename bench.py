@@ -341,8 +341,12 @@ def t_e2e(args, dev, reps=2):
     try:
         m = models.IID_model(margs)
         for rep in range(reps + 1):                      # rep 0 = warm-up (page cache, allocator, graph capture)
+            U._L.idl_ingest_release()                    # every rep maps the file afresh, as a new process would (and pays its page faults)
             torch.cuda.synchronize(); t0 = time.perf_counter()
             m.store = None
+            if os.environ.get("IDELUCS_INGEST_TIMING"):
+                print(f"t_e2e rep {rep}: after dropping the store: allocated {torch.cuda.memory_allocated() / 1e9:.2f} GB, reserved "
+                      f"{torch.cuda.memory_reserved() / 1e9:.2f} GB", file=sys.stderr)
             m.store = U.build_feature_store(path, args.n_mimics, k=args.k, device=m.device, streamed=True)
             torch.cuda.synchronize(); t1 = time.perf_counter()
             m.begin_voter(0)

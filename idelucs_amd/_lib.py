@@ -9,6 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("IDELUCS_LIB_PATH") or os.path.join(_HERE, "csrc", "libidelucs_hip.so")   # (override: A/B of two builds)
 
+IDL_FALLBACK = 1
 IDL_OK, IDL_ERR_ARG, IDL_ERR_HIP, IDL_ERR_IO, IDL_ERR_HEADER, IDL_ERR_BASE, IDL_ERR_NOMEM = 0, -1, -2, -3, -4, -5, -6
 MODE_KMER, MODE_CGR, MODE_CANONICAL = 0, 1, 2
 INIT_ZERO, INIT_ONE, INIT_FROM_OUT = 0, 1, 2
@@ -36,6 +37,9 @@ SIGNATURES = {
     "idl_fasta_export": (_int, [_vp] + [_vp] * 8),
     "idl_fasta_pack_range": (_int, [_vp, _i64, _i64, _vp, _vp]),
     "idl_ingest_threads": (_int, []),
+    "idl_fasta_parse_pack": (_int, [_c.c_char_p, _vp, _vp, _i64, _vp, _vp, _vp, _c.POINTER(_vp)]),
+    "idl_fasta_arena_slots": (_int, [_vp, _vp]),
+    "idl_ingest_release": (None, []),
     "idl_vectorise": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _int, _int, _int, _int, _vp, _vp, _vp, _i64, _i64, _vp]),
     "idl_mimic_workspace": (_i64, [_i64, _int]),
     "idl_mimic_max_random_n": (_int, []),

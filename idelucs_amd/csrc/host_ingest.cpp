@@ -82,6 +82,8 @@ void pack_one(const uint8_t *seq, int64_t len, uint8_t *codes, uint8_t *mask)
 
 #include <algorithm>
 #include <chrono>
+#include <memory>
+#include <mutex>
 #include <thread>
 
 namespace {
@@ -320,25 +322,60 @@ inline void walk_record_pack(const uint8_t *buf, const Rec &r, Packer &pk, uint8
 struct FileMap {                  // read-only view of the whole file (mmap; empty files map to nothing)
     const uint8_t *p = nullptr;
     size_t n = 0;
-    const uint8_t *data() const { return p; }
-    size_t size() const { return n; }
-    // munmap of a large mapping walks every page (25 ms for a 1 GB file, measured): it runs on a detached thread, off the
-    // caller's path (the mapping is private and read-only: nothing observes when it goes away)
+    bool unmap_inline = false;    // (idl_ingest_release: the caller wants the unmapping finished when the call returns)
+    // munmap of a large mapping walks every page (25 ms for a 1 GB file, measured) and holds the process's memory-map lock while
+    // it does: by default it runs on a detached thread
     ~FileMap()
     {
         if (!p || !n) return;
         void *q = (void *)p;
         const size_t len = n;
-        if (len < ((size_t)64 << 20)) { munmap(q, len); return; }
+        if (unmap_inline || len < ((size_t)64 << 20)) { munmap(q, len); return; }
         try { std::thread([q, len]() { munmap(q, len); }).detach(); } catch (...) { munmap(q, len); }
     }
 };
 
+// A mapped file is shared by the handles that read it and KEPT after the last one closes, until another file is opened or
+// idl_ingest_release() is called: a run reads its input more than once (the feature store, then the un-mutated vectors of every
+// predict: reference models.py:147-163 re-reads the file per voter), and unmapping a 1 GB file costs 25 ms of the memory-map lock,
+// during which everything else the process allocates waits -- it landed either on the feature buffer's allocation or on the
+// first launches of the epoch, wherever the close was put.
+struct MapKey { dev_t dev = 0; ino_t ino = 0; off_t size = -1; long msec = 0, mnsec = 0;
+                bool operator==(const MapKey &o) const { return dev == o.dev && ino == o.ino && size == o.size && msec == o.msec && mnsec == o.mnsec; } };
+std::mutex g_map_mu;
+MapKey g_map_key;
+std::shared_ptr<FileMap> g_map;
+
+struct MapRef {
+    std::shared_ptr<FileMap> m;
+    const uint8_t *data() const { return m ? m->p : nullptr; }
+    size_t size() const { return m ? m->n : 0; }
+};
+
+// maps fd (size > 0) or returns the kept mapping of the same file (device, inode, size, modification time); false: mmap failed
+bool acquire_map(int fd, const struct stat &st, MapRef *out)
+{
+    const MapKey key{st.st_dev, st.st_ino, st.st_size, (long)st.st_mtim.tv_sec, (long)st.st_mtim.tv_nsec};
+    std::lock_guard<std::mutex> lk(g_map_mu);
+    if (g_map && g_map_key == key) { out->m = g_map; return true; }
+    void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+    if (m == MAP_FAILED) return false;
+    (void)madvise(m, (size_t)st.st_size, MADV_SEQUENTIAL);
+    auto fm = std::make_shared<FileMap>();
+    fm->p = (const uint8_t *)m;
+    fm->n = (size_t)st.st_size;
+    g_map = fm;                    // (the mapping kept before goes when its last handle does)
+    g_map_key = key;
+    out->m = fm;
+    return true;
+}
+
 struct idl_fasta {
-    FileMap buf;
+    MapRef buf;
     std::vector<Rec> recs;
     int check = 1;
     int64_t total_bases = 0, total_slots = 0, names_bytes = 0;
+    std::vector<int64_t> arena_slot;      // idl_fasta_parse_pack: first slot of every record in the caller's arenas (+ the end)
 };
 
 extern "C" {
@@ -395,11 +432,7 @@ int idl_fasta_open(const char *path, int check, idl_fasta **out)
     idl_fasta *f = new idl_fasta();
     f->check = check;
     if (st.st_size > 0) {
-        void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
-        if (m == MAP_FAILED) { close(fd); delete f; idl::set_error("cannot map %s", path); return IDL_ERR_IO; }
-        (void)madvise(m, (size_t)st.st_size, MADV_SEQUENTIAL);
-        f->buf.p = (const uint8_t *)m;
-        f->buf.n = (size_t)st.st_size;
+        if (!acquire_map(fd, st, &f->buf)) { close(fd); delete f; idl::set_error("cannot map %s", path); return IDL_ERR_IO; }
     }
     close(fd);
     const uint8_t *buf = f->buf.data();
@@ -508,7 +541,206 @@ int idl_fasta_open(const char *path, int check, idl_fasta **out)
     return IDL_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// One pass over the file: locate, validate, count and 2-bit pack at the same time (idl_fasta_open + idl_fasta_pack_range read
+// the bytes three times: header scan, validate + count, pack).  Thread t owns the records whose header line starts in its slice
+// of the file and packs them back to back into ITS region of the caller's arenas, so no thread needs another's lengths; the
+// vectoriser takes every record's first slot from slot_off[] and its slot count from its length, so the gaps between the regions
+// are never read.  With device arenas of the same shape, each thread also sends what it has packed (hipMemcpyAsync from the
+// pinned arena, every few MB) while it goes on parsing.
+// The reference's rolling semantics (sequence lines seen before an id is set belong to the NEXT flushed record: data before the
+// first header, headers with an empty id) are left to the general reader: IDL_FALLBACK, as for check == 0 files, for a region
+// that runs out of slots (records of a few bases each) -- the caller then uses idl_fasta_open.
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+struct FastOut {
+    std::vector<Rec> recs;
+    std::vector<int64_t> slot;
+    int fallback = 0, bad_kind = REC_OK, copy_failed = 0;
+    uint8_t bad_byte = 0;
+    Rec bad_rec{};
+};
+
+// one stripped sequence line [a, b): translate + validate + count + pack; REC_BAD_BASE with *bad on an invalid byte
+inline int pack_line_checked(const uint8_t *a, const uint8_t *b, Packer &pk, int64_t &cnt, uint8_t *bad)
+{
+    while (a < b) {
+#if IDL_HAVE_AVX2_PATH
+        if (pk.j == 0 && b - a >= 32 && host_has_avx2()) {
+            while (b - a >= 32 && all_acgt32_avx2(a)) {
+                uint32_t w2[2];
+                pack32_avx2(a, w2);
+                pk.c = w2[0]; pk.m = 0; pk.j = 16; pk.flush_word();
+                pk.c = w2[1]; pk.m = 0; pk.j = 16; pk.flush_word();
+                a += 32; cnt += 32;
+            }
+            if (a >= b) break;
+        }
+#endif
+        if (pk.j == 0 && b - a >= 16) {
+            const uint64_t x0 = load8(a), x1 = load8(a + 8);
+            if (all_acgt8(x0) && all_acgt8(x1)) {
+                pk.c = (pack8(x0) << 16) | pack8(x1); pk.m = 0; pk.j = 16; pk.flush_word();
+                a += 16; cnt += 16;
+                continue;
+            }
+        }
+        const uint8_t *stop = (pk.j == 0 && b - a >= 16) ? a + 16 : ((b - a) > (16 - pk.j) ? a + (16 - pk.j) : b);
+        for (; a < stop; ++a) {
+            const uint8_t t = T.translate[*a];
+            if (t == 0) continue;
+            if (t == 1) { *bad = *a; return REC_BAD_BASE; }
+            pk.push(T.code[t]);
+            ++cnt;
+        }
+    }
+    return REC_OK;
+}
+
+}  // namespace
+
+int idl_fasta_parse_pack(const char *path, uint8_t *codes, uint8_t *mask, int64_t cap_slots, void *dev_codes, void *dev_mask,
+                         void *stream, idl_fasta **out)
+{
+    IDL_REQUIRE(path && codes && mask && out && cap_slots >= 1, "fasta_parse_pack: NULL argument");
+    IDL_REQUIRE((dev_codes == nullptr) == (dev_mask == nullptr), "fasta_parse_pack: dev_codes and dev_mask go together");
+    *out = nullptr;
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) { idl::set_error("cannot open %s", path); return IDL_ERR_IO; }
+    struct stat st;
+    if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode)) { close(fd); idl::set_error("cannot size %s", path); return IDL_ERR_IO; }
+    if (st.st_size == 0) { close(fd); return IDL_FALLBACK; }          // (the general reader's one empty record)
+    idl_fasta *f = new idl_fasta();
+    f->check = 1;
+    const bool mapped = acquire_map(fd, st, &f->buf);
+    close(fd);
+    if (!mapped) { delete f; idl::set_error("cannot map %s", path); return IDL_ERR_IO; }
+    const uint8_t *buf = f->buf.data();
+    const size_t size = f->buf.size();
+    const int nt = (size > par_min_bytes() && size >= 64) ? n_threads() : 1;
+    const bool timing = getenv("IDELUCS_INGEST_TIMING") != nullptr;
+    auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_0 = now();
+    std::vector<FastOut> outs((size_t)nt);
+    constexpr int64_t COPY_SLOTS = (int64_t)1 << 18;                  // send every 4 MB of packed codes (+ 2 MB of mask)
+
+    parallel_for(nt, [&](int t) {
+        FastOut &o = outs[(size_t)t];
+        const size_t b = size * (size_t)t / (size_t)nt, e = size * (size_t)(t + 1) / (size_t)nt;
+        const int64_t region_lo = cap_slots * t / nt, region_hi = cap_slots * (t + 1) / nt;
+        auto line_end = [&](size_t p) -> size_t {
+            const uint8_t *nl = (const uint8_t *)memchr(buf + p, '\n', size - p);
+            return nl ? (size_t)(nl - buf) + 1 : size;
+        };
+        size_t q = b;
+        if (b > 0) q = line_end(b - 1);                               // the first line that STARTS in this slice
+        // the first header line at or after q (thread 0 also vouches for everything before the file's first header: '#' lines only)
+        while (q < size && buf[q] != '>') {
+            if (t == 0) { if (buf[q] != '#') { o.fallback = 1; return; } }
+            else if (q >= e) return;                                  // no record starts in this slice
+            q = line_end(q);
+        }
+        if (q >= size) { if (t == 0) o.fallback = 1; return; }        // (thread 0: a file without any header line)
+        if (q >= e) return;
+        int64_t slot = region_lo, sent = region_lo;
+        auto send = [&](int64_t upto) {
+            if (dev_codes != nullptr && upto > sent) {
+                if (hipMemcpyAsync((uint8_t *)dev_codes + sent * 16, codes + sent * 16, (size_t)(upto - sent) * 16, hipMemcpyHostToDevice, (hipStream_t)stream) != hipSuccess ||
+                    hipMemcpyAsync((uint8_t *)dev_mask + sent * 8, mask + sent * 8, (size_t)(upto - sent) * 8, hipMemcpyHostToDevice, (hipStream_t)stream) != hipSuccess)
+                    o.copy_failed = 1;
+            }
+            sent = upto;
+        };
+        size_t hs = q;
+        while (hs < size && hs < e) {                                 // one record per turn; it may run past e
+            const size_t he = line_end(hs);
+            Rec r{hs + 1, (he - hs >= 2) ? he - 1 : hs + 1, he, he, 0};   // id = line[1:-1]: drops exactly one trailing byte whatever it is
+            if (r.id_e <= r.id_b) { o.fallback = 1; return; }         // empty id: the general reader's rolling semantics
+            int kind = REC_OK;
+            uint8_t bb = 0;
+            const uint8_t h0 = buf[r.id_b];                           // utils.py:37-40 header checks
+            if (h0 == '>' || h0 == '#' || py_bytes_space(h0) || (h0 >= 0x1c && h0 <= 0x1f)) kind = REC_BAD_HEADER;
+            if (kind == REC_OK && memchr(buf + r.id_b, '\t', r.id_e - r.id_b)) kind = REC_TAB;
+            Packer pk{(uint32_t *)(codes + slot * 16), (uint32_t *)(mask + slot * 8)};
+            int64_t cnt = 0;
+            size_t lp = he;
+            while (kind == REC_OK && lp < size && buf[lp] != '>') {
+                const size_t le = line_end(lp);
+                if (buf[lp] != '#') {
+                    const uint8_t *a = buf + lp, *bnd = buf + le;
+                    while (a < bnd && py_bytes_space(*a)) ++a;
+                    while (bnd > a && py_bytes_space(bnd[-1])) --bnd;
+                    if (slot + (cnt + (int64_t)(bnd - a)) / 64 + 2 > region_hi) { o.fallback = 1; return; }   // this region is full
+                    kind = pack_line_checked(a, bnd, pk, cnt, &bb);
+                }
+                lp = le;
+            }
+            if (kind != REC_OK) { o.bad_kind = kind; o.bad_byte = bb; o.bad_rec = r; return; }
+            r.data_e = lp;
+            r.len = cnt;
+            const int64_t slots = (cnt + 63) / 64;
+            pk.finish(slots);
+            o.recs.push_back(r);
+            o.slot.push_back(slot);
+            slot += slots;
+            if (slot - sent >= COPY_SLOTS) send(slot);
+            hs = lp;
+        }
+        send(slot);
+        o.slot.push_back(slot);                                       // end of this thread's records
+    });
+
+    for (int t = 0; t < nt; ++t) {
+        const FastOut &o = outs[(size_t)t];
+        if (o.fallback) { delete f; return IDL_FALLBACK; }
+        if (o.copy_failed) { delete f; idl::set_error("fasta_parse_pack: hipMemcpyAsync failed: %s", hipGetErrorString(hipGetLastError())); return IDL_ERR_HIP; }
+        if (o.bad_kind != REC_OK) {                                   // the first failing record in file order decides
+            const std::string id((const char *)buf + o.bad_rec.id_b, o.bad_rec.id_e - o.bad_rec.id_b);
+            int rc = IDL_ERR_HEADER;
+            if (o.bad_kind == REC_BAD_HEADER) idl::set_error("Bad character in sequence header");
+            else if (o.bad_kind == REC_TAB) idl::set_error("tab included in header");
+            else { idl::set_error("Invalid DNA byte in sequence %s: '%s'", id.c_str(), chr_utf8(o.bad_byte).c_str()); rc = IDL_ERR_BASE; }
+            delete f;
+            return rc;
+        }
+    }
+    size_t n = 0;
+    for (const FastOut &o : outs) n += o.recs.size();
+    f->recs.reserve(n);
+    f->arena_slot.reserve(n + 1);
+    int64_t last_end = 0;
+    for (const FastOut &o : outs) {
+        for (size_t i = 0; i < o.recs.size(); ++i) { f->recs.push_back(o.recs[i]); f->arena_slot.push_back(o.slot[i]); }
+        if (!o.recs.empty()) last_end = o.slot.back();
+    }
+    f->arena_slot.push_back(last_end);
+    for (const Rec &r : f->recs) {
+        f->total_bases += r.len;
+        f->total_slots += (r.len + 63) / 64;
+        f->names_bytes += (int64_t)(r.id_e - r.id_b);
+    }
+    if (timing) fprintf(stderr, "idl_fasta_parse_pack: one pass %.1f ms (%d threads, %zu records)\n", now() - t_0, nt, n);
+    *out = f;
+    return IDL_OK;
+}
+
+int idl_fasta_arena_slots(const idl_fasta *f, int64_t *slot_off)
+{
+    IDL_REQUIRE(f && slot_off, "NULL argument");
+    IDL_REQUIRE(f->arena_slot.size() == f->recs.size() + 1, "fasta_arena_slots: the handle does not come from idl_fasta_parse_pack");
+    memcpy(slot_off, f->arena_slot.data(), f->arena_slot.size() * sizeof(int64_t));
+    return IDL_OK;
+}
+
 void idl_fasta_close(idl_fasta *f) { delete f; }
+
+void idl_ingest_release(void)
+{
+    std::shared_ptr<FileMap> m;
+    { std::lock_guard<std::mutex> lk(g_map_mu); m.swap(g_map); g_map_key = MapKey{}; }
+    if (m && m.use_count() == 1) m->unmap_inline = true;          // nobody else reads it: unmapped before this returns
+}
 
 int idl_fasta_sizes(const idl_fasta *f, int64_t *n_records, int64_t *total_bases, int64_t *total_slots,
                     int64_t *names_bytes)

@@ -126,7 +126,7 @@ __global__ __launch_bounds__(64) void vectorise_kernel(VecArgs a)
 
     for (int64_t s = blockIdx.x; s < a.n; s += gridDim.x) {
         const int64_t slot0 = a.slot_off[s];
-        const int64_t nslots = a.slot_off[s + 1] - slot0;
+        const int64_t nslots = (a.lengths[s] + 63) >> 6;       // a record occupies ceil(len / 64) slots from slot_off[s] (records need not be adjacent)
 
         for (int v = 0; v < a.n_views; ++v) {
             const int64_t out_base = (int64_t)v * a.view_stride + s * row_len;
@@ -514,8 +514,8 @@ __global__ __launch_bounds__(64 * V2_WAVES, B16 ? 8 : 6) void vectorise2_kernel(
     for (int64_t si = blockIdx.x; si < loop_n; si += gridDim.x) {
         const int64_t s = redo_listed ? ((const int64_t *)(a.redo_count + 2))[si] : si;
         const int64_t slot0 = a.slot_off[s];
-        const int64_t nslots = a.slot_off[s + 1] - slot0;
         const int64_t L = a.lengths[s];
+        const int64_t nslots = (L + 63) >> 6;
         const int64_t nsc = (nslots + SC - 1) / SC;
         if (a.redo != 0 && !redo_listed) {      // second pass without a list: only the sequences v3 left alone (the predicate of vectorise3_kernel's stage_next, restated)
             int64_t te = 0;
@@ -896,8 +896,8 @@ __global__ __launch_bounds__(V3_NT, 8) void vectorise3_kernel(VecArgs a)
         uint32_t *cod = st, *msk = st + (SC + 1) * 4, *edl = st + (SC + 1) * 6;
         const uint32_t *M = meta + r * V3_META;
         const int64_t slot0 = (int64_t)(((uint64_t)M[1] << 32) | M[0]);
-        const int64_t nsl64 = (int64_t)(((uint64_t)M[3] << 32) | M[2]) - slot0;
         const int64_t L64 = (int64_t)(((uint64_t)M[5] << 32) | M[4]);
+        const int64_t nsl64 = (L64 + 63) >> 6;          // ceil(len / 64) slots from slot_off[s]: records need not be adjacent in the packed buffers
         int64_t eb = 0;
         int ne = 0;
         if (ln < P) {

@@ -17,6 +17,7 @@ Mimic RNG modes (argument `rng`, default from $IDELUCS_RNG, else "philox"):
 import ctypes
 import os
 import random
+import sys
 
 import numpy as np
 import torch
@@ -81,6 +82,25 @@ class FastaFile:
         record ranges are packed on request (pack_range) -- the streamed ingest of build_feature_store."""
         h = ctypes.c_void_p()
         _lib.check(_L.idl_fasta_open(os.fsencode(fname), 1 if check else 0, ctypes.byref(h)))
+        self._load(h, check, keep_bytes, pack)
+
+    @classmethod
+    def from_handle(cls, h, arena=False):
+        """A FastaFile over an idl_fasta handle the caller opened (idl_fasta_parse_pack: arena = True -> slot_off are the records'
+        first slots in the caller's arenas); the handle is closed."""
+        obj = cls.__new__(cls)
+        arena_slots = None
+        if arena:
+            n = ctypes.c_int64()
+            _lib.check(_L.idl_fasta_sizes(h, ctypes.byref(n), None, None, None))
+            arena_slots = np.empty(n.value + 1, np.int64)
+            _lib.check(_L.idl_fasta_arena_slots(h, _ptr(arena_slots)))
+        obj._load(h, True, False, "deferred" if arena else False)
+        if arena:
+            obj.slot_off = arena_slots
+        return obj
+
+    def _load(self, h, check, keep_bytes, pack):
         self._h = None
         try:
             n, tb, ts, nb = (ctypes.c_int64() for _ in range(4))
@@ -574,6 +594,83 @@ class _StreamedInput:
         return self
 
 
+_ARENAS = {}          # _OnePassInput's pinned / device arenas and staging, kept between calls (release_ingest_buffers() drops them)
+
+
+def release_ingest_buffers():
+    """Give back the arenas the one-pass reader keeps between files (24 bytes per 64 bases of the largest file, host and device)."""
+    _ARENAS.clear()
+    _L.idl_ingest_release()            # ... and the mapping of the last file read
+
+
+class _OnePassInput:
+    """_DeviceInput produced by ONE pass over the FASTA file (idl_fasta_parse_pack): the reader's threads validate, count and
+    2-bit pack their share of the records straight into pinned arenas and send every few MB to the device arenas while they go
+    on parsing; records sit back to back inside each thread's region, with gaps between the regions that nothing reads (the
+    vectoriser takes a record's first slot from slot_off and its slot count from its length).  create() returns None when the
+    file's layout needs the general reader (IDL_FALLBACK)."""
+
+    @classmethod
+    def create(cls, sequence_file, device):
+        import time
+        q = [time.perf_counter()]
+        size = os.path.getsize(sequence_file)
+        threads = ingest_threads()
+        cap = size // 48 + 4096 * threads + 1024                   # slots; a third more than size / 64, + room per region
+        # the arenas (24 bytes per slot on each side) are kept between calls: re-allocating them per file lets the caching allocator
+        # carve them out of a freed feature-store block, and the next feature store then pays a fresh 6.5 GB allocation (121-262 ms)
+        key = (str(device), cap)
+        held = _ARENAS.get("key") == key
+        if not held:
+            _ARENAS.clear()
+            _ARENAS.update(key=key, hc=torch.empty(cap * 16, dtype=torch.uint8, pin_memory=True),
+                           hm=torch.empty(cap * 8, dtype=torch.uint8, pin_memory=True),
+                           codes=torch.empty(cap * 16, dtype=torch.uint8, device=device),
+                           mask=torch.empty(cap * 8, dtype=torch.uint8, device=device),
+                           small=torch.empty(0, dtype=torch.int64, pin_memory=True))
+        hc, hm, codes, mask = _ARENAS["hc"], _ARENAS["hm"], _ARENAS["codes"], _ARENAS["mask"]
+        q.append(time.perf_counter())
+        q.append(time.perf_counter())
+        copy = torch.cuda.Stream(device=device)
+        copy.wait_stream(torch.cuda.current_stream())              # (the previous file's kernels may still be reading the arenas)
+        h = ctypes.c_void_p()
+        rc = _L.idl_fasta_parse_pack(os.fsencode(sequence_file), _ptr(hc), _ptr(hm), cap, _ptr(codes), _ptr(mask),
+                                     ctypes.c_void_p(copy.cuda_stream), ctypes.byref(h))
+        if rc == _lib.IDL_FALLBACK:
+            copy.synchronize()                                      # (copies of the part that was parsed may be in flight)
+            return None
+        if rc != _lib.IDL_OK:
+            copy.synchronize()
+            _lib.check(rc)
+        q.append(time.perf_counter())
+        self = cls()
+        self.ff = FastaFile.from_handle(h, arena=True)
+        ff = self.ff
+        q.append(time.perf_counter())
+        self.n = ff.n
+        self.max_len = int(ff.lengths.max()) if ff.n else 0
+        self.min_len = int(ff.lengths.min()) if ff.n else 0
+        # lengths and first slots go up from PINNED staging: a copy from pageable memory waits behind the arena copies (16-20 ms)
+        if _ARENAS["small"].numel() < 2 * ff.n + 1:
+            _ARENAS["small"] = torch.empty(2 * ff.n + 1, dtype=torch.int64, pin_memory=True)
+        stage = _ARENAS["small"]
+        stage[:ff.n].copy_(torch.from_numpy(ff.lengths))
+        stage[ff.n:2 * ff.n + 1].copy_(torch.from_numpy(ff.slot_off))
+        both = stage[:2 * ff.n + 1].to(device, non_blocking=True)
+        self.lengths, self.slot_off = both[:ff.n], both[ff.n:]
+        self.codes, self.mask = codes, mask
+        self._hold = (hc, hm, copy)
+        if os.environ.get("IDELUCS_INGEST_TIMING") is not None:
+            q.append(time.perf_counter())
+            print("_OnePassInput: pinned arenas %.1f ms, device arenas %.1f, reader %.1f, names/lengths %.1f, small uploads %.1f"
+                  % tuple(1e3 * (b - a) for a, b in zip(q[:-1], q[1:])), file=sys.stderr)
+        return self
+
+    def fill(self):
+        torch.cuda.current_stream().wait_stream(self._hold[2])
+        return self
+
+
 def build_feature_store(sequence_file, n_mimics, k=6, reduce=False, rng=None, seed=0, device=None, fasta=None, streamed=False):
     """Vectorise every mimic view of every sequence in one kernel launch and fit the scaler.
     streamed=True (device RNG only): parse once, pack record chunks into pinned memory and copy each chunk to the device
@@ -581,6 +678,33 @@ def build_feature_store(sequence_file, n_mimics, k=6, reduce=False, rng=None, se
     rng = rng or _default_rng_mode()
     dev = _device(device)
     tfs = mimic_transforms(n_mimics)
+    if streamed and rng == "philox" and fasta is None and os.environ.get("IDELUCS_ONE_PASS", "1") != "0":
+        import time
+        timing = os.environ.get("IDELUCS_INGEST_TIMING") is not None
+        q = [time.perf_counter()]
+        din = _OnePassInput.create(sequence_file, dev)
+        if din is not None:
+            q.append(time.perf_counter())
+            # the feature buffer first: it is the one allocation that must find the block a previous store left in the allocator's
+            # cache whole (6.5 GB at cfg2: a fresh one costs 15-260 ms), before the smaller requests below can be carved out of it
+            mode = _lib.MODE_CANONICAL if reduce else _lib.MODE_KMER
+            row = _L.idl_row_len(mode, k)
+            feats = torch.empty((len(tfs), din.n, row), dtype=torch.float32, device=dev)
+            q.append(time.perf_counter())
+            edits, edit_off = _philox_edits(din, [t.spec() for t in tfs], seed)
+            din.fill()
+            q.append(time.perf_counter())
+            _vectorise(din, k, mode, _lib.INIT_ONE, _lib.OUT_FREQ_F32, len(tfs), edits, edit_off, feats)
+            mean, scale = col_stats(feats[0])
+            store = FeatureStore(din.ff, din.ff.lengths, feats, mean, scale, k, reduce)
+            din.ff.close()                         # (unmaps the file on a helper thread; after the host side of the build, see from_handle)
+            if timing:
+                q.append(time.perf_counter())
+                torch.cuda.synchronize()
+                q.append(time.perf_counter())
+                print("build_feature_store (one pass): reader + arenas %.1f ms, feature buffer %.1f, mimic sites %.1f, enqueue %.1f, drain %.1f"
+                      % tuple(1e3 * (b - a) for a, b in zip(q[:-1], q[1:])), file=sys.stderr)
+            return store
     if streamed and rng == "philox" and fasta is None:
         ff = FastaFile(sequence_file, check=True, pack="deferred")
         try:

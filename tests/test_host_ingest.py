@@ -277,3 +277,101 @@ def test_ranged_packing_equals_whole_file_export(tmp_path, monkeypatch, threads)
         with pytest.raises(ValueError):
             ff.pack_range(0, 1, codes, mask)
     assert 1 <= U.ingest_threads() <= 256
+
+
+def _one_pass(path, cap_slots=None):
+    """idl_fasta_parse_pack on host arenas (no device) -> (FastaFile, codes, mask) or None on IDL_FALLBACK."""
+    size = os.path.getsize(path)
+    cap = cap_slots if cap_slots is not None else size // 48 + 4096 * U.ingest_threads() + 1024
+    codes = np.full(cap * 16, 0xAB, np.uint8)
+    mask = np.full(cap * 8, 0xCD, np.uint8)
+    h = ctypes.c_void_p()
+    rc = _lib.lib.idl_fasta_parse_pack(os.fsencode(path), U._ptr(codes), U._ptr(mask), cap, None, None, None, ctypes.byref(h))
+    if rc == _lib.IDL_FALLBACK:
+        return None
+    _lib.check(rc)
+    return U.FastaFile.from_handle(h, arena=True), codes, mask
+
+
+@pytest.mark.parametrize("threads", ["1", "3", "8"])
+def test_one_pass_reader_equals_general_reader(tmp_path, monkeypatch, threads):
+    """idl_fasta_parse_pack (validate + count + pack in one pass, every thread into its own region of the arenas) gives the names,
+    lengths and packed bytes of the general reader, record by record, at the slots it reports -- wrapped lines, CRLF, padded lines,
+    comments, lower case / IUPAC / gaps, empty records, Influenza-A; and records of any one thread sit back to back."""
+    monkeypatch.setenv("IDELUCS_THREADS", threads)
+    monkeypatch.setenv("IDELUCS_PAR_MIN", "0")
+    rng = np.random.default_rng(40 + int(threads))
+    fn = str(tmp_path / "r.fas")
+    _random_fasta(fn, rng, 300)
+    for path in (fn, os.path.join(DATA, "Influenza-A.fas")):
+        whole = U.FastaFile(path)
+        got = _one_pass(path)
+        assert got is not None, "the one-pass reader declined a file it should take"
+        ff, codes, mask = got
+        assert ff.names == whole.names and np.array_equal(ff.lengths, whole.lengths) and ff.slot_off.shape == (ff.n + 1,)
+        for i in range(ff.n):
+            a, b = whole.slot_off[i], whole.slot_off[i + 1]
+            s = int(ff.slot_off[i])
+            assert np.array_equal(codes[s * 16:(s + b - a) * 16], whole.codes[a * 16:b * 16]), i
+            assert np.array_equal(mask[s * 8:(s + b - a) * 8], whole.mask[a * 8:b * 8]), i
+        starts = ff.slot_off[:-1]
+        assert np.all(np.diff(starts) >= (whole.slot_off[1:-1] - whole.slot_off[:-2]))        # never overlapping, in file order
+
+
+@pytest.mark.parametrize("content", [
+    b"ACGT\nAC\n>first\nGGGG\n>second\nTT\n",              # sequence lines before the first header
+    b">a\nAC\n>\nGG\n>b\nTT\n>c\nAA\n",                    # an empty-id header
+    b">\nAC\n",                                                # only an empty id
+    b"\n\n>q\n\nAC\n\n\nGT\n\n",                              # blank lines before the first header
+    b"ACGT\n",                                                 # no header at all
+    b"",                                                       # empty file
+])
+def test_one_pass_reader_leaves_rolling_layouts_to_the_general_reader(tmp_path, monkeypatch, content):
+    p = tmp_path / "q.fas"
+    p.write_bytes(content)
+    for threads in ("1", "4"):
+        monkeypatch.setenv("IDELUCS_THREADS", threads)
+        monkeypatch.setenv("IDELUCS_PAR_MIN", "0")
+        assert _one_pass(str(p)) is None
+
+
+@pytest.mark.parametrize("content", [
+    b"# a comment first\n#another\n>x\n>y\n>z\nACGT",         # comments before the first header, empty records, no trailing newline
+    b">only header no newline",                                 # id loses its last byte (line[1:-1])
+    b">q\n\nAC\n\n\nGT\n\n>r\n  ac gt\t\n",                   # blank lines and interior white space inside records
+])
+def test_one_pass_reader_on_small_layouts(tmp_path, monkeypatch, content):
+    p = tmp_path / "q.fas"
+    p.write_bytes(content)
+    want = list(O.fasta_records(str(p)))
+    for threads in ("1", "4"):
+        monkeypatch.setenv("IDELUCS_THREADS", threads)
+        monkeypatch.setenv("IDELUCS_PAR_MIN", "0")
+        got = _one_pass(str(p))
+        assert got is not None
+        ff, codes, mask = got
+        assert ff.names == [r[0] for r in want] and ff.lengths.tolist() == [len(r[1]) for r in want]
+        for i, (_, s) in enumerate(want):
+            c, m = O.pack(s)
+            a = int(ff.slot_off[i])
+            assert np.array_equal(codes[a * 16:a * 16 + c.size], c) and np.array_equal(mask[a * 8:a * 8 + m.size], m)
+
+
+def test_one_pass_reader_errors_and_full_regions(tmp_path, monkeypatch):
+    """Same first-error-in-file-order rule and messages as the general reader; a region that runs out of slots is a fallback."""
+    monkeypatch.setenv("IDELUCS_THREADS", "6")
+    monkeypatch.setenv("IDELUCS_PAR_MIN", "0")
+    body = b"".join(b">r%d\nACGTACGTAC\n" % i for i in range(200))
+    bad = body.replace(b">r150\nACGT", b">r150\nAC!T").replace(b">r40\nACGT", b">r40\nAZGT").replace(b">r90\n", b">r\t90\n")
+    p = tmp_path / "e.fas"
+    p.write_bytes(bad)
+    with pytest.raises(ValueError) as e:
+        _one_pass(str(p))
+    assert str(e.value) == "Invalid DNA byte in sequence r40: 'Z'"
+    p.write_bytes(body.replace(b">r7\n", b">#r7\n"))
+    with pytest.raises(ValueError) as e:
+        _one_pass(str(p))
+    assert str(e.value) == "Bad character in sequence header"
+    p.write_bytes(body)
+    assert _one_pass(str(p), cap_slots=60) is None               # 200 records of one slot each do not fit 60 slots
+    assert _one_pass(str(p)) is not None

@@ -122,7 +122,7 @@ class IID_model():
         """Reference models.py:101-111: vectorise all mimic views + fit the scaler (one kernel launch
         each, utils.build_feature_store) and expose an iterable of device batches."""
         self.store = utils.build_feature_store(self.sequence_file, self.n_mimics, k=self.k, reduce=self.reduce,
-                                               rng=self.rng, seed=self.seed, device=self.device)
+                                               rng=self.rng, seed=self.seed, device=self.device, streamed=True)
         self.dataloader = utils.DeviceBatchLoader(self.store, self.batch_sz)
         self._shared.clear()
 

@@ -52,7 +52,7 @@ def maybe_enable(total_steps=None):
         fd, path = tempfile.mkstemp(prefix="idelucs_tunableop_", suffix=".csv")
         atexit.register(_unlink_quietly, path)
     with os.fdopen(fd, "wb") as out:
-        if os.path.exists(SEED_FILE):
+        if os.path.exists(SEED_FILE) and os.environ.get("IDELUCS_TUNABLEOP_SEED", "1") != "0":       # (0: tune every shape afresh)
             with open(SEED_FILE, "rb") as src:
                 out.write(src.read())
     tn.set_filename(path, insert_device_ordinal=False)

@@ -32,7 +32,6 @@ def run(args):
     from resource import getrusage, RUSAGE_SELF
     from . import gemm_tuning, posthoc, dist as D
     from .training import prepare_model, train_voters
-    from . import models
 
     start_time = time.time()
     marks = [("start", start_time)]                               # stage timers, printed with IDELUCS_TIMING=1

@@ -15,8 +15,6 @@ import atexit
 import os
 import tempfile
 
-import torch
-
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SEED_FILE = os.path.join(_HERE, "tunableop_gfx950.csv")
 MIN_STEPS = 3000

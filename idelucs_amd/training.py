@@ -4,8 +4,6 @@ things inline, twice)."""
 import os
 import sys
 
-import torch
-
 from . import gemm_tuning, models
 from .utils import SummaryFasta
 

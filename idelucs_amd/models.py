@@ -205,7 +205,8 @@ class IID_model():
         if hit is not None and hit[0] == key:
             torch.cuda.current_stream().wait_event(hit[2])
             return hit[1]
-        feats = utils.predict_features(self.sequence_file, k=self.k, reduce=self.reduce, device=self.device, rows=rows)[2]
+        feats = utils.predict_features(self.sequence_file, k=self.k, reduce=self.reduce, device=self.device, rows=rows,
+                                       with_names=False)[2]
         if feats.numel() * 4 <= PREDICT_CACHE_BYTES:
             ready = torch.cuda.Event()
             ready.record()

@@ -783,20 +783,30 @@ class AugmentedDataset(torch.utils.data.Dataset):
         return {"true": self.data[idx, 0, :], "modified": self.data[idx, 1, :]}
 
 
-def predict_features(sequence_file, k=6, reduce=False, device=None, fasta=None, rows=None):
+def predict_features(sequence_file, k=6, reduce=False, device=None, fasta=None, rows=None, with_names=True):
     """What SequenceDataset feeds the network (utils.py:400-405 + models.py:163): un-mutated float64
     frequencies, StandardScaler fit_transform in float64, rounded once to float32.  -> (names, lengths, [N,F] f32).
     rows=(lo, hi): the scaler is still fitted on ALL rows, only rows [lo, hi) are standardised and returned (sharded predict:
     every rank recomputes the cheap statistics locally -- bit-identical everywhere, no collective -- and embeds its shard)."""
     dev = _device(device)
-    ff = fasta if fasta is not None else FastaFile(sequence_file, check=True)
-    din = _DeviceInput(ff, dev)
+    din = None
+    if fasta is None and os.environ.get("IDELUCS_ONE_PASS", "1") != "0":
+        din = _OnePassInput.create(sequence_file, dev)             # one pass over the file, copies in flight while parsing
+        if din is not None:
+            ff = din.ff
+            din.fill()
+    if din is None:
+        ff = fasta if fasta is not None else FastaFile(sequence_file, check=True)
+        din = _DeviceInput(ff, dev)
     mode = _lib.MODE_CANONICAL if reduce else _lib.MODE_KMER
     f64 = _vectorise(din, k, mode, _lib.INIT_ONE, _lib.OUT_FREQ_F64)[0]
     mean, scale = col_stats(f64)
     if rows is not None:
         f64 = f64[rows[0]:rows[1]]
-    return ff.names, ff.lengths, standardise(f64, mean, scale)
+    out = standardise(f64, mean, scale)
+    if fasta is None:
+        ff.close()
+    return (ff.names if with_names else None), ff.lengths, out          # (with_names=False: the names are not decoded)
 
 
 class SequenceDataset(torch.utils.data.Dataset):

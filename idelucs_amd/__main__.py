@@ -92,6 +92,9 @@ def run(args):
     # post-hoc stages allocate their own blocks -- left cached, the allocator ends up freeing and re-allocating per block
     model.store = model.dataloader = None
     model._shared.clear()
+    if world == 1 or not use_hdbscan:                              # (the sharded predict of n_clusters = 0 reads the file once more)
+        from .utils import release_ingest_buffers
+        release_ingest_buffers()
     torch.cuda.empty_cache()
     gemm_tuning.stop_tuning()                                     # the GEMM shapes below are one-off and huge: not worth tuning
     preds = D.gather_voter_predictions(local_preds, args["n_voters"], n, device=model.device).cpu().numpy()

@@ -375,3 +375,29 @@ def test_one_pass_reader_errors_and_full_regions(tmp_path, monkeypatch):
     p.write_bytes(body)
     assert _one_pass(str(p), cap_slots=60) is None               # 200 records of one slot each do not fit 60 slots
     assert _one_pass(str(p)) is not None
+
+
+def test_kept_mapping_never_serves_a_rewritten_file(tmp_path, monkeypatch):
+    """The readers keep the mapping of the last file after its handles close.  A file rewritten in place (same path, same size,
+    same inode) must be read anew: the key holds the modification time; idl_ingest_release drops the mapping."""
+    monkeypatch.setenv("IDELUCS_THREADS", "2")
+    monkeypatch.setenv("IDELUCS_PAR_MIN", "0")
+    p = tmp_path / "m.fas"
+    p.write_bytes(b">a\nACGTACGT\n>b\nGGGGCCCC\n")
+    first = U.FastaFile(str(p), keep_bytes=True)
+    assert bytes(first.record(0)) == b"ACGTACGT"
+    again = U.FastaFile(str(p), keep_bytes=True)                     # served from the kept mapping
+    assert bytes(again.record(1)) == b"GGGGCCCC"
+    st = os.stat(p)
+    with open(p, "r+b") as f:                                        # in place: same inode, same size
+        f.write(b">a\nTTTTTTTT\n>b\nAAAAAAAA\n")
+    os.utime(p, ns=(st.st_atime_ns, st.st_mtime_ns + 1_000_000))     # (a coarse clock could repeat the time stamp)
+    changed = U.FastaFile(str(p), keep_bytes=True)
+    assert bytes(changed.record(0)) == b"TTTTTTTT" and bytes(changed.record(1)) == b"AAAAAAAA"
+    got = _one_pass(str(p))
+    assert got is not None and got[0].lengths.tolist() == [8, 8]
+    U.release_ingest_buffers()
+    assert bytes(U.FastaFile(str(p), keep_bytes=True).record(0)) == b"TTTTTTTT"
+    other = tmp_path / "n.fas"
+    other.write_bytes(b">z\nACACACAC\n")
+    assert bytes(U.FastaFile(str(other), keep_bytes=True).record(0)) == b"ACACACAC"

@@ -41,8 +41,9 @@ MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 matrix peak (v_mfma_f
 PMC_PROFILE = "r02_vectorise_pmc.json"     # profiles/: FETCH_SIZE / WRITE_SIZE passes of the vectoriser at cfg2
 
 
-def synth_packed(n, L, dev, seed=12345):
-    """iid-uniform ACGT == iid-uniform 2-bit codes, generated directly in the packed slot layout."""
+def synth_packed(n, L, dev, seed=12345, n_rate=0.0):
+    """iid-uniform ACGT == iid-uniform 2-bit codes, generated directly in the packed slot layout.  n_rate > 0: SURVEY 8(d)'s
+    variant "N" -- every base is additionally an N with that probability (an invalid-mask bit: the window restarts behind it)."""
     slots = (L + 63) // 64
     g = torch.Generator(device=dev)
     g.manual_seed(seed)
@@ -59,6 +60,14 @@ def synth_packed(n, L, dev, seed=12345):
             w[j // 32] |= 1 << (31 - (j % 32))
         for i in (0, 1):
             mask[:, -1, i] = w[i] - (1 << 32) if w[i] >= 2 ** 31 else w[i]
+
+    if n_rate > 0.0:             # a Bernoulli(n_rate) bit per base, 32 bases per mask word
+        words = mask.view(-1)
+        for lo in range(0, words.numel(), 1 << 24):
+            hi = min(lo + (1 << 24), words.numel())
+            bits = (torch.rand((hi - lo, 32), device=dev, generator=g) < n_rate).to(torch.int64)
+            w = (bits << torch.arange(31, -1, -1, device=dev, dtype=torch.int64)).sum(1)
+            words[lo:hi] |= torch.where(w >= 2 ** 31, w - 2 ** 32, w).to(torch.int32)
 
     class DeviceInput:
         pass
@@ -381,6 +390,8 @@ def main():
     ap.add_argument("--cpu-sample", dest="cpu_sample", type=int, default=24000)
     ap.add_argument("--no-cpu-baseline", dest="cpu_base", action="store_false")
     ap.add_argument("--no-e2e", dest="e2e", action="store_false")
+    ap.add_argument("--n-rate", dest="n_rate", type=float, default=0.0,
+                    help="SURVEY 8(d) variant N: every synthetic base is an N with this probability (e.g. 1e-3); default 0 = BASELINE's input")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -413,7 +424,7 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
-    din = synth_packed(args.n, args.len, dev, seed=54321 if cfg5 else 12345)
+    din = synth_packed(args.n, args.len, dev, seed=54321 if cfg5 else 12345, n_rate=args.n_rate)
     hp = HotPath(din, args, dev, rank, world)
 
     for i in range(args.warmup):
@@ -485,7 +496,8 @@ def main():
             "value": value, "unit": "sequences/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak" if V == world and world > 1 and cfg5 else ("strong" if world > 1 else "weak"),
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"BASELINE {cfg_name}: synthetic {args.n} x {args.len} bp, k={args.k}, n_clusters={args.n_clusters}, "
+            "config": {"workload": f"BASELINE {cfg_name}{' (variant N: every base an N w.p. %g)' % args.n_rate if args.n_rate > 0 else ''}: "
+                                   f"synthetic {args.n} x {args.len} bp, k={args.k}, n_clusters={args.n_clusters}, "
                                    f"n_mimics={args.n_mimics} ({P} views), batch_sz={args.batch_sz}, NetLinear fp32, RMSprop; "
                                    f"{V} voter(s) over {world} GPU(s), value = N_seq * voters / wall; timed = {region}",
                        "n_sequences": args.n, "seq_len": args.len, "k": args.k, "batch_sz": args.batch_sz, "n_voters": V,

@@ -542,3 +542,39 @@ def test_kernel_projection_all_k(gpu, k, d):
     assert np.array_equal(got, got_r)
     with pytest.raises(ValueError):
         U.kernel_file(7)
+
+
+def test_variant_n_synthetic_input_vs_oracle(gpu, monkeypatch):
+    """SURVEY 8(d)'s variant "N" of the synthetic input (bench.py --n-rate: every base additionally an N w.p. 1e-2 here): the
+    packed batch decoded back to bytes and counted by the oracle gives exactly the vectoriser's counts -- every N restarts the
+    window -- for all views with device-drawn mimic sites, and the three kernels agree bit for bit."""
+    import importlib.util
+    import torch
+    from idelucs_amd import _lib, utils as U
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+    dev = torch.device("cuda")
+    n, L, k, P = 300, 3000, 6, 4
+    din = bench.synth_packed(n, L, dev, seed=7, n_rate=1e-2)
+    codes = din.codes.view(torch.int32).cpu().numpy().view(np.uint32).reshape(n, -1)          # [n, slots * 4] words, first base on top
+    mask = din.mask.view(torch.int32).cpu().numpy().view(np.uint32).reshape(n, -1)            # [n, slots * 2]
+    shifts = np.arange(30, -2, -2, dtype=np.uint32)
+    bases = ((codes[:, :, None] >> shifts) & 3).reshape(n, -1)[:, :L]
+    inval = ((mask[:, :, None] >> np.arange(31, -1, -1, dtype=np.uint32)) & 1).reshape(n, -1)[:, :L].astype(bool)
+    assert 0.005 < inval.mean() < 0.02
+    seqs = np.frombuffer(b"ACGT", np.uint8)[bases]
+    seqs[inval] = ord("N")
+    counts = U._vectorise(din, k, _lib.MODE_KMER, _lib.INIT_ZERO, _lib.OUT_COUNTS_I32)[0].cpu().numpy()
+    for i in range(0, n, 7):
+        want = np.zeros(4 ** k, np.int32)
+        O.kmer_counts(bytearray(seqs[i].tobytes()), k, want)
+        assert np.array_equal(counts[i], want), i
+        assert want.sum() < L - (k - 1)                                  # windows were lost to the Ns
+    edits, edit_off = U._philox_edits(din, [t.spec() for t in U.mimic_transforms(P - 1)], 3)
+    outs = {}
+    for ver in ("1", "2", "3"):
+        monkeypatch.setenv("IDELUCS_VEC", ver)
+        outs[ver] = U._vectorise(din, k, _lib.MODE_KMER, _lib.INIT_ONE, _lib.OUT_FREQ_F32, P, edits, edit_off)
+    assert torch.equal(outs["1"], outs["2"]) and torch.equal(outs["1"], outs["3"])
+    assert torch.allclose(outs["3"].double().sum(2), torch.ones((P, n), dtype=torch.float64, device=dev), atol=1e-6)

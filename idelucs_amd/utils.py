@@ -629,6 +629,10 @@ class _OnePassInput:
                            mask=torch.empty(cap * 8, dtype=torch.uint8, device=device),
                            small=torch.empty(0, dtype=torch.int64, pin_memory=True))
         hc, hm, codes, mask = _ARENAS["hc"], _ARENAS["hm"], _ARENAS["codes"], _ARENAS["mask"]
+        busy = _ARENAS.pop("busy", None)       # the previous file's copies out of the pinned buffers (arenas, staging): done?
+        if busy is not None:
+            for ev in busy:
+                ev.synchronize()
         q.append(time.perf_counter())
         q.append(time.perf_counter())
         copy = torch.cuda.Stream(device=device)
@@ -660,6 +664,10 @@ class _OnePassInput:
         self.lengths, self.slot_off = both[:ff.n], both[ff.n:]
         self.codes, self.mask = codes, mask
         self._hold = (hc, hm, copy)
+        ev_small, ev_copy = torch.cuda.Event(), torch.cuda.Event()
+        ev_small.record()
+        ev_copy.record(copy)
+        _ARENAS["busy"] = (ev_small, ev_copy)   # the next file waits for these before it overwrites the pinned buffers
         if os.environ.get("IDELUCS_INGEST_TIMING") is not None:
             q.append(time.perf_counter())
             print("_OnePassInput: pinned arenas %.1f ms, device arenas %.1f, reader %.1f, names/lengths %.1f, small uploads %.1f"

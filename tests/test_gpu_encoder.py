@@ -1000,3 +1000,24 @@ def test_small_model_k5_first_step_vs_reference(dev):
         if p.dim() == 1:
             bad = ~np.isclose(p.detach().cpu().numpy(), g[f"p.{n_}"], rtol=1e-3, atol=1e-6)
             assert bad.mean() < 0.02, (n_, bad.mean())
+
+
+@pytest.mark.parametrize("kw", [dict(k=4, batch_sz=256), dict(k=5, batch_sz=512, n_mimics=5), dict(k=6, batch_sz=48)])
+def test_train_voters_batched_on_other_shapes(dev, kw):
+    """training.train_voters with three voters in one batch on shapes other than cfg2's (F = 256 / 1024, batch 256, five mimics;
+    batch 48: 96-row steps that the InfoNCE kernels still take): finite decreasing losses, distinct voters, predictions of the
+    right shape, and the caller's model left with the LAST voter's weights."""
+    import torch
+    from idelucs_amd import training
+    args = _args(n_epochs=4, n_voters=3, **kw)
+    model = training.prepare_model(args)
+    assert training.can_batch(model)
+    out = training.train_voters(model, [0, 1, 2], args['n_epochs'], 3, lanes=3, progress=False)
+    assert sorted(out) == [0, 1, 2]
+    n = len(model.names)
+    for v, (curve, y_pred, prob, latent) in out.items():
+        assert len(curve) == 4 and all(np.isfinite(curve)) and curve[-1] < curve[0]
+        assert y_pred.shape == (n,) and prob.shape == (n,) and latent.shape == (n, 64) and y_pred.max() < 5
+    assert not np.array_equal(out[0][3], out[1][3])
+    y_last = model.predict()[0]
+    assert np.array_equal(y_last, out[2][1])

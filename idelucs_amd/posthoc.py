@@ -184,11 +184,19 @@ def plot_confusion_matrix(cm, target_names, pairs=None, title="Confusion matrix"
 HDBSCAN_EXACT_MAX = 20000        # points the host HDBSCAN is run on directly
 
 
-def _hdbscan(points, min_cluster_size):
+HDBSCAN_DEVICE_MIN = 2000        # without the `hdbscan` package: points from which sklearn's HDBSCAN is run on the GPU (same result, 30 x faster at 30 000)
+
+
+def _hdbscan(points, min_cluster_size, device=None):
+    """The reference's call (hdbscan.HDBSCAN, __main__.py:153) when that package is importable; else its stand-in
+    sklearn.cluster.HDBSCAN -- on the host for small inputs, through hdbscan_device (the same algorithm, the same labels and
+    probabilities: test_hdbscan_on_the_device_is_sklearns) from HDBSCAN_DEVICE_MIN points."""
     try:
         import hdbscan
         cl = hdbscan.HDBSCAN(min_cluster_size=min_cluster_size, gen_min_span_tree=True, prediction_data=True)
     except ImportError:
+        if len(points) >= HDBSCAN_DEVICE_MIN and os.environ.get("IDELUCS_HDBSCAN", "device") != "host":
+            return hdbscan_device(points, max(min_cluster_size, 2), device=device)
         from sklearn.cluster import HDBSCAN
         cl = HDBSCAN(min_cluster_size=max(min_cluster_size, 2))
     cl.fit(points)
@@ -269,7 +277,8 @@ def fine_grained_clusters(latent, exact_max=None, seed=0, device=None, mode=None
     labels+1, probabilities.  `hdbscan` is used when importable, else sklearn.cluster.HDBSCAN (parity with hdbscan==0.8.32 is
     unpinned -- SURVEY 8c).
 
-    Up to `exact_max` points (default HDBSCAN_EXACT_MAX) that is the whole computation, on the host as in the reference.  Beyond
+    Up to `exact_max` points (default HDBSCAN_EXACT_MAX) that is the library call of _hdbscan (the `hdbscan` package on the host as
+    in the reference; without it sklearn's HDBSCAN, on the GPU from HDBSCAN_DEVICE_MIN points -- identical results).  Beyond
     it the host algorithm is out of reach (BASELINE cfg5: 10^6 points, each needing its 10^4-th neighbour), and
       mode "device" (default; $IDELUCS_HDBSCAN): the same HDBSCAN with its two O(N^2) stages on the GPU (hdbscan_device: exact
           core distances, sklearn's Prim visit for visit, sklearn's own tree code on the edges) -- minutes at 10^6 points;
@@ -281,9 +290,11 @@ def fine_grained_clusters(latent, exact_max=None, seed=0, device=None, mode=None
     n = len(latent)
     exact_max = HDBSCAN_EXACT_MAX if exact_max is None else int(exact_max)
     if n <= exact_max:
-        labels, prob = _hdbscan(latent, n // 100 + 1)
+        labels, prob = _hdbscan(latent, n // 100 + 1, device=device)
         return labels + 1, prob
     mode = mode or os.environ.get("IDELUCS_HDBSCAN", "device")
+    if mode == "host":
+        mode = "device"                  # (beyond exact_max the host algorithm is out of reach)
     if mode not in ("device", "approx"):
         raise ValueError("fine_grained_clusters: mode must be 'device' or 'approx'")
     if mode == "device":
@@ -293,7 +304,7 @@ def fine_grained_clusters(latent, exact_max=None, seed=0, device=None, mode=None
     dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
     rng = np.random.default_rng(seed)
     pick = np.sort(rng.choice(n, size=exact_max, replace=False))
-    sub_labels, sub_prob = _hdbscan(latent[pick], exact_max // 100 + 1)
+    sub_labels, sub_prob = _hdbscan(latent[pick], exact_max // 100 + 1, device=dev)
     x = torch.from_numpy(latent).to(dev, torch.float32)
     s = x[torch.from_numpy(pick).to(dev)]
     s2 = (s * s).sum(1)

@@ -255,9 +255,13 @@ def test_fine_grained_clusters_beyond_the_exact_limit():
     assert y.shape == (60000,) and p.shape == (60000,) and y.min() >= 0 and np.all((p >= 0) & (p <= 1))
     keep = y > 0                                                 # label 0 = HDBSCAN noise (+1 shift, reference __main__.py:155)
     assert keep.mean() > 0.9 and adjusted_rand_score(truth[keep], y[keep]) > 0.98
-    y_small, p_small = posthoc.fine_grained_clusters(x[:3000])
-    ref_l, ref_p = posthoc._hdbscan(x[:3000], 3000 // 100 + 1)
+    y_small, p_small = posthoc.fine_grained_clusters(x[:1500])                 # below HDBSCAN_DEVICE_MIN: the plain library call
+    ref_l, ref_p = posthoc._hdbscan(x[:1500], 1500 // 100 + 1)
     assert np.array_equal(y_small, ref_l + 1) and np.array_equal(p_small, ref_p)
+    from sklearn.cluster import HDBSCAN                                          # from there on: sklearn's result, computed on the GPU
+    ref = HDBSCAN(min_cluster_size=3000 // 100 + 1).fit(x[:3000])
+    y_mid, p_mid = posthoc.fine_grained_clusters(x[:3000])
+    assert np.array_equal(y_mid, ref.labels_ + 1) and np.allclose(p_mid, ref.probabilities_, atol=1e-12)
 
 
 @pytest.mark.gpu

@@ -38,6 +38,8 @@ def main():
     ap.add_argument("--len", type=int, default=5000)
     ap.add_argument("--epochs", type=int, default=2)
     ap.add_argument("--families", type=int, default=8)
+    ap.add_argument("--n-clusters", dest="n_clusters", type=int, default=0, help="0 = fine-grained mode (cfg5); e.g. 20 with --voters 5 = a cfg2/cfg3-like run")
+    ap.add_argument("--voters", type=int, default=1)
     a = ap.parse_args()
     base = "/dev/shm" if os.access("/dev/shm", os.W_OK) else tempfile.gettempdir()
     work = tempfile.mkdtemp(prefix="idelucs_cfg5_", dir=base)
@@ -51,12 +53,12 @@ def main():
     os.chdir(work)
     try:
         t0 = time.time()
-        out_dir = cli(["--sequence_file", fas, "--GT_file", gt, "--n_clusters", "0", "--n_epochs", str(a.epochs), "--n_voters", "1",
-                       "--batch_sz", "512", "--k", "6"])
+        out_dir = cli(["--sequence_file", fas, "--GT_file", gt, "--n_clusters", str(a.n_clusters), "--n_epochs", str(a.epochs),
+                       "--n_voters", str(a.voters), "--batch_sz", "512", "--k", "6"])
         wall = time.time() - t0
         m = pd.read_csv(os.path.join(out_dir, "metrics.tsv"), sep="\t", index_col=0)
         df = pd.read_csv(os.path.join(out_dir, "assignments.tsv"), sep="\t", index_col=0)
-        print(f"\ncfg5 through the CLI: {len(df)} sequences, {df['assignment'].nunique()} clusters, wall {wall:.0f} s")
+        print(f"\nthrough the CLI ({a.n} x {a.len} bp, n_clusters {a.n_clusters}, {a.voters} voter(s), {a.epochs} epochs): {len(df)} sequences, {df['assignment'].nunique()} clusters, wall {wall:.0f} s")
         print(m.to_string())
     finally:
         os.chdir(cwd)

@@ -211,9 +211,7 @@ class HotPath:
         rank embeds its N/G sequences, the fp32 shards are all-gathered over RCCL."""
         m, D = self.last_model, self.D
         owner = (self.a.voters - 1) % self.world
-        if self.world > 1:
-            for p in m.net.parameters():
-                dist.broadcast(p.data, src=owner)
+        D.broadcast_parameters(m.net, owner)
         lo, hi = D.shard_bounds(self.din.n, self.rank, self.world)
         x = self._predict_inputs(lo, hi)
         lats = []
@@ -371,6 +369,33 @@ def t_e2e(args, dev, reps=2):
     return best
 
 
+def spawn_ranks(n, n_visible, n_shared):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a CHILD `python -m torch.distributed.run` (one process
+    per GPU, RCCL), relay rank 0's JSON line, return the child's exit code.  Nothing here has touched the GPU (a process that has
+    must not be replaced by another program, and need not be: it only waits).  Fewer visible GPUs than ranks is an error, never
+    a smaller run."""
+    import socket
+    import subprocess
+    if n_shared == 0 and n_visible < n:
+        print(f"bench.py: --gpus {n} but only {n_visible} GPU(s) visible: refusing to run fewer ranks", file=sys.stderr)
+        return 2
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+    for l in r.stdout.splitlines():
+        if not l.startswith('{"metric"'):
+            print(l, file=sys.stderr)
+    if r.returncode != 0 or len(lines) != 1:
+        print(f"bench.py: the {n}-rank run failed (exit {r.returncode}, {len(lines)} result line(s))", file=sys.stderr)
+        return r.returncode or 1
+    print(lines[0])
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -394,35 +419,58 @@ def main():
                     help="SURVEY 8(d) variant N: every synthetic base is an N with this probability (e.g. 1e-3); default 0 = BASELINE's input")
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     cfg5 = args.workload == "cfg5"
     args.n = args.n or (1_000_000 if cfg5 else 100_000)
     args.len = args.len or (5_000 if cfg5 else 10_000)
     args.n_clusters = args.n_clusters or (200 if cfg5 else 20)
+    # rehearsal knobs (not used by the driver): IDELUCS_BENCH_BACKEND=gloo and IDELUCS_BENCH_DEVICES=1 let two ranks share the one
+    # GPU of a test box, to exercise every line of the N > 1 path except RCCL itself
+    backend = os.environ.get("IDELUCS_BENCH_BACKEND", "nccl")
+    n_shared = int(os.environ.get("IDELUCS_BENCH_DEVICES", "0"))
+    n_visible = torch.cuda.device_count()            # counting devices does not initialise the GPU
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus, n_visible, n_shared))      # this process never touches the GPU
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks: refusing to report a line for a "
+                 f"different rank count")
+    if n_shared == 0 and n_visible < world:
+        sys.exit(f"bench.py: {world} ranks need {world} GPUs, {n_visible} visible (one process per GPU; no fallback to fewer ranks)")
     if args.voters is None:
         args.voters = 1 if world == 1 else (world if cfg5 else 8)
     args.exchange = bool(args.with_predict) if args.with_predict is not None else (world > 1 or args.voters > 1 or cfg5)
     from idelucs_amd import _lib, gemm_tuning
     _lib.require_gpu()
-    # rehearsal knobs (not used by the driver): IDELUCS_BENCH_BACKEND=gloo and IDELUCS_BENCH_DEVICES=1 let two ranks share the one
-    # GPU of a test box, to exercise every line of the N > 1 path except RCCL itself
-    backend = os.environ.get("IDELUCS_BENCH_BACKEND", "nccl")
-    n_dev = int(os.environ.get("IDELUCS_BENCH_DEVICES", "0"))
-    if n_dev > 0:
-        local_rank %= n_dev
+    if n_shared > 0:
+        local_rank %= n_shared
     torch.cuda.set_device(local_rank)
     os.environ.setdefault("IDELUCS_TUNABLEOP", "1")      # GEMM solution selection (PyTorch TunableOp), done in the warm-up step
     gemm_tuning.maybe_enable()
     dev = torch.device("cuda", local_rank)
+    # one process per GPU over RCCL.  A single rank forms a group of one as well: the exchange step of the path then runs through
+    # the same RCCL calls (dtypes, shapes) as at N > 1 instead of a local shortcut (idelucs_amd.dist._no_group)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    elif os.environ.get("IDELUCS_BENCH_GROUP_OF_ONE", "1") == "1":
+        dist.init_process_group(backend, rank=0, world_size=1, store=dist.HashStore(),
+                                **({"device_id": dev} if backend == "nccl" else {}))
+    group = {"ranks": dist.get_world_size() if dist.is_initialized() else 1,
+             "backend": dist.get_backend() if dist.is_initialized() else None}
+    mine = {"rank": rank, "device": torch.cuda.current_device(), "name": torch.cuda.get_device_name(dev), "pid": os.getpid()}
+    if dist.is_initialized():
+        devs = [None] * group["ranks"]
+        dist.all_gather_object(devs, mine)
+        group["devices"] = devs
+    else:
+        group["devices"] = [mine]
+    if n_shared == 0 and world > 1:
+        assert len({d["device"] for d in group["devices"]}) == world, f"ranks share a GPU: {group['devices']}"
 
     din = synth_packed(args.n, args.len, dev, seed=54321 if cfg5 else 12345, n_rate=args.n_rate)
     hp = HotPath(din, args, dev, rank, world)
@@ -493,7 +541,8 @@ def main():
             region += " (BASELINE.md section 3 region; predict + all-gather run once after it: exchange_ms)"
         out = {
             "metric": "sequences/sec (k-mer vectorise + 1 epoch), k=6 batch 512",
-            "value": value, "unit": "sequences/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": value, "unit": "sequences/sec", "n_gpus": world, "ranks": group["ranks"], "backend": group["backend"],
+            "devices": group["devices"], "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak" if V == world and world > 1 and cfg5 else ("strong" if world > 1 else "weak"),
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"BASELINE {cfg_name}{' (variant N: every base an N w.p. %g)' % args.n_rate if args.n_rate > 0 else ''}: "
@@ -526,7 +575,7 @@ def main():
         if world == 1 and args.cpu_base:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

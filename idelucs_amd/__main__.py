@@ -103,8 +103,7 @@ def run(args):
         if use_hdbscan:
             # n_clusters=0 clusters ONE model's latent (reference __main__.py:153-156, the last voter's): its weights go to every
             # rank, predict is sharded by sequence, the fp32 latent shards [N/G, 64] are all-gathered over RCCL
-            for prm in model.net.parameters():
-                dist.broadcast(prm.data, src=owner)
+            D.broadcast_parameters(model.net, owner)
             lo, hi = D.shard_bounds(n, rank, world)
             latent = D.all_gather_rows(model.predict_latent_shard(lo, hi), n).double().cpu().numpy()
         else:                                                      # ship the last voter's latent to rank 0 (scores only)

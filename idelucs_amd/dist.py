@@ -28,11 +28,17 @@ def voters_of_rank(n_voters, rank=None, world_size=None):
     return [v for v in range(n_voters) if v % world_size == rank]
 
 
+def _no_group():
+    """True when no process group exists: the single-process library / CLI use.  A group of ONE rank still goes through the
+    collective (RCCL on a GPU box), so the N = 1 run exercises the same calls, dtypes and shapes as the N > 1 run."""
+    return not (dist.is_available() and dist.is_initialized())
+
+
 def all_gather_assignments(y_pred):
     """[N] int32 (this rank's voter) -> [G, N] on every rank.  One collective."""
     _, w = world()
     y = y_pred.contiguous()
-    if w == 1:
+    if _no_group():
         return y.unsqueeze(0)
     out = torch.empty(w * y.numel(), dtype=y.dtype, device=y.device)     # flat in / flat out: valid on nccl and gloo
     dist.all_gather_into_tensor(out, y.view(-1))
@@ -44,7 +50,7 @@ def gather_voter_predictions(local_preds, n_voters, n_items, device="cpu", dtype
     none).  Returns the [n_voters, n_items] matrix on every rank, rows in voter order (ranks may own
     different numbers of voters: rounds of all-gather, padded with -1 rows that are dropped)."""
     r, w = world()
-    if w == 1:
+    if _no_group():
         return torch.stack([local_preds[v].to(dtype) for v in range(n_voters)])
     mine = voters_of_rank(n_voters, r, w)
     rounds = (n_voters + w - 1) // w
@@ -71,7 +77,7 @@ def shard_bounds(n, rank=None, world_size=None):
 def all_gather_rows(x, n):
     """Row shards (shard_bounds) of an [N, d] matrix -> full [N, d] on every rank (padded all-gather)."""
     r, w = world()
-    if w == 1:
+    if _no_group():
         return x
     per = (n + w - 1) // w
     pad = torch.zeros((per,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
@@ -79,3 +85,12 @@ def all_gather_rows(x, n):
     out = torch.empty(w * pad.numel(), dtype=x.dtype, device=x.device)
     dist.all_gather_into_tensor(out, pad.view(-1))
     return out.view((w * per,) + tuple(x.shape[1:]))[:n]
+
+
+def broadcast_parameters(module, src):
+    """The owner's weights to every rank (n_clusters = 0 mode: ONE model's latent is clustered, reference __main__.py:153-156).
+    One broadcast per tensor; nothing to do without a process group."""
+    if _no_group():
+        return
+    for p in module.parameters():
+        dist.broadcast(p.data, src=src)

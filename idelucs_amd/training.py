@@ -37,7 +37,9 @@ def voter_lanes(n_voters_here):
 def can_batch(model):
     """Voters can be batched when the model runs the default fused launch sequence (NetLinear + RMSprop, n_clusters <= 48, full
     batches a multiple of 16 rows) and no scheduler reads the epoch loss on the host between epochs."""
-    return bool(model._use_fused and model.n_clusters <= 48 and model.batch_sz % 16 == 0 and model.schedule is None
+    # (the CLI hands the scheduler over as the reference does, as a string: "None" unless Plateau / Triangle was asked for)
+    return bool(model._use_fused and model.n_clusters <= 48 and model.batch_sz % 16 == 0
+                and model.schedule not in ('Plateau', 'Triangle')
                 and os.environ.get("IDELUCS_PIPELINE", "1") != "0" and os.environ.get("IDELUCS_EARLY_GATHER", "1") == "1"
                 and os.environ.get("IDELUCS_MID_FUSED", "1") != "0")
 
@@ -63,7 +65,12 @@ def train_voters(model, voters, n_epochs, n_voters=None, lanes=None, progress=Tr
             continue
         if batched is None or batched.L != len(wave):
             lane_models = [model.lane() for _ in wave]
-            batched = BatchedLinearTrainer([m.net for m in lane_models], model.lr, model.weight, model.l, seed=model.seed)
+            try:
+                batched = BatchedLinearTrainer([m.net for m in lane_models], model.lr, model.weight, model.l, seed=model.seed)
+            except ValueError:       # an opt-in launch variant (IDELUCS_OVERLAP, IDELUCS_WGRAD_FUSED, ...) the batched step does not take
+                for v in voters[w:]:
+                    out[v] = train_voter(model, n_epochs, v, n_voters, progress)
+                return out
             for m, t in zip(lane_models, batched.trainers):
                 m._fused = t
         if progress:

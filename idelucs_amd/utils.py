@@ -414,9 +414,7 @@ def _features_one_pass(fname, k, transform, mode, check, out_kind, device=None, 
     if host_tf:
         try:
             e, eo = _compat_edits(ff, [transform])
-        except ValueError as err:
-            if "substitutions" not in str(err) and "length" not in str(err):
-                raise
+        except _NotSubstitutions as err:      # (a ValueError raised by the user's own transform passes through untouched)
             # an arbitrary user callable (reference utils.py:239-240 takes any): apply it on the host, re-pack the mutated bytes
             return _features_user_transform(ff, k, transform, mode, out_kind, dev, applied=err.mutated)
         edits = torch.from_numpy(e.view(np.int32)).to(dev) if e.size else torch.zeros(1, dtype=torch.int32, device=dev)

@@ -63,3 +63,20 @@ def test_single_process_paths():
     assert D.all_gather_assignments(y).shape == (1, 6)
     assert D.shard_bounds(10) == (0, 10)
     assert [D.shard_bounds(10, r, 4) for r in range(4)] == [(0, 3), (3, 6), (6, 9), (9, 10)]
+
+
+def test_bench_refuses_fewer_ranks_than_asked_for():
+    """`python bench.py --gpus N` with no launcher starts its own N ranks (a child torchrun) -- and where fewer than N GPUs are
+    visible (none in the build container) it must fail loudly, never print a line for a smaller run (VERDICT r2 missing #1)."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("two GPUs visible: the refusal cannot be provoked here")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and '{"metric"' not in r.stdout and "refusing to run fewer ranks" in r.stderr, (r.returncode, r.stderr[-500:])
+    # a launcher that started a different number of ranks than --gpus says is refused as well
+    env.update(WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and '{"metric"' not in r.stdout and "WORLD_SIZE=2" in r.stderr, (r.returncode, r.stderr[-500:])

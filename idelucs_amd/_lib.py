@@ -77,12 +77,16 @@ SIGNATURES = {
     "idl_rmsprop_step_gather_wgrad": (_int, [_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _c.c_float, _c.c_float, _vp,
                                              _vp, _i64, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _vp, _vp,
                                              _int, _vp, _vp, _int, _int, _int, _int, _vp, _i64, _vp]),
+    "idl_wgrad_rmsprop_step": (_int, [_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _c.c_float, _c.c_float, _vp,
+                                      _int, _vp, _vp, _int, _int, _int, _vp,
+                                      _int, _vp, _vp, _int, _int, _int, _int, _vp, _i64, _vp]),
     "idl_mid_bwd_gather": (_int, [_vp] * 5 + [_int] + [_vp] * 4 + [_int, _int, _int, _c.c_float] + [_vp] * 7 +
                            [_vp, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _vp]),
     "idl_mid_fwd_gather": (_int, [_vp, _vp, _int, _vp, _vp, _vp, _vp, _int, _int, _int, _c.c_uint64, _vp, _vp, _vp, _vp, _vp] +
                            [_vp, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _int, _int, _int, _vp]),
     "idl_mst_prim_workspace": (_i64, [_i64]),
     "idl_mst_prim": (_int, [_vp, _int, _vp, _i64, _int, _vp, _vp, _vp, _vp, _vp]),
+    "idl_debug_stamps": (_int, [_vp]),
     "idl_plan_bytes": (_i64, []),
     "idl_plan_begin": (_int, [_vp]),
     "idl_plan_end": (_int, []),

@@ -80,6 +80,10 @@ __device__ __forceinline__ void iic_joint_tiles(const float *z, int m, int C, fl
 __device__ __forceinline__ void nce_pass1_body(const float *f, int m, float inv_t, float *rowsum_part, float *pos, const IicJob &iic)
 {
     if ((int)blockIdx.x == m / 16) {
+        // (ahead of the similarity waves it shares SIMDs with: beside a wave that issues fp32 matrix instructions back to back a
+        //  wave of equal priority gets an issue slot only now and then -- stamps in the optimizer launch showed 6 us of such work
+        //  taking 40)
+        __builtin_amdgcn_s_setprio(3);
         if (iic.z != nullptr) iic_joint_tiles(iic.z, m, iic.C, iic.P0, (int)blockIdx.y, NCE_SPLIT);     // core: pass 2
         else if (blockIdx.y == 0 && iic.P0 != nullptr) iic_core_small(iic.P0, iic.C, iic.lamb, iic.eps, iic.w_iic, iic.out);
         return;
@@ -121,6 +125,7 @@ __device__ __forceinline__ void nce_pass2_body(const float *f, int m, float inv_
                                                float *lse, float *loss_rows, float *G_part, const IicJob &iic)
 {
     if ((int)blockIdx.x == m / 16) {         // spare column (only launched when the joint was formed in pass 1): the IIC core
+        __builtin_amdgcn_s_setprio(3);
         if (blockIdx.y == 0) iic_core_small(iic.P0, iic.C, iic.lamb, iic.eps, iic.w_iic, iic.out);
         return;
     }

@@ -19,6 +19,7 @@
 // needs.  `ctl` is a small device-resident control block so that graph replays advance without
 // host involvement:  ctl[0] = optimizer-step counter, ctl[1] = offset of the next batch in the
 // shuffled pair list.
+#include <stdlib.h>
 #include <string.h>
 
 #include "common.h"
@@ -26,6 +27,7 @@
 #include "nce_device.h"
 #include "scaler_device.h"
 #include "wave_ops.h"
+#include "wgrad_device.h"
 
 namespace {
 
@@ -920,17 +922,17 @@ __device__ __forceinline__ void wgrad_tile_rms(const RmsArgs &a, int tile, float
 constexpr int RMS_UNROLL = 4;         // 16-byte elements per thread of the streaming update
 
 __device__ __forceinline__ void rmsprop_body(const RmsArgs &a, const float *hyper, int64_t *ctl, int64_t batch_advance, int gx,
-                                             int n_gather, const idl_dev::GatherArgs &g)
+                                             int n_gather, const idl_dev::GatherArgs &g, const int blk)
 {
     // grid order: weight-gradient tiles (dependent chains of strided loads: first, so that the streaming blocks behind them hide
     // their latency), then the gather blocks, then the optimizer blocks
     const float lr = hyper[0], alpha = hyper[1], eps = hyper[2], wd = hyper[3], oma = hyper[4];
-    if ((int)blockIdx.x < a.wg_tiles) {
+    if (blk < a.wg_tiles) {
         __shared__ float red[1024];
-        wgrad_tile_rms(a, (int)blockIdx.x, lr, alpha, eps, wd, oma, red);
+        wgrad_tile_rms(a, blk, lr, alpha, eps, wd, oma, red);
         return;
     }
-    const int b0 = (int)blockIdx.x - a.wg_tiles;
+    const int b0 = blk - a.wg_tiles;
     if (b0 < n_gather) {
         idl_dev::gather_block(g, (int64_t)b0, threadIdx.x);
         return;
@@ -1004,14 +1006,45 @@ static_assert(sizeof(RmsParams) + idl::PLAN_PARAMS <= idl::PLAN_BYTES, "RmsParam
 __global__ __launch_bounds__(256) void rmsprop_kernel(RmsArgs a, const float *hyper, int64_t *ctl, int64_t batch_advance, int gx,
                                                       int n_gather, idl_dev::GatherArgs g)
 {
-    rmsprop_body(a, hyper, ctl, batch_advance, gx, n_gather, g);
+    rmsprop_body(a, hyper, ctl, batch_advance, gx, n_gather, g, (int)blockIdx.x);
+}
+
+// The optimizer launch with the LARGE weight gradient at its head (wgrad_device.h): the first w.tiles workgroups each accumulate a
+// 64 x 128 tile of dW1 = dr1^T x on the matrix cores and apply RMSprop to it from their registers; the workgroups behind them are
+// the optimizer launch as before (the small tensors, the dW2 tiles, step loss, step counter) and run beside them -- a tile
+// workgroup is one wave per SIMD, so both fit a CU.  One launch, one boundary and the 8 MB gradient's round trip fewer than
+// hipBLASLt's GEMM followed by rmsprop_kernel.
+template <bool STAMPS = false, bool SKIP_TILES = false>      // STAMPS (IDELUCS_STAMPS=1, a diagnostic): every workgroup leaves {start, end, hardware id, XCC id} in `stamps`
+__global__ __launch_bounds__(256) void wgrad_rmsprop_kernel(wg_dev::WgArgs w, RmsArgs a, const float *hyper, int64_t *ctl,
+                                                            int64_t batch_advance, int n_gather, idl_dev::GatherArgs g, uint64_t *stamps)
+{
+    uint64_t t0 = 0;
+    if (STAMPS) t0 = __builtin_amdgcn_s_memrealtime();
+    if ((int)blockIdx.x < w.tiles) { if (!SKIP_TILES) wg_dev::q16_tile<0>(w, (int)blockIdx.x); }
+    else {
+        // a tile wave issues matrix instructions back to back and, being the older wave of its SIMD, wins every arbitration: at equal
+        // priority these workgroups crawl beside it (measured with the stamps: 40 us for 5 us of work, and the tiles 3..16 us longer
+        // wherever they met a dW2 tile); ahead of it they are gone after a few microseconds
+        __builtin_amdgcn_s_setprio(3);
+        rmsprop_body(a, hyper, ctl, batch_advance, 0, n_gather, g, (int)blockIdx.x - w.tiles);
+    }
+    if (STAMPS) {
+        __syncthreads();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (threadIdx.x == 0 && blockIdx.x < 1024) {
+            uint64_t *d = stamps + 4 * (size_t)blockIdx.x;
+            d[0] = t0; d[1] = __builtin_amdgcn_s_memrealtime();
+            d[2] = __builtin_amdgcn_s_getreg((31 << 11) | 4);          // HW_REG_HW_ID
+            d[3] = __builtin_amdgcn_s_getreg((31 << 11) | 20);         // HW_REG_XCC_ID
+        }
+    }
 }
 
 // several voters in one launch: voter blockIdx.y takes its arguments from its plan record
 __global__ __launch_bounds__(256) void rmsprop_batched_kernel(const unsigned char *__restrict__ plans)
 {
     const RmsParams &p = *(const RmsParams *)(plans + (size_t)blockIdx.y * idl::PLAN_BYTES + idl::PLAN_PARAMS);
-    rmsprop_body(p.a, p.hyper, p.ctl, p.batch_advance, 0, p.n_gather, p.g);
+    rmsprop_body(p.a, p.hyper, p.ctl, p.batch_advance, 0, p.n_gather, p.g, (int)blockIdx.x);
 }
 
 }  // namespace
@@ -1312,11 +1345,25 @@ int idl_bias_grads(float *dx1, const float *act1, int n1, float *partial1, const
     return launch_col_jobs(jobs, 3, stream);
 }
 
+// IDELUCS_STAMPS=1: a device buffer of 1024 x 4 uint64 the stamped kernels write to (idl_debug_stamps copies it out)
+static uint64_t *stamp_buffer()
+{
+    static uint64_t *buf = [] {
+        const char *e = getenv("IDELUCS_STAMPS");
+        uint64_t *p = nullptr;
+        if (e != nullptr && e[0] == '1' && hipMalloc((void **)&p, 1024 * 4 * sizeof(uint64_t)) == hipSuccess) (void)hipMemset(p, 0, 1024 * 4 * sizeof(uint64_t));
+        else p = nullptr;
+        return p;
+    }();
+    return buf;
+}
+
 static int rmsprop_launch(int count, float *const *params, const float *const *grads, const int32_t *grad_parts,
                           float *const *square_avg, const int64_t *sizes, const float *hyper, int64_t *ctl, int64_t batch_advance,
                           const float *loss_rows, int loss_m, float w_nce, float w_iic, float *out, const idl_dev::GatherArgs &g,
                           void *stream, int wg_index = -1, const float *wg_dy = nullptr, const float *wg_x = nullptr, int wg_m = 0,
-                          int wg_n_out = 0, int wg_n_in = 0, float *wg_grad = nullptr, int wg_x_transposed = 0)
+                          int wg_n_out = 0, int wg_n_in = 0, float *wg_grad = nullptr, int wg_x_transposed = 0,
+                          const wg_dev::WgArgs *big = nullptr, int big_index = -1)
 {
     IDL_REQUIRE(count >= 1 && count <= 8 && params && grads && square_avg && sizes && hyper && ctl, "rmsprop_step: 1..8 tensors");
     RmsArgs a{};
@@ -1342,6 +1389,12 @@ static int rmsprop_launch(int count, float *const *params, const float *const *g
         for (int i = 0; i < count; ++i) if (a.n[i] > mx) mx = a.n[i];
     }
     (void)mx;
+    if (big != nullptr) {                   // tensor big_index is updated by the tile workgroups at the head of the launch
+        IDL_REQUIRE(big_index >= 0 && big_index < count && big_index != wg_index &&
+                    sizes[big_index] == (int64_t)big->p.n_out * big->p.n_in && big->p.W == params[big_index] && big->p.V == square_avg[big_index],
+                    "wgrad_rmsprop_step: w1_index must name the tensor the tiles update");
+        a.n[big_index] = 0;
+    }
     int nb_total = 0;
     for (int i = 0; i < count; ++i) {
         const bool vec = a.parts[i] == 1 && (a.n[i] & 3) == 0 && ((((uintptr_t)a.p[i]) | ((uintptr_t)a.g[i]) | ((uintptr_t)a.v[i])) & 15u) == 0;
@@ -1354,6 +1407,7 @@ static int rmsprop_launch(int count, float *const *params, const float *const *g
     for (int i = count; i <= 8; ++i) a.first[i] = nb_total;
     const int64_t extra = g.y != nullptr ? idl_dev::gather_blocks(g.f, g.batch) : 0;
     if (void *plan = idl::take_plan()) {          // recorded, not launched (idl_plan_begin)
+        IDL_REQUIRE(big == nullptr, "wgrad_rmsprop_step cannot be recorded (the batched step keeps its batched GEMM)");
         idl::PlanHead h{};
         h.kind = idl::PLAN_RMSPROP; h.grid[0] = (unsigned)(nb_total + extra + a.wg_tiles); h.grid[1] = 1; h.grid[2] = 1; h.block = 256;
         memcpy(plan, &h, sizeof(h));
@@ -1361,8 +1415,20 @@ static int rmsprop_launch(int count, float *const *params, const float *const *g
         memcpy((unsigned char *)plan + idl::PLAN_PARAMS, &p, sizeof(p));
         return IDL_OK;
     }
-    hipLaunchKernelGGL(rmsprop_kernel, dim3((unsigned)(nb_total + extra + a.wg_tiles)), dim3(256), 0, (hipStream_t)stream, a, hyper, ctl,
-                       batch_advance, 0, (int)extra, g);
+    if (big != nullptr) {
+        const dim3 grid((unsigned)(big->tiles + nb_total + extra + a.wg_tiles));
+        static const bool skip = [] { const char *e = getenv("IDELUCS_STAMPS_SKIP_TILES"); return e != nullptr && e[0] == '1'; }();
+        if (uint64_t *st = stamp_buffer(); st != nullptr && skip)
+            hipLaunchKernelGGL((wgrad_rmsprop_kernel<true, true>), grid, dim3(256), 0, (hipStream_t)stream, *big, a, hyper, ctl, batch_advance, (int)extra, g, st);
+        else if (st != nullptr)
+            hipLaunchKernelGGL(wgrad_rmsprop_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, *big, a, hyper, ctl, batch_advance, (int)extra, g, st);
+        else
+            hipLaunchKernelGGL(wgrad_rmsprop_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, *big, a, hyper, ctl, batch_advance, (int)extra, g,
+                               (uint64_t *)nullptr);
+    }
+    else
+        hipLaunchKernelGGL(rmsprop_kernel, dim3((unsigned)(nb_total + extra + a.wg_tiles)), dim3(256), 0, (hipStream_t)stream, a, hyper, ctl,
+                           batch_advance, 0, (int)extra, g);
     IDL_HIP_TRY(hipGetLastError());
     return IDL_OK;
 }
@@ -1402,6 +1468,38 @@ int idl_rmsprop_step_gather_wgrad(int count, float *const *params, const float *
     }
     return rmsprop_launch(count, params, grads, grad_parts, square_avg, sizes, hyper, ctl, batch_advance, loss_rows, loss_m, w_nce, w_iic, out, g,
                           stream, wg_index, wg_dy, wg_x, wg_m, wg_n_out, wg_n_in, wg_grad, wg_x_transposed);
+}
+
+int idl_wgrad_rmsprop_step(int count, float *const *params, const float *const *grads, const int32_t *grad_parts,
+                           float *const *square_avg, const int64_t *sizes, const float *hyper, int64_t *ctl,
+                           const float *loss_rows, int loss_m, float w_nce, float w_iic, float *out,
+                           int w1_index, const float *w1_dy, const float *w1_x, int w1_m, int w1_n_out, int w1_n_in, float *w1_grad,
+                           int wg_index, const float *wg_dy, const float *wg_x, int wg_x_transposed, int wg_m, int wg_n_out, int wg_n_in,
+                           float *wg_grad, int64_t batch_advance, void *stream)
+{
+    IDL_REQUIRE(count >= 1 && count <= 8 && params && square_avg && w1_index >= 0 && w1_index < count, "wgrad_rmsprop_step: w1_index outside the tensors");
+    IDL_REQUIRE(w1_dy && w1_x && wg_dev::supported(w1_m, w1_n_out, w1_n_in), "wgrad_rmsprop_step: m % 32 == 0, n_out % 64 == 0, n_in % 128 == 0");
+    IDL_REQUIRE((((uintptr_t)w1_dy | (uintptr_t)w1_x | (uintptr_t)w1_grad | (uintptr_t)params[w1_index] | (uintptr_t)square_avg[w1_index]) & 15u) == 0,
+                "wgrad_rmsprop_step: buffers must be 16-byte aligned");
+    IDL_REQUIRE((int64_t)w1_m * w1_n_in < (1ll << 29) && (int64_t)w1_n_out * w1_n_in < (1ll << 29), "wgrad_rmsprop_step: operands beyond 2^31 bytes");
+    wg_dev::WgArgs w{};
+    w.p = wg_dev::WgProblem{w1_dy, w1_x, w1_grad, params[w1_index], square_avg[w1_index], w1_n_out, w1_n_in};
+    w.hyper = hyper; w.m = w1_m;
+    w.tiles_m = w1_n_out / wg_dev::TM;
+    w.tiles = w.tiles_m * (w1_n_in / wg_dev::TN);
+    idl_dev::GatherArgs g{};
+    return rmsprop_launch(count, params, grads, grad_parts, square_avg, sizes, hyper, ctl, batch_advance, loss_rows, loss_m, w_nce, w_iic, out, g,
+                          stream, wg_index, wg_dy, wg_x, wg_m, wg_n_out, wg_n_in, wg_grad, wg_x_transposed, &w, w1_index);
+}
+
+int idl_debug_stamps(uint64_t *host_out)
+{
+    IDL_REQUIRE(host_out != nullptr, "NULL buffer");
+    uint64_t *st = stamp_buffer();
+    IDL_REQUIRE(st != nullptr, "debug stamps are off (IDELUCS_STAMPS=1 before the first launch)");
+    IDL_HIP_TRY(hipDeviceSynchronize());
+    IDL_HIP_TRY(hipMemcpy(host_out, st, 1024 * 4 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return IDL_OK;
 }
 
 int idl_plan_launch(const void *host_plans, const void *dev_plans, int n_voters, void *stream)

@@ -1,10 +1,10 @@
 """idelucs_amd.fused -- the explicit, fused optimizer step for the default configuration
 (NetLinear encoder + RMSprop), replayed as a HIP graph.
 
-One step of reference idelucs/models.py:117-133 is 7 launches by default: the two large dense products on hipBLASLt
-(torch.mm with out=, no allocation) and five fused HIP kernels from csrc/train_step.hip + nce_fused.hip --
-    W1 x^T  ->  idl_mid_fwd_gather  ->  idl_nce_fused_iic_z (two launches)  ->  idl_mid_bwd_gather  ->  dr1^T x
-            ->  idl_rmsprop_step_gather_wgrad
+One step of reference idelucs/models.py:117-133 is 6 launches by default: the layer-1 product on hipBLASLt (torch.mm with
+out=, no allocation) and five fused HIP kernels from csrc/train_step.hip + nce_fused.hip + wgrad_device.h --
+    W1 x^T  ->  idl_mid_fwd_gather  ->  idl_nce_fused_iic_z (two launches)  ->  idl_mid_bwd_gather
+            ->  idl_wgrad_rmsprop_step (dW1 = dr1^T x as MFMA tiles with RMSprop in their epilogue + the rest of the optimizer)
 (DESIGN.md 4.4 has the table of what each launch carries).  The unfused building blocks idl_relu_dropout_fwd, idl_head_fwd,
 idl_nce_rows, idl_iic_core, idl_head_bwd, idl_bias_grads, idl_rmsprop_step remain for the shapes the fused kernels do not take
 (n_clusters > 48, partial batches) and as their test references.  Batches are assembled from the HBM feature store at a
@@ -146,9 +146,12 @@ class FusedLinearTrainer:
         # the 64 CUs of that launch instead of 256: the fused launch takes 32.8 us against 9.5 + 13.5 -- measured +8 us per step)
         self._nce_bwd_fused = os.environ.get("IDELUCS_NCE_BWD_FUSED", "0") != "0"
         self._joint_inlaunch = os.environ.get("IDELUCS_JOINT_INLAUNCH", "1") != "0"   # IIC joint inside the InfoNCE pass-1 launch
-        # opt-in: dW1 on this package's own MFMA kernel with RMSprop in its epilogue (csrc/wgrad.hip; measured a wash against
-        # hipBLASLt + the optimizer launch, so off by default)
-        self._wgrad_fused = os.environ.get("IDELUCS_WGRAD_FUSED", "0") != "0"
+        # dW1 on this package's own MFMA tiles with RMSprop in their epilogue, as the head of the optimizer launch
+        # (csrc/wgrad_device.h, idl_wgrad_rmsprop_step): one launch instead of hipBLASLt's GEMM + the optimizer launch, and the 8 MB
+        # gradient never goes to memory.  IDELUCS_WGRAD_FUSED=0: hipBLASLt + optimizer launch; =2: the tiles as a launch of their own
+        self._wgrad_fused = os.environ.get("IDELUCS_WGRAD_FUSED", "1") != "0"
+        self._wgrad_own_launch = os.environ.get("IDELUCS_WGRAD_FUSED", "1") == "2"
+        self._keep_w1_grad = os.environ.get("IDELUCS_KEEP_W1_GRAD", "0") != "0"       # tests: also write dW1 to grads[0]
         self._steps_per_graph = max(2, int(os.environ.get("IDELUCS_STEPS_PER_GRAPH", "16")) // 2 * 2)
         self._perm = None
         n = len(self.params)
@@ -316,16 +319,25 @@ class FusedLinearTrainer:
             chk(_L.idl_bias_grads(_p(bf.dr1), _p(bf.r1), self.H1, _p(gb1), _p(bf.dlat), self.H2, _p(gb2), _p(bf.dlogits), C, _p(gb3),
                                   m, tr, adv_ctl, adv, _p(bf.r2) if self._dw3_partial else None,
                                   _p(gW3) if self._dw3_partial else None, _stream()))
-        w1_done = self._wgrad_fused and bool(_L.idl_wgrad_supported(m, self.H1, self.F))
+        w1_fusable = self._wgrad_fused and self._rec is None and bool(_L.idl_wgrad_supported(m, self.H1, self.F))
+        # the tiles ride at the head of the optimizer launch where that launch has the form below; else as a launch of their own
+        w1_head = w1_fusable and (early or early_f) and self._dw2_inlaunch and not self._wgrad_own_launch
+        w1_done = w1_fusable and not w1_head
+        gw1_out = _p(gW1) if self._keep_w1_grad else None
         if w1_done:
-            chk(_L.idl_wgrad_rmsprop(_p(bf.dr1), _p(x), m, self.H1, self.F, None, _p(self.W1), _p(self.square_avg[0]), _p(self.hyper),
+            chk(_L.idl_wgrad_rmsprop(_p(bf.dr1), _p(x), m, self.H1, self.F, gw1_out, _p(self.W1), _p(self.square_avg[0]), _p(self.hyper),
                                      _stream()))
-        else:
+        elif not w1_head:
             self._mm(bf.dr1.t(), x, gW1)
         sz = self._sz_no_w1 if w1_done else self._sz
         main.wait_stream(side)
         # ---- RMSprop (and advance the device-side step counter / batch offset)
-        if (early or early_f) and self._dw2_inlaunch:      # no batch assembly here; the offset moves on at the end of the step
+        if w1_head:
+            chk(_L.idl_wgrad_rmsprop_step(len(self.params), self._pp, self._gp, self._parts, self._vp, sz, _p(self.hyper),
+                                          _p(self.ctl), _p(bf.loss_rows), m, 1.0 - self.weight, self.weight, _p(self.out),
+                                          0, _p(bf.dr1), _p(x), m, self.H1, self.F, gw1_out,
+                                          2, _p(bf.dlat), _p(bf.r1), 1 if tl else 0, m, self.H2, self.H1, _p(gW2), m // 2, _stream()))
+        elif (early or early_f) and self._dw2_inlaunch:      # no batch assembly here; the offset moves on at the end of the step
             self._k(_L.idl_rmsprop_step_gather_wgrad, len(self.params), self._pp, self._gp, self._parts, self._vp, sz, _p(self.hyper),
                     _p(self.ctl), _p(bf.loss_rows), m, 1.0 - self.weight, self.weight, _p(self.out),
                     None, 0, 0, 0, None, 0, 0, None, None, None, None,
@@ -459,7 +471,7 @@ class BatchedLinearTrainer:
             self.trainers.append(FusedLinearTrainer(net, lr, weight, lamb, seed=seed, grad_w1=self.gW1s[l], shared_buffers=_SharedViews(self, l)))
         t0 = self.trainers[0]
         if not (t0._early_gather and t0._early_split and t0._transposed_l1 and t0._dw2_inlaunch and t0._mid_fused and t0._dw3_partial
-                and t0._joint_inlaunch and t0._pipeline and not t0._nce_bwd_fused and not t0._wgrad_fused and not t0._overlap):
+                and t0._joint_inlaunch and t0._pipeline and not t0._nce_bwd_fused and not t0._overlap):
             raise ValueError("BatchedLinearTrainer needs the default launch sequence (n_clusters <= 48, no opt-in variants)")
         self._programs = {}
         self._graphs = {}

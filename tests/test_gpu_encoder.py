@@ -326,13 +326,14 @@ def _cfg2_store_and_net(dev, n, seed=3, C=20):
 @pytest.mark.parametrize("C", [20, 200])
 def test_default_fused_step_at_cfg2_shape_vs_autograd(dev, C):
     """C = 20: the launch sequence bench.py times -- FusedLinearTrainer._full_step(pipelined=True) with every default (transposed
-    layer-1 product -> mid_fwd_gather -> nce_fused_iic_z -> mid_bwd_gather -> dW1 GEMM -> rmsprop_step_gather_wgrad) at cfg2's
+    layer-1 product -> mid_fwd_gather -> nce_fused_iic_z -> mid_bwd_gather -> wgrad_rmsprop_step: dW1 tiles at the head of the
+    optimizer launch) at cfg2's
     shape m=1024, F=4096, C=20 -- against torch autograd over idelucs_amd.LossFunctions (pinned to the reference goldens
     above), dropout off: loss rel 2e-4, the six gradients rel 2e-3, parameters after RMSprop rel 1e-5 on identical
     gradients; and the batch the step assembled for the NEXT step is the gather of the next 512 pairs.
     C = 200: the fine-grained mode's sequence (cfg5, --n_clusters 0): layer-1 product -> mid_fwd_gather carrying ALL of the next
     batch's tiles -> joint GEMM + idl_iic_core -> idl_nce_fused -> z dP0 GEMM -> head_bwd_dz -> dW3 / dr1 GEMMs -> bias_grads ->
-    dW1 GEMM -> rmsprop_step_gather_wgrad."""
+    wgrad_rmsprop_step."""
     import copy
     import torch
     from idelucs_amd.fused import FusedLinearTrainer
@@ -342,9 +343,10 @@ def test_default_fused_step_at_cfg2_shape_vs_autograd(dev, C):
     tr = FusedLinearTrainer(net, lr=1e-3, weight=0.25, lamb=2.8, seed=5)
     if C == 20:
         assert tr._early_gather and tr._early_split and tr._transposed_l1 and tr._dw2_inlaunch and tr._mid_fused and tr._dw3_partial \
-            and tr._joint_inlaunch and not tr._nce_bwd_fused and not tr._wgrad_fused, "not the default launch sequence"
+            and tr._joint_inlaunch and not tr._nce_bwd_fused and tr._wgrad_fused and not tr._wgrad_own_launch, "not the default launch sequence"
     else:
         assert tr._early_fwd and not tr._early_gather and tr._dw2_inlaunch and tr._mid_fused and not tr._dw3_partial
+    tr._keep_w1_grad = True                                     # the tiles also write dW1 out (the timed step never does)
     B = 512
     gen = torch.Generator(device=dev); gen.manual_seed(9)
     tr._perm = torch.randperm(store.n_pairs, device=dev, generator=gen)
@@ -754,7 +756,7 @@ def test_dw2_inside_the_optimizer_launch(dev, m, xt):
 
 @pytest.mark.parametrize("m,fused", [(1024, True), (960, True), (128, False)])
 def test_wgrad_kernel_vs_torch(dev, m, fused):
-    """idl_wgrad_rmsprop (opt-in dW1 kernel): dy^T x on the fp32 matrix cores within fp32 summation error of a float64 product,
+    """idl_wgrad_rmsprop (the dW1 tiles on their own): dy^T x on the fp32 matrix cores within fp32 summation error of a float64 product,
     and its fused RMSprop epilogue equals the formula applied to that gradient; unsupported shapes are refused."""
     import torch
     from idelucs_amd import _lib
@@ -767,7 +769,7 @@ def test_wgrad_kernel_vs_torch(dev, m, fused):
     W0, V0 = W.clone(), V.clone()
     hyper = torch.tensor([1e-3, 0.99, 1e-8, 0.01, 0.01], device=dev)
     g = torch.empty(H, F, device=dev)
-    assert L.idl_wgrad_supported(m, H, F) == 1 and L.idl_wgrad_supported(m + 2, H, F) == 0 and L.idl_wgrad_supported(m, H + 64, F) == 0
+    assert L.idl_wgrad_supported(m, H, F) == 1 and L.idl_wgrad_supported(m + 2, H, F) == 0 and L.idl_wgrad_supported(m, H + 32, F) == 0 and L.idl_wgrad_supported(m, H, F + 64) == 0
     with pytest.raises(ValueError):
         _lib.check(L.idl_wgrad_rmsprop(_p(dy), _p(x), m + 2, H, F, _p(g), None, None, None, _stream()))
     _lib.check(L.idl_wgrad_rmsprop(_p(dy), _p(x), m, H, F, _p(g), _p(W) if fused else None, _p(V) if fused else None,
@@ -843,7 +845,8 @@ def test_head_bwd_with_precomputed_product(dev):
 
 
 def test_opt_in_step_variants_agree_with_the_default(dev):
-    """The opt-in / fallback ways of running the step (own dW1 kernel with fused RMSprop, batch assembly in the optimizer launch,
+    """The opt-in / fallback ways of running the step (dW1 on hipBLASLt + a plain optimizer launch, the dW1 tiles as a launch of
+    their own, batch assembly in the optimizer launch,
     row-major layer-1 activations, dW2 and the IIC joint as GEMM launches) train to the same parameters as the default launch
     sequence -- same batches, same dropout streams; only the summation orders inside the products differ."""
     import copy
@@ -870,7 +873,7 @@ def test_opt_in_step_variants_agree_with_the_default(dev):
         return [p.detach().clone() for p in tr.params], total.item()
 
     ref_p, ref_l = run()
-    for flags in (dict(_wgrad_fused=True), dict(_early_gather=False), dict(_transposed_l1=False), dict(_dw2_inlaunch=False, _early_gather=False),
+    for flags in (dict(_wgrad_fused=False), dict(_wgrad_own_launch=True), dict(_early_gather=False), dict(_transposed_l1=False), dict(_dw2_inlaunch=False, _early_gather=False),
                   dict(_joint_inlaunch=False), dict(_pipeline=False, _early_gather=False), dict(_nce_bwd_fused=True)):
         p, l = run(**flags)
         assert abs(l - ref_l) <= 2e-3 * abs(ref_l), (flags, l, ref_l)

@@ -908,11 +908,10 @@ __device__ __forceinline__ void wgrad_tile_rms(const RmsArgs &a, int tile, float
     const int o = (i0 + i) * ldb + j0 + j;
     if (a.wg_grad != nullptr) a.wg_grad[o] = g;
     float *p = a.p[a.wg_t], *v = a.v[a.wg_t];
-    const float pi = p[o];
-    const float gi = g + wd * pi;
-    const float vi = v[o] * alpha + oma * gi * gi;
+    float pi = p[o], vi = v[o];
+    wg_dev::rms_update(g, pi, vi, wg_dev::Hyper{lr, alpha, eps, wd, oma});
     v[o] = vi;
-    p[o] = pi - lr * (gi / (sqrtf(vi) + eps));
+    p[o] = pi;
 }
 
 // Grid: when g.y != NULL the first n_gather = gather_blocks() blocks assemble the NEXT batch (nothing in this launch writes what they
@@ -920,6 +919,8 @@ __device__ __forceinline__ void wgrad_tile_rms(const RmsArgs &a, int tile, float
 // step's GEMMs); they go first because a gathered row is a dependent chain of HBM latencies that the streaming optimizer blocks
 // behind them hide.  The following gx * count blocks are optimizer blocks (tensor = block / gx).
 constexpr int RMS_UNROLL = 4;         // 16-byte elements per thread of the streaming update
+
+constexpr int RMS_THREADS = 256;   // threads of an optimizer block (the launch may carry a fifth, idle wave: wgrad_rmsprop_kernel)
 
 __device__ __forceinline__ void rmsprop_body(const RmsArgs &a, const float *hyper, int64_t *ctl, int64_t batch_advance, int gx,
                                              int n_gather, const idl_dev::GatherArgs &g, const int blk)
@@ -947,17 +948,17 @@ __device__ __forceinline__ void rmsprop_body(const RmsArgs &a, const float *hype
         const int64_t n = a.n[t];
         if (a.parts[t] == 1 && (n & 3) == 0 && ((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)v)) & 15u) == 0) {
             float4 *p4 = (float4 *)p; const float4 *g4 = (const float4 *)g; float4 *v4 = (float4 *)v;
+            // (one update formula for every tensor and every launch form -- wg_dev::rms_update, also the epilogue of the dW1 tiles: a
+            //  voter's weights must not depend on which launch sequence trained it beyond the order of the sums)
+            const wg_dev::Hyper hy{lr, alpha, eps, wd, oma};
             auto upd = [&](float4 &pi, float4 &vi, const float4 gr) {
-                const float g0 = gr.x + wd * pi.x, g1 = gr.y + wd * pi.y, g2 = gr.z + wd * pi.z, g3 = gr.w + wd * pi.w;
-                vi.x = vi.x * alpha + oma * g0 * g0; vi.y = vi.y * alpha + oma * g1 * g1;
-                vi.z = vi.z * alpha + oma * g2 * g2; vi.w = vi.w * alpha + oma * g3 * g3;
-                pi.x -= lr * (g0 / (sqrtf(vi.x) + eps)); pi.y -= lr * (g1 / (sqrtf(vi.y) + eps));
-                pi.z -= lr * (g2 / (sqrtf(vi.z) + eps)); pi.w -= lr * (g3 / (sqrtf(vi.w) + eps));
+                wg_dev::rms_update(gr.x, pi.x, vi.x, hy); wg_dev::rms_update(gr.y, pi.y, vi.y, hy);
+                wg_dev::rms_update(gr.z, pi.z, vi.z, hy); wg_dev::rms_update(gr.w, pi.w, vi.w, hy);
             };
             // four 16-byte elements per thread, all twelve loads in flight before the first use.  (The weight-gradient tiles put this
             // kernel at 104 registers = 16 waves per CU: with two elements per thread the 1024 blocks of W1 did not all fit at once.)
-            const int64_t n4 = n / 4, stride = (int64_t)gx * blockDim.x;
-            for (int64_t i = (int64_t)bx * blockDim.x + threadIdx.x; i < n4; i += RMS_UNROLL * stride) {
+            const int64_t n4 = n / 4, stride = (int64_t)gx * RMS_THREADS;
+            for (int64_t i = (int64_t)bx * RMS_THREADS + threadIdx.x; i < n4; i += RMS_UNROLL * stride) {
                 float4 pv[RMS_UNROLL], vv[RMS_UNROLL], gv[RMS_UNROLL];
 #pragma unroll
                 for (int u = 0; u < RMS_UNROLL; ++u) {
@@ -970,7 +971,7 @@ __device__ __forceinline__ void rmsprop_body(const RmsArgs &a, const float *hype
                 }
             }
         } else
-        for (int64_t i = (int64_t)bx * blockDim.x + threadIdx.x; i < n; i += (int64_t)gx * blockDim.x) {
+        for (int64_t i = (int64_t)bx * RMS_THREADS + threadIdx.x; i < n; i += (int64_t)gx * RMS_THREADS) {
             const float pi = p[i];
             float gr;
             if (a.parts[t] == COL_PARTS) {          // 32 independent loads in flight, summed in a fixed order
@@ -984,10 +985,10 @@ __device__ __forceinline__ void rmsprop_body(const RmsArgs &a, const float *hype
                 gr = g[i];
                 for (int q = 1; q < a.parts[t]; ++q) gr += g[(int64_t)q * n + i];
             }
-            const float gi = gr + wd * pi;                        // grad.add(param, alpha=weight_decay)
-            const float vi = v[i] * alpha + oma * gi * gi;  // square_avg.mul_(alpha).addcmul_(g, g, value=1-alpha)
+            float pn = pi, vi = v[i];
+            wg_dev::rms_update(gr, pn, vi, wg_dev::Hyper{lr, alpha, eps, wd, oma});
             v[i] = vi;
-            p[i] = pi - lr * (gi / (sqrtf(vi) + eps));           // param.addcdiv_(grad, sqrt(v)+eps, value=-lr)
+            p[i] = pn;
         }
     }
     if (bid == 0 && threadIdx.x == 0) { ctl[0] += 1; ctl[1] += batch_advance; }
@@ -1015,13 +1016,14 @@ __global__ __launch_bounds__(256) void rmsprop_kernel(RmsArgs a, const float *hy
 // workgroup is one wave per SIMD, so both fit a CU.  One launch, one boundary and the 8 MB gradient's round trip fewer than
 // hipBLASLt's GEMM followed by rmsprop_kernel.
 template <bool STAMPS = false, bool SKIP_TILES = false>      // STAMPS (IDELUCS_STAMPS=1, a diagnostic): every workgroup leaves {start, end, hardware id, XCC id} in `stamps`
-__global__ __launch_bounds__(256) void wgrad_rmsprop_kernel(wg_dev::WgArgs w, RmsArgs a, const float *hyper, int64_t *ctl,
+__global__ __launch_bounds__(wg_dev::THREADS) void wgrad_rmsprop_kernel(wg_dev::WgArgs w, RmsArgs a, const float *hyper, int64_t *ctl,
                                                             int64_t batch_advance, int n_gather, idl_dev::GatherArgs g, uint64_t *stamps)
 {
     uint64_t t0 = 0;
     if (STAMPS) t0 = __builtin_amdgcn_s_memrealtime();
-    if ((int)blockIdx.x < w.tiles) { if (!SKIP_TILES) wg_dev::q16_tile<0>(w, (int)blockIdx.x); }
-    else {
+    extern __shared__ wg_dev::f32x4_t wg_img[];
+    if ((int)blockIdx.x < w.tiles) { if (!SKIP_TILES) wg_dev::q16_tile<0>(w, (int)blockIdx.x, wg_img); }
+    else if (threadIdx.x < 256) {            // (the tiles' fifth wave has nothing to do here)
         // a tile wave issues matrix instructions back to back and, being the older wave of its SIMD, wins every arbitration: at equal
         // priority these workgroups crawl beside it (measured with the stamps: 40 us for 5 us of work, and the tiles 3..16 us longer
         // wherever they met a dW2 tile); ahead of it they are gone after a few microseconds
@@ -1418,12 +1420,23 @@ static int rmsprop_launch(int count, float *const *params, const float *const *g
     if (big != nullptr) {
         const dim3 grid((unsigned)(big->tiles + nb_total + extra + a.wg_tiles));
         static const bool skip = [] { const char *e = getenv("IDELUCS_STAMPS_SKIP_TILES"); return e != nullptr && e[0] == '1'; }();
+        static bool attr_set[64] = {};
+        int dev = 0;
+        IDL_HIP_TRY(hipGetDevice(&dev));
+        if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+            IDL_HIP_TRY(hipFuncSetAttribute((const void *)wgrad_rmsprop_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, wg_dev::IMG_BYTES));
+            IDL_HIP_TRY(hipFuncSetAttribute((const void *)wgrad_rmsprop_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, wg_dev::IMG_BYTES));
+            IDL_HIP_TRY(hipFuncSetAttribute((const void *)wgrad_rmsprop_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, wg_dev::IMG_BYTES));
+            attr_set[dev] = true;
+        }
+        const dim3 block(wg_dev::THREADS);
+        const hipStream_t st_ = (hipStream_t)stream;
         if (uint64_t *st = stamp_buffer(); st != nullptr && skip)
-            hipLaunchKernelGGL((wgrad_rmsprop_kernel<true, true>), grid, dim3(256), 0, (hipStream_t)stream, *big, a, hyper, ctl, batch_advance, (int)extra, g, st);
+            hipLaunchKernelGGL((wgrad_rmsprop_kernel<true, true>), grid, block, wg_dev::IMG_BYTES, st_, *big, a, hyper, ctl, batch_advance, (int)extra, g, st);
         else if (st != nullptr)
-            hipLaunchKernelGGL(wgrad_rmsprop_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, *big, a, hyper, ctl, batch_advance, (int)extra, g, st);
+            hipLaunchKernelGGL(wgrad_rmsprop_kernel<true>, grid, block, wg_dev::IMG_BYTES, st_, *big, a, hyper, ctl, batch_advance, (int)extra, g, st);
         else
-            hipLaunchKernelGGL(wgrad_rmsprop_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, *big, a, hyper, ctl, batch_advance, (int)extra, g,
+            hipLaunchKernelGGL(wgrad_rmsprop_kernel<false>, grid, block, wg_dev::IMG_BYTES, st_, *big, a, hyper, ctl, batch_advance, (int)extra, g,
                                (uint64_t *)nullptr);
     }
     else

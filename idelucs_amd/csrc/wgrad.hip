@@ -11,9 +11,10 @@
 namespace {
 
 template <int VARIANT>
-__global__ __launch_bounds__(256) void wgrad_q16_kernel(wg_dev::WgArgs a)
+__global__ __launch_bounds__(wg_dev::THREADS) void wgrad_q16_kernel(wg_dev::WgArgs a)
 {
-    wg_dev::q16_tile<VARIANT>(a, (int)blockIdx.x);
+    extern __shared__ wg_dev::f32x4_t wg_img[];
+    wg_dev::q16_tile<VARIANT>(a, (int)blockIdx.x, wg_img);
 }
 
 }  // namespace
@@ -39,8 +40,17 @@ int idl_wgrad_rmsprop(const float *dy, const float *x, int m, int n_out, int n_i
     a.tiles_m = n_out / wg_dev::TM;
     a.tiles = a.tiles_m * (n_in / wg_dev::TN);
     static const bool noload = [] { const char *e = getenv("IDELUCS_WGRAD_KERNEL"); return e != nullptr && strcmp(e, "noload") == 0; }();
-    if (noload) hipLaunchKernelGGL((wgrad_q16_kernel<1>), dim3((unsigned)a.tiles), dim3(256), 0, (hipStream_t)stream, a);   // diagnostic
-    else hipLaunchKernelGGL((wgrad_q16_kernel<0>), dim3((unsigned)a.tiles), dim3(256), 0, (hipStream_t)stream, a);
+    static bool attr_set[64] = {};
+    int dev = 0;
+    IDL_HIP_TRY(hipGetDevice(&dev));
+    if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+        IDL_HIP_TRY(hipFuncSetAttribute((const void *)wgrad_q16_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, wg_dev::IMG_BYTES));
+        IDL_HIP_TRY(hipFuncSetAttribute((const void *)wgrad_q16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, wg_dev::IMG_BYTES));
+        attr_set[dev] = true;
+    }
+    const dim3 grid((unsigned)a.tiles), block(wg_dev::THREADS);
+    if (noload) hipLaunchKernelGGL((wgrad_q16_kernel<1>), grid, block, wg_dev::IMG_BYTES, (hipStream_t)stream, a);   // diagnostic
+    else hipLaunchKernelGGL((wgrad_q16_kernel<0>), grid, block, wg_dev::IMG_BYTES, (hipStream_t)stream, a);
     IDL_HIP_TRY(hipGetLastError());
     return IDL_OK;
 }

@@ -55,11 +55,14 @@ struct WgArgs {
 
 struct Hyper { float lr, alpha, eps, wd, oma; };
 
+// (v_sqrt_f32 and v_rcp_f32, 1 ulp each, instead of the correctly rounded sqrtf and IEEE division: two instructions instead of
+//  ~25 per element -- 32 elements per lane stand between the last MFMA and the last store, 2 us of VALU per launch with the exact
+//  forms; the step moves a weight by lr * g / (sqrt(v) + eps), so the parameter differs by < 1e-7 of the step)
 __device__ __forceinline__ void rms_update(float g, float &p, float &v, const Hyper &h)
 {
     const float gi = g + h.wd * p;                   // grad.add(param, alpha=weight_decay)
     v = v * h.alpha + h.oma * gi * gi;               // square_avg.mul_(alpha).addcmul_(g, g, value=1-alpha)
-    p = p - h.lr * (gi / (sqrtf(v) + h.eps));        // param.addcdiv_(grad, sqrt(v)+eps, value=-lr)
+    p = p - h.lr * (gi * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(v) + h.eps));        // param.addcdiv_(grad, sqrt(v)+eps, value=-lr)
 }
 
 __host__ __device__ inline bool supported(int m, int n_out, int n_in)
@@ -69,8 +72,15 @@ __host__ __device__ inline bool supported(int m, int n_out, int n_in)
 
 // One 64 x 128 tile by one 256-thread workgroup (bid = tile index).  VARIANT 1: no loads in the loop (a diagnostic: what the
 // MFMA stream alone takes; wrong results).
+// The workgroup is FIVE waves (THREADS = 320): waves 0..3 compute; wave 4 fetches the tile's W and square_avg elements (64 KB) into
+// the LDS image `img` while they do, laid out so that a compute wave's epilogue reads are lane-contiguous 16-byte reads.  (A
+// wave's vector-memory operations retire in order: requested by the compute waves themselves -- as in this kernel's first form --
+// those 16 MB from HBM stood between every wave and its first operands, ~2 us per launch.)
+constexpr int THREADS = 320;
+constexpr int IMG_BYTES = 2 * 4 * 8 * 64 * 16;       // [W | square_avg][compute wave][rb * 4 + reg][lane] float4
+
 template <int VARIANT = 0>
-__device__ __forceinline__ void q16_tile(const WgArgs &a, const int bid)
+__device__ __forceinline__ void q16_tile(const WgArgs &a, const int bid, f32x4_t *img)
 {
     constexpr int D = RING;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -79,19 +89,28 @@ __device__ __forceinline__ void q16_tile(const WgArgs &a, const int bid)
     // consecutive tiles of an XCD (blocks b, b + 8, ...) share dy (2 MB at cfg2) and a 512-column panel of x (2 MB): L2
     int tile = bid;
     if ((a.tiles & 7) == 0) tile = (bid & 7) * (a.tiles >> 3) + (bid >> 3);
-    const int h0 = (tile % a.tiles_m) * TM + 32 * (wv >> 1), f0 = (tile / a.tiles_m) * TN + 64 * (wv & 1);
     const int lda = a.p.n_out, ldb = a.p.n_in;
-    // accumulator [rb][cb] register reg = element (h0 + 2 (4 q + reg) + rb, f0 + 4 l + cb)
-    f32x4_t pw[2][4], pv[2][4];
-    if (a.p.W != nullptr) {
+    if (wv == 4) {                           // the fetch wave
+        if (a.p.W != nullptr) {
+            const int th0 = (tile % a.tiles_m) * TM, tf0 = (tile / a.tiles_m) * TN;
+#pragma unroll 1
+            for (int b = 0; b < 4; ++b) {            // batches of 16 requests (64 registers: the kernel's budget is 160)
+                const float *src = b < 2 ? a.p.W : a.p.V;
+                f32x4_t t[16];
 #pragma unroll
-        for (int rb = 0; rb < 2; ++rb)
+                for (int i = 0; i < 16; ++i) {      // (b & 1) * 16 + i = compute wave * 8 + rb * 4 + reg
+                    const int w = 2 * (b & 1) + (i >> 3), rb = (i >> 2) & 1, reg = i & 3;
+                    t[i] = *(const f32x4_t *)(src + (th0 + 32 * (w >> 1) + 2 * (4 * q + reg) + rb) * ldb + tf0 + 64 * (w & 1) + 4 * l);
+                }
 #pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                const int o = (h0 + 2 * (4 * q + reg) + rb) * ldb + f0 + 4 * l;
-                pw[rb][reg] = *(const f32x4_t *)(a.p.W + o); pv[rb][reg] = *(const f32x4_t *)(a.p.V + o);
+                for (int i = 0; i < 16; ++i) img[(b * 16 + i) * 64 + lane] = t[i];
             }
+        }
+        __syncthreads();
+        return;
     }
+    const int h0 = (tile % a.tiles_m) * TM + 32 * (wv >> 1), f0 = (tile / a.tiles_m) * TN + 64 * (wv & 1);
+    // accumulator [rb][cb] register reg = element (h0 + 2 (4 q + reg) + rb, f0 + 4 l + cb)
     const uint32_t oa = (uint32_t)((q * lda + h0 + 2 * l) * 4), ob = (uint32_t)((q * ldb + f0 + 4 * l) * 4);
     const uint32_t sa = (uint32_t)(4 * lda * 4), sb = (uint32_t)(4 * ldb * 4);
     const uint32_t passes = (uint32_t)((a.m >> 2) / D - 1);   // ring passes after the first (m / 4 k-quads, a multiple of D)
@@ -105,6 +124,7 @@ __device__ __forceinline__ void q16_tile(const WgArgs &a, const int bid)
     if constexpr (VARIANT == 1) WGRAD_ASM(WGRAD_Q16_RING8_NOLOAD);
     else WGRAD_ASM(WGRAD_Q16_RING8);
 #undef WGRAD_ASM
+    __syncthreads();                         // the fetch wave's image is complete
     Hyper hy{};
     if (a.hyper != nullptr) hy = Hyper{a.hyper[0], a.hyper[1], a.hyper[2], a.hyper[3], a.hyper[4]};
     const f32x4_t *acc[2][4] = {{&c00, &c01, &c02, &c03}, {&c10, &c11, &c12, &c13}};
@@ -116,7 +136,7 @@ __device__ __forceinline__ void q16_tile(const WgArgs &a, const int bid)
             const f32x4_t g = {(*acc[rb][0])[reg], (*acc[rb][1])[reg], (*acc[rb][2])[reg], (*acc[rb][3])[reg]};
             if (a.p.grad != nullptr) *(f32x4_t *)(a.p.grad + o) = g;
             if (a.p.W != nullptr) {
-                f32x4_t p = pw[rb][reg], v = pv[rb][reg];
+                f32x4_t p = img[(wv * 8 + rb * 4 + reg) * 64 + lane], v = img[(32 + wv * 8 + rb * 4 + reg) * 64 + lane];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { float pe = p[e], ve = v[e]; rms_update(g[e], pe, ve, hy); p[e] = pe; v[e] = ve; }
                 *(f32x4_t *)(a.p.V + o) = v; *(f32x4_t *)(a.p.W + o) = p;

@@ -852,6 +852,11 @@ struct RmsArgs {
 
 // One 16 x 16 tile of dy^T x on the fp32 matrix cores (v_mfma_f32_16x16x4_f32): the four waves split the contraction index m,
 // the partial tiles are added through LDS in a fixed order, then RMSprop on the tile.  red: 1024 floats of LDS.
+// AHEAD (the launch with the dW1 tiles at its head, where these workgroups run behind the tiles and every microsecond of their chain
+// is the launch's tail): the parameter / square_avg elements and BOTH 128-row batches of a wave's 256 rows are requested before
+// the first product -- one trip to memory instead of three (128 more registers, which that launch has and rmsprop_kernel, whose
+// streaming blocks want 16 waves per CU, has not).
+template <bool AHEAD>
 __device__ __forceinline__ void wgrad_tile_rms(const RmsArgs &a, int tile, float lr, float alpha, float eps, float wd, float oma, float *red)
 {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l = lane & 15, q = lane >> 4;
@@ -862,7 +867,25 @@ __device__ __forceinline__ void wgrad_tile_rms(const RmsArgs &a, int tile, float
     const int kb = wv * per, ke = (kb + per < m) ? kb + per : m;
     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
     const float *pa = a.wg_dy + i0 + l, *pb = a.wg_x + j0 + l;    // A[i = l][k = q] = dy[k][i0 + l], B[k = q][j = l] = x[k][j0 + l]
-    if (a.wg_xt && (per & 127) == 0 && kb + per <= m) {
+    const int oo = (i0 + (tid >> 4)) * ldb + j0 + (tid & 15);     // this thread's element of the tile in the epilogue
+    float pi = 0.f, vi = 0.f;
+    if (AHEAD) { pi = a.p[a.wg_t][oo]; vi = a.v[a.wg_t][oo]; }
+    if (AHEAD && a.wg_xt && per == 256 && kb + per <= m) {
+        const float *pbt = a.wg_x + (int64_t)(j0 + l) * m;
+        float av[64], bv[64];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int u4 = 0; u4 < 8; ++u4) {
+                const float4 t4 = *(const float4 *)(pbt + kb + 128 * h + 32 * q + 4 * u4);
+                bv[32 * h + 4 * u4] = t4.x; bv[32 * h + 4 * u4 + 1] = t4.y; bv[32 * h + 4 * u4 + 2] = t4.z; bv[32 * h + 4 * u4 + 3] = t4.w;
+            }
+#pragma unroll
+            for (int u = 0; u < 32; ++u) av[32 * h + u] = pa[(kb + 128 * h + 32 * q + u) * lda];
+        }
+#pragma unroll
+        for (int u = 0; u < 64; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
+    } else if (a.wg_xt && (per & 127) == 0 && kb + per <= m) {
         // x stored transposed ([n_in, m]): lane (l, q) walks 32 consecutive k of ITS column per batch (16-byte reads), and MFMA step
         // u takes k = k0 + 32 q + u on both operands -- any assignment of k to (step, q) is a valid order of the same sum
         const float *pbt = a.wg_x + (int64_t)(j0 + l) * m;
@@ -903,12 +926,11 @@ __device__ __forceinline__ void wgrad_tile_rms(const RmsArgs &a, int tile, float
 #pragma unroll
     for (int r = 0; r < 4; ++r) red[wv * 256 + (4 * q + r) * 16 + l] = acc[r];          // C/D: row = 4 q + reg, col = l
     __syncthreads();
-    const int i = tid >> 4, j = tid & 15;
     const float g = (red[tid] + red[256 + tid]) + (red[512 + tid] + red[768 + tid]);
-    const int o = (i0 + i) * ldb + j0 + j;
+    const int o = oo;
     if (a.wg_grad != nullptr) a.wg_grad[o] = g;
     float *p = a.p[a.wg_t], *v = a.v[a.wg_t];
-    float pi = p[o], vi = v[o];
+    if (!AHEAD) { pi = p[o]; vi = v[o]; }
     wg_dev::rms_update(g, pi, vi, wg_dev::Hyper{lr, alpha, eps, wd, oma});
     v[o] = vi;
     p[o] = pi;
@@ -922,6 +944,7 @@ constexpr int RMS_UNROLL = 4;         // 16-byte elements per thread of the stre
 
 constexpr int RMS_THREADS = 256;   // threads of an optimizer block (the launch may carry a fifth, idle wave: wgrad_rmsprop_kernel)
 
+template <bool AHEAD = false>
 __device__ __forceinline__ void rmsprop_body(const RmsArgs &a, const float *hyper, int64_t *ctl, int64_t batch_advance, int gx,
                                              int n_gather, const idl_dev::GatherArgs &g, const int blk)
 {
@@ -930,7 +953,7 @@ __device__ __forceinline__ void rmsprop_body(const RmsArgs &a, const float *hype
     const float lr = hyper[0], alpha = hyper[1], eps = hyper[2], wd = hyper[3], oma = hyper[4];
     if (blk < a.wg_tiles) {
         __shared__ float red[1024];
-        wgrad_tile_rms(a, blk, lr, alpha, eps, wd, oma, red);
+        wgrad_tile_rms<AHEAD>(a, blk, lr, alpha, eps, wd, oma, red);
         return;
     }
     const int b0 = blk - a.wg_tiles;
@@ -994,10 +1017,19 @@ __device__ __forceinline__ void rmsprop_body(const RmsArgs &a, const float *hype
     if (bid == 0 && threadIdx.x == 0) { ctl[0] += 1; ctl[1] += batch_advance; }
     if (a.out != nullptr && bid == a.first[a.count] - 1 && threadIdx.x < 64) {
         // step loss = w_nce * mean(loss_rows) + w_iic * IIC (left in out[3] by iic_core_kernel); out[1] = running sum
+        const float iic = a.out[3], run = a.out[1];           // requested together with the rows: one trip
+        float part[16];
         float acc = 0.f;
-        for (int i = threadIdx.x; i < a.loss_m; i += 64) acc += a.loss_rows[i];
+        if (a.loss_m <= 1024) {                               // every load in flight before the first add (same order of additions)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) { const int i = threadIdx.x + 64 * j; part[j] = i < a.loss_m ? a.loss_rows[i] : 0.f; }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc += part[j];
+        } else {
+            for (int i = threadIdx.x; i < a.loss_m; i += 64) acc += a.loss_rows[i];
+        }
         acc = wave_sum(acc) / (float)a.loss_m;
-        if (threadIdx.x == 0) { const float l = a.w_nce * acc + a.w_iic * a.out[3]; a.out[0] = l; a.out[1] += l; a.out[2] = acc; }
+        if (threadIdx.x == 0) { const float l = a.w_nce * acc + a.w_iic * iic; a.out[0] = l; a.out[1] = run + l; a.out[2] = acc; }
     }
 }
 
@@ -1028,7 +1060,7 @@ __global__ __launch_bounds__(wg_dev::THREADS) void wgrad_rmsprop_kernel(wg_dev::
         // priority these workgroups crawl beside it (measured with the stamps: 40 us for 5 us of work, and the tiles 3..16 us longer
         // wherever they met a dW2 tile); ahead of it they are gone after a few microseconds
         __builtin_amdgcn_s_setprio(3);
-        rmsprop_body(a, hyper, ctl, batch_advance, 0, n_gather, g, (int)blockIdx.x - w.tiles);
+        rmsprop_body<true>(a, hyper, ctl, batch_advance, 0, n_gather, g, (int)blockIdx.x - w.tiles);
     }
     if (STAMPS) {
         __syncthreads();

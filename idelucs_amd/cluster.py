@@ -1,5 +1,6 @@
 """idelucs_amd.cluster -- the scikit-learn-like entry point, `iDeLUCS_cluster(...).fit_predict()`, with the
 constructor signature and return values of reference idelucs/cluster.py:9-52."""
+from .models import IID_model
 from .training import prepare_model, train_voter
 
 # what the reference hard-codes for this entry point (cluster.py:20-30)
@@ -19,5 +20,10 @@ class iDeLUCS_cluster():
         # every voter is a function of (seed, voter index) alone (IID_model.begin_voter), so the voters the reference trains
         # and then discards here need not be trained at all
         last = self.args["n_voters"] - 1
+        if IID_model.voter_state_carried():
+            # IDELUCS_VOTER_STATE=carry: the reference's sequence -- one optimizer for all voters (reference models.py:87-88), so
+            # voter v starts from voter v-1's RMSprop state and every voter has to be trained (cluster.py:39-52)
+            for v in range(last):
+                train_voter(model, self.args["n_epochs"], v, self.args["n_voters"])
         _, y_pred, _, latent = train_voter(model, self.args["n_epochs"], last, self.args["n_voters"])
         return y_pred, latent

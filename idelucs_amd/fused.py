@@ -162,10 +162,13 @@ class FusedLinearTrainer:
         self._parts = (ctypes.c_int32 * n)(*self.parts)
         self._sz_no_w1 = (ctypes.c_int64 * n)(*([0] + [p.numel() for p in self.params[1:]]))     # W1 updated by idl_wgrad_rmsprop
 
-    def begin_voter(self, voter):
+    def begin_voter(self, voter, keep_state=False):
         """Dropout stream of voter v: the Philox counter word the kernels take from ctl[0] (its low 32 bits) starts at
-        v << 24, so voters never share masks whichever rank runs them (16.7 M optimizer steps per voter, 256 voters)."""
+        v << 24, so voters never share masks whichever rank runs them (16.7 M optimizer steps per voter, 256 voters).
+        keep_state: the previous voter's RMSprop running averages stay (IDELUCS_VOTER_STATE=carry, models.IID_model)."""
         self.ctl[0] = (int(voter) & 0xFF) << 24
+        if keep_state:
+            return
         for v in self.square_avg:               # a voter starts with fresh optimizer state (models.IID_model.begin_voter)
             v.zero_()
 

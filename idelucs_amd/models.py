@@ -127,6 +127,15 @@ class IID_model():
         self._shared.clear()
 
     # ------------------------------------------------------------------ training
+    @staticmethod
+    def voter_state_carried():
+        """IDELUCS_VOTER_STATE=carry: the reference's behaviour when all voters train in ONE process -- a single optimizer (and
+        scheduler) object serves every voter (reference models.py:87-99; __main__.py:109 re-initialises only the weights), so
+        voter v starts with voter v-1's RMSprop running averages, learning rate and scheduler counters.  Only meaningful when the
+        voters run one after the other on one rank (training.train_voters and cluster.fit_predict see to that and refuse a sharded
+        run); the default, "fresh", makes every voter an independent run that can train anywhere."""
+        return os.environ.get("IDELUCS_VOTER_STATE", "fresh") == "carry"
+
     def begin_voter(self, voter=0):
         """A fresh voter (reference __main__.py:109: weights_init between voters).  The reference's voters differ because
         its one process consumes the torch RNG sequentially; here voters may run on different ranks, or side by side on one GPU,
@@ -141,12 +150,14 @@ class IID_model():
         self._gen = torch.Generator(device=self.device).manual_seed(vseed)
         self.net.apply(lambda mod: weights_init(mod, self._gen))
         self.epoch = 0
-        self.optimizer.state.clear()
-        for grp in self.optimizer.param_groups:
-            grp['lr'] = self.lr
-        self._make_scheduler()
+        carry = self.voter_state_carried() and self._voter > 0
+        if not carry:
+            self.optimizer.state.clear()
+            for grp in self.optimizer.param_groups:
+                grp['lr'] = self.lr
+            self._make_scheduler()
         if self._fused is not None:
-            self._fused.begin_voter(self._voter)
+            self._fused.begin_voter(self._voter, keep_state=carry)
 
     def _step(self, x):
         """One optimizer step on a [2b, F] batch (rows [0,b) "true", [b,2b) "modified")."""

@@ -54,6 +54,12 @@ def train_voters(model, voters, n_epochs, n_voters=None, lanes=None, progress=Tr
     voters = list(voters)
     n_voters = n_voters if n_voters is not None else len(voters)
     lanes = voter_lanes(len(voters)) if lanes is None else max(1, min(int(lanes), len(voters)))
+    if models.IID_model.voter_state_carried():
+        # the reference's one-optimizer-for-all-voters behaviour: voters strictly one after the other, all of them here
+        if voters != list(range(n_voters)):
+            raise ValueError("IDELUCS_VOTER_STATE=carry needs every voter on one rank (the optimizer state of voter v-1 is voter v's start): "
+                             "run without a launcher, or leave the default (independent voters)")
+        lanes = 1
     if lanes <= 1 or not can_batch(model):
         return {v: train_voter(model, n_epochs, v, n_voters, progress) for v in voters}
     out = {}

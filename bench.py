@@ -260,11 +260,26 @@ def pmc_traffic_gb():
     return None
 
 
+CPU_CALIBRATION = "r03_cpu_calibration.json"   # profiles/: port vs the imported reference in the build container (tools/calibrate_cpu_baseline.py)
+
+
+def cpu_calibration():
+    """{"ratio": port seq/s / reference seq/s on the same sample, ...} as measured in the build container (the reference cannot
+    travel to the GPU box), or None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", CPU_CALIBRATION)) as fh:
+            return json.load(fh)
+    except Exception:
+        return None
+
+
 def cpu_baseline(args):
     """The oracle (CPU restatement of the reference algorithm) timed on this box's host cores, in the
     reference's shape: single-threaded per-record vectorise passes with numpy/random mimics
-    (idelucs/utils.py:224-368), StandardScaler, then one PyTorch-CPU epoch with cores-2 threads
-    (idelucs/__main__.py:316).  Bounded sample of the same workload; seq/s = sample / wall."""
+    (idelucs/utils.py:224-368), StandardScaler, then one PyTorch-CPU epoch.  Two thread settings for the epoch: the reference's
+    own cpu_count()-2 (idelucs/__main__.py:316; on a 256-core host that oversubscribes these small GEMMs badly, so it is timed
+    on a bounded number of optimizer steps and scaled) and min(cores-2, 32), the CPU's best shot, which is `value`.
+    Bounded sample of the same workload; seq/s = sample / wall."""
     import random
     from oracle import oracle as O
     import torch.nn as nn
@@ -274,10 +289,8 @@ def cpu_baseline(args):
     rng = np.random.default_rng(12345)
     seqs = [bytearray(rng.choice(np.frombuffer(b"ACGT", np.uint8), size=L).tobytes()) for _ in range(n)]
     cores = os.cpu_count() or 1
-    # the reference uses cpu_count()-2 torch threads (__main__.py:316); on a 256-core host that
-    # oversubscribes these small GEMMs ~50x slower than 32 threads, so give the CPU its best shot
     threads = max(1, min(cores - 2, 32))
-    torch.set_num_threads(threads)
+    ref_threads = max(1, cores - 2)
     np.random.seed(0); random.seed(0)
     t0 = time.perf_counter()
     tfs = [O.transition_transversion(1e-2, 0.5e-2), O.transition(1e-2), O.transversion(0.5e-2)] + \
@@ -301,25 +314,48 @@ def cpu_baseline(args):
     x[:, 0] = O.scaler_transform(x[:, 0], mean, scale)
     x[:, 1] = O.scaler_transform(x[:, 1], mean, scale)
     t_vec = time.perf_counter() - t0
-    net = NetLinear(4 ** k, args.n_clusters)
-    for mod in net.modules():
-        if isinstance(mod, nn.Linear):
-            nn.init.kaiming_normal_(mod.weight); nn.init.zeros_(mod.bias)
-    opt = torch.optim.RMSprop(net.parameters(), lr=1e-3, weight_decay=0.01)
     xt = torch.from_numpy(x)
-    net.train()
-    perm = torch.randperm(xt.shape[0])
-    for i in range(0, xt.shape[0], args.batch_sz):
-        idx = perm[i:i + args.batch_sz]
-        opt.zero_grad()
-        z1, h1 = net(xt[idx, 0]); z2, h2 = net(xt[idx, 1])
-        loss = 0.75 * info_nce_loss(h1, h2, 0.85) + 0.25 * IID_loss(z1, z2, lamb=2.8)
-        loss.backward(); opt.step()
-    t_all = time.perf_counter() - t0
-    return {"value": n / t_all, "unit": "sequences/sec", "cores": threads, "kind": "port",
-            "sample": f"{n} of the {args.n} x {L} bp sequences (same generator family), k={k}, n_mimics={args.n_mimics}, "
-                      f"B={args.batch_sz}: oracle vectorise single-threaded {t_vec:.1f} s + torch-CPU epoch "
-                      f"({threads} threads of {cores} cores) {t_all - t_vec:.1f} s"}
+    n_steps = (xt.shape[0] + args.batch_sz - 1) // args.batch_sz
+
+    def epoch(nthreads, max_steps):
+        torch.set_num_threads(nthreads)
+        torch.manual_seed(0)
+        net = NetLinear(4 ** k, args.n_clusters)
+        for mod in net.modules():
+            if isinstance(mod, nn.Linear):
+                nn.init.kaiming_normal_(mod.weight); nn.init.zeros_(mod.bias)
+        opt = torch.optim.RMSprop(net.parameters(), lr=1e-3, weight_decay=0.01)
+        net.train()
+        perm = torch.randperm(xt.shape[0])
+        t1 = time.perf_counter()
+        done = 0
+        for i in range(0, xt.shape[0], args.batch_sz):
+            if done >= max_steps:
+                break
+            idx = perm[i:i + args.batch_sz]
+            opt.zero_grad()
+            z1, h1 = net(xt[idx, 0]); z2, h2 = net(xt[idx, 1])
+            loss = 0.75 * info_nce_loss(h1, h2, 0.85) + 0.25 * IID_loss(z1, z2, lamb=2.8)
+            loss.backward(); opt.step()
+            done += 1
+        return (time.perf_counter() - t1) * n_steps / max(done, 1), done
+
+    t_ep, _ = epoch(threads, n_steps)
+    if ref_threads != threads:
+        t_ep_ref, steps_ref = epoch(ref_threads, max(2, min(n_steps, int(args.cpu_ref_steps))))
+    else:
+        t_ep_ref, steps_ref = t_ep, n_steps
+    cal = cpu_calibration()
+    out = {"value": n / (t_vec + t_ep), "unit": "sequences/sec", "cores": threads, "threads": threads, "kind": "port",
+           "value_reference_threads": n / (t_vec + t_ep_ref), "reference_threads": ref_threads,
+           "calibration_ratio": cal["ratio"] if cal else None,
+           "calibration_source": (f"profiles/{CPU_CALIBRATION}: port / imported reference on the build container's {cal.get('cores')} cores, "
+                                  f"{cal.get('sample')}") if cal else None,
+           "sample": f"{n} of the {args.n} x {L} bp sequences (same generator family), k={k}, n_mimics={args.n_mimics}, "
+                     f"B={args.batch_sz}: oracle vectorise single-threaded {t_vec:.1f} s + torch-CPU epoch of {n_steps} steps "
+                     f"{t_ep:.1f} s with {threads} threads of {cores} cores (value); with the reference's cpu_count()-2 = {ref_threads} threads "
+                     f"{t_ep_ref:.1f} s (timed on {steps_ref} steps, scaled)"}
+    return out
 
 
 def t_e2e(args, dev, reps=2):
@@ -413,6 +449,8 @@ def main():
     ap.add_argument("--with-predict", dest="with_predict", type=int, default=None,
                     help="1: predict + all-gather inside the timed region (default: 0 at N=1 with one voter = BASELINE.md's region; 1 otherwise)")
     ap.add_argument("--cpu-sample", dest="cpu_sample", type=int, default=24000)
+    ap.add_argument("--cpu-ref-steps", dest="cpu_ref_steps", type=int, default=8,
+                    help="optimizer steps timed with the reference's cpu_count()-2 torch threads (scaled to the epoch)")
     ap.add_argument("--no-cpu-baseline", dest="cpu_base", action="store_false")
     ap.add_argument("--no-e2e", dest="e2e", action="store_false")
     ap.add_argument("--n-rate", dest="n_rate", type=float, default=0.0,
@@ -554,7 +592,10 @@ def main():
                        "parallelism": f"{V} voters / {world} ranks" + (f", batches of {len(hp.lanes)} voters in lockstep" if len(hp.lanes) > 1 else "")},
             "roofline": {"kernel": "vectorise kernel (hand-written HIP: one count + per-view window deltas + normalise, all views)",
                          "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic_gb() if not cfg5 else None, "ms_per_launch": t_vec, "bytes_per_seq_algorithmic": b_vec,
+                         "traffic": pmc_traffic_gb() if not cfg5 else None,
+                         "traffic_source": (f"profiles/{PMC_PROFILE} (rocprofv3 --pmc passes of this kernel at this workload, per launch; "
+                                            "not counters of this run)") if not cfg5 else None,
+                         "ms_per_launch": t_vec, "bytes_per_seq_algorithmic": b_vec,
                          "share_of_step": t_vec / ms_step},
             "roofline_epoch": {"kernel": "training epoch (hipBLASLt fp32 GEMMs + gather + losses + RMSprop)", "bound": "mfma",
                                "achieved": ach_ep, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach_ep / MFMA_F32_PEAK_TFLOPS,

@@ -11,6 +11,7 @@ is held to (the bar must come from the reference, not from this repo
            (the CLI module itself needs `hdbscan`, which is absent here), seeds 0..2.
 
 Usage:  python tests/golden/make_anchor_seeds.py      (~15 min on 8 cores)
+        python tests/golden/make_anchor_seeds.py --extend-single 40      (round 3: seeds 10..39 of `single` appended)
 """
 import json
 import os
@@ -97,7 +98,43 @@ def main():
         json.dump(out, open(os.path.join(HERE, "anchor_seeds.json"), "w"), indent=1)
 
 
+def extend_single(upto):
+    """Round 3: more single-voter seeds (10 .. upto-1) appended to the existing fixture -- ten runs of a quantity with a standard
+    deviation of 0.06 cannot tell 'the same distribution' from '0.03 worse' (VERDICT r2 weak #1)."""
+    build_reference()
+    fas, gt = os.path.join(DATA, "Influenza-A.fas"), os.path.join(DATA, "Influenza-A_GT.tsv")
+    path = os.path.join(HERE, "anchor_seeds.json")
+    out = json.load(open(path))
+    have = {r["seed"] for r in out["single"]}
+    for seed in range(upto):
+        if seed in have:
+            continue
+        out["single"].append(run(SINGLE.format(scratch=SCRATCH, seed=seed, fas=fas, gt=gt)))
+        print(out["single"][-1], flush=True)
+        json.dump(out, open(path, "w"), indent=1)
+
+
+def extend_voters5(upto):
+    """More 5-voter ensembles (seeds 3 .. upto-1) appended to the existing fixture."""
+    build_reference()
+    fas, gt = os.path.join(DATA, "Influenza-A.fas"), os.path.join(DATA, "Influenza-A_GT.tsv")
+    path = os.path.join(HERE, "anchor_seeds.json")
+    out = json.load(open(path))
+    have = {r["seed"] for r in out["voters5"]}
+    for seed in range(upto):
+        if seed in have:
+            continue
+        out["voters5"].append(run(VOTERS5.format(scratch=SCRATCH, seed=seed, fas=fas, gt=gt)))
+        print(out["voters5"][-1], flush=True)
+        json.dump(out, open(path, "w"), indent=1)
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1:            # no options: anything on the command line gets the usage, not a 15-minute rerun that rewrites the fixture
+    if len(sys.argv) == 3 and sys.argv[1] == "--extend-single":
+        extend_single(int(sys.argv[2]))
+    elif len(sys.argv) == 3 and sys.argv[1] == "--extend-voters5":
+        extend_voters5(int(sys.argv[2]))
+    elif len(sys.argv) > 1:          # anything else on the command line gets the usage, not a 15-minute rerun that rewrites the fixture
         sys.exit(__doc__)
-    main()
+    else:
+        main()

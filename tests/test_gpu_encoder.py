@@ -126,19 +126,23 @@ def test_training_step_matches_reference(dev, tag):
 
 def test_end_to_end_quality_anchor(dev):
     """Statistical end-to-end anchor, pinned to the REFERENCE's own seed distribution (tests/golden/anchor_seeds.json, written by
-    tests/golden/make_anchor_seeds.py from the imported reference on CPU): Influenza-A, k=6, C=5, 10 epochs, ONE voter.  The
-    reference itself is noisy at one voter -- over its 10 seeds ACC = 0.80 .. 0.994, mean 0.948 (4 of 10 runs >= 0.99), which is
-    why it ensembles five -- so bit parity of a run is not definable (dropout / shuffle streams differ on the GPU); the bar is
-    that this implementation's distribution over 8 seeds is the reference's: mean within 0.05 of the reference's mean, best run
-    >= 0.985, worst run no more than 0.15 below the reference's worst (one bad voter in ten is the reference's own rate: its
-    seed 8 scores 0.80; an observed run of this implementation: 0.99 0.98 0.72 0.93 0.96 0.97 0.86 0.97)."""
+    tests/golden/make_anchor_seeds.py from the imported reference on CPU): Influenza-A, k=6, C=5, 10 epochs, ONE voter.
+    Round 3: 40 reference seeds instead of 10.  The reference at one voter is much noisier than its first ten seeds suggested --
+    over 40 seeds ACC = 0.655 .. 0.994, mean 0.902, standard deviation 0.088, 15 % of the runs >= 0.99 (the first ten had mean
+    0.948 and minimum 0.80: a lucky draw), which is why it ensembles five -- so bit parity of a run is not definable (dropout /
+    shuffle streams differ on the GPU) and the bar is distributional, over 48 seeds of this implementation: mean within 0.03 of
+    the reference's, worst run no more than 0.05 under the reference's worst, best run >= 0.985, and the two empirical
+    distributions no further apart than the two-sample Kolmogorov-Smirnov bound at alpha = 0.01.  (The 0.72 run round 2 reported
+    is the reference's own behaviour -- its seeds 14 and 25 score 0.655 and 0.675 -- and not the fused step's: the same seeds
+    through torch autograd, tools/acc_sweep.py / profiles/r03_acc_sweep.txt, give 0.72 .. 0.995, mean 0.926, the fused step
+    0.77 .. 0.992, mean 0.902.)"""
     import pandas as pd
     import torch
     import idelucs_amd
     from idelucs_amd import models
     anchor = json.load(open(os.path.join(GOLDEN, "anchor.json")))
-    ref = [r["acc"] for r in json.load(open(os.path.join(GOLDEN, "anchor_seeds.json")))["single"]]
-    assert len(ref) >= 8 and abs(ref[0] - anchor["acc"]) < 1e-12          # seed 0 of the sweep is the round-1 anchor run
+    ref = np.array([r["acc"] for r in json.load(open(os.path.join(GOLDEN, "anchor_seeds.json")))["single"]])
+    assert len(ref) >= 40 and abs(ref[0] - anchor["acc"]) < 1e-12          # seed 0 of the sweep is the round-1 anchor run
     df = pd.read_csv(os.path.join(DATA, "Influenza-A_GT.tsv"), sep="\t")
     u = {v: i for i, v in enumerate(sorted(set(df.cluster_id)))}
     gt = np.array([u[v] for v in df.cluster_id])
@@ -147,7 +151,7 @@ def test_end_to_end_quality_anchor(dev):
                                          batch_sz=512, k=6, weight=0.25, n_voters=1).fit_predict(None)
     assert y.dtype == np.int64 and y.shape == (949,) and lat.dtype == np.float64 and lat.shape == tuple(anchor["latent_shape"])
     accs = [idelucs_amd.cluster_acc(gt, y)[1]]
-    for seed in range(1, 8):
+    for seed in range(1, 48):
         m = models.IID_model({'sequence_file': os.path.join(DATA, "Influenza-A.fas"), 'GT_file': None, 'n_clusters': 5, 'k': 6,
                               'model_size': 'linear', 'n_mimics': 3, 'batch_sz': 512, 'optimizer': 'RMSprop', 'lambda': 2.8,
                               'lr': 1e-3, 'weight': 0.25, 'scheduler': None, 'n_epochs': 10, 'n_voters': 1, 'seed': seed})
@@ -156,9 +160,15 @@ def test_end_to_end_quality_anchor(dev):
         for _ in range(10):
             m.contrastive_training_epoch()
         accs.append(idelucs_amd.cluster_acc(gt, m.predict()[0])[1])
-    print("ACC over seeds", np.round(accs, 4), "| reference", np.round(ref, 4))
-    assert np.mean(accs) >= np.mean(ref) - 0.05, (np.mean(accs), np.mean(ref))
-    assert max(accs) >= 0.985 and min(accs) >= min(ref) - 0.15, (max(accs), min(accs), min(ref))
+    accs = np.array(accs)
+    grid = np.sort(np.concatenate([accs, ref]))
+    ks = np.max(np.abs(np.searchsorted(np.sort(accs), grid, side="right") / len(accs) - np.searchsorted(np.sort(ref), grid, side="right") / len(ref)))
+    ks_bound = 1.63 * np.sqrt((len(accs) + len(ref)) / (len(accs) * len(ref)))
+    print(f"ACC over {len(accs)} seeds: mean {accs.mean():.4f} std {accs.std(ddof=1):.4f} min {accs.min():.4f} max {accs.max():.4f} | reference over "
+          f"{len(ref)}: mean {ref.mean():.4f} std {ref.std(ddof=1):.4f} min {ref.min():.4f} max {ref.max():.4f} | KS {ks:.3f} (bound {ks_bound:.3f})")
+    assert abs(accs.mean() - ref.mean()) <= 0.03, (accs.mean(), ref.mean())
+    assert accs.max() >= 0.985 and accs.min() >= ref.min() - 0.05, (accs.max(), accs.min(), ref.min())
+    assert ks <= ks_bound, (ks, ks_bound)
 
 
 # ------------------------------------------------------------------------------------------------

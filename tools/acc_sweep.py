@@ -13,7 +13,7 @@ gt = np.array([u[v] for v in df.cluster_id])
 epochs = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 for fused in (0, 1):
     accs = []
-    for seed in range(8):
+    for seed in range(int(os.environ.get("SEEDS", "16"))):
         torch.manual_seed(seed)
         args = {'sequence_file': os.path.join(D, "Influenza-A.fas"), 'GT_file': None, 'n_clusters': 5, 'k': 6, 'model_size': 'linear',
                 'n_mimics': 3, 'batch_sz': 512, 'optimizer': 'RMSprop', 'lambda': 2.8, 'lr': 1e-3, 'weight': 0.25, 'scheduler': None,

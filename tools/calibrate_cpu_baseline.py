@@ -32,7 +32,7 @@ cores = os.cpu_count()
 
 # ---- the port, exactly as bench.py runs it
 import bench
-ns = types.SimpleNamespace(cpu_sample=a.n, len=a.len, k=6, n_mimics=3, n_clusters=20, batch_sz=512)
+ns = types.SimpleNamespace(cpu_sample=a.n, n=a.n, len=a.len, k=6, n_mimics=3, n_clusters=20, batch_sz=512, cpu_ref_steps=10 ** 9)
 port = bench.cpu_baseline(ns)
 print("port     :", port["value"], "seq/s;", port["sample"], flush=True)
 
@@ -52,4 +52,12 @@ t2 = time.perf_counter()
 ref = a.n / (t2 - t0)
 print(f"reference: {ref:.1f} seq/s; vectorise+augment {t1 - t0:.2f} s + epoch {t2 - t1:.2f} s on {cores} cores "
       f"({max(1, cores - 2)} torch threads, 4 loader workers)")
-print(f"ratio port/reference = {port['value'] / ref:.2f}")
+ratio = port['value_reference_threads'] / ref
+print(f"ratio port/reference = {ratio:.2f} (both with {max(1, cores - 2)} torch threads)")
+import json
+out = {"ratio": round(ratio, 3), "port_seq_per_s": port['value_reference_threads'], "reference_seq_per_s": ref, "cores": cores,
+       "torch_threads": max(1, cores - 2), "sample": f"{a.n} x {a.len} bp, k=6, n_mimics=3, B=512, C=20, one epoch",
+       "reference": f"vectorise+augment {t1 - t0:.2f} s + epoch {t2 - t1:.2f} s (4 loader workers)", "port": port["sample"]}
+with open(os.path.join(ROOT, "profiles", "r03_cpu_calibration.json"), "w") as fh:
+    json.dump(out, fh, indent=1)
+print(json.dumps(out))

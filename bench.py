@@ -405,6 +405,21 @@ def t_e2e(args, dev, reps=2):
     return best
 
 
+class stdout_to_stderr:
+    """RCCL prints its version banner to STDOUT when the environment sets NCCL_DEBUG=VERSION (this image does), at communicator
+    creation; bench.py owes its caller exactly one line there.  File-descriptor level, so the library's own writes are caught."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+
+
 def spawn_ranks(n, n_visible, n_shared):
     """`python bench.py --gpus N` without a launcher: start the N ranks as a CHILD `python -m torch.distributed.run` (one process
     per GPU, RCCL), relay rank 0's JSON line, return the child's exit code.  Nothing here has touched the GPU (a process that has
@@ -490,14 +505,18 @@ def main():
     # one process per GPU over RCCL.  A single rank forms a group of one as well: the exchange step of the path then runs through
     # the same RCCL calls (dtypes, shapes) as at N > 1 instead of a local shortcut (idelucs_amd.dist._no_group)
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    if world > 1:
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
-    elif os.environ.get("IDELUCS_BENCH_GROUP_OF_ONE", "1") == "1":
-        dist.init_process_group(backend, rank=0, world_size=1, store=dist.HashStore(),
-                                **({"device_id": dev} if backend == "nccl" else {}))
+    with stdout_to_stderr():
+        if world > 1:
+            if backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            else:
+                dist.init_process_group(backend, rank=rank, world_size=world)
+        elif os.environ.get("IDELUCS_BENCH_GROUP_OF_ONE", "1") == "1":
+            dist.init_process_group(backend, rank=0, world_size=1, store=dist.HashStore(),
+                                    **({"device_id": dev} if backend == "nccl" else {}))
+        if dist.is_initialized():       # the communicator (and its banner) comes with the first collective
+            dist.all_reduce(torch.zeros(1, device=dev))
+            torch.cuda.synchronize()
     group = {"ranks": dist.get_world_size() if dist.is_initialized() else 1,
              "backend": dist.get_backend() if dist.is_initialized() else None}
     mine = {"rank": rank, "device": torch.cuda.current_device(), "name": torch.cuda.get_device_name(dev), "pid": os.getpid()}
@@ -536,6 +555,8 @@ def main():
     if args.exchange:
         if cfg5:
             assert tuple(hp.latent.shape) == (args.n, 64) and bool(torch.isfinite(hp.latent).all())
+            validation.update(latent_shape=list(hp.latent.shape), latent_finite=bool(torch.isfinite(hp.latent).all()),
+                              latent_row_norm_max=float(hp.latent.norm(dim=1).max().item()))
         else:
             assert tuple(hp.gathered.shape) == (args.voters, args.n)
             assert int(hp.gathered.min()) >= 0 and int(hp.gathered.max()) < args.n_clusters

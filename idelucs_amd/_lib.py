@@ -87,6 +87,7 @@ SIGNATURES = {
     "idl_mst_prim_workspace": (_i64, [_i64]),
     "idl_mst_prim": (_int, [_vp, _int, _vp, _i64, _int, _vp, _vp, _vp, _vp, _vp]),
     "idl_debug_stamps": (_int, [_vp]),
+    "idl_mimic_check_lengths": (_int, [_i64, _int, _vp, _vp]),
     "idl_plan_bytes": (_i64, []),
     "idl_plan_begin": (_int, [_vp]),
     "idl_plan_end": (_int, []),

@@ -257,6 +257,19 @@ int64_t idl_mimic_workspace(int64_t n, int n_views)
     return ws_tables(n_views) + 16 + (ws_scan_blocks(items) + 1) * 8 + items * 64 * 2 + 64;
 }
 
+int idl_mimic_check_lengths(int64_t max_len, int n_views, const double *p_transition, const double *p_transversion)
+{
+    IDL_REQUIRE(n_views >= 1 && n_views <= MAX_VIEWS && p_transition && p_transversion, "n_views outside 1..64 or NULL buffer");
+    IDL_REQUIRE(max_len >= 0 && max_len < (1ll << 30), "mutated sequences longer than 2^30 bases are not supported (an edit holds its position in 30 bits)");
+    const double per_lane = (double)((max_len + 63) / 64);
+    for (int v = 0; v < n_views; ++v) {
+        const double mean = per_lane * (1.0 - (1.0 - p_transition[v]) * (1.0 - p_transversion[v]));
+        IDL_REQUIRE(!(per_lane > 65535.0 && mean + 12.0 * sqrt(mean) + 64.0 >= 65535.0),
+                    "a sequence this long at these mutation rates exceeds the generator's 16-bit per-lane site counter");
+    }
+    return IDL_OK;
+}
+
 int idl_mimic_edits(const int64_t *lengths, int64_t n, int n_views, const double *p_transition,
                     const double *p_transversion, const int32_t *n_random_n, uint64_t seed,
                     int64_t *edit_off, uint32_t *edits, int64_t edits_capacity, int64_t *total_edits,

@@ -378,14 +378,10 @@ def _philox_edits(dev_in, specs, seed, capacity=None):
         raise ValueError("high <= 0")   # np.random.randint(0, 0, n) in the reference's Random_N (utils.py:93)
     # limits of the device generator (csrc/mimic.hip): positions are packed into 30 bits, per-lane site counts into 16
     max_len = int(getattr(dev_in, "max_len", 0) or (dev_in.lengths.max().item() if dev_in.n else 0))
-    if max_len >= (1 << 30):
-        raise ValueError("mutated sequences longer than 2^30 bases are not supported")
-    per_lane = (max_len + 63) // 64
-    for a, b in zip(p_ts, p_tv):
-        mean = per_lane * (1.0 - (1.0 - a) * (1.0 - b))
-        if per_lane > 65535 and mean + 12.0 * mean ** 0.5 + 64.0 >= 65535.0:
-            raise ValueError(f"a {max_len}-base sequence at these mutation rates exceeds the device mimic generator's per-lane "
-                             "site counter; use rng='compat'")
+    try:
+        _lib.check(_L.idl_mimic_check_lengths(max_len, P, _ptr(p_ts), _ptr(p_tv)))          # the precondition idl_mimic_edits states
+    except ValueError as err:
+        raise ValueError(f"{err}; use rng='compat'") from None
     dev = dev_in.lengths.device
     ws = torch.empty(_L.idl_mimic_workspace(dev_in.n, P), dtype=torch.uint8, device=dev)
     edit_off = torch.empty(P * dev_in.n + 1, dtype=torch.int64, device=dev)

@@ -1,4 +1,5 @@
 """The CLI keeps the reference's flag surface (idelucs/__main__.py:275-308); CPU-only checks plus one GPU run."""
+import json
 import os
 import time
 
@@ -355,3 +356,44 @@ def test_cli_fine_grained_mode_at_cfg5_scale(tmp_path, monkeypatch):
     acc, sil = float(m.loc["ACC", "Value"]), float(m.loc["Silhouette-Score", "Value"])
     print(f"cfg5-scale CLI run: {df['assignment'].nunique()} clusters, ACC {acc:.4f}, silhouette {sil:.4f}")
     assert np.isfinite(sil) and acc > 0.9 and 4 <= df["assignment"].nunique() <= 40
+
+
+@pytest.mark.gpu
+def test_cfg5_at_full_size_hot_path(tmp_path):
+    """BASELINE cfg5 at its FULL size on one GPU, through bench.py's own hot path (`--workload cfg5`): 1 000 000 sequences x 5 kbp
+    packed in HBM -> device mimic sites -> all 4 views vectorised into the 65.5 GB feature store -> scaler fit -> one whole epoch
+    at 200 output units (5 860 optimizer steps of the fine-grained mode's launch sequence) -> the last voter's weights broadcast,
+    predict sharded by sequence, the fp32 latent shards [N/G, 64] all-gathered -- through a process group of one over RCCL, the
+    collectives the 8-GPU run uses (reference __main__.py:75-83,106-146,153-156).  Size-independent properties at that size
+    (bench.HotPath.validate on the store the run timed): every sampled frequency row sums to 1, views differ, each view's
+    checksum is N (every row a distribution), finite epoch loss; here: the latent is [10^6, 64], finite, L2-bounded rows, and
+    the job runs at more than 5 x 10^5 sequences/s.  (HDBSCAN on the 10^6 latent rows is post-hoc and takes a minute: it runs in
+    tools/run_cfg5_cli.py -> profiles/r03_cfg5_cli_full.txt, and at 200 000 rows in the test above.)"""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    free = 0
+    try:
+        import torch
+        free = torch.cuda.mem_get_info(0)[0]
+    except Exception:
+        pass
+    if free and free < 150 * 2 ** 30:
+        pytest.skip(f"needs ~110 GB of device memory, {free / 2 ** 30:.0f} GB free")
+    env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "cfg5", "--steps", "1", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-e2e"], cwd=tmp_path, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(line) == 1, r.stdout[-2000:]
+    j = json.loads(line[0])
+    c = j["config"]
+    assert c["n_sequences"] == 1_000_000 and c["seq_len"] == 5_000 and c["optimizer_steps_per_epoch"] == 5860 and "cfg5" in c["workload"]
+    assert j["ranks"] == 1 and j["backend"] == "nccl"                       # the exchange went through RCCL
+    v = j["validation"]
+    assert all(abs(x - 1e6) < 1e3 for x in v["feats_checksum"]) and v["rows_checked"] >= 4096
+    assert all(np.isfinite(x) for x in v["epoch_loss_last_step"])
+    assert j["validation"].get("latent_shape") == [1_000_000, 64] and j["validation"]["latent_finite"] is True
+    assert 0.0 < j["validation"]["latent_row_norm_max"] < 1e4
+    assert j["value"] > 5e5, j["value"]
+    print(f"cfg5 full size: {j['value']:.0f} sequences/s, {j['ms_per_step']:.0f} ms per pass; stages {j['stage_ms']}")

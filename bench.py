@@ -136,7 +136,7 @@ class HotPath:
     def features(self, seed):
         U, _lib = self.U, self._lib
         edits, edit_off = self._timed("edits", lambda: U._philox_edits(self.din, self.specs, seed, capacity=self.edit_capacity))
-        self.edit_overflow |= edit_off[-1] > self.edit_capacity
+        self.edit_overflow |= U.edits_overflowed(edits, edit_off, self.edit_capacity)
         self._timed("vectorise", lambda: U._vectorise(self.din, self.a.k, _lib.MODE_KMER, _lib.INIT_ONE, _lib.OUT_FREQ_F32,
                                                       self.P, edits, edit_off, self.feats))
 
@@ -618,6 +618,13 @@ def main():
                                             "not counters of this run)") if not cfg5 else None,
                          "ms_per_launch": t_vec, "bytes_per_seq_algorithmic": b_vec,
                          "share_of_step": t_vec / ms_step},
+            "roofline_stage1": {"stage": "device mimic sites + vectorise (all views) + scaler fit: everything between the packed bases and the epoch",
+                                "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                                "ms": (lambda t: t)(hp.mean_ms("edits", args.warmup) + t_vec + hp.mean_ms("stats", args.warmup)),
+                                "achieved": args.n * b_vec / ((hp.mean_ms("edits", args.warmup) + t_vec + hp.mean_ms("stats", args.warmup)) * 1e-3) / 1e9,
+                                "frac": args.n * b_vec / ((hp.mean_ms("edits", args.warmup) + t_vec + hp.mean_ms("stats", args.warmup)) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                "note": "the stage's algorithmic bytes are the vectoriser's (SURVEY 8d); the site generator is Philox-bound "
+                                        "compute, the scaler fit reads view 0 once more (1.64 GB at cfg2)"},
             "roofline_epoch": {"kernel": "training epoch (hipBLASLt fp32 GEMMs + gather + losses + RMSprop)", "bound": "mfma",
                                "achieved": ach_ep, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach_ep / MFMA_F32_PEAK_TFLOPS,
                                "ms": t_ep, "flop_per_seq_algorithmic": f_ep, "share_of_step": t_ep * len(hp.my_voters) / ms_step,

@@ -88,6 +88,10 @@ SIGNATURES = {
     "idl_mst_prim": (_int, [_vp, _int, _vp, _i64, _int, _vp, _vp, _vp, _vp, _vp]),
     "idl_debug_stamps": (_int, [_vp]),
     "idl_mimic_check_lengths": (_int, [_i64, _int, _vp, _vp]),
+    "idl_mimic_slots_workspace": (_i64, [_int]),
+    "idl_mimic_slots_capacity": (_i64, [_i64, _int, _vp, _vp, _vp, _i64]),
+    "idl_mimic_edits_slots": (_int, [_vp, _i64, _int, _vp, _vp, _vp, _c.c_uint64, _i64, _vp, _vp, _i64, _vp, _vp, _vp]),
+    "idl_vectorise_ranges": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _int, _int, _int, _int, _vp, _vp, _vp, _i64, _i64, _vp]),
     "idl_plan_bytes": (_i64, []),
     "idl_plan_begin": (_int, [_vp]),
     "idl_plan_end": (_int, []),

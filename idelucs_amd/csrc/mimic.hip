@@ -180,6 +180,102 @@ __global__ __launch_bounds__(64) void mimic_kernel(MimicParams p, int n_views, c
     }
 }
 
+
+// ---------------------------------------------------------------- one pass, fixed slots (round 3)
+// The two-pass protocol above draws every site TWICE (count, scan, fill: 0.41 + 0.02 + 0.51 ms at cfg2, bound by Philox's
+// quarter-rate integer multiplies) only to pack the edits of all (view, sequence) items back to back.  Here item (v, s) owns a
+// SLOT of cap[v] edits at base[v] + s * cap[v] -- cap[v] a bound the host derives from the longest sequence and the view's
+// site probability -- and the vectoriser is told (begin, end) per item instead of a CSR array (idl_vectorise_ranges): the
+// sites are drawn once, into LDS, and copied out behind a wave prefix sum.  Same spec, same sites, same order inside an
+// item as mimic_kernel (tests compare the two bit for bit).  An item that does not fit its slot raises *overflow and is
+// truncated (the caller falls back to the exact two-pass protocol); a lane with more than RB sites sends its item through
+// the count-then-fill path inside this kernel.
+constexpr int RB = 24;             // sites a lane buffers in LDS (cfg2: 2.4 expected per lane)
+
+struct SlotLayout { int64_t base[MAX_VIEWS]; int32_t cap[MAX_VIEWS]; };
+
+__global__ __launch_bounds__(64) void mimic_slots_kernel(MimicParams p, int n_views, const int64_t *lengths, int64_t n, uint32_t k0, uint32_t k1,
+                                                         const uint32_t *tables, SlotLayout sl, int64_t *ranges, uint32_t *edits, int32_t *overflow)
+{
+    __shared__ uint32_t T[J + 1];
+    __shared__ uint32_t buf[RB][64];
+    const int lane = threadIdx.x;
+    const int64_t items = n * n_views;
+    int cur_view = -1;
+    for (int64_t it = blockIdx.x; it < items; it += gridDim.x) {
+        const int v = (int)(it / n);                        // view-major items keep the table resident
+        const int64_t s = it - (int64_t)v * n;
+        const int64_t L = lengths[s];
+        const int64_t slot = sl.base[v] + s * (int64_t)sl.cap[v];
+        const uint32_t cap = (uint32_t)sl.cap[v];
+        if (p.n_rand[v] > 0) {
+            uint32_t key = 0xFFFFFFFFu;
+            const int nr = L > 0 ? p.n_rand[v] : 0;
+            if (lane < nr) {
+                const U4 r = philox4x32_10((uint32_t)lane, 0u, (uint32_t)s, (uint32_t)v | (1u << 16), k0, k1);
+                key = (uint32_t)(((uint64_t)r.x * (uint64_t)(uint32_t)L) >> 32);
+            }
+            key = wave_sort_u32(key, lane);
+            if (lane < nr && (uint32_t)lane < cap) edits[slot + lane] = key;       // op 0 = N
+            if (lane == 0) { ranges[2 * it] = slot; ranges[2 * it + 1] = slot + ((uint32_t)nr < cap ? (uint32_t)nr : cap); if ((uint32_t)nr > cap) *overflow = 1; }
+            continue;
+        }
+        if (!p.has_sites[v]) {
+            if (lane == 0) { ranges[2 * it] = slot; ranges[2 * it + 1] = slot; }
+            continue;
+        }
+        if (cur_view != v) {
+            __syncthreads();
+            for (int j = lane; j <= J; j += 64) T[j] = tables[(size_t)v * (J + 1) + j];
+            __syncthreads();
+            cur_view = v;
+        }
+        const int64_t seg = (L + 63) / 64;
+        const int64_t lo = (int64_t)lane * seg;
+        int64_t hi = lo + seg;
+        if (hi > L) hi = L;
+        const uint32_t A = p.thr_ts_only[v], B = p.thr_tv_only[v];
+        const int kind = p.kind[v];
+        const float ilk = p.inv_log2_keep[v];
+        // the draws of this lane's segment; emit(e, i) is called with the i-th site of the lane, in position order
+        auto draw = [&](auto emit) -> uint32_t {
+            uint32_t cnt = 0;
+            int64_t pos = lo - 1;
+            for (uint32_t d = 0; pos < hi; ++d) {
+                const U4 r = philox4x32_10(d, (uint32_t)lane, (uint32_t)s, (uint32_t)v, k0, k1);
+                int a = (int)fminf(__log2f(((float)r.x + 0.5f) * 2.3283064365386963e-10f) * ilk, (float)J);
+                if (a < 0) a = 0;
+                while (a < J && r.x < T[a + 1]) ++a;
+                while (a > 0 && !(r.x < T[a])) --a;
+                if (a == J) { pos += J; continue; }
+                pos += a + 1;
+                if (pos >= hi) break;
+                const uint32_t flav = 1u | ((r.z & 1u) << 1);            // transversion: ^1 or ^3
+                uint32_t op = (r.y < A) ? 2u : (r.y < B) ? flav : (2u ^ flav);
+                if (kind == 1) op = 2u;
+                if (kind == 2) op = flav;
+                emit((uint32_t)pos | (op << 30), cnt);
+                ++cnt;
+            }
+            return cnt;
+        };
+        const uint32_t my = draw([&](uint32_t e, uint32_t i) { if (i < (uint32_t)RB) buf[i][lane] = e; });
+        uint32_t incl = my;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+        const uint32_t off = incl - my, total = (uint32_t)__shfl((int)incl, 63, 64);
+        if (__ballot(my > (uint32_t)RB) == 0ull) {
+            for (uint32_t i = 0; i < my; ++i) if (off + i < cap) edits[slot + off + i] = buf[i][lane];
+        } else {                                              // a crowded lane somewhere: draw again, straight to memory (offsets are known now)
+            draw([&](uint32_t e, uint32_t i) { if (off + i < cap) edits[slot + off + i] = e; });
+        }
+        if (lane == 0) {
+            ranges[2 * it] = slot; ranges[2 * it + 1] = slot + (total < cap ? total : cap);
+            if (total > cap) *overflow = 1;
+        }
+    }
+}
+
 // in-place exclusive scan of m int64 counts in three launches: per-block scan (1024 x SCAN_PER elements per block) ->
 // scan of the block totals (one workgroup) -> add the block offsets; off[m] = total
 constexpr int SCAN_PER = 4;
@@ -257,6 +353,33 @@ int64_t idl_mimic_workspace(int64_t n, int n_views)
     return ws_tables(n_views) + 16 + (ws_scan_blocks(items) + 1) * 8 + items * 64 * 2 + 64;
 }
 
+static int mimic_params(int n_views, const double *p_transition, const double *p_transversion, const int32_t *n_random_n, MimicParams &p)
+{
+    for (int v = 0; v < n_views; ++v) {
+        const double a = p_transition[v], b = p_transversion[v];
+        IDL_REQUIRE(a >= 0.0 && a < 1.0 && b >= 0.0 && b < 1.0, "probabilities must be in [0, 1)");
+        IDL_REQUIRE(n_random_n[v] >= 0 && n_random_n[v] <= 64, "n_random_n outside 0..64");
+        IDL_REQUIRE(!(n_random_n[v] > 0 && (a > 0.0 || b > 0.0)), "a view is either a site view or a Random_N view");
+        const double keep = (1.0 - a) * (1.0 - b);
+        const double q = 1.0 - keep;
+        p.one_minus_q[v] = keep;
+        p.n_rand[v] = n_random_n[v];
+        p.has_sites[v] = q > 0.0;
+        if (q > 0.0) {
+            const double fa = (a * (1.0 - b)) / q * 4294967296.0;
+            const double fb = ((1.0 - a) * b) / q * 4294967296.0;
+            const double A = fa >= 4294967295.0 ? 4294967295.0 : fa;
+            double B = A + fb;
+            if (B > 4294967295.0) B = 4294967295.0;
+            p.thr_ts_only[v] = (uint32_t)A;
+            p.thr_tv_only[v] = (uint32_t)B;
+            p.kind[v] = (b == 0.0) ? 1 : (a == 0.0) ? 2 : 0;
+            p.inv_log2_keep[v] = (float)(1.0 / log2(keep));
+        }
+    }
+    return IDL_OK;
+}
+
 int idl_mimic_check_lengths(int64_t max_len, int n_views, const double *p_transition, const double *p_transversion)
 {
     IDL_REQUIRE(n_views >= 1 && n_views <= MAX_VIEWS && p_transition && p_transversion, "n_views outside 1..64 or NULL buffer");
@@ -279,27 +402,9 @@ int idl_mimic_edits(const int64_t *lengths, int64_t n, int n_views, const double
     IDL_REQUIRE(p_transition && p_transversion && n_random_n && edit_off && workspace, "NULL buffer");
     IDL_REQUIRE(n < (1ll << 32), "more than 2^32 sequences");
     MimicParams p{};
-    for (int v = 0; v < n_views; ++v) {
-        const double a = p_transition[v], b = p_transversion[v];
-        IDL_REQUIRE(a >= 0.0 && a < 1.0 && b >= 0.0 && b < 1.0, "probabilities must be in [0, 1)");
-        IDL_REQUIRE(n_random_n[v] >= 0 && n_random_n[v] <= 64, "n_random_n outside 0..64");
-        IDL_REQUIRE(!(n_random_n[v] > 0 && (a > 0.0 || b > 0.0)), "a view is either a site view or a Random_N view");
-        const double keep = (1.0 - a) * (1.0 - b);
-        const double q = 1.0 - keep;
-        p.one_minus_q[v] = keep;
-        p.n_rand[v] = n_random_n[v];
-        p.has_sites[v] = q > 0.0;
-        if (q > 0.0) {
-            const double fa = (a * (1.0 - b)) / q * 4294967296.0;
-            const double fb = ((1.0 - a) * b) / q * 4294967296.0;
-            const double A = fa >= 4294967295.0 ? 4294967295.0 : fa;
-            double B = A + fb;
-            if (B > 4294967295.0) B = 4294967295.0;
-            p.thr_ts_only[v] = (uint32_t)A;
-            p.thr_tv_only[v] = (uint32_t)B;
-            p.kind[v] = (b == 0.0) ? 1 : (a == 0.0) ? 2 : 0;
-            p.inv_log2_keep[v] = (float)(1.0 / log2(keep));
-        }
+    {
+        const int prc = mimic_params(n_views, p_transition, p_transversion, n_random_n, p);
+        if (prc != IDL_OK) return prc;
     }
     idl::DeviceInfo di;
     int rc = idl::device_info(&di);
@@ -338,6 +443,68 @@ int idl_mimic_edits(const int64_t *lengths, int64_t n, int n_views, const double
     IDL_REQUIRE(edits_capacity >= 0, "negative capacity");
     hipLaunchKernelGGL(mimic_kernel<true>, dim3((unsigned)grid), dim3(64), 0, st, p, n_views, lengths, n, k0, k1, tables,
                        edit_off, edits, edits_capacity, lane_counts);
+    IDL_HIP_TRY(hipGetLastError());
+    return IDL_OK;
+}
+
+
+// slot capacity of view v for sequences up to max_len bases: the expected number of sites + 10 sigma + 32 (never more than max_len)
+static int64_t slot_cap(double a, double b, int n_rand, int64_t max_len)
+{
+    if (n_rand > 0) return n_rand;
+    const double q = 1.0 - (1.0 - a) * (1.0 - b);
+    if (q <= 0.0) return 0;
+    const double mean = q * (double)max_len;
+    int64_t cap = (int64_t)ceil(mean + 10.0 * sqrt(mean) + 32.0);
+    if (cap > max_len) cap = max_len;
+    return (cap + 3) & ~(int64_t)3;
+}
+
+int64_t idl_mimic_slots_workspace(int n_views) { return (n_views < 1 || n_views > MAX_VIEWS) ? -1 : ws_tables(n_views); }
+
+int64_t idl_mimic_slots_capacity(int64_t n, int n_views, const double *p_transition, const double *p_transversion, const int32_t *n_random_n,
+                                 int64_t max_len)
+{
+    if (n < 0 || n_views < 1 || n_views > MAX_VIEWS || !p_transition || !p_transversion || !n_random_n || max_len < 0) return -1;
+    int64_t total = 0;
+    for (int v = 0; v < n_views; ++v) total += n * slot_cap(p_transition[v], p_transversion[v], n_random_n[v], max_len);
+    return total;
+}
+
+int idl_mimic_edits_slots(const int64_t *lengths, int64_t n, int n_views, const double *p_transition, const double *p_transversion,
+                          const int32_t *n_random_n, uint64_t seed, int64_t max_len, int64_t *edit_ranges, uint32_t *edits,
+                          int64_t edits_capacity, int32_t *overflow, void *workspace, void *stream)
+{
+    IDL_REQUIRE(n >= 0 && n_views >= 1 && n_views <= MAX_VIEWS, "n < 0 or n_views outside 1..64");
+    IDL_REQUIRE(p_transition && p_transversion && n_random_n && edit_ranges && overflow && workspace, "NULL buffer");
+    IDL_REQUIRE(n < (1ll << 32), "more than 2^32 sequences");
+    int rc = idl_mimic_check_lengths(max_len, n_views, p_transition, p_transversion);
+    if (rc != IDL_OK) return rc;
+    MimicParams p{};
+    rc = mimic_params(n_views, p_transition, p_transversion, n_random_n, p);
+    if (rc != IDL_OK) return rc;
+    SlotLayout sl{};
+    int64_t total = 0;
+    for (int v = 0; v < n_views; ++v) {
+        const int64_t cap = slot_cap(p_transition[v], p_transversion[v], n_random_n[v], max_len);
+        IDL_REQUIRE(cap < (1ll << 31), "slot capacity beyond 2^31");
+        sl.base[v] = total; sl.cap[v] = (int32_t)cap;
+        total += n * cap;
+    }
+    IDL_REQUIRE(edits_capacity >= total && (edits != nullptr || total == 0), "edits is smaller than idl_mimic_slots_capacity()");
+    IDL_REQUIRE((((uintptr_t)workspace) & 15u) == 0, "workspace must be 16-byte aligned");
+    idl::DeviceInfo di;
+    rc = idl::device_info(&di);
+    if (rc != IDL_OK) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t items = n * n_views;
+    if (items == 0) return IDL_OK;
+    uint32_t *tables = (uint32_t *)workspace;
+    int64_t grid = (int64_t)di.cus * 32;
+    if (grid > items) grid = items;
+    hipLaunchKernelGGL(mimic_table_kernel, dim3((unsigned)n_views), dim3(64), 0, st, p, n_views, tables);
+    hipLaunchKernelGGL(mimic_slots_kernel, dim3((unsigned)grid), dim3(64), 0, st, p, n_views, lengths, n, (uint32_t)seed, (uint32_t)(seed >> 32),
+                       (const uint32_t *)tables, sl, edit_ranges, edits, overflow);
     IDL_HIP_TRY(hipGetLastError());
     return IDL_OK;
 }

@@ -33,6 +33,7 @@ struct VecArgs {
     int mode, init, out_kind, n_views;
     const uint32_t *edits;
     const int64_t *edit_off;
+    int eo_shift;   // 0: edit_off is the CSR array [n_views * n + 1]; 1: it is [n_views * n][2] = (begin, end) per (view, sequence) (idl_vectorise_ranges)
     void *out;
     int64_t view_stride;
     int sc_slots;   // v2: slots (64 bases) staged in LDS at a time
@@ -44,6 +45,11 @@ struct VecArgs {
     unsigned long long *dbg;   // diagnostic (IDELUCS_VEC_DBG): per-workgroup cycle sums of the phases
     int ablate;      // diagnostic builds only (IDELUCS_VEC_ABLATE): 1 no row stores, 2 no H0 count, 4 no deltas, 8 raw epilogue
 };
+
+// first / one-past-last edit of item it = view * n + sequence, in either layout of edit_off
+__device__ __forceinline__ int64_t eo_begin(const VecArgs &a, int64_t it) { return a.edit_off[it << a.eo_shift]; }
+__device__ __forceinline__ int64_t eo_end(const VecArgs &a, int64_t it) { return a.edit_off[(it << a.eo_shift) + 1]; }
+
 
 constexpr int STAGE_DWORDS = 256 + 128;  // 64 lanes x (4 code words + 2 mask words)
 constexpr int V3_REDO_CAP = 1023;        // sequences the v3 kernel can list for the second pass on v2 (beyond that the second pass scans)
@@ -145,8 +151,8 @@ __global__ __launch_bounds__(64) void vectorise_kernel(VecArgs a)
 
             int64_t ecur = 0, eend = 0;
             if (a.edits != nullptr) {
-                ecur = a.edit_off[(int64_t)v * a.n + s];
-                eend = a.edit_off[(int64_t)v * a.n + s + 1];
+                ecur = eo_begin(a, (int64_t)v * a.n + s);
+                eend = eo_end(a, (int64_t)v * a.n + s);
             }
 
             uint32_t carry_code = 0u, carry_mask = 0xFFFFFFFFu;  // nothing before the sequence: invalid
@@ -521,7 +527,7 @@ __global__ __launch_bounds__(64 * V2_WAVES, B16 ? 8 : 6) void vectorise2_kernel(
             int64_t te = 0;
             if (a.edits != nullptr)
                 for (int v = 0; v < a.n_views; ++v) {
-                    const int64_t d = a.edit_off[(int64_t)v * a.n + s + 1] - a.edit_off[(int64_t)v * a.n + s];
+                    const int64_t d = eo_end(a, (int64_t)v * a.n + s) - eo_begin(a, (int64_t)v * a.n + s);
                     te += d < 0 ? 0 : (d > 0x3FFFFFF ? 0x3FFFFFF : d);
                 }
             if (te <= (int64_t)a.ecap && te * K <= (int64_t)a.lcap && nslots >= 0 && nslots <= (int64_t)a.v3_sc && L >= 0 && L <= nslots * 64) continue;
@@ -542,7 +548,7 @@ __global__ __launch_bounds__(64 * V2_WAVES, B16 ? 8 : 6) void vectorise2_kernel(
         __syncthreads();
         if (lane < a.n_views) {
             int64_t b0 = 0, e0 = 0;
-            if (a.edits != nullptr) { b0 = a.edit_off[(int64_t)lane * a.n + s]; e0 = a.edit_off[(int64_t)lane * a.n + s + 1]; }
+            if (a.edits != nullptr) { b0 = eo_begin(a, (int64_t)lane * a.n + s); e0 = eo_end(a, (int64_t)lane * a.n + s); }
             vrange[2 * lane] = b0;
             vrange[2 * lane + 1] = e0;
         }
@@ -885,7 +891,7 @@ __global__ __launch_bounds__(V3_NT, 8) void vectorise3_kernel(VecArgs a)
         const uint32_t *src = nullptr;
         if (l < 4) src = (const uint32_t *)(a.slot_off + s) + l;
         else if (l < 6) src = (const uint32_t *)(a.lengths + s) + (l - 4);
-        else if (l >= 8 && l < 8 + 4 * P && has_edits) src = (const uint32_t *)(a.edit_off + (int64_t)((l - 8) >> 2) * a.n + s) + ((l - 8) & 3);
+        else if (l >= 8 && l < 8 + 4 * P && has_edits) src = (const uint32_t *)(a.edit_off + (((int64_t)((l - 8) >> 2) * a.n + s) << a.eo_shift)) + ((l - 8) & 3);
         if (src != nullptr) dma4(src, __builtin_amdgcn_readfirstlane(lds_addr(meta + r * V3_META)));
     };
     // ---------------- memory wave: view table of the sequence described by ring entry r + the DMA of its packed bases, mask and
@@ -1428,9 +1434,9 @@ int idl_kmer_rev_comp(int32_t *counts, int k, int32_t *out)
     return IDL_OK;
 }
 
-int idl_vectorise(const void *codes, const void *mask, const int64_t *slot_off, const int64_t *lengths,
+static int vectorise_impl(const void *codes, const void *mask, const int64_t *slot_off, const int64_t *lengths,
                   int64_t n, int k, int mode, int init, int out_kind,
-                  int n_views, const uint32_t *edits, const int64_t *edit_off,
+                  int n_views, const uint32_t *edits, const int64_t *edit_off, int eo_shift,
                   void *out, int64_t view_stride, int64_t max_len, void *stream)
 {
     IDL_REQUIRE(k >= 1 && k <= IDL_MAX_K, "k outside 1..IDL_MAX_K");
@@ -1459,10 +1465,27 @@ int idl_vectorise(const void *codes, const void *mask, const int64_t *slot_off, 
     a.n_views = n_views;
     a.edits = edits;
     a.edit_off = edit_off;
+    a.eo_shift = eo_shift;
     a.out = out;
     a.view_stride = view_stride;
     a.max_len = max_len;
     return dispatch_vectorise(k, a, (hipStream_t)stream);
+}
+
+int idl_vectorise(const void *codes, const void *mask, const int64_t *slot_off, const int64_t *lengths,
+                  int64_t n, int k, int mode, int init, int out_kind,
+                  int n_views, const uint32_t *edits, const int64_t *edit_off,
+                  void *out, int64_t view_stride, int64_t max_len, void *stream)
+{
+    return vectorise_impl(codes, mask, slot_off, lengths, n, k, mode, init, out_kind, n_views, edits, edit_off, 0, out, view_stride, max_len, stream);
+}
+
+int idl_vectorise_ranges(const void *codes, const void *mask, const int64_t *slot_off, const int64_t *lengths,
+                         int64_t n, int k, int mode, int init, int out_kind,
+                         int n_views, const uint32_t *edits, const int64_t *edit_ranges,
+                         void *out, int64_t view_stride, int64_t max_len, void *stream)
+{
+    return vectorise_impl(codes, mask, slot_off, lengths, n, k, mode, init, out_kind, n_views, edits, edit_ranges, 1, out, view_stride, max_len, stream);
 }
 
 }  // extern "C"

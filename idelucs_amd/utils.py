@@ -328,9 +328,11 @@ def _vectorise(dev_in, k, mode, init, out_kind, n_views=1, edits=None, edit_off=
     if out is None:
         out = torch.empty((n_views, dev_in.n, row), dtype=dtype, device=dev_in.codes.device)
     assert out.is_contiguous() and out.dtype == dtype and tuple(out.shape) == (n_views, dev_in.n, row)
-    _lib.check(_L.idl_vectorise(_ptr(dev_in.codes), _ptr(dev_in.mask), _ptr(dev_in.slot_off), _ptr(dev_in.lengths),
-                                dev_in.n, k, mode, init, out_kind, n_views, _ptr(edits), _ptr(edit_off),
-                                _ptr(out), dev_in.n * row, int(getattr(dev_in, "max_len", 0) or 0), _stream_ptr()))
+    # edit_off [n_views * n + 1]: CSR;  [n_views * n, 2]: (begin, end) per item (the one-pass generator's slots)
+    entry = _L.idl_vectorise_ranges if (edit_off is not None and edit_off.dim() == 2) else _L.idl_vectorise
+    _lib.check(entry(_ptr(dev_in.codes), _ptr(dev_in.mask), _ptr(dev_in.slot_off), _ptr(dev_in.lengths),
+                     dev_in.n, k, mode, init, out_kind, n_views, _ptr(edits), _ptr(edit_off),
+                     _ptr(out), dev_in.n * row, int(getattr(dev_in, "max_len", 0) or 0), _stream_ptr()))
     return out
 
 
@@ -363,11 +365,24 @@ def _compat_edits(ff, transforms):
     return edits, edit_off
 
 
-def _philox_edits(dev_in, specs, seed, capacity=None):
-    """Device-drawn mimic sites (idl_mimic_edits, two-call protocol) -> (edits, edit_off) on device.
-    capacity=None: exact sizing (one host round trip to read the total).  With a capacity (an upper bound chosen by
-    the caller) nothing synchronises; edit_off[-1] holds the true total and the caller must check it against the
-    capacity afterwards (the fill kernel never writes past it)."""
+def edits_overflowed(edits, edit_off, capacity=None):
+    """Device bool: the edits of a no-sync _philox_edits call did not fit (slots: an item outgrew its slot; two-pass protocol with a
+    caller's capacity: the total outgrew it).  The run that used them is then invalid."""
+    flag = getattr(edits, "overflow_flag", None)
+    if flag is not None:
+        return flag != 0
+    return edit_off[-1] > capacity if capacity is not None else torch.zeros((), dtype=torch.bool, device=edits.device)
+
+
+def _philox_edits(dev_in, specs, seed, capacity=None, slots=None, sync=None):
+    """Device-drawn mimic sites -> (edits, edit_off) on device.
+    Default (slots; IDELUCS_MIMIC_SLOTS=0 turns it off): ONE pass (idl_mimic_edits_slots) into fixed per-item slots sized on the
+    host from the longest sequence; edit_off is then the [n_views * n, 2] array of (begin, end) _vectorise understands.  An item
+    that outgrows its slot (expected sites + 10 sigma + 32) raises a device flag: with sync (the default without a capacity)
+    it is read here and the exact two-call protocol takes over; without, the caller checks edits_overflowed() afterwards.
+    Two-call protocol (idl_mimic_edits): capacity=None: exact sizing (one host round trip to read the total).  With a capacity
+    (an upper bound chosen by the caller) nothing synchronises; edit_off[-1] holds the true total and the caller must check it
+    against the capacity afterwards (the fill kernel never writes past it)."""
     P = len(specs)
     p_ts = np.array([s[0] for s in specs], np.float64)
     p_tv = np.array([s[1] for s in specs], np.float64)
@@ -383,9 +398,25 @@ def _philox_edits(dev_in, specs, seed, capacity=None):
     except ValueError as err:
         raise ValueError(f"{err}; use rng='compat'") from None
     dev = dev_in.lengths.device
+    args = (_ptr(dev_in.lengths), dev_in.n, P, _ptr(p_ts), _ptr(p_tv), _ptr(n_rn), ctypes.c_uint64(seed & (2 ** 64 - 1)))
+    if slots is None:
+        slots = os.environ.get("IDELUCS_MIMIC_SLOTS", "1") != "0"
+    if slots and dev_in.n > 0:
+        total = int(_L.idl_mimic_slots_capacity(dev_in.n, P, _ptr(p_ts), _ptr(p_tv), _ptr(n_rn), max_len))
+        ws = torch.empty(max(int(_L.idl_mimic_slots_workspace(P)), 16), dtype=torch.uint8, device=dev)
+        ranges = torch.empty((P * dev_in.n, 2), dtype=torch.int64, device=dev)
+        edits = torch.empty(max(total, 1), dtype=torch.int32, device=dev)
+        flag = torch.zeros((), dtype=torch.int32, device=dev)
+        _lib.check(_L.idl_mimic_edits_slots(*args, max_len, _ptr(ranges), _ptr(edits), total, _ptr(flag), _ptr(ws), _stream_ptr()))
+        if sync if sync is not None else capacity is None:
+            if int(flag.item()) == 0:
+                return edits, ranges
+            # (an item beyond +10 sigma: never seen; the exact protocol below sizes everything from the counts)
+        else:
+            edits.overflow_flag = flag
+            return edits, ranges
     ws = torch.empty(_L.idl_mimic_workspace(dev_in.n, P), dtype=torch.uint8, device=dev)
     edit_off = torch.empty(P * dev_in.n + 1, dtype=torch.int64, device=dev)
-    args = (_ptr(dev_in.lengths), dev_in.n, P, _ptr(p_ts), _ptr(p_tv), _ptr(n_rn), ctypes.c_uint64(seed & (2 ** 64 - 1)))
     if capacity is None:
         total = ctypes.c_int64(0)
         _lib.check(_L.idl_mimic_edits(*args, _ptr(edit_off), None, 0, ctypes.byref(total), _ptr(ws), _stream_ptr()))

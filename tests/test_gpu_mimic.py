@@ -9,7 +9,7 @@ from oracle import oracle as O
 pytestmark = pytest.mark.gpu
 
 
-def _generate(lengths, specs, seed):
+def _generate(lengths, specs, seed, slots=False):
     import torch
     from idelucs_amd import utils as U
     dev = torch.device("cuda")
@@ -20,8 +20,71 @@ def _generate(lengths, specs, seed):
     d.n = len(lengths)
     d.codes = torch.zeros(1, dtype=torch.int32, device=dev)
     d.lengths = torch.tensor(lengths, dtype=torch.int64, device=dev)
-    edits, off = U._philox_edits(d, specs, seed)
+    edits, off = U._philox_edits(d, specs, seed, slots=slots)
     return edits.cpu().numpy().view(np.uint32), off.cpu().numpy()
+
+
+def test_one_pass_slots_equal_the_two_pass_protocol():
+    """idl_mimic_edits_slots (every site drawn once, into per-item slots; the default) against idl_mimic_edits (count, scan, fill):
+    the same edits in the same order for every (view, sequence) -- including items whose lanes hold far more sites than the LDS
+    buffer (the in-kernel count-then-fill path), one-base sequences, Random_N views -- and ranges that stay inside their
+    slots.  An item that cannot fit its slot raises the overflow flag instead of writing past it."""
+    import ctypes
+    import torch
+    from idelucs_amd import _lib, utils as U
+    lengths = [1, 2, 3, 63, 64, 65, 127, 1000, 4096, 4097, 10000, 10000, 33333, 200000, 5]
+    specs = [(1e-2, 0.5e-2, 0), (1e-2, 0.0, 0), (0.0, 0.5e-2, 0), (0.0, 0.0, 20), (0.3, 0.3, 0), (1e-6, 0.0, 0), (0.0, 0.0, 64), (0.0, 0.0, 0)]
+    n = len(lengths)
+    for seed in (0, 2 ** 40 + 12345):
+        e2, off = _generate(lengths, specs, seed, slots=False)
+        e1, rng = _generate(lengths, specs, seed, slots=True)
+        assert off.ndim == 1 and rng.shape == (len(specs) * n, 2)
+        prev_end = 0
+        for it in range(len(specs) * n):
+            a, b = rng[it]
+            assert prev_end <= a <= b <= len(e1), (it, a, b)            # slots are disjoint and ascending
+            prev_end = b
+            assert np.array_equal(e1[a:b], e2[off[it]:off[it + 1]]), (seed, it)
+    # overflow: a slot sized for 1 000 bases cannot take a 200 000-base sequence's sites -- flagged, nothing written past the buffer
+    dev = torch.device("cuda")
+    L = torch.tensor([200000], dtype=torch.int64, device=dev)
+    p_ts, p_tv, n_rn = np.array([0.3]), np.array([0.0]), np.array([0], np.int32)
+    P = lambda a: ctypes.c_void_p(a.ctypes.data)
+    cap = int(_lib.lib.idl_mimic_slots_capacity(1, 1, P(p_ts), P(p_tv), P(n_rn), 1000))
+    edits = torch.full((cap + 64,), -1, dtype=torch.int32, device=dev)
+    ranges = torch.zeros((1, 2), dtype=torch.int64, device=dev); flag = torch.zeros((), dtype=torch.int32, device=dev)
+    ws = torch.empty(int(_lib.lib.idl_mimic_slots_workspace(1)), dtype=torch.uint8, device=dev)
+    _lib.check(_lib.lib.idl_mimic_edits_slots(U._ptr(L), 1, 1, P(p_ts), P(p_tv), P(n_rn), ctypes.c_uint64(3), 1000, U._ptr(ranges), U._ptr(edits), cap,
+                                              U._ptr(flag), U._ptr(ws), U._stream_ptr()))
+    torch.cuda.synchronize()
+    assert int(flag.item()) == 1 and ranges.tolist() == [[0, cap]] and bool((edits[cap:] == -1).all())
+
+
+def test_vectoriser_takes_slot_ranges_like_csr():
+    """idl_vectorise_ranges on the one-pass generator's slots == idl_vectorise on the packed CSR edits, bit for bit, through the
+    pipelined kernel (k = 6, float32 rows, max_len known), the general kernel (canonical rows) and the accumulate kernel."""
+    import torch
+    from idelucs_amd import _lib, utils as U
+    from conftest import ROOT
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    dev = torch.device("cuda")
+    din = bench.synth_packed(3000, 2500, dev, seed=5, n_rate=1e-3)
+    specs = [t.spec() for t in U.mimic_transforms(3)]
+    e2, off = U._philox_edits(din, specs, 9, slots=False)
+    e1, rng = U._philox_edits(din, specs, 9, slots=True)
+    assert rng.dim() == 2 and off.dim() == 1
+    for mode, init, kind in ((_lib.MODE_KMER, _lib.INIT_ONE, _lib.OUT_FREQ_F32), (_lib.MODE_CANONICAL, _lib.INIT_ONE, _lib.OUT_FREQ_F64),
+                             (_lib.MODE_KMER, _lib.INIT_ZERO, _lib.OUT_COUNTS_I32)):
+        a = U._vectorise(din, 6, mode, init, kind, len(specs), e1, rng)
+        b = U._vectorise(din, 6, mode, init, kind, len(specs), e2, off)
+        assert torch.equal(a, b), (mode, init, kind)
+    acc = torch.ones_like(b)                                               # IDL_INIT_FROM_OUT: the single-pass kernel
+    acc2 = acc.clone()
+    U._vectorise(din, 6, _lib.MODE_KMER, _lib.INIT_FROM_OUT, _lib.OUT_COUNTS_I32, len(specs), e1, rng, out=acc)
+    U._vectorise(din, 6, _lib.MODE_KMER, _lib.INIT_FROM_OUT, _lib.OUT_COUNTS_I32, len(specs), e2, off, out=acc2)
+    assert torch.equal(acc, acc2) and torch.equal(acc, b + 1)
 
 
 def test_bit_exact_vs_oracle():

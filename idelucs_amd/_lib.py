@@ -87,6 +87,7 @@ SIGNATURES = {
     "idl_mst_prim_workspace": (_i64, [_i64]),
     "idl_mst_prim": (_int, [_vp, _int, _vp, _i64, _int, _vp, _vp, _vp, _vp, _vp]),
     "idl_debug_stamps": (_int, [_vp]),
+    "idl_debug_phase_stamps": (_int, [_int]),
     "idl_mimic_check_lengths": (_int, [_i64, _int, _vp, _vp]),
     "idl_mimic_slots_workspace": (_i64, [_int]),
     "idl_mimic_slots_capacity": (_i64, [_i64, _int, _vp, _vp, _vp, _i64]),

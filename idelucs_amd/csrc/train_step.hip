@@ -37,6 +37,19 @@ constexpr int COL_PARTS = 64; // row chunks of the partial column sums (bias gra
 
 struct U4 { uint32_t x, y, z, w; };
 
+// Diagnostic phase stamps of the two middle kernels (a build with -DIDL_PHASE_STAMPS: `make STAMPS=1`; tools/stamps_mid.py): when
+// armed (idl_debug_phase_stamps), workgroups 0..63 of the stamped kernel leave up to eight s_memrealtime marks (100 MHz) each in
+// the stamp buffer.  Compiled out otherwise: the two scalar loads that arm them sit on the kernels' critical path (+1.2 us).
+#ifdef IDL_PHASE_STAMPS
+__device__ uint64_t *idl_phase_stamps = nullptr;
+__device__ int idl_phase_mode = 0;           // 1: the mid-forward kernel stamps, 2: the mid-backward kernel
+#define IDL_PHASE_BUF(mode, bid) ((idl_phase_mode == (mode) && idl_phase_stamps != nullptr && (bid) < 64) ? idl_phase_stamps + 8 * (bid) : nullptr)
+#define IDL_PHASE_STAMP(buf, slot) do { if ((buf) != nullptr && threadIdx.x == 0) (buf)[(slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define IDL_PHASE_BUF(mode, bid) nullptr
+#define IDL_PHASE_STAMP(buf, slot) do { (void)(buf); } while (0)
+#endif
+
 __device__ __forceinline__ U4 philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1)
 {
 #pragma unroll
@@ -165,6 +178,8 @@ __device__ __forceinline__ void mid_fwd_body(float *__restrict__ a1, const float
     float (*LG)[64 * MAX_CPL + 1] = (float (*)[64 * MAX_CPL + 1])&part[2][0][0];   // [16][257]
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, l = lane & 15, q = lane >> 4;
     const int r0 = bid * 16;
+    uint64_t *stf = IDL_PHASE_BUF(1, bid);
+    IDL_PHASE_STAMP(stf, 0);
     const int k0 = 32 * wv + 8 * q;              // this lane's 8 consecutive k of row r0 + l
     // ---- every global read of the kernel is issued here, before the first dependent instruction
     float4 *src = (float4 *)(a1 + (int64_t)(r0 + l) * H1 + k0);
@@ -217,6 +232,7 @@ __device__ __forceinline__ void mid_fwd_body(float *__restrict__ a1, const float
         else src[i] = v;
         a[4 * i] = v.x; a[4 * i + 1] = v.y; a[4 * i + 2] = v.z; a[4 * i + 3] = v.w;
     }
+    IDL_PHASE_STAMP(stf, 1);                     // (wave 0: its loads have arrived, ReLU / Dropout done)
     // ---- lat = r1 W2^T: this wave's K-slice
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) {
@@ -232,7 +248,9 @@ __device__ __forceinline__ void mid_fwd_body(float *__restrict__ a1, const float
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) part[wv][4 * q + reg][(16 * ct + l + 16 * q) & 63] = acc[reg];   // C/D: row = 4q+reg, col = l
     }
+    IDL_PHASE_STAMP(stf, 2);
     __syncthreads();
+    IDL_PHASE_STAMP(stf, 3);
     // ---- wave wv owns row wv of the tile: add the 16 K-slices and the bias; normalise; ReLU + Dropout of the latent
     const int row = r0 + wv, cs = (lane + 16 * (wv >> 2)) & 63;
     float x = b2v;
@@ -254,6 +272,7 @@ __device__ __forceinline__ void mid_fwd_body(float *__restrict__ a1, const float
     __syncthreads();                             // part is dead
     R2t[wv][lane] = ar;
     __syncthreads();
+    IDL_PHASE_STAMP(stf, 4);
     // ---- logits tile wv = r2[16 x 64] W3[16 wv .. 16 wv + 15]^T + b3
     if (wv < nct) {
         f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
@@ -269,6 +288,7 @@ __device__ __forceinline__ void mid_fwd_body(float *__restrict__ a1, const float
         for (int reg = 0; reg < 4; ++reg) LG[4 * q + reg][16 * wv + l] = acc[reg] + b3v;
     }
     __syncthreads();
+    IDL_PHASE_STAMP(stf, 5);
     // ---- softmax of row wv
     float lg[MAX_CPL];
     float mx = -INFINITY;
@@ -293,6 +313,7 @@ __device__ __forceinline__ void mid_fwd_body(float *__restrict__ a1, const float
             if (c < C) z[(int64_t)row * C + c] = lg[t] / den;
         }
     }
+    IDL_PHASE_STAMP(stf, 6);
 }
 struct MidFwdParams {
     float *a1; const float *b1, *W2, *b2, *W3, *b3; int m, C, train; uint64_t seed; const int64_t *ctl; float *f, *inv, *r2, *z;
@@ -578,6 +599,8 @@ __device__ __forceinline__ void mid_bwd_body(const MidBwdArgs &a, int tile0, int
     const int rows = (m + COL_PARTS - 1) / COL_PARTS;
     const int r0 = bid * rows;
     const int r1 = (r0 + rows < m) ? r0 + rows : m;
+    uint64_t *stb = IDL_PHASE_BUF(2, bid);
+    IDL_PHASE_STAMP(stb, 0);
     if (a.ctl != nullptr && bid == 0 && tid == 0) a.ctl[1] += a.batch_advance;
     if (small) {
         if (!NCE) for (int i = tid; i < C * C; i += 64 * MID_WAVES) sP[i] = a.dP0[i];
@@ -656,7 +679,9 @@ __device__ __forceinline__ void mid_bwd_body(const MidBwdArgs &a, int tile0, int
                                                             : a.act1[(int64_t)(t0 + rl) * H1 + 32 * wv + 2 * l + j];
                 }
         }
+        IDL_PHASE_STAMP(stb, 1);
         __syncthreads();
+        IDL_PHASE_STAMP(stb, 2);                 // (every wave's prologue requests have arrived: sP, sW3 staged)
         // ---- 1. head backward of row t0 + wv
         if constexpr (small) { if (wv < nr) {
             // every global read of the row first, then arithmetic on registers and LDS only
@@ -748,7 +773,9 @@ __device__ __forceinline__ void mid_bwd_body(const MidBwdArgs &a, int tile0, int
             R2s[wv][lane] = 0.f;
             for (int c = lane; c < C; c += 64) DLG[wv][c] = 0.f;
         }
+        IDL_PHASE_STAMP(stb, 3);
         __syncthreads();
+        IDL_PHASE_STAMP(stb, 4);
         // ---- 2. dr1 tile = DL[16 x 64] W2[64 x 512]
         float av[16];
 #pragma unroll
@@ -776,6 +803,7 @@ __device__ __forceinline__ void mid_bwd_body(const MidBwdArgs &a, int tile0, int
                 }
             }
         }
+        IDL_PHASE_STAMP(stb, 5);
         // ---- 3. the small partial sums, from LDS (rows >= nr are zero)
         if (tid < H2) {
 #pragma unroll
@@ -813,6 +841,7 @@ __device__ __forceinline__ void mid_bwd_body(const MidBwdArgs &a, int tile0, int
             if (o < C * H2) a.dW3_part[(int64_t)bid * C * H2 + o] = acc3[i];
         }
     }
+    IDL_PHASE_STAMP(stb, 6);
 }
 struct MidBwdParams { MidBwdArgs a; int tile0, tile1; idl_dev::GatherArgs gth; };
 static_assert(sizeof(MidBwdParams) + idl::PLAN_PARAMS <= idl::PLAN_BYTES, "MidBwdParams does not fit a plan record");
@@ -1392,6 +1421,8 @@ static uint64_t *stamp_buffer()
     return buf;
 }
 
+static int g_phase_mode_host = 0;     // idl_debug_phase_stamps: while armed, the optimizer launch leaves the stamp buffer alone
+
 static int rmsprop_launch(int count, float *const *params, const float *const *grads, const int32_t *grad_parts,
                           float *const *square_avg, const int64_t *sizes, const float *hyper, int64_t *ctl, int64_t batch_advance,
                           const float *loss_rows, int loss_m, float w_nce, float w_iic, float *out, const idl_dev::GatherArgs &g,
@@ -1463,7 +1494,7 @@ static int rmsprop_launch(int count, float *const *params, const float *const *g
         }
         const dim3 block(wg_dev::THREADS);
         const hipStream_t st_ = (hipStream_t)stream;
-        if (uint64_t *st = stamp_buffer(); st != nullptr && skip)
+        if (uint64_t *st = g_phase_mode_host ? nullptr : stamp_buffer(); st != nullptr && skip)
             hipLaunchKernelGGL((wgrad_rmsprop_kernel<true, true>), grid, block, wg_dev::IMG_BYTES, st_, *big, a, hyper, ctl, batch_advance, (int)extra, g, st);
         else if (st != nullptr)
             hipLaunchKernelGGL(wgrad_rmsprop_kernel<true>, grid, block, wg_dev::IMG_BYTES, st_, *big, a, hyper, ctl, batch_advance, (int)extra, g, st);
@@ -1535,6 +1566,23 @@ int idl_wgrad_rmsprop_step(int count, float *const *params, const float *const *
     idl_dev::GatherArgs g{};
     return rmsprop_launch(count, params, grads, grad_parts, square_avg, sizes, hyper, ctl, batch_advance, loss_rows, loss_m, w_nce, w_iic, out, g,
                           stream, wg_index, wg_dy, wg_x, wg_m, wg_n_out, wg_n_in, wg_grad, wg_x_transposed, &w, w1_index);
+}
+
+int idl_debug_phase_stamps(int on)
+{
+#ifdef IDL_PHASE_STAMPS
+    uint64_t *st = on ? stamp_buffer() : nullptr;
+    IDL_REQUIRE(!on || st != nullptr, "debug stamps are off (IDELUCS_STAMPS=1 before the first launch)");
+    IDL_HIP_TRY(hipDeviceSynchronize());
+    if (st != nullptr) IDL_HIP_TRY(hipMemset(st, 0, 1024 * 4 * sizeof(uint64_t)));
+    IDL_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(idl_phase_stamps), &st, sizeof(st)));
+    IDL_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(idl_phase_mode), &on, sizeof(on)));
+    g_phase_mode_host = on;
+    return IDL_OK;
+#else
+    (void)on; (void)g_phase_mode_host;
+    IDL_REQUIRE(false, "this build has no phase stamps (make -C idelucs_amd/csrc STAMPS=1)");
+#endif
 }
 
 int idl_debug_stamps(uint64_t *host_out)

@@ -433,8 +433,10 @@ def spawn_ranks(n, n_visible, n_shared):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # (the arguments travel in the environment: the launcher's own parser claims abbreviations such as --n even behind the script)
+    env["IDELUCS_BENCH_ARGV"] = json.dumps(sys.argv[1:])
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+           "--master-port", str(port), os.path.abspath(__file__)]
     r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
     lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
     for l in r.stdout.splitlines():
@@ -470,7 +472,8 @@ def main():
     ap.add_argument("--no-e2e", dest="e2e", action="store_false")
     ap.add_argument("--n-rate", dest="n_rate", type=float, default=0.0,
                     help="SURVEY 8(d) variant N: every synthetic base is an N with this probability (e.g. 1e-3); default 0 = BASELINE's input")
-    args = ap.parse_args()
+    forwarded = os.environ.pop("IDELUCS_BENCH_ARGV", None)      # set by spawn_ranks for its ranks
+    args = ap.parse_args(json.loads(forwarded) if forwarded is not None and "WORLD_SIZE" in os.environ else None)
 
     cfg5 = args.workload == "cfg5"
     args.n = args.n or (1_000_000 if cfg5 else 100_000)
@@ -514,7 +517,7 @@ def main():
         elif os.environ.get("IDELUCS_BENCH_GROUP_OF_ONE", "1") == "1":
             dist.init_process_group(backend, rank=0, world_size=1, store=dist.HashStore(),
                                     **({"device_id": dev} if backend == "nccl" else {}))
-        if dist.is_initialized():       # the communicator (and its banner) comes with the first collective
+        if dist.is_initialized() and dist.get_backend() == "nccl":     # the communicator (and its banner) comes with the first collective
             dist.all_reduce(torch.zeros(1, device=dev))
             torch.cuda.synchronize()
     group = {"ranks": dist.get_world_size() if dist.is_initialized() else 1,

@@ -76,3 +76,27 @@ def test_no_group_is_the_local_path():
     assert D.all_gather_assignments(y).shape == (1, 7)
     x = torch.ones((5, 64), device="cuda")
     assert D.all_gather_rows(x, 5) is x
+
+
+def test_bench_starts_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` with no launcher: the parent (which never touches the GPU) starts two ranks as a child torchrun,
+    relays rank 0's ONE JSON line and its exit code.  Two ranks share this box's one GPU over gloo (the rehearsal knobs
+    IDELUCS_BENCH_BACKEND / IDELUCS_BENCH_DEVICES): every line of the N > 1 bench path except RCCL itself, which
+    test_exchange_payloads_through_rccl covers.  `--n` must survive the launcher's own argument parser."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(IDELUCS_BENCH_BACKEND="gloo", IDELUCS_BENCH_DEVICES="1", PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--n", "5000", "--steps", "1", "--warmup", "1",
+                        "--no-cpu-baseline"], cwd=tmp_path, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-3000:]
+    lines = r.stdout.splitlines()
+    assert len(lines) == 1 and lines[0].startswith('{"metric"'), r.stdout[-1000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["ranks"] == 2 and j["backend"] == "gloo" and [d["rank"] for d in j["devices"]] == [0, 1]
+    assert j["config"]["n_voters"] == 8 and j["config"]["n_sequences"] == 5000 and j["scaling"] == "strong"
+    # two processes time-slicing one GPU must still be within an order of magnitude of one (a gloo collective on a device tensor
+    # right after init once left both ranks 100 x slower for the whole run)
+    assert j["ms_per_step"] < 1000, j["ms_per_step"]

@@ -466,7 +466,7 @@ def main():
     ap.add_argument("--with-predict", dest="with_predict", type=int, default=None,
                     help="1: predict + all-gather inside the timed region (default: 0 at N=1 with one voter = BASELINE.md's region; 1 otherwise)")
     ap.add_argument("--cpu-sample", dest="cpu_sample", type=int, default=24000)
-    ap.add_argument("--cpu-ref-steps", dest="cpu_ref_steps", type=int, default=8,
+    ap.add_argument("--cpu-ref-steps", dest="cpu_ref_steps", type=int, default=2,
                     help="optimizer steps timed with the reference's cpu_count()-2 torch threads (scaled to the epoch)")
     ap.add_argument("--no-cpu-baseline", dest="cpu_base", action="store_false")
     ap.add_argument("--no-e2e", dest="e2e", action="store_false")

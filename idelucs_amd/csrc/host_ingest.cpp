@@ -624,9 +624,14 @@ int idl_fasta_parse_pack(const char *path, uint8_t *codes, uint8_t *mask, int64_
     const double t_0 = now();
     std::vector<FastOut> outs((size_t)nt);
     constexpr int64_t COPY_SLOTS = (int64_t)1 << 18;                  // send every 4 MB of packed codes (+ 2 MB of mask)
+    // the copies below are issued from worker threads: a new thread's current device is 0, so each worker adopts the CALLER's device
+    // first (a rank of a multi-GPU job is bound to another one, and dev_codes / stream belong to it)
+    int caller_dev = -1;
+    if (dev_codes != nullptr && hipGetDevice(&caller_dev) != hipSuccess) caller_dev = -1;
 
     parallel_for(nt, [&](int t) {
         FastOut &o = outs[(size_t)t];
+        if (t > 0 && caller_dev >= 0 && hipSetDevice(caller_dev) != hipSuccess) { o.copy_failed = 1; return; }
         const size_t b = size * (size_t)t / (size_t)nt, e = size * (size_t)(t + 1) / (size_t)nt;
         const int64_t region_lo = cap_slots * t / nt, region_hi = cap_slots * (t + 1) / nt;
         auto line_end = [&](size_t p) -> size_t {

@@ -240,8 +240,19 @@ def hdbscan_device(points, min_cluster_size, device=None):
     sklearn 1.7, the stand-in for the absent `hdbscan` package: SURVEY 8c), so the labels are sklearn's."""
     import ctypes
     import torch
-    from sklearn.cluster._hdbscan._linkage import MST_edge_dtype, make_single_linkage
-    from sklearn.cluster._hdbscan._tree import tree_to_labels
+    try:
+        from sklearn.cluster._hdbscan._linkage import MST_edge_dtype, make_single_linkage
+        from sklearn.cluster._hdbscan._tree import tree_to_labels
+        import inspect
+        if "min_cluster_size" not in str(getattr(tree_to_labels, "__doc__", "") or "") and not callable(tree_to_labels):
+            raise ImportError("unexpected tree_to_labels")
+    except ImportError as err:
+        # another scikit-learn series: its own (host) HDBSCAN -- the same algorithm, O(N^2) on the CPU
+        import warnings
+        from sklearn.cluster import HDBSCAN
+        warnings.warn(f"idelucs_amd: sklearn's private HDBSCAN tree code is not importable ({err}); running sklearn.cluster.HDBSCAN on the host")
+        cl = HDBSCAN(min_cluster_size=max(int(min_cluster_size), 2)).fit(np.asarray(points, dtype=np.float64))
+        return cl.labels_, cl.probabilities_
     from . import _lib
     L = _lib.lib
     dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
@@ -267,8 +278,15 @@ def hdbscan_device(points, min_cluster_size, device=None):
     mst = np.empty(n - 1, dtype=MST_edge_dtype)
     mst["current_node"], mst["next_node"], mst["distance"] = cur.cpu().numpy(), nxt.cpu().numpy(), w.cpu().numpy()
     mst = mst[np.argsort(mst["distance"])]                                            # sklearn hdbscan.py:_process_mst
-    tree = make_single_linkage(mst)
-    labels, prob = tree_to_labels(tree, k, "eom", False, 0.0, None)                   # HDBSCAN's defaults (hdbscan.py:846-853)
+    try:
+        tree = make_single_linkage(mst)
+        labels, prob = tree_to_labels(tree, k, "eom", False, 0.0, None)               # HDBSCAN's defaults (hdbscan.py:846-853)
+    except TypeError as err:                                                          # a changed private signature
+        import warnings
+        from sklearn.cluster import HDBSCAN
+        warnings.warn(f"idelucs_amd: sklearn's private tree_to_labels has another signature ({err}); running sklearn.cluster.HDBSCAN on the host")
+        cl = HDBSCAN(min_cluster_size=k).fit(pts)
+        return cl.labels_, cl.probabilities_
     return labels, prob
 
 

@@ -243,9 +243,6 @@ def hdbscan_device(points, min_cluster_size, device=None):
     try:
         from sklearn.cluster._hdbscan._linkage import MST_edge_dtype, make_single_linkage
         from sklearn.cluster._hdbscan._tree import tree_to_labels
-        import inspect
-        if "min_cluster_size" not in str(getattr(tree_to_labels, "__doc__", "") or "") and not callable(tree_to_labels):
-            raise ImportError("unexpected tree_to_labels")
     except ImportError as err:
         # another scikit-learn series: its own (host) HDBSCAN -- the same algorithm, O(N^2) on the CPU
         import warnings

@@ -76,8 +76,10 @@ def test_confusion_matrix_picture(tmp_path):
 @pytest.mark.gpu
 def test_cli_end_to_end_writes_reference_outputs(tmp_path, monkeypatch):
     """The run of Example/ALL_RESULTS.tsv:19 (Influenza-A, k=6, 5 clusters, 35 epochs x 5 voters, batch 512): the reference's
-    output files, and an ensemble accuracy inside the reference's own range for this run -- tests/golden/anchor_seeds.json holds
-    three 5-voter ensembles of the imported reference: 0.934, 0.928, 0.994 (the published 0.9947 is the lucky end of it)."""
+    output files, and ensemble accuracies inside the reference's own range for this run -- tests/golden/anchor_seeds.json holds
+    TEN 5-voter ensembles of the imported reference (round 3; three before): 0.928 .. 0.995, mean 0.965 (the published 0.9947 is the
+    lucky end of it).  Three seeds here (the CLI run + two through the same driver code): every one within 0.03 of the
+    reference's worst, their mean within 0.03 of the reference's mean."""
     import json
     import pandas as pd
     from conftest import GOLDEN
@@ -93,9 +95,14 @@ def test_cli_end_to_end_writes_reference_outputs(tmp_path, monkeypatch):
     assert list(df.columns) == ["sequence_id", "assignment", "confidence_score"] and len(df) == 949
     m = pd.read_csv(os.path.join(out_dir, "metrics.tsv"), sep="\t", index_col=0)
     assert {"ACC", "ARI", "NMI", "Silhouette-Score", "Davies-Boulding"} <= set(m.index)
-    acc = float(m.loc["ACC", "Value"])
-    print("5-voter ensemble ACC", acc, "| reference ensembles", np.round(ref, 4))
-    assert acc >= min(ref) - 0.03
+    accs = [float(m.loc["ACC", "Value"])]
+    for seed in (1, 2):
+        time.sleep(1.1)                                       # the results folder is stamped to the second
+        od = main(["--sequence_file", os.path.join(DATA, "Influenza-A.fas"), "--GT_file", os.path.join(DATA, "Influenza-A_GT.tsv"),
+                   "--n_clusters", "5", "--n_epochs", "35", "--n_voters", "5", "--batch_sz", "512", "--k", "6", "--seed", str(seed)])
+        accs.append(float(pd.read_csv(os.path.join(od, "metrics.tsv"), sep="\t", index_col=0).loc["ACC", "Value"]))
+    print("5-voter ensemble ACC over 3 seeds", np.round(accs, 4), "| reference ensembles", np.round(ref, 4))
+    assert len(ref) >= 10 and min(accs) >= min(ref) - 0.03 and abs(np.mean(accs) - np.mean(ref)) <= 0.03, (accs, np.mean(ref))
 
 
 @pytest.mark.gpu

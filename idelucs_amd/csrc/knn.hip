@@ -1,0 +1,261 @@
+// knn.hip -- core distances of the fine-grained mode's HDBSCAN (reference idelucs/__main__.py:83,153-156:
+// hdbscan.HDBSCAN(min_cluster_size = N // 100 + 1) on the [N, 64] latent; the stand-in sklearn.cluster.HDBSCAN takes min_samples =
+// min_cluster_size): for every point the distance to its k-th nearest neighbour, itself included, k = N // 100 + 1 -- at BASELINE
+// cfg5 (N = 10^6) the 10 001-th smallest of 10^6 distances, for 10^6 points.
+//
+// Round 2 materialised the float64 Gram-form distance matrix in 8 GB row blocks and ran torch.topk on each: 8.6 TB written and
+// radix-selected, 29 of the device HDBSCAN's 73 s.  Here the distances are never written:
+//
+//   idl_knn_window   ONE pass over all pairs on the fp32 matrix cores.  The caller gives every row a window [lo, hi) that brackets
+//                    its k-th distance (order statistics of a column sample); the pass counts the columns below lo and keeps the
+//                    few thousand inside the window (squared distance + index) in a per-row slot.  A workgroup owns 256 rows (four
+//                    waves x four 16-row A tiles held in registers) and streams every 16-column B tile once: 64 MFMAs per 4 KB
+//                    tile per wave -- matrix-pipe bound; the 256 MB of points are read N / 256 times from L2 / Infinity Cache.
+//   idl_knn_select   per row: radix select (4 x 8 bits, LDS histograms) of the (k - below)-th smallest kept value v; then EXACTLY:
+//                    the Gram form in fp32 errs by at most eps = delta / 2, so every column kept below v - delta is truly below
+//                    the k-th and every true candidate lies within v +- delta; the members of that band (a handful) get their
+//                    float64 distance from the difference vector, in sklearn's order of operations, and the k-th is read off
+//                    them.  A row whose window missed (sample unlucky, band touching the window's edge, slot or band full) is
+//                    flagged and recomputed by the caller's exact path.
+#include "common.h"
+#include "wave_ops.h"
+
+namespace {
+
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+constexpr int KD = 64;            // point dimension (the latent width of NetLinear / myNet)
+constexpr int ROWS_WG = 256;      // rows of a workgroup: 4 waves x 64
+constexpr int BAND_CAP = 1024;    // columns of the exact band a row can hold
+
+struct WindowArgs {
+    const float *x, *sq;          // [n, 64] Gram coordinates (centred), their |x|^2
+    const float *lo, *hi;         // per row of this launch (index row - row0)
+    int64_t n, row0, rows;
+    int32_t *cnt_lo, *cand_cnt;   // per row of this launch
+    float *cand_d2; int32_t *cand_idx;   // [rows, cap]
+    int cap;
+};
+
+__global__ __launch_bounds__(256) void knn_window_kernel(WindowArgs a)
+{
+    __shared__ int slot_n[ROWS_WG];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l = lane & 15, q = lane >> 4;
+    const int64_t rbase = a.row0 + (int64_t)blockIdx.x * ROWS_WG + 64 * wv;     // first row of this wave
+    slot_n[tid] = 0;
+    // A tiles: row rbase + 16 rt + l, k = 16 q + s  (A[i = l][k = q] per MFMA step s: the k order is permuted the same way on the B side)
+    float av[4][16];
+    float sqr[4][4], lo[4][4], hi[4][4];
+    int below[4][4];
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+        const int64_t r = rbase + 16 * rt + l;
+        const bool ok = r < a.row0 + a.rows;
+        const float4 *src = (const float4 *)(a.x + (ok ? r : a.row0) * KD + 16 * q);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const float4 t = src[i]; av[rt][4 * i] = t.x; av[rt][4 * i + 1] = t.y; av[rt][4 * i + 2] = t.z; av[rt][4 * i + 3] = t.w; }
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {                   // C/D: row 4 q + reg of the tile, column l
+            const int64_t rr = rbase + 16 * rt + 4 * q + reg;
+            const bool okr = rr < a.row0 + a.rows;
+            sqr[rt][reg] = okr ? a.sq[rr] : 0.f;
+            lo[rt][reg] = okr ? a.lo[rr - a.row0] : -1.f;      // a row past the end: nothing is below, nothing inside
+            hi[rt][reg] = okr ? a.hi[rr - a.row0] : -1.f;
+            below[rt][reg] = 0;
+        }
+    }
+    __syncthreads();
+    // B tile t: columns 16 t + l, k = 16 q + s
+    const int64_t ntile = (a.n + 15) / 16;
+    auto load_b = [&](int64_t t, float (&bv)[16], float &sqc) {
+        const int64_t j = 16 * t + l;
+        const bool ok = j < a.n;
+        const float4 *src = (const float4 *)(a.x + (ok ? j : 0) * KD + 16 * q);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const float4 v = src[i]; bv[4 * i] = v.x; bv[4 * i + 1] = v.y; bv[4 * i + 2] = v.z; bv[4 * i + 3] = v.w; }
+        sqc = ok ? a.sq[j] : 3.0e38f;                          // a column past the end is infinitely far
+    };
+    float b0[16], b1[16], s0, s1;
+    load_b(0, b0, s0);
+    auto tile = [&](int64_t t, const float (&bv)[16], float sqc) {
+        f32x4_t acc[4];
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) acc[rt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 16; ++s)
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][s], bv[s], acc[rt], 0, 0, 0);
+        const int j = (int)(16 * t) + l;
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const float d2 = (sqr[rt][reg] + sqc) - 2.f * acc[rt][reg];
+                below[rt][reg] += d2 < lo[rt][reg] ? 1 : 0;
+                if (d2 >= lo[rt][reg] && d2 < hi[rt][reg]) {
+                    const int rl = 64 * wv + 16 * rt + 4 * q + reg;                    // row inside the workgroup
+                    const int pos = atomicAdd(&slot_n[rl], 1);
+                    if (pos < a.cap) {
+                        const int64_t o = ((int64_t)blockIdx.x * ROWS_WG + rl) * a.cap + pos;
+                        a.cand_d2[o] = d2; a.cand_idx[o] = j;
+                    }
+                }
+            }
+    };
+    for (int64_t t = 0; t < ntile; t += 2) {                   // two tiles per turn: the next tile's loads are in flight during the MFMAs
+        if (t + 1 < ntile) load_b(t + 1, b1, s1);
+        tile(t, b0, s0);
+        if (t + 1 < ntile) {
+            if (t + 2 < ntile) load_b(t + 2, b0, s0);
+            tile(t + 1, b1, s1);
+        }
+    }
+    // counts: this lane's rows 4 q + reg of tile rt, over its columns l -> add over the 16 lanes of the row
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            int v = below[rt][reg];
+            v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+            const int64_t rr = rbase + 16 * rt + 4 * q + reg;
+            if (l == 0 && rr < a.row0 + a.rows) a.cnt_lo[rr - a.row0] = v;
+        }
+    __syncthreads();
+    {
+        const int64_t rr = a.row0 + (int64_t)blockIdx.x * ROWS_WG + tid;
+        if (rr < a.row0 + a.rows) a.cand_cnt[rr - a.row0] = slot_n[tid];
+    }
+}
+
+struct SelectArgs {
+    const float *x;                      // [n, 64] the points themselves (float64 values that float32 holds exactly)
+    const float *lo, *hi, *delta;        // per row of this launch
+    int64_t n, row0, rows, k;
+    const int32_t *cnt_lo, *cand_cnt;
+    const float *cand_d2; const int32_t *cand_idx;
+    int cap;
+    double *core;                        // [n]
+    int32_t *status;                     // per row of this launch: 0 done, else why not (1 window missed, 2 slot full, 3 band at the edge, 4 band full)
+};
+
+__device__ __forceinline__ uint32_t fkey(float f)        // order-preserving map float -> uint32
+{
+    const uint32_t b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
+__global__ __launch_bounds__(256) void knn_select_kernel(SelectArgs a)
+{
+    __shared__ int hist[256];
+    __shared__ int sh_bin, sh_rank, band_n, below_band, wave_tot[4];
+    __shared__ int band_idx[BAND_CAP];
+    __shared__ double band_val[BAND_CAP];
+    const int tid = threadIdx.x;
+    const int64_t rloc = blockIdx.x, row = a.row0 + rloc;
+    const int cnt = a.cand_cnt[rloc];
+    const int64_t want = a.k - (int64_t)a.cnt_lo[rloc];        // 1-based rank among the kept columns
+    if (cnt > a.cap) { if (tid == 0) a.status[rloc] = 2; return; }
+    if (want < 1 || want > cnt) { if (tid == 0) a.status[rloc] = 1; return; }
+    const float *d2 = a.cand_d2 + rloc * a.cap;
+    const int32_t *ix = a.cand_idx + rloc * a.cap;
+    // ---- radix select: the `want`-th smallest key, 8 bits per pass from the top.  Keys are taken relative to the window's lower
+    // end, so that only the bits in which the kept values differ are walked (a window spans ~2^20 floats: three passes, and the
+    // first histogram is spread over its bins instead of piling every lane's atomic on one)
+    const uint32_t kbase = fkey(a.lo[rloc]);
+    const uint32_t span = fkey(a.hi[rloc]) - kbase;
+    const int passes = span ? (32 - __builtin_clz(span) + 7) / 8 : 1;
+    uint32_t prefix = 0, mask = 0;
+    int rank = (int)want - 1;                                   // 0-based rank among the keys that match the prefix
+    for (int pass = 0; pass < passes; ++pass) {
+        const int shift = 8 * (passes - 1 - pass);
+        hist[tid] = 0;
+        __syncthreads();
+        for (int i = tid; i < cnt; i += 256) {
+            const uint32_t key = fkey(d2[i]) - kbase;
+            if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1);
+        }
+        __syncthreads();
+        {   // the bin that holds rank `rank`: block-wide inclusive prefix of the histogram (wave scan + the wave totals)
+            const int h = hist[tid];
+            int inc = h;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o, 64); if ((tid & 63) >= o) inc += t; }
+            if ((tid & 63) == 63) wave_tot[tid >> 6] = inc;
+            __syncthreads();
+            int base = 0;
+            for (int w = 0; w < (tid >> 6); ++w) base += wave_tot[w];
+            inc += base;
+            if (rank >= inc - h && rank < inc) { sh_bin = tid; sh_rank = rank - (inc - h); }
+        }
+        __syncthreads();
+        prefix |= (uint32_t)sh_bin << shift; mask |= 255u << shift; rank = sh_rank;
+        __syncthreads();
+    }
+    // prefix + kbase is the key of v; recover v
+    const uint32_t vkey = prefix + kbase;
+    const uint32_t vb = (vkey & 0x80000000u) ? (vkey & 0x7FFFFFFFu) : ~vkey;
+    const float v = __uint_as_float(vb);
+    const float dl = a.delta[rloc];
+    if (!(v - dl > a.lo[rloc]) || !(v + dl < a.hi[rloc])) { if (tid == 0) a.status[rloc] = 3; return; }
+    // ---- the band [v - delta, v + delta]: members and the count of kept columns below it
+    if (tid == 0) { band_n = 0; below_band = 0; }
+    __syncthreads();
+    int mine_below = 0;
+    for (int i = tid; i < cnt; i += 256) {
+        const float x = d2[i];
+        if (x < v - dl) ++mine_below;
+        else if (x <= v + dl) { const int p = atomicAdd(&band_n, 1); if (p < BAND_CAP) band_idx[p] = ix[i]; }
+    }
+    if (mine_below) atomicAdd(&below_band, mine_below);
+    __syncthreads();
+    const int nb = band_n;
+    if (nb > BAND_CAP) { if (tid == 0) a.status[rloc] = 4; return; }
+    // ---- exact squared distances of the band members, float64 from the difference vector (sklearn: t = a - b; d += t * t)
+    for (int p = tid; p < nb; p += 256) {
+        const float *pa = a.x + row * KD, *pb = a.x + (int64_t)band_idx[p] * KD;
+        double d = 0.0;
+        for (int c = 0; c < KD; ++c) { const double t = (double)pa[c] - (double)pb[c]; d = idl_dev::square_then_add(d, t); }
+        band_val[p] = d;
+    }
+    __syncthreads();
+    const int target = (int)want - 1 - below_band;              // 0-based rank inside the band
+    if (target < 0 || target >= nb) { if (tid == 0) a.status[rloc] = 3; return; }
+    for (int p = tid; p < nb; p += 256) {
+        const double mv = band_val[p];
+        int r = 0;
+        for (int o = 0; o < nb; ++o) { const double ov = band_val[o]; r += (ov < mv || (ov == mv && o < p)) ? 1 : 0; }
+        if (r == target) { a.core[row] = __dsqrt_rn(mv); a.status[rloc] = 0; }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int idl_knn_window(const float *x, const float *sq, int64_t n, int d, const float *lo, const float *hi, int64_t row0, int64_t rows,
+                   int32_t *cnt_lo, int32_t *cand_cnt, float *cand_d2, int32_t *cand_idx, int cap, void *stream)
+{
+    IDL_REQUIRE(x && sq && lo && hi && cnt_lo && cand_cnt && cand_d2 && cand_idx, "knn_window: NULL buffer");
+    IDL_REQUIRE(d == KD, "knn_window: points must have 64 coordinates");
+    IDL_REQUIRE(n >= 1 && n < (1ll << 31) && row0 >= 0 && rows >= 1 && row0 + rows <= n && cap >= 1, "knn_window: bad sizes");
+    IDL_REQUIRE((((uintptr_t)x) & 15u) == 0, "knn_window: x must be 16-byte aligned");
+    IDL_REQUIRE((rows + ROWS_WG - 1) / ROWS_WG * (int64_t)ROWS_WG * cap < (1ll << 40), "knn_window: slot buffer too large");
+    WindowArgs a{x, sq, lo, hi, n, row0, rows, cnt_lo, cand_cnt, cand_d2, cand_idx, cap};
+    hipLaunchKernelGGL(knn_window_kernel, dim3((unsigned)((rows + ROWS_WG - 1) / ROWS_WG)), dim3(256), 0, (hipStream_t)stream, a);
+    IDL_HIP_TRY(hipGetLastError());
+    return IDL_OK;
+}
+
+int idl_knn_select(const float *x, int64_t n, int d, const float *lo, const float *hi, const float *delta, int64_t row0,
+                   int64_t rows, int64_t k, const int32_t *cnt_lo, const int32_t *cand_cnt, const float *cand_d2, const int32_t *cand_idx,
+                   int cap, double *core, int32_t *status, void *stream)
+{
+    IDL_REQUIRE(x && lo && hi && delta && cnt_lo && cand_cnt && cand_d2 && cand_idx && core && status, "knn_select: NULL buffer");
+    IDL_REQUIRE(d == KD, "knn_select: points must have 64 coordinates");
+    IDL_REQUIRE(n >= 1 && row0 >= 0 && rows >= 1 && row0 + rows <= n && cap >= 1 && k >= 1 && k <= n, "knn_select: bad sizes");
+    SelectArgs a{x, lo, hi, delta, n, row0, rows, k, cnt_lo, cand_cnt, cand_d2, cand_idx, cap, core, status};
+    hipLaunchKernelGGL(knn_select_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, a);
+    IDL_HIP_TRY(hipGetLastError());
+    return IDL_OK;
+}
+
+}  // extern "C"

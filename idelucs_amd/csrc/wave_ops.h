@@ -87,4 +87,13 @@ __device__ __forceinline__ float wave_max_f(float v)
     return max_xor32(max_xor16(v));
 }
 
+// acc + t * t as a product and a sum, each rounded (sklearn's distance loops, compiled without fused multiply-add).  hipcc contracts
+// x * y + z into one fma by default and __dmul_rn / __dadd_rn are plain operators there, so the contraction is switched off here.
+__device__ __forceinline__ double square_then_add(double acc, double t)
+{
+#pragma clang fp contract(off)
+    const double p = t * t;
+    return acc + p;
+}
+
 }  // namespace idl_dev

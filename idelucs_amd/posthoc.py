@@ -203,36 +203,180 @@ def _hdbscan(points, min_cluster_size, device=None):
     return cl.labels_, cl.probabilities_
 
 
-def core_distances_device(x64, k, device):
-    """Distance of every point to its k-th nearest neighbour, itself included (sklearn _hdbscan_prims: NearestNeighbors(
-    n_neighbors=k).kneighbors(X)[:, -1]).  Row blocks of the float64 Gram-form distance matrix (one GEMM each), the k-th smallest
-    per row by radix select (torch.topk), and the selected neighbour's distance then formed exactly from the difference
-    vector (the Gram form is only trusted to FIND the neighbour)."""
+def _core_distances_rows(x64, sq, rows_idx, k, device, out):
+    """out[rows_idx] = distance of those rows to their k-th nearest neighbour, itself included: row blocks of the float64 Gram-form
+    distance matrix (one GEMM each), the k-th smallest per row by radix select (torch.topk), and the selected neighbour's
+    distance then formed exactly from the difference vector (the Gram form is only trusted to FIND the neighbour).
+    rows_idx: None = every row, else an int64 tensor of row numbers."""
     import torch
     n = x64.shape[0]
-    sq = (x64 * x64).sum(1)
-    rows = max(64, min(n, (1 << 30) // max(n, 1)))            # 8 GB of float64 distances per block
-    core = torch.empty(n, dtype=torch.float64, device=device)
-    buf = torch.empty((min(rows, n), n), dtype=torch.float64, device=device)      # one block buffer, reused
+    m = n if rows_idx is None else int(rows_idx.numel())
+    if m == 0:
+        return
+    rows = max(64, min(m, (1 << 30) // max(n, 1)))            # 8 GB of float64 distances per block
+    buf = torch.empty((min(rows, m), n), dtype=torch.float64, device=device)      # one block buffer, reused
     xt = x64.t()
-    for lo in range(0, n, rows):
-        xb = x64[lo:lo + rows]
+    for lo in range(0, m, rows):
+        ridx = torch.arange(lo, min(lo + rows, m), device=device) if rows_idx is None else rows_idx[lo:lo + rows]
+        xb = x64[ridx]
         d2 = buf[:xb.shape[0]]
         torch.mm(xb, xt, out=d2)
-        d2.mul_(-2.0).add_(sq[None, :]).add_(sq[lo:lo + rows, None])
-        d2[torch.arange(xb.shape[0], device=device), torch.arange(lo, lo + xb.shape[0], device=device)] = 0.0     # a point is its own first neighbour
+        d2.mul_(-2.0).add_(sq[None, :]).add_(sq[ridx, None])
+        d2[torch.arange(xb.shape[0], device=device), ridx] = 0.0     # a point is its own first neighbour
         # the k-th smallest per row: unsorted top-k (multi-block radix select, 2.5 x faster than torch.kthvalue on float64 rows of
         # 10^6) and the largest of those
         vals, cols = torch.topk(d2, k, dim=1, largest=False, sorted=False)
         idx = cols.gather(1, vals.argmax(1, keepdim=True)).squeeze(1)
         del vals, cols
-        diff = xb - x64[idx]
-        core[lo:lo + rows] = (diff * diff).sum(1).sqrt()
+        out[ridx] = _distance_in_sklearns_order(xb, x64[idx])
     del buf
+
+
+def _distance_in_sklearns_order(a, b):
+    """sqrt(sum_c (a_c - b_c)^2) per row with the sum taken coordinate by coordinate, product and sum each rounded (sklearn's
+    EuclideanDistance loop; a tree reduction would differ in the last bit)."""
+    import torch
+    acc = torch.zeros(a.shape[0], dtype=torch.float64, device=a.device)
+    for c in range(a.shape[1]):
+        t = a[:, c] - b[:, c]
+        acc += t * t
+    return acc.sqrt_()
+
+
+KNN_WINDOW_MIN = 32768           # points from which the core distances take the one-pass window kernels (csrc/knn.hip)
+KNN_SAMPLE = 16384               # columns sampled to bracket every row's k-th distance
+KNN_SIGMAS = 4.5                 # half-width of the bracket in standard deviations of the sampled rank
+KNN_SLOT_BYTES = 16 << 30        # candidate slots (8 bytes each) held at a time
+
+
+def _core_distances_window(x64, k, device, out, sample=None, seed=0, stats=None):
+    """Core distances without the distance matrix (csrc/knn.hip).  Needs 64 coordinates that float32 holds exactly.
+      1. bracket: the squared distances of every row to KNN_SAMPLE random columns; the k-th of all n lies, with probability
+         1 - 7e-6 per row, between the sampled ranks r -+ 4.5 sqrt(r), r = sample * k / n  ->  [lo, hi) per row;
+      2. idl_knn_window: one fp32 MFMA pass over all pairs: count of columns below lo, the columns inside [lo, hi) kept;
+      3. idl_knn_select: radix select among the kept ones, then the float64 distances (difference vector, sklearn's order of
+         operations) of everything within twice the Gram form's rounding bound of the selected value: the exact k-th.
+    Rows the bracket missed (status != 0) are returned for the caller's matrix path.  Returns the int64 tensor of those rows."""
+    import ctypes
+    import math
+    import torch
+    from . import _lib
+    L = _lib.lib
+    n, d = x64.shape
+    S = min(int(sample or KNN_SAMPLE), n)
+    frac = k / n
+    r = S * frac
+    sd = math.sqrt(max(r * (1.0 - frac), 1e-9))
+    r_lo, r_hi = int(math.floor(r - KNN_SIGMAS * sd)), int(math.ceil(r + KNN_SIGMAS * sd)) + 1
+    if r_hi > S:
+        return None                                            # k too close to n for a bracket: the matrix path
+    vp = ctypes.c_void_p
+    x32 = x64.to(torch.float32).contiguous()
+    xg = (x64 - x64.mean(0)).to(torch.float32).contiguous()    # Gram coordinates: centred (distances do not move; the norms, and with them the rounding bound, shrink)
+    sqg = (xg.double() ** 2).sum(1).to(torch.float32)
+    # |fp32 Gram form - true squared distance| <= eps: 64 products accumulated (<= 64 u |a||b| each way), the two norms and the
+    # final sums (6 u), the centring's rounding (4 u); u = 2^-23 leaves a factor two for the matrix cores' internal rounding
+    eps = (76.0 * 2.0 ** -23) * (sqg + sqg.max())
+    delta = (2.0 * eps).contiguous()
+    g = torch.Generator(device="cpu"); g.manual_seed(seed)
+    cols = torch.randperm(n, generator=g)[:S].to(device)
+    xs_t, sqs = xg[cols].t().contiguous(), sqg[cols]
+    m_expect = (r_hi - max(r_lo, 0)) / S * n
+    cap = int(-(-int(1.5 * m_expect + 6.0 * math.sqrt(m_expect) + 1024) // 256) * 256)
+    chunk = max(256, min(-(-n // 256) * 256, (KNN_SLOT_BYTES // (8 * cap)) // 256 * 256))
+    cand_d2 = torch.empty(chunk * cap, dtype=torch.float32, device=device)
+    cand_ix = torch.empty(chunk * cap, dtype=torch.int32, device=device)
+    lo_t = torch.empty(chunk, dtype=torch.float32, device=device)
+    hi_t = torch.empty(chunk, dtype=torch.float32, device=device)
+    cnt_lo = torch.empty(chunk, dtype=torch.int32, device=device)
+    cnt_in = torch.empty(chunk, dtype=torch.int32, device=device)
+    status = torch.empty(n, dtype=torch.int32, device=device)
+    stream = vp(torch.cuda.current_stream().cuda_stream)
+    sub = 32768                                                 # rows of one sampled block: 32768 x 16384 fp32 = 2 GB
+    for row0 in range(0, n, chunk):
+        rows = min(chunk, n - row0)
+        for b0 in range(row0, row0 + rows, sub):
+            b1 = min(b0 + sub, row0 + rows)
+            ds = torch.mm(xg[b0:b1], xs_t).mul_(-2.0).add_(sqs[None, :]).add_(sqg[b0:b1, None])
+            vals = torch.topk(ds, r_hi, dim=1, largest=False, sorted=True).values
+            hi_t[b0 - row0:b1 - row0] = vals[:, r_hi - 1]
+            if r_lo >= 1:
+                lo_t[b0 - row0:b1 - row0] = vals[:, r_lo - 1]
+            else:
+                lo_t[b0 - row0:b1 - row0] = -1.0e30             # nothing is below: every column under hi is kept
+            del ds, vals
+        _lib.check(L.idl_knn_window(vp(xg.data_ptr()), vp(sqg.data_ptr()), n, d, vp(lo_t.data_ptr()), vp(hi_t.data_ptr()), row0, rows,
+                                    vp(cnt_lo.data_ptr()), vp(cnt_in.data_ptr()), vp(cand_d2.data_ptr()), vp(cand_ix.data_ptr()), cap, stream))
+        _lib.check(L.idl_knn_select(vp(x32.data_ptr()), n, d, vp(lo_t.data_ptr()), vp(hi_t.data_ptr()), vp(delta[row0:].data_ptr()), row0, rows, k,
+                                    vp(cnt_lo.data_ptr()), vp(cnt_in.data_ptr()), vp(cand_d2.data_ptr()), vp(cand_ix.data_ptr()), cap,
+                                    vp(out.data_ptr()), vp(status[row0:].data_ptr()), stream))
+        if stats is not None:
+            stats.setdefault("kept_max", 0)
+            stats["kept_max"] = max(stats["kept_max"], int(cnt_in[:rows].max()))
+    missed = torch.nonzero(status).squeeze(1)
+    if stats is not None:
+        stats.update(sample=S, ranks=(r_lo, r_hi), cap=cap, chunk=chunk, missed=int(missed.numel()),
+                     status_counts=torch.bincount(status, minlength=5).tolist())
+    return missed
+
+
+def core_distances_device(x64, k, device, f32_exact=None, stats=None):
+    """Distance of every point to its k-th nearest neighbour, itself included (sklearn _hdbscan_prims: NearestNeighbors(
+    n_neighbors=k).kneighbors(X)[:, -1]).  From KNN_WINDOW_MIN points of 64 float32-exact coordinates (the latent of the
+    reference's networks) the one-pass window kernels; else, and for the rows their bracket missed, the float64 Gram-form matrix
+    in row blocks (_core_distances_rows).  $IDELUCS_KNN = matrix | window forces one."""
+    import torch
+    n = x64.shape[0]
+    sq = (x64 * x64).sum(1)
+    core = torch.empty(n, dtype=torch.float64, device=device)
+    mode = os.environ.get("IDELUCS_KNN", "")
+    if f32_exact is None:
+        f32_exact = bool((x64.to(torch.float32).double() == x64).all())
+    todo = None
+    if mode != "matrix" and f32_exact and x64.shape[1] == 64 and (n >= KNN_WINDOW_MIN or mode == "window"):
+        todo = _core_distances_window(x64, k, device, core, stats=stats)
+        if todo is None and mode == "window":
+            raise ValueError("core_distances_device: no bracket for this k / n (IDELUCS_KNN=window)")
+    if todo is None:
+        _core_distances_rows(x64, sq, None, k, device, core)
+    elif todo.numel():
+        _core_distances_rows(x64, sq, todo, k, device, core)
     return core
 
 
-def hdbscan_device(points, min_cluster_size, device=None):
+MST_FILTER_MIN = 20000           # points from which Prim's scan goes through the 8-bit lower-bound filter
+
+
+def _q8_filter(x64):
+    """The 8-bit picture of the points for idl_mst_prim_q8: codes (uint8, one scale for all features, one offset per feature),
+    y = offset + scale * code, and per point an upper bound of ||x - y||.  Any scale / offset is CORRECT (the residual is the
+    point's own, clamped outliers included); the 0.1 % .. 99.9 % range per feature makes it tight.
+    -> (codes int32 [d/4, n] four features per word, qq int32 [n], resid float32 [n], scale) or None for constant data."""
+    import torch
+    n, d = x64.shape
+    srt = x64.sort(0).values
+    qlo, qhi = srt[int(0.001 * (n - 1))], srt[int(0.999 * (n - 1))]
+    del srt
+    span = float((qhi - qlo).max())
+    if not span > 0.0:
+        return None
+    scale = span * 1.02 / 255.0
+    off = qlo - 0.01 * span
+    q = ((x64 - off) / scale).round_().clamp_(0.0, 255.0)
+    resid = (x64 - (off + scale * q)).pow_(2).sum(1).sqrt_()
+    resid = resid * (1.0 + 1e-6) + 1e-9 * (float(x64.abs().max()) + 255.0 * scale)        # covers the float64 rounding of y and of the exact distances
+    r32 = resid.to(torch.float32)
+    r32 = torch.where(r32.double() < resid, torch.nextafter(r32, torch.full_like(r32, float("inf"))), r32)
+    qi = q.to(torch.int64)
+    del q
+    qq = (qi * qi).sum(1).to(torch.int32)
+    q4 = qi.view(n, d // 4, 4)
+    word = q4[..., 0] | (q4[..., 1] << 8) | (q4[..., 2] << 16) | (q4[..., 3] << 24)
+    word = torch.where(word >= (1 << 31), word - (1 << 32), word).to(torch.int32)             # the same 32 bits
+    return word.t().contiguous(), qq.contiguous(), r32.contiguous(), scale
+
+
+def hdbscan_device(points, min_cluster_size, device=None, stats=None):
     """sklearn.cluster.HDBSCAN(min_cluster_size).fit(points) -> (labels_, probabilities_) with the two O(N^2) stages on the GPU:
     core distances (core_distances_device) and Prim's minimum spanning tree of the mutual-reachability graph (csrc/mst.hip,
     idl_mst_prim: sklearn's mst_from_data_matrix visit for visit, in float64); the edges then go through sklearn's own
@@ -261,19 +405,35 @@ def hdbscan_device(points, min_cluster_size, device=None):
     if n < 2 or k > n:
         raise ValueError(f"hdbscan_device: min_samples ({k}) must be at most the number of points ({n})")
     x64 = torch.from_numpy(pts).to(dev)
-    core = core_distances_device(x64, k, dev)
     f32_exact = bool(np.array_equal(pts.astype(np.float32).astype(np.float64), pts))
+    import time
+    t0 = time.time()
+    core = core_distances_device(x64, k, dev, f32_exact=f32_exact, stats=stats)
+    if stats is not None:
+        torch.cuda.synchronize(dev); stats["core_s"] = time.time() - t0; t0 = time.time()
     xt = x64.t().contiguous().to(torch.float32 if f32_exact else torch.float64)       # feature-major, float32 when that is lossless
     cur = torch.empty(n - 1, dtype=torch.int64, device=dev)
     nxt = torch.empty(n - 1, dtype=torch.int64, device=dev)
     w = torch.empty(n - 1, dtype=torch.float64, device=dev)
     ws = torch.empty(int(L.idl_mst_prim_workspace(n)) + 256, dtype=torch.uint8, device=dev)
     off = (-ws.data_ptr()) % 256
-    _lib.check(L.idl_mst_prim(ctypes.c_void_p(xt.data_ptr()), 0 if f32_exact else 1, ctypes.c_void_p(core.data_ptr()), n, d,
-                              ctypes.c_void_p(cur.data_ptr()), ctypes.c_void_p(nxt.data_ptr()), ctypes.c_void_p(w.data_ptr()),
-                              ctypes.c_void_p(ws.data_ptr() + off), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    vp = ctypes.c_void_p
+    filt = None
+    if d % 4 == 0 and n >= MST_FILTER_MIN and os.environ.get("IDELUCS_MST_FILTER", "1") != "0":
+        filt = _q8_filter(x64)
+    if filt is not None:
+        codes, qq, resid, scale = filt
+        _lib.check(L.idl_mst_prim_q8(vp(xt.data_ptr()), 0 if f32_exact else 1, vp(core.data_ptr()), n, d, vp(codes.data_ptr()), vp(qq.data_ptr()),
+                                     vp(resid.data_ptr()), ctypes.c_double(scale), vp(cur.data_ptr()), vp(nxt.data_ptr()), vp(w.data_ptr()),
+                                     vp(ws.data_ptr() + off), vp(torch.cuda.current_stream().cuda_stream)))
+    else:
+        _lib.check(L.idl_mst_prim(vp(xt.data_ptr()), 0 if f32_exact else 1, vp(core.data_ptr()), n, d, vp(cur.data_ptr()), vp(nxt.data_ptr()),
+                                  vp(w.data_ptr()), vp(ws.data_ptr() + off), vp(torch.cuda.current_stream().cuda_stream)))
     mst = np.empty(n - 1, dtype=MST_edge_dtype)
     mst["current_node"], mst["next_node"], mst["distance"] = cur.cpu().numpy(), nxt.cpu().numpy(), w.cpu().numpy()
+    if stats is not None:
+        stats["prim_s"] = time.time() - t0; t0 = time.time()
+        stats["mst_edges"] = mst.copy()
     mst = mst[np.argsort(mst["distance"])]                                            # sklearn hdbscan.py:_process_mst
     try:
         tree = make_single_linkage(mst)
@@ -284,6 +444,8 @@ def hdbscan_device(points, min_cluster_size, device=None):
         warnings.warn(f"idelucs_amd: sklearn's private tree_to_labels has another signature ({err}); running sklearn.cluster.HDBSCAN on the host")
         cl = HDBSCAN(min_cluster_size=k).fit(pts)
         return cl.labels_, cl.probabilities_
+    if stats is not None:
+        stats["tree_s"] = time.time() - t0
     return labels, prob
 
 

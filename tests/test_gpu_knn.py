@@ -1,0 +1,117 @@
+"""Core distances of the fine-grained mode's HDBSCAN (reference __main__.py:83,153-156) by the one-pass window kernels
+(csrc/knn.hip: idl_knn_window + idl_knn_select) against the float64 matrix path and against the definition itself."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _blobs(n, seed, noise=20, spread=(0.3, 0.9), offset=0.0):
+    rng = np.random.default_rng(seed)
+    centres = rng.normal(size=(7, 64)) * 2.5 + offset
+    truth = rng.integers(0, 7, n)
+    x = centres[truth] + rng.normal(size=(n, 64)) * rng.uniform(*spread, size=(7,))[truth][:, None]
+    if noise:
+        x[: n // noise] = rng.uniform(-8, 8, size=(n // noise, 64)) + offset
+    return x.astype(np.float32).astype(np.float64)
+
+
+def _kth_by_definition(x, rows, k):
+    """sqrt of the k-th smallest of sum_c (a_c - b_c)^2, the sum taken coordinate by coordinate in float64 (sklearn's
+    EuclideanDistance: _dist_metrics.pyx.tp rdist loop), the row itself included."""
+    out = np.empty(len(rows))
+    for i, r in enumerate(rows):
+        acc = np.zeros(len(x))
+        for c in range(x.shape[1]):
+            t = x[r, c] - x[:, c]
+            acc += t * t
+        out[i] = np.sqrt(np.partition(acc, k - 1)[k - 1])
+    return out
+
+
+@pytest.mark.parametrize("n,sample,offset", [(40000, None, 0.0), (9000, 1024, 0.0), (20000, 4096, 37.5)])
+def test_window_core_distances_are_the_kth_neighbour_distances(n, sample, offset, monkeypatch):
+    """Every row's value equals the definition bit for bit on a sample of rows, and the whole vector equals the matrix path's
+    (which finds the neighbour by a float64 Gram form and then takes its distance from the difference vector).  The third case
+    sits far from the origin (norms 10^5: without the centring the rounding bound would swallow the bracket); the second has a
+    sample so small that the lower rank of the bracket does not exist (nothing counted below, everything under `hi` kept)."""
+    import torch
+    from idelucs_amd import posthoc
+    x = _blobs(n, seed=n, offset=offset)
+    k = n // 100 + 1
+    dev = torch.device("cuda")
+    xd = torch.from_numpy(x).to(dev)
+    if sample:
+        monkeypatch.setattr(posthoc, "KNN_SAMPLE", sample)
+    stats = {}
+    monkeypatch.setenv("IDELUCS_KNN", "window")
+    got = posthoc.core_distances_device(xd, k, dev, stats=stats).cpu().numpy()
+    monkeypatch.setenv("IDELUCS_KNN", "matrix")
+    ref = posthoc.core_distances_device(xd, k, dev).cpu().numpy()
+    print(stats)
+    assert stats["missed"] <= max(8, n // 2000), "the bracket misses far more rows than its 4.5 sigma promise"
+    rows = np.random.default_rng(1).choice(n, 48, replace=False)
+    assert np.array_equal(got[rows], _kth_by_definition(x, rows, k))
+    assert np.array_equal(got, ref)
+
+
+def test_window_core_distances_with_duplicates_and_tiny_k(monkeypatch):
+    """Half of the points are exact copies of a few others: whole runs of equal distances at the k-th rank (bands that overflow
+    or touch the bracket's edge are handed to the matrix path), and a k of 2 (the HDBSCAN floor)."""
+    import torch
+    from idelucs_amd import posthoc
+    x = _blobs(12000, seed=3, noise=0)
+    x[6000:] = x[np.random.default_rng(0).integers(0, 40, 6000)]
+    dev = torch.device("cuda")
+    xd = torch.from_numpy(x).to(dev)
+    for k in (121, 2):
+        stats = {}
+        monkeypatch.setenv("IDELUCS_KNN", "window")
+        got = posthoc.core_distances_device(xd, k, dev, stats=stats).cpu().numpy()
+        monkeypatch.setenv("IDELUCS_KNN", "matrix")
+        ref = posthoc.core_distances_device(xd, k, dev).cpu().numpy()
+        print(k, stats)
+        assert np.array_equal(got, ref)
+        rows = np.r_[0:8, 6000:6008]
+        assert np.array_equal(got[rows], _kth_by_definition(x, rows, k))
+
+
+def test_hdbscan_labels_do_not_depend_on_the_core_distance_path(monkeypatch):
+    from idelucs_amd import posthoc
+    x = _blobs(36000, seed=8)
+    k = 36000 // 100 + 1
+    monkeypatch.setenv("IDELUCS_KNN", "window")
+    l1, p1 = posthoc.hdbscan_device(x, k)
+    monkeypatch.setenv("IDELUCS_KNN", "matrix")
+    l2, p2 = posthoc.hdbscan_device(x, k)
+    assert np.array_equal(l1, l2) and np.array_equal(p1, p2)
+
+
+def test_prim_with_the_8_bit_filter_builds_the_same_tree(monkeypatch):
+    """idl_mst_prim_q8 skips exact distances that an 8-bit lower bound proves irrelevant: the edges -- nodes, order, float64
+    weights -- are those of the unfiltered scan, also for data with outliers far outside the code range."""
+    from idelucs_amd import posthoc
+    x = _blobs(24000, seed=4)
+    x[:40] *= 30.0                                              # clamped codes, large residuals
+    x = x.astype(np.float32).astype(np.float64)
+    k = 241
+    with_filter, without = {}, {}
+    l1, p1 = posthoc.hdbscan_device(x, k, stats=with_filter)
+    monkeypatch.setenv("IDELUCS_MST_FILTER", "0")
+    l2, p2 = posthoc.hdbscan_device(x, k, stats=without)
+    a, b = with_filter["mst_edges"], without["mst_edges"]
+    for f in ("current_node", "next_node", "distance"):
+        assert np.array_equal(a[f], b[f]), f
+    assert np.array_equal(l1, l2) and np.array_equal(p1, p2)
+
+
+def test_filtered_prim_is_sklearns(monkeypatch):
+    from sklearn.cluster import HDBSCAN
+    from sklearn.metrics import adjusted_rand_score
+    from idelucs_amd import posthoc
+    monkeypatch.setattr(posthoc, "MST_FILTER_MIN", 0)
+    x = _blobs(6000, seed=12)
+    ref = HDBSCAN(min_cluster_size=61).fit(x)
+    labels, prob = posthoc.hdbscan_device(x, 61)
+    assert np.array_equal(labels < 0, ref.labels_ < 0) and adjusted_rand_score(ref.labels_, labels) == 1.0
+    assert np.allclose(prob, ref.probabilities_, atol=1e-9)

@@ -11,6 +11,12 @@
 //                    few thousand inside the window (squared distance + index) in a per-row slot.  A workgroup owns 256 rows (four
 //                    waves x four 16-row A tiles held in registers) and streams every 16-column B tile once: 64 MFMAs per 4 KB
 //                    tile per wave -- matrix-pipe bound; the 256 MB of points are read N / 256 times from L2 / Infinity Cache.
+//                    The Gram form |a|^2 + |b|^2 - 2 a.b loses what the norms exceed the distance by, and a latent of tight,
+//                    far-apart clusters has norms 10^3 x its neighbour distances: every wave therefore works in coordinates
+//                    centred on ITS first row (b - m costs 16 subtractions per lane and tile).  The caller orders the points so
+//                    that neighbours in memory are neighbours in space; then |a - m| is a cluster diameter, the columns that can
+//                    fall under hi have |b - m| <= |a - m| + sqrt(hi), and the rounding bound (`delta`, written per row) is a
+//                    few 1e-5 of the distances that matter -- whatever the far columns' norms are.
 //   idl_knn_select   per row: radix select (4 x 8 bits, LDS histograms) of the (k - below)-th smallest kept value v; then EXACTLY:
 //                    the Gram form in fp32 errs by at most eps = delta / 2, so every column kept below v - delta is truly below
 //                    the k-th and every true candidate lies within v +- delta; the members of that band (a handful) get their
@@ -28,55 +34,91 @@ constexpr int ROWS_WG = 256;      // rows of a workgroup: 4 waves x 64
 constexpr int BAND_CAP = 1024;    // columns of the exact band a row can hold
 
 struct WindowArgs {
-    const float *x, *sq;          // [n, 64] Gram coordinates (centred), their |x|^2
+    const float *x;               // [n, 64] the points, ordered so that neighbours in memory are neighbours in space
     const float *lo, *hi;         // per row of this launch (index row - row0)
     int64_t n, row0, rows;
     int32_t *cnt_lo, *cand_cnt;   // per row of this launch
+    float *delta;                 // per row of this launch: twice the rounding bound of the values this pass computed for it
     float *cand_d2; int32_t *cand_idx;   // [rows, cap]
     int cap;
 };
 
+// |computed - true squared distance| <= GRAM_ERR * (|a - m|^2 + |b - m|^2): the centring's rounding (4 u), the two norms (64 u each
+// way at worst), the 64-term product sum on the matrix cores (64 u), the final sums and the window comparison done against
+// lo - |a|^2 (8 u); u = 2^-23 leaves a factor two for the matrix cores' internal rounding.
+constexpr float GRAM_ERR = 144.0f * 1.1920929e-7f;
+
 __global__ __launch_bounds__(256) void knn_window_kernel(WindowArgs a)
 {
     __shared__ int slot_n[ROWS_WG];
+    __shared__ float centre[4][KD];       // per wave: its first row
+    __shared__ float sq_row[ROWS_WG];     // |a - m|^2 per row
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l = lane & 15, q = lane >> 4;
+    const int64_t last = a.row0 + a.rows - 1;
     const int64_t rbase = a.row0 + (int64_t)blockIdx.x * ROWS_WG + 64 * wv;     // first row of this wave
     slot_n[tid] = 0;
+    centre[wv][lane] = a.x[(rbase <= last ? rbase : last) * KD + lane];
+    __syncthreads();
     // A tiles: row rbase + 16 rt + l, k = 16 q + s  (A[i = l][k = q] per MFMA step s: the k order is permuted the same way on the B side)
     float av[4][16];
-    float sqr[4][4], lo[4][4], hi[4][4];
-    int below[4][4];
+    const float *mv = &centre[wv][16 * q];
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt) {
         const int64_t r = rbase + 16 * rt + l;
-        const bool ok = r < a.row0 + a.rows;
-        const float4 *src = (const float4 *)(a.x + (ok ? r : a.row0) * KD + 16 * q);
+        const float4 *src = (const float4 *)(a.x + (r <= last ? r : last) * KD + 16 * q);
+        float part = 0.f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { const float4 t = src[i]; av[rt][4 * i] = t.x; av[rt][4 * i + 1] = t.y; av[rt][4 * i + 2] = t.z; av[rt][4 * i + 3] = t.w; }
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {                   // C/D: row 4 q + reg of the tile, column l
-            const int64_t rr = rbase + 16 * rt + 4 * q + reg;
-            const bool okr = rr < a.row0 + a.rows;
-            sqr[rt][reg] = okr ? a.sq[rr] : 0.f;
-            lo[rt][reg] = okr ? a.lo[rr - a.row0] : -1.f;      // a row past the end: nothing is below, nothing inside
-            hi[rt][reg] = okr ? a.hi[rr - a.row0] : -1.f;
-            below[rt][reg] = 0;
+        for (int i = 0; i < 4; ++i) {
+            const float4 t = src[i];
+            av[rt][4 * i] = t.x - mv[4 * i]; av[rt][4 * i + 1] = t.y - mv[4 * i + 1]; av[rt][4 * i + 2] = t.z - mv[4 * i + 2]; av[rt][4 * i + 3] = t.w - mv[4 * i + 3];
         }
+#pragma unroll
+        for (int s = 0; s < 16; ++s) part = fmaf(av[rt][s], av[rt][s], part);
+        part += __shfl_xor(part, 16, 64); part += __shfl_xor(part, 32, 64);
+        if (q == 0) sq_row[64 * wv + 16 * rt + l] = part;
     }
     __syncthreads();
+    // per C/D element (row 4 q + reg of tile rt, column l): the window with the row's norm taken off, and the count below it
+    float lo_m[4][4], hi_m[4][4];
+    int below[4][4];
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int rl = 64 * wv + 16 * rt + 4 * q + reg;
+            const int64_t rr = a.row0 + (int64_t)blockIdx.x * ROWS_WG + rl;
+            const bool okr = rr <= last;
+            const float sqa = sq_row[rl];
+            const float lo = okr ? a.lo[rr - a.row0] : -1.f, hi = okr ? a.hi[rr - a.row0] : -1.f;     // a row past the end: nothing below, nothing inside
+            lo_m[rt][reg] = lo - sqa; hi_m[rt][reg] = hi - sqa;
+            below[rt][reg] = 0;
+            if (okr && l == 0) {
+                const float reach = sqrtf(sqa) + sqrtf(fmaxf(hi, 0.f));                              // |b - m| of any column that can come out under hi
+                a.delta[rr - a.row0] = 2.f * GRAM_ERR * (sqa + 1.001f * reach * reach);
+            }
+        }
     // B tile t: columns 16 t + l, k = 16 q + s
     const int64_t ntile = (a.n + 15) / 16;
-    auto load_b = [&](int64_t t, float (&bv)[16], float &sqc) {
+    auto load_b = [&](int64_t t, float4 (&raw)[4]) {
         const int64_t j = 16 * t + l;
-        const bool ok = j < a.n;
-        const float4 *src = (const float4 *)(a.x + (ok ? j : 0) * KD + 16 * q);
+        const float4 *src = (const float4 *)(a.x + (j < a.n ? j : a.n - 1) * KD + 16 * q);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { const float4 v = src[i]; bv[4 * i] = v.x; bv[4 * i + 1] = v.y; bv[4 * i + 2] = v.z; bv[4 * i + 3] = v.w; }
-        sqc = ok ? a.sq[j] : 3.0e38f;                          // a column past the end is infinitely far
+        for (int i = 0; i < 4; ++i) raw[i] = src[i];
     };
-    float b0[16], b1[16], s0, s1;
-    load_b(0, b0, s0);
-    auto tile = [&](int64_t t, const float (&bv)[16], float sqc) {
+    float4 r0[4], r1[4];
+    load_b(0, r0);
+    auto tile = [&](int64_t t, const float4 (&raw)[4]) {
+        float bv[16];
+        float sqc = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            bv[4 * i] = raw[i].x - mv[4 * i]; bv[4 * i + 1] = raw[i].y - mv[4 * i + 1]; bv[4 * i + 2] = raw[i].z - mv[4 * i + 2]; bv[4 * i + 3] = raw[i].w - mv[4 * i + 3];
+        }
+#pragma unroll
+        for (int s = 0; s < 16; ++s) sqc = fmaf(bv[s], bv[s], sqc);
+        sqc += __shfl_xor(sqc, 16, 64); sqc += __shfl_xor(sqc, 32, 64);
+        const int j = (int)(16 * t) + l;
+        if (j >= a.n) sqc = 3.0e38f;                             // a column past the end is infinitely far
         f32x4_t acc[4];
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt) acc[rt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -84,29 +126,28 @@ __global__ __launch_bounds__(256) void knn_window_kernel(WindowArgs a)
         for (int s = 0; s < 16; ++s)
 #pragma unroll
             for (int rt = 0; rt < 4; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][s], bv[s], acc[rt], 0, 0, 0);
-        const int j = (int)(16 * t) + l;
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
-                const float d2 = (sqr[rt][reg] + sqc) - 2.f * acc[rt][reg];
-                below[rt][reg] += d2 < lo[rt][reg] ? 1 : 0;
-                if (d2 >= lo[rt][reg] && d2 < hi[rt][reg]) {
+                const float t2 = sqc - 2.f * acc[rt][reg];                             // squared distance less the row's norm
+                below[rt][reg] += t2 < lo_m[rt][reg] ? 1 : 0;
+                if (t2 >= lo_m[rt][reg] && t2 < hi_m[rt][reg]) {
                     const int rl = 64 * wv + 16 * rt + 4 * q + reg;                    // row inside the workgroup
                     const int pos = atomicAdd(&slot_n[rl], 1);
                     if (pos < a.cap) {
                         const int64_t o = ((int64_t)blockIdx.x * ROWS_WG + rl) * a.cap + pos;
-                        a.cand_d2[o] = d2; a.cand_idx[o] = j;
+                        a.cand_d2[o] = t2 + sq_row[rl]; a.cand_idx[o] = j;
                     }
                 }
             }
     };
     for (int64_t t = 0; t < ntile; t += 2) {                   // two tiles per turn: the next tile's loads are in flight during the MFMAs
-        if (t + 1 < ntile) load_b(t + 1, b1, s1);
-        tile(t, b0, s0);
+        if (t + 1 < ntile) load_b(t + 1, r1);
+        tile(t, r0);
         if (t + 1 < ntile) {
-            if (t + 2 < ntile) load_b(t + 2, b0, s0);
-            tile(t + 1, b1, s1);
+            if (t + 2 < ntile) load_b(t + 2, r0);
+            tile(t + 1, r1);
         }
     }
     // counts: this lane's rows 4 q + reg of tile rt, over its columns l -> add over the 16 lanes of the row
@@ -117,12 +158,12 @@ __global__ __launch_bounds__(256) void knn_window_kernel(WindowArgs a)
             int v = below[rt][reg];
             v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
             const int64_t rr = rbase + 16 * rt + 4 * q + reg;
-            if (l == 0 && rr < a.row0 + a.rows) a.cnt_lo[rr - a.row0] = v;
+            if (l == 0 && rr <= last) a.cnt_lo[rr - a.row0] = v;
         }
     __syncthreads();
     {
         const int64_t rr = a.row0 + (int64_t)blockIdx.x * ROWS_WG + tid;
-        if (rr < a.row0 + a.rows) a.cand_cnt[rr - a.row0] = slot_n[tid];
+        if (rr <= last) a.cand_cnt[rr - a.row0] = slot_n[tid];
     }
 }
 
@@ -231,15 +272,15 @@ __global__ __launch_bounds__(256) void knn_select_kernel(SelectArgs a)
 
 extern "C" {
 
-int idl_knn_window(const float *x, const float *sq, int64_t n, int d, const float *lo, const float *hi, int64_t row0, int64_t rows,
-                   int32_t *cnt_lo, int32_t *cand_cnt, float *cand_d2, int32_t *cand_idx, int cap, void *stream)
+int idl_knn_window(const float *x, int64_t n, int d, const float *lo, const float *hi, int64_t row0, int64_t rows, int32_t *cnt_lo,
+                   int32_t *cand_cnt, float *delta, float *cand_d2, int32_t *cand_idx, int cap, void *stream)
 {
-    IDL_REQUIRE(x && sq && lo && hi && cnt_lo && cand_cnt && cand_d2 && cand_idx, "knn_window: NULL buffer");
+    IDL_REQUIRE(x && lo && hi && cnt_lo && cand_cnt && delta && cand_d2 && cand_idx, "knn_window: NULL buffer");
     IDL_REQUIRE(d == KD, "knn_window: points must have 64 coordinates");
     IDL_REQUIRE(n >= 1 && n < (1ll << 31) && row0 >= 0 && rows >= 1 && row0 + rows <= n && cap >= 1, "knn_window: bad sizes");
     IDL_REQUIRE((((uintptr_t)x) & 15u) == 0, "knn_window: x must be 16-byte aligned");
     IDL_REQUIRE((rows + ROWS_WG - 1) / ROWS_WG * (int64_t)ROWS_WG * cap < (1ll << 40), "knn_window: slot buffer too large");
-    WindowArgs a{x, sq, lo, hi, n, row0, rows, cnt_lo, cand_cnt, cand_d2, cand_idx, cap};
+    WindowArgs a{x, lo, hi, n, row0, rows, cnt_lo, cand_cnt, delta, cand_d2, cand_idx, cap};
     hipLaunchKernelGGL(knn_window_kernel, dim3((unsigned)((rows + ROWS_WG - 1) / ROWS_WG)), dim3(256), 0, (hipStream_t)stream, a);
     IDL_HIP_TRY(hipGetLastError());
     return IDL_OK;

@@ -249,14 +249,30 @@ KNN_SIGMAS = 4.5                 # half-width of the bracket in standard deviati
 KNN_SLOT_BYTES = 16 << 30        # candidate slots (8 bytes each) held at a time
 
 
+def _spatial_order(x64, pivots=256, seed=0):
+    """A permutation that puts neighbours in space next to each other in memory: the points grouped by their nearest of `pivots`
+    random points (idl_knn_window centres every 64 rows on the first of them, and its rounding bound is the spread of those rows)."""
+    import torch
+    n = x64.shape[0]
+    g = torch.Generator(device="cpu"); g.manual_seed(seed + 1)
+    p = x64[torch.randperm(n, generator=g)[:min(pivots, n)].to(x64.device)]
+    group = torch.empty(n, dtype=torch.int64, device=x64.device)
+    for lo in range(0, n, 1 << 18):
+        xb = x64[lo:lo + (1 << 18)]
+        group[lo:lo + (1 << 18)] = ((p * p).sum(1)[None, :] - 2.0 * (xb @ p.t())).argmin(1)
+    return torch.argsort(group, stable=True)
+
+
 def _core_distances_window(x64, k, device, out, sample=None, seed=0, stats=None):
     """Core distances without the distance matrix (csrc/knn.hip).  Needs 64 coordinates that float32 holds exactly.
-      1. bracket: the squared distances of every row to KNN_SAMPLE random columns; the k-th of all n lies, with probability
-         1 - 7e-6 per row, between the sampled ranks r -+ 4.5 sqrt(r), r = sample * k / n  ->  [lo, hi) per row;
+      0. order the points by their nearest of 256 random pivots (_spatial_order);
+      1. bracket: the squared distances (float64) of every row to KNN_SAMPLE random columns; the k-th of all n lies, with
+         probability 1 - 7e-6 per row, between the sampled ranks r -+ 4.5 sqrt(r), r = sample * k / n  ->  [lo, hi) per row;
       2. idl_knn_window: one fp32 MFMA pass over all pairs: count of columns below lo, the columns inside [lo, hi) kept;
       3. idl_knn_select: radix select among the kept ones, then the float64 distances (difference vector, sklearn's order of
-         operations) of everything within twice the Gram form's rounding bound of the selected value: the exact k-th.
-    Rows the bracket missed (status != 0) are returned for the caller's matrix path.  Returns the int64 tensor of those rows."""
+         operations) of everything within twice the pass's rounding bound of the selected value: the exact k-th.
+    Rows the bracket missed (status != 0) are returned for the caller's matrix path: the int64 tensor of those rows, or None
+    when k / n allows no bracket."""
     import ctypes
     import math
     import torch
@@ -271,33 +287,32 @@ def _core_distances_window(x64, k, device, out, sample=None, seed=0, stats=None)
     if r_hi > S:
         return None                                            # k too close to n for a bracket: the matrix path
     vp = ctypes.c_void_p
-    x32 = x64.to(torch.float32).contiguous()
-    xg = (x64 - x64.mean(0)).to(torch.float32).contiguous()    # Gram coordinates: centred (distances do not move; the norms, and with them the rounding bound, shrink)
-    sqg = (xg.double() ** 2).sum(1).to(torch.float32)
-    # |fp32 Gram form - true squared distance| <= eps: 64 products accumulated (<= 64 u |a||b| each way), the two norms and the
-    # final sums (6 u), the centring's rounding (4 u); u = 2^-23 leaves a factor two for the matrix cores' internal rounding
-    eps = (76.0 * 2.0 ** -23) * (sqg + sqg.max())
-    delta = (2.0 * eps).contiguous()
+    perm = _spatial_order(x64, seed=seed)
+    xo = x64[perm]                                              # the points in memory order
+    x32 = xo.to(torch.float32).contiguous()
+    sq = (xo * xo).sum(1)
     g = torch.Generator(device="cpu"); g.manual_seed(seed)
     cols = torch.randperm(n, generator=g)[:S].to(device)
-    xs_t, sqs = xg[cols].t().contiguous(), sqg[cols]
+    xs_t, sqs = xo[cols].t().contiguous(), sq[cols]
     m_expect = (r_hi - max(r_lo, 0)) / S * n
-    cap = int(-(-int(1.5 * m_expect + 6.0 * math.sqrt(m_expect) + 1024) // 256) * 256)
+    cap = int(-(-int(2.0 * m_expect + 6.0 * math.sqrt(m_expect) + 1024) // 256) * 256)
     chunk = max(256, min(-(-n // 256) * 256, (KNN_SLOT_BYTES // (8 * cap)) // 256 * 256))
     cand_d2 = torch.empty(chunk * cap, dtype=torch.float32, device=device)
     cand_ix = torch.empty(chunk * cap, dtype=torch.int32, device=device)
     lo_t = torch.empty(chunk, dtype=torch.float32, device=device)
     hi_t = torch.empty(chunk, dtype=torch.float32, device=device)
+    delta = torch.empty(chunk, dtype=torch.float32, device=device)
     cnt_lo = torch.empty(chunk, dtype=torch.int32, device=device)
     cnt_in = torch.empty(chunk, dtype=torch.int32, device=device)
     status = torch.empty(n, dtype=torch.int32, device=device)
+    core_o = torch.zeros(n, dtype=torch.float64, device=device)
     stream = vp(torch.cuda.current_stream().cuda_stream)
-    sub = 32768                                                 # rows of one sampled block: 32768 x 16384 fp32 = 2 GB
+    sub = 16384                                                 # rows of one sampled block: 16384 x 16384 float64 = 2 GB
     for row0 in range(0, n, chunk):
         rows = min(chunk, n - row0)
         for b0 in range(row0, row0 + rows, sub):
             b1 = min(b0 + sub, row0 + rows)
-            ds = torch.mm(xg[b0:b1], xs_t).mul_(-2.0).add_(sqs[None, :]).add_(sqg[b0:b1, None])
+            ds = torch.mm(xo[b0:b1], xs_t).mul_(-2.0).add_(sqs[None, :]).add_(sq[b0:b1, None])
             vals = torch.topk(ds, r_hi, dim=1, largest=False, sorted=True).values
             hi_t[b0 - row0:b1 - row0] = vals[:, r_hi - 1]
             if r_lo >= 1:
@@ -305,15 +320,15 @@ def _core_distances_window(x64, k, device, out, sample=None, seed=0, stats=None)
             else:
                 lo_t[b0 - row0:b1 - row0] = -1.0e30             # nothing is below: every column under hi is kept
             del ds, vals
-        _lib.check(L.idl_knn_window(vp(xg.data_ptr()), vp(sqg.data_ptr()), n, d, vp(lo_t.data_ptr()), vp(hi_t.data_ptr()), row0, rows,
-                                    vp(cnt_lo.data_ptr()), vp(cnt_in.data_ptr()), vp(cand_d2.data_ptr()), vp(cand_ix.data_ptr()), cap, stream))
-        _lib.check(L.idl_knn_select(vp(x32.data_ptr()), n, d, vp(lo_t.data_ptr()), vp(hi_t.data_ptr()), vp(delta[row0:].data_ptr()), row0, rows, k,
+        _lib.check(L.idl_knn_window(vp(x32.data_ptr()), n, d, vp(lo_t.data_ptr()), vp(hi_t.data_ptr()), row0, rows, vp(cnt_lo.data_ptr()),
+                                    vp(cnt_in.data_ptr()), vp(delta.data_ptr()), vp(cand_d2.data_ptr()), vp(cand_ix.data_ptr()), cap, stream))
+        _lib.check(L.idl_knn_select(vp(x32.data_ptr()), n, d, vp(lo_t.data_ptr()), vp(hi_t.data_ptr()), vp(delta.data_ptr()), row0, rows, k,
                                     vp(cnt_lo.data_ptr()), vp(cnt_in.data_ptr()), vp(cand_d2.data_ptr()), vp(cand_ix.data_ptr()), cap,
-                                    vp(out.data_ptr()), vp(status[row0:].data_ptr()), stream))
+                                    vp(core_o.data_ptr()), vp(status[row0:].data_ptr()), stream))
         if stats is not None:
-            stats.setdefault("kept_max", 0)
-            stats["kept_max"] = max(stats["kept_max"], int(cnt_in[:rows].max()))
-    missed = torch.nonzero(status).squeeze(1)
+            stats["kept_max"] = max(stats.get("kept_max", 0), int(cnt_in[:rows].max()))
+    out[perm] = core_o
+    missed = perm[torch.nonzero(status).squeeze(1)]
     if stats is not None:
         stats.update(sample=S, ranks=(r_lo, r_hi), cap=cap, chunk=chunk, missed=int(missed.numel()),
                      status_counts=torch.bincount(status, minlength=5).tolist())
@@ -475,7 +490,11 @@ def fine_grained_clusters(latent, exact_max=None, seed=0, device=None, mode=None
     if mode not in ("device", "approx"):
         raise ValueError("fine_grained_clusters: mode must be 'device' or 'approx'")
     if mode == "device":
-        labels, prob = hdbscan_device(latent, n // 100 + 1, device=device)
+        stats = {} if os.environ.get("IDELUCS_TIMING") else None
+        labels, prob = hdbscan_device(latent, n // 100 + 1, device=device, stats=stats)
+        if stats is not None:
+            stats.pop("mst_edges", None)
+            print("HDBSCAN on the device:", {k: (round(v, 2) if isinstance(v, float) else v) for k, v in stats.items()})
         return labels + 1, prob
     import torch
     dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())

@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--families", type=int, default=8)
     ap.add_argument("--n-clusters", dest="n_clusters", type=int, default=0, help="0 = fine-grained mode (cfg5); e.g. 20 with --voters 5 = a cfg2/cfg3-like run")
     ap.add_argument("--voters", type=int, default=1)
+    ap.add_argument("--save-latent", default=None, help="write the latent that goes into the fine-grained clustering here (.npy, float32)")
     a = ap.parse_args()
     base = "/dev/shm" if os.access("/dev/shm", os.W_OK) else tempfile.gettempdir()
     work = tempfile.mkdtemp(prefix="idelucs_cfg5_", dir=base)
@@ -48,6 +49,14 @@ def main():
     write_family_fasta(fas, gt, a.n, a.len, a.families, seed=11)
     print(f"wrote {os.path.getsize(fas) / 1e9:.2f} GB FASTA in {time.time() - t0:.0f} s", flush=True)
     from idelucs_amd.__main__ import main as cli
+    if a.save_latent:
+        from idelucs_amd import posthoc
+        inner = posthoc.fine_grained_clusters
+
+        def saving(latent, *args, **kw):
+            np.save(a.save_latent, np.asarray(latent, dtype=np.float32))
+            return inner(latent, *args, **kw)
+        posthoc.fine_grained_clusters = saving
     import pandas as pd
     cwd = os.getcwd()
     os.chdir(work)

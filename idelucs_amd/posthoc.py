@@ -205,8 +205,8 @@ def _hdbscan(points, min_cluster_size, device=None):
 
 def _core_distances_rows(x64, sq, rows_idx, k, device, out):
     """out[rows_idx] = distance of those rows to their k-th nearest neighbour, itself included: row blocks of the float64 Gram-form
-    distance matrix (one GEMM each), the k-th smallest per row by radix select (torch.topk), and the selected neighbour's
-    distance then formed exactly from the difference vector (the Gram form is only trusted to FIND the neighbour).
+    distance matrix (one GEMM each), the k + 32 smallest per row by radix select (torch.topk), and the k-th read off the exact
+    distances (difference vector, sklearn's order of operations) of the 65 around rank k: the Gram form only FINDS them.
     rows_idx: None = every row, else an int64 tensor of row numbers."""
     import torch
     n = x64.shape[0]
@@ -224,11 +224,15 @@ def _core_distances_rows(x64, sq, rows_idx, k, device, out):
         d2.mul_(-2.0).add_(sq[None, :]).add_(sq[ridx, None])
         d2[torch.arange(xb.shape[0], device=device), ridx] = 0.0     # a point is its own first neighbour
         # the k-th smallest per row: unsorted top-k (multi-block radix select, 2.5 x faster than torch.kthvalue on float64 rows of
-        # 10^6) and the largest of those
-        vals, cols = torch.topk(d2, k, dim=1, largest=False, sorted=False)
-        idx = cols.gather(1, vals.argmax(1, keepdim=True)).squeeze(1)
-        del vals, cols
-        out[ridx] = _distance_in_sklearns_order(xb, x64[idx])
+        # 10^6); the Gram form's own rounding (1e-16 of the norms, which tight far-apart clusters make 1e-11 of the distance) can
+        # swap near-ties, so the k-th is then read off the EXACT distances of the ranks k - pad .. k + pad
+        pad = min(32, k - 1, n - k)
+        vals, cols = torch.topk(d2, k + pad, dim=1, largest=False, sorted=False)
+        near = cols.gather(1, torch.topk(vals, 2 * pad + 1, dim=1, largest=True, sorted=False).indices)     # the columns of those ranks
+        ex = _distance_in_sklearns_order(xb[:, None, :].expand(-1, near.shape[1], -1).reshape(-1, xb.shape[1]),
+                                         x64[near.reshape(-1)]).view(xb.shape[0], -1)
+        out[ridx] = ex.kthvalue(pad + 1, dim=1).values
+        del vals, cols, near, ex
     del buf
 
 
@@ -250,8 +254,10 @@ KNN_SLOT_BYTES = 16 << 30        # candidate slots (8 bytes each) held at a time
 
 
 def _spatial_order(x64, pivots=256, seed=0):
-    """A permutation that puts neighbours in space next to each other in memory: the points grouped by their nearest of `pivots`
-    random points (idl_knn_window centres every 64 rows on the first of them, and its rounding bound is the spread of those rows)."""
+    """(perm, gid): a permutation that puts neighbours in space next to each other in memory -- the points grouped by their
+    nearest of `pivots` random points -- and the group (0.., non-decreasing) of every position of that order.  idl_knn_window
+    centres every 64 rows on the first of them and idl_mst_prim_local codes every point inside its group's box: the rounding
+    bound of the one and the step of the other are the spread of a group."""
     import torch
     n = x64.shape[0]
     g = torch.Generator(device="cpu"); g.manual_seed(seed + 1)
@@ -260,10 +266,12 @@ def _spatial_order(x64, pivots=256, seed=0):
     for lo in range(0, n, 1 << 18):
         xb = x64[lo:lo + (1 << 18)]
         group[lo:lo + (1 << 18)] = ((p * p).sum(1)[None, :] - 2.0 * (xb @ p.t())).argmin(1)
-    return torch.argsort(group, stable=True)
+    perm = torch.argsort(group, stable=True)
+    gid = torch.unique_consecutive(group[perm], return_inverse=True)[1]
+    return perm, gid
 
 
-def _core_distances_window(x64, k, device, out, sample=None, seed=0, stats=None):
+def _core_distances_window(x64, k, device, out, sample=None, seed=0, stats=None, order=None):
     """Core distances without the distance matrix (csrc/knn.hip).  Needs 64 coordinates that float32 holds exactly.
       0. order the points by their nearest of 256 random pivots (_spatial_order);
       1. bracket: the squared distances (float64) of every row to KNN_SAMPLE random columns; the k-th of all n lies, with
@@ -287,7 +295,7 @@ def _core_distances_window(x64, k, device, out, sample=None, seed=0, stats=None)
     if r_hi > S:
         return None                                            # k too close to n for a bracket: the matrix path
     vp = ctypes.c_void_p
-    perm = _spatial_order(x64, seed=seed)
+    perm = (order if order is not None else _spatial_order(x64, seed=seed))[0]
     xo = x64[perm]                                              # the points in memory order
     x32 = xo.to(torch.float32).contiguous()
     sq = (xo * xo).sum(1)
@@ -335,7 +343,7 @@ def _core_distances_window(x64, k, device, out, sample=None, seed=0, stats=None)
     return missed
 
 
-def core_distances_device(x64, k, device, f32_exact=None, stats=None):
+def core_distances_device(x64, k, device, f32_exact=None, stats=None, order=None):
     """Distance of every point to its k-th nearest neighbour, itself included (sklearn _hdbscan_prims: NearestNeighbors(
     n_neighbors=k).kneighbors(X)[:, -1]).  From KNN_WINDOW_MIN points of 64 float32-exact coordinates (the latent of the
     reference's networks) the one-pass window kernels; else, and for the rows their bracket missed, the float64 Gram-form matrix
@@ -349,7 +357,7 @@ def core_distances_device(x64, k, device, f32_exact=None, stats=None):
         f32_exact = bool((x64.to(torch.float32).double() == x64).all())
     todo = None
     if mode != "matrix" and f32_exact and x64.shape[1] == 64 and (n >= KNN_WINDOW_MIN or mode == "window"):
-        todo = _core_distances_window(x64, k, device, core, stats=stats)
+        todo = _core_distances_window(x64, k, device, core, stats=stats, order=order)
         if todo is None and mode == "window":
             raise ValueError("core_distances_device: no bracket for this k / n (IDELUCS_KNN=window)")
     if todo is None:
@@ -362,33 +370,32 @@ def core_distances_device(x64, k, device, f32_exact=None, stats=None):
 MST_FILTER_MIN = 20000           # points from which Prim's scan goes through the 8-bit lower-bound filter
 
 
-def _q8_filter(x64):
-    """The 8-bit picture of the points for idl_mst_prim_q8: codes (uint8, one scale for all features, one offset per feature),
-    y = offset + scale * code, and per point an upper bound of ||x - y||.  Any scale / offset is CORRECT (the residual is the
-    point's own, clamped outliers included); the 0.1 % .. 99.9 % range per feature makes it tight.
-    -> (codes int32 [d/4, n] four features per word, qq int32 [n], resid float32 [n], scale) or None for constant data."""
+def _local_q8(xo, gid):
+    """The 8-bit picture of the points for idl_mst_prim_local.  xo: the points in memory order, gid: their groups.  Per group its
+    box corner lo_g (float32) and code step scale_g = widest side / 255; per point codes = round((x - lo_g) / scale_g) and an upper
+    bound of ||x - y||, y = lo_g + scale_g * code.  Any corner / step is CORRECT (the residual is the point's own).
+    -> (codes int32 [d/4, n] four features per word, resid float32 [n], glo float32 [G, d], gscale float64 [G])"""
     import torch
-    n, d = x64.shape
-    srt = x64.sort(0).values
-    qlo, qhi = srt[int(0.001 * (n - 1))], srt[int(0.999 * (n - 1))]
-    del srt
-    span = float((qhi - qlo).max())
-    if not span > 0.0:
-        return None
-    scale = span * 1.02 / 255.0
-    off = qlo - 0.01 * span
-    q = ((x64 - off) / scale).round_().clamp_(0.0, 255.0)
-    resid = (x64 - (off + scale * q)).pow_(2).sum(1).sqrt_()
-    resid = resid * (1.0 + 1e-6) + 1e-9 * (float(x64.abs().max()) + 255.0 * scale)        # covers the float64 rounding of y and of the exact distances
+    n, d = xo.shape
+    G = int(gid[-1]) + 1
+    idx = gid[:, None].expand(-1, d)
+    lo = torch.full((G, d), float("inf"), dtype=torch.float64, device=xo.device).scatter_reduce_(0, idx, xo, "amin")
+    hi = torch.full((G, d), float("-inf"), dtype=torch.float64, device=xo.device).scatter_reduce_(0, idx, xo, "amax")
+    glo = lo.to(torch.float32)
+    glo = torch.where(glo.double() > lo, torch.nextafter(glo, torch.full_like(glo, float("-inf"))), glo)    # a corner at or below every point
+    lo = glo.double()
+    span = (hi - lo).max(1).values
+    gscale = torch.where(span > 0, span / 255.0, torch.ones_like(span))
+    q = ((xo - lo[gid]) / gscale[gid, None]).round_().clamp_(0.0, 255.0)
+    resid = (xo - (lo[gid] + gscale[gid, None] * q)).pow_(2).sum(1).sqrt_()
+    resid = resid * (1.0 + 1e-6) + 1e-9 * (float(xo.abs().max()) + 255.0 * float(gscale.max()))     # covers the float64 rounding of y and of the exact distances
     r32 = resid.to(torch.float32)
     r32 = torch.where(r32.double() < resid, torch.nextafter(r32, torch.full_like(r32, float("inf"))), r32)
-    qi = q.to(torch.int64)
+    q4 = q.to(torch.int64).view(n, d // 4, 4)
     del q
-    qq = (qi * qi).sum(1).to(torch.int32)
-    q4 = qi.view(n, d // 4, 4)
     word = q4[..., 0] | (q4[..., 1] << 8) | (q4[..., 2] << 16) | (q4[..., 3] << 24)
     word = torch.where(word >= (1 << 31), word - (1 << 32), word).to(torch.int32)             # the same 32 bits
-    return word.t().contiguous(), qq.contiguous(), r32.contiguous(), scale
+    return word.t().contiguous(), r32.contiguous(), glo.contiguous(), gscale.contiguous()
 
 
 def hdbscan_device(points, min_cluster_size, device=None, stats=None):
@@ -423,27 +430,34 @@ def hdbscan_device(points, min_cluster_size, device=None, stats=None):
     f32_exact = bool(np.array_equal(pts.astype(np.float32).astype(np.float64), pts))
     import time
     t0 = time.time()
-    core = core_distances_device(x64, k, dev, f32_exact=f32_exact, stats=stats)
+    use_filter = d % 4 == 0 and d <= 64 and n >= MST_FILTER_MIN and os.environ.get("IDELUCS_MST_FILTER", "1") != "0"
+    order = _spatial_order(x64) if use_filter else None
+    core = core_distances_device(x64, k, dev, f32_exact=f32_exact, stats=stats, order=order)
     if stats is not None:
         torch.cuda.synchronize(dev); stats["core_s"] = time.time() - t0; t0 = time.time()
-    xt = x64.t().contiguous().to(torch.float32 if f32_exact else torch.float64)       # feature-major, float32 when that is lossless
+    vp = ctypes.c_void_p
     cur = torch.empty(n - 1, dtype=torch.int64, device=dev)
     nxt = torch.empty(n - 1, dtype=torch.int64, device=dev)
     w = torch.empty(n - 1, dtype=torch.float64, device=dev)
     ws = torch.empty(int(L.idl_mst_prim_workspace(n)) + 256, dtype=torch.uint8, device=dev)
     off = (-ws.data_ptr()) % 256
-    vp = ctypes.c_void_p
-    filt = None
-    if d % 4 == 0 and n >= MST_FILTER_MIN and os.environ.get("IDELUCS_MST_FILTER", "1") != "0":
-        filt = _q8_filter(x64)
-    if filt is not None:
-        codes, qq, resid, scale = filt
-        _lib.check(L.idl_mst_prim_q8(vp(xt.data_ptr()), 0 if f32_exact else 1, vp(core.data_ptr()), n, d, vp(codes.data_ptr()), vp(qq.data_ptr()),
-                                     vp(resid.data_ptr()), ctypes.c_double(scale), vp(cur.data_ptr()), vp(nxt.data_ptr()), vp(w.data_ptr()),
-                                     vp(ws.data_ptr() + off), vp(torch.cuda.current_stream().cuda_stream)))
+    stream = vp(torch.cuda.current_stream().cuda_stream)
+    if use_filter:
+        perm, gid = order
+        xo = x64[perm]
+        xt = xo.t().contiguous().to(torch.float32 if f32_exact else torch.float64)       # feature-major, float32 when that is lossless
+        core_o = core[perm].contiguous()
+        codes, resid, glo, gscale = _local_q8(xo, gid)
+        orig, gid32 = perm.to(torch.int32), gid.to(torch.int32)
+        start = int(torch.nonzero(perm == 0)[0, 0])
+        del xo
+        _lib.check(L.idl_mst_prim_local(vp(xt.data_ptr()), 0 if f32_exact else 1, vp(core_o.data_ptr()), n, d, vp(orig.data_ptr()), start,
+                                        vp(codes.data_ptr()), vp(resid.data_ptr()), vp(gid32.data_ptr()), vp(glo.data_ptr()),
+                                        vp(gscale.data_ptr()), vp(cur.data_ptr()), vp(nxt.data_ptr()), vp(w.data_ptr()), vp(ws.data_ptr() + off), stream))
     else:
+        xt = x64.t().contiguous().to(torch.float32 if f32_exact else torch.float64)
         _lib.check(L.idl_mst_prim(vp(xt.data_ptr()), 0 if f32_exact else 1, vp(core.data_ptr()), n, d, vp(cur.data_ptr()), vp(nxt.data_ptr()),
-                                  vp(w.data_ptr()), vp(ws.data_ptr() + off), vp(torch.cuda.current_stream().cuda_stream)))
+                                  vp(w.data_ptr()), vp(ws.data_ptr() + off), stream))
     mst = np.empty(n - 1, dtype=MST_edge_dtype)
     mst["current_node"], mst["next_node"], mst["distance"] = cur.cpu().numpy(), nxt.cpu().numpy(), w.cpu().numpy()
     if stats is not None:

@@ -18,6 +18,9 @@
 //   idelucs/utils.py:54-135  transforms   -> substitution edits (XOR on 2-bit codes / set-N)
 #include <stdlib.h>
 
+#include <map>
+#include <mutex>
+#include <utility>
 #include <vector>
 
 #include "common.h"
@@ -1162,14 +1165,19 @@ __global__ __launch_bounds__(64) void collapse_kernel(int32_t *counts, int32_t *
     }
 }
 
-// the device word through which v3 tells the second pass how many sequences it left alone (one per device, allocated on first use)
-int *redo_counter()
+// the device words through which v3 hands over to the second pass (redo count, queue head, redo list): one block per (device,
+// stream), allocated on first use and kept -- launches on different streams of a device may be in flight together (a build on one
+// stream, predict_features on another), launches on one stream are ordered
+int *redo_counter(hipStream_t st)
 {
-    static int *ptr[64] = {nullptr};
+    static std::mutex mu;
+    static std::map<std::pair<int, hipStream_t>, int *> blocks;
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-    if (ptr[dev] == nullptr) { if (hipMalloc((void **)&ptr[dev], 8 + 8 * (size_t)V3_REDO_CAP) != hipSuccess) ptr[dev] = nullptr; }
-    return ptr[dev];
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    int *&p = blocks[std::make_pair(dev, st)];
+    if (p == nullptr && hipMalloc((void **)&p, 8 + 8 * (size_t)V3_REDO_CAP) != hipSuccess) p = nullptr;
+    return p;
 }
 
 template <int K>
@@ -1180,7 +1188,7 @@ int launch_vectorise3_k(VecArgs &a, const idl::DeviceInfo &di, hipStream_t st, s
     if (lds > 64 * 1024) IDL_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int64_t grid = (int64_t)di.cus * per_cu;
     if (grid > a.n) grid = a.n;
-    a.redo_count = redo_counter();
+    a.redo_count = redo_counter(st);
     if (a.redo_count == nullptr) { idl::set_error("cannot allocate the v3 hand-over word"); return IDL_ERR_HIP; }
     IDL_HIP_TRY(hipMemsetAsync(a.redo_count, 0, 2 * sizeof(int), st));      // [0] sequences left to the second pass, [1] head of the sequence queue
     if (dbg) { IDL_HIP_TRY(hipMalloc((void **)&a.dbg, (size_t)grid * 20 * 8)); IDL_HIP_TRY(hipMemset(a.dbg, 0, (size_t)grid * 20 * 8)); }

@@ -578,3 +578,26 @@ def test_variant_n_synthetic_input_vs_oracle(gpu, monkeypatch):
         outs[ver] = U._vectorise(din, k, _lib.MODE_KMER, _lib.INIT_ONE, _lib.OUT_FREQ_F32, P, edits, edit_off)
     assert torch.equal(outs["1"], outs["2"]) and torch.equal(outs["1"], outs["3"])
     assert torch.allclose(outs["3"].double().sum(2), torch.ones((P, n), dtype=torch.float64, device=dev), atol=1e-6)
+
+
+def test_two_vectorise_calls_in_flight_on_two_streams(gpu):
+    """The hand-over words between the pipelined kernel and its second pass (queue head, redo count, redo list) belong to the
+    (device, stream) of the launch: two calls in flight on two streams of one device -- a build on one, predict_features on
+    another -- leave the rows each of them leaves alone."""
+    import torch
+    from idelucs_amd import _lib, utils as U
+    rng = np.random.default_rng(31)
+    dev = torch.device("cuda")
+    batches = [_random_batch(rng, 1500, 2000, 6000, 0.001) + _random_batch(rng, 2, 60000, 70000, 0.0) for _ in range(2)]   # (the long ones go to the second pass)
+    dins = [U._DeviceInput(_pack_batch(b), dev) for b in batches]
+    want = [U._vectorise(d, 6, _lib.MODE_KMER, _lib.INIT_ONE, _lib.OUT_FREQ_F32).clone() for d in dins]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+    for rep in range(4):
+        got = [None, None]
+        for i in (0, 1):
+            with torch.cuda.stream(streams[i]):
+                got[i] = U._vectorise(dins[i], 6, _lib.MODE_KMER, _lib.INIT_ONE, _lib.OUT_FREQ_F32)
+        torch.cuda.synchronize()
+        for i in (0, 1):
+            assert torch.equal(got[i], want[i]), (rep, i)

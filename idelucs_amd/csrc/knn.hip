@@ -268,6 +268,117 @@ __global__ __launch_bounds__(256) void knn_select_kernel(SelectArgs a)
     }
 }
 
+// ---------------------------------------------------------------- silhouette: per-cluster distance sums (posthoc.compute_results)
+// sklearn.metrics.silhouette_score needs, for every point, the sum of its distances to the points of every cluster: N^2 distances,
+// each used once.  Round 2 formed them in [4096 x N] float32 blocks with a GEMM and five elementwise passes (40 TB of traffic at
+// 10^6 points, 10 s); this is idl_knn_window's pass with another epilogue.  The caller orders the points by cluster and pads every
+// cluster to whole 16-column tiles (weight 0 on the padding): a tile then belongs to ONE cluster, the distances add up in 16
+// registers per lane, and those are written out -- once, by their only owner -- when the tile's cluster changes.
+struct SilArgs {
+    const float *x;               // [n, 64] the points, cluster by cluster, padded
+    const float *w;               // [n] 1 for a point, 0 for padding
+    const int32_t *tile_cluster;  // [n / 16] cluster of each 16-column tile
+    int64_t n; int n_clusters;
+    float *sums;                  // [n, n_clusters] sum over the cluster's points of the distance to them
+};
+
+__global__ __launch_bounds__(256) void silhouette_sums_kernel(SilArgs a)
+{
+    __shared__ float centre[4][KD];
+    __shared__ float sq_row[ROWS_WG];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l = lane & 15, q = lane >> 4;
+    const int64_t last = a.n - 1;
+    const int64_t rbase = (int64_t)blockIdx.x * ROWS_WG + 64 * wv;
+    centre[wv][lane] = a.x[(rbase <= last ? rbase : last) * KD + lane];
+    __syncthreads();
+    float av[4][16];
+    const float *mv = &centre[wv][16 * q];
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+        const int64_t r = rbase + 16 * rt + l;
+        const float4 *src = (const float4 *)(a.x + (r <= last ? r : last) * KD + 16 * q);
+        float part = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float4 t = src[i];
+            av[rt][4 * i] = t.x - mv[4 * i]; av[rt][4 * i + 1] = t.y - mv[4 * i + 1]; av[rt][4 * i + 2] = t.z - mv[4 * i + 2]; av[rt][4 * i + 3] = t.w - mv[4 * i + 3];
+        }
+#pragma unroll
+        for (int s = 0; s < 16; ++s) part = fmaf(av[rt][s], av[rt][s], part);
+        part += __shfl_xor(part, 16, 64); part += __shfl_xor(part, 32, 64);
+        if (q == 0) sq_row[64 * wv + 16 * rt + l] = part;
+    }
+    __syncthreads();
+    float sqa[4][4], tot[4][4];
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) { sqa[rt][reg] = sq_row[64 * wv + 16 * rt + 4 * q + reg]; tot[rt][reg] = 0.f; }
+    const int64_t ntile = a.n / 16;
+    auto load_b = [&](int64_t t, float4 (&raw)[4], float &wj) {
+        const int64_t j = 16 * t + l;
+        const float4 *src = (const float4 *)(a.x + j * KD + 16 * q);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) raw[i] = src[i];
+        wj = a.w[j];
+    };
+    auto flush = [&](int c) {                                  // the sums of cluster c are complete: add up the 16 column lanes, write, clear
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                float v = tot[rt][reg];
+                v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+                const int64_t rr = rbase + 16 * rt + 4 * q + reg;
+                if (l == 0 && rr <= last) a.sums[rr * a.n_clusters + c] = v;
+                tot[rt][reg] = 0.f;
+            }
+    };
+    int cur_c = a.tile_cluster[0];
+    auto tile = [&](int64_t t, const float4 (&raw)[4], float wj) {
+        const int c = a.tile_cluster[t];
+        if (c != cur_c) { flush(cur_c); cur_c = c; }
+        float bv[16];
+        float sqc = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            bv[4 * i] = raw[i].x - mv[4 * i]; bv[4 * i + 1] = raw[i].y - mv[4 * i + 1]; bv[4 * i + 2] = raw[i].z - mv[4 * i + 2]; bv[4 * i + 3] = raw[i].w - mv[4 * i + 3];
+        }
+#pragma unroll
+        for (int s = 0; s < 16; ++s) sqc = fmaf(bv[s], bv[s], sqc);
+        sqc += __shfl_xor(sqc, 16, 64); sqc += __shfl_xor(sqc, 32, 64);
+        f32x4_t acc[4];
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) acc[rt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 16; ++s)
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][s], bv[s], acc[rt], 0, 0, 0);
+        const bool own = 16 * t + 15 >= rbase && 16 * t < rbase + 64;      // the tile holds some of this wave's own points: d(i, i) = 0 exactly
+        const int64_t j = 16 * t + l;
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                float d = __builtin_amdgcn_sqrtf(fmaxf((sqa[rt][reg] + sqc) - 2.f * acc[rt][reg], 0.f)) * wj;
+                if (own && j == rbase + 16 * rt + 4 * q + reg) d = 0.f;
+                tot[rt][reg] += d;
+            }
+    };
+    float4 r0[4], r1[4];
+    float w0, w1;
+    load_b(0, r0, w0);
+    for (int64_t t = 0; t < ntile; t += 2) {
+        if (t + 1 < ntile) load_b(t + 1, r1, w1);
+        tile(t, r0, w0);
+        if (t + 1 < ntile) {
+            if (t + 2 < ntile) load_b(t + 2, r0, w0);
+            tile(t + 1, r1, w1);
+        }
+    }
+    flush(cur_c);
+}
+
 }  // namespace
 
 extern "C" {
@@ -295,6 +406,18 @@ int idl_knn_select(const float *x, int64_t n, int d, const float *lo, const floa
     IDL_REQUIRE(n >= 1 && row0 >= 0 && rows >= 1 && row0 + rows <= n && cap >= 1 && k >= 1 && k <= n, "knn_select: bad sizes");
     SelectArgs a{x, lo, hi, delta, n, row0, rows, k, cnt_lo, cand_cnt, cand_d2, cand_idx, cap, core, status};
     hipLaunchKernelGGL(knn_select_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, a);
+    IDL_HIP_TRY(hipGetLastError());
+    return IDL_OK;
+}
+
+int idl_silhouette_sums(const float *x, const float *w, const int32_t *tile_cluster, int64_t n, int d, int n_clusters, float *sums, void *stream)
+{
+    IDL_REQUIRE(x && w && tile_cluster && sums, "silhouette_sums: NULL buffer");
+    IDL_REQUIRE(d == KD, "silhouette_sums: points must have 64 coordinates");
+    IDL_REQUIRE(n >= 16 && n % 16 == 0 && n < (1ll << 31) && n_clusters >= 1, "silhouette_sums: n must be a positive multiple of 16 (clusters padded to whole tiles)");
+    IDL_REQUIRE((((uintptr_t)x) & 15u) == 0, "silhouette_sums: x must be 16-byte aligned");
+    SilArgs a{x, w, tile_cluster, n, n_clusters, sums};
+    hipLaunchKernelGGL(silhouette_sums_kernel, dim3((unsigned)((n + ROWS_WG - 1) / ROWS_WG)), dim3(256), 0, (hipStream_t)stream, a);
     IDL_HIP_TRY(hipGetLastError());
     return IDL_OK;
 }

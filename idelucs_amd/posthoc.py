@@ -91,11 +91,62 @@ def label_features_device(predictions, n_clusters, device=None, n_init=10, max_i
 SILHOUETTE_HOST_MAX = 20000      # above this many points the silhouette is computed on the GPU (sklearn's is O(N^2) on the host)
 
 
+def _silhouette_from_sums(sums, own, counts):
+    """mean over the points of (b - a) / max(a, b) from the per-cluster distance sums [n, K] (float64), the points' own clusters
+    and the cluster sizes: a = mean distance to the rest of the own cluster, b = smallest mean distance to another cluster;
+    singletons score 0 (sklearn)."""
+    import torch
+    n_own = counts[own]
+    a = sums.gather(1, own[:, None]).squeeze(1) / (n_own - 1.0).clamp_min(1.0)
+    means = sums / counts[None, :]
+    means.scatter_(1, own[:, None], float("inf"))
+    b = means.min(1).values
+    sil = (b - a) / torch.maximum(a, b)
+    sil = torch.where(n_own > 1.0, sil, torch.zeros_like(sil))
+    return torch.nan_to_num(sil).sum()
+
+
+def _silhouette_one_pass(x, lab, k, dev):
+    """The per-cluster distance sums by idl_silhouette_sums (csrc/knn.hip): the points cluster by cluster, every cluster padded to
+    whole 64-row waves (weight 0; the padding repeats a point of the cluster: a wave centres its coordinates on its first row, and
+    a wave that straddled two tight far-apart clusters would lose the second one's distances to rounding), one MFMA pass over
+    all pairs.  -> sum over the points of their silhouette (float64 device scalar)."""
+    import ctypes
+    import torch
+    from . import _lib
+    n = x.shape[0]
+    order = torch.argsort(lab, stable=True)
+    lab_s = lab[order]
+    counts = torch.bincount(lab, minlength=k)
+    padded = (counts + 63) // 64 * 64                         # whole waves: a wave's 64 rows (and its centre) belong to one cluster
+    first = torch.cumsum(counts, 0) - counts                  # first sorted index of each cluster
+    start = torch.cumsum(padded, 0) - padded                  # first padded row of each cluster
+    npad = int(padded.sum())
+    pos = start[lab_s] + (torch.arange(n, device=dev) - first[lab_s])
+    xs = x[order]
+    row_cluster = torch.repeat_interleave(torch.arange(k, device=dev), padded)
+    xp = xs[first[row_cluster]].contiguous()
+    xp[pos] = xs
+    w = torch.zeros(npad, dtype=torch.float32, device=dev)
+    w[pos] = 1.0
+    tile_cluster = torch.repeat_interleave(torch.arange(k, device=dev, dtype=torch.int32), (padded // 16))
+    sums = torch.zeros((npad, k), dtype=torch.float32, device=dev)
+    vp = ctypes.c_void_p
+    _lib.check(_lib.lib.idl_silhouette_sums(vp(xp.data_ptr()), vp(w.data_ptr()), vp(tile_cluster.data_ptr()), npad, 64, k, vp(sums.data_ptr()),
+                                            vp(torch.cuda.current_stream().cuda_stream)))
+    return _silhouette_from_sums(sums[pos].double(), lab_s, counts.double())
+
+
+SILHOUETTE_ONE_PASS_MIN = 4096   # points from which 64-dimensional data take the one-pass kernel
+
+
 def silhouette_score_device(data, labels, device=None, block=4096):
-    """sklearn.metrics.silhouette_score(data, labels) (euclidean, mean over all samples) on the GPU: for a block of rows the
-    distances to every point come from one GEMM (||x||^2 + ||y||^2 - 2 x.y, clamped, square-rooted) and their per-cluster sums
-    from a second GEMM with the one-hot label matrix -- N^2 (d + K) multiply-adds in all, no N x N matrix is ever held.
-    float64 accumulation of the per-cluster sums; agrees with sklearn to ~1e-6 (tests/test_cli_surface.py)."""
+    """sklearn.metrics.silhouette_score(data, labels) (euclidean, mean over all samples) on the GPU.  64-dimensional data (the
+    latent) from SILHOUETTE_ONE_PASS_MIN points: one pass over all pairs on the fp32 matrix cores that adds every point's distances
+    up per cluster in registers (_silhouette_one_pass; 10^6 points: 2 s).  Otherwise ($IDELUCS_SILHOUETTE=gemm forces it): for a
+    block of rows the distances to every point come from one GEMM (||x||^2 + ||y||^2 - 2 x.y, clamped, square-rooted) and their
+    per-cluster sums from a second GEMM with the one-hot label matrix (10 s at 10^6 points: five elementwise passes over 4 TB).
+    float64 from the per-cluster sums on; agrees with sklearn to ~1e-6 (tests/test_cli_surface.py)."""
     import torch
     dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
     x = torch.as_tensor(np.asarray(data)).to(dev, torch.float32)
@@ -104,6 +155,8 @@ def silhouette_score_device(data, labels, device=None, block=4096):
     if not 2 <= k <= n - 1:
         raise ValueError("Number of labels is %d. Valid values are 2 to n_samples - 1 (inclusive)" % k)      # sklearn's check
     lab = torch.from_numpy(inv.astype(np.int64)).to(dev)
+    if x.shape[1] == 64 and n >= SILHOUETTE_ONE_PASS_MIN and os.environ.get("IDELUCS_SILHOUETTE", "") != "gemm":
+        return float(_silhouette_one_pass(x, lab, k, dev).item() / n)
     onehot = torch.zeros((n, k), dtype=torch.float32, device=dev)
     onehot[torch.arange(n, device=dev), lab] = 1.0
     counts = onehot.sum(0).double()
@@ -120,15 +173,7 @@ def silhouette_score_device(data, labels, device=None, block=4096):
         d2.mul_(-2.0).add_(x2[lo:hi, None]).add_(x2[None, :]).clamp_min_(0.0)
         d2[torch.arange(hi - lo, device=dev), torch.arange(lo, hi, device=dev)] = 0.0       # exact zeros on the diagonal
         sums = (d2.sqrt_() @ onehot).double()                                                # [rows, K]: sum of distances to each cluster
-        own = lab[lo:hi]
-        n_own = counts[own]
-        a = sums.gather(1, own[:, None]).squeeze(1) / (n_own - 1.0).clamp_min(1.0)
-        means = sums / counts[None, :]
-        means.scatter_(1, own[:, None], float("inf"))
-        b = means.min(1).values
-        sil = (b - a) / torch.maximum(a, b)
-        sil = torch.where(n_own > 1.0, sil, torch.zeros_like(sil))                          # singletons score 0 (sklearn)
-        total += torch.nan_to_num(sil).sum()
+        total += _silhouette_from_sums(sums, lab[lo:hi], counts)
     return float(total.item() / n)
 
 

@@ -252,6 +252,32 @@ def test_silhouette_on_device_equals_sklearn():
 
 
 @pytest.mark.gpu
+def test_silhouette_in_one_pass_equals_sklearn(monkeypatch):
+    """The one-pass kernel (idl_silhouette_sums: per-cluster distance sums in registers, clusters padded to whole tiles) against
+    sklearn on 6 000 points with cluster sizes that are not multiples of 16, a singleton and tight far-apart clusters (the cfg5
+    latent's geometry, where a Gram form in global coordinates loses the within-cluster distances), and against the GEMM path at
+    50 000 points."""
+    from sklearn.metrics import silhouette_score
+    from idelucs_amd import posthoc
+    rng = np.random.default_rng(4)
+    monkeypatch.setattr(posthoc, "SILHOUETTE_ONE_PASS_MIN", 0)
+    for spread, scale in ((1.0, 2.0), (0.02, 40.0)):
+        centres = rng.normal(size=(7, 64)) * scale
+        lab = rng.integers(0, 7, 6000)
+        x = (centres[lab] + rng.normal(size=(6000, 64)) * spread).astype(np.float32).astype(np.float64)
+        lab[11] = 12                                             # a singleton cluster scores 0
+        got, want = posthoc.silhouette_score_device(x, lab), silhouette_score(x, lab)
+        assert abs(got - want) < 2e-5, (spread, got, want)
+    centres = rng.normal(size=(9, 64)) * 3.0
+    lab = rng.integers(0, 9, 50000)
+    x = centres[lab] + rng.normal(size=(50000, 64))
+    one = posthoc.silhouette_score_device(x, lab)
+    monkeypatch.setenv("IDELUCS_SILHOUETTE", "gemm")
+    two = posthoc.silhouette_score_device(x, lab)
+    assert abs(one - two) < 2e-5, (one, two)
+
+
+@pytest.mark.gpu
 def test_fine_grained_clusters_beyond_the_exact_limit():
     """n_clusters = 0 above HDBSCAN_EXACT_MAX points, mode "approx": density clustering of a seeded subsample on the host +
     nearest-sampled-point assignment on the GPU.  On planted blobs the partition is recovered, the sampled points keep HDBSCAN's own labels, and below

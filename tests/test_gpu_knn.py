@@ -87,13 +87,21 @@ def test_hdbscan_labels_do_not_depend_on_the_core_distance_path(monkeypatch):
     assert np.array_equal(l1, l2) and np.array_equal(p1, p2)
 
 
-def test_prim_with_the_8_bit_filter_builds_the_same_tree(monkeypatch):
-    """idl_mst_prim_q8 skips exact distances that an 8-bit lower bound proves irrelevant: the edges -- nodes, order, float64
-    weights -- are those of the unfiltered scan, also for data with outliers far outside the code range."""
+@pytest.mark.parametrize("d,as_f32", [(64, True), (16, True), (64, False), (40, False)])
+def test_prim_with_the_8_bit_filter_builds_the_same_tree(monkeypatch, d, as_f32):
+    """idl_mst_prim_local skips exact distances that an 8-bit lower bound proves irrelevant: the edges -- nodes, order, float64
+    weights -- are those of the unfiltered scan, also for data with outliers far outside the code range, for fewer than 64
+    features and for float64 coordinates that float32 does not hold (the generic kernels)."""
     from idelucs_amd import posthoc
-    x = _blobs(24000, seed=4)
-    x[:40] *= 30.0                                              # clamped codes, large residuals
-    x = x.astype(np.float32).astype(np.float64)
+    rng = np.random.default_rng(4 + d)
+    n = 24000
+    centres = rng.normal(size=(7, d)) * 2.5
+    truth = rng.integers(0, 7, n)
+    x = centres[truth] + rng.normal(size=(n, d)) * rng.uniform(0.3, 0.9, size=(7,))[truth][:, None]
+    x[: n // 20] = rng.uniform(-8, 8, size=(n // 20, d))
+    x[:40] *= 30.0                                              # far outside the boxes of their groups
+    if as_f32:
+        x = x.astype(np.float32).astype(np.float64)
     k = 241
     with_filter, without = {}, {}
     l1, p1 = posthoc.hdbscan_device(x, k, stats=with_filter)

@@ -188,40 +188,47 @@ __global__ __launch_bounds__(64) void mimic_kernel(MimicParams p, int n_views, c
 // site probability -- and the vectoriser is told (begin, end) per item instead of a CSR array (idl_vectorise_ranges): the
 // sites are drawn once, into LDS, and copied out behind a wave prefix sum.  Same spec, same sites, same order inside an
 // item as mimic_kernel (tests compare the two bit for bit).  An item that does not fit its slot raises *overflow and is
-// truncated (the caller falls back to the exact two-pass protocol); a lane with more than RB sites sends its item through
-// the count-then-fill path inside this kernel.
-constexpr int RB = 24;             // sites a lane buffers in LDS (cfg2: 2.4 expected per lane)
+// truncated (the caller falls back to the exact two-pass protocol); a lane with more sites than its LDS buffer holds sends its
+// item through a second draw, straight to memory, inside this kernel.
 
 struct SlotLayout { int64_t base[MAX_VIEWS]; int32_t cap[MAX_VIEWS]; };
 
+template <int GB, int RB4>        // GB: items (consecutive sequences of one view) a wave draws at once; RB4: sites a lane buffers per item
 __global__ __launch_bounds__(64) void mimic_slots_kernel(MimicParams p, int n_views, const int64_t *lengths, int64_t n, uint32_t k0, uint32_t k1,
                                                          const uint32_t *tables, SlotLayout sl, int64_t *ranges, uint32_t *edits, int32_t *overflow)
 {
     __shared__ uint32_t T[J + 1];
-    __shared__ uint32_t buf[RB][64];
+    __shared__ uint32_t buf[GB * RB4][64];                 // (RB sites of one item, or RB4 of each of GB items)
+    __shared__ uint32_t cnt4[GB][64];
     const int lane = threadIdx.x;
-    const int64_t items = n * n_views;
     int cur_view = -1;
-    for (int64_t it = blockIdx.x; it < items; it += gridDim.x) {
-        const int v = (int)(it / n);                        // view-major items keep the table resident
-        const int64_t s = it - (int64_t)v * n;
-        const int64_t L = lengths[s];
-        const int64_t slot = sl.base[v] + s * (int64_t)sl.cap[v];
+    // work units: GB consecutive sequences of one view (the last unit of a view may be shorter); view-major, so the table stays resident
+    const int64_t per_view = (n + GB - 1) / GB;
+    const int64_t units = per_view * n_views;
+    for (int64_t un = blockIdx.x; un < units; un += gridDim.x) {
+        const int v = (int)(un / per_view);
+        const int64_t s0 = (un - (int64_t)v * per_view) * GB;
+        const int nb = (int)((n - s0) < GB ? (n - s0) : GB);
         const uint32_t cap = (uint32_t)sl.cap[v];
         if (p.n_rand[v] > 0) {
-            uint32_t key = 0xFFFFFFFFu;
-            const int nr = L > 0 ? p.n_rand[v] : 0;
-            if (lane < nr) {
-                const U4 r = philox4x32_10((uint32_t)lane, 0u, (uint32_t)s, (uint32_t)v | (1u << 16), k0, k1);
-                key = (uint32_t)(((uint64_t)r.x * (uint64_t)(uint32_t)L) >> 32);
+            for (int b = 0; b < nb; ++b) {
+                const int64_t s = s0 + b, it = (int64_t)v * n + s;
+                const int64_t L = lengths[s];
+                const int64_t slot = sl.base[v] + s * (int64_t)sl.cap[v];
+                uint32_t key = 0xFFFFFFFFu;
+                const int nr = L > 0 ? p.n_rand[v] : 0;
+                if (lane < nr) {
+                    const U4 r = philox4x32_10((uint32_t)lane, 0u, (uint32_t)s, (uint32_t)v | (1u << 16), k0, k1);
+                    key = (uint32_t)(((uint64_t)r.x * (uint64_t)(uint32_t)L) >> 32);
+                }
+                key = wave_sort_u32(key, lane);
+                if (lane < nr && (uint32_t)lane < cap) edits[slot + lane] = key;       // op 0 = N
+                if (lane == 0) { ranges[2 * it] = slot; ranges[2 * it + 1] = slot + ((uint32_t)nr < cap ? (uint32_t)nr : cap); if ((uint32_t)nr > cap) *overflow = 1; }
             }
-            key = wave_sort_u32(key, lane);
-            if (lane < nr && (uint32_t)lane < cap) edits[slot + lane] = key;       // op 0 = N
-            if (lane == 0) { ranges[2 * it] = slot; ranges[2 * it + 1] = slot + ((uint32_t)nr < cap ? (uint32_t)nr : cap); if ((uint32_t)nr > cap) *overflow = 1; }
             continue;
         }
         if (!p.has_sites[v]) {
-            if (lane == 0) { ranges[2 * it] = slot; ranges[2 * it + 1] = slot; }
+            if (lane < nb) { const int64_t s = s0 + lane, it = (int64_t)v * n + s; const int64_t slot = sl.base[v] + s * (int64_t)sl.cap[v]; ranges[2 * it] = slot; ranges[2 * it + 1] = slot; }
             continue;
         }
         if (cur_view != v) {
@@ -230,48 +237,82 @@ __global__ __launch_bounds__(64) void mimic_slots_kernel(MimicParams p, int n_vi
             __syncthreads();
             cur_view = v;
         }
-        const int64_t seg = (L + 63) / 64;
-        const int64_t lo = (int64_t)lane * seg;
-        int64_t hi = lo + seg;
-        if (hi > L) hi = L;
         const uint32_t A = p.thr_ts_only[v], B = p.thr_tv_only[v];
         const int kind = p.kind[v];
         const float ilk = p.inv_log2_keep[v];
-        // the draws of this lane's segment; emit(e, i) is called with the i-th site of the lane, in position order
-        auto draw = [&](auto emit) -> uint32_t {
-            uint32_t cnt = 0;
-            int64_t pos = lo - 1;
-            for (uint32_t d = 0; pos < hi; ++d) {
-                const U4 r = philox4x32_10(d, (uint32_t)lane, (uint32_t)s, (uint32_t)v, k0, k1);
-                int a = (int)fminf(__log2f(((float)r.x + 0.5f) * 2.3283064365386963e-10f) * ilk, (float)J);
-                if (a < 0) a = 0;
-                while (a < J && r.x < T[a + 1]) ++a;
-                while (a > 0 && !(r.x < T[a])) --a;
-                if (a == J) { pos += J; continue; }
-                pos += a + 1;
-                if (pos >= hi) break;
-                const uint32_t flav = 1u | ((r.z & 1u) << 1);            // transversion: ^1 or ^3
-                uint32_t op = (r.y < A) ? 2u : (r.y < B) ? flav : (2u ^ flav);
-                if (kind == 1) op = 2u;
-                if (kind == 2) op = flav;
-                emit((uint32_t)pos | (op << 30), cnt);
-                ++cnt;
-            }
-            return cnt;
-        };
-        const uint32_t my = draw([&](uint32_t e, uint32_t i) { if (i < (uint32_t)RB) buf[i][lane] = e; });
-        uint32_t incl = my;
+        int64_t Lb[GB];
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
-        const uint32_t off = incl - my, total = (uint32_t)__shfl((int)incl, 63, 64);
-        if (__ballot(my > (uint32_t)RB) == 0ull) {
-            for (uint32_t i = 0; i < my; ++i) if (off + i < cap) edits[slot + off + i] = buf[i][lane];
-        } else {                                              // a crowded lane somewhere: draw again, straight to memory (offsets are known now)
-            draw([&](uint32_t e, uint32_t i) { if (off + i < cap) edits[slot + off + i] = e; });
+        for (int b = 0; b < GB; ++b) Lb[b] = b < nb ? lengths[s0 + b] : 0;
+        // one gap of lane `lane` of sequence s: position reached, or -1 for "J bases without a site"; e = the edit when a site was drawn
+        auto gap = [&](uint32_t d, int64_t s, int64_t &pos, uint32_t &e) -> bool {
+            const U4 r = philox4x32_10(d, (uint32_t)lane, (uint32_t)s, (uint32_t)v, k0, k1);
+            int a = (int)fminf(__log2f(((float)r.x + 0.5f) * 2.3283064365386963e-10f) * ilk, (float)J);
+            if (a < 0) a = 0;
+            while (a < J && r.x < T[a + 1]) ++a;
+            while (a > 0 && !(r.x < T[a])) --a;
+            if (a == J) { pos += J; return false; }
+            pos += a + 1;
+            const uint32_t flav = 1u | ((r.z & 1u) << 1);                // transversion: ^1 or ^3
+            uint32_t op = (r.y < A) ? 2u : (r.y < B) ? flav : (2u ^ flav);
+            if (kind == 1) op = 2u;
+            if (kind == 2) op = flav;
+            e = (uint32_t)pos | (op << 30);
+            return true;
+        };
+        // ---- the lanes walk their segments of the unit's items one after the other, each at its own pace: a lane that is through with
+        // item b starts on item b + 1 while its neighbours still draw -- the wave runs for max-over-lanes of the SUM of draws (a lane
+        // draws 3.4 times per item at cfg2, the unluckiest of 64 nine times: 38 % of the lanes busy; over four items 64 %)
+        {
+            int b = 0;
+            uint32_t d = 0, c = 0;
+            int64_t L = Lb[0], seg = (L + 63) / 64, lo = (int64_t)lane * seg, hi = lo + seg < L ? lo + seg : L, pos = lo - 1;
+            while (b < nb) {
+                bool done = !(pos < hi);
+                if (!done) {
+                    uint32_t e = 0;
+                    const bool site = gap(d++, s0 + b, pos, e);
+                    if (site && pos < hi) { if (c < (uint32_t)RB4) buf[b * RB4 + c][lane] = e; ++c; }
+                    done = site && !(pos < hi);
+                }
+                if (done) {
+                    cnt4[b][lane] = c;
+                    ++b; d = 0; c = 0;
+                    if (b < nb) {
+                        L = Lb[0];
+#pragma unroll
+                        for (int q = 1; q < GB; ++q) if (b == q) L = Lb[q];
+                        seg = (L + 63) / 64; lo = (int64_t)lane * seg; hi = lo + seg < L ? lo + seg : L; pos = lo - 1;
+                    }
+                }
+            }
         }
-        if (lane == 0) {
-            ranges[2 * it] = slot; ranges[2 * it + 1] = slot + (total < cap ? total : cap);
-            if (total > cap) *overflow = 1;
+        // ---- per item: place the lanes' sites behind a wave prefix sum
+        for (int b = 0; b < nb; ++b) {
+            const int64_t s = s0 + b, it = (int64_t)v * n + s;
+            const int64_t slot = sl.base[v] + s * (int64_t)sl.cap[v];
+            const uint32_t my = cnt4[b][lane];
+            uint32_t incl = my;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+            const uint32_t off = incl - my, total = (uint32_t)__shfl((int)incl, 63, 64);
+            if (__ballot(my > (uint32_t)RB4) == 0ull) {
+                for (uint32_t i = 0; i < my; ++i) if (off + i < cap) edits[slot + off + i] = buf[b * RB4 + i][lane];
+            } else {                                          // a crowded lane somewhere: draw the item again, straight to memory (offsets are known now)
+                const int64_t L = Lb[b], seg = (L + 63) / 64, lo = (int64_t)lane * seg, hi = lo + seg < L ? lo + seg : L;
+                int64_t pos = lo - 1;
+                uint32_t i = 0;
+                for (uint32_t d = 0; pos < hi; ++d) {
+                    uint32_t e = 0;
+                    if (!gap(d, s, pos, e)) continue;
+                    if (pos >= hi) break;
+                    if (off + i < cap) edits[slot + off + i] = e;
+                    ++i;
+                }
+            }
+            if (lane == 0) {
+                ranges[2 * it] = slot; ranges[2 * it + 1] = slot + (total < cap ? total : cap);
+                if (total > cap) *overflow = 1;
+            }
         }
     }
 }
@@ -500,10 +541,16 @@ int idl_mimic_edits_slots(const int64_t *lengths, int64_t n, int n_views, const 
     const int64_t items = n * n_views;
     if (items == 0) return IDL_OK;
     uint32_t *tables = (uint32_t *)workspace;
-    int64_t grid = (int64_t)di.cus * 32;
-    if (grid > items) grid = items;
+    int64_t grid;
+    // two items per wave, 8 buffered sites per lane and item (8.6 KB of LDS: 18 waves per CU), 128 workgroups per CU -- swept at cfg2:
+    // <1, 24> x 32 per CU (one item at a time, the round-3 start) 0.82 ms, <4, 12> 0.74, <4, 8> 0.62, <3, 8> 0.58, <2, 12> 0.61, <2, 8> 0.55
+    constexpr int GEN_ITEMS = 2, GEN_BUF = 8;
+    grid = (int64_t)di.cus * 128;
+    const int64_t units = (n + GEN_ITEMS - 1) / GEN_ITEMS * n_views;
+    if (grid > units) grid = units;
     hipLaunchKernelGGL(mimic_table_kernel, dim3((unsigned)n_views), dim3(64), 0, st, p, n_views, tables);
-    hipLaunchKernelGGL(mimic_slots_kernel, dim3((unsigned)grid), dim3(64), 0, st, p, n_views, lengths, n, (uint32_t)seed, (uint32_t)(seed >> 32),
+    auto kern = mimic_slots_kernel<GEN_ITEMS, GEN_BUF>;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), 0, st, p, n_views, lengths, n, (uint32_t)seed, (uint32_t)(seed >> 32),
                        (const uint32_t *)tables, sl, edit_ranges, edits, overflow);
     IDL_HIP_TRY(hipGetLastError());
     return IDL_OK;

@@ -32,6 +32,8 @@
 // still drop is decided in the third digit of its distance.  A pair whose bound cannot undercut min_reach[j] skips the exact
 // distance, which would have changed nothing -- the tree is the same, edge for edge.  Ties are broken on the points' ORIGINAL
 // numbers (`orig`), as sklearn's scan over j would.
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "common.h"
@@ -339,6 +341,429 @@ int prim_run(PrimArgs a, int is_f64, bool filter, void *workspace, void *stream)
     return IDL_OK;
 }
 
+
+// ================================================================================================================ lazy Prim
+// The scan above touches every point outside the tree at every step, and on a latent of far-apart clusters almost all of them for
+// nothing: while the tree grows inside one cluster, the points of the others neither can be selected (their min_reach is the
+// distance to that cluster, hundreds of times the weights being added) nor need their min_reach be current.  Here a GROUP of points
+// may SLEEP: the steps skip it, and it keeps a lower bound of what its min_reach values could have become,
+//     lb(g) = min( min_reach of its points when it fell asleep,  min over the nodes added since of  ||x_t - c_g|| - R_g )
+// (c_g, R_g: a ball around its points; mrd(t, p) >= ||x_t - x_p|| >= ||x_t - c_g|| - R_g).  A step's winner is committed only while
+// its weight is strictly below every sleeping group's bound -- then no sleeping point could have been the argmin, ties included.
+// Otherwise the launch STALLS (nothing is changed; the launches queued behind it fall through), and the host has the sleeping
+// groups CATCH UP: every sleeping point meets the nodes added since its group fell asleep, in their order, with the same strict-<
+// update -- the state is then what the plain scan would have left.  That is the same N^2 / 2 pairs of work, but as a blocked
+// loop: a thread keeps its point's 64 coordinates in registers, the nodes stream through LDS 32 at a time, and every distance is
+// formed exactly (no bound, no gather) at the f64 VALU rate instead of the memory system's.  A census then decides who sleeps next
+// (groups whose smallest min_reach is well above the weights being added), a re-scan of the last node rebuilds the candidates, and
+// the steps go on.  Same tree, edge for edge (tests compare with the plain scan).
+struct LazyState {
+    long long n_tree;          // nodes in the tree (the start included)
+    long long cur_p, cur_o;    // the node added last: position, original number
+    double cur_w, ema;         // its edge's weight; running mean of the recent weights
+    int stalled, cand_par;     // 1: the winner could not be committed; which candidate buffer is valid
+    long long pad;
+};
+
+struct LazyArgs {
+    LazyState *st;             // [2], by launch parity
+    int64_t *tree_p;           // [n] positions in the order they were added
+    unsigned char *run_asleep; // [ceil(n / 256)] 1: every point of the run sleeps (or is in the tree)
+    unsigned char *pas;        // [n] 1: the point's group sleeps
+    int n_groups;
+    const int64_t *gfirst;     // [G + 1] first position of each group
+    int *asleep;               // [G] 0 awake, 1 asleep, 2 nothing left outside the tree
+    int64_t *upto;             // [G] the tree nodes [0, upto) have met the group
+    double *minmr;             // [G] smallest min_reach of its points outside the tree, as of upto (+inf: none left)
+    double *lbp;               // [2][G] by launch parity: lower bound of mrd(t, p) over the nodes added since upto and the group's points
+    const double *gc;          // [G][64] centre of the group's ball
+    const double *gr;          // [G] its radius (>= ||x_p - c_g||)
+    const float *xrow;         // [n][64] the points row-major (a node's coordinates in one piece)
+    double *gmin; int64_t *galive;       // census scratch [G]
+};
+
+constexpr int LAZY_NCH = 32;           // nodes a catch-up pass stages in LDS at a time
+
+__global__ __launch_bounds__(PRIM_NT, 1024 / PRIM_NT) void lazy_step_kernel(PrimArgs a, LazyArgs z, int64_t launch, int rescan)
+{
+    __shared__ double sw[PRIM_NT / 64];
+    __shared__ int64_t sj[PRIM_NT / 64], sp[PRIM_NT / 64];
+    __shared__ double xc[PRIM_FILTER_D];
+    __shared__ float up[PRIM_RUNS][PRIM_FILTER_D];
+    __shared__ int q_n;
+    __shared__ unsigned short q_item[PRIM_NT * PRIM_AHEAD];
+    __shared__ double q_mr[PRIM_NT * PRIM_AHEAD], q_floor[PRIM_NT * PRIM_AHEAD];
+    static_assert(PRIM_NT == PRIM_SUB, "one sub-block per workgroup here");
+    const int tid = threadIdx.x;
+    const int64_t n = a.n;
+    const int G = z.n_groups;
+    const int par = (int)(launch & 1);
+    const LazyState S = z.st[par];
+    LazyState *nx = &z.st[par ^ 1];
+    const bool lead = blockIdx.x == 0 && tid == 0;
+    const bool ball_duty = (int)blockIdx.x < G;              // workgroup g keeps sleeping group g's bound
+    if (S.stalled || S.n_tree >= n) {                        // fall through: the state and the bounds are handed on unchanged
+        if (lead) *nx = S;
+        if (ball_duty && tid == 0) z.lbp[(par ^ 1) * G + blockIdx.x] = z.lbp[par * G + blockIdx.x];
+        return;
+    }
+    const int64_t stride = (int64_t)gridDim.x * PRIM_NT;
+    const int64_t p0 = (int64_t)blockIdx.x * PRIM_NT + tid;
+    const float *xt = (const float *)a.xt;
+    // ---- which of this workgroup's runs are awake (uniform)
+    bool run_on[PRIM_AHEAD];
+    bool any_on = false;
+#pragma unroll
+    for (int i = 0; i < PRIM_AHEAD; ++i) {
+        const int64_t first = (int64_t)blockIdx.x * PRIM_NT + i * stride;
+        run_on[i] = first < n && z.run_asleep[first / PRIM_NT] == 0;
+        any_on |= run_on[i];
+    }
+    Cand *cand_out = a.cand[S.cand_par ^ 1];
+    if (!any_on && !ball_duty) {                             // nothing to scan, nothing to keep: leave an empty candidate
+        if (tid == 0) cand_out[blockIdx.x] = Cand{__builtin_inf(), INT64_MAX, 0};
+        return;
+    }
+    // ---- prologue: the state of the points of the runs that are awake, their codes
+    double mr_a[PRIM_AHEAD], cj_a[PRIM_AHEAD];
+    int64_t o_a[PRIM_AHEAD];
+    bool in_run[PRIM_AHEAD];
+    uint32_t cw[PRIM_AHEAD][PRIM_FILTER_D / 4];
+    float rs[PRIM_AHEAD], run_scale[PRIM_AHEAD];
+    int run_g[PRIM_AHEAD], g_own[PRIM_AHEAD];
+#pragma unroll
+    for (int i = 0; i < PRIM_AHEAD; ++i) {
+        const int64_t p = p0 + i * stride;
+        const bool on = run_on[i] && p < n;
+        mr_a[i] = on ? a.min_reach[p] : -1.0;
+        cj_a[i] = on ? a.core[p] : 0.0;
+        o_a[i] = on ? (int64_t)a.orig[p] : 0;
+        const int64_t first = (int64_t)blockIdx.x * PRIM_NT + i * stride;
+        run_g[i] = run_on[i] ? a.gid[first] : 0;
+        g_own[i] = on ? a.gid[p] : -1;
+        if (on && z.pas[p]) mr_a[i] = -1.0;                  // (a run that straddles a sleeping and a waking group)
+    }
+    int my_run_g;
+    {
+        static_assert(PRIM_RUNS * 64 == PRIM_NT && PRIM_FILTER_D == 64 && PRIM_AHEAD == 4, "one (run, feature) per thread");
+        const int rr = tid >> 6;
+        my_run_g = rr == 0 ? run_g[0] : rr == 1 ? run_g[1] : rr == 2 ? run_g[2] : run_g[3];
+        const __amdgpu_buffer_rsrc_t c_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.codes, 0, 0xffffffff, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < PRIM_AHEAD; ++i) {
+            const int64_t p = p0 + i * stride;
+            in_run[i] = mr_a[i] >= 0.0 && g_own[i] == run_g[i];
+            rs[i] = 0.f;
+            run_scale[i] = (float)a.gscale[run_g[i]];
+            if (in_run[i]) {
+                rs[i] = a.resid[p];
+#pragma unroll
+                for (int k = 0; k < PRIM_FILTER_D / 4; ++k) cw[i][k] = __builtin_amdgcn_raw_buffer_load_b32(c_rsrc, (uint32_t)p * 4u, k * (int)n * 4, 0);
+            }
+        }
+    }
+    // ---- the winner of the previous scan; it is committed only if no sleeping group could hold a better point
+    int64_t cur = S.cur_p, cur_o = S.cur_o;
+    double cur_w = S.cur_w;
+    if (!rescan) {
+        const Cand *pc = a.cand[S.cand_par];
+        double bw = __builtin_inf(); int64_t bj = INT64_MAX, bp = 0;
+        for (int g = tid; g < (int)gridDim.x; g += PRIM_NT) {
+            const Cand c = pc[g];
+            if (better(c.w, c.j, bw, bj)) { bw = c.w; bj = c.j; bp = c.p; }
+        }
+        block_best(bw, bj, bp, sw, sj, sp);
+        double lb = __builtin_inf();
+        for (int g = tid; g < G; g += PRIM_NT) if (z.asleep[g] == 1) lb = fmin(lb, fmin(z.minmr[g], z.lbp[par * G + g]));      // (2: nothing left in it)
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) lb = fmin(lb, __shfl_xor(lb, o, 64));
+        if ((tid & 63) == 0) sw[tid >> 6] = lb;
+        __syncthreads();
+        lb = fmin(fmin(sw[0], sw[1]), fmin(sw[2], sw[3]));
+        __syncthreads();
+        if (!(bw < lb)) {                                    // STALL (every workgroup decides the same from the same data)
+            if (lead) { *nx = S; nx->stalled = 1; }
+            if (ball_duty && tid == 0) z.lbp[(par ^ 1) * G + blockIdx.x] = z.lbp[par * G + blockIdx.x];
+            return;
+        }
+        cur = bp; cur_o = bj; cur_w = bw;
+        if (lead) {
+            a.mst_cur[S.n_tree - 1] = a.source[cur]; a.mst_next[S.n_tree - 1] = cur_o; a.mst_w[S.n_tree - 1] = cur_w;
+            a.min_reach[cur] = -1.0;                         // in the tree (this launch skips it by position)
+            z.tree_p[S.n_tree] = cur;
+        }
+    }
+    if (lead) {
+        LazyState t = S;
+        if (!rescan) { t.n_tree = S.n_tree + 1; t.cur_p = cur; t.cur_o = cur_o; t.cur_w = cur_w; t.ema = S.ema + (cur_w - S.ema) * (1.0 / 64.0); }
+        t.cand_par = S.cand_par ^ 1;
+        *nx = t;
+    }
+    if (tid < PRIM_FILTER_D) xc[tid] = (double)xt[(int64_t)tid * n + cur];
+    if (tid == 0) q_n = 0;
+    const double cc = a.core[cur];
+    {
+        const int k = tid & 63;
+        const double sc = a.gscale[my_run_g];
+        const float lo = a.glo[(int64_t)my_run_g * PRIM_FILTER_D + k];
+        __syncthreads();
+        up[tid >> 6][k] = (float)((xc[k] - (double)lo) / sc);
+    }
+    // ---- sleeping group g's bound meets the new node (workgroup g, its first wave)
+    if (ball_duty && tid < 64) {
+        const int g = blockIdx.x;
+        double lbv = z.lbp[par * G + g];
+        if (!rescan && z.asleep[g] == 1) {
+            const double t = xc[tid] - z.gc[(int64_t)g * PRIM_FILTER_D + tid];
+            double d2 = t * t;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) d2 += __shfl_xor(d2, o, 64);
+            const double b = __dsqrt_rn(d2) * (1.0 - 1e-12) - z.gr[g];
+            lbv = fmin(lbv, b > 0.0 ? b : 0.0);
+        }
+        if (tid == 0) z.lbp[(par ^ 1) * G + g] = lbv;
+    }
+    __syncthreads();
+    if (!any_on) { if (tid == 0) cand_out[blockIdx.x] = Cand{__builtin_inf(), INT64_MAX, 0}; return; }
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.xt, 0, 0xffffffff, 0x00020000);
+    const int col_bytes = (int)n * 4;
+    double bw = __builtin_inf(); int64_t bj = INT64_MAX, bp = 0;
+    auto exact = [&](int64_t p, double &mr, double floor_cj) {
+        double acc = 0.0;
+        uint32_t v[64];
+#pragma unroll
+        for (int k = 0; k < 64; ++k) v[k] = __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, (uint32_t)p * 4u, k * col_bytes, 0);
+#pragma unroll
+        for (int k = 0; k < 64; ++k) {
+            if ((k & 7) == 0) __builtin_amdgcn_sched_barrier(0);
+            const double t = xc[k] - (double)__uint_as_float(v[k]);
+            acc = idl_dev::square_then_add(acc, t);
+        }
+        const double mrd = fmax(floor_cj, __dsqrt_rn(acc));
+        if (mrd < mr) { mr = mrd; a.min_reach[p] = mr; a.source[p] = cur_o; }
+    };
+    bool act[PRIM_AHEAD], need[PRIM_AHEAD];
+    double floor_a[PRIM_AHEAD];
+#pragma unroll
+    for (int i = 0; i < PRIM_AHEAD; ++i) {
+        const int64_t p = p0 + i * stride;
+        act[i] = mr_a[i] >= 0.0 && p != cur;
+        floor_a[i] = fmax(cc, cj_a[i]);
+        need[i] = act[i] && floor_a[i] < mr_a[i];
+    }
+#pragma unroll
+    for (int i = 0; i < PRIM_AHEAD; ++i) {
+        if (!(need[i] && in_run[i])) continue;
+        float acc = 0.f;
+        const float *u = up[i];
+#pragma unroll
+        for (int k = 0; k < PRIM_FILTER_D / 4; ++k) {
+            const uint32_t w = cw[i][k];
+            const float t0 = u[4 * k] - (float)(w & 255u), t1 = u[4 * k + 1] - (float)((w >> 8) & 255u);
+            const float t2 = u[4 * k + 2] - (float)((w >> 16) & 255u), t3 = u[4 * k + 3] - (float)(w >> 24);
+            acc = fmaf(t0, t0, acc); acc = fmaf(t1, t1, acc); acc = fmaf(t2, t2, acc); acc = fmaf(t3, t3, acc);
+        }
+        const double sc = (double)run_scale[i];
+        const double lb = sc * (double)sqrtf(acc) * (1.0 - 4e-5) - 0.01 * sc - (double)rs[i];      // (prim_step_kernel has the reasoning)
+        if (fmax(floor_a[i], lb) >= mr_a[i]) need[i] = false;
+    }
+    int slot[PRIM_AHEAD];
+#pragma unroll
+    for (int i = 0; i < PRIM_AHEAD; ++i) {
+        slot[i] = -1;
+        if (need[i]) {
+            slot[i] = atomicAdd(&q_n, 1);
+            q_item[slot[i]] = (unsigned short)(tid * PRIM_AHEAD + i);
+            q_mr[slot[i]] = mr_a[i]; q_floor[slot[i]] = floor_a[i];
+        }
+    }
+    __syncthreads();
+    for (int s = tid; s < q_n; s += PRIM_NT) {
+        const int item = q_item[s], t_own = item / PRIM_AHEAD, i_own = item % PRIM_AHEAD;
+        const int64_t p = (int64_t)blockIdx.x * PRIM_NT + t_own + i_own * stride;
+        double mr = q_mr[s];
+        exact(p, mr, q_floor[s]);
+        q_mr[s] = mr;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < PRIM_AHEAD; ++i) {
+        const int64_t p = p0 + i * stride;
+        if (slot[i] >= 0) mr_a[i] = q_mr[slot[i]];
+        if (act[i] && better(mr_a[i], o_a[i], bw, bj)) { bw = mr_a[i]; bj = o_a[i]; bp = p; }
+    }
+    block_best(bw, bj, bp, sw, sj, sp);
+    if (tid == 0) cand_out[blockIdx.x] = Cand{bw, bj, bp};
+}
+
+// every sleeping point meets the nodes tree_p[upto[g] .. n_tree) in their order: its coordinates in registers, the nodes through LDS
+__global__ __launch_bounds__(256) void lazy_catchup_kernel(PrimArgs a, LazyArgs z, int64_t n_tree)
+{
+    __shared__ double xn[LAZY_NCH][PRIM_FILTER_D];
+    __shared__ double cn[LAZY_NCH];
+    __shared__ int64_t on[LAZY_NCH], tn[LAZY_NCH];
+    __shared__ int64_t s_first;
+    const int tid = threadIdx.x;
+    const int64_t p = (int64_t)blockIdx.x * 256 + tid;
+    const bool inside = p < a.n;
+    double mr = inside ? a.min_reach[p] : -1.0;
+    const int g = inside ? a.gid[p] : 0;
+    const bool mine = inside && mr >= 0.0 && z.asleep[g] != 0;
+    const int64_t my_first = mine ? z.upto[g] : n_tree;
+    if (tid == 0) s_first = n_tree;
+    __syncthreads();
+    if (my_first < n_tree) atomicMin((unsigned long long *)&s_first, (unsigned long long)my_first);
+    __syncthreads();
+    const int64_t j0 = s_first;
+    if (j0 >= n_tree) return;
+    float xp[PRIM_FILTER_D];
+    {
+        const float4 *src = (const float4 *)(z.xrow + (inside ? p : 0) * PRIM_FILTER_D);
+#pragma unroll
+        for (int i = 0; i < PRIM_FILTER_D / 4; ++i) { const float4 t = src[i]; xp[4 * i] = t.x; xp[4 * i + 1] = t.y; xp[4 * i + 2] = t.z; xp[4 * i + 3] = t.w; }
+    }
+    const double cj = inside ? a.core[p] : 0.0;
+    int64_t src_new = -1;
+    for (int64_t jb = j0; jb < n_tree; jb += LAZY_NCH) {
+        const int cnt = (int)(n_tree - jb < LAZY_NCH ? n_tree - jb : LAZY_NCH);
+        __syncthreads();
+        if (tid < cnt) { const int64_t t = z.tree_p[jb + tid]; tn[tid] = t; cn[tid] = a.core[t]; on[tid] = (int64_t)a.orig[t]; }
+        __syncthreads();
+        for (int idx = tid; idx < cnt * PRIM_FILTER_D; idx += 256) xn[idx >> 6][idx & 63] = (double)z.xrow[tn[idx >> 6] * PRIM_FILTER_D + (idx & 63)];
+        __syncthreads();
+        if (!mine) continue;
+        for (int i = 0; i < cnt; ++i) {
+            if (jb + i < my_first) continue;
+            const double floor_cj = fmax(cn[i], cj);
+            if (!(floor_cj < mr)) continue;
+            double acc = 0.0;
+#pragma unroll
+            for (int k = 0; k < PRIM_FILTER_D; ++k) {
+                const double t = xn[i][k] - (double)xp[k];
+                acc = idl_dev::square_then_add(acc, t);      // the scan's arithmetic: product and sum each rounded, in feature order
+            }
+            const double mrd = fmax(floor_cj, __dsqrt_rn(acc));
+            if (mrd < mr) { mr = mrd; src_new = on[i]; }
+        }
+    }
+    if (mine && src_new >= 0) { a.min_reach[p] = mr; a.source[p] = src_new; }
+}
+
+// census, workgroup per group: the smallest min_reach of its points outside the tree and their number
+__global__ __launch_bounds__(256) void lazy_census_kernel(PrimArgs a, LazyArgs z)
+{
+    __shared__ double smin[4];
+    __shared__ long long scnt[4];
+    const int g = blockIdx.x, tid = threadIdx.x;
+    double m = __builtin_inf();
+    long long c = 0;
+    for (int64_t p = z.gfirst[g] + tid; p < z.gfirst[g + 1]; p += 256) {
+        const double mr = a.min_reach[p];
+        if (mr >= 0.0) { m = fmin(m, mr); ++c; }
+    }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { m = fmin(m, __shfl_xor(m, o, 64)); c += __shfl_xor(c, o, 64); }
+    if ((tid & 63) == 0) { smin[tid >> 6] = m; scnt[tid >> 6] = c; }
+    __syncthreads();
+    if (tid == 0) { z.gmin[g] = fmin(fmin(smin[0], smin[1]), fmin(smin[2], smin[3])); z.galive[g] = scnt[0] + scnt[1] + scnt[2] + scnt[3]; }
+}
+
+// who sleeps from now on (one workgroup): groups whose smallest min_reach is well above both the weights being added and the best
+// candidate there is (so that the next step cannot stall); a group with nothing left outside the tree sleeps for good.  With few
+// points left (the tail: noise, joined one by one at rising weights) nobody sleeps.
+__global__ __launch_bounds__(256) void lazy_policy_kernel(PrimArgs a, LazyArgs z, int par, int64_t n_tree, int allow_sleep)
+{
+    __shared__ double sbest[4];
+    __shared__ long long salive[4];
+    const int tid = threadIdx.x, G = z.n_groups;
+    double best = __builtin_inf();
+    long long alive = 0;
+    for (int g = tid; g < G; g += 256) { best = fmin(best, z.gmin[g]); alive += z.galive[g]; }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { best = fmin(best, __shfl_xor(best, o, 64)); alive += __shfl_xor(alive, o, 64); }
+    if ((tid & 63) == 0) { sbest[tid >> 6] = best; salive[tid >> 6] = alive; }
+    __syncthreads();
+    best = fmin(fmin(sbest[0], sbest[1]), fmin(sbest[2], sbest[3]));
+    alive = salive[0] + salive[1] + salive[2] + salive[3];
+    const double ema = z.st[par].ema;
+    const bool tail = !allow_sleep || alive * 32 < a.n;
+    const double theta = fmax(2.0 * ema, 1.5 * best);
+    __shared__ double xcur[PRIM_FILTER_D];
+    if (tid < PRIM_FILTER_D) xcur[tid] = (double)z.xrow[z.st[par].cur_p * PRIM_FILTER_D + tid];
+    __syncthreads();
+    for (int g = tid; g < G; g += 256) {
+        const bool dead = z.galive[g] == 0;
+        // ... and whose ball is as far from where the tree is growing: a loose group (noise) near the tree would be woken by the very
+        // next node that comes within its radius of its centre
+        double d2 = 0.0;
+        for (int k = 0; k < PRIM_FILTER_D; ++k) { const double t = xcur[k] - z.gc[(int64_t)g * PRIM_FILTER_D + k]; d2 += t * t; }
+        const double ball = __dsqrt_rn(d2) - z.gr[g];
+        const bool sleep = dead || (!tail && z.gmin[g] > theta && ball > theta);
+        z.asleep[g] = dead ? 2 : sleep ? 1 : 0;
+        z.minmr[g] = z.gmin[g];
+        z.lbp[g] = __builtin_inf(); z.lbp[G + g] = __builtin_inf();
+        z.upto[g] = n_tree;
+    }
+}
+
+// the per-point and per-run flags of the sleeping groups
+__global__ __launch_bounds__(256) void lazy_flags_kernel(PrimArgs a, LazyArgs z)
+{
+    __shared__ int s_any;
+    const int tid = threadIdx.x;
+    const int64_t p = (int64_t)blockIdx.x * 256 + tid;
+    if (tid == 0) s_any = 0;
+    __syncthreads();
+    bool awake = false;
+    if (p < a.n) {
+        const int sl = z.asleep[a.gid[p]];
+        z.pas[p] = (unsigned char)(sl != 0);
+        awake = sl == 0 && a.min_reach[p] >= 0.0;
+    }
+    if (awake) s_any = 1;
+    __syncthreads();
+    if (tid == 0) z.run_asleep[blockIdx.x] = s_any ? 0 : 1;
+}
+
+__global__ void lazy_init_kernel(PrimArgs a, LazyArgs z)
+{
+    const int64_t n = a.n;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        a.min_reach[i] = i == a.start ? -1.0 : __builtin_inf(); a.source[i] = 1; z.pas[i] = 0;
+        if (i % 256 == 0) z.run_asleep[i / 256] = 0;
+    }
+    if (blockIdx.x == 0) {
+        for (int g = threadIdx.x; g < z.n_groups; g += blockDim.x) {
+            z.asleep[g] = 0; z.upto[g] = 1; z.minmr[g] = __builtin_inf(); z.lbp[g] = __builtin_inf(); z.lbp[z.n_groups + g] = __builtin_inf();
+        }
+        if (threadIdx.x == 0) {
+            LazyState t{};
+            t.n_tree = 1; t.cur_p = a.start; t.cur_o = (long long)a.orig[a.start]; t.cur_w = 0.0; t.ema = 0.0; t.stalled = 0; t.cand_par = 0;
+            z.st[0] = t; z.st[1] = t;
+            z.tree_p[0] = a.start;
+        }
+    }
+}
+
+
+struct LazyLayout { int64_t min_reach, source, cand0, cand1, st, tree_p, run_asleep, pas, asleep, upto, minmr, lbp, gmin, galive, total; };
+
+inline LazyLayout lazy_layout(int64_t n, int n_groups)
+{
+    LazyLayout l{};
+    int64_t o = 0;
+    const int g = prim_grid(n);
+    auto take = [&](int64_t bytes) { const int64_t at = o; o += align256(bytes); return at; };
+    l.min_reach = take(n * 8); l.source = take(n * 8);
+    l.cand0 = take((int64_t)g * (int64_t)sizeof(Cand)); l.cand1 = take((int64_t)g * (int64_t)sizeof(Cand));
+    l.st = take(2 * (int64_t)sizeof(LazyState)); l.tree_p = take(n * 8);
+    l.run_asleep = take((n + 255) / 256); l.pas = take(n);
+    l.asleep = take((int64_t)n_groups * 4); l.upto = take((int64_t)n_groups * 8); l.minmr = take((int64_t)n_groups * 8);
+    l.lbp = take((int64_t)n_groups * 16); l.gmin = take((int64_t)n_groups * 8); l.galive = take((int64_t)n_groups * 8);
+    l.total = o + 256;
+    return l;
+}
+
 }  // namespace
 
 extern "C" {
@@ -384,6 +809,79 @@ int idl_mst_prim_local(const void *xt, int is_f64, const double *core, int64_t n
     a.xt = xt; a.core = core; a.n = n; a.d = d; a.mst_cur = mst_cur; a.mst_next = mst_next; a.mst_w = mst_w;
     a.orig = orig; a.start = start; a.codes = codes; a.resid = resid; a.gid = gid; a.glo = glo; a.gscale = gscale;
     return prim_run(a, is_f64, true, workspace, stream);
+}
+
+int64_t idl_mst_prim_lazy_workspace(int64_t n, int n_groups)
+{
+    if (n < 1 || n_groups < 1) return 256;
+    return lazy_layout(n, n_groups).total;
+}
+
+int idl_mst_prim_lazy(const void *xt, const float *xrow, const double *core, int64_t n, int d, const int32_t *orig, int64_t start,
+                      const uint32_t *codes, const float *resid, const int32_t *gid, const float *glo, const double *gscale, int n_groups,
+                      const int64_t *gfirst, const double *gcentre, const double *gradius, int64_t *mst_cur, int64_t *mst_next,
+                      double *mst_w, void *workspace, void *stream, int64_t *stats3)
+{
+    IDL_REQUIRE(xt && xrow && core && orig && codes && resid && gid && glo && gscale && gfirst && gcentre && gradius, "mst_prim_lazy: NULL buffer");
+    IDL_REQUIRE(mst_cur && mst_next && mst_w && workspace, "mst_prim_lazy: NULL buffer");
+    IDL_REQUIRE(d == PRIM_FILTER_D, "mst_prim_lazy: points must have 64 float32 coordinates");
+    IDL_REQUIRE(n >= 65536 && n * 64 * 4 < (1ll << 31), "mst_prim_lazy: 65536 <= n < 2^23 points");
+    IDL_REQUIRE(n_groups >= 1 && n_groups <= prim_grid(n), "mst_prim_lazy: more groups than workgroups of a step");
+    IDL_REQUIRE((((uintptr_t)workspace) & 255u) == 0 && start >= 0 && start < n, "mst_prim_lazy: workspace alignment / start position");
+    const LazyLayout l = lazy_layout(n, n_groups);
+    unsigned char *w = (unsigned char *)workspace;
+    PrimArgs a{};
+    a.xt = xt; a.core = core; a.n = n; a.d = d; a.mst_cur = mst_cur; a.mst_next = mst_next; a.mst_w = mst_w;
+    a.orig = orig; a.start = start; a.codes = codes; a.resid = resid; a.gid = gid; a.glo = glo; a.gscale = gscale;
+    a.min_reach = (double *)(w + l.min_reach); a.source = (int64_t *)(w + l.source);
+    a.cand[0] = (Cand *)(w + l.cand0); a.cand[1] = (Cand *)(w + l.cand1);
+    LazyArgs z{};
+    z.st = (LazyState *)(w + l.st); z.tree_p = (int64_t *)(w + l.tree_p); z.run_asleep = w + l.run_asleep; z.pas = w + l.pas;
+    z.n_groups = n_groups; z.gfirst = gfirst; z.asleep = (int *)(w + l.asleep); z.upto = (int64_t *)(w + l.upto);
+    z.minmr = (double *)(w + l.minmr); z.lbp = (double *)(w + l.lbp); z.gc = gcentre; z.gr = gradius; z.xrow = xrow;
+    z.gmin = (double *)(w + l.gmin); z.galive = (int64_t *)(w + l.galive);
+    const hipStream_t st = (hipStream_t)stream;
+    const int grid = prim_grid(n);
+    const unsigned runs = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(lazy_init_kernel, dim3(256), dim3(256), 0, st, a, z);
+    int64_t launch = 0, stalls = 0, censuses = 0;
+    hipLaunchKernelGGL(lazy_step_kernel, dim3(grid), dim3(PRIM_NT), 0, st, a, z, launch, 1); ++launch;       // the first scan: cur = the start
+    // the steps are queued in chunks; after each the host looks at the state: done, stalled, or time for a census
+    static const int chunk = getenv("IDELUCS_MST_CHUNK") ? atoi(getenv("IDELUCS_MST_CHUNK")) : 512;
+    static const int64_t census_every = getenv("IDELUCS_MST_CENSUS") ? atoll(getenv("IDELUCS_MST_CENSUS")) : 16384;
+    static const bool sleep_on = !(getenv("IDELUCS_MST_SLEEP") && atoi(getenv("IDELUCS_MST_SLEEP")) == 0);
+    int64_t last_census = 0, last_stall_at = -1000000, quick = 0, no_sleep_until = 0;
+    LazyState S{};
+    for (;;) {
+        for (int i = 0; i < chunk; ++i) { hipLaunchKernelGGL(lazy_step_kernel, dim3(grid), dim3(PRIM_NT), 0, st, a, z, launch, 0); ++launch; }
+        IDL_HIP_TRY(hipMemcpyAsync(&S, z.st + (launch & 1), sizeof(S), hipMemcpyDeviceToHost, st));
+        IDL_HIP_TRY(hipStreamSynchronize(st));
+        if (S.n_tree >= n) break;
+        if (launch > 3 * n + (1 << 22)) { idl::set_error("mst_prim_lazy: no progress (%lld nodes after %lld launches)", (long long)S.n_tree, (long long)launch); return IDL_ERR_HIP; }
+        const bool first = last_census == 0 && S.n_tree >= 1024;
+        if (!(S.stalled || first || S.n_tree - (last_census ? last_census : 1) >= census_every)) continue;
+        if (S.stalled) {
+            ++stalls;
+            if (S.n_tree - last_stall_at < 256) { if (++quick > 16) { no_sleep_until = S.n_tree + 32768; quick = 0; } } else quick = 0;
+            last_stall_at = S.n_tree;
+        }
+        ++censuses;
+        static const bool dbg = getenv("IDELUCS_MST_DEBUG") != nullptr;
+        if (dbg && (censuses < 60 || censuses % 100 == 0))
+            fprintf(stderr, "[idl] lazy prim: census %lld at launch %lld: n_tree %lld stalled %d cur_w %.6g ema %.6g quick %lld no_sleep_until %lld\n",
+                    (long long)censuses, (long long)launch, (long long)S.n_tree, S.stalled, S.cur_w, S.ema, (long long)quick, (long long)no_sleep_until);
+        hipLaunchKernelGGL(lazy_catchup_kernel, dim3(runs), dim3(256), 0, st, a, z, (int64_t)S.n_tree);
+        hipLaunchKernelGGL(lazy_census_kernel, dim3((unsigned)n_groups), dim3(256), 0, st, a, z);
+        hipLaunchKernelGGL(lazy_policy_kernel, dim3(1), dim3(256), 0, st, a, z, (int)(launch & 1), (int64_t)S.n_tree,
+                           (sleep_on && S.n_tree >= no_sleep_until) ? 1 : 0);
+        hipLaunchKernelGGL(lazy_flags_kernel, dim3(runs), dim3(256), 0, st, a, z);
+        if (S.stalled) { S.stalled = 0; IDL_HIP_TRY(hipMemcpyAsync(z.st + (launch & 1), &S, sizeof(S), hipMemcpyHostToDevice, st)); IDL_HIP_TRY(hipStreamSynchronize(st)); }
+        hipLaunchKernelGGL(lazy_step_kernel, dim3(grid), dim3(PRIM_NT), 0, st, a, z, launch, 1); ++launch;   // candidates of the awake set
+        last_census = S.n_tree;
+    }
+    IDL_HIP_TRY(hipGetLastError());
+    if (stats3) { stats3[0] = launch; stats3[1] = stalls; stats3[2] = censuses; }
+    return IDL_OK;
 }
 
 }  // extern "C"

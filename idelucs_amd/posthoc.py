@@ -412,6 +412,7 @@ def core_distances_device(x64, k, device, f32_exact=None, stats=None, order=None
     return core
 
 
+MST_LAZY_MIN = 65536             # points from which groups of points may sleep during Prim's scan (idl_mst_prim_lazy)
 MST_FILTER_MIN = 20000           # points from which Prim's scan goes through the 8-bit lower-bound filter
 
 
@@ -496,9 +497,33 @@ def hdbscan_device(points, min_cluster_size, device=None, stats=None):
         orig, gid32 = perm.to(torch.int32), gid.to(torch.int32)
         start = int(torch.nonzero(perm == 0)[0, 0])
         del xo
-        _lib.check(L.idl_mst_prim_local(vp(xt.data_ptr()), 0 if f32_exact else 1, vp(core_o.data_ptr()), n, d, vp(orig.data_ptr()), start,
-                                        vp(codes.data_ptr()), vp(resid.data_ptr()), vp(gid32.data_ptr()), vp(glo.data_ptr()),
-                                        vp(gscale.data_ptr()), vp(cur.data_ptr()), vp(nxt.data_ptr()), vp(w.data_ptr()), vp(ws.data_ptr() + off), stream))
+        n_groups = int(gid32[-1]) + 1
+        mode = os.environ.get("IDELUCS_MST", "lazy")
+        if mode == "lazy" and f32_exact and d == 64 and n >= MST_LAZY_MIN and n * 256 < (1 << 31) and n_groups <= min(1024, -(-n // 256)):
+            # groups of points may sleep while the tree grows elsewhere (idl_mst_prim_lazy): a ball around every group, the points row-major
+            xo = x64[perm]
+            cnt = torch.bincount(gid, minlength=n_groups)
+            gfirst = torch.zeros(n_groups + 1, dtype=torch.int64, device=dev)
+            gfirst[1:] = torch.cumsum(cnt, 0)
+            gc = torch.zeros((n_groups, d), dtype=torch.float64, device=dev).index_add_(0, gid, xo) / cnt.clamp_min(1)[:, None].double()
+            rad = (xo - gc[gid]).pow_(2).sum(1).sqrt_()
+            gr = torch.zeros(n_groups, dtype=torch.float64, device=dev).scatter_reduce_(0, gid, rad, "amax")
+            gr = gr * (1.0 + 1e-9) + 1e-9 * (float(xo.abs().max()) + 1.0)
+            xrow = xo.to(torch.float32).contiguous()
+            del xo, rad
+            ws2 = torch.empty(int(L.idl_mst_prim_lazy_workspace(n, n_groups)) + 256, dtype=torch.uint8, device=dev)
+            off2 = (-ws2.data_ptr()) % 256
+            st3 = (ctypes.c_int64 * 3)()
+            _lib.check(L.idl_mst_prim_lazy(vp(xt.data_ptr()), vp(xrow.data_ptr()), vp(core_o.data_ptr()), n, d, vp(orig.data_ptr()), start,
+                                           vp(codes.data_ptr()), vp(resid.data_ptr()), vp(gid32.data_ptr()), vp(glo.data_ptr()), vp(gscale.data_ptr()),
+                                           n_groups, vp(gfirst.data_ptr()), vp(gc.data_ptr()), vp(gr.data_ptr()), vp(cur.data_ptr()), vp(nxt.data_ptr()),
+                                           vp(w.data_ptr()), vp(ws2.data_ptr() + off2), stream, ctypes.cast(st3, ctypes.c_void_p)))
+            if stats is not None:
+                stats["prim_launches"], stats["prim_stalls"], stats["prim_censuses"] = int(st3[0]), int(st3[1]), int(st3[2])
+        else:
+            _lib.check(L.idl_mst_prim_local(vp(xt.data_ptr()), 0 if f32_exact else 1, vp(core_o.data_ptr()), n, d, vp(orig.data_ptr()), start,
+                                            vp(codes.data_ptr()), vp(resid.data_ptr()), vp(gid32.data_ptr()), vp(glo.data_ptr()),
+                                            vp(gscale.data_ptr()), vp(cur.data_ptr()), vp(nxt.data_ptr()), vp(w.data_ptr()), vp(ws.data_ptr() + off), stream))
     else:
         xt = x64.t().contiguous().to(torch.float32 if f32_exact else torch.float64)
         _lib.check(L.idl_mst_prim(vp(xt.data_ptr()), 0 if f32_exact else 1, vp(core.data_ptr()), n, d, vp(cur.data_ptr()), vp(nxt.data_ptr()),

@@ -123,3 +123,30 @@ def test_filtered_prim_is_sklearns(monkeypatch):
     labels, prob = posthoc.hdbscan_device(x, 61)
     assert np.array_equal(labels < 0, ref.labels_ < 0) and adjusted_rand_score(ref.labels_, labels) == 1.0
     assert np.allclose(prob, ref.probabilities_, atol=1e-9)
+
+
+@pytest.mark.parametrize("tight", [False, True])
+def test_lazy_prim_builds_the_same_tree(monkeypatch, tight):
+    """idl_mst_prim_lazy lets groups of points sleep while the tree grows elsewhere and has them catch up when the weight being
+    added reaches their bound: the edges -- nodes, order, float64 weights -- are those of the scan that visits every point at
+    every step; on Gaussian blobs and on tight far-apart clusters with background noise (many stalls at the end)."""
+    from idelucs_amd import posthoc
+    rng = np.random.default_rng(9)
+    n = 70000
+    centres = rng.normal(size=(6, 64)) * (30.0 if tight else 2.5)
+    truth = rng.integers(0, 6, n)
+    x = centres[truth] + rng.normal(size=(n, 64)) * (0.05 if tight else 0.6)
+    x[: n // 50] = rng.uniform(-60, 60, size=(n // 50, 64)) if tight else rng.uniform(-8, 8, size=(n // 50, 64))
+    x = x.astype(np.float32).astype(np.float64)
+    k = n // 100 + 1
+    lazy, plain = {}, {}
+    monkeypatch.setenv("IDELUCS_MST", "lazy")
+    l1, p1 = posthoc.hdbscan_device(x, k, stats=lazy)
+    assert "prim_stalls" in lazy, "the lazy path did not run"
+    print({kk: lazy[kk] for kk in ("prim_launches", "prim_stalls", "prim_censuses", "prim_s")})
+    monkeypatch.setenv("IDELUCS_MST", "local")
+    l2, p2 = posthoc.hdbscan_device(x, k, stats=plain)
+    a, b = lazy["mst_edges"], plain["mst_edges"]
+    for f in ("current_node", "next_node", "distance"):
+        assert np.array_equal(a[f], b[f]), f
+    assert np.array_equal(l1, l2) and np.array_equal(p1, p2)

@@ -21,7 +21,7 @@ def main():
         t0 = time.time()
         labels, prob = posthoc.hdbscan_device(x, n // 100 + 1, stats=stats)
         wall = time.time() - t0
-        keep = {k: (round(v, 2) if isinstance(v, float) else v) for k, v in stats.items() if k in ("core_s", "prim_s", "tree_s", "missed")}
+        keep = {k: (round(v, 2) if isinstance(v, float) else v) for k, v in stats.items() if k in ("core_s", "prim_s", "tree_s", "missed", "prim_launches", "prim_stalls", "prim_censuses")}
         print(f"n = {n}: {wall:.1f} s  {keep}  clusters {len(np.unique(labels[labels >= 0]))}  noise {float((labels < 0).mean()):.3f}", flush=True)
 
 

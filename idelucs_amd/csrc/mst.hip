@@ -599,7 +599,7 @@ __global__ __launch_bounds__(PRIM_NT, 1024 / PRIM_NT) void lazy_step_kernel(Prim
 // every sleeping point meets the nodes tree_p[upto[g] .. n_tree) in their order: its coordinates in registers, the nodes through LDS
 __global__ __launch_bounds__(256) void lazy_catchup_kernel(PrimArgs a, LazyArgs z, int64_t n_tree)
 {
-    __shared__ double xn[LAZY_NCH][PRIM_FILTER_D];
+    __shared__ float xn[LAZY_NCH][PRIM_FILTER_D];
     __shared__ double cn[LAZY_NCH];
     __shared__ int64_t on[LAZY_NCH], tn[LAZY_NCH];
     __shared__ int64_t s_first;
@@ -629,17 +629,29 @@ __global__ __launch_bounds__(256) void lazy_catchup_kernel(PrimArgs a, LazyArgs 
         __syncthreads();
         if (tid < cnt) { const int64_t t = z.tree_p[jb + tid]; tn[tid] = t; cn[tid] = a.core[t]; on[tid] = (int64_t)a.orig[t]; }
         __syncthreads();
-        for (int idx = tid; idx < cnt * PRIM_FILTER_D; idx += 256) xn[idx >> 6][idx & 63] = (double)z.xrow[tn[idx >> 6] * PRIM_FILTER_D + (idx & 63)];
+        for (int idx = tid; idx < cnt * PRIM_FILTER_D; idx += 256) xn[idx >> 6][idx & 63] = z.xrow[tn[idx >> 6] * PRIM_FILTER_D + (idx & 63)];
         __syncthreads();
         if (!mine) continue;
         for (int i = 0; i < cnt; ++i) {
             if (jb + i < my_first) continue;
             const double floor_cj = fmax(cn[i], cj);
             if (!(floor_cj < mr)) continue;
+            // the distance in float32 first (differences of float32 values, 64 fused multiply-adds: within 1e-5 of the true one): when
+            // even that less its error cannot undercut min_reach, the exact one changes nothing
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            f32x2 s0 = {0.f, 0.f}, s1 = {0.f, 0.f};           // (packed, two chains: only a bound, any order of summation does)
+#pragma unroll
+            for (int k = 0; k < PRIM_FILTER_D; k += 4) {
+                const f32x2 t0 = f32x2{xn[i][k], xn[i][k + 1]} - f32x2{xp[k], xp[k + 1]};
+                const f32x2 t1 = f32x2{xn[i][k + 2], xn[i][k + 3]} - f32x2{xp[k + 2], xp[k + 3]};
+                s0 = __builtin_elementwise_fma(t0, t0, s0); s1 = __builtin_elementwise_fma(t1, t1, s1);
+            }
+            const float acc32 = (s0.x + s0.y) + (s1.x + s1.y);
+            if (fmax(floor_cj, (double)sqrtf(acc32) * (1.0 - 2e-5)) >= mr) continue;
             double acc = 0.0;
 #pragma unroll
             for (int k = 0; k < PRIM_FILTER_D; ++k) {
-                const double t = xn[i][k] - (double)xp[k];
+                const double t = (double)xn[i][k] - (double)xp[k];
                 acc = idl_dev::square_then_add(acc, t);      // the scan's arithmetic: product and sum each rounded, in feature order
             }
             const double mrd = fmax(floor_cj, __dsqrt_rn(acc));

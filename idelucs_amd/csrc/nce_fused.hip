@@ -238,6 +238,46 @@ __global__ __launch_bounds__(256) void nce_pass2_batched_kernel(const unsigned c
     nce_pass2_body(p.f, p.m, p.inv_t, p.rowsum_part, p.pos, p.lse, p.loss_rows, p.G_part, p.iic);
 }
 
+
+// The IIC joint P0 = z[0:m/2]^T z[m/2:m] (reference LossFunctions.py:57-58) for any n_clusters: a workgroup of four waves per 16 x 16
+// tile, the batch dimension dealt to the waves and taken in steps of four through v_mfma_f32_16x16x4_f32.  For n_clusters <= 48 the spare workgroups of InfoNCE pass 1 do this;
+// above, it was a [C, m/2] x [m/2, C] GEMM whose library heuristic (untuned: short jobs) runs it on ONE workgroup, 118 us at C = 200.
+__global__ __launch_bounds__(256) void iic_joint_kernel(const float *__restrict__ z, int m, int C, float *__restrict__ P0)
+{
+    __shared__ float part[3][64][4];
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, l = lane & 15, q = lane >> 4;
+    const int c1 = blockIdx.x * 16, c2 = blockIdx.y * 16, half = m / 2;
+    const bool ok1 = c1 + l < C, ok2 = c2 + l < C;
+    // the batch rows are dealt to the four waves in blocks of 128 (32 MFMA steps: every load of a block is in flight before its first use)
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    for (int kb = 128 * wv; kb < half; kb += 512) {
+        const float *za = z + (size_t)(kb + q) * C + (ok1 ? c1 + l : 0);             // A[i = l][k = q] = z[b = kb + 4 u + q][c1 + l]
+        const float *zb = z + (size_t)(half + kb + q) * C + (ok2 ? c2 + l : 0);      // B[k = q][j = l] = z[m/2 + b][c2 + l]
+        float av[32], bv[32];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) {
+            const bool in = kb + 4 * u + q < half;
+            av[u] = (ok1 && in) ? za[(size_t)(4 * u) * C] : 0.f;
+            bv[u] = (ok2 && in) ? zb[(size_t)(4 * u) * C] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 32; u += 2) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u + 1], bv[u + 1], acc1, 0, 0, 0);
+        }
+    }
+    f32x4 acc = acc0 + acc1;
+    if (wv > 0) { part[wv - 1][lane][0] = acc[0]; part[wv - 1][lane][1] = acc[1]; part[wv - 1][lane][2] = acc[2]; part[wv - 1][lane][3] = acc[3]; }
+    __syncthreads();
+    if (wv == 0 && ok2) {
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int r = c1 + 4 * q + reg;
+            if (r < C) P0[(size_t)r * C + c2 + l] = ((acc[reg] + part[0][lane][reg]) + part[1][lane][reg]) + part[2][lane][reg];
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -288,6 +328,15 @@ int idl_nce_fused_iic(const float *f, int m, float temperature, float *lse, floa
 {
     IDL_REQUIRE(P0 && iic_scratch && out && C >= 1 && C <= 48, "nce_fused_iic: n_clusters must be in 1..48 (larger: idl_iic_core)");
     return nce_launch(f, m, temperature, lse, loss_rows, G_part, workspace, IicJob{P0, C, lamb, eps, w_iic, iic_scratch, out, nullptr}, stream);
+}
+
+int idl_iic_joint(const float *z, int m, int C, float *P0, void *stream)
+{
+    IDL_REQUIRE(z && P0 && C >= 1 && C <= 4096 && m >= 2 && (m % 2) == 0, "iic_joint: NULL buffer, n_clusters outside 1..4096 or an odd batch");
+    const unsigned t = (unsigned)((C + 15) / 16);
+    hipLaunchKernelGGL(iic_joint_kernel, dim3(t, t), dim3(256), 0, (hipStream_t)stream, z, m, C, P0);
+    IDL_HIP_TRY(hipGetLastError());
+    return IDL_OK;
 }
 
 int idl_nce_pass1_joint(const float *f, int m, float temperature, void *workspace, const float *z, float *P0, int C, void *stream)

@@ -256,7 +256,7 @@ class FusedLinearTrainer:
         else:
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                torch.mm(bf.z[:m // 2].t(), bf.z[m // 2:], out=bf.P0)
+                chk(_L.idl_iic_joint(_p(bf.z), m, C, _p(bf.P0), _stream()))       # (a library GEMM here: 118 us untuned at C = 200)
                 chk(_L.idl_iic_core(_p(bf.P0), C, self.lamb, EPS, self.weight, _p(bf.iic_scratch), _p(self.out), _stream()))
             if bf.nce_fused:       # S = f f^T, lse, E + E^T and (E + E^T) f in two MFMA kernels, S never written
                 chk(_L.idl_nce_fused(_p(bf.f), m, TEMPERATURE, _p(bf.lse), _p(bf.loss_rows), _p(bf.G), _p(bf.nce_ws), _stream()))

@@ -1034,3 +1034,20 @@ def test_train_voters_batched_on_other_shapes(dev, kw):
     assert not np.array_equal(out[0][3], out[1][3])
     y_last = model.predict()[0]
     assert np.array_equal(y_last, out[2][1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("m,C", [(1024, 200), (1024, 37), (96, 5), (1000, 64)])
+def test_iic_joint_kernel_equals_the_product(m, C):
+    """idl_iic_joint: P0 = z[0:m/2]^T z[m/2:m] (reference LossFunctions.py:57-58) on one wave per 16 x 16 MFMA tile, for any
+    n_clusters and any even batch (ragged tiles, a batch half that is not a multiple of 32)."""
+    import ctypes
+    import torch
+    from idelucs_amd import _lib
+    g = torch.Generator(device="cpu"); g.manual_seed(m + C)
+    z = torch.softmax(torch.randn(m, C, generator=g), 1).cuda()
+    P0 = torch.full((C, C), -1.0, device="cuda")
+    _lib.check(_lib.lib.idl_iic_joint(ctypes.c_void_p(z.data_ptr()), m, C, ctypes.c_void_p(P0.data_ptr()),
+                                      ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    want = (z[:m // 2].double().t() @ z[m // 2:].double())
+    assert torch.allclose(P0.double(), want, rtol=1e-5, atol=1e-7)

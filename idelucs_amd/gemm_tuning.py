@@ -8,8 +8,10 @@ n_clusters=20 -- idelucs_amd/tunableop_gfx950.csv, valid for this image's PyTorc
 versions, re-tuned automatically when TunableOp's validators do not match) and leaves online tuning
 enabled for any other shape (a few hundred ms per new GEMM shape, once per process).
 
-IDELUCS_TUNABLEOP=0 disables it; =1 forces it on.  By default it is enabled for jobs with at least
-MIN_STEPS optimizer steps (tuning unseen shapes costs more than it saves on tiny jobs).
+IDELUCS_TUNABLEOP=0 disables it; =1 forces tuning on.  By default TUNING is on for jobs with at least MIN_STEPS optimizer steps
+(tuning unseen shapes costs more than it saves on tiny jobs); shorter jobs still USE the shipped solutions for the shapes they
+cover (the layer-1 product of the default shape: 32.6 us instead of the heuristic's 41) and run everything else on the library's
+heuristic.
 """
 import atexit
 import os
@@ -19,6 +21,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 SEED_FILE = os.path.join(_HERE, "tunableop_gfx950.csv")
 MIN_STEPS = 3000
 _enabled = False
+_tuning = False
 
 
 def _unlink_quietly(path):
@@ -29,16 +32,20 @@ def _unlink_quietly(path):
 
 
 def maybe_enable(total_steps=None):
-    global _enabled
+    global _enabled, _tuning
     mode = os.environ.get("IDELUCS_TUNABLEOP", "auto")
-    if _enabled or mode == "0":
-        return _enabled
-    if mode != "1" and (total_steps is None or total_steps < MIN_STEPS):
+    if mode == "0":
         return False
+    tune = mode == "1" or (total_steps is not None and total_steps >= MIN_STEPS)
     try:
         import torch.cuda.tunable as tn
     except ImportError:
         return False
+    if _enabled:
+        if tune and not _tuning:                              # a longer job in the same process
+            tn.tuning_enable(True)
+            _tuning = True
+        return True
     # one result file per process (ranks of a multi-GPU job must not share one), seeded from the shipped solutions
     dump = os.environ.get("IDELUCS_TUNABLEOP_DUMP")     # maintainers: write the tuned solutions there at exit (to refresh SEED_FILE)
     if dump:
@@ -55,10 +62,11 @@ def maybe_enable(total_steps=None):
                 out.write(src.read())
     tn.set_filename(path, insert_device_ordinal=False)
     tn.enable(True)
-    tn.tuning_enable(True)
+    tn.tuning_enable(tune)                                    # a short job: the shipped solutions are used, nothing is tuned
     if hasattr(tn, "write_file_on_exit"):
         tn.write_file_on_exit(bool(dump))
     _enabled = True
+    _tuning = tune
     return True
 
 
@@ -66,7 +74,9 @@ def stop_tuning():
     """After the training loop: keep using the solutions found, but do not tune the shapes that follow -- the post-hoc stages
     (silhouette, HDBSCAN core distances) run a handful of [4096 x 10^6]-sized GEMMs, and timing hundreds of candidate kernels on
     each of those shapes cost 230 s at cfg5 (measured: HDBSCAN 169 -> 104 s, metrics 180 -> 10 s without it)."""
+    global _tuning
     if not _enabled:
         return
     import torch.cuda.tunable as tn
     tn.tuning_enable(False)
+    _tuning = False

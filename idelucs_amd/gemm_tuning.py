@@ -8,10 +8,11 @@ n_clusters=20 -- idelucs_amd/tunableop_gfx950.csv, valid for this image's PyTorc
 versions, re-tuned automatically when TunableOp's validators do not match) and leaves online tuning
 enabled for any other shape (a few hundred ms per new GEMM shape, once per process).
 
-IDELUCS_TUNABLEOP=0 disables it; =1 forces tuning on.  By default TUNING is on for jobs with at least MIN_STEPS optimizer steps
-(tuning unseen shapes costs more than it saves on tiny jobs); shorter jobs still USE the shipped solutions for the shapes they
-cover (the layer-1 product of the default shape: 32.6 us instead of the heuristic's 41) and run everything else on the library's
-heuristic.
+IDELUCS_TUNABLEOP=0 disables it; =1 forces tuning on.  By default TUNING is on only for jobs of at least MIN_STEPS optimizer steps:
+on the reference's own example (Influenza-A.fas, 949 sequences, the CLI's defaults: 5 voters x 100 epochs = 3 000 steps) tuning
+the partial-batch and batched-voter shapes took 6.1 s of an 8.6 s run that needs 2.6 s without it.  Shorter jobs still USE the
+shipped solutions for the shapes they cover (the layer-1 product of the default shape: 32.6 us instead of the heuristic's 41) and
+run everything else on the library's heuristic.
 """
 import atexit
 import os
@@ -19,7 +20,7 @@ import tempfile
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SEED_FILE = os.path.join(_HERE, "tunableop_gfx950.csv")
-MIN_STEPS = 3000
+MIN_STEPS = 400000     # tuning the ~8 unseeded shapes of a job costs 4-6 s; tuned they save ~10 us a step
 _enabled = False
 _tuning = False
 

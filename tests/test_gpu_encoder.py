@@ -437,11 +437,25 @@ def test_graph_replay_equals_eager_at_cfg2_shape(dev, C, n):
 def test_batched_voters_step_like_single_voters(dev, n, use_graph):
     """fused.BatchedLinearTrainer (three voters in lockstep: batched GEMMs + recorded launches with the voter index in the grid)
     against three FusedLinearTrainer runs of the same voters: same initial weights, same permutations (one generator per voter),
-    same dropout streams.  Only the GEMM kernels differ (batched vs plain: another summation order), so after a whole epoch
-    (8 or 24 full batches + a partial one) the parameters agree to a few 1e-4 of their scale and the losses to 1e-4."""
+    same dropout streams -- after a whole epoch (8 or 24 full batches + a partial one) the parameters agree to a few 1e-4 of their
+    scale and the losses to 1e-4.  That needs the library GEMMs of both sides to be the heuristic's: the first RMSprop steps from a
+    fresh state move every weight by ~10 lr in the direction of its gradient's sign, and a rounding difference in the layer-1
+    product (a shipped TunableOp solution on one side, the strided-batched kernel on the other) grows by 3-40 x per step (3.8e-5 of
+    W1 after one step, 1.9e-2 after four: measured) -- two valid runs, no longer comparable element by element.  TunableOp is
+    therefore off inside this test."""
     import copy
     import torch
+    import torch.cuda.tunable as tunable
     from idelucs_amd.fused import FusedLinearTrainer, BatchedLinearTrainer
+    was_on = tunable.is_enabled()
+    tunable.enable(False)
+    try:
+        _batched_like_single(dev, n, use_graph, copy, torch, FusedLinearTrainer, BatchedLinearTrainer)
+    finally:
+        tunable.enable(was_on)
+
+
+def _batched_like_single(dev, n, use_graph, copy, torch, FusedLinearTrainer, BatchedLinearTrainer):
     store, net0 = _cfg2_store_and_net(dev, n, seed=4)
     B, L = 512, 3
     nets_a, nets_b = [], []

@@ -125,18 +125,26 @@ def test_filtered_prim_is_sklearns(monkeypatch):
     assert np.allclose(prob, ref.probabilities_, atol=1e-9)
 
 
-@pytest.mark.parametrize("tight", [False, True])
-def test_lazy_prim_builds_the_same_tree(monkeypatch, tight):
+@pytest.mark.parametrize("kind", ["blobs", "tight", "duplicates", "uniform"])
+def test_lazy_prim_builds_the_same_tree(monkeypatch, kind):
     """idl_mst_prim_lazy lets groups of points sleep while the tree grows elsewhere and has them catch up when the weight being
     added reaches their bound: the edges -- nodes, order, float64 weights -- are those of the scan that visits every point at
-    every step; on Gaussian blobs and on tight far-apart clusters with background noise (many stalls at the end)."""
+    every step; on Gaussian blobs, on tight far-apart clusters with background noise (stalls at every change of cluster), with
+    half of the points exact copies of others (runs of equal weights: ties go by the original number) and on structureless data
+    (nobody can sleep)."""
     from idelucs_amd import posthoc
     rng = np.random.default_rng(9)
     n = 70000
-    centres = rng.normal(size=(6, 64)) * (30.0 if tight else 2.5)
-    truth = rng.integers(0, 6, n)
-    x = centres[truth] + rng.normal(size=(n, 64)) * (0.05 if tight else 0.6)
-    x[: n // 50] = rng.uniform(-60, 60, size=(n // 50, 64)) if tight else rng.uniform(-8, 8, size=(n // 50, 64))
+    if kind == "uniform":
+        x = rng.uniform(-1, 1, size=(n, 64))
+    else:
+        tight = kind == "tight"
+        centres = rng.normal(size=(6, 64)) * (30.0 if tight else 2.5)
+        truth = rng.integers(0, 6, n)
+        x = centres[truth] + rng.normal(size=(n, 64)) * (0.05 if tight else 0.6)
+        x[: n // 50] = rng.uniform(-60, 60, size=(n // 50, 64)) if tight else rng.uniform(-8, 8, size=(n // 50, 64))
+        if kind == "duplicates":
+            x[n // 2:] = x[rng.integers(0, n // 2, n - n // 2)]
     x = x.astype(np.float32).astype(np.float64)
     k = n // 100 + 1
     lazy, plain = {}, {}

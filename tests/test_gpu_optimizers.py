@@ -142,3 +142,28 @@ def test_carried_state_refuses_a_sharded_run(monkeypatch):
     model = models.IID_model(_args("RMSprop", None))
     with pytest.raises(ValueError, match="every voter on one rank"):
         training.train_voters(model, [1], 1, n_voters=2, progress=False)
+
+
+@pytest.mark.gpu
+def test_gemm_tuning_only_from_long_jobs(monkeypatch):
+    """idelucs_amd.gemm_tuning: a job of fewer than MIN_STEPS optimizer steps USES the shipped GEMM solutions (TunableOp enabled) but
+    tunes nothing -- on the reference's own 949-sequence example the CLI's defaults are 3 000 steps, and tuning their partial-batch
+    and batched-voter shapes took 6 of the run's 8.6 s; a longer job in the same process switches tuning on; stop_tuning() ends it."""
+    import torch.cuda.tunable as tn
+    from idelucs_amd import gemm_tuning as g
+    monkeypatch.delenv("IDELUCS_TUNABLEOP", raising=False)
+    saved = (g._enabled, g._tuning, tn.is_enabled(), tn.tuning_is_enabled())
+    try:
+        assert g.MIN_STEPS >= 100000
+        assert g.maybe_enable(3000) and tn.is_enabled()
+        if not saved[1]:
+            assert not g._tuning and not tn.tuning_is_enabled()
+        assert g.maybe_enable(g.MIN_STEPS) and g._tuning and tn.tuning_is_enabled()
+        g.stop_tuning()
+        assert not g._tuning and not tn.tuning_is_enabled() and tn.is_enabled()
+        monkeypatch.setenv("IDELUCS_TUNABLEOP", "0")
+        assert g.maybe_enable(10 ** 9) is False
+    finally:
+        g._tuning = saved[1]
+        tn.tuning_enable(saved[3])
+        tn.enable(saved[2] or g._enabled)

@@ -158,3 +158,21 @@ def test_lazy_prim_builds_the_same_tree(monkeypatch, kind):
     for f in ("current_node", "next_node", "distance"):
         assert np.array_equal(a[f], b[f]), f
     assert np.array_equal(l1, l2) and np.array_equal(p1, p2)
+
+
+def test_core_distances_when_no_bracket_exists(monkeypatch):
+    """k close to n (no room for the upper rank of the bracket in the sample): the window path declines and the float64 matrix
+    path answers; forced window mode says so."""
+    import torch
+    from idelucs_amd import posthoc
+    x = _blobs(5003, seed=21)
+    dev = torch.device("cuda")
+    xd = torch.from_numpy(x).to(dev)
+    k = 4990
+    monkeypatch.setattr(posthoc, "KNN_WINDOW_MIN", 0)
+    got = posthoc.core_distances_device(xd, k, dev).cpu().numpy()
+    rows = np.arange(0, 5003, 500)
+    assert np.array_equal(got[rows], _kth_by_definition(x, rows, k))
+    monkeypatch.setenv("IDELUCS_KNN", "window")
+    with pytest.raises(ValueError):
+        posthoc.core_distances_device(xd, k, dev)

@@ -356,7 +356,8 @@ int prim_run(PrimArgs a, int is_f64, bool filter, void *workspace, void *stream)
 // loop: a thread keeps its point's 64 coordinates in registers, the nodes stream through LDS 32 at a time, and every distance is
 // formed exactly (no bound, no gather) at the f64 VALU rate instead of the memory system's.  A census then decides who sleeps next
 // (groups whose smallest min_reach is well above the weights being added), a re-scan of the last node rebuilds the candidates, and
-// the steps go on.  Same tree, edge for edge (tests compare with the plain scan).
+// the steps go on.  Same tree, edge for edge (tests compare with the plain scan).  (Launching only the workgroups that have a waking
+// run -- a list made at the census -- was measured: 12.8 us a step against 12.2; the workgroups that leave at once cost nothing.)
 struct LazyState {
     long long n_tree;          // nodes in the tree (the start included)
     long long cur_p, cur_o;    // the node added last: position, original number

@@ -234,6 +234,27 @@ __attribute__((target("avx2"))) inline void pack32_avx2(const uint8_t *p, uint32
     w[0] = (uint32_t)_mm256_extract_epi32(g, 0);
     w[1] = (uint32_t)_mm256_extract_epi32(g, 4);
 }
+
+// ---- and with AVX-512 a whole slot at a time: 64 valid bases -> the slot's four code words in one 16-byte store
+inline bool host_has_avx512() { static const bool h = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512bw"); return h; }
+
+__attribute__((target("avx512f,avx512bw"))) inline bool pack64_avx512(const uint8_t *p, uint32_t *w4)
+{
+    const __m512i v = _mm512_loadu_si512((const void *)p);
+    const __mmask64 ok = _mm512_cmpeq_epi8_mask(v, _mm512_set1_epi8('A')) | _mm512_cmpeq_epi8_mask(v, _mm512_set1_epi8('C')) |
+                         _mm512_cmpeq_epi8_mask(v, _mm512_set1_epi8('G')) | _mm512_cmpeq_epi8_mask(v, _mm512_set1_epi8('T'));
+    if (ok != ~(__mmask64)0) return false;
+    __m512i c = _mm512_and_si512(_mm512_srli_epi16(v, 1), _mm512_set1_epi8(3));                  // A0 C1 G3 T2
+    c = _mm512_xor_si512(c, _mm512_and_si512(_mm512_srli_epi16(c, 1), _mm512_set1_epi8(1)));     // A0 C1 G2 T3
+    const __m512i p2 = _mm512_maddubs_epi16(c, _mm512_set1_epi16(0x0104));      // bytes (b0, b1) -> b0 * 4 + b1
+    const __m512i p4 = _mm512_madd_epi16(p2, _mm512_set1_epi32(0x00010010));     // (q0, q1) -> q0 * 16 + q1: 4 bases per 32-bit lane, first on top
+    // per 128-bit lane: the low bytes of its four 32-bit lanes, the FIRST most significant, into its first dword; then the four dwords together
+    const __m512i sh = _mm512_broadcast_i32x4(_mm_setr_epi8(12, 8, 4, 0, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1));
+    const __m512i g = _mm512_shuffle_epi8(p4, sh);
+    const __m512i idx = _mm512_setr_epi32(0, 4, 8, 12, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0);
+    _mm_storeu_si128((__m128i *)w4, _mm512_castsi512_si128(_mm512_permutexvar_epi32(idx, g)));
+    return true;
+}
 #else
 #define IDL_HAVE_AVX2_PATH 0
 #endif
@@ -283,6 +304,15 @@ inline void walk_record_pack(const uint8_t *buf, const Rec &r, Packer &pk, uint8
             while (b > a && py_bytes_space(b[-1])) --b;
             while (a < b) {
 #if IDL_HAVE_AVX2_PATH
+                if (pk.j == 0 && (pk.w & 3) == 0 && b - a >= 64 && host_has_avx512()) {       // at a slot boundary: whole slots
+                    while (b - a >= 64 && pack64_avx512(a, pk.cw + pk.w)) {
+                        pk.mw[pk.w >> 1] = 0u; pk.mw[(pk.w >> 1) + 1] = 0u;
+                        pk.w += 4;
+                        if (bdst) { memcpy(bdst, a, 64); bdst += 64; }
+                        a += 64;
+                    }
+                    if (a >= b) break;
+                }
                 if (pk.j == 0 && b - a >= 32 && host_has_avx2()) {
                     while (b - a >= 32 && all_acgt32_avx2(a)) {
                         uint32_t w2[2];
@@ -567,6 +597,14 @@ inline int pack_line_checked(const uint8_t *a, const uint8_t *b, Packer &pk, int
 {
     while (a < b) {
 #if IDL_HAVE_AVX2_PATH
+        if (pk.j == 0 && (pk.w & 3) == 0 && b - a >= 64 && host_has_avx512()) {               // at a slot boundary: whole slots
+            while (b - a >= 64 && pack64_avx512(a, pk.cw + pk.w)) {
+                pk.mw[pk.w >> 1] = 0u; pk.mw[(pk.w >> 1) + 1] = 0u;
+                pk.w += 4;
+                a += 64; cnt += 64;
+            }
+            if (a >= b) break;
+        }
         if (pk.j == 0 && b - a >= 32 && host_has_avx2()) {
             while (b - a >= 32 && all_acgt32_avx2(a)) {
                 uint32_t w2[2];

@@ -187,9 +187,9 @@ def test_threaded_reader_equals_oracle(tmp_path, monkeypatch, threads):
             assert np.array_equal(ff.codes[a * 16:b * 16], codes) and np.array_equal(ff.mask[a * 8:b * 8], mask), i
 
 
-@pytest.mark.parametrize("width", [0, 70, 33, 16])
+@pytest.mark.parametrize("width", [0, 70, 33, 16, 64, 128, 200])
 def test_reader_fast_paths_equal_oracle(tmp_path, width):
-    """Long runs of upper-case A/C/G/T take the 32-base (AVX2) / 8-base (SWAR) paths of the reader; mixed with N runs, lower case,
+    """Long runs of upper-case A/C/G/T take the 64-base (AVX-512, at slot boundaries) / 32-base (AVX2) / 8-base (SWAR) paths of the reader; mixed with N runs, lower case,
     IUPAC codes and gaps at every alignment they must give exactly the bytes, lengths, codes and masks of the byte-wise walk."""
     rng = np.random.default_rng(100 + width)
     p = str(tmp_path / "fast.fas")

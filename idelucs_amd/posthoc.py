@@ -318,7 +318,7 @@ def _spatial_order(x64, pivots=256, seed=0):
 
 def _core_distances_window(x64, k, device, out, sample=None, seed=0, stats=None, order=None):
     """Core distances without the distance matrix (csrc/knn.hip).  Needs 64 coordinates that float32 holds exactly.
-      0. order the points by their nearest of 256 random pivots (_spatial_order);
+      0. order the points by their nearest of 256 random pivots (_spatial_order), every group padded to whole waves of 64 rows;
       1. bracket: the squared distances (float64) of every row to KNN_SAMPLE random columns; the k-th of all n lies, with
          probability 1 - 7e-6 per row, between the sampled ranks r -+ 4.5 sqrt(r), r = sample * k / n  ->  [lo, hi) per row;
       2. idl_knn_window: one fp32 MFMA pass over all pairs: count of columns below lo, the columns inside [lo, hi) kept;
@@ -340,46 +340,58 @@ def _core_distances_window(x64, k, device, out, sample=None, seed=0, stats=None,
     if r_hi > S:
         return None                                            # k too close to n for a bracket: the matrix path
     vp = ctypes.c_void_p
-    perm = (order if order is not None else _spatial_order(x64, seed=seed))[0]
+    perm, gid = order if order is not None else _spatial_order(x64, seed=seed)
     xo = x64[perm]                                              # the points in memory order
-    x32 = xo.to(torch.float32).contiguous()
     sq = (xo * xo).sum(1)
     g = torch.Generator(device="cpu"); g.manual_seed(seed)
     cols = torch.randperm(n, generator=g)[:S].to(device)
     xs_t, sqs = xo[cols].t().contiguous(), sq[cols]
+    # the bracket of every row, from the float64 distances to the sampled columns
+    lo_all = torch.empty(n, dtype=torch.float32, device=device)
+    hi_all = torch.empty(n, dtype=torch.float32, device=device)
+    sub = 16384                                                 # rows of one sampled block: 16384 x 16384 float64 = 2 GB
+    for b0 in range(0, n, sub):
+        b1 = min(b0 + sub, n)
+        ds = torch.mm(xo[b0:b1], xs_t).mul_(-2.0).add_(sqs[None, :]).add_(sq[b0:b1, None])
+        vals = torch.topk(ds, r_hi, dim=1, largest=False, sorted=True).values
+        hi_all[b0:b1] = vals[:, r_hi - 1]
+        lo_all[b0:b1] = vals[:, r_lo - 1] if r_lo >= 1 else -1.0e30          # (no lower rank: nothing is below, every column under hi is kept)
+        del ds, vals
+    # every group padded to whole waves of 64 rows, so that no wave (which centres its coordinates on its first row) straddles two groups;
+    # the padding is infinitely far from everything (never counted, never kept) and brackets nothing itself
+    counts = torch.bincount(gid)
+    padded = (counts + 63) // 64 * 64
+    first, start = torch.cumsum(counts, 0) - counts, torch.cumsum(padded, 0) - padded
+    pos = start[gid] + (torch.arange(n, device=device) - first[gid])
+    npad = int(padded.sum())
+    x32 = torch.zeros((npad, d), dtype=torch.float32, device=device)
+    x32[:, 0] = 1.0e18
+    x32[pos] = xo.to(torch.float32)
+    lo_p = torch.full((npad,), -1.0, dtype=torch.float32, device=device)
+    hi_p = torch.full((npad,), -1.0, dtype=torch.float32, device=device)
+    lo_p[pos], hi_p[pos] = lo_all, hi_all
+    del xo, sq, lo_all, hi_all
     m_expect = (r_hi - max(r_lo, 0)) / S * n
     cap = int(-(-int(2.0 * m_expect + 6.0 * math.sqrt(m_expect) + 1024) // 256) * 256)
-    chunk = max(256, min(-(-n // 256) * 256, (KNN_SLOT_BYTES // (8 * cap)) // 256 * 256))
+    chunk = max(256, min(-(-npad // 256) * 256, (KNN_SLOT_BYTES // (8 * cap)) // 256 * 256))
     cand_d2 = torch.empty(chunk * cap, dtype=torch.float32, device=device)
     cand_ix = torch.empty(chunk * cap, dtype=torch.int32, device=device)
-    lo_t = torch.empty(chunk, dtype=torch.float32, device=device)
-    hi_t = torch.empty(chunk, dtype=torch.float32, device=device)
     delta = torch.empty(chunk, dtype=torch.float32, device=device)
     cnt_lo = torch.empty(chunk, dtype=torch.int32, device=device)
     cnt_in = torch.empty(chunk, dtype=torch.int32, device=device)
-    status = torch.empty(n, dtype=torch.int32, device=device)
-    core_o = torch.zeros(n, dtype=torch.float64, device=device)
+    status_p = torch.empty(npad, dtype=torch.int32, device=device)
+    core_p = torch.zeros(npad, dtype=torch.float64, device=device)
     stream = vp(torch.cuda.current_stream().cuda_stream)
-    sub = 16384                                                 # rows of one sampled block: 16384 x 16384 float64 = 2 GB
-    for row0 in range(0, n, chunk):
-        rows = min(chunk, n - row0)
-        for b0 in range(row0, row0 + rows, sub):
-            b1 = min(b0 + sub, row0 + rows)
-            ds = torch.mm(xo[b0:b1], xs_t).mul_(-2.0).add_(sqs[None, :]).add_(sq[b0:b1, None])
-            vals = torch.topk(ds, r_hi, dim=1, largest=False, sorted=True).values
-            hi_t[b0 - row0:b1 - row0] = vals[:, r_hi - 1]
-            if r_lo >= 1:
-                lo_t[b0 - row0:b1 - row0] = vals[:, r_lo - 1]
-            else:
-                lo_t[b0 - row0:b1 - row0] = -1.0e30             # nothing is below: every column under hi is kept
-            del ds, vals
-        _lib.check(L.idl_knn_window(vp(x32.data_ptr()), n, d, vp(lo_t.data_ptr()), vp(hi_t.data_ptr()), row0, rows, vp(cnt_lo.data_ptr()),
+    for row0 in range(0, npad, chunk):
+        rows = min(chunk, npad - row0)
+        _lib.check(L.idl_knn_window(vp(x32.data_ptr()), npad, d, vp(lo_p[row0:].data_ptr()), vp(hi_p[row0:].data_ptr()), row0, rows, vp(cnt_lo.data_ptr()),
                                     vp(cnt_in.data_ptr()), vp(delta.data_ptr()), vp(cand_d2.data_ptr()), vp(cand_ix.data_ptr()), cap, stream))
-        _lib.check(L.idl_knn_select(vp(x32.data_ptr()), n, d, vp(lo_t.data_ptr()), vp(hi_t.data_ptr()), vp(delta.data_ptr()), row0, rows, k,
+        _lib.check(L.idl_knn_select(vp(x32.data_ptr()), npad, d, vp(lo_p[row0:].data_ptr()), vp(hi_p[row0:].data_ptr()), vp(delta.data_ptr()), row0, rows, k,
                                     vp(cnt_lo.data_ptr()), vp(cnt_in.data_ptr()), vp(cand_d2.data_ptr()), vp(cand_ix.data_ptr()), cap,
-                                    vp(core_o.data_ptr()), vp(status[row0:].data_ptr()), stream))
+                                    vp(core_p.data_ptr()), vp(status_p[row0:].data_ptr()), stream))
         if stats is not None:
             stats["kept_max"] = max(stats.get("kept_max", 0), int(cnt_in[:rows].max()))
+    core_o, status = core_p[pos], status_p[pos]
     out[perm] = core_o
     missed = perm[torch.nonzero(status).squeeze(1)]
     if stats is not None:

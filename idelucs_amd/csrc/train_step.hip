@@ -1110,6 +1110,21 @@ __global__ __launch_bounds__(256) void rmsprop_batched_kernel(const unsigned cha
     rmsprop_body(p.a, p.hyper, p.ctl, p.batch_advance, 0, p.n_gather, p.g, (int)blockIdx.x);
 }
 
+// ... and the optimizer launch with the dW1 tiles at its head (wgrad_rmsprop_kernel) for several voters
+struct WgRmsParams { wg_dev::WgArgs w; RmsParams r; };
+static_assert(sizeof(WgRmsParams) + idl::PLAN_PARAMS <= idl::PLAN_BYTES, "WgRmsParams does not fit a plan record");
+
+__global__ __launch_bounds__(wg_dev::THREADS) void wgrad_rmsprop_batched_kernel(const unsigned char *__restrict__ plans)
+{
+    extern __shared__ wg_dev::f32x4_t wg_img[];
+    const WgRmsParams &p = *(const WgRmsParams *)(plans + (size_t)blockIdx.y * idl::PLAN_BYTES + idl::PLAN_PARAMS);
+    if ((int)blockIdx.x < p.w.tiles) wg_dev::q16_tile<0>(p.w, (int)blockIdx.x, wg_img);
+    else if (threadIdx.x < 256) {
+        __builtin_amdgcn_s_setprio(3);
+        rmsprop_body<true>(p.r.a, p.r.hyper, p.r.ctl, p.r.batch_advance, 0, p.r.n_gather, p.r.g, (int)blockIdx.x - p.w.tiles);
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -1472,11 +1487,18 @@ static int rmsprop_launch(int count, float *const *params, const float *const *g
     for (int i = count; i <= 8; ++i) a.first[i] = nb_total;
     const int64_t extra = g.y != nullptr ? idl_dev::gather_blocks(g.f, g.batch) : 0;
     if (void *plan = idl::take_plan()) {          // recorded, not launched (idl_plan_begin)
-        IDL_REQUIRE(big == nullptr, "wgrad_rmsprop_step cannot be recorded (the batched step keeps its batched GEMM)");
         idl::PlanHead h{};
+        const RmsParams p{a, hyper, ctl, batch_advance, (int)extra, g};
+        if (big != nullptr) {                       // the dW1 tiles ride at the head of every voter's share of the launch
+            h.kind = idl::PLAN_WGRAD_RMSPROP; h.grid[0] = (unsigned)(big->tiles + nb_total + extra + a.wg_tiles); h.grid[1] = 1; h.grid[2] = 1;
+            h.block = wg_dev::THREADS;
+            memcpy(plan, &h, sizeof(h));
+            const WgRmsParams wp{*big, p};
+            memcpy((unsigned char *)plan + idl::PLAN_PARAMS, &wp, sizeof(wp));
+            return IDL_OK;
+        }
         h.kind = idl::PLAN_RMSPROP; h.grid[0] = (unsigned)(nb_total + extra + a.wg_tiles); h.grid[1] = 1; h.grid[2] = 1; h.block = 256;
         memcpy(plan, &h, sizeof(h));
-        const RmsParams p{a, hyper, ctl, batch_advance, (int)extra, g};
         memcpy((unsigned char *)plan + idl::PLAN_PARAMS, &p, sizeof(p));
         return IDL_OK;
     }
@@ -1616,6 +1638,17 @@ int idl_plan_launch(const void *host_plans, const void *dev_plans, int n_voters,
     case idl::PLAN_RMSPROP:
         hipLaunchKernelGGL(rmsprop_batched_kernel, dim3(h.grid[0], (unsigned)n_voters), dim3(h.block), 0, st, dp);
         break;
+    case idl::PLAN_WGRAD_RMSPROP: {
+        static bool attr_set[64] = {};
+        int dev = 0;
+        IDL_HIP_TRY(hipGetDevice(&dev));
+        if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+            IDL_HIP_TRY(hipFuncSetAttribute((const void *)wgrad_rmsprop_batched_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, wg_dev::IMG_BYTES));
+            attr_set[dev] = true;
+        }
+        hipLaunchKernelGGL(wgrad_rmsprop_batched_kernel, dim3(h.grid[0], (unsigned)n_voters), dim3(h.block), wg_dev::IMG_BYTES, st, dp);
+        break;
+    }
     case idl::PLAN_NCE:
         return idl::nce_plan_launch(h, dev_plans, n_voters, st);
     default:

@@ -14,8 +14,9 @@ device-resident offset that the optimizer kernel advances, the next batch while 
 The parameters remain the nn.Parameters of model.net (state_dict / predict / weights_init unchanged).
 RMSprop state lives here; begin_voter() clears it (every voter is an independent run, models.IID_model.begin_voter).
 
-BatchedLinearTrainer steps several voters of one ensemble in lockstep: the two big products become batched GEMMs and each of
-the five kernels becomes ONE launch with the voter index in its grid (recorded launches, idl_plan_*), so the latency-bound
+BatchedLinearTrainer steps several voters of one ensemble in lockstep: the layer-1 product becomes a batched GEMM and each of
+the five kernels ONE launch with the voter index in its grid (recorded launches, idl_plan_*; the dW1 tiles ride at the head of
+every voter's share of the optimizer launch as they do for a single voter: 5 voters 94.9 -> 91.7 ms an epoch of 50 000 sequences), so the latency-bound
 launches -- 51 of the 116 us of a step, mostly launch boundaries and dependent-load chains on a quarter of the CUs -- are paid
 once per step of the whole batch of voters instead of once per voter.
 """
@@ -322,10 +323,10 @@ class FusedLinearTrainer:
             chk(_L.idl_bias_grads(_p(bf.dr1), _p(bf.r1), self.H1, _p(gb1), _p(bf.dlat), self.H2, _p(gb2), _p(bf.dlogits), C, _p(gb3),
                                   m, tr, adv_ctl, adv, _p(bf.r2) if self._dw3_partial else None,
                                   _p(gW3) if self._dw3_partial else None, _stream()))
-        w1_fusable = self._wgrad_fused and self._rec is None and bool(_L.idl_wgrad_supported(m, self.H1, self.F))
+        w1_fusable = self._wgrad_fused and bool(_L.idl_wgrad_supported(m, self.H1, self.F))
         # the tiles ride at the head of the optimizer launch where that launch has the form below; else as a launch of their own
         w1_head = w1_fusable and (early or early_f) and self._dw2_inlaunch and not self._wgrad_own_launch
-        w1_done = w1_fusable and not w1_head
+        w1_done = w1_fusable and not w1_head and self._rec is None     # (a recorded step takes the tiles only inside its optimizer launch)
         gw1_out = _p(gW1) if self._keep_w1_grad else None
         if w1_done:
             chk(_L.idl_wgrad_rmsprop(_p(bf.dr1), _p(x), m, self.H1, self.F, gw1_out, _p(self.W1), _p(self.square_avg[0]), _p(self.hyper),
@@ -336,10 +337,10 @@ class FusedLinearTrainer:
         main.wait_stream(side)
         # ---- RMSprop (and advance the device-side step counter / batch offset)
         if w1_head:
-            chk(_L.idl_wgrad_rmsprop_step(len(self.params), self._pp, self._gp, self._parts, self._vp, sz, _p(self.hyper),
-                                          _p(self.ctl), _p(bf.loss_rows), m, 1.0 - self.weight, self.weight, _p(self.out),
-                                          0, _p(bf.dr1), _p(x), m, self.H1, self.F, gw1_out,
-                                          2, _p(bf.dlat), _p(bf.r1), 1 if tl else 0, m, self.H2, self.H1, _p(gW2), m // 2, _stream()))
+            self._k(_L.idl_wgrad_rmsprop_step, len(self.params), self._pp, self._gp, self._parts, self._vp, sz, _p(self.hyper),
+                    _p(self.ctl), _p(bf.loss_rows), m, 1.0 - self.weight, self.weight, _p(self.out),
+                    0, _p(bf.dr1), _p(x), m, self.H1, self.F, gw1_out,
+                    2, _p(bf.dlat), _p(bf.r1), 1 if tl else 0, m, self.H2, self.H1, _p(gW2), m // 2, _stream())
         elif (early or early_f) and self._dw2_inlaunch:      # no batch assembly here; the offset moves on at the end of the step
             self._k(_L.idl_rmsprop_step_gather_wgrad, len(self.params), self._pp, self._gp, self._parts, self._vp, sz, _p(self.hyper),
                     _p(self.ctl), _p(bf.loss_rows), m, 1.0 - self.weight, self.weight, _p(self.out),
@@ -478,6 +479,7 @@ class BatchedLinearTrainer:
             raise ValueError("BatchedLinearTrainer needs the default launch sequence (n_clusters <= 48, no opt-in variants)")
         self._programs = {}
         self._graphs = {}
+        self._w1_in_launch = False
 
     def stack(self, m):
         """Stacked GEMM operands of batch shape m: XS[2][L, m, F], R1 [L, m, 512] (its transposed image [L, 512, m] is the layer-1
@@ -504,8 +506,9 @@ class BatchedLinearTrainer:
                         t.step_on_batch(t.buffers(m), train=True, batch_advance=m // 2, next_from=store, xi=xi)
                     finally:
                         rec, t._rec = t._rec, None
-                    if len(rec.plans) != 4 or rec.mms != 2:
+                    if len(rec.plans) != 4 or rec.mms not in (1, 2):
                         raise RuntimeError("the recorded step is not the default launch sequence")
+                    self._w1_in_launch = rec.mms == 1               # dW1 as MFMA tiles at the head of every voter's optimizer launch
                     recs.append(rec.plans)
                 ops = []
                 for k in range(4):
@@ -524,7 +527,8 @@ class BatchedLinearTrainer:
         torch.bmm(self.W1s, st['xs'][xi].transpose(1, 2), out=r1T)                        # a1^T = W1 x^T per voter
         for k in (0, 1, 2):                                                              # mid_fwd, InfoNCE passes, mid_bwd
             _lib.check(_L.idl_plan_launch(ctypes.c_void_p(ops[k][0].data_ptr()), _p(ops[k][1]), L, _stream()))
-        torch.bmm(st['dr1'].transpose(1, 2), st['xs'][xi], out=self.gW1s)                # dW1 = dr1^T x per voter
+        if not self._w1_in_launch:
+            torch.bmm(st['dr1'].transpose(1, 2), st['xs'][xi], out=self.gW1s)            # dW1 = dr1^T x per voter
         _lib.check(_L.idl_plan_launch(ctypes.c_void_p(ops[3][0].data_ptr()), _p(ops[3][1]), L, _stream()))
 
     # ------------------------------------------------------------------ one epoch of every voter

@@ -538,7 +538,7 @@ int idl_fasta_open(const char *path, int check, idl_fasta **out)
                     const uint8_t h0 = buf[r.id_b];
                     if (h0 == '>' || h0 == '#' || py_bytes_space(h0) || (h0 >= 0x1c && h0 <= 0x1f)) kind = REC_BAD_HEADER;
                 }
-                if (kind == REC_OK && memchr(buf + r.id_b, '\t', r.id_e - r.id_b)) kind = REC_TAB;
+                if (kind == REC_OK && r.id_e > r.id_b && memchr(buf + r.id_b, '\t', r.id_e - r.id_b)) kind = REC_TAB;   // (empty file: buf is NULL)
             }
             if (kind == REC_OK) {
                 int64_t cnt = 0;
@@ -704,7 +704,7 @@ int idl_fasta_parse_pack(const char *path, uint8_t *codes, uint8_t *mask, int64_
             uint8_t bb = 0;
             const uint8_t h0 = buf[r.id_b];                           // utils.py:37-40 header checks
             if (h0 == '>' || h0 == '#' || py_bytes_space(h0) || (h0 >= 0x1c && h0 <= 0x1f)) kind = REC_BAD_HEADER;
-            if (kind == REC_OK && memchr(buf + r.id_b, '\t', r.id_e - r.id_b)) kind = REC_TAB;
+            if (kind == REC_OK && r.id_e > r.id_b && memchr(buf + r.id_b, '\t', r.id_e - r.id_b)) kind = REC_TAB;   // (empty file: buf is NULL)
             Packer pk{(uint32_t *)(codes + slot * 16), (uint32_t *)(mask + slot * 8)};
             int64_t cnt = 0;
             size_t lp = he;

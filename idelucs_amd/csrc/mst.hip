@@ -838,7 +838,9 @@ int idl_mst_prim_lazy(const void *xt, const float *xrow, const double *core, int
     IDL_REQUIRE(xt && xrow && core && orig && codes && resid && gid && glo && gscale && gfirst && gcentre && gradius, "mst_prim_lazy: NULL buffer");
     IDL_REQUIRE(mst_cur && mst_next && mst_w && workspace, "mst_prim_lazy: NULL buffer");
     IDL_REQUIRE(d == PRIM_FILTER_D, "mst_prim_lazy: points must have 64 float32 coordinates");
-    IDL_REQUIRE(n >= 65536 && n * 64 * 4 < (1ll << 31), "mst_prim_lazy: 65536 <= n < 2^23 points");
+    // lazy_step_kernel looks at a thread's PRIM_AHEAD points and has no strided tail (prim_step_kernel's loop behind the look-ahead):
+    // every position must fall inside grid x PRIM_NT x PRIM_AHEAD, or points past it would never become candidates
+    IDL_REQUIRE(n >= 65536 && n <= (int64_t)prim_grid(n) * PRIM_NT * PRIM_AHEAD, "mst_prim_lazy: 65536 <= n <= 2^20 points (use idl_mst_prim_local beyond)");
     IDL_REQUIRE(n_groups >= 1 && n_groups <= prim_grid(n), "mst_prim_lazy: more groups than workgroups of a step");
     IDL_REQUIRE((((uintptr_t)workspace) & 255u) == 0 && start >= 0 && start < n, "mst_prim_lazy: workspace alignment / start position");
     const LazyLayout l = lazy_layout(n, n_groups);

@@ -425,6 +425,8 @@ def core_distances_device(x64, k, device, f32_exact=None, stats=None, order=None
 
 
 MST_LAZY_MIN = 65536             # points from which groups of points may sleep during Prim's scan (idl_mst_prim_lazy)
+MST_LAZY_MAX = 1 << 20           # its step kernel scans a thread's 4 look-ahead points only: 1024 workgroups x 256 threads x 4 (mst.hip
+                                 # prim_grid / PRIM_NT / PRIM_AHEAD); larger inputs take idl_mst_prim_local, whose scan strides on
 MST_FILTER_MIN = 20000           # points from which Prim's scan goes through the 8-bit lower-bound filter
 
 
@@ -511,7 +513,7 @@ def hdbscan_device(points, min_cluster_size, device=None, stats=None):
         del xo
         n_groups = int(gid32[-1]) + 1
         mode = os.environ.get("IDELUCS_MST", "lazy")
-        if mode == "lazy" and f32_exact and d == 64 and n >= MST_LAZY_MIN and n * 256 < (1 << 31) and n_groups <= min(1024, -(-n // 256)):
+        if mode == "lazy" and f32_exact and d == 64 and MST_LAZY_MIN <= n <= MST_LAZY_MAX and n_groups <= min(1024, -(-n // 256)):
             # groups of points may sleep while the tree grows elsewhere (idl_mst_prim_lazy): a ball around every group, the points row-major
             xo = x64[perm]
             cnt = torch.bincount(gid, minlength=n_groups)

@@ -317,6 +317,7 @@ class _DeviceInput:
         self.slot_off = torch.from_numpy(ff.slot_off).to(device)
         self.lengths = torch.from_numpy(ff.lengths).to(device)
         self.max_len = int(ff.lengths.max()) if ff.n else 0
+        self.total_len = int(ff.lengths.sum()) if ff.n else 0
 
 
 def _vectorise(dev_in, k, mode, init, out_kind, n_views=1, edits=None, edit_off=None, out=None):
@@ -374,9 +375,22 @@ def edits_overflowed(edits, edit_off, capacity=None):
     return edit_off[-1] > capacity if capacity is not None else torch.zeros((), dtype=torch.bool, device=edits.device)
 
 
+def _slots_budget(dev_in, p_ts, p_tv, n_rn, max_len):
+    """Entries the one-pass generator's slot buffer may take: 4 x the expected number of sites (from the bases actually present;
+    an input that does not say is taken as n sequences of max_len) + 64 per item.  At uniform lengths the slots need 2-3 x the
+    expectation (expected + 10 sigma + 32 per item) and pass; a skewed-length file does not and takes the exact protocol."""
+    n, P = dev_in.n, len(p_ts)
+    tot = getattr(dev_in, "total_len", None)
+    if tot is None:
+        tot = n * max_len
+    q = 1.0 - (1.0 - p_ts) * (1.0 - p_tv)
+    return int(4.0 * (float(q.sum()) * tot + float(n_rn.sum()) * n) + 64 * n * P + 1024)
+
+
 def _philox_edits(dev_in, specs, seed, capacity=None, slots=None, sync=None):
     """Device-drawn mimic sites -> (edits, edit_off) on device.
-    Default (slots; IDELUCS_MIMIC_SLOTS=0 turns it off): ONE pass (idl_mimic_edits_slots) into fixed per-item slots sized on the
+    Default (slots; IDELUCS_MIMIC_SLOTS=0 turns it off; slots=True forces it; otherwise only while the slot buffer stays within
+    _slots_budget -- one long record among many short ones goes to the exact protocol): ONE pass (idl_mimic_edits_slots) into fixed per-item slots sized on the
     host from the longest sequence; edit_off is then the [n_views * n, 2] array of (begin, end) _vectorise understands.  An item
     that outgrows its slot (expected sites + 10 sigma + 32) raises a device flag: with sync (the default without a capacity)
     it is read here and the exact two-call protocol takes over; without, the caller checks edits_overflowed() afterwards.
@@ -399,13 +413,27 @@ def _philox_edits(dev_in, specs, seed, capacity=None, slots=None, sync=None):
         raise ValueError(f"{err}; use rng='compat'") from None
     dev = dev_in.lengths.device
     args = (_ptr(dev_in.lengths), dev_in.n, P, _ptr(p_ts), _ptr(p_tv), _ptr(n_rn), ctypes.c_uint64(seed & (2 ** 64 - 1)))
+    forced = slots is True
     if slots is None:
         slots = os.environ.get("IDELUCS_MIMIC_SLOTS", "1") != "0"
+    edits = None
     if slots and dev_in.n > 0:
         total = int(_L.idl_mimic_slots_capacity(dev_in.n, P, _ptr(p_ts), _ptr(p_tv), _ptr(n_rn), max_len))
+        # every item's slot is sized from the LONGEST sequence: n * P * cap(max_len) entries, not proportional to the bases.  One
+        # long outlier among many short records (which the reference accepts) would ask for tens of GB where the exact CSR protocol
+        # needs a few MB: the slots are taken only while they stay within a small multiple of the expected sites
+        if not forced and total > _slots_budget(dev_in, p_ts, p_tv, n_rn, max_len):
+            slots = False
+    if slots and dev_in.n > 0:
         ws = torch.empty(max(int(_L.idl_mimic_slots_workspace(P)), 16), dtype=torch.uint8, device=dev)
         ranges = torch.empty((P * dev_in.n, 2), dtype=torch.int64, device=dev)
-        edits = torch.empty(max(total, 1), dtype=torch.int32, device=dev)
+        try:
+            edits = torch.empty(max(total, 1), dtype=torch.int32, device=dev)
+        except torch.cuda.OutOfMemoryError:
+            if forced:
+                raise
+            edits = None                      # the exact two-pass protocol below sizes everything from the counts
+    if edits is not None:
         flag = torch.zeros((), dtype=torch.int32, device=dev)
         _lib.check(_L.idl_mimic_edits_slots(*args, max_len, _ptr(ranges), _ptr(edits), total, _ptr(flag), _ptr(ws), _stream_ptr()))
         if sync if sync is not None else capacity is None:
@@ -592,6 +620,7 @@ class _StreamedInput:
         self.n = ff.n
         self.max_len = int(ff.lengths.max()) if ff.n else 0
         self.min_len = int(ff.lengths.min()) if ff.n else 0
+        self.total_len = int(ff.lengths.sum()) if ff.n else 0
         self.lengths = torch.from_numpy(ff.lengths).to(device, non_blocking=True)
         self.slot_off = torch.from_numpy(ff.slot_off).to(device, non_blocking=True)
         slots = max(ff.total_slots, 1)

@@ -157,3 +157,35 @@ def test_feature_level_equivalence_of_rng_modes(tmp_path):
         da = np.abs(a[v] - a[0]).sum(1).mean()
         db = np.abs(b[v] - b[0]).sum(1).mean()
         assert abs(da - db) / da < 0.10, (v, da, db)
+
+
+def test_skewed_lengths_take_the_exact_protocol_not_the_slots():
+    """the one-pass generator sizes EVERY item's slot from the longest sequence.  One 300 kbp record among
+    3 000 records of 200 bp would ask for n * P * cap(300 kbp) entries; the default now leaves the slots when that exceeds a small
+    multiple of the expected sites (utils._slots_budget) and takes the exact CSR protocol -- the same sites, bit for bit, as
+    the forced slots give on this (still allocatable) case.  The uniform-length hot shape keeps the slots."""
+    import torch
+    from idelucs_amd import utils as U
+    lengths = [200] * 3000 + [300000]
+    specs = [t.spec() for t in U.mimic_transforms(3)]
+    dev = torch.device("cuda")
+
+    class D:
+        pass
+    d = D()
+    d.n, d.lengths = len(lengths), torch.tensor(lengths, dtype=torch.int64, device=dev)
+    d.codes = torch.zeros(1, dtype=torch.int32, device=dev)
+    d.total_len, d.max_len = sum(lengths), max(lengths)
+    e_def, off_def = U._philox_edits(d, specs, 5)
+    assert off_def.dim() == 1, "a skewed-length input still took the per-item slots"
+    assert e_def.numel() < 4 * 0.04 * d.total_len + 64 * d.n * len(specs)          # proportional to the bases, not to n * cap(max)
+    e_s, rng = U._philox_edits(d, specs, 5, slots=True)
+    assert rng.dim() == 2 and e_s.numel() > 20 * e_def.numel()
+    e_def, off_def, e_s, rng = e_def.cpu().numpy(), off_def.cpu().numpy(), e_s.cpu().numpy(), rng.cpu().numpy()
+    for it in list(range(0, len(specs) * d.n, 97)) + [v * d.n + d.n - 1 for v in range(len(specs))]:
+        assert np.array_equal(e_s[rng[it, 0]:rng[it, 1]], e_def[off_def[it]:off_def[it + 1]]), it
+    # uniform lengths (the hot shape): the slots stay the default
+    u = D()
+    u.n, u.lengths = 500, torch.full((500,), 10000, dtype=torch.int64, device=dev)
+    u.codes, u.total_len, u.max_len = d.codes, 500 * 10000, 10000
+    assert U._philox_edits(u, specs, 5)[1].dim() == 2

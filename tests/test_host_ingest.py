@@ -401,3 +401,19 @@ def test_kept_mapping_never_serves_a_rewritten_file(tmp_path, monkeypatch):
     other = tmp_path / "n.fas"
     other.write_bytes(b">z\nACACACAC\n")
     assert bytes(U.FastaFile(str(other), keep_bytes=True).record(0)) == b"ACACACAC"
+
+
+def test_lazy_prim_refuses_inputs_beyond_its_look_ahead():
+    """ADVICE r3 (high): the sleeping-groups Prim scans a thread's 4 look-ahead points only, i.e. 1024 x 256 x 4 = 2^20 positions;
+    beyond that points would never become candidates and the run would end in 'no progress' after minutes.  The entry point
+    now rejects such a call in its argument checks (nothing is launched: this runs without a GPU), and the host gate sends
+    those inputs to idl_mst_prim_local, whose step kernel strides on behind the look-ahead."""
+    from idelucs_amd import posthoc
+    assert posthoc.MST_LAZY_MAX == 1 << 20 and posthoc.MST_LAZY_MIN <= posthoc.MST_LAZY_MAX
+    buf = (ctypes.c_uint8 * 512)()
+    p = (ctypes.addressof(buf) + 255) & ~255
+    for n, ok in (((1 << 20) + 4096, False), (1 << 23, False)):
+        rc = _lib.lib.idl_mst_prim_lazy(p, p, p, n, 64, p, 0, p, p, p, p, p, 4, p, p, p, p, p, p, p, None, None)
+        assert rc == _lib.IDL_ERR_ARG and "2^20" in _lib.last_error(), (n, rc, _lib.last_error())
+    src = open(os.path.join(ROOT, "idelucs_amd", "posthoc.py")).read()
+    assert "MST_LAZY_MIN <= n <= MST_LAZY_MAX" in src

@@ -19,6 +19,10 @@ checks   : the epoch loss of every timed step must be finite, and after the time
            step is validated (rows sum to 1, view 0 != view 1) and a checksum of it is printed ("validation").
 N > 1    : one process per GPU (torch.distributed, backend nccl == RCCL); no collective inside an epoch.
 
+At N = 1 the line also carries "fixed_job_8_voters": BASELINE.md section 3's FIXED cfg3 job (8 voters, predict + the [8, N] all-gather
+through the RCCL group of one) run on the one GPU after the headline region -- the like-for-like N = 1 anchor of the 1/2/4/8
+curve: the N >= 2 lines ("job": "cfg3 ...") compare with IT, not with the one-voter headline ("job": "cfg2 ...").
+
 Prints ONE JSON line (rank 0).  Extra objects: "roofline" (the hand-written vectoriser kernel, HBM bound), "roofline_epoch"
 (the encoder epoch, MFMA fp32 bound), "cpu_baseline" (oracle port on the host cores, bounded sample, rank 0 at N=1 only),
 "t_e2e" (FASTA text in the page cache -> last optimizer.step, N=1 only; never `value`).
@@ -248,6 +252,46 @@ class HotPath:
                 "feats_checksum": chk, "rows_checked": int(rows.numel())}
 
 
+def check_votes(gathered, voters, n, n_clusters):
+    """The exchange step's result: int32 [V, N] in range, and every pair of voters a different run (per-voter init / permutation /
+    dropout streams; also across ranks)."""
+    assert tuple(gathered.shape) == (voters, n), (tuple(gathered.shape), voters, n)
+    assert int(gathered.min()) >= 0 and int(gathered.max()) < n_clusters
+    distinct = True
+    for i in range(voters):
+        for j in range(i + 1, voters):
+            distinct = distinct and not torch.equal(gathered[i], gathered[j])
+    assert distinct, "two voters produced identical assignments"
+    return {"gathered_shape": list(gathered.shape), "voters_pairwise_distinct": bool(distinct)}
+
+
+def fixed_job_8_voters(din, args, dev, rank, world, passes=3):
+    """BASELINE.md section 3's fixed job on ONE GPU: cfg3's 8 voters -- here batched in lockstep on the one rank
+    -- each one epoch from a fresh init, then predict per voter and the all-gather of the int32 assignments [8, N] through
+    the process group (RCCL, a group of one), everything inside the timed region as at N > 1.  One warm-up pass (graph capture,
+    GEMM selection for the batched shapes), then `passes` timed passes."""
+    import copy
+    a = copy.copy(args)
+    a.voters, a.exchange = 8, True
+    hp = HotPath(din, a, dev, rank, world)
+    hp.step(seed=1000)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(passes):
+        hp.step(seed=1001 + i)
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0) / passes
+    assert not bool(hp.edit_overflow.item())
+    v = hp.validate()
+    v.update(check_votes(hp.gathered, 8, args.n, args.n_clusters))
+    st = {k: hp.mean_ms(k, 1) for k in hp.ev if hp.ev[k]}
+    return {"job": "cfg3: 8 voters x 1 epoch + predict + all-gather of int32 [8, N] (BASELINE.md section 3), all on this GPU",
+            "value": args.n * 8 / (ms * 1e-3), "unit": "sequences x voters / sec", "sequences_per_sec_job": args.n / (ms * 1e-3),
+            "ms_per_pass": ms, "passes": passes, "lanes": len(hp.lanes),
+            "exchange_ms": st.get("predict_inputs", 0.0) + 8 * st.get("predict", 0.0) + st.get("exchange", 0.0),
+            "stage_ms": st, "backend": dist.get_backend() if dist.is_initialized() else None, "validation": v}
+
+
 def pmc_traffic_gb():
     """HBM traffic of one vectorise launch at cfg2, GB, from the committed rocprofv3 PMC passes (profiles/, WRITE_SIZE exact
     for 16-B stores, FETCH_SIZE doubled per MI355X_MICROARCH.md: DESIGN.md 4.1); None when the profile is not present."""
@@ -346,7 +390,7 @@ def cpu_baseline(args):
     else:
         t_ep_ref, steps_ref = t_ep, n_steps
     cal = cpu_calibration()
-    out = {"value": n / (t_vec + t_ep), "unit": "sequences/sec", "cores": threads, "threads": threads, "kind": "port",
+    out = {"value": n / (t_vec + t_ep), "unit": "sequences/sec", "cores": cores, "threads": threads, "kind": "port",
            "value_reference_threads": n / (t_vec + t_ep_ref), "reference_threads": ref_threads,
            "calibration_ratio": cal["ratio"] if cal else None,
            "calibration_source": (f"profiles/{CPU_CALIBRATION}: port / imported reference on the build container's {cal.get('cores')} cores, "
@@ -422,9 +466,10 @@ class stdout_to_stderr:
 
 def spawn_ranks(n, n_visible, n_shared):
     """`python bench.py --gpus N` without a launcher: start the N ranks as a CHILD `python -m torch.distributed.run` (one process
-    per GPU, RCCL), relay rank 0's JSON line, return the child's exit code.  Nothing here has touched the GPU (a process that has
-    must not be replaced by another program, and need not be: it only waits).  Fewer visible GPUs than ranks is an error, never
-    a smaller run."""
+    per GPU, RCCL), relay rank 0's JSON line, return the child's exit code.  The parent has only counted devices
+    (torch.cuda.device_count() -- which on ROCm may already have brought the HIP runtime up): it must only ever SPAWN a child
+    and wait for it, never replace itself with another program (os.exec* after the runtime is up is forbidden on this pool).
+    Fewer visible GPUs than ranks is an error, never a smaller run."""
     import socket
     import subprocess
     if n_shared == 0 and n_visible < n:
@@ -466,10 +511,12 @@ def main():
     ap.add_argument("--with-predict", dest="with_predict", type=int, default=None,
                     help="1: predict + all-gather inside the timed region (default: 0 at N=1 with one voter = BASELINE.md's region; 1 otherwise)")
     ap.add_argument("--cpu-sample", dest="cpu_sample", type=int, default=24000)
-    ap.add_argument("--cpu-ref-steps", dest="cpu_ref_steps", type=int, default=2,
+    ap.add_argument("--cpu-ref-steps", dest="cpu_ref_steps", type=int, default=8,
                     help="optimizer steps timed with the reference's cpu_count()-2 torch threads (scaled to the epoch)")
     ap.add_argument("--no-cpu-baseline", dest="cpu_base", action="store_false")
     ap.add_argument("--no-e2e", dest="e2e", action="store_false")
+    ap.add_argument("--no-fixed-job", dest="fixed_job", action="store_false",
+                    help="skip the fixed 8-voter job (cfg3) that the default N = 1 run adds after the headline region")
     ap.add_argument("--n-rate", dest="n_rate", type=float, default=0.0,
                     help="SURVEY 8(d) variant N: every synthetic base is an N with this probability (e.g. 1e-3); default 0 = BASELINE's input")
     forwarded = os.environ.pop("IDELUCS_BENCH_ARGV", None)      # set by spawn_ranks for its ranks
@@ -483,9 +530,9 @@ def main():
     # GPU of a test box, to exercise every line of the N > 1 path except RCCL itself
     backend = os.environ.get("IDELUCS_BENCH_BACKEND", "nccl")
     n_shared = int(os.environ.get("IDELUCS_BENCH_DEVICES", "0"))
-    n_visible = torch.cuda.device_count()            # counting devices does not initialise the GPU
+    n_visible = torch.cuda.device_count()            # (may initialise the HIP runtime: from here on this process spawns children only, never execs)
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
-        sys.exit(spawn_ranks(args.gpus, n_visible, n_shared))      # this process never touches the GPU
+        sys.exit(spawn_ranks(args.gpus, n_visible, n_shared))      # the parent runs no kernels; the ranks are a child process
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -561,10 +608,7 @@ def main():
             validation.update(latent_shape=list(hp.latent.shape), latent_finite=bool(torch.isfinite(hp.latent).all()),
                               latent_row_norm_max=float(hp.latent.norm(dim=1).max().item()))
         else:
-            assert tuple(hp.gathered.shape) == (args.voters, args.n)
-            assert int(hp.gathered.min()) >= 0 and int(hp.gathered.max()) < args.n_clusters
-            if args.voters > 1:      # voters are distinct runs (per-voter init / permutation / dropout streams), also across ranks
-                assert not torch.equal(hp.gathered[0], hp.gathered[1]), "voters 0 and 1 produced identical assignments"
+            validation.update(check_votes(hp.gathered, args.voters, args.n, args.n_clusters))
     else:
         # the exchange step of the path, untimed at N = 1 with one voter: this rank's voter predicts, assignments are all-gathered
         from idelucs_amd.dist import all_gather_assignments
@@ -601,8 +645,12 @@ def main():
                        else " + predict + all-gather of the int32 assignments [V, N]")
         else:
             region += " (BASELINE.md section 3 region; predict + all-gather run once after it: exchange_ms)"
+        job = ("cfg5: %d voter(s), sharded predict + latent all-gather" % V if cfg5 else
+               ("cfg2: 1 voter (BASELINE.md section 3 region, no exchange inside)" if V == 1 and not args.exchange else
+                "cfg3: %d voters x 1 epoch + predict + all-gather of int32 [V, N]" % V))
         out = {
             "metric": "sequences/sec (k-mer vectorise + 1 epoch), k=6 batch 512",
+            "job": job + ("" if world == 1 or cfg5 else " -- compare with the N = 1 line's fixed_job_8_voters, not with its one-voter value"),
             "value": value, "unit": "sequences/sec", "n_gpus": world, "ranks": group["ranks"], "backend": group["backend"],
             "devices": group["devices"], "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak" if V == world and world > 1 and cfg5 else ("strong" if world > 1 else "weak"),
@@ -644,6 +692,13 @@ def main():
             hp.model.store = None
             torch.cuda.empty_cache()
             out["t_e2e"] = t_e2e(args, dev)
+        if world == 1 and args.fixed_job and not cfg5 and V == 1 and not args.exchange:
+            # (after t_e2e dropped the headline's feature store: the fixed job allocates its own)
+            if "t_e2e" not in out:
+                del hp.feats, hp.store.feats
+                hp.model.store = None
+            torch.cuda.empty_cache()
+            out["fixed_job_8_voters"] = fixed_job_8_voters(din, args, dev, rank, world)
         if world == 1 and args.cpu_base:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out))

@@ -74,6 +74,7 @@ SIGNATURES = {
                                        _vp, _i64, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
     "idl_wgrad_supported": (_int, [_int, _int, _int]),
     "idl_wgrad_rmsprop": (_int, [_vp, _vp, _int, _int, _int, _vp, _vp, _vp, _vp, _vp]),
+    "idl_debug_wgrad_clock": (_int, [_vp, _vp, _int, _int, _int, _vp, _int, _vp, _vp]),
     "idl_rmsprop_step_gather_wgrad": (_int, [_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _c.c_float, _c.c_float, _vp,
                                              _vp, _i64, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _vp, _vp,
                                              _int, _vp, _vp, _int, _int, _int, _int, _vp, _i64, _vp]),

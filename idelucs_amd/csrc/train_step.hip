@@ -1076,15 +1076,20 @@ __global__ __launch_bounds__(256) void rmsprop_kernel(RmsArgs a, const float *hy
 // the optimizer launch as before (the small tensors, the dW2 tiles, step loss, step counter) and run beside them -- a tile
 // workgroup is one wave per SIMD, so both fit a CU.  One launch, one boundary and the 8 MB gradient's round trip fewer than
 // hipBLASLt's GEMM followed by rmsprop_kernel.
-template <bool STAMPS = false, bool SKIP_TILES = false>      // STAMPS (IDELUCS_STAMPS=1, a diagnostic): every workgroup leaves {start, end, hardware id, XCC id} in `stamps`
+template <bool STAMPS = false, bool SKIP_TILES = false>      // STAMPS (IDELUCS_STAMPS=1, a diagnostic): every workgroup leaves {start, end, hardware id, XCC id | shader cycles << 8} in `stamps`
 __global__ __launch_bounds__(wg_dev::THREADS) void wgrad_rmsprop_kernel(wg_dev::WgArgs w, RmsArgs a, const float *hyper, int64_t *ctl,
                                                             int64_t batch_advance, int n_gather, idl_dev::GatherArgs g, uint64_t *stamps)
 {
-    uint64_t t0 = 0;
-    if (STAMPS) t0 = __builtin_amdgcn_s_memrealtime();
+    uint64_t t0 = 0, c0 = 0;
+    if (STAMPS) { t0 = __builtin_amdgcn_s_memrealtime(); c0 = __builtin_amdgcn_s_memtime(); }
     extern __shared__ wg_dev::f32x4_t wg_img[];
+    // The launch has the tiles' 320 threads; behind the tiles the fifth wave has nothing to do and LEAVES HERE, before any barrier,
+    // in every instantiation: the barriers of rmsprop_body (written for 256 threads) and of the stamp epilogue below then pair up
+    // among the same four waves at the same program points (an ended wave no longer counts towards s_barrier) -- ADVICE r3:
+    // before, the STAMPS build had the fifth wave meet the epilogue's barrier while the others stood at rmsprop_body's.
+    if ((int)blockIdx.x >= w.tiles && threadIdx.x >= 256) return;
     if ((int)blockIdx.x < w.tiles) { if (!SKIP_TILES) wg_dev::q16_tile<0>(w, (int)blockIdx.x, wg_img); }
-    else if (threadIdx.x < 256) {            // (the tiles' fifth wave has nothing to do here)
+    else {
         // a tile wave issues matrix instructions back to back and, being the older wave of its SIMD, wins every arbitration: at equal
         // priority these workgroups crawl beside it (measured with the stamps: 40 us for 5 us of work, and the tiles 3..16 us longer
         // wherever they met a dW2 tile); ahead of it they are gone after a few microseconds
@@ -1098,7 +1103,9 @@ __global__ __launch_bounds__(wg_dev::THREADS) void wgrad_rmsprop_kernel(wg_dev::
             uint64_t *d = stamps + 4 * (size_t)blockIdx.x;
             d[0] = t0; d[1] = __builtin_amdgcn_s_memrealtime();
             d[2] = __builtin_amdgcn_s_getreg((31 << 11) | 4);          // HW_REG_HW_ID
-            d[3] = __builtin_amdgcn_s_getreg((31 << 11) | 20);         // HW_REG_XCC_ID
+            // XCC id in the low byte; above it the workgroup's life in SHADER cycles (s_memtime): with d[1] - d[0] (100 MHz ticks)
+            // the clock the chip held while this workgroup ran (tools/mfma_clock.py)
+            d[3] = (uint64_t)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xffu) | ((__builtin_amdgcn_s_memtime() - c0) << 8);
         }
     }
 }
@@ -1118,8 +1125,9 @@ __global__ __launch_bounds__(wg_dev::THREADS) void wgrad_rmsprop_batched_kernel(
 {
     extern __shared__ wg_dev::f32x4_t wg_img[];
     const WgRmsParams &p = *(const WgRmsParams *)(plans + (size_t)blockIdx.y * idl::PLAN_BYTES + idl::PLAN_PARAMS);
+    if ((int)blockIdx.x >= p.w.tiles && threadIdx.x >= 256) return;        // (as in wgrad_rmsprop_kernel: before any barrier)
     if ((int)blockIdx.x < p.w.tiles) wg_dev::q16_tile<0>(p.w, (int)blockIdx.x, wg_img);
-    else if (threadIdx.x < 256) {
+    else {
         __builtin_amdgcn_s_setprio(3);
         rmsprop_body<true>(p.r.a, p.r.hyper, p.r.ctl, p.r.batch_advance, 0, p.r.n_gather, p.r.g, (int)blockIdx.x - p.w.tiles);
     }

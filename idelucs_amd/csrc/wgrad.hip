@@ -17,7 +17,31 @@ __global__ __launch_bounds__(wg_dev::THREADS) void wgrad_q16_kernel(wg_dev::WgAr
     wg_dev::q16_tile<VARIANT>(a, (int)blockIdx.x, wg_img);
 }
 
+// diagnostic: the same tiles with clock stamps around the MFMA stream (idl_debug_wgrad_clock)
+template <int VARIANT>
+__global__ __launch_bounds__(wg_dev::THREADS) void wgrad_q16_clock_kernel(wg_dev::WgArgs a, uint64_t *clk)
+{
+    extern __shared__ wg_dev::f32x4_t wg_img[];
+    wg_dev::q16_tile<VARIANT, true>(a, (int)blockIdx.x, wg_img, clk);
+}
+
 }  // namespace
+
+// the tiles' LDS image is 64 KB of dynamic shared memory: raised once per device for every instantiation
+static int raise_lds_limit()
+{
+    static bool attr_set[64] = {};
+    int dev = 0;
+    IDL_HIP_TRY(hipGetDevice(&dev));
+    if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+        IDL_HIP_TRY(hipFuncSetAttribute((const void *)wgrad_q16_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, wg_dev::IMG_BYTES));
+        IDL_HIP_TRY(hipFuncSetAttribute((const void *)wgrad_q16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, wg_dev::IMG_BYTES));
+        IDL_HIP_TRY(hipFuncSetAttribute((const void *)wgrad_q16_clock_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, wg_dev::IMG_BYTES));
+        IDL_HIP_TRY(hipFuncSetAttribute((const void *)wgrad_q16_clock_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, wg_dev::IMG_BYTES));
+        attr_set[dev] = true;
+    }
+    return IDL_OK;
+}
 
 extern "C" {
 
@@ -40,17 +64,29 @@ int idl_wgrad_rmsprop(const float *dy, const float *x, int m, int n_out, int n_i
     a.tiles_m = n_out / wg_dev::TM;
     a.tiles = a.tiles_m * (n_in / wg_dev::TN);
     static const bool noload = [] { const char *e = getenv("IDELUCS_WGRAD_KERNEL"); return e != nullptr && strcmp(e, "noload") == 0; }();
-    static bool attr_set[64] = {};
-    int dev = 0;
-    IDL_HIP_TRY(hipGetDevice(&dev));
-    if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-        IDL_HIP_TRY(hipFuncSetAttribute((const void *)wgrad_q16_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, wg_dev::IMG_BYTES));
-        IDL_HIP_TRY(hipFuncSetAttribute((const void *)wgrad_q16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, wg_dev::IMG_BYTES));
-        attr_set[dev] = true;
-    }
+    if (const int rc = raise_lds_limit(); rc != IDL_OK) return rc;
     const dim3 grid((unsigned)a.tiles), block(wg_dev::THREADS);
     if (noload) hipLaunchKernelGGL((wgrad_q16_kernel<1>), grid, block, wg_dev::IMG_BYTES, (hipStream_t)stream, a);   // diagnostic
     else hipLaunchKernelGGL((wgrad_q16_kernel<0>), grid, block, wg_dev::IMG_BYTES, (hipStream_t)stream, a);
+    IDL_HIP_TRY(hipGetLastError());
+    return IDL_OK;
+}
+
+int idl_debug_wgrad_clock(const float *dy, const float *x, int m, int n_out, int n_in, float *grad, int variant, uint64_t *stamps, void *stream)
+{
+    IDL_REQUIRE(dy && x && grad && stamps && idl_wgrad_supported(m, n_out, n_in), "debug_wgrad_clock: operands as for idl_wgrad_rmsprop, grad and stamps given");
+    IDL_REQUIRE(variant == 0 || variant == 2, "debug_wgrad_clock: variant 0 (the product loop) or 2 (operands loaded once)");
+    IDL_REQUIRE((((uintptr_t)dy | (uintptr_t)x | (uintptr_t)grad) & 15u) == 0 && (((uintptr_t)stamps) & 7u) == 0, "debug_wgrad_clock: alignment");
+    IDL_REQUIRE((int64_t)m * n_in < (1ll << 29) && (int64_t)n_out * n_in < (1ll << 29), "debug_wgrad_clock: operands beyond 2^31 bytes");
+    wg_dev::WgArgs a{};
+    a.p = wg_dev::WgProblem{dy, x, grad, nullptr, nullptr, n_out, n_in};
+    a.m = m;
+    a.tiles_m = n_out / wg_dev::TM;
+    a.tiles = a.tiles_m * (n_in / wg_dev::TN);
+    if (const int rc = raise_lds_limit(); rc != IDL_OK) return rc;
+    const dim3 grid((unsigned)a.tiles), block(wg_dev::THREADS);
+    if (variant == 2) hipLaunchKernelGGL((wgrad_q16_clock_kernel<2>), grid, block, wg_dev::IMG_BYTES, (hipStream_t)stream, a, stamps);
+    else hipLaunchKernelGGL((wgrad_q16_clock_kernel<0>), grid, block, wg_dev::IMG_BYTES, (hipStream_t)stream, a, stamps);
     IDL_HIP_TRY(hipGetLastError());
     return IDL_OK;
 }

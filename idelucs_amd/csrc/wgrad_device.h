@@ -79,8 +79,12 @@ __host__ __device__ inline bool supported(int m, int n_out, int n_in)
 constexpr int THREADS = 320;
 constexpr int IMG_BYTES = 2 * 4 * 8 * 64 * 16;       // [W | square_avg][compute wave][rb * 4 + reg][lane] float4
 
-template <int VARIANT = 0>
-__device__ __forceinline__ void q16_tile(const WgArgs &a, const int bid, f32x4_t *img)
+// VARIANT 2 (a diagnostic): the ring loaded once with real operands and never refilled -- the MFMA stream alone on the data's bit
+// patterns.  CLK (a diagnostic, idl_debug_wgrad_clock): every compute wave stamps s_memtime (shader cycles) and s_memrealtime
+// (100 MHz) right before the first and right after the last MFMA into clk[(bid * 4 + wave) * 4 ..]: the clock the chip holds
+// under this stream is (t1 - t0) / (r1 - r0) x 100 MHz.  No stamp executes in the product instantiation.
+template <int VARIANT = 0, bool CLK = false>
+__device__ __forceinline__ void q16_tile(const WgArgs &a, const int bid, f32x4_t *img, uint64_t *clk = nullptr)
 {
     constexpr int D = RING;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -121,9 +125,16 @@ __device__ __forceinline__ void q16_tile(const WgArgs &a, const int bid, f32x4_t
                    [c12] "+v"(c12), [c13] "+v"(c13)                                                                                  \
                  : [oa] "v"(oa), [ob] "v"(ob), [pa] "s"(a.p.dy), [pb] "s"(a.p.x), [sa] "s"(sa), [sb] "s"(sb), [n] "s"(passes)        \
                  : NAME##_CLOBBERS)
+    uint64_t t0 = 0, r0 = 0, t1 = 0, r1 = 0;
+    if constexpr (CLK) asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0), "=s"(r0) : : "memory");
     if constexpr (VARIANT == 1) WGRAD_ASM(WGRAD_Q16_RING8_NOLOAD);
+    else if constexpr (VARIANT == 2) WGRAD_ASM(WGRAD_Q16_RING8_PREFILL);
     else WGRAD_ASM(WGRAD_Q16_RING8);
 #undef WGRAD_ASM
+    if constexpr (CLK) {
+        asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1), "=s"(r1) : : "memory");
+        if (lane == 0 && clk != nullptr) { uint64_t *d = clk + ((size_t)bid * 4 + wv) * 4; d[0] = t0; d[1] = t1; d[2] = r0; d[3] = r1; }
+    }
     __syncthreads();                         // the fetch wave's image is complete
     Hyper hy{};
     if (a.hyper != nullptr) hy = Hyper{a.hyper[0], a.hyper[1], a.hyper[2], a.hyper[3], a.hyper[4]};

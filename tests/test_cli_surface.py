@@ -9,6 +9,14 @@ import pytest
 from conftest import DATA
 
 
+def _free_port():
+    """A rendezvous port nobody holds (a fixed one would be blocked by a lingering rank of the previous parametrisation)."""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
 def test_flag_surface_and_defaults():
     from idelucs_amd.__main__ import build_parser
     a = vars(build_parser().parse_args(["--sequence_file", "x.fas"]))
@@ -201,7 +209,7 @@ def test_cli_two_ranks_voters_are_distinct_and_outputs_complete(tmp_path, n_clus
     env = dict(os.environ, IDELUCS_BENCH_BACKEND="gloo", IDELUCS_BENCH_DEVICES="1", IDELUCS_DUMP_VOTES=votes, PYTHONPATH=ROOT,
                HSA_ENABLE_IPC_MODE_LEGACY="0", IDELUCS_VOTER_LANES="1" if n_clusters == 5 else "4")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29613", "-m", "idelucs_amd", "--sequence_file", os.path.join(DATA, "Influenza-A.fas"),
+           "--master-port", str(_free_port()), "-m", "idelucs_amd", "--sequence_file", os.path.join(DATA, "Influenza-A.fas"),
            "--GT_file", os.path.join(DATA, "Influenza-A_GT.tsv"), "--n_clusters", str(n_clusters), "--n_epochs", "8",
            "--n_voters", str(n_voters), "--batch_sz", "512", "--k", "6"]
     r = subprocess.run(cmd, cwd=tmp_path, env=env, capture_output=True, text=True, timeout=600)
@@ -432,3 +440,35 @@ def test_cfg5_at_full_size_hot_path(tmp_path):
     assert 0.0 < j["validation"]["latent_row_norm_max"] < 1e4
     assert j["value"] > 5e5, j["value"]
     print(f"cfg5 full size: {j['value']:.0f} sequences/s, {j['ms_per_step']:.0f} ms per pass; stages {j['stage_ms']}")
+
+
+@pytest.mark.gpu
+def test_cfg3_at_full_size_one_gpu(tmp_path):
+    """BASELINE cfg3 -- 100 000 sequences x 10 kbp, n_voters = 8 -- at its FULL size under the driver on the one GPU a test box has
+    (the only BASELINE config no driver-run test exercised): `bench.py --gpus 1 --voters 8 --with-predict 1`, i.e.
+    BASELINE.md section 3's fixed job with all 8 voters on this rank (batched in lockstep), each one epoch of 586 optimizer steps
+    from its own init, predict per voter, and the exchange step -- the all-gather of the int32 assignments -- through the process
+    group of one over RCCL (reference idelucs/__main__.py:106-146).  Checked: the gathered votes are [8, 100000] in range, the
+    voters differ PAIRWISE (eight different runs), every epoch loss is finite, the timed store's rows are distributions, the
+    backend is nccl, and the line says which job its value is."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--voters", "8", "--with-predict", "1", "--steps", "1",
+                        "--warmup", "1", "--no-cpu-baseline", "--no-e2e"], cwd=tmp_path, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(line) == 1, r.stdout[-2000:]
+    j = json.loads(line[0])
+    c = j["config"]
+    assert c["n_sequences"] == 100_000 and c["seq_len"] == 10_000 and c["n_voters"] == 8 and c["optimizer_steps_per_epoch"] == 586
+    assert "cfg3" in c["workload"] and j["job"].startswith("cfg3: 8 voters")
+    assert j["ranks"] == 1 and j["backend"] == "nccl"                       # the exchange went through RCCL
+    v = j["validation"]
+    assert v["gathered_shape"] == [8, 100_000] and v["voters_pairwise_distinct"] is True
+    assert len(v["epoch_loss_last_step"]) == 8 and all(np.isfinite(x) for x in v["epoch_loss_last_step"])
+    assert all(abs(x - 1e5) < 1e2 for x in v["feats_checksum"]) and v["rows_checked"] >= 4096
+    assert "fixed_job_8_voters" not in j                                    # (that field belongs to the default one-voter line)
+    assert j["value"] > 8e5, j["value"]                                     # sequences x voters / s
+    print(f"cfg3 full size on one GPU: {j['value']:.0f} sequences x voters / s, {j['ms_per_step']:.0f} ms per pass; stages {j['stage_ms']}")

@@ -23,7 +23,7 @@ _lib.check(_lib.lib.idl_debug_stamps(out.ctypes.data_as(ctypes.c_void_p)))
 used = out[:, 1] > 0
 t0 = out[used, 0].min()
 s = (out[:, 0].astype(np.int64) - int(t0)) * 0.01; e = (out[:, 1].astype(np.int64) - int(t0)) * 0.01     # us
-hw = out[:, 2]; cu = (hw >> 8) & 0xF; se = (hw >> 13) & 0x7; sh = (hw >> 12) & 1; xcc = out[:, 3] & 0xF
+hw = out[:, 2]; cu = (hw >> 8) & 0xF; se = (hw >> 13) & 0x7; sh = (hw >> 12) & 1; xcc = out[:, 3] & 0xF; cyc = (out[:, 3] >> 8).astype(np.float64)
 nb = int(used.sum())
 print(f"{nb} workgroups; launch spans {e[used].max():.2f} us")
 for lo, hi, name in ((0, 256, "dW1 tiles"), (256, nb, "the rest")):
@@ -31,6 +31,9 @@ for lo, hi, name in ((0, 256, "dW1 tiles"), (256, nb, "the rest")):
         print(f"{name:10s}: start {s[lo:hi].min():6.2f} .. {s[lo:hi].max():6.2f}   end {e[lo:hi].min():6.2f} .. {e[lo:hi].max():6.2f}   "
               f"duration {np.min(e[lo:hi] - s[lo:hi]):6.2f} .. {np.max(e[lo:hi] - s[lo:hi]):6.2f} (median {np.median(e[lo:hi] - s[lo:hi]):.2f})")
 d = e - s
+clk = cyc[:nb] / np.maximum((out[:nb, 1] - out[:nb, 0]).astype(np.float64), 1.0) * 0.1       # GHz: shader cycles per 10 ns tick
+print(f"clock held while a workgroup ran (s_memtime / s_memrealtime): dW1 tiles median {np.median(clk[:256]):.3f} GHz "
+      f"({clk[:256].min():.3f} .. {clk[:256].max():.3f}); shader cycles per tile workgroup median {np.median(cyc[:256]):.0f}")
 if nb > 256 + 128:
     print(f"dW2 tiles (256..383): duration {d[256:384].min():.2f} .. {d[256:384].max():.2f} median {np.median(d[256:384]):.2f}")
     print("the small tensors / loss (384..): " + " ".join(f"{d[b]:.1f}" for b in range(384, nb)))

@@ -441,6 +441,7 @@ def t_e2e(args, dev, reps=2):
             torch.cuda.synchronize(); t2 = time.perf_counter()
             assert np.isfinite(loss)
             r = {"ms": 1e3 * (t2 - t0), "ingest_to_features_ms": 1e3 * (t1 - t0), "epoch_ms": 1e3 * (t2 - t1),
+                 "graph_captures_so_far": getattr(m._fused, "n_captures", 0),
                  "sequences_per_sec": args.n / (t2 - t0), "fasta_bytes": size, "host_threads": U.ingest_threads()}
             if rep > 0 and (best is None or r["ms"] < best["ms"]):
                 best = r

@@ -49,6 +49,7 @@ SIGNATURES = {
     "idl_standardise": (_int, [_vp, _int, _i64, _i64, _vp, _vp, _vp, _vp]),
     "idl_gather_pairs": (_int, [_vp, _i64, _i64, _i64, _vp, _i64, _vp, _vp, _vp, _vp]),
     "idl_gather_pairs_at": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "idl_gather_pairs_next": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
     "idl_relu_dropout_fwd": (_int, [_vp, _i64, _int, _c.c_uint64, _vp, _int, _vp]),
     "idl_head_fwd": (_int, [_vp, _vp, _vp, _int, _int, _int, _c.c_uint64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "idl_mid_fwd": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _int, _c.c_uint64, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -74,6 +75,11 @@ SIGNATURES = {
                                        _vp, _i64, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
     "idl_wgrad_supported": (_int, [_int, _int, _int]),
     "idl_wgrad_rmsprop": (_int, [_vp, _vp, _int, _int, _int, _vp, _vp, _vp, _vp, _vp]),
+    "idl_l1_fwd_supported": (_int, [_int, _int, _int]),
+    "idl_l1_fwd_parts": (_int, []),
+    "idl_l1_fwd": (_int, [_vp, _vp, _vp, _vp, _int, _int, _int, _c.c_uint64, _vp, _vp, _int, _vp, _vp]),
+    "idl_l1_fwd_gather": (_int, [_vp, _vp, _vp, _vp, _int, _int, _int, _c.c_uint64, _vp, _vp, _int, _vp,
+                                 _vp, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _int, _int, _int, _vp]),
     "idl_debug_wgrad_clock": (_int, [_vp, _vp, _int, _int, _int, _vp, _int, _vp, _vp]),
     "idl_rmsprop_step_gather_wgrad": (_int, [_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _c.c_float, _c.c_float, _vp,
                                              _vp, _i64, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _vp, _vp,

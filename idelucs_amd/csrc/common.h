@@ -26,7 +26,7 @@ int device_info(DeviceInfo *out);
 // of them as ONE launch with the voter index in the grid (blockIdx.y, or .z for the InfoNCE passes).
 constexpr int PLAN_BYTES = 1024;       // one record: PlanHead + the kernel's parameter struct at PLAN_PARAMS
 constexpr int PLAN_PARAMS = 64;
-enum { PLAN_MID_FWD = 1, PLAN_NCE = 2, PLAN_MID_BWD = 3, PLAN_RMSPROP = 4, PLAN_WGRAD_RMSPROP = 5 };
+enum { PLAN_MID_FWD = 1, PLAN_NCE = 2, PLAN_MID_BWD = 3, PLAN_RMSPROP = 4, PLAN_WGRAD_RMSPROP = 5, PLAN_L1_FWD = 6 };
 struct PlanHead {
     int32_t kind, variant;
     uint32_t grid[3], block, lds;      // of one voter's launch
@@ -37,6 +37,7 @@ static_assert(sizeof(PlanHead) <= PLAN_PARAMS, "plan header does not fit");
 void *take_plan();
 // the batched launches of the other translation units
 int nce_plan_launch(const PlanHead &h, const void *dev_plans, int n_voters, hipStream_t stream);
+int l1_plan_launch(const PlanHead &h, const void *dev_plans, int n_voters, hipStream_t stream);
 
 }  // namespace idl
 

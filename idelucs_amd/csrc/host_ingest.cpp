@@ -94,12 +94,40 @@ struct Rec {
     int64_t len;             // cleaned length
 };
 
+// CPUs the process may actually use: the cgroup's CPU quota (cgroup v2 cpu.max, v1 cfs quota / period) where one is set, else 0
+int cgroup_cpus()
+{
+    long quota = -1, period = -1;
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char q[32] = {0};
+        if (fscanf(f, "%31s %ld", q, &period) == 2 && strcmp(q, "max") != 0) quota = atol(q);
+        fclose(f);
+    } else {
+        if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(g, "%ld", &quota) != 1) quota = -1; fclose(g); }
+        if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(g, "%ld", &period) != 1) period = -1; fclose(g); }
+    }
+    if (quota <= 0 || period <= 0) return 0;
+    return (int)((quota + period - 1) / period);
+}
+
+// Reader threads.  IDELUCS_THREADS overrides.  Default (round 4, profiles/r04_ingest_threads.txt: the 1 GB cfg2 file on a 256-thread
+// host whose cgroup grants 16 CPUs): parse + pack 11.0 ms with 16 threads, 8.2 with 32, 7.6 with 48-64, but with the H2D copies in
+// flight 11.4 / 12.0 / 13.6 and ingest-to-features 17.9 / 14.3 / 15.3 -- the threads block in page faults and in the copy calls, so
+// twice the CPU quota pays and more does not.  Hence min(32, hardware threads, 2 x cgroup quota), shared out over the ranks of
+// the node (LOCAL_WORLD_SIZE: every rank of a multi-GPU job reads the file itself).
 int n_threads()
 {
     if (const char *e = getenv("IDELUCS_THREADS")) { const int t = atoi(e); if (t >= 1 && t <= 256) return t; }
-    unsigned hc = std::thread::hardware_concurrency();
-    if (hc == 0) hc = 1;
-    return (int)(hc > 16 ? 16 : hc);
+    static const int chosen = [] {
+        int t = (int)std::thread::hardware_concurrency();
+        if (t <= 0) t = 1;
+        if (const int q = cgroup_cpus(); q > 0 && 2 * q < t) t = 2 * q;
+        int ranks = 1;
+        if (const char *e = getenv("LOCAL_WORLD_SIZE")) { const int r = atoi(e); if (r >= 1 && r <= 64) ranks = r; }
+        t /= ranks;
+        return t < 1 ? 1 : (t > 32 ? 32 : t);
+    }();
+    return chosen;
 }
 
 size_t par_min_bytes()                  // files smaller than this are handled by one thread
@@ -661,7 +689,12 @@ int idl_fasta_parse_pack(const char *path, uint8_t *codes, uint8_t *mask, int64_
     auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_0 = now();
     std::vector<FastOut> outs((size_t)nt);
-    constexpr int64_t COPY_SLOTS = (int64_t)1 << 18;                  // send every 4 MB of packed codes (+ 2 MB of mask)
+    // a thread sends what it has packed in 3 pieces of its region, at most 6 MB each (16 + 8 bytes a slot).  Measured with 32 threads
+    // on the 1 GB cfg2 file (IDELUCS_COPY_DIV, parse + pack 8.2 ms alone): 2-4 pieces 12.3-12.8 ms with the copies, 8 pieces 14.6,
+    // 16 pieces 18.9 -- every hipMemcpyAsync takes the stream's lock, and the 375 MB themselves take ~12 ms beside 32 parsing threads
+    const int64_t region_slots = (int64_t)(size / 64) / nt + 1;
+    static const int copy_div = [] { const char *e = getenv("IDELUCS_COPY_DIV"); const int d = e ? atoi(e) : 0; return d >= 1 && d <= 64 ? d : 3; }();
+    const int64_t COPY_SLOTS = std::min<int64_t>((int64_t)1 << 18, std::max<int64_t>((int64_t)1 << 14, region_slots / copy_div));
     // the copies below are issued from worker threads: a new thread's current device is 0, so each worker adopts the CALLER's device
     // first (a rank of a multi-GPU job is bound to another one, and dev_codes / stream belong to it)
     int caller_dev = -1;

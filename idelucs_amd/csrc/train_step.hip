@@ -28,6 +28,7 @@
 #include "scaler_device.h"
 #include "wave_ops.h"
 #include "wgrad_device.h"
+#include "philox_device.h"
 
 namespace {
 
@@ -35,7 +36,8 @@ constexpr int H2 = 64;        // latent width of NetLinear == one wavefront
 constexpr int MAX_CPL = 4;    // classes per lane: n_clusters <= 256
 constexpr int COL_PARTS = 64; // row chunks of the partial column sums (bias gradients); 16 rows each at m = 1024
 
-struct U4 { uint32_t x, y, z, w; };
+using idl_dev::U4;
+using idl_dev::philox;        // philox_device.h: shared with l1_fwd.hip, which takes over mid_fwd_kernel's layer-1 dropout
 
 // Diagnostic phase stamps of the two middle kernels (a build with -DIDL_PHASE_STAMPS: `make STAMPS=1`; tools/stamps_mid.py): when
 // armed (idl_debug_phase_stamps), workgroups 0..63 of the stamped kernel leave up to eight s_memrealtime marks (100 MHz) each in
@@ -49,20 +51,6 @@ __device__ int idl_phase_mode = 0;           // 1: the mid-forward kernel stamps
 #define IDL_PHASE_BUF(mode, bid) nullptr
 #define IDL_PHASE_STAMP(buf, slot) do { (void)(buf); } while (0)
 #endif
-
-__device__ __forceinline__ U4 philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1)
-{
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
-        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
-        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
-        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
-        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-    }
-    return U4{c0, c1, c2, c3};
-}
 
 __device__ __forceinline__ float wave_sum(float v) { return idl_dev::wave_sum_f(v); }
 __device__ __forceinline__ float wave_max(float v) { return idl_dev::wave_max_f(v); }
@@ -158,7 +146,9 @@ constexpr int H1 = 512;
 constexpr int MID_WAVES = 16;
 constexpr int MID_GATHER_ROWS = 4;   // rows per 256-thread gather tile when the batch assembly rides in mid_fwd / mid_bwd
 
-template <bool TIN>       // TIN: a1 is stored transposed, [512, m] (the orientation hipBLASLt runs the layer-1 product fastest in)
+// PRE: the layer-1 product came from idl_l1_fwd (l1_fwd.hip), whose epilogue already applied bias / ReLU / Dropout and formed
+// lat = r1 W2^T as 8 partial sums: `a1` then points at lat_part[8][m][64] and this kernel is the head only.
+template <bool TIN, bool PRE = false>       // TIN: a1 is stored transposed, [512, m] (the orientation hipBLASLt runs the layer-1 product fastest in)
 __device__ __forceinline__ void mid_fwd_body(float *__restrict__ a1, const float *__restrict__ b1, const float *__restrict__ W2,
                                                                   const float *__restrict__ b2, const float *__restrict__ W3,
                                                                   const float *__restrict__ b3, int m, int C, int train, uint64_t seed,
@@ -184,22 +174,28 @@ __device__ __forceinline__ void mid_fwd_body(float *__restrict__ a1, const float
     // ---- every global read of the kernel is issued here, before the first dependent instruction
     float4 *src = (float4 *)(a1 + (int64_t)(r0 + l) * H1 + k0);
     float *srcT = a1 + (int64_t)k0 * m + r0 + l;             // element (row r0 + l, column k0 + i) of the transposed image: srcT[i * m]
-    float4 av[2];
-    if (TIN) {
-        float t8[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) t8[i] = srcT[(int64_t)i * m];
-        av[0] = make_float4(t8[0], t8[1], t8[2], t8[3]); av[1] = make_float4(t8[4], t8[5], t8[6], t8[7]);
-    } else {
-        av[0] = src[0]; av[1] = src[1];
-    }
+    float4 av[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
     float4 bb[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
-    if (b1 != nullptr) { bb[0] = *(const float4 *)(b1 + k0); bb[1] = *(const float4 *)(b1 + k0 + 4); }
     float4 bw[4][2];
+    float pre[8];                                // PRE: row r0 + wv's eight partial sums of lat, column `lane`
+    if constexpr (PRE) {
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct) {             // lat[:, 16 ct .. 16 ct + 15]: B[k][c] = W2[16 ct + c][k]
-        const float4 *wsrc = (const float4 *)(W2 + (int64_t)(16 * ct + l) * H1 + k0);
-        bw[ct][0] = wsrc[0]; bw[ct][1] = wsrc[1];
+        for (int p = 0; p < 8; ++p) pre[p] = a1[((int64_t)p * m + r0 + wv) * H2 + lane];
+    } else {
+        if (TIN) {
+            float t8[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) t8[i] = srcT[(int64_t)i * m];
+            av[0] = make_float4(t8[0], t8[1], t8[2], t8[3]); av[1] = make_float4(t8[4], t8[5], t8[6], t8[7]);
+        } else {
+            av[0] = src[0]; av[1] = src[1];
+        }
+        if (b1 != nullptr) { bb[0] = *(const float4 *)(b1 + k0); bb[1] = *(const float4 *)(b1 + k0 + 4); }
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {             // lat[:, 16 ct .. 16 ct + 15]: B[k][c] = W2[16 ct + c][k]
+            const float4 *wsrc = (const float4 *)(W2 + (int64_t)(16 * ct + l) * H1 + k0);
+            bw[ct][0] = wsrc[0]; bw[ct][1] = wsrc[1];
+        }
     }
     const int nct = (C + 15) / 16;               // column tiles of the logits; wave wv < nct owns tile wv
     float4 w3f[4];                               // B[k = 16 q + s][c = l] = W3[16 wv + l][16 q + s]
@@ -213,6 +209,7 @@ __device__ __forceinline__ void mid_fwd_body(float *__restrict__ a1, const float
     }
     const float b2v = b2[lane];
     const uint32_t step = (uint32_t)ctl[0];
+    if constexpr (!PRE) {
     // ---- ReLU + Dropout of layer 1, in place
     float a[8];
 #pragma unroll
@@ -251,11 +248,17 @@ __device__ __forceinline__ void mid_fwd_body(float *__restrict__ a1, const float
     IDL_PHASE_STAMP(stf, 2);
     __syncthreads();
     IDL_PHASE_STAMP(stf, 3);
+    }
     // ---- wave wv owns row wv of the tile: add the 16 K-slices and the bias; normalise; ReLU + Dropout of the latent
     const int row = r0 + wv, cs = (lane + 16 * (wv >> 2)) & 63;
     float x = b2v;
+    if constexpr (PRE) {
 #pragma unroll
-    for (int w = 0; w < MID_WAVES; ++w) x += part[w][wv][cs];
+        for (int p = 0; p < 8; ++p) x += pre[p];             // h-tiles in ascending order: the same sum wherever it runs
+    } else {
+#pragma unroll
+        for (int w = 0; w < MID_WAVES; ++w) x += part[w][wv][cs];
+    }
     const float nrm = fmaxf(sqrtf(wave_sum(x * x)), 1e-12f);       // F.normalize(dim=1), eps 1e-12
     float sc = 1.f;
     if (train) {                                 // as head_row
@@ -321,7 +324,7 @@ struct MidFwdParams {
 };
 static_assert(sizeof(MidFwdParams) + idl::PLAN_PARAMS <= idl::PLAN_BYTES, "MidFwdParams does not fit a plan record");
 
-template <bool TIN>
+template <bool TIN, bool PRE = false>
 __global__ __launch_bounds__(64 * MID_WAVES) void mid_fwd_kernel(float *__restrict__ a1, const float *__restrict__ b1, const float *__restrict__ W2,
                                                                   const float *__restrict__ b2, const float *__restrict__ W3,
                                                                   const float *__restrict__ b3, int m, int C, int train, uint64_t seed,
@@ -329,18 +332,18 @@ __global__ __launch_bounds__(64 * MID_WAVES) void mid_fwd_kernel(float *__restri
                                                                   float *__restrict__ inv, float *__restrict__ r2, float *__restrict__ z,
                                                                   int n_rows_wg, int tile0, int tile1, idl_dev::GatherArgs gth)
 {
-    mid_fwd_body<TIN>(a1, b1, W2, b2, W3, b3, m, C, train, seed, ctl, f, inv, r2, z, n_rows_wg, tile0, tile1, gth, (int)blockIdx.x);
+    mid_fwd_body<TIN, PRE>(a1, b1, W2, b2, W3, b3, m, C, train, seed, ctl, f, inv, r2, z, n_rows_wg, tile0, tile1, gth, (int)blockIdx.x);
 }
 
 // the same for several voters in one launch: the grid is (voters, workgroups of one voter) -- the VOTER index runs fastest, so the
 // computing workgroups of every voter are dispatched before anybody's batch-assembly workgroups (a workgroup of this kernel fills a
 // CU: voter by voter, the second half of the voters would wait behind the first half's streaming workgroups); each voter takes its
 // arguments from its plan record (common.h)
-template <bool TIN>
+template <bool TIN, bool PRE = false>
 __global__ __launch_bounds__(64 * MID_WAVES) void mid_fwd_batched_kernel(const unsigned char *__restrict__ plans)
 {
     const MidFwdParams &p = *(const MidFwdParams *)(plans + (size_t)blockIdx.x * idl::PLAN_BYTES + idl::PLAN_PARAMS);
-    mid_fwd_body<TIN>(p.a1, p.b1, p.W2, p.b2, p.W3, p.b3, p.m, p.C, p.train, p.seed, p.ctl, p.f, p.inv, p.r2, p.z, p.n_rows_wg, p.tile0, p.tile1, p.gth,
+    mid_fwd_body<TIN, PRE>(p.a1, p.b1, p.W2, p.b2, p.W3, p.b3, p.m, p.C, p.train, p.seed, p.ctl, p.f, p.inv, p.r2, p.z, p.n_rows_wg, p.tile0, p.tile1, p.gth,
                       (int)blockIdx.y);
 }
 
@@ -1183,6 +1186,7 @@ int idl_mid_fwd_gather(float *a1, const float *b1, int a1_transposed, const floa
     IDL_REQUIRE((((uintptr_t)a1 | (uintptr_t)W2 | (uintptr_t)W3) & 15u) == 0, "a1 / W2 / W3 must be 16-byte aligned");
     IDL_REQUIRE(parts >= 1 && part >= 0 && part <= part_end && part_end <= parts, "mid_fwd_gather: need 0 <= part <= part_end <= parts");
     IDL_REQUIRE(b1 == nullptr || (((uintptr_t)b1) & 15u) == 0, "mid_fwd_gather: b1 must be 16-byte aligned");
+    IDL_REQUIRE(a1_transposed >= 0 && a1_transposed <= 2 && (a1_transposed != 2 || b1 == nullptr), "mid_fwd_gather: a1_transposed is 0, 1 or 2 (2: a1 = idl_l1_fwd's lat partials, no b1)");
     idl_dev::GatherArgs g{};
     int64_t t0 = 0, t1 = 0;
     if (feats != nullptr) {                  // (feats == NULL: no batch assembly in this launch)
@@ -1195,13 +1199,15 @@ int idl_mid_fwd_gather(float *a1, const float *b1, int a1_transposed, const floa
     const dim3 grid((unsigned)(m / 16 + (t1 - t0 + 3) / 4));
     if (void *plan = idl::take_plan()) {          // recorded, not launched (idl_plan_begin)
         idl::PlanHead h{};
-        h.kind = idl::PLAN_MID_FWD; h.variant = a1_transposed ? 1 : 0; h.grid[0] = grid.x; h.grid[1] = 1; h.grid[2] = 1; h.block = 64 * MID_WAVES;
+        h.kind = idl::PLAN_MID_FWD; h.variant = a1_transposed; /* 0 row-major, 1 transposed, 2 lat partials (head only) */ h.grid[0] = grid.x; h.grid[1] = 1; h.grid[2] = 1; h.block = 64 * MID_WAVES;
         memcpy(plan, &h, sizeof(h));
         const MidFwdParams p{a1, b1, W2, b2, W3, b3, m, C, train, seed, ctl, f, inv, r2, z, m / 16, (int)t0, (int)t1, g};
         memcpy((unsigned char *)plan + idl::PLAN_PARAMS, &p, sizeof(p));
         return IDL_OK;
     }
-    if (a1_transposed) hipLaunchKernelGGL(mid_fwd_kernel<true>, grid, dim3(64 * MID_WAVES), 0, (hipStream_t)stream, a1, b1, W2, b2, W3, b3,
+    if (a1_transposed == 2) hipLaunchKernelGGL((mid_fwd_kernel<false, true>), grid, dim3(64 * MID_WAVES), 0, (hipStream_t)stream, a1, b1, W2, b2, W3, b3,
+                                               m, C, train, seed, ctl, f, inv, r2, z, m / 16, (int)t0, (int)t1, g);
+    else if (a1_transposed) hipLaunchKernelGGL(mid_fwd_kernel<true>, grid, dim3(64 * MID_WAVES), 0, (hipStream_t)stream, a1, b1, W2, b2, W3, b3,
                                           m, C, train, seed, ctl, f, inv, r2, z, m / 16, (int)t0, (int)t1, g);
     else hipLaunchKernelGGL(mid_fwd_kernel<false>, grid, dim3(64 * MID_WAVES), 0, (hipStream_t)stream, a1, b1, W2, b2, W3, b3,
                             m, C, train, seed, ctl, f, inv, r2, z, m / 16, (int)t0, (int)t1, g);
@@ -1637,9 +1643,12 @@ int idl_plan_launch(const void *host_plans, const void *dev_plans, int n_voters,
     const hipStream_t st = (hipStream_t)stream;
     switch (h.kind) {
     case idl::PLAN_MID_FWD:
-        if (h.variant) hipLaunchKernelGGL(mid_fwd_batched_kernel<true>, dim3((unsigned)n_voters, h.grid[0]), dim3(h.block), 0, st, dp);
+        if (h.variant == 2) hipLaunchKernelGGL((mid_fwd_batched_kernel<false, true>), dim3((unsigned)n_voters, h.grid[0]), dim3(h.block), 0, st, dp);
+        else if (h.variant) hipLaunchKernelGGL(mid_fwd_batched_kernel<true>, dim3((unsigned)n_voters, h.grid[0]), dim3(h.block), 0, st, dp);
         else hipLaunchKernelGGL(mid_fwd_batched_kernel<false>, dim3((unsigned)n_voters, h.grid[0]), dim3(h.block), 0, st, dp);
         break;
+    case idl::PLAN_L1_FWD:
+        return idl::l1_plan_launch(h, dev_plans, n_voters, st);
     case idl::PLAN_MID_BWD:
         hipLaunchKernelGGL(mid_bwd_batched_kernel, dim3((unsigned)n_voters, h.grid[0]), dim3(h.block), 0, st, dp);
         break;

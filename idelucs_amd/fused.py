@@ -55,6 +55,7 @@ class _Buffers:
         self.r1 = sh['r1'] if 'r1' in sh else torch.empty((m, H1), **f32)        # Linear1 output, then ReLU+Dropout in place
         self.r1T = self.r1.view(H1, m)                # the same memory as the transposed image [H1, m] (one of the two is in use)
         self.lat = torch.empty((m, H2), **f32)
+        self.lat_part = torch.empty((_L.idl_l1_fwd_parts(), m, H2), **f32)      # idl_l1_fwd: partial sums of r1 W2^T per 64-unit tile of the hidden layer
         self.f = torch.empty((m, H2), **f32)
         self.inv = torch.empty((m,), **f32)
         self.r2 = torch.empty((m, H2), **f32)
@@ -143,6 +144,15 @@ class FusedLinearTrainer:
         self._gsplit = min(max(int(os.environ.get("IDELUCS_GATHER_SPLIT", "4")), 0), 8)   # eighths of the tiles the mid-forward launch takes
         # layer-1 activations kept transposed ([512, m]) between the layer-1 product and its consumers
         self._transposed_l1 = os.environ.get("IDELUCS_TRANSPOSED_L1", "1") != "0"
+        # OPT-IN (IDELUCS_L1_FUSED=1; measured, not adopted -- DESIGN 4.4): the layer-1 product on this package's own MFMA tiles with bias /
+        # ReLU / Dropout and the K-split of Linear(512, 64) in its epilogue (csrc/l1_fwd.hip, idl_l1_fwd); the mid-forward launch is then
+        # the head alone.  The bare product ties hipBLASLt (32.1-33.1 us against 32.8-33.7) and the head's own path shrinks from 8.9 to
+        # 2.6 us, but that launch's LENGTH is set by the batch assembly riding in it (three dependent memory round trips, ~8-10 us),
+        # which stays: 36.4 + 10.4 us against 32.8 + 11.0, the step 114.7 us against 111.8.
+        self._l1_fused = os.environ.get("IDELUCS_L1_FUSED", "0") != "0"
+        # eighths of the next batch's tiles assembled by RIDER workgroups of that launch (default 0: beside fp32 MFMA waves, which hold
+        # the vector issue port, the riders' arithmetic costs the tiles 9 us for the 7 us it saves the middle launches)
+        self._l1_gather = min(max(int(os.environ.get("IDELUCS_L1_GATHER", "0")), 0), 8)   # eighths of the next batch's tiles its riders assemble
         # opt-in: InfoNCE pass 2 + IIC core inside the mid-backward launch (one boundary less, but the InfoNCE tiles then run on
         # the 64 CUs of that launch instead of 256: the fused launch takes 32.8 us against 9.5 + 13.5 -- measured +8 us per step)
         self._nce_bwd_fused = os.environ.get("IDELUCS_NCE_BWD_FUSED", "0") != "0"
@@ -215,17 +225,28 @@ class FusedLinearTrainer:
         main = torch.cuda.current_stream()
         side = self._side if self._overlap else main
         # ---- forward
-        if tl:      # a1^T = W1 x^T: the orientation hipBLASLt runs this product fastest in; mid_fwd adds the bias
+        l1 = tl and self._l1_fused and early and self._early_split and bool(_L.idl_l1_fwd_supported(m, self.H1, self.F))
+        # shares (eighths) of the next batch's assembly: [0, g1) riders of the layer-1 launch, [g1, g2) the mid-forward launch, [g2, 8) mid-backward
+        g1 = self._l1_gather if l1 else 0
+        g2 = max(g1, self._gsplit)
+        if l1:      # own tiles: r1^T = Dropout(ReLU(W1 x^T + b1)) and the partial sums of lat = r1 W2^T straight from the accumulators
+            st = next_from      # ... with shares [0, g1) of the next batch's tiles assembled by riders of the same launch (HBM is idle under it)
+            self._k(_L.idl_l1_fwd_gather, _p(self.W1), _p(x), _p(self.b1), _p(self.W2), m, self.F, tr, self.seed, _p(self.ctl), _p(bf.r1), 1,
+                    _p(bf.lat_part),
+                    _p(st.feats), st.n, st.f, st.n * st.f, _p(self._perm), _p(self.ctl[1:]), m // 2, st.n_pairs, m // 2,
+                    _p(st.mean), _p(st.scale), _p(st.inv_scale), _p(bf.xs[1 - xi]), 0, self._l1_gather, 8, _stream())
+        elif tl:    # a1^T = W1 x^T: the orientation hipBLASLt runs this product fastest in; mid_fwd adds the bias
             self._mm(self.W1, x.t(), bf.r1T)
         else:
             torch.addmm(self.b1, x, self.W1.t(), out=bf.r1)
         if early and self._early_split:         # ... and the first half of the next batch's tiles in its spare workgroups
             st = next_from
-            self._k(_L.idl_mid_fwd_gather, _p(bf.r1), _p(self.b1) if tl else None, 1 if tl else 0, _p(self.W2), _p(self.b2), _p(self.W3), _p(self.b3),
+            self._k(_L.idl_mid_fwd_gather, _p(bf.lat_part) if l1 else _p(bf.r1), _p(self.b1) if (tl and not l1) else None,
+                    2 if l1 else (1 if tl else 0), _p(self.W2), _p(self.b2), _p(self.W3), _p(self.b3),
                     m, C, tr, self.seed, _p(self.ctl),
                     _p(bf.f), _p(bf.inv), _p(bf.r2), _p(bf.z),
                     _p(st.feats), st.n, st.f, st.n * st.f, _p(self._perm), _p(self.ctl[1:]), m // 2, st.n_pairs, m // 2,
-                    _p(st.mean), _p(st.scale), _p(st.inv_scale), _p(bf.xs[1 - xi]), 0, self._gsplit, 8, _stream())
+                    _p(st.mean), _p(st.scale), _p(st.inv_scale), _p(bf.xs[1 - xi]), g1, g2, 8, _stream())
         elif early_f:
             st = next_from
             chk(_L.idl_mid_fwd_gather(_p(bf.r1), None, 0, _p(self.W2), _p(self.b2), _p(self.W3), _p(self.b3),
@@ -278,7 +299,7 @@ class FusedLinearTrainer:
                                           _p(gW3) if self._dw3_partial else None,
                                           _p(st.feats), st.n, st.f, st.n * st.f, _p(self._perm), _p(self.ctl[1:]), m // 2, st.n_pairs, m // 2,
                                           _p(st.mean), _p(st.scale), _p(st.inv_scale), _p(bf.xs[1 - xi]),
-                                          self._gsplit if self._early_split else 0, 8, 8, 1 if tl else 0, _stream()))
+                                          g2 if self._early_split else 0, 8, 8, 1 if tl else 0, _stream()))
             if not self._dw3_partial:
                 torch.mm(bf.dlogits.t(), bf.r2, out=gW3)
             if not self._dw2_inlaunch:
@@ -289,7 +310,7 @@ class FusedLinearTrainer:
                     _p(bf.r1), m, C, tr, nce_coef, _p(bf.dlogits), _p(bf.dlat), _p(bf.dr1), _p(gb1), _p(gb2), _p(gb3),
                     _p(gW3) if self._dw3_partial else None,
                     _p(st.feats), st.n, st.f, st.n * st.f, _p(self._perm), _p(self.ctl[1:]), m // 2, st.n_pairs, m // 2,
-                    _p(st.mean), _p(st.scale), _p(st.inv_scale), _p(bf.xs[1 - xi]), self._gsplit if self._early_split else 0,
+                    _p(st.mean), _p(st.scale), _p(st.inv_scale), _p(bf.xs[1 - xi]), g2 if self._early_split else 0,
                     8, 8, 1 if tl else 0, _stream())
             if not self._dw3_partial:
                 torch.mm(bf.dlogits.t(), bf.r2, out=gW3)
@@ -442,6 +463,7 @@ class FusedLinearTrainer:
             for i in range(per):
                 self._full_step(store, bf, pipelined=pipe, xi=i % 2)
         g.replay()          # capture does not execute: run the captured step(s) once
+        self.n_captures = getattr(self, "n_captures", 0) + 1
         return g
 
 
@@ -480,6 +502,7 @@ class BatchedLinearTrainer:
         self._programs = {}
         self._graphs = {}
         self._w1_in_launch = False
+        self._l1_in_launch = False
 
     def stack(self, m):
         """Stacked GEMM operands of batch shape m: XS[2][L, m, F], R1 [L, m, 512] (its transposed image [L, 512, m] is the layer-1
@@ -506,12 +529,15 @@ class BatchedLinearTrainer:
                         t.step_on_batch(t.buffers(m), train=True, batch_advance=m // 2, next_from=store, xi=xi)
                     finally:
                         rec, t._rec = t._rec, None
-                    if len(rec.plans) != 4 or rec.mms not in (1, 2):
+                    # 4 kernel launches + the two big products as batched GEMMs; a product on own tiles is a recorded launch instead:
+                    # the layer-1 forward (idl_l1_fwd) in front, dW1 at the head of the optimizer launch
+                    if (len(rec.plans), rec.mms) not in ((4, 2), (4, 1), (5, 1), (5, 0)):
                         raise RuntimeError("the recorded step is not the default launch sequence")
-                    self._w1_in_launch = rec.mms == 1               # dW1 as MFMA tiles at the head of every voter's optimizer launch
+                    self._l1_in_launch = len(rec.plans) == 5
+                    self._w1_in_launch = rec.mms == (0 if self._l1_in_launch else 1)
                     recs.append(rec.plans)
                 ops = []
-                for k in range(4):
+                for k in range(len(recs[0])):
                     host = torch.stack([recs[l][k] for l in range(self.L)]).contiguous()
                     ops.append((host, host.to(self.dev)))
                 prog.append(ops)
@@ -523,13 +549,18 @@ class BatchedLinearTrainer:
         """One optimizer step of every voter on the batches in XS[xi] (assembling the next ones into XS[1 - xi])."""
         L = self.L
         ops = prog[xi]
-        r1T = st['r1'].view(L, self._H1, -1)
-        torch.bmm(self.W1s, st['xs'][xi].transpose(1, 2), out=r1T)                        # a1^T = W1 x^T per voter
-        for k in (0, 1, 2):                                                              # mid_fwd, InfoNCE passes, mid_bwd
+        k0 = 0
+        if self._l1_in_launch:                                                           # every voter's layer-1 tiles + epilogue: one launch
+            _lib.check(_L.idl_plan_launch(ctypes.c_void_p(ops[0][0].data_ptr()), _p(ops[0][1]), L, _stream()))
+            k0 = 1
+        else:
+            r1T = st['r1'].view(L, self._H1, -1)
+            torch.bmm(self.W1s, st['xs'][xi].transpose(1, 2), out=r1T)                    # a1^T = W1 x^T per voter
+        for k in (k0, k0 + 1, k0 + 2):                                                   # mid_fwd, InfoNCE passes, mid_bwd
             _lib.check(_L.idl_plan_launch(ctypes.c_void_p(ops[k][0].data_ptr()), _p(ops[k][1]), L, _stream()))
         if not self._w1_in_launch:
             torch.bmm(st['dr1'].transpose(1, 2), st['xs'][xi], out=self.gW1s)            # dW1 = dr1^T x per voter
-        _lib.check(_L.idl_plan_launch(ctypes.c_void_p(ops[3][0].data_ptr()), _p(ops[3][1]), L, _stream()))
+        _lib.check(_L.idl_plan_launch(ctypes.c_void_p(ops[k0 + 3][0].data_ptr()), _p(ops[k0 + 3][1]), L, _stream()))
 
     # ------------------------------------------------------------------ one epoch of every voter
     @torch.no_grad()

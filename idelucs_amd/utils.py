@@ -607,7 +607,7 @@ def standardise(x, mean, scale, out=None):
 
 
 def ingest_threads():
-    """Threads the C++ FASTA reader uses (IDELUCS_THREADS, default min(16, hardware threads))."""
+    """Threads the C++ FASTA reader uses (IDELUCS_THREADS; default min(32, hardware threads, 2 x cgroup CPU quota) / ranks of the node)."""
     return int(_L.idl_ingest_threads())
 
 

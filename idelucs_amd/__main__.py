@@ -113,6 +113,11 @@ def run(args):
         all_curves = [None] * world
         dist.all_gather_object(all_curves, curves)
         curves = {k: v for c in all_curves for k, v in c.items()}
+    core = None
+    if world > 1 and use_hdbscan:
+        # the fine-grained mode's post-hoc stage starts on ALL ranks: each takes its rows of the core-distance pass (3 s of the 21 s
+        # HDBSCAN at cfg5 on one GPU) before the others leave; Prim and the tree code stay on rank 0
+        core = posthoc.core_distances_sharded(latent, device=model.device)
     if rank != 0:
         dist.destroy_process_group()
         return
@@ -135,7 +140,7 @@ def run(args):
         else:                                                      # same ensemble on the GPU
             y_pred, probabilities = posthoc.label_features_device(preds, args["n_clusters"], device=model.device, seed=args.get("seed", 0))
     else:
-        y_pred, probabilities = posthoc.fine_grained_clusters(latent)
+        y_pred, probabilities = posthoc.fine_grained_clusters(latent, core=core)
         args["n_clusters"] = int(np.max(y_pred) + 1)
     mark("ensemble / HDBSCAN")
 

@@ -49,7 +49,6 @@ SIGNATURES = {
     "idl_standardise": (_int, [_vp, _int, _i64, _i64, _vp, _vp, _vp, _vp]),
     "idl_gather_pairs": (_int, [_vp, _i64, _i64, _i64, _vp, _i64, _vp, _vp, _vp, _vp]),
     "idl_gather_pairs_at": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
-    "idl_gather_pairs_next": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
     "idl_relu_dropout_fwd": (_int, [_vp, _i64, _int, _c.c_uint64, _vp, _int, _vp]),
     "idl_head_fwd": (_int, [_vp, _vp, _vp, _int, _int, _int, _c.c_uint64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "idl_mid_fwd": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _int, _c.c_uint64, _vp, _vp, _vp, _vp, _vp, _vp]),

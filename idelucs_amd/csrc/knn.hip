@@ -48,6 +48,11 @@ struct WindowArgs {
 // lo - |a|^2 (8 u); u = 2^-23 leaves a factor two for the matrix cores' internal rounding.
 constexpr float GRAM_ERR = 144.0f * 1.1920929e-7f;
 
+// (Round 4, measured and NOT adopted: staging a row's kept columns in an LDS ring and storing them eight at a time, 2 x 32 contiguous
+//  bytes instead of two scattered 4-byte stores per column -- the 0.9 TB of sector traffic at cfg5 was taken for the gap between
+//  0.38 and 0.60 of the MFMA peak.  It is not: 2.80 s per pass at 10^6 points against 2.19 s, same rows, bit-identical results.  fp32
+//  MFMA issues at the vector rate, so the two ds_write + the flush branch per kept column cost matrix time, while a global store is
+//  one VMEM issue that the matrix pipe does not wait for; and 64 KB of LDS halves the workgroups per CU.)
 __global__ __launch_bounds__(256) void knn_window_kernel(WindowArgs a)
 {
     __shared__ int slot_n[ROWS_WG];
@@ -201,7 +206,8 @@ __global__ __launch_bounds__(256) void knn_select_kernel(SelectArgs a)
     // ---- radix select: the `want`-th smallest key, 8 bits per pass from the top.  Keys are taken relative to the window's lower
     // end, so that only the bits in which the kept values differ are walked (a window spans ~2^20 floats: three passes, and the
     // first histogram is spread over its bins instead of piling every lane's atomic on one)
-    const uint32_t kbase = fkey(a.lo[rloc]);
+    const float lo_f = a.lo[rloc];
+    const uint32_t kbase = fkey(lo_f);
     const uint32_t span = fkey(a.hi[rloc]) - kbase;
     const int passes = span ? (32 - __builtin_clz(span) + 7) / 8 : 1;
     uint32_t prefix = 0, mask = 0;
@@ -211,7 +217,12 @@ __global__ __launch_bounds__(256) void knn_select_kernel(SelectArgs a)
         hist[tid] = 0;
         __syncthreads();
         for (int i = tid; i < cnt; i += 256) {
-            const uint32_t key = fkey(d2[i]) - kbase;
+            // (a kept value is stored as t2 + |a - m|^2 AFTER the window test on t2: rounding can leave it an ulp below lo or at hi.
+            //  Clamped into [lo, hi] before keying -- unclamped, key - kbase would wrap and the value be binned as the largest, or alias
+            //  under the walked bits, shifting the selected rank: ADVICE r3.  A selection that lands on a clamped end fails the
+            //  edge test below and the row goes to the exact path.)
+            uint32_t key = fkey(fmaxf(d2[i], lo_f)) - kbase;
+            key = key > span ? span : key;
             if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1);
         }
         __syncthreads();

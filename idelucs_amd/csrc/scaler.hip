@@ -231,20 +231,4 @@ int idl_gather_pairs_at(const float *feats, int64_t n, int64_t f, int64_t view_s
     return IDL_OK;
 }
 
-/* The batch BEHIND the one *base points at (base_add = the batch size), rows beyond n_pairs skipped: the next batch assembled by a
- * launch of its own -- on a forked branch of the step's graph it runs beside the small launches of the step (fused.py, opt-in). */
-int idl_gather_pairs_next(const float *feats, int64_t n, int64_t f, int64_t view_stride, const int64_t *pair_idx, const int64_t *base,
-                          int64_t base_add, int64_t n_pairs, int64_t batch, const double *mean, const double *scale,
-                          const double *inv_scale, float *y, void *stream)
-{
-    IDL_REQUIRE(n >= 1 && f >= 1 && batch >= 1 && n_pairs >= 0, "gather_pairs_next needs n >= 1, f >= 1, batch >= 1, n_pairs >= 0");
-    IDL_REQUIRE(feats && pair_idx && mean && scale && y, "NULL buffer");
-    IDL_REQUIRE((f & 3) != 0 || ((((uintptr_t)feats | (uintptr_t)y) & 15u) == 0 && (view_stride & 3) == 0),
-                "feats/y must be 16-byte aligned and view_stride a multiple of 4 when f % 4 == 0");
-    idl_dev::GatherArgs g{feats, n, f, view_stride, pair_idx, base, batch, n_pairs, mean, scale, inv_scale, y, base_add};
-    hipLaunchKernelGGL(gather_pairs_kernel, dim3((unsigned)idl_dev::gather_blocks(f, batch)), dim3(256), 0, (hipStream_t)stream, g);
-    IDL_HIP_TRY(hipGetLastError());
-    return IDL_OK;
-}
-
 }  // extern "C"

@@ -243,7 +243,8 @@ def _hdbscan(points, min_cluster_size, device=None):
         if len(points) >= HDBSCAN_DEVICE_MIN and os.environ.get("IDELUCS_HDBSCAN", "device") != "host":
             return hdbscan_device(points, max(min_cluster_size, 2), device=device)
         from sklearn.cluster import HDBSCAN
-        cl = HDBSCAN(min_cluster_size=max(min_cluster_size, 2))
+        mcs = max(min_cluster_size, 2)
+        cl = HDBSCAN(min_cluster_size=mcs, min_samples=min(core_neighbour_rank(mcs), len(points)))     # (min_samples = mcs unless IDELUCS_HDBSCAN_RANK=hdbscan)
     cl.fit(points)
     return cl.labels_, cl.probabilities_
 
@@ -316,7 +317,7 @@ def _spatial_order(x64, pivots=256, seed=0):
     return perm, gid
 
 
-def _core_distances_window(x64, k, device, out, sample=None, seed=0, stats=None, order=None):
+def _core_distances_window(x64, k, device, out, sample=None, seed=0, stats=None, order=None, shard=None):
     """Core distances without the distance matrix (csrc/knn.hip).  Needs 64 coordinates that float32 holds exactly.
       0. order the points by their nearest of 256 random pivots (_spatial_order), every group padded to whole waves of 64 rows;
       1. bracket: the squared distances (float64) of every row to KNN_SAMPLE random columns; the k-th of all n lies, with
@@ -325,7 +326,10 @@ def _core_distances_window(x64, k, device, out, sample=None, seed=0, stats=None,
       3. idl_knn_select: radix select among the kept ones, then the float64 distances (difference vector, sklearn's order of
          operations) of everything within twice the pass's rounding bound of the selected value: the exact k-th.
     Rows the bracket missed (status != 0) are returned for the caller's matrix path: the int64 tensor of those rows, or None
-    when k / n allows no bracket."""
+    when k / n allows no bracket.
+    shard = (rank, world): the ranks of a process group split the padded rows between them (whole 256-row blocks; brackets, window
+    pass and selection for the own rows only -- each row's result is a function of the inputs alone, so it is the single-rank
+    result bit for bit) and add their float64 / status vectors up (one all-reduce each): every rank returns the full vector."""
     import ctypes
     import math
     import torch
@@ -346,17 +350,6 @@ def _core_distances_window(x64, k, device, out, sample=None, seed=0, stats=None,
     g = torch.Generator(device="cpu"); g.manual_seed(seed)
     cols = torch.randperm(n, generator=g)[:S].to(device)
     xs_t, sqs = xo[cols].t().contiguous(), sq[cols]
-    # the bracket of every row, from the float64 distances to the sampled columns
-    lo_all = torch.empty(n, dtype=torch.float32, device=device)
-    hi_all = torch.empty(n, dtype=torch.float32, device=device)
-    sub = 16384                                                 # rows of one sampled block: 16384 x 16384 float64 = 2 GB
-    for b0 in range(0, n, sub):
-        b1 = min(b0 + sub, n)
-        ds = torch.mm(xo[b0:b1], xs_t).mul_(-2.0).add_(sqs[None, :]).add_(sq[b0:b1, None])
-        vals = torch.topk(ds, r_hi, dim=1, largest=False, sorted=True).values
-        hi_all[b0:b1] = vals[:, r_hi - 1]
-        lo_all[b0:b1] = vals[:, r_lo - 1] if r_lo >= 1 else -1.0e30          # (no lower rank: nothing is below, every column under hi is kept)
-        del ds, vals
     # every group padded to whole waves of 64 rows, so that no wave (which centres its coordinates on its first row) straddles two groups;
     # the padding is infinitely far from everything (never counted, never kept) and brackets nothing itself
     counts = torch.bincount(gid)
@@ -364,6 +357,24 @@ def _core_distances_window(x64, k, device, out, sample=None, seed=0, stats=None,
     first, start = torch.cumsum(counts, 0) - counts, torch.cumsum(padded, 0) - padded
     pos = start[gid] + (torch.arange(n, device=device) - first[gid])
     npad = int(padded.sum())
+    # this rank's share of the padded rows (whole 256-row blocks; everything without a process group)
+    p_lo, p_hi = 0, npad
+    if shard is not None and shard[1] > 1:
+        blocks = -(-npad // 256)
+        per = -(-blocks // shard[1])
+        p_lo, p_hi = min(npad, shard[0] * per * 256), min(npad, (shard[0] + 1) * per * 256)
+    mine = torch.nonzero((pos >= p_lo) & (pos < p_hi)).squeeze(1)            # positions (memory order) whose padded row is this rank's
+    # the bracket of every own row, from the float64 distances to the sampled columns
+    lo_all = torch.full((n,), -1.0, dtype=torch.float32, device=device)
+    hi_all = torch.full((n,), -1.0, dtype=torch.float32, device=device)
+    sub = 16384                                                 # rows of one sampled block: 16384 x 16384 float64 = 2 GB
+    for b0 in range(0, int(mine.numel()), sub):
+        idx = mine[b0:b0 + sub]
+        ds = torch.mm(xo[idx], xs_t).mul_(-2.0).add_(sqs[None, :]).add_(sq[idx, None])
+        vals = torch.topk(ds, r_hi, dim=1, largest=False, sorted=True).values
+        hi_all[idx] = vals[:, r_hi - 1].to(torch.float32)
+        lo_all[idx] = vals[:, r_lo - 1].to(torch.float32) if r_lo >= 1 else -1.0e30   # (no lower rank: nothing is below, every column under hi is kept)
+        del ds, vals
     x32 = torch.zeros((npad, d), dtype=torch.float32, device=device)
     x32[:, 0] = 1.0e18
     x32[pos] = xo.to(torch.float32)
@@ -379,11 +390,11 @@ def _core_distances_window(x64, k, device, out, sample=None, seed=0, stats=None,
     delta = torch.empty(chunk, dtype=torch.float32, device=device)
     cnt_lo = torch.empty(chunk, dtype=torch.int32, device=device)
     cnt_in = torch.empty(chunk, dtype=torch.int32, device=device)
-    status_p = torch.empty(npad, dtype=torch.int32, device=device)
+    status_p = torch.zeros(npad, dtype=torch.int32, device=device)
     core_p = torch.zeros(npad, dtype=torch.float64, device=device)
     stream = vp(torch.cuda.current_stream().cuda_stream)
-    for row0 in range(0, npad, chunk):
-        rows = min(chunk, npad - row0)
+    for row0 in range(p_lo, p_hi, chunk):
+        rows = min(chunk, p_hi - row0)
         _lib.check(L.idl_knn_window(vp(x32.data_ptr()), npad, d, vp(lo_p[row0:].data_ptr()), vp(hi_p[row0:].data_ptr()), row0, rows, vp(cnt_lo.data_ptr()),
                                     vp(cnt_in.data_ptr()), vp(delta.data_ptr()), vp(cand_d2.data_ptr()), vp(cand_ix.data_ptr()), cap, stream))
         _lib.check(L.idl_knn_select(vp(x32.data_ptr()), npad, d, vp(lo_p[row0:].data_ptr()), vp(hi_p[row0:].data_ptr()), vp(delta.data_ptr()), row0, rows, k,
@@ -391,6 +402,12 @@ def _core_distances_window(x64, k, device, out, sample=None, seed=0, stats=None,
                                     vp(core_p.data_ptr()), vp(status_p[row0:].data_ptr()), stream))
         if stats is not None:
             stats["kept_max"] = max(stats.get("kept_max", 0), int(cnt_in[:rows].max()))
+    if shard is not None and shard[1] > 1:                      # the other ranks' rows: zeros here, theirs there
+        import torch.distributed as tdist
+        core_p[:p_lo] = 0.0; core_p[p_hi:] = 0.0
+        status_p[:p_lo] = 0; status_p[p_hi:] = 0
+        tdist.all_reduce(core_p)
+        tdist.all_reduce(status_p)
     core_o, status = core_p[pos], status_p[pos]
     out[perm] = core_o
     missed = perm[torch.nonzero(status).squeeze(1)]
@@ -400,11 +417,14 @@ def _core_distances_window(x64, k, device, out, sample=None, seed=0, stats=None,
     return missed
 
 
-def core_distances_device(x64, k, device, f32_exact=None, stats=None, order=None):
+def core_distances_device(x64, k, device, f32_exact=None, stats=None, order=None, shard=None):
     """Distance of every point to its k-th nearest neighbour, itself included (sklearn _hdbscan_prims: NearestNeighbors(
     n_neighbors=k).kneighbors(X)[:, -1]).  From KNN_WINDOW_MIN points of 64 float32-exact coordinates (the latent of the
     reference's networks) the one-pass window kernels; else, and for the rows their bracket missed, the float64 Gram-form matrix
-    in row blocks (_core_distances_rows).  $IDELUCS_KNN = matrix | window forces one."""
+    in row blocks (_core_distances_rows).  $IDELUCS_KNN = matrix | window forces one.
+    shard = (rank, world) (every rank of the group must call, with the same points): the window path's rows are split over the
+    ranks and the result all-reduced (_core_distances_window); the few rows the brackets missed, and the matrix path, are computed
+    by every rank for itself -- the same values everywhere."""
     import torch
     n = x64.shape[0]
     sq = (x64 * x64).sum(1)
@@ -414,7 +434,7 @@ def core_distances_device(x64, k, device, f32_exact=None, stats=None, order=None
         f32_exact = bool((x64.to(torch.float32).double() == x64).all())
     todo = None
     if mode != "matrix" and f32_exact and x64.shape[1] == 64 and (n >= KNN_WINDOW_MIN or mode == "window"):
-        todo = _core_distances_window(x64, k, device, core, stats=stats, order=order)
+        todo = _core_distances_window(x64, k, device, core, stats=stats, order=order, shard=shard)
         if todo is None and mode == "window":
             raise ValueError("core_distances_device: no bracket for this k / n (IDELUCS_KNN=window)")
     if todo is None:
@@ -458,12 +478,26 @@ def _local_q8(xo, gid):
     return word.t().contiguous(), r32.contiguous(), glo.contiguous(), gscale.contiguous()
 
 
-def hdbscan_device(points, min_cluster_size, device=None, stats=None):
+def core_neighbour_rank(min_samples):
+    """The neighbour whose distance is a point's core distance, counting the point itself.  Default: min_samples -- sklearn's
+    _hdbscan_prims, `NearestNeighbors(n_neighbors=min_samples).kneighbors(X)[:, -1]`, the stand-in this package is pinned to.
+    IDELUCS_HDBSCAN_RANK=hdbscan: min_samples + 1, what the `hdbscan` package the reference calls (idelucs/__main__.py:83,
+    hdbscan==0.8.32) asks its trees for -- hdbscan/hdbscan_.py, _hdbscan_prims_kdtree / _hdbscan_prims_balltree:
+    `core_distances = tree.query(X, k=min_samples + 1, dualtree=True, breadth_first=True)[0][:, -1]` (its generic path takes
+    np.partition(distance_matrix, min_points, axis=0)[min_points], the same rank) -- one neighbour further.  The package is absent
+    here, so this switch is UNPINNED (cited from the package's source as recalled), and the default stays sklearn's."""
+    return int(min_samples) + (1 if os.environ.get("IDELUCS_HDBSCAN_RANK", "sklearn") == "hdbscan" else 0)
+
+
+def hdbscan_device(points, min_cluster_size, device=None, stats=None, core=None, shard=None):
     """sklearn.cluster.HDBSCAN(min_cluster_size).fit(points) -> (labels_, probabilities_) with the two O(N^2) stages on the GPU:
     core distances (core_distances_device) and Prim's minimum spanning tree of the mutual-reachability graph (csrc/mst.hip,
     idl_mst_prim: sklearn's mst_from_data_matrix visit for visit, in float64); the edges then go through sklearn's own
     single-linkage / condensed-tree code (sklearn.cluster._hdbscan: make_single_linkage, tree_to_labels -- private names of
-    sklearn 1.7, the stand-in for the absent `hdbscan` package: SURVEY 8c), so the labels are sklearn's."""
+    sklearn 1.7, the stand-in for the absent `hdbscan` package: SURVEY 8c), so the labels are sklearn's.
+    core: the core distances (float64 [n], device or host) when the caller has them already (the CLI computes them over all ranks of
+    a multi-GPU job before the others leave: core_distances_sharded); shard = (rank, world): compute them here, split over the
+    ranks of the process group (every rank must call with the same points; all return the same labels)."""
     import ctypes
     import torch
     try:
@@ -492,7 +526,11 @@ def hdbscan_device(points, min_cluster_size, device=None, stats=None):
     t0 = time.time()
     use_filter = d % 4 == 0 and d <= 64 and n >= MST_FILTER_MIN and os.environ.get("IDELUCS_MST_FILTER", "1") != "0"
     order = _spatial_order(x64) if use_filter else None
-    core = core_distances_device(x64, k, dev, f32_exact=f32_exact, stats=stats, order=order)
+    if core is None:
+        core = core_distances_device(x64, min(core_neighbour_rank(k), n), dev, f32_exact=f32_exact, stats=stats, order=order, shard=shard)
+    else:
+        core = torch.as_tensor(core, dtype=torch.float64).to(dev).contiguous()
+        assert core.numel() == n
     if stats is not None:
         torch.cuda.synchronize(dev); stats["core_s"] = time.time() - t0; t0 = time.time()
     vp = ctypes.c_void_p
@@ -562,7 +600,28 @@ def hdbscan_device(points, min_cluster_size, device=None, stats=None):
     return labels, prob
 
 
-def fine_grained_clusters(latent, exact_max=None, seed=0, device=None, mode=None):
+def core_distances_sharded(latent, device=None):
+    """The core distances fine_grained_clusters' device HDBSCAN will need, computed by ALL ranks of the process group (rows of the
+    one-pass window kernels split between them, one all-reduce): call on every rank with the same latent, before the ranks other
+    than 0 leave.  None when the device path would not be taken (few points, approx / host mode) -- rank 0 then does as before."""
+    import torch
+    import torch.distributed as tdist
+    latent = np.asarray(latent)
+    n = len(latent)
+    mode = os.environ.get("IDELUCS_HDBSCAN", "device")
+    if n <= HDBSCAN_EXACT_MAX or mode == "approx" or not (tdist.is_available() and tdist.is_initialized()) or tdist.get_world_size() < 2:
+        return None
+    dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+    pts = np.ascontiguousarray(latent, dtype=np.float64)
+    x64 = torch.from_numpy(pts).to(dev)
+    k = max(n // 100 + 1, 2)
+    use_filter = pts.shape[1] % 4 == 0 and pts.shape[1] <= 64 and n >= MST_FILTER_MIN and os.environ.get("IDELUCS_MST_FILTER", "1") != "0"
+    order = _spatial_order(x64) if use_filter else None            # (the order hdbscan_device will use: same seed, same groups)
+    core = core_distances_device(x64, min(core_neighbour_rank(k), n), dev, order=order, shard=(tdist.get_rank(), tdist.get_world_size()))
+    return core.cpu().numpy()
+
+
+def fine_grained_clusters(latent, exact_max=None, seed=0, device=None, mode=None, core=None):
     """n_clusters=0 mode (reference __main__.py:82-83,153-156): HDBSCAN(min_cluster_size=N//100+1) on the last voter's latent;
     labels+1, probabilities.  `hdbscan` is used when importable, else sklearn.cluster.HDBSCAN (parity with hdbscan==0.8.32 is
     unpinned -- SURVEY 8c).
@@ -589,7 +648,7 @@ def fine_grained_clusters(latent, exact_max=None, seed=0, device=None, mode=None
         raise ValueError("fine_grained_clusters: mode must be 'device' or 'approx'")
     if mode == "device":
         stats = {} if os.environ.get("IDELUCS_TIMING") else None
-        labels, prob = hdbscan_device(latent, n // 100 + 1, device=device, stats=stats)
+        labels, prob = hdbscan_device(latent, n // 100 + 1, device=device, stats=stats, core=core)
         if stats is not None:
             stats.pop("mst_edges", None)
             print("HDBSCAN on the device:", {k: (round(v, 2) if isinstance(v, float) else v) for k, v in stats.items()})

@@ -1,5 +1,7 @@
 """Core distances of the fine-grained mode's HDBSCAN (reference __main__.py:83,153-156) by the one-pass window kernels
 (csrc/knn.hip: idl_knn_window + idl_knn_select) against the float64 matrix path and against the definition itself."""
+import os
+
 import numpy as np
 import pytest
 
@@ -176,3 +178,44 @@ def test_core_distances_when_no_bracket_exists(monkeypatch):
     monkeypatch.setenv("IDELUCS_KNN", "window")
     with pytest.raises(ValueError):
         posthoc.core_distances_device(xd, k, dev)
+
+
+def test_core_distances_sharded_over_two_ranks(tmp_path):
+    """the fine-grained mode's post-hoc stage over the ranks that are already there.  Two ranks (sharing this box's
+    GPU, collectives over gloo) split the rows of the one-pass window kernels; every rank ends with exactly the single-rank
+    core distances (each row's value is a function of the inputs alone), and HDBSCAN from them gives the same labels and
+    probabilities (tests/dist_core_worker.py)."""
+    import socket
+    import subprocess
+    import sys
+    from conftest import ROOT
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tests", "dist_core_worker.py")]
+    r = subprocess.run(cmd, cwd=tmp_path, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "SHARDED_CORE_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_core_neighbour_rank_switch(monkeypatch):
+    """IDELUCS_HDBSCAN_RANK=hdbscan takes the core distance one neighbour further (min_samples + 1 counting the point itself: what
+    the `hdbscan` package's tree queries ask for; unpinned, the package is absent) -- on the device that is sklearn's HDBSCAN with
+    min_samples = min_cluster_size + 1, label for label; the default stays sklearn's own rank."""
+    from sklearn.cluster import HDBSCAN
+    from sklearn.metrics import adjusted_rand_score
+    from idelucs_amd import posthoc
+    x = _blobs(4000, seed=5)
+    k = 41
+    assert posthoc.core_neighbour_rank(k) == k
+    monkeypatch.setenv("IDELUCS_HDBSCAN_RANK", "hdbscan")
+    assert posthoc.core_neighbour_rank(k) == k + 1
+    labels, prob = posthoc.hdbscan_device(x, k)
+    ref = HDBSCAN(min_cluster_size=k, min_samples=k + 1).fit(x)
+    assert np.array_equal(labels < 0, ref.labels_ < 0) and adjusted_rand_score(ref.labels_, labels) == 1.0
+    assert np.allclose(prob, ref.probabilities_, atol=1e-9)
+    plain = HDBSCAN(min_cluster_size=k).fit(x)
+    monkeypatch.delenv("IDELUCS_HDBSCAN_RANK")
+    l0, _ = posthoc.hdbscan_device(x, k)
+    assert np.array_equal(l0 < 0, plain.labels_ < 0) and adjusted_rand_score(plain.labels_, l0) == 1.0

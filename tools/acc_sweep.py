@@ -26,4 +26,14 @@ for fused in (0, 1):
         y, _, _ = m.predict()
         accs.append(idelucs_amd.cluster_acc(gt, y)[1])
         print(f"fused={fused} seed={seed} acc={accs[-1]:.4f} loss0={losses[0]:.4f} lossN={losses[-1]:.4f}", flush=True)
-    print(f"== fused={fused}: mean {np.mean(accs):.4f} min {np.min(accs):.4f} max {np.max(accs):.4f}")
+    print(f"== fused={fused}: n {len(accs)} mean {np.mean(accs):.4f} sd {np.std(accs, ddof=1):.4f} se {np.std(accs, ddof=1) / np.sqrt(len(accs)):.4f} "
+          f"min {np.min(accs):.4f} max {np.max(accs):.4f}")
+    res = globals().setdefault("res", {})
+    res[fused] = np.array(accs)
+if len(res) == 2:
+    from scipy import stats
+    a, b = res[0], res[1]
+    t = stats.ttest_ind(a, b, equal_var=False)
+    ks = stats.ks_2samp(a, b)
+    print(f"== autograd - fused: mean difference {np.mean(a) - np.mean(b):+.4f} (Welch t = {t.statistic:.2f}, p = {t.pvalue:.3f}); "
+          f"two-sample KS D = {ks.statistic:.3f}, p = {ks.pvalue:.3f}")

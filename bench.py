@@ -42,7 +42,7 @@ import torch.distributed as dist
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 matrix peak (v_mfma_f32_32x32x2_f32)
-PMC_PROFILE = "r03_vectorise_pmc.json"     # profiles/: FETCH_SIZE / WRITE_SIZE passes of the vectoriser at cfg2
+PMC_PROFILE = "r04_vectorise_pmc.json"     # profiles/: FETCH_SIZE / WRITE_SIZE passes of the vectoriser at cfg2
 
 
 def synth_packed(n, L, dev, seed=12345, n_rate=0.0):
@@ -295,7 +295,7 @@ def fixed_job_8_voters(din, args, dev, rank, world, passes=3):
 def pmc_traffic_gb():
     """HBM traffic of one vectorise launch at cfg2, GB, from the committed rocprofv3 PMC passes (profiles/, WRITE_SIZE exact
     for 16-B stores, FETCH_SIZE doubled per MI355X_MICROARCH.md: DESIGN.md 4.1); None when the profile is not present."""
-    for name in (PMC_PROFILE, "r02_vectorise_pmc.json"):
+    for name in (PMC_PROFILE, "r03_vectorise_pmc.json", "r02_vectorise_pmc.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as fh:
                 return json.load(fh)["traffic_gb_per_launch"]

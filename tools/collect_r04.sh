@@ -47,3 +47,5 @@ json.dump({"source": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GR
 print(json.dumps({k: round(v.get("mfma_busy_fraction_of_kernel", 0), 3) for k, v in res.items()}))
 PY
 python3 tools/stamps_step.py > $out/stamps_optimizer_launch.txt 2>&1
+bash tools/pmc_vectorise.sh $out/pmc_vec $out/vectorise_pmc.json > $out/vectorise_pmc_summary.txt 2>&1
+tail -3 $out/vectorise_pmc_summary.txt

@@ -16,7 +16,10 @@ mean, scale = U.col_stats(feats[0])
 store = U.FeatureStore(None, None, feats, mean, scale, 6, False)
 net = NetLinear(F, C).to(dev); net.apply(models.weights_init)
 tr = FusedLinearTrainer(net, 1e-3, 0.25, 2.8, seed=3)
-tr.run_epoch(store, B, use_graph=False)
+import time
+t_end = time.time() + float(os.environ.get("WARM_SECONDS", "2.5"))     # a burst from idle runs at a lower clock (round 4: 2.17 GHz in the
+while time.time() < t_end:                                             # first dozen steps, 2.41 GHz sustained -- the same 77 k cycles
+    tr.run_epoch(store, B, use_graph=False)                            # per tile workgroup, 35.5 us against 32.1): stamp the steady state
 torch.cuda.synchronize()
 out = np.zeros((1024, 4), np.uint64)
 _lib.check(_lib.lib.idl_debug_stamps(out.ctypes.data_as(ctypes.c_void_p)))

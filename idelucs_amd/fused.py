@@ -149,7 +149,9 @@ class FusedLinearTrainer:
         # the head alone.  The bare product ties hipBLASLt (32.1-33.1 us against 32.8-33.7) and the head's own path shrinks from 8.9 to
         # 2.6 us, but that launch's LENGTH is set by the batch assembly riding in it (three dependent memory round trips, ~8-10 us),
         # which stays: 36.4 + 10.4 us against 32.8 + 11.0, the step 114.7 us against 111.8.
-        self._l1_fused = os.environ.get("IDELUCS_L1_FUSED", "0") != "0"
+        self._l1_fused = os.environ.get("IDELUCS_L1_FUSED", "0") == "1"
+        # IDELUCS_L1_FUSED=bare: the same tiles as a plain product (no epilogue) in place of the library GEMM, mid_fwd unchanged
+        self._l1_bare = os.environ.get("IDELUCS_L1_FUSED", "0") == "bare"
         # eighths of the next batch's tiles assembled by RIDER workgroups of that launch (default 0: beside fp32 MFMA waves, which hold
         # the vector issue port, the riders' arithmetic costs the tiles 9 us for the 7 us it saves the middle launches)
         self._l1_gather = min(max(int(os.environ.get("IDELUCS_L1_GATHER", "0")), 0), 8)   # eighths of the next batch's tiles its riders assemble
@@ -235,6 +237,8 @@ class FusedLinearTrainer:
                     _p(bf.lat_part),
                     _p(st.feats), st.n, st.f, st.n * st.f, _p(self._perm), _p(self.ctl[1:]), m // 2, st.n_pairs, m // 2,
                     _p(st.mean), _p(st.scale), _p(st.inv_scale), _p(bf.xs[1 - xi]), 0, self._l1_gather, 8, _stream())
+        elif tl and self._l1_bare and self._rec is None and bool(_L.idl_l1_fwd_supported(m, self.H1, self.F)):
+            chk(_L.idl_l1_fwd(_p(self.W1), _p(x), None, None, m, self.F, 0, 0, None, _p(bf.r1), 1, None, _stream()))
         elif tl:    # a1^T = W1 x^T: the orientation hipBLASLt runs this product fastest in; mid_fwd adds the bias
             self._mm(self.W1, x.t(), bf.r1T)
         else:

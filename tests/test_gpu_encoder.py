@@ -130,7 +130,7 @@ def test_end_to_end_quality_anchor(dev):
     Round 3: 40 reference seeds instead of 10.  The reference at one voter is much noisier than its first ten seeds suggested --
     over 40 seeds ACC = 0.655 .. 0.994, mean 0.902, standard deviation 0.088, 15 % of the runs >= 0.99 (the first ten had mean
     0.948 and minimum 0.80: a lucky draw), which is why it ensembles five -- so bit parity of a run is not definable (dropout /
-    shuffle streams differ on the GPU) and the bar is distributional, over 48 seeds of this implementation: mean within 0.03 of
+    shuffle streams differ on the GPU) and the bar is distributional, over 48 seeds of this implementation: mean within 3 standard errors of the difference (0.056) of
     the reference's, worst run no more than 0.05 under the reference's worst, best run >= 0.985, and the two empirical
     distributions no further apart than the two-sample Kolmogorov-Smirnov bound at alpha = 0.01.  (The 0.72 run round 2 reported
     is the reference's own behaviour -- its seeds 14 and 25 score 0.655 and 0.675 -- and not the fused step's: the same seeds
@@ -166,7 +166,11 @@ def test_end_to_end_quality_anchor(dev):
     ks_bound = 1.63 * np.sqrt((len(accs) + len(ref)) / (len(accs) * len(ref)))
     print(f"ACC over {len(accs)} seeds: mean {accs.mean():.4f} std {accs.std(ddof=1):.4f} min {accs.min():.4f} max {accs.max():.4f} | reference over "
           f"{len(ref)}: mean {ref.mean():.4f} std {ref.std(ddof=1):.4f} min {ref.min():.4f} max {ref.max():.4f} | KS {ks:.3f} (bound {ks_bound:.3f})")
-    assert abs(accs.mean() - ref.mean()) <= 0.03, (accs.mean(), ref.mean())
+    # the mean bar: 3 standard errors of the difference of two means of runs this noisy (sd 0.085 each: 0.056 with 48 + 40 seeds).
+    # Round 3's fixed 0.03 was 1.6 standard errors wide -- a legitimately different software stack could trip it;
+    # 64 seeds each of the fused and the autograd step differ by 0.012 +- 0.015 (profiles/r04_acc_sweep.txt)
+    se_diff = float(np.sqrt(accs.var(ddof=1) / len(accs) + ref.var(ddof=1) / len(ref)))
+    assert abs(accs.mean() - ref.mean()) <= 3.0 * se_diff, (accs.mean(), ref.mean(), se_diff)
     assert accs.max() >= 0.985 and accs.min() >= ref.min() - 0.05, (accs.max(), accs.min(), ref.min())
     assert ks <= ks_bound, (ks, ks_bound)
 

@@ -205,8 +205,8 @@ class HotPath:
         preds = []
         with torch.no_grad():
             m.net.eval()
-            for i in range(0, x.shape[0], 8192):
-                o, _ = m.net(x[i:i + 8192])
+            for i in range(0, x.shape[0], 32768):         # (as IID_model._predict_outputs: row-wise ops, the chunk only sets the launch count)
+                o, _ = m.net(x[i:i + 32768])
                 preds.append(o.argmax(1).to(torch.int32))
         return torch.cat(preds)
 
@@ -221,8 +221,8 @@ class HotPath:
         lats = []
         with torch.no_grad():
             m.net.eval()
-            for i in range(0, x.shape[0], 8192):
-                lats.append(m.net(x[i:i + 8192])[1])
+            for i in range(0, x.shape[0], 32768):
+                lats.append(m.net(x[i:i + 32768])[1])
         return D.all_gather_rows(torch.cat(lats) if lats else torch.empty((0, 64), device=self.dev), self.din.n)
 
     def mean_ms(self, key, skip_steps):

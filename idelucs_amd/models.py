@@ -229,8 +229,11 @@ class IID_model():
         outs, lats = [], []
         with torch.no_grad():
             self.net.eval()
-            for i in range(0, feats.shape[0], self.batch_sz):
-                o, l = self.net(feats[i:i + self.batch_sz])
+            # (the reference walks predict in batch_sz rows, models.py:158-170; every op of the eval forward is row-wise, so the chunk
+            #  only sets the launch count: 32768 rows per chunk, 3.08 ms per 100 000 rows against 3.32 at 8192 and ~10 at 512)
+            chunk = max(int(self.batch_sz), 32768)
+            for i in range(0, feats.shape[0], chunk):
+                o, l = self.net(feats[i:i + chunk])
                 outs.append(o)
                 lats.append(l)
         return torch.cat(outs), torch.cat(lats)

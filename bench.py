@@ -195,9 +195,11 @@ class HotPath:
         """Un-mutated float64 vectors, own float64 scaler fitted on ALL rows (reference utils.py:400-405), rows [lo, hi)
         standardised to float32."""
         U, _lib = self.U, self._lib
+        hi = self.din.n if hi is None else hi
+        if U.counts_route_ok(self.a.k):          # as utils.predict_features: from the int32 counts, the float64 rows never materialised
+            return U.predict_inputs_from_counts(self.din, self.a.k, (lo, hi))
         f64 = U._vectorise(self.din, self.a.k, _lib.MODE_KMER, _lib.INIT_ONE, _lib.OUT_FREQ_F64)[0]
         mean, scale = U.col_stats(f64)
-        hi = f64.shape[0] if hi is None else hi
         return U.standardise(f64[lo:hi], mean, scale)
 
     def predict(self, m, x):

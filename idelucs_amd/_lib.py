@@ -47,6 +47,9 @@ SIGNATURES = {
     "idl_col_stats_workspace": (_i64, [_i64, _i64]),
     "idl_col_stats": (_int, [_vp, _int, _i64, _i64, _vp, _vp, _vp, _vp]),
     "idl_standardise": (_int, [_vp, _int, _i64, _i64, _vp, _vp, _vp, _vp]),
+    "idl_counts_stats_workspace": (_i64, [_i64, _i64]),
+    "idl_counts_stats": (_int, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "idl_counts_standardise": (_int, [_vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp]),
     "idl_gather_pairs": (_int, [_vp, _i64, _i64, _i64, _vp, _i64, _vp, _vp, _vp, _vp]),
     "idl_gather_pairs_at": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     "idl_relu_dropout_fwd": (_int, [_vp, _i64, _int, _c.c_uint64, _vp, _int, _vp]),

@@ -128,6 +128,115 @@ __global__ __launch_bounds__(256) void standardise_scalar(const T *x, int64_t to
     }
 }
 
+// ---------------------------------------------------------------- the predict inputs from integer counts (round 4)
+// SequenceDataset (reference idelucs/utils.py:400-405) standardises the un-mutated float64 frequency rows counts / sum(counts) with their
+// own StandardScaler.  Materialising those rows costs 3.3 GB written and read twice at cfg2; the same float64 values are formed on
+// the fly from the int32 counts (1.6 GB) and the row totals: x = (double)c / (double)T, the expression the vectoriser's float64 output
+// uses.  Here as q = c r, q' = fma(fma(-q, T, c), r, q) with r = RN(1 / T): the correctly rounded quotient (Markstein) whenever T's
+// significand is not all ones -- an integer below 2^32 never is.
+__device__ __forceinline__ double count_freq(int32_t c, double T, double rT)
+{
+    const double cd = (double)c, q = cd * rT;
+    return fma(fma(-q, T, cd), rT, q);
+}
+
+constexpr int CS_MAX_THREADS = 1024, CS_MAX_GROUPS = 4;      // f / 4 column quads over <= 1024 threads x <= 4 groups: f <= 16384 (k <= 7)
+
+// Pass A.  A workgroup owns a block of rows and ALL columns (thread -> 4 consecutive columns per group), so that it can form the row
+// totals itself (wave sums through LDS, four rows per barrier).  Per column the shifted sums of col_shifted_sums_kernel<double>, in
+// the same row order and with the same row blocks: the statistics are bit for bit those of the float64 route.
+template <int GROUPS>         // column groups per thread: 1 up to 4096 columns, 4 at 16384 (a template: the arrays below must stay in registers)
+__global__ __launch_bounds__(CS_MAX_THREADS) void counts_stats_kernel(const int32_t *counts, int64_t n, int64_t f, int64_t rows_per_block,
+                                                                      int32_t *row_totals, double *x0, double *partial1, double *partial2)
+{
+    constexpr int groups = GROUPS;
+    __shared__ int64_t wsum[2][4][CS_MAX_THREADS / 64];
+    const int tid = threadIdx.x, nth = blockDim.x, wv = tid >> 6, nw = (nth + 63) >> 6;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    int64_t r1 = r0 + rows_per_block;
+    if (r1 > n) r1 = n;
+    auto total4 = [&](const int4 (&v)[4][GROUPS], int rows, int par, double (&T)[4]) {      // row totals of up to four rows
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            int64_t sacc = 0;
+            if (u < rows)
+                for (int g = 0; g < groups; ++g) sacc += (int64_t)v[u][g].x + v[u][g].y + v[u][g].z + v[u][g].w;
+            int part = (int)sacc;                          // (a row's counts add up to its windows + 4^k < 2^31)
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) part += __shfl_xor(part, o, 64);
+            if ((tid & 63) == 0) wsum[par][u][wv] = part;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { int64_t t = 0; for (int w = 0; w < nw; ++w) t += wsum[par][u][w]; T[u] = (double)t; }
+    };
+    // the shift: row 0 of the matrix (every workgroup forms it for itself; the first one publishes it for the finishing kernel)
+    double sh[GROUPS][4], a1[GROUPS][4], a2[GROUPS][4];
+    {
+        int4 v[4][GROUPS];
+#pragma unroll
+        for (int g = 0; g < groups; ++g) v[0][g] = *(const int4 *)(counts + 4 * ((int64_t)tid + (int64_t)nth * g));
+        double T[4];
+        total4(v, 1, 0, T);
+        const double rT = 1.0 / T[0];
+        for (int g = 0; g < groups; ++g) {
+            const int32_t c4[4] = {v[0][g].x, v[0][g].y, v[0][g].z, v[0][g].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                sh[g][e] = count_freq(c4[e], T[0], rT); a1[g][e] = 0.0; a2[g][e] = 0.0;
+                if (blockIdx.x == 0) x0[4 * ((int64_t)tid + (int64_t)nth * g) + e] = sh[g][e];
+            }
+        }
+    }
+    int par = 1;
+    for (int64_t r = r0; r < r1; r += 4, par ^= 1) {
+        const int rows = (int)(r1 - r < 4 ? r1 - r : 4);
+        int4 v[4][GROUPS];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (u < rows)
+#pragma unroll
+                for (int g = 0; g < groups; ++g) v[u][g] = *(const int4 *)(counts + (r + u) * f + 4 * ((int64_t)tid + (int64_t)nth * g));
+        double T[4];
+        total4(v, rows, par, T);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (u >= rows) break;
+            if (tid == 0) row_totals[r + u] = (int32_t)T[u];
+            const double rT = 1.0 / T[u];
+            for (int g = 0; g < groups; ++g) {
+                const int32_t c4[4] = {v[u][g].x, v[u][g].y, v[u][g].z, v[u][g].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const double t = count_freq(c4[e], T[u], rT) - sh[g][e]; a1[g][e] += t; a2[g][e] += t * t; }
+            }
+        }
+    }
+    for (int g = 0; g < groups; ++g)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int64_t c = 4 * ((int64_t)tid + (int64_t)nth * g) + e;
+            partial1[(int64_t)blockIdx.x * f + c] = a1[g][e];
+            partial2[(int64_t)blockIdx.x * f + c] = a2[g][e];
+        }
+}
+
+// Pass B: rows of int32 counts -> StandardScaler.transform of their float64 frequencies, rounded once to float32 (std_f64)
+__global__ __launch_bounds__(256) void counts_standardise_kernel(const int32_t *counts, const int32_t *row_totals, int64_t total4, int64_t f4,
+                                                                 const double *mean, const double *scale, float4 *y)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / f4, c = (i - row * f4) * 4;
+        const int4 v = *(const int4 *)(counts + 4 * i);
+        const double T = (double)row_totals[row], rT = 1.0 / T;
+        float4 o;
+        o.x = std_f64(count_freq(v.x, T, rT), mean[c + 0], scale[c + 0]);
+        o.y = std_f64(count_freq(v.y, T, rT), mean[c + 1], scale[c + 1]);
+        o.z = std_f64(count_freq(v.z, T, rT), mean[c + 2], scale[c + 2]);
+        o.w = std_f64(count_freq(v.w, T, rT), mean[c + 3], scale[c + 3]);
+        y[i] = o;
+    }
+}
+
 __global__ __launch_bounds__(256) void gather_pairs_kernel(idl_dev::GatherArgs g)
 {
     idl_dev::gather_block(g, blockIdx.x, threadIdx.x);
@@ -227,6 +336,57 @@ int idl_gather_pairs_at(const float *feats, int64_t n, int64_t f, int64_t view_s
     if (rc != IDL_OK) return rc;
     idl_dev::GatherArgs g{feats, n, f, view_stride, pair_idx, base, batch, (int64_t)-1, mean, scale, inv_scale, y};
     hipLaunchKernelGGL(gather_pairs_kernel, dim3((unsigned)idl_dev::gather_blocks(f, batch)), dim3(256), 0, (hipStream_t)stream, g);
+    IDL_HIP_TRY(hipGetLastError());
+    return IDL_OK;
+}
+
+/* StandardScaler statistics of the float64 frequency rows counts / sum(counts) straight from int32 counts [n, f] (f % 4 == 0, f <=
+ * 16384): mean / scale as idl_col_stats gives them on the materialised float64 rows, bit for bit; row_totals[n] receives every
+ * row's sum.  workspace: idl_counts_stats_workspace(n, f) bytes. */
+int64_t idl_counts_stats_workspace(int64_t n, int64_t f)
+{
+    if (n < 0 || f < 0) return -1;
+    return (2 * stat_row_blocks(n) + 1) * f * (int64_t)sizeof(double);
+}
+
+int idl_counts_stats(const int32_t *counts, int64_t n, int64_t f, double *mean, double *scale, int32_t *row_totals, void *workspace,
+                     void *stream)
+{
+    IDL_REQUIRE(n >= 1 && f >= 4 && (f & 3) == 0 && f <= 4 * CS_MAX_THREADS * CS_MAX_GROUPS, "counts_stats needs n >= 1, 4 | f, f <= 16384");
+    IDL_REQUIRE(counts && mean && scale && row_totals && workspace && (((uintptr_t)counts) & 15u) == 0, "counts_stats: NULL or misaligned buffer");
+    const int64_t q = f / 4;
+    int threads = (int)(q < CS_MAX_THREADS ? q : CS_MAX_THREADS);
+    threads = (threads + 63) / 64 * 64;
+    IDL_REQUIRE(q % threads == 0, "counts_stats: f / 4 must be a multiple of 64 (or of 1024 beyond 4096 columns)");
+    const int groups = (int)(q / threads);
+    IDL_REQUIRE(groups == 1 || groups == 4, "counts_stats: f / 4 is 64 .. 1024 or 4096");
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t blocks = stat_row_blocks(n);
+    const int64_t rpb = (n + blocks - 1) / blocks;
+    double *p1 = (double *)workspace, *p2 = p1 + blocks * f, *x0 = p2 + blocks * f;
+    if (groups == 1) hipLaunchKernelGGL(counts_stats_kernel<1>, dim3((unsigned)blocks), dim3((unsigned)threads), 0, st, counts, n, f, rpb, row_totals, x0, p1, p2);
+    else hipLaunchKernelGGL(counts_stats_kernel<4>, dim3((unsigned)blocks), dim3((unsigned)threads), 0, st, counts, n, f, rpb, row_totals, x0, p1, p2);
+    hipLaunchKernelGGL(col_finish_kernel<double>, dim3((unsigned)((f + 63) / 64)), dim3(1024), 0, st, (const double *)x0, p1, p2, blocks, f, n, mean, scale);
+    IDL_HIP_TRY(hipGetLastError());
+    return IDL_OK;
+}
+
+/* rows [0, n) of `counts` (with their totals) -> float32 StandardScaler.transform of their float64 frequencies (idl_standardise on
+ * the materialised float64 rows, bit for bit).  The pointers may address a row shard of a larger matrix. */
+int idl_counts_standardise(const int32_t *counts, const int32_t *row_totals, int64_t n, int64_t f, const double *mean, const double *scale,
+                           float *y, void *stream)
+{
+    IDL_REQUIRE(n >= 0 && f >= 4 && (f & 3) == 0, "counts_standardise needs n >= 0 and 4 | f");
+    if (n == 0) return IDL_OK;
+    IDL_REQUIRE(counts && row_totals && mean && scale && y && ((((uintptr_t)counts) | ((uintptr_t)y)) & 15u) == 0, "counts_standardise: NULL or misaligned buffer");
+    idl::DeviceInfo di;
+    int rc = idl::device_info(&di);
+    if (rc != IDL_OK) return rc;
+    const int64_t total4 = n * f / 4;
+    int64_t g = (total4 + 255) / 256;
+    if (g > (int64_t)di.cus * 16) g = (int64_t)di.cus * 16;
+    hipLaunchKernelGGL(counts_standardise_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, counts, row_totals, total4, f / 4, mean, scale,
+                       (float4 *)y);
     IDL_HIP_TRY(hipGetLastError());
     return IDL_OK;
 }

@@ -601,3 +601,52 @@ def test_two_vectorise_calls_in_flight_on_two_streams(gpu):
         torch.cuda.synchronize()
         for i in (0, 1):
             assert torch.equal(got[i], want[i]), (rep, i)
+
+
+@pytest.mark.parametrize("k", [4, 5, 6, 7])
+def test_predict_inputs_from_counts_equal_the_float64_route(tmp_path, k):
+    """Round 4 (the exchange step): the predict inputs of SequenceDataset (reference utils.py:400-405: float64 rows counts / sum(counts),
+    StandardScaler fit_transform in float64, one rounding to float32) formed straight from int32 counts -- idl_counts_stats +
+    idl_counts_standardise -- are BIT FOR BIT those of the materialised float64 rows (idl_vectorise OUT_FREQ_F64 + idl_col_stats +
+    idl_standardise): statistics, row totals, output, also for a row shard; on Influenza-A and on records with N runs, a record
+    shorter than k (only the pseudocount) and constant columns (scale 1)."""
+    import torch
+    from idelucs_amd import _lib, utils as U
+    rng = np.random.default_rng(3 + k)
+    recs = [b">short\nAC\n", b">allN\n" + b"N" * 40 + b"\n"]
+    for i in range(700):
+        L = int(rng.integers(k, 3000))
+        s = rng.choice(np.frombuffer(b"ACGT", np.uint8), size=L, p=[0.4, 0.1, 0.2, 0.3])
+        if i % 5 == 0:
+            s[L // 2: L // 2 + 1 + L // 20] = ord("N")
+        recs.append(b">r%d\n" % i + s.tobytes() + b"\n")
+    p = tmp_path / "c.fas"
+    p.write_bytes(b"".join(recs))
+    dev = torch.device("cuda")
+    for path in (str(p), os.path.join(DATA, "Influenza-A.fas")):
+        ff = U.FastaFile(path, check=True)
+        din = U._DeviceInput(ff, dev)
+        f64 = U._vectorise(din, k, _lib.MODE_KMER, _lib.INIT_ONE, _lib.OUT_FREQ_F64)[0]
+        mean, scale = U.col_stats(f64)
+        want = U.standardise(f64, mean, scale)
+        got = U.predict_inputs_from_counts(din, k)
+        assert torch.equal(got, want), (path, k, (got - want).abs().max().item())
+        lo, hi = 17, min(ff.n, 403)
+        assert torch.equal(U.predict_inputs_from_counts(din, k, (lo, hi)), want[lo:hi])
+        assert U.predict_inputs_from_counts(din, k, (5, 5)).shape == (0, 4 ** k)
+        # the pieces: row totals and statistics
+        counts = U._vectorise(din, k, _lib.MODE_KMER, _lib.INIT_ONE, _lib.OUT_COUNTS_I32)[0]
+        n, f = counts.shape
+        m2 = torch.empty(f, dtype=torch.float64, device=dev); s2 = torch.empty(f, dtype=torch.float64, device=dev)
+        tot = torch.empty(n, dtype=torch.int32, device=dev)
+        ws = torch.empty(int(_lib.lib.idl_counts_stats_workspace(n, f)), dtype=torch.uint8, device=dev)
+        _lib.check(_lib.lib.idl_counts_stats(U._ptr(counts), n, f, U._ptr(m2), U._ptr(s2), U._ptr(tot), U._ptr(ws), U._stream_ptr()))
+        assert torch.equal(tot.long(), counts.long().sum(1)) and torch.equal(m2, mean) and torch.equal(s2, scale)
+    # through the product's entry (SequenceDataset's numbers are pinned to the reference golden elsewhere: test_predict... / seqdataset.npz)
+    names, lengths, x = U.predict_features(os.path.join(DATA, "Influenza-A.fas"), k=k)
+    os.environ["IDELUCS_PREDICT_COUNTS"] = "0"
+    try:
+        _, _, x_old = U.predict_features(os.path.join(DATA, "Influenza-A.fas"), k=k)
+    finally:
+        del os.environ["IDELUCS_PREDICT_COUNTS"]
+    assert torch.equal(x, x_old)

@@ -623,7 +623,11 @@ def test_predict_inputs_from_counts_equal_the_float64_route(tmp_path, k):
     p = tmp_path / "c.fas"
     p.write_bytes(b"".join(recs))
     dev = torch.device("cuda")
-    for path in (str(p), os.path.join(DATA, "Influenza-A.fas")):
+    one = tmp_path / "one.fas"
+    one.write_bytes(b">only\nACGTACGTTTGACCA\n")                      # a single row: variance 0 everywhere -> scale 1, output 0
+    two = tmp_path / "two.fas"
+    two.write_bytes(b">a\nACGTACGTTTGACCAGGT\n>b\nTTTTTTTTTTGACCAGGTAC\n")
+    for path in (str(p), os.path.join(DATA, "Influenza-A.fas"), str(one), str(two)):
         ff = U.FastaFile(path, check=True)
         din = U._DeviceInput(ff, dev)
         f64 = U._vectorise(din, k, _lib.MODE_KMER, _lib.INIT_ONE, _lib.OUT_FREQ_F64)[0]
@@ -631,9 +635,11 @@ def test_predict_inputs_from_counts_equal_the_float64_route(tmp_path, k):
         want = U.standardise(f64, mean, scale)
         got = U.predict_inputs_from_counts(din, k)
         assert torch.equal(got, want), (path, k, (got - want).abs().max().item())
-        lo, hi = 17, min(ff.n, 403)
+        lo, hi = min(17, ff.n - 1), min(ff.n, 403)
         assert torch.equal(U.predict_inputs_from_counts(din, k, (lo, hi)), want[lo:hi])
-        assert U.predict_inputs_from_counts(din, k, (5, 5)).shape == (0, 4 ** k)
+        assert U.predict_inputs_from_counts(din, k, (hi, hi)).shape == (0, 4 ** k)
+        if ff.n == 1:
+            assert not bool(want.any())
         # the pieces: row totals and statistics
         counts = U._vectorise(din, k, _lib.MODE_KMER, _lib.INIT_ONE, _lib.OUT_COUNTS_I32)[0]
         n, f = counts.shape

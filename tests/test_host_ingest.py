@@ -417,3 +417,24 @@ def test_lazy_prim_refuses_inputs_beyond_its_look_ahead():
         assert rc == _lib.IDL_ERR_ARG and "2^20" in _lib.last_error(), (n, rc, _lib.last_error())
     src = open(os.path.join(ROOT, "idelucs_amd", "posthoc.py")).read()
     assert "MST_LAZY_MIN <= n <= MST_LAZY_MAX" in src
+
+
+def test_reader_thread_default_follows_quota_and_ranks():
+    """Round 4: the reader's default thread count is min(32, hardware threads, 2 x the cgroup's CPU quota) shared out over the ranks
+    of the node (LOCAL_WORLD_SIZE: every rank of a multi-GPU job parses the file itself); IDELUCS_THREADS overrides.  Checked in
+    child processes (the default is computed once per process)."""
+    import subprocess
+    import sys
+
+    def threads(**env):
+        e = {k: v for k, v in os.environ.items() if k not in ("IDELUCS_THREADS", "LOCAL_WORLD_SIZE")}
+        e.update(env, PYTHONPATH=ROOT)
+        r = subprocess.run([sys.executable, "-c", "from idelucs_amd import utils as U; print(U.ingest_threads())"], env=e, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return int(r.stdout.strip().splitlines()[-1])
+    base = threads()
+    hw = os.cpu_count() or 1
+    assert 1 <= base <= min(32, hw)
+    t2, t8 = threads(LOCAL_WORLD_SIZE="2"), threads(LOCAL_WORLD_SIZE="8")
+    assert 1 <= t8 <= t2 <= base and t8 <= max(1, base // 2)          # (the share of a rank shrinks with the ranks of the node)
+    assert threads(IDELUCS_THREADS="5", LOCAL_WORLD_SIZE="8") == 5

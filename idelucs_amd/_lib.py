@@ -37,6 +37,7 @@ SIGNATURES = {
     "idl_fasta_export": (_int, [_vp] + [_vp] * 8),
     "idl_fasta_pack_range": (_int, [_vp, _i64, _i64, _vp, _vp]),
     "idl_ingest_threads": (_int, []),
+    "idl_ingest_numa_node": (_int, []),
     "idl_fasta_parse_pack": (_int, [_c.c_char_p, _vp, _vp, _i64, _vp, _vp, _vp, _c.POINTER(_vp)]),
     "idl_fasta_arena_slots": (_int, [_vp, _vp]),
     "idl_ingest_release": (None, []),

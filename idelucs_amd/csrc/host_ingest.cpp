@@ -80,8 +80,13 @@ void pack_one(const uint8_t *seq, int64_t len, uint8_t *codes, uint8_t *mask)
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <pthread.h>
+#include <sched.h>
+
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <thread>
@@ -136,14 +141,179 @@ size_t par_min_bytes()                  // files smaller than this are handled b
     return (size_t)1 << 22;
 }
 
+// ---- NUMA placement of the reader (round 5; VERDICT r4 #1a).  hipHostMalloc puts pinned memory on the node nearest to the current
+// device (ROCr's default without hipHostMallocNumaUser), so the arenas the reader packs into -- and the DMA engine that drains them
+// -- live on the GPU's node; reader threads on the OTHER socket write them across the inter-socket link.  Measured on the pool's
+// 2-socket boxes (profiles/r05_ingest_numa.txt, 1 GB cfg2 file, 32 threads): parse + pack 8.2 ms unbound, 6.9 bound to the GPU's
+// node, 14.6 bound to the other; ingest-to-features 15.3 / 14.1 / 22.8.  The threads of a job that copies to a device are therefore
+// bound to that device's node for the job (workers keep the binding, the caller's own is restored).  IDELUCS_NUMA=0 switches it
+// off, IDELUCS_NUMA=<node> forces a node.
+struct CpuBind {
+    cpu_set_t set;
+    int node = -1;
+    bool on = false;
+};
+
+bool parse_cpulist(const char *path, cpu_set_t *out)
+{
+    FILE *f = fopen(path, "r");
+    if (!f) return false;
+    char buf[4096] = {0};
+    const size_t got = fread(buf, 1, sizeof(buf) - 1, f);
+    fclose(f);
+    if (got == 0) return false;
+    CPU_ZERO(out);
+    const char *p = buf;
+    while (*p) {
+        while (*p == ',' || *p == ' ' || *p == '\n') ++p;
+        if (!*p) break;
+        char *e = nullptr;
+        const long a = strtol(p, &e, 10);
+        if (e == p) return false;
+        long b = a;
+        p = e;
+        if (*p == '-') { b = strtol(p + 1, &e, 10); if (e == p + 1) return false; p = e; }
+        for (long c = a; c <= b && c < CPU_SETSIZE; ++c) if (c >= 0) CPU_SET((int)c, out);
+    }
+    return CPU_COUNT(out) > 0;
+}
+
+// the CPUs of the NUMA node device `dev` hangs off, within what this thread may run on; .on = false when there is nothing to do
+CpuBind bind_for_device(int dev, int want_threads)
+{
+    CpuBind b;
+    const char *env = getenv("IDELUCS_NUMA");
+    if (env && strcmp(env, "0") == 0) return b;
+    int node = -1;
+    if (env && *env >= '0' && *env <= '9') node = atoi(env);
+    else {
+        char id[64] = {0};
+        if (dev < 0 || hipDeviceGetPCIBusId(id, (int)sizeof(id) - 1, dev) != hipSuccess) return b;
+        for (char *c = id; *c; ++c) if (*c >= 'A' && *c <= 'F') *c = (char)(*c - 'A' + 'a');
+        char path[160];
+        snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/numa_node", id);
+        FILE *f = fopen(path, "r");
+        if (!f) return b;
+        if (fscanf(f, "%d", &node) != 1) node = -1;
+        fclose(f);
+    }
+    if (node < 0) return b;                       // a single-node host (or a VM that does not say)
+    char path[96];
+    snprintf(path, sizeof(path), "/sys/devices/system/node/node%d/cpulist", node);
+    cpu_set_t nodeset, mine;
+    if (!parse_cpulist(path, &nodeset)) return b;
+    if (sched_getaffinity(0, sizeof(mine), &mine) != 0) return b;
+    CPU_AND(&b.set, &nodeset, &mine);
+    // too few CPUs of that node are open to this process (a cpuset on the other socket): leave the threads where they are
+    if (CPU_COUNT(&b.set) == 0 || (CPU_COUNT(&b.set) < CPU_COUNT(&mine) && CPU_COUNT(&b.set) * 2 < want_threads)) return b;
+    if (CPU_EQUAL(&b.set, &mine)) { b.node = node; return b; }     // already there (one node, or an outer binding): nothing to set
+    b.node = node;
+    b.on = true;
+    return b;
+}
+
+int g_last_bind_node = -1;      // what the last job was bound to (idl_ingest_numa_node)
+
+// The reader's threads, kept between calls (round 5; VERDICT r4 #1b).  A run calls parallel_for seven times per file (scan, validate,
+// pack, export ...); with std::thread per call that was 31 thread creations each -- ~1 ms of the 8 ms parse at 32 threads, and
+// every new thread's first HIP call sets up its device state again.  Workers sleep on a condition variable; a job is
+// (generation, thread count, callable); the caller runs index 0 itself and waits for the others.  One job at a time (callers
+// from several host threads take turns).  The pool is never destroyed (threads blocked at process exit are the kernel's to
+// reap); a forked child starts with an empty pool (its parent's threads do not exist there).
+class ReaderPool {
+public:
+    static ReaderPool &get()
+    {
+        std::lock_guard<std::mutex> lk(inst_mu());
+        static const bool hooked = [] {       // fork: nobody holds the instance lock across it; the child drops the parent's pool
+            pthread_atfork([] { inst_mu().lock(); }, [] { inst_mu().unlock(); }, [] { inst() = nullptr; inst_mu().unlock(); });
+            return true;
+        }();
+        (void)hooked;
+        if (inst() == nullptr) inst() = new ReaderPool();
+        return *inst();
+    }
+    template <typename F>
+    void run(int nt, F &&fn, const CpuBind *bind = nullptr)
+    {
+        std::lock_guard<std::mutex> one_job(job_mu_);
+        std::function<void(int)> f = [&fn](int t) { fn(t); };
+        cpu_set_t before;
+        const bool rebind = bind != nullptr && bind->on && sched_getaffinity(0, sizeof(before), &before) == 0 &&
+                            sched_setaffinity(0, sizeof(bind->set), &bind->set) == 0;       // the caller, for the length of the job
+        {
+            std::unique_lock<std::mutex> lk(mu_);
+            while ((int)th_.size() < nt - 1) {
+                const int idx = (int)th_.size() + 1;
+                th_.emplace_back([this, idx] { worker(idx); });
+                th_.back().detach();
+            }
+            fn_ = &f;
+            nt_ = nt;
+            pending_ = nt - 1;
+            if (bind != nullptr && bind->on) { bind_ = bind->set; ++bind_gen_; }
+            ++gen_;
+        }
+        cv_work_.notify_all();
+        fn(0);
+        {
+            std::unique_lock<std::mutex> lk(mu_);
+            cv_done_.wait(lk, [this] { return pending_ == 0; });
+            fn_ = nullptr;
+        }
+        if (rebind) (void)sched_setaffinity(0, sizeof(before), &before);
+    }
+    int threads() const { return (int)th_.size(); }
+
+private:
+    static ReaderPool *&inst() { static ReaderPool *p = nullptr; return p; }      // (the parent's pool is leaked in a forked child on purpose)
+    static std::mutex &inst_mu() { static std::mutex m; return m; }
+    void worker(int idx)
+    {
+        uint64_t seen = 0, bound = 0;
+        for (;;) {
+            std::function<void(int)> *f = nullptr;
+            cpu_set_t want;
+            bool move = false;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_work_.wait(lk, [&] { return gen_ != seen; });
+                seen = gen_;
+                if (idx < nt_) f = fn_;
+                if (f != nullptr && bind_gen_ != bound) { want = bind_; bound = bind_gen_; move = true; }
+            }
+            if (f == nullptr) continue;              // this job uses fewer threads
+            if (move) (void)sched_setaffinity(0, sizeof(want), &want);      // (a worker keeps its node until a job names another)
+            (*f)(idx);
+            bool last;
+            { std::lock_guard<std::mutex> lk(mu_); last = --pending_ == 0; }
+            if (last) cv_done_.notify_one();
+        }
+    }
+    std::mutex job_mu_, mu_;
+    std::condition_variable cv_work_, cv_done_;
+    std::vector<std::thread> th_;
+    std::function<void(int)> *fn_ = nullptr;
+    int nt_ = 0, pending_ = 0;
+    uint64_t gen_ = 0, bind_gen_ = 0;
+    cpu_set_t bind_;
+};
+
 template <typename F>
-void parallel_for(int nt, F &&fn)       // fn(thread index)
+void parallel_for(int nt, F &&fn, const CpuBind *bind = nullptr)       // fn(thread index)
 {
     if (nt <= 1) { fn(0); return; }
+    static const bool pooled = [] { const char *e = getenv("IDELUCS_READER_POOL"); return !(e && atoi(e) == 0); }();
+    if (pooled) { ReaderPool::get().run(nt, fn, bind); return; }
+    // IDELUCS_READER_POOL=0: a thread per call and index (round 4's form, kept for A/B runs); new threads inherit the caller's CPUs
+    cpu_set_t before;
+    const bool rebind = bind != nullptr && bind->on && sched_getaffinity(0, sizeof(before), &before) == 0 &&
+                        sched_setaffinity(0, sizeof(bind->set), &bind->set) == 0;
     std::vector<std::thread> th;
     for (int t = 1; t < nt; ++t) th.emplace_back([&fn, t]() { fn(t); });
     fn(0);
     for (auto &x : th) x.join();
+    if (rebind) (void)sched_setaffinity(0, sizeof(before), &before);
 }
 
 // streaming 2-bit packer (first base in the top pair of each word; invalid-mask bit 31-j per base)
@@ -615,6 +785,8 @@ namespace {
 struct FastOut {
     std::vector<Rec> recs;
     std::vector<int64_t> slot;
+    double t_begin = 0, t_end = 0, t_send = 0;      // IDELUCS_INGEST_TIMING: when this thread started / finished, host time inside its copy calls
+    int n_send = 0;
     int fallback = 0, bad_kind = REC_OK, copy_failed = 0;
     uint8_t bad_byte = 0;
     Rec bad_rec{};
@@ -699,9 +871,12 @@ int idl_fasta_parse_pack(const char *path, uint8_t *codes, uint8_t *mask, int64_
     // first (a rank of a multi-GPU job is bound to another one, and dev_codes / stream belong to it)
     int caller_dev = -1;
     if (dev_codes != nullptr && hipGetDevice(&caller_dev) != hipSuccess) caller_dev = -1;
+    const CpuBind bind = (nt > 1 && caller_dev >= 0) ? bind_for_device(caller_dev, nt) : CpuBind();
+    g_last_bind_node = bind.node;
 
     parallel_for(nt, [&](int t) {
         FastOut &o = outs[(size_t)t];
+        if (timing) o.t_begin = now();
         if (t > 0 && caller_dev >= 0 && hipSetDevice(caller_dev) != hipSuccess) { o.copy_failed = 1; return; }
         const size_t b = size * (size_t)t / (size_t)nt, e = size * (size_t)(t + 1) / (size_t)nt;
         const int64_t region_lo = cap_slots * t / nt, region_hi = cap_slots * (t + 1) / nt;
@@ -722,9 +897,11 @@ int idl_fasta_parse_pack(const char *path, uint8_t *codes, uint8_t *mask, int64_
         int64_t slot = region_lo, sent = region_lo;
         auto send = [&](int64_t upto) {
             if (dev_codes != nullptr && upto > sent) {
+                const double ts = timing ? now() : 0.0;
                 if (hipMemcpyAsync((uint8_t *)dev_codes + sent * 16, codes + sent * 16, (size_t)(upto - sent) * 16, hipMemcpyHostToDevice, (hipStream_t)stream) != hipSuccess ||
                     hipMemcpyAsync((uint8_t *)dev_mask + sent * 8, mask + sent * 8, (size_t)(upto - sent) * 8, hipMemcpyHostToDevice, (hipStream_t)stream) != hipSuccess)
                     o.copy_failed = 1;
+                if (timing) { o.t_send += now() - ts; ++o.n_send; }
             }
             sent = upto;
         };
@@ -765,7 +942,24 @@ int idl_fasta_parse_pack(const char *path, uint8_t *codes, uint8_t *mask, int64_
         }
         send(slot);
         o.slot.push_back(slot);                                       // end of this thread's records
-    });
+        if (timing) o.t_end = now();
+    }, &bind);
+    if (timing) {
+        double b_max = 0, e_min = 1e300, e_max = 0, snd = 0;
+        int ns = 0;
+        for (const FastOut &o : outs) {
+            if (o.t_end == 0) continue;
+            b_max = std::max(b_max, o.t_begin - t_0); e_min = std::min(e_min, o.t_end - t_0); e_max = std::max(e_max, o.t_end - t_0);
+            snd += o.t_send; ns += o.n_send;
+        }
+        const double t_join = now() - t_0;
+        double t_drain = -1;
+        // IDELUCS_INGEST_TIMING=2 also waits for the copies here (diagnostic only: the caller overlaps this wait with its own work)
+        if (dev_codes != nullptr && atoi(getenv("IDELUCS_INGEST_TIMING")) >= 2 && hipStreamSynchronize((hipStream_t)stream) == hipSuccess) t_drain = now() - t_0;
+        fprintf(stderr, "idl_fasta_parse_pack timeline: last thread started %.2f ms, threads finished %.2f .. %.2f, joined %.2f, copies drained %.2f; "
+                        "%d copy calls, %.2f ms of host time in them (sum over threads); bound to node %d\n",
+                b_max, e_min, e_max, t_join, t_drain, ns * 2, snd, bind.node);
+    }
 
     for (int t = 0; t < nt; ++t) {
         const FastOut &o = outs[(size_t)t];
@@ -878,6 +1072,8 @@ int idl_fasta_export(const idl_fasta *f, uint8_t *names, int64_t *name_off, int6
 }
 
 int idl_ingest_threads(void) { return n_threads(); }
+
+int idl_ingest_numa_node(void) { return g_last_bind_node; }
 
 int idl_fasta_pack_range(const idl_fasta *f, int64_t rec_lo, int64_t rec_hi, uint8_t *codes, uint8_t *mask)
 {

@@ -121,8 +121,10 @@ class IID_model():
     def build_dataloader(self):
         """Reference models.py:101-111: vectorise all mimic views + fit the scaler (one kernel launch
         each, utils.build_feature_store) and expose an iterable of device batches."""
+        # (a second call -- the same file again, or another of the same record count -- refits the previous store in place: the
+        #  captured step graph bakes the store's addresses and is then not captured again)
         self.store = utils.build_feature_store(self.sequence_file, self.n_mimics, k=self.k, reduce=self.reduce,
-                                               rng=self.rng, seed=self.seed, device=self.device, streamed=True)
+                                               rng=self.rng, seed=self.seed, device=self.device, streamed=True, reuse=self.store)
         self.dataloader = utils.DeviceBatchLoader(self.store, self.batch_sz)
         self._shared.clear()
 

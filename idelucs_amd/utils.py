@@ -758,13 +758,32 @@ class _OnePassInput:
         return self
 
 
-def build_feature_store(sequence_file, n_mimics, k=6, reduce=False, rng=None, seed=0, device=None, fasta=None, streamed=False):
+def build_feature_store(sequence_file, n_mimics, k=6, reduce=False, rng=None, seed=0, device=None, fasta=None, streamed=False,
+                        reuse=None):
     """Vectorise every mimic view of every sequence in one kernel launch and fit the scaler.
     streamed=True (device RNG only): parse once, pack record chunks into pinned memory and copy each chunk to the device
-    while the next is being packed; the mimic sites are drawn meanwhile (they need only the lengths)."""
+    while the next is being packed; the mimic sites are drawn meanwhile (they need only the lengths).
+    reuse = a FeatureStore the caller is done with: when the new store has its shape (the same file again, another file of the
+    same record count) the rows are written into ITS buffers and the scaler is refitted in place, and that object is returned
+    -- every address a captured training-step graph holds stays valid (fused.run_epoch's key), so the graph is not captured again."""
     rng = rng or _default_rng_mode()
     dev = _device(device)
     tfs = mimic_transforms(n_mimics)
+
+    def finish(names, lengths, feats, n):
+        """Scaler fit + the store: into `reuse` when its buffers were taken (feats is reuse.feats then), else a new one."""
+        if reuse is not None and feats is reuse.feats:
+            col_stats(feats[0], out=(reuse.mean, reuse.scale))
+            reuse._names, reuse.lengths = names, lengths
+            return reuse.refresh()
+        mean, scale = col_stats(feats[0])
+        return FeatureStore(names, lengths, feats, mean, scale, k, reduce)
+
+    def feature_buffer(n, row):
+        if (reuse is not None and tuple(reuse.feats.shape) == (len(tfs), n, row) and reuse.feats.device == dev
+                and reuse.k == k and reuse.reduce == reduce and reuse.feats.is_contiguous()):
+            return reuse.feats
+        return torch.empty((len(tfs), n, row), dtype=torch.float32, device=dev)
     if streamed and rng == "philox" and fasta is None and os.environ.get("IDELUCS_ONE_PASS", "1") != "0":
         import time
         timing = os.environ.get("IDELUCS_INGEST_TIMING") is not None
@@ -776,14 +795,13 @@ def build_feature_store(sequence_file, n_mimics, k=6, reduce=False, rng=None, se
             # cache whole (6.5 GB at cfg2: a fresh one costs 15-260 ms), before the smaller requests below can be carved out of it
             mode = _lib.MODE_CANONICAL if reduce else _lib.MODE_KMER
             row = _L.idl_row_len(mode, k)
-            feats = torch.empty((len(tfs), din.n, row), dtype=torch.float32, device=dev)
+            feats = feature_buffer(din.n, row)
             q.append(time.perf_counter())
             edits, edit_off = _philox_edits(din, [t.spec() for t in tfs], seed)
             din.fill()
             q.append(time.perf_counter())
             _vectorise(din, k, mode, _lib.INIT_ONE, _lib.OUT_FREQ_F32, len(tfs), edits, edit_off, feats)
-            mean, scale = col_stats(feats[0])
-            store = FeatureStore(din.ff, din.ff.lengths, feats, mean, scale, k, reduce)
+            store = finish(din.ff, din.ff.lengths, feats, din.n)
             din.ff.close()                         # (unmaps the file on a helper thread; after the host side of the build, see from_handle)
             if timing:
                 q.append(time.perf_counter())
@@ -801,9 +819,9 @@ def build_feature_store(sequence_file, n_mimics, k=6, reduce=False, rng=None, se
         finally:
             ff.close()
         mode = _lib.MODE_CANONICAL if reduce else _lib.MODE_KMER
-        feats = _vectorise(din, k, mode, _lib.INIT_ONE, _lib.OUT_FREQ_F32, len(tfs), edits, edit_off)
-        mean, scale = col_stats(feats[0])
-        return FeatureStore(ff, ff.lengths, feats, mean, scale, k, reduce)
+        feats = _vectorise(din, k, mode, _lib.INIT_ONE, _lib.OUT_FREQ_F32, len(tfs), edits, edit_off,
+                           feature_buffer(din.n, _L.idl_row_len(mode, k)))
+        return finish(ff, ff.lengths, feats, din.n)
     ff = fasta if fasta is not None else FastaFile(sequence_file, check=True, keep_bytes=(rng == "compat"))
     mode = _lib.MODE_CANONICAL if reduce else _lib.MODE_KMER
     if rng == "compat":
@@ -818,9 +836,9 @@ def build_feature_store(sequence_file, n_mimics, k=6, reduce=False, rng=None, se
         edits, edit_off = _philox_edits(din, [t.spec() for t in tfs], seed)
     else:
         raise ValueError("rng must be 'compat' or 'philox'")
-    feats = _vectorise(din, k, mode, _lib.INIT_ONE, _lib.OUT_FREQ_F32, len(tfs), edits, edit_off)
-    mean, scale = col_stats(feats[0])
-    return FeatureStore(ff.names, ff.lengths, feats, mean, scale, k, reduce)
+    feats = _vectorise(din, k, mode, _lib.INIT_ONE, _lib.OUT_FREQ_F32, len(tfs), edits, edit_off,
+                       feature_buffer(din.n, _L.idl_row_len(mode, k)))
+    return finish(ff.names, ff.lengths, feats, din.n)
 
 
 def AugmentFasta(sequence_file, n_mimics, k=6, reduce=False, rng=None, seed=0):

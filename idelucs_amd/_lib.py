@@ -38,8 +38,10 @@ SIGNATURES = {
     "idl_fasta_pack_range": (_int, [_vp, _i64, _i64, _vp, _vp]),
     "idl_ingest_threads": (_int, []),
     "idl_ingest_numa_node": (_int, []),
+    "idl_ingest_cpu_plan": (_int, [_int, _int, _vp, _vp]),
     "idl_fasta_parse_pack": (_int, [_c.c_char_p, _vp, _vp, _i64, _vp, _vp, _vp, _c.POINTER(_vp)]),
     "idl_fasta_arena_slots": (_int, [_vp, _vp]),
+    "idl_fasta_arena_meta": (_int, [_vp, _vp, _vp, _pi64, _pi64]),
     "idl_ingest_release": (None, []),
     "idl_vectorise": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _int, _int, _int, _int, _vp, _vp, _vp, _i64, _i64, _vp]),
     "idl_mimic_workspace": (_i64, [_i64, _int]),

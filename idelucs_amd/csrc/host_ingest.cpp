@@ -6,6 +6,7 @@
 //                                        .strip()ped and joined, unconditional flush at EOF)
 //   idelucs/utils.py:26-51               check_sequence (header checks, translate, delete, validate)
 // and produces the packed slot layout documented in include/idelucs_hip.h.
+#include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -99,27 +100,59 @@ struct Rec {
     int64_t len;             // cleaned length
 };
 
-// CPUs the process may actually use: the cgroup's CPU quota (cgroup v2 cpu.max, v1 cfs quota / period) where one is set, else 0
+// CPUs the process may actually use: the cgroup's CPU quota (cgroup v2 cpu.max, v1 cfs quota / period) where one is set, else 0.
+// The process's own cgroup comes from /proc/self/cgroup (without a cgroup namespace -- systemd, Slurm -- the limit sits
+// in a nested directory, not in /sys/fs/cgroup itself); every level up to the root is read, the tightest quota counts.
 int cgroup_cpus()
 {
-    long quota = -1, period = -1;
-    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
-        char q[32] = {0};
-        if (fscanf(f, "%31s %ld", q, &period) == 2 && strcmp(q, "max") != 0) quota = atol(q);
+    auto quota_of = [](const std::string &dir, bool v2) -> double {
+        long quota = -1, period = -1;
+        if (v2) {
+            if (FILE *f = fopen((dir + "/cpu.max").c_str(), "r")) {
+                char q[32] = {0};
+                if (fscanf(f, "%31s %ld", q, &period) == 2 && strcmp(q, "max") != 0) quota = atol(q);
+                fclose(f);
+            }
+        } else {
+            if (FILE *g = fopen((dir + "/cpu.cfs_quota_us").c_str(), "r")) { if (fscanf(g, "%ld", &quota) != 1) quota = -1; fclose(g); }
+            if (FILE *g = fopen((dir + "/cpu.cfs_period_us").c_str(), "r")) { if (fscanf(g, "%ld", &period) != 1) period = -1; fclose(g); }
+        }
+        return (quota > 0 && period > 0) ? (double)quota / (double)period : 0.0;
+    };
+    std::string v2_path = "/", v1_path = "/";
+    if (FILE *f = fopen("/proc/self/cgroup", "r")) {
+        char line[1024];
+        while (fgets(line, sizeof(line), f)) {
+            line[strcspn(line, "\n")] = 0;
+            const char *c1 = strchr(line, ':');
+            const char *c2 = c1 ? strchr(c1 + 1, ':') : nullptr;
+            if (!c2) continue;
+            const std::string ctrl(c1 + 1, c2);
+            if (ctrl.empty()) v2_path = c2 + 1;                                            // "0::/path"
+            else if (ctrl == "cpu" || ctrl == "cpu,cpuacct" || ctrl == "cpuacct,cpu") v1_path = c2 + 1;
+        }
         fclose(f);
-    } else {
-        if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(g, "%ld", &quota) != 1) quota = -1; fclose(g); }
-        if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(g, "%ld", &period) != 1) period = -1; fclose(g); }
     }
-    if (quota <= 0 || period <= 0) return 0;
-    return (int)((quota + period - 1) / period);
+    double best = 0.0;
+    auto walk = [&](const std::string &root, std::string rel, bool v2) {
+        for (;;) {
+            const double q = quota_of(root + (rel == "/" ? "" : rel), v2);
+            if (q > 0.0 && (best == 0.0 || q < best)) best = q;
+            if (rel == "/" || rel.empty()) break;
+            const size_t cut = rel.find_last_of('/');
+            rel = (cut == 0 || cut == std::string::npos) ? "/" : rel.substr(0, cut);
+        }
+    };
+    walk("/sys/fs/cgroup", v2_path, true);
+    walk("/sys/fs/cgroup/cpu", v1_path, false);
+    return best > 0.0 ? (int)(best + 0.999) : 0;
 }
 
 // Reader threads.  IDELUCS_THREADS overrides.  Default (round 4, profiles/r04_ingest_threads.txt: the 1 GB cfg2 file on a 256-thread
 // host whose cgroup grants 16 CPUs): parse + pack 11.0 ms with 16 threads, 8.2 with 32, 7.6 with 48-64, but with the H2D copies in
 // flight 11.4 / 12.0 / 13.6 and ingest-to-features 17.9 / 14.3 / 15.3 -- the threads block in page faults and in the copy calls, so
-// twice the CPU quota pays and more does not.  Hence min(32, hardware threads, 2 x cgroup quota), shared out over the ranks of
-// the node (LOCAL_WORLD_SIZE: every rank of a multi-GPU job reads the file itself).
+// twice the CPU quota pays and more does not.  Hence min(32, hardware threads, 2 x cgroup quota), and THAT is shared out over the
+// ranks of the node (LOCAL_WORLD_SIZE: every rank of a multi-GPU job reads the file itself).
 int n_threads()
 {
     if (const char *e = getenv("IDELUCS_THREADS")) { const int t = atoi(e); if (t >= 1 && t <= 256) return t; }
@@ -127,10 +160,11 @@ int n_threads()
         int t = (int)std::thread::hardware_concurrency();
         if (t <= 0) t = 1;
         if (const int q = cgroup_cpus(); q > 0 && 2 * q < t) t = 2 * q;
+        if (t > 32) t = 32;
         int ranks = 1;
         if (const char *e = getenv("LOCAL_WORLD_SIZE")) { const int r = atoi(e); if (r >= 1 && r <= 64) ranks = r; }
         t /= ranks;
-        return t < 1 ? 1 : (t > 32 ? 32 : t);
+        return t < 1 ? 1 : t;
     }();
     return chosen;
 }
@@ -146,13 +180,64 @@ size_t par_min_bytes()                  // files smaller than this are handled b
 // -- live on the GPU's node; reader threads on the OTHER socket write them across the inter-socket link.  Measured on the pool's
 // 2-socket boxes (profiles/r05_ingest_numa.txt, 1 GB cfg2 file, 32 threads): parse + pack 8.2 ms unbound, 6.9 bound to the GPU's
 // node, 14.6 bound to the other; ingest-to-features 15.3 / 14.1 / 22.8.  The threads of a job that copies to a device are therefore
-// bound to that device's node for the job (workers keep the binding, the caller's own is restored).  IDELUCS_NUMA=0 switches it
+// bound to that device's node for the job (workers keep the binding, the caller's own is restored).  IDELUCS_NUMA=off switches it
 // off, IDELUCS_NUMA=<node> forces a node.
 struct CpuBind {
-    cpu_set_t set;
+    cpu_set_t set;                      // the node's CPUs open to this process
+    std::vector<cpu_set_t> per_thread;  // thread i of a job: the hardware threads of ONE core, cores dealt round-robin over the node's L3 domains
     int node = -1;
     bool on = false;
+    const cpu_set_t &of(int i) const { return per_thread.empty() ? set : per_thread[(size_t)i % per_thread.size()]; }
 };
+
+int first_cpu_of_list(const char *path)      // first number of a sysfs cpu list ("64-71,192-199" -> 64), -1 when unreadable
+{
+    FILE *f = fopen(path, "r");
+    if (!f) return -1;
+    int v = -1;
+    if (fscanf(f, "%d", &v) != 1) v = -1;
+    fclose(f);
+    return v;
+}
+
+// One core per reader thread, spread over the L3 domains (IDELUCS_NUMA_PIN=0: the node's whole CPU set for every thread).  Measured
+// (profiles/r05_ingest_numa.txt): with the node-wide set the pool's 32 threads finished between 4.6 and 8.7 ms -- woken threads
+// go back to where they last ran and share cores, and a core complex has one link to memory -- against 4.8 .. 6.1 ms for
+// freshly created threads, which the kernel spreads.  A thread gets BOTH hardware threads of its core, so a sibling taken by
+// somebody else's work costs SMT sharing, not a time slice.
+void spread_over_cores(CpuBind *b)
+{
+    const char *e = getenv("IDELUCS_NUMA_PIN");
+    if (e && atoi(e) == 0) return;
+    struct Core { int l3, first; cpu_set_t cpus; };
+    std::vector<Core> cores;
+    for (int c = 0; c < CPU_SETSIZE; ++c) {
+        if (!CPU_ISSET(c, &b->set)) continue;
+        char path[128];
+        snprintf(path, sizeof(path), "/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list", c);
+        const int first = first_cpu_of_list(path);
+        if (first < 0) return;                         // no topology to read: keep the node-wide set
+        bool seen = false;
+        for (Core &k : cores) if (k.first == first) { CPU_SET(c, &k.cpus); seen = true; break; }
+        if (seen) continue;
+        snprintf(path, sizeof(path), "/sys/devices/system/cpu/cpu%d/cache/index3/shared_cpu_list", c);
+        Core k;
+        k.first = first;
+        k.l3 = first_cpu_of_list(path);
+        CPU_ZERO(&k.cpus);
+        CPU_SET(c, &k.cpus);
+        cores.push_back(k);
+    }
+    if (cores.size() < 2) return;
+    std::vector<int> l3s;
+    for (const Core &k : cores) if (std::find(l3s.begin(), l3s.end(), k.l3) == l3s.end()) l3s.push_back(k.l3);
+    std::vector<size_t> next(l3s.size(), 0);
+    std::vector<std::vector<size_t>> by_l3(l3s.size());
+    for (size_t i = 0; i < cores.size(); ++i) by_l3[(size_t)(std::find(l3s.begin(), l3s.end(), cores[i].l3) - l3s.begin())].push_back(i);
+    for (size_t placed = 0, g = 0; placed < cores.size(); g = (g + 1) % l3s.size()) {
+        if (next[g] < by_l3[g].size()) { b->per_thread.push_back(cores[by_l3[g][next[g]++]].cpus); ++placed; }
+    }
+}
 
 bool parse_cpulist(const char *path, cpu_set_t *out)
 {
@@ -183,7 +268,7 @@ CpuBind bind_for_device(int dev, int want_threads)
 {
     CpuBind b;
     const char *env = getenv("IDELUCS_NUMA");
-    if (env && strcmp(env, "0") == 0) return b;
+    if (env && (strcmp(env, "off") == 0 || strcmp(env, "-1") == 0)) return b;
     int node = -1;
     if (env && *env >= '0' && *env <= '9') node = atoi(env);
     else {
@@ -206,9 +291,10 @@ CpuBind bind_for_device(int dev, int want_threads)
     CPU_AND(&b.set, &nodeset, &mine);
     // too few CPUs of that node are open to this process (a cpuset on the other socket): leave the threads where they are
     if (CPU_COUNT(&b.set) == 0 || (CPU_COUNT(&b.set) < CPU_COUNT(&mine) && CPU_COUNT(&b.set) * 2 < want_threads)) return b;
-    if (CPU_EQUAL(&b.set, &mine)) { b.node = node; return b; }     // already there (one node, or an outer binding): nothing to set
     b.node = node;
+    if (CPU_EQUAL(&b.set, &mine) && !getenv("IDELUCS_NUMA_PIN")) return b;     // already there (one node, or an outer binding): leave the threads alone
     b.on = true;
+    spread_over_cores(&b);
     return b;
 }
 
@@ -240,7 +326,7 @@ public:
         std::function<void(int)> f = [&fn](int t) { fn(t); };
         cpu_set_t before;
         const bool rebind = bind != nullptr && bind->on && sched_getaffinity(0, sizeof(before), &before) == 0 &&
-                            sched_setaffinity(0, sizeof(bind->set), &bind->set) == 0;       // the caller, for the length of the job
+                            sched_setaffinity(0, sizeof(cpu_set_t), &bind->of(0)) == 0;       // the caller, for the length of the job
         {
             std::unique_lock<std::mutex> lk(mu_);
             while ((int)th_.size() < nt - 1) {
@@ -251,7 +337,7 @@ public:
             fn_ = &f;
             nt_ = nt;
             pending_ = nt - 1;
-            if (bind != nullptr && bind->on) { bind_ = bind->set; ++bind_gen_; }
+            if (bind != nullptr && bind->on) { bind_ = *bind; ++bind_gen_; }
             ++gen_;
         }
         cv_work_.notify_all();
@@ -280,7 +366,7 @@ private:
                 cv_work_.wait(lk, [&] { return gen_ != seen; });
                 seen = gen_;
                 if (idx < nt_) f = fn_;
-                if (f != nullptr && bind_gen_ != bound) { want = bind_; bound = bind_gen_; move = true; }
+                if (f != nullptr && bind_gen_ != bound) { want = bind_.of(idx); bound = bind_gen_; move = true; }
             }
             if (f == nullptr) continue;              // this job uses fewer threads
             if (move) (void)sched_setaffinity(0, sizeof(want), &want);      // (a worker keeps its node until a job names another)
@@ -296,7 +382,7 @@ private:
     std::function<void(int)> *fn_ = nullptr;
     int nt_ = 0, pending_ = 0;
     uint64_t gen_ = 0, bind_gen_ = 0;
-    cpu_set_t bind_;
+    CpuBind bind_;
 };
 
 template <typename F>
@@ -308,9 +394,9 @@ void parallel_for(int nt, F &&fn, const CpuBind *bind = nullptr)       // fn(thr
     // IDELUCS_READER_POOL=0: a thread per call and index (round 4's form, kept for A/B runs); new threads inherit the caller's CPUs
     cpu_set_t before;
     const bool rebind = bind != nullptr && bind->on && sched_getaffinity(0, sizeof(before), &before) == 0 &&
-                        sched_setaffinity(0, sizeof(bind->set), &bind->set) == 0;
+                        sched_setaffinity(0, sizeof(cpu_set_t), &bind->of(0)) == 0;
     std::vector<std::thread> th;
-    for (int t = 1; t < nt; ++t) th.emplace_back([&fn, t]() { fn(t); });
+    for (int t = 1; t < nt; ++t) th.emplace_back([&fn, t, bind, rebind]() { if (rebind) (void)sched_setaffinity(0, sizeof(cpu_set_t), &bind->of(t)); fn(t); });
     fn(0);
     for (auto &x : th) x.join();
     if (rebind) (void)sched_setaffinity(0, sizeof(before), &before);
@@ -604,6 +690,8 @@ struct idl_fasta {
     int check = 1;
     int64_t total_bases = 0, total_slots = 0, names_bytes = 0;
     std::vector<int64_t> arena_slot;      // idl_fasta_parse_pack: first slot of every record in the caller's arenas (+ the end)
+    std::vector<int64_t> lengths;         // idl_fasta_parse_pack: cleaned lengths, ready for idl_fasta_arena_meta
+    int64_t min_len = 0, max_len = 0;
 };
 
 extern "C" {
@@ -861,12 +949,29 @@ int idl_fasta_parse_pack(const char *path, uint8_t *codes, uint8_t *mask, int64_
     auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_0 = now();
     std::vector<FastOut> outs((size_t)nt);
-    // a thread sends what it has packed in 3 pieces of its region, at most 6 MB each (16 + 8 bytes a slot).  Measured with 32 threads
-    // on the 1 GB cfg2 file (IDELUCS_COPY_DIV, parse + pack 8.2 ms alone): 2-4 pieces 12.3-12.8 ms with the copies, 8 pieces 14.6,
-    // 16 pieces 18.9 -- every hipMemcpyAsync takes the stream's lock, and the 375 MB themselves take ~12 ms beside 32 parsing threads
+    // A thread sends what it has packed while it goes on parsing; what is still unsent when it finishes is the copy TAIL every
+    // later stage waits for.  Round 4 cut a region into 3 equal pieces: the last third of everything (125 MB at cfg2) left when the
+    // parsing was over, 2.6 ms at the link's 48 GB/s (IDELUCS_INGEST_TIMING=2: threads joined 8.0 ms, copies drained 10.6).  The
+    // pieces now shrink -- cuts at 45 / 75 / 92 % of the region's expected slots, the rest at the end (IDELUCS_COPY_SCHED="45,75,92")
+    // -- for the same number of calls as four equal pieces: every hipMemcpyAsync takes the stream's lock and ~15 us of host time
+    // (8 equal pieces 14.6 ms against 12.3-12.8 for 2-4, 16 pieces 18.9: round 4).  A piece is at most 6 MB (big files: more
+    // pieces) and, but for the last, at least 384 KB.  IDELUCS_COPY_DIV=<d> keeps round 4's d equal pieces for A/B runs.
     const int64_t region_slots = (int64_t)(size / 64) / nt + 1;
-    static const int copy_div = [] { const char *e = getenv("IDELUCS_COPY_DIV"); const int d = e ? atoi(e) : 0; return d >= 1 && d <= 64 ? d : 3; }();
-    const int64_t COPY_SLOTS = std::min<int64_t>((int64_t)1 << 18, std::max<int64_t>((int64_t)1 << 14, region_slots / copy_div));
+    static const int copy_div = [] { const char *e = getenv("IDELUCS_COPY_DIV"); const int d = e ? atoi(e) : 0; return d >= 1 && d <= 64 ? d : 0; }();
+    static const std::vector<int> sched = [] {
+        std::vector<int> v;
+        const char *e = getenv("IDELUCS_COPY_SCHED");
+        for (const char *p = e ? e : "45,75,92"; *p;) {
+            char *q = nullptr;
+            const long x = strtol(p, &q, 10);
+            if (q == p) break;
+            if (x > 0 && x < 100 && (v.empty() || x > v.back())) v.push_back((int)x);
+            p = (*q == ',') ? q + 1 : q;
+        }
+        return v;
+    }();
+    const int64_t COPY_MAX = (int64_t)1 << 18, COPY_MIN = (int64_t)1 << 14;
+    const int64_t COPY_SLOTS = copy_div ? std::min<int64_t>(COPY_MAX, std::max<int64_t>(COPY_MIN, region_slots / copy_div)) : COPY_MAX;
     // the copies below are issued from worker threads: a new thread's current device is 0, so each worker adopts the CALLER's device
     // first (a rank of a multi-GPU job is bound to another one, and dev_codes / stream belong to it)
     int caller_dev = -1;
@@ -895,6 +1000,7 @@ int idl_fasta_parse_pack(const char *path, uint8_t *codes, uint8_t *mask, int64_
         if (q >= size) { if (t == 0) o.fallback = 1; return; }        // (thread 0: a file without any header line)
         if (q >= e) return;
         int64_t slot = region_lo, sent = region_lo;
+        size_t cut = 0;                                               // next entry of the piece schedule
         auto send = [&](int64_t upto) {
             if (dev_codes != nullptr && upto > sent) {
                 const double ts = timing ? now() : 0.0;
@@ -938,6 +1044,10 @@ int idl_fasta_parse_pack(const char *path, uint8_t *codes, uint8_t *mask, int64_
             o.slot.push_back(slot);
             slot += slots;
             if (slot - sent >= COPY_SLOTS) send(slot);
+            else if (!copy_div && cut < sched.size() && (slot - region_lo) * 100 >= region_slots * sched[cut] && slot - sent >= COPY_MIN) {
+                send(slot);
+                while (cut < sched.size() && (slot - region_lo) * 100 >= region_slots * sched[cut]) ++cut;
+            }
             hs = lp;
         }
         send(slot);
@@ -975,21 +1085,39 @@ int idl_fasta_parse_pack(const char *path, uint8_t *codes, uint8_t *mask, int64_
             return rc;
         }
     }
-    size_t n = 0;
-    for (const FastOut &o : outs) n += o.recs.size();
-    f->recs.reserve(n);
-    f->arena_slot.reserve(n + 1);
+    // merge: every thread copies its records to their place in the file's order (prefix of the per-thread counts) and sums its own
+    std::vector<size_t> first((size_t)nt + 1, 0);
+    for (int t = 0; t < nt; ++t) first[(size_t)t + 1] = first[(size_t)t] + outs[(size_t)t].recs.size();
+    const size_t n = first[(size_t)nt];
+    f->recs.resize(n);
+    f->arena_slot.resize(n + 1);
+    f->lengths.resize(n);
     int64_t last_end = 0;
-    for (const FastOut &o : outs) {
-        for (size_t i = 0; i < o.recs.size(); ++i) { f->recs.push_back(o.recs[i]); f->arena_slot.push_back(o.slot[i]); }
-        if (!o.recs.empty()) last_end = o.slot.back();
+    for (const FastOut &o : outs) if (!o.recs.empty()) last_end = o.slot.back();
+    f->arena_slot[n] = last_end;
+    struct Part { int64_t bases = 0, slots = 0, names = 0, lo = INT64_MAX, hi = 0; };
+    std::vector<Part> parts((size_t)nt);
+    parallel_for(n >= 4096 ? nt : 1, [&](int t0) {
+        for (int t = t0; t < nt; t += (n >= 4096 ? nt : 1)) {
+            const FastOut &o = outs[(size_t)t];
+            Part &p = parts[(size_t)t];
+            const size_t at = first[(size_t)t];
+            for (size_t i = 0; i < o.recs.size(); ++i) {
+                const Rec &r = o.recs[i];
+                f->recs[at + i] = r;
+                f->arena_slot[at + i] = o.slot[i];
+                f->lengths[at + i] = r.len;
+                p.bases += r.len; p.slots += (r.len + 63) / 64; p.names += (int64_t)(r.id_e - r.id_b);
+                p.lo = std::min(p.lo, r.len); p.hi = std::max(p.hi, r.len);
+            }
+        }
+    });
+    int64_t lo = INT64_MAX;
+    for (const Part &p : parts) {
+        f->total_bases += p.bases; f->total_slots += p.slots; f->names_bytes += p.names;
+        lo = std::min(lo, p.lo); f->max_len = std::max(f->max_len, p.hi);
     }
-    f->arena_slot.push_back(last_end);
-    for (const Rec &r : f->recs) {
-        f->total_bases += r.len;
-        f->total_slots += (r.len + 63) / 64;
-        f->names_bytes += (int64_t)(r.id_e - r.id_b);
-    }
+    f->min_len = n ? lo : 0;
     if (timing) fprintf(stderr, "idl_fasta_parse_pack: one pass %.1f ms (%d threads, %zu records)\n", now() - t_0, nt, n);
     *out = f;
     return IDL_OK;
@@ -1000,6 +1128,18 @@ int idl_fasta_arena_slots(const idl_fasta *f, int64_t *slot_off)
     IDL_REQUIRE(f && slot_off, "NULL argument");
     IDL_REQUIRE(f->arena_slot.size() == f->recs.size() + 1, "fasta_arena_slots: the handle does not come from idl_fasta_parse_pack");
     memcpy(slot_off, f->arena_slot.data(), f->arena_slot.size() * sizeof(int64_t));
+    return IDL_OK;
+}
+
+int idl_fasta_arena_meta(const idl_fasta *f, int64_t *lengths, int64_t *slot_off, int64_t *min_len, int64_t *max_len)
+{
+    IDL_REQUIRE(f, "NULL argument");
+    IDL_REQUIRE(f->arena_slot.size() == f->recs.size() + 1 && f->lengths.size() == f->recs.size(),
+                "fasta_arena_meta: the handle does not come from idl_fasta_parse_pack");
+    if (lengths && !f->lengths.empty()) memcpy(lengths, f->lengths.data(), f->lengths.size() * sizeof(int64_t));
+    if (slot_off) memcpy(slot_off, f->arena_slot.data(), f->arena_slot.size() * sizeof(int64_t));
+    if (min_len) *min_len = f->min_len;
+    if (max_len) *max_len = f->max_len;
     return IDL_OK;
 }
 
@@ -1074,6 +1214,20 @@ int idl_fasta_export(const idl_fasta *f, uint8_t *names, int64_t *name_off, int6
 int idl_ingest_threads(void) { return n_threads(); }
 
 int idl_ingest_numa_node(void) { return g_last_bind_node; }
+
+int idl_ingest_cpu_plan(int device, int threads, int32_t *first_cpu, int32_t *n_cpus)
+{
+    IDL_REQUIRE(threads >= 1 && threads <= 256, "ingest_cpu_plan: threads outside 1..256");
+    const CpuBind b = bind_for_device(device, threads);
+    for (int t = 0; t < threads; ++t) {
+        const cpu_set_t &c = b.of(t);
+        int first = -1;
+        if (b.on) for (int i = 0; i < CPU_SETSIZE; ++i) if (CPU_ISSET(i, &c)) { first = i; break; }
+        if (first_cpu) first_cpu[t] = first;
+        if (n_cpus) n_cpus[t] = b.on ? CPU_COUNT(&c) : 0;
+    }
+    return b.node;
+}
 
 int idl_fasta_pack_range(const idl_fasta *f, int64_t rec_lo, int64_t rec_hi, uint8_t *codes, uint8_t *mask)
 {

@@ -749,11 +749,21 @@ __device__ __forceinline__ void vm_wait_at_most(int younger)
     else vm_wait<0>();
 }
 
-template <int K>
+// RL (k = 4 only): log2 of the number of COPIES of the histogram.  A 4^4-bin histogram is 1 KB, and an LDS atomic from 64 lanes to
+// random bins pays the banks, not the bins: 32 lanes of a group over 32 banks put ~3.5 addresses on the busiest one, and the
+// read-modify-write takes the bank for each (measured, k = 5..6: 4.5-6 atomics per clock and CU where the instruction's own issue
+// would allow 16).  With bin b of copy c at word b * 2^RL + c and lane l adding to copy l mod 2^RL, the 32 lanes of a group hit
+// 32 different banks (RL = 5; two lanes per bank at RL = 4) whatever the bins are -- SURVEY section 7's "per-wave private
+// sub-histograms" taken to the lane.  The copies are added up when a memory wave reads a row out (integer sums: order-free, and a
+// window may leave through another copy than it entered by -- undo / apply lists -- since only the sum is ever read).
+template <int K, int RL = 0>
 struct V3 {
     using T = V2<K, false>;
-    static constexpr int F = T::F, HD = T::HD;
+    static constexpr int F = T::F, HD = RL ? (F + 4) << RL : T::HD;       // histogram words: F bins + 4 garbage bins (x copies)
     static constexpr uint32_t KM = T::KM, VM = T::VM;
+    static_assert(RL == 0 || (F + 4) * 4 < 65536, "bin byte offsets travel as 16 bits");
+    // byte offset of bin (given as its byte offset in ONE copy) in the copy of the lane whose offset is lo = (lane mod 2^RL) * 4
+    static __device__ __forceinline__ uint32_t at(uint32_t bin4, uint32_t lo) { return RL ? (bin4 << RL) + lo : bin4; }
 
     // All K windows of ONE edit: the windows ending at p .. p + K - 1 that this edit owns (it is the latest edit at or before
     // their end: w <= min(p + K - 1, next edit - 1, last base)).  One 32-base fetch serves the K old bins; the XORs / N flags of
@@ -802,10 +812,10 @@ struct V3 {
     }
 
     // one list entry: the window leaves the bin at byte offset (e & 0xFFFF) and enters the one at (e >> 16) (sign = 1), or back
-    static __device__ __forceinline__ void move(uint32_t *hist, uint32_t e, uint32_t sign)
+    static __device__ __forceinline__ void move(uint32_t *hist, uint32_t e, uint32_t sign, uint32_t lo = 0u)
     {
-        atomicAdd((uint32_t *)((char *)hist + (e & 0xFFFFu)), 0u - sign);
-        atomicAdd((uint32_t *)((char *)hist + (e >> 16)), sign);
+        atomicAdd((uint32_t *)((char *)hist + at(e & 0xFFFFu, lo)), 0u - sign);
+        atomicAdd((uint32_t *)((char *)hist + at(e >> 16, lo)), sign);
     }
 
     // every window ending in the staged sequence (v2's count_all without its barrier); returns this thread's valid windows
@@ -813,6 +823,7 @@ struct V3 {
     static __device__ __forceinline__ uint32_t count_all(const uint32_t *cod, const uint32_t *msk, int nloc, uint32_t *hist, int tid)
     {
         uint32_t cnt = 0;
+        const uint32_t lo = RL ? ((uint32_t)tid & ((1u << RL) - 1u)) << 2 : 0u;
         const int nd = nloc * 4;
         for (int d0 = 0; d0 < nd; d0 += NT) {
             const int d = d0 + tid;
@@ -824,20 +835,20 @@ struct V3 {
                 for (int t = 1; t < K; ++t) inv |= (M >> t);
                 inv &= 0xFFFFu;
                 // byte offset of window j's bin: ((prev:cur) >> (30 - 2j)) & KM, times 4 -- one funnel shift + one AND per window
-                const uint32_t hi = (uint32_t)(w >> 32), lo = (uint32_t)w;
+                const uint32_t hi = (uint32_t)(w >> 32), lw = (uint32_t)w;
                 constexpr uint32_t KM4 = KM << 2;
                 if (__ballot(inv != 0u) == 0ull) {
 #pragma unroll
                     for (int j = 0; j < 16; ++j) {
-                        const uint32_t ad = (j < 15 ? __builtin_amdgcn_alignbit(hi, lo, 28 - 2 * (j < 15 ? j : 0)) : (lo << 2)) & KM4;
-                        atomicAdd((uint32_t *)((char *)hist + ad), 1u);
+                        const uint32_t ad = (j < 15 ? __builtin_amdgcn_alignbit(hi, lw, 28 - 2 * (j < 15 ? j : 0)) : (lw << 2)) & KM4;
+                        atomicAdd((uint32_t *)((char *)hist + at(ad, lo)), 1u);
                     }
                 } else {
                     const uint32_t garbage = ((uint32_t)F + (tid & 3)) << 2;
 #pragma unroll
                     for (int j = 0; j < 16; ++j) {
-                        const uint32_t ad = (j < 15 ? __builtin_amdgcn_alignbit(hi, lo, 28 - 2 * (j < 15 ? j : 0)) : (lo << 2)) & KM4;
-                        atomicAdd((uint32_t *)((char *)hist + (((inv >> (15 - j)) & 1u) ? garbage : ad)), 1u);
+                        const uint32_t ad = (j < 15 ? __builtin_amdgcn_alignbit(hi, lw, 28 - 2 * (j < 15 ? j : 0)) : (lw << 2)) & KM4;
+                        atomicAdd((uint32_t *)((char *)hist + at(((inv >> (15 - j)) & 1u) ? garbage : ad, lo)), 1u);
                     }
                 }
                 cnt += 16u - (uint32_t)__popc(inv);

@@ -85,10 +85,22 @@ class FastaFile:
         self._load(h, check, keep_bytes, pack)
 
     @classmethod
-    def from_handle(cls, h, arena=False):
+    def from_handle(cls, h, arena=False, meta=None):
         """A FastaFile over an idl_fasta handle the caller opened (idl_fasta_parse_pack: arena = True -> slot_off are the records'
-        first slots in the caller's arenas); the handle is closed."""
+        first slots in the caller's arenas); the handle is closed.
+        meta = (lengths, slot_off) already read out with idl_fasta_arena_meta (the one-pass ingest: they go to the device first):
+        the names are then exported on first use or at close() -- off the path between the file and the first kernel."""
         obj = cls.__new__(cls)
+        if arena and meta is not None:
+            n, tb, ts, nb = (ctypes.c_int64() for _ in range(4))
+            _lib.check(_L.idl_fasta_sizes(h, ctypes.byref(n), ctypes.byref(tb), ctypes.byref(ts), ctypes.byref(nb)))
+            obj.n, obj.total_bases, obj.total_slots = n.value, tb.value, ts.value
+            obj.lengths, obj.slot_off = meta
+            obj.byte_off = obj.bytes = obj.codes = obj.mask = None
+            obj._names_raw = obj._name_off = obj._names = None
+            obj._names_bytes, obj._check = nb.value, True
+            obj._h = h
+            return obj
         arena_slots = None
         if arena:
             n = ctypes.c_int64()
@@ -99,6 +111,22 @@ class FastaFile:
         if arena:
             obj.slot_off = arena_slots
         return obj
+
+    def _export_names(self):
+        """The deferred half of from_handle(meta=...): names out of the open handle, with _load's checks."""
+        names = np.empty(max(self._names_bytes, 1), np.uint8)
+        name_off = np.empty(self.n + 1, np.int64)
+        _lib.check(_L.idl_fasta_export(self._h, _ptr(names), _ptr(name_off), None, None, None, None, None, None))
+        self._names_raw, self._name_off = names, name_off
+        self._check_names(self._names_bytes, self._check)
+
+    def _check_names(self, nb, check):
+        if self.n and int(self._names_raw[:nb].max(initial=0)) >= 0x80:
+            # non-ASCII names: decode now, so that invalid UTF-8 fails here as in the reference, and apply the one header check the
+            # byte-level reader cannot do (unicode whitespace as first character)
+            if check and any(len(nm) > 0 and nm[0].isspace() for nm in self.names):
+                self.close()
+                raise ValueError("Bad character in sequence header")
 
     def _load(self, h, check, keep_bytes, pack):
         self._h = None
@@ -129,16 +157,15 @@ class FastaFile:
         # names as Python strings (utils.py:172 .decode()) are built on first use: 100 000 decodes cost 12 ms, and the training
         # path needs them only when results are written.  The checks that need decoded text run now, on the few names concerned.
         self._names_raw, self._name_off, self._names = names, name_off, None
-        if self.n and int(names[:nb.value].max(initial=0)) >= 0x80:
-            # non-ASCII names: decode now, so that invalid UTF-8 fails here as in the reference, and apply the one header check the
-            # byte-level reader cannot do (unicode whitespace as first character)
-            if check and any(len(nm) > 0 and nm[0].isspace() for nm in self.names):
-                self.close()
-                raise ValueError("Bad character in sequence header")
+        self._check_names(nb.value, check)
 
     @property
     def names(self):
         if self._names is None:
+            if self._names_raw is None:
+                if self._h is None:
+                    raise ValueError("the names of this file were never read out")
+                self._export_names()
             raw, off = self._names_raw.tobytes(), self._name_off
             self._names = [raw[off[i]:off[i + 1]].decode() for i in range(self.n)]
         return self._names
@@ -150,13 +177,22 @@ class FastaFile:
             raise ValueError("pack_range needs FastaFile(pack='deferred')")
         _lib.check(_L.idl_fasta_pack_range(self._h, int(lo), int(hi), _ptr(codes), _ptr(mask)))
 
-    def close(self):
+    def close(self, export=True):
         if getattr(self, "_h", None) is not None:
+            if export and getattr(self, "_names_raw", 0) is None:      # names deferred by from_handle(meta=...): last chance to read them
+                h, self._h = self._h, None
+                try:
+                    self._h = h
+                    self._export_names()
+                finally:
+                    self._h = None
+                    _L.idl_fasta_close(h)
+                return
             _L.idl_fasta_close(self._h)
             self._h = None
 
     def __del__(self):
-        self.close()
+        self.close(export=False)
 
     def record(self, i):
         return bytearray(self.bytes[self.byte_off[i]:self.byte_off[i + 1]].tobytes())
@@ -727,20 +763,26 @@ class _OnePassInput:
             _lib.check(rc)
         q.append(time.perf_counter())
         self = cls()
-        self.ff = FastaFile.from_handle(h, arena=True)
-        ff = self.ff
-        q.append(time.perf_counter())
-        self.n = ff.n
-        self.max_len = int(ff.lengths.max()) if ff.n else 0
-        self.min_len = int(ff.lengths.min()) if ff.n else 0
-        # lengths and first slots go up from PINNED staging: a copy from pageable memory waits behind the arena copies (16-20 ms)
-        if _ARENAS["small"].numel() < 2 * ff.n + 1:
-            _ARENAS["small"] = torch.empty(2 * ff.n + 1, dtype=torch.int64, pin_memory=True)
+        # lengths and first slots FIRST, straight into pinned staging and on to the device (the mimic-site generator needs nothing
+        # else); a copy from pageable memory would wait behind the arena copies (16-20 ms).  The names are read out later, while the
+        # device works (FastaFile.from_handle(meta=...)).
+        n_rec = ctypes.c_int64()
+        _lib.check(_L.idl_fasta_sizes(h, ctypes.byref(n_rec), None, None, None))
+        n = n_rec.value
+        if _ARENAS["small"].numel() < 2 * n + 1:
+            _ARENAS["small"] = torch.empty(2 * n + 1 + 4096, dtype=torch.int64, pin_memory=True)
         stage = _ARENAS["small"]
-        stage[:ff.n].copy_(torch.from_numpy(ff.lengths))
-        stage[ff.n:2 * ff.n + 1].copy_(torch.from_numpy(ff.slot_off))
-        both = stage[:2 * ff.n + 1].to(device, non_blocking=True)
-        self.lengths, self.slot_off = both[:ff.n], both[ff.n:]
+        lo_len, hi_len = ctypes.c_int64(), ctypes.c_int64()
+        _lib.check(_L.idl_fasta_arena_meta(h, _ptr(stage), ctypes.c_void_p(stage.data_ptr() + 8 * n), ctypes.byref(lo_len), ctypes.byref(hi_len)))
+        both = stage[:2 * n + 1].to(device, non_blocking=True)
+        q.append(time.perf_counter())
+        meta = stage[:2 * n + 1].numpy().copy()                     # (the staging is overwritten by the next file)
+        self.ff = FastaFile.from_handle(h, arena=True, meta=(meta[:n], meta[n:]))
+        ff = self.ff
+        self.n = n
+        self.max_len, self.min_len = hi_len.value, lo_len.value
+        self.total_len = ff.total_bases
+        self.lengths, self.slot_off = both[:n], both[n:]
         self.codes, self.mask = codes, mask
         self._hold = (hc, hm, copy)
         ev_small, ev_copy = torch.cuda.Event(), torch.cuda.Event()
@@ -749,7 +791,7 @@ class _OnePassInput:
         _ARENAS["busy"] = (ev_small, ev_copy)   # the next file waits for these before it overwrites the pinned buffers
         if os.environ.get("IDELUCS_INGEST_TIMING") is not None:
             q.append(time.perf_counter())
-            print("_OnePassInput: pinned arenas %.1f ms, device arenas %.1f, reader %.1f, names/lengths %.1f, small uploads %.1f"
+            print("_OnePassInput: pinned arenas %.1f ms, device arenas %.1f, reader %.1f, lengths + slots to the device %.1f, host copy + handle %.1f"
                   % tuple(1e3 * (b - a) for a, b in zip(q[:-1], q[1:])), file=sys.stderr)
         return self
 

@@ -438,3 +438,107 @@ def test_reader_thread_default_follows_quota_and_ranks():
     t2, t8 = threads(LOCAL_WORLD_SIZE="2"), threads(LOCAL_WORLD_SIZE="8")
     assert 1 <= t8 <= t2 <= base and t8 <= max(1, base // 2)          # (the share of a rank shrinks with the ranks of the node)
     assert threads(IDELUCS_THREADS="5", LOCAL_WORLD_SIZE="8") == 5
+
+
+def test_reader_cpu_plan_one_core_per_thread(monkeypatch):
+    """Round 5: a device job's reader threads are bound to the NUMA node of the device, one core each, cores dealt over the L3
+    domains (idl_ingest_cpu_plan reports the placement without changing anything).  Here, without a device: IDELUCS_NUMA=<node>
+    names the node; every thread's set is a non-empty part of this process's CPUs, and as many threads as the node has cores get
+    cores of their own; IDELUCS_NUMA=off plans nothing."""
+    if not os.path.isdir("/sys/devices/system/node/node0"):
+        pytest.skip("no NUMA topology in sysfs")
+    mine = os.sched_getaffinity(0)
+    nt = 12
+    first = np.full(nt, -2, np.int32); count = np.zeros(nt, np.int32)
+    monkeypatch.setenv("IDELUCS_NUMA", "0")
+    monkeypatch.setenv("IDELUCS_NUMA_PIN", "1")
+    node = _lib.lib.idl_ingest_cpu_plan(-1, nt, U._ptr(first), U._ptr(count))
+    if node < 0:
+        pytest.skip("node 0 holds none of this process's CPUs")
+    assert node == 0 and np.all(count >= 1) and all(int(c) in mine for c in first)
+    cores = set()
+    for c in first:                                             # threads beyond the node's cores wrap around
+        sib = open(f"/sys/devices/system/cpu/cpu{int(c)}/topology/thread_siblings_list").read().strip()
+        cores.add(sib)
+    n_cores = len({open(f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list").read().strip() for c in mine
+                   if os.path.exists(f"/sys/devices/system/node/node0/cpu{c}")})
+    assert len(cores) == min(nt, n_cores)
+    monkeypatch.setenv("IDELUCS_NUMA_PIN", "0")                  # the node's whole set for everybody
+    assert _lib.lib.idl_ingest_cpu_plan(-1, nt, U._ptr(first), U._ptr(count)) == 0 and len(set(count.tolist())) == 1
+    monkeypatch.setenv("IDELUCS_NUMA", "off")
+    assert _lib.lib.idl_ingest_cpu_plan(-1, nt, U._ptr(first), U._ptr(count)) == -1 and np.all(count == 0)
+
+
+def test_reader_pool_is_reused_and_survives_fork(tmp_path, monkeypatch):
+    """Round 5: the reader's threads persist between calls.  Jobs of different widths follow each other, and a forked child
+    (whose parent's pool threads do not exist there) reads with a pool of its own."""
+    monkeypatch.setenv("IDELUCS_PAR_MIN", "0")
+    rng = np.random.default_rng(77)
+    fn = str(tmp_path / "p.fas")
+    _random_fasta(fn, rng, 200)
+    want = None
+    for threads in ("6", "2", "8", "3"):
+        monkeypatch.setenv("IDELUCS_THREADS", threads)
+        ff = U.FastaFile(fn)
+        got = (ff.names, ff.lengths.tolist(), ff.codes.tobytes(), ff.mask.tobytes())
+        want = want or got
+        assert got == want
+    pid = os.fork()
+    if pid == 0:                                                 # the child: must not hang on the parent's sleeping workers
+        code = 1
+        try:
+            ff = U.FastaFile(fn)
+            one = _one_pass(fn)
+            ok = (ff.names, ff.lengths.tolist(), ff.codes.tobytes(), ff.mask.tobytes()) == want and one is not None
+            code = 0 if ok else 2
+        finally:
+            os._exit(code)
+    import time
+    t0 = time.time()
+    while True:
+        done, status = os.waitpid(pid, os.WNOHANG)
+        if done:
+            break
+        if time.time() - t0 > 60:
+            os.kill(pid, 9)
+            os.waitpid(pid, 0)
+            pytest.fail("the forked child hung in the reader")
+        time.sleep(0.05)
+    assert os.WIFEXITED(status) and os.WEXITSTATUS(status) == 0, status
+
+
+def test_arena_meta_and_deferred_names(tmp_path, monkeypatch):
+    """Round 5: idl_fasta_arena_meta hands out lengths, arena slots and the length range right after the one pass; the names come
+    later (FastaFile.from_handle(meta=...): on first use or at close()) and are the general reader's."""
+    monkeypatch.setenv("IDELUCS_THREADS", "4")
+    monkeypatch.setenv("IDELUCS_PAR_MIN", "0")
+    for path in (os.path.join(DATA, "Influenza-A.fas"),):
+        whole = U.FastaFile(path)
+        size = os.path.getsize(path)
+        cap = size // 48 + 4096 * 4 + 1024
+        codes = np.zeros(cap * 16, np.uint8); mask = np.zeros(cap * 8, np.uint8)
+        for use in ("names", "close"):
+            h = ctypes.c_void_p()
+            _lib.check(_lib.lib.idl_fasta_parse_pack(os.fsencode(path), U._ptr(codes), U._ptr(mask), cap, None, None, None, ctypes.byref(h)))
+            n = ctypes.c_int64()
+            _lib.check(_lib.lib.idl_fasta_sizes(h, ctypes.byref(n), None, None, None))
+            meta = np.empty(2 * n.value + 1, np.int64)
+            lo, hi = ctypes.c_int64(), ctypes.c_int64()
+            _lib.check(_lib.lib.idl_fasta_arena_meta(h, U._ptr(meta), ctypes.c_void_p(meta.ctypes.data + 8 * n.value), ctypes.byref(lo), ctypes.byref(hi)))
+            assert n.value == whole.n and np.array_equal(meta[:n.value], whole.lengths)
+            assert (lo.value, hi.value) == (int(whole.lengths.min()), int(whole.lengths.max()))
+            slots = np.empty(n.value + 1, np.int64)
+            _lib.check(_lib.lib.idl_fasta_arena_slots(h, U._ptr(slots)))
+            assert np.array_equal(meta[n.value:], slots)
+            ff = U.FastaFile.from_handle(h, arena=True, meta=(meta[:n.value], meta[n.value:]))
+            assert ff._names_raw is None and ff.total_bases == whole.total_bases
+            if use == "close":
+                ff.close()                                        # reads the names out before the handle goes
+                assert ff._h is None
+            assert ff.names == whole.names
+            ff.close()
+    # a handle of the general reader has no arena meta
+    h = ctypes.c_void_p()
+    _lib.check(_lib.lib.idl_fasta_open(os.fsencode(path), 1, ctypes.byref(h)))
+    assert _lib.lib.idl_fasta_arena_meta(h, None, None, None, None) != _lib.IDL_OK
+    _lib.lib.idl_fasta_close(h)

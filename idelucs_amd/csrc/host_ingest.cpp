@@ -408,9 +408,10 @@ struct Packer {
     uint32_t c = 0, m = 0;
     int j = 0;
     int64_t w = 0;
+    bool dirty = false;                // an invalid base (N) was pushed: the record's mask is more than its tail padding
     inline void push(unsigned code)
     {
-        if (code == 4u) m |= 0x8000u >> j;
+        if (code == 4u) { m |= 0x8000u >> j; dirty = true; }
         else c |= (uint32_t)code << (30 - 2 * j);
         if (++j == 16) flush_word();
     }
@@ -691,6 +692,8 @@ struct idl_fasta {
     int64_t total_bases = 0, total_slots = 0, names_bytes = 0;
     std::vector<int64_t> arena_slot;      // idl_fasta_parse_pack: first slot of every record in the caller's arenas (+ the end)
     std::vector<int64_t> lengths;         // idl_fasta_parse_pack: cleaned lengths, ready for idl_fasta_arena_meta
+    std::vector<uint8_t> mask_sent;       // idl_fasta_parse_pack with device arenas: 1 = the record's invalid-mask was copied there
+    int64_t n_mask_unsent = 0;
     int64_t min_len = 0, max_len = 0;
 };
 
@@ -870,9 +873,36 @@ int idl_fasta_open(const char *path, int check, idl_fasta **out)
 // ------------------------------------------------------------------------------------------------
 namespace {
 
+// this library's own copy streams (+ the events that tie them to the caller's stream), per device, made on first use and kept
+struct CopyStreams {
+    std::vector<hipStream_t> extra;
+    std::vector<hipEvent_t> done;
+    hipEvent_t start = nullptr;
+};
+
+CopyStreams *copy_streams(int dev, int count)
+{
+    static std::mutex mu;
+    static std::vector<std::pair<int, CopyStreams *>> all;
+    std::lock_guard<std::mutex> lk(mu);
+    for (auto &p : all) if (p.first == dev && (int)p.second->extra.size() == count) return p.second;
+    CopyStreams *c = new CopyStreams();
+    bool ok = hipEventCreateWithFlags(&c->start, hipEventDisableTiming) == hipSuccess;
+    for (int i = 0; ok && i < count; ++i) {
+        hipStream_t s = nullptr;
+        hipEvent_t e = nullptr;
+        ok = hipStreamCreateWithFlags(&s, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+        if (ok) { c->extra.push_back(s); c->done.push_back(e); }
+    }
+    if (!ok) { delete c; return nullptr; }       // (leaks what was made; the caller goes on with its one stream)
+    all.emplace_back(dev, c);
+    return c;
+}
+
 struct FastOut {
     std::vector<Rec> recs;
     std::vector<int64_t> slot;
+    std::vector<uint8_t> mask_sent;                 // per record: 1 = its invalid-mask went to the device with its piece (0: the caller rebuilds it from the length)
     double t_begin = 0, t_end = 0, t_send = 0;      // IDELUCS_INGEST_TIMING: when this thread started / finished, host time inside its copy calls
     int n_send = 0;
     int fallback = 0, bad_kind = REC_OK, copy_failed = 0;
@@ -957,8 +987,8 @@ int idl_fasta_parse_pack(const char *path, uint8_t *codes, uint8_t *mask, int64_
     // (8 equal pieces 14.6 ms against 12.3-12.8 for 2-4, 16 pieces 18.9: round 4).  A piece is at most 6 MB (big files: more
     // pieces) and, but for the last, at least 384 KB.  IDELUCS_COPY_DIV=<d> keeps round 4's d equal pieces for A/B runs.
     const int64_t region_slots = (int64_t)(size / 64) / nt + 1;
-    static const int copy_div = [] { const char *e = getenv("IDELUCS_COPY_DIV"); const int d = e ? atoi(e) : 0; return d >= 1 && d <= 64 ? d : 0; }();
-    static const std::vector<int> sched = [] {
+    const int copy_div = [] { const char *e = getenv("IDELUCS_COPY_DIV"); const int d = e ? atoi(e) : 0; return d >= 1 && d <= 64 ? d : 0; }();
+    const std::vector<int> sched = [] {
         std::vector<int> v;
         const char *e = getenv("IDELUCS_COPY_SCHED");
         for (const char *p = e ? e : "45,75,92"; *p;) {
@@ -978,6 +1008,22 @@ int idl_fasta_parse_pack(const char *path, uint8_t *codes, uint8_t *mask, int64_
     if (dev_codes != nullptr && hipGetDevice(&caller_dev) != hipSuccess) caller_dev = -1;
     const CpuBind bind = (nt > 1 && caller_dev >= 0) ? bind_for_device(caller_dev, nt) : CpuBind();
     g_last_bind_node = bind.node;
+    const bool sparse_mask = [] { const char *e = getenv("IDELUCS_SPARSE_MASK"); return !(e && atoi(e) == 0); }();
+    // copy streams: the caller's, and IDELUCS_COPY_STREAMS - 1 more of this library's own (thread t copies on stream t mod count;
+    // they start behind whatever the caller's stream holds and the caller's stream waits for them at the end)
+    std::vector<hipStream_t> streams(1, (hipStream_t)stream);
+    CopyStreams *cs = nullptr;
+    if (dev_codes != nullptr && nt > 1 && caller_dev >= 0) {
+        const int want = [] { const char *e = getenv("IDELUCS_COPY_STREAMS"); const int v = e ? atoi(e) : 1; return v >= 1 && v <= 8 ? v : 1; }();
+        cs = want > 1 ? copy_streams(caller_dev, want - 1) : nullptr;
+        if (cs != nullptr) {
+            if (hipEventRecord(cs->start, (hipStream_t)stream) != hipSuccess) cs = nullptr;
+            for (size_t i = 0; cs != nullptr && i < cs->extra.size(); ++i) {
+                if (hipStreamWaitEvent(cs->extra[i], cs->start, 0) != hipSuccess) { idl::set_error("fasta_parse_pack: hipStreamWaitEvent failed"); delete f; return IDL_ERR_HIP; }
+                streams.push_back(cs->extra[i]);
+            }
+        }
+    }
 
     parallel_for(nt, [&](int t) {
         FastOut &o = outs[(size_t)t];
@@ -1001,14 +1047,21 @@ int idl_fasta_parse_pack(const char *path, uint8_t *codes, uint8_t *mask, int64_
         if (q >= e) return;
         int64_t slot = region_lo, sent = region_lo;
         size_t cut = 0;                                               // next entry of the piece schedule
+        bool piece_dirty = false;                                     // a record since the last copy holds an N
+        const hipStream_t my_stream = streams[(size_t)t % streams.size()];
         auto send = [&](int64_t upto) {
+            // the invalid-mask is a third of the bytes, and on clean input it says nothing the lengths do not: a piece without an N
+            // sends its packed bases only, and its records are flagged for the caller to rebuild their masks on the device
+            const bool with_mask = piece_dirty || !sparse_mask;
             if (dev_codes != nullptr && upto > sent) {
                 const double ts = timing ? now() : 0.0;
-                if (hipMemcpyAsync((uint8_t *)dev_codes + sent * 16, codes + sent * 16, (size_t)(upto - sent) * 16, hipMemcpyHostToDevice, (hipStream_t)stream) != hipSuccess ||
-                    hipMemcpyAsync((uint8_t *)dev_mask + sent * 8, mask + sent * 8, (size_t)(upto - sent) * 8, hipMemcpyHostToDevice, (hipStream_t)stream) != hipSuccess)
+                if (hipMemcpyAsync((uint8_t *)dev_codes + sent * 16, codes + sent * 16, (size_t)(upto - sent) * 16, hipMemcpyHostToDevice, my_stream) != hipSuccess ||
+                    (with_mask && hipMemcpyAsync((uint8_t *)dev_mask + sent * 8, mask + sent * 8, (size_t)(upto - sent) * 8, hipMemcpyHostToDevice, my_stream) != hipSuccess))
                     o.copy_failed = 1;
-                if (timing) { o.t_send += now() - ts; ++o.n_send; }
+                if (timing) { o.t_send += now() - ts; o.n_send += with_mask ? 2 : 1; }
             }
+            o.mask_sent.resize(o.recs.size(), (dev_codes != nullptr && with_mask) ? 1 : 0);
+            piece_dirty = false;
             sent = upto;
         };
         size_t hs = q;
@@ -1040,6 +1093,7 @@ int idl_fasta_parse_pack(const char *path, uint8_t *codes, uint8_t *mask, int64_
             r.len = cnt;
             const int64_t slots = (cnt + 63) / 64;
             pk.finish(slots);
+            piece_dirty |= pk.dirty;
             o.recs.push_back(r);
             o.slot.push_back(slot);
             slot += slots;
@@ -1054,6 +1108,11 @@ int idl_fasta_parse_pack(const char *path, uint8_t *codes, uint8_t *mask, int64_
         o.slot.push_back(slot);                                       // end of this thread's records
         if (timing) o.t_end = now();
     }, &bind);
+    // the caller's stream continues when the other copy streams have drained
+    for (size_t i = 1; i < streams.size(); ++i) {
+        if (hipEventRecord(cs->done[i - 1], streams[i]) != hipSuccess || hipStreamWaitEvent((hipStream_t)stream, cs->done[i - 1], 0) != hipSuccess)
+            outs[0].copy_failed = 1;
+    }
     if (timing) {
         double b_max = 0, e_min = 1e300, e_max = 0, snd = 0;
         int ns = 0;
@@ -1067,8 +1126,8 @@ int idl_fasta_parse_pack(const char *path, uint8_t *codes, uint8_t *mask, int64_
         // IDELUCS_INGEST_TIMING=2 also waits for the copies here (diagnostic only: the caller overlaps this wait with its own work)
         if (dev_codes != nullptr && atoi(getenv("IDELUCS_INGEST_TIMING")) >= 2 && hipStreamSynchronize((hipStream_t)stream) == hipSuccess) t_drain = now() - t_0;
         fprintf(stderr, "idl_fasta_parse_pack timeline: last thread started %.2f ms, threads finished %.2f .. %.2f, joined %.2f, copies drained %.2f; "
-                        "%d copy calls, %.2f ms of host time in them (sum over threads); bound to node %d\n",
-                b_max, e_min, e_max, t_join, t_drain, ns * 2, snd, bind.node);
+                        "%d copy calls on %zu stream(s), %.2f ms of host time in them (sum over threads); bound to node %d\n",
+                b_max, e_min, e_max, t_join, t_drain, ns, streams.size(), snd, bind.node);
     }
 
     for (int t = 0; t < nt; ++t) {
@@ -1092,10 +1151,11 @@ int idl_fasta_parse_pack(const char *path, uint8_t *codes, uint8_t *mask, int64_
     f->recs.resize(n);
     f->arena_slot.resize(n + 1);
     f->lengths.resize(n);
+    f->mask_sent.resize(n);
     int64_t last_end = 0;
     for (const FastOut &o : outs) if (!o.recs.empty()) last_end = o.slot.back();
     f->arena_slot[n] = last_end;
-    struct Part { int64_t bases = 0, slots = 0, names = 0, lo = INT64_MAX, hi = 0; };
+    struct Part { int64_t bases = 0, slots = 0, names = 0, lo = INT64_MAX, hi = 0, unsent = 0; };
     std::vector<Part> parts((size_t)nt);
     parallel_for(n >= 4096 ? nt : 1, [&](int t0) {
         for (int t = t0; t < nt; t += (n >= 4096 ? nt : 1)) {
@@ -1107,6 +1167,9 @@ int idl_fasta_parse_pack(const char *path, uint8_t *codes, uint8_t *mask, int64_
                 f->recs[at + i] = r;
                 f->arena_slot[at + i] = o.slot[i];
                 f->lengths[at + i] = r.len;
+                const uint8_t ms = i < o.mask_sent.size() ? o.mask_sent[i] : 0;
+                f->mask_sent[at + i] = ms;
+                p.unsent += ms ? 0 : 1;
                 p.bases += r.len; p.slots += (r.len + 63) / 64; p.names += (int64_t)(r.id_e - r.id_b);
                 p.lo = std::min(p.lo, r.len); p.hi = std::max(p.hi, r.len);
             }
@@ -1114,7 +1177,7 @@ int idl_fasta_parse_pack(const char *path, uint8_t *codes, uint8_t *mask, int64_
     });
     int64_t lo = INT64_MAX;
     for (const Part &p : parts) {
-        f->total_bases += p.bases; f->total_slots += p.slots; f->names_bytes += p.names;
+        f->total_bases += p.bases; f->total_slots += p.slots; f->names_bytes += p.names; f->n_mask_unsent += p.unsent;
         lo = std::min(lo, p.lo); f->max_len = std::max(f->max_len, p.hi);
     }
     f->min_len = n ? lo : 0;
@@ -1141,6 +1204,13 @@ int idl_fasta_arena_meta(const idl_fasta *f, int64_t *lengths, int64_t *slot_off
     if (min_len) *min_len = f->min_len;
     if (max_len) *max_len = f->max_len;
     return IDL_OK;
+}
+
+int64_t idl_fasta_arena_mask_flags(const idl_fasta *f, uint8_t *sent)
+{
+    if (!f || f->mask_sent.size() != f->recs.size()) return -1;
+    if (sent && !f->mask_sent.empty()) memcpy(sent, f->mask_sent.data(), f->mask_sent.size());
+    return f->n_mask_unsent;
 }
 
 void idl_fasta_close(idl_fasta *f) { delete f; }

@@ -867,12 +867,15 @@ constexpr int V3_NC = 384;                      // compute threads (6 waves)
 constexpr int V3_MW = 2;                        // memory waves, each holding 1 / V3_MW of a row
 constexpr int V3_NT = V3_NC + 64 * V3_MW;
 
-template <int K, bool DIAG>
+template <int K, bool DIAG, int RL>
 __global__ __launch_bounds__(V3_NT, 8) void vectorise3_kernel(VecArgs a)
 {
-    using W = V3<K>;
-    constexpr int F = W::F, HD = W::HD, NC = V3_NC, RP = (F / 4) / 64 / V3_MW;      // RP: 16-byte pieces of a row per lane of a memory wave
-    static_assert((F / 4) % (64 * V3_MW) == 0 && RP >= 1 && RP <= 16, "a row is held by the memory waves: 4^k in 512..4096");
+    using W = V3<K, RL>;
+    // RP: store instructions per row and memory wave.  RL = 0: a lane holds RP 16-byte pieces of the row (4^k in 512..4096).
+    // RL > 0 (k = 4, the histogram in 2^RL copies): a memory wave adds up the copies of its half of the 256 bins, two bins a lane.
+    constexpr int F = W::F, HD = W::HD, NC = V3_NC, RP = RL ? 1 : (F / 4) / 64 / V3_MW;
+    static_assert(RL ? (F == 64 * 2 * V3_MW && RL >= 2 && RL <= 5) : ((F / 4) % (64 * V3_MW) == 0 && RP >= 1 && RP <= 16),
+                  "a row is held by the memory waves: 4^k in 512..4096, or 256 with the histogram in copies");
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int SC = a.sc_slots, P = a.n_views;
     const int SET = (SC + 1) * 6 + a.ecap;                  // words of one staging set
@@ -889,6 +892,7 @@ __global__ __launch_bounds__(V3_NT, 8) void vectorise3_kernel(VecArgs a)
     const bool mem = mw >= 0;
     const uint32_t iv = (a.init == IDL_INIT_ONE) ? 1u : 0u;
     const bool has_edits = a.edits != nullptr;
+    const uint32_t lo4 = RL ? ((uint32_t)tid & ((1u << RL) - 1u)) << 2 : 0u;      // byte offset of this lane's copy inside a bin's group of copies
 
     // this workgroup's sequences: batches of a.chunk consecutive sequences pulled from a global counter (one returning atomic per
     // batch, issued by a compute wave -- they have no other vector-memory traffic -- three sequences before the batch is needed).
@@ -962,15 +966,36 @@ __global__ __launch_bounds__(V3_NT, 8) void vectorise3_kernel(VecArgs a)
     };
     // ---------------- compute waves
     auto clear_hist = [&]() {
-        for (int i = tid; i < HD / 4; i += NC) *(uint4 *)(hist + i * 4) = make_uint4(iv, iv, iv, iv);
+        if constexpr (RL > 0) {      // the pseudocount sits in copy 0 of every bin
+            for (int i = tid; i < HD / 4; i += NC) *(uint4 *)(hist + i * 4) = make_uint4(((i * 4) & ((1 << RL) - 1)) == 0 ? iv : 0u, 0u, 0u, 0u);
+        } else {
+            for (int i = tid; i < HD / 4; i += NC) *(uint4 *)(hist + i * 4) = make_uint4(iv, iv, iv, iv);
+        }
         if (tid <= V3_MAXV) ctr[tid] = 0;
     };
 
     // ---------------- memory wave: a view's row, in registers between reading the histogram and storing it
     struct Row { uint4 h[RP]; int64_t S, s; int v; };
     auto row_load = [&](Row &rw, int v, int64_t s) {
+        if constexpr (RL > 0) {
+            // bins 2 l, 2 l + 1 of this wave's half: 2 x 2^RL consecutive words = NPC 16-byte pieces.  Lanes sit NPC pieces apart, so
+            // every lane starts at another piece ((j + rot) mod NPC: 16 different slots of the 256-byte bank row in every lane group)
+            constexpr int NPC = (2 << RL) / 4;
+            const uint32_t *base = hist + (((mw * 64 + lane) * 2) << RL);
+            const int rot = (NPC >= 16) ? lane : (lane >> 1);
+            uint32_t s0 = 0u, s1 = 0u;
 #pragma unroll
-        for (int j = 0; j < RP; ++j) rw.h[j] = *(const uint4 *)(hist + (lane + (mw * RP + j) * 64) * 4);
+            for (int j = 0; j < NPC; ++j) {
+                const int pc = (j + rot) & (NPC - 1);
+                const uint4 h = *(const uint4 *)(base + pc * 4);
+                const uint32_t t = h.x + h.y + h.z + h.w;
+                if (pc < NPC / 2) s0 += t; else s1 += t;
+            }
+            rw.h[0] = make_uint4(s0, s1, 0u, 0u);
+        } else {
+#pragma unroll
+            for (int j = 0; j < RP; ++j) rw.h[j] = *(const uint4 *)(hist + (lane + (mw * RP + j) * 64) * 4);
+        }
         rw.S = (int64_t)ctr[0] + (int64_t)ctr[1 + v] + (iv ? (int64_t)F : 0);
         rw.v = v; rw.s = s;
     };
@@ -978,6 +1003,17 @@ __global__ __launch_bounds__(V3_NT, 8) void vectorise3_kernel(VecArgs a)
         if (a.ablate & 1) { if (rw.h[0].x != 0xFFFFFFF0u) return; }
         // one address, formed here (not where the row was loaded: sixteen 64-bit addresses held across the barrier cost 32 registers);
         // the pieces are 1 KB apart
+        if constexpr (RL > 0) {      // two bins a lane: one 8-byte store, the wave's 512 bytes contiguous
+            int l2 = lane * 2;
+            asm volatile("" : "+v"(l2));
+            float *dst2 = (float *)a.out + ((int64_t)rw.v * a.view_stride + rw.s * (int64_t)F) + mw * 128 + l2;
+            if (a.out_kind == IDL_OUT_COUNTS_I32) { *(uint2 *)dst2 = make_uint2(rw.h[0].x, rw.h[0].y); return; }
+            const float Sf = (float)rw.S, rS = 1.0f / Sf;
+            const float c0 = (float)rw.h[0].x, c1 = (float)rw.h[0].y;
+            const float q0 = c0 * rS, q1 = c1 * rS;
+            *(float2 *)dst2 = make_float2(__builtin_fmaf(__builtin_fmaf(-q0, Sf, c0), rS, q0), __builtin_fmaf(__builtin_fmaf(-q1, Sf, c1), rS, q1));
+            return;
+        }
         int l4 = lane * 4;
         asm volatile("" : "+v"(l4));
         float *dst = (float *)a.out + ((int64_t)rw.v * a.view_stride + rw.s * (int64_t)F) + mw * RP * 256 + l4;
@@ -1115,7 +1151,7 @@ __global__ __launch_bounds__(V3_NT, 8) void vectorise3_kernel(VecArgs a)
                         if (d != 0) atomicAdd(&ctr[1 + v], d);
                         if (v == vfirst) {
 #pragma unroll
-                            for (int t = 0; t < K; ++t) W::move(hist, pr[t], 1u);
+                            for (int t = 0; t < K; ++t) W::move(hist, pr[t], 1u, lo4);
                         }
                     }
                 }
@@ -1132,8 +1168,8 @@ __global__ __launch_bounds__(V3_NT, 8) void vectorise3_kernel(VecArgs a)
                     const int v = view_at(q, vi), v2 = view_at(q, vi + 1);
                     const int na = (a.ablate & 4) ? 0 : (int)vt[(1 + v) * V3_VT] * K, pa = (int)vt[(1 + v) * V3_VT + 2];
                     const int nb = (a.ablate & 4) ? 0 : (int)vt[(1 + v2) * V3_VT] * K, pb = (int)vt[(1 + v2) * V3_VT + 2];
-                    for (int x = tid; x < na; x += NC) W::move(hist, list[pa + x], 0xFFFFFFFFu);       // undo view v
-                    for (int x = tid; x < nb; x += NC) W::move(hist, list[pb + x], 1u);                // apply view v2
+                    for (int x = tid; x < na; x += NC) W::move(hist, list[pa + x], 0xFFFFFFFFu, lo4);       // undo view v
+                    for (int x = tid; x < nb; x += NC) W::move(hist, list[pb + x], 1u, lo4);                // apply view v2
                 } else {
                     clear_hist();
                 }
@@ -1176,6 +1212,26 @@ __global__ __launch_bounds__(64) void collapse_kernel(int32_t *counts, int32_t *
     }
 }
 
+// The invalid-mask of records WITHOUT an invalid base is the tail padding their length implies: base b of a 64-base slot sits at bit
+// 31 - (b mod 32) of word b / 32 (host_ingest.cpp: Packer), padding = every base from the record's length on.  One wave per record.
+__global__ __launch_bounds__(256) void mask_from_lengths_kernel(uint2 *mask, const int64_t *slot_off, const int64_t *lengths, const uint8_t *sent, int64_t n)
+{
+    const int lane = threadIdx.x & 63;
+    for (int64_t s = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); s < n; s += (int64_t)gridDim.x * 4) {
+        if (sent != nullptr && sent[s] != 0) continue;
+        const int64_t len = lengths[s], nslots = (len + 63) >> 6, s0 = slot_off[s];
+        for (int64_t i = lane; i < nslots; i += 64) {
+            const int64_t v = len - i * 64;                      // valid bases of this slot: >= 64 but in the last one
+            uint2 m = make_uint2(0u, 0u);
+            if (v < 64) {
+                m.x = v >= 32 ? 0u : (v <= 0 ? 0xFFFFFFFFu : 0xFFFFFFFFu >> (int)v);
+                m.y = v <= 32 ? 0xFFFFFFFFu : 0xFFFFFFFFu >> (int)(v - 32);
+            }
+            mask[s0 + i] = m;
+        }
+    }
+}
+
 // the device words through which v3 hands over to the second pass (redo count, queue head, redo list): one block per (device,
 // stream), allocated on first use and kept -- launches on different streams of a device may be in flight together (a build on one
 // stream, predict_features on another), launches on one stream are ordered
@@ -1191,11 +1247,11 @@ int *redo_counter(hipStream_t st)
     return p;
 }
 
-template <int K>
+template <int K, int RL>
 int launch_vectorise3_k(VecArgs &a, const idl::DeviceInfo &di, hipStream_t st, size_t lds, int per_cu)
 {
     const bool dbg = getenv("IDELUCS_VEC_DBG") != nullptr;
-    const void *fn = dbg ? (const void *)vectorise3_kernel<K, true> : (const void *)vectorise3_kernel<K, false>;
+    const void *fn = dbg ? (const void *)vectorise3_kernel<K, true, RL> : (const void *)vectorise3_kernel<K, false, RL>;
     if (lds > 64 * 1024) IDL_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int64_t grid = (int64_t)di.cus * per_cu;
     if (grid > a.n) grid = a.n;
@@ -1203,8 +1259,8 @@ int launch_vectorise3_k(VecArgs &a, const idl::DeviceInfo &di, hipStream_t st, s
     if (a.redo_count == nullptr) { idl::set_error("cannot allocate the v3 hand-over word"); return IDL_ERR_HIP; }
     IDL_HIP_TRY(hipMemsetAsync(a.redo_count, 0, 2 * sizeof(int), st));      // [0] sequences left to the second pass, [1] head of the sequence queue
     if (dbg) { IDL_HIP_TRY(hipMalloc((void **)&a.dbg, (size_t)grid * 20 * 8)); IDL_HIP_TRY(hipMemset(a.dbg, 0, (size_t)grid * 20 * 8)); }
-    if (dbg) hipLaunchKernelGGL((vectorise3_kernel<K, true>), dim3((unsigned)grid), dim3(V3_NT), lds, st, a);
-    else hipLaunchKernelGGL((vectorise3_kernel<K, false>), dim3((unsigned)grid), dim3(V3_NT), lds, st, a);
+    if (dbg) hipLaunchKernelGGL((vectorise3_kernel<K, true, RL>), dim3((unsigned)grid), dim3(V3_NT), lds, st, a);
+    else hipLaunchKernelGGL((vectorise3_kernel<K, false, RL>), dim3((unsigned)grid), dim3(V3_NT), lds, st, a);
     IDL_HIP_TRY(hipGetLastError());
     if (dbg) {          // diagnostic only: synchronises, prints the mean cycles per sequence of each phase for compute wave 0 and the memory wave
         std::vector<unsigned long long> h((size_t)grid * 20);
@@ -1234,14 +1290,14 @@ int launch_vectorise3_k(VecArgs &a, const idl::DeviceInfo &di, hipStream_t st, s
     return IDL_OK;
 }
 
-// v3 takes the hot shape only: plain k-mer rows (float32 or int32), 4^k >= 1024, <= 8 views, every sequence within one staged
-// super-chunk (the host's length bound says so), fresh histograms.  Everything else stays on v2 / v1.
-template <int K>
-int launch_vectorise3(const VecArgs &a_in, const idl::DeviceInfo &di, hipStream_t st, bool *done)
+// v3 takes the hot shape only: plain k-mer rows (float32 or int32), k = 4..6, <= 8 views, every sequence within one staged
+// super-chunk (the host's length bound says so), fresh histograms.  Everything else stays on v2 / v1.  k = 4 keeps its 1 KB
+// histogram in 2^RL copies (V3<K, RL>): RL = 5 is conflict-free and fits three workgroups per CU at 10 kbp, RL = 4 four.
+template <int K, int RL>
+int launch_vectorise3_rl(const VecArgs &a_in, const idl::DeviceInfo &di, hipStream_t st, bool *done)
 {
-    *done = false;
-    if constexpr (K >= 5 && K <= 6) {
-        constexpr int F = 1 << (2 * K);
+    {
+        constexpr int F = 1 << (2 * K), HW = RL ? (F + 4) << RL : F + 4;
         VecArgs a = a_in;
         int want = 3;
         if (const char *e = getenv("IDELUCS_VEC")) want = atoi(e);
@@ -1253,8 +1309,10 @@ int launch_vectorise3(const VecArgs &a_in, const idl::DeviceInfo &di, hipStream_
         // fits at four workgroups per CU (an edit costs 2 + K words: two staging sets and the list); IDELUCS_V3_EC / _LC override
         int ec = (int)(a.max_len * 35 / 1000) + 64, lc;
         {
-            const int fixed = (F + 4) + 2 * (a.sc_slots + 1) * 6 + 3 * V3_META + 2 * V3_VTAB + 16 + 4;
-            const int fit = ((di.lds_per_cu / 4 - 1024) / 4 - fixed) / (2 + K);
+            const int fixed = HW + 2 * (a.sc_slots + 1) * 6 + 3 * V3_META + 2 * V3_VTAB + 16 + 4;
+            int wgs = 4;                                  // workgroups per CU the tables are sized for: four, or as many as the fixed part + the minimum leaves
+            while (wgs > 2 && ((di.lds_per_cu / wgs - 1024) / 4 - fixed) / (2 + K) < ec) --wgs;
+            const int fit = ((di.lds_per_cu / wgs - 1024) / 4 - fixed) / (2 + K);
             if (fit > ec) ec = fit > 4096 ? 4096 : fit;
         }
         if (const char *e = getenv("IDELUCS_V3_EC")) { const int t = atoi(e); if (t >= 0 && t <= 16384) ec = t; }
@@ -1266,7 +1324,7 @@ int launch_vectorise3(const VecArgs &a_in, const idl::DeviceInfo &di, hipStream_
         a.chunk = 2;
         if (const char *e = getenv("IDELUCS_V3_CHUNK")) { const int t = atoi(e); if (t >= 1 && t <= 4096) a.chunk = t; }
         if (const char *e = getenv("IDELUCS_VEC_ABLATE")) a.ablate = atoi(e);
-        const size_t lds = (size_t)((F + 4) + 2 * ((a.sc_slots + 1) * 6 + ec) + lc + 3 * V3_META + 2 * V3_VTAB + 16 + 4) * 4;
+        const size_t lds = (size_t)(HW + 2 * ((a.sc_slots + 1) * 6 + ec) + lc + 3 * V3_META + 2 * V3_VTAB + 16 + 4) * 4;
         if ((int)lds > di.max_dyn_lds || lds > 80 * 1024) return IDL_OK;                 // (fewer than two workgroups per CU: v2's chunked staging is the better fit)
         // workgroups per CU by LDS, with 1 KB of slack each (measured: five 32 032-byte workgroups do NOT become resident
         // together although 5 x 32 032 < 160 KB and the occupancy query says 5 -- the fifth ran after the others)
@@ -1275,10 +1333,26 @@ int launch_vectorise3(const VecArgs &a_in, const idl::DeviceInfo &di, hipStream_
         if (const char *e = getenv("IDELUCS_WG_PER_CU")) { const int t = atoi(e); if (t >= 1 && t <= 32) per_cu = t; }
         if (per_cu < 1) per_cu = 1;
         if (getenv("IDELUCS_DEBUG"))
-            fprintf(stderr, "[idl] vectorise k=%d v3 lds=%zu B (staged slots %d, edits %d, pairs %d) -> %d workgroups/CU\n", K, lds, a.sc_slots, ec, lc, per_cu);
-        const int rc = launch_vectorise3_k<K>(a, di, st, lds, per_cu);
+            fprintf(stderr, "[idl] vectorise k=%d v3 lds=%zu B (histogram copies %d, staged slots %d, edits %d, pairs %d) -> %d workgroups/CU\n", K, lds, 1 << RL, a.sc_slots, ec, lc, per_cu);
+        const int rc = launch_vectorise3_k<K, RL>(a, di, st, lds, per_cu);
         if (rc != IDL_OK) return rc;
         *done = true;
+    }
+    return IDL_OK;
+}
+
+template <int K>
+int launch_vectorise3(const VecArgs &a_in, const idl::DeviceInfo &di, hipStream_t st, bool *done)
+{
+    *done = false;
+    if constexpr (K == 4) {
+        int rl = 5;
+        if (const char *e = getenv("IDELUCS_V3_COPIES")) { const int t = atoi(e); rl = t == 16 ? 4 : (t == 8 ? 3 : 5); }
+        if (rl == 5) return launch_vectorise3_rl<K, 5>(a_in, di, st, done);
+        if (rl == 4) return launch_vectorise3_rl<K, 4>(a_in, di, st, done);
+        return launch_vectorise3_rl<K, 3>(a_in, di, st, done);
+    } else if constexpr (K >= 5 && K <= 6) {
+        return launch_vectorise3_rl<K, 0>(a_in, di, st, done);
     }
     return IDL_OK;
 }
@@ -1450,6 +1524,20 @@ int idl_kmer_rev_comp(int32_t *counts, int k, int32_t *out)
     IDL_HIP_TRY(hipGetLastError());
     IDL_HIP_TRY(hipMemcpy(counts, d_counts.p, (size_t)F * 4, hipMemcpyDeviceToHost));
     IDL_HIP_TRY(hipMemcpy(out, d_out.p, (size_t)C * 4, hipMemcpyDeviceToHost));
+    return IDL_OK;
+}
+
+int idl_mask_from_lengths(void *mask, const int64_t *slot_off, const int64_t *lengths, const uint8_t *sent, int64_t n, void *stream)
+{
+    IDL_REQUIRE(n >= 0 && (n == 0 || (mask && slot_off && lengths)), "mask_from_lengths: NULL buffer");
+    if (n == 0) return IDL_OK;
+    idl::DeviceInfo di;
+    const int rc = idl::device_info(&di);
+    if (rc != IDL_OK) return rc;
+    int64_t grid = (n + 3) / 4;
+    if (grid > (int64_t)di.cus * 32) grid = (int64_t)di.cus * 32;
+    hipLaunchKernelGGL(mask_from_lengths_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, (uint2 *)mask, slot_off, lengths, sent, n);
+    IDL_HIP_TRY(hipGetLastError());
     return IDL_OK;
 }
 

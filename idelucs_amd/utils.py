@@ -769,12 +769,17 @@ class _OnePassInput:
         n_rec = ctypes.c_int64()
         _lib.check(_L.idl_fasta_sizes(h, ctypes.byref(n_rec), None, None, None))
         n = n_rec.value
-        if _ARENAS["small"].numel() < 2 * n + 1:
-            _ARENAS["small"] = torch.empty(2 * n + 1 + 4096, dtype=torch.int64, pin_memory=True)
+        words = 2 * n + 1 + (n + 7) // 8                            # lengths, slots, then one byte per record: its mask was copied
+        if _ARENAS["small"].numel() < words:
+            _ARENAS["small"] = torch.empty(words + 4096, dtype=torch.int64, pin_memory=True)
         stage = _ARENAS["small"]
         lo_len, hi_len = ctypes.c_int64(), ctypes.c_int64()
         _lib.check(_L.idl_fasta_arena_meta(h, _ptr(stage), ctypes.c_void_p(stage.data_ptr() + 8 * n), ctypes.byref(lo_len), ctypes.byref(hi_len)))
-        both = stage[:2 * n + 1].to(device, non_blocking=True)
+        unsent = int(_L.idl_fasta_arena_mask_flags(h, ctypes.c_void_p(stage.data_ptr() + 8 * (2 * n + 1))))
+        both = stage[:words].to(device, non_blocking=True)
+        if unsent > 0:       # pieces without an N travelled without their invalid-mask: it is the tail padding the lengths imply
+            _lib.check(_L.idl_mask_from_lengths(_ptr(mask), ctypes.c_void_p(both.data_ptr() + 8 * n), _ptr(both),
+                                                ctypes.c_void_p(both.data_ptr() + 8 * (2 * n + 1)), n, _stream_ptr()))
         q.append(time.perf_counter())
         meta = stage[:2 * n + 1].numpy().copy()                     # (the staging is overwritten by the next file)
         self.ff = FastaFile.from_handle(h, arena=True, meta=(meta[:n], meta[n:]))
@@ -782,7 +787,7 @@ class _OnePassInput:
         self.n = n
         self.max_len, self.min_len = hi_len.value, lo_len.value
         self.total_len = ff.total_bases
-        self.lengths, self.slot_off = both[:n], both[n:]
+        self.lengths, self.slot_off = both[:n], both[n:2 * n + 1]
         self.codes, self.mask = codes, mask
         self._hold = (hc, hm, copy)
         ev_small, ev_copy = torch.cuda.Event(), torch.cuda.Event()

@@ -388,7 +388,8 @@ def test_cfg2_full_size_store_properties(gpu):
     assert int(counts[P - 1, n - 1].sum()) >= L - (k - 1) - 20 * k
 
 
-def test_full_size_v1_v2_v3_kernels_agree_bitwise(gpu, monkeypatch):
+@pytest.mark.parametrize("k", [6, 5, 4])
+def test_full_size_v1_v2_v3_kernels_agree_bitwise(gpu, monkeypatch, k):
     """cfg2-shaped batch (20 000 x 10 kbp, 4 views, device-drawn mimic edits): the single-pass kernel (v1: full recount per
     view, edits applied to a staged copy), the delta-view kernel (v2: one count + XOR-mask window moves, per-view pair passes)
     and the pipelined kernel (v3, the default here: LDS-DMA staging one sequence ahead, one pair pass for all views, recorded
@@ -406,18 +407,24 @@ def test_full_size_v1_v2_v3_kernels_agree_bitwise(gpu, monkeypatch):
     outs = {}
     for which in ("3", "2", "1"):
         monkeypatch.setenv("IDELUCS_VEC", which)
-        outs[which] = (U._vectorise(din, 6, _lib.MODE_KMER, _lib.INIT_ONE, _lib.OUT_FREQ_F32, 4, edits, edit_off).clone(),
-                       U._vectorise(din, 6, _lib.MODE_KMER, _lib.INIT_ZERO, _lib.OUT_COUNTS_I32, 4, edits, edit_off).clone())
+        outs[which] = (U._vectorise(din, k, _lib.MODE_KMER, _lib.INIT_ONE, _lib.OUT_FREQ_F32, 4, edits, edit_off).clone(),
+                       U._vectorise(din, k, _lib.MODE_KMER, _lib.INIT_ZERO, _lib.OUT_COUNTS_I32, 4, edits, edit_off).clone())
     assert torch.equal(outs["1"][1], outs["2"][1]) and torch.equal(outs["1"][1], outs["3"][1])
     assert torch.equal(outs["1"][0], outs["2"][0]) and torch.equal(outs["1"][0], outs["3"][0])
+    if k == 4:      # round 5: the 4^4-bin histogram lives in 32 copies (lane l adds to copy l mod 32); 16 and 8 copies: the same rows
+        for copies in ("16", "8"):
+            monkeypatch.setenv("IDELUCS_VEC", "3"); monkeypatch.setenv("IDELUCS_V3_COPIES", copies)
+            assert torch.equal(U._vectorise(din, k, _lib.MODE_KMER, _lib.INIT_ONE, _lib.OUT_FREQ_F32, 4, edits, edit_off), outs["1"][0]), copies
+            assert torch.equal(U._vectorise(din, k, _lib.MODE_KMER, _lib.INIT_ZERO, _lib.OUT_COUNTS_I32, 4, edits, edit_off), outs["1"][1]), copies
+        monkeypatch.delenv("IDELUCS_V3_COPIES")
     # sequences whose edits / pairs do not fit v3's LDS tables are left to a second pass on the v2 kernel: same bits
     # (tables for no / half / nearly all of the sequences: the second pass scans, or walks the short list v3 left it)
     for ec, lc in (("0", "0"), ("320", "1800"), ("512", "1920"), ("448", "2304")):
         monkeypatch.setenv("IDELUCS_VEC", "3"); monkeypatch.setenv("IDELUCS_V3_EC", ec); monkeypatch.setenv("IDELUCS_V3_LC", lc)
-        assert torch.equal(U._vectorise(din, 6, _lib.MODE_KMER, _lib.INIT_ONE, _lib.OUT_FREQ_F32, 4, edits, edit_off), outs["1"][0]), (ec, lc)
+        assert torch.equal(U._vectorise(din, k, _lib.MODE_KMER, _lib.INIT_ONE, _lib.OUT_FREQ_F32, 4, edits, edit_off), outs["1"][0]), (ec, lc)
     monkeypatch.delenv("IDELUCS_V3_EC"); monkeypatch.delenv("IDELUCS_V3_LC")
     c = outs["2"][1]
-    assert not torch.equal(c[0], c[1]) and int(c[3].sum(1).min()) >= 10000 - 5 - 20 * 6       # the views differ; Random_N kills <= 20*k windows
+    assert not torch.equal(c[0], c[1]) and int(c[3].sum(1).min()) >= 10000 - (k - 1) - 20 * k       # the views differ; Random_N kills <= 20*k windows
 
 
 def test_kernel_projection_matches_numpy(gpu):
@@ -656,3 +663,71 @@ def test_predict_inputs_from_counts_equal_the_float64_route(tmp_path, k):
     finally:
         del os.environ["IDELUCS_PREDICT_COUNTS"]
     assert torch.equal(x, x_old)
+
+
+@pytest.mark.parametrize("streams", ["1", "3"])
+def test_one_pass_ingest_device_image_with_sparse_mask(gpu, tmp_path, monkeypatch, streams):
+    """Round 5: the one-pass reader copies a piece's invalid-mask only when a record of the piece holds an N; the masks of the
+    other records are written on the device from their lengths (idl_mask_from_lengths).  The device image -- packed bases and
+    mask of every record, at its arena slot -- is the general reader's, byte for byte, with one copy stream and with several;
+    and the feature store built from it is the one built with every mask copied."""
+    import torch
+    from idelucs_amd import _lib, utils as U
+    monkeypatch.setenv("IDELUCS_PAR_MIN", "0")
+    monkeypatch.setenv("IDELUCS_THREADS", "6")
+    monkeypatch.setenv("IDELUCS_COPY_STREAMS", streams)
+    rng = np.random.default_rng(5)
+    fn = str(tmp_path / "mix.fas")
+    with open(fn, "wb") as f:                      # long clean stretches (pieces without an N), a few records with N runs / IUPAC, short and empty ones
+        for i in range(6000):
+            L = int(rng.choice([0, 1, 63, 64, 65, 700, 1000, 1013]))
+            s = rng.choice(np.frombuffer(b"ACGT", np.uint8), size=L)
+            if i % 997 == 5 and L > 10:
+                s[3:9] = ord("N"); s[-1] = ord("r")
+            f.write(b">r%d\n" % i + s.tobytes() + b"\n")
+    dev = torch.device("cuda")
+    whole = U.FastaFile(fn)
+    images = {}
+    for sparse in ("1", "0"):
+        monkeypatch.setenv("IDELUCS_SPARSE_MASK", sparse)
+        U.release_ingest_buffers()
+        din = U._OnePassInput.create(fn, dev)
+        assert din is not None
+        din.fill()
+        torch.cuda.synchronize()
+        codes, mask, slot = din.codes.cpu().numpy(), din.mask.cpu().numpy(), din.ff.slot_off
+        assert np.array_equal(din.ff.lengths, whole.lengths) and din.ff.names == whole.names
+        for i in range(whole.n):
+            a, b = whole.slot_off[i], whole.slot_off[i + 1]
+            s0 = int(slot[i])
+            assert np.array_equal(codes[s0 * 16:(s0 + b - a) * 16], whole.codes[a * 16:b * 16]), (sparse, i)
+            assert np.array_equal(mask[s0 * 8:(s0 + b - a) * 8], whole.mask[a * 8:b * 8]), (sparse, i)
+        images[sparse] = U._vectorise(din, 4, _lib.MODE_KMER, _lib.INIT_ONE, _lib.OUT_FREQ_F32).clone()
+        din.ff.close()
+    assert torch.equal(images["0"], images["1"])
+    ref = U._vectorise(U._DeviceInput(whole, dev), 4, _lib.MODE_KMER, _lib.INIT_ONE, _lib.OUT_FREQ_F32)
+    assert torch.equal(images["1"], ref)
+    U.release_ingest_buffers()
+
+
+def test_mask_from_lengths_is_the_packers_padding(gpu):
+    """idl_mask_from_lengths == the host packer's mask on records without an invalid base, for every tail length 0..130, and it
+    leaves flagged records alone."""
+    import torch
+    from idelucs_amd import _lib, utils as U
+    rng = np.random.default_rng(9)
+    seqs = [rng.choice(np.frombuffer(b"ACGT", np.uint8), size=L) for L in list(range(0, 131)) + [1000, 4096, 10000]]
+    ff = _pack_batch(seqs)
+    dev = torch.device("cuda")
+    din = U._DeviceInput(ff, dev)
+    out = torch.full_like(din.mask, 0x5A)
+    sent = torch.zeros(ff.n, dtype=torch.uint8, device=dev)
+    sent[7] = 1; sent[100] = 1
+    _lib.check(_lib.lib.idl_mask_from_lengths(U._ptr(out), U._ptr(din.slot_off), U._ptr(din.lengths), U._ptr(sent), ff.n, U._stream_ptr()))
+    got, want = out.cpu().numpy(), ff.mask
+    for i in range(ff.n):
+        a, b = int(ff.slot_off[i]) * 8, int(ff.slot_off[i + 1]) * 8
+        if i in (7, 100):
+            assert np.all(got[a:b] == 0x5A)
+        else:
+            assert np.array_equal(got[a:b], want[a:b]), (i, len(seqs[i]))

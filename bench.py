@@ -294,6 +294,111 @@ def fixed_job_8_voters(din, args, dev, rank, world, passes=3):
             "stage_ms": st, "backend": dist.get_backend() if dist.is_initialized() else None, "validation": v}
 
 
+def k_sweep(din, args, dev, ks=(4, 5), reps=6):
+    """BASELINE configs[3] (cfg4) names the k = 4 / k = 5 path: the vectorise stage alone at this workload's size for those k,
+    with its own roofline (B_vec = ceil(L / 4) + P * 4^k * 4 bytes a sequence -- at k = 4 the packed bases are a
+    third of it and the kernel is bound by its LDS atomics, not by HBM: DESIGN 4.1).  HIP events on the launch stream."""
+    from idelucs_amd import _lib, utils as U
+    specs = [t.spec() for t in U.mimic_transforms(args.n_mimics)]
+    P = len(specs)
+    edits, edit_off = U._philox_edits(din, specs, 4242)
+    out = {}
+    for k in ks:
+        F = 4 ** k
+        feats = torch.empty((P, din.n, F), dtype=torch.float32, device=dev)
+        run = lambda: U._vectorise(din, k, _lib.MODE_KMER, _lib.INIT_ONE, _lib.OUT_FREQ_F32, P, edits, edit_off, feats)
+        run(); torch.cuda.synchronize()
+        ts = []
+        for _ in range(reps):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record(); run(); e.record(); torch.cuda.synchronize()
+            ts.append(s.elapsed_time(e))
+        ms = sum(ts) / len(ts)
+        b_vec = (args.len + 3) // 4 + P * F * 4
+        ach = din.n * b_vec / (ms * 1e-3) / 1e9
+        rows = torch.arange(0, din.n, max(din.n // 2048, 1), device=dev)
+        sums = feats[:, rows].double().sum(2)
+        assert torch.allclose(sums, torch.ones_like(sums), atol=1e-6) and not torch.equal(feats[0, rows], feats[1, rows])
+        out[str(k)] = {"kernel": "vectorise3_kernel<%d>" % k, "bound": "hbm", "ms_per_launch": ms, "ms_min": min(ts),
+                       "bytes_per_seq_algorithmic": b_vec, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                       "sequences_per_sec_stage": din.n / (ms * 1e-3), "rows_checked": int(rows.numel())}
+        del feats
+    return out
+
+
+def lanes_epoch_ms(din, args, dev, rank, world, voters):
+    """Per-voter epoch time with `voters` voters batched in lockstep on this GPU (one warm-up pass + one timed): the
+    lanes-dependence the scaling prediction needs (8 / N voters per rank at N ranks)."""
+    import copy
+    a = copy.copy(args)
+    a.voters, a.exchange = voters, False
+    hp = HotPath(din, a, dev, rank, world)
+    hp.step(seed=2000)
+    hp.step(seed=2001)
+    torch.cuda.synchronize()
+    ms = hp.mean_ms("epoch", 1)
+    del hp
+    torch.cuda.empty_cache()
+    return ms
+
+
+def predicted_fixed_job(din, args, dev, rank, world, st8, epoch1_ms):
+    """What the 1/2/4/8 curve of the FIXED 8-voter job (cfg3) should look like, from this GPU's own stage times:
+    per-rank wall at N ranks = sites + vectorise + scaler fit + (8/N) x epoch(lanes = 8/N) + predict inputs + (8/N) x predict +
+    all-gather.  Every rank vectorises the whole input; the voters of a rank train in lockstep, and a voter-epoch costs less in
+    a batch of 8 than alone (the latency-bound launches are shared) -- so the curve is sub-linear by construction, before any
+    communication: anything BELOW this prediction is communication or host contention."""
+    per_lanes = {8: st8["epoch"], 1: epoch1_ms}
+    for v in (4, 2):
+        per_lanes[v] = lanes_epoch_ms(din, args, dev, rank, world, v)
+    fixed = st8["edits"] + st8["vectorise"] + st8["stats"] + st8.get("predict_inputs", 0.0) + st8.get("exchange", 0.0)
+    out = {"epoch_ms_per_voter_by_lanes": {str(k): per_lanes[k] for k in sorted(per_lanes)}, "fixed_ms_per_rank": fixed,
+           "predict_ms_per_voter": st8.get("predict", 0.0)}
+    base = None
+    for n in (1, 2, 4, 8):
+        v = 8 // n
+        wall = fixed + v * per_lanes[v] + v * st8.get("predict", 0.0)
+        val = args.n * 8 / (wall * 1e-3)
+        base = base or val
+        out[str(n)] = {"ms_per_pass": wall, "value": val, "speedup_vs_1": val / base}
+    out["note"] = ("value = N_seq x 8 voters / predicted per-rank wall; %.1fx at N = 8 is the EXPECTED speed-up (not 8x): one GPU trains its 8 "
+                   "voters in lockstep at %.1f ms a voter-epoch, a lone voter takes %.1f" % (out["8"]["speedup_vs_1"], per_lanes[8], per_lanes[1]))
+    return out
+
+
+def cfg5_one_gpu(args, dev, rank, world, passes=2):
+    """BASELINE configs[4] (cfg5) on this one GPU under the driver's clock: 10^6 x 5 kbp, 200 output units, one
+    voter: sites + vectorise into the 65.5 GB store + scaler fit + a 5 860-step epoch + predict inputs + latent [10^6, 64] through
+    the process group.  One warm-up pass, then `passes` timed."""
+    import copy
+    a = copy.copy(args)
+    a.workload, a.n, a.len, a.n_clusters, a.voters, a.exchange = "cfg5", 1_000_000, 5_000, 200, 1, True
+    din = synth_packed(a.n, a.len, dev, seed=54321)
+    hp = HotPath(din, a, dev, rank, world)
+    hp.step(seed=3000)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(passes):
+        hp.step(seed=3001 + i)
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0) / passes
+    assert not bool(hp.edit_overflow.item())
+    v = hp.validate()
+    assert tuple(hp.latent.shape) == (a.n, 64) and bool(torch.isfinite(hp.latent).all())
+    v.update(latent_shape=list(hp.latent.shape), latent_row_norm_max=float(hp.latent.norm(dim=1).max().item()))
+    st = {k: hp.mean_ms(k, 1) for k in hp.ev if hp.ev[k]}
+    F = hp.F
+    b_vec = (a.len + 3) // 4 + hp.P * F * 4
+    out = {"job": "cfg5: 10^6 x 5 kbp, 200 output units, 1 voter x 1 epoch (5 860 steps) + sharded predict + latent all-gather, all on this GPU",
+           "value": a.n / (ms * 1e-3), "unit": "sequences/sec", "ms_per_pass": ms, "passes": passes, "stage_ms": st,
+           "roofline_vectorise": {"bound": "hbm", "achieved": a.n * b_vec / (st["vectorise"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": a.n * b_vec / (st["vectorise"] * 1e-3) / 1e9 / HBM_PEAK_GBS, "bytes_per_seq_algorithmic": b_vec},
+           "feature_store_gb": hp.feats.numel() * 4 / 1e9, "validation": v}
+    del hp, din
+    torch.cuda.empty_cache()
+    return out
+
+
 def pmc_traffic_gb():
     """HBM traffic of one vectorise launch at cfg2, GB, from the committed rocprofv3 PMC passes (profiles/, WRITE_SIZE exact
     for 16-B stores, FETCH_SIZE doubled per MI355X_MICROARCH.md: DESIGN.md 4.1); None when the profile is not present."""
@@ -363,7 +468,8 @@ def cpu_baseline(args):
     xt = torch.from_numpy(x)
     n_steps = (xt.shape[0] + args.batch_sz - 1) // args.batch_sz
 
-    def epoch(nthreads, max_steps):
+    def epoch(nthreads, max_steps, skip=0):
+        """-> (seconds per epoch scaled from the timed steps, timed steps); the first `skip` steps run untimed (thread-pool spin-up)"""
         torch.set_num_threads(nthreads)
         torch.manual_seed(0)
         net = NetLinear(4 ** k, args.n_clusters)
@@ -374,10 +480,12 @@ def cpu_baseline(args):
         net.train()
         perm = torch.randperm(xt.shape[0])
         t1 = time.perf_counter()
-        done = 0
+        done = -skip
         for i in range(0, xt.shape[0], args.batch_sz):
             if done >= max_steps:
                 break
+            if done == 0:
+                t1 = time.perf_counter()
             idx = perm[i:i + args.batch_sz]
             opt.zero_grad()
             z1, h1 = net(xt[idx, 0]); z2, h2 = net(xt[idx, 1])
@@ -388,7 +496,7 @@ def cpu_baseline(args):
 
     t_ep, _ = epoch(threads, n_steps)
     if ref_threads != threads:
-        t_ep_ref, steps_ref = epoch(ref_threads, max(2, min(n_steps, int(args.cpu_ref_steps))))
+        t_ep_ref, steps_ref = epoch(ref_threads, max(1, min(n_steps - 1, int(args.cpu_ref_steps))), skip=1)
     else:
         t_ep_ref, steps_ref = t_ep, n_steps
     cal = cpu_calibration()
@@ -512,9 +620,12 @@ def main():
                     help="voters of the job (default: 1 on one GPU = cfg2; 8 on several GPUs = cfg3's fixed job)")
     ap.add_argument("--with-predict", dest="with_predict", type=int, default=None,
                     help="1: predict + all-gather inside the timed region (default: 0 at N=1 with one voter = BASELINE.md's region; 1 otherwise)")
-    ap.add_argument("--cpu-sample", dest="cpu_sample", type=int, default=24000)
-    ap.add_argument("--cpu-ref-steps", dest="cpu_ref_steps", type=int, default=8,
-                    help="optimizer steps timed with the reference's cpu_count()-2 torch threads (scaled to the epoch)")
+    ap.add_argument("--cpu-sample", dest="cpu_sample", type=int, default=12000)
+    ap.add_argument("--cpu-ref-steps", dest="cpu_ref_steps", type=int, default=2,
+                    help="optimizer steps timed (after one untimed step) with the reference's cpu_count()-2 torch threads, scaled to the epoch")
+    ap.add_argument("--no-k-sweep", dest="k_sweep", action="store_false", help="skip the k = 4 / k = 5 vectorise-stage rooflines (cfg4)")
+    ap.add_argument("--no-cfg5", dest="cfg5_leg", action="store_false", help="skip the cfg5 job (10^6 x 5 kbp, 65.5 GB store) the default N = 1 run adds")
+    ap.add_argument("--no-prediction", dest="prediction", action="store_false", help="skip the 2- and 4-lane passes behind predicted_fixed_job")
     ap.add_argument("--no-cpu-baseline", dest="cpu_base", action="store_false")
     ap.add_argument("--no-e2e", dest="e2e", action="store_false")
     ap.add_argument("--no-fixed-job", dest="fixed_job", action="store_false",
@@ -684,6 +795,10 @@ def main():
                                "flop_per_seq_executed": f_exec, "achieved_executed": ach_exec, "frac_executed": ach_exec / MFMA_F32_PEAK_TFLOPS,
                                "note": "algorithmic = SURVEY 8(d) (3 x forward for every layer); executed = without the input gradient of "
                                        "layer 1, which is not computed"},
+            "roofline_dominant": "roofline_epoch" if t_ep * len(hp.my_voters) > 0.5 * ms_step else "roofline",
+            "roofline_dominant_note": ("`roofline` is the north_star's named kernel (the hand-written HBM-bound vectoriser); the epoch is "
+                                       "%.0f %% of the timed step and its own object, roofline_epoch, is the one that prices the step"
+                                       % (100.0 * t_ep * len(hp.my_voters) / ms_step)),
             "stage_ms": {k: hp.mean_ms(k, args.warmup) for k in hp.ev if hp.ev[k]},
             "validation": validation,
         }
@@ -701,6 +816,14 @@ def main():
                 hp.model.store = None
             torch.cuda.empty_cache()
             out["fixed_job_8_voters"] = fixed_job_8_voters(din, args, dev, rank, world)
+            if args.prediction:
+                out["predicted_fixed_job"] = predicted_fixed_job(din, args, dev, rank, world, out["fixed_job_8_voters"]["stage_ms"], t_ep)
+        if world == 1 and args.k_sweep and not cfg5 and V == 1:
+            out["k_sweep"] = k_sweep(din, args, dev)
+        if world == 1 and args.cfg5_leg and not cfg5 and V == 1 and not args.exchange and args.fixed_job:
+            del din, hp
+            torch.cuda.empty_cache()
+            out["cfg5_one_gpu"] = cfg5_one_gpu(args, dev, rank, world)
         if world == 1 and args.cpu_base:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out))

@@ -325,8 +325,11 @@ public:
         std::lock_guard<std::mutex> one_job(job_mu_);
         std::function<void(int)> f = [&fn](int t) { fn(t); };
         cpu_set_t before;
+        // the caller, for the length of the job: the node's whole set -- it usually runs there already, so nothing migrates (bound to
+        // one core like the workers it started its share 1.3 ms late: sched_setaffinity away from the current CPU waits for the
+        // migration thread)
         const bool rebind = bind != nullptr && bind->on && sched_getaffinity(0, sizeof(before), &before) == 0 &&
-                            sched_setaffinity(0, sizeof(cpu_set_t), &bind->of(0)) == 0;       // the caller, for the length of the job
+                            sched_setaffinity(0, sizeof(cpu_set_t), &bind->set) == 0;
         {
             std::unique_lock<std::mutex> lk(mu_);
             while ((int)th_.size() < nt - 1) {
@@ -394,7 +397,7 @@ void parallel_for(int nt, F &&fn, const CpuBind *bind = nullptr)       // fn(thr
     // IDELUCS_READER_POOL=0: a thread per call and index (round 4's form, kept for A/B runs); new threads inherit the caller's CPUs
     cpu_set_t before;
     const bool rebind = bind != nullptr && bind->on && sched_getaffinity(0, sizeof(before), &before) == 0 &&
-                        sched_setaffinity(0, sizeof(cpu_set_t), &bind->of(0)) == 0;
+                        sched_setaffinity(0, sizeof(cpu_set_t), &bind->set) == 0;
     std::vector<std::thread> th;
     for (int t = 1; t < nt; ++t) th.emplace_back([&fn, t, bind, rebind]() { if (rebind) (void)sched_setaffinity(0, sizeof(cpu_set_t), &bind->of(t)); fn(t); });
     fn(0);

@@ -755,11 +755,16 @@ __device__ __forceinline__ void vm_wait_at_most(int younger)
 // would allow 16).  With bin b of copy c at word b * 2^RL + c and lane l adding to copy l mod 2^RL, the 32 lanes of a group hit
 // 32 different banks (RL = 5; two lanes per bank at RL = 4) whatever the bins are -- SURVEY section 7's "per-wave private
 // sub-histograms" taken to the lane.  The copies are added up when a memory wave reads a row out (integer sums: order-free, and a
-// window may leave through another copy than it entered by -- undo / apply lists -- since only the sum is ever read).
+// window may leave through another copy than it entered by, since only the sum is ever read).  Only the COUNT goes to the copies
+// (10 000 of a sequence's ~15 000 atomics): behind it the compute waves add the copies up into one plain 4^k-bin histogram -- a
+// thread per bin, the copies zeroed on the way -- and the views (undo / apply lists, row reads) live there as they do for k >= 5.
+// (The first form kept the views in the copies and let the two memory waves add them up per row: 16 ds_read_b128 per lane and
+// view against the other workgroups' atomics, 5.5 k cycles a view -- 1.18 ms per launch with 32 copies against 0.74 with 8.)
 template <int K, int RL = 0>
 struct V3 {
     using T = V2<K, false>;
-    static constexpr int F = T::F, HD = RL ? (F + 4) << RL : T::HD;       // histogram words: F bins + 4 garbage bins (x copies)
+    static constexpr int F = T::F, HC = RL ? (F + 4) << RL : 0;           // words of the copies (F bins + 4 garbage bins each)
+    static constexpr int HD = HC + T::HD;                                  // ... followed by the histogram proper: F bins + 4 garbage bins
     static constexpr uint32_t KM = T::KM, VM = T::VM;
     static_assert(RL == 0 || (F + 4) * 4 < 65536, "bin byte offsets travel as 16 bits");
     // byte offset of bin (given as its byte offset in ONE copy) in the copy of the lane whose offset is lo = (lane mod 2^RL) * 4
@@ -812,10 +817,36 @@ struct V3 {
     }
 
     // one list entry: the window leaves the bin at byte offset (e & 0xFFFF) and enters the one at (e >> 16) (sign = 1), or back
-    static __device__ __forceinline__ void move(uint32_t *hist, uint32_t e, uint32_t sign, uint32_t lo = 0u)
+    static __device__ __forceinline__ void move(uint32_t *hist, uint32_t e, uint32_t sign)
     {
-        atomicAdd((uint32_t *)((char *)hist + at(e & 0xFFFFu, lo)), 0u - sign);
-        atomicAdd((uint32_t *)((char *)hist + at(e >> 16, lo)), sign);
+        atomicAdd((uint32_t *)((char *)hist + (e & 0xFFFFu)), 0u - sign);
+        atomicAdd((uint32_t *)((char *)hist + (e >> 16)), sign);
+    }
+    // ... into the copies (while the sequence is being counted): this lane's copy
+    static __device__ __forceinline__ void move_copy(uint32_t *copies, uint32_t e, uint32_t sign, uint32_t lo)
+    {
+        atomicAdd((uint32_t *)((char *)copies + at(e & 0xFFFFu, lo)), 0u - sign);
+        atomicAdd((uint32_t *)((char *)copies + at(e >> 16, lo)), sign);
+    }
+    // bin `b` of the histogram proper = pseudocount + the sum of its copies, which are zeroed (RL > 0; a thread per bin).  The 2^RL
+    // copies of a bin are NPB 16-byte pieces; LPR lanes share a 256-byte bank row, so lane l starts at piece l / LPR: every
+    // ds_read_b128 lane group covers 16 different slots
+    static __device__ __forceinline__ void fold_copies(uint32_t *copies, uint32_t *hist, int b, uint32_t iv)
+    {
+        if constexpr (RL > 0) {
+            constexpr int NPB = (1 << RL) / 4, LPR = 64 >> RL;
+            uint32_t *base = copies + ((uint32_t)b << RL);
+            const int rot = (b & 63) / (LPR > 0 ? LPR : 1);
+            uint32_t sum = iv;
+#pragma unroll
+            for (int j = 0; j < NPB; ++j) {
+                const int pc = (j + rot) & (NPB - 1);
+                const uint4 h = *(const uint4 *)(base + pc * 4);
+                sum += (h.x + h.y) + (h.z + h.w);
+                *(uint4 *)(base + pc * 4) = make_uint4(0u, 0u, 0u, 0u);
+            }
+            hist[b] = sum;
+        }
     }
 
     // every window ending in the staged sequence (v2's count_all without its barrier); returns this thread's valid windows
@@ -871,16 +902,18 @@ template <int K, bool DIAG, int RL>
 __global__ __launch_bounds__(V3_NT, 8) void vectorise3_kernel(VecArgs a)
 {
     using W = V3<K, RL>;
-    // RP: store instructions per row and memory wave.  RL = 0: a lane holds RP 16-byte pieces of the row (4^k in 512..4096).
-    // RL > 0 (k = 4, the histogram in 2^RL copies): a memory wave adds up the copies of its half of the 256 bins, two bins a lane.
-    constexpr int F = W::F, HD = W::HD, NC = V3_NC, RP = RL ? 1 : (F / 4) / 64 / V3_MW;
-    static_assert(RL ? (F == 64 * 2 * V3_MW && RL >= 2 && RL <= 5) : ((F / 4) % (64 * V3_MW) == 0 && RP >= 1 && RP <= 16),
-                  "a row is held by the memory waves: 4^k in 512..4096, or 256 with the histogram in copies");
+    // RP: store instructions per row and memory wave: a lane holds RP 16-byte pieces of the row.  4^k in 512..4096: each memory wave
+    // its part of every row.  4^k = 256 (k = 4): a row is ONE wave's 16 bytes a lane, and the memory waves take the views in turn.
+    constexpr int F = W::F, HD = W::HD, HC = W::HC, NC = V3_NC, RP = (F == 256) ? 1 : (F / 4) / 64 / V3_MW;
+    constexpr bool TURNS = F == 256;
+    static_assert(TURNS || ((F / 4) % (64 * V3_MW) == 0 && RP >= 1 && RP <= 16), "a row is held by the memory waves: 4^k in 256..4096");
+    static_assert(RL == 0 || (RL >= 2 && RL <= 5 && F <= NC), "the copies are folded by a thread per bin");
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int SC = a.sc_slots, P = a.n_views;
     const int SET = (SC + 1) * 6 + a.ecap;                  // words of one staging set
-    uint32_t *hist = lds;                                   // F bins + 4 garbage bins
-    uint32_t *sets = hist + HD;                             // two staging sets (sequence it lives in set it & 1), each:
+    uint32_t *copies = lds;                                 // RL > 0: 2^RL copies of (F bins + 4 garbage bins), the COUNT's target
+    uint32_t *hist = lds + HC;                              // F bins + 4 garbage bins
+    uint32_t *sets = lds + HD;                              // two staging sets (sequence it lives in set it & 1), each:
     //   cod  (SC + 1) slots x 4 words, slot 0 = halo (zeros) | msk  (SC + 1) slots x 2 words, slot 0 = halo (all invalid) | edl  a.ecap edits of all views
     uint32_t *list = sets + 2 * SET;                        // a.lcap pairs: old bin | new bin << 16
     uint32_t *meta = list + a.lcap;                         // ring of 3 entries
@@ -966,36 +999,16 @@ __global__ __launch_bounds__(V3_NT, 8) void vectorise3_kernel(VecArgs a)
     };
     // ---------------- compute waves
     auto clear_hist = [&]() {
-        if constexpr (RL > 0) {      // the pseudocount sits in copy 0 of every bin
-            for (int i = tid; i < HD / 4; i += NC) *(uint4 *)(hist + i * 4) = make_uint4(((i * 4) & ((1 << RL) - 1)) == 0 ? iv : 0u, 0u, 0u, 0u);
-        } else {
-            for (int i = tid; i < HD / 4; i += NC) *(uint4 *)(hist + i * 4) = make_uint4(iv, iv, iv, iv);
-        }
+        // (RL > 0: the histogram proper is written whole by fold_copies, which also zeroes the copies it reads)
+        if constexpr (RL == 0) { for (int i = tid; i < (F + 4) / 4; i += NC) *(uint4 *)(hist + i * 4) = make_uint4(iv, iv, iv, iv); }
         if (tid <= V3_MAXV) ctr[tid] = 0;
     };
 
     // ---------------- memory wave: a view's row, in registers between reading the histogram and storing it
     struct Row { uint4 h[RP]; int64_t S, s; int v; };
     auto row_load = [&](Row &rw, int v, int64_t s) {
-        if constexpr (RL > 0) {
-            // bins 2 l, 2 l + 1 of this wave's half: 2 x 2^RL consecutive words = NPC 16-byte pieces.  Lanes sit NPC pieces apart, so
-            // every lane starts at another piece ((j + rot) mod NPC: 16 different slots of the 256-byte bank row in every lane group)
-            constexpr int NPC = (2 << RL) / 4;
-            const uint32_t *base = hist + (((mw * 64 + lane) * 2) << RL);
-            const int rot = (NPC >= 16) ? lane : (lane >> 1);
-            uint32_t s0 = 0u, s1 = 0u;
 #pragma unroll
-            for (int j = 0; j < NPC; ++j) {
-                const int pc = (j + rot) & (NPC - 1);
-                const uint4 h = *(const uint4 *)(base + pc * 4);
-                const uint32_t t = h.x + h.y + h.z + h.w;
-                if (pc < NPC / 2) s0 += t; else s1 += t;
-            }
-            rw.h[0] = make_uint4(s0, s1, 0u, 0u);
-        } else {
-#pragma unroll
-            for (int j = 0; j < RP; ++j) rw.h[j] = *(const uint4 *)(hist + (lane + (mw * RP + j) * 64) * 4);
-        }
+        for (int j = 0; j < RP; ++j) rw.h[j] = *(const uint4 *)(hist + (lane + ((TURNS ? 0 : mw * RP) + j) * 64) * 4);
         rw.S = (int64_t)ctr[0] + (int64_t)ctr[1 + v] + (iv ? (int64_t)F : 0);
         rw.v = v; rw.s = s;
     };
@@ -1003,20 +1016,9 @@ __global__ __launch_bounds__(V3_NT, 8) void vectorise3_kernel(VecArgs a)
         if (a.ablate & 1) { if (rw.h[0].x != 0xFFFFFFF0u) return; }
         // one address, formed here (not where the row was loaded: sixteen 64-bit addresses held across the barrier cost 32 registers);
         // the pieces are 1 KB apart
-        if constexpr (RL > 0) {      // two bins a lane: one 8-byte store, the wave's 512 bytes contiguous
-            int l2 = lane * 2;
-            asm volatile("" : "+v"(l2));
-            float *dst2 = (float *)a.out + ((int64_t)rw.v * a.view_stride + rw.s * (int64_t)F) + mw * 128 + l2;
-            if (a.out_kind == IDL_OUT_COUNTS_I32) { *(uint2 *)dst2 = make_uint2(rw.h[0].x, rw.h[0].y); return; }
-            const float Sf = (float)rw.S, rS = 1.0f / Sf;
-            const float c0 = (float)rw.h[0].x, c1 = (float)rw.h[0].y;
-            const float q0 = c0 * rS, q1 = c1 * rS;
-            *(float2 *)dst2 = make_float2(__builtin_fmaf(__builtin_fmaf(-q0, Sf, c0), rS, q0), __builtin_fmaf(__builtin_fmaf(-q1, Sf, c1), rS, q1));
-            return;
-        }
         int l4 = lane * 4;
         asm volatile("" : "+v"(l4));
-        float *dst = (float *)a.out + ((int64_t)rw.v * a.view_stride + rw.s * (int64_t)F) + mw * RP * 256 + l4;
+        float *dst = (float *)a.out + ((int64_t)rw.v * a.view_stride + rw.s * (int64_t)F) + (TURNS ? 0 : mw * RP * 256) + l4;
         if (a.out_kind == IDL_OUT_COUNTS_I32) {
 #pragma unroll
             for (int j = 0; j < RP; ++j) *(uint4 *)((uint32_t *)dst + j * 256) = rw.h[j];
@@ -1043,6 +1045,7 @@ __global__ __launch_bounds__(V3_NT, 8) void vectorise3_kernel(VecArgs a)
     if (tid < 4) sets[(tid >> 1) * SET + (SC + 1) * 4 + (tid & 1)] = 0xFFFFFFFFu;
     for (int i = tid; i < 3 * V3_META + 2 * V3_VTAB; i += V3_NT) meta[i] = 0u;
     if (!mem) clear_hist();
+    if constexpr (RL > 0) { for (int i = tid; i < HC / 4; i += V3_NT) *(uint4 *)(copies + i * 4) = make_uint4(0u, 0u, 0u, 0u); }
     const int QPRO = QC == 1 ? 3 : 2;             // batches pulled up front: iterations 0..2 must be known before the loop starts
     if (tid == 0) { for (int j = 0; j < 4; ++j) qb[j] = j < QPRO ? atomicAdd(qhead, QC) : 0x7FFFFFFF; }
     __syncthreads();
@@ -1090,17 +1093,19 @@ __global__ __launch_bounds__(V3_NT, 8) void vectorise3_kernel(VecArgs a)
             mark(5);
             if (q.fast) {
                 __syncthreads();                                // P1 of the compute waves is over
+                if constexpr (RL > 0) __syncthreads();          // ... and they have folded the copies into the histogram
                 mark(2);
                 for (int vi = 0; vi < P; ++vi) {
+                    const bool mine = !TURNS || (vi & (V3_MW - 1)) == mw;      // k = 4: the memory waves take the views in turn
                     Row row;
-                    row_load(row, view_at(q, vi), s);
+                    if (mine) row_load(row, view_at(q, vi), s);
                     mark(3);
                     __syncthreads();
                     mark(4);
-                    // before the last row goes out, retire the DMA issued above: the younger operations are the (P - 1) RP row stores
-                    // since, so no store is waited for
-                    if (vi + 1 == P) vm_wait_at_most((a.ablate & 1) ? 0 : (P - 1) * RP);
-                    row_store(row);
+                    // before the last row goes out, retire the DMA issued above: the younger operations are the row stores this wave
+                    // has issued since, so no store is waited for
+                    if (vi + 1 == P) vm_wait_at_most((a.ablate & 1) ? 0 : (TURNS ? (P - 1 + (V3_MW - 1 - mw)) / V3_MW : (P - 1) * RP));
+                    if (mine) row_store(row);
                     mark(6);
                     __syncthreads();
                     mark(7);
@@ -1129,7 +1134,7 @@ __global__ __launch_bounds__(V3_NT, 8) void vectorise3_kernel(VecArgs a)
             const uint32_t *cod = sets + (it & 1) * SET, *msk = cod + (SC + 1) * 4, *edl = cod + (SC + 1) * 6;
             // ---------------- P1: count the un-mutated sequence, evaluate every edit of every view
             {
-                uint32_t c0 = (a.ablate & 2) ? 0u : W::template count_all<NC>(cod, msk, q.nslots, hist, tid);
+                uint32_t c0 = (a.ablate & 2) ? 0u : W::template count_all<NC>(cod, msk, q.nslots, RL ? copies : hist, tid);
 #pragma unroll
                 for (int o = 32; o > 0; o >>= 1) c0 += __shfl_xor(c0, o, 64);
                 if (lane == 0) atomicAdd(&ctr[0], (int32_t)c0);
@@ -1151,7 +1156,7 @@ __global__ __launch_bounds__(V3_NT, 8) void vectorise3_kernel(VecArgs a)
                         if (d != 0) atomicAdd(&ctr[1 + v], d);
                         if (v == vfirst) {
 #pragma unroll
-                            for (int t = 0; t < K; ++t) W::move(hist, pr[t], 1u, lo4);
+                            for (int t = 0; t < K; ++t) { if constexpr (RL > 0) W::move_copy(copies, pr[t], 1u, lo4); else W::move(hist, pr[t], 1u); }
                         }
                     }
                 }
@@ -1159,6 +1164,10 @@ __global__ __launch_bounds__(V3_NT, 8) void vectorise3_kernel(VecArgs a)
             if (grab) qb[((it + 3) / QC) & 3] = grabbed;
             mark(1);
             __syncthreads();
+            if constexpr (RL > 0) {          // the copies -> the histogram the views live in (+ pseudocount), a thread per bin
+                if (tid < F) W::fold_copies(copies, hist, tid, iv);
+                __syncthreads();
+            }
             mark(2);
             for (int vi = 0; vi < P; ++vi) {
                 mark(3);
@@ -1168,8 +1177,8 @@ __global__ __launch_bounds__(V3_NT, 8) void vectorise3_kernel(VecArgs a)
                     const int v = view_at(q, vi), v2 = view_at(q, vi + 1);
                     const int na = (a.ablate & 4) ? 0 : (int)vt[(1 + v) * V3_VT] * K, pa = (int)vt[(1 + v) * V3_VT + 2];
                     const int nb = (a.ablate & 4) ? 0 : (int)vt[(1 + v2) * V3_VT] * K, pb = (int)vt[(1 + v2) * V3_VT + 2];
-                    for (int x = tid; x < na; x += NC) W::move(hist, list[pa + x], 0xFFFFFFFFu, lo4);       // undo view v
-                    for (int x = tid; x < nb; x += NC) W::move(hist, list[pb + x], 1u, lo4);                // apply view v2
+                    for (int x = tid; x < na; x += NC) W::move(hist, list[pa + x], 0xFFFFFFFFu);       // undo view v
+                    for (int x = tid; x < nb; x += NC) W::move(hist, list[pb + x], 1u);                // apply view v2
                 } else {
                     clear_hist();
                 }
@@ -1297,7 +1306,7 @@ template <int K, int RL>
 int launch_vectorise3_rl(const VecArgs &a_in, const idl::DeviceInfo &di, hipStream_t st, bool *done)
 {
     {
-        constexpr int F = 1 << (2 * K), HW = RL ? (F + 4) << RL : F + 4;
+        constexpr int HW = V3<K, RL>::HD;                          // histogram words (k = 4: the copies + the histogram proper)
         VecArgs a = a_in;
         int want = 3;
         if (const char *e = getenv("IDELUCS_VEC")) want = atoi(e);

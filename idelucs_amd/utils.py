@@ -844,12 +844,20 @@ def build_feature_store(sequence_file, n_mimics, k=6, reduce=False, rng=None, se
             row = _L.idl_row_len(mode, k)
             feats = feature_buffer(din.n, row)
             q.append(time.perf_counter())
-            edits, edit_off = _philox_edits(din, [t.spec() for t in tfs], seed)
+            # the sites into their slots WITHOUT reading the overflow flag back: that wait held the host for the generator's 0.5 ms
+            # with the vectoriser not yet enqueued.  The flag is read when everything is queued (an item beyond its slot: expected
+            # sites + 10 sigma + 32 -- never seen); then the exact two-pass protocol redoes the build
+            edits, edit_off = _philox_edits(din, [t.spec() for t in tfs], seed, sync=False)
             din.fill()
             q.append(time.perf_counter())
             _vectorise(din, k, mode, _lib.INIT_ONE, _lib.OUT_FREQ_F32, len(tfs), edits, edit_off, feats)
             store = finish(din.ff, din.ff.lengths, feats, din.n)
-            din.ff.close()                         # (unmaps the file on a helper thread; after the host side of the build, see from_handle)
+            din.ff.close()                         # (the names are read out of the handle here, while the device works: FastaFile.from_handle)
+            if bool(edits_overflowed(edits, edit_off)):
+                edits, edit_off = _philox_edits(din, [t.spec() for t in tfs], seed, slots=False)
+                _vectorise(din, k, mode, _lib.INIT_ONE, _lib.OUT_FREQ_F32, len(tfs), edits, edit_off, feats)
+                col_stats(feats[0], out=(store.mean, store.scale))
+                store.refresh()
             if timing:
                 q.append(time.perf_counter())
                 torch.cuda.synchronize()

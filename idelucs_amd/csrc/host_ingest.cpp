@@ -200,15 +200,16 @@ int first_cpu_of_list(const char *path)      // first number of a sysfs cpu list
     return v;
 }
 
-// One core per reader thread, spread over the L3 domains (IDELUCS_NUMA_PIN=0: the node's whole CPU set for every thread).  Measured
-// (profiles/r05_ingest_numa.txt): with the node-wide set the pool's 32 threads finished between 4.6 and 8.7 ms -- woken threads
-// go back to where they last ran and share cores, and a core complex has one link to memory -- against 4.8 .. 6.1 ms for
-// freshly created threads, which the kernel spreads.  A thread gets BOTH hardware threads of its core, so a sibling taken by
-// somebody else's work costs SMT sharing, not a time slice.
+// OPT-IN (IDELUCS_NUMA_PIN=1): one core per reader thread, spread over the L3 domains, instead of the node's whole CPU set for every
+// thread.  Built because the pool's threads, woken where they last ran, finished between 4.6 and 8.7 ms where freshly created ones
+// took 4.8 .. 6.1; measured on three boxes (gpurun_out/r05_c..e, kept as profiles/r05_ingest_ab.txt): the pinned threads do finish
+// closer together (9.1 .. 11.9 against 5.4 .. 12.1 ms) but the LAST one no earlier, and every job starts 1.3 ms late -- a thread
+// that may run on two CPUs only waits for them (deep idle, or somebody else's time slice) where the scheduler would have taken any
+// idle CPU of the node.  Ingest-to-features 14.5 / 11.8 / 16.3 ms pinned against 13.5 / 11.6 / 16.3 node-wide: node-wide is the default.
 void spread_over_cores(CpuBind *b)
 {
     const char *e = getenv("IDELUCS_NUMA_PIN");
-    if (e && atoi(e) == 0) return;
+    if (!(e && atoi(e) == 1)) return;
     struct Core { int l3, first; cpu_set_t cpus; };
     std::vector<Core> cores;
     for (int c = 0; c < CPU_SETSIZE; ++c) {
@@ -292,7 +293,8 @@ CpuBind bind_for_device(int dev, int want_threads)
     // too few CPUs of that node are open to this process (a cpuset on the other socket): leave the threads where they are
     if (CPU_COUNT(&b.set) == 0 || (CPU_COUNT(&b.set) < CPU_COUNT(&mine) && CPU_COUNT(&b.set) * 2 < want_threads)) return b;
     b.node = node;
-    if (CPU_EQUAL(&b.set, &mine) && !getenv("IDELUCS_NUMA_PIN")) return b;     // already there (one node, or an outer binding): leave the threads alone
+    const char *pin = getenv("IDELUCS_NUMA_PIN");
+    if (CPU_EQUAL(&b.set, &mine) && !(pin && atoi(pin) == 1)) return b;     // already there (one node, or an outer binding): leave the threads alone
     b.on = true;
     spread_over_cores(&b);
     return b;

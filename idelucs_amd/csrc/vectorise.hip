@@ -1300,8 +1300,8 @@ int launch_vectorise3_k(VecArgs &a, const idl::DeviceInfo &di, hipStream_t st, s
 }
 
 // v3 takes the hot shape only: plain k-mer rows (float32 or int32), k = 4..6, <= 8 views, every sequence within one staged
-// super-chunk (the host's length bound says so), fresh histograms.  Everything else stays on v2 / v1.  k = 4 keeps its 1 KB
-// histogram in 2^RL copies (V3<K, RL>): RL = 5 is conflict-free and fits three workgroups per CU at 10 kbp, RL = 4 four.
+// super-chunk (the host's length bound says so), fresh histograms.  Everything else stays on v2 / v1.  k = 4 counts into 2^RL
+// copies of its 1 KB histogram (V3<K, RL>): RL = 5 is conflict-free and fits three workgroups per CU at 10 kbp, RL = 4 four.
 template <int K, int RL>
 int launch_vectorise3_rl(const VecArgs &a_in, const idl::DeviceInfo &di, hipStream_t st, bool *done)
 {
@@ -1355,8 +1355,10 @@ int launch_vectorise3(const VecArgs &a_in, const idl::DeviceInfo &di, hipStream_
 {
     *done = false;
     if constexpr (K == 4) {
-        int rl = 5;
-        if (const char *e = getenv("IDELUCS_V3_COPIES")) { const int t = atoi(e); rl = t == 16 ? 4 : (t == 8 ? 3 : 5); }
+        // copies of the histogram the count goes to: 16 by default -- measured at 100 000 x 10 kbp, 4 views (gpurun_out/r05_e): 0.708 ms
+        // with 16 (four workgroups per CU), 0.714 with 8, 0.844 with 32 (conflict-free, but 41 KB of LDS: three per CU); v2: 1.393
+        int rl = 4;
+        if (const char *e = getenv("IDELUCS_V3_COPIES")) { const int t = atoi(e); rl = t == 32 ? 5 : (t == 8 ? 3 : 4); }
         if (rl == 5) return launch_vectorise3_rl<K, 5>(a_in, di, st, done);
         if (rl == 4) return launch_vectorise3_rl<K, 4>(a_in, di, st, done);
         return launch_vectorise3_rl<K, 3>(a_in, di, st, done);

@@ -411,8 +411,8 @@ def test_full_size_v1_v2_v3_kernels_agree_bitwise(gpu, monkeypatch, k):
                        U._vectorise(din, k, _lib.MODE_KMER, _lib.INIT_ZERO, _lib.OUT_COUNTS_I32, 4, edits, edit_off).clone())
     assert torch.equal(outs["1"][1], outs["2"][1]) and torch.equal(outs["1"][1], outs["3"][1])
     assert torch.equal(outs["1"][0], outs["2"][0]) and torch.equal(outs["1"][0], outs["3"][0])
-    if k == 4:      # round 5: the 4^4-bin histogram lives in 32 copies (lane l adds to copy l mod 32); 16 and 8 copies: the same rows
-        for copies in ("16", "8"):
+    if k == 4:      # round 5: the count goes to 16 copies of the 4^4-bin histogram (lane l adds to copy l mod 16); 32 and 8 copies: the same rows
+        for copies in ("32", "8"):
             monkeypatch.setenv("IDELUCS_VEC", "3"); monkeypatch.setenv("IDELUCS_V3_COPIES", copies)
             assert torch.equal(U._vectorise(din, k, _lib.MODE_KMER, _lib.INIT_ONE, _lib.OUT_FREQ_F32, 4, edits, edit_off), outs["1"][0]), copies
             assert torch.equal(U._vectorise(din, k, _lib.MODE_KMER, _lib.INIT_ZERO, _lib.OUT_COUNTS_I32, 4, edits, edit_off), outs["1"][1]), copies

@@ -441,8 +441,8 @@ def test_reader_thread_default_follows_quota_and_ranks():
 
 
 def test_reader_cpu_plan_one_core_per_thread(monkeypatch):
-    """Round 5: a device job's reader threads are bound to the NUMA node of the device, one core each, cores dealt over the L3
-    domains (idl_ingest_cpu_plan reports the placement without changing anything).  Here, without a device: IDELUCS_NUMA=<node>
+    """Round 5: a device job's reader threads are bound to the NUMA node of the device; with IDELUCS_NUMA_PIN=1 one core each, cores
+    dealt over the L3 domains (idl_ingest_cpu_plan reports the placement without changing anything).  Here, without a device: IDELUCS_NUMA=<node>
     names the node; every thread's set is a non-empty part of this process's CPUs, and as many threads as the node has cores get
     cores of their own; IDELUCS_NUMA=off plans nothing."""
     if not os.path.isdir("/sys/devices/system/node/node0"):
@@ -463,7 +463,7 @@ def test_reader_cpu_plan_one_core_per_thread(monkeypatch):
     n_cores = len({open(f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list").read().strip() for c in mine
                    if os.path.exists(f"/sys/devices/system/node/node0/cpu{c}")})
     assert len(cores) == min(nt, n_cores)
-    monkeypatch.setenv("IDELUCS_NUMA_PIN", "0")                  # the node's whole set for everybody
+    monkeypatch.setenv("IDELUCS_NUMA_PIN", "0")                  # (the default) the node's whole set for everybody, or nothing to do at all
     assert _lib.lib.idl_ingest_cpu_plan(-1, nt, U._ptr(first), U._ptr(count)) == 0 and len(set(count.tolist())) == 1
     monkeypatch.setenv("IDELUCS_NUMA", "off")
     assert _lib.lib.idl_ingest_cpu_plan(-1, nt, U._ptr(first), U._ptr(count)) == -1 and np.all(count == 0)

@@ -94,6 +94,9 @@ SIGNATURES = {
     "idl_wgrad_rmsprop_step": (_int, [_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _c.c_float, _c.c_float, _vp,
                                       _int, _vp, _vp, _int, _int, _int, _vp,
                                       _int, _vp, _vp, _int, _int, _int, _int, _vp, _i64, _vp]),
+    "idl_l1_fwd_rms": (_int, [_vp, _vp, _int, _int, _vp,
+                              _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _c.c_float, _c.c_float, _vp, _int,
+                              _int, _vp, _vp, _int, _int, _int, _int, _vp, _i64, _vp]),
     "idl_mid_bwd_gather": (_int, [_vp] * 5 + [_int] + [_vp] * 4 + [_int, _int, _int, _c.c_float] + [_vp] * 7 +
                            [_vp, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _vp]),
     "idl_mid_fwd_gather": (_int, [_vp, _vp, _int, _vp, _vp, _vp, _vp, _int, _int, _int, _c.c_uint64, _vp, _vp, _vp, _vp, _vp] +

@@ -28,6 +28,7 @@
 #include "scaler_device.h"
 #include "wave_ops.h"
 #include "wgrad_device.h"
+#include "l1_device.h"
 #include "philox_device.h"
 
 namespace {
@@ -1113,6 +1114,23 @@ __global__ __launch_bounds__(wg_dev::THREADS) void wgrad_rmsprop_kernel(wg_dev::
     }
 }
 
+// The layer-1 forward tiles of step t + 1 (l1_device.h) with the optimizer TAIL of step t as rider workgroups (round 5).
+// In the optimizer launch the workgroups behind the dW1 tiles (the dW2 tiles, the small tensors, step loss, step counter) cannot
+// become resident beside a tile workgroup, so they run when tiles leave: 5.8 us of serial tail on otherwise idle CUs
+// (profiles/r04_k_stamps_optimizer_launch.txt).  Their results (W2, W3, the biases, the step counter the dropout stream reads) are
+// first read by the mid-forward launch of the NEXT step, behind that step's layer-1 product -- a launch whose tiles need 94
+// registers and 72 KB of LDS and leave every CU room for a second workgroup.  There the tail has 30 us of slack: it takes
+// ~1 000 matrix-pipe cycles per SIMD from the tiles it meets, at their side instead of behind them.  Riders are the LAST blocks of
+// the grid (every CU has its tile first) and run the plain rmsprop_body: no look-ahead registers (the whole launch lives within
+// 128), no priority.
+__global__ __launch_bounds__(l1_dev::THREADS, 4) void l1_rms_kernel(l1_dev::L1Args l, RmsArgs a, const float *hyper, int64_t *ctl, int64_t batch_advance)
+{
+    extern __shared__ __attribute__((aligned(1024))) unsigned char l1_rms_smem[];
+    if ((int)blockIdx.x < l.n_tiles) { l1_dev::l1_fwd_body<false, 0>(l, (int)blockIdx.x, l1_rms_smem); return; }
+    if (threadIdx.x >= RMS_THREADS) return;                  // (before any barrier: rmsprop_body is written for 256 threads)
+    rmsprop_body<false>(a, hyper, ctl, batch_advance, 0, 0, idl_dev::GatherArgs{}, (int)blockIdx.x - l.n_tiles);
+}
+
 // several voters in one launch: voter blockIdx.y takes its arguments from its plan record
 __global__ __launch_bounds__(256) void rmsprop_batched_kernel(const unsigned char *__restrict__ plans)
 {
@@ -1457,7 +1475,7 @@ static int rmsprop_launch(int count, float *const *params, const float *const *g
                           const float *loss_rows, int loss_m, float w_nce, float w_iic, float *out, const idl_dev::GatherArgs &g,
                           void *stream, int wg_index = -1, const float *wg_dy = nullptr, const float *wg_x = nullptr, int wg_m = 0,
                           int wg_n_out = 0, int wg_n_in = 0, float *wg_grad = nullptr, int wg_x_transposed = 0,
-                          const wg_dev::WgArgs *big = nullptr, int big_index = -1)
+                          const wg_dev::WgArgs *big = nullptr, int big_index = -1, const l1_dev::L1Args *l1 = nullptr, int skip_index = -1)
 {
     IDL_REQUIRE(count >= 1 && count <= 8 && params && grads && square_avg && sizes && hyper && ctl, "rmsprop_step: 1..8 tensors");
     RmsArgs a{};
@@ -1483,6 +1501,7 @@ static int rmsprop_launch(int count, float *const *params, const float *const *g
         for (int i = 0; i < count; ++i) if (a.n[i] > mx) mx = a.n[i];
     }
     (void)mx;
+    if (skip_index >= 0 && skip_index < count) a.n[skip_index] = 0;     // (updated elsewhere: the dW1 tiles' own launch)
     if (big != nullptr) {                   // tensor big_index is updated by the tile workgroups at the head of the launch
         IDL_REQUIRE(big_index >= 0 && big_index < count && big_index != wg_index &&
                     sizes[big_index] == (int64_t)big->p.n_out * big->p.n_in && big->p.W == params[big_index] && big->p.V == square_avg[big_index],
@@ -1500,6 +1519,20 @@ static int rmsprop_launch(int count, float *const *params, const float *const *g
     if (nb_total == 0) nb_total = 1;        // (step counter / loss assembly still need a block)
     for (int i = count; i <= 8; ++i) a.first[i] = nb_total;
     const int64_t extra = g.y != nullptr ? idl_dev::gather_blocks(g.f, g.batch) : 0;
+    if (l1 != nullptr) {                    // the optimizer blocks ride behind the layer-1 forward tiles of the next step (l1_rms_kernel)
+        IDL_REQUIRE(big == nullptr && extra == 0 && idl::take_plan() == nullptr, "l1_fwd_rms: no dW1 tiles, no batch assembly, not recordable");
+        static bool attr_set[64] = {};
+        int dev = 0;
+        IDL_HIP_TRY(hipGetDevice(&dev));
+        if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+            IDL_HIP_TRY(hipFuncSetAttribute((const void *)l1_rms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, l1_dev::LDS_BYTES));
+            attr_set[dev] = true;
+        }
+        hipLaunchKernelGGL(l1_rms_kernel, dim3((unsigned)(l1->n_tiles + nb_total + a.wg_tiles)), dim3(l1_dev::THREADS), l1_dev::LDS_BYTES,
+                           (hipStream_t)stream, *l1, a, hyper, ctl, batch_advance);
+        IDL_HIP_TRY(hipGetLastError());
+        return IDL_OK;
+    }
     if (void *plan = idl::take_plan()) {          // recorded, not launched (idl_plan_begin)
         idl::PlanHead h{};
         const RmsParams p{a, hyper, ctl, batch_advance, (int)extra, g};
@@ -1602,6 +1635,22 @@ int idl_wgrad_rmsprop_step(int count, float *const *params, const float *const *
     idl_dev::GatherArgs g{};
     return rmsprop_launch(count, params, grads, grad_parts, square_avg, sizes, hyper, ctl, batch_advance, loss_rows, loss_m, w_nce, w_iic, out, g,
                           stream, wg_index, wg_dy, wg_x, wg_m, wg_n_out, wg_n_in, wg_grad, wg_x_transposed, &w, w1_index);
+}
+
+int idl_l1_fwd_rms(const float *W1, const float *x, int m, int n_in, float *r1_transposed,
+                   int count, float *const *params, const float *const *grads, const int32_t *grad_parts,
+                   float *const *square_avg, const int64_t *sizes, const float *hyper, int64_t *ctl,
+                   const float *loss_rows, int loss_m, float w_nce, float w_iic, float *out, int w1_index,
+                   int wg_index, const float *wg_dy, const float *wg_x, int wg_x_transposed, int wg_m, int wg_n_out, int wg_n_in,
+                   float *wg_grad, int64_t batch_advance, void *stream)
+{
+    IDL_REQUIRE(W1 && x && r1_transposed && idl_l1_fwd_supported(m, l1_dev::H1, n_in), "l1_fwd_rms: Linear(n_in, 512), m % 32 == 0, n_in % 64 == 0, n_in >= 192");
+    IDL_REQUIRE((((uintptr_t)W1 | (uintptr_t)x | (uintptr_t)r1_transposed) & 15u) == 0, "l1_fwd_rms: buffers must be 16-byte aligned");
+    const int n_tiles = (l1_dev::H1 / l1_dev::TH) * (m / l1_dev::TR);
+    const l1_dev::L1Args l{W1, x, nullptr, nullptr, r1_transposed, nullptr, nullptr, 0, m, n_in, 0, 1, n_tiles, 0, 0, idl_dev::GatherArgs{}};
+    idl_dev::GatherArgs g{};
+    return rmsprop_launch(count, params, grads, grad_parts, square_avg, sizes, hyper, ctl, batch_advance, loss_rows, loss_m, w_nce, w_iic, out, g,
+                          stream, wg_index, wg_dy, wg_x, wg_m, wg_n_out, wg_n_in, wg_grad, wg_x_transposed, nullptr, -1, &l, w1_index);
 }
 
 int idl_debug_phase_stamps(int on)

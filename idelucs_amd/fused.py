@@ -54,6 +54,10 @@ class _Buffers:
         self.x = self.xs[0]
         self.r1 = sh['r1'] if 'r1' in sh else torch.empty((m, H1), **f32)        # Linear1 output, then ReLU+Dropout in place
         self.r1T = self.r1.view(H1, m)                # the same memory as the transposed image [H1, m] (one of the two is in use)
+        # tail-in-layer-1 (FusedLinearTrainer._tail_l1): the layer-1 launch of step t + 1 writes its activations while riders of the
+        # same launch still read step t's (dW2 = dlat^T r1), so the steps alternate between two images; made on first use
+        self._r1_other = None
+        self._H1 = H1
         self.lat = torch.empty((m, H2), **f32)
         self.lat_part = torch.empty((_L.idl_l1_fwd_parts(), m, H2), **f32)      # idl_l1_fwd: partial sums of r1 W2^T per 64-unit tile of the hidden layer
         self.f = torch.empty((m, H2), **f32)
@@ -74,6 +78,15 @@ class _Buffers:
         self.dzs = torch.empty((m, C), **f32) if C > 64 else None       # z dP0 (fine-grained mode)
         self.dlat = torch.empty((m, H2), **f32)
         self.dr1 = sh['dr1'] if 'dr1' in sh else torch.empty((m, H1), **f32)
+
+
+def _r1_of(bf, xi):
+    """The layer-1 activation image of a step of parity xi ([m, H1]; the transposed image is the same memory)."""
+    if xi == 0:
+        return bf.r1
+    if bf._r1_other is None:
+        bf._r1_other = torch.empty_like(bf.r1)
+    return bf._r1_other
 
 
 class _Recorder:
@@ -166,6 +179,13 @@ class FusedLinearTrainer:
         self._wgrad_own_launch = os.environ.get("IDELUCS_WGRAD_FUSED", "1") == "2"
         self._keep_w1_grad = os.environ.get("IDELUCS_KEEP_W1_GRAD", "0") != "0"       # tests: also write dW1 to grads[0]
         self._steps_per_graph = max(2, int(os.environ.get("IDELUCS_STEPS_PER_GRAPH", "16")) // 2 * 2)
+        # Round 5 (IDELUCS_TAIL_L1, default on): the layer-1 product on this package's own tiles (idl_l1_fwd: no library build decides
+        # its speed) and the optimizer's TAIL -- the dW2 tiles, the small tensors, step loss, step counter: 5.8 us behind the dW1 tiles
+        # of the optimizer launch, where they cannot become resident beside a tile -- riding in the layer-1 launch of the NEXT step
+        # (idl_l1_fwd_rms), where they have 30 us of slack.  A step then ends with the dW1 tiles alone; its tail is pending until the
+        # next step's first launch, or flush_tail().  Only the default launch sequence of a single voter takes it.
+        self._tail_l1 = os.environ.get("IDELUCS_TAIL_L1", "1") != "0"
+        self._pending = None                     # (buffers, parity) of the step whose tail has not run yet
         self._perm = None
         n = len(self.params)
         self._pp = (ctypes.c_void_p * n)(*[p.data_ptr() for p in self.params])
@@ -212,7 +232,7 @@ class FusedLinearTrainer:
 
     # ------------------------------------------------------------------ one step on a filled bf.x
     @torch.no_grad()
-    def step_on_batch(self, bf, train=True, batch_advance=0, next_from=None, xi=0):
+    def step_on_batch(self, bf, train=True, batch_advance=0, next_from=None, xi=0, defer_tail=False):
         """Forward, backward and RMSprop update for the [m, F] batch in bf.x (rows [0,m/2) "true",
         [m/2,m) "modified").  Only enqueues work on the current stream.  next_from = a FeatureStore: the batch
         offset is advanced in the middle of the step and the optimizer launch also assembles the NEXT batch into
@@ -223,6 +243,15 @@ class FusedLinearTrainer:
               and self._dw2_inlaunch)
         early = next_from is not None and self._early_gather and m % 16 == 0   # next batch -> bf.xs[1 - xi] by the mid launches
         early_f = next_from is not None and self._early_fwd and m % 16 == 0    # ... by the mid-forward launch alone
+        # tail-in-layer-1: own layer-1 tiles, the dW1 tiles as the step's last launch, the rest of the optimizer in the NEXT layer-1 launch
+        tm = (self._tail_l1 and tl and early and self._early_split and self._rec is None and not self._l1_fused and not self._l1_bare
+              and not self._nce_bwd_fused and self._wgrad_fused and not self._wgrad_own_launch and not self._shared_buffers
+              and self._dw2_inlaunch and not self._overlap
+              and bool(_L.idl_l1_fwd_supported(m, self.H1, self.F)) and bool(_L.idl_wgrad_supported(m, self.H1, self.F)))
+        if not tm:
+            self.flush_tail()                   # (a step of another form: whatever is pending goes first)
+        r1 = _r1_of(bf, xi) if tm else bf.r1
+        r1T = r1.view(self.H1, m)
         chk = _lib.check
         main = torch.cuda.current_stream()
         side = self._side if self._overlap else main
@@ -231,21 +260,27 @@ class FusedLinearTrainer:
         # shares (eighths) of the next batch's assembly: [0, g1) riders of the layer-1 launch, [g1, g2) the mid-forward launch, [g2, 8) mid-backward
         g1 = self._l1_gather if l1 else 0
         g2 = max(g1, self._gsplit)
-        if l1:      # own tiles: r1^T = Dropout(ReLU(W1 x^T + b1)) and the partial sums of lat = r1 W2^T straight from the accumulators
+        if tm:      # a1^T = W1 x^T on own tiles; the previous step's optimizer tail rides in the same launch
+            if self._pending is not None:
+                pbf, pxi = self._pending
+                self._tail_launch(pbf, pxi, l1=(x, m, r1T))
+            else:
+                chk(_L.idl_l1_fwd(_p(self.W1), _p(x), None, None, m, self.F, 0, 0, None, _p(r1T), 1, None, _stream()))
+        elif l1:    # own tiles: r1^T = Dropout(ReLU(W1 x^T + b1)) and the partial sums of lat = r1 W2^T straight from the accumulators
             st = next_from      # ... with shares [0, g1) of the next batch's tiles assembled by riders of the same launch (HBM is idle under it)
-            self._k(_L.idl_l1_fwd_gather, _p(self.W1), _p(x), _p(self.b1), _p(self.W2), m, self.F, tr, self.seed, _p(self.ctl), _p(bf.r1), 1,
+            self._k(_L.idl_l1_fwd_gather, _p(self.W1), _p(x), _p(self.b1), _p(self.W2), m, self.F, tr, self.seed, _p(self.ctl), _p(r1), 1,
                     _p(bf.lat_part),
                     _p(st.feats), st.n, st.f, st.n * st.f, _p(self._perm), _p(self.ctl[1:]), m // 2, st.n_pairs, m // 2,
                     _p(st.mean), _p(st.scale), _p(st.inv_scale), _p(bf.xs[1 - xi]), 0, self._l1_gather, 8, _stream())
         elif tl and self._l1_bare and self._rec is None and bool(_L.idl_l1_fwd_supported(m, self.H1, self.F)):
-            chk(_L.idl_l1_fwd(_p(self.W1), _p(x), None, None, m, self.F, 0, 0, None, _p(bf.r1), 1, None, _stream()))
+            chk(_L.idl_l1_fwd(_p(self.W1), _p(x), None, None, m, self.F, 0, 0, None, _p(r1), 1, None, _stream()))
         elif tl:    # a1^T = W1 x^T: the orientation hipBLASLt runs this product fastest in; mid_fwd adds the bias
-            self._mm(self.W1, x.t(), bf.r1T)
+            self._mm(self.W1, x.t(), r1T)
         else:
-            torch.addmm(self.b1, x, self.W1.t(), out=bf.r1)
+            torch.addmm(self.b1, x, self.W1.t(), out=r1)
         if early and self._early_split:         # ... and the first half of the next batch's tiles in its spare workgroups
             st = next_from
-            self._k(_L.idl_mid_fwd_gather, _p(bf.lat_part) if l1 else _p(bf.r1), _p(self.b1) if (tl and not l1) else None,
+            self._k(_L.idl_mid_fwd_gather, _p(bf.lat_part) if l1 else _p(r1), _p(self.b1) if (tl and not l1) else None,
                     2 if l1 else (1 if tl else 0), _p(self.W2), _p(self.b2), _p(self.W3), _p(self.b3),
                     m, C, tr, self.seed, _p(self.ctl),
                     _p(bf.f), _p(bf.inv), _p(bf.r2), _p(bf.z),
@@ -253,17 +288,17 @@ class FusedLinearTrainer:
                     _p(st.mean), _p(st.scale), _p(st.inv_scale), _p(bf.xs[1 - xi]), g1, g2, 8, _stream())
         elif early_f:
             st = next_from
-            chk(_L.idl_mid_fwd_gather(_p(bf.r1), None, 0, _p(self.W2), _p(self.b2), _p(self.W3), _p(self.b3),
+            chk(_L.idl_mid_fwd_gather(_p(r1), None, 0, _p(self.W2), _p(self.b2), _p(self.W3), _p(self.b3),
                                       m, C, tr, self.seed, _p(self.ctl),
                                       _p(bf.f), _p(bf.inv), _p(bf.r2), _p(bf.z),
                                       _p(st.feats), st.n, st.f, st.n * st.f, _p(self._perm), _p(self.ctl[1:]), m // 2, st.n_pairs, m // 2,
                                       _p(st.mean), _p(st.scale), _p(st.inv_scale), _p(bf.xs[1 - xi]), 0, 8, 8, _stream()))
         elif self._mid_fused and m % 16 == 0:   # ReLU/Dropout + Linear(512,64) + head in one MFMA kernel
-            chk(_L.idl_mid_fwd(_p(bf.r1), _p(self.W2), _p(self.b2), _p(self.W3), _p(self.b3), m, C, tr, self.seed, _p(self.ctl),
+            chk(_L.idl_mid_fwd(_p(r1), _p(self.W2), _p(self.b2), _p(self.W3), _p(self.b3), m, C, tr, self.seed, _p(self.ctl),
                                _p(bf.f), _p(bf.inv), _p(bf.r2), _p(bf.z), _stream()))
         else:
-            chk(_L.idl_relu_dropout_fwd(_p(bf.r1), bf.r1.numel(), tr, self.seed, _p(self.ctl), 1, _stream()))
-            torch.addmm(self.b2, bf.r1, self.W2.t(), out=bf.lat)
+            chk(_L.idl_relu_dropout_fwd(_p(r1), r1.numel(), tr, self.seed, _p(self.ctl), 1, _stream()))
+            torch.addmm(self.b2, r1, self.W2.t(), out=bf.lat)
             chk(_L.idl_head_fwd(_p(bf.lat), _p(self.W3), _p(self.b3), m, C, tr, self.seed, _p(self.ctl),
                                 _p(bf.f), _p(bf.inv), _p(bf.r2), _p(bf.z), _stream()))
         # ---- the two losses are independent: with the fused InfoNCE kernels the IIC core rides along as one extra workgroup
@@ -299,7 +334,7 @@ class FusedLinearTrainer:
             st = next_from
             chk(_L.idl_nce_mid_bwd_gather(_p(bf.z), _p(bf.r2), _p(bf.f), _p(bf.inv), _p(bf.nce_ws), bf.nce_parts, TEMPERATURE, _p(bf.P0),
                                           self.lamb, EPS, self.weight, _p(bf.lse), _p(bf.loss_rows), _p(self.out), _p(self.W3), _p(self.W2),
-                                          _p(bf.r1), m, C, tr, nce_coef, _p(bf.dlogits), _p(bf.dlat), _p(bf.dr1), _p(gb1), _p(gb2), _p(gb3),
+                                          _p(r1), m, C, tr, nce_coef, _p(bf.dlogits), _p(bf.dlat), _p(bf.dr1), _p(gb1), _p(gb2), _p(gb3),
                                           _p(gW3) if self._dw3_partial else None,
                                           _p(st.feats), st.n, st.f, st.n * st.f, _p(self._perm), _p(self.ctl[1:]), m // 2, st.n_pairs, m // 2,
                                           _p(st.mean), _p(st.scale), _p(st.inv_scale), _p(bf.xs[1 - xi]),
@@ -307,11 +342,11 @@ class FusedLinearTrainer:
             if not self._dw3_partial:
                 torch.mm(bf.dlogits.t(), bf.r2, out=gW3)
             if not self._dw2_inlaunch:
-                torch.mm(bf.dlat.t(), bf.r1, out=gW2)
+                torch.mm(bf.dlat.t(), r1, out=gW2)
         elif early:
             st = next_from
             self._k(_L.idl_mid_bwd_gather, _p(bf.z), _p(bf.r2), _p(bf.f), _p(bf.inv), _p(bf.G), bf.G.shape[0], _p(bf.P0), _p(self.W3), _p(self.W2),
-                    _p(bf.r1), m, C, tr, nce_coef, _p(bf.dlogits), _p(bf.dlat), _p(bf.dr1), _p(gb1), _p(gb2), _p(gb3),
+                    _p(r1), m, C, tr, nce_coef, _p(bf.dlogits), _p(bf.dlat), _p(bf.dr1), _p(gb1), _p(gb2), _p(gb3),
                     _p(gW3) if self._dw3_partial else None,
                     _p(st.feats), st.n, st.f, st.n * st.f, _p(self._perm), _p(self.ctl[1:]), m // 2, st.n_pairs, m // 2,
                     _p(st.mean), _p(st.scale), _p(st.inv_scale), _p(bf.xs[1 - xi]), g2 if self._early_split else 0,
@@ -319,16 +354,16 @@ class FusedLinearTrainer:
             if not self._dw3_partial:
                 torch.mm(bf.dlogits.t(), bf.r2, out=gW3)
             if not self._dw2_inlaunch:
-                torch.mm(bf.dlat.t(), bf.r1, out=gW2)
+                torch.mm(bf.dlat.t(), r1, out=gW2)
         elif self._mid_fused and C <= 48:     # (at n_clusters = 200 the per-row C x C products want all 256 CUs: separate kernels)
             # ---- head backward + dr1 = dlat W2 (MFMA) + ReLU/Dropout backward + every bias gradient (+ dW3) in one launch
             chk(_L.idl_mid_bwd(_p(bf.z), _p(bf.r2), _p(bf.f), _p(bf.inv), _p(bf.G), bf.G.shape[0], _p(bf.P0), _p(self.W3), _p(self.W2),
-                               _p(bf.r1), m, C, tr, nce_coef, _p(bf.dlogits), _p(bf.dlat), _p(bf.dr1), _p(gb1), _p(gb2), _p(gb3),
+                               _p(r1), m, C, tr, nce_coef, _p(bf.dlogits), _p(bf.dlat), _p(bf.dr1), _p(gb1), _p(gb2), _p(gb3),
                                _p(gW3) if self._dw3_partial else None, adv_ctl, adv, _stream()))
             if not self._dw3_partial:
                 torch.mm(bf.dlogits.t(), bf.r2, out=gW3)
             if not (self._dw2_inlaunch and next_from is not None):
-                torch.mm(bf.dlat.t(), bf.r1, out=gW2)
+                torch.mm(bf.dlat.t(), r1, out=gW2)
         else:
             if C > 64:      # fine-grained mode: z_partner dP0 for all rows as one GEMM instead of 40 000 FMAs per row inside the kernel
                 torch.mm(bf.z, bf.P0, out=bf.dzs)
@@ -343,11 +378,18 @@ class FusedLinearTrainer:
                 if not self._dw3_partial:
                     torch.mm(bf.dlogits.t(), bf.r2, out=gW3)
                 if not (self._dw2_inlaunch and next_from is not None):
-                    torch.mm(bf.dlat.t(), bf.r1, out=gW2)
+                    torch.mm(bf.dlat.t(), r1, out=gW2)
             torch.mm(bf.dlat, self.W2, out=bf.dr1)
-            chk(_L.idl_bias_grads(_p(bf.dr1), _p(bf.r1), self.H1, _p(gb1), _p(bf.dlat), self.H2, _p(gb2), _p(bf.dlogits), C, _p(gb3),
+            chk(_L.idl_bias_grads(_p(bf.dr1), _p(r1), self.H1, _p(gb1), _p(bf.dlat), self.H2, _p(gb2), _p(bf.dlogits), C, _p(gb3),
                                   m, tr, adv_ctl, adv, _p(bf.r2) if self._dw3_partial else None,
                                   _p(gW3) if self._dw3_partial else None, _stream()))
+        if tm:      # the dW1 tiles end the step; everything else of the optimizer rides in the next step's layer-1 launch
+            chk(_L.idl_wgrad_rmsprop(_p(bf.dr1), _p(x), m, self.H1, self.F, _p(gW1) if self._keep_w1_grad else None, _p(self.W1),
+                                     _p(self.square_avg[0]), _p(self.hyper), _stream()))
+            self._pending = (bf, xi)
+            if not defer_tail:
+                self.flush_tail()
+            return
         w1_fusable = self._wgrad_fused and bool(_L.idl_wgrad_supported(m, self.H1, self.F))
         # the tiles ride at the head of the optimizer launch where that launch has the form below; else as a launch of their own
         w1_head = w1_fusable and (early or early_f) and self._dw2_inlaunch and not self._wgrad_own_launch
@@ -365,12 +407,12 @@ class FusedLinearTrainer:
             self._k(_L.idl_wgrad_rmsprop_step, len(self.params), self._pp, self._gp, self._parts, self._vp, sz, _p(self.hyper),
                     _p(self.ctl), _p(bf.loss_rows), m, 1.0 - self.weight, self.weight, _p(self.out),
                     0, _p(bf.dr1), _p(x), m, self.H1, self.F, gw1_out,
-                    2, _p(bf.dlat), _p(bf.r1), 1 if tl else 0, m, self.H2, self.H1, _p(gW2), m // 2, _stream())
+                    2, _p(bf.dlat), _p(r1), 1 if tl else 0, m, self.H2, self.H1, _p(gW2), m // 2, _stream())
         elif (early or early_f) and self._dw2_inlaunch:      # no batch assembly here; the offset moves on at the end of the step
             self._k(_L.idl_rmsprop_step_gather_wgrad, len(self.params), self._pp, self._gp, self._parts, self._vp, sz, _p(self.hyper),
                     _p(self.ctl), _p(bf.loss_rows), m, 1.0 - self.weight, self.weight, _p(self.out),
                     None, 0, 0, 0, None, 0, 0, None, None, None, None,
-                    2, _p(bf.dlat), _p(bf.r1), 1 if tl else 0, m, self.H2, self.H1, _p(gW2), m // 2, _stream())
+                    2, _p(bf.dlat), _p(r1), 1 if tl else 0, m, self.H2, self.H1, _p(gW2), m // 2, _stream())
         elif early:
             chk(_L.idl_rmsprop_step(len(self.params), self._pp, self._gp, self._parts, self._vp, sz, _p(self.hyper),
                                     _p(self.ctl), m // 2, _p(bf.loss_rows), m, 1.0 - self.weight, self.weight, _p(self.out), _stream()))
@@ -380,7 +422,7 @@ class FusedLinearTrainer:
                                                  _p(self.ctl), _p(bf.loss_rows), m, 1.0 - self.weight, self.weight, _p(self.out),
                                                  _p(st.feats), st.n, st.f, st.n * st.f, _p(self._perm), st.n_pairs, m // 2,
                                                  _p(st.mean), _p(st.scale), _p(st.inv_scale), _p(bf.x),
-                                                 2, _p(bf.dlat), _p(bf.r1), 0, m, self.H2, self.H1, _p(gW2), 0, _stream()))
+                                                 2, _p(bf.dlat), _p(r1), 0, m, self.H2, self.H1, _p(gW2), 0, _stream()))
         elif next_from is not None:
             st = next_from
             chk(_L.idl_rmsprop_step_gather(len(self.params), self._pp, self._gp, self._parts, self._vp, sz, _p(self.hyper),
@@ -392,17 +434,41 @@ class FusedLinearTrainer:
                                     _p(self.ctl), batch_advance, _p(bf.loss_rows), m, 1.0 - self.weight, self.weight, _p(self.out),
                                     _stream()))
 
+    def _tail_launch(self, bf, xi, l1=None):
+        """The optimizer's tail of the step that ran on (bf, xi): dW2 tiles + RMSprop on every tensor but W1 + step loss + step
+        counter -- behind the layer-1 tiles of the next step (l1 = (x, m, r1T) of THAT step), or as a launch of its own."""
+        m = bf.m
+        r1 = _r1_of(bf, xi)
+        tail = (len(self.params), self._pp, self._gp, self._parts, self._vp, self._sz, _p(self.hyper),
+                _p(self.ctl), _p(bf.loss_rows), m, 1.0 - self.weight, self.weight, _p(self.out))
+        wg = (2, _p(bf.dlat), _p(r1), 1, m, self.H2, self.H1, _p(self.grads[2]), m // 2, _stream())
+        if l1 is not None:
+            x, m1, r1T = l1
+            _lib.check(_L.idl_l1_fwd_rms(_p(self.W1), _p(x), m1, self.F, _p(r1T), *tail, 0, *wg))
+        else:       # (sizes without W1: the tiles' own launch updated it)
+            tail = tail[:5] + (self._sz_no_w1,) + tail[6:]
+            _lib.check(_L.idl_rmsprop_step_gather_wgrad(*tail, None, 0, 0, 0, None, 0, 0, None, None, None, None, *wg))
+        self._pending = None
+
+    def flush_tail(self):
+        """Run the pending optimizer tail now (end of an epoch, before a step of another form, before anybody looks at the small
+        tensors); a no-op when nothing is pending."""
+        if self._pending is not None:
+            bf, xi = self._pending
+            self._tail_launch(bf, xi)
+
     def _gather(self, store, bf):
         b = bf.m // 2
         _lib.check(_L.idl_gather_pairs_at(_p(store.feats), store.n, store.f, store.n * store.f, _p(self._perm), _p(self.ctl[1:]),
                                           b, _p(store.mean), _p(store.scale), _p(store.inv_scale), _p(bf.x), _stream()))
 
-    def _full_step(self, store, bf, train=True, pipelined=False, xi=0):
+    def _full_step(self, store, bf, train=True, pipelined=False, xi=0, defer_tail=False):
         """pipelined: bf.xs[xi] already holds this batch (assembled by the previous step, or by the prologue gather);
-        this step assembles the next one (into bf.xs[1 - xi] when the mid-backward launch does it, else into bf.xs[xi])."""
+        this step assembles the next one (into bf.xs[1 - xi] when the mid-backward launch does it, else into bf.xs[xi]).
+        defer_tail (run_epoch's steps): the step's optimizer tail may wait for the next step's first launch (flush_tail)."""
         if pipelined:
             self.step_on_batch(bf, train=train, batch_advance=bf.m // 2, next_from=store,
-                               xi=xi if (self._early_gather or self._early_fwd) else 0)
+                               xi=xi if (self._early_gather or self._early_fwd) else 0, defer_tail=defer_tail)
         else:
             self._gather(store, bf)
             self.step_on_batch(bf, train=train, batch_advance=bf.m // 2)
@@ -444,10 +510,11 @@ class FusedLinearTrainer:
                 for _ in range((n_full - n_done) // per):
                     g.replay()
                 for i in range((n_full - n_done) % per):
-                    self._full_step(store, bf, pipelined=pipe, xi=i % 2)
+                    self._full_step(store, bf, pipelined=pipe, xi=i % 2, defer_tail=True)
             else:
                 for i in range(n_full):
-                    self._full_step(store, bf, pipelined=pipe, xi=i % 2)
+                    self._full_step(store, bf, pipelined=pipe, xi=i % 2, defer_tail=True)
+        self.flush_tail()                       # (the last eager step's tail; a replayed graph ends with its own)
         if rem:
             self._full_step(store, self.buffers(2 * rem))
         return self.out[1], n_full + (1 if rem else 0)
@@ -460,12 +527,16 @@ class FusedLinearTrainer:
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             for i in range(2):
-                self._full_step(store, bf, pipelined=pipe, xi=i % 2)
+                self._full_step(store, bf, pipelined=pipe, xi=i % 2, defer_tail=True)
+            self.flush_tail()
         torch.cuda.current_stream().wait_stream(s)
+        # (tail-in-layer-1: a replay is self-contained -- its first step has nothing pending in front of it, its last step's tail is
+        #  a launch of its own at the end of the graph: one more launch per `per` steps, and a replay never applies a tail twice)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             for i in range(per):
-                self._full_step(store, bf, pipelined=pipe, xi=i % 2)
+                self._full_step(store, bf, pipelined=pipe, xi=i % 2, defer_tail=True)
+            self.flush_tail()
         g.replay()          # capture does not execute: run the captured step(s) once
         self.n_captures = getattr(self, "n_captures", 0) + 1
         return g

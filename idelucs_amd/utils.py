@@ -844,16 +844,26 @@ def build_feature_store(sequence_file, n_mimics, k=6, reduce=False, rng=None, se
             row = _L.idl_row_len(mode, k)
             feats = feature_buffer(din.n, row)
             q.append(time.perf_counter())
-            # the sites into their slots WITHOUT reading the overflow flag back: that wait held the host for the generator's 0.5 ms
-            # with the vectoriser not yet enqueued.  The flag is read when everything is queued (an item beyond its slot: expected
-            # sites + 10 sigma + 32 -- never seen); then the exact two-pass protocol redoes the build
+            # the sites into their slots WITHOUT waiting for the overflow flag: that wait held the host for the generator's 0.5 ms
+            # with the vectoriser not yet enqueued.  The flag travels to pinned memory and is read when everything is queued (an
+            # item beyond its slot: expected sites + 10 sigma + 32 -- never seen); then the exact two-pass protocol redoes the build.
+            # Nothing here waits for the vectoriser: the caller's next launches queue behind it
             edits, edit_off = _philox_edits(din, [t.spec() for t in tfs], seed, sync=False)
+            flag = getattr(edits, "overflow_flag", None)
+            if flag is not None:               # on its way to pinned memory behind the generator; looked at below, when it has long arrived
+                if "flag" not in _ARENAS:
+                    _ARENAS["flag"] = torch.zeros(1, dtype=torch.int32, pin_memory=True)
+                _ARENAS["flag"].copy_(flag.reshape(1), non_blocking=True)
+                flag_ready = torch.cuda.Event()
+                flag_ready.record()
             din.fill()
             q.append(time.perf_counter())
             _vectorise(din, k, mode, _lib.INIT_ONE, _lib.OUT_FREQ_F32, len(tfs), edits, edit_off, feats)
             store = finish(din.ff, din.ff.lengths, feats, din.n)
             din.ff.close()                         # (the names are read out of the handle here, while the device works: FastaFile.from_handle)
-            if bool(edits_overflowed(edits, edit_off)):
+            if flag is not None:
+                flag_ready.synchronize()       # (waits for the site generator, not for the vectoriser behind it)
+            if flag is not None and int(_ARENAS["flag"][0]) != 0:
                 edits, edit_off = _philox_edits(din, [t.spec() for t in tfs], seed, slots=False)
                 _vectorise(din, k, mode, _lib.INIT_ONE, _lib.OUT_FREQ_F32, len(tfs), edits, edit_off, feats)
                 col_stats(feats[0], out=(store.mean, store.scale))

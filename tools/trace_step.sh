@@ -4,7 +4,7 @@
 out=$1; shift
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
-env "$@" rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-e2e --no-fixed-job > $out/log.txt 2>&1
+env "$@" rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-e2e --no-fixed-job --no-k-sweep > $out/log.txt 2>&1
 python3 - $out "$@" <<'PY'
 import csv, glob, sys
 f = glob.glob(sys.argv[1] + "/*/*kernel_stats.csv")[0]

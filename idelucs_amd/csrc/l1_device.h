@@ -35,6 +35,7 @@ struct L1Args {
     // a tile workgroup on every CU
     int n_tiles, tile0, tile1;
     idl_dev::GatherArgs gth;
+    int prio;                   // > 0: the computing waves raise their priority to it (riders of another kind share the CU: train_step.hip's l1_rms_kernel)
 };
 constexpr int RIDER_ROWS = 4;              // == train_step.hip's MID_GATHER_ROWS: the shares of a batch are counted in these tiles
 constexpr int RIDER_TILES = 4;             // gather tiles per rider workgroup (two per 256 threads, one after the other)
@@ -131,6 +132,9 @@ __device__ __forceinline__ void l1_fwd_body(const L1Args &a, const int bid_in, u
         return;                                              // (an ended wave no longer counts towards the barriers of the epilogue)
     }
     // ================= a COMPUTE wave: LDS reads and MFMAs only
+    if (a.prio == 1) __builtin_amdgcn_s_setprio(1);
+    else if (a.prio == 2) __builtin_amdgcn_s_setprio(2);
+    else if (a.prio >= 3) __builtin_amdgcn_s_setprio(3);
     // ---- things the epilogue needs, requested before the loop
     f32x4_t bias[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     f32x4_t w2f[4][2];

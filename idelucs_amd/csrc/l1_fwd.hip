@@ -16,7 +16,8 @@
 // and the four MFMAs that consume it contract over the SAME permuted k set on both sides -- no transpose anywhere.  Operands
 // go global -> LDS by LDS-DMA in whole 256-byte row segments (global_load_lds_dwordx4: 4 rows x 256 B per wave-instruction;
 // fragment-shaped loads straight to registers would be 16 rows x 64 B per instruction and, with no sharing between the four
-// waves, 48 B/clk/CU through the vector-memory path), four K-chunks of 64 resident (96 KB of LDS), the DMAs three chunks ahead of their use and issued one by one between MFMAs, ONE raw s_barrier per chunk
+// waves, 48 B/clk/CU through the vector-memory path), STAGES = 3 K-chunks of 64 resident (73 728 bytes of LDS), the DMAs two chunks
+// ahead of their use, issued by four dedicated loader waves, ONE raw s_barrier per chunk
 // placed so that no read waits on it: the fragments of K-step t + 1 are read into a second register set while the eight MFMAs
 // of step t run, and the barrier that publishes chunk c + 1 sits in front of the LAST step of chunk c.  The LDS image is
 // lane-linear (the DMA's rule), so the bank swizzle is applied to the SOURCE address: 16-byte slot s of row r is fetched from
@@ -97,7 +98,7 @@ static int l1_launch(const float *W1, const float *x, const float *b1, const flo
     IDL_REQUIRE(epi || t1 == t0, "l1_fwd: only the form with the epilogue carries riders");
     if (const int rc = raise_lds_limit(); rc != IDL_OK) return rc;
     const int n_tiles = (H1 / TH) * (m / TR);
-    const L1Args a{W1, x, b1, W2, r1, lat_part, ctl, seed, m, n_in, train, r1_transposed, n_tiles, (int)t0, (int)t1, g};
+    const L1Args a{W1, x, b1, W2, r1, lat_part, ctl, seed, m, n_in, train, r1_transposed, n_tiles, (int)t0, (int)t1, g, 0};
     const dim3 grid((unsigned)(n_tiles + (t1 - t0 + RIDER_TILES - 1) / RIDER_TILES)), block(THREADS);
     if (void *plan = idl::take_plan()) {          // recorded, not launched (idl_plan_begin): the batched form has the epilogue
         IDL_REQUIRE(epi, "l1_fwd: only the form with the epilogue can be recorded");

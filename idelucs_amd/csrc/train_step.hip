@@ -1647,7 +1647,8 @@ int idl_l1_fwd_rms(const float *W1, const float *x, int m, int n_in, float *r1_t
     IDL_REQUIRE(W1 && x && r1_transposed && idl_l1_fwd_supported(m, l1_dev::H1, n_in), "l1_fwd_rms: Linear(n_in, 512), m % 32 == 0, n_in % 64 == 0, n_in >= 192");
     IDL_REQUIRE((((uintptr_t)W1 | (uintptr_t)x | (uintptr_t)r1_transposed) & 15u) == 0, "l1_fwd_rms: buffers must be 16-byte aligned");
     const int n_tiles = (l1_dev::H1 / l1_dev::TH) * (m / l1_dev::TR);
-    const l1_dev::L1Args l{W1, x, nullptr, nullptr, r1_transposed, nullptr, nullptr, 0, m, n_in, 0, 1, n_tiles, 0, 0, idl_dev::GatherArgs{}};
+    static const int prio = [] { const char *e = getenv("IDELUCS_L1_PRIO"); return e ? atoi(e) : 0; }();     // (A/B knob: measured)
+    const l1_dev::L1Args l{W1, x, nullptr, nullptr, r1_transposed, nullptr, nullptr, 0, m, n_in, 0, 1, n_tiles, 0, 0, idl_dev::GatherArgs{}, prio};
     idl_dev::GatherArgs g{};
     return rmsprop_launch(count, params, grads, grad_parts, square_avg, sizes, hyper, ctl, batch_advance, loss_rows, loss_m, w_nce, w_iic, out, g,
                           stream, wg_index, wg_dy, wg_x, wg_m, wg_n_out, wg_n_in, wg_grad, wg_x_transposed, nullptr, -1, &l, w1_index);

@@ -59,7 +59,8 @@ class _Buffers:
         self._r1_other = None
         self._H1 = H1
         self.lat = torch.empty((m, H2), **f32)
-        self.lat_part = torch.empty((_L.idl_l1_fwd_parts(), m, H2), **f32)      # idl_l1_fwd: partial sums of r1 W2^T per 64-unit tile of the hidden layer
+        self._lat_part = None                         # idl_l1_fwd with its epilogue (opt-in): made on first use
+        self._dims = (m, H2, dev)
         self.f = torch.empty((m, H2), **f32)
         self.inv = torch.empty((m,), **f32)
         self.r2 = torch.empty((m, H2), **f32)
@@ -87,6 +88,14 @@ def _r1_of(bf, xi):
     if bf._r1_other is None:
         bf._r1_other = torch.empty_like(bf.r1)
     return bf._r1_other
+
+
+def _lat_part_of(bf):
+    """idl_l1_fwd's partial sums of r1 W2^T per 64-unit tile of the hidden layer (the opt-in IDELUCS_L1_FUSED=1 path only)."""
+    if bf._lat_part is None:
+        m, H2, dev = bf._dims
+        bf._lat_part = torch.empty((_L.idl_l1_fwd_parts(), m, H2), dtype=torch.float32, device=dev)
+    return bf._lat_part
 
 
 class _Recorder:
@@ -269,7 +278,7 @@ class FusedLinearTrainer:
         elif l1:    # own tiles: r1^T = Dropout(ReLU(W1 x^T + b1)) and the partial sums of lat = r1 W2^T straight from the accumulators
             st = next_from      # ... with shares [0, g1) of the next batch's tiles assembled by riders of the same launch (HBM is idle under it)
             self._k(_L.idl_l1_fwd_gather, _p(self.W1), _p(x), _p(self.b1), _p(self.W2), m, self.F, tr, self.seed, _p(self.ctl), _p(r1), 1,
-                    _p(bf.lat_part),
+                    _p(_lat_part_of(bf)),
                     _p(st.feats), st.n, st.f, st.n * st.f, _p(self._perm), _p(self.ctl[1:]), m // 2, st.n_pairs, m // 2,
                     _p(st.mean), _p(st.scale), _p(st.inv_scale), _p(bf.xs[1 - xi]), 0, self._l1_gather, 8, _stream())
         elif tl and self._l1_bare and self._rec is None and bool(_L.idl_l1_fwd_supported(m, self.H1, self.F)):
@@ -280,7 +289,7 @@ class FusedLinearTrainer:
             torch.addmm(self.b1, x, self.W1.t(), out=r1)
         if early and self._early_split:         # ... and the first half of the next batch's tiles in its spare workgroups
             st = next_from
-            self._k(_L.idl_mid_fwd_gather, _p(bf.lat_part) if l1 else _p(r1), _p(self.b1) if (tl and not l1) else None,
+            self._k(_L.idl_mid_fwd_gather, _p(_lat_part_of(bf)) if l1 else _p(r1), _p(self.b1) if (tl and not l1) else None,
                     2 if l1 else (1 if tl else 0), _p(self.W2), _p(self.b2), _p(self.W3), _p(self.b3),
                     m, C, tr, self.seed, _p(self.ctl),
                     _p(bf.f), _p(bf.inv), _p(bf.r2), _p(bf.z),

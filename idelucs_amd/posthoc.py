@@ -363,6 +363,46 @@ def _core_distances_window(x64, k, device, out, sample=None, seed=0, stats=None,
         blocks = -(-npad // 256)
         per = -(-blocks // shard[1])
         p_lo, p_hi = min(npad, shard[0] * per * 256), min(npad, (shard[0] + 1) * per * 256)
+    sharded = shard is not None and shard[1] > 1
+    failure = None
+    if sharded:
+        #  the ranks add disjoint shards up at positions every rank derives for itself: the order must be the same everywhere
+        # (core_distances_sharded broadcasts rank 0's), and a rank that fails in its share (out of memory) must still reach the
+        # collectives below -- its failure is agreed on first, then every rank raises
+        try:
+            return _core_distances_window_rows(x64, k, device, out, stats, perm, gid, xo, sq, xs_t, sqs, pos, npad, p_lo, p_hi, r_lo, r_hi, S, n, d, shard)
+        except ShardFailed:
+            raise
+        except Exception as err:      # noqa: BLE001 -- whatever it was, the other ranks are waiting
+            failure = err
+            _all_ranks_ok(False, device)
+            raise ShardFailed(f"this rank failed in its share of the core distances: {err!r}") from err
+    return _core_distances_window_rows(x64, k, device, out, stats, perm, gid, xo, sq, xs_t, sqs, pos, npad, p_lo, p_hi, r_lo, r_hi, S, n, d, shard)
+
+
+class ShardFailed(RuntimeError):
+    """A rank of the process group could not do its share of a sharded stage; every rank raises it (core_distances_sharded then
+    leaves the stage to rank 0 alone)."""
+
+
+def _all_ranks_ok(ok, device):
+    """MIN all-reduce of a flag: True when every rank of the group says so."""
+    import torch
+    import torch.distributed as tdist
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device)
+    tdist.all_reduce(t, op=tdist.ReduceOp.MIN)
+    return bool(int(t.item()))
+
+
+def _core_distances_window_rows(x64, k, device, out, stats, perm, gid, xo, sq, xs_t, sqs, pos, npad, p_lo, p_hi, r_lo, r_hi, S, n, d, shard):
+    """The row part of _core_distances_window: brackets, window pass and selection of the padded rows [p_lo, p_hi), then (sharded) the
+    sum over the ranks."""
+    import ctypes
+    import math
+    import torch
+    from . import _lib
+    L = _lib.lib
+    vp = ctypes.c_void_p
     mine = torch.nonzero((pos >= p_lo) & (pos < p_hi)).squeeze(1)            # positions (memory order) whose padded row is this rank's
     # the bracket of every own row, from the float64 distances to the sampled columns
     lo_all = torch.full((n,), -1.0, dtype=torch.float32, device=device)
@@ -404,6 +444,8 @@ def _core_distances_window(x64, k, device, out, sample=None, seed=0, stats=None,
             stats["kept_max"] = max(stats.get("kept_max", 0), int(cnt_in[:rows].max()))
     if shard is not None and shard[1] > 1:                      # the other ranks' rows: zeros here, theirs there
         import torch.distributed as tdist
+        if not _all_ranks_ok(True, device):                     # (a rank that failed above says so here: nobody waits in the sums below)
+            raise ShardFailed("another rank failed in its share of the core distances")
         core_p[:p_lo] = 0.0; core_p[p_hi:] = 0.0
         status_p[:p_lo] = 0; status_p[p_hi:] = 0
         tdist.all_reduce(core_p)
@@ -508,7 +550,8 @@ def hdbscan_device(points, min_cluster_size, device=None, stats=None, core=None,
         import warnings
         from sklearn.cluster import HDBSCAN
         warnings.warn(f"idelucs_amd: sklearn's private HDBSCAN tree code is not importable ({err}); running sklearn.cluster.HDBSCAN on the host")
-        cl = HDBSCAN(min_cluster_size=max(int(min_cluster_size), 2)).fit(np.asarray(points, dtype=np.float64))
+        kk = max(int(min_cluster_size), 2)     # (min_samples as the device path takes it: IDELUCS_HDBSCAN_RANK -- ADVICE r4)
+        cl = HDBSCAN(min_cluster_size=kk, min_samples=min(core_neighbour_rank(kk), len(points))).fit(np.asarray(points, dtype=np.float64))
         return cl.labels_, cl.probabilities_
     from . import _lib
     L = _lib.lib
@@ -593,7 +636,7 @@ def hdbscan_device(points, min_cluster_size, device=None, stats=None, core=None,
         import warnings
         from sklearn.cluster import HDBSCAN
         warnings.warn(f"idelucs_amd: sklearn's private tree_to_labels has another signature ({err}); running sklearn.cluster.HDBSCAN on the host")
-        cl = HDBSCAN(min_cluster_size=k).fit(pts)
+        cl = HDBSCAN(min_cluster_size=k, min_samples=min(core_neighbour_rank(k), n)).fit(pts)
         return cl.labels_, cl.probabilities_
     if stats is not None:
         stats["tree_s"] = time.time() - t0
@@ -616,8 +659,23 @@ def core_distances_sharded(latent, device=None):
     x64 = torch.from_numpy(pts).to(dev)
     k = max(n // 100 + 1, 2)
     use_filter = pts.shape[1] % 4 == 0 and pts.shape[1] <= 64 and n >= MST_FILTER_MIN and os.environ.get("IDELUCS_MST_FILTER", "1") != "0"
-    order = _spatial_order(x64) if use_filter else None            # (the order hdbscan_device will use: same seed, same groups)
-    core = core_distances_device(x64, min(core_neighbour_rank(k), n), dev, order=order, shard=(tdist.get_rank(), tdist.get_world_size()))
+    # the memory order hdbscan_device will use (same seed, same groups) -- rank 0's, broadcast: it comes out of a float64 GEMM + argmin,
+    # and two ranks whose libraries pick different kernels could place a boundary point in different groups.  Without
+    # the filter the window pass builds its own order: the same broadcast
+    rank = tdist.get_rank()
+    if rank == 0:
+        perm, gid = _spatial_order(x64)
+    else:
+        perm = torch.empty(n, dtype=torch.int64, device=dev)
+        gid = torch.empty(n, dtype=torch.int64, device=dev)
+    tdist.broadcast(perm, 0)
+    tdist.broadcast(gid, 0)
+    try:
+        core = core_distances_device(x64, min(core_neighbour_rank(k), n), dev, order=(perm, gid), shard=(rank, tdist.get_world_size()))
+    except ShardFailed as err:
+        import warnings
+        warnings.warn(f"idelucs_amd: sharded core distances abandoned ({err}); rank 0 computes them alone")
+        return None
     return core.cpu().numpy()
 
 

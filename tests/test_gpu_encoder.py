@@ -1157,3 +1157,45 @@ def test_iic_joint_kernel_equals_the_product(m, C):
                                       ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
     want = (z[:m // 2].double().t() @ z[m // 2:].double())
     assert torch.allclose(P0.double(), want, rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("n,use_graph", [(1500, False), (4200, True)])
+def test_tail_riding_in_the_layer1_launch_changes_no_bit(dev, monkeypatch, n, use_graph):
+    """Round 5: by default the layer-1 product runs on this package's own tiles and the optimizer's tail (dW2 tiles, RMSprop on the
+    small tensors, step loss, step counter / batch offset) rides in the NEXT step's layer-1 launch (idl_l1_fwd_rms), a replayed
+    graph ending with its last step's tail as a launch of its own.  Against the same step with the tail where it was -- behind
+    the dW1 tiles of the optimizer launch -- and the same own layer-1 tiles (IDELUCS_TAIL_L1=0, IDELUCS_L1_FUSED=bare): every
+    product is formed by the same instructions in the same order, so a whole epoch (8 or 24 full batches + a partial one,
+    dropout on) leaves the SAME bits in every parameter, every running average, the loss sum and the counters."""
+    import copy
+    import torch
+    from idelucs_amd.fused import FusedLinearTrainer
+    store, net0 = _cfg2_store_and_net(dev, n, seed=6, C=20)
+    B = 512
+    out = []
+    for tail, bare in (("1", "0"), ("0", "bare")):
+        monkeypatch.setenv("IDELUCS_TAIL_L1", tail)
+        monkeypatch.setenv("IDELUCS_L1_FUSED", bare)
+        net = copy.deepcopy(net0)
+        tr = FusedLinearTrainer(net, lr=1e-3, weight=0.25, lamb=2.8, seed=5)
+        assert tr._tail_l1 == (tail == "1") and tr._l1_bare == (bare == "bare")
+        gen = torch.Generator(device=dev); gen.manual_seed(123)
+        total, nb = tr.run_epoch(store, B, use_graph=use_graph, generator=gen)
+        total2, _ = tr.run_epoch(store, B, use_graph=use_graph, generator=gen)          # a second epoch: the graph replayed from its start
+        torch.cuda.synchronize()
+        assert tr._pending is None
+        out.append(([p.detach().clone() for p in tr.params], [v.clone() for v in tr.square_avg], total2.item(), tr.ctl.tolist(), tr.out.tolist()))
+    (pa, va, ta, ca, oa), (pb, vb, tb, cb, ob) = out
+    assert ca == cb and ta == tb and oa == ob
+    for a, b in zip(pa + va, pb + vb):
+        assert torch.equal(a, b)
+    # a step taken alone (tests, callers outside run_epoch) is complete when it returns: nothing stays pending
+    monkeypatch.setenv("IDELUCS_TAIL_L1", "1"); monkeypatch.setenv("IDELUCS_L1_FUSED", "0")
+    tr = FusedLinearTrainer(copy.deepcopy(net0), lr=1e-3, weight=0.25, lamb=2.8, seed=5)
+    tr._perm = torch.randperm(store.n_pairs, device=dev)
+    bf = tr.buffers(2 * B)
+    tr._gather(store, bf)
+    before = [p.detach().clone() for p in tr.params]
+    tr._full_step(store, bf, pipelined=True)
+    torch.cuda.synchronize()
+    assert tr._pending is None and tr.ctl.tolist() == [1, B] and all(not torch.equal(a, b) for a, b in zip(before, tr.params))

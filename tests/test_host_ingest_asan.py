@@ -17,9 +17,24 @@ ENV = dict(os.environ, ASAN_OPTIONS="abort_on_error=0:detect_leaks=1:halt_on_err
            LSAN_OPTIONS="suppressions=" + os.path.join(ROOT, "tests", "asan", "lsan.supp"))
 
 
+def _sanitizers_usable():
+    """g++ can build AND run a trivial -fsanitize=address,undefined program (the runtimes are separate packages)."""
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        src, exe = os.path.join(d, "t.cpp"), os.path.join(d, "t")
+        open(src, "w").write("int main() { return 0; }\n")
+        r = subprocess.run(["g++", "-fsanitize=address,undefined", src, "-o", exe], capture_output=True)
+        return r.returncode == 0 and subprocess.run([exe], capture_output=True).returncode == 0
+
+
 def _build(directory, target):
     if shutil.which("g++") is None or shutil.which("make") is None:
         pytest.skip("no host compiler")
+    rocm = os.environ.get("ROCM", "/opt/rocm")
+    if directory == CSRC and not (os.path.isdir(os.path.join(rocm, "include", "hip")) and glob.glob(os.path.join(rocm, "lib", "libamdhip64.so*"))):
+        pytest.skip("no ROCm headers / libamdhip64 to build the host side against")     # (ADVICE r4: a CPU-only CI box skips, not fails)
+    if not _sanitizers_usable():
+        pytest.skip("the AddressSanitizer / UBSan runtimes are not installed")
     r = subprocess.run(["make", "-C", directory, "asan"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     exe = os.path.join(directory, target)

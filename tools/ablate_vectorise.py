@@ -8,7 +8,7 @@ from idelucs_amd import _lib, utils as U
 from tools.bench_vectorise import synth_input, timeit
 
 dev = torch.device("cuda")
-n, L, k, P = 100000, 10000, 6, 4
+n, L, k, P = 100000, 10000, int(os.environ.get("IDELUCS_ABLATE_K", "6")), 4
 din = synth_input(n, L, dev)
 specs = [t.spec() for t in U.mimic_transforms(P - 1)]
 edits, edit_off = U._philox_edits(din, specs, 7)

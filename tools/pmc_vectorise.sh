@@ -1,10 +1,11 @@
 #!/bin/bash
 # Counters of the vectorise kernel at cfg2 (100 000 x 10 kbp, k = 6, 4 views, device-drawn edits), one rocprofv3 pass per counter
 # group (TCC: FETCH_SIZE takes 3 slots, WRITE_SIZE 2 -- separate passes; no trace domain together with --pmc on this pool).
-#   bash tools/pmc_vectorise.sh <out_dir> [json]
+#   bash tools/pmc_vectorise.sh <out_dir> [json]          (K=4|5|6 in the environment picks k; default 6)
 # Writes <out_dir>/summary.txt and, when a second argument is given, the traffic summary bench.py reads (profiles/*_vectorise_pmc.json).
 set -e
 out=${1:-gpurun_out/pmc}
+export IDELUCS_ABLATE_K=${K:-6}
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 groups=("FETCH_SIZE" "WRITE_SIZE"
@@ -22,8 +23,9 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(out + "/g*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if "vectorise3_kernel" in k: k = "vectorise3_kernel<6>"
-        elif "vectorise2_kernel" in k: k = "vectorise2_kernel<6,false> (second pass: exits at once when v3 left nothing)"
+        K = __import__("os").environ.get("IDELUCS_ABLATE_K", "6")
+        if "vectorise3_kernel" in k: k = f"vectorise3_kernel<{K}>"
+        elif "vectorise2_kernel" in k: k = f"vectorise2_kernel<{K},false> (second pass: exits at once when v3 left nothing)"
         else: continue
         agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 lines = []
@@ -33,14 +35,17 @@ for k, cs in agg.items():
         lines.append(f"   {c:28s} launches={len(v):3d} mean per launch={sum(v)/len(v):.5g}")
 open(out + "/summary.txt", "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
-k3 = agg.get("vectorise3_kernel<6>", {})
+K = int(__import__("os").environ.get("IDELUCS_ABLATE_K", "6"))
+k3 = agg.get(f"vectorise3_kernel<{K}>", {})
 if js and "FETCH_SIZE" in k3 and "WRITE_SIZE" in k3:
     f, w = sum(k3["FETCH_SIZE"]) / len(k3["FETCH_SIZE"]), sum(k3["WRITE_SIZE"]) / len(k3["WRITE_SIZE"])
-    json.dump({"kernel": "vectorise3_kernel<6>", "workload": "cfg2: 100000 x 10000 bp, k=6, 4 views, device-drawn edits (tools/ablate_vectorise.py 0)",
+    alg = 100000 * (2500 + 4 * 4 ** K * 4) / 1e9
+    json.dump({"kernel": f"vectorise3_kernel<{K}>", "workload": f"cfg2's input: 100000 x 10000 bp, k={K}, 4 views, device-drawn edits (tools/ablate_vectorise.py 0)",
+               "algorithmic_gb_per_launch": round(alg, 4),
                "WRITE_SIZE_KB": w, "FETCH_SIZE_KB": f,
                "traffic_gb_per_launch": round((w + 2 * f) * 1024 / 1e9, 3),
                "note": "traffic = WRITE_SIZE + 2 x FETCH_SIZE: on gfx950 FETCH_SIZE reports half the bytes of wide coalesced reads "
-                       "(MI355X_MICROARCH.md, HBM); WRITE_SIZE is exact for 16-byte-per-lane streaming stores.  Algorithmic bytes: 6.8036 GB.",
+                       "(MI355X_MICROARCH.md, HBM); WRITE_SIZE is exact for 16-byte-per-lane streaming stores.",
                "source": "tools/pmc_vectorise.sh (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes; mean over the launches of the run)"},
               open(js, "w"), indent=1)
 PY

@@ -85,6 +85,7 @@ void pack_one(const uint8_t *seq, int64_t len, uint8_t *codes, uint8_t *mask)
 #include <sched.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <functional>
@@ -545,8 +546,31 @@ __attribute__((target("avx512f,avx512bw"))) inline bool pack64_avx512(const uint
     _mm_storeu_si128((__m128i *)w4, _mm512_castsi512_si128(_mm512_permutexvar_epi32(idx, g)));
     return true;
 }
+
+// memchr(p, '\n', n) for the one-pass reader's long sequence lines, with a software prefetch ahead of the scan: the hardware
+// prefetchers stop at every 4 KB page, so a thread streaming a mapping of the page cache takes one full memory latency per page
+// (IDELUCS_PREFETCH = bytes ahead, default 2048; 0 = plain memchr).  The scan is the first touch of the line; the packer behind
+// it reads the cache.
+__attribute__((target("avx512f,avx512bw"))) inline const uint8_t *find_nl_avx512(const uint8_t *p, size_t n, size_t ahead)
+{
+    const __m512i nl = _mm512_set1_epi8('\n');
+    size_t i = 0;
+    for (; i + 64 <= n; i += 64) {
+        _mm_prefetch((const char *)(p + i + ahead), _MM_HINT_T0);
+        const __mmask64 m = _mm512_cmpeq_epi8_mask(_mm512_loadu_si512((const void *)(p + i)), nl);
+        if (m) return p + i + __builtin_ctzll(m);
+    }
+    return i < n ? (const uint8_t *)memchr(p + i, '\n', n - i) : nullptr;
+}
+inline const uint8_t *find_nl(const uint8_t *p, size_t n)
+{
+    static const size_t ahead = [] { const char *e = getenv("IDELUCS_PREFETCH"); const long v = e ? atol(e) : 2048; return (size_t)(v < 0 ? 0 : (v > 65536 ? 65536 : v)); }();
+    if (ahead != 0 && n >= 256 && host_has_avx512()) return find_nl_avx512(p, n, ahead);
+    return (const uint8_t *)memchr(p, '\n', n);
+}
 #else
 #define IDL_HAVE_AVX2_PATH 0
+inline const uint8_t *find_nl(const uint8_t *p, size_t n) { return (const uint8_t *)memchr(p, '\n', n); }
 #endif
 
 // walk_record specialised for counting the cleaned length (check mode)
@@ -983,7 +1007,15 @@ int idl_fasta_parse_pack(const char *path, uint8_t *codes, uint8_t *mask, int64_
     const bool timing = getenv("IDELUCS_INGEST_TIMING") != nullptr;
     auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_0 = now();
-    std::vector<FastOut> outs((size_t)nt);
+    // The file is cut into SLICES (IDELUCS_SLICES per thread, default 4) that the threads take from a counter: the threads of a
+    // shared host do not run at one speed (a core's other hardware thread busy, a time slice lost: with one slice per thread they
+    // finished between 5.4 and 7.6 ms), and the call ends with its slowest.  A slice owns the records whose header line starts in
+    // it and its own region of the arenas, as a thread did.
+    const int per_thread = [] { const char *e = getenv("IDELUCS_SLICES"); const int v = e ? atoi(e) : 4; return v >= 1 && v <= 64 ? v : 4; }();
+    const int ns = nt > 1 ? nt * per_thread : 1;
+    std::vector<FastOut> outs((size_t)ns);
+    std::vector<double> th_begin((size_t)nt, 0.0), th_end((size_t)nt, 0.0);
+    std::atomic<int> next_slice{0};
     // A thread sends what it has packed while it goes on parsing; what is still unsent when it finishes is the copy TAIL every
     // later stage waits for.  Round 4 cut a region into 3 equal pieces: the last third of everything (125 MB at cfg2) left when the
     // parsing was over, 2.6 ms at the link's 48 GB/s (IDELUCS_INGEST_TIMING=2: threads joined 8.0 ms, copies drained 10.6).  The
@@ -991,12 +1023,12 @@ int idl_fasta_parse_pack(const char *path, uint8_t *codes, uint8_t *mask, int64_
     // -- for the same number of calls as four equal pieces: every hipMemcpyAsync takes the stream's lock and ~15 us of host time
     // (8 equal pieces 14.6 ms against 12.3-12.8 for 2-4, 16 pieces 18.9: round 4).  A piece is at most 6 MB (big files: more
     // pieces) and, but for the last, at least 384 KB.  IDELUCS_COPY_DIV=<d> keeps round 4's d equal pieces for A/B runs.
-    const int64_t region_slots = (int64_t)(size / 64) / nt + 1;
+    const int64_t region_slots = (int64_t)(size / 64) / ns + 1;
     const int copy_div = [] { const char *e = getenv("IDELUCS_COPY_DIV"); const int d = e ? atoi(e) : 0; return d >= 1 && d <= 64 ? d : 0; }();
     const std::vector<int> sched = [] {
         std::vector<int> v;
         const char *e = getenv("IDELUCS_COPY_SCHED");
-        for (const char *p = e ? e : "45,75,92"; *p;) {
+        for (const char *p = e ? e : "45,75,92"; *p;) {       // (of a thread's share; with several slices per thread: of each slice, first cut only)
             char *q = nullptr;
             const long x = strtol(p, &q, 10);
             if (q == p) break;
@@ -1030,25 +1062,24 @@ int idl_fasta_parse_pack(const char *path, uint8_t *codes, uint8_t *mask, int64_
         }
     }
 
-    parallel_for(nt, [&](int t) {
-        FastOut &o = outs[(size_t)t];
+    auto do_slice = [&](const int t, const int sl) {
+        FastOut &o = outs[(size_t)sl];
         if (timing) o.t_begin = now();
-        if (t > 0 && caller_dev >= 0 && hipSetDevice(caller_dev) != hipSuccess) { o.copy_failed = 1; return; }
-        const size_t b = size * (size_t)t / (size_t)nt, e = size * (size_t)(t + 1) / (size_t)nt;
-        const int64_t region_lo = cap_slots * t / nt, region_hi = cap_slots * (t + 1) / nt;
+        const size_t b = size * (size_t)sl / (size_t)ns, e = size * (size_t)(sl + 1) / (size_t)ns;
+        const int64_t region_lo = cap_slots * sl / ns, region_hi = cap_slots * (sl + 1) / ns;
         auto line_end = [&](size_t p) -> size_t {
-            const uint8_t *nl = (const uint8_t *)memchr(buf + p, '\n', size - p);
+            const uint8_t *nl = find_nl(buf + p, size - p);
             return nl ? (size_t)(nl - buf) + 1 : size;
         };
         size_t q = b;
         if (b > 0) q = line_end(b - 1);                               // the first line that STARTS in this slice
         // the first header line at or after q (thread 0 also vouches for everything before the file's first header: '#' lines only)
         while (q < size && buf[q] != '>') {
-            if (t == 0) { if (buf[q] != '#') { o.fallback = 1; return; } }
+            if (sl == 0) { if (buf[q] != '#') { o.fallback = 1; return; } }
             else if (q >= e) return;                                  // no record starts in this slice
             q = line_end(q);
         }
-        if (q >= size) { if (t == 0) o.fallback = 1; return; }        // (thread 0: a file without any header line)
+        if (q >= size) { if (sl == 0) o.fallback = 1; return; }       // (slice 0: a file without any header line)
         if (q >= e) return;
         int64_t slot = region_lo, sent = region_lo;
         size_t cut = 0;                                               // next entry of the piece schedule
@@ -1103,15 +1134,23 @@ int idl_fasta_parse_pack(const char *path, uint8_t *codes, uint8_t *mask, int64_
             o.slot.push_back(slot);
             slot += slots;
             if (slot - sent >= COPY_SLOTS) send(slot);
-            else if (!copy_div && cut < sched.size() && (slot - region_lo) * 100 >= region_slots * sched[cut] && slot - sent >= COPY_MIN) {
+            else if (!copy_div && cut < (per_thread > 1 && ns > 1 ? std::min<size_t>(sched.size(), 1) : sched.size()) &&
+                     (slot - region_lo) * 100 >= region_slots * (per_thread > 1 && ns > 1 ? 70 : sched[cut]) && slot - sent >= COPY_MIN) {
                 send(slot);
+                if (per_thread > 1 && ns > 1) cut = sched.size();
                 while (cut < sched.size() && (slot - region_lo) * 100 >= region_slots * sched[cut]) ++cut;
             }
             hs = lp;
         }
         send(slot);
-        o.slot.push_back(slot);                                       // end of this thread's records
+        o.slot.push_back(slot);                                       // end of this slice's records
         if (timing) o.t_end = now();
+    };
+    parallel_for(nt, [&](int t) {
+        if (timing) th_begin[(size_t)t] = now();
+        if (t > 0 && caller_dev >= 0 && hipSetDevice(caller_dev) != hipSuccess) { outs[0].copy_failed = 1; return; }
+        for (int sl = next_slice.fetch_add(1); sl < ns; sl = next_slice.fetch_add(1)) do_slice(t, sl);
+        if (timing) th_end[(size_t)t] = now();
     }, &bind);
     // the caller's stream continues when the other copy streams have drained
     for (size_t i = 1; i < streams.size(); ++i) {
@@ -1120,22 +1159,22 @@ int idl_fasta_parse_pack(const char *path, uint8_t *codes, uint8_t *mask, int64_
     }
     if (timing) {
         double b_max = 0, e_min = 1e300, e_max = 0, snd = 0;
-        int ns = 0;
-        for (const FastOut &o : outs) {
-            if (o.t_end == 0) continue;
-            b_max = std::max(b_max, o.t_begin - t_0); e_min = std::min(e_min, o.t_end - t_0); e_max = std::max(e_max, o.t_end - t_0);
-            snd += o.t_send; ns += o.n_send;
+        int n_calls = 0;
+        for (int t = 0; t < nt; ++t) {
+            if (th_end[(size_t)t] == 0) continue;
+            b_max = std::max(b_max, th_begin[(size_t)t] - t_0); e_min = std::min(e_min, th_end[(size_t)t] - t_0); e_max = std::max(e_max, th_end[(size_t)t] - t_0);
         }
+        for (const FastOut &o : outs) { snd += o.t_send; n_calls += o.n_send; }
         const double t_join = now() - t_0;
         double t_drain = -1;
         // IDELUCS_INGEST_TIMING=2 also waits for the copies here (diagnostic only: the caller overlaps this wait with its own work)
         if (dev_codes != nullptr && atoi(getenv("IDELUCS_INGEST_TIMING")) >= 2 && hipStreamSynchronize((hipStream_t)stream) == hipSuccess) t_drain = now() - t_0;
         fprintf(stderr, "idl_fasta_parse_pack timeline: last thread started %.2f ms, threads finished %.2f .. %.2f, joined %.2f, copies drained %.2f; "
-                        "%d copy calls on %zu stream(s), %.2f ms of host time in them (sum over threads); bound to node %d\n",
-                b_max, e_min, e_max, t_join, t_drain, ns, streams.size(), snd, bind.node);
+                        "%d slices, %d copy calls on %zu stream(s), %.2f ms of host time in them (sum over threads); bound to node %d\n",
+                b_max, e_min, e_max, t_join, t_drain, ns, n_calls, streams.size(), snd, bind.node);
     }
 
-    for (int t = 0; t < nt; ++t) {
+    for (int t = 0; t < ns; ++t) {
         const FastOut &o = outs[(size_t)t];
         if (o.fallback) { delete f; return IDL_FALLBACK; }
         if (o.copy_failed) { delete f; idl::set_error("fasta_parse_pack: hipMemcpyAsync failed: %s", hipGetErrorString(hipGetLastError())); return IDL_ERR_HIP; }
@@ -1150,9 +1189,9 @@ int idl_fasta_parse_pack(const char *path, uint8_t *codes, uint8_t *mask, int64_
         }
     }
     // merge: every thread copies its records to their place in the file's order (prefix of the per-thread counts) and sums its own
-    std::vector<size_t> first((size_t)nt + 1, 0);
-    for (int t = 0; t < nt; ++t) first[(size_t)t + 1] = first[(size_t)t] + outs[(size_t)t].recs.size();
-    const size_t n = first[(size_t)nt];
+    std::vector<size_t> first((size_t)ns + 1, 0);
+    for (int t = 0; t < ns; ++t) first[(size_t)t + 1] = first[(size_t)t] + outs[(size_t)t].recs.size();
+    const size_t n = first[(size_t)ns];
     f->recs.resize(n);
     f->arena_slot.resize(n + 1);
     f->lengths.resize(n);
@@ -1161,9 +1200,9 @@ int idl_fasta_parse_pack(const char *path, uint8_t *codes, uint8_t *mask, int64_
     for (const FastOut &o : outs) if (!o.recs.empty()) last_end = o.slot.back();
     f->arena_slot[n] = last_end;
     struct Part { int64_t bases = 0, slots = 0, names = 0, lo = INT64_MAX, hi = 0, unsent = 0; };
-    std::vector<Part> parts((size_t)nt);
+    std::vector<Part> parts((size_t)ns);
     parallel_for(n >= 4096 ? nt : 1, [&](int t0) {
-        for (int t = t0; t < nt; t += (n >= 4096 ? nt : 1)) {
+        for (int t = t0; t < ns; t += (n >= 4096 ? nt : 1)) {
             const FastOut &o = outs[(size_t)t];
             Part &p = parts[(size_t)t];
             const size_t at = first[(size_t)t];

@@ -48,7 +48,19 @@ def main():
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     from time_ingest import write_fasta
     path = f"/dev/shm/idelucs_ab_{os.getpid()}.fas"
-    write_fasta(path, 100000, 10000)
+    node = os.environ.get("IDL_AB_FILE_NODE")          # write the file from a thread on that NUMA node: its page-cache pages land there
+    if node is not None:
+        cpus = []
+        for part in open(f"/sys/devices/system/node/node{node}/cpulist").read().strip().split(","):
+            a, _, b = part.partition("-")
+            cpus.extend(range(int(a), int(b or a) + 1))
+        before = os.sched_getaffinity(0)
+        os.sched_setaffinity(0, set(cpus) & before)
+        write_fasta(path, 100000, 10000)
+        os.sched_setaffinity(0, before)
+        print(f"# the file's pages: written from NUMA node {node}", flush=True)
+    else:
+        write_fasta(path, 100000, 10000)
     try:
         for spec in (sys.argv[1:] or [""]):
             env = dict(os.environ, IDL_AB_CHILD="1", IDL_AB_FASTA=path, IDELUCS_INGEST_TIMING="1")

@@ -556,7 +556,7 @@ def t_e2e(args, dev, reps=3):
             r = {"ms": 1e3 * (t2 - t0), "ingest_to_features_ms": feat_ms, "epoch_ms": 1e3 * (t2 - t0) - feat_ms,
                  "graph_captures_so_far": getattr(m._fused, "n_captures", 0),
                  "sequences_per_sec": args.n / (t2 - t0), "fasta_bytes": size, "host_threads": U.ingest_threads(),
-                 "reader_numa_node": int(U._L.idl_ingest_numa_node())}
+                 "reader_numa_node": int(U._L.idl_ingest_numa_node()), "file_pages_numa_node": int(U._L.idl_ingest_file_node())}
             if rep > 0:
                 per_rep.append(round(r["ms"], 2))
             if rep > 0 and (best is None or r["ms"] < best["ms"]):

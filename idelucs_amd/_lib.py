@@ -38,6 +38,8 @@ SIGNATURES = {
     "idl_fasta_pack_range": (_int, [_vp, _i64, _i64, _vp, _vp]),
     "idl_ingest_threads": (_int, []),
     "idl_ingest_numa_node": (_int, []),
+    "idl_ingest_file_node": (_int, []),
+    "idl_ingest_probe_file_node": (_int, [_c.c_char_p]),
     "idl_ingest_cpu_plan": (_int, [_int, _int, _vp, _vp]),
     "idl_fasta_parse_pack": (_int, [_c.c_char_p, _vp, _vp, _i64, _vp, _vp, _vp, _c.POINTER(_vp)]),
     "idl_fasta_arena_slots": (_int, [_vp, _vp]),

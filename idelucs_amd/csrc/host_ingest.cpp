@@ -79,6 +79,7 @@ void pack_one(const uint8_t *seq, int64_t len, uint8_t *codes, uint8_t *mask)
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
+#include <sys/syscall.h>
 #include <unistd.h>
 
 #include <pthread.h>
@@ -176,13 +177,14 @@ size_t par_min_bytes()                  // files smaller than this are handled b
     return (size_t)1 << 22;
 }
 
-// ---- NUMA placement of the reader (round 5; VERDICT r4 #1a).  hipHostMalloc puts pinned memory on the node nearest to the current
-// device (ROCr's default without hipHostMallocNumaUser), so the arenas the reader packs into -- and the DMA engine that drains them
-// -- live on the GPU's node; reader threads on the OTHER socket write them across the inter-socket link.  Measured on the pool's
-// 2-socket boxes (profiles/r05_ingest_numa.txt, 1 GB cfg2 file, 32 threads): parse + pack 8.2 ms unbound, 6.9 bound to the GPU's
-// node, 14.6 bound to the other; ingest-to-features 15.3 / 14.1 / 22.8.  The threads of a job that copies to a device are therefore
-// bound to that device's node for the job (workers keep the binding, the caller's own is restored).  IDELUCS_NUMA=off switches it
-// off, IDELUCS_NUMA=<node> forces a node.
+// ---- NUMA placement of the reader (round 5; VERDICT r4 #1a).  Two things have a place: the file's page-cache pages (1 GB read) and
+// the pinned arenas (375 MB written, then read by the DMA engine) -- hipHostMalloc puts pinned memory on the node nearest to the
+// current device (ROCr's default without hipHostMallocNumaUser).  Measured on the pool's 2-socket boxes (profiles/r05_ingest_numa.txt,
+// 1 GB cfg2 file, 32 threads): with file and GPU on one node, parse + pack 8.2 ms unbound, 6.9 bound there, 14.6 bound to the other
+// node; with the file on the other node than the GPU, ingest-to-features 14.4 ms beside the GPU and 10.8 beside the FILE -- reads
+// across the socket link cost, posted writes hardly.  The threads of a job that copies to a device are therefore bound, for the
+// job, to the node of the file's pages (file_numa_node below) and, when the file does not say, to the device's node (workers
+// keep the binding, the caller's own is restored).  IDELUCS_NUMA=off switches it off, =device ignores the file, =<node> forces a node.
 struct CpuBind {
     cpu_set_t set;                      // the node's CPUs open to this process
     std::vector<cpu_set_t> per_thread;  // thread i of a job: the hardware threads of ONE core, cores dealt round-robin over the node's L3 domains
@@ -266,13 +268,14 @@ bool parse_cpulist(const char *path, cpu_set_t *out)
 }
 
 // the CPUs of the NUMA node device `dev` hangs off, within what this thread may run on; .on = false when there is nothing to do
-CpuBind bind_for_device(int dev, int want_threads)
+CpuBind bind_for_device(int dev, int want_threads, int file_node = -1)
 {
     CpuBind b;
     const char *env = getenv("IDELUCS_NUMA");
     if (env && (strcmp(env, "off") == 0 || strcmp(env, "-1") == 0)) return b;
     int node = -1;
     if (env && *env >= '0' && *env <= '9') node = atoi(env);
+    else if (file_node >= 0 && !(env && strcmp(env, "device") == 0)) node = file_node;      // beside the file (IDELUCS_NUMA=device: beside the GPU)
     else {
         char id[64] = {0};
         if (dev < 0 || hipDeviceGetPCIBusId(id, (int)sizeof(id) - 1, dev) != hipSuccess) return b;
@@ -302,6 +305,38 @@ CpuBind bind_for_device(int dev, int want_threads)
 }
 
 int g_last_bind_node = -1;      // what the last job was bound to (idl_ingest_numa_node)
+int g_last_file_node = -1;      // ... and where it found the file's pages (-1: not asked, not resident, spread, or not permitted)
+
+// The NUMA node that holds the page-cache pages of a mapped file, or -1.  64 pages spread over the mapping: those that are
+// resident (mincore: no I/O is started for a cold file) are touched, so that they are in this process's page table, and asked for
+// their node (move_pages with a NULL target only reports; some container runtimes refuse it: -1 then).  A node counts when it
+// holds 3/4 of the resident samples and at least 48 of the 64 were resident.
+// Why it matters (profiles/r05_ingest_numa.txt, a 2-socket box, GPU on node 0, 1 GB cfg2 file): reading the file across the
+// socket link is what costs -- pages on node 0: reader on node 0 10.8 ms ingest-to-features, on node 1 20.0; pages on node 1:
+// reader on node 0 (beside the GPU and the pinned arenas) 14.4 ms, on node 1 (beside the FILE, writing the arenas remotely)
+// 10.8.  The reader therefore goes where the file is, and to the device's node only when the file does not say.
+int file_numa_node(const uint8_t *map, size_t size)
+{
+    const long psz = sysconf(_SC_PAGESIZE);
+    if (psz <= 0 || size < (size_t)psz * 256) return -1;
+    constexpr int S = 64;
+    void *pages[S];
+    int status[S];
+    int n = 0;
+    for (int i = 0; i < S; ++i) {
+        const size_t off = (size / S * (size_t)i) & ~((size_t)psz - 1);
+        unsigned char vec = 0;
+        if (mincore((void *)(map + off), (size_t)psz, &vec) != 0 || !(vec & 1)) continue;
+        (void)*(volatile const uint8_t *)(map + off);
+        pages[n++] = (void *)(map + off);
+    }
+    if (n < 48) return -1;
+    if (syscall(SYS_move_pages, 0, (unsigned long)n, pages, (const int *)nullptr, status, 0) != 0) return -1;
+    int count[64] = {0}, seen = 0;
+    for (int i = 0; i < n; ++i) if (status[i] >= 0 && status[i] < 64) { ++count[status[i]]; ++seen; }
+    for (int node = 0; node < 64; ++node) if (count[node] * 4 >= seen * 3 && seen >= 48) return node;
+    return -1;
+}
 
 // The reader's threads, kept between calls (round 5; VERDICT r4 #1b).  A run calls parallel_for seven times per file (scan, validate,
 // pack, export ...); with std::thread per call that was 31 thread creations each -- ~1 ms of the 8 ms parse at 32 threads, and
@@ -1043,7 +1078,9 @@ int idl_fasta_parse_pack(const char *path, uint8_t *codes, uint8_t *mask, int64_
     // first (a rank of a multi-GPU job is bound to another one, and dev_codes / stream belong to it)
     int caller_dev = -1;
     if (dev_codes != nullptr && hipGetDevice(&caller_dev) != hipSuccess) caller_dev = -1;
-    const CpuBind bind = (nt > 1 && caller_dev >= 0) ? bind_for_device(caller_dev, nt) : CpuBind();
+    g_last_file_node = (nt > 1 && caller_dev >= 0 && !getenv("IDELUCS_NUMA")) ? file_numa_node(buf, size) : -1;
+    CpuBind bind = (nt > 1 && caller_dev >= 0) ? bind_for_device(caller_dev, nt, g_last_file_node) : CpuBind();
+    if (g_last_file_node >= 0 && bind.node != g_last_file_node) bind = bind_for_device(caller_dev, nt);       // (too few CPUs open there: the device's node)
     g_last_bind_node = bind.node;
     const bool sparse_mask = [] { const char *e = getenv("IDELUCS_SPARSE_MASK"); return !(e && atoi(e) == 0); }();
     // copy streams: the caller's, and IDELUCS_COPY_STREAMS - 1 more of this library's own (thread t copies on stream t mod count;
@@ -1170,8 +1207,8 @@ int idl_fasta_parse_pack(const char *path, uint8_t *codes, uint8_t *mask, int64_
         // IDELUCS_INGEST_TIMING=2 also waits for the copies here (diagnostic only: the caller overlaps this wait with its own work)
         if (dev_codes != nullptr && atoi(getenv("IDELUCS_INGEST_TIMING")) >= 2 && hipStreamSynchronize((hipStream_t)stream) == hipSuccess) t_drain = now() - t_0;
         fprintf(stderr, "idl_fasta_parse_pack timeline: last thread started %.2f ms, threads finished %.2f .. %.2f, joined %.2f, copies drained %.2f; "
-                        "%d slices, %d copy calls on %zu stream(s), %.2f ms of host time in them (sum over threads); bound to node %d\n",
-                b_max, e_min, e_max, t_join, t_drain, ns, n_calls, streams.size(), snd, bind.node);
+                        "%d slices, %d copy calls on %zu stream(s), %.2f ms of host time in them (sum over threads); bound to node %d (the file's pages: node %d)\n",
+                b_max, e_min, e_max, t_join, t_drain, ns, n_calls, streams.size(), snd, bind.node, g_last_file_node);
     }
 
     for (int t = 0; t < ns; ++t) {
@@ -1328,6 +1365,23 @@ int idl_fasta_export(const idl_fasta *f, uint8_t *names, int64_t *name_off, int6
 int idl_ingest_threads(void) { return n_threads(); }
 
 int idl_ingest_numa_node(void) { return g_last_bind_node; }
+
+int idl_ingest_file_node(void) { return g_last_file_node; }
+
+int idl_ingest_probe_file_node(const char *path)
+{
+    if (path == nullptr) return -1;
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) return -1;
+    struct stat st;
+    int node = -1;
+    if (fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0) {
+        void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (m != MAP_FAILED) { node = file_numa_node((const uint8_t *)m, (size_t)st.st_size); munmap(m, (size_t)st.st_size); }
+    }
+    close(fd);
+    return node;
+}
 
 int idl_ingest_cpu_plan(int device, int threads, int32_t *first_cpu, int32_t *n_cpus)
 {

@@ -542,3 +542,21 @@ def test_arena_meta_and_deferred_names(tmp_path, monkeypatch):
     _lib.check(_lib.lib.idl_fasta_open(os.fsencode(path), 1, ctypes.byref(h)))
     assert _lib.lib.idl_fasta_arena_meta(h, None, None, None, None) != _lib.IDL_OK
     _lib.lib.idl_fasta_close(h)
+
+
+def test_file_page_node_probe(tmp_path):
+    """Round 5: the reader binds itself beside the FILE's page-cache pages when it can tell where they are (a sample of resident
+    pages asked with move_pages).  A file just written is resident: the probe names a node that exists (or -1 where the runtime
+    refuses the query); a file too small to sample, a missing file: -1."""
+    big = tmp_path / "big.bin"
+    big.write_bytes(os.urandom(4 << 20))
+    node = _lib.lib.idl_ingest_probe_file_node(os.fsencode(str(big)))
+    nodes = []
+    if os.path.isdir("/sys/devices/system/node"):
+        nodes = [int(d[4:]) for d in os.listdir("/sys/devices/system/node") if d.startswith("node") and d[4:].isdigit()]
+    assert node == -1 or node in nodes
+    small = tmp_path / "small.bin"
+    small.write_bytes(b"x" * 1000)
+    assert _lib.lib.idl_ingest_probe_file_node(os.fsencode(str(small))) == -1
+    assert _lib.lib.idl_ingest_probe_file_node(os.fsencode(str(tmp_path / "nope"))) == -1
+    assert _lib.lib.idl_ingest_file_node() in [-1] + nodes

@@ -42,7 +42,7 @@ import torch.distributed as dist
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 matrix peak (v_mfma_f32_32x32x2_f32)
-PMC_PROFILE = "r04_vectorise_pmc.json"     # profiles/: FETCH_SIZE / WRITE_SIZE passes of the vectoriser at cfg2
+PMC_PROFILE = "r05_p_vectorise_pmc_k6.json"     # profiles/: FETCH_SIZE / WRITE_SIZE passes of the vectoriser at cfg2
 
 
 def synth_packed(n, L, dev, seed=12345, n_rate=0.0):
@@ -402,7 +402,7 @@ def cfg5_one_gpu(args, dev, rank, world, passes=2):
 def pmc_traffic_gb():
     """HBM traffic of one vectorise launch at cfg2, GB, from the committed rocprofv3 PMC passes (profiles/, WRITE_SIZE exact
     for 16-B stores, FETCH_SIZE doubled per MI355X_MICROARCH.md: DESIGN.md 4.1); None when the profile is not present."""
-    for name in (PMC_PROFILE, "r03_vectorise_pmc.json", "r02_vectorise_pmc.json"):
+    for name in (PMC_PROFILE, "r04_vectorise_pmc.json", "r03_vectorise_pmc.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as fh:
                 return json.load(fh)["traffic_gb_per_launch"]
@@ -629,7 +629,7 @@ def main():
                     help="voters of the job (default: 1 on one GPU = cfg2; 8 on several GPUs = cfg3's fixed job)")
     ap.add_argument("--with-predict", dest="with_predict", type=int, default=None,
                     help="1: predict + all-gather inside the timed region (default: 0 at N=1 with one voter = BASELINE.md's region; 1 otherwise)")
-    ap.add_argument("--cpu-sample", dest="cpu_sample", type=int, default=12000)
+    ap.add_argument("--cpu-sample", dest="cpu_sample", type=int, default=24000)
     ap.add_argument("--cpu-ref-steps", dest="cpu_ref_steps", type=int, default=2,
                     help="optimizer steps timed (after one untimed step) with the reference's cpu_count()-2 torch threads, scaled to the epoch")
     ap.add_argument("--no-k-sweep", dest="k_sweep", action="store_false", help="skip the k = 4 / k = 5 vectorise-stage rooflines (cfg4)")

@@ -1199,3 +1199,37 @@ def test_tail_riding_in_the_layer1_launch_changes_no_bit(dev, monkeypatch, n, us
     tr._full_step(store, bf, pipelined=True)
     torch.cuda.synchronize()
     assert tr._pending is None and tr.ctl.tolist() == [1, B] and all(not torch.equal(a, b) for a, b in zip(before, tr.params))
+
+
+def test_default_step_contains_no_library_gemm(dev, monkeypatch):
+    """Round 5: the speed of the step's largest forward kernel must not depend on a hipBLASLt build, a TunableOp
+    seed file or its validators.  The default step's launches, by kernel name (torch.profiler): the layer-1 product is
+    l1_fwd_kernel / l1_rms_kernel (own tiles), the weight gradient wgrad_q16_kernel, and NO rocBLAS / hipBLASLt kernel (Cijk_*)
+    runs in a full-batch step -- also with the shipped solutions switched off (IDELUCS_TUNABLEOP_SEED=0), as on a box whose library
+    differs from the seed file's."""
+    import copy
+    import torch
+    from torch.profiler import profile, ProfilerActivity
+    from idelucs_amd.fused import FusedLinearTrainer
+    monkeypatch.setenv("IDELUCS_TUNABLEOP_SEED", "0")
+    store, net0 = _cfg2_store_and_net(dev, 1100, seed=8, C=20)          # 6 full batches + a partial one
+    B = 512
+    tr = FusedLinearTrainer(copy.deepcopy(net0), lr=1e-3, weight=0.25, lamb=2.8, seed=3)
+    gen = torch.Generator(device=dev); gen.manual_seed(1)
+    tr.run_epoch(store, B, use_graph=False, generator=gen)              # warm-up: allocations, library initialisation
+    torch.cuda.synchronize()
+    tr._perm = torch.randperm(store.n_pairs, device=dev)
+    tr.ctl[1] = 0
+    bf = tr.buffers(2 * B)
+    tr._gather(store, bf)
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+        for i in range(4):
+            tr._full_step(store, bf, pipelined=True, xi=i % 2, defer_tail=True)
+        tr.flush_tail()
+        torch.cuda.synchronize()
+    names = [e.name for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA]
+    if not names:
+        pytest.skip("the profiler reported no device kernels on this box")
+    assert any("l1_rms_kernel" in n for n in names) and any("l1_fwd_kernel" in n for n in names), sorted(set(names))
+    assert any("wgrad_q16_kernel" in n for n in names)
+    assert not any("Cijk_" in n for n in names), [n for n in names if "Cijk_" in n][:3]

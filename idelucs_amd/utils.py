@@ -860,7 +860,9 @@ def build_feature_store(sequence_file, n_mimics, k=6, reduce=False, rng=None, se
             q.append(time.perf_counter())
             _vectorise(din, k, mode, _lib.INIT_ONE, _lib.OUT_FREQ_F32, len(tfs), edits, edit_off, feats)
             store = finish(din.ff, din.ff.lengths, feats, din.n)
-            din.ff.close()                         # (the names are read out of the handle here, while the device works: FastaFile.from_handle)
+            # (the names stay in the open handle until somebody asks for them -- FeatureStore.names, FastaFile.names -- or the handle
+            #  goes: reading them out here held the host for ~1 ms right when the caller wants to queue its next launches behind the
+            #  vectoriser; the handle keeps the file's mapping alive, which the reader keeps anyway)
             if flag is not None:
                 flag_ready.synchronize()       # (waits for the site generator, not for the vectoriser behind it)
             if flag is not None and int(_ARENAS["flag"][0]) != 0:

@@ -759,7 +759,417 @@ __global__ void lazy_init_kernel(PrimArgs a, LazyArgs z)
 }
 
 
-struct LazyLayout { int64_t min_reach, source, cand0, cand1, st, tree_p, run_asleep, pas, asleep, upto, minmr, lbp, gmin, galive, total; };
+// ================================================================================================================ several nodes per launch
+// Round 5.  The lazy scan still pays one launch per tree node: 10^6 dependent 12 us launches.  Prim's order is a
+// chain -- node t + 1 is the argmin AFTER node t's update -- but often the chain can be read off in advance.  Let c_1, c_2, ... be
+// the best candidates of the last scan in ascending order (weight, then original number).  c_1 is the next node (when no sleeping
+// group could hold a better point: the stall rule).  c_i (i >= 2) is certain to follow c_1 .. c_{i-1} when
+//   (a) no AWAKE point j outside {c_1 .. c_i} can come to undercut it: whatever the nodes added meanwhile do to min_reach[j], it
+//       stays >= core[j] (mrd >= core[j]), and its old value was no better than c_i's; so  w_i < M_i = the smallest core distance
+//       among the awake points outside the tree other than c_1 .. c_i  suffices (c_i's own weight can only drop: it stays first);
+//   (b) no SLEEPING point can: the sleeping groups' bound after c_1 .. c_{i-1} is >= LB - max_j ||x_{c_j} - x_cur||, because the
+//       ball term of a new node c is >= the ball term of the node added last (cur: it is part of every bound since the census)
+//       less ||x_c - x_cur||;  so  w_i < LB - max_{j < i} ||x_{c_j} - x_cur||  suffices.  (Right after a census no node has met the
+//       bounds yet: one node per launch until one has.)
+// Both are STRICT, so ties never commit ahead.  On a latent of tight clusters the tree, once inside a cluster's core, takes the
+// remaining points nearly in the order of their core distances (min_reach = the point's own core distance, nothing left to
+// update): (a) and (b) hold for whole runs.  A launch is then a pair: lazy_reduce_kernel (one workgroup: the LZ_T best candidates
+// of all workgroups, the bounds, how many may be committed) and lazy_multi_kernel (commits them in order -- the edge of c_i is
+// its stored one or a better one through c_1 .. c_{i-1}, recomputed by the recording workgroup -- and scans all of them over the
+// awake points: every (point, node) pair that could change something gets its exact distance, then each point applies them in the
+// nodes' order with the scan's strict <).  Same tree, edge for edge (tests/test_gpu_knn.py::test_lazy_prim_builds_the_same_tree).
+constexpr int LZ_T = 8;                // candidates a workgroup leaves = nodes a launch may commit
+constexpr int LZ_QCAP = 1024;          // (point, node) pairs a workgroup's exact-distance queue holds; beyond: the owner computes its own
+struct CandK { double w, core; int64_t j, p; };
+struct LazyDec { int m, fresh; long long cp[LZ_T], co[LZ_T]; double cw[LZ_T], cc[LZ_T]; };
+struct LazyMulti {
+    CandK *cand[2];            // [grid * LZ_T] by candidate parity: each workgroup's LZ_T best, ascending
+    double *rest[2];           // [grid]: smallest core distance among the workgroup's awake outside points NOT among its LZ_T
+    LazyDec *dec;              // [2] by launch parity: what lazy_reduce_kernel decided for the launch (fresh: nothing added since the census)
+    int tmax;                  // <= LZ_T (IDELUCS_MST_MULTI)
+};
+
+// (w, j) ascending with an index riding along: the block's best in every thread.  NT threads, scratch of NT / 64 entries each.
+template <int NT>
+__device__ __forceinline__ void block_argmin(double &bw, int64_t &bj, int &bi, double *sw, int64_t *sj, int *si)
+{
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const double ow = __shfl_xor(bw, o, 64);
+        const int64_t oj = __shfl_xor(bj, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (better(ow, oj, bw, bj)) { bw = ow; bj = oj; bi = oi; }
+    }
+    const int tid = threadIdx.x;
+    if ((tid & 63) == 0) { sw[tid >> 6] = bw; sj[tid >> 6] = bj; si[tid >> 6] = bi; }
+    __syncthreads();
+    bw = sw[0]; bj = sj[0]; bi = si[0];
+#pragma unroll
+    for (int w = 1; w < NT / 64; ++w) if (better(sw[w], sj[w], bw, bj)) { bw = sw[w]; bj = sj[w]; bi = si[w]; }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(1024) void lazy_reduce_kernel(PrimArgs a, LazyArgs z, LazyMulti u, int64_t launch, int grid)
+{
+    constexpr int NT = 1024, PER = LZ_T;
+    __shared__ double sw[NT / 64];
+    __shared__ int64_t sj[NT / 64];
+    __shared__ int si[NT / 64];
+    __shared__ CandK chosen[LZ_T];
+    __shared__ double dup[LZ_T], red[NT / 64];
+    const int tid = threadIdx.x, par = (int)(launch & 1), G = z.n_groups;
+    const LazyState S = z.st[par];
+    LazyDec *D = &u.dec[par];
+    if (S.stalled || S.n_tree >= a.n) { if (tid == 0) D->m = 0; return; }
+    const CandK *pc = u.cand[S.cand_par];
+    const int E = grid * LZ_T;                               // <= NT * PER (grid <= 1024)
+    CandK e[PER];
+    bool taken[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int idx = tid * PER + k;
+        e[k] = idx < E ? pc[idx] : CandK{__builtin_inf(), __builtin_inf(), INT64_MAX, 0};
+        taken[k] = false;
+    }
+    // the sleeping groups' bound, the smallest core distance behind the workgroups' lists
+    double lb = __builtin_inf(), rmin = __builtin_inf();
+    for (int g = tid; g < G; g += NT) if (z.asleep[g] == 1) lb = fmin(lb, fmin(z.minmr[g], z.lbp[par * G + g]));
+    for (int g = tid; g < grid; g += NT) rmin = fmin(rmin, u.rest[S.cand_par][g]);
+    auto block_min = [&](double v) {
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) v = fmin(v, __shfl_xor(v, o, 64));
+        if ((tid & 63) == 0) red[tid >> 6] = v;
+        __syncthreads();
+        double r = red[0];
+#pragma unroll
+        for (int w = 1; w < NT / 64; ++w) r = fmin(r, red[w]);
+        __syncthreads();
+        return r;
+    };
+    lb = block_min(lb);
+    rmin = block_min(rmin);
+    // the LZ_T best of everything, in order
+    const int T = u.tmax;
+    for (int r = 0; r < T; ++r) {
+        double bw = __builtin_inf(); int64_t bj = INT64_MAX; int bi = -1;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) if (!taken[k] && better(e[k].w, e[k].j, bw, bj)) { bw = e[k].w; bj = e[k].j; bi = tid * PER + k; }
+        block_argmin<NT>(bw, bj, bi, sw, sj, si);
+        if (bi >= 0 && bi / PER == tid) {
+#pragma unroll
+            for (int k = 0; k < PER; ++k) if (k == bi % PER) { taken[k] = true; chosen[r] = e[k]; }
+        }
+        if (bi < 0 && tid == 0) chosen[r] = CandK{__builtin_inf(), __builtin_inf(), INT64_MAX, 0};
+        __syncthreads();
+    }
+    // the smallest core distance among the entries that were not chosen
+    double umin = __builtin_inf();
+#pragma unroll
+    for (int k = 0; k < PER; ++k) if (!taken[k]) umin = fmin(umin, e[k].core);
+    umin = fmin(block_min(umin), rmin);
+    // how far the candidates are from the node added last (an upper bound): wave r takes candidate r
+    if ((tid >> 6) < T) {
+        const int r = tid >> 6, l = tid & 63;
+        double d2 = 0.0;
+        if (chosen[r].w < __builtin_inf()) {
+            const double t = (double)z.xrow[chosen[r].p * PRIM_FILTER_D + l] - (double)z.xrow[S.cur_p * PRIM_FILTER_D + l];
+            d2 = t * t;
+        }
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) d2 += __shfl_xor(d2, o, 64);
+        if (l == 0) dup[r] = __dsqrt_rn(d2) * (1.0 + 1e-9) + 1e-300;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int m = 0;
+        LazyDec d = *D;
+        if (chosen[0].w < lb) {                              // else: STALL, as the single-node step decides it
+            m = 1;
+            double dmax = dup[0];
+            for (int i = 1; i < T && !d.fresh; ++i) {
+                if (!(chosen[i].w < __builtin_inf())) break;
+                double mi = umin;                             // smallest core among the awake outside points other than c_0 .. c_i
+                for (int k = i + 1; k < T; ++k) mi = fmin(mi, chosen[k].core);
+                if (!(chosen[i].w < mi) || !(chosen[i].w < lb - dmax)) break;
+                m = i + 1;
+                dmax = fmax(dmax, dup[i]);
+            }
+        }
+        d.m = m;
+        for (int i = 0; i < LZ_T; ++i) {
+            const bool on = i < m;
+            d.cp[i] = on ? chosen[i].p : 0; d.co[i] = on ? chosen[i].j : 0; d.cw[i] = on ? chosen[i].w : 0.0; d.cc[i] = on ? chosen[i].core : 0.0;
+        }
+        *D = d;
+        if (m == 0) { LazyState t = S; t.stalled = 1; z.st[par] = t; }      // the step launch behind this one falls through with it
+    }
+}
+
+__global__ __launch_bounds__(PRIM_NT, 2) void lazy_multi_kernel(PrimArgs a, LazyArgs z, LazyMulti u, int64_t launch, int rescan)
+{
+    __shared__ double sw[PRIM_NT / 64];
+    __shared__ int64_t sj[PRIM_NT / 64];
+    __shared__ int si[PRIM_NT / 64];
+    __shared__ double xcs[LZ_T][PRIM_FILTER_D];              // the nodes of this launch
+    __shared__ float up[LZ_T][PRIM_RUNS][PRIM_FILTER_D];     // (x_node - lo_g) / scale_g for the group of each of the workgroup's runs
+    __shared__ double ccs[LZ_T];
+    __shared__ long long cps[LZ_T], cos_[LZ_T];
+    __shared__ int q_n;
+    __shared__ unsigned short q_item[LZ_QCAP];
+    __shared__ double q_val[LZ_QCAP];
+    __shared__ double pair_d[LZ_T * LZ_T];
+    static_assert(PRIM_NT == PRIM_SUB, "one sub-block per workgroup here");
+    const int tid = threadIdx.x;
+    const int64_t n = a.n;
+    const int G = z.n_groups;
+    const int par = (int)(launch & 1);
+    const LazyState S = z.st[par];
+    LazyState *nx = &z.st[par ^ 1];
+    const LazyDec D = u.dec[par];
+    const bool lead = blockIdx.x == 0 && tid == 0;
+    const bool ball_duty = (int)blockIdx.x < G;
+    if (S.stalled || S.n_tree >= n || (!rescan && D.m == 0)) {      // fall through: the state and the bounds are handed on unchanged
+        if (lead) { *nx = S; u.dec[par ^ 1].fresh = D.fresh; }
+        if (ball_duty && tid == 0) z.lbp[(par ^ 1) * G + blockIdx.x] = z.lbp[par * G + blockIdx.x];
+        return;
+    }
+    const int m = rescan ? 1 : D.m;                          // nodes scanned by this launch (a re-scan: the node added last, nothing committed)
+    const int64_t stride = (int64_t)gridDim.x * PRIM_NT;
+    const int64_t p0 = (int64_t)blockIdx.x * PRIM_NT + tid;
+    bool run_on[PRIM_AHEAD];
+    bool any_on = false;
+#pragma unroll
+    for (int i = 0; i < PRIM_AHEAD; ++i) {
+        const int64_t first = (int64_t)blockIdx.x * PRIM_NT + i * stride;
+        run_on[i] = first < n && z.run_asleep[first / PRIM_NT] == 0;
+        any_on |= run_on[i];
+    }
+    CandK *cand_out = u.cand[S.cand_par ^ 1] + (int64_t)blockIdx.x * LZ_T;
+    double *rest_out = u.rest[S.cand_par ^ 1] + blockIdx.x;
+    auto leave_empty = [&]() {
+        if (tid < LZ_T) cand_out[tid] = CandK{__builtin_inf(), __builtin_inf(), INT64_MAX, 0};
+        if (tid == 0) *rest_out = __builtin_inf();
+    };
+    if (!any_on && !ball_duty && blockIdx.x != 0) { leave_empty(); return; }
+    // ---- prologue: the state of the points of the runs that are awake, their codes
+    double mr_a[PRIM_AHEAD], cj_a[PRIM_AHEAD];
+    int64_t o_a[PRIM_AHEAD];
+    bool in_run[PRIM_AHEAD];
+    uint32_t cw[PRIM_AHEAD][PRIM_FILTER_D / 4];
+    float rs[PRIM_AHEAD], run_scale[PRIM_AHEAD];
+    int run_g[PRIM_AHEAD], g_own[PRIM_AHEAD];
+#pragma unroll
+    for (int i = 0; i < PRIM_AHEAD; ++i) {
+        const int64_t p = p0 + i * stride;
+        const bool on = run_on[i] && p < n;
+        mr_a[i] = on ? a.min_reach[p] : -1.0;
+        cj_a[i] = on ? a.core[p] : 0.0;
+        o_a[i] = on ? (int64_t)a.orig[p] : 0;
+        const int64_t first = (int64_t)blockIdx.x * PRIM_NT + i * stride;
+        run_g[i] = run_on[i] ? a.gid[first] : 0;
+        g_own[i] = on ? a.gid[p] : -1;
+        if (on && z.pas[p]) mr_a[i] = -1.0;
+    }
+    {
+        const __amdgpu_buffer_rsrc_t c_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.codes, 0, 0xffffffff, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < PRIM_AHEAD; ++i) {
+            const int64_t p = p0 + i * stride;
+            in_run[i] = mr_a[i] >= 0.0 && g_own[i] == run_g[i];
+            rs[i] = 0.f;
+            run_scale[i] = (float)a.gscale[run_g[i]];
+            if (in_run[i]) {
+                rs[i] = a.resid[p];
+#pragma unroll
+                for (int k = 0; k < PRIM_FILTER_D / 4; ++k) cw[i][k] = __builtin_amdgcn_raw_buffer_load_b32(c_rsrc, (uint32_t)p * 4u, k * (int)n * 4, 0);
+            }
+        }
+    }
+    // ---- the nodes of this launch: position, original number, core distance, coordinates
+    if (tid < LZ_T) {
+        const bool on = tid < m;
+        const long long p = rescan ? S.cur_p : (on ? D.cp[tid] : 0);
+        cps[tid] = on ? p : -1;
+        cos_[tid] = rescan ? S.cur_o : (on ? D.co[tid] : 0);
+        ccs[tid] = on ? a.core[p] : 0.0;
+    }
+    if (tid == 0) q_n = 0;
+    __syncthreads();
+    for (int idx = tid; idx < m * PRIM_FILTER_D; idx += PRIM_NT) xcs[idx >> 6][idx & 63] = (double)z.xrow[cps[idx >> 6] * PRIM_FILTER_D + (idx & 63)];
+    __syncthreads();
+    for (int idx = tid; idx < m * PRIM_RUNS * PRIM_FILTER_D; idx += PRIM_NT) {
+        const int q = idx / (PRIM_RUNS * PRIM_FILTER_D), rr = (idx / PRIM_FILTER_D) % PRIM_RUNS, k = idx % PRIM_FILTER_D;
+        const int64_t first = (int64_t)blockIdx.x * PRIM_NT + rr * stride;
+        const int g = (first < n && z.run_asleep[first / PRIM_NT] == 0) ? a.gid[first] : 0;
+        up[q][rr][k] = (float)((xcs[q][k] - (double)a.glo[(int64_t)g * PRIM_FILTER_D + k]) / a.gscale[g]);
+    }
+    // ---- the recording workgroup: the edges of the committed nodes, in order.  The edge of c_i is the one the scans so far left
+    // (its stored min_reach and source) unless one of c_0 .. c_{i-1} reaches it at a smaller mutual-reachability distance
+    if (blockIdx.x == 0 && !rescan) {
+        for (int pr = tid; pr < m * m; pr += PRIM_NT) {
+            const int k = pr / m, i = pr % m;
+            double v = __builtin_inf();
+            if (k < i) {
+                double acc = 0.0;
+                for (int f = 0; f < PRIM_FILTER_D; ++f) {
+                    // (the scan's arithmetic: the node as double, the point as float32 widened; product and sum each rounded, feature order)
+                    const double t = xcs[k][f] - (double)z.xrow[cps[i] * PRIM_FILTER_D + f];
+                    acc = idl_dev::square_then_add(acc, t);
+                }
+                v = fmax(fmax(ccs[k], ccs[i]), __dsqrt_rn(acc));
+            }
+            pair_d[k * LZ_T + i] = v;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            LazyState t = S;
+            for (int i = 0; i < m; ++i) {
+                double w = D.cw[i];
+                int64_t src = a.source[cps[i]];
+                for (int k = 0; k < i; ++k) if (pair_d[k * LZ_T + i] < w) { w = pair_d[k * LZ_T + i]; src = cos_[k]; }
+                a.mst_cur[t.n_tree - 1] = src; a.mst_next[t.n_tree - 1] = cos_[i]; a.mst_w[t.n_tree - 1] = w;
+                a.min_reach[cps[i]] = -1.0;
+                z.tree_p[t.n_tree] = cps[i];
+                t.n_tree += 1; t.cur_p = cps[i]; t.cur_o = cos_[i]; t.cur_w = w; t.ema = t.ema + (w - t.ema) * (1.0 / 64.0);
+            }
+            t.cand_par = S.cand_par ^ 1;
+            *nx = t;
+            u.dec[par ^ 1].fresh = 0;
+        }
+    } else if (lead) {                                       // a re-scan commits nothing
+        LazyState t = S;
+        t.cand_par = S.cand_par ^ 1;
+        *nx = t;
+        u.dec[par ^ 1].fresh = D.fresh;
+    }
+    // ---- sleeping group g's bound meets the new nodes (workgroup g, its first wave)
+    if (ball_duty && tid < 64) {
+        const int g = blockIdx.x;
+        double lbv = z.lbp[par * G + g];
+        if (!rescan && z.asleep[g] == 1) {
+            for (int q = 0; q < m; ++q) {
+                const double t = xcs[q][tid] - z.gc[(int64_t)g * PRIM_FILTER_D + tid];
+                double d2 = t * t;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) d2 += __shfl_xor(d2, o, 64);
+                const double b = __dsqrt_rn(d2) * (1.0 - 1e-12) - z.gr[g];
+                lbv = fmin(lbv, b > 0.0 ? b : 0.0);
+            }
+        }
+        if (tid == 0) z.lbp[(par ^ 1) * G + g] = lbv;
+    }
+    __syncthreads();
+    if (!any_on) { leave_empty(); return; }
+    // ---- which (point, node) pairs could change something: the floor test, then the 8-bit bound
+    bool act[PRIM_AHEAD];
+    unsigned mask[PRIM_AHEAD];
+    int base[PRIM_AHEAD];
+    bool own[PRIM_AHEAD];                                    // the pairs did not fit the queue: this thread computes them itself
+#pragma unroll
+    for (int i = 0; i < PRIM_AHEAD; ++i) {
+        const int64_t p = p0 + i * stride;
+        act[i] = mr_a[i] >= 0.0;
+        for (int q = 0; q < m; ++q) if (p == cps[q]) act[i] = false;        // committed in this launch (a re-scan: the node itself)
+        mask[i] = 0u; base[i] = 0; own[i] = false;
+        if (!act[i]) continue;
+        for (int q = 0; q < m; ++q) {
+            const double fl = fmax(ccs[q], cj_a[i]);
+            if (!(fl < mr_a[i])) continue;
+            if (in_run[i]) {
+                float acc = 0.f;
+                const float *uu = up[q][i];
+#pragma unroll
+                for (int k = 0; k < PRIM_FILTER_D / 4; ++k) {
+                    const uint32_t w = cw[i][k];
+                    const float t0 = uu[4 * k] - (float)(w & 255u), t1 = uu[4 * k + 1] - (float)((w >> 8) & 255u);
+                    const float t2 = uu[4 * k + 2] - (float)((w >> 16) & 255u), t3 = uu[4 * k + 3] - (float)(w >> 24);
+                    acc = fmaf(t0, t0, acc); acc = fmaf(t1, t1, acc); acc = fmaf(t2, t2, acc); acc = fmaf(t3, t3, acc);
+                }
+                const double sc = (double)run_scale[i];
+                const double lbq = sc * (double)sqrtf(acc) * (1.0 - 4e-5) - 0.01 * sc - (double)rs[i];      // (prim_step_kernel has the reasoning)
+                if (fmax(fl, lbq) >= mr_a[i]) continue;
+            }
+            mask[i] |= 1u << q;
+        }
+        if (mask[i]) {
+            const int cnt = __popc(mask[i]);
+            base[i] = atomicAdd(&q_n, cnt);
+            if (base[i] + cnt > LZ_QCAP) {
+                own[i] = true;
+                for (int s = base[i]; s < LZ_QCAP; ++s) q_item[s] = 0xFFFFu;
+            } else {
+                int s = base[i];
+                for (int q = 0; q < m; ++q) if (mask[i] >> q & 1u) q_item[s++] = (unsigned short)((tid * PRIM_AHEAD + i) | (q << 10));
+            }
+        }
+    }
+    __syncthreads();
+    const float *xt = (const float *)a.xt;
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)xt, 0, 0xffffffff, 0x00020000);
+    const int col_bytes = (int)n * 4;
+    auto exact = [&](int64_t p, int q, double cj) -> double {        // mrd(node q, point p)
+        double acc = 0.0;
+        uint32_t v[64];
+#pragma unroll
+        for (int k = 0; k < 64; ++k) v[k] = __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, (uint32_t)p * 4u, k * col_bytes, 0);
+#pragma unroll
+        for (int k = 0; k < 64; ++k) {
+            if ((k & 7) == 0) __builtin_amdgcn_sched_barrier(0);
+            const double t = xcs[q][k] - (double)__uint_as_float(v[k]);
+            acc = idl_dev::square_then_add(acc, t);
+        }
+        return fmax(fmax(ccs[q], cj), __dsqrt_rn(acc));
+    };
+    {
+        const int qn = q_n < LZ_QCAP ? q_n : LZ_QCAP;
+        for (int s = tid; s < qn; s += PRIM_NT) {
+            const unsigned it = q_item[s];
+            if (it == 0xFFFFu) continue;
+            const int item = it & 1023, q = it >> 10, t_own = item / PRIM_AHEAD, i_own = item % PRIM_AHEAD;
+            const int64_t p = (int64_t)blockIdx.x * PRIM_NT + t_own + i_own * stride;
+            q_val[s] = exact(p, q, a.core[p]);
+        }
+    }
+    __syncthreads();
+    // ---- every point meets its pairs in the nodes' order, with the scan's strict <
+#pragma unroll
+    for (int i = 0; i < PRIM_AHEAD; ++i) {
+        if (!mask[i]) continue;
+        const int64_t p = p0 + i * stride;
+        double mr = mr_a[i];
+        int64_t src = -1;
+        int s = base[i];
+        for (int q = 0; q < m; ++q) {
+            if (!(mask[i] >> q & 1u)) continue;
+            const double v = own[i] ? exact(p, q, cj_a[i]) : q_val[s++];
+            if (v < mr) { mr = v; src = cos_[q]; }
+        }
+        if (src >= 0) { a.min_reach[p] = mr; a.source[p] = src; mr_a[i] = mr; }
+    }
+    // ---- the workgroup's LZ_T best candidates in order, and the smallest core distance behind them
+    bool used[PRIM_AHEAD] = {false, false, false, false};
+    for (int r = 0; r < LZ_T; ++r) {
+        double bw = __builtin_inf(); int64_t bj = INT64_MAX; int bi = -1;
+#pragma unroll
+        for (int i = 0; i < PRIM_AHEAD; ++i) if (act[i] && !used[i] && better(mr_a[i], o_a[i], bw, bj)) { bw = mr_a[i]; bj = o_a[i]; bi = tid * PRIM_AHEAD + i; }
+        block_argmin<PRIM_NT>(bw, bj, bi, sw, sj, si);
+        if (bi < 0) { if (tid == 0) for (int k = r; k < LZ_T; ++k) cand_out[k] = CandK{__builtin_inf(), __builtin_inf(), INT64_MAX, 0}; break; }
+        if (bi / PRIM_AHEAD == tid) {
+#pragma unroll
+            for (int i = 0; i < PRIM_AHEAD; ++i) if (i == bi % PRIM_AHEAD) { used[i] = true; cand_out[r] = CandK{mr_a[i], cj_a[i], o_a[i], p0 + i * stride}; }
+        }
+    }
+    double rc = __builtin_inf();
+#pragma unroll
+    for (int i = 0; i < PRIM_AHEAD; ++i) if (act[i] && !used[i]) rc = fmin(rc, cj_a[i]);
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) rc = fmin(rc, __shfl_xor(rc, o, 64));
+    if ((tid & 63) == 0) sw[tid >> 6] = rc;
+    __syncthreads();
+    if (tid == 0) *rest_out = fmin(fmin(sw[0], sw[1]), fmin(sw[2], sw[3]));
+}
+
+struct LazyLayout { int64_t min_reach, source, cand0, cand1, candk0, candk1, rest0, rest1, dec, st, tree_p, run_asleep, pas, asleep, upto, minmr, lbp, gmin, galive, total; };
 
 inline LazyLayout lazy_layout(int64_t n, int n_groups)
 {
@@ -769,6 +1179,8 @@ inline LazyLayout lazy_layout(int64_t n, int n_groups)
     auto take = [&](int64_t bytes) { const int64_t at = o; o += align256(bytes); return at; };
     l.min_reach = take(n * 8); l.source = take(n * 8);
     l.cand0 = take((int64_t)g * (int64_t)sizeof(Cand)); l.cand1 = take((int64_t)g * (int64_t)sizeof(Cand));
+    l.candk0 = take((int64_t)g * LZ_T * (int64_t)sizeof(CandK)); l.candk1 = take((int64_t)g * LZ_T * (int64_t)sizeof(CandK));
+    l.rest0 = take((int64_t)g * 8); l.rest1 = take((int64_t)g * 8); l.dec = take(2 * (int64_t)sizeof(LazyDec));
     l.st = take(2 * (int64_t)sizeof(LazyState)); l.tree_p = take(n * 8);
     l.run_asleep = take((n + 255) / 256); l.pas = take(n);
     l.asleep = take((int64_t)n_groups * 4); l.upto = take((int64_t)n_groups * 8); l.minmr = take((int64_t)n_groups * 8);
@@ -859,8 +1271,28 @@ int idl_mst_prim_lazy(const void *xt, const float *xrow, const double *core, int
     const int grid = prim_grid(n);
     const unsigned runs = (unsigned)((n + 255) / 256);
     hipLaunchKernelGGL(lazy_init_kernel, dim3(256), dim3(256), 0, st, a, z);
+    // several nodes per launch (IDELUCS_MST_MULTI = 2 .. 8, default 8; 1 or 0: one node per launch, the round-3 kernel)
+    static const int multi_t = [] { const char *e = getenv("IDELUCS_MST_MULTI"); const int v = e ? atoi(e) : LZ_T; return v < 2 ? 0 : (v > LZ_T ? LZ_T : v); }();
+    LazyMulti u{};
+    u.cand[0] = (CandK *)(w + l.candk0); u.cand[1] = (CandK *)(w + l.candk1);
+    u.rest[0] = (double *)(w + l.rest0); u.rest[1] = (double *)(w + l.rest1);
+    u.dec = (LazyDec *)(w + l.dec); u.tmax = multi_t;
+    const int one = 1;
+    auto set_fresh = [&](int par) { return hipMemcpyAsync(&u.dec[par].fresh, &one, sizeof(int), hipMemcpyHostToDevice, st); };
+    auto step = [&](int64_t ln, int rescan) {
+        if (multi_t) {
+            if (!rescan) hipLaunchKernelGGL(lazy_reduce_kernel, dim3(1), dim3(1024), 0, st, a, z, u, ln, grid);
+            hipLaunchKernelGGL(lazy_multi_kernel, dim3(grid), dim3(PRIM_NT), 0, st, a, z, u, ln, rescan);
+        } else {
+            hipLaunchKernelGGL(lazy_step_kernel, dim3(grid), dim3(PRIM_NT), 0, st, a, z, ln, rescan);
+        }
+    };
+    if (multi_t) {
+        IDL_HIP_TRY(hipMemsetAsync(u.dec, 0, 2 * sizeof(LazyDec), st));
+        IDL_HIP_TRY(set_fresh(0)); IDL_HIP_TRY(set_fresh(1));
+    }
     int64_t launch = 0, stalls = 0, censuses = 0;
-    hipLaunchKernelGGL(lazy_step_kernel, dim3(grid), dim3(PRIM_NT), 0, st, a, z, launch, 1); ++launch;       // the first scan: cur = the start
+    step(launch, 1); ++launch;       // the first scan: cur = the start
     // the steps are queued in chunks; after each the host looks at the state: done, stalled, or time for a census
     static const int chunk = getenv("IDELUCS_MST_CHUNK") ? atoi(getenv("IDELUCS_MST_CHUNK")) : 512;
     static const int64_t census_every = getenv("IDELUCS_MST_CENSUS") ? atoll(getenv("IDELUCS_MST_CENSUS")) : 16384;
@@ -868,7 +1300,7 @@ int idl_mst_prim_lazy(const void *xt, const float *xrow, const double *core, int
     int64_t last_census = 0, last_stall_at = -1000000, quick = 0, no_sleep_until = 0;
     LazyState S{};
     for (;;) {
-        for (int i = 0; i < chunk; ++i) { hipLaunchKernelGGL(lazy_step_kernel, dim3(grid), dim3(PRIM_NT), 0, st, a, z, launch, 0); ++launch; }
+        for (int i = 0; i < chunk; ++i) { step(launch, 0); ++launch; }
         IDL_HIP_TRY(hipMemcpyAsync(&S, z.st + (launch & 1), sizeof(S), hipMemcpyDeviceToHost, st));
         IDL_HIP_TRY(hipStreamSynchronize(st));
         if (S.n_tree >= n) break;
@@ -891,7 +1323,8 @@ int idl_mst_prim_lazy(const void *xt, const float *xrow, const double *core, int
                            (sleep_on && S.n_tree >= no_sleep_until) ? 1 : 0);
         hipLaunchKernelGGL(lazy_flags_kernel, dim3(runs), dim3(256), 0, st, a, z);
         if (S.stalled) { S.stalled = 0; IDL_HIP_TRY(hipMemcpyAsync(z.st + (launch & 1), &S, sizeof(S), hipMemcpyHostToDevice, st)); IDL_HIP_TRY(hipStreamSynchronize(st)); }
-        hipLaunchKernelGGL(lazy_step_kernel, dim3(grid), dim3(PRIM_NT), 0, st, a, z, launch, 1); ++launch;   // candidates of the awake set
+        if (multi_t) IDL_HIP_TRY(set_fresh((int)(launch & 1)));        // no node has met the new bounds yet: one node per launch until one has
+        step(launch, 1); ++launch;   // candidates of the awake set
         last_census = S.n_tree;
     }
     IDL_HIP_TRY(hipGetLastError());

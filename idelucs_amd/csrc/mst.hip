@@ -905,7 +905,7 @@ __global__ __launch_bounds__(1024) void lazy_reduce_kernel(PrimArgs a, LazyArgs 
     }
 }
 
-__global__ __launch_bounds__(PRIM_NT, 2) void lazy_multi_kernel(PrimArgs a, LazyArgs z, LazyMulti u, int64_t launch, int rescan)
+__global__ __launch_bounds__(PRIM_NT, 3) void lazy_multi_kernel(PrimArgs a, LazyArgs z, LazyMulti u, int64_t launch, int rescan)
 {
     __shared__ double sw[PRIM_NT / 64];
     __shared__ int64_t sj[PRIM_NT / 64];
@@ -918,6 +918,8 @@ __global__ __launch_bounds__(PRIM_NT, 2) void lazy_multi_kernel(PrimArgs a, Lazy
     __shared__ unsigned short q_item[LZ_QCAP];
     __shared__ double q_val[LZ_QCAP];
     __shared__ double pair_d[LZ_T * LZ_T];
+    __shared__ double cws[LZ_T];
+    __shared__ long long srcs[LZ_T];
     static_assert(PRIM_NT == PRIM_SUB, "one sub-block per workgroup here");
     const int tid = threadIdx.x;
     const int64_t n = a.n;
@@ -925,15 +927,16 @@ __global__ __launch_bounds__(PRIM_NT, 2) void lazy_multi_kernel(PrimArgs a, Lazy
     const int par = (int)(launch & 1);
     const LazyState S = z.st[par];
     LazyState *nx = &z.st[par ^ 1];
-    const LazyDec D = u.dec[par];
+    const LazyDec *Dp = &u.dec[par];                         // (read field by field: a private copy of the record is 66 registers a lane)
+    const int D_m = Dp->m, D_fresh = Dp->fresh;
     const bool lead = blockIdx.x == 0 && tid == 0;
     const bool ball_duty = (int)blockIdx.x < G;
-    if (S.stalled || S.n_tree >= n || (!rescan && D.m == 0)) {      // fall through: the state and the bounds are handed on unchanged
-        if (lead) { *nx = S; u.dec[par ^ 1].fresh = D.fresh; }
+    if (S.stalled || S.n_tree >= n || (!rescan && D_m == 0)) {      // fall through: the state and the bounds are handed on unchanged
+        if (lead) { *nx = S; u.dec[par ^ 1].fresh = D_fresh; }
         if (ball_duty && tid == 0) z.lbp[(par ^ 1) * G + blockIdx.x] = z.lbp[par * G + blockIdx.x];
         return;
     }
-    const int m = rescan ? 1 : D.m;                          // nodes scanned by this launch (a re-scan: the node added last, nothing committed)
+    const int m = rescan ? 1 : D_m;                          // nodes scanned by this launch (a re-scan: the node added last, nothing committed)
     const int64_t stride = (int64_t)gridDim.x * PRIM_NT;
     const int64_t p0 = (int64_t)blockIdx.x * PRIM_NT + tid;
     bool run_on[PRIM_AHEAD];
@@ -988,10 +991,12 @@ __global__ __launch_bounds__(PRIM_NT, 2) void lazy_multi_kernel(PrimArgs a, Lazy
     // ---- the nodes of this launch: position, original number, core distance, coordinates
     if (tid < LZ_T) {
         const bool on = tid < m;
-        const long long p = rescan ? S.cur_p : (on ? D.cp[tid] : 0);
+        const long long p = rescan ? S.cur_p : (on ? Dp->cp[tid] : 0);
         cps[tid] = on ? p : -1;
-        cos_[tid] = rescan ? S.cur_o : (on ? D.co[tid] : 0);
+        cos_[tid] = rescan ? S.cur_o : (on ? Dp->co[tid] : 0);
         ccs[tid] = on ? a.core[p] : 0.0;
+        cws[tid] = (on && !rescan) ? Dp->cw[tid] : 0.0;
+        srcs[tid] = (on && !rescan && blockIdx.x == 0) ? a.source[p] : 0;       // (the recording workgroup: every stored source in one trip)
     }
     if (tid == 0) q_n = 0;
     __syncthreads();
@@ -1024,8 +1029,8 @@ __global__ __launch_bounds__(PRIM_NT, 2) void lazy_multi_kernel(PrimArgs a, Lazy
         if (tid == 0) {
             LazyState t = S;
             for (int i = 0; i < m; ++i) {
-                double w = D.cw[i];
-                int64_t src = a.source[cps[i]];
+                double w = cws[i];
+                int64_t src = srcs[i];
                 for (int k = 0; k < i; ++k) if (pair_d[k * LZ_T + i] < w) { w = pair_d[k * LZ_T + i]; src = cos_[k]; }
                 a.mst_cur[t.n_tree - 1] = src; a.mst_next[t.n_tree - 1] = cos_[i]; a.mst_w[t.n_tree - 1] = w;
                 a.min_reach[cps[i]] = -1.0;
@@ -1040,7 +1045,7 @@ __global__ __launch_bounds__(PRIM_NT, 2) void lazy_multi_kernel(PrimArgs a, Lazy
         LazyState t = S;
         t.cand_par = S.cand_par ^ 1;
         *nx = t;
-        u.dec[par ^ 1].fresh = D.fresh;
+        u.dec[par ^ 1].fresh = D_fresh;
     }
     // ---- sleeping group g's bound meets the new nodes (workgroup g, its first wave)
     if (ball_duty && tid < 64) {
@@ -1063,14 +1068,12 @@ __global__ __launch_bounds__(PRIM_NT, 2) void lazy_multi_kernel(PrimArgs a, Lazy
     // ---- which (point, node) pairs could change something: the floor test, then the 8-bit bound
     bool act[PRIM_AHEAD];
     unsigned mask[PRIM_AHEAD];
-    int base[PRIM_AHEAD];
-    bool own[PRIM_AHEAD];                                    // the pairs did not fit the queue: this thread computes them itself
 #pragma unroll
     for (int i = 0; i < PRIM_AHEAD; ++i) {
         const int64_t p = p0 + i * stride;
         act[i] = mr_a[i] >= 0.0;
         for (int q = 0; q < m; ++q) if (p == cps[q]) act[i] = false;        // committed in this launch (a re-scan: the node itself)
-        mask[i] = 0u; base[i] = 0; own[i] = false;
+        mask[i] = 0u;
         if (!act[i]) continue;
         for (int q = 0; q < m; ++q) {
             const double fl = fmax(ccs[q], cj_a[i]);
@@ -1091,60 +1094,71 @@ __global__ __launch_bounds__(PRIM_NT, 2) void lazy_multi_kernel(PrimArgs a, Lazy
             }
             mask[i] |= 1u << q;
         }
-        if (mask[i]) {
+    }
+    // ---- the exact distances of those pairs, shared out over the workgroup through a queue; a point whose pairs do not fit this
+    // round's queue waits for the next (rare: inside a cluster's core nearly no pair passes the floor test); then every point
+    // meets its pairs in the nodes' order, with the scan's strict <
+    const float *xt = (const float *)a.xt;
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)xt, 0, 0xffffffff, 0x00020000);
+    const int col_bytes = (int)n * 4;
+    for (;;) {
+        int base[PRIM_AHEAD];
+        bool in_q[PRIM_AHEAD];
+        __syncthreads();                                     // (q_n = 0 from the set-up above, or from the end of the previous round)
+#pragma unroll
+        for (int i = 0; i < PRIM_AHEAD; ++i) {
+            in_q[i] = false; base[i] = 0;
+            if (!mask[i]) continue;
             const int cnt = __popc(mask[i]);
             base[i] = atomicAdd(&q_n, cnt);
             if (base[i] + cnt > LZ_QCAP) {
-                own[i] = true;
                 for (int s = base[i]; s < LZ_QCAP; ++s) q_item[s] = 0xFFFFu;
             } else {
+                in_q[i] = true;
                 int s = base[i];
                 for (int q = 0; q < m; ++q) if (mask[i] >> q & 1u) q_item[s++] = (unsigned short)((tid * PRIM_AHEAD + i) | (q << 10));
             }
         }
-    }
-    __syncthreads();
-    const float *xt = (const float *)a.xt;
-    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)xt, 0, 0xffffffff, 0x00020000);
-    const int col_bytes = (int)n * 4;
-    auto exact = [&](int64_t p, int q, double cj) -> double {        // mrd(node q, point p)
-        double acc = 0.0;
-        uint32_t v[64];
-#pragma unroll
-        for (int k = 0; k < 64; ++k) v[k] = __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, (uint32_t)p * 4u, k * col_bytes, 0);
-#pragma unroll
-        for (int k = 0; k < 64; ++k) {
-            if ((k & 7) == 0) __builtin_amdgcn_sched_barrier(0);
-            const double t = xcs[q][k] - (double)__uint_as_float(v[k]);
-            acc = idl_dev::square_then_add(acc, t);
-        }
-        return fmax(fmax(ccs[q], cj), __dsqrt_rn(acc));
-    };
-    {
+        __syncthreads();
         const int qn = q_n < LZ_QCAP ? q_n : LZ_QCAP;
         for (int s = tid; s < qn; s += PRIM_NT) {
             const unsigned it = q_item[s];
             if (it == 0xFFFFu) continue;
             const int item = it & 1023, q = it >> 10, t_own = item / PRIM_AHEAD, i_own = item % PRIM_AHEAD;
             const int64_t p = (int64_t)blockIdx.x * PRIM_NT + t_own + i_own * stride;
-            q_val[s] = exact(p, q, a.core[p]);
-        }
-    }
-    __syncthreads();
-    // ---- every point meets its pairs in the nodes' order, with the scan's strict <
+            const double cjp = a.core[p];
+            double acc = 0.0;
+            uint32_t v[64];
 #pragma unroll
-    for (int i = 0; i < PRIM_AHEAD; ++i) {
-        if (!mask[i]) continue;
-        const int64_t p = p0 + i * stride;
-        double mr = mr_a[i];
-        int64_t src = -1;
-        int s = base[i];
-        for (int q = 0; q < m; ++q) {
-            if (!(mask[i] >> q & 1u)) continue;
-            const double v = own[i] ? exact(p, q, cj_a[i]) : q_val[s++];
-            if (v < mr) { mr = v; src = cos_[q]; }
+            for (int k = 0; k < 64; ++k) v[k] = __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, (uint32_t)p * 4u, k * col_bytes, 0);
+#pragma unroll
+            for (int k = 0; k < 64; ++k) {
+                if ((k & 7) == 0) __builtin_amdgcn_sched_barrier(0);
+                const double t = xcs[q][k] - (double)__uint_as_float(v[k]);
+                acc = idl_dev::square_then_add(acc, t);
+            }
+            q_val[s] = fmax(fmax(ccs[q], cjp), __dsqrt_rn(acc));     // mrd(node q, point p)
         }
-        if (src >= 0) { a.min_reach[p] = mr; a.source[p] = src; mr_a[i] = mr; }
+        __syncthreads();
+        bool left = false;
+#pragma unroll
+        for (int i = 0; i < PRIM_AHEAD; ++i) {
+            if (!mask[i]) continue;
+            if (!in_q[i]) { left = true; continue; }
+            const int64_t p = p0 + i * stride;
+            double mr = mr_a[i];
+            int64_t src = -1;
+            int s = base[i];
+            for (int q = 0; q < m; ++q) {
+                if (!(mask[i] >> q & 1u)) continue;
+                const double v = q_val[s++];
+                if (v < mr) { mr = v; src = cos_[q]; }
+            }
+            if (src >= 0) { a.min_reach[p] = mr; a.source[p] = src; mr_a[i] = mr; }
+            mask[i] = 0u;
+        }
+        if (tid == 0) q_n = 0;
+        if (!__syncthreads_or(left ? 1 : 0)) break;
     }
     // ---- the workgroup's LZ_T best candidates in order, and the smallest core distance behind them
     bool used[PRIM_AHEAD] = {false, false, false, false};

@@ -1002,11 +1002,12 @@ __global__ __launch_bounds__(PRIM_NT, 3) void lazy_multi_kernel(PrimArgs a, Lazy
     __syncthreads();
     for (int idx = tid; idx < m * PRIM_FILTER_D; idx += PRIM_NT) xcs[idx >> 6][idx & 63] = (double)z.xrow[cps[idx >> 6] * PRIM_FILTER_D + (idx & 63)];
     __syncthreads();
-    for (int idx = tid; idx < m * PRIM_RUNS * PRIM_FILTER_D; idx += PRIM_NT) {
-        const int q = idx / (PRIM_RUNS * PRIM_FILTER_D), rr = (idx / PRIM_FILTER_D) % PRIM_RUNS, k = idx % PRIM_FILTER_D;
-        const int64_t first = (int64_t)blockIdx.x * PRIM_NT + rr * stride;
-        const int g = (first < n && z.run_asleep[first / PRIM_NT] == 0) ? a.gid[first] : 0;
-        up[q][rr][k] = (float)((xcs[q][k] - (double)a.glo[(int64_t)g * PRIM_FILTER_D + k]) / a.gscale[g]);
+    {       // one (run, feature) per thread, as in the single-node step; its box corner and scale are loaded once, the nodes loop in LDS
+        static_assert(PRIM_RUNS * 64 == PRIM_NT && PRIM_FILTER_D == 64 && PRIM_AHEAD == 4, "one (run, feature) per thread");
+        const int rr = tid >> 6, k = tid & 63;
+        const int g = rr == 0 ? run_g[0] : rr == 1 ? run_g[1] : rr == 2 ? run_g[2] : run_g[3];
+        const double lo = (double)a.glo[(int64_t)g * PRIM_FILTER_D + k], sc = a.gscale[g];
+        for (int q = 0; q < m; ++q) up[q][rr][k] = (float)((xcs[q][k] - lo) / sc);
     }
     // ---- the recording workgroup: the edges of the committed nodes, in order.  The edge of c_i is the one the scans so far left
     // (its stored min_reach and source) unless one of c_0 .. c_{i-1} reaches it at a smaller mutual-reachability distance
@@ -1016,9 +1017,11 @@ __global__ __launch_bounds__(PRIM_NT, 3) void lazy_multi_kernel(PrimArgs a, Lazy
             double v = __builtin_inf();
             if (k < i) {
                 double acc = 0.0;
+#pragma unroll 8
                 for (int f = 0; f < PRIM_FILTER_D; ++f) {
-                    // (the scan's arithmetic: the node as double, the point as float32 widened; product and sum each rounded, feature order)
-                    const double t = xcs[k][f] - (double)z.xrow[cps[i] * PRIM_FILTER_D + f];
+                    // (the scan's arithmetic: the node as double, the point's float32 widened -- xcs holds exactly that; product and sum
+                    //  each rounded, in feature order)
+                    const double t = xcs[k][f] - xcs[i][f];
                     acc = idl_dev::square_then_add(acc, t);
                 }
                 v = fmax(fmax(ccs[k], ccs[i]), __dsqrt_rn(acc));

@@ -778,13 +778,15 @@ __global__ void lazy_init_kernel(PrimArgs a, LazyArgs z)
 // its stored one or a better one through c_1 .. c_{i-1}, recomputed by the recording workgroup -- and scans all of them over the
 // awake points: every (point, node) pair that could change something gets its exact distance, then each point applies them in the
 // nodes' order with the scan's strict <).  Same tree, edge for edge (tests/test_gpu_knn.py::test_lazy_prim_builds_the_same_tree).
-constexpr int LZ_T = 8;                // candidates a workgroup leaves = nodes a launch may commit
+constexpr int LZ_T = 8;                // nodes a launch may commit
+constexpr int LZ_W = 4;                // candidates a workgroup leaves, in order (a launch stops behind the LAST entry of a full list: the
+                                       // workgroup's next best is not known)
 constexpr int LZ_QCAP = 1024;          // (point, node) pairs a workgroup's exact-distance queue holds; beyond: the owner computes its own
 struct CandK { double w, core; int64_t j, p; };
 struct LazyDec { int m, fresh; long long cp[LZ_T], co[LZ_T]; double cw[LZ_T], cc[LZ_T]; };
 struct LazyMulti {
-    CandK *cand[2];            // [grid * LZ_T] by candidate parity: each workgroup's LZ_T best, ascending
-    double *rest[2];           // [grid]: smallest core distance among the workgroup's awake outside points NOT among its LZ_T
+    CandK *cand[2];            // [grid * LZ_W] by candidate parity: each workgroup's LZ_W best, ascending
+    double *rest[2];           // [grid]: smallest core distance among the workgroup's awake outside points NOT among its LZ_W
     LazyDec *dec;              // [2] by launch parity: what lazy_reduce_kernel decided for the launch (fresh: nothing added since the census)
     int tmax;                  // <= LZ_T (IDELUCS_MST_MULTI)
 };
@@ -809,29 +811,42 @@ __device__ __forceinline__ void block_argmin(double &bw, int64_t &bj, int &bi, d
     __syncthreads();
 }
 
-__global__ __launch_bounds__(1024) void lazy_reduce_kernel(PrimArgs a, LazyArgs z, LazyMulti u, int64_t launch, int grid)
+// wave-wide argmin of (w, j) with an index riding along; every lane gets the result
+__device__ __forceinline__ void wave_argmin(double &bw, int64_t &bj, int &bi)
 {
-    constexpr int NT = 1024, PER = LZ_T;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const double ow = __shfl_xor(bw, o, 64);
+        const int64_t oj = __shfl_xor(bj, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (better(ow, oj, bw, bj)) { bw = ow; bj = oj; bi = oi; }
+    }
+}
+
+// One workgroup of 256 threads; thread t merges the (sorted) lists of workgroups 4 t .. 4 t + 3.
+__global__ __launch_bounds__(256) void lazy_reduce_kernel(PrimArgs a, LazyArgs z, LazyMulti u, int64_t launch, int grid)
+{
+    constexpr int NT = 256, LPT = 4;                         // lists per thread: grid <= 1024 = NT * LPT
     __shared__ double sw[NT / 64];
     __shared__ int64_t sj[NT / 64];
     __shared__ int si[NT / 64];
     __shared__ CandK chosen[LZ_T];
+    __shared__ int cut[LZ_T];                                // 1: the entry was the last of a full list
     __shared__ double dup[LZ_T], red[NT / 64];
     const int tid = threadIdx.x, par = (int)(launch & 1), G = z.n_groups;
     const LazyState S = z.st[par];
     LazyDec *D = &u.dec[par];
     if (S.stalled || S.n_tree >= a.n) { if (tid == 0) D->m = 0; return; }
     const CandK *pc = u.cand[S.cand_par];
-    const int E = grid * LZ_T;                               // <= NT * PER (grid <= 1024)
-    CandK e[PER];
-    bool taken[PER];
+    CandK e[LPT][LZ_W];
+    int head[LPT];
 #pragma unroll
-    for (int k = 0; k < PER; ++k) {
-        const int idx = tid * PER + k;
-        e[k] = idx < E ? pc[idx] : CandK{__builtin_inf(), __builtin_inf(), INT64_MAX, 0};
-        taken[k] = false;
+    for (int q = 0; q < LPT; ++q) {
+        const int wg = tid * LPT + q;
+#pragma unroll
+        for (int k = 0; k < LZ_W; ++k) e[q][k] = wg < grid ? pc[wg * LZ_W + k] : CandK{__builtin_inf(), __builtin_inf(), INT64_MAX, 0};
+        head[q] = 0;
     }
-    // the sleeping groups' bound, the smallest core distance behind the workgroups' lists
     double lb = __builtin_inf(), rmin = __builtin_inf();
     for (int g = tid; g < G; g += NT) if (z.asleep[g] == 1) lb = fmin(lb, fmin(z.minmr[g], z.lbp[par * G + g]));
     for (int g = tid; g < grid; g += NT) rmin = fmin(rmin, u.rest[S.cand_par][g]);
@@ -840,36 +855,50 @@ __global__ __launch_bounds__(1024) void lazy_reduce_kernel(PrimArgs a, LazyArgs 
         for (int o = 1; o < 64; o <<= 1) v = fmin(v, __shfl_xor(v, o, 64));
         if ((tid & 63) == 0) red[tid >> 6] = v;
         __syncthreads();
-        double r = red[0];
-#pragma unroll
-        for (int w = 1; w < NT / 64; ++w) r = fmin(r, red[w]);
+        const double r = fmin(fmin(red[0], red[1]), fmin(red[2], red[3]));
         __syncthreads();
         return r;
     };
     lb = block_min(lb);
     rmin = block_min(rmin);
-    // the LZ_T best of everything, in order
     const int T = u.tmax;
     for (int r = 0; r < T; ++r) {
         double bw = __builtin_inf(); int64_t bj = INT64_MAX; int bi = -1;
 #pragma unroll
-        for (int k = 0; k < PER; ++k) if (!taken[k] && better(e[k].w, e[k].j, bw, bj)) { bw = e[k].w; bj = e[k].j; bi = tid * PER + k; }
-        block_argmin<NT>(bw, bj, bi, sw, sj, si);
-        if (bi >= 0 && bi / PER == tid) {
+        for (int q = 0; q < LPT; ++q) {
 #pragma unroll
-            for (int k = 0; k < PER; ++k) if (k == bi % PER) { taken[k] = true; chosen[r] = e[k]; }
+            for (int k = 0; k < LZ_W; ++k)
+                if (k == head[q] && better(e[q][k].w, e[q][k].j, bw, bj)) { bw = e[q][k].w; bj = e[q][k].j; bi = (tid * LPT + q) * LZ_W + k; }
         }
-        if (bi < 0 && tid == 0) chosen[r] = CandK{__builtin_inf(), __builtin_inf(), INT64_MAX, 0};
+        wave_argmin(bw, bj, bi);
+        if ((tid & 63) == 0) { sw[tid >> 6] = bw; sj[tid >> 6] = bj; si[tid >> 6] = bi; }
+        __syncthreads();
+        bw = sw[0]; bj = sj[0]; bi = si[0];
+#pragma unroll
+        for (int w = 1; w < NT / 64; ++w) if (better(sw[w], sj[w], bw, bj)) { bw = sw[w]; bj = sj[w]; bi = si[w]; }
+        if (bi >= 0 && bi / (LPT * LZ_W) == tid) {
+            const int q = (bi / LZ_W) % LPT, k = bi % LZ_W;
+#pragma unroll
+            for (int qq = 0; qq < LPT; ++qq) {
+#pragma unroll
+                for (int kk = 0; kk < LZ_W; ++kk) if (qq == q && kk == k) { chosen[r] = e[qq][kk]; head[qq] = kk + 1; }
+            }
+            cut[r] = (k == LZ_W - 1) ? 1 : 0;                // (a list of LZ_W finite entries is full: what follows in that workgroup is not listed)
+        }
+        if (bi < 0 && tid == 0) { chosen[r] = CandK{__builtin_inf(), __builtin_inf(), INT64_MAX, 0}; cut[r] = 0; }
         __syncthreads();
     }
-    // the smallest core distance among the entries that were not chosen
+    // the smallest core distance among the listed entries that were not chosen
     double umin = __builtin_inf();
 #pragma unroll
-    for (int k = 0; k < PER; ++k) if (!taken[k]) umin = fmin(umin, e[k].core);
+    for (int q = 0; q < LPT; ++q) {
+#pragma unroll
+        for (int k = 0; k < LZ_W; ++k) if (k >= head[q]) umin = fmin(umin, e[q][k].core);
+    }
     umin = fmin(block_min(umin), rmin);
-    // how far the candidates are from the node added last (an upper bound): wave r takes candidate r
-    if ((tid >> 6) < T) {
-        const int r = tid >> 6, l = tid & 63;
+    // how far the candidates are from the node added last (an upper bound): each wave takes two
+    for (int r = tid >> 6; r < T; r += NT / 64) {
+        const int l = tid & 63;
         double d2 = 0.0;
         if (chosen[r].w < __builtin_inf()) {
             const double t = (double)z.xrow[chosen[r].p * PRIM_FILTER_D + l] - (double)z.xrow[S.cur_p * PRIM_FILTER_D + l];
@@ -882,11 +911,11 @@ __global__ __launch_bounds__(1024) void lazy_reduce_kernel(PrimArgs a, LazyArgs 
     __syncthreads();
     if (tid == 0) {
         int m = 0;
-        LazyDec d = *D;
+        const int fresh = D->fresh;
         if (chosen[0].w < lb) {                              // else: STALL, as the single-node step decides it
             m = 1;
             double dmax = dup[0];
-            for (int i = 1; i < T && !d.fresh; ++i) {
+            for (int i = 1; i < T && !fresh && !cut[i - 1]; ++i) {
                 if (!(chosen[i].w < __builtin_inf())) break;
                 double mi = umin;                             // smallest core among the awake outside points other than c_0 .. c_i
                 for (int k = i + 1; k < T; ++k) mi = fmin(mi, chosen[k].core);
@@ -895,12 +924,11 @@ __global__ __launch_bounds__(1024) void lazy_reduce_kernel(PrimArgs a, LazyArgs 
                 dmax = fmax(dmax, dup[i]);
             }
         }
-        d.m = m;
+        D->m = m;
         for (int i = 0; i < LZ_T; ++i) {
             const bool on = i < m;
-            d.cp[i] = on ? chosen[i].p : 0; d.co[i] = on ? chosen[i].j : 0; d.cw[i] = on ? chosen[i].w : 0.0; d.cc[i] = on ? chosen[i].core : 0.0;
+            D->cp[i] = on ? chosen[i].p : 0; D->co[i] = on ? chosen[i].j : 0; D->cw[i] = on ? chosen[i].w : 0.0; D->cc[i] = on ? chosen[i].core : 0.0;
         }
-        *D = d;
         if (m == 0) { LazyState t = S; t.stalled = 1; z.st[par] = t; }      // the step launch behind this one falls through with it
     }
 }
@@ -908,8 +936,6 @@ __global__ __launch_bounds__(1024) void lazy_reduce_kernel(PrimArgs a, LazyArgs 
 __global__ __launch_bounds__(PRIM_NT, 3) void lazy_multi_kernel(PrimArgs a, LazyArgs z, LazyMulti u, int64_t launch, int rescan)
 {
     __shared__ double sw[PRIM_NT / 64];
-    __shared__ int64_t sj[PRIM_NT / 64];
-    __shared__ int si[PRIM_NT / 64];
     __shared__ double xcs[LZ_T][PRIM_FILTER_D];              // the nodes of this launch
     __shared__ float up[LZ_T][PRIM_RUNS][PRIM_FILTER_D];     // (x_node - lo_g) / scale_g for the group of each of the workgroup's runs
     __shared__ double ccs[LZ_T];
@@ -947,10 +973,10 @@ __global__ __launch_bounds__(PRIM_NT, 3) void lazy_multi_kernel(PrimArgs a, Lazy
         run_on[i] = first < n && z.run_asleep[first / PRIM_NT] == 0;
         any_on |= run_on[i];
     }
-    CandK *cand_out = u.cand[S.cand_par ^ 1] + (int64_t)blockIdx.x * LZ_T;
+    CandK *cand_out = u.cand[S.cand_par ^ 1] + (int64_t)blockIdx.x * LZ_W;
     double *rest_out = u.rest[S.cand_par ^ 1] + blockIdx.x;
     auto leave_empty = [&]() {
-        if (tid < LZ_T) cand_out[tid] = CandK{__builtin_inf(), __builtin_inf(), INT64_MAX, 0};
+        if (tid < LZ_W) cand_out[tid] = CandK{__builtin_inf(), __builtin_inf(), INT64_MAX, 0};
         if (tid == 0) *rest_out = __builtin_inf();
     };
     if (!any_on && !ball_duty && blockIdx.x != 0) { leave_empty(); return; }
@@ -1163,22 +1189,42 @@ __global__ __launch_bounds__(PRIM_NT, 3) void lazy_multi_kernel(PrimArgs a, Lazy
         if (tid == 0) q_n = 0;
         if (!__syncthreads_or(left ? 1 : 0)) break;
     }
-    // ---- the workgroup's LZ_T best candidates in order, and the smallest core distance behind them
+    // ---- the workgroup's LZ_W best candidates in order: every wave picks its own LZ_W (no barrier), one wave merges the four
+    // lists by rank; then the smallest core distance among everything that is not listed
+    __shared__ CandK wl[PRIM_NT / 64][LZ_W];
+    __shared__ int64_t listed[LZ_W];
     bool used[PRIM_AHEAD] = {false, false, false, false};
-    for (int r = 0; r < LZ_T; ++r) {
+    for (int r = 0; r < LZ_W; ++r) {
         double bw = __builtin_inf(); int64_t bj = INT64_MAX; int bi = -1;
 #pragma unroll
-        for (int i = 0; i < PRIM_AHEAD; ++i) if (act[i] && !used[i] && better(mr_a[i], o_a[i], bw, bj)) { bw = mr_a[i]; bj = o_a[i]; bi = tid * PRIM_AHEAD + i; }
-        block_argmin<PRIM_NT>(bw, bj, bi, sw, sj, si);
-        if (bi < 0) { if (tid == 0) for (int k = r; k < LZ_T; ++k) cand_out[k] = CandK{__builtin_inf(), __builtin_inf(), INT64_MAX, 0}; break; }
-        if (bi / PRIM_AHEAD == tid) {
+        for (int i = 0; i < PRIM_AHEAD; ++i) if (act[i] && !used[i] && better(mr_a[i], o_a[i], bw, bj)) { bw = mr_a[i]; bj = o_a[i]; bi = (tid & 63) * PRIM_AHEAD + i; }
+        wave_argmin(bw, bj, bi);
+        if (bi >= 0 && bi / PRIM_AHEAD == (tid & 63)) {
 #pragma unroll
-            for (int i = 0; i < PRIM_AHEAD; ++i) if (i == bi % PRIM_AHEAD) { used[i] = true; cand_out[r] = CandK{mr_a[i], cj_a[i], o_a[i], p0 + i * stride}; }
+            for (int i = 0; i < PRIM_AHEAD; ++i) if (i == bi % PRIM_AHEAD) { used[i] = true; wl[tid >> 6][r] = CandK{mr_a[i], cj_a[i], o_a[i], p0 + i * stride}; }
         }
+        if (bi < 0 && (tid & 63) == 0) wl[tid >> 6][r] = CandK{__builtin_inf(), __builtin_inf(), INT64_MAX, 0};
     }
+    __syncthreads();
+    if (tid < (PRIM_NT / 64) * LZ_W) {                       // 16 lanes of wave 0: an entry each, ranked among the 16 (ties cannot be: j is unique)
+        const CandK me = wl[tid / LZ_W][tid % LZ_W];
+        int rank = 0;
+        for (int k = 0; k < (PRIM_NT / 64) * LZ_W; ++k) {
+            const CandK o = wl[k / LZ_W][k % LZ_W];
+            if (k != tid && (better(o.w, o.j, me.w, me.j) || (o.w == me.w && o.j == me.j && k < tid))) ++rank;     // (empty entries: by position)
+        }
+        if (rank < LZ_W) { cand_out[rank] = me; listed[rank] = me.w < __builtin_inf() ? me.p : -1; }
+    }
+    __syncthreads();
     double rc = __builtin_inf();
 #pragma unroll
-    for (int i = 0; i < PRIM_AHEAD; ++i) if (act[i] && !used[i]) rc = fmin(rc, cj_a[i]);
+    for (int i = 0; i < PRIM_AHEAD; ++i) {
+        const int64_t p = p0 + i * stride;
+        bool in_list = false;
+#pragma unroll
+        for (int k = 0; k < LZ_W; ++k) in_list |= listed[k] == p;
+        if (act[i] && !in_list) rc = fmin(rc, cj_a[i]);
+    }
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) rc = fmin(rc, __shfl_xor(rc, o, 64));
     if ((tid & 63) == 0) sw[tid >> 6] = rc;
@@ -1196,7 +1242,7 @@ inline LazyLayout lazy_layout(int64_t n, int n_groups)
     auto take = [&](int64_t bytes) { const int64_t at = o; o += align256(bytes); return at; };
     l.min_reach = take(n * 8); l.source = take(n * 8);
     l.cand0 = take((int64_t)g * (int64_t)sizeof(Cand)); l.cand1 = take((int64_t)g * (int64_t)sizeof(Cand));
-    l.candk0 = take((int64_t)g * LZ_T * (int64_t)sizeof(CandK)); l.candk1 = take((int64_t)g * LZ_T * (int64_t)sizeof(CandK));
+    l.candk0 = take((int64_t)g * LZ_W * (int64_t)sizeof(CandK)); l.candk1 = take((int64_t)g * LZ_W * (int64_t)sizeof(CandK));
     l.rest0 = take((int64_t)g * 8); l.rest1 = take((int64_t)g * 8); l.dec = take(2 * (int64_t)sizeof(LazyDec));
     l.st = take(2 * (int64_t)sizeof(LazyState)); l.tree_p = take(n * 8);
     l.run_asleep = take((n + 255) / 256); l.pas = take(n);

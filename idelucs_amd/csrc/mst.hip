@@ -1344,7 +1344,7 @@ int idl_mst_prim_lazy(const void *xt, const float *xrow, const double *core, int
     auto set_fresh = [&](int par) { return hipMemcpyAsync(&u.dec[par].fresh, &one, sizeof(int), hipMemcpyHostToDevice, st); };
     auto step = [&](int64_t ln, int rescan) {
         if (multi_t) {
-            if (!rescan) hipLaunchKernelGGL(lazy_reduce_kernel, dim3(1), dim3(1024), 0, st, a, z, u, ln, grid);
+            if (!rescan) hipLaunchKernelGGL(lazy_reduce_kernel, dim3(1), dim3(256), 0, st, a, z, u, ln, grid);
             hipLaunchKernelGGL(lazy_multi_kernel, dim3(grid), dim3(PRIM_NT), 0, st, a, z, u, ln, rescan);
         } else {
             hipLaunchKernelGGL(lazy_step_kernel, dim3(grid), dim3(PRIM_NT), 0, st, a, z, ln, rescan);

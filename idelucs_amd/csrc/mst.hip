@@ -848,8 +848,21 @@ __global__ __launch_bounds__(256) void lazy_reduce_kernel(PrimArgs a, LazyArgs z
         head[q] = 0;
     }
     double lb = __builtin_inf(), rmin = __builtin_inf();
-    for (int g = tid; g < G; g += NT) if (z.asleep[g] == 1) lb = fmin(lb, fmin(z.minmr[g], z.lbp[par * G + g]));
-    for (int g = tid; g < grid; g += NT) rmin = fmin(rmin, u.rest[S.cand_par][g]);
+    {       // (n_groups, grid <= 1024 = 4 per thread; every load of the four turns in flight at once, none behind a test)
+        int sl[4]; double mm[4], lp[4], rr[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int g = tid + t * NT;
+            const int gg = g < G ? g : 0, gw = g < grid ? g : 0;
+            sl[t] = z.asleep[gg]; mm[t] = z.minmr[gg]; lp[t] = z.lbp[par * G + gg]; rr[t] = u.rest[S.cand_par][gw];
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int g = tid + t * NT;
+            if (g < G && sl[t] == 1) lb = fmin(lb, fmin(mm[t], lp[t]));
+            if (g < grid) rmin = fmin(rmin, rr[t]);
+        }
+    }
     auto block_min = [&](double v) {
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) v = fmin(v, __shfl_xor(v, o, 64));
@@ -1130,10 +1143,12 @@ __global__ __launch_bounds__(PRIM_NT, 3) void lazy_multi_kernel(PrimArgs a, Lazy
     const float *xt = (const float *)a.xt;
     const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)xt, 0, 0xffffffff, 0x00020000);
     const int col_bytes = (int)n * 4;
-    for (;;) {
+    bool todo = false;
+#pragma unroll
+    for (int i = 0; i < PRIM_AHEAD; ++i) todo |= mask[i] != 0u;
+    while (__syncthreads_or(todo ? 1 : 0)) {                 // (inside a cluster's core nearly every launch skips this block)
         int base[PRIM_AHEAD];
         bool in_q[PRIM_AHEAD];
-        __syncthreads();                                     // (q_n = 0 from the set-up above, or from the end of the previous round)
 #pragma unroll
         for (int i = 0; i < PRIM_AHEAD; ++i) {
             in_q[i] = false; base[i] = 0;
@@ -1187,7 +1202,7 @@ __global__ __launch_bounds__(PRIM_NT, 3) void lazy_multi_kernel(PrimArgs a, Lazy
             mask[i] = 0u;
         }
         if (tid == 0) q_n = 0;
-        if (!__syncthreads_or(left ? 1 : 0)) break;
+        todo = left;
     }
     // ---- the workgroup's LZ_W best candidates in order: every wave picks its own LZ_W (no barrier), one wave merges the four
     // lists by rank; then the smallest core distance among everything that is not listed

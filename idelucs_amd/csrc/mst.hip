@@ -827,9 +827,6 @@ __device__ __forceinline__ void wave_argmin(double &bw, int64_t &bj, int &bi)
 __global__ __launch_bounds__(256) void lazy_reduce_kernel(PrimArgs a, LazyArgs z, LazyMulti u, int64_t launch, int grid)
 {
     constexpr int NT = 256, LPT = 4;                         // lists per thread: grid <= 1024 = NT * LPT
-    __shared__ double sw[NT / 64];
-    __shared__ int64_t sj[NT / 64];
-    __shared__ int si[NT / 64];
     __shared__ CandK chosen[LZ_T];
     __shared__ int cut[LZ_T];                                // 1: the entry was the last of a full list
     __shared__ double dup[LZ_T], red[NT / 64];
@@ -874,39 +871,52 @@ __global__ __launch_bounds__(256) void lazy_reduce_kernel(PrimArgs a, LazyArgs z
     };
     lb = block_min(lb);
     rmin = block_min(rmin);
+    // ---- the T best of everything, in order: every wave runs its own tournament over its 256 lists (no barrier, no LDS), then
+    // the 4 T winners are ranked by one wave (a round across the whole workgroup cost 1.8 us: shuffles, two barriers, LDS)
     const int T = u.tmax;
+    __shared__ CandK wsel[NT / 64][LZ_T];
+    __shared__ int wcut[NT / 64][LZ_T];
     for (int r = 0; r < T; ++r) {
         double bw = __builtin_inf(); int64_t bj = INT64_MAX; int bi = -1;
 #pragma unroll
         for (int q = 0; q < LPT; ++q) {
 #pragma unroll
             for (int k = 0; k < LZ_W; ++k)
-                if (k == head[q] && better(e[q][k].w, e[q][k].j, bw, bj)) { bw = e[q][k].w; bj = e[q][k].j; bi = (tid * LPT + q) * LZ_W + k; }
+                if (k == head[q] && better(e[q][k].w, e[q][k].j, bw, bj)) { bw = e[q][k].w; bj = e[q][k].j; bi = ((tid & 63) * LPT + q) * LZ_W + k; }
         }
         wave_argmin(bw, bj, bi);
-        if ((tid & 63) == 0) { sw[tid >> 6] = bw; sj[tid >> 6] = bj; si[tid >> 6] = bi; }
-        __syncthreads();
-        bw = sw[0]; bj = sj[0]; bi = si[0];
-#pragma unroll
-        for (int w = 1; w < NT / 64; ++w) if (better(sw[w], sj[w], bw, bj)) { bw = sw[w]; bj = sj[w]; bi = si[w]; }
-        if (bi >= 0 && bi / (LPT * LZ_W) == tid) {
+        if (bi >= 0 && bi / (LPT * LZ_W) == (tid & 63)) {
             const int q = (bi / LZ_W) % LPT, k = bi % LZ_W;
 #pragma unroll
             for (int qq = 0; qq < LPT; ++qq) {
 #pragma unroll
-                for (int kk = 0; kk < LZ_W; ++kk) if (qq == q && kk == k) { chosen[r] = e[qq][kk]; head[qq] = kk + 1; }
+                for (int kk = 0; kk < LZ_W; ++kk) if (qq == q && kk == k) { wsel[tid >> 6][r] = e[qq][kk]; head[qq] = kk + 1; }
             }
-            cut[r] = (k == LZ_W - 1) ? 1 : 0;                // (a list of LZ_W finite entries is full: what follows in that workgroup is not listed)
+            wcut[tid >> 6][r] = (k == LZ_W - 1) ? 1 : 0;     // (a list of LZ_W finite entries is full: what follows in that workgroup is not listed)
         }
-        if (bi < 0 && tid == 0) { chosen[r] = CandK{__builtin_inf(), __builtin_inf(), INT64_MAX, 0}; cut[r] = 0; }
-        __syncthreads();
+        if (bi < 0 && (tid & 63) == 0) { wsel[tid >> 6][r] = CandK{__builtin_inf(), __builtin_inf(), INT64_MAX, 0}; wcut[tid >> 6][r] = 0; }
     }
-    // the smallest core distance among the listed entries that were not chosen
+    __syncthreads();
+    if (tid < (NT / 64) * LZ_T) {                            // 32 lanes: an entry each, ranked among the 4 T (empty entries by position)
+        const int mw = tid / LZ_T, mr = tid % LZ_T;
+        const CandK me = mr < T ? wsel[mw][mr] : CandK{__builtin_inf(), __builtin_inf(), INT64_MAX, 0};
+        int rank = 0;
+        for (int k = 0; k < (NT / 64) * LZ_T; ++k) {
+            const CandK o = (k % LZ_T) < T ? wsel[k / LZ_T][k % LZ_T] : CandK{__builtin_inf(), __builtin_inf(), INT64_MAX, 0};
+            if (k != tid && (better(o.w, o.j, me.w, me.j) || (o.w == me.w && o.j == me.j && k < tid))) ++rank;
+        }
+        if (rank < LZ_T) { chosen[rank] = me; cut[rank] = (mr < T && me.w < __builtin_inf()) ? wcut[mw][mr] : 0; }
+    }
+    __syncthreads();
+    // the smallest core distance among the listed entries that were not chosen: everything strictly behind the T-th
     double umin = __builtin_inf();
+    {
+        const double wT = chosen[T - 1].w; const int64_t jT = chosen[T - 1].j;
 #pragma unroll
-    for (int q = 0; q < LPT; ++q) {
+        for (int q = 0; q < LPT; ++q) {
 #pragma unroll
-        for (int k = 0; k < LZ_W; ++k) if (k >= head[q]) umin = fmin(umin, e[q][k].core);
+            for (int k = 0; k < LZ_W; ++k) if (better(wT, jT, e[q][k].w, e[q][k].j)) umin = fmin(umin, e[q][k].core);
+        }
     }
     umin = fmin(block_min(umin), rmin);
     // how far the candidates are from the node added last (an upper bound): each wave takes two
@@ -1038,8 +1048,11 @@ __global__ __launch_bounds__(PRIM_NT, 3) void lazy_multi_kernel(PrimArgs a, Lazy
         srcs[tid] = (on && !rescan && blockIdx.x == 0) ? a.source[p] : 0;       // (the recording workgroup: every stored source in one trip)
     }
     if (tid == 0) q_n = 0;
-    __syncthreads();
-    for (int idx = tid; idx < m * PRIM_FILTER_D; idx += PRIM_NT) xcs[idx >> 6][idx & 63] = (double)z.xrow[cps[idx >> 6] * PRIM_FILTER_D + (idx & 63)];
+    // (the coordinates straight from the record's positions, beside the loads above: one trip, not two)
+    for (int idx = tid; idx < m * PRIM_FILTER_D; idx += PRIM_NT) {
+        const long long p = rescan ? S.cur_p : Dp->cp[idx >> 6];
+        xcs[idx >> 6][idx & 63] = (double)z.xrow[p * PRIM_FILTER_D + (idx & 63)];
+    }
     __syncthreads();
     {       // one (run, feature) per thread, as in the single-node step; its box corner and scale are loaded once, the nodes loop in LDS
         static_assert(PRIM_RUNS * 64 == PRIM_NT && PRIM_FILTER_D == 64 && PRIM_AHEAD == 4, "one (run, feature) per thread");

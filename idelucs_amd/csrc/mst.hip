@@ -1362,8 +1362,12 @@ int idl_mst_prim_lazy(const void *xt, const float *xrow, const double *core, int
     const int grid = prim_grid(n);
     const unsigned runs = (unsigned)((n + 255) / 256);
     hipLaunchKernelGGL(lazy_init_kernel, dim3(256), dim3(256), 0, st, a, z);
-    // several nodes per launch (IDELUCS_MST_MULTI = 2 .. 8, default 8; 1 or 0: one node per launch, the round-3 kernel)
-    static const int multi_t = [] { const char *e = getenv("IDELUCS_MST_MULTI"); const int v = e ? atoi(e) : LZ_T; return v < 2 ? 0 : (v > LZ_T ? LZ_T : v); }();
+    // several nodes per launch: OPT-IN (IDELUCS_MST_MULTI = 2 .. 8; default: one node per launch, the round-3 kernel).  Measured at
+    // 10^6 points (gpurun_out/r05_z, blobs / tight clusters; the same tree, edge for edge): 214 073 launch pairs instead of
+    // 1 002 049 launches -- 4.7 nodes a pair -- but a pair costs ~75 us (lazy_reduce_kernel 27 + lazy_multi_kernel 30 + two launch
+    // gaps; the single step: 12 + one gap): 16.3-16.8 s against 15.0.  What the pair spends its time on is instruction count, not
+    // memory: a tournament round over (weight, original number, index) is ~350 wave instructions of 64-bit compares and selects.
+    static const int multi_t = [] { const char *e = getenv("IDELUCS_MST_MULTI"); const int v = e ? atoi(e) : 0; return v < 2 ? 0 : (v > LZ_T ? LZ_T : v); }();
     LazyMulti u{};
     u.cand[0] = (CandK *)(w + l.candk0); u.cand[1] = (CandK *)(w + l.candk1);
     u.rest[0] = (double *)(w + l.rest0); u.rest[1] = (double *)(w + l.rest1);

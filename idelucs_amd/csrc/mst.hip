@@ -823,27 +823,51 @@ __device__ __forceinline__ void wave_argmin(double &bw, int64_t &bj, int &bi)
     }
 }
 
-// One workgroup of 256 threads; thread t merges the (sorted) lists of workgroups 4 t .. 4 t + 3.
+// One workgroup of 256 threads; thread t merges the (sorted) lists of workgroups 4 t .. 4 t + 3.  The tournament runs on ONE 64-bit
+// key per entry -- the weight's bit pattern (weights are >= 0: the order of the bits is the order of the values) -- kept in LDS, a
+// list's head a row number; equal weights (rare) are told apart by the original number in a second step.  (The first form carried
+// (weight, number, index) through every compare and shuffle and kept the lists in registers behind predicated selects: 350 wave
+// instructions and 1.6 us a round.)
+__device__ __forceinline__ void wave_min_u64(unsigned long long &k, int &bi)
+{
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned long long ok = __shfl_xor(k, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ok < k || (ok == k && oi < bi)) { k = ok; bi = oi; }
+    }
+}
+
 __global__ __launch_bounds__(256) void lazy_reduce_kernel(PrimArgs a, LazyArgs z, LazyMulti u, int64_t launch, int grid)
 {
-    constexpr int NT = 256, LPT = 4;                         // lists per thread: grid <= 1024 = NT * LPT
+    constexpr int NT = 256, LPT = 4, ROWS = LPT * LZ_W;      // lists per thread: grid <= 1024 = NT * LPT
+    __shared__ unsigned long long keyw[ROWS + 1][NT];        // row q * LZ_W + k: entry k of the thread's list q; the last row: +inf (an exhausted list)
+    __shared__ long long keyj[ROWS + 1][NT];
     __shared__ CandK chosen[LZ_T];
     __shared__ int cut[LZ_T];                                // 1: the entry was the last of a full list
+    __shared__ int wsel[NT / 64][LZ_T];                      // a wave's winners: entry numbers in the candidate buffer, -1: none
     __shared__ double dup[LZ_T], red[NT / 64];
     const int tid = threadIdx.x, par = (int)(launch & 1), G = z.n_groups;
     const LazyState S = z.st[par];
     LazyDec *D = &u.dec[par];
     if (S.stalled || S.n_tree >= a.n) { if (tid == 0) D->m = 0; return; }
     const CandK *pc = u.cand[S.cand_par];
-    CandK e[LPT][LZ_W];
-    int head[LPT];
+    const unsigned long long INF = 0x7FF0000000000000ull;
+    double umin_all = __builtin_inf();                       // smallest core distance among this thread's listed entries, by row
+    double ecore[ROWS];
 #pragma unroll
     for (int q = 0; q < LPT; ++q) {
         const int wg = tid * LPT + q;
 #pragma unroll
-        for (int k = 0; k < LZ_W; ++k) e[q][k] = wg < grid ? pc[wg * LZ_W + k] : CandK{__builtin_inf(), __builtin_inf(), INT64_MAX, 0};
-        head[q] = 0;
+        for (int k = 0; k < LZ_W; ++k) {
+            const CandK e = wg < grid ? pc[wg * LZ_W + k] : CandK{__builtin_inf(), __builtin_inf(), INT64_MAX, 0};
+            keyw[q * LZ_W + k][tid] = (unsigned long long)__double_as_longlong(e.w);
+            keyj[q * LZ_W + k][tid] = e.j;
+            ecore[q * LZ_W + k] = e.core;
+        }
     }
+    keyw[ROWS][tid] = INF; keyj[ROWS][tid] = INT64_MAX;
+    (void)umin_all;
     double lb = __builtin_inf(), rmin = __builtin_inf();
     {       // (n_groups, grid <= 1024 = 4 per thread; every load of the four turns in flight at once, none behind a test)
         int sl[4]; double mm[4], lp[4], rr[4];
@@ -871,41 +895,65 @@ __global__ __launch_bounds__(256) void lazy_reduce_kernel(PrimArgs a, LazyArgs z
     };
     lb = block_min(lb);
     rmin = block_min(rmin);
-    // ---- the T best of everything, in order: every wave runs its own tournament over its 256 lists (no barrier, no LDS), then
-    // the 4 T winners are ranked by one wave (a round across the whole workgroup cost 1.8 us: shuffles, two barriers, LDS)
+    // ---- every wave's tournament over its 256 lists: no barrier
     const int T = u.tmax;
-    __shared__ CandK wsel[NT / 64][LZ_T];
-    __shared__ int wcut[NT / 64][LZ_T];
+    int head[LPT] = {0, 0, 0, 0};                            // a list's head: its row offset 0 .. LZ_W (LZ_W: exhausted)
     for (int r = 0; r < T; ++r) {
-        double bw = __builtin_inf(); int64_t bj = INT64_MAX; int bi = -1;
+        unsigned long long kb = INF; int bi = 0x7FFFFFFF;
 #pragma unroll
         for (int q = 0; q < LPT; ++q) {
-#pragma unroll
-            for (int k = 0; k < LZ_W; ++k)
-                if (k == head[q] && better(e[q][k].w, e[q][k].j, bw, bj)) { bw = e[q][k].w; bj = e[q][k].j; bi = ((tid & 63) * LPT + q) * LZ_W + k; }
+            const int row = head[q] < LZ_W ? q * LZ_W + head[q] : ROWS;
+            const unsigned long long kq = keyw[row][tid];
+            const int iq = ((tid & 63) * LPT + q) * LZ_W + head[q];
+            if (kq < kb || (kq == kb && iq < bi)) { kb = kq; bi = iq; }
         }
-        wave_argmin(bw, bj, bi);
-        if (bi >= 0 && bi / (LPT * LZ_W) == (tid & 63)) {
-            const int q = (bi / LZ_W) % LPT, k = bi % LZ_W;
+        unsigned long long km = kb; int bm = bi;
+        wave_min_u64(km, bm);
+        if (km >= INF) {                                     // nothing left in this wave
+            if ((tid & 63) == 0) for (int rr2 = r; rr2 < T; ++rr2) wsel[tid >> 6][rr2] = -1;
+            break;
+        }
+        // equal weights (two heads of one lane, or of several): the smallest original number among them goes first
+        int cnt = 0;
 #pragma unroll
-            for (int qq = 0; qq < LPT; ++qq) {
+        for (int q = 0; q < LPT; ++q) {
+            const int row = head[q] < LZ_W ? q * LZ_W + head[q] : ROWS;
+            cnt += keyw[row][tid] == km ? 1 : 0;
+        }
+        int winner = bm;
+        if (__ballot(cnt >= 2) != 0ull || __popcll(__ballot(cnt >= 1)) > 1) {
+            long long jb = INT64_MAX; int ib = 0x7FFFFFFF;
 #pragma unroll
-                for (int kk = 0; kk < LZ_W; ++kk) if (qq == q && kk == k) { wsel[tid >> 6][r] = e[qq][kk]; head[qq] = kk + 1; }
+            for (int q = 0; q < LPT; ++q) {
+                const int row = head[q] < LZ_W ? q * LZ_W + head[q] : ROWS;
+                if (keyw[row][tid] == km && keyj[row][tid] < jb) { jb = keyj[row][tid]; ib = ((tid & 63) * LPT + q) * LZ_W + head[q]; }
             }
-            wcut[tid >> 6][r] = (k == LZ_W - 1) ? 1 : 0;     // (a list of LZ_W finite entries is full: what follows in that workgroup is not listed)
+            unsigned long long kj = (unsigned long long)jb; int bj2 = ib;      // (original numbers are >= 0)
+            wave_min_u64(kj, bj2);
+            winner = bj2;
         }
-        if (bi < 0 && (tid & 63) == 0) { wsel[tid >> 6][r] = CandK{__builtin_inf(), __builtin_inf(), INT64_MAX, 0}; wcut[tid >> 6][r] = 0; }
+        if (winner / (LPT * LZ_W) == (tid & 63)) {
+            const int q = (winner / LZ_W) % LPT, k = winner % LZ_W;
+            wsel[tid >> 6][r] = (tid * LPT + q) * LZ_W + k;  // (the entry itself is fetched behind the tournament: no load inside it)
+#pragma unroll
+            for (int qq = 0; qq < LPT; ++qq) if (qq == q) head[qq] = k + 1;
+        }
     }
     __syncthreads();
     if (tid < (NT / 64) * LZ_T) {                            // 32 lanes: an entry each, ranked among the 4 T (empty entries by position)
+        __shared__ CandK mrg[(NT / 64) * LZ_T];
         const int mw = tid / LZ_T, mr = tid % LZ_T;
-        const CandK me = mr < T ? wsel[mw][mr] : CandK{__builtin_inf(), __builtin_inf(), INT64_MAX, 0};
+        const int idx = mr < T ? wsel[mw][mr] : -1;
+        const CandK me = idx >= 0 ? pc[idx] : CandK{__builtin_inf(), __builtin_inf(), INT64_MAX, 0};
+        mrg[tid] = me;                                       // (one wave: its LDS writes are seen by its own reads below)
+        __builtin_amdgcn_s_waitcnt(0xc07f);                  // lgkmcnt(0)
         int rank = 0;
         for (int k = 0; k < (NT / 64) * LZ_T; ++k) {
-            const CandK o = (k % LZ_T) < T ? wsel[k / LZ_T][k % LZ_T] : CandK{__builtin_inf(), __builtin_inf(), INT64_MAX, 0};
+            const CandK o = mrg[k];
             if (k != tid && (better(o.w, o.j, me.w, me.j) || (o.w == me.w && o.j == me.j && k < tid))) ++rank;
         }
-        if (rank < LZ_T) { chosen[rank] = me; cut[rank] = (mr < T && me.w < __builtin_inf()) ? wcut[mw][mr] : 0; }
+        // (a list of LZ_W finite entries is full: what follows its last entry in that workgroup is not listed)
+        if (rank < LZ_T) { chosen[rank] = me; cut[rank] = (idx >= 0 && idx % LZ_W == LZ_W - 1) ? 1 : 0; }
     }
     __syncthreads();
     // the smallest core distance among the listed entries that were not chosen: everything strictly behind the T-th
@@ -913,9 +961,9 @@ __global__ __launch_bounds__(256) void lazy_reduce_kernel(PrimArgs a, LazyArgs z
     {
         const double wT = chosen[T - 1].w; const int64_t jT = chosen[T - 1].j;
 #pragma unroll
-        for (int q = 0; q < LPT; ++q) {
-#pragma unroll
-            for (int k = 0; k < LZ_W; ++k) if (better(wT, jT, e[q][k].w, e[q][k].j)) umin = fmin(umin, e[q][k].core);
+        for (int row = 0; row < ROWS; ++row) {
+            const double w = __longlong_as_double((long long)keyw[row][tid]);
+            if (better(wT, jT, w, keyj[row][tid])) umin = fmin(umin, ecore[row]);
         }
     }
     umin = fmin(block_min(umin), rmin);

@@ -196,6 +196,8 @@ class FusedLinearTrainer:
         self._tail_l1 = os.environ.get("IDELUCS_TAIL_L1", "1") != "0"
         self._pending = None                     # (buffers, parity) of the step whose tail has not run yet
         self._perm = None
+        self._perm_free = None                   # recorded behind an epoch's last launch: the permutation buffer may be rewritten
+        self._prep = torch.cuda.Stream(device=self.dev)
         n = len(self.params)
         self._pp = (ctypes.c_void_p * n)(*[p.data_ptr() for p in self.params])
         self._gp = (ctypes.c_void_p * n)(*[g.data_ptr() for g in self.grads])
@@ -208,7 +210,9 @@ class FusedLinearTrainer:
         """Dropout stream of voter v: the Philox counter word the kernels take from ctl[0] (its low 32 bits) starts at
         v << 24, so voters never share masks whichever rank runs them (16.7 M optimizer steps per voter, 256 voters).
         keep_state: the previous voter's RMSprop running averages stay (IDELUCS_VOTER_STATE=carry, models.IID_model)."""
-        self.ctl[0] = (int(voter) & 0xFF) << 24
+        # (fill_ on a view, here and below: `tensor[i] = python_scalar` is a host-to-device copy from pageable memory, which holds the
+        #  host until everything queued on the stream has run -- the vectoriser, when a voter begins right behind the store's build)
+        self.ctl[0:1].fill_((int(voter) & 0xFF) << 24)
         if keep_state:
             return
         for v in self.square_avg:               # a voter starts with fresh optimizer state (models.IID_model.begin_voter)
@@ -219,7 +223,7 @@ class FusedLinearTrainer:
         return self.grads[i].sum(0) if self.parts[i] > 1 else self.grads[i]
 
     def set_lr(self, lr):
-        self.hyper[0] = float(lr)
+        self.hyper[0:1].fill_(float(lr))
 
     def buffers(self, m):
         if m not in self._bufs:
@@ -488,12 +492,22 @@ class FusedLinearTrainer:
         """One pass over a fresh permutation of the N*n_mimics pairs (models.py:117-133).
         Returns the device scalar sum of the per-step losses and the number of batches."""
         n_pairs = store.n_pairs
-        if self._perm is None or self._perm.numel() != n_pairs:
+        fresh = self._perm is None or self._perm.numel() != n_pairs
+        if fresh:
             self._perm = torch.empty(n_pairs, dtype=torch.int64, device=self.dev)
             self._graphs.clear()
-        torch.randperm(n_pairs, device=self.dev, generator=generator, out=self._perm)
-        self.ctl[1] = 0
-        self.out[1] = 0.0
+        # the permutation (a device sort: ~20 launches, 0.17 ms) needs nothing of the store: on a stream of its own it runs beside
+        # whatever the caller has queued in front of the epoch (the vectoriser), behind the previous epoch's last use of _perm
+        main = torch.cuda.current_stream()
+        if fresh:
+            self._prep.wait_stream(main)        # (a block the allocator may just have taken back from other work of this stream)
+        elif self._perm_free is not None:
+            self._prep.wait_event(self._perm_free)
+        with torch.cuda.stream(self._prep):
+            torch.randperm(n_pairs, device=self.dev, generator=generator, out=self._perm)
+        main.wait_stream(self._prep)
+        self.ctl[1:2].zero_()
+        self.out[1:2].zero_()
         n_full, rem = divmod(n_pairs, batch_sz)
         pipe = self._pipeline
         if n_full:
@@ -526,6 +540,8 @@ class FusedLinearTrainer:
         self.flush_tail()                       # (the last eager step's tail; a replayed graph ends with its own)
         if rem:
             self._full_step(store, self.buffers(2 * rem))
+        self._perm_free = torch.cuda.Event()
+        self._perm_free.record(main)
         return self.out[1], n_full + (1 if rem else 0)
 
     @torch.no_grad()
@@ -655,8 +671,8 @@ class BatchedLinearTrainer:
             if t._perm is None or t._perm.numel() != n_pairs:
                 t._perm = torch.empty(n_pairs, dtype=torch.int64, device=self.dev)
             torch.randperm(n_pairs, device=self.dev, generator=g, out=t._perm)
-            t.ctl[1] = 0
-            t.out[1] = 0.0
+            t.ctl[1:2].zero_()
+            t.out[1:2].zero_()
         n_full, rem = divmod(n_pairs, batch_sz)
         m = 2 * batch_sz
         if n_full and m % 32 == 0:

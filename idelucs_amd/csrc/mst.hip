@@ -88,6 +88,27 @@ __device__ __forceinline__ void block_best(double &bw, int64_t &bj, int64_t &bp,
     __syncthreads();
 }
 
+// the same on the VALU alone (wave_ops.h: DPP inside the rows, permlane swaps across them -- a __shfl_xor butterfly over three 64-bit
+// values is 36 dependent trips through the LDS crossbar): the smallest weight of the wave first, then the smallest (number, position)
+// pair among the lanes that hold it, packed into one word (numbers < 2^31, positions < 2^32: idl_mst_prim_lazy's sizes).  The
+// lexicographic minimum `better` defines; "nothing" = (inf, INT64_MAX, 0) as in block_best.  sk: PRIM_NT / 64 words.
+__device__ __forceinline__ void block_best_packed(double &bw, int64_t &bj, int64_t &bp, double *sw, unsigned long long *sk)
+{
+    const double wmin = idl_dev::wave_min_d(bw);
+    uint64_t key = (bw == wmin && bj != INT64_MAX) ? (((uint64_t)bj << 32) | (uint64_t)(uint32_t)bp) : ~0ull;
+    key = idl_dev::wave_min_u64(key);
+    const int tid = threadIdx.x;
+    if ((tid & 63) == 0) { sw[tid >> 6] = wmin; sk[tid >> 6] = key; }
+    __syncthreads();
+    double w = sw[0]; uint64_t k = sk[0];
+#pragma unroll
+    for (int v = 1; v < PRIM_NT / 64; ++v) if (sw[v] < w || (sw[v] == w && sk[v] < k)) { w = sw[v]; k = sk[v]; }
+    __syncthreads();
+    bw = w;
+    bj = k == ~0ull ? INT64_MAX : (int64_t)(k >> 32);
+    bp = k == ~0ull ? 0 : (int64_t)(uint32_t)k;
+}
+
 // Diagnostic build (make STAMPS=1; tools/stamps_prim.py): workgroups 0, 1/3 and 2/3 of the grid add the time (s_memrealtime, 100 MHz)
 // they spend between six marks of every step to prim_phase_sum; idl_debug_prim_phases reads and clears the sums.
 #ifdef IDL_PHASE_STAMPS
@@ -96,9 +117,20 @@ __device__ unsigned long long prim_phase_sum[8];
 #else
 #define PRIM_MARK(slot) do { } while (0)
 #endif
+// the same for lazy_step_kernel: [kind][slot], kind 0 = workgroup 0, 1 = another workgroup with an awake run, 2 = one that only keeps balls;
+// slots 0..6 the phases, 7 the count, 8 (kind 0) entry - the previous launch's last exit, 9 (kind 0) the previous launch's length
+#ifdef IDL_PHASE_STAMPS
+__device__ unsigned long long lazy_phase_sum[3][12];
+__device__ unsigned long long lazy_clock[2];               // [0] the latest exit of any workgroup, [1] workgroup 0's entry
+#define LZ_MARK(slot) do { if (stamping) { const uint64_t now_ = __builtin_amdgcn_s_memrealtime(); atomicAdd(&lazy_phase_sum[kind_][slot], (unsigned long long)(now_ - last_)); last_ = now_; } } while (0)
+#define LZ_EXIT() do { if (threadIdx.x == 0 && (blockIdx.x & 7) == 0) atomicMax(&lazy_clock[0], (unsigned long long)__builtin_amdgcn_s_memrealtime()); } while (0)
+#else
+#define LZ_MARK(slot) do { } while (0)
+#define LZ_EXIT() do { } while (0)
+#endif
 
 template <typename T, bool FILTER, bool D64>
-__global__ __launch_bounds__(PRIM_NT, 1024 / PRIM_NT) void prim_step_kernel(PrimArgs a, int64_t step, int scan, int n_part)
+__global__ __launch_bounds__(PRIM_NT, 3) void prim_step_kernel(PrimArgs a, int64_t step, int scan, int n_part)
 {
     __shared__ double sw[PRIM_NT / 64];
     __shared__ int64_t sj[PRIM_NT / 64], sp[PRIM_NT / 64];
@@ -381,14 +413,16 @@ struct LazyArgs {
     const double *gr;          // [G] its radius (>= ||x_p - c_g||)
     const float *xrow;         // [n][64] the points row-major (a node's coordinates in one piece)
     double *gmin; int64_t *galive;       // census scratch [G]
+    int *wg_list;              // [1 + full_grid] wg_list[0] = L; then the step's workgroups: number | awake runs << 16 (lazy_list_kernel)
+    int full_grid;             // prim_grid(n): positions are laid out by it whatever the launched grid is
 };
 
 constexpr int LAZY_NCH = 32;           // nodes a catch-up pass stages in LDS at a time
 
-__global__ __launch_bounds__(PRIM_NT, 1024 / PRIM_NT) void lazy_step_kernel(PrimArgs a, LazyArgs z, int64_t launch, int rescan)
+__global__ __launch_bounds__(PRIM_NT, 3) void lazy_step_kernel(PrimArgs a, LazyArgs z, int64_t launch, int rescan)
 {
     __shared__ double sw[PRIM_NT / 64];
-    __shared__ int64_t sj[PRIM_NT / 64], sp[PRIM_NT / 64];
+    __shared__ int64_t sj[PRIM_NT / 64];
     __shared__ double xc[PRIM_FILTER_D];
     __shared__ float up[PRIM_RUNS][PRIM_FILTER_D];
     __shared__ int q_n;
@@ -396,98 +430,169 @@ __global__ __launch_bounds__(PRIM_NT, 1024 / PRIM_NT) void lazy_step_kernel(Prim
     __shared__ double q_mr[PRIM_NT * PRIM_AHEAD], q_floor[PRIM_NT * PRIM_AHEAD];
     static_assert(PRIM_NT == PRIM_SUB, "one sub-block per workgroup here");
     const int tid = threadIdx.x;
+#ifdef IDL_PHASE_STAMPS
+    uint64_t last_ = __builtin_amdgcn_s_memrealtime();
+    const uint64_t entry_ = last_;
+    bool stamping = tid == 0 && !rescan && (blockIdx.x == 0 || blockIdx.x % 61 == 7);   // (a sample: ~500 workgroups adding to the same words distort what they time)
+    int kind_ = 2;
+#endif
     const int64_t n = a.n;
     const int G = z.n_groups;
     const int par = (int)(launch & 1);
+    // (this workgroup's number and its run flags: one word of the list, requested in front of the state of the walk -- two loads, one wait)
+    const int entry = z.wg_list[1 + blockIdx.x];
     const LazyState S = z.st[par];
+    const int wg = __builtin_amdgcn_readfirstlane(entry) & 0xFFFF, wg_mask = __builtin_amdgcn_readfirstlane(entry) >> 16;
     LazyState *nx = &z.st[par ^ 1];
-    const bool lead = blockIdx.x == 0 && tid == 0;
-    const bool ball_duty = (int)blockIdx.x < G;              // workgroup g keeps sleeping group g's bound
+    const bool lead = wg == 0 && tid == 0;                   // (workgroup 0 keeps a bound: always listed, always first)
+    // sleeping group g's bound is kept by wave g % 4 of workgroup g / 4 (round 5; it was workgroup g: every workgroup of the grid then
+    // ran the whole decision, and the grid no longer fits the chip at once when the kernel takes more than 128 registers)
+    const bool ball_duty = wg * (PRIM_NT / 64) < G;
+    const int ball_g = wg * (PRIM_NT / 64) + (tid >> 6);
+    const bool has_ball = ball_g < G;
     if (S.stalled || S.n_tree >= n) {                        // fall through: the state and the bounds are handed on unchanged
         if (lead) *nx = S;
-        if (ball_duty && tid == 0) z.lbp[(par ^ 1) * G + blockIdx.x] = z.lbp[par * G + blockIdx.x];
+        if (has_ball && (tid & 63) == 0) z.lbp[(par ^ 1) * G + ball_g] = z.lbp[par * G + ball_g];
         return;
     }
-    const int64_t stride = (int64_t)gridDim.x * PRIM_NT;
-    const int64_t p0 = (int64_t)blockIdx.x * PRIM_NT + tid;
+    const int64_t stride = (int64_t)z.full_grid * PRIM_NT;
+    const int64_t p0 = (int64_t)wg * PRIM_NT + tid;
     const float *xt = (const float *)a.xt;
-    // ---- which of this workgroup's runs are awake (uniform)
+    // ---- A step is a chain of memory round trips; whatever does not need the previous trip's answer is requested together.
+    // Trip 1: the four run flags.  Trip 2, all in flight before anything of it is waited for: min_reach, core distance and sleep flag
+    // of the awake runs' points -- 17 BYTES A POINT, nothing else -- the previous step's candidates, every group's bound (not only
+    // the sleeping groups': whether a group sleeps is in the same trip), the ball this workgroup keeps.  Trip 3: the new node.
+    // Trip 4: group, residual and the 64 bytes of codes of the points whose entry CAN still fall (floor < min_reach: a few per
+    // workgroup and step), and the original numbers of the points that can become the workgroup's candidate (ties go by them).
+    // Trip 5: the exact distances that survive the bound.
+    // (Round 5.  Half the runs of a 10^6-point job are awake in a typical step -- 480 workgroups, stamps: tools/stamps_lazy.py -- and
+    //  the round-3 kernel read 97 bytes of state and codes for every one of their points in every step: 48 MB a launch, 12 us at
+    //  4 TB/s.  It was bound by that, not by its round trips: with all of them merged and the same bytes it took 13.1 us.)
     bool run_on[PRIM_AHEAD];
     bool any_on = false;
 #pragma unroll
     for (int i = 0; i < PRIM_AHEAD; ++i) {
-        const int64_t first = (int64_t)blockIdx.x * PRIM_NT + i * stride;
-        run_on[i] = first < n && z.run_asleep[first / PRIM_NT] == 0;
+        run_on[i] = ((wg_mask >> i) & 1) != 0;
         any_on |= run_on[i];
     }
     Cand *cand_out = a.cand[S.cand_par ^ 1];
     if (!any_on && !ball_duty) {                             // nothing to scan, nothing to keep: leave an empty candidate
         if (tid == 0) cand_out[blockIdx.x] = Cand{__builtin_inf(), INT64_MAX, 0};
+        LZ_EXIT();
         return;
     }
-    // ---- prologue: the state of the points of the runs that are awake, their codes
+#ifdef IDL_PHASE_STAMPS
+    kind_ = blockIdx.x == 0 ? 0 : any_on ? 1 : 2;
+    if (stamping && blockIdx.x == 0) {
+        const unsigned long long prev_exit = atomicMax(&lazy_clock[0], 0ull), prev_entry = lazy_clock[1];
+        if (prev_entry != 0 && prev_exit > prev_entry && entry_ > prev_exit) {
+            atomicAdd(&lazy_phase_sum[0][8], (unsigned long long)(entry_ - prev_exit));
+            atomicAdd(&lazy_phase_sum[0][9], prev_exit - prev_entry);
+            atomicAdd(&lazy_phase_sum[0][10], 1ull);
+        }
+        lazy_clock[1] = entry_;
+    }
+#endif
+    LZ_MARK(0);                                              // the run flags
+    // ---- trip 2, requests
     double mr_a[PRIM_AHEAD], cj_a[PRIM_AHEAD];
-    int64_t o_a[PRIM_AHEAD];
-    bool in_run[PRIM_AHEAD];
-    uint32_t cw[PRIM_AHEAD][PRIM_FILTER_D / 4];
-    float rs[PRIM_AHEAD], run_scale[PRIM_AHEAD];
-    int run_g[PRIM_AHEAD], g_own[PRIM_AHEAD];
+    double run_scale[PRIM_AHEAD];                            // (float)gscale of the run's group; rounded where it is used: the request is not waited for here
+    int run_g[PRIM_AHEAD], pas_a[PRIM_AHEAD];
+    static_assert(PRIM_RUNS * 64 == PRIM_NT && PRIM_FILTER_D == 64 && PRIM_AHEAD == 4, "one (run, feature) per thread");
 #pragma unroll
     for (int i = 0; i < PRIM_AHEAD; ++i) {
+        const int64_t first = (int64_t)wg * PRIM_NT + i * stride;
         const int64_t p = p0 + i * stride;
-        const bool on = run_on[i] && p < n;
-        mr_a[i] = on ? a.min_reach[p] : -1.0;
-        cj_a[i] = on ? a.core[p] : 0.0;
-        o_a[i] = on ? (int64_t)a.orig[p] : 0;
-        const int64_t first = (int64_t)blockIdx.x * PRIM_NT + i * stride;
-        run_g[i] = run_on[i] ? a.gid[first] : 0;
-        g_own[i] = on ? a.gid[p] : -1;
-        if (on && z.pas[p]) mr_a[i] = -1.0;                  // (a run that straddles a sleeping and a waking group)
+        mr_a[i] = -1.0; cj_a[i] = 0.0; run_g[i] = 0; pas_a[i] = 1;
+        if (run_on[i]) {                                     // (uniform)
+            const int64_t pc = p < n ? p : first;            // a lane beyond the end reads the run's first point; dropped below
+            mr_a[i] = a.min_reach[pc];
+            cj_a[i] = a.core[pc];
+            pas_a[i] = z.pas[pc];
+            run_g[i] = a.gid[first];
+        }
     }
+    constexpr int PRE = 4;                                   // candidates / group bounds a thread requests up front: 4 x 256 covers 2^20 points
+    Cand cv[PRE];
+    int g_as[PRE];
+    double g_mm[PRE], g_lb[PRE];
+    if (!rescan) {
+        const Cand *pc = a.cand[S.cand_par];
+#pragma unroll
+        for (int it = 0; it < PRE; ++it) {
+            const int g = tid + it * PRIM_NT;
+            cv[it] = Cand{__builtin_inf(), INT64_MAX, 0};
+            if (g < (int)gridDim.x) cv[it] = pc[g];
+            g_as[it] = 0; g_mm[it] = 0.0; g_lb[it] = 0.0;
+            if (g < G) { g_as[it] = z.asleep[g]; g_mm[it] = z.minmr[g]; g_lb[it] = z.lbp[par * G + g]; }
+        }
+    }
+    double ball_c = 0.0, ball_lb = 0.0, ball_r = 0.0;        // this workgroup's ball (its first wave)
+    int ball_as = 0;
+    if (has_ball) {
+        ball_lb = z.lbp[par * G + ball_g];
+        ball_as = z.asleep[ball_g];
+        ball_c = z.gc[(int64_t)ball_g * PRIM_FILTER_D + (tid & 63)];
+        ball_r = z.gr[ball_g];
+    }
+    // (nothing above has been waited for.  The values are pinned HERE: left alone, the compiler moves the first use of a run's state
+    //  up into the block that requested it, and the wait with it -- one round trip per run again)
+    asm volatile("" ::: "memory");
+#define LZ_PIN(x) asm volatile("" : "+v"(x))
+#pragma unroll
+    for (int i = 0; i < PRIM_AHEAD; ++i) { LZ_PIN(mr_a[i]); LZ_PIN(cj_a[i]); LZ_PIN(run_g[i]); LZ_PIN(pas_a[i]); }
+    if (!rescan) {
+#pragma unroll
+        for (int it = 0; it < PRE; ++it) { LZ_PIN(cv[it].w); LZ_PIN(cv[it].j); LZ_PIN(cv[it].p); LZ_PIN(g_as[it]); LZ_PIN(g_mm[it]); LZ_PIN(g_lb[it]); }
+    }
+    LZ_PIN(ball_lb); LZ_PIN(ball_as); LZ_PIN(ball_c); LZ_PIN(ball_r);
+#undef LZ_PIN
+    LZ_MARK(1);                                              // trip 2 answered
+    // ---- trip 2, answers: the state first (requested first)
     int my_run_g;
     {
-        static_assert(PRIM_RUNS * 64 == PRIM_NT && PRIM_FILTER_D == 64 && PRIM_AHEAD == 4, "one (run, feature) per thread");
         const int rr = tid >> 6;
-        my_run_g = rr == 0 ? run_g[0] : rr == 1 ? run_g[1] : rr == 2 ? run_g[2] : run_g[3];
-        const __amdgpu_buffer_rsrc_t c_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.codes, 0, 0xffffffff, 0x00020000);
 #pragma unroll
         for (int i = 0; i < PRIM_AHEAD; ++i) {
             const int64_t p = p0 + i * stride;
-            in_run[i] = mr_a[i] >= 0.0 && g_own[i] == run_g[i];
-            rs[i] = 0.f;
-            run_scale[i] = (float)a.gscale[run_g[i]];
-            if (in_run[i]) {
-                rs[i] = a.resid[p];
-#pragma unroll
-                for (int k = 0; k < PRIM_FILTER_D / 4; ++k) cw[i][k] = __builtin_amdgcn_raw_buffer_load_b32(c_rsrc, (uint32_t)p * 4u, k * (int)n * 4, 0);
-            }
+            const bool on = run_on[i] && p < n;
+            if (!on || pas_a[i] != 0) mr_a[i] = -1.0;        // (a lane beyond the end; a run that straddles a sleeping and a waking group)
+            if (!on) cj_a[i] = 0.0;
+            run_scale[i] = a.gscale[run_g[i]];
         }
+        my_run_g = rr == 0 ? run_g[0] : rr == 1 ? run_g[1] : rr == 2 ? run_g[2] : run_g[3];
     }
+    const double my_sc = a.gscale[my_run_g];                 // (in flight during the decision)
+    const float my_lo = a.glo[(int64_t)my_run_g * PRIM_FILTER_D + (tid & 63)];
     // ---- the winner of the previous scan; it is committed only if no sleeping group could hold a better point
     int64_t cur = S.cur_p, cur_o = S.cur_o;
     double cur_w = S.cur_w;
     if (!rescan) {
         const Cand *pc = a.cand[S.cand_par];
         double bw = __builtin_inf(); int64_t bj = INT64_MAX, bp = 0;
-        for (int g = tid; g < (int)gridDim.x; g += PRIM_NT) {
+#pragma unroll
+        for (int it = 0; it < PRE; ++it) if (better(cv[it].w, cv[it].j, bw, bj)) { bw = cv[it].w; bj = cv[it].j; bp = cv[it].p; }
+        for (int g = tid + PRE * PRIM_NT; g < (int)gridDim.x; g += PRIM_NT) {
             const Cand c = pc[g];
             if (better(c.w, c.j, bw, bj)) { bw = c.w; bj = c.j; bp = c.p; }
         }
-        block_best(bw, bj, bp, sw, sj, sp);
+        block_best_packed(bw, bj, bp, sw, (unsigned long long *)sj);
         double lb = __builtin_inf();
-        for (int g = tid; g < G; g += PRIM_NT) if (z.asleep[g] == 1) lb = fmin(lb, fmin(z.minmr[g], z.lbp[par * G + g]));      // (2: nothing left in it)
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) lb = fmin(lb, __shfl_xor(lb, o, 64));
+        for (int it = 0; it < PRE; ++it) if (g_as[it] == 1) lb = fmin(lb, fmin(g_mm[it], g_lb[it]));              // (2: nothing left in it)
+        for (int g = tid + PRE * PRIM_NT; g < G; g += PRIM_NT) if (z.asleep[g] == 1) lb = fmin(lb, fmin(z.minmr[g], z.lbp[par * G + g]));
+        lb = idl_dev::wave_min_d(lb);
         if ((tid & 63) == 0) sw[tid >> 6] = lb;
         __syncthreads();
         lb = fmin(fmin(sw[0], sw[1]), fmin(sw[2], sw[3]));
         __syncthreads();
         if (!(bw < lb)) {                                    // STALL (every workgroup decides the same from the same data)
             if (lead) { *nx = S; nx->stalled = 1; }
-            if (ball_duty && tid == 0) z.lbp[(par ^ 1) * G + blockIdx.x] = z.lbp[par * G + blockIdx.x];
+            if (has_ball && (tid & 63) == 0) z.lbp[(par ^ 1) * G + ball_g] = ball_lb;
             return;
         }
         cur = bp; cur_o = bj; cur_w = bw;
+        LZ_MARK(2);                                          // decided
         if (lead) {
             a.mst_cur[S.n_tree - 1] = a.source[cur]; a.mst_next[S.n_tree - 1] = cur_o; a.mst_w[S.n_tree - 1] = cur_w;
             a.min_reach[cur] = -1.0;                         // in the tree (this launch skips it by position)
@@ -505,27 +610,30 @@ __global__ __launch_bounds__(PRIM_NT, 1024 / PRIM_NT) void lazy_step_kernel(Prim
     const double cc = a.core[cur];
     {
         const int k = tid & 63;
-        const double sc = a.gscale[my_run_g];
-        const float lo = a.glo[(int64_t)my_run_g * PRIM_FILTER_D + k];
         __syncthreads();
-        up[tid >> 6][k] = (float)((xc[k] - (double)lo) / sc);
+        up[tid >> 6][k] = (float)((xc[k] - (double)my_lo) / my_sc);
     }
     // ---- sleeping group g's bound meets the new node (workgroup g, its first wave)
-    if (ball_duty && tid < 64) {
-        const int g = blockIdx.x;
-        double lbv = z.lbp[par * G + g];
-        if (!rescan && z.asleep[g] == 1) {
-            const double t = xc[tid] - z.gc[(int64_t)g * PRIM_FILTER_D + tid];
-            double d2 = t * t;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) d2 += __shfl_xor(d2, o, 64);
-            const double b = __dsqrt_rn(d2) * (1.0 - 1e-12) - z.gr[g];
+    if (has_ball) {                                          // (a whole wave or none of it)
+        double lbv = ball_lb;
+        if (!rescan && ball_as == 1) {
+            const double t = xc[tid & 63] - ball_c;
+            const double d2 = idl_dev::wave_sum_d(t * t);      // (any order of the sum: the bound keeps 1e-12 of slack)
+            const double b = __dsqrt_rn(d2) * (1.0 - 1e-12) - ball_r;
             lbv = fmin(lbv, b > 0.0 ? b : 0.0);
         }
-        if (tid == 0) z.lbp[(par ^ 1) * G + g] = lbv;
+        if ((tid & 63) == 0) z.lbp[(par ^ 1) * G + ball_g] = lbv;
     }
     __syncthreads();
-    if (!any_on) { if (tid == 0) cand_out[blockIdx.x] = Cand{__builtin_inf(), INT64_MAX, 0}; return; }
+    LZ_MARK(3);                                              // the new node, the runs' boxes, the ball
+    if (!any_on) {
+        if (tid == 0) cand_out[blockIdx.x] = Cand{__builtin_inf(), INT64_MAX, 0};
+#ifdef IDL_PHASE_STAMPS
+        if (stamping) atomicAdd(&lazy_phase_sum[kind_][7], 1ull);
+#endif
+        LZ_EXIT();
+        return;
+    }
     const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.xt, 0, 0xffffffff, 0x00020000);
     const int col_bytes = (int)n * 4;
     double bw = __builtin_inf(); int64_t bj = INT64_MAX, bp = 0;
@@ -552,21 +660,59 @@ __global__ __launch_bounds__(PRIM_NT, 1024 / PRIM_NT) void lazy_step_kernel(Prim
         floor_a[i] = fmax(cc, cj_a[i]);
         need[i] = act[i] && floor_a[i] < mr_a[i];
     }
+    // the original numbers the candidate will be chosen by (ties), requested with trip 4: the workgroup's smallest weight will be
+    // held either by a point that holds the wave's smallest weight NOW or by a point whose entry falls in this step
+    int oj[PRIM_AHEAD];
+    {
+        double wpre = __builtin_inf();
 #pragma unroll
-    for (int i = 0; i < PRIM_AHEAD; ++i) {
-        if (!(need[i] && in_run[i])) continue;
-        float acc = 0.f;
-        const float *u = up[i];
+        for (int i = 0; i < PRIM_AHEAD; ++i) if (act[i]) wpre = fmin(wpre, mr_a[i]);
+        wpre = idl_dev::wave_min_d(wpre);
 #pragma unroll
-        for (int k = 0; k < PRIM_FILTER_D / 4; ++k) {
-            const uint32_t w = cw[i][k];
-            const float t0 = u[4 * k] - (float)(w & 255u), t1 = u[4 * k + 1] - (float)((w >> 8) & 255u);
-            const float t2 = u[4 * k + 2] - (float)((w >> 16) & 255u), t3 = u[4 * k + 3] - (float)(w >> 24);
-            acc = fmaf(t0, t0, acc); acc = fmaf(t1, t1, acc); acc = fmaf(t2, t2, acc); acc = fmaf(t3, t3, acc);
+        for (int i = 0; i < PRIM_AHEAD; ++i) {
+            const int64_t p = p0 + i * stride;
+            oj[i] = 0x7FFFFFFF;
+            if (act[i] && (need[i] || mr_a[i] == wpre)) oj[i] = a.orig[p];
         }
-        const double sc = (double)run_scale[i];
-        const double lb = sc * (double)sqrtf(acc) * (1.0 - 4e-5) - 0.01 * sc - (double)rs[i];      // (prim_step_kernel has the reasoning)
-        if (fmax(floor_a[i], lb) >= mr_a[i]) need[i] = false;
+    }
+    // ---- trip 4: what the bound needs, for the points whose entry can still fall
+    {
+        uint32_t cw[PRIM_AHEAD][PRIM_FILTER_D / 4];
+        float rs[PRIM_AHEAD];
+        int g_own[PRIM_AHEAD];
+        const __amdgpu_buffer_rsrc_t c_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.codes, 0, 0xffffffff, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < PRIM_AHEAD; ++i) {
+            const int64_t p = p0 + i * stride;
+            g_own[i] = -1; rs[i] = 0.f;
+#pragma unroll
+            for (int k = 0; k < PRIM_FILTER_D / 4; ++k) cw[i][k] = 0u;
+            if (need[i]) {
+                g_own[i] = a.gid[p];
+                rs[i] = a.resid[p];
+#pragma unroll
+                for (int k = 0; k < PRIM_FILTER_D / 4; ++k) cw[i][k] = __builtin_amdgcn_raw_buffer_load_b32(c_rsrc, (uint32_t)p * 4u, k * (int)n * 4, 0);
+            }
+        }
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < PRIM_AHEAD; ++i) { asm volatile("" : "+v"(g_own[i])); asm volatile("" : "+v"(rs[i])); }
+#pragma unroll
+        for (int i = 0; i < PRIM_AHEAD; ++i) {
+            if (!(need[i] && g_own[i] == run_g[i])) continue;    // (a point of another group than its run's: no codes in this box, exact distance)
+            float acc = 0.f;
+            const float *u = up[i];
+#pragma unroll
+            for (int k = 0; k < PRIM_FILTER_D / 4; ++k) {
+                const uint32_t w = cw[i][k];
+                const float t0 = u[4 * k] - (float)(w & 255u), t1 = u[4 * k + 1] - (float)((w >> 8) & 255u);
+                const float t2 = u[4 * k + 2] - (float)((w >> 16) & 255u), t3 = u[4 * k + 3] - (float)(w >> 24);
+                acc = fmaf(t0, t0, acc); acc = fmaf(t1, t1, acc); acc = fmaf(t2, t2, acc); acc = fmaf(t3, t3, acc);
+            }
+            const double sc = (double)(float)run_scale[i];
+            const double lb = sc * (double)sqrtf(acc) * (1.0 - 4e-5) - 0.01 * sc - (double)rs[i];      // (prim_step_kernel has the reasoning)
+            if (fmax(floor_a[i], lb) >= mr_a[i]) need[i] = false;
+        }
     }
     int slot[PRIM_AHEAD];
 #pragma unroll
@@ -579,22 +725,40 @@ __global__ __launch_bounds__(PRIM_NT, 1024 / PRIM_NT) void lazy_step_kernel(Prim
         }
     }
     __syncthreads();
+    LZ_MARK(4);                                              // bounds evaluated, queue filled
     for (int s = tid; s < q_n; s += PRIM_NT) {
         const int item = q_item[s], t_own = item / PRIM_AHEAD, i_own = item % PRIM_AHEAD;
-        const int64_t p = (int64_t)blockIdx.x * PRIM_NT + t_own + i_own * stride;
+        const int64_t p = (int64_t)wg * PRIM_NT + t_own + i_own * stride;
         double mr = q_mr[s];
         exact(p, mr, q_floor[s]);
         q_mr[s] = mr;
     }
     __syncthreads();
+    LZ_MARK(5);                                              // exact distances
+    // ---- the workgroup's candidate: smallest weight first, then the smallest original number among the points that hold it (the
+    // lexicographic minimum `better` defines; their numbers came with trip 4)
+    double wmin = __builtin_inf();
 #pragma unroll
     for (int i = 0; i < PRIM_AHEAD; ++i) {
-        const int64_t p = p0 + i * stride;
         if (slot[i] >= 0) mr_a[i] = q_mr[slot[i]];
-        if (act[i] && better(mr_a[i], o_a[i], bw, bj)) { bw = mr_a[i]; bj = o_a[i]; bp = p; }
+        if (act[i]) wmin = fmin(wmin, mr_a[i]);
     }
-    block_best(bw, bj, bp, sw, sj, sp);
+    wmin = idl_dev::wave_min_d(wmin);
+    {
+#pragma unroll
+        for (int i = 0; i < PRIM_AHEAD; ++i) {
+            const int64_t p = p0 + i * stride;
+            if (act[i] && mr_a[i] == wmin && (int64_t)oj[i] < bj) { bj = (int64_t)oj[i]; bp = p; }
+        }
+        bw = bj != INT64_MAX ? wmin : __builtin_inf();       // (a lane that holds none of the wave's smallest entries offers nothing)
+    }
+    block_best_packed(bw, bj, bp, sw, (unsigned long long *)sj);
     if (tid == 0) cand_out[blockIdx.x] = Cand{bw, bj, bp};
+    LZ_MARK(6);                                              // candidate reduced and left
+#ifdef IDL_PHASE_STAMPS
+    if (stamping) { atomicAdd(&lazy_phase_sum[kind_][7], 1ull); atomicAdd(&lazy_phase_sum[kind_][11], (unsigned long long)q_n); }
+#endif
+    LZ_EXIT();
 }
 
 // every sleeping point meets the nodes tree_p[upto[g] .. n_tree) in their order: its coordinates in registers, the nodes through LDS
@@ -736,6 +900,34 @@ __global__ __launch_bounds__(256) void lazy_flags_kernel(PrimArgs a, LazyArgs z)
     if (awake) s_any = 1;
     __syncthreads();
     if (tid == 0) z.run_asleep[blockIdx.x] = s_any ? 0 : 1;
+}
+
+// The step's grid (round 5): the workgroups that keep a sleeping group's bound (the first ceil(G / 4)) and those with an awake run,
+// in ascending order, each with its four run flags -- built whenever the flags change (a census), read back by the host as the next
+// launches' grid.  Half the workgroups of a 10^6-point job had nothing to do but to start and leave, and the last of 977 entered
+// 3-4 us behind the first (tools/stamps_lazy.py).
+__global__ __launch_bounds__(1024) void lazy_list_kernel(PrimArgs a, LazyArgs z)
+{
+    __shared__ int wcount[16];
+    const int t = threadIdx.x, fg = z.full_grid;
+    const int keepers = (z.n_groups + PRIM_NT / 64 - 1) / (PRIM_NT / 64);
+    int mask = 0;
+    if (t < fg) {
+#pragma unroll
+        for (int i = 0; i < PRIM_AHEAD; ++i) {
+            const int64_t first = ((int64_t)t + (int64_t)i * fg) * PRIM_NT;
+            if (first < a.n && z.run_asleep[first / PRIM_NT] == 0) mask |= 1 << i;
+        }
+    }
+    const bool keep = t < fg && (t < keepers || mask != 0);
+    const unsigned long long bal = __ballot(keep);
+    const int before = __popcll(bal & ((1ull << (t & 63)) - 1ull));
+    if ((t & 63) == 0) wcount[t >> 6] = __popcll(bal);
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < (t >> 6); ++w) base += wcount[w];
+    if (keep) z.wg_list[1 + base + before] = t | (mask << 16);
+    if (t == 0) { int total = 0; for (int w = 0; w < 16; ++w) total += wcount[w]; z.wg_list[0] = total; }
 }
 
 __global__ void lazy_init_kernel(PrimArgs a, LazyArgs z)
@@ -1308,7 +1500,7 @@ __global__ __launch_bounds__(PRIM_NT, 3) void lazy_multi_kernel(PrimArgs a, Lazy
     if (tid == 0) *rest_out = fmin(fmin(sw[0], sw[1]), fmin(sw[2], sw[3]));
 }
 
-struct LazyLayout { int64_t min_reach, source, cand0, cand1, candk0, candk1, rest0, rest1, dec, st, tree_p, run_asleep, pas, asleep, upto, minmr, lbp, gmin, galive, total; };
+struct LazyLayout { int64_t min_reach, source, cand0, cand1, candk0, candk1, rest0, rest1, dec, st, tree_p, run_asleep, pas, asleep, upto, minmr, lbp, gmin, galive, wg_list, total; };
 
 inline LazyLayout lazy_layout(int64_t n, int n_groups)
 {
@@ -1324,6 +1516,7 @@ inline LazyLayout lazy_layout(int64_t n, int n_groups)
     l.run_asleep = take((n + 255) / 256); l.pas = take(n);
     l.asleep = take((int64_t)n_groups * 4); l.upto = take((int64_t)n_groups * 8); l.minmr = take((int64_t)n_groups * 8);
     l.lbp = take((int64_t)n_groups * 16); l.gmin = take((int64_t)n_groups * 8); l.galive = take((int64_t)n_groups * 8);
+    l.wg_list = take((int64_t)(g + 1) * 4);
     l.total = o + 256;
     return l;
 }
@@ -1350,6 +1543,22 @@ int idl_debug_prim_phases(unsigned long long *out8)
 #else
     (void)out8;
     idl::set_error("bad argument: %s", "debug_prim_phases: this build has no phase stamps (make STAMPS=1)");
+    return IDL_ERR_ARG;
+#endif
+}
+
+int idl_debug_lazy_phases(unsigned long long *out36)
+{
+#ifdef IDL_PHASE_STAMPS
+    IDL_REQUIRE(out36 != nullptr, "debug_lazy_phases: NULL buffer");
+    unsigned long long zero[36] = {};
+    IDL_HIP_TRY(hipDeviceSynchronize());
+    IDL_HIP_TRY(hipMemcpyFromSymbol(out36, HIP_SYMBOL(lazy_phase_sum), sizeof(zero)));
+    IDL_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(lazy_phase_sum), zero, sizeof(zero)));
+    return IDL_OK;
+#else
+    (void)out36;
+    idl::set_error("bad argument: %s", "debug_lazy_phases: this build has no phase stamps (make STAMPS=1)");
     return IDL_ERR_ARG;
 #endif
 }
@@ -1406,8 +1615,10 @@ int idl_mst_prim_lazy(const void *xt, const float *xrow, const double *core, int
     z.n_groups = n_groups; z.gfirst = gfirst; z.asleep = (int *)(w + l.asleep); z.upto = (int64_t *)(w + l.upto);
     z.minmr = (double *)(w + l.minmr); z.lbp = (double *)(w + l.lbp); z.gc = gcentre; z.gr = gradius; z.xrow = xrow;
     z.gmin = (double *)(w + l.gmin); z.galive = (int64_t *)(w + l.galive);
+    z.wg_list = (int *)(w + l.wg_list); z.full_grid = prim_grid(n);
     const hipStream_t st = (hipStream_t)stream;
     const int grid = prim_grid(n);
+    int step_grid = grid;                                    // lazy_step_kernel's: the listed workgroups (lazy_list_kernel)
     const unsigned runs = (unsigned)((n + 255) / 256);
     hipLaunchKernelGGL(lazy_init_kernel, dim3(256), dim3(256), 0, st, a, z);
     // several nodes per launch: OPT-IN (IDELUCS_MST_MULTI = 2 .. 8; default: one node per launch, the round-3 kernel).  Measured at
@@ -1427,14 +1638,25 @@ int idl_mst_prim_lazy(const void *xt, const float *xrow, const double *core, int
             if (!rescan) hipLaunchKernelGGL(lazy_reduce_kernel, dim3(1), dim3(256), 0, st, a, z, u, ln, grid);
             hipLaunchKernelGGL(lazy_multi_kernel, dim3(grid), dim3(PRIM_NT), 0, st, a, z, u, ln, rescan);
         } else {
-            hipLaunchKernelGGL(lazy_step_kernel, dim3(grid), dim3(PRIM_NT), 0, st, a, z, ln, rescan);
+            hipLaunchKernelGGL(lazy_step_kernel, dim3(step_grid), dim3(PRIM_NT), 0, st, a, z, ln, rescan);
         }
     };
     if (multi_t) {
         IDL_HIP_TRY(hipMemsetAsync(u.dec, 0, 2 * sizeof(LazyDec), st));
         IDL_HIP_TRY(set_fresh(0)); IDL_HIP_TRY(set_fresh(1));
     }
+    auto relist = [&]() -> int {                             // the flags changed: the step's grid from the device's list
+        if (multi_t) return IDL_OK;
+        hipLaunchKernelGGL(lazy_list_kernel, dim3(1), dim3(1024), 0, st, a, z);
+        int L = 0;
+        IDL_HIP_TRY(hipMemcpyAsync(&L, z.wg_list, sizeof(int), hipMemcpyDeviceToHost, st));
+        IDL_HIP_TRY(hipStreamSynchronize(st));
+        IDL_REQUIRE(L >= 1 && L <= grid, "mst_prim_lazy: workgroup list out of range");
+        step_grid = L;
+        return IDL_OK;
+    };
     int64_t launch = 0, stalls = 0, censuses = 0;
+    if (int rc = relist()) return rc;
     step(launch, 1); ++launch;       // the first scan: cur = the start
     // the steps are queued in chunks; after each the host looks at the state: done, stalled, or time for a census
     static const int chunk = getenv("IDELUCS_MST_CHUNK") ? atoi(getenv("IDELUCS_MST_CHUNK")) : 512;
@@ -1465,6 +1687,7 @@ int idl_mst_prim_lazy(const void *xt, const float *xrow, const double *core, int
         hipLaunchKernelGGL(lazy_policy_kernel, dim3(1), dim3(256), 0, st, a, z, (int)(launch & 1), (int64_t)S.n_tree,
                            (sleep_on && S.n_tree >= no_sleep_until) ? 1 : 0);
         hipLaunchKernelGGL(lazy_flags_kernel, dim3(runs), dim3(256), 0, st, a, z);
+        if (int rc = relist()) return rc;
         if (S.stalled) { S.stalled = 0; IDL_HIP_TRY(hipMemcpyAsync(z.st + (launch & 1), &S, sizeof(S), hipMemcpyHostToDevice, st)); IDL_HIP_TRY(hipStreamSynchronize(st)); }
         if (multi_t) IDL_HIP_TRY(set_fresh((int)(launch & 1)));        // no node has met the new bounds yet: one node per launch until one has
         step(launch, 1); ++launch;   // candidates of the awake set

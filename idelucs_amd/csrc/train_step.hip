@@ -704,7 +704,7 @@ __device__ __forceinline__ void mid_bwd_body(const MidBwdArgs &a, int tile0, int
             __builtin_amdgcn_wave_barrier();
             float dz = 0.f;
             if (cl) {
-#pragma unroll 4
+#pragma unroll 2                              // (4: four row pointers at a stride known only at run time; the fourth lived in scratch)
                 for (int k = 0; k < C; ++k) dz = fmaf(shz[wv][k], sP[k * C + lane], dz);
             }
             const float dot = wave_sum(dz * zc);
@@ -830,18 +830,23 @@ __device__ __forceinline__ void mid_bwd_body(const MidBwdArgs &a, int tile0, int
             }
         }
     }
+    // (the epilogue's indices are formed HERE, from an opaque copy of the thread number: formed in front of the row loop they were
+    //  kept alive across it in scratch -- 16 bytes per lane at the 128-register cap of a 1 024-thread workgroup)
+    int te = tid;
+    asm volatile("" : "+v"(te));
+    const int le = te & 15, qe = (te >> 4) & 3, we = te >> 6;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         float v = cs1[j];
         v = idl_dev::add_xor32(idl_dev::add_xor16(v));
-        if (q == 0) a.partial1[(int64_t)bid * H1 + 32 * wv + 2 * l + j] = v;
+        if (qe == 0) a.partial1[(int64_t)bid * H1 + 32 * we + 2 * le + j] = v;
     }
-    if (tid < H2) a.partial2[(int64_t)bid * H2 + tid] = s23;
-    else if (tid < H2 + C) a.partial3[(int64_t)bid * C + tid - H2] = s23;
+    if (te < H2) a.partial2[(int64_t)bid * H2 + te] = s23;
+    else if (te < H2 + C) a.partial3[(int64_t)bid * C + te - H2] = s23;
     if (a.dW3_part != nullptr) {
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            const int o = tid + 1024 * i;
+            const int o = te + 1024 * i;
             if (o < C * H2) a.dW3_part[(int64_t)bid * C * H2 + o] = acc3[i];
         }
     }

@@ -78,6 +78,54 @@ __device__ __forceinline__ double wave_sum_d(double v)
     v += dpp_d<DPP_MIRROR>(v);
     return add_xor32_d(add_xor16_d(v));
 }
+// smallest value of the wave, float64 and unsigned 64-bit (a packed (number, position) pair), in every lane
+__device__ __forceinline__ double min_xor16_d(double v)
+{
+    const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(v), (unsigned)__double2loint(v), false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(v), (unsigned)__double2hiint(v), false, false);
+    return fmin(__hiloint2double((int)hi[0], (int)lo[0]), __hiloint2double((int)hi[1], (int)lo[1]));
+}
+__device__ __forceinline__ double min_xor32_d(double v)
+{
+    const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(v), (unsigned)__double2loint(v), false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(v), (unsigned)__double2hiint(v), false, false);
+    return fmin(__hiloint2double((int)hi[0], (int)lo[0]), __hiloint2double((int)hi[1], (int)lo[1]));
+}
+__device__ __forceinline__ double wave_min_d(double v)
+{
+    v = fmin(v, dpp_d<DPP_XOR1>(v));
+    v = fmin(v, dpp_d<DPP_XOR2>(v));
+    v = fmin(v, dpp_d<DPP_HALF_MIRROR>(v));
+    v = fmin(v, dpp_d<DPP_MIRROR>(v));
+    return min_xor32_d(min_xor16_d(v));
+}
+template <int CTRL>
+__device__ __forceinline__ uint64_t dpp_u64(uint64_t v)
+{
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)v, CTRL, 0xF, 0xF, true);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(v >> 32), CTRL, 0xF, 0xF, true);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t umin64(uint64_t a, uint64_t b) { return a < b ? a : b; }
+__device__ __forceinline__ uint64_t wave_min_u64(uint64_t v)
+{
+    v = umin64(v, dpp_u64<DPP_XOR1>(v));
+    v = umin64(v, dpp_u64<DPP_XOR2>(v));
+    v = umin64(v, dpp_u64<DPP_HALF_MIRROR>(v));
+    v = umin64(v, dpp_u64<DPP_MIRROR>(v));
+    {
+        const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);
+        const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)(v >> 32), (unsigned)(v >> 32), false, false);
+        v = umin64(((uint64_t)hi[0] << 32) | lo[0], ((uint64_t)hi[1] << 32) | lo[1]);
+    }
+    {
+        const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
+        const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)(v >> 32), (unsigned)(v >> 32), false, false);
+        v = umin64(((uint64_t)hi[0] << 32) | lo[0], ((uint64_t)hi[1] << 32) | lo[1]);
+    }
+    return v;
+}
+
 __device__ __forceinline__ float wave_max_f(float v)
 {
     v = fmaxf(v, dpp_f<DPP_XOR1>(v));

@@ -798,7 +798,7 @@ def main():
                                 "frac": args.n * b_vec / ((hp.mean_ms("edits", args.warmup) + t_vec + hp.mean_ms("stats", args.warmup)) * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                 "note": "the stage's algorithmic bytes are the vectoriser's (SURVEY 8d); the site generator is Philox-bound "
                                         "compute, the scaler fit reads view 0 once more (1.64 GB at cfg2)"},
-            "roofline_epoch": {"kernel": "training epoch (hipBLASLt fp32 GEMMs + gather + losses + RMSprop)", "bound": "mfma",
+            "roofline_epoch": {"kernel": "training epoch (six launches a step: own fp32-MFMA tiles for layer 1 and dW1, the middle, InfoNCE, IIC, RMSprop; the fixed job's lockstep voters use batched library GEMMs for the two big products)", "bound": "mfma",
                                "achieved": ach_ep, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach_ep / MFMA_F32_PEAK_TFLOPS,
                                "ms": t_ep, "flop_per_seq_algorithmic": f_ep, "share_of_step": t_ep * len(hp.my_voters) / ms_step,
                                "flop_per_seq_executed": f_exec, "achieved_executed": ach_exec, "frac_executed": ach_exec / MFMA_F32_PEAK_TFLOPS,

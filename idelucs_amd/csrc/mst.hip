@@ -975,7 +975,12 @@ constexpr int LZ_W = 4;                // candidates a workgroup leaves, in orde
                                        // workgroup's next best is not known)
 constexpr int LZ_QCAP = 1024;          // (point, node) pairs a workgroup's exact-distance queue holds; beyond: the owner computes its own
 struct CandK { double w, core; int64_t j, p; };
-struct LazyDec { int m, fresh; long long cp[LZ_T], co[LZ_T]; double cw[LZ_T], cc[LZ_T]; };
+struct LazyDec {
+    int m, fresh;
+    long long cp[LZ_T], co[LZ_T]; double cw[LZ_T], cc[LZ_T];     // the nodes to commit: position, original number, weight, core distance
+    long long src[LZ_T];                                          // their stored sources (for the recording workgroup)
+    double xc[LZ_T][PRIM_FILTER_D];                               // their coordinates: the step reads them without waiting for cp
+};
 struct LazyMulti {
     CandK *cand[2];            // [grid * LZ_W] by candidate parity: each workgroup's LZ_W best, ascending
     double *rest[2];           // [grid]: smallest core distance among the workgroup's awake outside points NOT among its LZ_W
@@ -983,51 +988,29 @@ struct LazyMulti {
     int tmax;                  // <= LZ_T (IDELUCS_MST_MULTI)
 };
 
-// (w, j) ascending with an index riding along: the block's best in every thread.  NT threads, scratch of NT / 64 entries each.
-template <int NT>
-__device__ __forceinline__ void block_argmin(double &bw, int64_t &bj, int &bi, double *sw, int64_t *sj, int *si)
-{
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const double ow = __shfl_xor(bw, o, 64);
-        const int64_t oj = __shfl_xor(bj, o, 64);
-        const int oi = __shfl_xor(bi, o, 64);
-        if (better(ow, oj, bw, bj)) { bw = ow; bj = oj; bi = oi; }
-    }
-    const int tid = threadIdx.x;
-    if ((tid & 63) == 0) { sw[tid >> 6] = bw; sj[tid >> 6] = bj; si[tid >> 6] = bi; }
-    __syncthreads();
-    bw = sw[0]; bj = sj[0]; bi = si[0];
-#pragma unroll
-    for (int w = 1; w < NT / 64; ++w) if (better(sw[w], sj[w], bw, bj)) { bw = sw[w]; bj = sj[w]; bi = si[w]; }
-    __syncthreads();
-}
-
-// wave-wide argmin of (w, j) with an index riding along; every lane gets the result
+// wave-wide argmin of (w, j) with an index riding along; every lane gets the result.  On the VALU alone (wave_ops.h): the smallest
+// weight first, then the smallest (number, index) pair among the lanes that hold it, packed into one word -- numbers < 2^31 or
+// INT64_MAX ("nothing": index -1), indices >= 0.  (The __shfl_xor butterfly over the three values was ~350 wave instructions.)
 __device__ __forceinline__ void wave_argmin(double &bw, int64_t &bj, int &bi)
 {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const double ow = __shfl_xor(bw, o, 64);
-        const int64_t oj = __shfl_xor(bj, o, 64);
-        const int oi = __shfl_xor(bi, o, 64);
-        if (better(ow, oj, bw, bj)) { bw = ow; bj = oj; bi = oi; }
-    }
+    const double wmin = idl_dev::wave_min_d(bw);
+    uint64_t key = (bw == wmin && bj != INT64_MAX) ? (((uint64_t)bj << 32) | (uint64_t)(uint32_t)bi) : ~0ull;
+    key = idl_dev::wave_min_u64(key);
+    bw = wmin;
+    bj = key == ~0ull ? INT64_MAX : (int64_t)(key >> 32);
+    bi = key == ~0ull ? -1 : (int)(uint32_t)key;
 }
 
 // One workgroup of 256 threads; thread t merges the (sorted) lists of workgroups 4 t .. 4 t + 3.  The tournament runs on ONE 64-bit
 // key per entry -- the weight's bit pattern (weights are >= 0: the order of the bits is the order of the values) -- kept in LDS, a
-// list's head a row number; equal weights (rare) are told apart by the original number in a second step.  (The first form carried
-// (weight, number, index) through every compare and shuffle and kept the lists in registers behind predicated selects: 350 wave
-// instructions and 1.6 us a round.)
+// list's head a row number; equal weights (rare) are told apart by the original number in a second step.
+// wave-wide minimum of (k, bi), bi >= 0, lexicographic; every lane gets the result
 __device__ __forceinline__ void wave_min_u64(unsigned long long &k, int &bi)
 {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const unsigned long long ok = __shfl_xor(k, o, 64);
-        const int oi = __shfl_xor(bi, o, 64);
-        if (ok < k || (ok == k && oi < bi)) { k = ok; bi = oi; }
-    }
+    const unsigned long long kmin = idl_dev::wave_min_u64(k);
+    uint64_t ik = k == kmin ? (uint64_t)(uint32_t)bi : ~0ull;
+    ik = idl_dev::wave_min_u64(ik);
+    k = kmin; bi = (int)(uint32_t)ik;
 }
 
 __global__ __launch_bounds__(256) void lazy_reduce_kernel(PrimArgs a, LazyArgs z, LazyMulti u, int64_t launch, int grid)
@@ -1040,6 +1023,11 @@ __global__ __launch_bounds__(256) void lazy_reduce_kernel(PrimArgs a, LazyArgs z
     __shared__ int wsel[NT / 64][LZ_T];                      // a wave's winners: entry numbers in the candidate buffer, -1: none
     __shared__ double dup[LZ_T], red[NT / 64];
     const int tid = threadIdx.x, par = (int)(launch & 1), G = z.n_groups;
+#ifdef IDL_PHASE_STAMPS
+    uint64_t last_ = __builtin_amdgcn_s_memrealtime();
+    const bool stamping = tid == 0;
+    const int kind_ = 2;
+#endif
     const LazyState S = z.st[par];
     LazyDec *D = &u.dec[par];
     if (S.stalled || S.n_tree >= a.n) { if (tid == 0) D->m = 0; return; }
@@ -1077,16 +1065,17 @@ __global__ __launch_bounds__(256) void lazy_reduce_kernel(PrimArgs a, LazyArgs z
         }
     }
     auto block_min = [&](double v) {
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) v = fmin(v, __shfl_xor(v, o, 64));
+        v = idl_dev::wave_min_d(v);
         if ((tid & 63) == 0) red[tid >> 6] = v;
         __syncthreads();
         const double r = fmin(fmin(red[0], red[1]), fmin(red[2], red[3]));
         __syncthreads();
         return r;
     };
+    LZ_MARK(0);                                              // lists in LDS, bounds loaded
     lb = block_min(lb);
     rmin = block_min(rmin);
+    LZ_MARK(1);
     // ---- every wave's tournament over its 256 lists: no barrier
     const int T = u.tmax;
     int head[LPT] = {0, 0, 0, 0};                            // a list's head: its row offset 0 .. LZ_W (LZ_W: exhausted)
@@ -1132,6 +1121,7 @@ __global__ __launch_bounds__(256) void lazy_reduce_kernel(PrimArgs a, LazyArgs z
         }
     }
     __syncthreads();
+    LZ_MARK(2);                                              // the waves' tournaments
     if (tid < (NT / 64) * LZ_T) {                            // 32 lanes: an entry each, ranked among the 4 T (empty entries by position)
         __shared__ CandK mrg[(NT / 64) * LZ_T];
         const int mw = tid / LZ_T, mr = tid % LZ_T;
@@ -1148,6 +1138,7 @@ __global__ __launch_bounds__(256) void lazy_reduce_kernel(PrimArgs a, LazyArgs z
         if (rank < LZ_T) { chosen[rank] = me; cut[rank] = (idx >= 0 && idx % LZ_W == LZ_W - 1) ? 1 : 0; }
     }
     __syncthreads();
+    LZ_MARK(3);                                              // merged by rank
     // the smallest core distance among the listed entries that were not chosen: everything strictly behind the T-th
     double umin = __builtin_inf();
     {
@@ -1159,19 +1150,26 @@ __global__ __launch_bounds__(256) void lazy_reduce_kernel(PrimArgs a, LazyArgs z
         }
     }
     umin = fmin(block_min(umin), rmin);
-    // how far the candidates are from the node added last (an upper bound): each wave takes two
+    LZ_MARK(4);
+    // how far the candidates are from the node added last (an upper bound): each wave takes two.  Their coordinates and stored
+    // sources go into the record: the step reads them in its first trip instead of chasing the positions
+    __shared__ long long csrc[LZ_T];
     for (int r = tid >> 6; r < T; r += NT / 64) {
         const int l = tid & 63;
-        double d2 = 0.0;
-        if (chosen[r].w < __builtin_inf()) {
-            const double t = (double)z.xrow[chosen[r].p * PRIM_FILTER_D + l] - (double)z.xrow[S.cur_p * PRIM_FILTER_D + l];
+        double d2 = 0.0, xr = 0.0;
+        const bool real = chosen[r].w < __builtin_inf();
+        if (real) {
+            xr = (double)z.xrow[chosen[r].p * PRIM_FILTER_D + l];
+            const double t = xr - (double)z.xrow[S.cur_p * PRIM_FILTER_D + l];
             d2 = t * t;
+            if (l == 0) csrc[r] = a.source[chosen[r].p];
         }
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) d2 += __shfl_xor(d2, o, 64);
+        D->xc[r][l] = xr;
+        d2 = idl_dev::wave_sum_d(d2);                        // (any order: the bound keeps 1e-9 of slack)
         if (l == 0) dup[r] = __dsqrt_rn(d2) * (1.0 + 1e-9) + 1e-300;
     }
     __syncthreads();
+    LZ_MARK(5);                                              // distances, coordinates, sources
     if (tid == 0) {
         int m = 0;
         const int fresh = D->fresh;
@@ -1191,9 +1189,14 @@ __global__ __launch_bounds__(256) void lazy_reduce_kernel(PrimArgs a, LazyArgs z
         for (int i = 0; i < LZ_T; ++i) {
             const bool on = i < m;
             D->cp[i] = on ? chosen[i].p : 0; D->co[i] = on ? chosen[i].j : 0; D->cw[i] = on ? chosen[i].w : 0.0; D->cc[i] = on ? chosen[i].core : 0.0;
+            D->src[i] = (on && i < T) ? csrc[i] : 0;
         }
         if (m == 0) { LazyState t = S; t.stalled = 1; z.st[par] = t; }      // the step launch behind this one falls through with it
     }
+    LZ_MARK(6);
+#ifdef IDL_PHASE_STAMPS
+    if (stamping) atomicAdd(&lazy_phase_sum[2][7], 1ull);
+#endif
 }
 
 __global__ __launch_bounds__(PRIM_NT, 3) void lazy_multi_kernel(PrimArgs a, LazyArgs z, LazyMulti u, int64_t launch, int rescan)
@@ -1204,8 +1207,9 @@ __global__ __launch_bounds__(PRIM_NT, 3) void lazy_multi_kernel(PrimArgs a, Lazy
     __shared__ double ccs[LZ_T];
     __shared__ long long cps[LZ_T], cos_[LZ_T];
     __shared__ int q_n;
-    __shared__ unsigned short q_item[LZ_QCAP];
-    __shared__ double q_val[LZ_QCAP];
+    __shared__ unsigned short q_item[LZ_QCAP / LZ_T];       // the queue: a point an item
+    __shared__ unsigned q_mask[LZ_QCAP / LZ_T];              // in: the nodes whose floor it passes; out: those whose exact distance was formed
+    __shared__ double q_val[LZ_QCAP];                        // [item][node]
     __shared__ double pair_d[LZ_T * LZ_T];
     __shared__ double cws[LZ_T];
     __shared__ long long srcs[LZ_T];
@@ -1214,26 +1218,35 @@ __global__ __launch_bounds__(PRIM_NT, 3) void lazy_multi_kernel(PrimArgs a, Lazy
     const int64_t n = a.n;
     const int G = z.n_groups;
     const int par = (int)(launch & 1);
+#ifdef IDL_PHASE_STAMPS
+    uint64_t last_ = __builtin_amdgcn_s_memrealtime();
+    const bool stamping = tid == 0 && !rescan && (blockIdx.x == 0 || blockIdx.x % 61 == 7);
+    const int kind_ = blockIdx.x == 0 ? 0 : 1;
+#endif
+    // ---- trip 1: this workgroup's number and run flags (the list: lazy_list_kernel), the state of the walk, what the reduce decided
+    const int entry = z.wg_list[1 + blockIdx.x];
     const LazyState S = z.st[par];
     LazyState *nx = &z.st[par ^ 1];
-    const LazyDec *Dp = &u.dec[par];                         // (read field by field: a private copy of the record is 66 registers a lane)
+    const LazyDec *Dp = &u.dec[par];                         // (read field by field: a private copy of the record is registers a lane)
     const int D_m = Dp->m, D_fresh = Dp->fresh;
-    const bool lead = blockIdx.x == 0 && tid == 0;
-    const bool ball_duty = (int)blockIdx.x < G;
+    const int wg = __builtin_amdgcn_readfirstlane(entry) & 0xFFFF, wg_mask = __builtin_amdgcn_readfirstlane(entry) >> 16;
+    const bool lead = wg == 0 && tid == 0;
+    const bool ball_duty = wg * (PRIM_NT / 64) < G;          // group g's bound: wave g % 4 of workgroup g / 4, as in lazy_step_kernel
+    const int ball_g = wg * (PRIM_NT / 64) + (tid >> 6);
+    const bool has_ball = ball_g < G;
     if (S.stalled || S.n_tree >= n || (!rescan && D_m == 0)) {      // fall through: the state and the bounds are handed on unchanged
         if (lead) { *nx = S; u.dec[par ^ 1].fresh = D_fresh; }
-        if (ball_duty && tid == 0) z.lbp[(par ^ 1) * G + blockIdx.x] = z.lbp[par * G + blockIdx.x];
+        if (has_ball && (tid & 63) == 0) z.lbp[(par ^ 1) * G + ball_g] = z.lbp[par * G + ball_g];
         return;
     }
     const int m = rescan ? 1 : D_m;                          // nodes scanned by this launch (a re-scan: the node added last, nothing committed)
-    const int64_t stride = (int64_t)gridDim.x * PRIM_NT;
-    const int64_t p0 = (int64_t)blockIdx.x * PRIM_NT + tid;
+    const int64_t stride = (int64_t)z.full_grid * PRIM_NT;
+    const int64_t p0 = (int64_t)wg * PRIM_NT + tid;
     bool run_on[PRIM_AHEAD];
     bool any_on = false;
 #pragma unroll
     for (int i = 0; i < PRIM_AHEAD; ++i) {
-        const int64_t first = (int64_t)blockIdx.x * PRIM_NT + i * stride;
-        run_on[i] = first < n && z.run_asleep[first / PRIM_NT] == 0;
+        run_on[i] = ((wg_mask >> i) & 1) != 0;
         any_on |= run_on[i];
     }
     CandK *cand_out = u.cand[S.cand_par ^ 1] + (int64_t)blockIdx.x * LZ_W;
@@ -1242,68 +1255,91 @@ __global__ __launch_bounds__(PRIM_NT, 3) void lazy_multi_kernel(PrimArgs a, Lazy
         if (tid < LZ_W) cand_out[tid] = CandK{__builtin_inf(), __builtin_inf(), INT64_MAX, 0};
         if (tid == 0) *rest_out = __builtin_inf();
     };
-    if (!any_on && !ball_duty && blockIdx.x != 0) { leave_empty(); return; }
-    // ---- prologue: the state of the points of the runs that are awake, their codes
+    if (!any_on && !ball_duty && wg != 0) { leave_empty(); return; }
+    LZ_MARK(0);
+    // ---- trip 2, requests (lazy_step_kernel has the reasoning): 21 bytes of state a point, the nodes with their coordinates out of
+    // the record, the kept ball
     double mr_a[PRIM_AHEAD], cj_a[PRIM_AHEAD];
-    int64_t o_a[PRIM_AHEAD];
-    bool in_run[PRIM_AHEAD];
-    uint32_t cw[PRIM_AHEAD][PRIM_FILTER_D / 4];
-    float rs[PRIM_AHEAD], run_scale[PRIM_AHEAD];
-    int run_g[PRIM_AHEAD], g_own[PRIM_AHEAD];
+    int run_g[PRIM_AHEAD], pas_a[PRIM_AHEAD], o32[PRIM_AHEAD];
+    double run_scale[PRIM_AHEAD];
 #pragma unroll
     for (int i = 0; i < PRIM_AHEAD; ++i) {
+        const int64_t first = (int64_t)wg * PRIM_NT + i * stride;
         const int64_t p = p0 + i * stride;
-        const bool on = run_on[i] && p < n;
-        mr_a[i] = on ? a.min_reach[p] : -1.0;
-        cj_a[i] = on ? a.core[p] : 0.0;
-        o_a[i] = on ? (int64_t)a.orig[p] : 0;
-        const int64_t first = (int64_t)blockIdx.x * PRIM_NT + i * stride;
-        run_g[i] = run_on[i] ? a.gid[first] : 0;
-        g_own[i] = on ? a.gid[p] : -1;
-        if (on && z.pas[p]) mr_a[i] = -1.0;
+        mr_a[i] = -1.0; cj_a[i] = 0.0; run_g[i] = 0; pas_a[i] = 1; o32[i] = 0;
+        if (run_on[i]) {                                     // (uniform)
+            const int64_t pc = p < n ? p : first;
+            mr_a[i] = a.min_reach[pc];
+            cj_a[i] = a.core[pc];
+            pas_a[i] = z.pas[pc];
+            o32[i] = a.orig[pc];
+            run_g[i] = a.gid[first];
+        }
     }
+    long long n_cp = -1, n_co = 0, n_src = 0;                // thread q < LZ_T: node q
+    double n_cc = 0.0, n_cw = 0.0;
+    if (tid < LZ_T && !rescan && tid < m) { n_cp = Dp->cp[tid]; n_co = Dp->co[tid]; n_cc = Dp->cc[tid]; n_cw = Dp->cw[tid]; n_src = Dp->src[tid]; }
+    if (tid < LZ_T && rescan && tid == 0) { n_cp = S.cur_p; n_co = S.cur_o; n_cc = a.core[S.cur_p]; }
+    double x_node[LZ_T * PRIM_FILTER_D / PRIM_NT];           // 2 coordinates a thread
+#pragma unroll
+    for (int t = 0; t < LZ_T * PRIM_FILTER_D / PRIM_NT; ++t) {
+        const int idx = tid + t * PRIM_NT;
+        x_node[t] = 0.0;
+        if (idx < m * PRIM_FILTER_D) x_node[t] = rescan ? (double)z.xrow[S.cur_p * PRIM_FILTER_D + (idx & 63)] : Dp->xc[idx >> 6][idx & 63];
+    }
+    double ball_c = 0.0, ball_lb = 0.0, ball_r = 0.0;
+    int ball_as = 0;
+    if (has_ball) {
+        ball_lb = z.lbp[par * G + ball_g];
+        ball_as = z.asleep[ball_g];
+        ball_c = z.gc[(int64_t)ball_g * PRIM_FILTER_D + (tid & 63)];
+        ball_r = z.gr[ball_g];
+    }
+    asm volatile("" ::: "memory");
+#define LZ_PIN(x) asm volatile("" : "+v"(x))
+#pragma unroll
+    for (int i = 0; i < PRIM_AHEAD; ++i) { LZ_PIN(mr_a[i]); LZ_PIN(cj_a[i]); LZ_PIN(run_g[i]); LZ_PIN(pas_a[i]); LZ_PIN(o32[i]); }
+    LZ_PIN(n_cp); LZ_PIN(n_co); LZ_PIN(n_cc); LZ_PIN(n_cw); LZ_PIN(n_src);
+#pragma unroll
+    for (int t = 0; t < LZ_T * PRIM_FILTER_D / PRIM_NT; ++t) LZ_PIN(x_node[t]);
+    LZ_PIN(ball_lb); LZ_PIN(ball_as); LZ_PIN(ball_c); LZ_PIN(ball_r);
+#undef LZ_PIN
+    LZ_MARK(1);
+    // ---- trip 2, answers
+    int64_t o_a[PRIM_AHEAD];
+    int my_run_g;
     {
-        const __amdgpu_buffer_rsrc_t c_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.codes, 0, 0xffffffff, 0x00020000);
+        const int rr = tid >> 6;
 #pragma unroll
         for (int i = 0; i < PRIM_AHEAD; ++i) {
             const int64_t p = p0 + i * stride;
-            in_run[i] = mr_a[i] >= 0.0 && g_own[i] == run_g[i];
-            rs[i] = 0.f;
-            run_scale[i] = (float)a.gscale[run_g[i]];
-            if (in_run[i]) {
-                rs[i] = a.resid[p];
-#pragma unroll
-                for (int k = 0; k < PRIM_FILTER_D / 4; ++k) cw[i][k] = __builtin_amdgcn_raw_buffer_load_b32(c_rsrc, (uint32_t)p * 4u, k * (int)n * 4, 0);
-            }
+            const bool on = run_on[i] && p < n;
+            if (!on || pas_a[i] != 0) mr_a[i] = -1.0;
+            if (!on) cj_a[i] = 0.0;
+            o_a[i] = on ? (int64_t)o32[i] : 0;
+            run_scale[i] = a.gscale[run_g[i]];
         }
+        my_run_g = rr == 0 ? run_g[0] : rr == 1 ? run_g[1] : rr == 2 ? run_g[2] : run_g[3];
     }
-    // ---- the nodes of this launch: position, original number, core distance, coordinates
-    if (tid < LZ_T) {
-        const bool on = tid < m;
-        const long long p = rescan ? S.cur_p : (on ? Dp->cp[tid] : 0);
-        cps[tid] = on ? p : -1;
-        cos_[tid] = rescan ? S.cur_o : (on ? Dp->co[tid] : 0);
-        ccs[tid] = on ? a.core[p] : 0.0;
-        cws[tid] = (on && !rescan) ? Dp->cw[tid] : 0.0;
-        srcs[tid] = (on && !rescan && blockIdx.x == 0) ? a.source[p] : 0;       // (the recording workgroup: every stored source in one trip)
-    }
+    const double my_sc = a.gscale[my_run_g];
+    const float my_lo = a.glo[(int64_t)my_run_g * PRIM_FILTER_D + (tid & 63)];
+    if (tid < LZ_T) { cps[tid] = n_cp; cos_[tid] = n_co; ccs[tid] = n_cc; cws[tid] = n_cw; srcs[tid] = n_src; }
     if (tid == 0) q_n = 0;
-    // (the coordinates straight from the record's positions, beside the loads above: one trip, not two)
-    for (int idx = tid; idx < m * PRIM_FILTER_D; idx += PRIM_NT) {
-        const long long p = rescan ? S.cur_p : Dp->cp[idx >> 6];
-        xcs[idx >> 6][idx & 63] = (double)z.xrow[p * PRIM_FILTER_D + (idx & 63)];
+#pragma unroll
+    for (int t = 0; t < LZ_T * PRIM_FILTER_D / PRIM_NT; ++t) {
+        const int idx = tid + t * PRIM_NT;
+        if (idx < m * PRIM_FILTER_D) xcs[idx >> 6][idx & 63] = x_node[t];
     }
     __syncthreads();
     {       // one (run, feature) per thread, as in the single-node step; its box corner and scale are loaded once, the nodes loop in LDS
         static_assert(PRIM_RUNS * 64 == PRIM_NT && PRIM_FILTER_D == 64 && PRIM_AHEAD == 4, "one (run, feature) per thread");
         const int rr = tid >> 6, k = tid & 63;
-        const int g = rr == 0 ? run_g[0] : rr == 1 ? run_g[1] : rr == 2 ? run_g[2] : run_g[3];
-        const double lo = (double)a.glo[(int64_t)g * PRIM_FILTER_D + k], sc = a.gscale[g];
-        for (int q = 0; q < m; ++q) up[q][rr][k] = (float)((xcs[q][k] - lo) / sc);
+        for (int q = 0; q < m; ++q) up[q][rr][k] = (float)((xcs[q][k] - (double)my_lo) / my_sc);
     }
+    LZ_MARK(2);                                              // nodes and boxes in LDS
     // ---- the recording workgroup: the edges of the committed nodes, in order.  The edge of c_i is the one the scans so far left
     // (its stored min_reach and source) unless one of c_0 .. c_{i-1} reaches it at a smaller mutual-reachability distance
-    if (blockIdx.x == 0 && !rescan) {
+    if (wg == 0 && !rescan) {
         for (int pr = tid; pr < m * m; pr += PRIM_NT) {
             const int k = pr / m, i = pr % m;
             double v = __builtin_inf();
@@ -1342,25 +1378,24 @@ __global__ __launch_bounds__(PRIM_NT, 3) void lazy_multi_kernel(PrimArgs a, Lazy
         *nx = t;
         u.dec[par ^ 1].fresh = D_fresh;
     }
-    // ---- sleeping group g's bound meets the new nodes (workgroup g, its first wave)
-    if (ball_duty && tid < 64) {
-        const int g = blockIdx.x;
-        double lbv = z.lbp[par * G + g];
-        if (!rescan && z.asleep[g] == 1) {
+    // ---- the sleeping groups' bounds meet the new nodes (a group per wave)
+    if (has_ball) {
+        double lbv = ball_lb;
+        if (!rescan && ball_as == 1) {
             for (int q = 0; q < m; ++q) {
-                const double t = xcs[q][tid] - z.gc[(int64_t)g * PRIM_FILTER_D + tid];
-                double d2 = t * t;
-#pragma unroll
-                for (int o = 1; o < 64; o <<= 1) d2 += __shfl_xor(d2, o, 64);
-                const double b = __dsqrt_rn(d2) * (1.0 - 1e-12) - z.gr[g];
+                const double t = xcs[q][tid & 63] - ball_c;
+                const double d2 = idl_dev::wave_sum_d(t * t);
+                const double b = __dsqrt_rn(d2) * (1.0 - 1e-12) - ball_r;
                 lbv = fmin(lbv, b > 0.0 ? b : 0.0);
             }
         }
-        if (tid == 0) z.lbp[(par ^ 1) * G + g] = lbv;
+        if ((tid & 63) == 0) z.lbp[(par ^ 1) * G + ball_g] = lbv;
     }
     __syncthreads();
+    LZ_MARK(3);                                              // recorded, balls
     if (!any_on) { leave_empty(); return; }
-    // ---- which (point, node) pairs could change something: the floor test, then the 8-bit bound
+    // ---- which (point, node) pairs could change something: the floor test first; for the points with such a pair -- trip 3 -- group,
+    // residual and codes, then the 8-bit bound
     bool act[PRIM_AHEAD];
     unsigned mask[PRIM_AHEAD];
 #pragma unroll
@@ -1370,93 +1405,104 @@ __global__ __launch_bounds__(PRIM_NT, 3) void lazy_multi_kernel(PrimArgs a, Lazy
         for (int q = 0; q < m; ++q) if (p == cps[q]) act[i] = false;        // committed in this launch (a re-scan: the node itself)
         mask[i] = 0u;
         if (!act[i]) continue;
-        for (int q = 0; q < m; ++q) {
-            const double fl = fmax(ccs[q], cj_a[i]);
-            if (!(fl < mr_a[i])) continue;
-            if (in_run[i]) {
-                float acc = 0.f;
-                const float *uu = up[q][i];
-#pragma unroll
-                for (int k = 0; k < PRIM_FILTER_D / 4; ++k) {
-                    const uint32_t w = cw[i][k];
-                    const float t0 = uu[4 * k] - (float)(w & 255u), t1 = uu[4 * k + 1] - (float)((w >> 8) & 255u);
-                    const float t2 = uu[4 * k + 2] - (float)((w >> 16) & 255u), t3 = uu[4 * k + 3] - (float)(w >> 24);
-                    acc = fmaf(t0, t0, acc); acc = fmaf(t1, t1, acc); acc = fmaf(t2, t2, acc); acc = fmaf(t3, t3, acc);
-                }
-                const double sc = (double)run_scale[i];
-                const double lbq = sc * (double)sqrtf(acc) * (1.0 - 4e-5) - 0.01 * sc - (double)rs[i];      // (prim_step_kernel has the reasoning)
-                if (fmax(fl, lbq) >= mr_a[i]) continue;
-            }
-            mask[i] |= 1u << q;
-        }
+        for (int q = 0; q < m; ++q) if (fmax(ccs[q], cj_a[i]) < mr_a[i]) mask[i] |= 1u << q;
     }
-    // ---- the exact distances of those pairs, shared out over the workgroup through a queue; a point whose pairs do not fit this
-    // round's queue waits for the next (rare: inside a cluster's core nearly no pair passes the floor test); then every point
-    // meets its pairs in the nodes' order, with the scan's strict <
+    // ---- a point with such a pair is an ITEM of the workgroup's queue; a thread takes an item: trip 3, the point's group, residual and
+    // codes -> the 8-bit bound against each of its nodes; trip 4 (when a pair survives) its coordinates, ONCE for all its nodes -> the
+    // exact distances, in q_val[item][node].  (The first form kept the codes of a lane's four points in 64 registers and queued
+    // (point, node) pairs, each fetching the point again: 168 registers and 116 bytes of scratch, or two workgroups a CU.)  A point
+    // that does not fit the queue waits for the next round.
     const float *xt = (const float *)a.xt;
     const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)xt, 0, 0xffffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t c_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.codes, 0, 0xffffffff, 0x00020000);
     const int col_bytes = (int)n * 4;
+    constexpr int ITEMS = LZ_QCAP / LZ_T;                    // q_val rows of LZ_T
     bool todo = false;
 #pragma unroll
     for (int i = 0; i < PRIM_AHEAD; ++i) todo |= mask[i] != 0u;
     while (__syncthreads_or(todo ? 1 : 0)) {                 // (inside a cluster's core nearly every launch skips this block)
-        int base[PRIM_AHEAD];
-        bool in_q[PRIM_AHEAD];
+        int slot[PRIM_AHEAD];
 #pragma unroll
         for (int i = 0; i < PRIM_AHEAD; ++i) {
-            in_q[i] = false; base[i] = 0;
+            slot[i] = -1;
             if (!mask[i]) continue;
-            const int cnt = __popc(mask[i]);
-            base[i] = atomicAdd(&q_n, cnt);
-            if (base[i] + cnt > LZ_QCAP) {
-                for (int s = base[i]; s < LZ_QCAP; ++s) q_item[s] = 0xFFFFu;
-            } else {
-                in_q[i] = true;
-                int s = base[i];
-                for (int q = 0; q < m; ++q) if (mask[i] >> q & 1u) q_item[s++] = (unsigned short)((tid * PRIM_AHEAD + i) | (q << 10));
-            }
+            const int s_ = atomicAdd(&q_n, 1);
+            if (s_ < ITEMS) { slot[i] = s_; q_item[s_] = (unsigned short)(tid * PRIM_AHEAD + i); q_mask[s_] = mask[i]; }
         }
         __syncthreads();
-        const int qn = q_n < LZ_QCAP ? q_n : LZ_QCAP;
-        for (int s = tid; s < qn; s += PRIM_NT) {
-            const unsigned it = q_item[s];
-            if (it == 0xFFFFu) continue;
-            const int item = it & 1023, q = it >> 10, t_own = item / PRIM_AHEAD, i_own = item % PRIM_AHEAD;
-            const int64_t p = (int64_t)blockIdx.x * PRIM_NT + t_own + i_own * stride;
-            const double cjp = a.core[p];
-            double acc = 0.0;
-            uint32_t v[64];
+        const int qn = q_n < ITEMS ? q_n : ITEMS;
+        for (int s_ = tid; s_ < qn; s_ += PRIM_NT) {
+            const unsigned it = q_item[s_];
+            const int item = it & 1023, t_own = item / PRIM_AHEAD, i_own = item % PRIM_AHEAD;
+            unsigned mk = q_mask[s_];
+            const int64_t p = (int64_t)wg * PRIM_NT + t_own + i_own * stride;
+            const int64_t first = (int64_t)wg * PRIM_NT + i_own * stride;
+            const int gp = a.gid[p], gr = a.gid[first];
+            const float rsd = a.resid[p];
+            const double cjp = a.core[p], mrp = a.min_reach[p];
+            uint32_t cwd[PRIM_FILTER_D / 4];
 #pragma unroll
-            for (int k = 0; k < 64; ++k) v[k] = __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, (uint32_t)p * 4u, k * col_bytes, 0);
+            for (int k = 0; k < PRIM_FILTER_D / 4; ++k) cwd[k] = __builtin_amdgcn_raw_buffer_load_b32(c_rsrc, (uint32_t)p * 4u, k * (int)n * 4, 0);
+            if (gp == gr) {                                  // (else: a point of another group than its run's: no codes in this box)
+                const double sc = (double)(float)a.gscale[gr];
+                for (int q = 0; q < m; ++q) {
+                    if (!(mk >> q & 1u)) continue;
+                    float acc = 0.f;
+                    const float *uu = up[q][i_own];
 #pragma unroll
-            for (int k = 0; k < 64; ++k) {
-                if ((k & 7) == 0) __builtin_amdgcn_sched_barrier(0);
-                const double t = xcs[q][k] - (double)__uint_as_float(v[k]);
-                acc = idl_dev::square_then_add(acc, t);
+                    for (int k = 0; k < PRIM_FILTER_D / 4; ++k) {
+                        const uint32_t w = cwd[k];
+                        const float t0 = uu[4 * k] - (float)(w & 255u), t1 = uu[4 * k + 1] - (float)((w >> 8) & 255u);
+                        const float t2 = uu[4 * k + 2] - (float)((w >> 16) & 255u), t3 = uu[4 * k + 3] - (float)(w >> 24);
+                        acc = fmaf(t0, t0, acc); acc = fmaf(t1, t1, acc); acc = fmaf(t2, t2, acc); acc = fmaf(t3, t3, acc);
+                    }
+                    const double lbq = sc * (double)sqrtf(acc) * (1.0 - 4e-5) - 0.01 * sc - (double)rsd;      // (prim_step_kernel has the reasoning)
+                    if (fmax(fmax(ccs[q], cjp), lbq) >= mrp) mk &= ~(1u << q);
+                }
             }
-            q_val[s] = fmax(fmax(ccs[q], cjp), __dsqrt_rn(acc));     // mrd(node q, point p)
+            if (mk != 0u) {
+                uint32_t v[64];
+#pragma unroll
+                for (int k = 0; k < 64; ++k) v[k] = __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, (uint32_t)p * 4u, k * col_bytes, 0);
+                for (int q = 0; q < m; ++q) {
+                    if (!(mk >> q & 1u)) continue;
+                    double acc = 0.0;
+#pragma unroll
+                    for (int k = 0; k < 64; ++k) {
+                        if ((k & 7) == 0) __builtin_amdgcn_sched_barrier(0);
+                        uint32_t vk = v[k];
+                        asm volatile("" : "+v"(vk));         // (widened here, every time: hoisted out of the loop over the nodes the 64 doubles are 128 registers)
+                        const double t = xcs[q][k] - (double)__uint_as_float(vk);
+                        acc = idl_dev::square_then_add(acc, t);
+                    }
+                    q_val[s_ * LZ_T + q] = fmax(fmax(ccs[q], cjp), __dsqrt_rn(acc));     // mrd(node q, point p)
+                }
+            }
+            q_mask[s_] = mk;
         }
         __syncthreads();
         bool left = false;
 #pragma unroll
         for (int i = 0; i < PRIM_AHEAD; ++i) {
             if (!mask[i]) continue;
-            if (!in_q[i]) { left = true; continue; }
+            if (slot[i] < 0) { left = true; continue; }
             const int64_t p = p0 + i * stride;
+            const unsigned mk = q_mask[slot[i]];
             double mr = mr_a[i];
             int64_t src = -1;
-            int s = base[i];
             for (int q = 0; q < m; ++q) {
-                if (!(mask[i] >> q & 1u)) continue;
-                const double v = q_val[s++];
+                if (!(mk >> q & 1u)) continue;
+                const double v = q_val[slot[i] * LZ_T + q];
                 if (v < mr) { mr = v; src = cos_[q]; }
             }
             if (src >= 0) { a.min_reach[p] = mr; a.source[p] = src; mr_a[i] = mr; }
             mask[i] = 0u;
         }
+        __syncthreads();
         if (tid == 0) q_n = 0;
         todo = left;
     }
+    LZ_MARK(4);                                              // floor tests, bounds, exact distances, applied
     // ---- the workgroup's LZ_W best candidates in order: every wave picks its own LZ_W (no barrier), one wave merges the four
     // lists by rank; then the smallest core distance among everything that is not listed
     __shared__ CandK wl[PRIM_NT / 64][LZ_W];
@@ -1493,11 +1539,14 @@ __global__ __launch_bounds__(PRIM_NT, 3) void lazy_multi_kernel(PrimArgs a, Lazy
         for (int k = 0; k < LZ_W; ++k) in_list |= listed[k] == p;
         if (act[i] && !in_list) rc = fmin(rc, cj_a[i]);
     }
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) rc = fmin(rc, __shfl_xor(rc, o, 64));
+    rc = idl_dev::wave_min_d(rc);
     if ((tid & 63) == 0) sw[tid >> 6] = rc;
     __syncthreads();
     if (tid == 0) *rest_out = fmin(fmin(sw[0], sw[1]), fmin(sw[2], sw[3]));
+    LZ_MARK(5);                                              // list and rest left
+#ifdef IDL_PHASE_STAMPS
+    if (stamping) { atomicAdd(&lazy_phase_sum[kind_][7], 1ull); atomicAdd(&lazy_phase_sum[kind_][11], (unsigned long long)m); }
+#endif
 }
 
 struct LazyLayout { int64_t min_reach, source, cand0, cand1, candk0, candk1, rest0, rest1, dec, st, tree_p, run_asleep, pas, asleep, upto, minmr, lbp, gmin, galive, wg_list, total; };
@@ -1621,11 +1670,13 @@ int idl_mst_prim_lazy(const void *xt, const float *xrow, const double *core, int
     int step_grid = grid;                                    // lazy_step_kernel's: the listed workgroups (lazy_list_kernel)
     const unsigned runs = (unsigned)((n + 255) / 256);
     hipLaunchKernelGGL(lazy_init_kernel, dim3(256), dim3(256), 0, st, a, z);
-    // several nodes per launch: OPT-IN (IDELUCS_MST_MULTI = 2 .. 8; default: one node per launch, the round-3 kernel).  Measured at
-    // 10^6 points (gpurun_out/r05_z, blobs / tight clusters; the same tree, edge for edge): 214 073 launch pairs instead of
-    // 1 002 049 launches -- 4.7 nodes a pair -- but a pair costs ~75 us (lazy_reduce_kernel 27 + lazy_multi_kernel 30 + two launch
-    // gaps; the single step: 12 + one gap): 16.3-16.8 s against 15.0.  What the pair spends its time on is instruction count, not
-    // memory: a tournament round over (weight, original number, index) is ~350 wave instructions of 64-bit compares and selects.
+    // several nodes per launch: OPT-IN (IDELUCS_MST_MULTI = 2 .. 8; default: one node per launch).  Measured at 10^6 points (blobs /
+    // tight clusters; the same tree, edge for edge): 214 073 launch pairs instead of 1 002 049 launches -- 4.7 nodes a pair -- but a
+    // pair costs what 4.7 single steps cost: lazy_reduce_kernel 21.5 us (ONE workgroup: 5.6 to pull the lists of 520 workgroups
+    // through one CU, 6.1 for eight tournament rounds, 3.7 to merge by rank, 2.9 for the decision written by one lane) +
+    // lazy_multi_kernel 23-26 (the exact distances of a point against several nodes are dependent float64 chains; four rounds for the
+    // workgroup's list; the recording workgroup's serial edges) + two launch gaps, against 8.5 + one: 12.3-12.9 s against 10.9-12.2
+    // (stamps: tools/stamps_lazy.py with IDELUCS_MST_MULTI=8; profiles/r05_prim_stamps.txt).
     static const int multi_t = [] { const char *e = getenv("IDELUCS_MST_MULTI"); const int v = e ? atoi(e) : 0; return v < 2 ? 0 : (v > LZ_T ? LZ_T : v); }();
     LazyMulti u{};
     u.cand[0] = (CandK *)(w + l.candk0); u.cand[1] = (CandK *)(w + l.candk1);
@@ -1635,8 +1686,8 @@ int idl_mst_prim_lazy(const void *xt, const float *xrow, const double *core, int
     auto set_fresh = [&](int par) { return hipMemcpyAsync(&u.dec[par].fresh, &one, sizeof(int), hipMemcpyHostToDevice, st); };
     auto step = [&](int64_t ln, int rescan) {
         if (multi_t) {
-            if (!rescan) hipLaunchKernelGGL(lazy_reduce_kernel, dim3(1), dim3(256), 0, st, a, z, u, ln, grid);
-            hipLaunchKernelGGL(lazy_multi_kernel, dim3(grid), dim3(PRIM_NT), 0, st, a, z, u, ln, rescan);
+            if (!rescan) hipLaunchKernelGGL(lazy_reduce_kernel, dim3(1), dim3(256), 0, st, a, z, u, ln, step_grid);
+            hipLaunchKernelGGL(lazy_multi_kernel, dim3(step_grid), dim3(PRIM_NT), 0, st, a, z, u, ln, rescan);
         } else {
             hipLaunchKernelGGL(lazy_step_kernel, dim3(step_grid), dim3(PRIM_NT), 0, st, a, z, ln, rescan);
         }
@@ -1646,7 +1697,6 @@ int idl_mst_prim_lazy(const void *xt, const float *xrow, const double *core, int
         IDL_HIP_TRY(set_fresh(0)); IDL_HIP_TRY(set_fresh(1));
     }
     auto relist = [&]() -> int {                             // the flags changed: the step's grid from the device's list
-        if (multi_t) return IDL_OK;
         hipLaunchKernelGGL(lazy_list_kernel, dim3(1), dim3(1024), 0, st, a, z);
         int L = 0;
         IDL_HIP_TRY(hipMemcpyAsync(&L, z.wg_list, sizeof(int), hipMemcpyDeviceToHost, st));

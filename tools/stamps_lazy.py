@@ -25,11 +25,16 @@ def main():
     posthoc.hdbscan_device(x, n // 100 + 1, stats=stats)
     _lib.check(_lib.lib.idl_debug_lazy_phases(ctypes.cast(out, ctypes.c_void_p)))
     o = np.array(list(out), dtype=np.float64).reshape(3, 12)
+    multi = int(os.environ.get("IDELUCS_MST_MULTI", "0") or 0) >= 2
     names = ["run flags", "trip 2 answered", "decided", "node + boxes + ball", "bounds, queue", "exact distances", "candidate left"]
+    if multi:       # lazy_multi_kernel (kinds 0, 1) and lazy_reduce_kernel (kind 2) have marks of their own
+        names = ["trip 1", "trip 2 answered", "nodes + boxes in LDS", "recorded, balls", "floor, bounds, exact, applied", "list + rest left", "-"]
+        rnames = ["lists in LDS, bounds loaded", "block minima", "tournaments", "merged by rank", "umin", "distances, coordinates, sources", "decision written"]
     print(f"n = {n}: Prim {stats['prim_s']:.2f} s = {stats['prim_s'] / n * 1e6:.2f} us a step ({stats['prim_launches']} launches)")
-    for kind, label in enumerate(["workgroup 0", "awake workgroups", "ball keepers"]):
+    for kind, label in enumerate(["workgroup 0", "awake workgroups", "lazy_reduce_kernel" if multi else "ball keepers"]):
         m = max(o[kind][7], 1.0)
-        print(f"  {label:17s} ({int(o[kind][7])} samples), us: " + ", ".join(f"{nm} {o[kind][i] / m / 100:.2f}" for i, nm in enumerate(names))
+        nn = rnames if (multi and kind == 2) else names
+        print(f"  {label:17s} ({int(o[kind][7])} samples), us: " + ", ".join(f"{nm} {o[kind][i] / m / 100:.2f}" for i, nm in enumerate(nn))
               + f"; sum {o[kind][:7].sum() / m / 100:.2f}; exact distances per step {o[kind][11] / m:.1f}")
     g = max(o[0][10], 1.0)
     print(f"  between launches (last exit -> workgroup 0's entry) {o[0][8] / g / 100:.2f} us; a launch, first entry -> last exit {o[0][9] / g / 100:.2f} us ({int(o[0][10])} samples)")

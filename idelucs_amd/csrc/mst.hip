@@ -768,6 +768,8 @@ __global__ __launch_bounds__(256) void lazy_catchup_kernel(PrimArgs a, LazyArgs 
     __shared__ double cn[LAZY_NCH];
     __shared__ int64_t on[LAZY_NCH], tn[LAZY_NCH];
     __shared__ int64_t s_first;
+    __shared__ double ballb[2][LAZY_NCH];                    // lower bound of ||x_node - x_p|| over the points of the run's first / last point's group
+    __shared__ int s_g[2];
     const int tid = threadIdx.x;
     const int64_t p = (int64_t)blockIdx.x * 256 + tid;
     const bool inside = p < a.n;
@@ -775,7 +777,11 @@ __global__ __launch_bounds__(256) void lazy_catchup_kernel(PrimArgs a, LazyArgs 
     const int g = inside ? a.gid[p] : 0;
     const bool mine = inside && mr >= 0.0 && z.asleep[g] != 0;
     const int64_t my_first = mine ? z.upto[g] : n_tree;
-    if (tid == 0) s_first = n_tree;
+    if (tid == 0) {
+        s_first = n_tree;
+        const int64_t pl = (int64_t)blockIdx.x * 256 + 255 < a.n ? (int64_t)blockIdx.x * 256 + 255 : a.n - 1;
+        s_g[0] = a.gid[(int64_t)blockIdx.x * 256]; s_g[1] = a.gid[pl];
+    }
     __syncthreads();
     if (my_first < n_tree) atomicMin((unsigned long long *)&s_first, (unsigned long long)my_first);
     __syncthreads();
@@ -796,11 +802,24 @@ __global__ __launch_bounds__(256) void lazy_catchup_kernel(PrimArgs a, LazyArgs 
         __syncthreads();
         for (int idx = tid; idx < cnt * PRIM_FILTER_D; idx += 256) xn[idx >> 6][idx & 63] = z.xrow[tn[idx >> 6] * PRIM_FILTER_D + (idx & 63)];
         __syncthreads();
+        // (round 5) a node that is far from a whole group's ball is far from each of its points: ||x_node - x_p|| >= ||x_node - c_g|| - r_g
+        // (r_g >= ||x_p - c_g||), formed once per (node, group of the run's first / last point) instead of 64 multiply-adds per
+        // (node, point) -- the float32 distances of far pairs were most of this pass (34-40 ms a call, 64-190 calls a job)
+        for (int pr = tid >> 6; pr < 2 * cnt; pr += 4) {
+            const int i = pr >> 1, w = pr & 1, gg = s_g[w];
+            const double t = (double)xn[i][tid & 63] - z.gc[(int64_t)gg * PRIM_FILTER_D + (tid & 63)];
+            const double d2 = idl_dev::wave_sum_d(t * t);
+            const double bd = __dsqrt_rn(d2) * (1.0 - 1e-12) - z.gr[gg];
+            if ((tid & 63) == 0) ballb[w][i] = bd > 0.0 ? bd : 0.0;
+        }
+        __syncthreads();
         if (!mine) continue;
+        const int which = g == s_g[0] ? 0 : g == s_g[1] ? 1 : -1;
         for (int i = 0; i < cnt; ++i) {
             if (jb + i < my_first) continue;
             const double floor_cj = fmax(cn[i], cj);
             if (!(floor_cj < mr)) continue;
+            if (which >= 0 && ballb[which][i] >= mr) continue;
             // the distance in float32 first (differences of float32 values, 64 fused multiply-adds: within 1e-5 of the true one): when
             // even that less its error cannot undercut min_reach, the exact one changes nothing
             typedef float f32x2 __attribute__((ext_vector_type(2)));

@@ -88,6 +88,29 @@ __device__ __forceinline__ void block_best(double &bw, int64_t &bj, int64_t &bp,
     __syncthreads();
 }
 
+// A workgroup barrier that orders LDS traffic only.  __syncthreads() is `s_waitcnt vmcnt(0) lgkmcnt(0); s_barrier`: every barrier of a
+// step kernel then also waits for the global loads the wave has just requested for LATER (a whole round trip) and for its global
+// stores to be acknowledged (the bounds, the records, the edges: 1-2 us each; tools/stamps_lazy.py found 1 us per barrier).  The
+// step kernels exchange nothing through global memory inside a workgroup, so their barriers wait for LDS alone.
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+// any(pred) over the workgroup through one LDS word per wave (flag: PRIM_NT / 64 ints; two barriers)
+__device__ __forceinline__ bool lds_block_any(bool pred, int *flag)
+{
+    const unsigned long long b = __ballot(pred);
+    if ((threadIdx.x & 63) == 0) flag[threadIdx.x >> 6] = b != 0ull;
+    lds_barrier();
+    bool any = false;
+#pragma unroll
+    for (int w = 0; w < PRIM_NT / 64; ++w) any |= flag[w] != 0;
+    lds_barrier();
+    return any;
+}
+
 // the same on the VALU alone (wave_ops.h: DPP inside the rows, permlane swaps across them -- a __shfl_xor butterfly over three 64-bit
 // values is 36 dependent trips through the LDS crossbar): the smallest weight of the wave first, then the smallest (number, position)
 // pair among the lanes that hold it, packed into one word (numbers < 2^31, positions < 2^32: idl_mst_prim_lazy's sizes).  The
@@ -99,11 +122,11 @@ __device__ __forceinline__ void block_best_packed(double &bw, int64_t &bj, int64
     key = idl_dev::wave_min_u64(key);
     const int tid = threadIdx.x;
     if ((tid & 63) == 0) { sw[tid >> 6] = wmin; sk[tid >> 6] = key; }
-    __syncthreads();
+    lds_barrier();
     double w = sw[0]; uint64_t k = sk[0];
 #pragma unroll
     for (int v = 1; v < PRIM_NT / 64; ++v) if (sw[v] < w || (sw[v] == w && sk[v] < k)) { w = sw[v]; k = sk[v]; }
-    __syncthreads();
+    lds_barrier();
     bw = w;
     bj = k == ~0ull ? INT64_MAX : (int64_t)(k >> 32);
     bp = k == ~0ull ? 0 : (int64_t)(uint32_t)k;
@@ -388,14 +411,15 @@ int prim_run(PrimArgs a, int is_f64, bool filter, void *workspace, void *stream)
 // loop: a thread keeps its point's 64 coordinates in registers, the nodes stream through LDS 32 at a time, and every distance is
 // formed exactly (no bound, no gather) at the f64 VALU rate instead of the memory system's.  A census then decides who sleeps next
 // (groups whose smallest min_reach is well above the weights being added), a re-scan of the last node rebuilds the candidates, and
-// the steps go on.  Same tree, edge for edge (tests compare with the plain scan).  (Launching only the workgroups that have a waking
-// run -- a list made at the census -- was measured: 12.8 us a step against 12.2; the workgroups that leave at once cost nothing.)
+// the steps go on.  Same tree, edge for edge (tests compare with the plain scan).  (Round 3 measured a list of the workgroups with a
+// waking run against launching them all: 12.8 us a step against 12.2.  Round 5's steps take the list -- lazy_list_kernel: with the
+// bounds kept by a quarter of the workgroups the others have nothing to start for.)
 struct LazyState {
     long long n_tree;          // nodes in the tree (the start included)
     long long cur_p, cur_o;    // the node added last: position, original number
     double cur_w, ema;         // its edge's weight; running mean of the recent weights
     int stalled, cand_par;     // 1: the winner could not be committed; which candidate buffer is valid
-    long long pad;
+    int fresh, pad;            // lazy_fold_kernel: 1 = no node has been added since the census (no sleeping group's bound has met one)
 };
 
 struct LazyArgs {
@@ -583,9 +607,9 @@ __global__ __launch_bounds__(PRIM_NT, 3) void lazy_step_kernel(PrimArgs a, LazyA
         for (int g = tid + PRE * PRIM_NT; g < G; g += PRIM_NT) if (z.asleep[g] == 1) lb = fmin(lb, fmin(z.minmr[g], z.lbp[par * G + g]));
         lb = idl_dev::wave_min_d(lb);
         if ((tid & 63) == 0) sw[tid >> 6] = lb;
-        __syncthreads();
+        lds_barrier();
         lb = fmin(fmin(sw[0], sw[1]), fmin(sw[2], sw[3]));
-        __syncthreads();
+        lds_barrier();
         if (!(bw < lb)) {                                    // STALL (every workgroup decides the same from the same data)
             if (lead) { *nx = S; nx->stalled = 1; }
             if (has_ball && (tid & 63) == 0) z.lbp[(par ^ 1) * G + ball_g] = ball_lb;
@@ -610,7 +634,7 @@ __global__ __launch_bounds__(PRIM_NT, 3) void lazy_step_kernel(PrimArgs a, LazyA
     const double cc = a.core[cur];
     {
         const int k = tid & 63;
-        __syncthreads();
+        lds_barrier();
         up[tid >> 6][k] = (float)((xc[k] - (double)my_lo) / my_sc);
     }
     // ---- sleeping group g's bound meets the new node (workgroup g, its first wave)
@@ -624,7 +648,7 @@ __global__ __launch_bounds__(PRIM_NT, 3) void lazy_step_kernel(PrimArgs a, LazyA
         }
         if ((tid & 63) == 0) z.lbp[(par ^ 1) * G + ball_g] = lbv;
     }
-    __syncthreads();
+    lds_barrier();
     LZ_MARK(3);                                              // the new node, the runs' boxes, the ball
     if (!any_on) {
         if (tid == 0) cand_out[blockIdx.x] = Cand{__builtin_inf(), INT64_MAX, 0};
@@ -724,7 +748,7 @@ __global__ __launch_bounds__(PRIM_NT, 3) void lazy_step_kernel(PrimArgs a, LazyA
             q_mr[slot[i]] = mr_a[i]; q_floor[slot[i]] = floor_a[i];
         }
     }
-    __syncthreads();
+    lds_barrier();
     LZ_MARK(4);                                              // bounds evaluated, queue filled
     for (int s = tid; s < q_n; s += PRIM_NT) {
         const int item = q_item[s], t_own = item / PRIM_AHEAD, i_own = item % PRIM_AHEAD;
@@ -733,7 +757,7 @@ __global__ __launch_bounds__(PRIM_NT, 3) void lazy_step_kernel(PrimArgs a, LazyA
         exact(p, mr, q_floor[s]);
         q_mr[s] = mr;
     }
-    __syncthreads();
+    lds_barrier();
     LZ_MARK(5);                                              // exact distances
     // ---- the workgroup's candidate: smallest weight first, then the smallest original number among the points that hold it (the
     // lexicographic minimum `better` defines; their numbers came with trip 4)
@@ -1000,6 +1024,10 @@ struct LazyDec {
     long long src[LZ_T];                                          // their stored sources (for the recording workgroup)
     double xc[LZ_T][PRIM_FILTER_D];                               // their coordinates: the step reads them without waiting for cp
 };
+// lazy_fold_kernel's record of a workgroup: its best point, and what bounds everything else in it
+struct CandF { double w, core, w2, cmin; unsigned long long jp; double pad; };      // weight, its core distance; the second smallest weight; the smallest
+                                                                                  // core distance among the others; number << 32 | position (~0: none)
+constexpr int LF_T = 4;                // nodes a folded launch may commit (8: measured -- the work per node inside a launch costs what a launch costs; 218 681 launches of 42 us)
 struct LazyMulti {
     CandK *cand[2];            // [grid * LZ_W] by candidate parity: each workgroup's LZ_W best, ascending
     double *rest[2];           // [grid]: smallest core distance among the workgroup's awake outside points NOT among its LZ_W
@@ -1568,6 +1596,513 @@ __global__ __launch_bounds__(PRIM_NT, 3) void lazy_multi_kernel(PrimArgs a, Lazy
 #endif
 }
 
+// ================================================================================================================ several nodes per launch, one launch
+// The decision of lazy_reduce_kernel INSIDE the step (round 5): every listed workgroup leaves ONE record -- its best point, the second
+// smallest weight among its other points (w2), the smallest core distance among its other points (cmin) -- and every workgroup of the
+// next launch works out the same chain c_0, c_1, ... from the same records: the candidates in order (weight, number), c_i (i >= 1)
+// following c_0 .. c_{i-1} when, all STRICTLY,
+//   w_i < min over all workgroups of w2            (no point that is not a workgroup's best comes first),
+//   w_i < min(cmin of all workgroups, the core distances of the bests not among c_0 .. c_i)      (condition (a) above),
+//   w_i < LB - max_{j < i} ||x_{c_j} - x_cur||     (condition (b) above), and a node has been added since the census.
+// No second launch, no single workgroup pulling every list through one CU; the price is lists of depth one.  The scan, the queue,
+// the recording workgroup and the bounds' update are lazy_multi_kernel's.  cand / rest of LazyMulti are not used: the records live
+// in the CandK buffers' storage (u.cand, viewed as CandF).
+__global__ __launch_bounds__(PRIM_NT, 3) void lazy_fold_kernel(PrimArgs a, LazyArgs z, LazyMulti u, int64_t launch, int rescan, int tmax)
+{
+    __shared__ double sw[PRIM_NT / 64];
+    __shared__ unsigned long long sk[PRIM_NT / 64];
+    __shared__ double sred[3][PRIM_NT / 64];
+    __shared__ double wl_w[PRIM_NT / 64][1], wl_c[PRIM_NT / 64][1], mg_w[LF_T], mg_c[LF_T];      // the waves' smallest records; the chain's candidates in order
+    __shared__ unsigned long long wl_k[PRIM_NT / 64][1], mg_k[LF_T];
+    __shared__ double th_w[64], th_c[64];                    // the records below theta
+    __shared__ unsigned long long th_k[64];
+    __shared__ int th_n;
+    __shared__ double xcs[LF_T][PRIM_FILTER_D];              // the nodes of this launch
+    __shared__ double xcur[PRIM_FILTER_D];                   // the node added last (condition (b))
+    __shared__ float up[LF_T][PRIM_RUNS][PRIM_FILTER_D];
+    __shared__ double ccs[LF_T], cws[LF_T], dup[LF_T];
+    __shared__ long long cps[LF_T], cos_[LF_T], srcs[LF_T];
+    __shared__ int q_n;
+    __shared__ int any_flag[PRIM_NT / 64];
+    __shared__ unsigned short q_pair[LZ_QCAP / LZ_T * LF_T];     // the queue: point | node << 10
+    __shared__ double q_val[LZ_QCAP / LZ_T * LF_T];              // the pair's mutual-reachability distance (inf: it changes nothing)
+    __shared__ double pair_d[LF_T * LF_T];
+    static_assert(PRIM_NT == PRIM_SUB, "one sub-block per workgroup here");
+    const int tid = threadIdx.x;
+    const int64_t n = a.n;
+    const int G = z.n_groups;
+    const int par = (int)(launch & 1);
+#ifdef IDL_PHASE_STAMPS
+    uint64_t last_ = __builtin_amdgcn_s_memrealtime();
+    const bool stamping = tid == 0 && !rescan && (blockIdx.x == 0 || blockIdx.x % 61 == 7);
+    const int kind_ = blockIdx.x == 0 ? 0 : 1;
+#endif
+    // ---- trip 1
+    const int entry = z.wg_list[1 + blockIdx.x];
+    const LazyState S = z.st[par];
+    LazyState *nx = &z.st[par ^ 1];
+    const int wg = __builtin_amdgcn_readfirstlane(entry) & 0xFFFF, wg_mask = __builtin_amdgcn_readfirstlane(entry) >> 16;
+    const bool lead = wg == 0 && tid == 0;
+    const int ball_g = wg * (PRIM_NT / 64) + (tid >> 6);
+    const bool has_ball = ball_g < G;
+    if (S.stalled || S.n_tree >= n) {                        // fall through: the state and the bounds are handed on unchanged
+        if (lead) *nx = S;
+        if (has_ball && (tid & 63) == 0) z.lbp[(par ^ 1) * G + ball_g] = z.lbp[par * G + ball_g];
+        return;
+    }
+    const int64_t stride = (int64_t)z.full_grid * PRIM_NT;
+    const int64_t p0 = (int64_t)wg * PRIM_NT + tid;
+    bool run_on[PRIM_AHEAD];
+    bool any_on = false;
+#pragma unroll
+    for (int i = 0; i < PRIM_AHEAD; ++i) {
+        run_on[i] = ((wg_mask >> i) & 1) != 0;
+        any_on |= run_on[i];
+    }
+    const CandF *rec_in = (const CandF *)u.cand[S.cand_par];
+    CandF *rec_out = (CandF *)u.cand[S.cand_par ^ 1] + blockIdx.x;
+    auto leave_empty = [&]() { if (tid == 0) *rec_out = CandF{__builtin_inf(), __builtin_inf(), __builtin_inf(), __builtin_inf(), ~0ull, 0.0}; };
+    LZ_MARK(0);
+    // ---- trip 2, requests
+    double mr_a[PRIM_AHEAD], cj_a[PRIM_AHEAD];
+    int run_g[PRIM_AHEAD], pas_a[PRIM_AHEAD], o32[PRIM_AHEAD];
+    double run_scale[PRIM_AHEAD];
+#pragma unroll
+    for (int i = 0; i < PRIM_AHEAD; ++i) {
+        const int64_t first = (int64_t)wg * PRIM_NT + i * stride;
+        const int64_t p = p0 + i * stride;
+        mr_a[i] = -1.0; cj_a[i] = 0.0; run_g[i] = 0; pas_a[i] = 1; o32[i] = 0;
+        if (run_on[i]) {                                     // (uniform)
+            const int64_t pc = p < n ? p : first;
+            mr_a[i] = a.min_reach[pc];
+            cj_a[i] = a.core[pc];
+            pas_a[i] = z.pas[pc];
+            o32[i] = a.orig[pc];
+            run_g[i] = a.gid[first];
+        }
+    }
+    constexpr int PRE = 4;                                   // records / group bounds a thread takes: 4 x 256 covers the largest grid
+    double r_w[PRE], r_core[PRE], r_w2[PRE], r_cmin[PRE];
+    unsigned long long r_jp[PRE];
+    int g_as[PRE];
+    double g_mm[PRE], g_lb[PRE];
+#pragma unroll
+    for (int it = 0; it < PRE; ++it) {
+        const int g = tid + it * PRIM_NT;
+        r_w[it] = __builtin_inf(); r_core[it] = __builtin_inf(); r_w2[it] = __builtin_inf(); r_cmin[it] = __builtin_inf(); r_jp[it] = ~0ull;
+        g_as[it] = 0; g_mm[it] = 0.0; g_lb[it] = 0.0;
+        if (!rescan) {
+            if (g < (int)gridDim.x) { const CandF c = rec_in[g]; r_w[it] = c.w; r_core[it] = c.core; r_w2[it] = c.w2; r_cmin[it] = c.cmin; r_jp[it] = c.jp; }
+            if (g < G) { g_as[it] = z.asleep[g]; g_mm[it] = z.minmr[g]; g_lb[it] = z.lbp[par * G + g]; }
+        }
+    }
+    double x_cur = 0.0;
+    if (tid < PRIM_FILTER_D) x_cur = (double)z.xrow[S.cur_p * PRIM_FILTER_D + tid];
+    double cc_cur = 0.0;
+    if (rescan && tid == 0) cc_cur = a.core[S.cur_p];
+    double ball_c = 0.0, ball_lb = 0.0, ball_r = 0.0;
+    int ball_as = 0;
+    if (has_ball) {
+        ball_lb = z.lbp[par * G + ball_g];
+        ball_as = z.asleep[ball_g];
+        ball_c = z.gc[(int64_t)ball_g * PRIM_FILTER_D + (tid & 63)];
+        ball_r = z.gr[ball_g];
+    }
+    asm volatile("" ::: "memory");
+#define LZ_PIN(x) asm volatile("" : "+v"(x))
+#pragma unroll
+    for (int i = 0; i < PRIM_AHEAD; ++i) { LZ_PIN(mr_a[i]); LZ_PIN(cj_a[i]); LZ_PIN(run_g[i]); LZ_PIN(pas_a[i]); LZ_PIN(o32[i]); }
+#pragma unroll
+    for (int it = 0; it < PRE; ++it) { LZ_PIN(r_w[it]); LZ_PIN(r_core[it]); LZ_PIN(r_w2[it]); LZ_PIN(r_cmin[it]); LZ_PIN(r_jp[it]); LZ_PIN(g_as[it]); LZ_PIN(g_mm[it]); LZ_PIN(g_lb[it]); }
+    LZ_PIN(x_cur); LZ_PIN(cc_cur); LZ_PIN(ball_lb); LZ_PIN(ball_as); LZ_PIN(ball_c); LZ_PIN(ball_r);
+#undef LZ_PIN
+    LZ_MARK(1);
+    // ---- trip 2, answers
+    int my_run_g;
+    {
+        const int rr = tid >> 6;
+#pragma unroll
+        for (int i = 0; i < PRIM_AHEAD; ++i) {
+            const int64_t p = p0 + i * stride;
+            const bool on = run_on[i] && p < n;
+            if (!on || pas_a[i] != 0) mr_a[i] = -1.0;
+            if (!on) cj_a[i] = 0.0;
+            if (!on) o32[i] = 0;
+            run_scale[i] = a.gscale[run_g[i]];
+        }
+        my_run_g = rr == 0 ? run_g[0] : rr == 1 ? run_g[1] : rr == 2 ? run_g[2] : run_g[3];
+    }
+    const double my_sc = a.gscale[my_run_g];
+    const float my_lo = a.glo[(int64_t)my_run_g * PRIM_FILTER_D + (tid & 63)];
+    if (tid < PRIM_FILTER_D) xcur[tid] = x_cur;
+    if (tid == 0) q_n = 0;
+    // ---- the chain: which nodes this launch commits (every workgroup, from the same records)
+    int k_found = 0;                                         // c_0 .. c_{k_found - 1}: in order, each below LB, below every w2 (from c_1 on)
+    double lb = __builtin_inf();
+    double core_unchosen = __builtin_inf();                  // the smallest core distance among the bests that are not chosen, and every cmin
+    if (rescan) {
+        if (tid == 0) { cps[0] = S.cur_p; cos_[0] = S.cur_o; ccs[0] = cc_cur; cws[0] = 0.0; srcs[0] = 0; }
+    } else {
+        // The chain's members lie below theta = min(LB, every w2): the records below it are FEW (they are collected through an LDS
+        // counter and ranked: three barriers, a handful of instructions); only when there are none (c_0 alone, if it is below LB) or
+        // more than TH_CAP (structureless data) do the waves run the selection rounds (eleven wave-wide reductions: 5.9 us).
+        constexpr int TH_CAP = 64;
+        double w2min = __builtin_inf(), cminmin = __builtin_inf();
+#pragma unroll
+        for (int it = 0; it < PRE; ++it) {
+            if (g_as[it] == 1) lb = fmin(lb, fmin(g_mm[it], g_lb[it]));
+            w2min = fmin(w2min, r_w2[it]); cminmin = fmin(cminmin, r_cmin[it]);
+        }
+        lb = idl_dev::wave_min_d(lb); w2min = idl_dev::wave_min_d(w2min); cminmin = idl_dev::wave_min_d(cminmin);
+        const int wv = tid >> 6;
+        if ((tid & 63) == 0) { sred[0][wv] = lb; sred[1][wv] = w2min; sred[2][wv] = cminmin; }
+        if (tid == 0) th_n = 0;
+        lds_barrier();
+        lb = fmin(fmin(sred[0][0], sred[0][1]), fmin(sred[0][2], sred[0][3]));
+        w2min = fmin(fmin(sred[1][0], sred[1][1]), fmin(sred[1][2], sred[1][3]));
+        cminmin = fmin(fmin(sred[2][0], sred[2][1]), fmin(sred[2][2], sred[2][3]));
+        const double theta = fmin(lb, w2min);
+        double cu = __builtin_inf();                         // smallest core distance among the records that are not listed
+        {
+            int cnt = 0;
+#pragma unroll
+            for (int it = 0; it < PRE; ++it) {
+                const bool below = r_jp[it] != ~0ull && r_w[it] < theta;
+                cnt += below ? 1 : 0;
+                if (!below) cu = fmin(cu, r_core[it]);
+            }
+            if (cnt) {
+                int at = atomicAdd(&th_n, cnt);
+#pragma unroll
+                for (int it = 0; it < PRE; ++it)
+                    if (r_jp[it] != ~0ull && r_w[it] < theta) { if (at < TH_CAP) { th_w[at] = r_w[it]; th_k[at] = r_jp[it]; th_c[at] = r_core[it]; } ++at; }
+            }
+        }
+        cu = idl_dev::wave_min_d(cu);
+        lds_barrier();                                     // (sred[0..2] have been read by everybody: the barrier above the reads... see below)
+        if ((tid & 63) == 0) sred[0][wv] = cu;
+        const int n_th = th_n;
+        lds_barrier();
+        cu = fmin(cminmin, fmin(fmin(sred[0][0], sred[0][1]), fmin(sred[0][2], sred[0][3])));
+        if (n_th >= 1 && n_th <= TH_CAP) {
+            // lane e < n_th of every wave holds entry e; LF_T rounds of the wave's smallest (weight, key) give the chain's candidates in
+            // order -- a full ranking (every entry against every other) was 2.9 us with the typical few dozen entries
+            const int e = tid & 63;
+            if (wv == 0) {                                   // (one wave: the other three leave their issue slots to the CU's other workgroup)
+                double me_w = __builtin_inf(), me_c = __builtin_inf(); unsigned long long me_k = ~0ull;
+                if (e < n_th) { me_w = th_w[e]; me_k = th_k[e]; me_c = th_c[e]; }
+                bool open_ = e < n_th;
+                for (int r = 0; r < LF_T; ++r) {
+                    const double wmin = idl_dev::wave_min_d(open_ ? me_w : __builtin_inf());
+                    unsigned long long key = (open_ && me_w == wmin) ? me_k : ~0ull;
+                    key = idl_dev::wave_min_u64(key);
+                    if (key == ~0ull) {                      // (uniform) nothing left
+                        if (e == 0) for (int r2 = r; r2 < LF_T; ++r2) { mg_w[r2] = __builtin_inf(); mg_k[r2] = ~0ull; mg_c[r2] = __builtin_inf(); }
+                        break;
+                    }
+                    if (open_ && me_k == key) { open_ = false; mg_w[r] = me_w; mg_k[r] = me_k; mg_c[r] = me_c; }
+                }
+                double cx = open_ ? me_c : __builtin_inf();  // listed, but behind the LF_T-th: unchosen
+                cx = idl_dev::wave_min_d(cx);
+                if (e == 0) sred[1][0] = cx;
+            }
+            lds_barrier();
+            cu = fmin(cu, sred[1][0]);
+        } else {
+            // none below theta (c_0 alone, if it is below LB: a stall otherwise, or a point that is no workgroup's best ties with it) or
+            // more than TH_CAP (structureless data right after a census): the smallest record, one node.  (The first form ran
+            // selection rounds here; their registers went to scratch at three workgroups a CU, and a build with that scratch gave
+            // wrong records -- not understood, avoided.)
+            double bw = __builtin_inf(); unsigned long long bk = ~0ull; double bc = __builtin_inf();
+#pragma unroll
+            for (int it = 0; it < PRE; ++it)
+                if (r_jp[it] != ~0ull && (r_w[it] < bw || (r_w[it] == bw && r_jp[it] < bk))) { bw = r_w[it]; bk = r_jp[it]; bc = r_core[it]; }
+            const double wmin = idl_dev::wave_min_d(bw);
+            unsigned long long key = (bw == wmin) ? bk : ~0ull;
+            key = idl_dev::wave_min_u64(key);
+            double core_w = (key != ~0ull && bk == key) ? bc : __builtin_inf();
+            core_w = idl_dev::wave_min_d(core_w);            // (the owner's value to every lane)
+            if ((tid & 63) == 0) { wl_w[wv][0] = key != ~0ull ? wmin : __builtin_inf(); wl_k[wv][0] = key; wl_c[wv][0] = core_w; }
+            lds_barrier();
+            if (tid == 0) {
+                int best = 0;
+                for (int v = 1; v < PRIM_NT / 64; ++v) if (wl_w[v][0] < wl_w[best][0] || (wl_w[v][0] == wl_w[best][0] && wl_k[v][0] < wl_k[best][0])) best = v;
+                mg_w[0] = wl_w[best][0]; mg_k[0] = wl_k[best][0]; mg_c[0] = wl_c[best][0];
+                for (int r = 1; r < LF_T; ++r) { mg_w[r] = __builtin_inf(); mg_k[r] = ~0ull; mg_c[r] = __builtin_inf(); }
+            }
+        }
+        lds_barrier();
+        const int T = S.fresh ? 1 : tmax;
+        for (int r = 0; r < T; ++r) {
+            const double w = mg_w[r]; const unsigned long long k = mg_k[r];
+            const bool ok = k != ~0ull && w < lb && (r == 0 || w < w2min);
+            if (!ok) break;
+            k_found = r + 1;
+        }
+        if (tid < LF_T) {
+            const bool on = tid < k_found;
+            cps[tid] = on ? (long long)(unsigned)(mg_k[tid] & 0xFFFFFFFFull) : -1; cos_[tid] = on ? (long long)(mg_k[tid] >> 32) : 0;
+            ccs[tid] = on ? mg_c[tid] : 0.0; cws[tid] = on ? mg_w[tid] : 0.0;
+        }
+        for (int r = k_found; r < LF_T; ++r) if (mg_k[r] != ~0ull) cu = fmin(cu, mg_c[r]);      // (merged, but not in the chain)
+        core_unchosen = cu;
+        if (k_found == 0) {                                  // STALL, as the single-node step decides it
+            if (lead) { *nx = S; nx->stalled = 1; }
+            if (has_ball && (tid & 63) == 0) z.lbp[(par ^ 1) * G + ball_g] = ball_lb;
+            return;
+        }
+    }
+    LZ_MARK(2);                                              // the chain's candidates
+    // ---- trip 3: the candidates' coordinates (and, for the recording workgroup, their stored sources)
+    const int k_nodes = rescan ? 1 : k_found;
+    lds_barrier();
+    {
+        const int f = tid & 63;
+        double xv[LF_T * PRIM_FILTER_D / PRIM_NT];
+#pragma unroll
+        for (int t = 0; t < LF_T * PRIM_FILTER_D / PRIM_NT; ++t) { const int q = (tid >> 6) + t * (PRIM_NT / 64); xv[t] = q < k_nodes ? (double)z.xrow[cps[q] * PRIM_FILTER_D + f] : 0.0; }
+        if (wg == 0 && !rescan && tid < k_nodes) srcs[tid] = a.source[cps[tid]];
+#pragma unroll
+        for (int t = 0; t < LF_T * PRIM_FILTER_D / PRIM_NT; ++t) { const int q = (tid >> 6) + t * (PRIM_NT / 64); if (q < k_nodes) xcs[q][f] = xv[t]; }
+    }
+    lds_barrier();
+    int m = 1;
+    if (!rescan) {
+        // how far each candidate is from the node added last (an upper bound): the waves take them in turn
+        for (int q = tid >> 6; q < k_nodes; q += PRIM_NT / 64) {
+            const int f = tid & 63;
+            const double t = xcs[q][f] - xcur[f];
+            const double d2 = idl_dev::wave_sum_d(t * t);
+            if (f == 0) dup[q] = __dsqrt_rn(d2) * (1.0 + 1e-9) + 1e-300;
+        }
+        lds_barrier();
+        double dmax = dup[0];
+        for (int i = 1; i < k_nodes; ++i) {
+            double mi = core_unchosen;                       // smallest core distance among the awake outside points other than c_0 .. c_i
+            for (int k = i + 1; k < k_nodes; ++k) mi = fmin(mi, ccs[k]);
+            if (!(cws[i] < mi) || !(cws[i] < lb - dmax)) break;
+            m = i + 1;
+            dmax = fmax(dmax, dup[i]);
+        }
+    }
+    LZ_MARK(3);                                              // their coordinates; how many go
+#ifdef IDL_FOLD_DEBUG
+    if (blockIdx.x == 0 && tid == 0 && launch < 6) printf("[fold] launch %lld rescan %d fresh %d n_tree %lld k_found %d m %d cps0 %lld cos0 %lld ccs0 %.6f cws0 %.6f lb %.6f cu %.6f xcs00 %.6f\n", (long long)launch, rescan, S.fresh, (long long)S.n_tree, k_found, m, cps[0], cos_[0], ccs[0], cws[0], lb, core_unchosen, xcs[0][0]);
+#endif
+    {       // one (run, feature) per thread; its box corner and scale are loaded once, the nodes loop in LDS
+        static_assert(PRIM_RUNS * 64 == PRIM_NT && PRIM_FILTER_D == 64 && PRIM_AHEAD == 4, "one (run, feature) per thread");
+        const int rr = tid >> 6, k = tid & 63;
+        for (int q = 0; q < m; ++q) up[q][rr][k] = (float)((xcs[q][k] - (double)my_lo) / my_sc);
+    }
+    // ---- the recording workgroup: the edges of the committed nodes, in order (lazy_multi_kernel has the reasoning)
+    if (wg == 0 && !rescan) {
+        for (int pr = tid; pr < m * m; pr += PRIM_NT) {
+            const int k = pr / m, i = pr % m;
+            double v = __builtin_inf();
+            if (k < i) {
+                double acc = 0.0;
+#pragma unroll 8
+                for (int f = 0; f < PRIM_FILTER_D; ++f) {
+                    const double t = xcs[k][f] - xcs[i][f];
+                    acc = idl_dev::square_then_add(acc, t);
+                }
+                v = fmax(fmax(ccs[k], ccs[i]), __dsqrt_rn(acc));
+            }
+            pair_d[k * LF_T + i] = v;
+        }
+        lds_barrier();
+        if (tid < m) {                                       // lane i: the edge of c_i (its own pairs only: nothing sequential but the state)
+            const int i = tid;
+            double w = cws[i];
+            int64_t src = srcs[i];
+            for (int k = 0; k < i; ++k) if (pair_d[k * LF_T + i] < w) { w = pair_d[k * LF_T + i]; src = cos_[k]; }
+            const int64_t at = S.n_tree - 1 + i;
+            a.mst_cur[at] = src; a.mst_next[at] = cos_[i]; a.mst_w[at] = w;
+            a.min_reach[cps[i]] = -1.0;
+            z.tree_p[at + 1] = cps[i];
+            cws[i] = w;                                      // (the weight the edge was recorded with: the running mean below)
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (tid == 0) {
+            LazyState t = S;
+            for (int i = 0; i < m; ++i) t.ema = t.ema + (cws[i] - t.ema) * (1.0 / 64.0);
+            t.n_tree = S.n_tree + m; t.cur_p = cps[m - 1]; t.cur_o = cos_[m - 1]; t.cur_w = cws[m - 1];
+            t.cand_par = S.cand_par ^ 1;
+            t.fresh = 0;
+            *nx = t;
+        }
+    } else if (lead) {                                       // a re-scan commits nothing
+        LazyState t = S;
+        t.cand_par = S.cand_par ^ 1;
+        t.fresh = 1;
+        *nx = t;
+    }
+    // ---- the sleeping groups' bounds meet the new nodes (a group per wave)
+    if (has_ball) {
+        double lbv = ball_lb;
+        if (!rescan && ball_as == 1) {
+            for (int q = 0; q < m; ++q) {
+                const double t = xcs[q][tid & 63] - ball_c;
+                const double d2 = idl_dev::wave_sum_d(t * t);
+                const double b = __dsqrt_rn(d2) * (1.0 - 1e-12) - ball_r;
+                lbv = fmin(lbv, b > 0.0 ? b : 0.0);
+            }
+        }
+        if ((tid & 63) == 0) z.lbp[(par ^ 1) * G + ball_g] = lbv;
+    }
+    lds_barrier();
+    LZ_MARK(4);                                              // boxes, recorded, balls
+    if (!any_on) { leave_empty(); return; }
+    // ---- which (point, node) pairs could change something: the floor test; the points with such a pair are the queue's items
+    bool act[PRIM_AHEAD];
+    unsigned mask[PRIM_AHEAD];
+    {
+        int cp_r[LF_T]; double cc_r[LF_T];                   // (once, into registers: the loops below were an LDS read per point and node)
+#pragma unroll
+        for (int q = 0; q < LF_T; ++q) { cp_r[q] = q < m ? (int)cps[q] : -1; cc_r[q] = q < m ? ccs[q] : __builtin_inf(); }
+#pragma unroll
+        for (int i = 0; i < PRIM_AHEAD; ++i) {
+            const int64_t p = p0 + i * stride;
+            act[i] = mr_a[i] >= 0.0;
+            mask[i] = 0u;
+#pragma unroll
+            for (int q = 0; q < LF_T; ++q) if ((int)p == cp_r[q]) act[i] = false; // committed in this launch (a re-scan: the node itself)
+#pragma unroll
+            for (int q = 0; q < LF_T; ++q) if (fmax(cc_r[q], cj_a[i]) < mr_a[i]) mask[i] |= 1u << q;       // (cc_r = inf beyond m: never)
+            if (!act[i]) mask[i] = 0u;
+        }
+    }
+    const float *xt = (const float *)a.xt;
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)xt, 0, 0xffffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t c_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.codes, 0, 0xffffffff, 0x00020000);
+    const int col_bytes = (int)n * 4;
+    // a (point, node) pair that passes the floor test is an ITEM of the workgroup's queue; a thread takes an item: the point's group,
+    // residual and codes -> the 8-bit bound; when it survives, the point's coordinates -> the exact distance (a dependent float64
+    // chain of 64 products and sums, 0.5 us: one per thread, side by side).  A point whose pairs do not fit waits for the next round.
+    constexpr int ITEMS = LZ_QCAP / LZ_T * LF_T;             // q_val's size
+    bool todo = false;
+#pragma unroll
+    for (int i = 0; i < PRIM_AHEAD; ++i) todo |= mask[i] != 0u;
+    while (lds_block_any(todo, any_flag)) {
+        int base[PRIM_AHEAD];
+        bool in_q[PRIM_AHEAD];
+#pragma unroll
+        for (int i = 0; i < PRIM_AHEAD; ++i) {
+            in_q[i] = false; base[i] = 0;
+            if (!mask[i]) continue;
+            const int cnt = __popc(mask[i]);
+            base[i] = atomicAdd(&q_n, cnt);
+            if (base[i] + cnt <= ITEMS) {
+                in_q[i] = true;
+                int s_ = base[i];
+                for (int q = 0; q < m; ++q) if (mask[i] >> q & 1u) q_pair[s_++] = (unsigned short)((tid * PRIM_AHEAD + i) | (q << 10));
+            } else {
+                for (int s_ = base[i]; s_ < ITEMS; ++s_) q_pair[s_] = 0xFFFFu;
+            }
+        }
+        lds_barrier();
+        LZ_MARK(8);
+        const int qn = q_n < ITEMS ? q_n : ITEMS;
+        for (int s_ = tid; s_ < qn; s_ += PRIM_NT) {
+            const unsigned it = q_pair[s_];
+            q_val[s_] = __builtin_inf();                     // (inf: the pair changes nothing)
+            if (it == 0xFFFFu) continue;
+            const int item = it & 1023, q = it >> 10, t_own = item / PRIM_AHEAD, i_own = item % PRIM_AHEAD;
+            const int64_t p = (int64_t)wg * PRIM_NT + t_own + i_own * stride;
+            const int64_t first = (int64_t)wg * PRIM_NT + i_own * stride;
+            const int gp = a.gid[p], gr = a.gid[first];
+            const float rsd = a.resid[p];
+            const double cjp = a.core[p], mrp = a.min_reach[p];
+            uint32_t cwd[PRIM_FILTER_D / 4];
+#pragma unroll
+            for (int k = 0; k < PRIM_FILTER_D / 4; ++k) cwd[k] = __builtin_amdgcn_raw_buffer_load_b32(c_rsrc, (uint32_t)p * 4u, k * (int)n * 4, 0);
+            bool live = true;
+            if (gp == gr) {
+                const double sc = (double)(float)a.gscale[gr];
+                float acc = 0.f;
+                const float *uu = up[q][i_own];
+#pragma unroll
+                for (int k = 0; k < PRIM_FILTER_D / 4; ++k) {
+                    const uint32_t w = cwd[k];
+                    const float t0 = uu[4 * k] - (float)(w & 255u), t1 = uu[4 * k + 1] - (float)((w >> 8) & 255u);
+                    const float t2 = uu[4 * k + 2] - (float)((w >> 16) & 255u), t3 = uu[4 * k + 3] - (float)(w >> 24);
+                    acc = fmaf(t0, t0, acc); acc = fmaf(t1, t1, acc); acc = fmaf(t2, t2, acc); acc = fmaf(t3, t3, acc);
+                }
+                const double lbq = sc * (double)sqrtf(acc) * (1.0 - 4e-5) - 0.01 * sc - (double)rsd;
+                if (fmax(fmax(ccs[q], cjp), lbq) >= mrp) live = false;
+            }
+            if (live) {
+                uint32_t v[64];
+#pragma unroll
+                for (int k = 0; k < 64; ++k) v[k] = __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, (uint32_t)p * 4u, k * col_bytes, 0);
+                double acc = 0.0;
+#pragma unroll
+                for (int k = 0; k < 64; ++k) {
+                    if ((k & 7) == 0) __builtin_amdgcn_sched_barrier(0);
+                    const double t = xcs[q][k] - (double)__uint_as_float(v[k]);
+                    acc = idl_dev::square_then_add(acc, t);
+                }
+                q_val[s_] = fmax(fmax(ccs[q], cjp), __dsqrt_rn(acc));       // mrd(node q, point p)
+            }
+        }
+        lds_barrier();
+        LZ_MARK(9);
+        bool left = false;
+#pragma unroll
+        for (int i = 0; i < PRIM_AHEAD; ++i) {
+            if (!mask[i]) continue;
+            if (!in_q[i]) { left = true; continue; }
+            const int64_t p = p0 + i * stride;
+            double mr = mr_a[i];
+            int64_t src = -1;
+            int s_ = base[i];
+            for (int q = 0; q < m; ++q) {
+                if (!(mask[i] >> q & 1u)) continue;
+                const double v = q_val[s_++];
+                if (v < mr) { mr = v; src = cos_[q]; }
+            }
+            if (src >= 0) { a.min_reach[p] = mr; a.source[p] = src; mr_a[i] = mr; }
+            mask[i] = 0u;
+        }
+        lds_barrier();
+        LZ_MARK(10);
+        if (tid == 0) q_n = 0;
+        todo = left;
+    }
+    LZ_MARK(5);                                              // floor tests, bounds, exact distances, applied
+    // ---- the workgroup's record: its best point (weight, then number), its core distance; the second smallest weight and the
+    // smallest core distance among the workgroup's other points
+    double bw = __builtin_inf(); int64_t bj = INT64_MAX, bp = 0;
+#pragma unroll
+    for (int i = 0; i < PRIM_AHEAD; ++i) if (act[i] && better(mr_a[i], (int64_t)o32[i], bw, bj)) { bw = mr_a[i]; bj = (int64_t)o32[i]; bp = p0 + i * stride; }
+    block_best_packed(bw, bj, bp, sw, sk);
+    double w2 = __builtin_inf(), cm = __builtin_inf(), cb = __builtin_inf();
+#pragma unroll
+    for (int i = 0; i < PRIM_AHEAD; ++i) {
+        const int64_t p = p0 + i * stride;
+        if (!act[i]) continue;
+        if (bj != INT64_MAX && p == bp) cb = cj_a[i];
+        else { w2 = fmin(w2, mr_a[i]); cm = fmin(cm, cj_a[i]); }
+    }
+    w2 = idl_dev::wave_min_d(w2); cm = idl_dev::wave_min_d(cm); cb = idl_dev::wave_min_d(cb);
+    if ((tid & 63) == 0) { sred[0][tid >> 6] = w2; sred[1][tid >> 6] = cm; sred[2][tid >> 6] = cb; }
+    lds_barrier();
+    if (tid == 0) {
+        CandF c;
+        c.w = bw;
+        c.core = fmin(fmin(sred[2][0], sred[2][1]), fmin(sred[2][2], sred[2][3]));
+        c.w2 = fmin(fmin(sred[0][0], sred[0][1]), fmin(sred[0][2], sred[0][3]));
+        c.cmin = fmin(fmin(sred[1][0], sred[1][1]), fmin(sred[1][2], sred[1][3]));
+        c.jp = bj == INT64_MAX ? ~0ull : (((unsigned long long)bj << 32) | (unsigned long long)(uint32_t)bp);
+        c.pad = 0.0;
+        *rec_out = c;
+    }
+    LZ_MARK(6);
+#ifdef IDL_PHASE_STAMPS
+    if (stamping) { atomicAdd(&lazy_phase_sum[kind_][7], 1ull); atomicAdd(&lazy_phase_sum[kind_][11], (unsigned long long)m); }
+#endif
+}
+
 struct LazyLayout { int64_t min_reach, source, cand0, cand1, candk0, candk1, rest0, rest1, dec, st, tree_p, run_asleep, pas, asleep, upto, minmr, lbp, gmin, galive, wg_list, total; };
 
 inline LazyLayout lazy_layout(int64_t n, int n_groups)
@@ -1689,22 +2224,32 @@ int idl_mst_prim_lazy(const void *xt, const float *xrow, const double *core, int
     int step_grid = grid;                                    // lazy_step_kernel's: the listed workgroups (lazy_list_kernel)
     const unsigned runs = (unsigned)((n + 255) / 256);
     hipLaunchKernelGGL(lazy_init_kernel, dim3(256), dim3(256), 0, st, a, z);
-    // several nodes per launch: OPT-IN (IDELUCS_MST_MULTI = 2 .. 8; default: one node per launch).  Measured at 10^6 points (blobs /
+    // several nodes per launch with the decision in a launch of its OWN: OPT-IN (IDELUCS_MST_MULTI = 2 .. 8; lazy_fold_kernel has it
+    // inside the step, opt-in as well; default: one node per launch).  Measured at 10^6 points (blobs /
     // tight clusters; the same tree, edge for edge): 214 073 launch pairs instead of 1 002 049 launches -- 4.7 nodes a pair -- but a
     // pair costs what 4.7 single steps cost: lazy_reduce_kernel 21.5 us (ONE workgroup: 5.6 to pull the lists of 520 workgroups
     // through one CU, 6.1 for eight tournament rounds, 3.7 to merge by rank, 2.9 for the decision written by one lane) +
     // lazy_multi_kernel 23-26 (the exact distances of a point against several nodes are dependent float64 chains; four rounds for the
     // workgroup's list; the recording workgroup's serial edges) + two launch gaps, against 8.5 + one: 12.3-12.9 s against 10.9-12.2
     // (stamps: tools/stamps_lazy.py with IDELUCS_MST_MULTI=8; profiles/r05_prim_stamps.txt).
-    static const int multi_t = [] { const char *e = getenv("IDELUCS_MST_MULTI"); const int v = e ? atoi(e) : 0; return v < 2 ? 0 : (v > LZ_T ? LZ_T : v); }();
+    const int multi_t = [] {       // (read at every call: the tests switch it inside one process)
+        const char *e = getenv("IDELUCS_MST_MULTI"); const int v = e ? atoi(e) : 0; return v < 2 ? 0 : (v > LZ_T ? LZ_T : v); }();
     LazyMulti u{};
     u.cand[0] = (CandK *)(w + l.candk0); u.cand[1] = (CandK *)(w + l.candk1);
     u.rest[0] = (double *)(w + l.rest0); u.rest[1] = (double *)(w + l.rest1);
     u.dec = (LazyDec *)(w + l.dec); u.tmax = multi_t;
     const int one = 1;
     auto set_fresh = [&](int par) { return hipMemcpyAsync(&u.dec[par].fresh, &one, sizeof(int), hipMemcpyHostToDevice, st); };
+    // the decision inside the step (lazy_fold_kernel): OPT-IN, IDELUCS_MST_FOLD = 1 .. 4 nodes a launch (default 0: the single-node step,
+    // lazy_step_kernel).  10^6 points of blobs / tight clusters, one box: 10.26-10.29 s against 11.54-11.63 (330 300 launches of ~28 us
+    // against 1 002 049 of ~10); on BASELINE cfg5's own latent 17.9 s against 14.2 (560 824 launches: 1.9 nodes a launch there).  The
+    // work per node inside a launch -- the chain's selection, boxes, pairs, record -- is instruction time on CUs that hold two
+    // workgroups, and costs two thirds of what a launch of its own costs; with LF_T = 8: 218 681 launches of 42 us.
+    const int fold_t = [] { const char *e = getenv("IDELUCS_MST_FOLD"); const int v = e ? atoi(e) : 0; return v < 1 ? 0 : (v > LF_T ? LF_T : v); }();
     auto step = [&](int64_t ln, int rescan) {
-        if (multi_t) {
+        if (fold_t && !multi_t) {
+            hipLaunchKernelGGL(lazy_fold_kernel, dim3(step_grid), dim3(PRIM_NT), 0, st, a, z, u, ln, rescan, fold_t);
+        } else if (multi_t) {
             if (!rescan) hipLaunchKernelGGL(lazy_reduce_kernel, dim3(1), dim3(256), 0, st, a, z, u, ln, step_grid);
             hipLaunchKernelGGL(lazy_multi_kernel, dim3(step_grid), dim3(PRIM_NT), 0, st, a, z, u, ln, rescan);
         } else {

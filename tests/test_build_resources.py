@@ -1,0 +1,32 @@
+"""Register / scratch budget of the kernels whose correctness was seen to depend on it (CPU: hipcc cross-compiles)."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="no hipcc")
+def test_prim_step_kernels_have_no_scratch(tmp_path):
+    """Round 5: a build of lazy_fold_kernel that spilled 12 bytes a lane to scratch (168 registers at three workgroups a CU)
+    produced wrong records -- trees that differ from sklearn's from the second edge on; the same source without the spill is exact.
+    Not understood (the step kernels pin loaded values with empty `asm volatile`s), so the condition is held by a test: the three
+    step kernels of idl_mst_prim_lazy compile without scratch."""
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    src = os.path.join(ROOT, "idelucs_amd", "csrc", "mst.hip")
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-c", src, "-o", str(tmp_path / "mst.o"),
+                        "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True, cwd=os.path.dirname(src))
+    assert r.returncode == 0, r.stderr[-2000:]
+    blocks = re.split(r"remark: [^\n]*Function Name: ", r.stderr)[1:]
+    seen = {}
+    for b in blocks:
+        name = b.split()[0]
+        m = re.search(r"ScratchSize \[bytes/lane\]: (\d+)", b)
+        for k in ("lazy_step_kernel", "lazy_fold_kernel", "lazy_multi_kernel"):
+            if k in name and m:
+                seen[k] = int(m.group(1))
+    assert set(seen) == {"lazy_step_kernel", "lazy_fold_kernel", "lazy_multi_kernel"}, seen
+    assert all(v == 0 for v in seen.values()), seen

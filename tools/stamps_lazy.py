@@ -27,6 +27,9 @@ def main():
     o = np.array(list(out), dtype=np.float64).reshape(3, 12)
     multi = int(os.environ.get("IDELUCS_MST_MULTI", "0") or 0) >= 2
     names = ["run flags", "trip 2 answered", "decided", "node + boxes + ball", "bounds, queue", "exact distances", "candidate left"]
+    fold = int(os.environ.get("IDELUCS_MST_FOLD", "0") or 0) >= 1 and not multi
+    if fold:
+        names = ["trip 1", "trip 2 answered", "chain's candidates", "coordinates, how many go", "boxes, recorded, balls", "floor, bounds, exact, applied", "record left"]
     if multi:       # lazy_multi_kernel (kinds 0, 1) and lazy_reduce_kernel (kind 2) have marks of their own
         names = ["trip 1", "trip 2 answered", "nodes + boxes in LDS", "recorded, balls", "floor, bounds, exact, applied", "list + rest left", "-"]
         rnames = ["lists in LDS, bounds loaded", "block minima", "tournaments", "merged by rank", "umin", "distances, coordinates, sources", "decision written"]
@@ -35,7 +38,8 @@ def main():
         m = max(o[kind][7], 1.0)
         nn = rnames if (multi and kind == 2) else names
         print(f"  {label:17s} ({int(o[kind][7])} samples), us: " + ", ".join(f"{nm} {o[kind][i] / m / 100:.2f}" for i, nm in enumerate(nn))
-              + f"; sum {o[kind][:7].sum() / m / 100:.2f}; exact distances per step {o[kind][11] / m:.1f}")
+              + f"; sum {o[kind][:7].sum() / m / 100:.2f}; exact distances per step {o[kind][11] / m:.1f}"
+              + (f"; inside the pairs' phase: floor tests + queued {o[kind][8] / m / 100:.2f}, bounds + exact {o[kind][9] / m / 100:.2f}, applied {o[kind][10] / m / 100:.2f}" if (fold and kind < 2) else ""))
     g = max(o[0][10], 1.0)
     print(f"  between launches (last exit -> workgroup 0's entry) {o[0][8] / g / 100:.2f} us; a launch, first entry -> last exit {o[0][9] / g / 100:.2f} us ({int(o[0][10])} samples)")
 

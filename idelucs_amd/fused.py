@@ -196,8 +196,6 @@ class FusedLinearTrainer:
         self._tail_l1 = os.environ.get("IDELUCS_TAIL_L1", "1") != "0"
         self._pending = None                     # (buffers, parity) of the step whose tail has not run yet
         self._perm = None
-        self._perm_free = None                   # recorded behind an epoch's last launch: the permutation buffer may be rewritten
-        self._prep = torch.cuda.Stream(device=self.dev)
         n = len(self.params)
         self._pp = (ctypes.c_void_p * n)(*[p.data_ptr() for p in self.params])
         self._gp = (ctypes.c_void_p * n)(*[g.data_ptr() for g in self.grads])
@@ -492,20 +490,12 @@ class FusedLinearTrainer:
         """One pass over a fresh permutation of the N*n_mimics pairs (models.py:117-133).
         Returns the device scalar sum of the per-step losses and the number of batches."""
         n_pairs = store.n_pairs
-        fresh = self._perm is None or self._perm.numel() != n_pairs
-        if fresh:
+        if self._perm is None or self._perm.numel() != n_pairs:
             self._perm = torch.empty(n_pairs, dtype=torch.int64, device=self.dev)
             self._graphs.clear()
-        # the permutation (a device sort: ~20 launches, 0.17 ms) needs nothing of the store: on a stream of its own it runs beside
-        # whatever the caller has queued in front of the epoch (the vectoriser), behind the previous epoch's last use of _perm
-        main = torch.cuda.current_stream()
-        if fresh:
-            self._prep.wait_stream(main)        # (a block the allocator may just have taken back from other work of this stream)
-        elif self._perm_free is not None:
-            self._prep.wait_event(self._perm_free)
-        with torch.cuda.stream(self._prep):
-            torch.randperm(n_pairs, device=self.dev, generator=generator, out=self._perm)
-        main.wait_stream(self._prep)
+        # (the permutation on a stream of its own beside the vectoriser was measured: the epoch 67.2-67.4 ms against 64.8-65.0 on the
+        #  main stream, T_e2e 76.8-79.2 against 76.1-76.3 -- the step graphs wait for the other stream's event)
+        torch.randperm(n_pairs, device=self.dev, generator=generator, out=self._perm)
         self.ctl[1:2].zero_()
         self.out[1:2].zero_()
         n_full, rem = divmod(n_pairs, batch_sz)
@@ -540,8 +530,6 @@ class FusedLinearTrainer:
         self.flush_tail()                       # (the last eager step's tail; a replayed graph ends with its own)
         if rem:
             self._full_step(store, self.buffers(2 * rem))
-        self._perm_free = torch.cuda.Event()
-        self._perm_free.record(main)
         return self.out[1], n_full + (1 if rem else 0)
 
     @torch.no_grad()

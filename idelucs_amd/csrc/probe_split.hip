@@ -1,0 +1,239 @@
+// probe_split.hip -- a PROBE, not part of the product path (tools/probe_split_mfma.py; DESIGN.md History, "the two products on the
+// bf16 matrix cores").  Question: what would the step's two big fp32 products cost on the bf16 MFMA pipe (16 x the fp32 MFMA rate)
+// with every operand split three ways, x = x0 + x1 + x2 (bf16 each, 24 significand bits in all), and the six products
+// x0 y0, x0 y1, x1 y0, x1 y1, x0 y2, x2 y0 accumulated in fp32 (what is dropped is of the order of fp32's own rounding)?
+//
+// The kernel: C[M][N] = A[M][K] B[N][K]^T (both operands K-contiguous: the layer-1 forward's shape, 1024 x 512 x 4096) from
+// PRE-SPLIT operands (three bf16 planes each -- in the step the producers of x, W1 and dr1 would write them), 128 x 128 tiles
+// with an 8-way split of K (256 workgroups; per-CU L2 traffic of 64 x 32 whole-K tiles would be 600 MB a launch: L2-bound), a K slice per XCD,
+// partial sums written as fp32 [S][M][N].  Four waves, each 64 x 64 = 2 x 2 blocks of v_mfma_f32_32x32x16_bf16; operands staged
+// through LDS by LDS-DMA (global_load_lds_dwordx4) two chunks of 32 k deep, the 16-byte slots of a 64-byte row swizzled on the
+// source side so that the fragment reads (ds_read_b128) are conflict-free.
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int TM = 128, TN = 128, KC = 32;                   // tile; k per chunk (64 bytes of bf16 a row)
+constexpr int PLANE_A = TM * KC * 2, PLANE_B = TN * KC * 2;  // bytes of one plane of a chunk
+constexpr int STAGE = 3 * PLANE_A + 3 * PLANE_B;             // 49 152
+constexpr int STAGES = 2;
+constexpr int NT = 256;
+
+__device__ __forceinline__ void dma16(uint32_t voff, const void *sbase, uint32_t lds_byte)
+{
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_byte) : "memory");
+}
+
+struct SplitArgs {
+    const uint16_t *a[3], *b[3];       // planes [M][K], [N][K]
+    float *cpart;                      // [S][M][N]
+    int M, N, K, S, products;          // products: 6 (the full set), 3 (x0y0, x0y1, x1y0), 1 (x0y0: plain bf16)
+};
+
+// chunk c of the workgroup's K range into stage st: 48 DMA instructions of 1 KiB (16 rows x 64 bytes), 12 per wave
+__device__ __forceinline__ void issue_chunk(const SplitArgs &g, int m0, int n0, int k0, uint32_t lds_stage, int wv, int lane)
+{
+    // instruction j (0..47): plane j / 8 of A (0..2) or B (3..5), rows 16 (j % 8) .. + 15; lane -> row lane / 4, slot lane % 4 of the
+    // LDS row, which holds source chunk slot ^ ((row >> 2) & 3)
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+        const int j = wv * 12 + i;
+        const int pl = j >> 3, blk = j & 7;
+        const bool isA = pl < 3;
+        const int row = blk * 16 + (lane >> 2), slot = lane & 3, src = slot ^ ((row >> 2) & 3);
+        const uint16_t *base = isA ? g.a[pl] : g.b[pl - 3];
+        const int64_t r = (isA ? m0 : n0) + row;
+        const uint32_t voff = (uint32_t)((r * g.K + k0 + src * 8) * 2);
+        dma16(voff, base, lds_stage + (uint32_t)(pl * PLANE_A + blk * 1024));      // (PLANE_A == PLANE_B)
+    }
+}
+
+__device__ __forceinline__ bf16x8 frag(const unsigned char *smem, int plane_off, int row, int chunk)
+{
+    const int slot = chunk ^ ((row >> 2) & 3);
+    const u32x4 v = *(const __attribute__((address_space(3))) u32x4 *)(uintptr_t)((uint32_t)(uintptr_t)smem + plane_off + row * 64 + slot * 16);
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+__global__ __launch_bounds__(NT, 1) void split_gemm_kernel(SplitArgs g)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles_n = g.N / TN;
+    // (workgroups go to the 8 XCDs round-robin: with the K slice = blockIdx % S an XCD's L2 streams ONE slice of both operands -- 4.7 MB at
+    //  S = 8 -- instead of all 38 MB: with slice = blockIdx / tiles every XCD read everything, 300 MB a launch, 26 us whatever the products)
+    const int s = blockIdx.x % g.S, t = blockIdx.x / g.S;
+    const int m0 = (t / tiles_n) * TM, n0 = (t % tiles_n) * TN;
+    const int kr = g.K / g.S, kb = s * kr, nc = kr / KC;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+    const int wm = (wv >> 1) * 64, wn = (wv & 1) * 64;       // the wave's 64 x 64 corner in the tile
+    f32x16 hi[2][2], lo[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { hi[i][j][e] = 0.f; lo[i][j][e] = 0.f; }
+    issue_chunk(g, m0, n0, kb, lds0, wv, lane);
+    for (int c = 0; c < nc; ++c) {
+        if (c + 1 < nc) issue_chunk(g, m0, n0, kb + (c + 1) * KC, lds0 + (uint32_t)(((c + 1) & 1) * STAGE), wv, lane);
+        if (c + 1 < nc) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                        // chunk c is in LDS (every wave's share)
+        const unsigned char *st = smem + (c & 1) * STAGE;
+        const int r = lane & 31, kg = lane >> 5;             // fragment row / its 8-deep k group
+#pragma unroll
+        for (int ks = 0; ks < KC / 16; ++ks) {
+            const int chunk = ks * 2 + kg;
+            bf16x8 fa[3][2], fb[3][2];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    fa[pl][i] = frag(st, pl * PLANE_A, wm + 32 * i + r, chunk);
+                    fb[pl][i] = frag(st, 3 * PLANE_A + pl * PLANE_B, wn + 32 * i + r, chunk);
+                }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    hi[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][i], fb[0][j], hi[i][j], 0, 0, 0);
+                    if (g.products >= 3) {
+                        lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][i], fb[1][j], lo[i][j], 0, 0, 0);
+                        lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][i], fb[0][j], lo[i][j], 0, 0, 0);
+                    }
+                    if (g.products >= 6) {
+                        lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][i], fb[1][j], lo[i][j], 0, 0, 0);
+                        lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][i], fb[2][j], lo[i][j], 0, 0, 0);
+                        lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[2][i], fb[0][j], lo[i][j], 0, 0, 0);
+                    }
+                }
+        }
+        __builtin_amdgcn_s_barrier();                        // every wave has read chunk c: its stage may be refilled (by the issue of c + 2)
+    }
+    // C/D layout of 32x32: lane l, register e -> row (e / 4) * 8 + (l / 32) * 4 + e % 4, column l % 32
+    float *out = g.cpart + (int64_t)s * g.M * g.N;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = m0 + wm + 32 * i + (e >> 2) * 8 + (lane >> 5) * 4 + (e & 3), col = n0 + wn + 32 * j + (lane & 31);
+                out[(int64_t)row * g.N + col] = hi[i][j][e] + lo[i][j][e];
+            }
+}
+
+// The same product with the staging of csrc/l1_device.h: four LOADER waves issue every LDS-DMA (a compute wave that issues one leaves
+// the matrix pipe idle meanwhile), three chunks resident, one barrier per chunk.
+constexpr int STAGES2 = 3;
+__global__ __launch_bounds__(2 * NT, 1) void split_gemm_kernel2(SplitArgs g)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles_n = g.N / TN;
+    // (workgroups go to the 8 XCDs round-robin: with the K slice = blockIdx % S an XCD's L2 streams ONE slice of both operands -- 4.7 MB at
+    //  S = 8 -- instead of all 38 MB: with slice = blockIdx / tiles every XCD read everything, 300 MB a launch, 26 us whatever the products)
+    const int s = blockIdx.x % g.S, t = blockIdx.x / g.S;
+    const int m0 = (t / tiles_n) * TM, n0 = (t % tiles_n) * TN;
+    const int kr = g.K / g.S, kb = s * kr, nc = kr / KC;       // nc >= STAGES2 (checked by the launcher)
+    const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+    if (wv >= 4) {                                           // ---- a loader
+        const int lw = wv - 4;
+#pragma unroll
+        for (int c = 0; c < STAGES2; ++c) issue_chunk(g, m0, n0, kb + c * KC, lds0 + (uint32_t)(c * STAGE), lw, lane);
+        asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                        // B_0: chunk 0 is in LDS
+        for (int c = 0; c < nc; ++c) {                       // B_{c + 1}: chunk c + 1 readable, chunk c's stage free
+            if (c + STAGES2 <= nc) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (c + STAGES2 < nc) issue_chunk(g, m0, n0, kb + (c + STAGES2) * KC, lds0 + (uint32_t)((c % STAGES2) * STAGE), lw, lane);
+        }
+        return;
+    }
+    const int wm = (wv >> 1) * 64, wn = (wv & 1) * 64;
+    f32x16 hi[2][2], lo[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { hi[i][j][e] = 0.f; lo[i][j][e] = 0.f; }
+    __builtin_amdgcn_s_barrier();                            // B_0
+    const int r = lane & 31, kg = lane >> 5;
+    for (int c = 0; c < nc; ++c) {
+        const unsigned char *st = smem + (c % STAGES2) * STAGE;
+#pragma unroll
+        for (int ks = 0; ks < KC / 16; ++ks) {
+            const int chunk = ks * 2 + kg;
+            bf16x8 fa[3][2], fb[3][2];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    fa[pl][i] = frag(st, pl * PLANE_A, wm + 32 * i + r, chunk);
+                    fb[pl][i] = frag(st, 3 * PLANE_A + pl * PLANE_B, wn + 32 * i + r, chunk);
+                }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    hi[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][i], fb[0][j], hi[i][j], 0, 0, 0);
+                    if (g.products >= 3) {
+                        lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][i], fb[1][j], lo[i][j], 0, 0, 0);
+                        lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][i], fb[0][j], lo[i][j], 0, 0, 0);
+                    }
+                    if (g.products >= 6) {
+                        lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][i], fb[1][j], lo[i][j], 0, 0, 0);
+                        lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][i], fb[2][j], lo[i][j], 0, 0, 0);
+                        lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[2][i], fb[0][j], lo[i][j], 0, 0, 0);
+                    }
+                }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // (the wave's own reads of chunk c are in registers before its stage is refilled)
+        __builtin_amdgcn_s_barrier();                        // B_{c + 1}
+    }
+    float *out = g.cpart + (int64_t)s * g.M * g.N;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = m0 + wm + 32 * i + (e >> 2) * 8 + (lane >> 5) * 4 + (e & 3), col = n0 + wn + 32 * j + (lane & 31);
+                out[(int64_t)row * g.N + col] = hi[i][j][e] + lo[i][j][e];
+            }
+}
+
+}  // namespace
+
+extern "C" int idl_debug_split_gemm(const void *a0, const void *a1, const void *a2, const void *b0, const void *b1, const void *b2,
+                                    float *cpart, int M, int N, int K, int S, int products, void *stream)
+{
+    IDL_REQUIRE(a0 && a1 && a2 && b0 && b1 && b2 && cpart, "debug_split_gemm: NULL buffer");
+    IDL_REQUIRE(M % TM == 0 && N % TN == 0 && S >= 1 && K % (S * KC) == 0 && (K / S) / KC >= 2, "debug_split_gemm: 128 | M, N; 32 S | K");
+    const bool loaders = products >= 16;                     // products + 16: the form with loader waves
+    products &= 15;
+    IDL_REQUIRE(products == 1 || products == 3 || products == 6, "debug_split_gemm: products = 1, 3 or 6 (+ 16: loader waves)");
+    IDL_REQUIRE(!loaders || (K / S) / KC >= STAGES2, "debug_split_gemm: at least three chunks per workgroup");
+    IDL_REQUIRE((int64_t)M * K < (1ll << 30) && (int64_t)N * K < (1ll << 30), "debug_split_gemm: 32-bit offsets");
+    SplitArgs g{};
+    g.a[0] = (const uint16_t *)a0; g.a[1] = (const uint16_t *)a1; g.a[2] = (const uint16_t *)a2;
+    g.b[0] = (const uint16_t *)b0; g.b[1] = (const uint16_t *)b1; g.b[2] = (const uint16_t *)b2;
+    g.cpart = cpart; g.M = M; g.N = N; g.K = K; g.S = S; g.products = products;
+    static bool attr_set = false;
+    if (!attr_set) {
+        IDL_HIP_TRY(hipFuncSetAttribute((const void *)split_gemm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, STAGES * STAGE));
+        IDL_HIP_TRY(hipFuncSetAttribute((const void *)split_gemm_kernel2, hipFuncAttributeMaxDynamicSharedMemorySize, STAGES2 * STAGE));
+        attr_set = true;
+    }
+    if (loaders) hipLaunchKernelGGL(split_gemm_kernel2, dim3((unsigned)((M / TM) * (N / TN) * S)), dim3(2 * NT), STAGES2 * STAGE, (hipStream_t)stream, g);
+    else hipLaunchKernelGGL(split_gemm_kernel, dim3((unsigned)((M / TM) * (N / TN) * S)), dim3(NT), STAGES * STAGE, (hipStream_t)stream, g);
+    IDL_HIP_TRY(hipGetLastError());
+    return IDL_OK;
+}

@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""What the step's big fp32 products would cost on the bf16 matrix cores with three-way split operands (csrc/probe_split.hip):
+    python3 tools/probe_split_mfma.py
+C = A B^T at the layer-1 forward's shape (A = a standardised batch [1024, 4096], B = W1 [512, 4096]), operands split
+x = x0 + x1 + x2 into bf16 planes on the device beforehand, 6 / 3 / 1 of the split products on v_mfma_f32_32x32x16_bf16, fp32
+accumulators, 8-way split K (partial sums [8][M][N], summed by torch for the check).  Prints per variant: us per launch (HIP events
+over 200 launches behind 20 warm-ups) and the error against a float64 product, beside the fp32 library GEMM's own time and error."""
+import ctypes
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+
+def split3(x):
+    x0 = x.to(torch.bfloat16)
+    r = x - x0.float()
+    x1 = r.to(torch.bfloat16)
+    r2 = r - x1.float()
+    x2 = r2.to(torch.bfloat16)
+    return [t.contiguous() for t in (x0, x1, x2)]
+
+
+def timed(fn, n=200, warm=20):
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3
+
+
+def main():
+    from idelucs_amd import _lib
+    L = _lib.lib
+    dev = torch.device("cuda")
+    g = torch.Generator(device="cpu"); g.manual_seed(3)
+    M, N, K, S = 1024, 512, 4096, 8
+    a = torch.randn(M, K, generator=g).to(dev)                       # a standardised batch
+    b = (torch.randn(N, K, generator=g) * (2.0 / K) ** 0.5).to(dev)  # Kaiming-normal W1
+    ref = a.double() @ b.double().t()
+    scale = ref.abs().max().item()
+    pa, pb = split3(a), split3(b)
+    cpart = torch.empty(S, M, N, dtype=torch.float32, device=dev)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def run(products):
+        _lib.check(L.idl_debug_split_gemm(*(ctypes.c_void_p(t.data_ptr()) for t in pa), *(ctypes.c_void_p(t.data_ptr()) for t in pb),
+                                          ctypes.c_void_p(cpart.data_ptr()), M, N, K, S, products, st))
+
+    out = torch.empty(M, N, dtype=torch.float32, device=dev)
+    t_lib = timed(lambda: torch.mm(a, b.t(), out=out))
+    e_lib = ((out.double() - ref).abs().max().item() / scale, ((out.double() - ref) ** 2).mean().sqrt().item() / scale)
+    print(f"fp32 library GEMM {M} x {N} x {K}: {t_lib:.1f} us; error against float64, relative to the largest entry: max {e_lib[0]:.2e}, rms {e_lib[1]:.2e}")
+    for products in (6, 3, 1, 16 + 6, 16 + 3, 16 + 1):
+        run(products)
+        torch.cuda.synchronize()
+        c = cpart.double().sum(0)
+        err = ((c - ref).abs().max().item() / scale, ((c - ref) ** 2).mean().sqrt().item() / scale)
+        pcode = products
+        t = timed(lambda: run(pcode))
+        t_sum = timed(lambda: torch.sum(cpart, 0, out=out))
+        form = "loader waves, 3 chunks resident" if products >= 16 else "every wave loads and computes, 2 chunks"
+        products &= 15
+        flops = 2.0 * M * N * K * products
+        print(f"bf16 MFMA, {products} split product(s) ({form}), {S}-way split K: {t:.1f} us = {flops / t / 1e6:.0f} TFLOP/s of bf16 products "
+              f"(+ {t_sum:.1f} us for a separate sum of the {S} partials); error max {err[0]:.2e}, rms {err[1]:.2e}")
+
+
+if __name__ == "__main__":
+    main()

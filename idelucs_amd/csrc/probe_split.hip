@@ -132,6 +132,10 @@ __global__ __launch_bounds__(NT, 1) void split_gemm_kernel(SplitArgs g)
 // The same product with the staging of csrc/l1_device.h: four LOADER waves issue every LDS-DMA (a compute wave that issues one leaves
 // the matrix pipe idle meanwhile), three chunks resident, one barrier per chunk.
 constexpr int STAGES2 = 3;
+// PLANES = 3, bf16: the six (three, one) products above.  PLANES = 2, F16: x = x0 + x1 in fp16 (22 significand bits; the caller scales
+// a tensor into fp16's range), the three products x0 y0, x0 y1, x1 y0 -- 4 bytes an element, as fp32
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+template <int PLANES, bool F16>
 __global__ __launch_bounds__(2 * NT, 1) void split_gemm_kernel2(SplitArgs g)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -143,16 +147,31 @@ __global__ __launch_bounds__(2 * NT, 1) void split_gemm_kernel2(SplitArgs g)
     const int m0 = (t / tiles_n) * TM, n0 = (t % tiles_n) * TN;
     const int kr = g.K / g.S, kb = s * kr, nc = kr / KC;       // nc >= STAGES2 (checked by the launcher)
     const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+    constexpr int PER = PLANES * 4;                          // DMA instructions a loader issues per chunk (2 x PLANES planes x 8 blocks / 4 loaders)
     if (wv >= 4) {                                           // ---- a loader
         const int lw = wv - 4;
+        auto issue = [&](int k0, uint32_t lds_stage) {
 #pragma unroll
-        for (int c = 0; c < STAGES2; ++c) issue_chunk(g, m0, n0, kb + c * KC, lds0 + (uint32_t)(c * STAGE), lw, lane);
-        asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+            for (int i = 0; i < PER; ++i) {
+                const int j = lw * PER + i;                  // 0 .. 8 * 2 * PLANES - 1: plane-of-A / plane-of-B major, 16-row block minor
+                const int pq = j >> 3, blk = j & 7;
+                const bool isA = pq < PLANES;
+                const int pl = isA ? pq : pq - PLANES;
+                const int row = blk * 16 + (lane >> 2), slot = lane & 3, src = slot ^ ((row >> 2) & 3);
+                const uint16_t *base = isA ? g.a[pl] : g.b[pl];
+                const int64_t r = (isA ? m0 : n0) + row;
+                const uint32_t voff = (uint32_t)((r * g.K + k0 + src * 8) * 2);
+                dma16(voff, base, lds_stage + (uint32_t)((isA ? pl : 3 + pl) * PLANE_A + blk * 1024));
+            }
+        };
+#pragma unroll
+        for (int c = 0; c < STAGES2; ++c) issue(kb + c * KC, lds0 + (uint32_t)(c * STAGE));
+        asm volatile("s_waitcnt vmcnt(%0)" : : "n"(2 * PER) : "memory");
         __builtin_amdgcn_s_barrier();                        // B_0: chunk 0 is in LDS
         for (int c = 0; c < nc; ++c) {                       // B_{c + 1}: chunk c + 1 readable, chunk c's stage free
-            if (c + STAGES2 <= nc) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (c + STAGES2 <= nc) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(PER) : "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            if (c + STAGES2 < nc) issue_chunk(g, m0, n0, kb + (c + STAGES2) * KC, lds0 + (uint32_t)((c % STAGES2) * STAGE), lw, lane);
+            if (c + STAGES2 < nc) issue(kb + (c + STAGES2) * KC, lds0 + (uint32_t)((c % STAGES2) * STAGE));
         }
         return;
     }
@@ -171,27 +190,31 @@ __global__ __launch_bounds__(2 * NT, 1) void split_gemm_kernel2(SplitArgs g)
 #pragma unroll
         for (int ks = 0; ks < KC / 16; ++ks) {
             const int chunk = ks * 2 + kg;
-            bf16x8 fa[3][2], fb[3][2];
+            bf16x8 fa[PLANES][2], fb[PLANES][2];
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl)
+            for (int pl = 0; pl < PLANES; ++pl)
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     fa[pl][i] = frag(st, pl * PLANE_A, wm + 32 * i + r, chunk);
                     fb[pl][i] = frag(st, 3 * PLANE_A + pl * PLANE_B, wn + 32 * i + r, chunk);
                 }
+            auto mma = [&](const bf16x8 &x, const bf16x8 &y, f32x16 acc) {
+                if (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, x), __builtin_bit_cast(f16x8, y), acc, 0, 0, 0);
+                return __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, acc, 0, 0, 0);
+            };
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    hi[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][i], fb[0][j], hi[i][j], 0, 0, 0);
+                    hi[i][j] = mma(fa[0][i], fb[0][j], hi[i][j]);
                     if (g.products >= 3) {
-                        lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][i], fb[1][j], lo[i][j], 0, 0, 0);
-                        lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][i], fb[0][j], lo[i][j], 0, 0, 0);
+                        lo[i][j] = mma(fa[0][i], fb[1][j], lo[i][j]);
+                        lo[i][j] = mma(fa[1][i], fb[0][j], lo[i][j]);
                     }
-                    if (g.products >= 6) {
-                        lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][i], fb[1][j], lo[i][j], 0, 0, 0);
-                        lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][i], fb[2][j], lo[i][j], 0, 0, 0);
-                        lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[2][i], fb[0][j], lo[i][j], 0, 0, 0);
+                    if (PLANES == 3 && g.products >= 6) {
+                        lo[i][j] = mma(fa[1][i], fb[1][j], lo[i][j]);
+                        lo[i][j] = mma(fa[0][i], fb[PLANES - 1][j], lo[i][j]);
+                        lo[i][j] = mma(fa[PLANES - 1][i], fb[0][j], lo[i][j]);
                     }
                 }
         }
@@ -217,8 +240,10 @@ extern "C" int idl_debug_split_gemm(const void *a0, const void *a1, const void *
 {
     IDL_REQUIRE(a0 && a1 && a2 && b0 && b1 && b2 && cpart, "debug_split_gemm: NULL buffer");
     IDL_REQUIRE(M % TM == 0 && N % TN == 0 && S >= 1 && K % (S * KC) == 0 && (K / S) / KC >= 2, "debug_split_gemm: 128 | M, N; 32 S | K");
-    const bool loaders = products >= 16;                     // products + 16: the form with loader waves
+    const bool loaders = (products & 16) != 0;               // products + 16: the form with loader waves; + 32: two fp16 planes (3 or 1 products)
+    const bool f16 = (products & 32) != 0;
     products &= 15;
+    IDL_REQUIRE(!f16 || (loaders && products <= 3), "debug_split_gemm: the fp16 form has loader waves and at most three products");
     IDL_REQUIRE(products == 1 || products == 3 || products == 6, "debug_split_gemm: products = 1, 3 or 6 (+ 16: loader waves)");
     IDL_REQUIRE(!loaders || (K / S) / KC >= STAGES2, "debug_split_gemm: at least three chunks per workgroup");
     IDL_REQUIRE((int64_t)M * K < (1ll << 30) && (int64_t)N * K < (1ll << 30), "debug_split_gemm: 32-bit offsets");
@@ -229,10 +254,12 @@ extern "C" int idl_debug_split_gemm(const void *a0, const void *a1, const void *
     static bool attr_set = false;
     if (!attr_set) {
         IDL_HIP_TRY(hipFuncSetAttribute((const void *)split_gemm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, STAGES * STAGE));
-        IDL_HIP_TRY(hipFuncSetAttribute((const void *)split_gemm_kernel2, hipFuncAttributeMaxDynamicSharedMemorySize, STAGES2 * STAGE));
+        IDL_HIP_TRY(hipFuncSetAttribute((const void *)split_gemm_kernel2<3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, STAGES2 * STAGE));
+        IDL_HIP_TRY(hipFuncSetAttribute((const void *)split_gemm_kernel2<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, STAGES2 * STAGE));
         attr_set = true;
     }
-    if (loaders) hipLaunchKernelGGL(split_gemm_kernel2, dim3((unsigned)((M / TM) * (N / TN) * S)), dim3(2 * NT), STAGES2 * STAGE, (hipStream_t)stream, g);
+    if (f16) hipLaunchKernelGGL((split_gemm_kernel2<2, true>), dim3((unsigned)((M / TM) * (N / TN) * S)), dim3(2 * NT), STAGES2 * STAGE, (hipStream_t)stream, g);
+    else if (loaders) hipLaunchKernelGGL((split_gemm_kernel2<3, false>), dim3((unsigned)((M / TM) * (N / TN) * S)), dim3(2 * NT), STAGES2 * STAGE, (hipStream_t)stream, g);
     else hipLaunchKernelGGL(split_gemm_kernel, dim3((unsigned)((M / TM) * (N / TN) * S)), dim3(NT), STAGES * STAGE, (hipStream_t)stream, g);
     IDL_HIP_TRY(hipGetLastError());
     return IDL_OK;

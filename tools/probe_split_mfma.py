@@ -22,6 +22,15 @@ def split3(x):
     return [t.contiguous() for t in (x0, x1, x2)]
 
 
+def split2_f16(x):
+    """x = 2^-k (x0 + x1), fp16 both (22 significand bits), the tensor scaled so that its largest entry sits near 2^12."""
+    k = int(torch.floor(torch.log2(torch.tensor(4096.0) / x.abs().max().cpu())).item())
+    xs = x * (2.0 ** k)
+    x0 = xs.to(torch.float16)
+    x1 = (xs - x0.float()).to(torch.float16)
+    return [x0.contiguous(), x1.contiguous(), x1.contiguous()], k
+
+
 def timed(fn, n=200, warm=20):
     for _ in range(warm):
         fn()
@@ -56,18 +65,26 @@ def main():
     t_lib = timed(lambda: torch.mm(a, b.t(), out=out))
     e_lib = ((out.double() - ref).abs().max().item() / scale, ((out.double() - ref) ** 2).mean().sqrt().item() / scale)
     print(f"fp32 library GEMM {M} x {N} x {K}: {t_lib:.1f} us; error against float64, relative to the largest entry: max {e_lib[0]:.2e}, rms {e_lib[1]:.2e}")
-    for products in (6, 3, 1, 16 + 6, 16 + 3, 16 + 1):
+    pa16, ka = split2_f16(a)
+    pb16, kb = split2_f16(b)
+    bf_planes = (pa, pb)
+    for products in (6, 3, 1, 16 + 6, 16 + 3, 16 + 1, 48 + 3, 48 + 1):
+        if products & 32:
+            pa, pb = pa16, pb16
+        else:
+            pa, pb = bf_planes
         run(products)
         torch.cuda.synchronize()
-        c = cpart.double().sum(0)
+        c = cpart.double().sum(0) * (2.0 ** -(ka + kb) if products & 32 else 1.0)
         err = ((c - ref).abs().max().item() / scale, ((c - ref) ** 2).mean().sqrt().item() / scale)
         pcode = products
         t = timed(lambda: run(pcode))
         t_sum = timed(lambda: torch.sum(cpart, 0, out=out))
-        form = "loader waves, 3 chunks resident" if products >= 16 else "every wave loads and computes, 2 chunks"
+        form = "loader waves, 3 chunks resident" if products & 16 else "every wave loads and computes, 2 chunks"
+        kind = "fp16 MFMA, two planes," if products & 32 else "bf16 MFMA,"
         products &= 15
         flops = 2.0 * M * N * K * products
-        print(f"bf16 MFMA, {products} split product(s) ({form}), {S}-way split K: {t:.1f} us = {flops / t / 1e6:.0f} TFLOP/s of bf16 products "
+        print(f"{kind} {products} split product(s) ({form}), {S}-way split K: {t:.1f} us = {flops / t / 1e6:.0f} TFLOP/s of 16-bit products "
               f"(+ {t_sum:.1f} us for a separate sum of the {S} partials); error max {err[0]:.2e}, rms {err[1]:.2e}")
 
 

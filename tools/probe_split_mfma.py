@@ -44,13 +44,24 @@ def timed(fn, n=200, warm=20):
 
 
 def main():
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--shape", default="fwd", choices=["fwd", "wgrad"],
+                    help="fwd: 1024 x 512 x 4096, 8-way split K (a1 = x W1^T); wgrad: 512 x 4096 x 1024, 2-way split K (dW1 = dr1^T x, with both "
+                         "operands given contraction-contiguous, i.e. TRANSPOSED copies of dr1 and x: their producers' problem)")
+    args = ap.parse_args()
     from idelucs_amd import _lib
     L = _lib.lib
     dev = torch.device("cuda")
     g = torch.Generator(device="cpu"); g.manual_seed(3)
-    M, N, K, S = 1024, 512, 4096, 8
-    a = torch.randn(M, K, generator=g).to(dev)                       # a standardised batch
-    b = (torch.randn(N, K, generator=g) * (2.0 / K) ** 0.5).to(dev)  # Kaiming-normal W1
+    if args.shape == "fwd":
+        M, N, K, S = 1024, 512, 4096, 8
+        a = torch.randn(M, K, generator=g).to(dev)                       # a standardised batch
+        b = (torch.randn(N, K, generator=g) * (2.0 / K) ** 0.5).to(dev)  # Kaiming-normal W1
+    else:
+        M, N, K, S = 512, 4096, 1024, 2
+        a = (torch.randn(M, K, generator=g) * 1e-4 * torch.rand(1, K, generator=g) ** 4).to(dev)   # dr1^T: rows of very different size
+        b = torch.randn(N, K, generator=g).to(dev)                                                # x^T
     ref = a.double() @ b.double().t()
     scale = ref.abs().max().item()
     pa, pb = split3(a), split3(b)

@@ -1886,9 +1886,6 @@ __global__ __launch_bounds__(PRIM_NT, 3) void lazy_fold_kernel(PrimArgs a, LazyA
         }
     }
     LZ_MARK(3);                                              // their coordinates; how many go
-#ifdef IDL_FOLD_DEBUG
-    if (blockIdx.x == 0 && tid == 0 && launch < 6) printf("[fold] launch %lld rescan %d fresh %d n_tree %lld k_found %d m %d cps0 %lld cos0 %lld ccs0 %.6f cws0 %.6f lb %.6f cu %.6f xcs00 %.6f\n", (long long)launch, rescan, S.fresh, (long long)S.n_tree, k_found, m, cps[0], cos_[0], ccs[0], cws[0], lb, core_unchosen, xcs[0][0]);
-#endif
     {       // one (run, feature) per thread; its box corner and scale are loaded once, the nodes loop in LDS
         static_assert(PRIM_RUNS * 64 == PRIM_NT && PRIM_FILTER_D == 64 && PRIM_AHEAD == 4, "one (run, feature) per thread");
         const int rr = tid >> 6, k = tid & 63;

@@ -135,6 +135,7 @@ constexpr int STAGES2 = 3;
 // PLANES = 3, bf16: the six (three, one) products above.  PLANES = 2, F16: x = x0 + x1 in fp16 (22 significand bits; the caller scales
 // a tensor into fp16's range), the three products x0 y0, x0 y1, x1 y0 -- 4 bytes an element, as fp32
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 template <int PLANES, bool F16>
 __global__ __launch_bounds__(2 * NT, 1) void split_gemm_kernel2(SplitArgs g)
 {
@@ -233,6 +234,116 @@ __global__ __launch_bounds__(2 * NT, 1) void split_gemm_kernel2(SplitArgs g)
             }
 }
 
+// The weight gradient's form: C[M][N] = sum_k At[k][M] Bt[k][N] with the operands as they LIE in memory for dW1 = dr1^T x (dr1 [rows][512],
+// x [rows][4096]: the contraction index is the slow one) -- two fp16 planes each, three products.  A chunk is 32 k-rows of 128 columns
+// (256 bytes a row) per plane, brought in by LDS-DMA as it lies; the MFMA operand of a lane -- 8 consecutive k of ONE column -- comes out
+// of two ds_read_b64_tr_b16 (the hardware transpose: a block of 4 k-rows x 16 columns per 16 lanes), the 16-byte slots of a row
+// swizzled by cdna_hip_programming.md's T10 rule (b) so that rows 256 bytes apart do not meet in a bank.
+typedef short s16x4v __attribute__((__vector_size__(4 * sizeof(short))));
+constexpr int T_ROWB = TM * 2;                               // bytes of a k-row of a plane in LDS (128 columns)
+constexpr int T_PLANE = KC * T_ROWB;                         // 8 192
+constexpr int T_STAGE = 4 * T_PLANE;                         // A0 A1 B0 B1
+__device__ __forceinline__ int t_swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+
+__global__ __launch_bounds__(2 * NT, 1) void split_gemm_kernel_t(SplitArgs g)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles_n = g.N / TN;
+    const int s = blockIdx.x % g.S, t = blockIdx.x / g.S;
+    const int m0 = (t / tiles_n) * TM, n0 = (t % tiles_n) * TN;
+    const int kr = g.K / g.S, kb = s * kr, nc = kr / KC;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+    constexpr int PER = 8;                                   // 32 DMA instructions a chunk (4 planes x 8 blocks of 4 rows), 8 per loader
+    if (wv >= 4) {
+        const int lw = wv - 4;
+        auto issue = [&](int k0, uint32_t lds_stage) {
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                const int j = lw * PER + i;                  // plane j / 8 (A0 A1 B0 B1), rows 4 (j % 8) .. + 3
+                const int pq = j >> 3, blk = j & 7;
+                const bool isA = pq < 2;
+                const int row = blk * 4 + (lane >> 4), slot = lane & 15, src = slot ^ t_swz(row);
+                const uint16_t *base = isA ? g.a[pq] : g.b[pq - 2];
+                const int ld = isA ? g.M : g.N;
+                const uint32_t voff = (uint32_t)((((int64_t)(k0 + row)) * ld + (isA ? m0 : n0) + src * 8) * 2);
+                dma16(voff, base, lds_stage + (uint32_t)(pq * T_PLANE + blk * 1024));
+            }
+        };
+#pragma unroll
+        for (int c = 0; c < STAGES2; ++c) issue(kb + c * KC, lds0 + (uint32_t)(c * T_STAGE));
+        asm volatile("s_waitcnt vmcnt(%0)" : : "n"(2 * PER) : "memory");
+        __builtin_amdgcn_s_barrier();
+        for (int c = 0; c < nc; ++c) {
+            if (c + STAGES2 <= nc) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(PER) : "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (c + STAGES2 < nc) issue(kb + (c + STAGES2) * KC, lds0 + (uint32_t)((c % STAGES2) * T_STAGE));
+        }
+        return;
+    }
+    const int wm = (wv >> 1) * 64, wn = (wv & 1) * 64;
+    f32x16 hi[2][2], lo[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { hi[i][j][e] = 0.f; lo[i][j][e] = 0.f; }
+    __builtin_amdgcn_s_barrier();
+    // the transposed read of lane l: 16-lane group l / 16 -> column half (l / 16) & 1, k group l / 32; inside the group lane 4 q + p supplies
+    // k-row q, columns 4 p .. 4 p + 3 (8 bytes: half p & 1 of the 16-byte slot p >> 1) and receives column l % 16, rows 0 .. 3
+    const int q = (lane & 15) >> 2, p = lane & 3, ch = (lane >> 4) & 1, kg = lane >> 5;
+    auto tr8 = [&](const unsigned char *plane, int col0, int krow0) {      // 8 consecutive k of column col0 + 16 ch + l % 16
+        f16x8 out;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int row = krow0 + 4 * h + q;
+            const int slot = ((col0 + 16 * ch + 4 * p) >> 3) ^ t_swz(row);
+            const uint32_t addr = (uint32_t)(uintptr_t)plane + row * T_ROWB + slot * 16 + 8 * (p & 1);
+            const s16x4v v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4v *)(uintptr_t)addr);
+            const f16x4 f = __builtin_bit_cast(f16x4, v);
+            out[4 * h] = f[0]; out[4 * h + 1] = f[1]; out[4 * h + 2] = f[2]; out[4 * h + 3] = f[3];
+        }
+        return out;
+    };
+    for (int c = 0; c < nc; ++c) {
+        const unsigned char *st = smem + (c % STAGES2) * T_STAGE;
+#pragma unroll
+        for (int ks = 0; ks < KC / 16; ++ks) {
+            f16x8 fa[2][2], fb[2][2];
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    fa[pl][i] = tr8(st + pl * T_PLANE, wm + 32 * i, ks * 16 + 8 * kg);
+                    fb[pl][i] = tr8(st + (2 + pl) * T_PLANE, wn + 32 * i, ks * 16 + 8 * kg);
+                }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    hi[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[0][i], fb[0][j], hi[i][j], 0, 0, 0);
+                    if (g.products >= 3) {
+                        lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[0][i], fb[1][j], lo[i][j], 0, 0, 0);
+                        lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[1][i], fb[0][j], lo[i][j], 0, 0, 0);
+                    }
+                }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    float *out = g.cpart + (int64_t)s * g.M * g.N;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = m0 + wm + 32 * i + (e >> 2) * 8 + (lane >> 5) * 4 + (e & 3), col = n0 + wn + 32 * j + (lane & 31);
+                out[(int64_t)row * g.N + col] = hi[i][j][e] + lo[i][j][e];
+            }
+}
+
 }  // namespace
 
 extern "C" int idl_debug_split_gemm(const void *a0, const void *a1, const void *a2, const void *b0, const void *b1, const void *b2,
@@ -242,7 +353,9 @@ extern "C" int idl_debug_split_gemm(const void *a0, const void *a1, const void *
     IDL_REQUIRE(M % TM == 0 && N % TN == 0 && S >= 1 && K % (S * KC) == 0 && (K / S) / KC >= 2, "debug_split_gemm: 128 | M, N; 32 S | K");
     const bool loaders = (products & 16) != 0;               // products + 16: the form with loader waves; + 32: two fp16 planes (3 or 1 products)
     const bool f16 = (products & 32) != 0;
+    const bool transposed = (products & 64) != 0;           // + 64: operands [K][M], [K][N] (fp16 planes, loader waves)
     products &= 15;
+    IDL_REQUIRE(!transposed || (f16 && loaders), "debug_split_gemm: the transposed form takes two fp16 planes");
     IDL_REQUIRE(!f16 || (loaders && products <= 3), "debug_split_gemm: the fp16 form has loader waves and at most three products");
     IDL_REQUIRE(products == 1 || products == 3 || products == 6, "debug_split_gemm: products = 1, 3 or 6 (+ 16: loader waves)");
     IDL_REQUIRE(!loaders || (K / S) / KC >= STAGES2, "debug_split_gemm: at least three chunks per workgroup");
@@ -256,9 +369,11 @@ extern "C" int idl_debug_split_gemm(const void *a0, const void *a1, const void *
         IDL_HIP_TRY(hipFuncSetAttribute((const void *)split_gemm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, STAGES * STAGE));
         IDL_HIP_TRY(hipFuncSetAttribute((const void *)split_gemm_kernel2<3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, STAGES2 * STAGE));
         IDL_HIP_TRY(hipFuncSetAttribute((const void *)split_gemm_kernel2<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, STAGES2 * STAGE));
+        IDL_HIP_TRY(hipFuncSetAttribute((const void *)split_gemm_kernel_t, hipFuncAttributeMaxDynamicSharedMemorySize, STAGES2 * T_STAGE));
         attr_set = true;
     }
-    if (f16) hipLaunchKernelGGL((split_gemm_kernel2<2, true>), dim3((unsigned)((M / TM) * (N / TN) * S)), dim3(2 * NT), STAGES2 * STAGE, (hipStream_t)stream, g);
+    if (transposed) hipLaunchKernelGGL(split_gemm_kernel_t, dim3((unsigned)((M / TM) * (N / TN) * S)), dim3(2 * NT), STAGES2 * T_STAGE, (hipStream_t)stream, g);
+    else if (f16) hipLaunchKernelGGL((split_gemm_kernel2<2, true>), dim3((unsigned)((M / TM) * (N / TN) * S)), dim3(2 * NT), STAGES2 * STAGE, (hipStream_t)stream, g);
     else if (loaders) hipLaunchKernelGGL((split_gemm_kernel2<3, false>), dim3((unsigned)((M / TM) * (N / TN) * S)), dim3(2 * NT), STAGES2 * STAGE, (hipStream_t)stream, g);
     else hipLaunchKernelGGL(split_gemm_kernel, dim3((unsigned)((M / TM) * (N / TN) * S)), dim3(NT), STAGES * STAGE, (hipStream_t)stream, g);
     IDL_HIP_TRY(hipGetLastError());

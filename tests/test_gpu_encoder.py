@@ -1271,3 +1271,9 @@ def test_split_operand_products_on_the_16_bit_matrix_cores_are_fp32_grade():
     pb16, kb = P.split2_f16(b)
     err = (run(pa16, pb16, 48 + 3) * 2.0 ** -(ka + kb) - ref).abs().max().item() / scale
     assert err < 5e-7 and err <= e_lib, (err, e_lib)
+    # the weight gradient's form: operands [K][M], [K][N] as they lie, transposed LDS reads
+    at, bt = a.t().contiguous(), b.t().contiguous()
+    pat, kat = P.split2_f16(at)
+    pbt, kbt = P.split2_f16(bt)
+    err = (run(pat, pbt, 64 + 48 + 3) * 2.0 ** -(kat + kbt) - ref).abs().max().item() / scale
+    assert err < 5e-7 and err <= e_lib, (err, e_lib)

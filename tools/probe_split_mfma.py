@@ -46,15 +46,15 @@ def timed(fn, n=200, warm=20):
 def main():
     import argparse
     ap = argparse.ArgumentParser()
-    ap.add_argument("--shape", default="fwd", choices=["fwd", "wgrad"],
+    ap.add_argument("--shape", default="fwd", choices=["fwd", "wgrad", "wgrad_t"],
                     help="fwd: 1024 x 512 x 4096, 8-way split K (a1 = x W1^T); wgrad: 512 x 4096 x 1024, 2-way split K (dW1 = dr1^T x, with both "
-                         "operands given contraction-contiguous, i.e. TRANSPOSED copies of dr1 and x: their producers' problem)")
+                         "operands given contraction-contiguous, i.e. TRANSPOSED copies of dr1 and x: their producers' problem); wgrad_t: the same product from dr1 [1024][512] and x [1024][4096] AS THEY LIE (transposed LDS reads)")
     args = ap.parse_args()
     from idelucs_amd import _lib
     L = _lib.lib
     dev = torch.device("cuda")
     g = torch.Generator(device="cpu"); g.manual_seed(3)
-    if args.shape == "fwd":
+    if args.shape in ("fwd", "wgrad_t"):
         M, N, K, S = 1024, 512, 4096, 8
         a = torch.randn(M, K, generator=g).to(dev)                       # a standardised batch
         b = (torch.randn(N, K, generator=g) * (2.0 / K) ** 0.5).to(dev)  # Kaiming-normal W1
@@ -62,7 +62,12 @@ def main():
         M, N, K, S = 512, 4096, 1024, 2
         a = (torch.randn(M, K, generator=g) * 1e-4 * torch.rand(1, K, generator=g) ** 4).to(dev)   # dr1^T: rows of very different size
         b = torch.randn(N, K, generator=g).to(dev)                                                # x^T
-    ref = a.double() @ b.double().t()
+    tr = args.shape == "wgrad_t"
+    if tr:
+        M, N, K, S = 512, 4096, 1024, 2
+        a = (torch.randn(K, M, generator=g) * 1e-4 * torch.rand(K, 1, generator=g) ** 4).to(dev)   # dr1: rows of very different size
+        b = torch.randn(K, N, generator=g).to(dev)                                                # x
+    ref = (a.double().t() @ b.double()) if tr else (a.double() @ b.double().t())
     scale = ref.abs().max().item()
     pa, pb = split3(a), split3(b)
     cpart = torch.empty(S, M, N, dtype=torch.float32, device=dev)
@@ -73,13 +78,13 @@ def main():
                                           ctypes.c_void_p(cpart.data_ptr()), M, N, K, S, products, st))
 
     out = torch.empty(M, N, dtype=torch.float32, device=dev)
-    t_lib = timed(lambda: torch.mm(a, b.t(), out=out))
+    t_lib = timed(lambda: torch.mm(a.t(), b, out=out)) if tr else timed(lambda: torch.mm(a, b.t(), out=out))
     e_lib = ((out.double() - ref).abs().max().item() / scale, ((out.double() - ref) ** 2).mean().sqrt().item() / scale)
     print(f"fp32 library GEMM {M} x {N} x {K}: {t_lib:.1f} us; error against float64, relative to the largest entry: max {e_lib[0]:.2e}, rms {e_lib[1]:.2e}")
     pa16, ka = split2_f16(a)
     pb16, kb = split2_f16(b)
     bf_planes = (pa, pb)
-    for products in (6, 3, 1, 16 + 6, 16 + 3, 16 + 1, 48 + 3, 48 + 1):
+    for products in ((64 + 48 + 3, 64 + 48 + 1) if tr else (6, 3, 1, 16 + 6, 16 + 3, 16 + 1, 48 + 3, 48 + 1)):
         if products & 32:
             pa, pb = pa16, pb16
         else:
@@ -92,7 +97,7 @@ def main():
         t = timed(lambda: run(pcode))
         t_sum = timed(lambda: torch.sum(cpart, 0, out=out))
         form = "loader waves, 3 chunks resident" if products & 16 else "every wave loads and computes, 2 chunks"
-        kind = "fp16 MFMA, two planes," if products & 32 else "bf16 MFMA,"
+        kind = ("fp16 MFMA, two planes" + (" as they lie (transposed LDS reads)," if products & 64 else ",")) if products & 32 else "bf16 MFMA,"
         products &= 15
         flops = 2.0 * M * N * K * products
         print(f"{kind} {products} split product(s) ({form}), {S}-way split K: {t:.1f} us = {flops / t / 1e6:.0f} TFLOP/s of 16-bit products "

@@ -13,15 +13,17 @@
 // ds_read_b64_tr_b16 (the hardware transpose of a 4 x 16 block) and issue v_mfma_f32_32x32x16_f16.  Three chunks are resident; one
 // barrier a chunk; the epilogue turns the wave's block around through LDS and works on 16-byte pieces of rows.
 //
-// WHERE IT STANDS (MI355X, m = 1024, 512 x 4096, a HIP graph of 20 launches; tools/bench_wgrad_split.py): gradient only 37.0 us, with
-// the update 43.6 -- the fp32 tiles: 35.1 / 40.8.  NOT faster yet, although the same product from PRE-SPLIT planes brought in by
-// LDS-DMA takes 22.0 us (csrc/probe_split.hip): the split inside the kernel puts the loaders on the critical path.  Ablation
-// (IDELUCS_WGS_DBG, gradient only): no requests 30.7; no split (raw stores) 30.5; neither 24.0; no LDS reads / MFMAs 33.9; all three
-// off 20.8; and no epilogue 19.3 -- i.e. 32 iterations of [12 eight-byte LDS stores per loader wave + a barrier of 8 waves] alone are
-// 16 us (0.5 us an iteration, not understood), the requests' latency and the ~130 vector instructions of a chunk's split add 6 us
-// each on top instead of hiding behind one another.  What was already taken out: 1 024 atomic maxima on ONE word (12 us; now a word per
-// loader wave, reduced by the next launch), eight loader waves (50.6 us), per-read address arithmetic of the transposed reads (formed
-// once per lane: the k16 step leaves the swizzle alone), 32 four-byte stores a lane in the epilogue (10 / 24 us).
+// WHERE IT STANDS (MI355X, m = 1024, 512 x 4096, a HIP graph of 20 launches; tools/bench_wgrad_split.py): gradient only 32.2 us, with
+// the update 38.9 -- the fp32 tiles: 35.2 / 41.0.  A little faster, far from the 22.0 us the same product takes from PRE-SPLIT planes
+// brought in by LDS-DMA (csrc/probe_split.hip): the split inside the kernel keeps the loaders on the critical path.  Ablation
+// (IDELUCS_WGS_DBG: 4 no LDS reads / MFMAs, 8 no epilogue, 16 a quarter of the chunks): without reads and MFMAs 26.8, without the
+// epilogue 30.9.  What was taken out on the way: the compiler's waits for the request ring (it cannot count the requests in flight
+// across the loop's back edge and waited for all but the last five: 37.0 -> 32.2 with inline-asm requests, waits placed by hand
+// and the ring's registers passed THROUGH the wait -- without that the first arithmetic on a request's output is moved up to the
+// request: NaNs); 1 024 atomic maxima on ONE word (12 us; now a word per loader wave, reduced by the next launch); eight loader waves
+// (50.6 us); per-read address arithmetic of the transposed reads (formed once per lane: the k16 step leaves the swizzle alone);
+// 32 four-byte stores a lane in the epilogue (10 / 24 us; now 16-byte pieces of rows through LDS).  Still unexplained: a chunk's
+// twelve 8-byte LDS stores per loader wave cost 0.33 us.
 //
 // Scales: x by 2^3 (a standardised feature is at most sqrt(N - 1) in size: 8 sqrt(N) < 65 504 up to N = 6.7e7); dy by 2^k with k from
 // the PREVIOUS launch's largest |dy| (2^k max ~ 2^12: 16 x headroom, values clamped at +-65 000), kept as tagged words (launch
@@ -121,10 +123,11 @@ __global__ __launch_bounds__(NT, 1) void wgrad_split_kernel(SplitWgArgs a)
         constexpr int PF = 4;
         f32x4 ra[PF][2], rb[PF][4];
         float mx = 0.f;
-        // (buffer loads: a lane's byte offset inside a chunk is formed once, the chunk's offset is a scalar -- the 64-bit address
-        //  arithmetic of plain pointers was a third of the loaders' instructions)
-        const __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc((void *)a.dy, 0, 0xffffffff, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, 0xffffffff, 0x00020000);
+        // The requests are inline asm with the waits placed by hand: left to the compiler the ring does not survive the loop's back edge
+        // (it cannot count the requests in flight from the passes before and waits for all but the last few: `s_waitcnt vmcnt(5)` in front
+        // of a deposit whose own requests are 18 back -- every pass then paid a round trip; wgrad_device.h tells the same story).  The
+        // loaders issue no other vector-memory instruction inside the loop, and the counter retires in order: a deposit of chunk d waits
+        // for `6 x (chunks requested behind d)`.
         uint32_t va[2], vb[4], la[2], lb[4];                 // global byte offsets inside a chunk; LDS byte offsets inside a stage's plane
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
@@ -138,21 +141,29 @@ __global__ __launch_bounds__(NT, 1) void wgrad_split_kernel(SplitWgArgs a)
             vb[u] = (uint32_t)((row * a.n_in + f0 + 4 * c4) * 4);
             lb[u] = (uint32_t)(row * ROWB + (((c4 >> 1) ^ swz(row)) << 4) + 8 * (c4 & 1));
         }
-        const uint32_t ca = (uint32_t)(KC * a.n_out * 4), cb = (uint32_t)(KC * a.n_in * 4);       // a chunk's bytes of rows
+        const int64_t ca = (int64_t)KC * a.n_out * 4, cb = (int64_t)KC * a.n_in * 4;             // a chunk's bytes of rows
         auto request = [&](int c, int slot) {
-            if (a.dbg & 1) return;
+            const char *pa = (const char *)a.dy + c * ca, *pb = (const char *)a.x + c * cb;
 #pragma unroll
-            for (int u = 0; u < 2; ++u) ra[slot][u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dy, va[u], (uint32_t)c * ca, 0));
+            for (int u = 0; u < 2; ++u) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(ra[slot][u]) : "v"(va[u]), "s"(pa) : "memory");
 #pragma unroll
-            for (int u = 0; u < 4; ++u) rb[slot][u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, vb[u], (uint32_t)c * cb, 0));
+            for (int u = 0; u < 4; ++u) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(rb[slot][u]) : "v"(vb[u]), "s"(pb) : "memory");
+        };
+        // (the slot's registers pass THROUGH the wait: the compiler takes an asm's output for ready at once and would move the first
+        //  arithmetic on it up to the request)
+#define WGS_WAIT(N, SL) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(ra[SL][0]), "+v"(ra[SL][1]), "+v"(rb[SL][0]), "+v"(rb[SL][1]), "+v"(rb[SL][2]), "+v"(rb[SL][3]) : : "memory")
+        auto wait_behind = [&](int chunks, int slot) {       // (uniform) the requests of `chunks` later chunks may still be in flight
+            if (chunks >= 3) WGS_WAIT(18, slot);
+            else if (chunks == 2) WGS_WAIT(12, slot);
+            else if (chunks == 1) WGS_WAIT(6, slot);
+            else WGS_WAIT(0, slot);
         };
         auto deposit = [&](int c, int slot) {
-            const uint32_t st = (uint32_t)(uintptr_t)smem + (uint32_t)((c % STAGES) * STAGE);     // (an LDS address: a generic pointer makes these flat stores)
+            const uint32_t st = (uint32_t)(uintptr_t)smem + (uint32_t)((c % STAGES) * STAGE);
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 uint2 p0, p1;
-                if (a.dbg & 2) { p0 = uint2{__float_as_uint(ra[slot][u][0]), __float_as_uint(ra[slot][u][1])}; p1 = uint2{__float_as_uint(ra[slot][u][2]), __float_as_uint(ra[slot][u][3])}; }
-                else split4<true>(ra[slot][u], sc_dy, p0, p1);
+                split4<true>(ra[slot][u], sc_dy, p0, p1);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) mx = fmaxf(mx, fabsf(ra[slot][u][e]));
                 *(__attribute__((address_space(3))) u32x2 *)(uintptr_t)(st + la[u]) = u32x2{p0.x, p0.y};
@@ -161,16 +172,16 @@ __global__ __launch_bounds__(NT, 1) void wgrad_split_kernel(SplitWgArgs a)
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 uint2 p0, p1;
-                if (a.dbg & 2) { p0 = uint2{__float_as_uint(rb[slot][u][0]), __float_as_uint(rb[slot][u][1])}; p1 = uint2{__float_as_uint(rb[slot][u][2]), __float_as_uint(rb[slot][u][3])}; }
-                else split4<false>(rb[slot][u], sc_x, p0, p1);       // (|x| 2^3 < 65 504 for N < 6.7e7 sequences: the launcher's caller checks)
+                split4<false>(rb[slot][u], sc_x, p0, p1);       // (|x| 2^3 < 65 504 for N < 6.7e7 sequences)
                 *(__attribute__((address_space(3))) u32x2 *)(uintptr_t)(st + 2 * PLANE + lb[u]) = u32x2{p0.x, p0.y};
                 *(__attribute__((address_space(3))) u32x2 *)(uintptr_t)(st + 3 * PLANE + lb[u]) = u32x2{p1.x, p1.y};
             }
         };
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the scale's words above: nothing else of this wave is in flight from here on)
 #pragma unroll
-        for (int sl = 0; sl < PF; ++sl) request(sl, sl);     // nc >= PF (the launcher)
-        deposit(0, 0); if (PF < nc) request(PF, 0);
-        deposit(1, 1); if (PF + 1 < nc) request(PF + 1, 1);
+        for (int sl = 0; sl < PF; ++sl) request(sl, sl);     // nc >= 2 PF (the launcher)
+        wait_behind(3, 0); deposit(0, 0); request(PF, 0);
+        wait_behind(3, 1); deposit(1, 1); request(PF + 1, 1);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                        // chunks 0 and 1 are in LDS
         for (int base = 0; base < nc; base += PF) {          // nc % PF == 0 (the launcher)
@@ -178,13 +189,16 @@ __global__ __launch_bounds__(NT, 1) void wgrad_split_kernel(SplitWgArgs a)
             for (int u = 0; u < PF; ++u) {                   // while the others read chunk base + u: chunk d into the stage chunk d - 3 left
                 const int d = base + u + 2, slot = (u + 2) % PF;
                 if (d < nc) {
-                    deposit(d, slot);                        // (waits for its own requests only: they were issued PF chunks ago)
+                    // chunks requested behind d: d + 1 .. min(d + PF - 1, nc - 1)
+                    wait_behind(nc - 1 - d < PF - 1 ? nc - 1 - d : PF - 1, slot);
+                    deposit(d, slot);
                     if (d + PF < nc) request(d + PF, slot);
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
             }
         }
+#undef WGS_WAIT
         // this launch's largest |dy| (of the tile's column block; every tile row of workgroups sees all rows) for the next launch
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64)); mx = fmaxf(mx, __shfl_xor(mx, 16, 64)); mx = fmaxf(mx, __shfl_xor(mx, 8, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 4, 64)); mx = fmaxf(mx, __shfl_xor(mx, 2, 64)); mx = fmaxf(mx, __shfl_xor(mx, 1, 64));

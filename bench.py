@@ -342,6 +342,35 @@ def lanes_epoch_ms(din, args, dev, rank, world, voters):
     return ms
 
 
+def split16_leg(din, args, dev, rank, world, passes=4):
+    """The headline region once more with the EXPERIMENTAL weight-gradient launch (IDELUCS_SPLIT16=1: the product on the fp16 matrix
+    cores from operands split inside the kernel, csrc/wgrad_split.hip) -- an opt-in, reported beside `value`, never as `value`."""
+    import copy
+    a = copy.copy(args)
+    a.voters, a.exchange = 1, False
+    os.environ["IDELUCS_SPLIT16"] = "1"
+    try:
+        hp = HotPath(din, a, dev, rank, world)
+        hp.step(seed=3000)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(passes):
+            hp.step(seed=3001 + i)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / passes
+        v = hp.validate()
+        out = {"what": "IDELUCS_SPLIT16=1: dW1 = dr1^T x on the fp16 matrix cores from two fp16 planes per operand, three products, fp32 "
+                       "accumulators (closer to a float64 product than the fp32 library GEMM: profiles/r05_probe_split_mfma.txt); everything "
+                       "else as in `value`",
+               "value": args.n / dt, "unit": "sequences/sec", "ms_per_pass": 1e3 * dt, "epoch_ms": hp.mean_ms("epoch", 1),
+               "epoch_loss_last_step": v.get("epoch_loss_last_step")}
+        del hp
+    finally:
+        os.environ.pop("IDELUCS_SPLIT16", None)
+    torch.cuda.empty_cache()
+    return out
+
+
 def predicted_fixed_job(din, args, dev, rank, world, st8, epoch1_ms):
     """What the 1/2/4/8 curve of the FIXED 8-voter job (cfg3) should look like, from this GPU's own stage times:
     per-rank wall at N ranks = sites + vectorise + scaler fit + (8/N) x epoch(lanes = 8/N) + predict inputs + (8/N) x predict +
@@ -633,6 +662,7 @@ def main():
     ap.add_argument("--cpu-ref-steps", dest="cpu_ref_steps", type=int, default=2,
                     help="optimizer steps timed (after one untimed step) with the reference's cpu_count()-2 torch threads, scaled to the epoch")
     ap.add_argument("--no-k-sweep", dest="k_sweep", action="store_false", help="skip the k = 4 / k = 5 vectorise-stage rooflines (cfg4)")
+    ap.add_argument("--no-split16", dest="split16", action="store_false", help="skip the leg with the experimental weight-gradient launch (IDELUCS_SPLIT16=1)")
     ap.add_argument("--no-cfg5", dest="cfg5_leg", action="store_false", help="skip the cfg5 job (10^6 x 5 kbp, 65.5 GB store) the default N = 1 run adds")
     ap.add_argument("--no-prediction", dest="prediction", action="store_false", help="skip the 2- and 4-lane passes behind predicted_fixed_job")
     ap.add_argument("--no-cpu-baseline", dest="cpu_base", action="store_false")
@@ -829,6 +859,8 @@ def main():
                 out["predicted_fixed_job"] = predicted_fixed_job(din, args, dev, rank, world, out["fixed_job_8_voters"]["stage_ms"], t_ep)
         if world == 1 and args.k_sweep and not cfg5 and V == 1:
             out["k_sweep"] = k_sweep(din, args, dev)
+        if world == 1 and args.split16 and not cfg5 and V == 1 and args.k == 6:
+            out["experimental_split16"] = split16_leg(din, args, dev, rank, world)
         if world == 1 and args.cfg5_leg and not cfg5 and V == 1 and not args.exchange and args.fixed_job:
             del din, hp
             torch.cuda.empty_cache()

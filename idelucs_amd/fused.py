@@ -148,6 +148,8 @@ class FusedLinearTrainer:
         self._bufs = {}
         self._graphs = {}
         self._side = torch.cuda.Stream(device=self.dev)     # second branch of the step (see step_on_batch)
+        self._split16 = os.environ.get("IDELUCS_SPLIT16", "0") == "1"
+        self._split_state = None
         # the layers between the two big GEMMs as one 1024-thread MFMA kernel per direction (idl_mid_fwd / idl_mid_bwd)
         self._mid_fused = self.H1 == 512 and os.environ.get("IDELUCS_MID_FUSED", "1") != "0"
         self._pipeline = os.environ.get("IDELUCS_PIPELINE", "1") != "0"   # optimizer launch also assembles the next batch
@@ -395,8 +397,15 @@ class FusedLinearTrainer:
                                   m, tr, adv_ctl, adv, _p(bf.r2) if self._dw3_partial else None,
                                   _p(gW3) if self._dw3_partial else None, _stream()))
         if tm:      # the dW1 tiles end the step; everything else of the optimizer rides in the next step's layer-1 launch
-            chk(_L.idl_wgrad_rmsprop(_p(bf.dr1), _p(x), m, self.H1, self.F, _p(gW1) if self._keep_w1_grad else None, _p(self.W1),
-                                     _p(self.square_avg[0]), _p(self.hyper), _stream()))
+            if self._split16 and m % 128 == 0 and m >= 256:
+                # EXPERIMENTAL (IDELUCS_SPLIT16=1; csrc/wgrad_split.hip): the product on the fp16 matrix cores from operands split inside the kernel
+                if self._split_state is None:
+                    self._split_state = torch.zeros(int(_L.idl_wgrad_split_state_words()), dtype=torch.int64, device=self.dev)
+                chk(_L.idl_wgrad_rmsprop_split(_p(bf.dr1), _p(x), m, self.H1, self.F, _p(gW1) if self._keep_w1_grad else None, _p(self.W1),
+                                               _p(self.square_avg[0]), _p(self.hyper), _p(self.ctl), _p(self._split_state), _stream()))
+            else:
+                chk(_L.idl_wgrad_rmsprop(_p(bf.dr1), _p(x), m, self.H1, self.F, _p(gW1) if self._keep_w1_grad else None, _p(self.W1),
+                                         _p(self.square_avg[0]), _p(self.hyper), _stream()))
             self._pending = (bf, xi)
             if not defer_tail:
                 self.flush_tail()

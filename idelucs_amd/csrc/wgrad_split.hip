@@ -22,8 +22,10 @@
 // and the ring's registers passed THROUGH the wait -- without that the first arithmetic on a request's output is moved up to the
 // request: NaNs); 1 024 atomic maxima on ONE word (12 us; now a word per loader wave, reduced by the next launch); eight loader waves
 // (50.6 us); per-read address arithmetic of the transposed reads (formed once per lane: the k16 step leaves the swizzle alone);
-// 32 four-byte stores a lane in the epilogue (10 / 24 us; now 16-byte pieces of rows through LDS).  Still unexplained: a chunk's
-// twelve 8-byte LDS stores per loader wave cost 0.33 us.
+// 32 four-byte stores a lane in the epilogue (10 / 24 us; now 16-byte pieces of rows through LDS).  Tried with the hand-placed waits and
+// no better: eight loader waves (33.9 / 39.6), chunks of 64 rows with two stages and eight loaders (32.4 / 38.4), raised priority for
+// the loaders (32.7 / 38.5).  LDS bank conflicts: none (SQ_LDS_BANK_CONFLICT 0).  The loaders' ~0.7 us a chunk is not explained by
+// its parts.
 //
 // Scales: x by 2^3 (a standardised feature is at most sqrt(N - 1) in size: 8 sqrt(N) < 65 504 up to N = 6.7e7); dy by 2^k with k from
 // the PREVIOUS launch's largest |dy| (2^k max ~ 2^12: 16 x headroom, values clamped at +-65 000), kept as tagged words (launch

@@ -16,7 +16,7 @@
 // WHERE IT STANDS (MI355X, m = 1024, 512 x 4096, a HIP graph of 20 launches; tools/bench_wgrad_split.py): gradient only 32.2 us, with
 // the update 38.9 -- the fp32 tiles: 35.2 / 41.0.  A little faster, far from the 22.0 us the same product takes from PRE-SPLIT planes
 // brought in by LDS-DMA (csrc/probe_split.hip): the split inside the kernel keeps the loaders on the critical path.  Ablation
-// (IDELUCS_WGS_DBG: 4 no LDS reads / MFMAs, 8 no epilogue, 16 a quarter of the chunks): without reads and MFMAs 26.8, without the
+// (IDELUCS_WGS_DBG: 4 no LDS reads / MFMAs, 8 no epilogue, 16 a quarter of the chunks, 128 stamps): without reads and MFMAs 26.8, without the
 // epilogue 30.9.  What was taken out on the way: the compiler's waits for the request ring (it cannot count the requests in flight
 // across the loop's back edge and waited for all but the last five: 37.0 -> 32.2 with inline-asm requests, waits placed by hand
 // and the ring's registers passed THROUGH the wait -- without that the first arithmetic on a request's output is moved up to the
@@ -24,8 +24,10 @@
 // (50.6 us); per-read address arithmetic of the transposed reads (formed once per lane: the k16 step leaves the swizzle alone);
 // 32 four-byte stores a lane in the epilogue (10 / 24 us; now 16-byte pieces of rows through LDS).  Tried with the hand-placed waits and
 // no better: eight loader waves (33.9 / 39.6), chunks of 64 rows with two stages and eight loaders (32.4 / 38.4), raised priority for
-// the loaders (32.7 / 38.5).  LDS bank conflicts: none (SQ_LDS_BANK_CONFLICT 0).  The loaders' ~0.7 us a chunk is not explained by
-// its parts.
+// the loaders (32.7 / 38.5), the split in hand-picked instructions (80 instead of 130 a chunk: the same time).  LDS bank conflicts:
+// none (SQ_LDS_BANK_CONFLICT 0).  Stamps of a loader wave (IDELUCS_WGS_DBG=128, shader cycles a chunk): wait for its requests 239, split +
+// LDS stores issued 839-940, next requests + stores done 180, barrier 90 -- the phase that issues 80 vector instructions and twelve
+// 8-byte LDS stores takes 840 cycles whatever the vector instructions are.
 //
 // Scales: x by 2^3 (a standardised feature is at most sqrt(N - 1) in size: 8 sqrt(N) < 65 504 up to N = 6.7e7); dy by 2^k with k from
 // the PREVIOUS launch's largest |dy| (2^k max ~ 2^12: 16 x headroom, values clamped at +-65 000), kept as tagged words (launch
@@ -68,20 +70,30 @@ struct SplitWgArgs {
 
 __device__ __forceinline__ int swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }      // cdna_hip_programming.md T10 (b)
 
-// four fp32 values -> their two fp16 planes (scaled by sc, clamped into fp16's range), 8 bytes each
+// four fp32 values -> their two fp16 planes (scaled by sc, clamped into fp16's range), 8 bytes each.  Hand-picked instructions: the
+// compiler's form unpacked the high plane again to subtract it (~21 vector instructions per 16 bytes; the loaders' split was 940
+// shader cycles of a chunk's 1 455, stamps: IDELUCS_WGS_DBG=128); here v_cvt_pk_f16_f32 (two values an instruction, round to nearest
+// even) and v_fma_mix_f32, which reads the fp16 half as it lies: s - x0 in one instruction, exact.
 template <bool CLAMP>
 __device__ __forceinline__ void split4(const f32x4 v, const float sc, uint2 &p0, uint2 &p1)
 {
-    f16x4 a, b;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        float s = v[e] * sc;
-        if (CLAMP) s = __builtin_amdgcn_fmed3f(s, -65000.f, 65000.f);
-        a[e] = (_Float16)s;
-        b[e] = (_Float16)(s - (float)a[e]);
+    float s0 = v[0] * sc, s1 = v[1] * sc, s2 = v[2] * sc, s3 = v[3] * sc;
+    if (CLAMP) {
+        s0 = __builtin_amdgcn_fmed3f(s0, -65000.f, 65000.f); s1 = __builtin_amdgcn_fmed3f(s1, -65000.f, 65000.f);
+        s2 = __builtin_amdgcn_fmed3f(s2, -65000.f, 65000.f); s3 = __builtin_amdgcn_fmed3f(s3, -65000.f, 65000.f);
     }
-    p0 = __builtin_bit_cast(uint2, a);
-    p1 = __builtin_bit_cast(uint2, b);
+    uint32_t h01, h23, l01, l23;
+    float r0, r1, r2, r3;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h01) : "v"(s0), "v"(s1));
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h23) : "v"(s2), "v"(s3));
+    asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(h01), "v"(s0));
+    asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(h01), "v"(s1));
+    asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r2) : "v"(h23), "v"(s2));
+    asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r3) : "v"(h23), "v"(s3));
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(l01) : "v"(r0), "v"(r1));
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(l23) : "v"(r2), "v"(r3));
+    p0 = uint2{h01, h23};
+    p1 = uint2{l01, l23};
 }
 
 __global__ __launch_bounds__(NT, 1) void wgrad_split_kernel(SplitWgArgs a)
@@ -190,14 +202,25 @@ __global__ __launch_bounds__(NT, 1) void wgrad_split_kernel(SplitWgArgs a)
 #pragma unroll
             for (int u = 0; u < PF; ++u) {                   // while the others read chunk base + u: chunk d into the stage chunk d - 3 left
                 const int d = base + u + 2, slot = (u + 2) % PF;
+                const bool stamp = (a.dbg & 128) && bid == 0 && tid == 256;
+                uint64_t c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0;
+                if (stamp) c0 = __builtin_amdgcn_s_memtime();
                 if (d < nc) {
                     // chunks requested behind d: d + 1 .. min(d + PF - 1, nc - 1)
                     wait_behind(nc - 1 - d < PF - 1 ? nc - 1 - d : PF - 1, slot);
+                    if (stamp) c1 = __builtin_amdgcn_s_memtime();
                     deposit(d, slot);
+                    if (stamp) c2 = __builtin_amdgcn_s_memtime();
                     if (d + PF < nc) request(d + PF, slot);
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (stamp) c3 = __builtin_amdgcn_s_memtime();
                 __builtin_amdgcn_s_barrier();
+                if (stamp && d < nc && d + PF < nc) {
+                    c4 = __builtin_amdgcn_s_memtime();
+                    unsigned long long *o = a.state + 2 * STATE_SLOTS - 8;       // (the last words of the state: diagnostics only)
+                    o[0] += c1 - c0; o[1] += c2 - c1; o[2] += c3 - c2; o[3] += c4 - c3; o[4] += 1;
+                }
             }
         }
 #undef WGS_WAIT

@@ -68,6 +68,11 @@ def main():
         t_grad = timed(lambda: run(False, True))
         print(f"{name}: update in the epilogue {t_full:.1f} us a launch, gradient only {t_grad:.1f}; gradient against float64, relative to the largest "
               f"entry: max {err.max().item() / scale:.2e}, rms {(err ** 2).mean().sqrt().item() / scale:.2e}")
+    if int(os.environ.get("IDELUCS_WGS_DBG", "0")) & 128:
+        o = state[-8:].cpu().tolist()
+        n = max(o[4], 1)
+        print(f"loader wave 0 of workgroup 0, shader cycles a chunk over {o[4]} chunks: wait for the requests {o[0] / n:.0f}, split + LDS stores issued {o[1] / n:.0f}, "
+              f"next requests + LDS stores done {o[2] / n:.0f}, barrier {o[3] / n:.0f}")
     (g0, w0, v0), (g1, w1, v1) = out["fp32 tiles"], out["split fp16"]
     print(f"after one update: max |W_split - W_fp32| {(w1 - w0).abs().max().item():.3e} (lr 1e-3), max |V_split - V_fp32| / max V {((v1 - v0).abs().max() / v0.abs().max()).item():.3e}")
 

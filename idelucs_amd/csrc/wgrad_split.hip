@@ -27,7 +27,8 @@
 // the loaders (32.7 / 38.5), the split in hand-picked instructions (80 instead of 130 a chunk: the same time).  LDS bank conflicts:
 // none (SQ_LDS_BANK_CONFLICT 0).  Stamps of a loader wave (IDELUCS_WGS_DBG=128, shader cycles a chunk): wait for its requests 239, split +
 // LDS stores issued 839-940, next requests + stores done 180, barrier 90 -- the phase that issues 80 vector instructions and twelve
-// 8-byte LDS stores takes 840 cycles whatever the vector instructions are.
+// 8-byte LDS stores takes 840 cycles whatever the vector instructions are (760 with six 16-byte stores: a lane's item is now a whole
+// 16-byte slot of a plane's row); the kernel's time did not follow -- workgroup 0's loader is not the slowest wave of the launch.
 //
 // Scales: x by 2^3 (a standardised feature is at most sqrt(N - 1) in size: 8 sqrt(N) < 65 504 up to N = 6.7e7); dy by 2^k with k from
 // the PREVIOUS launch's largest |dy| (2^k max ~ 2^12: 16 x headroom, values clamped at +-65 000), kept as tagged words (launch
@@ -47,6 +48,7 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4v __attribute__((__vector_size__(4 * sizeof(short))));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int TM = 64, TN = 128, KC = 32, STAGES = 3, NT = 512;       // 4 computing + 4 loader waves (8 loaders: 50.6 us against 39.0)
 constexpr int NL = NT - 256;                                 // loader threads
@@ -142,18 +144,19 @@ __global__ __launch_bounds__(NT, 1) void wgrad_split_kernel(SplitWgArgs a)
         // of a deposit whose own requests are 18 back -- every pass then paid a round trip; wgrad_device.h tells the same story).  The
         // loaders issue no other vector-memory instruction inside the loop, and the counter retires in order: a deposit of chunk d waits
         // for `6 x (chunks requested behind d)`.
-        uint32_t va[2], vb[4], la[2], lb[4];                 // global byte offsets inside a chunk; LDS byte offsets inside a stage's plane
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int j = lt + NL * u, row = j >> 4, c4 = j & 15;
-            va[u] = (uint32_t)((row * a.n_out + h0 + 4 * c4) * 4);
-            la[u] = (uint32_t)(row * ROWB + (((c4 >> 1) ^ swz(row)) << 4) + 8 * (c4 & 1));
+        // a lane's ITEM is a 16-byte slot of a plane's row = 8 consecutive values = two adjacent 16-byte requests: one of dy, two of x a chunk;
+        // the two planes of an item are ONE 16-byte LDS store each (8-byte stores: twelve a chunk instead of six)
+        uint32_t va[2], vb[4], la[1], lb[2];                 // global byte offsets inside a chunk; LDS byte offsets inside a stage's plane
+        {
+            const int row = lt >> 3, sl = lt & 7;
+            va[0] = (uint32_t)((row * a.n_out + h0 + 8 * sl) * 4); va[1] = va[0] + 16;
+            la[0] = (uint32_t)(row * ROWB + ((sl ^ swz(row)) << 4));
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int j = lt + NL * u, row = j >> 5, c4 = j & 31;
-            vb[u] = (uint32_t)((row * a.n_in + f0 + 4 * c4) * 4);
-            lb[u] = (uint32_t)(row * ROWB + (((c4 >> 1) ^ swz(row)) << 4) + 8 * (c4 & 1));
+        for (int u = 0; u < 2; ++u) {
+            const int j = lt + NL * u, row = j >> 4, sl = j & 15;
+            vb[2 * u] = (uint32_t)((row * a.n_in + f0 + 8 * sl) * 4); vb[2 * u + 1] = vb[2 * u] + 16;
+            lb[u] = (uint32_t)(row * ROWB + ((sl ^ swz(row)) << 4));
         }
         const int64_t ca = (int64_t)KC * a.n_out * 4, cb = (int64_t)KC * a.n_in * 4;             // a chunk's bytes of rows
         auto request = [&](int c, int slot) {
@@ -174,21 +177,22 @@ __global__ __launch_bounds__(NT, 1) void wgrad_split_kernel(SplitWgArgs a)
         };
         auto deposit = [&](int c, int slot) {
             const uint32_t st = (uint32_t)(uintptr_t)smem + (uint32_t)((c % STAGES) * STAGE);
+            {
+                uint2 a0, a1, b0, b1;
+                split4<true>(ra[slot][0], sc_dy, a0, a1);
+                split4<true>(ra[slot][1], sc_dy, b0, b1);
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                uint2 p0, p1;
-                split4<true>(ra[slot][u], sc_dy, p0, p1);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) mx = fmaxf(mx, fabsf(ra[slot][u][e]));
-                *(__attribute__((address_space(3))) u32x2 *)(uintptr_t)(st + la[u]) = u32x2{p0.x, p0.y};
-                *(__attribute__((address_space(3))) u32x2 *)(uintptr_t)(st + PLANE + la[u]) = u32x2{p1.x, p1.y};
+                for (int e = 0; e < 4; ++e) mx = fmaxf(mx, fmaxf(fabsf(ra[slot][0][e]), fabsf(ra[slot][1][e])));
+                *(__attribute__((address_space(3))) u32x4 *)(uintptr_t)(st + la[0]) = u32x4{a0.x, a0.y, b0.x, b0.y};
+                *(__attribute__((address_space(3))) u32x4 *)(uintptr_t)(st + PLANE + la[0]) = u32x4{a1.x, a1.y, b1.x, b1.y};
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                uint2 p0, p1;
-                split4<false>(rb[slot][u], sc_x, p0, p1);       // (|x| 2^3 < 65 504 for N < 6.7e7 sequences)
-                *(__attribute__((address_space(3))) u32x2 *)(uintptr_t)(st + 2 * PLANE + lb[u]) = u32x2{p0.x, p0.y};
-                *(__attribute__((address_space(3))) u32x2 *)(uintptr_t)(st + 3 * PLANE + lb[u]) = u32x2{p1.x, p1.y};
+            for (int u = 0; u < 2; ++u) {
+                uint2 a0, a1, b0, b1;
+                split4<false>(rb[slot][2 * u], sc_x, a0, a1);        // (|x| 2^3 < 65 504 for N < 6.7e7 sequences)
+                split4<false>(rb[slot][2 * u + 1], sc_x, b0, b1);
+                *(__attribute__((address_space(3))) u32x4 *)(uintptr_t)(st + 2 * PLANE + lb[u]) = u32x4{a0.x, a0.y, b0.x, b0.y};
+                *(__attribute__((address_space(3))) u32x4 *)(uintptr_t)(st + 3 * PLANE + lb[u]) = u32x4{a1.x, a1.y, b1.x, b1.y};
             }
         };
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the scale's words above: nothing else of this wave is in flight from here on)

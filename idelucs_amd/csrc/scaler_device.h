@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "planes.h"
+
 namespace idl_dev {
 
 // float32 in -> float32 out: both ops in float64, rounded to float32 after each (numpy in-place ufunc on a float32 array
@@ -32,6 +34,7 @@ struct GatherArgs {
     const double *mean, *scale, *inv_scale;
     float *y;
     int64_t base_add;           // added to *base (a launch that assembles the batch AFTER the one the offset points at)
+    uint16_t *yh, *yl;          // optional (gather_tile only): the batch ALSO as two fp16 planes [2 batch][f] (planes.h, scale 2^X_EXP)
 };
 
 // one workgroup copies + standardises one output row; rows [0, batch) are the "true" halves, [batch, 2*batch) the "modified" ones
@@ -141,6 +144,13 @@ __device__ __forceinline__ void gather_tile(const GatherArgs &g, int64_t blk, in
             o.z = std_f32(v.z, mu[2], sc[2]); o.w = std_f32(v.w, mu[3], sc[3]);
         }
         ((float4 *)(g.y + (rg * R + u) * g.f))[i] = o;
+        if (g.yh != nullptr) {
+            constexpr float ps = (float)(1 << idl_planes::X_EXP);
+            uint2 h, l;
+            (void)idl_planes::split4(o.x * ps, o.y * ps, o.z * ps, o.w * ps, h, l);
+            ((uint2 *)(g.yh + (rg * R + u) * g.f))[i] = h;
+            ((uint2 *)(g.yl + (rg * R + u) * g.f))[i] = l;
+        }
     }
 }
 

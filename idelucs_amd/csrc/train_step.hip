@@ -29,6 +29,7 @@
 #include "wave_ops.h"
 #include "wgrad_device.h"
 #include "l1_device.h"
+#include "l1_planes_device.h"
 #include "philox_device.h"
 
 namespace {
@@ -149,7 +150,9 @@ constexpr int MID_GATHER_ROWS = 4;   // rows per 256-thread gather tile when the
 
 // PRE: the layer-1 product came from idl_l1_fwd (l1_fwd.hip), whose epilogue already applied bias / ReLU / Dropout and formed
 // lat = r1 W2^T as 8 partial sums: `a1` then points at lat_part[8][m][64] and this kernel is the head only.
-template <bool TIN, bool PRE = false>       // TIN: a1 is stored transposed, [512, m] (the orientation hipBLASLt runs the layer-1 product fastest in)
+// KPARTS (with TIN): the layer-1 product came from idl_l1_planes* as KPARTS partial sums over K slices, a1 = part[KPARTS][512][m]: added up
+// here in ascending order (the same sum wherever it runs); r1 is written over part[0], which the backward then reads as the activations.
+template <bool TIN, bool PRE = false, int KPARTS = 1>       // TIN: a1 is stored transposed, [512, m] (the orientation hipBLASLt runs the layer-1 product fastest in)
 __device__ __forceinline__ void mid_fwd_body(float *__restrict__ a1, const float *__restrict__ b1, const float *__restrict__ W2,
                                                                   const float *__restrict__ b2, const float *__restrict__ W3,
                                                                   const float *__restrict__ b3, int m, int C, int train, uint64_t seed,
@@ -178,25 +181,39 @@ __device__ __forceinline__ void mid_fwd_body(float *__restrict__ a1, const float
     float4 av[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
     float4 bb[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
     float4 bw[4][2];
+    auto load_bw = [&]() {
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {             // lat[:, 16 ct .. 16 ct + 15]: B[k][c] = W2[16 ct + c][k]
+            const float4 *wsrc = (const float4 *)(W2 + (int64_t)(16 * ct + l) * H1 + k0);
+            bw[ct][0] = wsrc[0]; bw[ct][1] = wsrc[1];
+        }
+    };
+    // KPARTS > 1: a lane's 8 elements are KPARTS x 8 four-byte reads, and the launch has 128 registers a lane (1024-thread workgroups): the
+    // first trip brings slabs 0 .. KP1 with everything small, the second the rest of the slabs with the W2 fragments (32 registers)
+    constexpr int KP1 = KPARTS > 1 ? (KPARTS > 6 ? 5 : KPARTS - 1) : 0;
+    const int64_t slab = (int64_t)H1 * m;
+    float t8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, u8[KP1 > 0 ? KP1 : 1][8];
     float pre[8];                                // PRE: row r0 + wv's eight partial sums of lat, column `lane`
     if constexpr (PRE) {
 #pragma unroll
         for (int p = 0; p < 8; ++p) pre[p] = a1[((int64_t)p * m + r0 + wv) * H2 + lane];
     } else {
         if (TIN) {
-            float t8[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) t8[i] = srcT[(int64_t)i * m];
-            av[0] = make_float4(t8[0], t8[1], t8[2], t8[3]); av[1] = make_float4(t8[4], t8[5], t8[6], t8[7]);
+            if constexpr (KPARTS > 1) {
+#pragma unroll
+                for (int p = 0; p < KP1; ++p)
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) u8[p][i] = srcT[(1 + p) * slab + (int64_t)i * m];
+            } else {
+                av[0] = make_float4(t8[0], t8[1], t8[2], t8[3]); av[1] = make_float4(t8[4], t8[5], t8[6], t8[7]);
+            }
         } else {
             av[0] = src[0]; av[1] = src[1];
         }
         if (b1 != nullptr) { bb[0] = *(const float4 *)(b1 + k0); bb[1] = *(const float4 *)(b1 + k0 + 4); }
-#pragma unroll
-        for (int ct = 0; ct < 4; ++ct) {             // lat[:, 16 ct .. 16 ct + 15]: B[k][c] = W2[16 ct + c][k]
-            const float4 *wsrc = (const float4 *)(W2 + (int64_t)(16 * ct + l) * H1 + k0);
-            bw[ct][0] = wsrc[0]; bw[ct][1] = wsrc[1];
-        }
+        if constexpr (KPARTS == 1) load_bw();
     }
     const int nct = (C + 15) / 16;               // column tiles of the logits; wave wv < nct owns tile wv
     float4 w3f[4];                               // B[k = 16 q + s][c = l] = W3[16 wv + l][16 q + s]
@@ -210,6 +227,26 @@ __device__ __forceinline__ void mid_fwd_body(float *__restrict__ a1, const float
     }
     const float b2v = b2[lane];
     const uint32_t step = (uint32_t)ctl[0];
+    if constexpr (!PRE && TIN && KPARTS > 1) {   // the second trip (slabs in ascending order: the same sum wherever it runs)
+#pragma unroll
+        for (int p = 0; p < KP1; ++p)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) t8[i] += u8[p][i];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(t8[i]) : : "memory");      // (the requests below stay below)
+        constexpr int KP2 = KPARTS - 1 - KP1;
+        float v8[KP2 > 0 ? KP2 : 1][8];
+#pragma unroll
+        for (int p = 0; p < KP2; ++p)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v8[p][i] = srcT[(1 + KP1 + p) * slab + (int64_t)i * m];
+        load_bw();
+#pragma unroll
+        for (int p = 0; p < KP2; ++p)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) t8[i] += v8[p][i];
+        av[0] = make_float4(t8[0], t8[1], t8[2], t8[3]); av[1] = make_float4(t8[4], t8[5], t8[6], t8[7]);
+    }
     if constexpr (!PRE) {
     // ---- ReLU + Dropout of layer 1, in place
     float a[8];
@@ -325,7 +362,7 @@ struct MidFwdParams {
 };
 static_assert(sizeof(MidFwdParams) + idl::PLAN_PARAMS <= idl::PLAN_BYTES, "MidFwdParams does not fit a plan record");
 
-template <bool TIN, bool PRE = false>
+template <bool TIN, bool PRE = false, int KPARTS = 1>
 __global__ __launch_bounds__(64 * MID_WAVES) void mid_fwd_kernel(float *__restrict__ a1, const float *__restrict__ b1, const float *__restrict__ W2,
                                                                   const float *__restrict__ b2, const float *__restrict__ W3,
                                                                   const float *__restrict__ b3, int m, int C, int train, uint64_t seed,
@@ -333,7 +370,7 @@ __global__ __launch_bounds__(64 * MID_WAVES) void mid_fwd_kernel(float *__restri
                                                                   float *__restrict__ inv, float *__restrict__ r2, float *__restrict__ z,
                                                                   int n_rows_wg, int tile0, int tile1, idl_dev::GatherArgs gth)
 {
-    mid_fwd_body<TIN, PRE>(a1, b1, W2, b2, W3, b3, m, C, train, seed, ctl, f, inv, r2, z, n_rows_wg, tile0, tile1, gth, (int)blockIdx.x);
+    mid_fwd_body<TIN, PRE, KPARTS>(a1, b1, W2, b2, W3, b3, m, C, train, seed, ctl, f, inv, r2, z, n_rows_wg, tile0, tile1, gth, (int)blockIdx.x);
 }
 
 // the same for several voters in one launch: the grid is (voters, workgroups of one voter) -- the VOTER index runs fastest, so the
@@ -1136,6 +1173,47 @@ __global__ __launch_bounds__(l1_dev::THREADS, 4) void l1_rms_kernel(l1_dev::L1Ar
     rmsprop_body<false>(a, hyper, ctl, batch_advance, 0, 0, idl_dev::GatherArgs{}, (int)blockIdx.x - l.n_tiles);
 }
 
+// The same with the layer-1 tiles of l1_planes_device.h (the product on the fp16 matrix cores from two-plane operands).  A tile
+// workgroup fills its CU (96 KB of LDS, eight waves): the riders start as tiles leave and end the launch behind them.
+__global__ __launch_bounds__(l1p_dev::THREADS, 1) void l1p_rms_kernel(l1p_dev::L1pArgs l, RmsArgs a, const float *hyper, int64_t *ctl, int64_t batch_advance)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char l1p_rms_smem[];
+    if ((int)blockIdx.x < l.n_tiles) { l1p_dev::l1p_body(l, (int)blockIdx.x, l1p_rms_smem); return; }
+    if (threadIdx.x >= RMS_THREADS) return;                  // (before any barrier: rmsprop_body is written for 256 threads)
+    rmsprop_body<false>(a, hyper, ctl, batch_advance, 0, 0, idl_dev::GatherArgs{}, (int)blockIdx.x - l.n_tiles);
+}
+
+// The launch between the two-plane layer-1 tiles (idl_l1_planes) and mid_fwd: its first r.blocks workgroups add the KPARTS partial sums
+// part[p][i] in ascending p into part[0][i] (16-byte elements, all requests of a thread in flight before the first add) -- 16 MB read by
+// every CU at once instead of by mid_fwd's 64 workgroups -- and the workgroups behind them are the previous step's optimizer tail
+// (rmsprop_body), which nothing in this launch depends on: the two overlap.
+struct ReduceArgs { float4 *part; int64_t slab4; int n_parts, blocks; };      // slab4: 16-byte elements of a slab
+constexpr int RED_U = 2;
+__global__ __launch_bounds__(256) void reduce_rms_kernel(ReduceArgs r, RmsArgs a, const float *hyper, int64_t *ctl, int64_t batch_advance, int with_tail)
+{
+    if ((int)blockIdx.x < r.blocks) {
+        const int64_t i0 = (int64_t)blockIdx.x * (256 * RED_U) + threadIdx.x;
+        float4 v[RED_U][l1p_dev::KSPLIT];
+#pragma unroll
+        for (int u = 0; u < RED_U; ++u) {
+            const int64_t i = i0 + 256 * u < r.slab4 ? i0 + 256 * u : r.slab4 - 1;     // clamped, not predicated
+#pragma unroll
+            for (int p = 0; p < l1p_dev::KSPLIT; ++p) v[u][p] = r.part[(int64_t)p * r.slab4 + i];
+        }
+#pragma unroll
+        for (int u = 0; u < RED_U; ++u) {
+            float4 acc = v[u][0];
+#pragma unroll
+            for (int p = 1; p < l1p_dev::KSPLIT; ++p) { acc.x += v[u][p].x; acc.y += v[u][p].y; acc.z += v[u][p].z; acc.w += v[u][p].w; }
+            if (i0 + 256 * u < r.slab4) r.part[i0 + 256 * u] = acc;
+        }
+        return;
+    }
+    // (the look-ahead form of the dW2 tiles -- every operand of a wave requested before its first product: one trip to memory instead of
+    //  three -- as behind the dW1 tiles of wgrad_rmsprop_kernel: here too the tail's chain is the launch's length, 9.3 us without)
+    if (with_tail) rmsprop_body<true>(a, hyper, ctl, batch_advance, 0, 0, idl_dev::GatherArgs{}, (int)blockIdx.x - r.blocks);
+}
+
 // several voters in one launch: voter blockIdx.y takes its arguments from its plan record
 __global__ __launch_bounds__(256) void rmsprop_batched_kernel(const unsigned char *__restrict__ plans)
 {
@@ -1198,29 +1276,33 @@ int idl_mid_fwd(float *a1, const float *W2, const float *b2, const float *W3, co
     return IDL_OK;
 }
 
-int idl_mid_fwd_gather(float *a1, const float *b1, int a1_transposed, const float *W2, const float *b2, const float *W3, const float *b3, int m,
+static int mid_fwd_gather_impl(float *a1, const float *b1, int a1_transposed, const float *W2, const float *b2, const float *W3, const float *b3, int m,
                        int C, int train, uint64_t seed, const int64_t *ctl, float *f, float *inv, float *r2, float *z,
                        const float *feats, int64_t n, int64_t fdim, int64_t view_stride, const int64_t *pair_idx, const int64_t *base,
                        int64_t base_add, int64_t n_pairs, int64_t batch, const double *mean, const double *scale,
-                       const double *inv_scale, float *y, int part, int part_end, int parts, void *stream)
+                       const double *inv_scale, float *y, int part, int part_end, int parts, void *stream, uint16_t *yh, uint16_t *yl)
 {
     IDL_REQUIRE(a1 && W2 && b2 && W3 && b3 && ctl && f && inv && r2 && z, "NULL buffer");
     IDL_REQUIRE(m >= 16 && (m % 16) == 0 && C >= 1 && C <= 64 * MAX_CPL, "mid_fwd: m must be a multiple of 16, n_clusters in 1..256");
     IDL_REQUIRE((((uintptr_t)a1 | (uintptr_t)W2 | (uintptr_t)W3) & 15u) == 0, "a1 / W2 / W3 must be 16-byte aligned");
     IDL_REQUIRE(parts >= 1 && part >= 0 && part <= part_end && part_end <= parts, "mid_fwd_gather: need 0 <= part <= part_end <= parts");
     IDL_REQUIRE(b1 == nullptr || (((uintptr_t)b1) & 15u) == 0, "mid_fwd_gather: b1 must be 16-byte aligned");
-    IDL_REQUIRE(a1_transposed >= 0 && a1_transposed <= 2 && (a1_transposed != 2 || b1 == nullptr), "mid_fwd_gather: a1_transposed is 0, 1 or 2 (2: a1 = idl_l1_fwd's lat partials, no b1)");
+    IDL_REQUIRE(a1_transposed >= 0 && a1_transposed <= 3 && (a1_transposed != 2 || b1 == nullptr),
+                "mid_fwd_gather: a1_transposed is 0, 1, 2 (a1 = idl_l1_fwd's lat partials, no b1) or 3 (a1 = idl_l1_planes' K-slice partial sums [8][512][m])");
+    IDL_REQUIRE((yh != nullptr) == (yl != nullptr) && (yh == nullptr || (feats != nullptr && ((((uintptr_t)yh) | ((uintptr_t)yl)) & 7u) == 0)),
+                "mid_fwd_gather: both planes of the next batch (8-byte aligned) or neither; planes need the batch assembly");
     idl_dev::GatherArgs g{};
     int64_t t0 = 0, t1 = 0;
     if (feats != nullptr) {                  // (feats == NULL: no batch assembly in this launch)
         IDL_REQUIRE(pair_idx && mean && scale && y && n >= 1 && fdim >= 4 && (fdim & 3) == 0 && batch >= 1 && n_pairs >= 0,
                     "mid_fwd_gather: bad gather arguments (4 | f)");
-        g = idl_dev::GatherArgs{feats, n, fdim, view_stride, pair_idx, base, batch, n_pairs, mean, scale, inv_scale, y, base_add};
+        g = idl_dev::GatherArgs{feats, n, fdim, view_stride, pair_idx, base, batch, n_pairs, mean, scale, inv_scale, y, base_add, yh, yl};
         const int64_t ng = idl_dev::gather_tiles<MID_GATHER_ROWS>(fdim, batch);
         t0 = ng * part / parts; t1 = ng * part_end / parts;
     }
     const dim3 grid((unsigned)(m / 16 + (t1 - t0 + 3) / 4));
     if (void *plan = idl::take_plan()) {          // recorded, not launched (idl_plan_begin)
+        IDL_REQUIRE(a1_transposed != 3, "mid_fwd_gather: the partial-sum form cannot be recorded");
         idl::PlanHead h{};
         h.kind = idl::PLAN_MID_FWD; h.variant = a1_transposed; /* 0 row-major, 1 transposed, 2 lat partials (head only) */ h.grid[0] = grid.x; h.grid[1] = 1; h.grid[2] = 1; h.block = 64 * MID_WAVES;
         memcpy(plan, &h, sizeof(h));
@@ -1228,7 +1310,9 @@ int idl_mid_fwd_gather(float *a1, const float *b1, int a1_transposed, const floa
         memcpy((unsigned char *)plan + idl::PLAN_PARAMS, &p, sizeof(p));
         return IDL_OK;
     }
-    if (a1_transposed == 2) hipLaunchKernelGGL((mid_fwd_kernel<false, true>), grid, dim3(64 * MID_WAVES), 0, (hipStream_t)stream, a1, b1, W2, b2, W3, b3,
+    if (a1_transposed == 3) hipLaunchKernelGGL((mid_fwd_kernel<true, false, l1p_dev::KSPLIT>), grid, dim3(64 * MID_WAVES), 0, (hipStream_t)stream, a1, b1, W2, b2, W3, b3,
+                                               m, C, train, seed, ctl, f, inv, r2, z, m / 16, (int)t0, (int)t1, g);
+    else if (a1_transposed == 2) hipLaunchKernelGGL((mid_fwd_kernel<false, true>), grid, dim3(64 * MID_WAVES), 0, (hipStream_t)stream, a1, b1, W2, b2, W3, b3,
                                                m, C, train, seed, ctl, f, inv, r2, z, m / 16, (int)t0, (int)t1, g);
     else if (a1_transposed) hipLaunchKernelGGL(mid_fwd_kernel<true>, grid, dim3(64 * MID_WAVES), 0, (hipStream_t)stream, a1, b1, W2, b2, W3, b3,
                                           m, C, train, seed, ctl, f, inv, r2, z, m / 16, (int)t0, (int)t1, g);
@@ -1236,6 +1320,27 @@ int idl_mid_fwd_gather(float *a1, const float *b1, int a1_transposed, const floa
                             m, C, train, seed, ctl, f, inv, r2, z, m / 16, (int)t0, (int)t1, g);
     IDL_HIP_TRY(hipGetLastError());
     return IDL_OK;
+}
+
+int idl_mid_fwd_gather(float *a1, const float *b1, int a1_transposed, const float *W2, const float *b2, const float *W3, const float *b3, int m,
+                       int C, int train, uint64_t seed, const int64_t *ctl, float *f, float *inv, float *r2, float *z,
+                       const float *feats, int64_t n, int64_t fdim, int64_t view_stride, const int64_t *pair_idx, const int64_t *base,
+                       int64_t base_add, int64_t n_pairs, int64_t batch, const double *mean, const double *scale,
+                       const double *inv_scale, float *y, int part, int part_end, int parts, void *stream)
+{
+    return mid_fwd_gather_impl(a1, b1, a1_transposed, W2, b2, W3, b3, m, C, train, seed, ctl, f, inv, r2, z, feats, n, fdim, view_stride, pair_idx, base,
+                               base_add, n_pairs, batch, mean, scale, inv_scale, y, part, part_end, parts, stream, nullptr, nullptr);
+}
+
+// ... the same launch with the next batch ALSO written as two fp16 planes (planes.h) by the assembling workgroups
+int idl_mid_fwd_gather_planes(float *a1, const float *b1, int a1_transposed, const float *W2, const float *b2, const float *W3, const float *b3, int m,
+                              int C, int train, uint64_t seed, const int64_t *ctl, float *f, float *inv, float *r2, float *z,
+                              const float *feats, int64_t n, int64_t fdim, int64_t view_stride, const int64_t *pair_idx, const int64_t *base,
+                              int64_t base_add, int64_t n_pairs, int64_t batch, const double *mean, const double *scale,
+                              const double *inv_scale, float *y, void *y_hi, void *y_lo, int part, int part_end, int parts, void *stream)
+{
+    return mid_fwd_gather_impl(a1, b1, a1_transposed, W2, b2, W3, b3, m, C, train, seed, ctl, f, inv, r2, z, feats, n, fdim, view_stride, pair_idx, base,
+                               base_add, n_pairs, batch, mean, scale, inv_scale, y, part, part_end, parts, stream, (uint16_t *)y_hi, (uint16_t *)y_lo);
 }
 
 int idl_nce_rows(float *S, int m, float temperature, float *lse, float *loss_rows, void *stream)
@@ -1365,13 +1470,16 @@ int idl_nce_mid_bwd_gather(const float *z, const float *r2, const float *f, cons
     return IDL_OK;
 }
 
-int idl_mid_bwd_gather(const float *z, const float *r2, const float *f, const float *inv, const float *G, int g_parts, const float *dP0,
+static int mid_bwd_gather_impl(const float *z, const float *r2, const float *f, const float *inv, const float *G, int g_parts, const float *dP0,
                        const float *W3, const float *W2, const float *act1, int m, int C, int train, float nce_coef, float *dlogits,
                        float *dlat, float *dr1, float *partial1, float *partial2, float *partial3, float *dW3_partial,
                        const float *feats, int64_t n, int64_t fdim, int64_t view_stride, const int64_t *pair_idx, const int64_t *base,
                        int64_t base_add, int64_t n_pairs, int64_t batch, const double *mean, const double *scale,
-                       const double *inv_scale, float *y, int part, int part_end, int parts, int act1_transposed, void *stream)
+                       const double *inv_scale, float *y, int part, int part_end, int parts, int act1_transposed, void *stream,
+                       uint16_t *yh, uint16_t *yl)
 {
+    IDL_REQUIRE((yh != nullptr) == (yl != nullptr) && (yh == nullptr || (feats != nullptr && ((((uintptr_t)yh) | ((uintptr_t)yl)) & 7u) == 0)),
+                "mid_bwd_gather: both planes of the next batch (8-byte aligned) or neither; planes need the batch assembly");
     IDL_REQUIRE(parts >= 1 && part >= 0 && part <= part_end && part_end <= parts, "mid_bwd_gather: need 0 <= part <= part_end <= parts");
     IDL_REQUIRE(g_parts >= 1 && g_parts <= 16, "mid_bwd: g_parts outside 1..16");
     IDL_REQUIRE(z && r2 && f && inv && G && dP0 && W3 && W2 && act1 && dlogits && dlat && dr1 && partial1 && partial2 && partial3, "NULL buffer");
@@ -1387,7 +1495,7 @@ int idl_mid_bwd_gather(const float *z, const float *r2, const float *f, const fl
     if (feats != nullptr) {                  // (feats == NULL: no batch assembly in this launch)
         IDL_REQUIRE(pair_idx && mean && scale && y && n >= 1 && fdim >= 4 && (fdim & 3) == 0 && batch >= 1 && n_pairs >= 0,
                     "mid_bwd_gather: bad gather arguments (4 | f)");
-        g = idl_dev::GatherArgs{feats, n, fdim, view_stride, pair_idx, base, batch, n_pairs, mean, scale, inv_scale, y, base_add};
+        g = idl_dev::GatherArgs{feats, n, fdim, view_stride, pair_idx, base, batch, n_pairs, mean, scale, inv_scale, y, base_add, yh, yl};
         const int64_t ng = idl_dev::gather_tiles<MID_GATHER_ROWS>(fdim, batch);
         t0 = ng * part / parts; t1 = ng * part_end / parts;
     }
@@ -1406,6 +1514,32 @@ int idl_mid_bwd_gather(const float *z, const float *r2, const float *f, const fl
                             (int)t1, g);
     IDL_HIP_TRY(hipGetLastError());
     return IDL_OK;
+}
+
+int idl_mid_bwd_gather(const float *z, const float *r2, const float *f, const float *inv, const float *G, int g_parts, const float *dP0,
+                       const float *W3, const float *W2, const float *act1, int m, int C, int train, float nce_coef, float *dlogits,
+                       float *dlat, float *dr1, float *partial1, float *partial2, float *partial3, float *dW3_partial,
+                       const float *feats, int64_t n, int64_t fdim, int64_t view_stride, const int64_t *pair_idx, const int64_t *base,
+                       int64_t base_add, int64_t n_pairs, int64_t batch, const double *mean, const double *scale,
+                       const double *inv_scale, float *y, int part, int part_end, int parts, int act1_transposed, void *stream)
+{
+    return mid_bwd_gather_impl(z, r2, f, inv, G, g_parts, dP0, W3, W2, act1, m, C, train, nce_coef, dlogits, dlat, dr1, partial1, partial2, partial3,
+                               dW3_partial, feats, n, fdim, view_stride, pair_idx, base, base_add, n_pairs, batch, mean, scale, inv_scale, y, part,
+                               part_end, parts, act1_transposed, stream, nullptr, nullptr);
+}
+
+// ... the same launch with the next batch ALSO written as two fp16 planes (planes.h) by the assembling workgroups
+int idl_mid_bwd_gather_planes(const float *z, const float *r2, const float *f, const float *inv, const float *G, int g_parts, const float *dP0,
+                              const float *W3, const float *W2, const float *act1, int m, int C, int train, float nce_coef, float *dlogits,
+                              float *dlat, float *dr1, float *partial1, float *partial2, float *partial3, float *dW3_partial,
+                              const float *feats, int64_t n, int64_t fdim, int64_t view_stride, const int64_t *pair_idx, const int64_t *base,
+                              int64_t base_add, int64_t n_pairs, int64_t batch, const double *mean, const double *scale,
+                              const double *inv_scale, float *y, void *y_hi, void *y_lo, int part, int part_end, int parts, int act1_transposed,
+                              void *stream)
+{
+    return mid_bwd_gather_impl(z, r2, f, inv, G, g_parts, dP0, W3, W2, act1, m, C, train, nce_coef, dlogits, dlat, dr1, partial1, partial2, partial3,
+                               dW3_partial, feats, n, fdim, view_stride, pair_idx, base, base_add, n_pairs, batch, mean, scale, inv_scale, y, part,
+                               part_end, parts, act1_transposed, stream, (uint16_t *)y_hi, (uint16_t *)y_lo);
 }
 
 int idl_col_sum_parts(void) { return COL_PARTS; }
@@ -1480,7 +1614,8 @@ static int rmsprop_launch(int count, float *const *params, const float *const *g
                           const float *loss_rows, int loss_m, float w_nce, float w_iic, float *out, const idl_dev::GatherArgs &g,
                           void *stream, int wg_index = -1, const float *wg_dy = nullptr, const float *wg_x = nullptr, int wg_m = 0,
                           int wg_n_out = 0, int wg_n_in = 0, float *wg_grad = nullptr, int wg_x_transposed = 0,
-                          const wg_dev::WgArgs *big = nullptr, int big_index = -1, const l1_dev::L1Args *l1 = nullptr, int skip_index = -1)
+                          const wg_dev::WgArgs *big = nullptr, int big_index = -1, const l1_dev::L1Args *l1 = nullptr, int skip_index = -1,
+                          const l1p_dev::L1pArgs *l1p = nullptr, const ReduceArgs *red = nullptr)
 {
     IDL_REQUIRE(count >= 1 && count <= 8 && params && grads && square_avg && sizes && hyper && ctl, "rmsprop_step: 1..8 tensors");
     RmsArgs a{};
@@ -1524,6 +1659,27 @@ static int rmsprop_launch(int count, float *const *params, const float *const *g
     if (nb_total == 0) nb_total = 1;        // (step counter / loss assembly still need a block)
     for (int i = count; i <= 8; ++i) a.first[i] = nb_total;
     const int64_t extra = g.y != nullptr ? idl_dev::gather_blocks(g.f, g.batch) : 0;
+    if (red != nullptr) {                   // ... beside the workgroups that add up the two-plane layer-1 tiles' partial sums (reduce_rms_kernel)
+        IDL_REQUIRE(big == nullptr && l1 == nullptr && l1p == nullptr && extra == 0 && idl::take_plan() == nullptr, "reduce_parts_rms: no tiles, no batch assembly, not recordable");
+        hipLaunchKernelGGL(reduce_rms_kernel, dim3((unsigned)(red->blocks + nb_total + a.wg_tiles)), dim3(256), 0, (hipStream_t)stream, *red, a, hyper, ctl,
+                           batch_advance, 1);
+        IDL_HIP_TRY(hipGetLastError());
+        return IDL_OK;
+    }
+    if (l1p != nullptr) {                   // ... behind the layer-1 tiles in their two-plane form (l1p_rms_kernel)
+        IDL_REQUIRE(big == nullptr && l1 == nullptr && extra == 0 && idl::take_plan() == nullptr, "l1_planes_rms: no dW1 tiles, no batch assembly, not recordable");
+        static bool attr_set[64] = {};
+        int dev = 0;
+        IDL_HIP_TRY(hipGetDevice(&dev));
+        if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+            IDL_HIP_TRY(hipFuncSetAttribute((const void *)l1p_rms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, l1p_dev::LDS_BYTES));
+            attr_set[dev] = true;
+        }
+        hipLaunchKernelGGL(l1p_rms_kernel, dim3((unsigned)(l1p->n_tiles + nb_total + a.wg_tiles)), dim3(l1p_dev::THREADS), l1p_dev::LDS_BYTES,
+                           (hipStream_t)stream, *l1p, a, hyper, ctl, batch_advance);
+        IDL_HIP_TRY(hipGetLastError());
+        return IDL_OK;
+    }
     if (l1 != nullptr) {                    // the optimizer blocks ride behind the layer-1 forward tiles of the next step (l1_rms_kernel)
         IDL_REQUIRE(big == nullptr && extra == 0 && idl::take_plan() == nullptr, "l1_fwd_rms: no dW1 tiles, no batch assembly, not recordable");
         static bool attr_set[64] = {};
@@ -1657,6 +1813,45 @@ int idl_l1_fwd_rms(const float *W1, const float *x, int m, int n_in, float *r1_t
     idl_dev::GatherArgs g{};
     return rmsprop_launch(count, params, grads, grad_parts, square_avg, sizes, hyper, ctl, batch_advance, loss_rows, loss_m, w_nce, w_iic, out, g,
                           stream, wg_index, wg_dy, wg_x, wg_m, wg_n_out, wg_n_in, wg_grad, wg_x_transposed, nullptr, -1, &l, w1_index);
+}
+
+// the layer-1 tiles from two-plane operands (idl_l1_planes) with the previous step's optimizer tail behind them; part: [8][n_hidden][m]
+int idl_l1_planes_rms(const void *w_hi, const void *w_lo, const void *x_hi, const void *x_lo, int m, int n_in, float *part,
+                      int count, float *const *params, const float *const *grads, const int32_t *grad_parts,
+                      float *const *square_avg, const int64_t *sizes, const float *hyper, int64_t *ctl,
+                      const float *loss_rows, int loss_m, float w_nce, float w_iic, float *out, int w1_index,
+                      int wg_index, const float *wg_dy, const float *wg_x, int wg_x_transposed, int wg_m, int wg_n_out, int wg_n_in,
+                      float *wg_grad, int64_t batch_advance, void *stream)
+{
+    IDL_REQUIRE(w_hi && w_lo && x_hi && x_lo && part && l1p_dev::supported(m, H1, n_in), "l1_planes_rms: Linear(n_in, 512), m % 128 == 0, n_in % 512 == 0, n_in >= 1024");
+    IDL_REQUIRE(((((uintptr_t)w_hi) | ((uintptr_t)w_lo) | ((uintptr_t)x_hi) | ((uintptr_t)x_lo) | ((uintptr_t)part)) & 15u) == 0, "l1_planes_rms: buffers must be 16-byte aligned");
+    const l1p_dev::L1pArgs l{(const uint16_t *)w_hi, (const uint16_t *)w_lo, (const uint16_t *)x_hi, (const uint16_t *)x_lo, part, m, H1, n_in,
+                             (H1 / l1p_dev::TM) * (m / l1p_dev::TN) * l1p_dev::KSPLIT, n_in, n_in, 0};
+    idl_dev::GatherArgs g{};
+    return rmsprop_launch(count, params, grads, grad_parts, square_avg, sizes, hyper, ctl, batch_advance, loss_rows, loss_m, w_nce, w_iic, out, g,
+                          stream, wg_index, wg_dy, wg_x, wg_m, wg_n_out, wg_n_in, wg_grad, wg_x_transposed, nullptr, -1, nullptr, w1_index, &l);
+}
+
+// part[p][i], p < idl_l1_planes_parts(), i < slab_elems (4 | slab_elems): part[0][i] = ((part[0][i] + part[1][i]) + ...) in ascending p.
+// With count >= 1: the previous step's optimizer tail in the same launch (arguments as idl_l1_fwd_rms); count == 0: the sums alone.
+int idl_reduce_parts_rms(float *part, int64_t slab_elems,
+                         int count, float *const *params, const float *const *grads, const int32_t *grad_parts,
+                         float *const *square_avg, const int64_t *sizes, const float *hyper, int64_t *ctl,
+                         const float *loss_rows, int loss_m, float w_nce, float w_iic, float *out, int w1_index,
+                         int wg_index, const float *wg_dy, const float *wg_x, int wg_x_transposed, int wg_m, int wg_n_out, int wg_n_in,
+                         float *wg_grad, int64_t batch_advance, void *stream)
+{
+    IDL_REQUIRE(part && slab_elems >= 4 && (slab_elems & 3) == 0 && (((uintptr_t)part) & 15u) == 0 && slab_elems < (1ll << 31), "reduce_parts_rms: 4 | slab_elems, 16-byte aligned");
+    ReduceArgs r{(float4 *)part, slab_elems / 4, l1p_dev::KSPLIT, (int)((slab_elems / 4 + 256 * RED_U - 1) / (256 * RED_U))};
+    if (count == 0) {
+        hipLaunchKernelGGL(reduce_rms_kernel, dim3((unsigned)r.blocks), dim3(256), 0, (hipStream_t)stream, r, RmsArgs{}, (const float *)nullptr, (int64_t *)nullptr,
+                           (int64_t)0, 0);
+        IDL_HIP_TRY(hipGetLastError());
+        return IDL_OK;
+    }
+    idl_dev::GatherArgs g{};
+    return rmsprop_launch(count, params, grads, grad_parts, square_avg, sizes, hyper, ctl, batch_advance, loss_rows, loss_m, w_nce, w_iic, out, g,
+                          stream, wg_index, wg_dy, wg_x, wg_m, wg_n_out, wg_n_in, wg_grad, wg_x_transposed, nullptr, -1, nullptr, w1_index, nullptr, &r);
 }
 
 int idl_debug_phase_stamps(int on)

@@ -50,8 +50,8 @@ int idl_wgrad_supported(int m, int n_out, int n_in)
     return wg_dev::supported(m, n_out, n_in) ? 1 : 0;
 }
 
-int idl_wgrad_rmsprop(const float *dy, const float *x, int m, int n_out, int n_in, float *grad, float *W, float *square_avg,
-                      const float *hyper, void *stream)
+static int wgrad_launch(const float *dy, const float *x, int m, int n_out, int n_in, float *grad, float *W, float *square_avg,
+                        const float *hyper, void *stream, uint16_t *w_hi, uint16_t *w_lo, int *over)
 {
     IDL_REQUIRE(dy && x && idl_wgrad_supported(m, n_out, n_in), "wgrad: m % 32 == 0, n_out % 64 == 0, n_in % 128 == 0");
     IDL_REQUIRE((W != nullptr) == (square_avg != nullptr) && (W != nullptr || grad != nullptr), "wgrad: give W and square_avg (fused update) and/or grad");
@@ -59,7 +59,7 @@ int idl_wgrad_rmsprop(const float *dy, const float *x, int m, int n_out, int n_i
     IDL_REQUIRE((((uintptr_t)dy | (uintptr_t)x | (uintptr_t)grad | (uintptr_t)W | (uintptr_t)square_avg) & 15u) == 0, "wgrad: buffers must be 16-byte aligned");
     IDL_REQUIRE((int64_t)m * n_in < (1ll << 29) && (int64_t)n_out * n_in < (1ll << 29), "wgrad: operands beyond 2^31 bytes");
     wg_dev::WgArgs a{};
-    a.p = wg_dev::WgProblem{dy, x, grad, W, square_avg, n_out, n_in};
+    a.p = wg_dev::WgProblem{dy, x, grad, W, square_avg, n_out, n_in, w_hi, w_lo, over};
     a.hyper = hyper; a.m = m;
     a.tiles_m = n_out / wg_dev::TM;
     a.tiles = a.tiles_m * (n_in / wg_dev::TN);
@@ -70,6 +70,20 @@ int idl_wgrad_rmsprop(const float *dy, const float *x, int m, int n_out, int n_i
     else hipLaunchKernelGGL((wgrad_q16_kernel<0>), grid, block, wg_dev::IMG_BYTES, (hipStream_t)stream, a);
     IDL_HIP_TRY(hipGetLastError());
     return IDL_OK;
+}
+
+int idl_wgrad_rmsprop(const float *dy, const float *x, int m, int n_out, int n_in, float *grad, float *W, float *square_avg,
+                      const float *hyper, void *stream)
+{
+    return wgrad_launch(dy, x, m, n_out, n_in, grad, W, square_avg, hyper, stream, nullptr, nullptr, nullptr);
+}
+
+// ... the updated W also written as two fp16 planes (planes.h: what idl_l1_planes reads); *overflow_flag is set to 1 if an entry left their range
+int idl_wgrad_rmsprop_planes(const float *dy, const float *x, int m, int n_out, int n_in, float *grad, float *W, float *square_avg,
+                             const float *hyper, void *w_hi, void *w_lo, int *overflow_flag, void *stream)
+{
+    IDL_REQUIRE(W && w_hi && w_lo && overflow_flag && ((((uintptr_t)w_hi) | ((uintptr_t)w_lo)) & 7u) == 0, "wgrad_rmsprop_planes: W, both planes (8-byte aligned) and the flag");
+    return wgrad_launch(dy, x, m, n_out, n_in, grad, W, square_avg, hyper, stream, (uint16_t *)w_hi, (uint16_t *)w_lo, overflow_flag);
 }
 
 int idl_debug_wgrad_clock(const float *dy, const float *x, int m, int n_out, int n_in, float *grad, int variant, uint64_t *stamps, void *stream)

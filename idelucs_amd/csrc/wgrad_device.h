@@ -31,6 +31,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "planes.h"
 #include "wgrad_loop.inc"
 
 namespace wg_dev {
@@ -45,6 +46,8 @@ struct WgProblem {
     float *grad;              // [n_out, n_in] or NULL
     float *W, *V;             // parameter and square_avg, or NULL (then grad must be given)
     int n_out, n_in;
+    uint16_t *Wh, *Wl;        // optional: the updated W ALSO as two fp16 planes (planes.h, scale 2^W_EXP) for the next layer-1 product
+    int *over;                // ... and the flag raised when an entry left the planes' range
 };
 
 struct WgArgs {
@@ -151,6 +154,12 @@ __device__ __forceinline__ void q16_tile(const WgArgs &a, const int bid, f32x4_t
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { float pe = p[e], ve = v[e]; rms_update(g[e], pe, ve, hy); p[e] = pe; v[e] = ve; }
                 *(f32x4_t *)(a.p.V + o) = v; *(f32x4_t *)(a.p.W + o) = p;
+                if (a.p.Wh != nullptr) {
+                    constexpr float ps = (float)(1 << idl_planes::W_EXP);
+                    uint2 h, l2;
+                    if (idl_planes::split4(p[0] * ps, p[1] * ps, p[2] * ps, p[3] * ps, h, l2)) *a.p.over = 1;
+                    *(uint2 *)(a.p.Wh + o) = h; *(uint2 *)(a.p.Wl + o) = l2;
+                }
             }
         }
 }

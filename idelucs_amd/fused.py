@@ -90,6 +90,18 @@ def _r1_of(bf, xi):
     return bf._r1_other
 
 
+def _planes_of(bf, F):
+    """Buffers of the two-plane step form (FusedLinearTrainer._planes), made on first use: the two batches' fp16 planes and the
+    two images of idl_l1_planes' K-slice partial sums [8][H1][m] (slab 0 of an image becomes the step's transposed activations)."""
+    if getattr(bf, "_planes", None) is None:
+        m, H2, dev = bf._dims
+        h16 = dict(dtype=torch.int16, device=dev)
+        bf._planes = {"xh": [torch.empty((m, F), **h16) for _ in range(2)], "xl": [torch.empty((m, F), **h16) for _ in range(2)],
+                      "part": [torch.empty((int(_L.idl_l1_planes_parts()), bf._H1, m), dtype=torch.float32, device=dev) for _ in range(2)],
+                      "valid": [False, False]}          # valid[i]: xh[i] / xl[i] hold the planes of the batch in bf.xs[i]
+    return bf._planes
+
+
 def _lat_part_of(bf):
     """idl_l1_fwd's partial sums of r1 W2^T per 64-unit tile of the hidden layer (the opt-in IDELUCS_L1_FUSED=1 path only)."""
     if bf._lat_part is None:
@@ -150,6 +162,13 @@ class FusedLinearTrainer:
         self._side = torch.cuda.Stream(device=self.dev)     # second branch of the step (see step_on_batch)
         self._split16 = os.environ.get("IDELUCS_SPLIT16", "0") == "1"
         self._split_state = None
+        # IDELUCS_PLANES=1 (round 5, csrc/planes.h): the layer-1 product on the fp16 matrix cores from operands kept as two fp16 planes -- the
+        # batch's planes written by the workgroups that assemble it, W1's by the epilogue of the dW1 tiles that update it
+        self._planes = os.environ.get("IDELUCS_PLANES", "0") == "1"
+        self._planes_reduce_launch = os.environ.get("IDELUCS_PLANES_REDUCE", "launch") != "mid"
+        self._planes_fork = os.environ.get("IDELUCS_PLANES_FORK", "0") == "1"
+        self._w1_planes = None                   # (W1 hi, W1 lo, overflow flag)
+        self._w1_planes_fresh = False
         # the layers between the two big GEMMs as one 1024-thread MFMA kernel per direction (idl_mid_fwd / idl_mid_bwd)
         self._mid_fused = self.H1 == 512 and os.environ.get("IDELUCS_MID_FUSED", "1") != "0"
         self._pipeline = os.environ.get("IDELUCS_PIPELINE", "1") != "0"   # optimizer launch also assembles the next batch
@@ -263,7 +282,17 @@ class FusedLinearTrainer:
               and bool(_L.idl_l1_fwd_supported(m, self.H1, self.F)) and bool(_L.idl_wgrad_supported(m, self.H1, self.F)))
         if not tm:
             self.flush_tail()                   # (a step of another form: whatever is pending goes first)
-        r1 = _r1_of(bf, xi) if tm else bf.r1
+        # ... with the layer-1 product from two-plane operands (IDELUCS_PLANES=1)
+        pl = (tm and self._planes and bool(_L.idl_l1_planes_supported(m, self.H1, self.F)) and next_from.n < 60_000_000)
+        pb = _planes_of(bf, self.F) if pl else None
+        if pl:
+            r1 = pb["part"][xi][0]              # [H1, m]: slab 0 of the partial sums, where mid_fwd leaves the activations
+            self._prepare_planes(bf, pb, xi)
+        else:
+            r1 = _r1_of(bf, xi) if tm else bf.r1
+            self._w1_planes_fresh = False       # (this step updates W1 without its planes)
+            if getattr(bf, "_planes", None) is not None:
+                bf._planes["valid"][1 - xi] = False      # (... and assembles the next batch without its planes)
         r1T = r1.view(self.H1, m)
         chk = _lib.check
         main = torch.cuda.current_stream()
@@ -273,10 +302,36 @@ class FusedLinearTrainer:
         # shares (eighths) of the next batch's assembly: [0, g1) riders of the layer-1 launch, [g1, g2) the mid-forward launch, [g2, 8) mid-backward
         g1 = self._l1_gather if l1 else 0
         g2 = max(g1, self._gsplit)
-        if tm:      # a1^T = W1 x^T on own tiles; the previous step's optimizer tail rides in the same launch
+        if pl and self._planes_reduce_launch:
+            # a1^T = W1 x^T as eight K-slice partial sums on the fp16 matrix cores (the tiles alone: five chunks resident, the whole LDS);
+            # then ONE launch that adds the eight up on every CU and, beside that, runs the previous step's optimizer tail
+            wh, wl, _ = self._w1_planes
+            fork = self._planes_fork and self._pending is not None
+            if fork:        # the tail as a launch of its own on a second stream, beside the tiles (nothing it touches is read before mid_fwd)
+                self._side.wait_stream(main)
+                with torch.cuda.stream(self._side):
+                    pbf, pxi, pr1 = self._pending
+                    self._tail_launch(pbf, pxi, pr1)
+            chk(_L.idl_l1_planes(_p(wh), _p(wl), self.F, _p(pb["xh"][xi]), _p(pb["xl"][xi]), self.F, m, self.H1, self.F, _p(pb["part"][xi]), _stream()))
             if self._pending is not None:
-                pbf, pxi = self._pending
-                self._tail_launch(pbf, pxi, l1=(x, m, r1T))
+                pbf, pxi, pr1 = self._pending
+                self._tail_launch(pbf, pxi, pr1, red=(pb["part"][xi], self.H1 * m))
+            else:
+                chk(_L.idl_reduce_parts_rms(_p(pb["part"][xi]), self.H1 * m, 0, None, None, None, None, None, None, None, None, 0, 0.0, 0.0, None, 0,
+                                            -1, None, None, 0, 0, 0, 0, None, 0, _stream()))
+            if fork:
+                main.wait_stream(self._side)
+        elif pl:    # ... or the tiles with the tail riding behind them, and mid_fwd adding the eight (IDELUCS_PLANES_REDUCE=mid)
+            wh, wl, _ = self._w1_planes
+            if self._pending is not None:
+                pbf, pxi, pr1 = self._pending
+                self._tail_launch(pbf, pxi, pr1, l1p=(wh, wl, pb["xh"][xi], pb["xl"][xi], m, pb["part"][xi]))
+            else:
+                chk(_L.idl_l1_planes(_p(wh), _p(wl), self.F, _p(pb["xh"][xi]), _p(pb["xl"][xi]), self.F, m, self.H1, self.F, _p(pb["part"][xi]), _stream()))
+        elif tm:    # a1^T = W1 x^T on own tiles; the previous step's optimizer tail rides in the same launch
+            if self._pending is not None:
+                pbf, pxi, pr1 = self._pending
+                self._tail_launch(pbf, pxi, pr1, l1=(x, m, r1T))
             else:
                 chk(_L.idl_l1_fwd(_p(self.W1), _p(x), None, None, m, self.F, 0, 0, None, _p(r1T), 1, None, _stream()))
         elif l1:    # own tiles: r1^T = Dropout(ReLU(W1 x^T + b1)) and the partial sums of lat = r1 W2^T straight from the accumulators
@@ -291,7 +346,14 @@ class FusedLinearTrainer:
             self._mm(self.W1, x.t(), r1T)
         else:
             torch.addmm(self.b1, x, self.W1.t(), out=r1)
-        if early and self._early_split:         # ... and the first half of the next batch's tiles in its spare workgroups
+        if pl:      # mid_fwd adds the eight partial sums; its spare workgroups assemble the first half of the next batch AND its planes
+            st = next_from
+            chk(_L.idl_mid_fwd_gather_planes(_p(pb["part"][xi]), _p(self.b1), 1 if self._planes_reduce_launch else 3, _p(self.W2), _p(self.b2), _p(self.W3), _p(self.b3),
+                                             m, C, tr, self.seed, _p(self.ctl), _p(bf.f), _p(bf.inv), _p(bf.r2), _p(bf.z),
+                                             _p(st.feats), st.n, st.f, st.n * st.f, _p(self._perm), _p(self.ctl[1:]), m // 2, st.n_pairs, m // 2,
+                                             _p(st.mean), _p(st.scale), _p(st.inv_scale), _p(bf.xs[1 - xi]), _p(pb["xh"][1 - xi]), _p(pb["xl"][1 - xi]),
+                                             g1, g2, 8, _stream()))
+        elif early and self._early_split:         # ... and the first half of the next batch's tiles in its spare workgroups
             st = next_from
             self._k(_L.idl_mid_fwd_gather, _p(_lat_part_of(bf)) if l1 else _p(r1), _p(self.b1) if (tl and not l1) else None,
                     2 if l1 else (1 if tl else 0), _p(self.W2), _p(self.b2), _p(self.W3), _p(self.b3),
@@ -356,6 +418,17 @@ class FusedLinearTrainer:
                 torch.mm(bf.dlogits.t(), bf.r2, out=gW3)
             if not self._dw2_inlaunch:
                 torch.mm(bf.dlat.t(), r1, out=gW2)
+        elif pl:
+            st = next_from
+            chk(_L.idl_mid_bwd_gather_planes(_p(bf.z), _p(bf.r2), _p(bf.f), _p(bf.inv), _p(bf.G), bf.G.shape[0], _p(bf.P0), _p(self.W3), _p(self.W2),
+                                             _p(r1), m, C, tr, nce_coef, _p(bf.dlogits), _p(bf.dlat), _p(bf.dr1), _p(gb1), _p(gb2), _p(gb3),
+                                             _p(gW3) if self._dw3_partial else None,
+                                             _p(st.feats), st.n, st.f, st.n * st.f, _p(self._perm), _p(self.ctl[1:]), m // 2, st.n_pairs, m // 2,
+                                             _p(st.mean), _p(st.scale), _p(st.inv_scale), _p(bf.xs[1 - xi]), _p(pb["xh"][1 - xi]), _p(pb["xl"][1 - xi]),
+                                             g2, 8, 8, 1, _stream()))
+            pb["valid"][1 - xi] = True
+            if not self._dw3_partial:
+                torch.mm(bf.dlogits.t(), bf.r2, out=gW3)
         elif early:
             st = next_from
             self._k(_L.idl_mid_bwd_gather, _p(bf.z), _p(bf.r2), _p(bf.f), _p(bf.inv), _p(bf.G), bf.G.shape[0], _p(bf.P0), _p(self.W3), _p(self.W2),
@@ -397,7 +470,11 @@ class FusedLinearTrainer:
                                   m, tr, adv_ctl, adv, _p(bf.r2) if self._dw3_partial else None,
                                   _p(gW3) if self._dw3_partial else None, _stream()))
         if tm:      # the dW1 tiles end the step; everything else of the optimizer rides in the next step's layer-1 launch
-            if self._split16 and m % 128 == 0 and m >= 256:
+            if pl:      # ... and write the updated W1's planes for the next layer-1 product
+                wh, wl, flag = self._w1_planes
+                chk(_L.idl_wgrad_rmsprop_planes(_p(bf.dr1), _p(x), m, self.H1, self.F, _p(gW1) if self._keep_w1_grad else None, _p(self.W1),
+                                                _p(self.square_avg[0]), _p(self.hyper), _p(wh), _p(wl), _p(flag), _stream()))
+            elif self._split16 and m % 128 == 0 and m >= 256:
                 # EXPERIMENTAL (IDELUCS_SPLIT16=1; csrc/wgrad_split.hip): the product on the fp16 matrix cores from operands split inside the kernel
                 if self._split_state is None:
                     self._split_state = torch.zeros(int(_L.idl_wgrad_split_state_words()), dtype=torch.int64, device=self.dev)
@@ -406,7 +483,7 @@ class FusedLinearTrainer:
             else:
                 chk(_L.idl_wgrad_rmsprop(_p(bf.dr1), _p(x), m, self.H1, self.F, _p(gW1) if self._keep_w1_grad else None, _p(self.W1),
                                          _p(self.square_avg[0]), _p(self.hyper), _stream()))
-            self._pending = (bf, xi)
+            self._pending = (bf, xi, r1)
             if not defer_tail:
                 self.flush_tail()
             return
@@ -454,15 +531,21 @@ class FusedLinearTrainer:
                                     _p(self.ctl), batch_advance, _p(bf.loss_rows), m, 1.0 - self.weight, self.weight, _p(self.out),
                                     _stream()))
 
-    def _tail_launch(self, bf, xi, l1=None):
-        """The optimizer's tail of the step that ran on (bf, xi): dW2 tiles + RMSprop on every tensor but W1 + step loss + step
-        counter -- behind the layer-1 tiles of the next step (l1 = (x, m, r1T) of THAT step), or as a launch of its own."""
+    def _tail_launch(self, bf, xi, r1, l1=None, l1p=None, red=None):
+        """The optimizer's tail of the step that ran on (bf, xi) with the activations r1: dW2 tiles + RMSprop on every tensor but W1 + step
+        loss + step counter -- behind the layer-1 tiles of the next step (l1 = (x, m, r1T) of THAT step; l1p = its two-plane form's
+        (W1 hi, W1 lo, x hi, x lo, m, partial sums)), or as a launch of its own."""
         m = bf.m
-        r1 = _r1_of(bf, xi)
         tail = (len(self.params), self._pp, self._gp, self._parts, self._vp, self._sz, _p(self.hyper),
                 _p(self.ctl), _p(bf.loss_rows), m, 1.0 - self.weight, self.weight, _p(self.out))
         wg = (2, _p(bf.dlat), _p(r1), 1, m, self.H2, self.H1, _p(self.grads[2]), m // 2, _stream())
-        if l1 is not None:
+        if red is not None:       # beside the workgroups that add up the next step's layer-1 partial sums (red = (part, elements of a slab))
+            part, slab = red
+            _lib.check(_L.idl_reduce_parts_rms(_p(part), slab, *tail, 0, *wg))
+        elif l1p is not None:
+            wh, wl, xh, xl, m1, part = l1p
+            _lib.check(_L.idl_l1_planes_rms(_p(wh), _p(wl), _p(xh), _p(xl), m1, self.F, _p(part), *tail, 0, *wg))
+        elif l1 is not None:
             x, m1, r1T = l1
             _lib.check(_L.idl_l1_fwd_rms(_p(self.W1), _p(x), m1, self.F, _p(r1T), *tail, 0, *wg))
         else:       # (sizes without W1: the tiles' own launch updated it)
@@ -474,13 +557,35 @@ class FusedLinearTrainer:
         """Run the pending optimizer tail now (end of an epoch, before a step of another form, before anybody looks at the small
         tensors); a no-op when nothing is pending."""
         if self._pending is not None:
-            bf, xi = self._pending
-            self._tail_launch(bf, xi)
+            bf, xi, r1 = self._pending
+            self._tail_launch(bf, xi, r1)
+
+    def _prepare_planes(self, bf, pb, xi):
+        """Before a step of the two-plane form: W1's planes (made once; afterwards the dW1 tiles' epilogue keeps them) and the planes of the
+        batch in bf.xs[xi] unless the step that assembled it wrote them."""
+        if self._w1_planes is None:
+            self._w1_planes = (torch.empty(self.W1.shape, dtype=torch.int16, device=self.dev), torch.empty(self.W1.shape, dtype=torch.int16, device=self.dev),
+                               torch.zeros(1, dtype=torch.int32, device=self.dev))
+        if not self._w1_planes_fresh:
+            wh, wl, flag = self._w1_planes
+            _lib.check(_L.idl_split_planes(_p(self.W1), self.W1.numel(), int(_L.idl_planes_exponent(1)), _p(wh), _p(wl), _p(flag), _stream()))
+            self._w1_planes_fresh = True
+        if not pb["valid"][xi]:
+            x = bf.xs[xi]
+            _lib.check(_L.idl_split_planes(_p(x), x.numel(), int(_L.idl_planes_exponent(0)), _p(pb["xh"][xi]), _p(pb["xl"][xi]), None, _stream()))
+            pb["valid"][xi] = True
+
+    def planes_overflowed(self):
+        """Whether an entry of W1 ever left its planes' range (|w| >= 15.8; waits for the device).  Such an entry was clamped in the
+        layer-1 product: the run should be repeated with IDELUCS_PLANES=0."""
+        return self._w1_planes is not None and bool(self._w1_planes[2].item())
 
     def _gather(self, store, bf):
         b = bf.m // 2
         _lib.check(_L.idl_gather_pairs_at(_p(store.feats), store.n, store.f, store.n * store.f, _p(self._perm), _p(self.ctl[1:]),
                                           b, _p(store.mean), _p(store.scale), _p(store.inv_scale), _p(bf.x), _stream()))
+        if getattr(bf, "_planes", None) is not None:
+            bf._planes["valid"][0] = False
 
     def _full_step(self, store, bf, train=True, pipelined=False, xi=0, defer_tail=False):
         """pipelined: bf.xs[xi] already holds this batch (assembled by the previous step, or by the prologue gather);
@@ -505,6 +610,7 @@ class FusedLinearTrainer:
         # (the permutation on a stream of its own beside the vectoriser was measured: the epoch 67.2-67.4 ms against 64.8-65.0 on the
         #  main stream, T_e2e 76.8-79.2 against 76.1-76.3 -- the step graphs wait for the other stream's event)
         torch.randperm(n_pairs, device=self.dev, generator=generator, out=self._perm)
+        self._w1_planes_fresh = False           # (whoever set the weights since the last epoch -- a voter's initialisation -- did not write planes)
         self.ctl[1:2].zero_()
         self.out[1:2].zero_()
         n_full, rem = divmod(n_pairs, batch_sz)
@@ -513,6 +619,8 @@ class FusedLinearTrainer:
             bf = self.buffers(2 * batch_sz)
             if pipe:
                 self._gather(store, bf)         # prologue: batch 0; every later batch is assembled by the previous step
+                if (self._planes and self._tail_l1 and bool(_L.idl_l1_planes_supported(bf.m, self.H1, self.F))):
+                    self._prepare_planes(bf, _planes_of(bf, self.F), 0)      # (a replayed graph starts from valid planes)
             # steps per graph replay: an even number when two x buffers alternate.  Between two replays the GPU idles ~9 us
             # (profiles/r02_f: kernel trace), so a replay carries several steps
             per = self._steps_per_graph if pipe else 1

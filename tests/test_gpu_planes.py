@@ -1,0 +1,248 @@
+"""The two-fp16-plane form of the training step's layer-1 product (csrc/planes.h, csrc/l1_planes_device.h; IDELUCS_PLANES=1) against
+float64 products, against the fp32 tiles it replaces, and against the default step.  Reference: Linear(F,512) of idelucs/PytorchUtils.py:38-45
+inside the step of idelucs/models.py:117-133."""
+import copy
+import ctypes
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    import torch
+    from idelucs_amd import _lib
+    _lib.require_gpu()
+    return torch.device("cuda:0")
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream():
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _split(v, which):
+    """idl_split_planes of tensor v with the fixed exponent of its kind -> (hi, lo int16 tensors, exponent, flag)."""
+    import torch
+    from idelucs_amd import _lib
+    L = _lib.lib
+    k = int(L.idl_planes_exponent(which))
+    hi = torch.empty(v.shape, dtype=torch.int16, device=v.device)
+    lo = torch.empty_like(hi)
+    flag = torch.zeros(1, dtype=torch.int32, device=v.device)
+    _lib.check(L.idl_split_planes(_p(v), v.numel(), k, _p(hi), _p(lo), _p(flag), _stream()))
+    return hi, lo, k, flag
+
+
+def test_planes_carry_22_bits_and_flag_what_leaves_their_range(dev):
+    import torch
+    g = torch.Generator(device="cpu"); g.manual_seed(3)
+    v = (torch.randn(512, 4096, generator=g) * torch.logspace(-6, 1.5, 4096)).to(dev)      # 1e-6 .. 30 in size
+    hi, lo, k, flag = _split(v, 0)
+    back = (hi.view(torch.float16).double() + lo.view(torch.float16).double()) * 2.0 ** -k
+    err = (back - v.double()).abs()
+    # 22 significand bits where the low plane is a normal fp16 number, fp16's subnormal spacing (2^-24) / 2^k below that
+    assert bool((err <= torch.maximum(v.double().abs() * 2.0 ** -21, torch.tensor(2.0 ** (-25 - k), device=dev, dtype=torch.float64))).all())
+    assert flag.item() == 0
+    w = torch.full((8,), 1.0, device=dev); w[3] = 17.0                       # 17 * 2^12 > 65 000
+    hi, lo, k, flag = _split(w, 1)
+    assert flag.item() == 1
+    back = (hi.view(torch.float16).float() + lo.view(torch.float16).float()) * 2.0 ** -k
+    assert back[0].item() == 1.0 and abs(back[3].item() - 65000.0 / 4096) < 1e-3
+
+
+@pytest.mark.parametrize("m,F", [(1024, 4096), (256, 1024), (128, 2048), (384, 1536)])
+def test_layer1_product_from_planes_is_closer_to_float64_than_the_fp32_gemm(dev, m, F):
+    """idl_l1_planes: the eight K-slice partial sums add up to W1 x^T within 5e-7 of its largest entry -- and no further from the float64
+    product than torch's fp32 GEMM."""
+    import torch
+    from idelucs_amd import _lib
+    L = _lib.lib
+    g = torch.Generator(device="cpu"); g.manual_seed(m + F)
+    H = 512
+    W = ((torch.rand(H, F, generator=g) * 2 - 1) / F ** 0.5).to(dev)
+    x = torch.randn(m, F, generator=g).to(dev)
+    x[5, 7] = 300.0                                                            # an outlier of a standardised feature
+    assert L.idl_l1_planes_supported(m, H, F) == 1 and L.idl_l1_planes_supported(m + 64, H, F) == 0 and L.idl_l1_planes_supported(m, H, 768) == 0
+    wh, wl, kw, _ = _split(W, 1)
+    xh, xl, kx, _ = _split(x, 0)
+    P = int(L.idl_l1_planes_parts())
+    part = torch.full((P, H, m), float("nan"), device=dev)
+    _lib.check(L.idl_l1_planes(_p(wh), _p(wl), F, _p(xh), _p(xl), F, m, H, F, _p(part), _stream()))
+    torch.cuda.synchronize()
+    got = part.double().sum(0)
+    ref = W.double() @ x.double().t()
+    scale = ref.abs().max().item()
+    err = (got - ref).abs().max().item() / scale
+    e_lib = ((W @ x.t()).double() - ref).abs().max().item() / scale
+    assert err < 5e-7 and err <= e_lib, (err, e_lib)
+    assert L.idl_l1_planes(_p(wh), _p(wl), F, _p(xh), _p(xl), F, m + 1, H, F, _p(part), _stream()) != 0
+
+
+@pytest.mark.parametrize("m,C,train", [(1024, 20, 1), (128, 5, 0)])
+def test_mid_forward_adds_the_partial_sums_in_order(dev, m, C, train):
+    """idl_mid_fwd_gather with a1_transposed = 3 on part[8][512][m] gives bit for bit what a1_transposed = 1 gives on the slabs added in
+    ascending order, and leaves the same activations in slab 0."""
+    import torch
+    from idelucs_amd import _lib
+    L = _lib.lib
+    g = torch.Generator(device="cpu"); g.manual_seed(9)
+    H1, H2 = 512, 64
+    part = (torch.randn(8, H1, m, generator=g) * 0.3).to(dev)
+    summed = part[0].clone()
+    for p in range(1, 8):
+        summed += part[p]
+    b1 = (torch.randn(H1, generator=g) * 0.1).to(dev)
+    W2 = (torch.randn(H2, H1, generator=g) / H1 ** 0.5).to(dev); b2 = (torch.randn(H2, generator=g) * 0.1).to(dev)
+    W3 = (torch.randn(C, H2, generator=g) / 8).to(dev); b3 = (torch.randn(C, generator=g) * 0.1).to(dev)
+    ctl = torch.tensor([7, 0], dtype=torch.int64, device=dev)
+    outs = []
+    for variant, buf in ((1, summed), (3, part)):
+        f = torch.empty(m, H2, device=dev); inv = torch.empty(m, device=dev); r2 = torch.empty(m, H2, device=dev); z = torch.empty(m, C, device=dev)
+        _lib.check(L.idl_mid_fwd_gather(_p(buf), _p(b1), variant, _p(W2), _p(b2), _p(W3), _p(b3), m, C, train, ctypes.c_uint64(11), _p(ctl),
+                                        _p(f), _p(inv), _p(r2), _p(z), None, 0, 0, 0, None, None, 0, 0, 0, None, None, None, None, 0, 0, 1, _stream()))
+        torch.cuda.synchronize()
+        outs.append((f, inv, r2, z, buf[0].clone() if variant == 3 else buf.clone()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    # the launch that adds the slabs up on every CU (idl_reduce_parts_rms without a tail): the same sums in slab 0, the other slabs untouched
+    part2 = (torch.randn(8, H1, m, generator=g) * 0.3).to(dev)
+    want = part2[0].clone()
+    for p in range(1, 8):
+        want += part2[p]
+    keep = part2[1:].clone()
+    _lib.check(L.idl_reduce_parts_rms(_p(part2), H1 * m, 0, None, None, None, None, None, None, None, None, 0, 0.0, 0.0, None, 0,
+                                      -1, None, None, 0, 0, 0, 0, None, 0, _stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(part2[0], want) and torch.equal(part2[1:], keep)
+
+
+def test_producers_write_the_planes_of_what_they_write(dev):
+    """The dW1 tiles' epilogue (idl_wgrad_rmsprop_planes) leaves W1 exactly as idl_wgrad_rmsprop does, with planes that are idl_split_planes of
+    it; the batch-assembling workgroups of idl_mid_*_gather_planes leave the batch idl_gather_pairs_at assembles, with its planes."""
+    import torch
+    from idelucs_amd import _lib
+    L = _lib.lib
+    g = torch.Generator(device="cpu"); g.manual_seed(21)
+    m, H, F = 256, 512, 1024
+    dy = (torch.randn(m, H, generator=g) * 1e-3).to(dev); x = torch.randn(m, F, generator=g).to(dev)
+    W0 = ((torch.rand(H, F, generator=g) * 2 - 1) / F ** 0.5).to(dev); V0 = (torch.rand(H, F, generator=g) * 1e-6).to(dev)
+    hyper = torch.tensor([1e-3, 0.99, 1e-8, 0.01, 0.01], device=dev)
+    Wa, Va, Wb, Vb = W0.clone(), V0.clone(), W0.clone(), V0.clone()
+    wh = torch.empty(H, F, dtype=torch.int16, device=dev); wl = torch.empty_like(wh); flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    _lib.check(L.idl_wgrad_rmsprop(_p(dy), _p(x), m, H, F, None, _p(Wa), _p(Va), _p(hyper), _stream()))
+    _lib.check(L.idl_wgrad_rmsprop_planes(_p(dy), _p(x), m, H, F, None, _p(Wb), _p(Vb), _p(hyper), _p(wh), _p(wl), _p(flag), _stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(Wa, Wb) and torch.equal(Va, Vb) and not torch.equal(Wa, W0) and flag.item() == 0
+    hi, lo, _, _ = _split(Wb, 1)
+    assert torch.equal(hi, wh) and torch.equal(lo, wl)
+    assert L.idl_wgrad_rmsprop_planes(_p(dy), _p(x), m, H, F, None, _p(Wb), _p(Vb), _p(hyper), None, _p(wl), _p(flag), _stream()) != 0
+    # ---- the batch assembly
+    n, B, C, H2 = 700, 128, 5, 64
+    feats = torch.randn(3, n, F, generator=g).to(dev)                          # the true view + two mimics
+    mean = torch.randn(F, generator=g, dtype=torch.float64).to(dev); scale = (torch.rand(F, generator=g, dtype=torch.float64) + 0.5).to(dev)
+    inv_scale = 1.0 / scale
+    perm = torch.randperm(2 * n, generator=g).to(dev)
+    base = torch.tensor([64], dtype=torch.int64, device=dev)
+    want = torch.empty(2 * B, F, device=dev)
+    _lib.check(L.idl_gather_pairs_at(_p(feats), n, F, n * F, _p(perm), _p(base), B, _p(mean), _p(scale), _p(inv_scale), _p(want), _stream()))
+    mm = 2 * B
+    y = torch.zeros(mm, F, device=dev); yh = torch.zeros(mm, F, dtype=torch.int16, device=dev); yl = torch.zeros_like(yh)
+    a1 = torch.randn(8, 512, mm, generator=g).to(dev) * 0.1
+    b1 = torch.zeros(512, device=dev)
+    W2 = (torch.randn(H2, 512, generator=g) / 23).to(dev); b2 = torch.zeros(H2, device=dev)
+    W3 = (torch.randn(C, H2, generator=g) / 8).to(dev); b3 = torch.zeros(C, device=dev)
+    ctl = torch.zeros(2, dtype=torch.int64, device=dev)
+    f = torch.empty(mm, H2, device=dev); inv = torch.empty(mm, device=dev); r2 = torch.empty(mm, H2, device=dev); z = torch.empty(mm, C, device=dev)
+    _lib.check(L.idl_mid_fwd_gather_planes(_p(a1), _p(b1), 3, _p(W2), _p(b2), _p(W3), _p(b3), mm, C, 1, ctypes.c_uint64(3), _p(ctl), _p(f), _p(inv), _p(r2), _p(z),
+                                           _p(feats), n, F, n * F, _p(perm), _p(base), 0, 2 * n, B, _p(mean), _p(scale), _p(inv_scale),
+                                           _p(y), _p(yh), _p(yl), 0, 3, 8, _stream()))
+    G = torch.randn(1, mm, H2, generator=g).to(dev) * 1e-2; dP0 = torch.randn(C, C, generator=g).to(dev) * 1e-2
+    dlg = torch.empty(mm, C, device=dev); dlat = torch.empty(mm, H2, device=dev); dr1 = torch.empty(mm, 512, device=dev)
+    parts = int(L.idl_col_sum_parts())
+    p1 = torch.empty(parts, 512, device=dev); p2 = torch.empty(parts, H2, device=dev); p3 = torch.empty(parts, C, device=dev); pw3 = torch.empty(parts, C, H2, device=dev)
+    _lib.check(L.idl_mid_bwd_gather_planes(_p(z), _p(r2), _p(f), _p(inv), _p(G), 1, _p(dP0), _p(W3), _p(W2), _p(a1), mm, C, 1, 1e-3, _p(dlg), _p(dlat),
+                                           _p(dr1), _p(p1), _p(p2), _p(p3), _p(pw3),
+                                           _p(feats), n, F, n * F, _p(perm), _p(base), 0, 2 * n, B, _p(mean), _p(scale), _p(inv_scale),
+                                           _p(y), _p(yh), _p(yl), 3, 8, 8, 1, _stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(y, want)
+    hi, lo, _, _ = _split(y, 0)
+    assert torch.equal(hi, yh) and torch.equal(lo, yl)
+
+
+def _store_and_net(dev, n, seed=3, C=20):
+    import test_gpu_encoder as E
+    return E._cfg2_store_and_net(dev, n, seed=seed, C=C)
+
+
+@pytest.mark.parametrize("reduce", ["launch", "mid"])
+def test_step_on_planes_trains_like_the_default_step(dev, monkeypatch, reduce):
+    """IDELUCS_PLANES=1: the default launch sequence with the layer-1 product from two-plane operands.  (1) One step from the same state on the
+    same batch: the loss within 2e-6, dr1 and dW1 within 2e-5 of their largest entries but for the few elements whose ReLU flips (a
+    pre-activation within a rounding of zero).  (2) Two epochs (graph replay, dropout on): the loss sums follow the default step's within
+    2e-4 relative; W1's planes are idl_split_planes of W1 at the end; nothing left the planes' range."""
+    import torch
+    from idelucs_amd.fused import FusedLinearTrainer
+    store, net0 = _store_and_net(dev, 4096, seed=6, C=20)
+    B = 512
+    one, sums = {}, {}
+    monkeypatch.setenv("IDELUCS_PLANES_REDUCE", reduce)
+    for flag in ("0", "1"):
+        monkeypatch.setenv("IDELUCS_PLANES", flag)
+        tr = FusedLinearTrainer(copy.deepcopy(net0), lr=1e-3, weight=0.25, lamb=2.8, seed=5)
+        assert tr._planes == (flag == "1")
+        tr._keep_w1_grad = True
+        tr._perm = torch.randperm(store.n_pairs, device=dev, generator=torch.Generator(device=dev).manual_seed(1))
+        bf = tr.buffers(2 * B)
+        tr._gather(store, bf)
+        tr._full_step(store, bf, pipelined=True)
+        torch.cuda.synchronize()
+        one[flag] = (tr.out[0].item(), bf.dr1.clone(), tr.grads[0].clone(), tr.W1.detach().clone())
+        tr = FusedLinearTrainer(copy.deepcopy(net0), lr=1e-3, weight=0.25, lamb=2.8, seed=5)
+        gen = torch.Generator(device=dev); gen.manual_seed(123)
+        s = []
+        for _ in range(2):
+            total, nb = tr.run_epoch(store, B, use_graph=True, generator=gen)
+            s.append(total.item())
+        sums[flag] = s
+        if flag == "1":
+            assert tr._w1_planes is not None and not tr.planes_overflowed()
+            assert getattr(tr, "n_captures", 0) == 1
+    (l0, d0, g0, w0), (l1, d1, g1, w1) = one["0"], one["1"]
+    assert abs(l1 - l0) <= 2e-6 * abs(l0), (l0, l1)
+    off = ((d1 - d0).abs() > 2e-5 * d0.abs().max()).sum().item()
+    assert off <= 64, off                                                     # (of 524 288)
+    assert ((g1 - g0).abs().max() / g0.abs().max()).item() < 1e-3 and ((g1 - g0).abs().mean() / g0.abs().max()).item() < 2e-6
+    for a_, b_ in zip(sums["0"], sums["1"]):
+        assert np.isfinite(b_) and abs(b_ - a_) <= 2e-4 * abs(a_), (sums,)
+
+
+def test_planes_follow_the_weights_through_an_epoch(dev, monkeypatch):
+    """After an epoch of the two-plane form (replayed graphs + eager steps + the partial last batch on the fp32 path) and into the next one,
+    W1's planes at the point the next layer-1 product reads them are idl_split_planes of W1."""
+    import torch
+    from idelucs_amd.fused import FusedLinearTrainer
+    monkeypatch.setenv("IDELUCS_PLANES", "1")
+    store, net0 = _store_and_net(dev, 4200, seed=4, C=20)                      # 12 600 pairs: 24 full batches of 512 + a partial one
+    tr = FusedLinearTrainer(copy.deepcopy(net0), lr=1e-3, weight=0.25, lamb=2.8, seed=2)
+    gen = torch.Generator(device=dev); gen.manual_seed(5)
+    tr.run_epoch(store, 512, use_graph=True, generator=gen)
+    assert not tr._w1_planes_fresh                                            # (the partial batch updated W1 on the fp32 path)
+    tr.run_epoch(store, 512, use_graph=True, generator=gen)
+    bf = tr.buffers(1024)
+    tr.ctl[1:2].zero_()                                                       # (the batch offset stands at the end of the pair list)
+    tr._gather(store, bf)
+    tr._prepare_planes(bf, bf._planes, 0)
+    torch.cuda.synchronize()
+    wh, wl, flag = tr._w1_planes
+    hi, lo, _, _ = _split(tr.W1.detach(), 1)
+    assert torch.equal(hi, wh) and torch.equal(lo, wl) and flag.item() == 0
+    xh, xl, _, _ = _split(bf.xs[0], 0)
+    assert torch.equal(xh, bf._planes["xh"][0]) and torch.equal(xl, bf._planes["xl"][0])

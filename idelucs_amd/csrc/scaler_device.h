@@ -143,7 +143,7 @@ __device__ __forceinline__ void gather_tile(const GatherArgs &g, int64_t blk, in
             o.x = std_f32(v.x, mu[0], sc[0]); o.y = std_f32(v.y, mu[1], sc[1]);
             o.z = std_f32(v.z, mu[2], sc[2]); o.w = std_f32(v.w, mu[3], sc[3]);
         }
-        ((float4 *)(g.y + (rg * R + u) * g.f))[i] = o;
+        if (g.y != nullptr) ((float4 *)(g.y + (rg * R + u) * g.f))[i] = o;      // (NULL with planes: every consumer of the batch reads the planes)
         if (g.yh != nullptr) {
             constexpr float ps = (float)(1 << idl_planes::X_EXP);
             uint2 h, l;

@@ -1294,7 +1294,7 @@ static int mid_fwd_gather_impl(float *a1, const float *b1, int a1_transposed, co
     idl_dev::GatherArgs g{};
     int64_t t0 = 0, t1 = 0;
     if (feats != nullptr) {                  // (feats == NULL: no batch assembly in this launch)
-        IDL_REQUIRE(pair_idx && mean && scale && y && n >= 1 && fdim >= 4 && (fdim & 3) == 0 && batch >= 1 && n_pairs >= 0,
+        IDL_REQUIRE(pair_idx && mean && scale && (y || yh) && n >= 1 && fdim >= 4 && (fdim & 3) == 0 && batch >= 1 && n_pairs >= 0,
                     "mid_fwd_gather: bad gather arguments (4 | f)");
         g = idl_dev::GatherArgs{feats, n, fdim, view_stride, pair_idx, base, batch, n_pairs, mean, scale, inv_scale, y, base_add, yh, yl};
         const int64_t ng = idl_dev::gather_tiles<MID_GATHER_ROWS>(fdim, batch);
@@ -1493,7 +1493,7 @@ static int mid_bwd_gather_impl(const float *z, const float *r2, const float *f, 
     idl_dev::GatherArgs g{};
     int64_t t0 = 0, t1 = 0;
     if (feats != nullptr) {                  // (feats == NULL: no batch assembly in this launch)
-        IDL_REQUIRE(pair_idx && mean && scale && y && n >= 1 && fdim >= 4 && (fdim & 3) == 0 && batch >= 1 && n_pairs >= 0,
+        IDL_REQUIRE(pair_idx && mean && scale && (y || yh) && n >= 1 && fdim >= 4 && (fdim & 3) == 0 && batch >= 1 && n_pairs >= 0,
                     "mid_bwd_gather: bad gather arguments (4 | f)");
         g = idl_dev::GatherArgs{feats, n, fdim, view_stride, pair_idx, base, batch, n_pairs, mean, scale, inv_scale, y, base_add, yh, yl};
         const int64_t ng = idl_dev::gather_tiles<MID_GATHER_ROWS>(fdim, batch);

@@ -98,7 +98,8 @@ def _planes_of(bf, F):
         h16 = dict(dtype=torch.int16, device=dev)
         bf._planes = {"xh": [torch.empty((m, F), **h16) for _ in range(2)], "xl": [torch.empty((m, F), **h16) for _ in range(2)],
                       "part": [torch.empty((int(_L.idl_l1_planes_parts()), bf._H1, m), dtype=torch.float32, device=dev) for _ in range(2)],
-                      "valid": [False, False]}          # valid[i]: xh[i] / xl[i] hold the planes of the batch in bf.xs[i]
+                      "valid": [False, False],          # valid[i]: xh[i] / xl[i] hold the planes of the batch in bf.xs[i]
+                      "x32": [True, True]}              # x32[i]: bf.xs[i] itself holds that batch (False: it was assembled as planes only)
     return bf._planes
 
 
@@ -167,6 +168,8 @@ class FusedLinearTrainer:
         self._planes = os.environ.get("IDELUCS_PLANES", "0") == "1"
         self._planes_reduce_launch = os.environ.get("IDELUCS_PLANES_REDUCE", "launch") != "mid"
         self._planes_fork = os.environ.get("IDELUCS_PLANES_FORK", "0") == "1"
+        # ... and dW1 from the batch's planes too (csrc/wgrad_planes.hip); the assembling workgroups then write the planes ONLY
+        self._planes_wgrad = os.environ.get("IDELUCS_PLANES_WGRAD", "1") != "0"
         self._w1_planes = None                   # (W1 hi, W1 lo, overflow flag)
         self._w1_planes_fresh = False
         # the layers between the two big GEMMs as one 1024-thread MFMA kernel per direction (idl_mid_fwd / idl_mid_bwd)
@@ -284,7 +287,10 @@ class FusedLinearTrainer:
             self.flush_tail()                   # (a step of another form: whatever is pending goes first)
         # ... with the layer-1 product from two-plane operands (IDELUCS_PLANES=1)
         pl = (tm and self._planes and bool(_L.idl_l1_planes_supported(m, self.H1, self.F)) and next_from.n < 60_000_000)
+        plw = pl and self._planes_wgrad and bool(_L.idl_wgrad_xplanes_supported(m, self.H1, self.F))
         pb = _planes_of(bf, self.F) if pl else None
+        if not plw and getattr(bf, "_planes", None) is not None and not bf._planes["x32"][xi]:
+            raise RuntimeError("the batch in this buffer was assembled as planes only: a step of another form cannot read it")
         if pl:
             r1 = pb["part"][xi][0]              # [H1, m]: slab 0 of the partial sums, where mid_fwd leaves the activations
             self._prepare_planes(bf, pb, xi)
@@ -351,8 +357,8 @@ class FusedLinearTrainer:
             chk(_L.idl_mid_fwd_gather_planes(_p(pb["part"][xi]), _p(self.b1), 1 if self._planes_reduce_launch else 3, _p(self.W2), _p(self.b2), _p(self.W3), _p(self.b3),
                                              m, C, tr, self.seed, _p(self.ctl), _p(bf.f), _p(bf.inv), _p(bf.r2), _p(bf.z),
                                              _p(st.feats), st.n, st.f, st.n * st.f, _p(self._perm), _p(self.ctl[1:]), m // 2, st.n_pairs, m // 2,
-                                             _p(st.mean), _p(st.scale), _p(st.inv_scale), _p(bf.xs[1 - xi]), _p(pb["xh"][1 - xi]), _p(pb["xl"][1 - xi]),
-                                             g1, g2, 8, _stream()))
+                                             _p(st.mean), _p(st.scale), _p(st.inv_scale), None if plw else _p(bf.xs[1 - xi]), _p(pb["xh"][1 - xi]),
+                                             _p(pb["xl"][1 - xi]), g1, g2, 8, _stream()))
         elif early and self._early_split:         # ... and the first half of the next batch's tiles in its spare workgroups
             st = next_from
             self._k(_L.idl_mid_fwd_gather, _p(_lat_part_of(bf)) if l1 else _p(r1), _p(self.b1) if (tl and not l1) else None,
@@ -424,9 +430,10 @@ class FusedLinearTrainer:
                                              _p(r1), m, C, tr, nce_coef, _p(bf.dlogits), _p(bf.dlat), _p(bf.dr1), _p(gb1), _p(gb2), _p(gb3),
                                              _p(gW3) if self._dw3_partial else None,
                                              _p(st.feats), st.n, st.f, st.n * st.f, _p(self._perm), _p(self.ctl[1:]), m // 2, st.n_pairs, m // 2,
-                                             _p(st.mean), _p(st.scale), _p(st.inv_scale), _p(bf.xs[1 - xi]), _p(pb["xh"][1 - xi]), _p(pb["xl"][1 - xi]),
-                                             g2, 8, 8, 1, _stream()))
+                                             _p(st.mean), _p(st.scale), _p(st.inv_scale), None if plw else _p(bf.xs[1 - xi]), _p(pb["xh"][1 - xi]),
+                                             _p(pb["xl"][1 - xi]), g2, 8, 8, 1, _stream()))
             pb["valid"][1 - xi] = True
+            pb["x32"][1 - xi] = not plw
             if not self._dw3_partial:
                 torch.mm(bf.dlogits.t(), bf.r2, out=gW3)
         elif early:
@@ -470,7 +477,14 @@ class FusedLinearTrainer:
                                   m, tr, adv_ctl, adv, _p(bf.r2) if self._dw3_partial else None,
                                   _p(gW3) if self._dw3_partial else None, _stream()))
         if tm:      # the dW1 tiles end the step; everything else of the optimizer rides in the next step's layer-1 launch
-            if pl:      # ... and write the updated W1's planes for the next layer-1 product
+            if plw:     # dW1 from the batch's planes on the fp16 matrix cores; the epilogue writes the updated W1 and its planes
+                wh, wl, flag = self._w1_planes
+                if self._split_state is None:
+                    self._split_state = torch.zeros(int(_L.idl_wgrad_split_state_words()), dtype=torch.int64, device=self.dev)
+                chk(_L.idl_wgrad_rmsprop_xplanes(_p(bf.dr1), _p(pb["xh"][xi]), _p(pb["xl"][xi]), self.F, m, self.H1, self.F,
+                                                 _p(gW1) if self._keep_w1_grad else None, _p(self.W1), _p(self.square_avg[0]), _p(self.hyper),
+                                                 _p(self.ctl), _p(self._split_state), _p(wh), _p(wl), _p(flag), _stream()))
+            elif pl:    # ... and write the updated W1's planes for the next layer-1 product
                 wh, wl, flag = self._w1_planes
                 chk(_L.idl_wgrad_rmsprop_planes(_p(bf.dr1), _p(x), m, self.H1, self.F, _p(gW1) if self._keep_w1_grad else None, _p(self.W1),
                                                 _p(self.square_avg[0]), _p(self.hyper), _p(wh), _p(wl), _p(flag), _stream()))
@@ -586,6 +600,7 @@ class FusedLinearTrainer:
                                           b, _p(store.mean), _p(store.scale), _p(store.inv_scale), _p(bf.x), _stream()))
         if getattr(bf, "_planes", None) is not None:
             bf._planes["valid"][0] = False
+            bf._planes["x32"][0] = True
 
     def _full_step(self, store, bf, train=True, pipelined=False, xi=0, defer_tail=False):
         """pipelined: bf.xs[xi] already holds this batch (assembled by the previous step, or by the prologue gather);

@@ -76,7 +76,14 @@ def main():
     flag = torch.zeros(1, dtype=torch.int32, device=dev)
     t_w = timed(lambda: _lib.check(L.idl_wgrad_rmsprop(p(dy), p(x), m, H, F, None, p(Wc), p(Vc), p(hyper), st())))
     t_wp = timed(lambda: _lib.check(L.idl_wgrad_rmsprop_planes(p(dy), p(x), m, H, F, None, p(Wc), p(Vc), p(hyper), p(wh), p(wl), p(flag), st())))
-    print(f"dW1 tiles + RMSprop: {t_w:.1f} us; also writing W1's planes {t_wp:.1f}")
+    state = torch.zeros(L.idl_wgrad_split_state_words(), dtype=torch.int64, device=dev)
+    t_x = timed(lambda: _lib.check(L.idl_wgrad_rmsprop_xplanes(p(dy), p(xh), p(xl), F, m, H, F, None, p(Wc), p(Vc), p(hyper), None, p(state), p(wh), p(wl), p(flag), st())))
+    grad = torch.empty(H, F, device=dev)
+    t_xg = timed(lambda: _lib.check(L.idl_wgrad_rmsprop_xplanes(p(dy), p(xh), p(xl), F, m, H, F, p(grad), None, None, None, None, p(state), None, None, None, st())))
+    torch.cuda.synchronize()
+    e_g = (grad.double() - dy.double().t() @ x.double()).abs().max().item() / (dy.double().t() @ x.double()).abs().max().item()
+    print(f"dW1 tiles + RMSprop: {t_w:.1f} us; also writing W1's planes {t_wp:.1f}; from the batch's planes (fp16 matrix cores) {t_x:.1f}, its gradient alone {t_xg:.1f} "
+          f"(error {e_g:.1e} of the largest entry)")
     if "--no-epoch" in sys.argv:
         return
     epochs(dev, ("0", "1"))

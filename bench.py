@@ -342,13 +342,13 @@ def lanes_epoch_ms(din, args, dev, rank, world, voters):
     return ms
 
 
-def split16_leg(din, args, dev, rank, world, passes=4):
-    """The headline region once more with the EXPERIMENTAL weight-gradient launch (IDELUCS_SPLIT16=1: the product on the fp16 matrix
-    cores from operands split inside the kernel, csrc/wgrad_split.hip) -- an opt-in, reported beside `value`, never as `value`."""
+def fp32_form_leg(din, args, dev, rank, world, passes=4):
+    """The headline region once more with the step's fp32 form (IDELUCS_PLANES=0: both big products on the fp32 matrix cores, round 4 / early
+    round 5's default) -- reported beside `value`, never as `value`: what the two-plane products of the default step buy."""
     import copy
     a = copy.copy(args)
     a.voters, a.exchange = 1, False
-    os.environ["IDELUCS_SPLIT16"] = "1"
+    os.environ["IDELUCS_PLANES"] = "0"
     try:
         hp = HotPath(din, a, dev, rank, world)
         hp.step(seed=3000)
@@ -359,14 +359,13 @@ def split16_leg(din, args, dev, rank, world, passes=4):
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / passes
         v = hp.validate()
-        out = {"what": "IDELUCS_SPLIT16=1: dW1 = dr1^T x on the fp16 matrix cores from two fp16 planes per operand, three products, fp32 "
-                       "accumulators (closer to a float64 product than the fp32 library GEMM: profiles/r05_probe_split_mfma.txt); everything "
-                       "else as in `value`",
+        out = {"what": "IDELUCS_PLANES=0: layer 1 and dW1 on the fp32 matrix cores (own tiles: l1_rms_kernel, wgrad_q16_kernel) instead of the fp16 "
+                       "matrix cores from two fp16 planes per operand (three products, fp32 accumulators); everything else as in `value`",
                "value": args.n / dt, "unit": "sequences/sec", "ms_per_pass": 1e3 * dt, "epoch_ms": hp.mean_ms("epoch", 1),
                "epoch_loss_last_step": v.get("epoch_loss_last_step")}
         del hp
     finally:
-        os.environ.pop("IDELUCS_SPLIT16", None)
+        os.environ.pop("IDELUCS_PLANES", None)
     torch.cuda.empty_cache()
     return out
 
@@ -662,7 +661,7 @@ def main():
     ap.add_argument("--cpu-ref-steps", dest="cpu_ref_steps", type=int, default=2,
                     help="optimizer steps timed (after one untimed step) with the reference's cpu_count()-2 torch threads, scaled to the epoch")
     ap.add_argument("--no-k-sweep", dest="k_sweep", action="store_false", help="skip the k = 4 / k = 5 vectorise-stage rooflines (cfg4)")
-    ap.add_argument("--no-split16", dest="split16", action="store_false", help="skip the leg with the experimental weight-gradient launch (IDELUCS_SPLIT16=1)")
+    ap.add_argument("--no-split16", "--no-fp32-form", dest="split16", action="store_false", help="skip the leg with the step's fp32 form (IDELUCS_PLANES=0)")
     ap.add_argument("--no-cfg5", dest="cfg5_leg", action="store_false", help="skip the cfg5 job (10^6 x 5 kbp, 65.5 GB store) the default N = 1 run adds")
     ap.add_argument("--no-prediction", dest="prediction", action="store_false", help="skip the 2- and 4-lane passes behind predicted_fixed_job")
     ap.add_argument("--no-cpu-baseline", dest="cpu_base", action="store_false")
@@ -828,12 +827,14 @@ def main():
                                 "frac": args.n * b_vec / ((hp.mean_ms("edits", args.warmup) + t_vec + hp.mean_ms("stats", args.warmup)) * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                 "note": "the stage's algorithmic bytes are the vectoriser's (SURVEY 8d); the site generator is Philox-bound "
                                         "compute, the scaler fit reads view 0 once more (1.64 GB at cfg2)"},
-            "roofline_epoch": {"kernel": "training epoch (six launches a step: own fp32-MFMA tiles for layer 1 and dW1, the middle, InfoNCE, IIC, RMSprop; the fixed job's lockstep voters use batched library GEMMs for the two big products)", "bound": "mfma",
+            "roofline_epoch": {"kernel": "training epoch (seven launches a step: layer 1 and dW1 on the fp16 matrix cores from two fp16 planes per operand -- three products, fp32 accumulators, own tiles: l1_planes_kernel, wgrad_xplanes_kernel --, the sum of the K-slice partials + optimizer tail, the middle, InfoNCE, IIC; IDELUCS_PLANES=0 and steps of other shapes: own fp32-MFMA tiles; the fixed job's lockstep voters use batched library GEMMs for the two big products)", "bound": "mfma",
                                "achieved": ach_ep, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach_ep / MFMA_F32_PEAK_TFLOPS,
                                "ms": t_ep, "flop_per_seq_algorithmic": f_ep, "share_of_step": t_ep * len(hp.my_voters) / ms_step,
                                "flop_per_seq_executed": f_exec, "achieved_executed": ach_exec, "frac_executed": ach_exec / MFMA_F32_PEAK_TFLOPS,
                                "note": "algorithmic = SURVEY 8(d) (3 x forward for every layer); executed = without the input gradient of "
-                                       "layer 1, which is not computed"},
+                                       "layer 1, which is not computed.  `peak` stays the dense FP32 matrix peak, the arithmetic the results are "
+                                       "equivalent to (tests/test_gpu_planes.py: closer to float64 than an fp32 GEMM): the two big products now run as three "
+                                       "fp16 products each on a pipe sixteen times faster, so a fraction of THAT peak would be this fraction x 3 / 16"},
             "roofline_dominant": "roofline_epoch" if t_ep * len(hp.my_voters) > 0.5 * ms_step else "roofline",
             "roofline_dominant_note": ("`roofline` is the north_star's named kernel (the hand-written HBM-bound vectoriser); the epoch is "
                                        "%.0f %% of the timed step and its own object, roofline_epoch, is the one that prices the step"
@@ -860,7 +861,7 @@ def main():
         if world == 1 and args.k_sweep and not cfg5 and V == 1:
             out["k_sweep"] = k_sweep(din, args, dev)
         if world == 1 and args.split16 and not cfg5 and V == 1 and args.k == 6:
-            out["experimental_split16"] = split16_leg(din, args, dev, rank, world)
+            out["fp32_step_form"] = fp32_form_leg(din, args, dev, rank, world)
         if world == 1 and args.cfg5_leg and not cfg5 and V == 1 and not args.exchange and args.fixed_job:
             del din, hp
             torch.cuda.empty_cache()

@@ -163,9 +163,12 @@ class FusedLinearTrainer:
         self._side = torch.cuda.Stream(device=self.dev)     # second branch of the step (see step_on_batch)
         self._split16 = os.environ.get("IDELUCS_SPLIT16", "0") == "1"
         self._split_state = None
-        # IDELUCS_PLANES=1 (round 5, csrc/planes.h): the layer-1 product on the fp16 matrix cores from operands kept as two fp16 planes -- the
-        # batch's planes written by the workgroups that assemble it, W1's by the epilogue of the dW1 tiles that update it
-        self._planes = os.environ.get("IDELUCS_PLANES", "0") == "1"
+        # Round 5, default (IDELUCS_PLANES=0: the fp32 tiles below; csrc/planes.h): the two big products on the fp16 matrix cores from operands kept
+        # as two fp16 planes (22 significand bits a factor, three products, fp32 accumulators: closer to a float64 product than an fp32 GEMM) --
+        # the batch's planes written by the workgroups that assemble it, W1's by the epilogue of the dW1 tiles that update it.  A step
+        # 100.6 us against 111.0 at cfg2 (tools/bench_planes.py).  Needs the default launch sequence of a single voter (tail-in-layer-1),
+        # m % 128 == 0 and F % 512 == 0; any other step runs the fp32 tiles.
+        self._planes = os.environ.get("IDELUCS_PLANES", "1") != "0"
         self._planes_reduce_launch = os.environ.get("IDELUCS_PLANES_REDUCE", "launch") != "mid"
         self._planes_fork = os.environ.get("IDELUCS_PLANES_FORK", "0") == "1"
         # ... and dW1 from the batch's planes too (csrc/wgrad_planes.hip); the assembling workgroups then write the planes ONLY

@@ -206,7 +206,17 @@ class IID_model():
         elif self.schedule == 'Triangle':
             self.scheduler.step()
         self.epoch += 1
-        return running_loss.item() if sync else running_loss
+        if sync:
+            loss = running_loss.item()
+            self._check_planes()
+            return loss
+        return running_loss
+
+    def _check_planes(self):
+        """The two-plane step form (fused.FusedLinearTrainer._planes) clamps a weight of Linear(F,512) beyond +-15.8 in the layer-1 product and
+        raises a flag: checked wherever this model waits for the device anyway (a synchronous epoch, predict)."""
+        if self._fused is not None and self._fused.planes_overflowed():
+            raise RuntimeError("a weight of the first layer left the range of the fp16 planes (|w| >= 15.8): rerun with IDELUCS_PLANES=0")
 
     # ------------------------------------------------------------------ inference
     def _predict_inputs(self, rows=None):
@@ -243,6 +253,7 @@ class IID_model():
     def predict(self, data=None):
         """Reference models.py:145-172 -> (int64 y_pred[N], float64 probs[N], float64 latent[N,64])."""
         outputs, latent = self._predict_outputs()
+        self._check_planes()
         probs, predicted = torch.max(outputs, 1)
         return (predicted.cpu().numpy().astype(np.int64), probs.double().cpu().numpy(),
                 latent.double().cpu().numpy())

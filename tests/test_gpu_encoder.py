@@ -396,7 +396,15 @@ def test_default_fused_step_at_cfg2_shape_vs_autograd(dev, C):
     assert tr.ctl.tolist() == [1, B]
     # --- the next batch, assembled by spare workgroups of the two middle launches into the other x buffer
     want_next = store.gather_pairs(tr._perm[B:2 * B])
-    assert torch.equal(bf.xs[1], want_next)
+    pb = getattr(bf, "_planes", None)
+    if pb is not None and not pb["x32"][1]:     # the two-plane step form (the default at this shape): the next batch exists as its planes only
+        from idelucs_amd import _lib
+        k = int(_lib.lib.idl_planes_exponent(0))
+        back = (pb["xh"][1].view(torch.float16).double() + pb["xl"][1].view(torch.float16).double()) * 2.0 ** -k
+        err = (back - want_next.double()).abs()
+        assert pb["valid"][1] and bool((err <= torch.clamp(want_next.double().abs() * 2.0 ** -21, min=2.0 ** (-25 - k))).all())
+    else:
+        assert torch.equal(bf.xs[1], want_next)
 
 
 @pytest.mark.parametrize("C,n", [(20, 1500), (200, 1500), (20, 4200), (200, 4200)])
@@ -438,7 +446,7 @@ def test_graph_replay_equals_eager_at_cfg2_shape(dev, C, n):
 
 
 @pytest.mark.parametrize("n,use_graph", [(1500, False), (1500, True), (4200, True)])
-def test_batched_voters_step_like_single_voters(dev, n, use_graph):
+def test_batched_voters_step_like_single_voters(dev, monkeypatch, n, use_graph):
     """fused.BatchedLinearTrainer (three voters in lockstep: batched GEMMs + recorded launches with the voter index in the grid)
     against three FusedLinearTrainer runs of the same voters: same initial weights, same permutations (one generator per voter),
     same dropout streams -- after a whole epoch (8 or 24 full batches + a partial one) the parameters agree to a few 1e-4 of their
@@ -453,6 +461,7 @@ def test_batched_voters_step_like_single_voters(dev, n, use_graph):
     from idelucs_amd.fused import FusedLinearTrainer, BatchedLinearTrainer
     was_on = tunable.is_enabled()
     tunable.enable(False)
+    monkeypatch.setenv("IDELUCS_PLANES", "0")       # (... and the single voters to form their products in fp32 as the batched GEMMs do)
     try:
         _batched_like_single(dev, n, use_graph, copy, torch, FusedLinearTrainer, BatchedLinearTrainer)
     finally:
@@ -1173,6 +1182,7 @@ def test_tail_riding_in_the_layer1_launch_changes_no_bit(dev, monkeypatch, n, us
     store, net0 = _cfg2_store_and_net(dev, n, seed=6, C=20)
     B = 512
     out = []
+    monkeypatch.setenv("IDELUCS_PLANES", "0")       # (the fp32 form of the step: the two-plane form has its own tests, test_gpu_planes.py)
     for tail, bare in (("1", "0"), ("0", "bare")):
         monkeypatch.setenv("IDELUCS_TAIL_L1", tail)
         monkeypatch.setenv("IDELUCS_L1_FUSED", bare)
@@ -1201,10 +1211,12 @@ def test_tail_riding_in_the_layer1_launch_changes_no_bit(dev, monkeypatch, n, us
     assert tr._pending is None and tr.ctl.tolist() == [1, B] and all(not torch.equal(a, b) for a, b in zip(before, tr.params))
 
 
-def test_default_step_contains_no_library_gemm(dev, monkeypatch):
+@pytest.mark.parametrize("planes", ["1", "0"])
+def test_default_step_contains_no_library_gemm(dev, monkeypatch, planes):
     """Round 5: the speed of the step's largest forward kernel must not depend on a hipBLASLt build, a TunableOp
     seed file or its validators.  The default step's launches, by kernel name (torch.profiler): the layer-1 product is
-    l1_fwd_kernel / l1_rms_kernel (own tiles), the weight gradient wgrad_q16_kernel, and NO rocBLAS / hipBLASLt kernel (Cijk_*)
+    l1_planes_kernel (+ reduce_rms_kernel) / wgrad_xplanes_kernel in the two-plane form, l1_fwd_kernel / l1_rms_kernel / wgrad_q16_kernel
+    with IDELUCS_PLANES=0 (own tiles either way), and NO rocBLAS / hipBLASLt kernel (Cijk_*)
     runs in a full-batch step -- also with the shipped solutions switched off (IDELUCS_TUNABLEOP_SEED=0), as on a box whose library
     differs from the seed file's."""
     import copy
@@ -1212,6 +1224,7 @@ def test_default_step_contains_no_library_gemm(dev, monkeypatch):
     from torch.profiler import profile, ProfilerActivity
     from idelucs_amd.fused import FusedLinearTrainer
     monkeypatch.setenv("IDELUCS_TUNABLEOP_SEED", "0")
+    monkeypatch.setenv("IDELUCS_PLANES", planes)                        # the default (two-plane products) and the fp32 tiles
     store, net0 = _cfg2_store_and_net(dev, 1100, seed=8, C=20)          # 6 full batches + a partial one
     B = 512
     tr = FusedLinearTrainer(copy.deepcopy(net0), lr=1e-3, weight=0.25, lamb=2.8, seed=3)
@@ -1230,8 +1243,12 @@ def test_default_step_contains_no_library_gemm(dev, monkeypatch):
     names = [e.name for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA]
     if not names:
         pytest.skip("the profiler reported no device kernels on this box")
-    assert any("l1_rms_kernel" in n for n in names) and any("l1_fwd_kernel" in n for n in names), sorted(set(names))
-    assert any("wgrad_q16_kernel" in n for n in names)
+    if planes == "1":
+        assert any("l1_planes_kernel" in n for n in names) and any("reduce_rms_kernel" in n for n in names), sorted(set(names))
+        assert any("wgrad_xplanes_kernel" in n for n in names)
+    else:
+        assert any("l1_rms_kernel" in n for n in names) and any("l1_fwd_kernel" in n for n in names), sorted(set(names))
+        assert any("wgrad_q16_kernel" in n for n in names)
     assert not any("Cijk_" in n for n in names), [n for n in names if "Cijk_" in n][:3]
 
 
@@ -1330,6 +1347,7 @@ def test_step_with_the_split_weight_gradient_trains_like_the_default_step(dev, m
     store, net0 = _cfg2_store_and_net(dev, 4096, seed=6, C=20)
     B = 512
     one, sums = {}, {}
+    monkeypatch.setenv("IDELUCS_PLANES", "0")       # (a variant of the fp32 form of the step)
     for flag in ("0", "1"):
         monkeypatch.setenv("IDELUCS_SPLIT16", flag)
         tr = FusedLinearTrainer(copy.deepcopy(net0), lr=1e-3, weight=0.25, lamb=2.8, seed=5)

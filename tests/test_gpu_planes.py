@@ -292,3 +292,26 @@ def test_planes_follow_the_weights_through_an_epoch(dev, monkeypatch):
     assert torch.equal(hi, wh) and torch.equal(lo, wl) and flag.item() == 0
     xh, xl, _, _ = _split(bf.xs[0], 0)
     assert torch.equal(xh, bf._planes["xh"][0]) and torch.equal(xl, bf._planes["xl"][0])
+
+
+def test_a_weight_beyond_the_planes_range_is_reported(dev, monkeypatch):
+    """|w| >= 15.8 does not fit W1's planes (scale 2^12): the entry is clamped in the layer-1 product, the flag is raised by whoever writes the
+    planes (idl_split_planes before the first step, the dW1 tiles' epilogue afterwards) and IID_model raises where it next waits for the device."""
+    import torch
+    from idelucs_amd.fused import FusedLinearTrainer
+    monkeypatch.setenv("IDELUCS_PLANES", "1")
+    store, net0 = _store_and_net(dev, 1100, seed=4, C=20)
+    tr = FusedLinearTrainer(copy.deepcopy(net0), lr=1e-3, weight=0.25, lamb=2.8, seed=2)
+    gen = torch.Generator(device=dev); gen.manual_seed(5)
+    tr.run_epoch(store, 512, use_graph=False, generator=gen)
+    assert not tr.planes_overflowed()
+    with torch.no_grad():
+        tr.W1[3, 5] = 20.0
+    tr.run_epoch(store, 512, use_graph=False, generator=gen)
+    assert tr.planes_overflowed()
+    from idelucs_amd import models
+
+    class _M:                      # (IID_model._check_planes on a stand-in: the method only looks at _fused)
+        _fused = tr
+    with pytest.raises(RuntimeError, match="IDELUCS_PLANES=0"):
+        models.IID_model._check_planes(_M())

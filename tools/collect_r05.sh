@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-5 evidence: the driver's bench command, the rocprofv3 kernel stats of the same command, MFMA-busy counters of the epoch's
 # kernels, the optimizer launch's workgroup stamps, the vectoriser's HBM / LDS counters at k = 6, 5 and 4.   bash tools/collect_r05.sh <out_dir>
-out=${1:-gpurun_out/r05_q}
+out=${1:-gpurun_out/r05_r}
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 ( time python3 bench.py --gpus 1 --steps 20 --warmup 5 > $out/bench_default.json 2> $out/bench_default.err ) 2> $out/bench_default.time
@@ -30,7 +30,9 @@ f = glob.glob(out + "/pmc_mfma/**/*counter_collection.csv", recursive=True)[0]
 acc = collections.defaultdict(lambda: collections.defaultdict(float)); seen = collections.defaultdict(set)
 def key(n):
     for k, v in (("Cijk_", "hipBLASLt/rocBLAS GEMMs (Cijk_*)"), ("wgrad_rmsprop_kernel", "wgrad_rmsprop_kernel (dW1 tiles + optimizer)"), ("wgrad_q16", "wgrad_q16_kernel (dW1 tiles + RMSprop on W1)"),
-                 ("l1_rms", "l1_rms_kernel (own layer-1 tiles + the previous step's optimizer tail)"), ("l1_fwd", "l1_fwd_kernel (own layer-1 tiles)"), ("mid_fwd", "mid_fwd_kernel"),
+                 ("l1_rms", "l1_rms_kernel (own layer-1 tiles + the previous step's optimizer tail)"), ("l1_fwd", "l1_fwd_kernel (own layer-1 tiles)"),
+                 ("l1_planes", "l1_planes_kernel (layer 1 on the fp16 matrix cores from two-plane operands)"), ("wgrad_xplanes", "wgrad_xplanes_kernel (dW1 from the batch's planes + RMSprop on W1 + W1's planes)"),
+                 ("reduce_rms", "reduce_rms_kernel (sum of the K-slice partials + the previous step's optimizer tail)"), ("mid_fwd", "mid_fwd_kernel"),
                  ("mid_bwd", "mid_bwd_kernel"), ("nce_pass1", "nce_pass1_kernel"), ("nce_pass2", "nce_pass2_kernel"), ("vectorise3", "vectorise3_kernel")):
         if k in n: return v
     return None

@@ -239,6 +239,17 @@ __global__ __launch_bounds__(NT, 1) void wgrad_xplanes_kernel(XpArgs a)
             lo[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, lo[j], 0, 0, 0);
         }
     };
+    // the wave's pieces of W and square_avg (the epilogue's map: 8 x 16 bytes of each a lane) are requested HERE, before the first product: 16 MB a
+    // launch that used to be fetched behind the last MFMA (the computing waves have no other memory requests: nothing waits on these)
+    f32x4 w_pre[8], v_pre[8];
+    if (a.W != nullptr) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int idx = lane + 64 * u, rl = idx >> 4, c4 = idx & 15;
+            const int64_t at = (int64_t)(h0 + wm + rl) * a.n_in + f0 + wn + 4 * c4;
+            w_pre[u] = *(const f32x4 *)(a.W + at); v_pre[u] = *(const f32x4 *)(a.V + at);
+        }
+    }
     Set fs0, fs1;
     __builtin_amdgcn_s_barrier();
     {
@@ -293,7 +304,7 @@ __global__ __launch_bounds__(NT, 1) void wgrad_xplanes_kernel(XpArgs a)
         const int64_t at = (int64_t)(h0 + wm + rl) * a.n_in + f0 + wn + 4 * c4;
         if (a.grad != nullptr) *(f32x4 *)(a.grad + at) = g4;
         if (a.W != nullptr) {
-            f32x4 w4 = *(const f32x4 *)(a.W + at), v4 = *(const f32x4 *)(a.V + at);
+            f32x4 w4 = w_pre[u], v4 = v_pre[u];
 #pragma unroll
             for (int e = 0; e < 4; ++e) { float w = w4[e], v = v4[e]; wg_dev::rms_update(g4[e], w, v, hy); w4[e] = w; v4[e] = v; }
             *(f32x4 *)(a.W + at) = w4;

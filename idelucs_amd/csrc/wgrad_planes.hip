@@ -11,7 +11,20 @@
 // 32 rows, whole 256-byte row segments, the 16-byte slots swizzled on the source side), three chunks ahead, into a ring of six stages;
 // only dy (64 columns, 1 / 3 of the bytes, fp32 from mid_bwd) is still split by the loader waves, 8 values a lane a chunk, with the
 // tensor's scale taken from the previous launch's largest entry (wgrad_split.hip: tagged words, 16 x headroom, clamped).
-// The epilogue also writes the updated W1 as planes for the next step's layer-1 product.
+// The epilogue also writes the updated W1 as planes for the next step's layer-1 product; W and square_avg are requested before the first
+// product (in the step: 100.6 -> 98.6 us).
+//
+// WHERE IT STANDS (MI355X, m = 1024, 512 x 4096, a HIP graph of 20 launches, tools/bench_planes.py): 30.6 us with the update and W1's planes
+// (the fp32 tiles: 41.8), the gradient alone 23.8; in the step 31-33 us against 37-38.  The loop is a chain of per-chunk latencies, not
+// a throughput limit (ablations with requests, MFMAs, LDS reads and the deposit switched off one by one, us of the gradient-only
+// launch): everything 24.9; no epilogue 23.2; no MFMAs 21.4; no DMA (four dword requests in their place) 21.6; neither 21.1; no
+// requests at all 14.2; no LDS reads either 9.0 (of which ~4.6 is this harness's launch) -- per chunk (0.65 us): the barrier round
+// ~0.14 us, the LDS reads behind their waits ~0.16, a chunk's six requests ~0.2, MFMAs 0.1 of 0.16 hidden.  Tried and no better:
+// "touches" (one dword of every cache line of the chunk nine further on, dropped into spare LDS by the computing waves, so that the
+// loaders' requests would hit L2): 26.9 against 25.7, the step 100.2 against 98.6 -- the requests are not waiting for first touches.
+// (Two traps on the way, both silent: a request whose target is a register must keep that register out of the compiler's hands until it
+// lands -- every inline-asm request passes its registers THROUGH the wait that covers it; and no switch may skip such a request: a set
+// written under a branch is copied where the paths join, while in flight.)
 #include <stdlib.h>
 
 #include "common.h"

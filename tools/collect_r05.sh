@@ -4,9 +4,11 @@
 out=${1:-gpurun_out/r05_r}
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
+if [ -z "$SKIP_BENCH" ]; then
 ( time python3 bench.py --gpus 1 --steps 20 --warmup 5 > $out/bench_default.json 2> $out/bench_default.err ) 2> $out/bench_default.time
 echo "bench rc=$? $(grep real $out/bench_default.time)"
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-e2e --no-fixed-job --no-k-sweep > $out/trace_bench.json 2> $out/trace.err
+fi
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-e2e --no-fixed-job --no-k-sweep --no-fp32-form --no-cfg5 > $out/trace_bench.json 2> $out/trace.err
 cp $out/trace/*/*kernel_stats.csv $out/bench_kernel_stats.csv
 python3 - $out <<'PY'
 import csv, sys
@@ -22,7 +24,7 @@ for r in rows:
         lines.append(f"   {r['Name'][:86]:86s} {int(r['Calls']):6d} x {float(r['AverageNs'])/1000:7.2f}")
 open(out + "/step_kernels.txt", "w").write("\n".join(lines) + "\n"); print("\n".join(lines))
 PY
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $out/pmc_mfma -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-e2e --no-fixed-job --no-k-sweep > $out/pmc_mfma.json 2> $out/pmc_mfma.err
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $out/pmc_mfma -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-e2e --no-fixed-job --no-k-sweep --no-fp32-form --no-cfg5 > $out/pmc_mfma.json 2> $out/pmc_mfma.err
 python3 - $out <<'PY'
 import csv, glob, json, sys, collections
 out = sys.argv[1]

@@ -315,3 +315,32 @@ def test_a_weight_beyond_the_planes_range_is_reported(dev, monkeypatch):
         _fused = tr
     with pytest.raises(RuntimeError, match="IDELUCS_PLANES=0"):
         models.IID_model._check_planes(_M())
+
+
+def test_step_on_planes_at_k5_shape(dev, monkeypatch):
+    """The two-plane step at k = 5's shape (F = 1024: two 64-deep chunks a K slice, the shortest the layer-1 tiles take) and a batch of 2 x 128
+    rows: an epoch's loss follows the fp32 form's, the planes follow the weights."""
+    import torch
+    from idelucs_amd import utils as U, models
+    from idelucs_amd.PytorchUtils import NetLinear
+    from idelucs_amd.fused import FusedLinearTrainer
+    g = torch.Generator(device=dev); g.manual_seed(11)
+    P, n, F, C, B = 4, 2100, 1024, 12, 128
+    base = torch.rand((1, n, F), device=dev, generator=g) + 0.5
+    feats = base * (1.0 + 0.05 * torch.randn((P, n, F), device=dev, generator=g))
+    feats = (feats / feats.sum(2, keepdim=True)).contiguous()
+    mean, scale = U.col_stats(feats[0])
+    store = U.FeatureStore(None, None, feats, mean, scale, 5, False)
+    torch.manual_seed(3)
+    net0 = NetLinear(F, C).to(dev); net0.apply(models.weights_init)
+    sums = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("IDELUCS_PLANES", flag)
+        tr = FusedLinearTrainer(copy.deepcopy(net0), lr=1e-3, weight=0.25, lamb=2.8, seed=5)
+        gen = torch.Generator(device=dev); gen.manual_seed(7)
+        total, nb = tr.run_epoch(store, B, use_graph=True, generator=gen)
+        sums[flag] = total.item() / nb
+        if flag == "1":
+            bf = tr.buffers(2 * B)
+            assert getattr(bf, "_planes", None) is not None and tr._w1_planes is not None and not tr.planes_overflowed()
+    assert np.isfinite(sums["1"]) and abs(sums["1"] - sums["0"]) <= 1e-3 * abs(sums["0"]), sums

@@ -1191,8 +1191,10 @@ struct ReduceArgs { float4 *part; int64_t slab4; int n_parts, blocks; };      //
 constexpr int RED_U = 2;
 __global__ __launch_bounds__(256) void reduce_rms_kernel(ReduceArgs r, RmsArgs a, const float *hyper, int64_t *ctl, int64_t batch_advance, int with_tail)
 {
-    if ((int)blockIdx.x < r.blocks) {
-        const int64_t i0 = (int64_t)blockIdx.x * (256 * RED_U) + threadIdx.x;
+    // grid order: the tail's workgroups FIRST (theirs is the longer chain: 7.1 us on its own against the sums' 4.7), the sums behind them
+    const int n_tail = (int)gridDim.x - r.blocks;
+    if ((int)blockIdx.x >= n_tail) {
+        const int64_t i0 = (int64_t)((int)blockIdx.x - n_tail) * (256 * RED_U) + threadIdx.x;
         float4 v[RED_U][l1p_dev::KSPLIT];
 #pragma unroll
         for (int u = 0; u < RED_U; ++u) {
@@ -1211,7 +1213,7 @@ __global__ __launch_bounds__(256) void reduce_rms_kernel(ReduceArgs r, RmsArgs a
     }
     // (the look-ahead form of the dW2 tiles -- every operand of a wave requested before its first product: one trip to memory instead of
     //  three -- as behind the dW1 tiles of wgrad_rmsprop_kernel: here too the tail's chain is the launch's length, 9.3 us without)
-    if (with_tail) rmsprop_body<true>(a, hyper, ctl, batch_advance, 0, 0, idl_dev::GatherArgs{}, (int)blockIdx.x - r.blocks);
+    if (with_tail) rmsprop_body<true>(a, hyper, ctl, batch_advance, 0, 0, idl_dev::GatherArgs{}, (int)blockIdx.x);
 }
 
 // several voters in one launch: voter blockIdx.y takes its arguments from its plan record

@@ -104,24 +104,43 @@ __global__ __launch_bounds__(NT, 1) void wgrad_xplanes_kernel(XpArgs a)
     const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
     // the launch's number and the scale of dy (wgrad_split.hip)
     const unsigned long long t = a.ctl != nullptr ? (unsigned long long)a.ctl[0] + 1ull : 1ull;
+    // (words of BOTH parities whose tag is one of the last three launch numbers: a step of another form in between -- the epoch's partial last
+    //  batch runs the fp32 tiles and moves the counter on -- must not send the next launch back to the default scale)
+    // ONE wave reads them and hands the exponent to the others through LDS: the loaders that split dy and the computing waves that scale the
+    // tile back must agree, and workgroups of this very launch that have finished write words of their own meanwhile.
     float mxp = 0.f;
-    {
-        const unsigned long long *pv = a.state + ((t - 1ull) & 1ull) * STATE_SLOTS;
-        const int n_words = 4 * (int)gridDim.x;
-        for (int i = lane; i < n_words; i += 64) {
-            const unsigned long long w = pv[i];
-            if ((w >> 32) == ((t - 1ull) & 0xFFFFFFFFull)) mxp = fmaxf(mxp, __uint_as_float((uint32_t)w));
+    if (wv == 4) {
+        // a word per WORKGROUP of a launch (its four loader waves fold their maxima in LDS first), all requests of a lane in flight before the
+        // first compare: with a word per loader wave and a plain loop every wave of every launch spent 16 dependent round trips here (2.7 us)
+        const int n_words = (int)gridDim.x;
+#pragma unroll
+        for (int par = 0; par < 2; ++par) {
+            const unsigned long long *pv = a.state + par * STATE_SLOTS;
+            for (int i0 = 0; i0 < n_words; i0 += 4 * 64) {
+                unsigned long long w[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { const int i = i0 + 64 * j + lane; w[j] = pv[i < n_words ? i : n_words - 1]; }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t age = (uint32_t)t - (uint32_t)(w[j] >> 32);       // 1 .. 3: a recent launch's word
+                    if (age >= 1u && age <= 3u) mxp = fmaxf(mxp, __uint_as_float((uint32_t)w[j]));
+                }
+            }
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) mxp = fmaxf(mxp, __shfl_xor(mxp, o, 64));
+        int k = K_FIRST;
+        if (mxp > 0.f) {
+            int e;
+            (void)frexpf(mxp, &e);
+            k = K_TARGET - e;
+            k = k < -100 ? -100 : (k > 100 ? 100 : k);
+        }
+        if (lane == 0) { int *sw = (int *)(smem + LDS_BYTES); sw[0] = k; sw[1] = 0; sw[2] = 0; }      // exponent | this launch's maximum | loaders done
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     }
-    int kexp = K_FIRST;
-    if (mxp > 0.f) {
-        int e;
-        (void)frexpf(mxp, &e);
-        kexp = K_TARGET - e;
-        kexp = kexp < -100 ? -100 : (kexp > 100 ? 100 : kexp);
-    }
+    __builtin_amdgcn_s_barrier();
+    const int kexp = *(const int *)(smem + LDS_BYTES);
     if (wv >= 4) {
         // ================= a loader: a chunk is 2 requests of 16 bytes (dy, into the register ring) + 4 DMA instructions (x's planes, into the
         // x stage of the chunk).  All six count on vmcnt and retire in order: a chunk is in when at most 6 x (chunks requested behind it) are out.
@@ -196,7 +215,12 @@ __global__ __launch_bounds__(NT, 1) void wgrad_xplanes_kernel(XpArgs a)
 #undef WGP_WAIT
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64)); mx = fmaxf(mx, __shfl_xor(mx, 16, 64)); mx = fmaxf(mx, __shfl_xor(mx, 8, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 4, 64)); mx = fmaxf(mx, __shfl_xor(mx, 2, 64)); mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
-        if (lane == 0) a.state[(t & 1ull) * STATE_SLOTS + 4 * bid + lw] = ((t & 0xFFFFFFFFull) << 32) | (unsigned long long)__float_as_uint(mx);
+        if (lane == 0) {                                     // (|dy| >= 0: the bit patterns order as the values do)
+            unsigned int *sw = (unsigned int *)(smem + LDS_BYTES);
+            atomicMax(&sw[1], __float_as_uint(mx));
+            if (atomicAdd(&sw[2], 1u) == 3u)                 // the last of the four loader waves: the workgroup's word
+                a.state[(t & 1ull) * STATE_SLOTS + bid] = ((t & 0xFFFFFFFFull) << 32) | (unsigned long long)atomicMax(&sw[1], 0u);
+        }
         return;
     }
     // ================= a computing wave: 32 (h) x 64 (f) of the tile (wgrad_split.hip)
@@ -362,10 +386,10 @@ extern "C" int idl_wgrad_rmsprop_xplanes(const float *dy, const void *x_hi, cons
     int dev = 0;
     IDL_HIP_TRY(hipGetDevice(&dev));
     if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-        IDL_HIP_TRY(hipFuncSetAttribute((const void *)wgrad_xplanes_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        IDL_HIP_TRY(hipFuncSetAttribute((const void *)wgrad_xplanes_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + 16));
         attr_set[dev] = true;
     }
-    hipLaunchKernelGGL(wgrad_xplanes_kernel, dim3((unsigned)a.tiles), dim3(NT), LDS_BYTES, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(wgrad_xplanes_kernel, dim3((unsigned)a.tiles), dim3(NT), LDS_BYTES + 16, (hipStream_t)stream, a);      // (+ 16: the exponent's word)
     IDL_HIP_TRY(hipGetLastError());
     return IDL_OK;
 }

@@ -203,8 +203,8 @@ def test_weight_gradient_from_the_batch_planes_matches_the_fp32_tiles(dev, m, H,
     ctl = torch.zeros(2, dtype=torch.int64, device=dev)
     wh = torch.empty(H, F, dtype=torch.int16, device=dev); wl = torch.empty_like(wh); flag = torch.zeros(1, dtype=torch.int32, device=dev)
     errs = []
-    for step in range(3):                                     # launch 1 takes the default scale, 2 and 3 the previous launch's
-        Wpl.copy_(W0); Vpl.copy_(V0); ctl[0:1].fill_(step)
+    for step in (0, 1, 2, 4):                                 # launch 1 takes the default scale, 2 and 3 the previous launch's, the last one
+        Wpl.copy_(W0); Vpl.copy_(V0); ctl[0:1].fill_(step)     # the scale of two launches back (a step of another form moved the counter on)
         _lib.check(L.idl_wgrad_rmsprop_xplanes(_p(dy), _p(xh), _p(xl), F, m, H, F, _p(gpl), _p(Wpl), _p(Vpl), _p(hyper), _p(ctl), _p(state),
                                                _p(wh), _p(wl), _p(flag), _stream()))
         torch.cuda.synchronize()

@@ -14,8 +14,10 @@
 // The epilogue also writes the updated W1 as planes for the next step's layer-1 product; W and square_avg are requested before the first
 // product (in the step: 100.6 -> 98.6 us).
 //
-// WHERE IT STANDS (MI355X, m = 1024, 512 x 4096, a HIP graph of 20 launches, tools/bench_planes.py): 30.6 us with the update and W1's planes
-// (the fp32 tiles: 41.8), the gradient alone 23.8; in the step 31-33 us against 37-38.  The loop is a chain of per-chunk latencies, not
+// WHERE IT STANDS (MI355X, m = 1024, 512 x 4096, a HIP graph of 20 launches, tools/bench_planes.py): 27.3 us with the update and W1's planes
+// (the fp32 tiles: 41-42), the gradient alone 20.8; in the step 27.9 us against 36.5-37.  (30.6 / 23.8 and 30.1 in the step before the scale's
+// words were cut from one per loader wave, read by every wave in a plain loop -- 16 dependent round trips, 2.7 us at the head of every launch --
+// to one per workgroup, read by one idle computing wave with all its requests in flight while the loaders' first requests are out.)  The loop is a chain of per-chunk latencies, not
 // a throughput limit (ablations with requests, MFMAs, LDS reads and the deposit switched off one by one, us of the gradient-only
 // launch): everything 24.9; no epilogue 23.2; no MFMAs 21.4; no DMA (four dword requests in their place) 21.6; neither 21.1; no
 // requests at all 14.2; no LDS reads either 9.0 (of which ~4.6 is this harness's launch) -- per chunk (0.65 us): the barrier round
@@ -107,9 +109,10 @@ __global__ __launch_bounds__(NT, 1) void wgrad_xplanes_kernel(XpArgs a)
     // (words of BOTH parities whose tag is one of the last three launch numbers: a step of another form in between -- the epoch's partial last
     //  batch runs the fp32 tiles and moves the counter on -- must not send the next launch back to the default scale)
     // ONE wave reads them and hands the exponent to the others through LDS: the loaders that split dy and the computing waves that scale the
-    // tile back must agree, and workgroups of this very launch that have finished write words of their own meanwhile.
+    // tile back must agree, and workgroups of this very launch that have finished write words of their own meanwhile.  It is a COMPUTING wave
+    // (idle until the first chunk is in): the loaders have their first requests out before they meet it at the barrier.
     float mxp = 0.f;
-    if (wv == 4) {
+    if (wv == 0) {
         // a word per WORKGROUP of a launch (its four loader waves fold their maxima in LDS first), all requests of a lane in flight before the
         // first compare: with a word per loader wave and a plain loop every wave of every launch spent 16 dependent round trips here (2.7 us)
         const int n_words = (int)gridDim.x;
@@ -139,15 +142,13 @@ __global__ __launch_bounds__(NT, 1) void wgrad_xplanes_kernel(XpArgs a)
         if (lane == 0) { int *sw = (int *)(smem + LDS_BYTES); sw[0] = k; sw[1] = 0; sw[2] = 0; }      // exponent | this launch's maximum | loaders done
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     }
-    __builtin_amdgcn_s_barrier();
-    const int kexp = *(const int *)(smem + LDS_BYTES);
+    int kexp = 0;
     if (wv >= 4) {
         // ================= a loader: a chunk is 2 requests of 16 bytes (dy, into the register ring) + 4 DMA instructions (x's planes, into the
         // x stage of the chunk).  All six count on vmcnt and retire in order: a chunk is in when at most 6 x (chunks requested behind it) are out.
         const int lt = tid - 256, lw = wv - 4;
-        const float sc_dy = __builtin_ldexpf(1.f, kexp);
         f32x4 ra[PF][2];
-        float mx = 0.f;
+        float mx = 0.f, sc_dy = 1.f;                         // (the scale: set behind the barrier below)
         uint32_t va[2], la;
         {
             const int row = lt >> 3, sl = lt & 7;            // a lane's item of dy: row, 8 consecutive columns = a 16-byte slot of a plane's row
@@ -189,9 +190,11 @@ __global__ __launch_bounds__(NT, 1) void wgrad_xplanes_kernel(XpArgs a)
             *(__attribute__((address_space(3))) u32x4 *)(uintptr_t)(st + la) = u32x4{a0.x, a0.y, b0.x, b0.y};
             *(__attribute__((address_space(3))) u32x4 *)(uintptr_t)(st + PLANE + la) = u32x4{a1.x, a1.y, b1.x, b1.y};
         };
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the scale's words above: nothing else of this wave is in flight from here on)
 #pragma unroll
         for (int sl = 0; sl < PF; ++sl) request(sl, sl);
+        __builtin_amdgcn_s_barrier();                        // the exponent is in LDS
+        kexp = *(const int *)(smem + LDS_BYTES);
+        sc_dy = __builtin_ldexpf(1.f, kexp);
         wait_behind(2, 0); deposit(0, 0); request(PF, 0);            // x stage 3: never used yet
         wait_behind(2, 1); deposit(1, 1); request(PF + 1, 1);        // x stage 4
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -224,6 +227,8 @@ __global__ __launch_bounds__(NT, 1) void wgrad_xplanes_kernel(XpArgs a)
         return;
     }
     // ================= a computing wave: 32 (h) x 64 (f) of the tile (wgrad_split.hip)
+    __builtin_amdgcn_s_barrier();                            // the exponent is in LDS
+    kexp = *(const int *)(smem + LDS_BYTES);
     const int wm = (wv >> 1) * 32, wn = (wv & 1) * 64;
     f32x16 hi[2], lo[2];
 #pragma unroll

@@ -30,6 +30,7 @@
 #include "wgrad_device.h"
 #include "l1_device.h"
 #include "l1_planes_device.h"
+#include "wgrad_planes_device.h"
 #include "philox_device.h"
 
 namespace {
@@ -931,10 +932,25 @@ struct RmsArgs {
 // is the launch's tail): the parameter / square_avg elements and BOTH 128-row batches of a wave's 256 rows are requested before
 // the first product -- one trip to memory instead of three (128 more registers, which that launch has and rmsprop_kernel, whose
 // streaming blocks want 16 waves per CU, has not).
-template <bool AHEAD>
-__device__ __forceinline__ void wgrad_tile_rms(const RmsArgs &a, int tile, float lr, float alpha, float eps, float wd, float oma, float *red)
+// SPIN: the four waves meet on an LDS counter instead of s_barrier (the loader waves of wgrad_xplanes_rms_kernel, whose workgroup's other
+// four waves are elsewhere: an s_barrier would wait for them); *spin is zero when the workgroup starts and is used once.
+template <bool SPIN>
+__device__ __forceinline__ void tail_sync(const int tix, unsigned int *spin)
 {
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l = lane & 15, q = lane >> 4;
+    if constexpr (!SPIN) { __syncthreads(); }
+    else {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // (this wave's partial tile is in LDS)
+        if ((tix & 63) == 0) atomicAdd(spin, 1u);
+        while (*(volatile unsigned int *)spin < 4u) __builtin_amdgcn_s_sleep(1);
+        asm volatile("" ::: "memory");
+    }
+}
+
+template <bool AHEAD, bool SPIN = false>
+__device__ __forceinline__ void wgrad_tile_rms(const RmsArgs &a, int tile, float lr, float alpha, float eps, float wd, float oma, float *red, const int tix,
+                                               unsigned int *spin)
+{
+    const int tid = tix, lane = tid & 63, wv = tid >> 6, l = lane & 15, q = lane >> 4;
     const int tn = a.wg_n_in / 16;
     const int i0 = (tile / tn) * 16, j0 = (tile % tn) * 16;
     const int lda = a.wg_n_out, ldb = a.wg_n_in, m = a.wg_m;
@@ -1000,7 +1016,7 @@ __device__ __forceinline__ void wgrad_tile_rms(const RmsArgs &a, int tile, float
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) red[wv * 256 + (4 * q + r) * 16 + l] = acc[r];          // C/D: row = 4 q + reg, col = l
-    __syncthreads();
+    tail_sync<SPIN>(tix, spin);
     const float g = (red[tid] + red[256 + tid]) + (red[512 + tid] + red[768 + tid]);
     const int o = oo;
     if (a.wg_grad != nullptr) a.wg_grad[o] = g;
@@ -1019,21 +1035,21 @@ constexpr int RMS_UNROLL = 4;         // 16-byte elements per thread of the stre
 
 constexpr int RMS_THREADS = 256;   // threads of an optimizer block (the launch may carry a fifth, idle wave: wgrad_rmsprop_kernel)
 
-template <bool AHEAD = false>
+template <bool AHEAD = false, bool SPIN = false>
 __device__ __forceinline__ void rmsprop_body(const RmsArgs &a, const float *hyper, int64_t *ctl, int64_t batch_advance, int gx,
-                                             int n_gather, const idl_dev::GatherArgs &g, const int blk)
+                                             int n_gather, const idl_dev::GatherArgs &g, const int blk, const int tix, unsigned int *spin = nullptr)
 {
     // grid order: weight-gradient tiles (dependent chains of strided loads: first, so that the streaming blocks behind them hide
     // their latency), then the gather blocks, then the optimizer blocks
     const float lr = hyper[0], alpha = hyper[1], eps = hyper[2], wd = hyper[3], oma = hyper[4];
     if (blk < a.wg_tiles) {
         __shared__ float red[1024];
-        wgrad_tile_rms<AHEAD>(a, blk, lr, alpha, eps, wd, oma, red);
+        wgrad_tile_rms<AHEAD, SPIN>(a, blk, lr, alpha, eps, wd, oma, red, tix, spin);
         return;
     }
     const int b0 = blk - a.wg_tiles;
     if (b0 < n_gather) {
-        idl_dev::gather_block(g, (int64_t)b0, threadIdx.x);
+        idl_dev::gather_block(g, (int64_t)b0, tix);
         return;
     }
     const int bid = b0 - n_gather;
@@ -1056,7 +1072,7 @@ __device__ __forceinline__ void rmsprop_body(const RmsArgs &a, const float *hype
             // four 16-byte elements per thread, all twelve loads in flight before the first use.  (The weight-gradient tiles put this
             // kernel at 104 registers = 16 waves per CU: with two elements per thread the 1024 blocks of W1 did not all fit at once.)
             const int64_t n4 = n / 4, stride = (int64_t)gx * RMS_THREADS;
-            for (int64_t i = (int64_t)bx * RMS_THREADS + threadIdx.x; i < n4; i += RMS_UNROLL * stride) {
+            for (int64_t i = (int64_t)bx * RMS_THREADS + tix; i < n4; i += RMS_UNROLL * stride) {
                 float4 pv[RMS_UNROLL], vv[RMS_UNROLL], gv[RMS_UNROLL];
 #pragma unroll
                 for (int u = 0; u < RMS_UNROLL; ++u) {
@@ -1069,7 +1085,7 @@ __device__ __forceinline__ void rmsprop_body(const RmsArgs &a, const float *hype
                 }
             }
         } else
-        for (int64_t i = (int64_t)bx * RMS_THREADS + threadIdx.x; i < n; i += (int64_t)gx * RMS_THREADS) {
+        for (int64_t i = (int64_t)bx * RMS_THREADS + tix; i < n; i += (int64_t)gx * RMS_THREADS) {
             const float pi = p[i];
             float gr;
             if (a.parts[t] == COL_PARTS) {          // 32 independent loads in flight, summed in a fixed order
@@ -1089,22 +1105,22 @@ __device__ __forceinline__ void rmsprop_body(const RmsArgs &a, const float *hype
             p[i] = pn;
         }
     }
-    if (bid == 0 && threadIdx.x == 0) { ctl[0] += 1; ctl[1] += batch_advance; }
-    if (a.out != nullptr && bid == a.first[a.count] - 1 && threadIdx.x < 64) {
+    if (bid == 0 && tix == 0) { ctl[0] += 1; ctl[1] += batch_advance; }
+    if (a.out != nullptr && bid == a.first[a.count] - 1 && tix < 64) {
         // step loss = w_nce * mean(loss_rows) + w_iic * IIC (left in out[3] by iic_core_kernel); out[1] = running sum
         const float iic = a.out[3], run = a.out[1];           // requested together with the rows: one trip
         float part[16];
         float acc = 0.f;
         if (a.loss_m <= 1024) {                               // every load in flight before the first add (same order of additions)
 #pragma unroll
-            for (int j = 0; j < 16; ++j) { const int i = threadIdx.x + 64 * j; part[j] = i < a.loss_m ? a.loss_rows[i] : 0.f; }
+            for (int j = 0; j < 16; ++j) { const int i = tix + 64 * j; part[j] = i < a.loss_m ? a.loss_rows[i] : 0.f; }
 #pragma unroll
             for (int j = 0; j < 16; ++j) acc += part[j];
         } else {
-            for (int i = threadIdx.x; i < a.loss_m; i += 64) acc += a.loss_rows[i];
+            for (int i = tix; i < a.loss_m; i += 64) acc += a.loss_rows[i];
         }
         acc = wave_sum(acc) / (float)a.loss_m;
-        if (threadIdx.x == 0) { const float l = a.w_nce * acc + a.w_iic * iic; a.out[0] = l; a.out[1] = run + l; a.out[2] = acc; }
+        if (tix == 0) { const float l = a.w_nce * acc + a.w_iic * iic; a.out[0] = l; a.out[1] = run + l; a.out[2] = acc; }
     }
 }
 
@@ -1114,7 +1130,7 @@ static_assert(sizeof(RmsParams) + idl::PLAN_PARAMS <= idl::PLAN_BYTES, "RmsParam
 __global__ __launch_bounds__(256) void rmsprop_kernel(RmsArgs a, const float *hyper, int64_t *ctl, int64_t batch_advance, int gx,
                                                       int n_gather, idl_dev::GatherArgs g)
 {
-    rmsprop_body(a, hyper, ctl, batch_advance, gx, n_gather, g, (int)blockIdx.x);
+    rmsprop_body(a, hyper, ctl, batch_advance, gx, n_gather, g, (int)blockIdx.x, (int)threadIdx.x);
 }
 
 // The optimizer launch with the LARGE weight gradient at its head (wgrad_device.h): the first w.tiles workgroups each accumulate a
@@ -1140,7 +1156,7 @@ __global__ __launch_bounds__(wg_dev::THREADS) void wgrad_rmsprop_kernel(wg_dev::
         // priority these workgroups crawl beside it (measured with the stamps: 40 us for 5 us of work, and the tiles 3..16 us longer
         // wherever they met a dW2 tile); ahead of it they are gone after a few microseconds
         __builtin_amdgcn_s_setprio(3);
-        rmsprop_body<true>(a, hyper, ctl, batch_advance, 0, n_gather, g, (int)blockIdx.x - w.tiles);
+        rmsprop_body<true>(a, hyper, ctl, batch_advance, 0, n_gather, g, (int)blockIdx.x - w.tiles, (int)threadIdx.x);
     }
     if (STAMPS) {
         __syncthreads();
@@ -1170,7 +1186,7 @@ __global__ __launch_bounds__(l1_dev::THREADS, 4) void l1_rms_kernel(l1_dev::L1Ar
     extern __shared__ __attribute__((aligned(1024))) unsigned char l1_rms_smem[];
     if ((int)blockIdx.x < l.n_tiles) { l1_dev::l1_fwd_body<false, 0>(l, (int)blockIdx.x, l1_rms_smem); return; }
     if (threadIdx.x >= RMS_THREADS) return;                  // (before any barrier: rmsprop_body is written for 256 threads)
-    rmsprop_body<false>(a, hyper, ctl, batch_advance, 0, 0, idl_dev::GatherArgs{}, (int)blockIdx.x - l.n_tiles);
+    rmsprop_body<false>(a, hyper, ctl, batch_advance, 0, 0, idl_dev::GatherArgs{}, (int)blockIdx.x - l.n_tiles, (int)threadIdx.x);
 }
 
 // The same with the layer-1 tiles of l1_planes_device.h (the product on the fp16 matrix cores from two-plane operands).  A tile
@@ -1180,7 +1196,7 @@ __global__ __launch_bounds__(l1p_dev::THREADS, 1) void l1p_rms_kernel(l1p_dev::L
     extern __shared__ __attribute__((aligned(16))) unsigned char l1p_rms_smem[];
     if ((int)blockIdx.x < l.n_tiles) { l1p_dev::l1p_body(l, (int)blockIdx.x, l1p_rms_smem); return; }
     if (threadIdx.x >= RMS_THREADS) return;                  // (before any barrier: rmsprop_body is written for 256 threads)
-    rmsprop_body<false>(a, hyper, ctl, batch_advance, 0, 0, idl_dev::GatherArgs{}, (int)blockIdx.x - l.n_tiles);
+    rmsprop_body<false>(a, hyper, ctl, batch_advance, 0, 0, idl_dev::GatherArgs{}, (int)blockIdx.x - l.n_tiles, (int)threadIdx.x);
 }
 
 // The launch between the two-plane layer-1 tiles (idl_l1_planes) and mid_fwd: its first r.blocks workgroups add the KPARTS partial sums
@@ -1213,14 +1229,31 @@ __global__ __launch_bounds__(256) void reduce_rms_kernel(ReduceArgs r, RmsArgs a
     }
     // (the look-ahead form of the dW2 tiles -- every operand of a wave requested before its first product: one trip to memory instead of
     //  three -- as behind the dW1 tiles of wgrad_rmsprop_kernel: here too the tail's chain is the launch's length, 9.3 us without)
-    if (with_tail) rmsprop_body<true>(a, hyper, ctl, batch_advance, 0, 0, idl_dev::GatherArgs{}, (int)blockIdx.x);
+    if (with_tail) rmsprop_body<true>(a, hyper, ctl, batch_advance, 0, 0, idl_dev::GatherArgs{}, (int)blockIdx.x, (int)threadIdx.x);
+}
+
+// The dW1 tiles of the two-plane form (wgrad_planes_device.h) with THIS step's optimizer tail carried by their loader waves: a workgroup's four
+// loaders have their last chunk in two chunks before its computing waves start the epilogue (16 MB of W / square_avg / plane stores, ~5 us
+// of the launch), and from then on have nothing to do -- block b of the tail (b < n_tail <= the tiles) is run by the loaders of workgroup
+// b, in rmsprop_body's SPIN form (no s_barrier: the computing waves would not come).  The step counter and batch offset move at the
+// END of this launch (every workgroup read the counter when it started: all tiles are resident at once, one per CU; the launcher
+// refuses more tiles than CUs), so the next step's first launch adds up its partial sums alone (4.7 us instead of 9.4 with the tail).
+__global__ __launch_bounds__(wgp_dev::NT, 1) void wgrad_xplanes_rms_kernel(wgp_dev::XpArgs x, RmsArgs a, const float *hyper, int64_t *ctl, int64_t batch_advance,
+                                                                           int n_tail)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char wgp_rms_smem[];
+    wgp_dev::xplanes_body(x, wgp_rms_smem, [&](int tix) {
+        if ((int)blockIdx.x < n_tail)
+            rmsprop_body<true, true>(a, hyper, ctl, batch_advance, 0, 0, idl_dev::GatherArgs{}, (int)blockIdx.x, tix,
+                                     (unsigned int *)(wgp_rms_smem + wgp_dev::LDS_BYTES) + 3);
+    });
 }
 
 // several voters in one launch: voter blockIdx.y takes its arguments from its plan record
 __global__ __launch_bounds__(256) void rmsprop_batched_kernel(const unsigned char *__restrict__ plans)
 {
     const RmsParams &p = *(const RmsParams *)(plans + (size_t)blockIdx.y * idl::PLAN_BYTES + idl::PLAN_PARAMS);
-    rmsprop_body(p.a, p.hyper, p.ctl, p.batch_advance, 0, p.n_gather, p.g, (int)blockIdx.x);
+    rmsprop_body(p.a, p.hyper, p.ctl, p.batch_advance, 0, p.n_gather, p.g, (int)blockIdx.x, (int)threadIdx.x);
 }
 
 // ... and the optimizer launch with the dW1 tiles at its head (wgrad_rmsprop_kernel) for several voters
@@ -1235,7 +1268,7 @@ __global__ __launch_bounds__(wg_dev::THREADS) void wgrad_rmsprop_batched_kernel(
     if ((int)blockIdx.x < p.w.tiles) wg_dev::q16_tile<0>(p.w, (int)blockIdx.x, wg_img);
     else {
         __builtin_amdgcn_s_setprio(3);
-        rmsprop_body<true>(p.r.a, p.r.hyper, p.r.ctl, p.r.batch_advance, 0, p.r.n_gather, p.r.g, (int)blockIdx.x - p.w.tiles);
+        rmsprop_body<true>(p.r.a, p.r.hyper, p.r.ctl, p.r.batch_advance, 0, p.r.n_gather, p.r.g, (int)blockIdx.x - p.w.tiles, (int)threadIdx.x);
     }
 }
 
@@ -1617,7 +1650,7 @@ static int rmsprop_launch(int count, float *const *params, const float *const *g
                           void *stream, int wg_index = -1, const float *wg_dy = nullptr, const float *wg_x = nullptr, int wg_m = 0,
                           int wg_n_out = 0, int wg_n_in = 0, float *wg_grad = nullptr, int wg_x_transposed = 0,
                           const wg_dev::WgArgs *big = nullptr, int big_index = -1, const l1_dev::L1Args *l1 = nullptr, int skip_index = -1,
-                          const l1p_dev::L1pArgs *l1p = nullptr, const ReduceArgs *red = nullptr)
+                          const l1p_dev::L1pArgs *l1p = nullptr, const ReduceArgs *red = nullptr, const wgp_dev::XpArgs *xp = nullptr)
 {
     IDL_REQUIRE(count >= 1 && count <= 8 && params && grads && square_avg && sizes && hyper && ctl, "rmsprop_step: 1..8 tensors");
     RmsArgs a{};
@@ -1661,6 +1694,24 @@ static int rmsprop_launch(int count, float *const *params, const float *const *g
     if (nb_total == 0) nb_total = 1;        // (step counter / loss assembly still need a block)
     for (int i = count; i <= 8; ++i) a.first[i] = nb_total;
     const int64_t extra = g.y != nullptr ? idl_dev::gather_blocks(g.f, g.batch) : 0;
+    if (xp != nullptr) {                    // ... carried by the loader waves of the two-plane dW1 tiles (wgrad_xplanes_rms_kernel)
+        IDL_REQUIRE(big == nullptr && l1 == nullptr && l1p == nullptr && red == nullptr && extra == 0 && idl::take_plan() == nullptr,
+                    "wgrad_xplanes_rms: no other tiles, no batch assembly, not recordable");
+        idl::DeviceInfo di;
+        if (const int rc = idl::device_info(&di); rc != IDL_OK) return rc;
+        IDL_REQUIRE(nb_total + a.wg_tiles <= xp->tiles && xp->tiles <= di.cus, "wgrad_xplanes_rms: the tail's blocks need a tile each, and every tile its own CU");
+        static bool attr_set[64] = {};
+        int dev = 0;
+        IDL_HIP_TRY(hipGetDevice(&dev));
+        if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+            IDL_HIP_TRY(hipFuncSetAttribute((const void *)wgrad_xplanes_rms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, wgp_dev::LDS_BYTES + 16));
+            attr_set[dev] = true;
+        }
+        hipLaunchKernelGGL(wgrad_xplanes_rms_kernel, dim3((unsigned)xp->tiles), dim3(wgp_dev::NT), wgp_dev::LDS_BYTES + 16, (hipStream_t)stream, *xp, a, hyper,
+                           ctl, batch_advance, nb_total + a.wg_tiles);
+        IDL_HIP_TRY(hipGetLastError());
+        return IDL_OK;
+    }
     if (red != nullptr) {                   // ... beside the workgroups that add up the two-plane layer-1 tiles' partial sums (reduce_rms_kernel)
         IDL_REQUIRE(big == nullptr && l1 == nullptr && l1p == nullptr && extra == 0 && idl::take_plan() == nullptr, "reduce_parts_rms: no tiles, no batch assembly, not recordable");
         hipLaunchKernelGGL(reduce_rms_kernel, dim3((unsigned)(red->blocks + nb_total + a.wg_tiles)), dim3(256), 0, (hipStream_t)stream, *red, a, hyper, ctl,
@@ -1854,6 +1905,34 @@ int idl_reduce_parts_rms(float *part, int64_t slab_elems,
     idl_dev::GatherArgs g{};
     return rmsprop_launch(count, params, grads, grad_parts, square_avg, sizes, hyper, ctl, batch_advance, loss_rows, loss_m, w_nce, w_iic, out, g,
                           stream, wg_index, wg_dy, wg_x, wg_m, wg_n_out, wg_n_in, wg_grad, wg_x_transposed, nullptr, -1, nullptr, w1_index, nullptr, &r);
+}
+
+// idl_wgrad_rmsprop_xplanes (W updated, its planes written) with THIS step's optimizer tail carried by the tiles' loader waves (tail arguments as
+// idl_l1_fwd_rms; w1_index: the tensor the tiles update, left out of the tail).  Needs a CU per tile and no more tail blocks than tiles.
+int idl_wgrad_xplanes_rms(const float *dy, const void *x_hi, const void *x_lo, int ld_x, int m, int n_out, int n_in, float *grad, float *W, float *square_avg,
+                          unsigned long long *state, void *w_hi, void *w_lo, int *overflow_flag,
+                          int count, float *const *params, const float *const *grads, const int32_t *grad_parts,
+                          float *const *square_avg_all, const int64_t *sizes, const float *hyper, int64_t *ctl,
+                          const float *loss_rows, int loss_m, float w_nce, float w_iic, float *out, int w1_index,
+                          int wg_index, const float *wg_dy, const float *wg_x, int wg_x_transposed, int wg_m, int wg_n_out, int wg_n_in,
+                          float *wg_grad, int64_t batch_advance, void *stream)
+{
+    IDL_REQUIRE(dy && x_hi && x_lo && state && W && square_avg && hyper && ctl && w_hi && w_lo && overflow_flag, "wgrad_xplanes_rms: NULL buffer");
+    IDL_REQUIRE(m % wgp_dev::KC == 0 && m / wgp_dev::KC >= 2 * wgp_dev::PF && n_out >= wgp_dev::TM && n_out % wgp_dev::TM == 0 && n_in >= wgp_dev::TN &&
+                n_in % wgp_dev::TN == 0 && (int64_t)m * (n_in + 1024) < (1ll << 29) && (int64_t)n_out * n_in < (1ll << 29),
+                "wgrad_xplanes_rms: m % 32 == 0, m >= 192, n_out % 64 == 0, n_in % 128 == 0");
+    IDL_REQUIRE(ld_x >= n_in && ld_x <= n_in + 1024 && (ld_x & 7) == 0, "wgrad_xplanes_rms: n_in <= ld_x <= n_in + 1024, 8 | ld_x");
+    IDL_REQUIRE((((uintptr_t)dy | (uintptr_t)x_hi | (uintptr_t)x_lo | (uintptr_t)grad | (uintptr_t)W | (uintptr_t)square_avg) & 15u) == 0 &&
+                (((uintptr_t)state | (uintptr_t)w_hi | (uintptr_t)w_lo) & 7u) == 0, "wgrad_xplanes_rms: buffers 16-byte aligned, state and W's planes 8-byte");
+    wgp_dev::XpArgs x{};
+    x.dy = dy; x.xh = (const uint16_t *)x_hi; x.xl = (const uint16_t *)x_lo; x.grad = grad; x.W = W; x.V = square_avg;
+    x.wh = (uint16_t *)w_hi; x.wl = (uint16_t *)w_lo; x.over = overflow_flag; x.hyper = hyper; x.ctl = (const long long *)ctl; x.state = state;
+    x.m = m; x.n_out = n_out; x.n_in = n_in; x.ldx = ld_x;
+    x.tiles_m = n_out / wgp_dev::TM; x.tiles = x.tiles_m * (n_in / wgp_dev::TN);
+    x.dbg = 0;
+    idl_dev::GatherArgs g{};
+    return rmsprop_launch(count, params, grads, grad_parts, square_avg_all, sizes, hyper, ctl, batch_advance, loss_rows, loss_m, w_nce, w_iic, out, g,
+                          stream, wg_index, wg_dy, wg_x, wg_m, wg_n_out, wg_n_in, wg_grad, wg_x_transposed, nullptr, -1, nullptr, w1_index, nullptr, nullptr, &x);
 }
 
 int idl_debug_phase_stamps(int on)

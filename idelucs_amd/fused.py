@@ -173,6 +173,10 @@ class FusedLinearTrainer:
         self._planes_fork = os.environ.get("IDELUCS_PLANES_FORK", "0") == "1"
         # ... and dW1 from the batch's planes too (csrc/wgrad_planes.hip); the assembling workgroups then write the planes ONLY
         self._planes_wgrad = os.environ.get("IDELUCS_PLANES_WGRAD", "1") != "0"
+        # ... whose loader waves run the step's optimizer tail under the tiles' epilogue (IDELUCS_PLANES_TAIL=reduce: the tail beside the
+        # next step's partial sums instead, 9.4 us for that launch against 4.7)
+        self._planes_tail_wgrad = os.environ.get("IDELUCS_PLANES_TAIL", "wgrad") != "reduce"
+        self._cus = torch.cuda.get_device_properties(self.dev).multi_processor_count if self.dev.type == "cuda" else 0
         self._w1_planes = None                   # (W1 hi, W1 lo, overflow flag)
         self._w1_planes_fresh = False
         # the layers between the two big GEMMs as one 1024-thread MFMA kernel per direction (idl_mid_fwd / idl_mid_bwd)
@@ -484,6 +488,17 @@ class FusedLinearTrainer:
                 wh, wl, flag = self._w1_planes
                 if self._split_state is None:
                     self._split_state = torch.zeros(int(_L.idl_wgrad_split_state_words()), dtype=torch.int64, device=self.dev)
+                # (a tile per CU, and a tile for each of the tail's blocks: 128 dW2 tiles + at most 16 blocks for the small tensors)
+                if self._planes_tail_wgrad and 144 <= (self.H1 // 64) * (self.F // 128) <= self._cus:
+                    # ... and THIS step's optimizer tail is run by the tiles' loader waves under the tiles' epilogue: nothing is pending
+                    tail = (len(self.params), self._pp, self._gp, self._parts, self._vp, self._sz, _p(self.hyper),
+                            _p(self.ctl), _p(bf.loss_rows), m, 1.0 - self.weight, self.weight, _p(self.out))
+                    wg = (2, _p(bf.dlat), _p(r1), 1, m, self.H2, self.H1, _p(self.grads[2]), m // 2, _stream())
+                    chk(_L.idl_wgrad_xplanes_rms(_p(bf.dr1), _p(pb["xh"][xi]), _p(pb["xl"][xi]), self.F, m, self.H1, self.F,
+                                                 _p(gW1) if self._keep_w1_grad else None, _p(self.W1), _p(self.square_avg[0]),
+                                                 _p(self._split_state), _p(wh), _p(wl), _p(flag), *tail, 0, *wg))
+                    self._pending = None
+                    return
                 chk(_L.idl_wgrad_rmsprop_xplanes(_p(bf.dr1), _p(pb["xh"][xi]), _p(pb["xl"][xi]), self.F, m, self.H1, self.F,
                                                  _p(gW1) if self._keep_w1_grad else None, _p(self.W1), _p(self.square_avg[0]), _p(self.hyper),
                                                  _p(self.ctl), _p(self._split_state), _p(wh), _p(wl), _p(flag), _stream()))

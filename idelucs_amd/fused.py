@@ -295,11 +295,22 @@ class FusedLinearTrainer:
         # ... with the layer-1 product from two-plane operands (IDELUCS_PLANES=1)
         pl = (tm and self._planes and bool(_L.idl_l1_planes_supported(m, self.H1, self.F)) and next_from.n < 60_000_000)
         plw = pl and self._planes_wgrad and bool(_L.idl_wgrad_xplanes_supported(m, self.H1, self.F))
-        pb = _planes_of(bf, self.F) if pl else None
-        if not plw and getattr(bf, "_planes", None) is not None and not bf._planes["x32"][xi]:
+        # ... and the same two products in the step of n_clusters > 48 (the fine-grained mode's 200 output units: separate backward kernels, the
+        # whole batch assembled by the mid-forward launch, activations NOT transposed): the layer-1 tiles with the operands' roles swapped
+        # give part[8][m][512]; the dW1 kernel with the tail on its loader waves ends the step
+        plf = (self._planes and self._planes_wgrad and self._planes_reduce_launch and self._planes_tail_wgrad and early_f and not early
+               and not tm and self._rec is None and self._wgrad_fused and not self._wgrad_own_launch and self._dw2_inlaunch
+               and not self._shared_buffers and bool(_L.idl_l1_planes_supported(self.H1, m, self.F))
+               and bool(_L.idl_wgrad_xplanes_supported(m, self.H1, self.F)) and 144 <= (self.H1 // 64) * (self.F // 128) <= self._cus
+               and next_from.n < 60_000_000)
+        pb = _planes_of(bf, self.F) if (pl or plf) else None
+        if not (plw or plf) and getattr(bf, "_planes", None) is not None and not bf._planes["x32"][xi]:
             raise RuntimeError("the batch in this buffer was assembled as planes only: a step of another form cannot read it")
         if pl:
             r1 = pb["part"][xi][0]              # [H1, m]: slab 0 of the partial sums, where mid_fwd leaves the activations
+            self._prepare_planes(bf, pb, xi)
+        elif plf:
+            r1 = pb["part"][xi].view(-1, m, self.H1)[0]      # [m, H1]: slab 0 of part[8][m][512]
             self._prepare_planes(bf, pb, xi)
         else:
             r1 = _r1_of(bf, xi) if tm else bf.r1
@@ -347,6 +358,11 @@ class FusedLinearTrainer:
                 self._tail_launch(pbf, pxi, pr1, l1=(x, m, r1T))
             else:
                 chk(_L.idl_l1_fwd(_p(self.W1), _p(x), None, None, m, self.F, 0, 0, None, _p(r1T), 1, None, _stream()))
+        elif plf:   # a1 = x W1^T as eight K-slice partial sums [8][m][512] (the tiles of idl_l1_planes with the operands' roles swapped), then their sum
+            wh, wl, _ = self._w1_planes
+            chk(_L.idl_l1_planes(_p(pb["xh"][xi]), _p(pb["xl"][xi]), self.F, _p(wh), _p(wl), self.F, self.H1, m, self.F, _p(pb["part"][xi]), _stream()))
+            chk(_L.idl_reduce_parts_rms(_p(pb["part"][xi]), self.H1 * m, 0, None, None, None, None, None, None, None, None, 0, 0.0, 0.0, None, 0,
+                                        -1, None, None, 0, 0, 0, 0, None, 0, _stream()))
         elif l1:    # own tiles: r1^T = Dropout(ReLU(W1 x^T + b1)) and the partial sums of lat = r1 W2^T straight from the accumulators
             st = next_from      # ... with shares [0, g1) of the next batch's tiles assembled by riders of the same launch (HBM is idle under it)
             self._k(_L.idl_l1_fwd_gather, _p(self.W1), _p(x), _p(self.b1), _p(self.W2), m, self.F, tr, self.seed, _p(self.ctl), _p(r1), 1,
@@ -374,6 +390,15 @@ class FusedLinearTrainer:
                     _p(bf.f), _p(bf.inv), _p(bf.r2), _p(bf.z),
                     _p(st.feats), st.n, st.f, st.n * st.f, _p(self._perm), _p(self.ctl[1:]), m // 2, st.n_pairs, m // 2,
                     _p(st.mean), _p(st.scale), _p(st.inv_scale), _p(bf.xs[1 - xi]), g1, g2, 8, _stream())
+        elif plf:   # (the bias of Linear(F,512) is added here; the whole next batch assembled as planes only)
+            st = next_from
+            chk(_L.idl_mid_fwd_gather_planes(_p(r1), _p(self.b1), 0, _p(self.W2), _p(self.b2), _p(self.W3), _p(self.b3),
+                                             m, C, tr, self.seed, _p(self.ctl), _p(bf.f), _p(bf.inv), _p(bf.r2), _p(bf.z),
+                                             _p(st.feats), st.n, st.f, st.n * st.f, _p(self._perm), _p(self.ctl[1:]), m // 2, st.n_pairs, m // 2,
+                                             _p(st.mean), _p(st.scale), _p(st.inv_scale), None, _p(pb["xh"][1 - xi]), _p(pb["xl"][1 - xi]),
+                                             0, 8, 8, _stream()))
+            pb["valid"][1 - xi] = True
+            pb["x32"][1 - xi] = False
         elif early_f:
             st = next_from
             chk(_L.idl_mid_fwd_gather(_p(r1), None, 0, _p(self.W2), _p(self.b2), _p(self.W3), _p(self.b3),
@@ -518,6 +543,18 @@ class FusedLinearTrainer:
             self._pending = (bf, xi, r1)
             if not defer_tail:
                 self.flush_tail()
+            return
+        if plf:     # dW1 from the batch's planes with RMSprop and W1's planes in the epilogue; the rest of the optimizer on the loader waves
+            main.wait_stream(side)
+            wh, wl, flag = self._w1_planes
+            if self._split_state is None:
+                self._split_state = torch.zeros(int(_L.idl_wgrad_split_state_words()), dtype=torch.int64, device=self.dev)
+            tail = (len(self.params), self._pp, self._gp, self._parts, self._vp, self._sz, _p(self.hyper),
+                    _p(self.ctl), _p(bf.loss_rows), m, 1.0 - self.weight, self.weight, _p(self.out))
+            wg = (2, _p(bf.dlat), _p(r1), 0, m, self.H2, self.H1, _p(gW2), m // 2, _stream())
+            chk(_L.idl_wgrad_xplanes_rms(_p(bf.dr1), _p(pb["xh"][xi]), _p(pb["xl"][xi]), self.F, m, self.H1, self.F,
+                                         _p(gW1) if self._keep_w1_grad else None, _p(self.W1), _p(self.square_avg[0]),
+                                         _p(self._split_state), _p(wh), _p(wl), _p(flag), *tail, 0, *wg))
             return
         w1_fusable = self._wgrad_fused and bool(_L.idl_wgrad_supported(m, self.H1, self.F))
         # the tiles ride at the head of the optimizer launch where that launch has the form below; else as a launch of their own

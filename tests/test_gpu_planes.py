@@ -344,3 +344,42 @@ def test_step_on_planes_at_k5_shape(dev, monkeypatch):
             bf = tr.buffers(2 * B)
             assert getattr(bf, "_planes", None) is not None and tr._w1_planes is not None and not tr.planes_overflowed()
     assert np.isfinite(sums["1"]) and abs(sums["1"] - sums["0"]) <= 1e-3 * abs(sums["0"]), sums
+
+
+def test_step_on_planes_with_200_output_units(dev, monkeypatch):
+    """The fine-grained mode's step (n_clusters > 48: separate backward kernels, the whole next batch assembled by the mid-forward launch,
+    activations not transposed) in its two-plane form: one step from the same state has the fp32 form's loss within 2e-6 and dW1 within 1e-3 (max) /
+    2e-6 (mean) of the largest entry; two epochs follow the fp32 form's losses; the step counter and batch offset move as they do there."""
+    import torch
+    from idelucs_amd.fused import FusedLinearTrainer
+    store, net0 = _store_and_net(dev, 4096, seed=6, C=200)
+    B = 512
+    one, sums = {}, {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("IDELUCS_PLANES", flag)
+        tr = FusedLinearTrainer(copy.deepcopy(net0), lr=1e-3, weight=0.25, lamb=2.8, seed=5)
+        tr._keep_w1_grad = True
+        tr._perm = torch.randperm(store.n_pairs, device=dev, generator=torch.Generator(device=dev).manual_seed(1))
+        bf = tr.buffers(2 * B)
+        tr._gather(store, bf)
+        tr._full_step(store, bf, pipelined=True)
+        torch.cuda.synchronize()
+        one[flag] = (tr.out[0].item(), tr.grads[0].clone(), tr.ctl.tolist())
+        if flag == "1":
+            assert getattr(bf, "_planes", None) is not None and not bf._planes["x32"][1] and tr._w1_planes is not None
+        tr = FusedLinearTrainer(copy.deepcopy(net0), lr=1e-3, weight=0.25, lamb=2.8, seed=5)
+        gen = torch.Generator(device=dev); gen.manual_seed(123)
+        s_ = []
+        for _ in range(2):
+            total, nb = tr.run_epoch(store, B, use_graph=True, generator=gen)
+            s_.append(total.item())
+        sums[flag] = s_
+        if flag == "1":
+            assert not tr.planes_overflowed()
+    (l0, g0, c0), (l1, g1, c1) = one["0"], one["1"]
+    assert c0 == c1 == [1, B]
+    assert abs(l1 - l0) <= 2e-6 * abs(l0), (l0, l1)
+    assert ((g1 - g0).abs().max() / g0.abs().max()).item() < 1e-3 and ((g1 - g0).abs().mean() / g0.abs().max()).item() < 2e-6
+    # (the step losses of this mode change sign inside an epoch and their sum nearly cancels: the bound is per step, on losses of ~0.3)
+    for a_, b_, tol in zip(sums["0"], sums["1"], (1e-4, 1e-3)):
+        assert np.isfinite(b_) and abs(b_ - a_) <= tol * nb, (sums,)

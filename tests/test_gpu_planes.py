@@ -226,7 +226,7 @@ def _store_and_net(dev, n, seed=3, C=20):
     return E._cfg2_store_and_net(dev, n, seed=seed, C=C)
 
 
-@pytest.mark.parametrize("reduce", ["launch", "mid"])
+@pytest.mark.parametrize("reduce", ["launch", "mid", "tail_beside_the_sums", "fp32_wgrad"])
 def test_step_on_planes_trains_like_the_default_step(dev, monkeypatch, reduce):
     """IDELUCS_PLANES=1: the default launch sequence with the layer-1 product from two-plane operands.  (1) One step from the same state on the
     same batch: the loss within 2e-6, dr1 and dW1 within 2e-5 of their largest entries but for the few elements whose ReLU flips (a
@@ -237,7 +237,10 @@ def test_step_on_planes_trains_like_the_default_step(dev, monkeypatch, reduce):
     store, net0 = _store_and_net(dev, 4096, seed=6, C=20)
     B = 512
     one, sums = {}, {}
-    monkeypatch.setenv("IDELUCS_PLANES_REDUCE", reduce)
+    # the default (the sums as a launch, the tail on the dW1 kernel's loader waves) and the measured variants kept as switches
+    monkeypatch.setenv("IDELUCS_PLANES_REDUCE", "mid" if reduce == "mid" else "launch")
+    monkeypatch.setenv("IDELUCS_PLANES_TAIL", "reduce" if reduce == "tail_beside_the_sums" else "wgrad")
+    monkeypatch.setenv("IDELUCS_PLANES_WGRAD", "0" if reduce == "fp32_wgrad" else "1")
     for flag in ("0", "1"):
         monkeypatch.setenv("IDELUCS_PLANES", flag)
         tr = FusedLinearTrainer(copy.deepcopy(net0), lr=1e-3, weight=0.25, lamb=2.8, seed=5)
@@ -266,7 +269,7 @@ def test_step_on_planes_trains_like_the_default_step(dev, monkeypatch, reduce):
     assert ((g1 - g0).abs().max() / g0.abs().max()).item() < 1e-3 and ((g1 - g0).abs().mean() / g0.abs().max()).item() < 2e-6
     # (the second epoch: two fp32-grade implementations of a product part at the rate the step amplifies a rounding -- a gradient differing
     #  by 1e-6 flips ReLU / Dropout patterns a step later; measured 2.1e-4 here, 2e-4 .. 5e-4 over the epochs of tools/bench_planes.py)
-    for a_, b_, tol in zip(sums["0"], sums["1"], (5e-5, 1e-3)):
+    for a_, b_, tol in zip(sums["0"], sums["1"], (2e-4, 1e-3)):              # (first epoch: 7e-6 .. 8e-5 over the variants)
         assert np.isfinite(b_) and abs(b_ - a_) <= tol * abs(a_), (sums,)
 
 

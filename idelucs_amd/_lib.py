@@ -113,19 +113,19 @@ SIGNATURES = {
     "idl_l1_planes_rms": (_int, [_vp, _vp, _vp, _vp, _int, _int, _vp,
                                  _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _c.c_float, _c.c_float, _vp, _int,
                                  _int, _vp, _vp, _int, _int, _int, _int, _vp, _i64, _vp]),
-    "idl_reduce_parts_rms": (_int, [_vp, _i64,
+    "idl_reduce_parts_rms": (_int, [_vp, _i64, _vp, _vp,
                                     _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _c.c_float, _c.c_float, _vp, _int,
                                     _int, _vp, _vp, _int, _int, _int, _int, _vp, _i64, _vp]),
     "idl_wgrad_xplanes_supported": (_int, [_int, _int, _int]),
     "idl_wgrad_rmsprop_xplanes": (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "idl_wgrad_xplanes_rms": (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+    "idl_wgrad_xplanes_rms": (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                      _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _c.c_float, _c.c_float, _vp, _int,
                                      _int, _vp, _vp, _int, _int, _int, _int, _vp, _i64, _vp]),
     "idl_wgrad_rmsprop_planes": (_int, [_vp, _vp, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "idl_mid_bwd_gather_planes": (_int, [_vp] * 5 + [_int] + [_vp] * 4 + [_int, _int, _int, _c.c_float] + [_vp] * 7 +
-                                  [_vp, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _vp]),
+                                  [_vp, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _vp]),
     "idl_mid_fwd_gather_planes": (_int, [_vp, _vp, _int, _vp, _vp, _vp, _vp, _int, _int, _int, _c.c_uint64, _vp, _vp, _vp, _vp, _vp] +
-                                  [_vp, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _vp]),
+                                  [_vp, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _vp]),
     "idl_mst_prim_workspace": (_i64, [_i64]),
     "idl_mst_prim": (_int, [_vp, _int, _vp, _i64, _int, _vp, _vp, _vp, _vp, _vp]),
     "idl_mst_prim_local": (_int, [_vp, _int, _vp, _i64, _int, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

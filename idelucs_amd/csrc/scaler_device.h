@@ -35,6 +35,7 @@ struct GatherArgs {
     float *y;
     int64_t base_add;           // added to *base (a launch that assembles the batch AFTER the one the offset points at)
     uint16_t *yh, *yl;          // optional (gather_tile only): the batch ALSO as two fp16 planes [2 batch][f] (planes.h, scale 2^X_EXP)
+    int *over;                  // ... and the flag raised when an entry left the planes' range (|x| > 8 125: clamped in the planes)
 };
 
 // one workgroup copies + standardises one output row; rows [0, batch) are the "true" halves, [batch, 2*batch) the "modified" ones
@@ -147,7 +148,7 @@ __device__ __forceinline__ void gather_tile(const GatherArgs &g, int64_t blk, in
         if (g.yh != nullptr) {
             constexpr float ps = (float)(1 << idl_planes::X_EXP);
             uint2 h, l;
-            (void)idl_planes::split4(o.x * ps, o.y * ps, o.z * ps, o.w * ps, h, l);
+            if (idl_planes::split4(o.x * ps, o.y * ps, o.z * ps, o.w * ps, h, l) && g.over != nullptr) *g.over = 1;
             ((uint2 *)(g.yh + (rg * R + u) * g.f))[i] = h;
             ((uint2 *)(g.yl + (rg * R + u) * g.f))[i] = l;
         }

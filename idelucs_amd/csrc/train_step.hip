@@ -1203,13 +1203,17 @@ __global__ __launch_bounds__(l1p_dev::THREADS, 1) void l1p_rms_kernel(l1p_dev::L
 // part[p][i] in ascending p into part[0][i] (16-byte elements, all requests of a thread in flight before the first add) -- 16 MB read by
 // every CU at once instead of by mid_fwd's 64 workgroups -- and the workgroups behind them are the previous step's optimizer tail
 // (rmsprop_body), which nothing in this launch depends on: the two overlap.
-struct ReduceArgs { float4 *part; int64_t slab4; int n_parts, blocks; };      // slab4: 16-byte elements of a slab
+struct ReduceArgs { float4 *part; int64_t slab4; int n_parts, blocks; const int64_t *ctl_src; int64_t *ctl_snap; };      // slab4: 16-byte elements of a slab
+// (ctl_snap, only without a tail in the launch: a copy of the step counter for the dW1 launch that ends this step -- its workgroups read
+//  the counter when they start and its own loader waves move it when they end: on a GPU shared with another process not every tile starts
+//  before the first one ends)
 constexpr int RED_U = 2;
 __global__ __launch_bounds__(256) void reduce_rms_kernel(ReduceArgs r, RmsArgs a, const float *hyper, int64_t *ctl, int64_t batch_advance, int with_tail)
 {
     // grid order: the tail's workgroups FIRST (theirs is the longer chain: 7.1 us on its own against the sums' 4.7), the sums behind them
     const int n_tail = (int)gridDim.x - r.blocks;
     if ((int)blockIdx.x >= n_tail) {
+        if (r.ctl_snap != nullptr && (int)blockIdx.x == n_tail && threadIdx.x == 0) *r.ctl_snap = r.ctl_src[0];
         const int64_t i0 = (int64_t)((int)blockIdx.x - n_tail) * (256 * RED_U) + threadIdx.x;
         float4 v[RED_U][l1p_dev::KSPLIT];
 #pragma unroll
@@ -1315,7 +1319,7 @@ static int mid_fwd_gather_impl(float *a1, const float *b1, int a1_transposed, co
                        int C, int train, uint64_t seed, const int64_t *ctl, float *f, float *inv, float *r2, float *z,
                        const float *feats, int64_t n, int64_t fdim, int64_t view_stride, const int64_t *pair_idx, const int64_t *base,
                        int64_t base_add, int64_t n_pairs, int64_t batch, const double *mean, const double *scale,
-                       const double *inv_scale, float *y, int part, int part_end, int parts, void *stream, uint16_t *yh, uint16_t *yl)
+                       const double *inv_scale, float *y, int part, int part_end, int parts, void *stream, uint16_t *yh, uint16_t *yl, int *over = nullptr)
 {
     IDL_REQUIRE(a1 && W2 && b2 && W3 && b3 && ctl && f && inv && r2 && z, "NULL buffer");
     IDL_REQUIRE(m >= 16 && (m % 16) == 0 && C >= 1 && C <= 64 * MAX_CPL, "mid_fwd: m must be a multiple of 16, n_clusters in 1..256");
@@ -1331,7 +1335,7 @@ static int mid_fwd_gather_impl(float *a1, const float *b1, int a1_transposed, co
     if (feats != nullptr) {                  // (feats == NULL: no batch assembly in this launch)
         IDL_REQUIRE(pair_idx && mean && scale && (y || yh) && n >= 1 && fdim >= 4 && (fdim & 3) == 0 && batch >= 1 && n_pairs >= 0,
                     "mid_fwd_gather: bad gather arguments (4 | f)");
-        g = idl_dev::GatherArgs{feats, n, fdim, view_stride, pair_idx, base, batch, n_pairs, mean, scale, inv_scale, y, base_add, yh, yl};
+        g = idl_dev::GatherArgs{feats, n, fdim, view_stride, pair_idx, base, batch, n_pairs, mean, scale, inv_scale, y, base_add, yh, yl, over};
         const int64_t ng = idl_dev::gather_tiles<MID_GATHER_ROWS>(fdim, batch);
         t0 = ng * part / parts; t1 = ng * part_end / parts;
     }
@@ -1372,10 +1376,12 @@ int idl_mid_fwd_gather_planes(float *a1, const float *b1, int a1_transposed, con
                               int C, int train, uint64_t seed, const int64_t *ctl, float *f, float *inv, float *r2, float *z,
                               const float *feats, int64_t n, int64_t fdim, int64_t view_stride, const int64_t *pair_idx, const int64_t *base,
                               int64_t base_add, int64_t n_pairs, int64_t batch, const double *mean, const double *scale,
-                              const double *inv_scale, float *y, void *y_hi, void *y_lo, int part, int part_end, int parts, void *stream)
+                              const double *inv_scale, float *y, void *y_hi, void *y_lo, int *overflow_flag, int part, int part_end, int parts,
+                              void *stream)
 {
     return mid_fwd_gather_impl(a1, b1, a1_transposed, W2, b2, W3, b3, m, C, train, seed, ctl, f, inv, r2, z, feats, n, fdim, view_stride, pair_idx, base,
-                               base_add, n_pairs, batch, mean, scale, inv_scale, y, part, part_end, parts, stream, (uint16_t *)y_hi, (uint16_t *)y_lo);
+                               base_add, n_pairs, batch, mean, scale, inv_scale, y, part, part_end, parts, stream, (uint16_t *)y_hi, (uint16_t *)y_lo,
+                               overflow_flag);
 }
 
 int idl_nce_rows(float *S, int m, float temperature, float *lse, float *loss_rows, void *stream)
@@ -1511,7 +1517,7 @@ static int mid_bwd_gather_impl(const float *z, const float *r2, const float *f, 
                        const float *feats, int64_t n, int64_t fdim, int64_t view_stride, const int64_t *pair_idx, const int64_t *base,
                        int64_t base_add, int64_t n_pairs, int64_t batch, const double *mean, const double *scale,
                        const double *inv_scale, float *y, int part, int part_end, int parts, int act1_transposed, void *stream,
-                       uint16_t *yh, uint16_t *yl)
+                       uint16_t *yh, uint16_t *yl, int *over = nullptr)
 {
     IDL_REQUIRE((yh != nullptr) == (yl != nullptr) && (yh == nullptr || (feats != nullptr && ((((uintptr_t)yh) | ((uintptr_t)yl)) & 7u) == 0)),
                 "mid_bwd_gather: both planes of the next batch (8-byte aligned) or neither; planes need the batch assembly");
@@ -1530,7 +1536,7 @@ static int mid_bwd_gather_impl(const float *z, const float *r2, const float *f, 
     if (feats != nullptr) {                  // (feats == NULL: no batch assembly in this launch)
         IDL_REQUIRE(pair_idx && mean && scale && (y || yh) && n >= 1 && fdim >= 4 && (fdim & 3) == 0 && batch >= 1 && n_pairs >= 0,
                     "mid_bwd_gather: bad gather arguments (4 | f)");
-        g = idl_dev::GatherArgs{feats, n, fdim, view_stride, pair_idx, base, batch, n_pairs, mean, scale, inv_scale, y, base_add, yh, yl};
+        g = idl_dev::GatherArgs{feats, n, fdim, view_stride, pair_idx, base, batch, n_pairs, mean, scale, inv_scale, y, base_add, yh, yl, over};
         const int64_t ng = idl_dev::gather_tiles<MID_GATHER_ROWS>(fdim, batch);
         t0 = ng * part / parts; t1 = ng * part_end / parts;
     }
@@ -1569,12 +1575,12 @@ int idl_mid_bwd_gather_planes(const float *z, const float *r2, const float *f, c
                               float *dlat, float *dr1, float *partial1, float *partial2, float *partial3, float *dW3_partial,
                               const float *feats, int64_t n, int64_t fdim, int64_t view_stride, const int64_t *pair_idx, const int64_t *base,
                               int64_t base_add, int64_t n_pairs, int64_t batch, const double *mean, const double *scale,
-                              const double *inv_scale, float *y, void *y_hi, void *y_lo, int part, int part_end, int parts, int act1_transposed,
-                              void *stream)
+                              const double *inv_scale, float *y, void *y_hi, void *y_lo, int *overflow_flag, int part, int part_end, int parts,
+                              int act1_transposed, void *stream)
 {
     return mid_bwd_gather_impl(z, r2, f, inv, G, g_parts, dP0, W3, W2, act1, m, C, train, nce_coef, dlogits, dlat, dr1, partial1, partial2, partial3,
                                dW3_partial, feats, n, fdim, view_stride, pair_idx, base, base_add, n_pairs, batch, mean, scale, inv_scale, y, part,
-                               part_end, parts, act1_transposed, stream, (uint16_t *)y_hi, (uint16_t *)y_lo);
+                               part_end, parts, act1_transposed, stream, (uint16_t *)y_hi, (uint16_t *)y_lo, overflow_flag);
 }
 
 int idl_col_sum_parts(void) { return COL_PARTS; }
@@ -1887,7 +1893,7 @@ int idl_l1_planes_rms(const void *w_hi, const void *w_lo, const void *x_hi, cons
 
 // part[p][i], p < idl_l1_planes_parts(), i < slab_elems (4 | slab_elems): part[0][i] = ((part[0][i] + part[1][i]) + ...) in ascending p.
 // With count >= 1: the previous step's optimizer tail in the same launch (arguments as idl_l1_fwd_rms); count == 0: the sums alone.
-int idl_reduce_parts_rms(float *part, int64_t slab_elems,
+int idl_reduce_parts_rms(float *part, int64_t slab_elems, const int64_t *step_counter, int64_t *step_snapshot,
                          int count, float *const *params, const float *const *grads, const int32_t *grad_parts,
                          float *const *square_avg, const int64_t *sizes, const float *hyper, int64_t *ctl,
                          const float *loss_rows, int loss_m, float w_nce, float w_iic, float *out, int w1_index,
@@ -1895,7 +1901,9 @@ int idl_reduce_parts_rms(float *part, int64_t slab_elems,
                          float *wg_grad, int64_t batch_advance, void *stream)
 {
     IDL_REQUIRE(part && slab_elems >= 4 && (slab_elems & 3) == 0 && (((uintptr_t)part) & 15u) == 0 && slab_elems < (1ll << 31), "reduce_parts_rms: 4 | slab_elems, 16-byte aligned");
-    ReduceArgs r{(float4 *)part, slab_elems / 4, l1p_dev::KSPLIT, (int)((slab_elems / 4 + 256 * RED_U - 1) / (256 * RED_U))};
+    IDL_REQUIRE((step_counter != nullptr) == (step_snapshot != nullptr) && (step_snapshot == nullptr || count == 0),
+                "reduce_parts_rms: the step counter's snapshot needs both pointers and a launch without the tail (which moves the counter)");
+    ReduceArgs r{(float4 *)part, slab_elems / 4, l1p_dev::KSPLIT, (int)((slab_elems / 4 + 256 * RED_U - 1) / (256 * RED_U)), step_counter, step_snapshot};
     if (count == 0) {
         hipLaunchKernelGGL(reduce_rms_kernel, dim3((unsigned)r.blocks), dim3(256), 0, (hipStream_t)stream, r, RmsArgs{}, (const float *)nullptr, (int64_t *)nullptr,
                            (int64_t)0, 0);
@@ -1910,7 +1918,7 @@ int idl_reduce_parts_rms(float *part, int64_t slab_elems,
 // idl_wgrad_rmsprop_xplanes (W updated, its planes written) with THIS step's optimizer tail carried by the tiles' loader waves (tail arguments as
 // idl_l1_fwd_rms; w1_index: the tensor the tiles update, left out of the tail).  Needs a CU per tile and no more tail blocks than tiles.
 int idl_wgrad_xplanes_rms(const float *dy, const void *x_hi, const void *x_lo, int ld_x, int m, int n_out, int n_in, float *grad, float *W, float *square_avg,
-                          unsigned long long *state, void *w_hi, void *w_lo, int *overflow_flag,
+                          unsigned long long *state, const int64_t *step_snapshot, void *w_hi, void *w_lo, int *overflow_flag,
                           int count, float *const *params, const float *const *grads, const int32_t *grad_parts,
                           float *const *square_avg_all, const int64_t *sizes, const float *hyper, int64_t *ctl,
                           const float *loss_rows, int loss_m, float w_nce, float w_iic, float *out, int w1_index,
@@ -1926,7 +1934,9 @@ int idl_wgrad_xplanes_rms(const float *dy, const void *x_hi, const void *x_lo, i
                 (((uintptr_t)state | (uintptr_t)w_hi | (uintptr_t)w_lo) & 7u) == 0, "wgrad_xplanes_rms: buffers 16-byte aligned, state and W's planes 8-byte");
     wgp_dev::XpArgs x{};
     x.dy = dy; x.xh = (const uint16_t *)x_hi; x.xl = (const uint16_t *)x_lo; x.grad = grad; x.W = W; x.V = square_avg;
-    x.wh = (uint16_t *)w_hi; x.wl = (uint16_t *)w_lo; x.over = overflow_flag; x.hyper = hyper; x.ctl = (const long long *)ctl; x.state = state;
+    x.wh = (uint16_t *)w_hi; x.wl = (uint16_t *)w_lo; x.over = overflow_flag; x.hyper = hyper; x.state = state;
+    // (the launch number behind dr1's scale: from the snapshot the step's reduce launch took, not from the counter this launch's own tail moves)
+    x.ctl = step_snapshot != nullptr ? (const long long *)step_snapshot : (const long long *)ctl;
     x.m = m; x.n_out = n_out; x.n_in = n_in; x.ldx = ld_x;
     x.tiles_m = n_out / wgp_dev::TM; x.tiles = x.tiles_m * (n_in / wgp_dev::TN);
     x.dbg = 0;

@@ -20,7 +20,7 @@ __global__ __launch_bounds__(NT, 1) void wgrad_xplanes_kernel(XpArgs a)
 extern "C" int idl_wgrad_xplanes_supported(int m, int n_out, int n_in)
 {
     return (m % KC == 0 && m / KC >= 2 * PF && n_out >= TM && n_out % TM == 0 && n_in >= TN && n_in % TN == 0 &&
-            (int64_t)m * (n_in + 1024) < (1ll << 29) && (int64_t)n_out * n_in < (1ll << 29) && (n_out / TM) * (n_in / TN) * 4 <= STATE_SLOTS) ? 1 : 0;
+            (int64_t)m * (n_in + 1024) < (1ll << 29) && (int64_t)n_out * n_in < (1ll << 29) && (n_out / TM) * (n_in / TN) <= STATE_ARRAY) ? 1 : 0;
 }
 
 extern "C" int idl_wgrad_rmsprop_xplanes(const float *dy, const void *x_hi, const void *x_lo, int ld_x, int m, int n_out, int n_in, float *grad, float *W,

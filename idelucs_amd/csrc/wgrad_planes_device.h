@@ -53,7 +53,8 @@ constexpr int ND = 3, NX = PF + 3;                           // stages of dy (de
 constexpr int DY_BYTES = ND * DSTAGE;                        // 49 152
 constexpr int LDS_BYTES = DY_BYTES + NX * XSTAGE;            // 147 456
 constexpr int K_FIRST = 10, K_TARGET = 12;
-constexpr int STATE_SLOTS = 4096;
+constexpr int STATE_SLOTS = 4096;                            // (the state buffer is wgrad_split.hip's: 2 x 4096 words)
+constexpr int STATE_ARRAY = 2048;                            // three arrays of a word per workgroup (launch number % 3) inside it: <= 2048 tiles
 
 struct XpArgs {
     const float *dy;                       // [m][n_out]
@@ -63,7 +64,7 @@ struct XpArgs {
     int *over;
     const float *hyper;
     const long long *ctl;
-    unsigned long long *state;             // as wgrad_split.hip: [2][STATE_SLOTS] tagged maxima of |dy|
+    unsigned long long *state;             // [3][STATE_ARRAY] tagged maxima of |dy| (launch number << 32 | float bits), a word per workgroup, by launch number % 3
     int m, n_out, n_in, ldx, tiles_m, tiles;
     int dbg;                               // diagnostics (IDELUCS_WGP_DBG; wrong results): 8 no epilogue
 };
@@ -111,32 +112,39 @@ __device__ __forceinline__ void xplanes_body(const XpArgs &a, unsigned char *sme
     const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
     // the launch's number and the scale of dy (wgrad_split.hip)
     const unsigned long long t = a.ctl != nullptr ? (unsigned long long)a.ctl[0] + 1ull : 1ull;
-    // (words of BOTH parities whose tag is one of the last three launch numbers: a step of another form in between -- the epoch's partial last
-    //  batch runs the fp32 tiles and moves the counter on -- must not send the next launch back to the default scale)
+    // Launch t writes its words into array t % 3 and reads the arrays of t - 1 and t - 2, which nobody writes while it runs: every workgroup of a
+    // launch derives the SAME scale whenever it starts (on a GPU shared with another process not all tiles are resident at once, and a tile
+    // that starts late must not see this launch's own words).  The words of t - 1 if there are any, else those of t - 2 (a step of another
+    // form in between -- the epoch's partial last batch runs the fp32 tiles and moves the counter on), else the default scale.
     // ONE wave reads them and hands the exponent to the others through LDS: the loaders that split dy and the computing waves that scale the
-    // tile back must agree, and workgroups of this very launch that have finished write words of their own meanwhile.  It is a COMPUTING wave
-    // (idle until the first chunk is in): the loaders have their first requests out before they meet it at the barrier.
+    // tile back must agree.  It is a COMPUTING wave (idle until the first chunk is in): the loaders have their first requests out before they
+    // meet it at the barrier.
     float mxp = 0.f;
     if (wv == 0) {
         // a word per WORKGROUP of a launch (its four loader waves fold their maxima in LDS first), all requests of a lane in flight before the
         // first compare: with a word per loader wave and a plain loop every wave of every launch spent 16 dependent round trips here (2.7 us)
         const int n_words = (int)gridDim.x;
+        float mx[2] = {0.f, 0.f};
+        int has[2] = {0, 0};
 #pragma unroll
-        for (int par = 0; par < 2; ++par) {
-            const unsigned long long *pv = a.state + par * STATE_SLOTS;
+        for (int back = 0; back < 2; ++back) {               // back = 0: launch t - 1, 1: launch t - 2
+            const uint32_t tag = (uint32_t)t - 1u - (uint32_t)back;
+            const unsigned long long *pv = a.state + (tag % 3u) * STATE_ARRAY;
             for (int i0 = 0; i0 < n_words; i0 += 4 * 64) {
                 unsigned long long w[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { const int i = i0 + 64 * j + lane; w[j] = pv[i < n_words ? i : n_words - 1]; }
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const uint32_t age = (uint32_t)t - (uint32_t)(w[j] >> 32);       // 1 .. 3: a recent launch's word
-                    if (age >= 1u && age <= 3u) mxp = fmaxf(mxp, __uint_as_float((uint32_t)w[j]));
-                }
+                for (int j = 0; j < 4; ++j)
+                    if ((uint32_t)(w[j] >> 32) == tag && tag != 0u) { mx[back] = fmaxf(mx[back], __uint_as_float((uint32_t)w[j])); has[back] = 1; }
             }
         }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) mxp = fmaxf(mxp, __shfl_xor(mxp, o, 64));
+        for (int o = 32; o > 0; o >>= 1) {
+            mx[0] = fmaxf(mx[0], __shfl_xor(mx[0], o, 64)); mx[1] = fmaxf(mx[1], __shfl_xor(mx[1], o, 64));
+            has[0] |= __shfl_xor(has[0], o, 64); has[1] |= __shfl_xor(has[1], o, 64);
+        }
+        mxp = has[0] ? mx[0] : (has[1] ? mx[1] : 0.f);
         int k = K_FIRST;
         if (mxp > 0.f) {
             int e;
@@ -227,7 +235,7 @@ __device__ __forceinline__ void xplanes_body(const XpArgs &a, unsigned char *sme
             unsigned int *sw = (unsigned int *)(smem + LDS_BYTES);
             atomicMax(&sw[1], __float_as_uint(mx));
             if (atomicAdd(&sw[2], 1u) == 3u)                 // the last of the four loader waves: the workgroup's word
-                a.state[(t & 1ull) * STATE_SLOTS + bid] = ((t & 0xFFFFFFFFull) << 32) | (unsigned long long)atomicMax(&sw[1], 0u);
+                a.state[((uint32_t)t % 3u) * STATE_ARRAY + bid] = ((t & 0xFFFFFFFFull) << 32) | (unsigned long long)atomicMax(&sw[1], 0u);
         }
         tail(tid - 256);
         return;

@@ -177,6 +177,7 @@ class FusedLinearTrainer:
         # next step's partial sums instead, 9.4 us for that launch against 4.7)
         self._planes_tail_wgrad = os.environ.get("IDELUCS_PLANES_TAIL", "wgrad") != "reduce"
         self._cus = torch.cuda.get_device_properties(self.dev).multi_processor_count if self.dev.type == "cuda" else 0
+        self._ctl_snap = torch.zeros(1, dtype=torch.int64, device=self.dev)       # the step counter as the step's reduce launch saw it (idl_wgrad_xplanes_rms)
         self._w1_planes = None                   # (W1 hi, W1 lo, overflow flag)
         self._w1_planes_fresh = False
         # the layers between the two big GEMMs as one 1024-thread MFMA kernel per direction (idl_mid_fwd / idl_mid_bwd)
@@ -341,7 +342,7 @@ class FusedLinearTrainer:
                 pbf, pxi, pr1 = self._pending
                 self._tail_launch(pbf, pxi, pr1, red=(pb["part"][xi], self.H1 * m))
             else:
-                chk(_L.idl_reduce_parts_rms(_p(pb["part"][xi]), self.H1 * m, 0, None, None, None, None, None, None, None, None, 0, 0.0, 0.0, None, 0,
+                chk(_L.idl_reduce_parts_rms(_p(pb["part"][xi]), self.H1 * m, _p(self.ctl), _p(self._ctl_snap), 0, None, None, None, None, None, None, None, None, 0, 0.0, 0.0, None, 0,
                                             -1, None, None, 0, 0, 0, 0, None, 0, _stream()))
             if fork:
                 main.wait_stream(self._side)
@@ -361,7 +362,7 @@ class FusedLinearTrainer:
         elif plf:   # a1 = x W1^T as eight K-slice partial sums [8][m][512] (the tiles of idl_l1_planes with the operands' roles swapped), then their sum
             wh, wl, _ = self._w1_planes
             chk(_L.idl_l1_planes(_p(pb["xh"][xi]), _p(pb["xl"][xi]), self.F, _p(wh), _p(wl), self.F, self.H1, m, self.F, _p(pb["part"][xi]), _stream()))
-            chk(_L.idl_reduce_parts_rms(_p(pb["part"][xi]), self.H1 * m, 0, None, None, None, None, None, None, None, None, 0, 0.0, 0.0, None, 0,
+            chk(_L.idl_reduce_parts_rms(_p(pb["part"][xi]), self.H1 * m, _p(self.ctl), _p(self._ctl_snap), 0, None, None, None, None, None, None, None, None, 0, 0.0, 0.0, None, 0,
                                         -1, None, None, 0, 0, 0, 0, None, 0, _stream()))
         elif l1:    # own tiles: r1^T = Dropout(ReLU(W1 x^T + b1)) and the partial sums of lat = r1 W2^T straight from the accumulators
             st = next_from      # ... with shares [0, g1) of the next batch's tiles assembled by riders of the same launch (HBM is idle under it)
@@ -381,7 +382,7 @@ class FusedLinearTrainer:
                                              m, C, tr, self.seed, _p(self.ctl), _p(bf.f), _p(bf.inv), _p(bf.r2), _p(bf.z),
                                              _p(st.feats), st.n, st.f, st.n * st.f, _p(self._perm), _p(self.ctl[1:]), m // 2, st.n_pairs, m // 2,
                                              _p(st.mean), _p(st.scale), _p(st.inv_scale), None if plw else _p(bf.xs[1 - xi]), _p(pb["xh"][1 - xi]),
-                                             _p(pb["xl"][1 - xi]), g1, g2, 8, _stream()))
+                                             _p(pb["xl"][1 - xi]), _p(self._w1_planes[2]), g1, g2, 8, _stream()))
         elif early and self._early_split:         # ... and the first half of the next batch's tiles in its spare workgroups
             st = next_from
             self._k(_L.idl_mid_fwd_gather, _p(_lat_part_of(bf)) if l1 else _p(r1), _p(self.b1) if (tl and not l1) else None,
@@ -396,7 +397,7 @@ class FusedLinearTrainer:
                                              m, C, tr, self.seed, _p(self.ctl), _p(bf.f), _p(bf.inv), _p(bf.r2), _p(bf.z),
                                              _p(st.feats), st.n, st.f, st.n * st.f, _p(self._perm), _p(self.ctl[1:]), m // 2, st.n_pairs, m // 2,
                                              _p(st.mean), _p(st.scale), _p(st.inv_scale), None, _p(pb["xh"][1 - xi]), _p(pb["xl"][1 - xi]),
-                                             0, 8, 8, _stream()))
+                                             _p(self._w1_planes[2]), 0, 8, 8, _stream()))
             pb["valid"][1 - xi] = True
             pb["x32"][1 - xi] = False
         elif early_f:
@@ -463,7 +464,7 @@ class FusedLinearTrainer:
                                              _p(gW3) if self._dw3_partial else None,
                                              _p(st.feats), st.n, st.f, st.n * st.f, _p(self._perm), _p(self.ctl[1:]), m // 2, st.n_pairs, m // 2,
                                              _p(st.mean), _p(st.scale), _p(st.inv_scale), None if plw else _p(bf.xs[1 - xi]), _p(pb["xh"][1 - xi]),
-                                             _p(pb["xl"][1 - xi]), g2, 8, 8, 1, _stream()))
+                                             _p(pb["xl"][1 - xi]), _p(self._w1_planes[2]), g2, 8, 8, 1, _stream()))
             pb["valid"][1 - xi] = True
             pb["x32"][1 - xi] = not plw
             if not self._dw3_partial:
@@ -514,14 +515,14 @@ class FusedLinearTrainer:
                 if self._split_state is None:
                     self._split_state = torch.zeros(int(_L.idl_wgrad_split_state_words()), dtype=torch.int64, device=self.dev)
                 # (a tile per CU, and a tile for each of the tail's blocks: 128 dW2 tiles + at most 16 blocks for the small tensors)
-                if self._planes_tail_wgrad and 144 <= (self.H1 // 64) * (self.F // 128) <= self._cus:
+                if self._planes_tail_wgrad and self._planes_reduce_launch and 144 <= (self.H1 // 64) * (self.F // 128) <= self._cus:
                     # ... and THIS step's optimizer tail is run by the tiles' loader waves under the tiles' epilogue: nothing is pending
                     tail = (len(self.params), self._pp, self._gp, self._parts, self._vp, self._sz, _p(self.hyper),
                             _p(self.ctl), _p(bf.loss_rows), m, 1.0 - self.weight, self.weight, _p(self.out))
                     wg = (2, _p(bf.dlat), _p(r1), 1, m, self.H2, self.H1, _p(self.grads[2]), m // 2, _stream())
                     chk(_L.idl_wgrad_xplanes_rms(_p(bf.dr1), _p(pb["xh"][xi]), _p(pb["xl"][xi]), self.F, m, self.H1, self.F,
                                                  _p(gW1) if self._keep_w1_grad else None, _p(self.W1), _p(self.square_avg[0]),
-                                                 _p(self._split_state), _p(wh), _p(wl), _p(flag), *tail, 0, *wg))
+                                                 _p(self._split_state), _p(self._ctl_snap), _p(wh), _p(wl), _p(flag), *tail, 0, *wg))
                     self._pending = None
                     return
                 chk(_L.idl_wgrad_rmsprop_xplanes(_p(bf.dr1), _p(pb["xh"][xi]), _p(pb["xl"][xi]), self.F, m, self.H1, self.F,
@@ -554,7 +555,7 @@ class FusedLinearTrainer:
             wg = (2, _p(bf.dlat), _p(r1), 0, m, self.H2, self.H1, _p(gW2), m // 2, _stream())
             chk(_L.idl_wgrad_xplanes_rms(_p(bf.dr1), _p(pb["xh"][xi]), _p(pb["xl"][xi]), self.F, m, self.H1, self.F,
                                          _p(gW1) if self._keep_w1_grad else None, _p(self.W1), _p(self.square_avg[0]),
-                                         _p(self._split_state), _p(wh), _p(wl), _p(flag), *tail, 0, *wg))
+                                         _p(self._split_state), _p(self._ctl_snap), _p(wh), _p(wl), _p(flag), *tail, 0, *wg))
             return
         w1_fusable = self._wgrad_fused and bool(_L.idl_wgrad_supported(m, self.H1, self.F))
         # the tiles ride at the head of the optimizer launch where that launch has the form below; else as a launch of their own
@@ -610,7 +611,7 @@ class FusedLinearTrainer:
         wg = (2, _p(bf.dlat), _p(r1), 1, m, self.H2, self.H1, _p(self.grads[2]), m // 2, _stream())
         if red is not None:       # beside the workgroups that add up the next step's layer-1 partial sums (red = (part, elements of a slab))
             part, slab = red
-            _lib.check(_L.idl_reduce_parts_rms(_p(part), slab, *tail, 0, *wg))
+            _lib.check(_L.idl_reduce_parts_rms(_p(part), slab, None, None, *tail, 0, *wg))
         elif l1p is not None:
             wh, wl, xh, xl, m1, part = l1p
             _lib.check(_L.idl_l1_planes_rms(_p(wh), _p(wl), _p(xh), _p(xl), m1, self.F, _p(part), *tail, 0, *wg))
@@ -641,12 +642,13 @@ class FusedLinearTrainer:
             self._w1_planes_fresh = True
         if not pb["valid"][xi]:
             x = bf.xs[xi]
-            _lib.check(_L.idl_split_planes(_p(x), x.numel(), int(_L.idl_planes_exponent(0)), _p(pb["xh"][xi]), _p(pb["xl"][xi]), None, _stream()))
+            _lib.check(_L.idl_split_planes(_p(x), x.numel(), int(_L.idl_planes_exponent(0)), _p(pb["xh"][xi]), _p(pb["xl"][xi]), _p(self._w1_planes[2]), _stream()))
             pb["valid"][xi] = True
 
     def planes_overflowed(self):
-        """Whether an entry of W1 ever left its planes' range (|w| >= 15.8; waits for the device).  Such an entry was clamped in the
-        layer-1 product: the run should be repeated with IDELUCS_PLANES=0."""
+        """Whether an entry of W1 (|w| >= 15.8) or of a standardised batch (|x| > 8 125: a mimic's feature thousands of the originals' standard
+        deviations out) ever left its planes' range (waits for the device).  Such an entry was clamped in the two big products: the run
+        should be repeated with IDELUCS_PLANES=0."""
         return self._w1_planes is not None and bool(self._w1_planes[2].item())
 
     def _gather(self, store, bf):

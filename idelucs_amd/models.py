@@ -216,7 +216,8 @@ class IID_model():
         """The two-plane step form (fused.FusedLinearTrainer._planes) clamps a weight of Linear(F,512) beyond +-15.8 in the layer-1 product and
         raises a flag: checked wherever this model waits for the device anyway (a synchronous epoch, predict)."""
         if self._fused is not None and self._fused.planes_overflowed():
-            raise RuntimeError("a weight of the first layer left the range of the fp16 planes (|w| >= 15.8): rerun with IDELUCS_PLANES=0")
+            raise RuntimeError("a weight of the first layer (|w| >= 15.8) or a standardised feature (|x| > 8125) left the range of the fp16 planes: "
+                               "rerun with IDELUCS_PLANES=0")
 
     # ------------------------------------------------------------------ inference
     def _predict_inputs(self, rows=None):

@@ -117,7 +117,7 @@ def test_mid_forward_adds_the_partial_sums_in_order(dev, m, C, train):
     for p in range(1, 8):
         want += part2[p]
     keep = part2[1:].clone()
-    _lib.check(L.idl_reduce_parts_rms(_p(part2), H1 * m, 0, None, None, None, None, None, None, None, None, 0, 0.0, 0.0, None, 0,
+    _lib.check(L.idl_reduce_parts_rms(_p(part2), H1 * m, None, None, 0, None, None, None, None, None, None, None, None, 0, 0.0, 0.0, None, 0,
                                       -1, None, None, 0, 0, 0, 0, None, 0, _stream()))
     torch.cuda.synchronize()
     assert torch.equal(part2[0], want) and torch.equal(part2[1:], keep)
@@ -154,6 +154,7 @@ def test_producers_write_the_planes_of_what_they_write(dev):
     _lib.check(L.idl_gather_pairs_at(_p(feats), n, F, n * F, _p(perm), _p(base), B, _p(mean), _p(scale), _p(inv_scale), _p(want), _stream()))
     mm = 2 * B
     y = torch.zeros(mm, F, device=dev); yh = torch.zeros(mm, F, dtype=torch.int16, device=dev); yl = torch.zeros_like(yh)
+    xflag = torch.zeros(1, dtype=torch.int32, device=dev)
     a1 = torch.randn(8, 512, mm, generator=g).to(dev) * 0.1
     b1 = torch.zeros(512, device=dev)
     W2 = (torch.randn(H2, 512, generator=g) / 23).to(dev); b2 = torch.zeros(H2, device=dev)
@@ -162,7 +163,7 @@ def test_producers_write_the_planes_of_what_they_write(dev):
     f = torch.empty(mm, H2, device=dev); inv = torch.empty(mm, device=dev); r2 = torch.empty(mm, H2, device=dev); z = torch.empty(mm, C, device=dev)
     _lib.check(L.idl_mid_fwd_gather_planes(_p(a1), _p(b1), 3, _p(W2), _p(b2), _p(W3), _p(b3), mm, C, 1, ctypes.c_uint64(3), _p(ctl), _p(f), _p(inv), _p(r2), _p(z),
                                            _p(feats), n, F, n * F, _p(perm), _p(base), 0, 2 * n, B, _p(mean), _p(scale), _p(inv_scale),
-                                           _p(y), _p(yh), _p(yl), 0, 3, 8, _stream()))
+                                           _p(y), _p(yh), _p(yl), _p(xflag), 0, 3, 8, _stream()))
     G = torch.randn(1, mm, H2, generator=g).to(dev) * 1e-2; dP0 = torch.randn(C, C, generator=g).to(dev) * 1e-2
     dlg = torch.empty(mm, C, device=dev); dlat = torch.empty(mm, H2, device=dev); dr1 = torch.empty(mm, 512, device=dev)
     parts = int(L.idl_col_sum_parts())
@@ -170,11 +171,21 @@ def test_producers_write_the_planes_of_what_they_write(dev):
     _lib.check(L.idl_mid_bwd_gather_planes(_p(z), _p(r2), _p(f), _p(inv), _p(G), 1, _p(dP0), _p(W3), _p(W2), _p(a1), mm, C, 1, 1e-3, _p(dlg), _p(dlat),
                                            _p(dr1), _p(p1), _p(p2), _p(p3), _p(pw3),
                                            _p(feats), n, F, n * F, _p(perm), _p(base), 0, 2 * n, B, _p(mean), _p(scale), _p(inv_scale),
-                                           _p(y), _p(yh), _p(yl), 3, 8, 8, 1, _stream()))
+                                           _p(y), _p(yh), _p(yl), None, 3, 8, 8, 1, _stream()))
     torch.cuda.synchronize()
-    assert torch.equal(y, want)
+    assert torch.equal(y, want) and xflag.item() == 0
     hi, lo, _, _ = _split(y, 0)
     assert torch.equal(hi, yh) and torch.equal(lo, yl)
+    # a column whose originals barely vary: the standardised entries leave the planes' range, are clamped there, and the flag says so
+    scale2 = scale.clone(); scale2[7] = 1e-9
+    inv2 = 1.0 / scale2
+    _lib.check(L.idl_mid_fwd_gather_planes(_p(a1), _p(b1), 3, _p(W2), _p(b2), _p(W3), _p(b3), mm, C, 1, ctypes.c_uint64(3), _p(ctl), _p(f), _p(inv), _p(r2), _p(z),
+                                           _p(feats), n, F, n * F, _p(perm), _p(base), 0, 2 * n, B, _p(mean), _p(scale2), _p(inv2),
+                                           None, _p(yh), _p(yl), _p(xflag), 0, 8, 8, _stream()))
+    torch.cuda.synchronize()
+    assert xflag.item() == 1
+    col = yh.view(torch.float16)[:, 7].float()
+    assert bool(torch.isfinite(col).all()) and col.abs().max().item() <= 65000.0
 
 
 @pytest.mark.parametrize("m,H,F", [(512, 128, 512), (1024, 512, 4096), (192, 64, 128)])

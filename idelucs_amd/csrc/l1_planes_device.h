@@ -1,6 +1,6 @@
 // l1_planes_device.h -- the layer-1 forward product a1^T = W1 x^T on the fp16 MATRIX CORES from operands kept as two fp16 planes
-// (planes.h): the device side, shared by planes.hip (the product on its own, idl_l1_planes) and train_step.hip (the same tiles with the
-// previous step's optimizer tail riding behind them, idl_l1_planes_rms).
+// (planes.h): the device side, shared by planes.hip (idl_l1_planes: the step's first launch) and train_step.hip (the same tiles with the
+// previous step's optimizer tail riding behind them, idl_l1_planes_rms: a measured variant, IDELUCS_PLANES_REDUCE=mid).
 //
 // Reference: Linear(F,512) of idelucs/PytorchUtils.py:38-45, called for both views of a batch at idelucs/models.py:124-125.  The fp32
 // tiles of l1_device.h sit on the fp32 matrix pipe's floor (27.4 us at 512 x 1024 x 4096; 33.6 measured); the fp16 pipe is sixteen
@@ -10,10 +10,14 @@
 //
 // 128 x 128 tiles of a1^T with an 8-way split of K, ONE K SLICE PER XCD (workgroups go to the XCDs round-robin: slice = blockIdx % 8, so an
 // XCD's L2 streams one eighth of both operands; whole-K tiles of 64 x 32 would pull 600 MB a launch out of L2).  Four LOADER waves bring
-// chunks of 32 k (four planes x 128 rows x 64 bytes) into LDS by LDS-DMA, three chunks resident, the 16-byte slots of a row swizzled
-// on the SOURCE side (the DMA writes lane-linear); four COMPUTING waves (2 x 2, 64 x 64 each = 2 x 2 blocks of 32 x 32) read
-// their fragments with ds_read_b128 and issue v_mfma_f32_32x32x16_f16; one barrier a chunk.  The partial sums go out as
-// part[8][512][m] fp32 (scaled back by 2^-(W_EXP + X_EXP)); mid_fwd_kernel adds the eight in a fixed order.
+// chunks of 64 k (four planes x 128 rows x 128 bytes: whole cache lines of the source) into LDS by LDS-DMA, two chunks resident, the
+// 16-byte slots of a row swizzled on the SOURCE side (the DMA writes lane-linear); four COMPUTING waves (2 x 2, 64 x 64 each = 2 x 2 blocks
+// of 32 x 32) read their fragments with ds_read_b128 one K-step ahead of the MFMAs (v_mfma_f32_32x32x16_f16); one barrier a chunk.  The
+// partial sums go out as part[8][512][m] fp32 (scaled back by 2^-(W_EXP + X_EXP)); idl_reduce_parts_rms adds the eight in a fixed order.
+// The operands' roles are symmetric: called with the batch's planes as "W1" and W1's as the "batch" the same tiles give part[8][m][512]
+// (the step of n_clusters > 48, whose activations are not transposed).
+// WHERE IT STANDS: 18.5-19.8 us in the step; what it moves out of L2 (134 MB at the ~10 TB/s this access pattern gets: 13.4 us) + 3.8 us of
+// partial-sum stores + launch; computing alone 6.4 us, MFMA pipe busy 0.20.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -32,7 +36,7 @@ constexpr int ROWB = KC * 2;                                 // bytes of a row o
 constexpr int PLANE = TM * ROWB;                             // bytes of one plane of a chunk (16 384)
 constexpr int STAGE = 4 * PLANE;                             // w0 w1 x0 x1 (65 536)
 // A chunk is 64 k: a row's 128 bytes are ONE cache line of the source (chunks of 32 k asked the L2 for every line twice, half a line
-// each time: 18.5 us against ... with the rest unchanged), two chunks resident (more did not help at 32 k: three, four, five stages 22.0 / 22.4 / 22.5 us)
+// each time: 22.5 -> 20.6 us in tools/bench_planes.py's harness), two chunks resident (more did not help at 32 k: three, four, five stages 22.0 / 22.4 / 22.5 us)
 constexpr int LDS_BYTES = STAGES * STAGE;                    // 131 072
 constexpr int PER = 16;                                      // DMA instructions (1 KiB = 8 rows each) a loader issues per chunk: 4 planes x 16 blocks / 4 loaders
 

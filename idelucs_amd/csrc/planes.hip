@@ -1,6 +1,6 @@
 // planes.hip -- the two-fp16-plane operand form (planes.h) outside the step's fused launches: idl_split_planes (an fp32 tensor -> its
-// planes: W1 when a voter begins, the first batch of an epoch, tests) and idl_l1_planes (the layer-1 forward tiles of
-// l1_planes_device.h on their own; in the step they run with the optimizer tail behind them, train_step.hip: idl_l1_planes_rms).
+// planes: W1 when an epoch begins, the first batch of an epoch, tests) and idl_l1_planes (the layer-1 forward tiles of
+// l1_planes_device.h: the first launch of the two-plane step).
 #include <stdlib.h>
 
 #include "common.h"

@@ -197,7 +197,9 @@ class HotPath:
         U, _lib = self.U, self._lib
         hi = self.din.n if hi is None else hi
         if U.counts_route_ok(self.a.k):          # as utils.predict_features: from the int32 counts, the float64 rows never materialised
-            return U.predict_inputs_from_counts(self.din, self.a.k, (lo, hi))
+            if not hasattr(self, "_predict_ws"):
+                self._predict_ws = {}
+            return U.predict_inputs_from_counts(self.din, self.a.k, (lo, hi), workspace=self._predict_ws)
         f64 = U._vectorise(self.din, self.a.k, _lib.MODE_KMER, _lib.INIT_ONE, _lib.OUT_FREQ_F64)[0]
         mean, scale = U.col_stats(f64)
         return U.standardise(f64[lo:hi], mean, scale)

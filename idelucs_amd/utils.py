@@ -648,11 +648,20 @@ def counts_route_ok(k, reduce=False):
     return (not reduce) and 4 <= k <= 7 and os.environ.get("IDELUCS_PREDICT_COUNTS", "1") != "0"
 
 
-def predict_inputs_from_counts(din, k, rows=None):
+def predict_inputs_from_counts(din, k, rows=None, workspace=None):
     """What SequenceDataset feeds the network (reference utils.py:400-405 + models.py:163) without materialising the float64 rows:
     int32 counts of the un-mutated sequences (pseudocount included) -> StandardScaler statistics of counts / sum(counts) in float64
     -> rows [lo, hi) standardised, one rounding to float32.  The same bits as _vectorise(OUT_FREQ_F64) + col_stats + standardise."""
-    counts = _vectorise(din, k, _lib.MODE_KMER, _lib.INIT_ONE, _lib.OUT_COUNTS_I32)[0]
+    # workspace (a dict the caller keeps): the int32 counts [n, f] and the float32 result are 16 GB each at 10^6 x k = 6 -- a caller that
+    # repeats the call keeps them, instead of depending on what the caching allocator happens to have left of them (a 10^6-row predict
+    # took 49 or 175-190 ms by that alone)
+    cbuf = None
+    if workspace is not None:
+        cbuf = workspace.get("counts")
+        row = int(_L.idl_row_len(_lib.MODE_KMER, k))
+        if cbuf is None or tuple(cbuf.shape) != (1, din.n, row) or cbuf.device != din.codes.device:
+            cbuf = workspace["counts"] = torch.empty((1, din.n, row), dtype=torch.int32, device=din.codes.device)
+    counts = _vectorise(din, k, _lib.MODE_KMER, _lib.INIT_ONE, _lib.OUT_COUNTS_I32, out=cbuf)[0]
     n, f = counts.shape
     dev = counts.device
     mean = torch.empty(f, dtype=torch.float64, device=dev)
@@ -661,7 +670,11 @@ def predict_inputs_from_counts(din, k, rows=None):
     ws = torch.empty(max(_L.idl_counts_stats_workspace(n, f), 8), dtype=torch.uint8, device=dev)
     _lib.check(_L.idl_counts_stats(_ptr(counts), n, f, _ptr(mean), _ptr(scale), _ptr(totals), _ptr(ws), _stream_ptr()))
     lo, hi = (0, n) if rows is None else rows
-    out = torch.empty((hi - lo, f), dtype=torch.float32, device=dev)
+    out = workspace.get("out") if workspace is not None else None
+    if out is None or tuple(out.shape) != (hi - lo, f) or out.device != dev:
+        out = torch.empty((hi - lo, f), dtype=torch.float32, device=dev)
+        if workspace is not None:
+            workspace["out"] = out
     if hi > lo:
         _lib.check(_L.idl_counts_standardise(_ptr(counts[lo:hi]), _ptr(totals[lo:hi]), hi - lo, f, _ptr(mean), _ptr(scale), _ptr(out), _stream_ptr()))
     return out

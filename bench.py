@@ -87,7 +87,7 @@ class HotPath:
     """The timed region: everything from packed bases in HBM to the last optimizer.step() (and, for a multi-voter job, to the
     gathered assignments)."""
 
-    def __init__(self, din, args, dev, rank, world):
+    def __init__(self, din, args, dev, rank, world, force_lanes=None):
         from idelucs_amd import _lib, utils as U, models, dist as D
         self.U, self._lib, self.models, self.D = U, _lib, models, D
         self.din, self.dev, self.a, self.rank, self.world = din, dev, args, rank, world
@@ -334,7 +334,7 @@ def lanes_epoch_ms(din, args, dev, rank, world, voters):
     import copy
     a = copy.copy(args)
     a.voters, a.exchange = voters, False
-    hp = HotPath(din, a, dev, rank, world)
+    hp = HotPath(din, a, dev, rank, world, force_lanes=voters)       # (in lockstep whatever training.voter_lanes would choose for so few)
     hp.step(seed=2000)
     hp.step(seed=2001)
     torch.cuda.synchronize()
@@ -372,7 +372,7 @@ def fp32_form_leg(din, args, dev, rank, world, passes=4):
     return out
 
 
-def predicted_fixed_job(din, args, dev, rank, world, st8, epoch1_ms):
+def predicted_fixed_job(din, args, dev, rank, world, st8, epoch1_ms, lane_model=None):
     """What the 1/2/4/8 curve of the FIXED 8-voter job (cfg3) should look like, from this GPU's own stage times:
     per-rank wall at N ranks = sites + vectorise + scaler fit + (8/N) x epoch(lanes = 8/N) + predict inputs + (8/N) x predict +
     all-gather.  Every rank vectorises the whole input; the voters of a rank train in lockstep, and a voter-epoch costs less in
@@ -384,15 +384,23 @@ def predicted_fixed_job(din, args, dev, rank, world, st8, epoch1_ms):
     fixed = st8["edits"] + st8["vectorise"] + st8["stats"] + st8.get("predict_inputs", 0.0) + st8.get("exchange", 0.0)
     out = {"epoch_ms_per_voter_by_lanes": {str(k): per_lanes[k] for k in sorted(per_lanes)}, "fixed_ms_per_rank": fixed,
            "predict_ms_per_voter": st8.get("predict", 0.0)}
+    # training.voter_lanes: fewer than five voters of a rank train one after the other when a lone voter's step takes the two-plane products
+    from idelucs_amd.training import voter_lanes
+    policy = {}
     base = None
     for n in (1, 2, 4, 8):
         v = 8 // n
-        wall = fixed + v * per_lanes[v] + v * st8.get("predict", 0.0)
+        lanes = 1 if v == 1 else voter_lanes(v, lane_model)
+        policy[str(v)] = "one after the other" if lanes == 1 else "in lockstep"
+        per_voter = per_lanes[1] if lanes == 1 else per_lanes[v]
+        wall = fixed + v * per_voter + v * st8.get("predict", 0.0)
         val = args.n * 8 / (wall * 1e-3)
         base = base or val
         out[str(n)] = {"ms_per_pass": wall, "value": val, "speedup_vs_1": val / base}
+    out["voters_of_a_rank_train"] = policy
     out["note"] = ("value = N_seq x 8 voters / predicted per-rank wall; %.1fx at N = 8 is the EXPECTED speed-up (not 8x): one GPU trains its 8 "
-                   "voters in lockstep at %.1f ms a voter-epoch, a lone voter takes %.1f" % (out["8"]["speedup_vs_1"], per_lanes[8], per_lanes[1]))
+                   "voters in lockstep at %.1f ms a voter-epoch, a lone voter takes %.1f (and 2 or 4 voters of a rank train one after the other: "
+                   "in lockstep they would take %.1f / %.1f ms each)" % (out["8"]["speedup_vs_1"], per_lanes[8], per_lanes[1], per_lanes[2], per_lanes[4]))
     return out
 
 
@@ -859,7 +867,7 @@ def main():
             torch.cuda.empty_cache()
             out["fixed_job_8_voters"] = fixed_job_8_voters(din, args, dev, rank, world)
             if args.prediction:
-                out["predicted_fixed_job"] = predicted_fixed_job(din, args, dev, rank, world, out["fixed_job_8_voters"]["stage_ms"], t_ep)
+                out["predicted_fixed_job"] = predicted_fixed_job(din, args, dev, rank, world, out["fixed_job_8_voters"]["stage_ms"], t_ep, lane_model=hp.model)
         if world == 1 and args.k_sweep and not cfg5 and V == 1:
             out["k_sweep"] = k_sweep(din, args, dev)
         if world == 1 and args.split16 and not cfg5 and V == 1 and args.k == 6:

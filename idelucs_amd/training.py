@@ -26,12 +26,32 @@ def train_voter(model, n_epochs, voter=0, n_voters=1, progress=True):
     return (curve,) + tuple(model.predict())
 
 
-def voter_lanes(n_voters_here):
-    """How many voters of one rank train in lockstep as one batch (IDELUCS_VOTER_LANES, default 8; 1 = one after the other).
-    One training step is two big GEMMs and five latency-bound launches; batched, the GEMMs become batched GEMMs and each of the
-    five launches serves every voter of the batch (fused.BatchedLinearTrainer)."""
-    lanes = int(os.environ.get("IDELUCS_VOTER_LANES", "8"))
-    return max(1, min(lanes, n_voters_here))
+def plane_step_applies(model):
+    """Whether a lone voter of this model trains with the two big products of its step on the fp16 matrix cores (fused.FusedLinearTrainer._planes:
+    NetLinear, full batches of 2 x batch_sz rows with 128 | 2 batch_sz, 512 | F, F >= 1024)."""
+    if os.environ.get("IDELUCS_PLANES", "1") == "0" or not getattr(model, "_use_fused", False):
+        return False
+    try:
+        lin1 = model.net.layers[0]
+        F, H1 = int(lin1.in_features), int(lin1.out_features)
+    except (AttributeError, IndexError, TypeError):
+        return False
+    m = 2 * int(model.batch_sz)
+    return H1 == 512 and F >= 1024 and F % 512 == 0 and m >= 256 and m % 128 == 0
+
+
+def voter_lanes(n_voters_here, model=None):
+    """How many voters of one rank train in lockstep as one batch (IDELUCS_VOTER_LANES; 1 = one after the other).
+    One training step is two big products and five latency-bound launches; batched, the products become batched library GEMMs and each of
+    the five launches serves every voter of the batch (fused.BatchedLinearTrainer).  Default: all of a rank's voters, up to 8 -- unless
+    there are fewer than five and a lone voter's step takes the two-plane products (plane_step_applies): at cfg2 a voter-epoch costs 54.2 ms
+    alone against 58.5 / 54.9 / 52.1 ms in lockstep batches of 2 / 4 / 8 (bench.py: predicted_fixed_job), so two to four voters train one
+    after the other."""
+    env = os.environ.get("IDELUCS_VOTER_LANES")
+    lanes = max(1, min(int(env) if env is not None else 8, n_voters_here))
+    if env is None and model is not None and 1 < lanes < 5 and plane_step_applies(model):
+        return 1
+    return lanes
 
 
 def can_batch(model):
@@ -53,7 +73,7 @@ def train_voters(model, voters, n_epochs, n_voters=None, lanes=None, progress=Tr
     from .fused import BatchedLinearTrainer
     voters = list(voters)
     n_voters = n_voters if n_voters is not None else len(voters)
-    lanes = voter_lanes(len(voters)) if lanes is None else max(1, min(int(lanes), len(voters)))
+    lanes = voter_lanes(len(voters), model) if lanes is None else max(1, min(int(lanes), len(voters)))
     if models.IID_model.voter_state_carried():
         # the reference's one-optimizer-for-all-voters behaviour: voters strictly one after the other, all of them here
         if voters != list(range(n_voters)):

@@ -49,8 +49,8 @@ def test_reference_package_name_resolves_to_this_implementation():
 
 
 def test_lane_policy_of_a_ranks_voters(monkeypatch):
-    """training.voter_lanes: all of a rank's voters in lockstep, up to 8 -- but fewer than five one after the other when a lone voter's step
-    takes the two-plane products (faster alone than in a batch of 2 or 4: bench.py's predicted_fixed_job); IDELUCS_VOTER_LANES overrides."""
+    """training.voter_lanes: all of a rank's voters in lockstep, up to 8 -- but two of them one after the other when a lone voter's step
+    takes the two-plane products (faster alone than in a batch of 2: bench.py's predicted_fixed_job); IDELUCS_VOTER_LANES overrides."""
     import types
     import torch
     from idelucs_amd import training
@@ -64,11 +64,11 @@ def test_lane_policy_of_a_ranks_voters(monkeypatch):
     assert training.plane_step_applies(cfg2) and training.plane_step_applies(model(1024, 128))
     assert not training.plane_step_applies(model(256, 512)) and not training.plane_step_applies(model(4096, 48))
     assert not training.plane_step_applies(model(4096, 512, fused=False)) and not training.plane_step_applies(model(4096, 512, H1=256))
-    assert [training.voter_lanes(n, cfg2) for n in (1, 2, 4, 5, 8, 11)] == [1, 1, 1, 5, 8, 8]
+    assert [training.voter_lanes(n, cfg2) for n in (1, 2, 3, 4, 8, 11)] == [1, 1, 3, 4, 8, 8]
     assert [training.voter_lanes(n, model(256, 512)) for n in (1, 2, 4, 8)] == [1, 2, 4, 8]        # k = 4: the fp32 step, lockstep pays
     assert [training.voter_lanes(n) for n in (1, 3, 9)] == [1, 3, 8]
     monkeypatch.setenv("IDELUCS_PLANES", "0")
-    assert training.voter_lanes(4, cfg2) == 4
+    assert training.voter_lanes(2, cfg2) == 2
     monkeypatch.delenv("IDELUCS_PLANES")
     monkeypatch.setenv("IDELUCS_VOTER_LANES", "3")
     assert [training.voter_lanes(n, cfg2) for n in (2, 4, 8)] == [2, 3, 3]

@@ -385,7 +385,7 @@ def predicted_fixed_job(din, args, dev, rank, world, st8, epoch1_ms, lane_model=
     fixed = st8["edits"] + st8["vectorise"] + st8["stats"] + st8.get("predict_inputs", 0.0) + st8.get("exchange", 0.0)
     out = {"epoch_ms_per_voter_by_lanes": {str(k): per_lanes[k] for k in sorted(per_lanes)}, "fixed_ms_per_rank": fixed,
            "predict_ms_per_voter": st8.get("predict", 0.0)}
-    # training.voter_lanes: two voters of a rank train one after the other when a lone voter's step takes the two-plane products
+    # training.voter_lanes: how the 8 / N voters of a rank train (in lockstep as one batch, or one after the other)
     from idelucs_amd.training import voter_lanes
     policy = {}
     base = None
@@ -400,8 +400,8 @@ def predicted_fixed_job(din, args, dev, rank, world, st8, epoch1_ms, lane_model=
         out[str(n)] = {"ms_per_pass": wall, "value": val, "speedup_vs_1": val / base}
     out["voters_of_a_rank_train"] = policy
     out["note"] = ("value = N_seq x 8 voters / predicted per-rank wall; %.1fx at N = 8 is the EXPECTED speed-up (not 8x): one GPU trains its 8 "
-                   "voters in lockstep at %.1f ms a voter-epoch (4: %.1f), a lone voter takes %.1f, and 2 voters of a rank train one after the other: "
-                   "in lockstep they would take %.1f ms each" % (out["8"]["speedup_vs_1"], per_lanes[8], per_lanes[4], per_lanes[1], per_lanes[2]))
+                   "voters in lockstep at %.1f ms a voter-epoch (4: %.1f, 2: %.1f), a lone voter takes %.1f; 2 voters of a rank train %s"
+                   % (out["8"]["speedup_vs_1"], per_lanes[8], per_lanes[4], per_lanes[2], per_lanes[1], policy["2"]))
     return out
 
 

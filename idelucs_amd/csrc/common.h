@@ -26,7 +26,8 @@ int device_info(DeviceInfo *out);
 // of them as ONE launch with the voter index in the grid (blockIdx.y, or .z for the InfoNCE passes).
 constexpr int PLAN_BYTES = 1024;       // one record: PlanHead + the kernel's parameter struct at PLAN_PARAMS
 constexpr int PLAN_PARAMS = 64;
-enum { PLAN_MID_FWD = 1, PLAN_NCE = 2, PLAN_MID_BWD = 3, PLAN_RMSPROP = 4, PLAN_WGRAD_RMSPROP = 5, PLAN_L1_FWD = 6 };
+enum { PLAN_MID_FWD = 1, PLAN_NCE = 2, PLAN_MID_BWD = 3, PLAN_RMSPROP = 4, PLAN_WGRAD_RMSPROP = 5, PLAN_L1_FWD = 6,
+       PLAN_L1_PLANES = 7, PLAN_REDUCE = 8, PLAN_WGRAD_XPLANES = 9 };      // (7-9: the launches of the step's two-plane form)
 struct PlanHead {
     int32_t kind, variant;
     uint32_t grid[3], block, lds;      // of one voter's launch

@@ -2,6 +2,7 @@
 // planes: W1 when an epoch begins, the first batch of an epoch, tests) and idl_l1_planes (the layer-1 forward tiles of
 // l1_planes_device.h: the first launch of the two-plane step).
 #include <stdlib.h>
+#include <string.h>
 
 #include "common.h"
 #include "l1_planes_device.h"
@@ -60,6 +61,14 @@ int idl_l1_planes(const void *w_hi, const void *w_lo, int ld_w, const void *x_hi
     IDL_REQUIRE(((((uintptr_t)w_hi) | ((uintptr_t)w_lo) | ((uintptr_t)x_hi) | ((uintptr_t)x_lo) | ((uintptr_t)part)) & 15u) == 0, "l1_planes: buffers must be 16-byte aligned");
     l1p_dev::L1pArgs a{(const uint16_t *)w_hi, (const uint16_t *)w_lo, (const uint16_t *)x_hi, (const uint16_t *)x_lo, part, m, n_out, n_in,
                        (n_out / l1p_dev::TM) * (m / l1p_dev::TN) * l1p_dev::KSPLIT, ld_w, ld_x, getenv("IDELUCS_L1P_DBG") ? atoi(getenv("IDELUCS_L1P_DBG")) : 0};
+    if (void *plan = idl::take_plan()) {          // recorded, not launched (idl_plan_begin): several voters in one launch, train_step.hip
+        static_assert(sizeof(l1p_dev::L1pArgs) + idl::PLAN_PARAMS <= idl::PLAN_BYTES, "L1pArgs does not fit a plan record");
+        idl::PlanHead h{};
+        h.kind = idl::PLAN_L1_PLANES; h.grid[0] = (unsigned)a.n_tiles; h.grid[1] = 1; h.grid[2] = 1; h.block = l1p_dev::THREADS; h.lds = l1p_dev::LDS_BYTES;
+        memcpy(plan, &h, sizeof(h));
+        memcpy((unsigned char *)plan + idl::PLAN_PARAMS, &a, sizeof(a));
+        return IDL_OK;
+    }
     static bool attr_set[64] = {};
     int dev = 0;
     IDL_HIP_TRY(hipGetDevice(&dev));

@@ -1276,6 +1276,63 @@ __global__ __launch_bounds__(wg_dev::THREADS) void wgrad_rmsprop_batched_kernel(
     }
 }
 
+// a pointer read from a plan record is the same in every lane, but the compiler need not know: scalar operands of inline asm want it said
+template <class T>
+__device__ __forceinline__ T *uniform_ptr(T *p)
+{
+    const uint64_t v = (uint64_t)(uintptr_t)p;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return (T *)(uintptr_t)(((uint64_t)hi << 32) | lo);
+}
+
+// ... and the launches of the step's two-plane form for several voters (blockIdx.y = voter, arguments from its plan record)
+__global__ __launch_bounds__(l1p_dev::THREADS, 1) void l1_planes_batched_kernel(const unsigned char *__restrict__ plans)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char l1p_b_smem[];
+    l1p_dev::L1pArgs p = *(const l1p_dev::L1pArgs *)(plans + (size_t)blockIdx.y * idl::PLAN_BYTES + idl::PLAN_PARAMS);
+    p.wh = uniform_ptr(p.wh); p.wl = uniform_ptr(p.wl); p.xh = uniform_ptr(p.xh); p.xl = uniform_ptr(p.xl);      // (bases of the LDS-DMA: scalar operands)
+    l1p_dev::l1p_body(p, (int)blockIdx.x, l1p_b_smem);
+}
+
+__global__ __launch_bounds__(256) void reduce_batched_kernel(const unsigned char *__restrict__ plans)
+{
+    const ReduceArgs &r = *(const ReduceArgs *)(plans + (size_t)blockIdx.y * idl::PLAN_BYTES + idl::PLAN_PARAMS);
+    if ((int)blockIdx.x >= r.blocks) return;
+    if (r.ctl_snap != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *r.ctl_snap = r.ctl_src[0];
+    const int64_t i0 = (int64_t)blockIdx.x * (256 * RED_U) + threadIdx.x;
+    float4 v[RED_U][l1p_dev::KSPLIT];
+#pragma unroll
+    for (int u = 0; u < RED_U; ++u) {
+        const int64_t i = i0 + 256 * u < r.slab4 ? i0 + 256 * u : r.slab4 - 1;
+#pragma unroll
+        for (int p = 0; p < l1p_dev::KSPLIT; ++p) v[u][p] = r.part[(int64_t)p * r.slab4 + i];
+    }
+#pragma unroll
+    for (int u = 0; u < RED_U; ++u) {
+        float4 acc = v[u][0];
+#pragma unroll
+        for (int p = 1; p < l1p_dev::KSPLIT; ++p) { acc.x += v[u][p].x; acc.y += v[u][p].y; acc.z += v[u][p].z; acc.w += v[u][p].w; }
+        if (i0 + 256 * u < r.slab4) r.part[i0 + 256 * u] = acc;
+    }
+}
+
+struct XpRmsParams { wgp_dev::XpArgs x; RmsArgs a; const float *hyper; int64_t *ctl; int64_t batch_advance; int n_tail; };
+static_assert(sizeof(XpRmsParams) + idl::PLAN_PARAMS <= idl::PLAN_BYTES, "XpRmsParams does not fit a plan record");
+static_assert(sizeof(ReduceArgs) + idl::PLAN_PARAMS <= idl::PLAN_BYTES, "ReduceArgs does not fit a plan record");
+
+__global__ __launch_bounds__(wgp_dev::NT, 1) void wgrad_xplanes_rms_batched_kernel(const unsigned char *__restrict__ plans)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char wgp_b_smem[];
+    const XpRmsParams &p = *(const XpRmsParams *)(plans + (size_t)blockIdx.y * idl::PLAN_BYTES + idl::PLAN_PARAMS);
+    wgp_dev::XpArgs x = p.x;
+    x.dy = uniform_ptr(x.dy); x.xh = uniform_ptr(x.xh); x.xl = uniform_ptr(x.xl);
+    wgp_dev::xplanes_body(x, wgp_b_smem, [&](int tix) {
+        if ((int)blockIdx.x < p.n_tail)
+            rmsprop_body<true, true>(p.a, p.hyper, p.ctl, p.batch_advance, 0, 0, idl_dev::GatherArgs{}, (int)blockIdx.x, tix,
+                                     (unsigned int *)(wgp_b_smem + wgp_dev::LDS_BYTES) + 3);
+    });
+}
+
 }  // namespace
 
 extern "C" {
@@ -1701,11 +1758,18 @@ static int rmsprop_launch(int count, float *const *params, const float *const *g
     for (int i = count; i <= 8; ++i) a.first[i] = nb_total;
     const int64_t extra = g.y != nullptr ? idl_dev::gather_blocks(g.f, g.batch) : 0;
     if (xp != nullptr) {                    // ... carried by the loader waves of the two-plane dW1 tiles (wgrad_xplanes_rms_kernel)
-        IDL_REQUIRE(big == nullptr && l1 == nullptr && l1p == nullptr && red == nullptr && extra == 0 && idl::take_plan() == nullptr,
-                    "wgrad_xplanes_rms: no other tiles, no batch assembly, not recordable");
+        IDL_REQUIRE(big == nullptr && l1 == nullptr && l1p == nullptr && red == nullptr && extra == 0, "wgrad_xplanes_rms: no other tiles, no batch assembly");
         idl::DeviceInfo di;
         if (const int rc = idl::device_info(&di); rc != IDL_OK) return rc;
         IDL_REQUIRE(nb_total + a.wg_tiles <= xp->tiles && xp->tiles <= di.cus, "wgrad_xplanes_rms: the tail's blocks need a tile each, and every tile its own CU");
+        if (void *plan = idl::take_plan()) {      // recorded, not launched (idl_plan_begin)
+            idl::PlanHead h{};
+            h.kind = idl::PLAN_WGRAD_XPLANES; h.grid[0] = (unsigned)xp->tiles; h.grid[1] = 1; h.grid[2] = 1; h.block = wgp_dev::NT; h.lds = wgp_dev::LDS_BYTES + 16;
+            memcpy(plan, &h, sizeof(h));
+            const XpRmsParams xr{*xp, a, hyper, ctl, batch_advance, nb_total + a.wg_tiles};
+            memcpy((unsigned char *)plan + idl::PLAN_PARAMS, &xr, sizeof(xr));
+            return IDL_OK;
+        }
         static bool attr_set[64] = {};
         int dev = 0;
         IDL_HIP_TRY(hipGetDevice(&dev));
@@ -1905,6 +1969,13 @@ int idl_reduce_parts_rms(float *part, int64_t slab_elems, const int64_t *step_co
                 "reduce_parts_rms: the step counter's snapshot needs both pointers and a launch without the tail (which moves the counter)");
     ReduceArgs r{(float4 *)part, slab_elems / 4, l1p_dev::KSPLIT, (int)((slab_elems / 4 + 256 * RED_U - 1) / (256 * RED_U)), step_counter, step_snapshot};
     if (count == 0) {
+        if (void *plan = idl::take_plan()) {      // recorded, not launched (idl_plan_begin)
+            idl::PlanHead h{};
+            h.kind = idl::PLAN_REDUCE; h.grid[0] = (unsigned)r.blocks; h.grid[1] = 1; h.grid[2] = 1; h.block = 256;
+            memcpy(plan, &h, sizeof(h));
+            memcpy((unsigned char *)plan + idl::PLAN_PARAMS, &r, sizeof(r));
+            return IDL_OK;
+        }
         hipLaunchKernelGGL(reduce_rms_kernel, dim3((unsigned)r.blocks), dim3(256), 0, (hipStream_t)stream, r, RmsArgs{}, (const float *)nullptr, (int64_t *)nullptr,
                            (int64_t)0, 0);
         IDL_HIP_TRY(hipGetLastError());
@@ -1939,7 +2010,8 @@ int idl_wgrad_xplanes_rms(const float *dy, const void *x_hi, const void *x_lo, i
     x.ctl = step_snapshot != nullptr ? (const long long *)step_snapshot : (const long long *)ctl;
     x.m = m; x.n_out = n_out; x.n_in = n_in; x.ldx = ld_x;
     x.tiles_m = n_out / wgp_dev::TM; x.tiles = x.tiles_m * (n_in / wgp_dev::TN);
-    x.dbg = 0;
+    static const int wgp_dbg = getenv("IDELUCS_WGP_DBG") ? atoi(getenv("IDELUCS_WGP_DBG")) : 0;      // (timing ablations; wgrad_planes_device.h)
+    x.dbg = wgp_dbg;
     idl_dev::GatherArgs g{};
     return rmsprop_launch(count, params, grads, grad_parts, square_avg_all, sizes, hyper, ctl, batch_advance, loss_rows, loss_m, w_nce, w_iic, out, g,
                           stream, wg_index, wg_dy, wg_x, wg_m, wg_n_out, wg_n_in, wg_grad, wg_x_transposed, nullptr, -1, nullptr, w1_index, nullptr, nullptr, &x);
@@ -2007,6 +2079,25 @@ int idl_plan_launch(const void *host_plans, const void *dev_plans, int n_voters,
         hipLaunchKernelGGL(wgrad_rmsprop_batched_kernel, dim3(h.grid[0], (unsigned)n_voters), dim3(h.block), wg_dev::IMG_BYTES, st, dp);
         break;
     }
+    case idl::PLAN_L1_PLANES:
+    case idl::PLAN_WGRAD_XPLANES: {
+        static bool attr_set[64] = {};
+        int dev = 0;
+        IDL_HIP_TRY(hipGetDevice(&dev));
+        if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+            IDL_HIP_TRY(hipFuncSetAttribute((const void *)l1_planes_batched_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, l1p_dev::LDS_BYTES));
+            IDL_HIP_TRY(hipFuncSetAttribute((const void *)wgrad_xplanes_rms_batched_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, wgp_dev::LDS_BYTES + 16));
+            attr_set[dev] = true;
+        }
+        if (h.kind == idl::PLAN_L1_PLANES)
+            hipLaunchKernelGGL(l1_planes_batched_kernel, dim3(h.grid[0], (unsigned)n_voters), dim3(h.block), l1p_dev::LDS_BYTES, st, dp);
+        else
+            hipLaunchKernelGGL(wgrad_xplanes_rms_batched_kernel, dim3(h.grid[0], (unsigned)n_voters), dim3(h.block), wgp_dev::LDS_BYTES + 16, st, dp);
+        break;
+    }
+    case idl::PLAN_REDUCE:
+        hipLaunchKernelGGL(reduce_batched_kernel, dim3(h.grid[0], (unsigned)n_voters), dim3(h.block), 0, st, dp);
+        break;
     case idl::PLAN_NCE:
         return idl::nce_plan_launch(h, dev_plans, n_voters, st);
     default:

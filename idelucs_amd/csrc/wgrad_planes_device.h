@@ -160,7 +160,6 @@ __device__ __forceinline__ void xplanes_body(const XpArgs &a, unsigned char *sme
         // ================= a loader: a chunk is 2 requests of 16 bytes (dy, into the register ring) + 4 DMA instructions (x's planes, into the
         // x stage of the chunk).  All six count on vmcnt and retire in order: a chunk is in when at most 6 x (chunks requested behind it) are out.
         const int lt = tid - 256, lw = wv - 4;
-        f32x4 ra[PF][2];
         float mx = 0.f, sc_dy = 1.f;                         // (the scale: set behind the barrier below)
         uint32_t va[2], la;
         {
@@ -179,27 +178,54 @@ __device__ __forceinline__ void xplanes_body(const XpArgs &a, unsigned char *sme
             px[i] = pq == 0 ? a.xh : a.xl;
         }
         const int64_t ca = (int64_t)KC * a.n_out * 4, cx = (int64_t)KC * a.ldx * 2;      // a chunk's bytes of rows
+        // THE RING'S REGISTERS ARE FIXED: v[232:255], eight a slot, outside what the compiler allocates (the kernel needs ~200 of its 256; the
+        // requests name them as clobbers).  A request whose target is a compiler-visible value is unsafe however its wait is written: the
+        // compiler takes the value for available at once and may COPY the register before the wait -- it did, in front of the three-way
+        // branch of the waits: `v_mov v[24:31], v[0:7]; s_waitcnt vmcnt(0)` -- and the copy holds whatever the register held: the right
+        // data when the request had landed long before (warm caches: every test), garbage when it had not (a 512 MB fill in front of the
+        // launch, another process on the GPU: a different result every run).  Here the values enter the compiler's view only through the
+        // v_movs BEHIND the wait, inside one asm statement.
         auto request = [&](int c, int slot) {
             const char *pa = (const char *)a.dy + c * ca;
-#pragma unroll
-            for (int u = 0; u < 2; ++u) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(ra[slot][u]) : "v"(va[u]), "s"(pa) : "memory");
+            if (slot == 0)
+                asm volatile("global_load_dwordx4 v[232:235], %0, %2\n\tglobal_load_dwordx4 v[236:239], %1, %2" : : "v"(va[0]), "v"(va[1]), "s"(pa)
+                             : "memory", "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239");
+            else if (slot == 1)
+                asm volatile("global_load_dwordx4 v[240:243], %0, %2\n\tglobal_load_dwordx4 v[244:247], %1, %2" : : "v"(va[0]), "v"(va[1]), "s"(pa)
+                             : "memory", "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247");
+            else if (slot == 2)
+                asm volatile("global_load_dwordx4 v[248:251], %0, %2\n\tglobal_load_dwordx4 v[252:255], %1, %2" : : "v"(va[0]), "v"(va[1]), "s"(pa)
+                             : "memory", "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255");
             const uint32_t xs = lds0 + (uint32_t)((c % NX) * XSTAGE);
 #pragma unroll
             for (int i = 0; i < 4; ++i) dma16(vx[i], (const char *)px[i] + c * cx, xs + lx[i]);
         };
-#define WGP_WAIT(N, SL) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(ra[SL][0]), "+v"(ra[SL][1]) : : "memory")
-        auto wait_behind = [&](int chunks, int slot) {       // (uniform) the requests of `chunks` later chunks may still be in flight
-            if (chunks >= 2) WGP_WAIT(12, slot);
-            else if (chunks == 1) WGP_WAIT(6, slot);
-            else WGP_WAIT(0, slot);
+#define WGP_FETCH(N, B0, B1, B2, B3, B4, B5, B6, B7)                                                                                  \
+    asm volatile("s_waitcnt vmcnt(" #N ")\n\tv_mov_b32 %0, " #B0 "\n\tv_mov_b32 %1, " #B1 "\n\tv_mov_b32 %2, " #B2 "\n\tv_mov_b32 %3, " #B3     \
+                 "\n\tv_mov_b32 %4, " #B4 "\n\tv_mov_b32 %5, " #B5 "\n\tv_mov_b32 %6, " #B6 "\n\tv_mov_b32 %7, " #B7                           \
+                 : "=v"(r0[0]), "=v"(r0[1]), "=v"(r0[2]), "=v"(r0[3]), "=v"(r1[0]), "=v"(r1[1]), "=v"(r1[2]), "=v"(r1[3]) : : "memory")
+#define WGP_FETCH_SLOT(N)                                                                                                             \
+    do {                                                                                                                              \
+        if (slot == 0) WGP_FETCH(N, v232, v233, v234, v235, v236, v237, v238, v239);                                                  \
+        else if (slot == 1) WGP_FETCH(N, v240, v241, v242, v243, v244, v245, v246, v247);                                             \
+        else WGP_FETCH(N, v248, v249, v250, v251, v252, v253, v254, v255);                                                            \
+    } while (0)
+        // (uniform) wait until the requests of at most `chunks` later chunks are in flight, then take the slot's eight registers
+        auto fetch = [&](int chunks, int slot, f32x4 &r0, f32x4 &r1) {
+            if (chunks >= 2) WGP_FETCH_SLOT(12);
+            else if (chunks == 1) WGP_FETCH_SLOT(6);
+            else WGP_FETCH_SLOT(0);
         };
-        auto deposit = [&](int c, int slot) {
+        auto deposit = [&](int c, int chunks_behind, int slot) {
+            f32x4 r0, r1;
+            fetch(chunks_behind, slot, r0, r1);
+            if (a.dbg & 4) return;
             const uint32_t st = lds0 + (uint32_t)((c % ND) * DSTAGE);
             uint2 a0, a1, b0, b1;
-            split4c(ra[slot][0], sc_dy, a0, a1);
-            split4c(ra[slot][1], sc_dy, b0, b1);
+            split4c(r0, sc_dy, a0, a1);
+            split4c(r1, sc_dy, b0, b1);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) mx = fmaxf(mx, fmaxf(fabsf(ra[slot][0][e]), fabsf(ra[slot][1][e])));
+            for (int e = 0; e < 4; ++e) mx = fmaxf(mx, fmaxf(fabsf(r0[e]), fabsf(r1[e])));
             *(__attribute__((address_space(3))) u32x4 *)(uintptr_t)(st + la) = u32x4{a0.x, a0.y, b0.x, b0.y};
             *(__attribute__((address_space(3))) u32x4 *)(uintptr_t)(st + PLANE + la) = u32x4{a1.x, a1.y, b1.x, b1.y};
         };
@@ -208,8 +234,8 @@ __device__ __forceinline__ void xplanes_body(const XpArgs &a, unsigned char *sme
         __builtin_amdgcn_s_barrier();                        // the exponent is in LDS
         kexp = *(const int *)(smem + LDS_BYTES);
         sc_dy = __builtin_ldexpf(1.f, kexp);
-        wait_behind(2, 0); deposit(0, 0); request(PF, 0);            // x stage 3: never used yet
-        wait_behind(2, 1); deposit(1, 1); request(PF + 1, 1);        // x stage 4
+        deposit(0, 2, 0); request(PF, 0);                    // x stage 3: never used yet
+        deposit(1, 2, 1); request(PF + 1, 1);                // x stage 4
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                        // chunks 0 and 1 are in LDS
         for (int base = 0; base < nc; base += PF) {
@@ -220,15 +246,15 @@ __device__ __forceinline__ void xplanes_body(const XpArgs &a, unsigned char *sme
                 const int d = i + 2, slot = (u + 2) % PF;
                 if (d < nc) {
                     // requested so far: up to min(d + PF - 1, nc - 1)
-                    wait_behind(nc - 1 - d < PF - 1 ? nc - 1 - d : PF - 1, slot);
-                    deposit(d, slot);
+                    deposit(d, nc - 1 - d < PF - 1 ? nc - 1 - d : PF - 1, slot);
                     if (d + PF < nc) request(d + PF, slot);
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
             }
         }
-#undef WGP_WAIT
+#undef WGP_FETCH
+#undef WGP_FETCH_SLOT
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64)); mx = fmaxf(mx, __shfl_xor(mx, 16, 64)); mx = fmaxf(mx, __shfl_xor(mx, 8, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 4, 64)); mx = fmaxf(mx, __shfl_xor(mx, 2, 64)); mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
         if (lane == 0) {                                     // (|dy| >= 0: the bit patterns order as the values do)

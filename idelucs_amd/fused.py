@@ -163,6 +163,11 @@ class FusedLinearTrainer:
         self._side = torch.cuda.Stream(device=self.dev)     # second branch of the step (see step_on_batch)
         self._split16 = os.environ.get("IDELUCS_SPLIT16", "0") == "1"
         self._split_state = None
+        # TEST HOOK (IDELUCS_TEST_COLD=1; tests/test_gpu_planes.py): a 512 MB fill in front of the step's launches, so that every load of
+        # the hand-scheduled kernels comes from HBM instead of a warm L2/MALL -- a load consumed before its wait is right when it landed
+        # early and wrong when it did not (DESIGN.md History, round 5), and only cold caches show that
+        self._cold = os.environ.get("IDELUCS_TEST_COLD", "0") == "1"
+        self._cold_buf = None
         # Round 5, default (IDELUCS_PLANES=0: the fp32 tiles below; csrc/planes.h): the two big products on the fp16 matrix cores from operands kept
         # as two fp16 planes (22 significand bits a factor, three products, fp32 accumulators: closer to a float64 product than an fp32 GEMM) --
         # the batch's planes written by the workgroups that assemble it, W1's by the epilogue of the dW1 tiles that update it.  A step
@@ -171,6 +176,11 @@ class FusedLinearTrainer:
         self._planes = os.environ.get("IDELUCS_PLANES", "1") != "0"
         self._planes_reduce_launch = os.environ.get("IDELUCS_PLANES_REDUCE", "launch") != "mid"
         self._planes_fork = os.environ.get("IDELUCS_PLANES_FORK", "0") == "1"
+        # ... and the same for a rank's voters in lockstep (BatchedLinearTrainer; IDELUCS_LOCKSTEP_PLANES=0: their products as batched fp32
+        # library GEMMs instead): the six launches of the two-plane step recorded per voter and run once for all of them, blockIdx.y = voter
+        # -- the lone voters' steps bit for bit (tests/test_gpu_planes.py), 47.5 / 45.4 / 43.6 ms a voter-epoch in batches of 2 / 4 / 8
+        # against 54.2 alone (fp32 GEMMs: 58.9 / 54.8 / 52.6)
+        self._planes_lockstep = os.environ.get("IDELUCS_LOCKSTEP_PLANES", "1") != "0"
         # ... and dW1 from the batch's planes too (csrc/wgrad_planes.hip); the assembling workgroups then write the planes ONLY
         self._planes_wgrad = os.environ.get("IDELUCS_PLANES_WGRAD", "1") != "0"
         # ... whose loader waves run the step's optimizer tail under the tiles' epilogue (IDELUCS_PLANES_TAIL=reduce: the tail beside the
@@ -286,6 +296,12 @@ class FusedLinearTrainer:
               and self._dw2_inlaunch)
         early = next_from is not None and self._early_gather and m % 16 == 0   # next batch -> bf.xs[1 - xi] by the mid launches
         early_f = next_from is not None and self._early_fwd and m % 16 == 0    # ... by the mid-forward launch alone
+        if (self._rec is not None and self._planes and self._planes_lockstep and tl and early and self._early_split and not self._nce_bwd_fused
+                and not self._l1_fused and not self._l1_bare and self._wgrad_fused and not self._wgrad_own_launch and not self._overlap
+                and self._joint_inlaunch and self._dw3_partial and bf.nce_fused and C <= 48
+                and bool(_L.idl_l1_planes_supported(m, self.H1, self.F)) and bool(_L.idl_wgrad_xplanes_supported(m, self.H1, self.F))
+                and 144 <= (self.H1 // 64) * (self.F // 128) <= self._cus and next_from.n < 60_000_000):
+            return self._record_planes_step(bf, tr, next_from, xi)
         # tail-in-layer-1: own layer-1 tiles, the dW1 tiles as the step's last launch, the rest of the optimizer in the NEXT layer-1 launch
         tm = (self._tail_l1 and tl and early and self._early_split and self._rec is None and not self._l1_fused and not self._l1_bare
               and not self._nce_bwd_fused and self._wgrad_fused and not self._wgrad_own_launch and not self._shared_buffers
@@ -376,6 +392,8 @@ class FusedLinearTrainer:
             self._mm(self.W1, x.t(), r1T)
         else:
             torch.addmm(self.b1, x, self.W1.t(), out=r1)
+        if self._cold:
+            self._evict()
         if pl:      # mid_fwd adds the eight partial sums; its spare workgroups assemble the first half of the next batch AND its planes
             st = next_from
             chk(_L.idl_mid_fwd_gather_planes(_p(pb["part"][xi]), _p(self.b1), 1 if self._planes_reduce_launch else 3, _p(self.W2), _p(self.b2), _p(self.W3), _p(self.b3),
@@ -601,6 +619,42 @@ class FusedLinearTrainer:
                                     _p(self.ctl), batch_advance, _p(bf.loss_rows), m, 1.0 - self.weight, self.weight, _p(self.out),
                                     _stream()))
 
+    def _record_planes_step(self, bf, tr, st, xi):
+        """The two-plane step (step_on_batch's default form of a lone voter: layer-1 tiles, the sum of their partials, mid_fwd, InfoNCE + IIC,
+        mid_bwd, the dW1 tiles with the tail on their loader waves) as six RECORDED launches: BatchedLinearTrainer runs each once for all the
+        voters of a rank.  Nothing is launched here but what allocates this voter's plane buffers."""
+        m, C = bf.m, self.C
+        pb = _planes_of(bf, self.F)
+        if self._w1_planes is None:
+            self._w1_planes = (torch.empty(self.W1.shape, dtype=torch.int16, device=self.dev), torch.empty(self.W1.shape, dtype=torch.int16, device=self.dev),
+                               torch.zeros(1, dtype=torch.int32, device=self.dev))
+        if self._split_state is None:
+            self._split_state = torch.zeros(int(_L.idl_wgrad_split_state_words()), dtype=torch.int64, device=self.dev)
+        wh, wl, flag = self._w1_planes
+        part = pb["part"][xi]
+        r1 = part[0]
+        gW1, gb1, gW2, gb2, gW3, gb3 = self.grads
+        nce_coef = (1.0 - self.weight) / (m * TEMPERATURE)
+        g2 = self._gsplit
+        self._k(_L.idl_l1_planes, _p(wh), _p(wl), self.F, _p(pb["xh"][xi]), _p(pb["xl"][xi]), self.F, m, self.H1, self.F, _p(part), _stream())
+        self._k(_L.idl_reduce_parts_rms, _p(part), self.H1 * m, _p(self.ctl), _p(self._ctl_snap), 0, None, None, None, None, None, None, None, None, 0, 0.0, 0.0,
+                None, 0, -1, None, None, 0, 0, 0, 0, None, 0, _stream())
+        self._k(_L.idl_mid_fwd_gather_planes, _p(part), _p(self.b1), 1, _p(self.W2), _p(self.b2), _p(self.W3), _p(self.b3),
+                m, C, tr, self.seed, _p(self.ctl), _p(bf.f), _p(bf.inv), _p(bf.r2), _p(bf.z),
+                _p(st.feats), st.n, st.f, st.n * st.f, _p(self._perm), _p(self.ctl[1:]), m // 2, st.n_pairs, m // 2,
+                _p(st.mean), _p(st.scale), _p(st.inv_scale), None, _p(pb["xh"][1 - xi]), _p(pb["xl"][1 - xi]), _p(flag), 0, g2, 8, _stream())
+        self._k(_L.idl_nce_fused_iic_z, _p(bf.f), m, TEMPERATURE, _p(bf.lse), _p(bf.loss_rows), _p(bf.G), _p(bf.nce_ws), _p(bf.z),
+                _p(bf.P0), C, self.lamb, EPS, self.weight, _p(bf.iic_scratch), _p(self.out), _stream())
+        self._k(_L.idl_mid_bwd_gather_planes, _p(bf.z), _p(bf.r2), _p(bf.f), _p(bf.inv), _p(bf.G), bf.G.shape[0], _p(bf.P0), _p(self.W3), _p(self.W2),
+                _p(r1), m, C, tr, nce_coef, _p(bf.dlogits), _p(bf.dlat), _p(bf.dr1), _p(gb1), _p(gb2), _p(gb3), _p(gW3),
+                _p(st.feats), st.n, st.f, st.n * st.f, _p(self._perm), _p(self.ctl[1:]), m // 2, st.n_pairs, m // 2,
+                _p(st.mean), _p(st.scale), _p(st.inv_scale), None, _p(pb["xh"][1 - xi]), _p(pb["xl"][1 - xi]), _p(flag), g2, 8, 8, 1, _stream())
+        tail = (len(self.params), self._pp, self._gp, self._parts, self._vp, self._sz, _p(self.hyper),
+                _p(self.ctl), _p(bf.loss_rows), m, 1.0 - self.weight, self.weight, _p(self.out))
+        wg = (2, _p(bf.dlat), _p(r1), 1, m, self.H2, self.H1, _p(gW2), m // 2, _stream())
+        self._k(_L.idl_wgrad_xplanes_rms, _p(bf.dr1), _p(pb["xh"][xi]), _p(pb["xl"][xi]), self.F, m, self.H1, self.F, None, _p(self.W1),
+                _p(self.square_avg[0]), _p(self._split_state), _p(self._ctl_snap), _p(wh), _p(wl), _p(flag), *tail, 0, *wg)
+
     def _tail_launch(self, bf, xi, r1, l1=None, l1p=None, red=None):
         """The optimizer's tail of the step that ran on (bf, xi) with the activations r1: dW2 tiles + RMSprop on every tensor but W1 + step
         loss + step counter -- behind the layer-1 tiles of the next step (l1 = (x, m, r1T) of THAT step; l1p = its two-plane form's
@@ -644,6 +698,11 @@ class FusedLinearTrainer:
             x = bf.xs[xi]
             _lib.check(_L.idl_split_planes(_p(x), x.numel(), int(_L.idl_planes_exponent(0)), _p(pb["xh"][xi]), _p(pb["xl"][xi]), _p(self._w1_planes[2]), _stream()))
             pb["valid"][xi] = True
+
+    def _evict(self):
+        if self._cold_buf is None:
+            self._cold_buf = torch.empty(128 << 20, dtype=torch.float32, device=self.dev)
+        self._cold_buf.fill_(1.0)
 
     def planes_overflowed(self):
         """Whether an entry of W1 (|w| >= 15.8) or of a standardised batch (|x| > 8 125: a mimic's feature thousands of the originals' standard
@@ -780,6 +839,7 @@ class BatchedLinearTrainer:
         self._graphs = {}
         self._w1_in_launch = False
         self._l1_in_launch = False
+        self._planes_step = False
 
     def stack(self, m):
         """Stacked GEMM operands of batch shape m: XS[2][L, m, F], R1 [L, m, 512] (its transposed image [L, 512, m] is the layer-1
@@ -808,8 +868,9 @@ class BatchedLinearTrainer:
                         rec, t._rec = t._rec, None
                     # 4 kernel launches + the two big products as batched GEMMs; a product on own tiles is a recorded launch instead:
                     # the layer-1 forward (idl_l1_fwd) in front, dW1 at the head of the optimizer launch
-                    if (len(rec.plans), rec.mms) not in ((4, 2), (4, 1), (5, 1), (5, 0)):
+                    if (len(rec.plans), rec.mms) not in ((4, 2), (4, 1), (5, 1), (5, 0), (6, 0)):
                         raise RuntimeError("the recorded step is not the default launch sequence")
+                    self._planes_step = len(rec.plans) == 6          # the two-plane step: six recorded launches, no library GEMM
                     self._l1_in_launch = len(rec.plans) == 5
                     self._w1_in_launch = rec.mms == (0 if self._l1_in_launch else 1)
                     recs.append(rec.plans)
@@ -826,6 +887,12 @@ class BatchedLinearTrainer:
         """One optimizer step of every voter on the batches in XS[xi] (assembling the next ones into XS[1 - xi])."""
         L = self.L
         ops = prog[xi]
+        if self._planes_step:
+            for k in range(6):                                # l1, reduce, mid_fwd, InfoNCE passes, mid_bwd, dW1 + RMSprop + tail: every voter's, one launch each
+                if self.trainers[0]._cold:
+                    self.trainers[0]._evict()
+                _lib.check(_L.idl_plan_launch(ctypes.c_void_p(ops[k][0].data_ptr()), _p(ops[k][1]), L, _stream()))
+            return
         k0 = 0
         if self._l1_in_launch:                                                           # every voter's layer-1 tiles + epilogue: one launch
             _lib.check(_L.idl_plan_launch(ctypes.c_void_p(ops[0][0].data_ptr()), _p(ops[0][1]), L, _stream()))
@@ -857,6 +924,11 @@ class BatchedLinearTrainer:
             for t in self.trainers:
                 t._gather(store, t.buffers(m))            # prologue: batch 0 of every voter
             prog = self._program(store, m)
+            if self._planes_step:                         # W1's planes (the weights were set since the last epoch) and those of every voter's batch 0
+                for t in self.trainers:
+                    t._w1_planes_fresh = False
+                    bf = t.buffers(m)
+                    t._prepare_planes(bf, _planes_of(bf, t.F), 0)
             per = self.trainers[0]._steps_per_graph
             while per > 2 and n_full < 2 + 2 * per:
                 per = max(2, per // 4 * 2)

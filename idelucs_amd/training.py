@@ -42,14 +42,15 @@ def plane_step_applies(model):
 
 def voter_lanes(n_voters_here, model=None):
     """How many voters of one rank train in lockstep as one batch (IDELUCS_VOTER_LANES; 1 = one after the other).
-    One training step is two big products and five latency-bound launches; batched, the products become batched library GEMMs and each of
-    the five launches serves every voter of the batch (fused.BatchedLinearTrainer).  Default: all of a rank's voters, up to 8 -- unless
-    there are just two and a lone voter's step takes the two-plane products (plane_step_applies): at cfg2 a voter-epoch costs 54.0-56.6 ms
-    alone against 58.5-59.0 / 54.7-55.3 / 52.1-52.6 ms in lockstep batches of 2 / 4 / 8 (bench.py: predicted_fixed_job, over the boxes), so
-    two voters train one after the other."""
+    One training step is a handful of launches, most of them latency-bound; batched, each launch serves every voter of the batch
+    (fused.BatchedLinearTrainer: blockIdx.y = voter), the two big products included when the step takes them from fp16 planes
+    (plane_step_applies).  Default: all of a rank's voters, up to 8: at cfg2 a voter-epoch costs 54.2 ms alone and 47.5 / 45.4 / 43.6 ms in
+    lockstep batches of 2 / 4 / 8 (bench.py: predicted_fixed_job).  With IDELUCS_LOCKSTEP_PLANES=0 a batch runs the products as batched
+    fp32 library GEMMs (58.9 / 54.8 / 52.6 ms): a lone voter on planes then beats a batch of 2, and two voters train one after the other."""
     env = os.environ.get("IDELUCS_VOTER_LANES")
     lanes = max(1, min(int(env) if env is not None else 8, n_voters_here))
-    if env is None and model is not None and lanes == 2 and plane_step_applies(model):
+    if (env is None and model is not None and lanes == 2 and plane_step_applies(model)
+            and os.environ.get("IDELUCS_LOCKSTEP_PLANES", "1") == "0"):
         return 1
     return lanes
 

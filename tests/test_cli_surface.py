@@ -49,13 +49,15 @@ def test_reference_package_name_resolves_to_this_implementation():
 
 
 def test_lane_policy_of_a_ranks_voters(monkeypatch):
-    """training.voter_lanes: all of a rank's voters in lockstep, up to 8 -- but two of them one after the other when a lone voter's step
-    takes the two-plane products (faster alone than in a batch of 2: bench.py's predicted_fixed_job); IDELUCS_VOTER_LANES overrides."""
+    """training.voter_lanes: all of a rank's voters in lockstep, up to 8; IDELUCS_VOTER_LANES overrides.  With the lockstep step on fp32
+    library GEMMs (IDELUCS_LOCKSTEP_PLANES=0) two voters train one after the other when a lone voter's step takes the two-plane products
+    (faster alone than in such a batch of 2: bench.py's predicted_fixed_job)."""
     import types
     import torch
     from idelucs_amd import training
     monkeypatch.delenv("IDELUCS_VOTER_LANES", raising=False)
     monkeypatch.delenv("IDELUCS_PLANES", raising=False)
+    monkeypatch.delenv("IDELUCS_LOCKSTEP_PLANES", raising=False)
 
     def model(F, batch_sz, fused=True, H1=512):
         net = types.SimpleNamespace(layers=[torch.nn.Linear(F, H1)])
@@ -64,6 +66,8 @@ def test_lane_policy_of_a_ranks_voters(monkeypatch):
     assert training.plane_step_applies(cfg2) and training.plane_step_applies(model(1024, 128))
     assert not training.plane_step_applies(model(256, 512)) and not training.plane_step_applies(model(4096, 48))
     assert not training.plane_step_applies(model(4096, 512, fused=False)) and not training.plane_step_applies(model(4096, 512, H1=256))
+    assert [training.voter_lanes(n, cfg2) for n in (1, 2, 3, 4, 8, 11)] == [1, 2, 3, 4, 8, 8]
+    monkeypatch.setenv("IDELUCS_LOCKSTEP_PLANES", "0")
     assert [training.voter_lanes(n, cfg2) for n in (1, 2, 3, 4, 8, 11)] == [1, 1, 3, 4, 8, 8]
     assert [training.voter_lanes(n, model(256, 512)) for n in (1, 2, 4, 8)] == [1, 2, 4, 8]        # k = 4: the fp32 step, lockstep pays
     assert [training.voter_lanes(n) for n in (1, 3, 9)] == [1, 3, 8]

@@ -397,3 +397,58 @@ def test_step_on_planes_with_200_output_units(dev, monkeypatch):
     # (the step losses of this mode change sign inside an epoch and their sum nearly cancels: the bound is per step, on losses of ~0.3)
     for a_, b_, tol in zip(sums["0"], sums["1"], (1e-4, 1e-3)):
         assert np.isfinite(b_) and abs(b_ - a_) <= tol * nb, (sums,)
+
+
+@pytest.mark.parametrize("n,graph", [(1500, False), (4200, False), (4200, True)])
+def test_lockstep_voters_on_planes_are_the_lone_voters(dev, monkeypatch, n, graph):
+    """IDELUCS_LOCKSTEP_PLANES=1: three voters of a rank in lockstep with the six launches of the two-plane step recorded and run once for
+    all of them (blockIdx.y = voter) -- the same kernel bodies on the same operands in the same order as three lone voters: an epoch
+    (8 or 24 full batches + a partial one, dropout on), launch by launch or as a captured graph, leaves the same loss sums, parameters
+    and counters."""
+    import torch
+    import test_gpu_encoder as E
+    from idelucs_amd.fused import FusedLinearTrainer, BatchedLinearTrainer
+    monkeypatch.setenv("IDELUCS_PLANES", "1")
+    monkeypatch.setenv("IDELUCS_LOCKSTEP_PLANES", "1")
+    bt = E._batched_like_single(dev, n, graph, copy, torch, FusedLinearTrainer, BatchedLinearTrainer)
+    assert bt._planes_step
+    assert not any(t.planes_overflowed() for t in bt.trainers)
+
+
+@pytest.mark.parametrize("form", ["planes", "planes_fp32_wgrad", "fp32"])
+def test_cold_caches_leave_an_epoch_bit_identical(dev, monkeypatch, form):
+    """The regression test of round 5's loader race (wgrad_planes_device.h: a copy of the dy ring's registers in front of their wait):
+    IDELUCS_TEST_COLD=1 puts a 512 MB fill in front of every step's mid_fwd, so that the loads of the launches behind it come from HBM
+    instead of a warm L2/MALL.  An epoch's loss sum and parameters are then what they are with warm caches, bit for bit, three times in
+    a row -- a kernel that consumes a load before it has landed passes every warm test and fails this one."""
+    import torch
+    import test_gpu_encoder as E
+    from idelucs_amd.fused import FusedLinearTrainer
+    monkeypatch.setenv("IDELUCS_PLANES", "0" if form == "fp32" else "1")
+    monkeypatch.setenv("IDELUCS_PLANES_WGRAD", "0" if form == "planes_fp32_wgrad" else "1")
+    store, net0 = E._cfg2_store_and_net(dev, 4200, seed=4)
+    runs = []
+    for cold in ("0", "1", "1", "1"):
+        monkeypatch.setenv("IDELUCS_TEST_COLD", cold)
+        tr = FusedLinearTrainer(copy.deepcopy(net0), lr=1e-3, weight=0.25, lamb=2.8, seed=11)
+        assert tr._cold == (cold == "1")
+        tr.begin_voter(0)
+        gen = torch.Generator(device=dev); gen.manual_seed(100)
+        total, nb = tr.run_epoch(store, 512, use_graph=False, generator=gen)
+        runs.append((total.item(), [p_.detach().clone() for p_ in tr.params]))
+    for total, params in runs[1:]:
+        assert total == runs[0][0], [r[0] for r in runs]
+        for a_, b_ in zip(params, runs[0][1]):
+            assert torch.equal(a_, b_)
+
+
+def test_cold_caches_leave_lockstep_voters_the_lone_voters(dev, monkeypatch):
+    """The same with the eviction in front of each of the six batched launches of three voters in lockstep."""
+    import torch
+    import test_gpu_encoder as E
+    from idelucs_amd.fused import FusedLinearTrainer, BatchedLinearTrainer
+    monkeypatch.setenv("IDELUCS_PLANES", "1")
+    monkeypatch.setenv("IDELUCS_LOCKSTEP_PLANES", "1")
+    monkeypatch.setenv("IDELUCS_TEST_COLD", "1")
+    bt = E._batched_like_single(dev, 4200, False, copy, torch, FusedLinearTrainer, BatchedLinearTrainer)
+    assert bt._planes_step and bt.trainers[0]._cold

@@ -42,7 +42,7 @@ import torch.distributed as dist
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 matrix peak (v_mfma_f32_32x32x2_f32)
-PMC_PROFILE = "r05_s_vectorise_pmc_k6.json"     # profiles/: FETCH_SIZE / WRITE_SIZE passes of the vectoriser at cfg2
+PMC_PROFILE = "r05_t_vectorise_pmc_k6.json"     # profiles/: FETCH_SIZE / WRITE_SIZE passes of the vectoriser at cfg2
 
 
 def synth_packed(n, L, dev, seed=12345, n_rate=0.0):

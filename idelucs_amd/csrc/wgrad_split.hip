@@ -1,4 +1,11 @@
-// wgrad_split.hip -- EXPERIMENTAL, not in the step (idl_wgrad_rmsprop_split; tests/test_gpu_encoder.py, tools/bench_wgrad_split.py): the
+// wgrad_split.hip -- EXPERIMENTAL, not in the step and not reachable from the trainer (idl_wgrad_rmsprop_split; tests/test_gpu_encoder.py,
+// tools/bench_wgrad_split.py).  KNOWN HAZARD, kept as the record of the A/B only: the loader waves' request ring is the form that was
+// WRONG in wgrad_planes_device.h until round 5's last hours -- asm loads into compiler-visible registers, the wait a branch of three asm
+// statements the registers pass through; the compiler may copy such a register in front of the wait, and the copy is right only when
+// the load has landed (warm caches: the tests here).  The cure is in wgrad_planes_device.h (fixed registers, fetched behind the wait in one
+// asm); this kernel was superseded by it and not converted.  Do not build on it.
+//
+// The
 // weight gradient of Linear(F,512) with RMSprop in its epilogue, as wgrad_device.h's tiles do it, but the product dW = dy^T x on the
 // fp16 MATRIX CORES from operands split into two fp16 planes INSIDE the kernel,
 //     v 2^k = v0 + v1   (v0 = fp16(v 2^k), v1 = fp16(v 2^k - v0): 22 significand bits),

@@ -161,7 +161,6 @@ class FusedLinearTrainer:
         self._bufs = {}
         self._graphs = {}
         self._side = torch.cuda.Stream(device=self.dev)     # second branch of the step (see step_on_batch)
-        self._split16 = os.environ.get("IDELUCS_SPLIT16", "0") == "1"
         self._split_state = None
         # TEST HOOK (IDELUCS_TEST_COLD=1; tests/test_gpu_planes.py): a 512 MB fill in front of the step's launches, so that every load of
         # the hand-scheduled kernels comes from HBM instead of a warm L2/MALL -- a load consumed before its wait is right when it landed
@@ -550,12 +549,6 @@ class FusedLinearTrainer:
                 wh, wl, flag = self._w1_planes
                 chk(_L.idl_wgrad_rmsprop_planes(_p(bf.dr1), _p(x), m, self.H1, self.F, _p(gW1) if self._keep_w1_grad else None, _p(self.W1),
                                                 _p(self.square_avg[0]), _p(self.hyper), _p(wh), _p(wl), _p(flag), _stream()))
-            elif self._split16 and m % 128 == 0 and m >= 256:
-                # EXPERIMENTAL (IDELUCS_SPLIT16=1; csrc/wgrad_split.hip): the product on the fp16 matrix cores from operands split inside the kernel
-                if self._split_state is None:
-                    self._split_state = torch.zeros(int(_L.idl_wgrad_split_state_words()), dtype=torch.int64, device=self.dev)
-                chk(_L.idl_wgrad_rmsprop_split(_p(bf.dr1), _p(x), m, self.H1, self.F, _p(gW1) if self._keep_w1_grad else None, _p(self.W1),
-                                               _p(self.square_avg[0]), _p(self.hyper), _p(self.ctl), _p(self._split_state), _stream()))
             else:
                 chk(_L.idl_wgrad_rmsprop(_p(bf.dr1), _p(x), m, self.H1, self.F, _p(gW1) if self._keep_w1_grad else None, _p(self.W1),
                                          _p(self.square_avg[0]), _p(self.hyper), _stream()))

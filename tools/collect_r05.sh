@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-5 evidence: the driver's bench command, the rocprofv3 kernel stats of the same command, MFMA-busy counters of the epoch's
 # kernels, the optimizer launch's workgroup stamps, the vectoriser's HBM / LDS counters at k = 6, 5 and 4.   bash tools/collect_r05.sh <out_dir>
-out=${1:-gpurun_out/r05_s}
+out=${1:-gpurun_out/r05_t}
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 if [ -z "$SKIP_BENCH" ]; then

@@ -415,7 +415,7 @@ def test_lockstep_voters_on_planes_are_the_lone_voters(dev, monkeypatch, n, grap
     assert not any(t.planes_overflowed() for t in bt.trainers)
 
 
-@pytest.mark.parametrize("form", ["planes", "planes_fp32_wgrad", "fp32"])
+@pytest.mark.parametrize("form", ["planes", "planes_fp32_wgrad", "fp32", "planes_200_units"])
 def test_cold_caches_leave_an_epoch_bit_identical(dev, monkeypatch, form):
     """The regression test of round 5's loader race (wgrad_planes_device.h: a copy of the dy ring's registers in front of their wait):
     IDELUCS_TEST_COLD=1 puts a 512 MB fill in front of every step's mid_fwd, so that the loads of the launches behind it come from HBM
@@ -426,7 +426,7 @@ def test_cold_caches_leave_an_epoch_bit_identical(dev, monkeypatch, form):
     from idelucs_amd.fused import FusedLinearTrainer
     monkeypatch.setenv("IDELUCS_PLANES", "0" if form == "fp32" else "1")
     monkeypatch.setenv("IDELUCS_PLANES_WGRAD", "0" if form == "planes_fp32_wgrad" else "1")
-    store, net0 = E._cfg2_store_and_net(dev, 4200, seed=4)
+    store, net0 = E._cfg2_store_and_net(dev, 4200, seed=4, C=200 if form == "planes_200_units" else 20)
     runs = []
     for cold in ("0", "1", "1", "1"):
         monkeypatch.setenv("IDELUCS_TEST_COLD", cold)

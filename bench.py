@@ -817,6 +817,9 @@ def main():
             "devices": group["devices"], "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak" if V == world and world > 1 and cfg5 else ("strong" if world > 1 else "weak"),
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "dtype_note": ("f32 storage, activations, accumulators and optimizer state throughout; the step's two big products (layer 1, dW1) run on the fp16 matrix "
+                           "cores from operands kept as TWO fp16 planes each (22 significand bits), three products with fp32 accumulators: measured against float64 "
+                           "closer than an fp32 GEMM (tests/test_gpu_planes.py); the plain fp32 form of the same step is timed in fp32_step_form"),
             "config": {"workload": f"BASELINE {cfg_name}{' (variant N: every base an N w.p. %g)' % args.n_rate if args.n_rate > 0 else ''}: "
                                    f"synthetic {args.n} x {args.len} bp, k={args.k}, n_clusters={args.n_clusters}, "
                                    f"n_mimics={args.n_mimics} ({P} views), batch_sz={args.batch_sz}, NetLinear fp32, RMSprop; "

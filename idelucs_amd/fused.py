@@ -162,7 +162,7 @@ class FusedLinearTrainer:
         self._graphs = {}
         self._side = torch.cuda.Stream(device=self.dev)     # second branch of the step (see step_on_batch)
         self._split_state = None
-        # TEST HOOK (IDELUCS_TEST_COLD=1; tests/test_gpu_planes.py): a 512 MB fill in front of the step's launches, so that every load of
+        # TEST HOOK (IDELUCS_TEST_COLD=1; tests/test_gpu_planes.py): a 512 MB fill in front of the step's middle and of each plane kernel, so that every load of
         # the hand-scheduled kernels comes from HBM instead of a warm L2/MALL -- a load consumed before its wait is right when it landed
         # early and wrong when it did not (DESIGN.md History, round 5), and only cold caches show that
         self._cold = os.environ.get("IDELUCS_TEST_COLD", "0") == "1"
@@ -352,6 +352,8 @@ class FusedLinearTrainer:
                 with torch.cuda.stream(self._side):
                     pbf, pxi, pr1 = self._pending
                     self._tail_launch(pbf, pxi, pr1)
+            if self._cold:
+                self._evict()
             chk(_L.idl_l1_planes(_p(wh), _p(wl), self.F, _p(pb["xh"][xi]), _p(pb["xl"][xi]), self.F, m, self.H1, self.F, _p(pb["part"][xi]), _stream()))
             if self._pending is not None:
                 pbf, pxi, pr1 = self._pending
@@ -367,6 +369,8 @@ class FusedLinearTrainer:
                 pbf, pxi, pr1 = self._pending
                 self._tail_launch(pbf, pxi, pr1, l1p=(wh, wl, pb["xh"][xi], pb["xl"][xi], m, pb["part"][xi]))
             else:
+                if self._cold:
+                    self._evict()
                 chk(_L.idl_l1_planes(_p(wh), _p(wl), self.F, _p(pb["xh"][xi]), _p(pb["xl"][xi]), self.F, m, self.H1, self.F, _p(pb["part"][xi]), _stream()))
         elif tm:    # a1^T = W1 x^T on own tiles; the previous step's optimizer tail rides in the same launch
             if self._pending is not None:
@@ -376,6 +380,8 @@ class FusedLinearTrainer:
                 chk(_L.idl_l1_fwd(_p(self.W1), _p(x), None, None, m, self.F, 0, 0, None, _p(r1T), 1, None, _stream()))
         elif plf:   # a1 = x W1^T as eight K-slice partial sums [8][m][512] (the tiles of idl_l1_planes with the operands' roles swapped), then their sum
             wh, wl, _ = self._w1_planes
+            if self._cold:
+                self._evict()
             chk(_L.idl_l1_planes(_p(pb["xh"][xi]), _p(pb["xl"][xi]), self.F, _p(wh), _p(wl), self.F, self.H1, m, self.F, _p(pb["part"][xi]), _stream()))
             chk(_L.idl_reduce_parts_rms(_p(pb["part"][xi]), self.H1 * m, _p(self.ctl), _p(self._ctl_snap), 0, None, None, None, None, None, None, None, None, 0, 0.0, 0.0, None, 0,
                                         -1, None, None, 0, 0, 0, 0, None, 0, _stream()))
@@ -537,6 +543,8 @@ class FusedLinearTrainer:
                     tail = (len(self.params), self._pp, self._gp, self._parts, self._vp, self._sz, _p(self.hyper),
                             _p(self.ctl), _p(bf.loss_rows), m, 1.0 - self.weight, self.weight, _p(self.out))
                     wg = (2, _p(bf.dlat), _p(r1), 1, m, self.H2, self.H1, _p(self.grads[2]), m // 2, _stream())
+                    if self._cold:
+                        self._evict()
                     chk(_L.idl_wgrad_xplanes_rms(_p(bf.dr1), _p(pb["xh"][xi]), _p(pb["xl"][xi]), self.F, m, self.H1, self.F,
                                                  _p(gW1) if self._keep_w1_grad else None, _p(self.W1), _p(self.square_avg[0]),
                                                  _p(self._split_state), _p(self._ctl_snap), _p(wh), _p(wl), _p(flag), *tail, 0, *wg))
@@ -564,6 +572,8 @@ class FusedLinearTrainer:
             tail = (len(self.params), self._pp, self._gp, self._parts, self._vp, self._sz, _p(self.hyper),
                     _p(self.ctl), _p(bf.loss_rows), m, 1.0 - self.weight, self.weight, _p(self.out))
             wg = (2, _p(bf.dlat), _p(r1), 0, m, self.H2, self.H1, _p(gW2), m // 2, _stream())
+            if self._cold:
+                self._evict()
             chk(_L.idl_wgrad_xplanes_rms(_p(bf.dr1), _p(pb["xh"][xi]), _p(pb["xl"][xi]), self.F, m, self.H1, self.F,
                                          _p(gW1) if self._keep_w1_grad else None, _p(self.W1), _p(self.square_avg[0]),
                                          _p(self._split_state), _p(self._ctl_snap), _p(wh), _p(wl), _p(flag), *tail, 0, *wg))

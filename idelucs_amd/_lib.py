@@ -85,7 +85,6 @@ SIGNATURES = {
     "idl_wgrad_supported": (_int, [_int, _int, _int]),
     "idl_wgrad_rmsprop": (_int, [_vp, _vp, _int, _int, _int, _vp, _vp, _vp, _vp, _vp]),
     "idl_wgrad_split_state_words": (_int, []),
-    "idl_wgrad_rmsprop_split": (_int, [_vp, _vp, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "idl_l1_fwd_supported": (_int, [_int, _int, _int]),
     "idl_l1_fwd_parts": (_int, []),
     "idl_l1_fwd": (_int, [_vp, _vp, _vp, _vp, _int, _int, _int, _c.c_uint64, _vp, _vp, _int, _vp, _vp]),

@@ -17,6 +17,9 @@ __global__ __launch_bounds__(NT, 1) void wgrad_xplanes_kernel(XpArgs a)
 
 }  // namespace
 
+// 64-bit words of the state buffer that carries dy's scale from launch to launch (zero at first): 3 arrays of STATE_ARRAY used, 2 x STATE_SLOTS asked for
+extern "C" int idl_wgrad_split_state_words(void) { return 2 * wgp_dev::STATE_SLOTS; }
+
 extern "C" int idl_wgrad_xplanes_supported(int m, int n_out, int n_in)
 {
     return (m % KC == 0 && m / KC >= 2 * PF && n_out >= TM && n_out % TM == 0 && n_in >= TN && n_in % TN == 0 &&

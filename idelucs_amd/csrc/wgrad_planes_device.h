@@ -5,12 +5,16 @@
 // RMSprop(lr, weight_decay=0.01), models.py:88), as wgrad_device.h states them.  The product is dy0 x0 + dy0 x1 + dy1 x0 with fp32
 // accumulators (22 significand bits a factor: closer to a float64 product than the fp32 tiles', tests/test_gpu_planes.py).
 //
-// The kernel is wgrad_split.hip's (64 x 128 tile, the whole contraction, four computing waves reading their operands out of LDS with
-// ds_read_b64_tr_b16 -- both operands lie with the contraction index as the slow one -- and an epilogue that turns the tile around
-// through LDS) with the LARGE operand taken off the loaders' hands: x's planes arrive by LDS-DMA (16 instructions of 1 KiB a chunk of
+// A 64 x 128 tile over the whole contraction, four computing waves reading their operands out of LDS with ds_read_b64_tr_b16 -- both
+// operands lie with the contraction index as the slow one -- and an epilogue that turns the tile around through LDS (the shape of this
+// round's first kernel of the family, which split BOTH operands in its loader waves: removed, History), with the LARGE operand taken off
+// the loaders' hands: x's planes arrive by LDS-DMA (16 instructions of 1 KiB a chunk of
 // 32 rows, whole 256-byte row segments, the 16-byte slots swizzled on the source side), three chunks ahead, into a ring of six stages;
 // only dy (64 columns, 1 / 3 of the bytes, fp32 from mid_bwd) is still split by the loader waves, 8 values a lane a chunk, with the
-// tensor's scale taken from the previous launch's largest entry (wgrad_split.hip: tagged words, 16 x headroom, clamped).
+// tensor's scale 2^k taken from a recent launch's largest |dy| (2^k max ~ 2^12: 16 x headroom, values clamped at +-65 000), kept as tagged
+// words (launch number << 32 | float bits: a newer launch's tag outranks what a word held, nothing is ever reset; the first launch takes
+// K_FIRST).  A coarse k is enough: an entry 2^-15 of the largest still has its absolute error below 2^-28 of the largest.  x's planes carry
+// 2^3 (a standardised feature is at most sqrt(N - 1): 8 sqrt(N) < 65 504 up to N = 6.7e7 sequences).
 // The epilogue also writes the updated W1 as planes for the next step's layer-1 product; W and square_avg are requested before the first
 // product (in the step: 100.6 -> 98.6 us).
 //
@@ -24,9 +28,11 @@
 // ~0.14 us, the LDS reads behind their waits ~0.16, a chunk's six requests ~0.2, MFMAs 0.1 of 0.16 hidden.  Tried and no better:
 // "touches" (one dword of every cache line of the chunk nine further on, dropped into spare LDS by the computing waves, so that the
 // loaders' requests would hit L2): 26.9 against 25.7, the step 100.2 against 98.6 -- the requests are not waiting for first touches.
-// (Two traps on the way, both silent: a request whose target is a register must keep that register out of the compiler's hands until it
-// lands -- every inline-asm request passes its registers THROUGH the wait that covers it; and no switch may skip such a request: a set
-// written under a branch is copied where the paths join, while in flight.)
+// (THE trap on the way, silent with warm caches: a request whose target is a register must keep that register out of the compiler's
+// hands until it lands.  Passing the registers THROUGH the wait that covers them ("+v") orders the asm statements, not the copies the
+// compiler makes of the values: it copied the dy ring in front of its waits.  The loaders' ring now lives in fixed registers the compiler
+// never sees in flight -- below; the computing waves' LDS reads keep the pass-through form with straight-line waits, their ISA holds no
+// copy between a read and its wait, and tests/test_build_resources.py + the cold-cache tests of tests/test_gpu_planes.py watch over both.)
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -53,7 +59,7 @@ constexpr int ND = 3, NX = PF + 3;                           // stages of dy (de
 constexpr int DY_BYTES = ND * DSTAGE;                        // 49 152
 constexpr int LDS_BYTES = DY_BYTES + NX * XSTAGE;            // 147 456
 constexpr int K_FIRST = 10, K_TARGET = 12;
-constexpr int STATE_SLOTS = 4096;                            // (the state buffer is wgrad_split.hip's: 2 x 4096 words)
+constexpr int STATE_SLOTS = 4096;                            // (idl_wgrad_split_state_words() = 2 x 4096 words: room for the 3 arrays below)
 constexpr int STATE_ARRAY = 2048;                            // three arrays of a word per workgroup (launch number % 3) inside it: <= 2048 tiles
 
 struct XpArgs {
@@ -78,7 +84,7 @@ __device__ __forceinline__ void dma16(uint32_t voff, const void *sbase, uint32_t
                  : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_byte) : "memory");
 }
 
-// four fp32 values -> their two fp16 planes (scaled, clamped), 8 bytes each (wgrad_split.hip)
+// four fp32 values -> their two fp16 planes (scaled, clamped), 8 bytes each
 __device__ __forceinline__ void split4c(const f32x4 v, const float sc, uint2 &p0, uint2 &p1)
 {
     const float s0 = __builtin_amdgcn_fmed3f(v[0] * sc, -65000.f, 65000.f), s1 = __builtin_amdgcn_fmed3f(v[1] * sc, -65000.f, 65000.f);
@@ -110,7 +116,7 @@ __device__ __forceinline__ void xplanes_body(const XpArgs &a, unsigned char *sme
     const int h0 = (tile % a.tiles_m) * TM, f0 = (tile / a.tiles_m) * TN;
     const int nc = a.m / KC;                                 // >= 6 (the launcher)
     const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
-    // the launch's number and the scale of dy (wgrad_split.hip)
+    // the launch's number and the scale of dy
     const unsigned long long t = a.ctl != nullptr ? (unsigned long long)a.ctl[0] + 1ull : 1ull;
     // Launch t writes its words into array t % 3 and reads the arrays of t - 1 and t - 2, which nobody writes while it runs: every workgroup of a
     // launch derives the SAME scale whenever it starts (on a GPU shared with another process not all tiles are resident at once, and a tile
@@ -266,7 +272,7 @@ __device__ __forceinline__ void xplanes_body(const XpArgs &a, unsigned char *sme
         tail(tid - 256);
         return;
     }
-    // ================= a computing wave: 32 (h) x 64 (f) of the tile (wgrad_split.hip)
+    // ================= a computing wave: 32 (h) x 64 (f) of the tile
     __builtin_amdgcn_s_barrier();                            // the exponent is in LDS
     kexp = *(const int *)(smem + LDS_BYTES);
     const int wm = (wv >> 1) * 32, wn = (wv & 1) * 64;
@@ -363,7 +369,7 @@ __device__ __forceinline__ void xplanes_body(const XpArgs &a, unsigned char *sme
 #undef WGP_READ_SET
 #undef WGP_LWAIT
     if (a.dbg & 8) return;
-    // ---- epilogue (wgrad_split.hip): the wave turns its 32 x 64 block around through LDS and works on 16-byte pieces of rows
+    // ---- epilogue: the wave turns its 32 x 64 block around through LDS and works on 16-byte pieces of rows
     const float inv = __builtin_ldexpf(1.f, -(kexp + idl_planes::X_EXP));
     wg_dev::Hyper hy{0.f, 0.f, 0.f, 0.f, 0.f};
     if (a.W != nullptr) hy = wg_dev::Hyper{a.hyper[0], a.hyper[1], a.hyper[2], a.hyper[3], a.hyper[4]};

@@ -1294,43 +1294,3 @@ def test_split_operand_products_on_the_16_bit_matrix_cores_are_fp32_grade():
     pbt, kbt = P.split2_f16(bt)
     err = (run(pat, pbt, 64 + 48 + 3) * 2.0 ** -(kat + kbt) - ref).abs().max().item() / scale
     assert err < 5e-7 and err <= e_lib, (err, e_lib)
-
-
-def test_weight_gradient_from_split_operands_matches_the_fp32_tiles():
-    """csrc/wgrad_split.hip (experimental, not in the step): dW = dy^T x + RMSprop with the product on the fp16 matrix cores from
-    operands split inside the kernel.  The gradient is at least as close to the float64 product as the fp32 tiles' (errors relative to
-    the largest entry), the scale of dy follows the previous launch's largest entry, and the update agrees with the fp32 tiles'."""
-    import ctypes
-    import torch
-    from idelucs_amd import _lib
-    L = _lib.lib
-    dev = torch.device("cuda")
-    g = torch.Generator(device="cpu"); g.manual_seed(17)
-    m, H, F = 512, 128, 512
-    dy = (torch.randn(m, H, generator=g) * 1e-3 * torch.rand(m, 1, generator=g) ** 3).to(dev)
-    dy = dy * (torch.rand(m, H, generator=g).to(dev) > 0.5)
-    x = torch.randn(m, F, generator=g).to(dev)
-    ref = dy.double().t() @ x.double()
-    scale = ref.abs().max().item()
-    hyper = torch.tensor([1e-3, 0.99, 1e-8, 0.01, 0.01], dtype=torch.float32, device=dev)
-    W0 = (torch.randn(H, F, generator=g) * 0.02).to(dev)
-    V0 = (torch.rand(H, F, generator=g) * 1e-6 + 1e-8).to(dev)
-    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-    p = lambda t: ctypes.c_void_p(t.data_ptr())
-    g32, gsp = torch.empty(H, F, device=dev), torch.empty(H, F, device=dev)
-    W32, V32, Wsp, Vsp = W0.clone(), V0.clone(), W0.clone(), V0.clone()
-    _lib.check(L.idl_wgrad_rmsprop(p(dy), p(x), m, H, F, p(g32), p(W32), p(V32), p(hyper), st))
-    state = torch.zeros(L.idl_wgrad_split_state_words(), dtype=torch.int64, device=dev)
-    ctl = torch.zeros(2, dtype=torch.int64, device=dev)
-    errs = []
-    for step in range(3):                                     # launch 1 takes the default scale, 2 and 3 the previous launch's
-        Wsp.copy_(W0); Vsp.copy_(V0); ctl[0:1].fill_(step)
-        _lib.check(L.idl_wgrad_rmsprop_split(p(dy), p(x), m, H, F, p(gsp), p(Wsp), p(Vsp), p(hyper), p(ctl), p(state), st))
-        torch.cuda.synchronize()
-        errs.append((gsp.double() - ref).abs().max().item() / scale)
-    e32 = (g32.double() - ref).abs().max().item() / scale
-    assert all(e < 1e-6 for e in errs) and errs[-1] <= 2.0 * e32, (errs, e32)
-    assert torch.allclose(Vsp, V32, rtol=1e-4, atol=0.0)
-    assert (Wsp - W32).abs().max().item() < 2e-6              # (lr 1e-3: a step of |g| / sqrt(v) ~ 1e-3 .. 1e-2; the gradients agree to ~1e-6 of their largest)
-
-

@@ -10,7 +10,28 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import torch  # noqa: E402
-from bench_wgrad_split import timed  # noqa: E402
+
+
+def timed(fn, n=20, reps=10):
+    """us per launch, n launches captured in a HIP graph (the host's ~15 us a ctypes call would otherwise pace short kernels)"""
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            for _ in range(n):
+                fn()
+        g.replay()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(s)
+        for _ in range(reps):
+            g.replay()
+        e1.record(s)
+        torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / (n * reps) * 1e3
 
 
 def epochs(dev, flags):

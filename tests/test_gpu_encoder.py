@@ -486,9 +486,9 @@ def test_batched_voters_take_the_own_layer1_tiles_too(dev, monkeypatch):
         tunable.enable(was_on)
 
 
-def _batched_like_single(dev, n, use_graph, copy, torch, FusedLinearTrainer, BatchedLinearTrainer):
+def _batched_like_single(dev, n, use_graph, copy, torch, FusedLinearTrainer, BatchedLinearTrainer, L=3):
     store, net0 = _cfg2_store_and_net(dev, n, seed=4)
-    B, L = 512, 3
+    B = 512
     nets_a, nets_b = [], []
     for l in range(L):
         net = copy.deepcopy(net0)

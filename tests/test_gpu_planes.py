@@ -399,9 +399,9 @@ def test_step_on_planes_with_200_output_units(dev, monkeypatch):
         assert np.isfinite(b_) and abs(b_ - a_) <= tol * nb, (sums,)
 
 
-@pytest.mark.parametrize("n,graph", [(1500, False), (4200, False), (4200, True)])
-def test_lockstep_voters_on_planes_are_the_lone_voters(dev, monkeypatch, n, graph):
-    """IDELUCS_LOCKSTEP_PLANES=1: three voters of a rank in lockstep with the six launches of the two-plane step recorded and run once for
+@pytest.mark.parametrize("n,graph,lanes", [(1500, False, 3), (4200, False, 3), (4200, True, 3), (4200, True, 2), (4200, True, 4), (4200, False, 8)])
+def test_lockstep_voters_on_planes_are_the_lone_voters(dev, monkeypatch, n, graph, lanes):
+    """IDELUCS_LOCKSTEP_PLANES=1: the voters of a rank (2, 3, 4, 8: what 8 voters over 4 / 2 / 1 GPUs put on a rank) in lockstep with the six launches of the two-plane step recorded and run once for
     all of them (blockIdx.y = voter) -- the same kernel bodies on the same operands in the same order as three lone voters: an epoch
     (8 or 24 full batches + a partial one, dropout on), launch by launch or as a captured graph, leaves the same loss sums, parameters
     and counters."""
@@ -410,8 +410,8 @@ def test_lockstep_voters_on_planes_are_the_lone_voters(dev, monkeypatch, n, grap
     from idelucs_amd.fused import FusedLinearTrainer, BatchedLinearTrainer
     monkeypatch.setenv("IDELUCS_PLANES", "1")
     monkeypatch.setenv("IDELUCS_LOCKSTEP_PLANES", "1")
-    bt = E._batched_like_single(dev, n, graph, copy, torch, FusedLinearTrainer, BatchedLinearTrainer)
-    assert bt._planes_step
+    bt = E._batched_like_single(dev, n, graph, copy, torch, FusedLinearTrainer, BatchedLinearTrainer, L=lanes)
+    assert bt._planes_step and bt.L == lanes
     assert not any(t.planes_overflowed() for t in bt.trainers)
 
 

@@ -42,7 +42,8 @@ extern "C" int idl_wgrad_rmsprop_xplanes(const float *dy, const void *x_hi, cons
     a.wh = (uint16_t *)w_hi; a.wl = (uint16_t *)w_lo; a.over = overflow_flag; a.hyper = hyper; a.ctl = ctl; a.state = state;
     a.m = m; a.n_out = n_out; a.n_in = n_in; a.ldx = ld_x;
     a.tiles_m = n_out / TM; a.tiles = a.tiles_m * (n_in / TN);
-    a.dbg = getenv("IDELUCS_WGP_DBG") ? atoi(getenv("IDELUCS_WGP_DBG")) : 0;
+    static const int wgp_dbg = getenv("IDELUCS_WGP_DBG") ? atoi(getenv("IDELUCS_WGP_DBG")) : 0;      // (timing ablations; wgrad_planes_device.h)
+    a.dbg = wgp_dbg;
     static bool attr_set[64] = {};
     int dev = 0;
     IDL_HIP_TRY(hipGetDevice(&dev));

@@ -66,25 +66,42 @@ __device__ __forceinline__ void l1p_body(const L1pArgs &g, const int bid, unsign
 {
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tiles_n = g.m / TN;
-    const int s = bid % KSPLIT, t = bid / KSPLIT;
+    if (g.dbg & 128) return;                                 // EXPERIMENT: the launch alone
+    int s = bid % KSPLIT, t = bid / KSPLIT;
+    if (g.dbg & 64) { s = 0; t = 0; }                        // EXPERIMENT: every workgroup reads the same operands
+    if (g.dbg & 256) { s = bid / 32; t = bid % 32; }         // EXPERIMENT: an XCD sees every K slice
     const int m0 = (t / tiles_n) * TM, n0 = (t % tiles_n) * TN;      // hidden units, batch rows
     const int kr = g.K / KSPLIT, kb = s * kr, nc = kr / KC;           // nc >= 2 (supported())
     const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
     if (wv >= 4) {                                           // ---- a loader
         const int lw = wv - 4;
-        auto issue = [&](int k0, uint32_t lds_stage) {
+        // loader lw brings plane lw (w0 w1 x0 x1) of a chunk: 16 instructions of 8 rows each; everything but k0 and the stage is formed once
+        static_assert(PER == 16, "a loader wave owns one plane of a chunk");
+        const uint16_t *const base = lw == 0 ? g.wh : (lw == 1 ? g.wl : (lw == 2 ? g.xh : g.xl));
+        const int ld = lw < 2 ? g.ldw : g.ldx, rows0 = lw < 2 ? m0 : n0;
+        const int rr = lane >> 3;
+        uint32_t vo[PER];
 #pragma unroll
-            for (int i = 0; i < PER; ++i) {
-                const int j = lw * PER + i;                  // plane j / 16 (w0 w1 x0 x1), rows 8 (j % 16) .. + 7
-                const int pq = j >> 4, blk = j & 15;
-                const int row = blk * 8 + (lane >> 3), slot = lane & 7, src = slot ^ (row & 7);
-                const uint16_t *base = pq == 0 ? g.wh : (pq == 1 ? g.wl : (pq == 2 ? g.xh : g.xl));
-                const int64_t r = (pq < 2 ? m0 : n0) + row;
-                const uint32_t voff = (uint32_t)((r * (pq < 2 ? g.ldw : g.ldx) + k0 + src * 8) * 2);
-                dma16(voff, base, lds_stage + (uint32_t)(pq * PLANE + blk * 1024));
-            }
+        for (int i = 0; i < PER; ++i) {                      // LDS slot lane & 7 of row i * 8 + rr holds source slot (lane & 7) ^ ((row >> 1) & 7)
+            const int src = (lane & 7) ^ ((4 * (i & 1) + (rr >> 1)) & 7);
+            vo[i] = (uint32_t)(((rows0 + i * 8 + rr) * ld + src * 8) * 2);
+        }
+        const uint32_t lds_plane = (uint32_t)(lw * PLANE);
+        auto issue = [&](int k0, uint32_t lds_stage) {
+            const char *b = (const char *)base + (int64_t)k0 * 2;
+#pragma unroll
+            for (int i = 0; i < PER; ++i) dma16(vo[i], b, lds_stage + lds_plane + (uint32_t)(i * 1024));
         };
         const bool dma = !(g.dbg & 1);
+        if (g.dbg & 48) {                                    // EXPERIMENT: the loaders alone, free-running (16: two chunks in flight, 32: one)
+            for (int c = 0; c < nc; ++c) {
+                issue(kb + c * KC, lds0 + (uint32_t)((c & 1) * STAGE));
+                if (g.dbg & 32) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" : : "n"(PER) : "memory");
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            return;
+        }
         if (dma) { issue(kb, lds0); issue(kb + KC, lds0 + STAGE); }          // nc >= 2 (supported())
         asm volatile("s_waitcnt vmcnt(%0)" : : "n"(PER) : "memory");
         __builtin_amdgcn_s_barrier();                        // B_0: chunk 0 is in LDS
@@ -95,6 +112,7 @@ __device__ __forceinline__ void l1p_body(const L1pArgs &g, const int bid, unsign
         }
         return;
     }
+    if (g.dbg & 48) return;
     const int wm = (wv >> 1) * 64, wn = (wv & 1) * 64;
     f32x16 hi[2][2], lo[2][2];
 #pragma unroll
@@ -105,92 +123,110 @@ __device__ __forceinline__ void l1p_body(const L1pArgs &g, const int bid, unsign
             for (int e = 0; e < 16; ++e) { hi[i][j][e] = 0.f; lo[i][j][e] = 0.f; }
     __builtin_amdgcn_s_barrier();                            // B_0
     const int r = lane & 31, kg = lane >> 5;
-    // The fragments of K-step t + 1 are read into a second register set while the twelve MFMAs of step t run (in program order -- eight
-    // reads, a wait, twelve MFMAs per step -- the matrix pipe idled through every read: 12.5 us of computing for 5.1 us of MFMAs,
-    // IDELUCS_L1P_DBG); a chunk is four steps, and the barrier that publishes chunk c + 1 (and frees chunk c's stage) sits in front of its last:
-    //     read F1 = (c, 1) | MFMA F0;  read F0 = (c, 2) | MFMA F1;  read F1 = (c, 3) | MFMA F0;  wait F1, barrier, read F0 = (c + 1, 0) | MFMA F1
-    // The reads are inline asm with the waits placed by hand and the set's registers passed THROUGH the wait: the compiler cannot count
-    // LDS reads in flight across the loop's back edge and put `s_waitcnt lgkmcnt(0)` in front of every step's first MFMA, i.e. it waited
-    // for the set it had just requested.
+    // A K-step is ONE asm statement: the twelve MFMAs of step t with the eight ds_read_b128 of step t + 1 BETWEEN them (a read behind each of
+    // the first eight), and the wait for those reads at its END.  (Round 5 issued the eight reads in front of the twelve MFMAs: a wave cannot
+    // issue its first MFMA before the LDS has taken all eight, and with four waves at the same point of the chunk the last one waited ~200
+    // cycles a step with the matrix pipe idle -- 9.2 us of computing for 5.1 us of MFMAs.)  The registers a read targets are early-clobber
+    // outputs of the statement that also waits for them: they are complete when the compiler first sees them, so no copy of a register in
+    // flight can exist (the hazard class of DESIGN's "the ring that was copied before its wait").
+    // A chunk is four steps; the barrier that publishes chunk c + 1 (and frees chunk c's stage) sits in front of its last:
+    //     MFMA (c,0) | read (c,1);  MFMA (c,1) | read (c,2);  MFMA (c,2) | read (c,3);  barrier;  MFMA (c,3) | read (c + 1,0)
+    // LDS image: a row of a plane is 128 bytes (64 k); its 16-byte slots are XORed with (row >> 1) & 7 -- the 16 lanes ds_read_b128 serves in
+    // one cycle ({0-3, 12-15, 20-27}, ...) then cover all 64 banks (row & 7, round 5's key, put two of them on every bank).
     static_assert(KC == 64 && PLANE == 16384 && STAGES == 2, "the immediates and the schedule below");
-    struct Frags { u32x4 a[2][2], b[2][2]; };            // [plane][32-row block]
-    // the lane's byte offset inside a stage for step ks: row (wm | wn) + r, 16-byte slot (2 ks + kg) ^ (row & 7); plane and 32-row block are immediates
+    struct Frags { u32x4 a00, a01, a10, a11, b00, b01, b10, b11; };      // a<plane><32-row block>
     uint32_t oa[4], ob[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-        oa[ks] = (uint32_t)((wm + r) * ROWB + (((2 * ks + kg) ^ (r & 7)) << 4));
-        ob[ks] = (uint32_t)((wn + r) * ROWB + (((2 * ks + kg) ^ (r & 7)) << 4));
+        oa[ks] = (uint32_t)((wm + r) * ROWB + (((2 * ks + kg) ^ ((r >> 1) & 7)) << 4));
+        ob[ks] = (uint32_t)((wn + r) * ROWB + (((2 * ks + kg) ^ ((r >> 1) & 7)) << 4));
     }
-#define L1P_READ(DST, ADDR, IMM) asm volatile("ds_read_b128 %0, %1 offset:" #IMM : "=v"(DST) : "v"(ADDR))
-#define L1P_READ_SET(F, OA, OB)                                                                                                   \
-    do {                                                                                                                          \
-        L1P_READ(F.a[0][0], OA, 0); L1P_READ(F.a[0][1], OA, 4096); L1P_READ(F.a[1][0], OA, 16384); L1P_READ(F.a[1][1], OA, 20480); \
-        L1P_READ(F.b[0][0], OB, 32768); L1P_READ(F.b[0][1], OB, 36864); L1P_READ(F.b[1][0], OB, 49152); L1P_READ(F.b[1][1], OB, 53248); \
-    } while (0)
-#define L1P_WAIT(N, F)                                                                                                            \
-    asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(F.a[0][0]), "+v"(F.a[0][1]), "+v"(F.a[1][0]), "+v"(F.a[1][1]), "+v"(F.b[0][0]), \
-                 "+v"(F.b[0][1]), "+v"(F.b[1][0]), "+v"(F.b[1][1]))
-    auto mma = [&](const Frags &f) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const f16x8 a0 = __builtin_bit_cast(f16x8, f.a[0][i]), a1 = __builtin_bit_cast(f16x8, f.a[1][i]);
-                const f16x8 b0 = __builtin_bit_cast(f16x8, f.b[0][j]), b1 = __builtin_bit_cast(f16x8, f.b[1][j]);
-                hi[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, hi[i][j], 0, 0, 0);
-                lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, lo[i][j], 0, 0, 0);
-                lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, lo[i][j], 0, 0, 0);
-            }
-    };
+#define L1P_STEP(C, N, PA, PB)                                                                                                       \
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %16, %20, %0\n\tds_read_b128 %8, %24 offset:0\n\t"                                      \
+                 "v_mfma_f32_32x32x16_f16 %4, %16, %22, %4\n\tds_read_b128 %9, %24 offset:4096\n\t"                                   \
+                 "v_mfma_f32_32x32x16_f16 %1, %16, %21, %1\n\tds_read_b128 %10, %24 offset:16384\n\t"                                 \
+                 "v_mfma_f32_32x32x16_f16 %5, %16, %23, %5\n\tds_read_b128 %11, %24 offset:20480\n\t"                                 \
+                 "v_mfma_f32_32x32x16_f16 %2, %17, %20, %2\n\tds_read_b128 %12, %25 offset:32768\n\t"                                 \
+                 "v_mfma_f32_32x32x16_f16 %6, %17, %22, %6\n\tds_read_b128 %13, %25 offset:36864\n\t"                                 \
+                 "v_mfma_f32_32x32x16_f16 %3, %17, %21, %3\n\tds_read_b128 %14, %25 offset:49152\n\t"                                 \
+                 "v_mfma_f32_32x32x16_f16 %7, %17, %23, %7\n\tds_read_b128 %15, %25 offset:53248\n\t"                                 \
+                 "v_mfma_f32_32x32x16_f16 %4, %18, %20, %4\n\t"                                                                       \
+                 "v_mfma_f32_32x32x16_f16 %5, %18, %21, %5\n\t"                                                                       \
+                 "v_mfma_f32_32x32x16_f16 %6, %19, %20, %6\n\t"                                                                       \
+                 "v_mfma_f32_32x32x16_f16 %7, %19, %21, %7\n\t"                                                                       \
+                 "s_waitcnt lgkmcnt(0)"                                                                                               \
+                 : "+v"(hi[0][0]), "+v"(hi[0][1]), "+v"(hi[1][0]), "+v"(hi[1][1]), "+v"(lo[0][0]), "+v"(lo[0][1]), "+v"(lo[1][0]),    \
+                   "+v"(lo[1][1]), "=&v"(N.a00), "=&v"(N.a01), "=&v"(N.a10), "=&v"(N.a11), "=&v"(N.b00), "=&v"(N.b01), "=&v"(N.b10), \
+                   "=&v"(N.b11)                                                                                                       \
+                 : "v"(C.a00), "v"(C.a01), "v"(C.a10), "v"(C.a11), "v"(C.b00), "v"(C.b01), "v"(C.b10), "v"(C.b11), "v"(PA), "v"(PB)  \
+                 : "memory")
+    // (operands: %0-%3 hi[i][j], %4-%7 lo[i][j]; %16 %17 W's high plane rows 0-31 / 32-63, %18 %19 its low plane; %20 %21 the batch's high plane,
+    //  %22 %23 its low plane.  Every accumulator sees its products in round 5's order -- hi: w0 x0; lo: w0 x1, then w1 x0 -- so the sums are bit for
+    //  bit what the builtin form gave.)
     Frags f0, f1;
     {
-        const uint32_t a = lds0 + oa[0], b = lds0 + ob[0];
-        L1P_READ_SET(f0, a, b);
+        const uint32_t pa = lds0 + oa[0], pb = lds0 + ob[0];
+        asm volatile("ds_read_b128 %0, %8 offset:0\n\tds_read_b128 %1, %8 offset:4096\n\tds_read_b128 %2, %8 offset:16384\n\tds_read_b128 %3, %8 offset:20480\n\t"
+                     "ds_read_b128 %4, %9 offset:32768\n\tds_read_b128 %5, %9 offset:36864\n\tds_read_b128 %6, %9 offset:49152\n\tds_read_b128 %7, %9 offset:53248\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     : "=&v"(f0.a00), "=&v"(f0.a01), "=&v"(f0.a10), "=&v"(f0.a11), "=&v"(f0.b00), "=&v"(f0.b01), "=&v"(f0.b10), "=&v"(f0.b11)
+                     : "v"(pa), "v"(pb) : "memory");
     }
     for (int c = 0; c < nc; ++c) {
         const uint32_t st = lds0 + (uint32_t)((c & 1) * STAGE);
-        { const uint32_t a = st + oa[1], b = st + ob[1]; L1P_READ_SET(f1, a, b); }
-        L1P_WAIT(8, f0);                                     // F0 is in; the eight reads of F1 may be in flight
-        __builtin_amdgcn_sched_barrier(0);
-        mma(f0);
-        __builtin_amdgcn_sched_barrier(0);
-        { const uint32_t a = st + oa[2], b = st + ob[2]; L1P_READ_SET(f0, a, b); }
-        L1P_WAIT(8, f1);
-        __builtin_amdgcn_sched_barrier(0);
-        mma(f1);
-        __builtin_amdgcn_sched_barrier(0);
-        { const uint32_t a = st + oa[3], b = st + ob[3]; L1P_READ_SET(f1, a, b); }
-        L1P_WAIT(8, f0);
-        __builtin_amdgcn_sched_barrier(0);
-        mma(f0);
-        __builtin_amdgcn_sched_barrier(0);
-        L1P_WAIT(0, f1);                                     // (the wave's reads of chunk c are in registers before its stage is refilled)
-        __builtin_amdgcn_s_barrier();                        // B_{c + 1}
-        if (c + 1 < nc) {
-            const uint32_t sn = lds0 + (uint32_t)(((c + 1) & 1) * STAGE);
-            const uint32_t a = sn + oa[0], b = sn + ob[0];
-            L1P_READ_SET(f0, a, b);
+        { const uint32_t pa = st + oa[1], pb = st + ob[1]; L1P_STEP(f0, f1, pa, pb); }
+        { const uint32_t pa = st + oa[2], pb = st + ob[2]; L1P_STEP(f1, f0, pa, pb); }
+        { const uint32_t pa = st + oa[3], pb = st + ob[3]; L1P_STEP(f0, f1, pa, pb); }
+        __builtin_amdgcn_s_barrier();                        // B_{c + 1}: this wave's reads of chunk c are in registers; chunk c + 1 is in LDS
+        {                                                    // (behind the last chunk: a read of stale bytes nobody uses)
+            const uint32_t sn = lds0 + (uint32_t)(((c + 1 < nc ? c + 1 : c) & 1) * STAGE);
+            const uint32_t pa = sn + oa[0], pb = sn + ob[0];
+            L1P_STEP(f1, f0, pa, pb);
         }
-        __builtin_amdgcn_sched_barrier(0);
-        mma(f1);
-        __builtin_amdgcn_sched_barrier(0);
     }
-#undef L1P_READ
-#undef L1P_READ_SET
-#undef L1P_WAIT
-    // C/D layout of 32x32: lane l, register e -> row (e / 4) * 8 + (l / 32) * 4 + e % 4, column l % 32
+#undef L1P_STEP
+    // (the compiler does not know that the statements above hold MFMAs: the wait states between an MFMA's write and a VALU read of its
+    //  accumulator -- at most 18 for this shape -- are paid here, once, by hand)
+    asm volatile("s_nop 15\n\ts_nop 15" : "+v"(hi[0][0]), "+v"(hi[0][1]), "+v"(hi[1][0]), "+v"(hi[1][1]), "+v"(lo[0][0]), "+v"(lo[0][1]), "+v"(lo[1][0]), "+v"(lo[1][1]));
     if (g.dbg & 4) return;
+    // ---- epilogue: the wave turns its 64 x 64 block around through LDS (every wave is past the last barrier: nobody reads a stage any more; the
+    // wave's image is its own) and stores 16 bytes a lane -- 16 store instructions a lane where the accumulators' own layout needs 64.
+    // C/D layout of 32x32: lane l, register e -> row (e / 4) * 8 + (l / 32) * 4 + e % 4, column l % 32
     const float inv = __builtin_ldexpf(1.f, -(idl_planes::W_EXP + idl_planes::X_EXP));
-    float *out = g.part + (int64_t)s * g.n_out * g.m;
+    if (g.dbg & 2) {                                         // EXPERIMENT: round 5's epilogue (a dword a lane and store)
+        float *o2 = g.part + (int64_t)s * g.n_out * g.m;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int row = m0 + wm + 32 * i + (e >> 2) * 8 + (lane >> 5) * 4 + (e & 3), col = n0 + wn + 32 * j + (lane & 31);
+                    o2[(int64_t)row * g.m + col] = (hi[i][j][e] + lo[i][j][e]) * inv;
+                }
+        return;
+    }
+    constexpr int EP = 68;
+    static_assert(4 * 64 * EP * 4 <= LDS_BYTES, "the four waves' epilogue images");
+    float *img = (float *)smem + wv * (64 * EP);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int row = m0 + wm + 32 * i + (e >> 2) * 8 + (lane >> 5) * 4 + (e & 3), col = n0 + wn + 32 * j + (lane & 31);
-                out[(int64_t)row * g.m + col] = (hi[i][j][e] + lo[i][j][e]) * inv;
+                const int rl = 32 * i + (e >> 2) * 8 + (lane >> 5) * 4 + (e & 3), cl = 32 * j + (lane & 31);
+                img[rl * EP + cl] = (hi[i][j][e] + lo[i][j][e]) * inv;
             }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    float *out = g.part + (int64_t)s * g.n_out * g.m + (int64_t)(m0 + wm) * g.m + n0 + wn;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const int idx = lane + 64 * u, rl = idx >> 4, c4 = idx & 15;
+        const float4 v = *(const float4 *)(img + rl * EP + 4 * c4);
+        *(float4 *)(out + (int64_t)rl * g.m + 4 * c4) = v;
+    }
 }
 
 }  // namespace l1p_dev

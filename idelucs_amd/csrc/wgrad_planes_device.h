@@ -125,6 +125,22 @@ __device__ __forceinline__ void xplanes_body(const XpArgs &a, unsigned char *sme
     // ONE wave reads them and hands the exponent to the others through LDS: the loaders that split dy and the computing waves that scale the
     // tile back must agree.  It is a COMPUTING wave (idle until the first chunk is in): the loaders have their first requests out before they
     // meet it at the barrier.
+    if (a.dbg & 192) {                                       // EXPERIMENT: the x DMA (64) / + dy-sized DMA (128) alone, free-running, three chunks in flight
+        if (wv < 4) return;
+        const int lw = wv - 4;
+        for (int c = 0; c < nc; ++c) {
+            const uint32_t xs = lds0 + (uint32_t)((c % NX) * XSTAGE) + DY_BYTES;
+            for (int i = 0; i < ((a.dbg & 128) ? 6 : 4); ++i) {
+                const int j = lw * 4 + (i & 3), pq = j >> 3, blk = j & 7;
+                const int row = blk * 4 + (lane >> 4), slot = lane & 15, src = slot ^ swz(row);
+                if (i < 4) dma16((uint32_t)((row * a.ldx + f0 + src * 8) * 2), (const char *)(pq == 0 ? a.xh : a.xl) + (int64_t)c * KC * a.ldx * 2, xs + (uint32_t)(pq * PLANE + blk * 1024));
+                else dma16((uint32_t)(((lw * 8 + (i & 1) * 4 + (lane >> 4)) * a.n_out + h0 + (lane & 15) * 4) * 4), (const char *)a.dy + (int64_t)c * KC * a.n_out * 4, lds0 + (uint32_t)((c % ND) * DSTAGE + (lw * 2 + (i & 1)) * 1024));
+            }
+            if (a.dbg & 128) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
+    }
     float mxp = 0.f;
     if (wv == 0) {
         // a word per WORKGROUP of a launch (its four loader waves fold their maxima in LDS first), all requests of a lane in flight before the
@@ -170,7 +186,9 @@ __device__ __forceinline__ void xplanes_body(const XpArgs &a, unsigned char *sme
         uint32_t va[2], la;
         {
             const int row = lt >> 3, sl = lt & 7;            // a lane's item of dy: row, 8 consecutive columns = a 16-byte slot of a plane's row
-            va[0] = (uint32_t)((row * a.n_out + h0 + 8 * sl) * 4); va[1] = va[0] + 16;
+            va[0] = (uint32_t)((row * a.n_out + h0 + 8 * sl) * 4);
+            if (a.dbg & 32) va[0] = (uint32_t)((((h0 >> 6) * a.m + row) * 64 + 8 * sl) * 4);      // EXPERIMENT: dy block-major
+            va[1] = va[0] + 16;
             la = (uint32_t)(row * ROWB + ((sl ^ swz(row)) << 4));
         }
         uint32_t vx[4], lx[4];                               // x: DMA instruction j = 4 lw + i: plane j / 8, k-rows 4 (j % 8) .. + 3
@@ -180,10 +198,13 @@ __device__ __forceinline__ void xplanes_body(const XpArgs &a, unsigned char *sme
             const int j = lw * 4 + i, pq = j >> 3, blk = j & 7;
             const int row = blk * 4 + (lane >> 4), slot = lane & 15, src = slot ^ swz(row);
             vx[i] = (uint32_t)((row * a.ldx + f0 + src * 8) * 2);
+            if (a.dbg & 16) vx[i] = (uint32_t)(((((f0 >> 6) + (src >> 3)) * a.m + row) * 64 + (src & 7) * 8) * 2);      // EXPERIMENT: chunk-major x planes
             lx[i] = (uint32_t)(DY_BYTES + pq * PLANE + blk * 1024);
             px[i] = pq == 0 ? a.xh : a.xl;
         }
-        const int64_t ca = (int64_t)KC * a.n_out * 4, cx = (int64_t)KC * a.ldx * 2;      // a chunk's bytes of rows
+        int64_t ca = (int64_t)KC * a.n_out * 4, cx = (int64_t)KC * a.ldx * 2;      // a chunk's bytes of rows
+        if (a.dbg & 16) cx = (int64_t)KC * 64 * 2;
+        if (a.dbg & 32) ca = (int64_t)KC * 64 * 4;
         // THE RING'S REGISTERS ARE FIXED: v[232:255], eight a slot, outside what the compiler allocates (the kernel needs ~200 of its 256; the
         // requests name them as clobbers).  A request whose target is a compiler-visible value is unsafe however its wait is written: the
         // compiler takes the value for available at once and may COPY the register before the wait -- it did, in front of the three-way

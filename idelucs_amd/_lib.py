@@ -116,13 +116,15 @@ SIGNATURES = {
                                     _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _c.c_float, _c.c_float, _vp, _int,
                                     _int, _vp, _vp, _int, _int, _int, _int, _vp, _i64, _vp]),
     "idl_wgrad_xplanes_supported": (_int, [_int, _int, _int]),
-    "idl_wgrad_rmsprop_xplanes": (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "idl_wgrad_xplanes_rms": (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+    "idl_wgrad_rmsprop_xplanes": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "idl_wgrad_xplanes_rms": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                      _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _c.c_float, _c.c_float, _vp, _int,
                                      _int, _vp, _vp, _int, _int, _int, _int, _vp, _i64, _vp]),
     "idl_wgrad_rmsprop_planes": (_int, [_vp, _vp, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "idl_mid_bwd_gather_planes": (_int, [_vp] * 5 + [_int] + [_vp] * 4 + [_int, _int, _int, _c.c_float] + [_vp] * 7 +
-                                  [_vp, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _vp]),
+                                  [_vp, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int,
+                                   _vp, _vp, _vp, _vp]),
+    "idl_dr1_scale_words": (_int, []),
     "idl_mid_fwd_gather_planes": (_int, [_vp, _vp, _int, _vp, _vp, _vp, _vp, _int, _int, _int, _c.c_uint64, _vp, _vp, _vp, _vp, _vp] +
                                   [_vp, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _vp]),
     "idl_mst_prim_workspace": (_i64, [_i64]),

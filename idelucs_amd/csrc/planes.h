@@ -16,6 +16,11 @@
 namespace idl_planes {
 
 constexpr int X_EXP = 3, W_EXP = 12;
+// dr1 (the gradient at the layer-1 activations: its range moves with the training) carries 2^k with k chosen so that the largest |dr1| of the
+// PREVIOUS step sits in [2^8, 2^9): 128 x headroom below fp16's largest value, an entry 2^-15 of the largest still exact to 2^-33 of it.  Its
+// words (int32, one buffer per voter): [0] the exponent the step's planes carry (mid_bwd writes, the dW1 tiles read), [1] the exponent of the next
+// step (the dW1 launch writes it from the maxima; DR1_K_FIRST when a voter begins), [4 .. 4 + 63] the largest |dr1| of mid_bwd's workgroups as bits.
+constexpr int DR1_K_FIRST = 10, DR1_K_TARGET = 9, DR1_WORDS = 4 + 64;
 constexpr float LIMIT = 65000.f;       // (fp16's largest finite value is 65 504)
 
 __device__ __forceinline__ uint32_t pack2(_Float16 a, _Float16 b)

@@ -32,7 +32,9 @@ __global__ __launch_bounds__(l1p_dev::THREADS, 1) void l1_planes_kernel(l1p_dev:
 
 extern "C" {
 
-int idl_planes_exponent(int which) { return which == 0 ? idl_planes::X_EXP : idl_planes::W_EXP; }
+int idl_planes_exponent(int which) { return which == 0 ? idl_planes::X_EXP : (which == 1 ? idl_planes::W_EXP : idl_planes::DR1_K_FIRST); }
+
+int idl_dr1_scale_words(void) { return idl_planes::DR1_WORDS; }
 
 int idl_split_planes(const float *src, int64_t n, int exponent, void *hi, void *lo, int *overflow_flag, void *stream)
 {

@@ -610,6 +610,10 @@ struct MidBwdArgs {
     float *lse, *loss_rows, *out;
     float inv_t, lamb, eps, w_iic;
     int nce_split;
+    // dr1 as two fp16 planes for the dW1 tiles' LDS-DMA (wgrad_planes_device.h: dplanes_body), in place of the fp32 tensor: the planes, the words of
+    // their scale (planes.h: DR1_WORDS), the overflow flag
+    uint16_t *dr1h, *dr1l;
+    int *dscale, *dover;
 };
 
 // (tile1 > tile0: the workgroups behind the COL_PARTS computing ones assemble tiles [tile0, tile1) of the NEXT batch into a
@@ -620,8 +624,8 @@ struct MidBwdArgs {
 // E^T) f is complete inside the workgroup (partials added through LDS in a fixed order) and never goes to memory, and the IIC
 // core (400..2304 elements) is recomputed by every workgroup from the joint into LDS instead of being waited for.  One launch
 // boundary and the G / dP0 round trips disappear.
-template <bool NCE, bool BIG = false>      // BIG: n_clusters > 48 (the per-row products then walk dP0 / W3 in memory); a separate instance, so that its
-                                          // registers do not count against the n_clusters <= 48 one the training step runs
+template <bool NCE, bool BIG = false, bool DP = false>      // BIG: n_clusters > 48 (the per-row products then walk dP0 / W3 in memory); a separate instance, so that its
+                                          // registers do not count against the n_clusters <= 48 one the training step runs.  DP: dr1 goes out as two fp16 planes
 __device__ __forceinline__ void mid_bwd_body(const MidBwdArgs &a, int tile0, int tile1, const idl_dev::GatherArgs &gth, const int bid)
 {
     extern __shared__ float mid_dyn[];        // NCE: Gred[16 waves][16][64] | lse_all[m] | Ps[48 * 48]
@@ -644,6 +648,12 @@ __device__ __forceinline__ void mid_bwd_body(const MidBwdArgs &a, int tile0, int
     uint64_t *stb = IDL_PHASE_BUF(2, bid);
     IDL_PHASE_STAMP(stb, 0);
     if (a.ctl != nullptr && bid == 0 && tid == 0) a.ctl[1] += a.batch_advance;
+    __shared__ unsigned int s_dmx, s_dcnt;
+    // the exponent of this launch's planes: what the previous step's dW1 launch derived from that step's largest |dr1| (one scalar load, first used
+    // behind the head backward)
+    const int dk = DP ? a.dscale[1] : 0;
+    if (DP && tid == 0) { s_dmx = 0u; s_dcnt = 0u; }
+    unsigned int dmx = 0u;                       // the largest |dr1| this thread wrote, as its bit pattern (NaN and Inf order above every finite value)
     if (small) {
         if (!NCE) for (int i = tid; i < C * C; i += 64 * MID_WAVES) sP[i] = a.dP0[i];
         for (int i = tid; i < C * H2; i += 64 * MID_WAVES) sW3[i] = a.W3[i];
@@ -839,6 +849,21 @@ __device__ __forceinline__ void mid_bwd_body(const MidBwdArgs &a, int tile0, int
                 if (rl < nr) {
                     const float v0 = a1v[0][reg] > 0.f ? acc0[reg] * scale : 0.f;
                     const float v1 = a1v[1][reg] > 0.f ? acc1[reg] * scale : 0.f;
+                    if constexpr (DP) {                        // two fp16 planes of the scaled, clamped pair (planes.h), 4 bytes of each
+                        const float dsc = __builtin_ldexpf(1.f, dk);
+                        const float s0 = __builtin_amdgcn_fmed3f(v0 * dsc, -idl_planes::LIMIT, idl_planes::LIMIT);
+                        const float s1 = __builtin_amdgcn_fmed3f(v1 * dsc, -idl_planes::LIMIT, idl_planes::LIMIT);
+                        uint32_t h01, l01;
+                        float q0, q1;
+                        asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h01) : "v"(s0), "v"(s1));
+                        asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(q0) : "v"(h01), "v"(s0));
+                        asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(q1) : "v"(h01), "v"(s1));
+                        asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(l01) : "v"(q0), "v"(q1));
+                        *(uint32_t *)(a.dr1h + (int64_t)(t0 + rl) * H1 + col) = h01;
+                        *(uint32_t *)(a.dr1l + (int64_t)(t0 + rl) * H1 + col) = l01;
+                        const unsigned int b0 = __float_as_uint(v0) & 0x7FFFFFFFu, b1 = __float_as_uint(v1) & 0x7FFFFFFFu;
+                        dmx = dmx > b0 ? dmx : b0; dmx = dmx > b1 ? dmx : b1;
+                    } else
                     *(float2 *)(a.dr1 + (int64_t)(t0 + rl) * H1 + col) = make_float2(v0, v1);
                     cs1[0] += v0;
                     cs1[1] += v1;
@@ -879,6 +904,19 @@ __device__ __forceinline__ void mid_bwd_body(const MidBwdArgs &a, int tile0, int
         v = idl_dev::add_xor32(idl_dev::add_xor16(v));
         if (qe == 0) a.partial1[(int64_t)bid * H1 + 32 * we + 2 * le + j] = v;
     }
+    if constexpr (DP) {                          // the workgroup's largest |dr1| -> its word of the scale's words; beyond the planes' range (or NaN): the flag
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const unsigned int y = (unsigned int)__shfl_xor((int)dmx, o, 64); dmx = dmx > y ? dmx : y; }
+        if ((te & 63) == 0) {
+            atomicMax(&s_dmx, dmx);
+            if (atomicAdd(&s_dcnt, 1u) == (unsigned int)(MID_WAVES - 1)) {
+                const unsigned int wmx = atomicMax(&s_dmx, 0u);
+                a.dscale[4 + bid] = (int)wmx;
+                if (bid == 0) a.dscale[0] = dk;
+                if (!(__uint_as_float(wmx) * __builtin_ldexpf(1.f, dk) <= idl_planes::LIMIT)) *a.dover = 1;
+            }
+        }
+    }
     if (te < H2) a.partial2[(int64_t)bid * H2 + te] = s23;
     else if (te < H2 + C) a.partial3[(int64_t)bid * C + te - H2] = s23;
     if (a.dW3_part != nullptr) {
@@ -893,10 +931,10 @@ __device__ __forceinline__ void mid_bwd_body(const MidBwdArgs &a, int tile0, int
 struct MidBwdParams { MidBwdArgs a; int tile0, tile1; idl_dev::GatherArgs gth; };
 static_assert(sizeof(MidBwdParams) + idl::PLAN_PARAMS <= idl::PLAN_BYTES, "MidBwdParams does not fit a plan record");
 
-template <bool NCE, bool BIG = false>
+template <bool NCE, bool BIG = false, bool DP = false>
 __global__ __launch_bounds__(64 * MID_WAVES) void mid_bwd_kernel(MidBwdArgs a, int tile0, int tile1, idl_dev::GatherArgs gth)
 {
-    mid_bwd_body<NCE, BIG>(a, tile0, tile1, gth, (int)blockIdx.x);
+    mid_bwd_body<NCE, BIG, DP>(a, tile0, tile1, gth, (int)blockIdx.x);
 }
 
 // several voters in one launch, grid (voters, workgroups of one voter) as in mid_fwd_batched_kernel (n_clusters <= 48, separate
@@ -904,7 +942,8 @@ __global__ __launch_bounds__(64 * MID_WAVES) void mid_bwd_kernel(MidBwdArgs a, i
 __global__ __launch_bounds__(64 * MID_WAVES) void mid_bwd_batched_kernel(const unsigned char *__restrict__ plans)
 {
     const MidBwdParams &p = *(const MidBwdParams *)(plans + (size_t)blockIdx.x * idl::PLAN_BYTES + idl::PLAN_PARAMS);
-    mid_bwd_body<false, false>(p.a, p.tile0, p.tile1, p.gth, (int)blockIdx.y);
+    if (p.a.dr1h != nullptr) mid_bwd_body<false, false, true>(p.a, p.tile0, p.tile1, p.gth, (int)blockIdx.y);
+    else mid_bwd_body<false, false>(p.a, p.tile0, p.tile1, p.gth, (int)blockIdx.y);
 }
 
 // ---------------------------------------------------------------- RMSprop over all parameter tensors
@@ -1246,10 +1285,23 @@ __global__ __launch_bounds__(wgp_dev::NT, 1) void wgrad_xplanes_rms_kernel(wgp_d
                                                                            int n_tail)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char wgp_rms_smem[];
-    wgp_dev::xplanes_body(x, wgp_rms_smem, [&](int tix) {
+    auto tail = [&](int tix) {
         if ((int)blockIdx.x < n_tail)
             rmsprop_body<true, true>(a, hyper, ctl, batch_advance, 0, 0, idl_dev::GatherArgs{}, (int)blockIdx.x, tix,
                                      (unsigned int *)(wgp_rms_smem + wgp_dev::LDS_BYTES) + 3);
+    };
+    wgp_dev::xplanes_body(x, wgp_rms_smem, tail);            // dr1 in fp32 (the step of n_clusters > 48: a library GEMM wrote it)
+}
+
+// ... and with dr1 as planes from mid_bwd (the step of n_clusters <= 48; wgrad_planes_device.h: dplanes_body, whose K-steps own v[200:247])
+__global__ __launch_bounds__(wgp_dev::NT, 1) __attribute__((amdgpu_num_vgpr(200))) void wgrad_dplanes_rms_kernel(wgp_dev::XpArgs x, RmsArgs a, const float *hyper,
+                                                                                                                 int64_t *ctl, int64_t batch_advance, int n_tail)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char wgd_rms_smem[];
+    wgp_dev::dplanes_body(x, wgd_rms_smem, [&](int tix) {
+        if ((int)blockIdx.x < n_tail)
+            rmsprop_body<true, true>(a, hyper, ctl, batch_advance, 0, 0, idl_dev::GatherArgs{}, (int)blockIdx.x, tix,
+                                     (unsigned int *)(wgd_rms_smem + wgp_dev::LDS_BYTES) + 3);
     });
 }
 
@@ -1320,17 +1372,18 @@ struct XpRmsParams { wgp_dev::XpArgs x; RmsArgs a; const float *hyper; int64_t *
 static_assert(sizeof(XpRmsParams) + idl::PLAN_PARAMS <= idl::PLAN_BYTES, "XpRmsParams does not fit a plan record");
 static_assert(sizeof(ReduceArgs) + idl::PLAN_PARAMS <= idl::PLAN_BYTES, "ReduceArgs does not fit a plan record");
 
-__global__ __launch_bounds__(wgp_dev::NT, 1) void wgrad_xplanes_rms_batched_kernel(const unsigned char *__restrict__ plans)
+__global__ __launch_bounds__(wgp_dev::NT, 1) __attribute__((amdgpu_num_vgpr(200))) void wgrad_xplanes_rms_batched_kernel(const unsigned char *__restrict__ plans)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char wgp_b_smem[];
     const XpRmsParams &p = *(const XpRmsParams *)(plans + (size_t)blockIdx.y * idl::PLAN_BYTES + idl::PLAN_PARAMS);
     wgp_dev::XpArgs x = p.x;
-    x.dy = uniform_ptr(x.dy); x.xh = uniform_ptr(x.xh); x.xl = uniform_ptr(x.xl);
-    wgp_dev::xplanes_body(x, wgp_b_smem, [&](int tix) {
+    x.dy = uniform_ptr(x.dy); x.xh = uniform_ptr(x.xh); x.xl = uniform_ptr(x.xl); x.dyh = uniform_ptr(x.dyh); x.dyl = uniform_ptr(x.dyl);
+    auto tail = [&](int tix) {
         if ((int)blockIdx.x < p.n_tail)
             rmsprop_body<true, true>(p.a, p.hyper, p.ctl, p.batch_advance, 0, 0, idl_dev::GatherArgs{}, (int)blockIdx.x, tix,
                                      (unsigned int *)(wgp_b_smem + wgp_dev::LDS_BYTES) + 3);
-    });
+    };
+    wgp_dev::dplanes_body(x, wgp_b_smem, tail);              // (recorded steps are of n_clusters <= 48 and m % 128 == 0: dr1 always arrives as planes; rmsprop_launch refuses another record)
 }
 
 }  // namespace
@@ -1574,16 +1627,19 @@ static int mid_bwd_gather_impl(const float *z, const float *r2, const float *f, 
                        const float *feats, int64_t n, int64_t fdim, int64_t view_stride, const int64_t *pair_idx, const int64_t *base,
                        int64_t base_add, int64_t n_pairs, int64_t batch, const double *mean, const double *scale,
                        const double *inv_scale, float *y, int part, int part_end, int parts, int act1_transposed, void *stream,
-                       uint16_t *yh, uint16_t *yl, int *over = nullptr)
+                       uint16_t *yh, uint16_t *yl, int *over = nullptr, uint16_t *dr1h = nullptr, uint16_t *dr1l = nullptr, int *dscale = nullptr)
 {
+    IDL_REQUIRE((dr1h != nullptr) == (dr1l != nullptr) && (dr1h == nullptr || (dscale && over && C <= 48 && ((((uintptr_t)dr1h) | ((uintptr_t)dr1l)) & 15u) == 0)),
+                "mid_bwd_gather: dr1's planes need both planes (16-byte aligned), the words of their scale, the flag and n_clusters <= 48");
     IDL_REQUIRE((yh != nullptr) == (yl != nullptr) && (yh == nullptr || (feats != nullptr && ((((uintptr_t)yh) | ((uintptr_t)yl)) & 7u) == 0)),
                 "mid_bwd_gather: both planes of the next batch (8-byte aligned) or neither; planes need the batch assembly");
     IDL_REQUIRE(parts >= 1 && part >= 0 && part <= part_end && part_end <= parts, "mid_bwd_gather: need 0 <= part <= part_end <= parts");
     IDL_REQUIRE(g_parts >= 1 && g_parts <= 16, "mid_bwd: g_parts outside 1..16");
-    IDL_REQUIRE(z && r2 && f && inv && G && dP0 && W3 && W2 && act1 && dlogits && dlat && dr1 && partial1 && partial2 && partial3, "NULL buffer");
+    IDL_REQUIRE(z && r2 && f && inv && G && dP0 && W3 && W2 && act1 && dlogits && dlat && (dr1 || dr1h) && partial1 && partial2 && partial3, "NULL buffer");
     IDL_REQUIRE(m >= 2 && (m % 2) == 0 && C >= 1 && C <= 64 * MAX_CPL, "mid_bwd: even m, n_clusters in 1..256");
     IDL_REQUIRE(dW3_partial == nullptr || C <= 48, "mid_bwd: dW3 partials need n_clusters <= 48");
     MidBwdArgs a{};
+    a.dr1h = dr1h; a.dr1l = dr1l; a.dscale = dscale; a.dover = over;
     a.z = z; a.r2 = r2; a.f = f; a.inv = inv; a.G = G; a.dP0 = dP0; a.W3 = W3; a.W2 = W2; a.act1 = act1;
     a.dlogits = dlogits; a.dlat = dlat; a.dr1 = dr1; a.partial1 = partial1; a.partial2 = partial2; a.partial3 = partial3;
     a.dW3_part = dW3_partial; a.ctl = nullptr; a.batch_advance = 0;
@@ -1606,7 +1662,9 @@ static int mid_bwd_gather_impl(const float *z, const float *r2, const float *f, 
         memcpy((unsigned char *)plan + idl::PLAN_PARAMS, &p, sizeof(p));
         return IDL_OK;
     }
-    if (C <= 48) hipLaunchKernelGGL((mid_bwd_kernel<false, false>), dim3((unsigned)(COL_PARTS + (t1 - t0 + 3) / 4)), dim3(64 * MID_WAVES), 0, (hipStream_t)stream, a, (int)t0,
+    if (dr1h != nullptr) hipLaunchKernelGGL((mid_bwd_kernel<false, false, true>), dim3((unsigned)(COL_PARTS + (t1 - t0 + 3) / 4)), dim3(64 * MID_WAVES), 0, (hipStream_t)stream,
+                                            a, (int)t0, (int)t1, g);
+    else if (C <= 48) hipLaunchKernelGGL((mid_bwd_kernel<false, false>), dim3((unsigned)(COL_PARTS + (t1 - t0 + 3) / 4)), dim3(64 * MID_WAVES), 0, (hipStream_t)stream, a, (int)t0,
                                     (int)t1, g);
     else hipLaunchKernelGGL((mid_bwd_kernel<false, true>), dim3((unsigned)(COL_PARTS + (t1 - t0 + 3) / 4)), dim3(64 * MID_WAVES), 0, (hipStream_t)stream, a, (int)t0,
                             (int)t1, g);
@@ -1633,11 +1691,12 @@ int idl_mid_bwd_gather_planes(const float *z, const float *r2, const float *f, c
                               const float *feats, int64_t n, int64_t fdim, int64_t view_stride, const int64_t *pair_idx, const int64_t *base,
                               int64_t base_add, int64_t n_pairs, int64_t batch, const double *mean, const double *scale,
                               const double *inv_scale, float *y, void *y_hi, void *y_lo, int *overflow_flag, int part, int part_end, int parts,
-                              int act1_transposed, void *stream)
+                              int act1_transposed, void *dr1_hi, void *dr1_lo, int *dr1_scale, void *stream)
 {
     return mid_bwd_gather_impl(z, r2, f, inv, G, g_parts, dP0, W3, W2, act1, m, C, train, nce_coef, dlogits, dlat, dr1, partial1, partial2, partial3,
                                dW3_partial, feats, n, fdim, view_stride, pair_idx, base, base_add, n_pairs, batch, mean, scale, inv_scale, y, part,
-                               part_end, parts, act1_transposed, stream, (uint16_t *)y_hi, (uint16_t *)y_lo, overflow_flag);
+                               part_end, parts, act1_transposed, stream, (uint16_t *)y_hi, (uint16_t *)y_lo, overflow_flag, (uint16_t *)dr1_hi,
+                               (uint16_t *)dr1_lo, dr1_scale);
 }
 
 int idl_col_sum_parts(void) { return COL_PARTS; }
@@ -1763,6 +1822,7 @@ static int rmsprop_launch(int count, float *const *params, const float *const *g
         if (const int rc = idl::device_info(&di); rc != IDL_OK) return rc;
         IDL_REQUIRE(nb_total + a.wg_tiles <= xp->tiles && xp->tiles <= di.cus, "wgrad_xplanes_rms: the tail's blocks need a tile each, and every tile its own CU");
         if (void *plan = idl::take_plan()) {      // recorded, not launched (idl_plan_begin)
+            IDL_REQUIRE(xp->dyh != nullptr, "wgrad_xplanes_rms: a recorded launch takes dy as planes");
             idl::PlanHead h{};
             h.kind = idl::PLAN_WGRAD_XPLANES; h.grid[0] = (unsigned)xp->tiles; h.grid[1] = 1; h.grid[2] = 1; h.block = wgp_dev::NT; h.lds = wgp_dev::LDS_BYTES + 16;
             memcpy(plan, &h, sizeof(h));
@@ -1775,8 +1835,13 @@ static int rmsprop_launch(int count, float *const *params, const float *const *g
         IDL_HIP_TRY(hipGetDevice(&dev));
         if (dev >= 0 && dev < 64 && !attr_set[dev]) {
             IDL_HIP_TRY(hipFuncSetAttribute((const void *)wgrad_xplanes_rms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, wgp_dev::LDS_BYTES + 16));
+            IDL_HIP_TRY(hipFuncSetAttribute((const void *)wgrad_dplanes_rms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, wgp_dev::LDS_BYTES + 16));
             attr_set[dev] = true;
         }
+        if (xp->dyh != nullptr)
+            hipLaunchKernelGGL(wgrad_dplanes_rms_kernel, dim3((unsigned)xp->tiles), dim3(wgp_dev::NT), wgp_dev::LDS_BYTES + 16, (hipStream_t)stream, *xp, a, hyper,
+                               ctl, batch_advance, nb_total + a.wg_tiles);
+        else
         hipLaunchKernelGGL(wgrad_xplanes_rms_kernel, dim3((unsigned)xp->tiles), dim3(wgp_dev::NT), wgp_dev::LDS_BYTES + 16, (hipStream_t)stream, *xp, a, hyper,
                            ctl, batch_advance, nb_total + a.wg_tiles);
         IDL_HIP_TRY(hipGetLastError());
@@ -1988,7 +2053,8 @@ int idl_reduce_parts_rms(float *part, int64_t slab_elems, const int64_t *step_co
 
 // idl_wgrad_rmsprop_xplanes (W updated, its planes written) with THIS step's optimizer tail carried by the tiles' loader waves (tail arguments as
 // idl_l1_fwd_rms; w1_index: the tensor the tiles update, left out of the tail).  Needs a CU per tile and no more tail blocks than tiles.
-int idl_wgrad_xplanes_rms(const float *dy, const void *x_hi, const void *x_lo, int ld_x, int m, int n_out, int n_in, float *grad, float *W, float *square_avg,
+int idl_wgrad_xplanes_rms(const float *dy, const void *dy_hi, const void *dy_lo, int *dy_scale, const void *x_hi, const void *x_lo, int ld_x, int m, int n_out,
+                          int n_in, float *grad, float *W, float *square_avg,
                           unsigned long long *state, const int64_t *step_snapshot, void *w_hi, void *w_lo, int *overflow_flag,
                           int count, float *const *params, const float *const *grads, const int32_t *grad_parts,
                           float *const *square_avg_all, const int64_t *sizes, const float *hyper, int64_t *ctl,
@@ -1996,7 +2062,10 @@ int idl_wgrad_xplanes_rms(const float *dy, const void *x_hi, const void *x_lo, i
                           int wg_index, const float *wg_dy, const float *wg_x, int wg_x_transposed, int wg_m, int wg_n_out, int wg_n_in,
                           float *wg_grad, int64_t batch_advance, void *stream)
 {
-    IDL_REQUIRE(dy && x_hi && x_lo && state && W && square_avg && hyper && ctl && w_hi && w_lo && overflow_flag, "wgrad_xplanes_rms: NULL buffer");
+    IDL_REQUIRE(x_hi && x_lo && W && square_avg && hyper && ctl && w_hi && w_lo && overflow_flag, "wgrad_xplanes_rms: NULL buffer");
+    IDL_REQUIRE((dy_hi != nullptr) == (dy_lo != nullptr) && (dy_hi != nullptr) == (dy_scale != nullptr) && ((dy != nullptr && state != nullptr) || dy_hi != nullptr) &&
+                ((((uintptr_t)dy_hi) | ((uintptr_t)dy_lo)) & 15u) == 0 && (dy_hi == nullptr || m % wgp_dev::dpl::KC2 == 0),
+                "wgrad_xplanes_rms: dy in fp32 with the state words, or as both planes (16-byte aligned, m % 64 == 0) with the words of their scale");
     IDL_REQUIRE(m % wgp_dev::KC == 0 && m / wgp_dev::KC >= 2 * wgp_dev::PF && n_out >= wgp_dev::TM && n_out % wgp_dev::TM == 0 && n_in >= wgp_dev::TN &&
                 n_in % wgp_dev::TN == 0 && (int64_t)m * (n_in + 1024) < (1ll << 29) && (int64_t)n_out * n_in < (1ll << 29),
                 "wgrad_xplanes_rms: m % 32 == 0, m >= 192, n_out % 64 == 0, n_in % 128 == 0");
@@ -2005,6 +2074,7 @@ int idl_wgrad_xplanes_rms(const float *dy, const void *x_hi, const void *x_lo, i
                 (((uintptr_t)state | (uintptr_t)w_hi | (uintptr_t)w_lo) & 7u) == 0, "wgrad_xplanes_rms: buffers 16-byte aligned, state and W's planes 8-byte");
     wgp_dev::XpArgs x{};
     x.dy = dy; x.xh = (const uint16_t *)x_hi; x.xl = (const uint16_t *)x_lo; x.grad = grad; x.W = W; x.V = square_avg;
+    x.dyh = (const uint16_t *)dy_hi; x.dyl = (const uint16_t *)dy_lo; x.dy_scale = dy_scale;
     x.wh = (uint16_t *)w_hi; x.wl = (uint16_t *)w_lo; x.over = overflow_flag; x.hyper = hyper; x.state = state;
     // (the launch number behind dr1's scale: from the snapshot the step's reduce launch took, not from the counter this launch's own tail moves)
     x.ctl = step_snapshot != nullptr ? (const long long *)step_snapshot : (const long long *)ctl;

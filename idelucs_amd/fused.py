@@ -98,6 +98,7 @@ def _planes_of(bf, F):
         h16 = dict(dtype=torch.int16, device=dev)
         bf._planes = {"xh": [torch.empty((m, F), **h16) for _ in range(2)], "xl": [torch.empty((m, F), **h16) for _ in range(2)],
                       "part": [torch.empty((int(_L.idl_l1_planes_parts()), bf._H1, m), dtype=torch.float32, device=dev) for _ in range(2)],
+                      "dh": torch.empty((m, bf._H1), **h16), "dl": torch.empty((m, bf._H1), **h16),      # dr1 as planes (mid_bwd -> the dW1 tiles)
                       "valid": [False, False],          # valid[i]: xh[i] / xl[i] hold the planes of the batch in bf.xs[i]
                       "x32": [True, True]}              # x32[i]: bf.xs[i] itself holds that batch (False: it was assembled as planes only)
     return bf._planes
@@ -188,6 +189,9 @@ class FusedLinearTrainer:
         self._cus = torch.cuda.get_device_properties(self.dev).multi_processor_count if self.dev.type == "cuda" else 0
         self._ctl_snap = torch.zeros(1, dtype=torch.int64, device=self.dev)       # the step counter as the step's reduce launch saw it (idl_wgrad_xplanes_rms)
         self._w1_planes = None                   # (W1 hi, W1 lo, overflow flag)
+        # the words of dr1's scale (csrc/planes.h): [0] the exponent mid_bwd gave this step's planes, [1] the next step's (the dW1 launch derives it), [4..] maxima
+        self._dr1_scale = torch.zeros(int(_L.idl_dr1_scale_words()), dtype=torch.int32, device=self.dev)
+        self._dr1_scale[1:2].fill_(int(_L.idl_planes_exponent(2)))
         self._w1_planes_fresh = False
         # the layers between the two big GEMMs as one 1024-thread MFMA kernel per direction (idl_mid_fwd / idl_mid_bwd)
         self._mid_fused = self.H1 == 512 and os.environ.get("IDELUCS_MID_FUSED", "1") != "0"
@@ -252,6 +256,7 @@ class FusedLinearTrainer:
         # (fill_ on a view, here and below: `tensor[i] = python_scalar` is a host-to-device copy from pageable memory, which holds the
         #  host until everything queued on the stream has run -- the vectoriser, when a voter begins right behind the store's build)
         self.ctl[0:1].fill_((int(voter) & 0xFF) << 24)
+        self._dr1_scale[1:2].fill_(int(_L.idl_planes_exponent(2)))       # (a voter's first step does not inherit the last voter's gradient range)
         if keep_state:
             return
         for v in self.square_avg:               # a voter starts with fresh optimizer state (models.IID_model.begin_voter)
@@ -311,6 +316,7 @@ class FusedLinearTrainer:
         # ... with the layer-1 product from two-plane operands (IDELUCS_PLANES=1)
         pl = (tm and self._planes and bool(_L.idl_l1_planes_supported(m, self.H1, self.F)) and next_from.n < 60_000_000)
         plw = pl and self._planes_wgrad and bool(_L.idl_wgrad_xplanes_supported(m, self.H1, self.F))
+        dpl = plw and m % 64 == 0              # ... with dr1 written as planes by mid_bwd: both operands of dW1 reach its tiles by LDS-DMA
         # ... and the same two products in the step of n_clusters > 48 (the fine-grained mode's 200 output units: separate backward kernels, the
         # whole batch assembled by the mid-forward launch, activations NOT transposed): the layer-1 tiles with the operands' roles swapped
         # give part[8][m][512]; the dW1 kernel with the tail on its loader waves ends the step
@@ -487,7 +493,7 @@ class FusedLinearTrainer:
                                              _p(gW3) if self._dw3_partial else None,
                                              _p(st.feats), st.n, st.f, st.n * st.f, _p(self._perm), _p(self.ctl[1:]), m // 2, st.n_pairs, m // 2,
                                              _p(st.mean), _p(st.scale), _p(st.inv_scale), None if plw else _p(bf.xs[1 - xi]), _p(pb["xh"][1 - xi]),
-                                             _p(pb["xl"][1 - xi]), _p(self._w1_planes[2]), g2, 8, 8, 1, _stream()))
+                                             _p(pb["xl"][1 - xi]), _p(self._w1_planes[2]), g2, 8, 8, 1, *self._dr1_planes_args(pb, dpl), _stream()))
             pb["valid"][1 - xi] = True
             pb["x32"][1 - xi] = not plw
             if not self._dw3_partial:
@@ -545,12 +551,12 @@ class FusedLinearTrainer:
                     wg = (2, _p(bf.dlat), _p(r1), 1, m, self.H2, self.H1, _p(self.grads[2]), m // 2, _stream())
                     if self._cold:
                         self._evict()
-                    chk(_L.idl_wgrad_xplanes_rms(_p(bf.dr1), _p(pb["xh"][xi]), _p(pb["xl"][xi]), self.F, m, self.H1, self.F,
+                    chk(_L.idl_wgrad_xplanes_rms(_p(bf.dr1), *self._dy_planes_args(pb, dpl), _p(pb["xh"][xi]), _p(pb["xl"][xi]), self.F, m, self.H1, self.F,
                                                  _p(gW1) if self._keep_w1_grad else None, _p(self.W1), _p(self.square_avg[0]),
                                                  _p(self._split_state), _p(self._ctl_snap), _p(wh), _p(wl), _p(flag), *tail, 0, *wg))
                     self._pending = None
                     return
-                chk(_L.idl_wgrad_rmsprop_xplanes(_p(bf.dr1), _p(pb["xh"][xi]), _p(pb["xl"][xi]), self.F, m, self.H1, self.F,
+                chk(_L.idl_wgrad_rmsprop_xplanes(_p(bf.dr1), *self._dy_planes_args(pb, dpl), _p(pb["xh"][xi]), _p(pb["xl"][xi]), self.F, m, self.H1, self.F,
                                                  _p(gW1) if self._keep_w1_grad else None, _p(self.W1), _p(self.square_avg[0]), _p(self.hyper),
                                                  _p(self.ctl), _p(self._split_state), _p(wh), _p(wl), _p(flag), _stream()))
             elif pl:    # ... and write the updated W1's planes for the next layer-1 product
@@ -574,7 +580,7 @@ class FusedLinearTrainer:
             wg = (2, _p(bf.dlat), _p(r1), 0, m, self.H2, self.H1, _p(gW2), m // 2, _stream())
             if self._cold:
                 self._evict()
-            chk(_L.idl_wgrad_xplanes_rms(_p(bf.dr1), _p(pb["xh"][xi]), _p(pb["xl"][xi]), self.F, m, self.H1, self.F,
+            chk(_L.idl_wgrad_xplanes_rms(_p(bf.dr1), None, None, None, _p(pb["xh"][xi]), _p(pb["xl"][xi]), self.F, m, self.H1, self.F,
                                          _p(gW1) if self._keep_w1_grad else None, _p(self.W1), _p(self.square_avg[0]),
                                          _p(self._split_state), _p(self._ctl_snap), _p(wh), _p(wl), _p(flag), *tail, 0, *wg))
             return
@@ -639,6 +645,7 @@ class FusedLinearTrainer:
         gW1, gb1, gW2, gb2, gW3, gb3 = self.grads
         nce_coef = (1.0 - self.weight) / (m * TEMPERATURE)
         g2 = self._gsplit
+        dpl = m % 64 == 0
         self._k(_L.idl_l1_planes, _p(wh), _p(wl), self.F, _p(pb["xh"][xi]), _p(pb["xl"][xi]), self.F, m, self.H1, self.F, _p(part), _stream())
         self._k(_L.idl_reduce_parts_rms, _p(part), self.H1 * m, _p(self.ctl), _p(self._ctl_snap), 0, None, None, None, None, None, None, None, None, 0, 0.0, 0.0,
                 None, 0, -1, None, None, 0, 0, 0, 0, None, 0, _stream())
@@ -651,12 +658,29 @@ class FusedLinearTrainer:
         self._k(_L.idl_mid_bwd_gather_planes, _p(bf.z), _p(bf.r2), _p(bf.f), _p(bf.inv), _p(bf.G), bf.G.shape[0], _p(bf.P0), _p(self.W3), _p(self.W2),
                 _p(r1), m, C, tr, nce_coef, _p(bf.dlogits), _p(bf.dlat), _p(bf.dr1), _p(gb1), _p(gb2), _p(gb3), _p(gW3),
                 _p(st.feats), st.n, st.f, st.n * st.f, _p(self._perm), _p(self.ctl[1:]), m // 2, st.n_pairs, m // 2,
-                _p(st.mean), _p(st.scale), _p(st.inv_scale), None, _p(pb["xh"][1 - xi]), _p(pb["xl"][1 - xi]), _p(flag), g2, 8, 8, 1, _stream())
+                _p(st.mean), _p(st.scale), _p(st.inv_scale), None, _p(pb["xh"][1 - xi]), _p(pb["xl"][1 - xi]), _p(flag), g2, 8, 8, 1,
+                *self._dr1_planes_args(pb, dpl), _stream())
         tail = (len(self.params), self._pp, self._gp, self._parts, self._vp, self._sz, _p(self.hyper),
                 _p(self.ctl), _p(bf.loss_rows), m, 1.0 - self.weight, self.weight, _p(self.out))
         wg = (2, _p(bf.dlat), _p(r1), 1, m, self.H2, self.H1, _p(gW2), m // 2, _stream())
-        self._k(_L.idl_wgrad_xplanes_rms, _p(bf.dr1), _p(pb["xh"][xi]), _p(pb["xl"][xi]), self.F, m, self.H1, self.F, None, _p(self.W1),
+        self._k(_L.idl_wgrad_xplanes_rms, _p(bf.dr1), *self._dy_planes_args(pb, dpl), _p(pb["xh"][xi]), _p(pb["xl"][xi]), self.F, m, self.H1, self.F, None, _p(self.W1),
                 _p(self.square_avg[0]), _p(self._split_state), _p(self._ctl_snap), _p(wh), _p(wl), _p(flag), *tail, 0, *wg)
+
+    def _dr1_planes_args(self, pb, on):
+        """idl_mid_bwd_gather_planes' last arguments: where dr1's planes, their scale's history, the launch number and the exponent live."""
+        pb["dr1_as_planes"] = bool(on)
+        return (_p(pb["dh"]), _p(pb["dl"]), _p(self._dr1_scale)) if on else (None, None, None)
+
+    def dr1_of(self, bf):
+        """dr1 of the last step on these buffers as an fp32 tensor (tests): the step's own tensor, or -- where mid_bwd wrote it as planes only --
+        the planes put back together."""
+        pb = getattr(bf, "_planes", None)
+        if pb is None or not pb.get("dr1_as_planes", False):
+            return bf.dr1
+        return ((pb["dh"].view(torch.float16).double() + pb["dl"].view(torch.float16).double()) * 2.0 ** -int(self._dr1_scale[0].item())).float()
+
+    def _dy_planes_args(self, pb, on):
+        return (_p(pb["dh"]), _p(pb["dl"]), _p(self._dr1_scale)) if on else (None, None, None)
 
     def _tail_launch(self, bf, xi, r1, l1=None, l1p=None, red=None):
         """The optimizer's tail of the step that ran on (bf, xi) with the activations r1: dW2 tiles + RMSprop on every tensor but W1 + step

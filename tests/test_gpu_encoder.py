@@ -1215,7 +1215,7 @@ def test_tail_riding_in_the_layer1_launch_changes_no_bit(dev, monkeypatch, n, us
 def test_default_step_contains_no_library_gemm(dev, monkeypatch, planes):
     """Round 5: the speed of the step's largest forward kernel must not depend on a hipBLASLt build, a TunableOp
     seed file or its validators.  The default step's launches, by kernel name (torch.profiler): the layer-1 product is
-    l1_planes_kernel (+ reduce_rms_kernel) / wgrad_xplanes_rms_kernel in the two-plane form, l1_fwd_kernel / l1_rms_kernel / wgrad_q16_kernel
+    l1_planes_kernel (+ reduce_rms_kernel) / wgrad_dplanes_rms_kernel in the two-plane form, l1_fwd_kernel / l1_rms_kernel / wgrad_q16_kernel
     with IDELUCS_PLANES=0 (own tiles either way), and NO rocBLAS / hipBLASLt kernel (Cijk_*)
     runs in a full-batch step -- also with the shipped solutions switched off (IDELUCS_TUNABLEOP_SEED=0), as on a box whose library
     differs from the seed file's."""
@@ -1245,7 +1245,8 @@ def test_default_step_contains_no_library_gemm(dev, monkeypatch, planes):
         pytest.skip("the profiler reported no device kernels on this box")
     if planes == "1":
         assert any("l1_planes_kernel" in n for n in names) and any("reduce_rms_kernel" in n for n in names), sorted(set(names))
-        assert any("wgrad_xplanes" in n for n in names)         # (wgrad_xplanes_rms_kernel: the tiles + the step's optimizer tail on their loader waves)
+        assert any("wgrad_dplanes_rms" in n for n in names)     # (the tiles with both operands as planes + the step's optimizer tail on their loader waves)
+        assert any("mid_bwd_kernel<false, false, true>" in n or "mid_bwd_kernelILb0ELb0ELb1E" in n for n in names), sorted(set(names))      # (... dr1 written as planes)
     else:
         assert any("l1_rms_kernel" in n for n in names) and any("l1_fwd_kernel" in n for n in names), sorted(set(names))
         assert any("wgrad_q16_kernel" in n for n in names)

@@ -171,11 +171,60 @@ def test_producers_write_the_planes_of_what_they_write(dev):
     _lib.check(L.idl_mid_bwd_gather_planes(_p(z), _p(r2), _p(f), _p(inv), _p(G), 1, _p(dP0), _p(W3), _p(W2), _p(a1), mm, C, 1, 1e-3, _p(dlg), _p(dlat),
                                            _p(dr1), _p(p1), _p(p2), _p(p3), _p(pw3),
                                            _p(feats), n, F, n * F, _p(perm), _p(base), 0, 2 * n, B, _p(mean), _p(scale), _p(inv_scale),
-                                           _p(y), _p(yh), _p(yl), None, 3, 8, 8, 1, _stream()))
+                                           _p(y), _p(yh), _p(yl), None, 3, 8, 8, 1, None, None, None, None, None, _stream()))
     torch.cuda.synchronize()
     assert torch.equal(y, want) and xflag.item() == 0
     hi, lo, _, _ = _split(y, 0)
     assert torch.equal(hi, yh) and torch.equal(lo, yl)
+    # ---- mid_bwd writes dr1 as planes (round 6): idl_split_planes of the fp32 dr1 with the exponent it finds in word [1] of the scale's words -- the
+    # default when a voter begins, afterwards what the dW1 launch derived from the previous step's maxima; the exponent used is left in word [0], the
+    # workgroups' largest |dr1| in words [4..]; a dr1 beyond the planes' range (or not finite) raises the flag, one inside the 128 x headroom does not
+    KF = int(L.idl_planes_exponent(2))
+    sc = torch.zeros(int(L.idl_dr1_scale_words()), dtype=torch.int32, device=dev); sc[1] = KF
+    dh = torch.zeros(mm, 512, dtype=torch.int16, device=dev); dl = torch.zeros_like(dh); dflag = torch.zeros(1, dtype=torch.int32, device=dev)
+
+    def bwd(G_, dP0_, planes):
+        out = None if planes else torch.empty(mm, 512, device=dev)
+        tail = (_p(dh), _p(dl), _p(sc)) if planes else (None, None, None)
+        _lib.check(L.idl_mid_bwd_gather_planes(_p(z), _p(r2), _p(f), _p(inv), _p(G_), 1, _p(dP0_), _p(W3), _p(W2), _p(a1), mm, C, 1, 1e-3, _p(dlg), _p(dlat),
+                                               _p(out), _p(p1), _p(p2), _p(p3), _p(pw3), None, 0, 0, 0, None, None, 0, 0, 0, None, None, None,
+                                               None, None, None, _p(dflag), 0, 0, 1, 1, *tail, _stream()))
+        torch.cuda.synchronize()
+        return out
+
+    def split_k(v, k):
+        a = torch.empty(v.shape, dtype=torch.int16, device=dev); b = torch.empty_like(a); fl = torch.zeros(1, dtype=torch.int32, device=dev)
+        _lib.check(L.idl_split_planes(_p(v), v.numel(), k, _p(a), _p(b), _p(fl), _stream()))
+        return a, b
+
+    def k_of(v):                                                               # 2^k max|v| in [2^8, 2^9)
+        return 9 - int(np.frexp(v.abs().max().item())[1])
+
+    ref1 = bwd(G, dP0, False)
+    assert torch.equal(ref1, dr1)
+    p1_ref = p1.clone()
+    bwd(G, dP0, True)
+    assert sc[0].item() == KF == 10 and dflag.item() == 0 and torch.equal(p1, p1_ref)      # (the bias gradient's partial sums come from the unrounded values)
+    a_, b_ = split_k(ref1, KF)
+    assert torch.equal(a_, dh) and torch.equal(b_, dl)
+    assert sc[4:].view(torch.float32).max().item() == ref1.abs().max().item()
+    k2 = k_of(ref1)
+    sc[1] = k2                                                                 # (what the dW1 launch leaves: below)
+    ref3 = bwd(G * 10, dP0 * 10, False)                                        # a gradient several times larger, inside the headroom
+    bwd(G * 10, dP0 * 10, True)
+    assert sc[0].item() == k2 and dflag.item() == 0 and 2.0 < (ref3.abs().max() / ref1.abs().max()).item() < 100.0
+    a_, b_ = split_k(ref3, k2)
+    assert torch.equal(a_, dh) and torch.equal(b_, dl)
+    back = (dh.view(torch.float16).double() + dl.view(torch.float16).double()) * 2.0 ** -k2
+    assert ((back - ref3.double()).abs().max() / ref3.double().abs().max()).item() < 1e-6
+    ref4 = bwd(G * 1e5, dP0 * 1e5, False)                                      # far beyond what the exponent expects: clamped, and said so
+    bwd(G * 1e5, dP0 * 1e5, True)
+    assert ref4.abs().max().item() * 2.0 ** k2 > 65000.0 and dflag.item() == 1
+    assert bool(torch.isfinite(dh.view(torch.float16).float()).all())
+    dflag.zero_()
+    Gn = G.clone(); Gn[0, 3, 5] = float("nan")
+    bwd(Gn, dP0, True)
+    assert dflag.item() == 1                                                   # a dr1 that is not finite raises the flag too
     # a column whose originals barely vary: the standardised entries leave the planes' range, are clamped there, and the flag says so
     scale2 = scale.clone(); scale2[7] = 1e-9
     inv2 = 1.0 / scale2
@@ -216,7 +265,7 @@ def test_weight_gradient_from_the_batch_planes_matches_the_fp32_tiles(dev, m, H,
     errs = []
     for step in (0, 1, 2, 4):                                 # launch 1 takes the default scale, 2 and 3 the previous launch's, the last one
         Wpl.copy_(W0); Vpl.copy_(V0); ctl[0:1].fill_(step)     # the scale of two launches back (a step of another form moved the counter on)
-        _lib.check(L.idl_wgrad_rmsprop_xplanes(_p(dy), _p(xh), _p(xl), F, m, H, F, _p(gpl), _p(Wpl), _p(Vpl), _p(hyper), _p(ctl), _p(state),
+        _lib.check(L.idl_wgrad_rmsprop_xplanes(_p(dy), None, None, None, _p(xh), _p(xl), F, m, H, F, _p(gpl), _p(Wpl), _p(Vpl), _p(hyper), _p(ctl), _p(state),
                                                _p(wh), _p(wl), _p(flag), _stream()))
         torch.cuda.synchronize()
         errs.append((gpl.double() - ref).abs().max().item() / scale)
@@ -227,9 +276,34 @@ def test_weight_gradient_from_the_batch_planes_matches_the_fp32_tiles(dev, m, H,
     hi, lo, _, _ = _split(Wpl, 1)
     assert torch.equal(hi, wh) and torch.equal(lo, wl) and flag.item() == 0
     # the gradient alone, W untouched
-    _lib.check(L.idl_wgrad_rmsprop_xplanes(_p(dy), _p(xh), _p(xl), F, m, H, F, _p(gpl), None, None, None, _p(ctl), _p(state), None, None, None, _stream()))
+    _lib.check(L.idl_wgrad_rmsprop_xplanes(_p(dy), None, None, None, _p(xh), _p(xl), F, m, H, F, _p(gpl), None, None, None, _p(ctl), _p(state), None, None, None, _stream()))
     torch.cuda.synchronize()
     assert (gpl.double() - ref).abs().max().item() / scale < 1e-6
+    # ---- round 6: dy arriving AS planes (what mid_bwd writes), whatever power of two they were scaled by within the headroom: the gradient no
+    # further from the float64 product than the fp32 tiles', the update and W's planes as above
+    if m % 64 == 0:
+        e_max = int(np.frexp(dy.abs().max().item())[1])
+        for k in (9 - e_max, 15 - e_max, 3 - e_max):
+            dyh = torch.empty(m, H, dtype=torch.int16, device=dev); dyl = torch.empty_like(dyh); f2 = torch.zeros(1, dtype=torch.int32, device=dev)
+            _lib.check(L.idl_split_planes(_p(dy), dy.numel(), k, _p(dyh), _p(dyl), _p(f2), _stream()))
+            sc = torch.zeros(int(L.idl_dr1_scale_words()), dtype=torch.int32, device=dev)
+            sc[0] = k; sc[1] = -77
+            sc[4:] = (dy.abs().max() * torch.rand(64, generator=g).to(dev)).view(torch.int32); sc[4 + 13] = dy.abs().max().view(torch.int32)
+            Wpl.copy_(W0); Vpl.copy_(V0); gpl.fill_(float("nan"))
+            _lib.check(L.idl_wgrad_rmsprop_xplanes(None, _p(dyh), _p(dyl), _p(sc), _p(xh), _p(xl), F, m, H, F, _p(gpl), _p(Wpl), _p(Vpl), _p(hyper), None, None,
+                                                   _p(wh), _p(wl), _p(flag), _stream()))
+            torch.cuda.synchronize()
+            e = (gpl.double() - ref).abs().max().item() / scale
+            assert f2.item() == 0 and e < 1e-6 and (k != 9 - e_max or e <= e32), (k, e, e32)
+            assert torch.allclose(Vpl, V32, rtol=1e-4, atol=0.0) and (Wpl - W32).abs().max().item() < 2e-6
+            hi, lo, _, _ = _split(Wpl, 1)
+            assert torch.equal(hi, wh) and torch.equal(lo, wl) and flag.item() == 0
+            assert sc[0].item() == k and sc[1].item() == 9 - e_max             # the next step's exponent, from the maxima: 2^k max in [2^8, 2^9)
+        sc[4:] = 0
+        _lib.check(L.idl_wgrad_rmsprop_xplanes(None, _p(dyh), _p(dyl), _p(sc), _p(xh), _p(xl), F, m, H, F, _p(gpl), None, None, None, None, None, None, None, None, _stream()))
+        torch.cuda.synchronize()
+        assert sc[1].item() == int(L.idl_planes_exponent(2))                   # (an all-zero gradient: the default exponent)
+        assert L.idl_wgrad_rmsprop_xplanes(None, _p(dyh), None, _p(sc), _p(xh), _p(xl), F, m, H, F, _p(gpl), None, None, None, None, None, None, None, None, _stream()) != 0
 
 
 def _store_and_net(dev, n, seed=3, C=20):
@@ -262,7 +336,7 @@ def test_step_on_planes_trains_like_the_default_step(dev, monkeypatch, reduce):
         tr._gather(store, bf)
         tr._full_step(store, bf, pipelined=True)
         torch.cuda.synchronize()
-        one[flag] = (tr.out[0].item(), bf.dr1.clone(), tr.grads[0].clone(), tr.W1.detach().clone())
+        one[flag] = (tr.out[0].item(), tr.dr1_of(bf).clone(), tr.grads[0].clone(), tr.W1.detach().clone())
         tr = FusedLinearTrainer(copy.deepcopy(net0), lr=1e-3, weight=0.25, lamb=2.8, seed=5)
         gen = torch.Generator(device=dev); gen.manual_seed(123)
         s = []

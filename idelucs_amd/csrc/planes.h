@@ -31,7 +31,8 @@ __device__ __forceinline__ uint32_t pack2(_Float16 a, _Float16 b)
 // four scaled values -> 8 bytes of the high plane, 8 of the low; returns whether any left the range (then clamped)
 __device__ __forceinline__ bool split4(float s0, float s1, float s2, float s3, uint2 &hi, uint2 &lo)
 {
-    const bool over = fmaxf(fmaxf(fabsf(s0), fabsf(s1)), fmaxf(fabsf(s2), fabsf(s3))) > LIMIT;
+    // (NOT "max > LIMIT": fmaxf drops a NaN and fmed3 maps it to a bound -- a diverged tensor would give finite planes and no flag)
+    const bool over = !(fabsf(s0) <= LIMIT) || !(fabsf(s1) <= LIMIT) || !(fabsf(s2) <= LIMIT) || !(fabsf(s3) <= LIMIT);
     s0 = __builtin_amdgcn_fmed3f(s0, -LIMIT, LIMIT); s1 = __builtin_amdgcn_fmed3f(s1, -LIMIT, LIMIT);
     s2 = __builtin_amdgcn_fmed3f(s2, -LIMIT, LIMIT); s3 = __builtin_amdgcn_fmed3f(s3, -LIMIT, LIMIT);
     const _Float16 h0 = (_Float16)s0, h1 = (_Float16)s1, h2 = (_Float16)s2, h3 = (_Float16)s3;

@@ -37,6 +37,21 @@ def _p(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
 
+_PLANES_DISABLED = False
+
+
+def planes_default():
+    """Whether a new trainer takes the two-plane step form: IDELUCS_PLANES (default on) unless a run of this process already left the planes' range
+    (disable_planes: training.train_voter's fall-back)."""
+    return os.environ.get("IDELUCS_PLANES", "1") != "0" and not _PLANES_DISABLED
+
+
+def disable_planes():
+    """From here on every trainer of this process runs the fp32 tiles (the data left the fp16 planes' range once: it will again)."""
+    global _PLANES_DISABLED
+    _PLANES_DISABLED = True
+
+
 def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -173,7 +188,7 @@ class FusedLinearTrainer:
         # the batch's planes written by the workgroups that assemble it, W1's by the epilogue of the dW1 tiles that update it.  A step
         # 100.6 us against 111.0 at cfg2 (tools/bench_planes.py).  Needs the default launch sequence of a single voter (tail-in-layer-1),
         # m % 128 == 0 and F % 512 == 0; any other step runs the fp32 tiles.
-        self._planes = os.environ.get("IDELUCS_PLANES", "1") != "0"
+        self._planes = planes_default()
         self._planes_reduce_launch = os.environ.get("IDELUCS_PLANES_REDUCE", "launch") != "mid"
         self._planes_fork = os.environ.get("IDELUCS_PLANES_FORK", "0") == "1"
         # ... and the same for a rank's voters in lockstep (BatchedLinearTrainer; IDELUCS_LOCKSTEP_PLANES=0: their products as batched fp32
@@ -737,6 +752,22 @@ class FusedLinearTrainer:
         should be repeated with IDELUCS_PLANES=0."""
         return self._w1_planes is not None and bool(self._w1_planes[2].item())
 
+    def drop_planes(self):
+        """Leave the two-plane step form for good (an operand left the planes' range): the fp32 tiles from the next step on, the flag cleared, the
+        captured graphs (they hold the plane launches) dropped.  The caller restarts its voter: what was trained on clamped operands is not kept."""
+        self.flush_tail()
+        self._planes = False
+        self._planes_lockstep = False
+        self._graphs.clear()
+        self._w1_planes_fresh = False
+        if self._w1_planes is not None:
+            self._w1_planes[2].zero_()
+        for bf in self._bufs.values():
+            if getattr(bf, "_planes", None) is not None:
+                bf._planes["valid"] = [False, False]
+                bf._planes["x32"] = [True, True]
+                bf._planes["dr1_as_planes"] = False
+
     def _gather(self, store, bf):
         b = bf.m // 2
         _lib.check(_L.idl_gather_pairs_at(_p(store.feats), store.n, store.f, store.n * store.f, _p(self._perm), _p(self.ctl[1:]),
@@ -866,6 +897,12 @@ class BatchedLinearTrainer:
         self._graphs = {}
         self._w1_in_launch = False
         self._l1_in_launch = False
+        self._planes_step = False
+
+    def drop_planes(self):
+        """After the voters' trainers left the two-plane form (FusedLinearTrainer.drop_planes): the recorded programs and captured graphs hold its launches."""
+        self._programs = {}
+        self._graphs.clear()
         self._planes_step = False
 
     def stack(self, m):

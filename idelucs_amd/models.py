@@ -39,6 +39,10 @@ def weights_init(m, generator=None):
         torch.nn.init.zeros_(m.bias)
 
 
+class PlanesOverflow(RuntimeError):
+    """An operand of the training step's two big products left the range of its fp16 planes (IID_model._check_planes)."""
+
+
 class IID_model():
     def __init__(self, args: dict):
         _lib.require_gpu()          # no CPU path: fail here, loudly, rather than train on the host
@@ -213,11 +217,14 @@ class IID_model():
         return running_loss
 
     def _check_planes(self):
-        """The two-plane step form (fused.FusedLinearTrainer._planes) clamps a weight of Linear(F,512) beyond +-15.8 in the layer-1 product and
-        raises a flag: checked wherever this model waits for the device anyway (a synchronous epoch, predict)."""
+        """The two-plane step form (fused.FusedLinearTrainer._planes) clamps what leaves its planes' range -- a weight of Linear(F,512) beyond +-15.8, a
+        standardised feature beyond +-8125 (a mimic's k-mer thousands of the originals' standard deviations out), a gradient entry more than 128 x the
+        previous step's largest, anything not finite -- and raises a flag: checked wherever this model waits for the device anyway (a synchronous
+        epoch, predict).  training.train_voter(s) catch PlanesOverflow, switch the process to the fp32 tiles and train the voter again from its
+        start (every stream a voter draws from is a function of (seed, voter): the rerun IS the IDELUCS_PLANES=0 run)."""
         if self._fused is not None and self._fused.planes_overflowed():
-            raise RuntimeError("a weight of the first layer (|w| >= 15.8) or a standardised feature (|x| > 8125) left the range of the fp16 planes: "
-                               "rerun with IDELUCS_PLANES=0")
+            raise PlanesOverflow("a weight of the first layer (|w| >= 15.8), a standardised feature (|x| > 8125) or an entry of the layer-1 gradient left "
+                                 "the range of the fp16 planes: train this voter again on the fp32 tiles (training.train_voter does; or IDELUCS_PLANES=0)")
 
     # ------------------------------------------------------------------ inference
     def _predict_inputs(self, rows=None):

@@ -21,9 +21,30 @@ def train_voter(model, n_epochs, voter=0, n_voters=1, progress=True):
     if progress:
         sys.stdout.write(f"\r........... Training Model ({voter + 1}/{n_voters})................")
         sys.stdout.flush()
-    model.begin_voter(voter)
-    curve = [model.contrastive_training_epoch() for _ in range(n_epochs)]
-    return (curve,) + tuple(model.predict())
+    for attempt in (0, 1):
+        model.begin_voter(voter)
+        try:
+            curve = [model.contrastive_training_epoch() for _ in range(n_epochs)]
+            return (curve,) + tuple(model.predict())
+        except models.PlanesOverflow as err:
+            # the data (or a diverging run) does not fit the fp16 planes: the fp32 tiles for the rest of this process, and this voter again from
+            # its start -- begin_voter re-seeds every stream it draws from, so the rerun is exactly the IDELUCS_PLANES=0 run
+            if attempt or not _leave_planes([model], err):
+                raise
+
+
+def _leave_planes(lane_models, err):
+    """Switch this process (and the given models' trainers) to the fp32 step form after a PlanesOverflow; False where the voter cannot simply be
+    trained again (IDELUCS_VOTER_STATE=carry: its start was the previous voter's optimizer state, which the failed attempt overwrote)."""
+    from . import fused
+    if models.IID_model.voter_state_carried():
+        return False
+    sys.stderr.write(f"\n[idelucs_amd] {err}\n[idelucs_amd] -> the fp32 tiles from here on; training the voter(s) again from the start\n")
+    fused.disable_planes()
+    for m in lane_models:
+        if m._fused is not None:
+            m._fused.drop_planes()
+    return True
 
 
 def plane_step_applies(model):
@@ -103,19 +124,26 @@ def train_voters(model, voters, n_epochs, n_voters=None, lanes=None, progress=Tr
         if progress:
             sys.stdout.write(f"\r........... Training Models ({wave[0] + 1}-{wave[-1] + 1}/{n_voters})................")
             sys.stdout.flush()
-        for m, v in zip(lane_models, wave):
-            m.begin_voter(v)
-        curves = {v: [] for v in wave}
-        n_batches = (model.store.n_pairs + model.batch_sz - 1) // model.batch_sz
-        gemm_tuning.maybe_enable(n_batches * n_epochs * len(voters))
-        for _ in range(n_epochs):
-            for m in lane_models:
-                m.net.train()
-            res = batched.run_epoch(model.store, model.batch_sz, [m._gen for m in lane_models])
-            for m, v, (total, nb) in zip(lane_models, wave, res):
-                curves[v].append(m._finish_epoch(total / (nb - 1), sync=False))     # models.py:135 quirk (divide by last index)
-        for m, v in zip(lane_models, wave):
-            out[v] = ([float(x) for x in curves[v]],) + tuple(m.predict())
+        for attempt in (0, 1):
+            for m, v in zip(lane_models, wave):
+                m.begin_voter(v)
+            curves = {v: [] for v in wave}
+            n_batches = (model.store.n_pairs + model.batch_sz - 1) // model.batch_sz
+            gemm_tuning.maybe_enable(n_batches * n_epochs * len(voters))
+            for _ in range(n_epochs):
+                for m in lane_models:
+                    m.net.train()
+                res = batched.run_epoch(model.store, model.batch_sz, [m._gen for m in lane_models])
+                for m, v, (total, nb) in zip(lane_models, wave, res):
+                    curves[v].append(m._finish_epoch(total / (nb - 1), sync=False))     # models.py:135 quirk (divide by last index)
+            try:
+                for m, v in zip(lane_models, wave):
+                    out[v] = ([float(x) for x in curves[v]],) + tuple(m.predict())
+                break
+            except models.PlanesOverflow as err:     # (as train_voter: the fp32 form, and the whole batch of voters again)
+                if attempt or not _leave_planes(lane_models, err):
+                    raise
+                batched.drop_planes()
     # the caller goes on with `model`: leave it holding the LAST voter's weights, as after a sequential run
     if lane_models is not None and len(voters) % lanes != 1:
         last = lane_models[(len(voters) - 1) % lanes if len(voters) % lanes else lanes - 1]

@@ -351,7 +351,12 @@ def test_step_on_planes_trains_like_the_default_step(dev, monkeypatch, reduce):
     assert abs(l1 - l0) <= 2e-6 * abs(l0), (l0, l1)
     off = ((d1 - d0).abs() > 2e-5 * d0.abs().max()).sum().item()
     assert off <= 64, off                                                     # (of 524 288)
-    assert ((g1 - g0).abs().max() / g0.abs().max()).item() < 1e-3 and ((g1 - g0).abs().mean() / g0.abs().max()).item() < 2e-6
+    # dW1 = dr1^T x: a row of it (a hidden unit) inherits what its column of dr1 differs by -- the rows of the units WITHOUT a flipped element agree
+    # within 2e-5 of the largest entry, and no more rows than flipped elements are beyond that (VERDICT r5 #2c: counted, not excused by a 1e-3 maximum)
+    flipped = ((d1 - d0).abs() > 2e-5 * d0.abs().max()).any(0)                # [512] hidden units
+    gdiff = (g1 - g0).abs().max(1).values / g0.abs().max()
+    assert flipped.sum().item() <= off and (gdiff[~flipped] < 2e-5).all(), (flipped.sum().item(), off, gdiff[~flipped].max().item())
+    assert (gdiff[flipped] < 5e-3).all() and ((g1 - g0).abs().mean() / g0.abs().max()).item() < 2e-6
     # (the second epoch: two fp32-grade implementations of a product part at the rate the step amplifies a rounding -- a gradient differing
     #  by 1e-6 flips ReLU / Dropout patterns a step later; measured 2.1e-4 here, 2e-4 .. 5e-4 over the epochs of tools/bench_planes.py)
     for a_, b_, tol in zip(sums["0"], sums["1"], (2e-4, 1e-3)):              # (first epoch: 7e-6 .. 8e-5 over the variants)
@@ -526,3 +531,102 @@ def test_cold_caches_leave_lockstep_voters_the_lone_voters(dev, monkeypatch):
     monkeypatch.setenv("IDELUCS_TEST_COLD", "1")
     bt = E._batched_like_single(dev, 4200, False, copy, torch, FusedLinearTrainer, BatchedLinearTrainer)
     assert bt._planes_step and bt.trainers[0]._cold
+
+
+def test_plane_products_on_adversarial_operands(dev):
+    """VERDICT r5 #2b: both plane products against float64 where a fixed power-of-two scale and fp16's subnormal floor could bite (tools/planes_adversarial.py
+    has the cases: columns and rows spanning 1e-6 .. 30, near-cancelling sums, entries whose low plane is subnormal, outliers at the end of the planes'
+    range, sparse operands).  The claim, as measured (profiles/r06_planes_adversarial.txt): relative to the float64 product's LARGEST entry a plane
+    product of standardised operands is within 7e-7 on every case, and on long dense sums (the training step's shape) it is closer than the fp32
+    arithmetic it replaces, whose error grows with the sum's length (2.4e-7 against 2.6e-6; dW1 4.5e-7 against 1.5e-6).  On sums carried by a few
+    terms (outliers, sparse operands) fp32 accumulation is exact to 2^-24 and the planes are up to twice as far (4.9e-7 against 2.6e-7): "fp32-grade",
+    not "better than fp32".  Outside the contract -- a batch that is ~1e-4 THROUGHOUT, which a standardised batch is not -- the fixed 2^3 leaves the
+    low plane in fp16's subnormals: 2e-5 (the fp32 tiles 3e-6)."""
+    import os
+    import sys
+    import math
+    import torch
+    from idelucs_amd import _lib
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from planes_adversarial import cases
+    L = _lib.lib
+    g = torch.Generator(device="cpu"); g.manual_seed(11)
+    m, H, F = 1024, 512, 4096
+    h16 = lambda t: torch.empty(t.shape, dtype=torch.int16, device=dev)
+    seen = {}
+    for name, W, x, dy in cases(m, H, F, g):
+        W, x, dy = W.to(dev).contiguous(), x.to(dev).contiguous(), dy.to(dev).contiguous()
+        wh, wl, xh, xl, flag = h16(W), h16(W), h16(x), h16(x), torch.zeros(1, dtype=torch.int32, device=dev)
+        _lib.check(L.idl_split_planes(_p(W), W.numel(), L.idl_planes_exponent(1), _p(wh), _p(wl), _p(flag), _stream()))
+        _lib.check(L.idl_split_planes(_p(x), x.numel(), L.idl_planes_exponent(0), _p(xh), _p(xl), _p(flag), _stream()))
+        part = torch.empty(int(L.idl_l1_planes_parts()), H, m, device=dev)
+        _lib.check(L.idl_l1_planes(_p(wh), _p(wl), F, _p(xh), _p(xl), F, m, H, F, _p(part), _stream()))
+        ref = W.double() @ x.double().t()
+        s1 = ref.abs().max().item()
+        e_pl = (part.double().sum(0) - ref).abs().max().item() / s1
+        e_lib = ((W @ x.t()).double() - ref).abs().max().item() / s1
+        refg = dy.double().t() @ x.double()
+        s2 = refg.abs().max().item()
+        g32, gpl = torch.empty(H, F, device=dev), torch.empty(H, F, device=dev)
+        _lib.check(L.idl_wgrad_rmsprop(_p(dy), _p(x), m, H, F, _p(g32), None, None, None, _stream()))
+        kd = 9 - math.frexp(dy.abs().max().item())[1]
+        dyh, dyl = h16(dy), h16(dy)
+        _lib.check(L.idl_split_planes(_p(dy), dy.numel(), kd, _p(dyh), _p(dyl), _p(flag), _stream()))
+        sc = torch.zeros(int(L.idl_dr1_scale_words()), dtype=torch.int32, device=dev); sc[0] = kd
+        _lib.check(L.idl_wgrad_rmsprop_xplanes(None, _p(dyh), _p(dyl), _p(sc), _p(xh), _p(xl), F, m, H, F, _p(gpl), None, None, None, None, None, None, None, None, _stream()))
+        torch.cuda.synchronize()
+        e_g = (gpl.double() - refg).abs().max().item() / s2
+        e_32 = (g32.double() - refg).abs().max().item() / s2
+        seen[name] = (e_pl, e_lib, e_g, e_32)
+        assert flag.item() == 0, name
+        if name.startswith("near-cancelling"):               # (the largest entry is itself what cancellation left: every arithmetic is noise there -- no worse than fp32's)
+            assert e_pl <= 2.0 * e_lib and e_g <= 3.0 * e_32, (name, seen[name])
+        elif name.startswith("low plane subnormal"):         # OUTSIDE the step's contract (x is standardised: |x| ~ 1): a batch that is 1e-4 throughout leaves
+            assert e_pl < 1e-4 and e_g < 1e-4, (name, seen[name])      # its low plane in fp16's subnormals under the fixed 2^3 -- 14 bits, the documented limit
+        else:
+            assert e_pl < 7e-7 and e_g < 7e-7, (name, seen[name])
+    # the step's own regime (dense standardised operands, sums of 4096 / 1024 products): closer than the fp32 arithmetic
+    e_pl, e_lib, e_g, e_32 = seen["plain"]
+    assert e_pl <= e_lib and e_g <= e_32, seen["plain"]
+    print({k: tuple(f"{v:.1e}" for v in t) for k, t in seen.items()})
+
+
+def test_data_beyond_the_planes_range_falls_back_to_the_fp32_tiles(dev, monkeypatch, capsys):
+    """a dataset the reference handles must not fail after a full training pass.  A standardised feature beyond +-8125 (here: a
+    column whose scale is made tiny, as a k-mer absent from nearly every original gives) raises the planes' flag; training.train_voter then switches
+    the process to the fp32 tiles and trains the voter again from its start -- the result is bit for bit the IDELUCS_PLANES=0 run's, and new trainers
+    of the process take the fp32 form."""
+    import os
+    import torch
+    from idelucs_amd import fused, models, training
+    import test_gpu_encoder as E
+    monkeypatch.setattr(fused, "_PLANES_DISABLED", False)
+
+    def model(planes):
+        monkeypatch.setenv("IDELUCS_PLANES", planes)
+        m = models.IID_model({'sequence_file': os.path.join(E.DATA, "Influenza-A.fas"), 'GT_file': None, 'n_clusters': 5, 'k': 6,
+                              'model_size': 'linear', 'n_mimics': 3, 'batch_sz': 512, 'optimizer': 'RMSprop', 'lambda': 2.8,
+                              'lr': 1e-3, 'weight': 0.25, 'scheduler': None, 'n_epochs': 2, 'n_voters': 1, 'seed': 3})
+        m.build_dataloader()
+        col = 77
+        m.store.scale[col] = m.store.scale[col] * 1e-7                           # the column's standardised entries: ~1e7 standard deviations
+        m.store.inv_scale[col] = 1.0 / m.store.scale[col]
+        return m
+
+    m1 = model("1")
+    curve1, y1, p1, lat1 = training.train_voter(m1, 2, voter=0, n_voters=1, progress=False)
+    assert "fp32 tiles" in capsys.readouterr().err
+    assert fused._PLANES_DISABLED and not m1._fused._planes and not m1._fused.planes_overflowed()
+    monkeypatch.setattr(fused, "_PLANES_DISABLED", False)
+    m0 = model("0")
+    curve0, y0, p0, lat0 = training.train_voter(m0, 2, voter=0, n_voters=1, progress=False)
+    assert curve1 == curve0 and np.array_equal(y1, y0) and np.array_equal(lat1, lat0)
+    for a, b in zip(m1.net.parameters(), m0.net.parameters()):
+        assert torch.equal(a, b)
+    # without the fall-back (a caller driving the epochs itself): the exception names what happened
+    monkeypatch.setattr(fused, "_PLANES_DISABLED", False)
+    m2 = model("1")
+    m2.begin_voter(0)
+    with pytest.raises(models.PlanesOverflow):
+        m2.contrastive_training_epoch()
+    monkeypatch.setattr(fused, "_PLANES_DISABLED", False)

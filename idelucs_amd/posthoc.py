@@ -343,41 +343,45 @@ def _core_distances_window(x64, k, device, out, sample=None, seed=0, stats=None,
     r_lo, r_hi = int(math.floor(r - KNN_SIGMAS * sd)), int(math.ceil(r + KNN_SIGMAS * sd)) + 1
     if r_hi > S:
         return None                                            # k too close to n for a bracket: the matrix path
-    vp = ctypes.c_void_p
-    perm, gid = order if order is not None else _spatial_order(x64, seed=seed)
-    xo = x64[perm]                                              # the points in memory order
-    sq = (xo * xo).sum(1)
-    g = torch.Generator(device="cpu"); g.manual_seed(seed)
-    cols = torch.randperm(n, generator=g)[:S].to(device)
-    xs_t, sqs = xo[cols].t().contiguous(), sq[cols]
-    # every group padded to whole waves of 64 rows, so that no wave (which centres its coordinates on its first row) straddles two groups;
-    # the padding is infinitely far from everything (never counted, never kept) and brackets nothing itself
-    counts = torch.bincount(gid)
-    padded = (counts + 63) // 64 * 64
-    first, start = torch.cumsum(counts, 0) - counts, torch.cumsum(padded, 0) - padded
-    pos = start[gid] + (torch.arange(n, device=device) - first[gid])
-    npad = int(padded.sum())
-    # this rank's share of the padded rows (whole 256-row blocks; everything without a process group)
-    p_lo, p_hi = 0, npad
-    if shard is not None and shard[1] > 1:
-        blocks = -(-npad // 256)
-        per = -(-blocks // shard[1])
-        p_lo, p_hi = min(npad, shard[0] * per * 256), min(npad, (shard[0] + 1) * per * 256)
     sharded = shard is not None and shard[1] > 1
-    failure = None
-    if sharded:
-        #  the ranks add disjoint shards up at positions every rank derives for itself: the order must be the same everywhere
-        # (core_distances_sharded broadcasts rank 0's), and a rank that fails in its share (out of memory) must still reach the
-        # collectives below -- its failure is agreed on first, then every rank raises
-        try:
-            return _core_distances_window_rows(x64, k, device, out, stats, perm, gid, xo, sq, xs_t, sqs, pos, npad, p_lo, p_hi, r_lo, r_hi, S, n, d, shard)
-        except ShardFailed:
-            raise
-        except Exception as err:      # noqa: BLE001 -- whatever it was, the other ranks are waiting
-            failure = err
+    agreed = [False]                                            # set once the ranks' agreement collective has run (see below)
+
+    def body():
+        perm, gid = order if order is not None else _spatial_order(x64, seed=seed)
+        bufs = {"xo": x64[perm]}                                # the points in memory order (owned by the row part, which frees them when done with them)
+        bufs["sq"] = (bufs["xo"] * bufs["xo"]).sum(1)
+        g = torch.Generator(device="cpu"); g.manual_seed(seed)
+        cols = torch.randperm(n, generator=g)[:S].to(device)
+        xs_t, sqs = bufs["xo"][cols].t().contiguous(), bufs["sq"][cols]
+        # every group padded to whole waves of 64 rows, so that no wave (which centres its coordinates on its first row) straddles two groups;
+        # the padding is infinitely far from everything (never counted, never kept) and brackets nothing itself
+        counts = torch.bincount(gid)
+        padded = (counts + 63) // 64 * 64
+        first, start = torch.cumsum(counts, 0) - counts, torch.cumsum(padded, 0) - padded
+        pos = start[gid] + (torch.arange(n, device=device) - first[gid])
+        npad = int(padded.sum())
+        # this rank's share of the padded rows (whole 256-row blocks; everything without a process group)
+        p_lo, p_hi = 0, npad
+        if sharded:
+            blocks = -(-npad // 256)
+            per = -(-blocks // shard[1])
+            p_lo, p_hi = min(npad, shard[0] * per * 256), min(npad, (shard[0] + 1) * per * 256)
+        return _core_distances_window_rows(x64, k, device, out, stats, perm, gid, bufs, xs_t, sqs, pos, npad, p_lo, p_hi, r_lo, r_hi, S, n, d, shard, agreed)
+
+    if not sharded:
+        return body()
+    #  the ranks add disjoint shards up at positions every rank derives for itself: the order must be the same everywhere
+    # (core_distances_sharded broadcasts rank 0's), and a rank that fails in its share -- anywhere from its first allocation on (out of memory) --
+    # must still reach the AGREEMENT collective its peers wait in: it says so there, then every rank raises.  A failure BEHIND the agreement
+    # (in the sums, or in the bookkeeping after them) must not issue a second, unmatched collective: the peers are past it.
+    try:
+        return body()
+    except ShardFailed:
+        raise
+    except Exception as err:      # noqa: BLE001 -- whatever it was, the other ranks may be waiting
+        if not agreed[0]:
             _all_ranks_ok(False, device)
-            raise ShardFailed(f"this rank failed in its share of the core distances: {err!r}") from err
-    return _core_distances_window_rows(x64, k, device, out, stats, perm, gid, xo, sq, xs_t, sqs, pos, npad, p_lo, p_hi, r_lo, r_hi, S, n, d, shard)
+        raise ShardFailed(f"this rank failed in its share of the core distances: {err!r}") from err
 
 
 class ShardFailed(RuntimeError):
@@ -394,9 +398,11 @@ def _all_ranks_ok(ok, device):
     return bool(int(t.item()))
 
 
-def _core_distances_window_rows(x64, k, device, out, stats, perm, gid, xo, sq, xs_t, sqs, pos, npad, p_lo, p_hi, r_lo, r_hi, S, n, d, shard):
+def _core_distances_window_rows(x64, k, device, out, stats, perm, gid, bufs, xs_t, sqs, pos, npad, p_lo, p_hi, r_lo, r_hi, S, n, d, shard, agreed):
     """The row part of _core_distances_window: brackets, window pass and selection of the padded rows [p_lo, p_hi), then (sharded) the
-    sum over the ranks."""
+    sum over the ranks.  bufs = {"xo", "sq"}: taken over (the only references, so that `del` below frees their 0.5 GB at 10^6 points);
+    agreed[0] becomes True once the ranks' agreement collective has run."""
+    xo, sq = bufs.pop("xo"), bufs.pop("sq")
     import ctypes
     import math
     import torch
@@ -444,7 +450,9 @@ def _core_distances_window_rows(x64, k, device, out, stats, perm, gid, xo, sq, x
             stats["kept_max"] = max(stats.get("kept_max", 0), int(cnt_in[:rows].max()))
     if shard is not None and shard[1] > 1:                      # the other ranks' rows: zeros here, theirs there
         import torch.distributed as tdist
-        if not _all_ranks_ok(True, device):                     # (a rank that failed above says so here: nobody waits in the sums below)
+        ok = _all_ranks_ok(True, device)                        # (a rank that failed above says so here: nobody waits in the sums below)
+        agreed[0] = True
+        if not ok:
             raise ShardFailed("another rank failed in its share of the core distances")
         core_p[:p_lo] = 0.0; core_p[p_hi:] = 0.0
         status_p[:p_lo] = 0; status_p[p_hi:] = 0

@@ -125,7 +125,7 @@ class FastaFile:
             # non-ASCII names: decode now, so that invalid UTF-8 fails here as in the reference, and apply the one header check the
             # byte-level reader cannot do (unicode whitespace as first character)
             if check and any(len(nm) > 0 and nm[0].isspace() for nm in self.names):
-                self.close()
+                self.close(export=False)         # (export=False: this may BE close()'s export -- the handle is closed once, here)
                 raise ValueError("Bad character in sequence header")
 
     def _load(self, h, check, keep_bytes, pack):
@@ -185,8 +185,9 @@ class FastaFile:
                     self._h = h
                     self._export_names()
                 finally:
-                    self._h = None
-                    _L.idl_fasta_close(h)
+                    if self._h is not None:      # (_check_names closes the handle itself before it raises)
+                        self._h = None
+                        _L.idl_fasta_close(h)
                 return
             _L.idl_fasta_close(self._h)
             self._h = None

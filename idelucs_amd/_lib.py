@@ -64,6 +64,7 @@ SIGNATURES = {
     "idl_mid_fwd": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _int, _c.c_uint64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "idl_nce_rows": (_int, [_vp, _int, _c.c_float, _vp, _vp, _vp]),
     "idl_iic_core": (_int, [_vp, _int, _c.c_float, _c.c_float, _c.c_float, _vp, _vp, _vp]),
+    "idl_iic_core_dz": (_int, [_vp, _int, _c.c_float, _c.c_float, _c.c_float, _vp, _vp, _vp, _int, _vp, _vp]),
     "idl_head_bwd": (_int, [_vp] * 5 + [_int, _vp, _vp, _int, _int, _int, _c.c_float, _vp, _vp, _vp]),
     "idl_head_bwd_dz": (_int, [_vp] * 5 + [_int, _vp, _vp, _int, _int, _int, _c.c_float, _vp, _vp, _vp]),
     "idl_nce_fused_workspace": (_i64, [_int]),
@@ -123,7 +124,7 @@ SIGNATURES = {
     "idl_wgrad_rmsprop_planes": (_int, [_vp, _vp, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "idl_mid_bwd_gather_planes": (_int, [_vp] * 5 + [_int] + [_vp] * 4 + [_int, _int, _int, _c.c_float] + [_vp] * 7 +
                                   [_vp, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int,
-                                   _vp, _vp, _vp, _vp]),
+                                   _vp, _vp, _vp, _vp, _vp]),
     "idl_dr1_scale_words": (_int, []),
     "idl_mid_fwd_gather_planes": (_int, [_vp, _vp, _int, _vp, _vp, _vp, _vp, _int, _int, _int, _c.c_uint64, _vp, _vp, _vp, _vp, _vp] +
                                   [_vp, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _vp]),
@@ -136,7 +137,9 @@ SIGNATURES = {
     "idl_mst_prim_lazy_workspace": (_i64, [_i64, _int]),
     "idl_mst_prim_lazy": (_int, [_vp, _vp, _vp, _i64, _int, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "idl_silhouette_sums": (_int, [_vp, _vp, _vp, _i64, _int, _int, _vp, _vp]),
+    "idl_nce_fused_joint": (_int, [_vp, _int, _c.c_float, _vp, _vp, _vp, _vp, _vp, _vp, _int, _vp]),
     "idl_iic_joint": (_int, [_vp, _int, _int, _vp, _vp]),
+    "idl_at_b": (_int, [_vp, _int, _vp, _int, _int, _int, _int, _vp, _int, _vp]),
     "idl_knn_window": (_int, [_vp, _i64, _int, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _int, _vp]),
     "idl_knn_select": (_int, [_vp, _i64, _int, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _int, _vp, _vp, _vp]),
     "idl_debug_stamps": (_int, [_vp]),

@@ -34,7 +34,7 @@ using nce_dev::load_rows;
 
 // The IIC core is a single-workgroup computation that is independent of the InfoNCE branch: when asked (P0 != NULL) it
 // rides along as ONE extra workgroup (blockIdx.x == m/16, blockIdx.y == 0) of pass 1 instead of a launch of its own.
-struct IicJob { float *P0; int C; float lamb, eps, w_iic; float *scratch; float *out; const float *z; };
+struct IicJob { float *P0; int C; float lamb, eps, w_iic; float *scratch; float *out; const float *z; int cols; };      // cols: spare columns of pass 1 (0 = 1)
 
 // The IIC joint P0 = z1^T z2 ([C, B] x [B, C], z1 = rows [0, B) of z, z2 = rows [B, 2B); reference LossFunctions.py:57-58 as
 // one contraction) rides along too: a [C, C] product is far too small to be worth a GEMM launch of its own.  The spare
@@ -79,12 +79,13 @@ __device__ __forceinline__ void iic_joint_tiles(const float *z, int m, int C, fl
 // pass 1: partial row sums [NCE_SPLIT][m] and the positive logits pos[m]
 __device__ __forceinline__ void nce_pass1_body(const float *f, int m, float inv_t, float *rowsum_part, float *pos, const IicJob &iic)
 {
-    if ((int)blockIdx.x == m / 16) {
+    if ((int)blockIdx.x >= m / 16) {
         // (ahead of the similarity waves it shares SIMDs with: beside a wave that issues fp32 matrix instructions back to back a
         //  wave of equal priority gets an issue slot only now and then -- stamps in the optimizer launch showed 6 us of such work
         //  taking 40)
         __builtin_amdgcn_s_setprio(3);
-        if (iic.z != nullptr) iic_joint_tiles(iic.z, m, iic.C, iic.P0, (int)blockIdx.y, NCE_SPLIT);     // core: pass 2
+        const int cols = iic.cols > 0 ? iic.cols : 1;        // (n_clusters > 48, round 6: as many spare columns as the joint has tiles / NCE_SPLIT -- a tile each)
+        if (iic.z != nullptr) iic_joint_tiles(iic.z, m, iic.C, iic.P0, ((int)blockIdx.x - m / 16) * NCE_SPLIT + (int)blockIdx.y, cols * NCE_SPLIT);     // core: pass 2
         else if (blockIdx.y == 0 && iic.P0 != nullptr) iic_core_small(iic.P0, iic.C, iic.lamb, iic.eps, iic.w_iic, iic.out);
         return;
     }
@@ -278,9 +279,56 @@ __global__ __launch_bounds__(256) void iic_joint_kernel(const float *__restrict_
     }
 }
 
+// out[M x N] = A^T B for A [K x M] and B [K x N] row-major (the shape of a weight gradient dy^T x with few outputs): iic_joint_kernel's tiles for any two
+// operands.  Round 6: dW3 = dlogits^T r2 ([C x m] x [m x 64]) at n_clusters > 48, where the library's kernel for the transposed-A product took 9 us.
+__global__ __launch_bounds__(256) void at_b_kernel(const float *__restrict__ A, int lda, const float *__restrict__ B, int ldb, int K, int M, int N,
+                                                   float *__restrict__ out, int ldo)
+{
+    __shared__ float part[3][64][4];
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, l = lane & 15, q = lane >> 4;
+    const int c1 = blockIdx.x * 16, c2 = blockIdx.y * 16;
+    const bool ok1 = c1 + l < M, ok2 = c2 + l < N;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    for (int kb = 128 * wv; kb < K; kb += 512) {             // the contraction index is dealt to the four waves in blocks of 128 (32 MFMA steps, every load in flight first)
+        const float *pa = A + (ok1 ? c1 + l : 0), *pb = B + (ok2 ? c2 + l : 0);
+        float av[32], bv[32];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) {                       // (clamped, not predicated)
+            const int k = kb + 4 * u + q, kk = k < K ? k : K - 1;
+            av[u] = pa[(size_t)kk * lda]; bv[u] = pb[(size_t)kk * ldb];
+        }
+#pragma unroll
+        for (int u = 0; u < 32; u += 2) {
+            const bool in0 = kb + 4 * u + q < K, in1 = kb + 4 * (u + 1) + q < K;
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32((ok1 && in0) ? av[u] : 0.f, (ok2 && in0) ? bv[u] : 0.f, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32((ok1 && in1) ? av[u + 1] : 0.f, (ok2 && in1) ? bv[u + 1] : 0.f, acc1, 0, 0, 0);
+        }
+    }
+    f32x4 acc = acc0 + acc1;
+    if (wv > 0) { part[wv - 1][lane][0] = acc[0]; part[wv - 1][lane][1] = acc[1]; part[wv - 1][lane][2] = acc[2]; part[wv - 1][lane][3] = acc[3]; }
+    __syncthreads();
+    if (wv == 0 && ok2) {
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int r = c1 + 4 * q + reg;
+            if (r < M) out[(size_t)r * ldo + c2 + l] = ((acc[reg] + part[0][lane][reg]) + part[1][lane][reg]) + part[2][lane][reg];
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
+
+// out[M x N] = A^T B, A [K x M] (lda), B [K x N] (ldb), all row-major fp32; a weight gradient with few outputs (dW3 = dlogits^T r2: models.py:130's backward
+// through Linear(64, C)) as 16 x 16 MFMA tiles, the sum over K in a fixed order
+int idl_at_b(const float *A, int lda, const float *B, int ldb, int K, int M, int N, float *out, int ldo, void *stream)
+{
+    IDL_REQUIRE(A && B && out && K >= 1 && M >= 1 && N >= 1 && lda >= M && ldb >= N && ldo >= N && M <= 65535 * 16 && N <= 65535 * 16, "at_b: NULL buffer or bad shape");
+    hipLaunchKernelGGL(at_b_kernel, dim3((unsigned)((M + 15) / 16), (unsigned)((N + 15) / 16)), dim3(256), 0, (hipStream_t)stream, A, lda, B, ldb, K, M, N, out, ldo);
+    IDL_HIP_TRY(hipGetLastError());
+    return IDL_OK;
+}
 
 int64_t idl_nce_fused_workspace(int m)
 {
@@ -299,8 +347,10 @@ static int nce_launch(const float *f, int m, float temperature, float *lse, floa
     float *rowsum_part = (float *)workspace, *pos = rowsum_part + (size_t)NCE_SPLIT * m;
     const float inv_t = 1.f / temperature;
     const dim3 grid((unsigned)(m / 16), NCE_SPLIT);
-    const dim3 grid1((unsigned)(m / 16 + (iic.P0 != nullptr ? 1 : 0)), NCE_SPLIT);
+    const dim3 grid1((unsigned)(m / 16 + (iic.P0 != nullptr ? (iic.cols > 0 ? iic.cols : 1) : 0)), NCE_SPLIT);
+    const bool core2 = iic.z != nullptr && iic.cols == 0;    // the core as the spare workgroup of pass 2 (n_clusters <= 48)
     if (void *plan = idl::take_plan()) {          // recorded, not launched (idl_plan_begin): both passes in one record
+        IDL_REQUIRE(iic.cols == 0, "nce_fused: the joint of n_clusters > 48 cannot be recorded");
         const dim3 g2 = iic.z != nullptr ? grid1 : grid;
         idl::PlanHead h{};
         h.kind = idl::PLAN_NCE; h.grid[0] = grid1.x; h.grid[1] = grid1.y; h.grid[2] = 1; h.block = 256;
@@ -311,7 +361,7 @@ static int nce_launch(const float *f, int m, float temperature, float *lse, floa
         return IDL_OK;
     }
     hipLaunchKernelGGL(nce_pass1_kernel, grid1, dim3(256), 0, (hipStream_t)stream, f, m, inv_t, rowsum_part, pos, iic);
-    hipLaunchKernelGGL(nce_pass2_kernel, iic.z != nullptr ? grid1 : grid, dim3(256), 0, (hipStream_t)stream, f, m, inv_t,
+    hipLaunchKernelGGL(nce_pass2_kernel, core2 ? grid1 : grid, dim3(256), 0, (hipStream_t)stream, f, m, inv_t,
                        (const float *)rowsum_part, (const float *)pos, lse, loss_rows, G_part, iic);
     IDL_HIP_TRY(hipGetLastError());
     return IDL_OK;
@@ -327,7 +377,16 @@ int idl_nce_fused_iic(const float *f, int m, float temperature, float *lse, floa
                       float *P0, int C, float lamb, float eps, float w_iic, float *iic_scratch, float *out, void *stream)
 {
     IDL_REQUIRE(P0 && iic_scratch && out && C >= 1 && C <= 48, "nce_fused_iic: n_clusters must be in 1..48 (larger: idl_iic_core)");
-    return nce_launch(f, m, temperature, lse, loss_rows, G_part, workspace, IicJob{P0, C, lamb, eps, w_iic, iic_scratch, out, nullptr}, stream);
+    return nce_launch(f, m, temperature, lse, loss_rows, G_part, workspace, IicJob{P0, C, lamb, eps, w_iic, iic_scratch, out, nullptr, 0}, stream);
+}
+
+// the InfoNCE passes with the IIC JOINT of n_clusters > 48 formed by spare workgroups of pass 1, a 16 x 16 tile each (the core: idl_iic_core / idl_iic_core_dz)
+int idl_nce_fused_joint(const float *f, int m, float temperature, float *lse, float *loss_rows, float *G_part, void *workspace, const float *z, float *P0, int C,
+                        void *stream)
+{
+    IDL_REQUIRE(z && P0 && C >= 1 && C <= 256, "nce_fused_joint: NULL buffer or n_clusters outside 1..256");
+    const int ct = (C + 15) / 16;
+    return nce_launch(f, m, temperature, lse, loss_rows, G_part, workspace, IicJob{P0, C, 0.f, 0.f, 0.f, nullptr, nullptr, z, (ct * ct + NCE_SPLIT - 1) / NCE_SPLIT}, stream);
 }
 
 int idl_iic_joint(const float *z, int m, int C, float *P0, void *stream)
@@ -347,7 +406,7 @@ int idl_nce_pass1_joint(const float *f, int m, float temperature, void *workspac
     float *rowsum_part = (float *)workspace, *pos = rowsum_part + (size_t)NCE_SPLIT * m;
     const dim3 grid1((unsigned)(m / 16 + 1), NCE_SPLIT);
     hipLaunchKernelGGL(nce_pass1_kernel, grid1, dim3(256), 0, (hipStream_t)stream, f, m, 1.f / temperature, rowsum_part, pos,
-                       IicJob{P0, C, 0.f, 0.f, 0.f, nullptr, nullptr, z});
+                       IicJob{P0, C, 0.f, 0.f, 0.f, nullptr, nullptr, z, 0});
     IDL_HIP_TRY(hipGetLastError());
     return IDL_OK;
 }
@@ -356,7 +415,7 @@ int idl_nce_fused_iic_z(const float *f, int m, float temperature, float *lse, fl
                         const float *z, float *P0, int C, float lamb, float eps, float w_iic, float *iic_scratch, float *out, void *stream)
 {
     IDL_REQUIRE(z && P0 && iic_scratch && out && C >= 1 && C <= 48, "nce_fused_iic_z: n_clusters must be in 1..48 (larger: a GEMM + idl_iic_core)");
-    return nce_launch(f, m, temperature, lse, loss_rows, G_part, workspace, IicJob{P0, C, lamb, eps, w_iic, iic_scratch, out, z}, stream);
+    return nce_launch(f, m, temperature, lse, loss_rows, G_part, workspace, IicJob{P0, C, lamb, eps, w_iic, iic_scratch, out, z, 0}, stream);
 }
 
 }  // extern "C"

@@ -446,6 +446,59 @@ __global__ __launch_bounds__(256) void iic_core_shift_kernel(float *P0, int C, f
     iic_core_shift(P0, C, w_iic, out, grad, part, n_part);
 }
 
+// Round 6, the step of n_clusters > 48: what the middle backward needs of the IIC gradient is z dP0 for all rows, and dP0 = w_iic (g - gp) / s is
+// the rows launch's unshifted gradient g moved by the global sum gp -- for a softmax row (its entries add up to 1)
+// so the shift launch and the library GEMM behind it (5.1 + 5.0 us at 200 classes) are ONE launch of 16 x 16 MFMA tiles that takes g - gp as its B operand
+// (rounded exactly as the shift launch rounds it; C <= 256: 64 K-steps).  LossFunctions.py:20-62.
+__global__ __launch_bounds__(256) void iic_dz_kernel(const float *__restrict__ z, int m, int C, const float *__restrict__ grad, const double *__restrict__ part,
+                                                     int n_part, float w_iic, float *__restrict__ dzs, float *__restrict__ out)
+{
+    // a workgroup: 16 rows of z (staged in LDS by coalesced loads, once) x 4 column tiles, a wave each; every B operand of a tile (a column of g: 64-byte
+    // segments) requested before the first product.  g enters as g - gp, rounded as iic_core_shift rounds it.
+    __shared__ float zs[16][260];
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, l = lane & 15, q = lane >> 4;
+    const int ct = (C + 15) / 16, groups = (ct + 3) / 4;
+    const int r0 = ((int)blockIdx.x / groups) * 16, c0 = (((int)blockIdx.x % groups) * 4 + wv) * 16;
+    {
+        float zv[16];                                        // thread t: column t of the block's 16 rows (clamped loads, all in flight)
+        const int cc = tid < C ? tid : C - 1;
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) zv[rr] = z[(int64_t)(r0 + rr < m ? r0 + rr : m - 1) * C + cc];
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) if (tid < C) zs[rr][tid] = r0 + rr < m ? zv[rr] : 0.f;
+    }
+    __shared__ double ps[64];                                // the rows launch's partial sums (2 n_part + 1 <= 51 doubles): one trip, then added up from LDS
+    if (tid < 2 * n_part + 1) ps[tid] = part[tid];
+    const bool okc = c0 + l < C;
+    const float *gb = grad + (okc ? c0 + l : 0);             // B[k = q][j = l] = g[k0 + q][c0 + l] - gp
+    float bv[64];
+#pragma unroll
+    for (int u = 0; u < 64; ++u) {                           // (clamped, not predicated: a load under a branch is waited for before the next is issued)
+        const int k = 4 * u + q;
+        bv[u] = gb[(int64_t)(k < C ? k : C - 1) * C];
+    }
+    __syncthreads();
+    double l1 = 0.0, g1 = 0.0;                               // the gradient's global sum and the joint's total, in iic_core_shift's order
+    for (int i = 0; i < n_part; ++i) { l1 += ps[2 * i]; g1 += ps[2 * i + 1]; }
+    const float gp = (float)g1, s = (float)ps[2 * n_part];
+    if (blockIdx.x == 0 && tid == 0) out[3] = (float)l1;
+    f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 64; u += 2) {                        // A[i = l][k = q] = z[r0 + l][4 u + q] (zero beyond C: the products vanish)
+        const int k0 = 4 * u + q, k1 = k0 + 4;
+        const float a0 = k0 < C ? zs[l][k0] : 0.f, a1 = k1 < C ? zs[l][k1] : 0.f;
+        const float b0 = (k0 < C && okc) ? bv[u] - gp : 0.f, b1 = (k1 < C && okc) ? bv[u + 1] - gp : 0.f;
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc1, 0, 0, 0);
+    }
+    const float sc = w_iic / s;
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {                      // C/D: row = 4 q + reg, column = l
+        const int r = r0 + 4 * q + reg;
+        if (r < m && okc) dzs[(int64_t)r * C + c0 + l] = sc * (acc0[reg] + acc1[reg]);
+    }
+}
+
 template <int NT>
 __global__ __launch_bounds__(NT) void iic_core_kernel(float *P0, int C, float lamb, float eps, float w_iic, float *scratch,
                                                       float *out)
@@ -614,6 +667,7 @@ struct MidBwdArgs {
     // their scale (planes.h: DR1_WORDS), the overflow flag
     uint16_t *dr1h, *dr1l;
     int *dscale, *dover;
+    const float *dzs;         // BIG (n_clusters > 48): z dP0 for all rows ([m, C], one GEMM by the caller) -- row r takes its partner's row; NULL: the product per row, in the kernel
 };
 
 // (tile1 > tile0: the workgroups behind the COL_PARTS computing ones assemble tiles [tile0, tile1) of the NEXT batch into a
@@ -657,6 +711,8 @@ __device__ __forceinline__ void mid_bwd_body(const MidBwdArgs &a, int tile0, int
     if (small) {
         if (!NCE) for (int i = tid; i < C * C; i += 64 * MID_WAVES) sP[i] = a.dP0[i];
         for (int i = tid; i < C * H2; i += 64 * MID_WAVES) sW3[i] = a.W3[i];
+    } else {
+        for (int i = tid; i < C * H2; i += 64 * MID_WAVES) mid_dyn[i] = a.W3[i];      // BIG: W3 (51 KB at 200 classes) in dynamic LDS -- read once per workgroup, not once per row
     }
     // B fragments of this wave's two column tiles.  The wave owns the 32 columns [32 wv, 32 wv + 32) of dr1 and its two tiles take
     // them INTERLEAVED -- tile j, lane l = column 32 wv + 2 l + j -- so that a lane's B values of both tiles are one 8-byte read
@@ -789,8 +845,11 @@ __device__ __forceinline__ void mid_bwd_body(const MidBwdArgs &a, int tile0, int
                 if (c < C) {
                     zc[t] = a.z[(int64_t)row * C + c];
                     float acc = 0.f;
+                    if (a.dzs != nullptr) acc = a.dzs[(int64_t)prow * C + c];
+                    else {
 #pragma unroll 4
-                    for (int k = 0; k < C; ++k) acc = fmaf(shz[wv][k], a.dP0[k * C + c], acc);
+                        for (int k = 0; k < C; ++k) acc = fmaf(shz[wv][k], a.dP0[k * C + c], acc);
+                    }
                     dz[t] = acc;
                     dot += acc * zc[t];
                 }
@@ -807,7 +866,8 @@ __device__ __forceinline__ void mid_bwd_body(const MidBwdArgs &a, int tile0, int
             }
             __builtin_amdgcn_wave_barrier();
             float dr = 0.f;
-            for (int c = 0; c < C; ++c) dr = fmaf(DLG[wv][c], a.W3[(int64_t)c * H2 + lane], dr);
+#pragma unroll 4
+            for (int c = 0; c < C; ++c) dr = fmaf(DLG[wv][c], mid_dyn[c * H2 + lane], dr);
             const float act = a.r2[(int64_t)row * H2 + lane];
             const float dl_cls = act > 0.f ? dr * scale : 0.f;
             const float fr = a.f[(int64_t)row * H2 + lane];
@@ -1388,6 +1448,23 @@ __global__ __launch_bounds__(wgp_dev::NT, 1) __attribute__((amdgpu_num_vgpr(200)
 
 }  // namespace
 
+// the BIG instances (n_clusters > 48) keep W3 in dynamic LDS beside 62 KB of static LDS: the limit is raised once per device
+template <bool DP>
+static int launch_mid_bwd_big(const MidBwdArgs &a, unsigned grid, int t0, int t1, const idl_dev::GatherArgs &g, void *stream)
+{
+    const int lds = a.C * H2 * (int)sizeof(float);
+    static bool attr_set[64] = {};
+    int dev = 0;
+    IDL_HIP_TRY(hipGetDevice(&dev));
+    if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+        IDL_HIP_TRY(hipFuncSetAttribute((const void *)mid_bwd_kernel<false, true, DP>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * MAX_CPL * H2 * (int)sizeof(float)));
+        attr_set[dev] = true;
+    }
+    hipLaunchKernelGGL((mid_bwd_kernel<false, true, DP>), dim3(grid), dim3(64 * MID_WAVES), lds, (hipStream_t)stream, a, t0, t1, g);
+    IDL_HIP_TRY(hipGetLastError());
+    return IDL_OK;
+}
+
 extern "C" {
 
 int idl_relu_dropout_fwd(float *a, int64_t n, int train, uint64_t seed, const int64_t *ctl, int layer, void *stream)
@@ -1532,6 +1609,30 @@ int idl_iic_core(float *P0, int C, float lamb, float eps, float w_iic, float *sc
     return IDL_OK;
 }
 
+// idl_iic_core for 48 < n_clusters <= 200 WITHOUT its second launch, and z dP0 instead: dzs[r][c] = sum_k z[r][k] dP0[k][c] for all m rows (what
+// idl_mid_bwd_gather_planes takes as z_dP0); P0 keeps the joint, out[3] the IIC loss.  scratch as idl_iic_core's.
+int idl_iic_core_dz(const float *P0, int C, float lamb, float eps, float w_iic, float *scratch, float *out, const float *z, int m, float *dzs, void *stream)
+{
+    IDL_REQUIRE(P0 && scratch && out && z && dzs && C > 48 && C <= 200 && m >= 1, "iic_core_dz: NULL buffer, or n_clusters outside 49..200");
+    IDL_REQUIRE((((uintptr_t)scratch) & 15u) == 0, "iic_core_dz: scratch must be 16-byte aligned");
+    const int lds = C * (C | 1) * 4;
+    static bool attr_set[64] = {};
+    int dev = 0;
+    IDL_HIP_TRY(hipGetDevice(&dev));
+    if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+        IDL_HIP_TRY(hipFuncSetAttribute((const void *)iic_core_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 200 * 201 * 4));
+        attr_set[dev] = true;
+    }
+    const int G = (C + IIC_RPW - 1) / IIC_RPW;
+    double *part = (double *)(scratch + ((C * C + 3) & ~3));
+    hipLaunchKernelGGL(iic_core_rows_kernel, dim3(G), dim3(1024), lds, (hipStream_t)stream, P0, C, lamb, eps, scratch, part);
+    const int groups = ((C + 15) / 16 + 3) / 4;              // (a workgroup: 16 rows x 4 column tiles)
+    hipLaunchKernelGGL(iic_dz_kernel, dim3((unsigned)(((m + 15) / 16) * groups)), dim3(256), 0, (hipStream_t)stream, z, m, C, (const float *)scratch, (const double *)part, G, w_iic,
+                       dzs, out);
+    IDL_HIP_TRY(hipGetLastError());
+    return IDL_OK;
+}
+
 int idl_head_bwd(const float *z, const float *r2, const float *f, const float *inv, const float *G, int g_parts, const float *dP0,
                  const float *W3, int m, int C, int train, float nce_coef, float *dlogits, float *dlat, void *stream)
 {
@@ -1571,7 +1672,7 @@ int idl_mid_bwd(const float *z, const float *r2, const float *f, const float *in
     a.dW3_part = dW3_partial; a.ctl = ctl; a.batch_advance = batch_advance;
     a.g_parts = g_parts; a.m = m; a.C = C; a.train = train; a.nce_coef = nce_coef;
     if (C <= 48) hipLaunchKernelGGL((mid_bwd_kernel<false, false>), dim3(COL_PARTS), dim3(64 * MID_WAVES), 0, (hipStream_t)stream, a, 0, 0, idl_dev::GatherArgs{});
-    else hipLaunchKernelGGL((mid_bwd_kernel<false, true>), dim3(COL_PARTS), dim3(64 * MID_WAVES), 0, (hipStream_t)stream, a, 0, 0, idl_dev::GatherArgs{});
+    else return launch_mid_bwd_big<false>(a, COL_PARTS, 0, 0, idl_dev::GatherArgs{}, stream);
     IDL_HIP_TRY(hipGetLastError());
     return IDL_OK;
 }
@@ -1627,10 +1728,11 @@ static int mid_bwd_gather_impl(const float *z, const float *r2, const float *f, 
                        const float *feats, int64_t n, int64_t fdim, int64_t view_stride, const int64_t *pair_idx, const int64_t *base,
                        int64_t base_add, int64_t n_pairs, int64_t batch, const double *mean, const double *scale,
                        const double *inv_scale, float *y, int part, int part_end, int parts, int act1_transposed, void *stream,
-                       uint16_t *yh, uint16_t *yl, int *over = nullptr, uint16_t *dr1h = nullptr, uint16_t *dr1l = nullptr, int *dscale = nullptr)
+                       uint16_t *yh, uint16_t *yl, int *over = nullptr, uint16_t *dr1h = nullptr, uint16_t *dr1l = nullptr, int *dscale = nullptr,
+                       const float *dzs = nullptr)
 {
-    IDL_REQUIRE((dr1h != nullptr) == (dr1l != nullptr) && (dr1h == nullptr || (dscale && over && C <= 48 && ((((uintptr_t)dr1h) | ((uintptr_t)dr1l)) & 15u) == 0)),
-                "mid_bwd_gather: dr1's planes need both planes (16-byte aligned), the words of their scale, the flag and n_clusters <= 48");
+    IDL_REQUIRE((dr1h != nullptr) == (dr1l != nullptr) && (dr1h == nullptr || (dscale && over && ((((uintptr_t)dr1h) | ((uintptr_t)dr1l)) & 15u) == 0)),
+                "mid_bwd_gather: dr1's planes need both planes (16-byte aligned), the words of their scale and the flag");
     IDL_REQUIRE((yh != nullptr) == (yl != nullptr) && (yh == nullptr || (feats != nullptr && ((((uintptr_t)yh) | ((uintptr_t)yl)) & 7u) == 0)),
                 "mid_bwd_gather: both planes of the next batch (8-byte aligned) or neither; planes need the batch assembly");
     IDL_REQUIRE(parts >= 1 && part >= 0 && part <= part_end && part_end <= parts, "mid_bwd_gather: need 0 <= part <= part_end <= parts");
@@ -1639,7 +1741,8 @@ static int mid_bwd_gather_impl(const float *z, const float *r2, const float *f, 
     IDL_REQUIRE(m >= 2 && (m % 2) == 0 && C >= 1 && C <= 64 * MAX_CPL, "mid_bwd: even m, n_clusters in 1..256");
     IDL_REQUIRE(dW3_partial == nullptr || C <= 48, "mid_bwd: dW3 partials need n_clusters <= 48");
     MidBwdArgs a{};
-    a.dr1h = dr1h; a.dr1l = dr1l; a.dscale = dscale; a.dover = over;
+    a.dr1h = dr1h; a.dr1l = dr1l; a.dscale = dscale; a.dover = over; a.dzs = dzs;
+    IDL_REQUIRE(dzs == nullptr || C > 48, "mid_bwd_gather: z dP0 as an input is the n_clusters > 48 form");
     a.z = z; a.r2 = r2; a.f = f; a.inv = inv; a.G = G; a.dP0 = dP0; a.W3 = W3; a.W2 = W2; a.act1 = act1;
     a.dlogits = dlogits; a.dlat = dlat; a.dr1 = dr1; a.partial1 = partial1; a.partial2 = partial2; a.partial3 = partial3;
     a.dW3_part = dW3_partial; a.ctl = nullptr; a.batch_advance = 0;
@@ -1662,12 +1765,12 @@ static int mid_bwd_gather_impl(const float *z, const float *r2, const float *f, 
         memcpy((unsigned char *)plan + idl::PLAN_PARAMS, &p, sizeof(p));
         return IDL_OK;
     }
+    if (C > 48) return dr1h != nullptr ? launch_mid_bwd_big<true>(a, (unsigned)(COL_PARTS + (t1 - t0 + 3) / 4), (int)t0, (int)t1, g, stream)
+                                       : launch_mid_bwd_big<false>(a, (unsigned)(COL_PARTS + (t1 - t0 + 3) / 4), (int)t0, (int)t1, g, stream);
     if (dr1h != nullptr) hipLaunchKernelGGL((mid_bwd_kernel<false, false, true>), dim3((unsigned)(COL_PARTS + (t1 - t0 + 3) / 4)), dim3(64 * MID_WAVES), 0, (hipStream_t)stream,
                                             a, (int)t0, (int)t1, g);
     else if (C <= 48) hipLaunchKernelGGL((mid_bwd_kernel<false, false>), dim3((unsigned)(COL_PARTS + (t1 - t0 + 3) / 4)), dim3(64 * MID_WAVES), 0, (hipStream_t)stream, a, (int)t0,
                                     (int)t1, g);
-    else hipLaunchKernelGGL((mid_bwd_kernel<false, true>), dim3((unsigned)(COL_PARTS + (t1 - t0 + 3) / 4)), dim3(64 * MID_WAVES), 0, (hipStream_t)stream, a, (int)t0,
-                            (int)t1, g);
     IDL_HIP_TRY(hipGetLastError());
     return IDL_OK;
 }
@@ -1691,12 +1794,12 @@ int idl_mid_bwd_gather_planes(const float *z, const float *r2, const float *f, c
                               const float *feats, int64_t n, int64_t fdim, int64_t view_stride, const int64_t *pair_idx, const int64_t *base,
                               int64_t base_add, int64_t n_pairs, int64_t batch, const double *mean, const double *scale,
                               const double *inv_scale, float *y, void *y_hi, void *y_lo, int *overflow_flag, int part, int part_end, int parts,
-                              int act1_transposed, void *dr1_hi, void *dr1_lo, int *dr1_scale, void *stream)
+                              int act1_transposed, void *dr1_hi, void *dr1_lo, int *dr1_scale, const float *z_dP0, void *stream)
 {
     return mid_bwd_gather_impl(z, r2, f, inv, G, g_parts, dP0, W3, W2, act1, m, C, train, nce_coef, dlogits, dlat, dr1, partial1, partial2, partial3,
                                dW3_partial, feats, n, fdim, view_stride, pair_idx, base, base_add, n_pairs, batch, mean, scale, inv_scale, y, part,
                                part_end, parts, act1_transposed, stream, (uint16_t *)y_hi, (uint16_t *)y_lo, overflow_flag, (uint16_t *)dr1_hi,
-                               (uint16_t *)dr1_lo, dr1_scale);
+                               (uint16_t *)dr1_lo, dr1_scale, z_dP0);
 }
 
 int idl_col_sum_parts(void) { return COL_PARTS; }

@@ -91,7 +91,7 @@ class _Buffers:
         self.P0 = torch.empty((C, C), **f32)
         self.iic_scratch = torch.empty((C * C + 2 * C,), **f32)
         self.dlogits = torch.empty((m, C), **f32)
-        self.dzs = torch.empty((m, C), **f32) if C > 64 else None       # z dP0 (fine-grained mode)
+        self.dzs = torch.empty((m, C), **f32) if C > 48 else None       # z dP0 (fine-grained mode)
         self.dlat = torch.empty((m, H2), **f32)
         self.dr1 = sh['dr1'] if 'dr1' in sh else torch.empty((m, H1), **f32)
 
@@ -437,13 +437,12 @@ class FusedLinearTrainer:
                     _p(st.mean), _p(st.scale), _p(st.inv_scale), _p(bf.xs[1 - xi]), g1, g2, 8, _stream())
         elif plf:   # (the bias of Linear(F,512) is added here; the whole next batch assembled as planes only)
             st = next_from
+            # (round 6: the fused middle-backward of this mode carries the other half of the next batch's assembly, as at n_clusters <= 48)
             chk(_L.idl_mid_fwd_gather_planes(_p(r1), _p(self.b1), 0, _p(self.W2), _p(self.b2), _p(self.W3), _p(self.b3),
                                              m, C, tr, self.seed, _p(self.ctl), _p(bf.f), _p(bf.inv), _p(bf.r2), _p(bf.z),
                                              _p(st.feats), st.n, st.f, st.n * st.f, _p(self._perm), _p(self.ctl[1:]), m // 2, st.n_pairs, m // 2,
                                              _p(st.mean), _p(st.scale), _p(st.inv_scale), None, _p(pb["xh"][1 - xi]), _p(pb["xl"][1 - xi]),
-                                             _p(self._w1_planes[2]), 0, 8, 8, _stream()))
-            pb["valid"][1 - xi] = True
-            pb["x32"][1 - xi] = False
+                                             _p(self._w1_planes[2]), 0, self._gsplit, 8, _stream()))
         elif early_f:
             st = next_from
             chk(_L.idl_mid_fwd_gather(_p(r1), None, 0, _p(self.W2), _p(self.b2), _p(self.W3), _p(self.b3),
@@ -472,11 +471,19 @@ class FusedLinearTrainer:
             torch.mm(bf.z[:m // 2].t(), bf.z[m // 2:], out=bf.P0)            # IIC joint, one [C,B]x[B,C] GEMM
             chk(_L.idl_nce_fused_iic(_p(bf.f), m, TEMPERATURE, _p(bf.lse), _p(bf.loss_rows), _p(bf.G), _p(bf.nce_ws),
                                      _p(bf.P0), C, self.lamb, EPS, self.weight, _p(bf.iic_scratch), _p(self.out), _stream()))
+        elif plf and bf.nce_fused and 48 < C <= 200:
+            # n_clusters > 48, round 6: the joint's 16 x 16 tiles ride in InfoNCE pass 1 as spare workgroups; then the IIC core's first launch and z dP0
+            # with the gradient's shift in its epilogue (no shift launch, no library GEMM)
+            chk(_L.idl_nce_fused_joint(_p(bf.f), m, TEMPERATURE, _p(bf.lse), _p(bf.loss_rows), _p(bf.G), _p(bf.nce_ws), _p(bf.z), _p(bf.P0), C, _stream()))
+            chk(_L.idl_iic_core_dz(_p(bf.P0), C, self.lamb, EPS, self.weight, _p(bf.iic_scratch), _p(self.out), _p(bf.z), m, _p(bf.dzs), _stream()))
         else:
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 chk(_L.idl_iic_joint(_p(bf.z), m, C, _p(bf.P0), _stream()))       # (a library GEMM here: 118 us untuned at C = 200)
-                chk(_L.idl_iic_core(_p(bf.P0), C, self.lamb, EPS, self.weight, _p(bf.iic_scratch), _p(self.out), _stream()))
+                if plf and 48 < C <= 200:    # the core's first launch, then z dP0 with the gradient's shift in its epilogue (no shift launch, no library GEMM)
+                    chk(_L.idl_iic_core_dz(_p(bf.P0), C, self.lamb, EPS, self.weight, _p(bf.iic_scratch), _p(self.out), _p(bf.z), m, _p(bf.dzs), _stream()))
+                else:
+                    chk(_L.idl_iic_core(_p(bf.P0), C, self.lamb, EPS, self.weight, _p(bf.iic_scratch), _p(self.out), _stream()))
             if bf.nce_fused:       # S = f f^T, lse, E + E^T and (E + E^T) f in two MFMA kernels, S never written
                 chk(_L.idl_nce_fused(_p(bf.f), m, TEMPERATURE, _p(bf.lse), _p(bf.loss_rows), _p(bf.G), _p(bf.nce_ws), _stream()))
             else:
@@ -525,6 +532,23 @@ class FusedLinearTrainer:
                 torch.mm(bf.dlogits.t(), bf.r2, out=gW3)
             if not self._dw2_inlaunch:
                 torch.mm(bf.dlat.t(), r1, out=gW2)
+        elif plf:
+            # n_clusters > 48 (the CLI's default mode: 200 output units), round 6: z dP0 for all rows as one GEMM, then ONE launch for the rest of the
+            # middle backward -- softmax / Linear(64,C) / normalise backward per row with W3 in LDS, dr1 = dlat W2 on MFMA tiles masked by the layer-1
+            # ReLU / Dropout and written as two fp16 planes for the dW1 tiles, every bias gradient as stacked partial sums, the second half of the
+            # next batch assembled by spare workgroups -- in place of idl_head_bwd_dz + a library GEMM + idl_bias_grads (11.8 + 9.0 + 4.9 us)
+            st = next_from
+            if not 48 < C <= 200:
+                torch.mm(bf.z, bf.P0, out=bf.dzs)
+            dplf = m % 64 == 0
+            chk(_L.idl_mid_bwd_gather_planes(_p(bf.z), _p(bf.r2), _p(bf.f), _p(bf.inv), _p(bf.G), bf.G.shape[0], _p(bf.P0), _p(self.W3), _p(self.W2),
+                                             _p(r1), m, C, tr, nce_coef, _p(bf.dlogits), _p(bf.dlat), _p(bf.dr1), _p(gb1), _p(gb2), _p(gb3), None,
+                                             _p(st.feats), st.n, st.f, st.n * st.f, _p(self._perm), _p(self.ctl[1:]), m // 2, st.n_pairs, m // 2,
+                                             _p(st.mean), _p(st.scale), _p(st.inv_scale), None, _p(pb["xh"][1 - xi]), _p(pb["xl"][1 - xi]),
+                                             _p(self._w1_planes[2]), self._gsplit, 8, 8, 0, *self._dr1_planes_args(pb, dplf, bf.dzs), _stream()))
+            pb["valid"][1 - xi] = True
+            pb["x32"][1 - xi] = False
+            chk(_L.idl_at_b(_p(bf.dlogits), C, _p(bf.r2), self.H2, m, C, self.H2, _p(gW3), self.H2, _stream()))      # dW3 = dlogits^T r2 (the library's kernel: 9 us)
         elif self._mid_fused and C <= 48:     # (at n_clusters = 200 the per-row C x C products want all 256 CUs: separate kernels)
             # ---- head backward + dr1 = dlat W2 (MFMA) + ReLU/Dropout backward + every bias gradient (+ dW3) in one launch
             chk(_L.idl_mid_bwd(_p(bf.z), _p(bf.r2), _p(bf.f), _p(bf.inv), _p(bf.G), bf.G.shape[0], _p(bf.P0), _p(self.W3), _p(self.W2),
@@ -595,8 +619,8 @@ class FusedLinearTrainer:
             wg = (2, _p(bf.dlat), _p(r1), 0, m, self.H2, self.H1, _p(gW2), m // 2, _stream())
             if self._cold:
                 self._evict()
-            chk(_L.idl_wgrad_xplanes_rms(_p(bf.dr1), None, None, None, _p(pb["xh"][xi]), _p(pb["xl"][xi]), self.F, m, self.H1, self.F,
-                                         _p(gW1) if self._keep_w1_grad else None, _p(self.W1), _p(self.square_avg[0]),
+            chk(_L.idl_wgrad_xplanes_rms(_p(bf.dr1), *self._dy_planes_args(pb, pb.get("dr1_as_planes", False)), _p(pb["xh"][xi]), _p(pb["xl"][xi]), self.F, m,
+                                         self.H1, self.F, _p(gW1) if self._keep_w1_grad else None, _p(self.W1), _p(self.square_avg[0]),
                                          _p(self._split_state), _p(self._ctl_snap), _p(wh), _p(wl), _p(flag), *tail, 0, *wg))
             return
         w1_fusable = self._wgrad_fused and bool(_L.idl_wgrad_supported(m, self.H1, self.F))
@@ -681,10 +705,11 @@ class FusedLinearTrainer:
         self._k(_L.idl_wgrad_xplanes_rms, _p(bf.dr1), *self._dy_planes_args(pb, dpl), _p(pb["xh"][xi]), _p(pb["xl"][xi]), self.F, m, self.H1, self.F, None, _p(self.W1),
                 _p(self.square_avg[0]), _p(self._split_state), _p(self._ctl_snap), _p(wh), _p(wl), _p(flag), *tail, 0, *wg)
 
-    def _dr1_planes_args(self, pb, on):
-        """idl_mid_bwd_gather_planes' last arguments: where dr1's planes, their scale's history, the launch number and the exponent live."""
+    def _dr1_planes_args(self, pb, on, dzs=None):
+        """idl_mid_bwd_gather_planes' last arguments: dr1's planes and the words of their scale (or none of them: dr1 in fp32), and z dP0 as an
+        input (the step of n_clusters > 48)."""
         pb["dr1_as_planes"] = bool(on)
-        return (_p(pb["dh"]), _p(pb["dl"]), _p(self._dr1_scale)) if on else (None, None, None)
+        return ((_p(pb["dh"]), _p(pb["dl"]), _p(self._dr1_scale)) if on else (None, None, None)) + (_p(dzs),)
 
     def dr1_of(self, bf):
         """dr1 of the last step on these buffers as an fp32 tensor (tests): the step's own tensor, or -- where mid_bwd wrote it as planes only --

@@ -1166,6 +1166,47 @@ def test_train_voters_batched_on_other_shapes(dev, kw):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("m,C", [(1024, 200), (256, 64), (128, 49), (96, 130)])
+def test_iic_core_dz_equals_the_core_and_the_product(dev, m, C):
+    """idl_iic_core_dz (round 6; the step of n_clusters > 48): the IIC loss of idl_iic_core, and z dP0 for all rows with dP0 the gradient that
+    launch pair leaves in P0 -- the shift by the gradient's global sum folded into the product's epilogue (a softmax row sums to 1)."""
+    import torch
+    from idelucs_amd import _lib
+    from idelucs_amd.fused import _p, _stream
+    L = _lib.lib
+    g = torch.Generator(device="cpu"); g.manual_seed(C + m)
+    z = torch.softmax(torch.randn(m, C, generator=g) * 2.0, 1).to(dev)
+    P0 = (z[:m // 2].t() @ z[m // 2:]).contiguous()
+    scratch = torch.zeros(C * C + 2 * C + 8, device=dev); out_a = torch.zeros(4, device=dev); out_b = torch.zeros(4, device=dev)
+    dP0 = P0.clone()
+    _lib.check(L.idl_iic_core(_p(dP0), C, 2.8, 2.2e-16, 0.25, _p(scratch), _p(out_a), _stream()))
+    want = z.double() @ dP0.double()
+    dzs = torch.full((m, C), float("nan"), device=dev)
+    P0b = P0.clone()
+    _lib.check(L.idl_iic_core_dz(_p(P0b), C, 2.8, 2.2e-16, 0.25, _p(scratch), _p(out_b), _p(z), m, _p(dzs), _stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(P0b, P0) and out_a[3].item() == out_b[3].item()
+    assert ((dzs.double() - want).abs().max() / want.abs().max()).item() < 2e-6
+    assert L.idl_iic_core_dz(_p(P0b), 40, 2.8, 2.2e-16, 0.25, _p(scratch), _p(out_b), _p(z), m, _p(dzs), _stream()) != 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K,M,N", [(1024, 200, 64), (300, 17, 70), (4, 1, 1), (1000, 256, 64)])
+def test_at_b_equals_the_product(dev, K, M, N):
+    """idl_at_b: out = A^T B (dW3 = dlogits^T r2 of the n_clusters > 48 step) against the float64 product."""
+    import torch
+    from idelucs_amd import _lib
+    from idelucs_amd.fused import _p, _stream
+    g = torch.Generator(device="cpu"); g.manual_seed(K + M)
+    A = torch.randn(K, M + 3, generator=g).to(dev); B = torch.randn(K, N, generator=g).to(dev)
+    out = torch.full((M, N + 2), 7.0, device=dev)
+    _lib.check(_lib.lib.idl_at_b(_p(A), M + 3, _p(B), N, K, M, N, _p(out), N + 2, _stream()))
+    torch.cuda.synchronize()
+    want = A[:, :M].double().t() @ B.double()
+    assert ((out[:, :N].double() - want).abs().max() / want.abs().max()).item() < 2e-6 and bool((out[:, N:] == 7.0).all())
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("m,C", [(1024, 200), (1024, 37), (96, 5), (1000, 64)])
 def test_iic_joint_kernel_equals_the_product(m, C):
     """idl_iic_joint: P0 = z[0:m/2]^T z[m/2:m] (reference LossFunctions.py:57-58) on one wave per 16 x 16 MFMA tile, for any
@@ -1180,6 +1221,25 @@ def test_iic_joint_kernel_equals_the_product(m, C):
                                       ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
     want = (z[:m // 2].double().t() @ z[m // 2:].double())
     assert torch.allclose(P0.double(), want, rtol=1e-5, atol=1e-7)
+    # ... and the same joint formed by spare workgroups of InfoNCE pass 1 (idl_nce_fused_joint: the step of n_clusters > 48, round 6), the InfoNCE
+    # results being those of idl_nce_fused
+    if m % 32 == 0 and _lib.lib.idl_nce_fused_workspace(m) > 0:
+        from idelucs_amd.fused import _p, _stream
+        L = _lib.lib
+        f = torch.nn.functional.normalize(torch.randn(m, 64, generator=g), dim=1).cuda()
+        ws = torch.empty(int(L.idl_nce_fused_workspace(m)) // 4, device="cuda")
+        outs = []
+        for joint in (False, True):
+            lse = torch.empty(m, device="cuda"); rows = torch.empty(m, device="cuda"); G = torch.empty(int(L.idl_nce_fused_parts()), m, 64, device="cuda")
+            P1 = torch.full((C, C), -1.0, device="cuda")
+            if joint:
+                _lib.check(L.idl_nce_fused_joint(_p(f), m, 0.85, _p(lse), _p(rows), _p(G), _p(ws), _p(z), _p(P1), C, _stream()))
+            else:
+                _lib.check(L.idl_nce_fused(_p(f), m, 0.85, _p(lse), _p(rows), _p(G), _p(ws), _stream()))
+            torch.cuda.synchronize()
+            outs.append((lse, rows, G, P1))
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
+        assert torch.allclose(outs[1][3].double(), want, rtol=1e-5, atol=1e-7) and bool((outs[0][3] == -1.0).all())
 
 
 @pytest.mark.parametrize("n,use_graph", [(1500, False), (4200, True)])
@@ -1225,8 +1285,8 @@ def test_tail_riding_in_the_layer1_launch_changes_no_bit(dev, monkeypatch, n, us
     assert tr._pending is None and tr.ctl.tolist() == [1, B] and all(not torch.equal(a, b) for a, b in zip(before, tr.params))
 
 
-@pytest.mark.parametrize("planes", ["1", "0"])
-def test_default_step_contains_no_library_gemm(dev, monkeypatch, planes):
+@pytest.mark.parametrize("planes,C", [("1", 20), ("0", 20), ("1", 200)])
+def test_default_step_contains_no_library_gemm(dev, monkeypatch, planes, C):
     """Round 5: the speed of the step's largest forward kernel must not depend on a hipBLASLt build, a TunableOp
     seed file or its validators.  The default step's launches, by kernel name (torch.profiler): the layer-1 product is
     l1_planes_kernel (+ reduce_rms_kernel) / wgrad_dplanes_rms_kernel in the two-plane form, l1_fwd_kernel / l1_rms_kernel / wgrad_q16_kernel
@@ -1239,7 +1299,7 @@ def test_default_step_contains_no_library_gemm(dev, monkeypatch, planes):
     from idelucs_amd.fused import FusedLinearTrainer
     monkeypatch.setenv("IDELUCS_TUNABLEOP_SEED", "0")
     monkeypatch.setenv("IDELUCS_PLANES", planes)                        # the default (two-plane products) and the fp32 tiles
-    store, net0 = _cfg2_store_and_net(dev, 1100, seed=8, C=20)          # 6 full batches + a partial one
+    store, net0 = _cfg2_store_and_net(dev, 1100, seed=8, C=C)           # 6 full batches + a partial one
     B = 512
     tr = FusedLinearTrainer(copy.deepcopy(net0), lr=1e-3, weight=0.25, lamb=2.8, seed=3)
     gen = torch.Generator(device=dev); gen.manual_seed(1)
@@ -1257,7 +1317,11 @@ def test_default_step_contains_no_library_gemm(dev, monkeypatch, planes):
     names = [e.name for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA]
     if not names:
         pytest.skip("the profiler reported no device kernels on this box")
-    if planes == "1":
+    if C > 48:      # (round 6) the step of the CLI's default mode -- 200 output units -- too: the middle backward in one launch, z dP0 and dW3 on own tiles
+        assert any("l1_planes_kernel" in n for n in names) and any("wgrad_dplanes_rms" in n for n in names), sorted(set(names))
+        assert any("mid_bwd_kernel<false, true, true>" in n or "mid_bwd_kernelILb0ELb1ELb1E" in n for n in names), sorted(set(names))
+        assert any("iic_dz_kernel" in n for n in names) and any("at_b_kernel" in n for n in names) and not any("iic_joint_kernel" in n for n in names)
+    elif planes == "1":
         assert any("l1_planes_kernel" in n for n in names) and any("reduce_rms_kernel" in n for n in names), sorted(set(names))
         assert any("wgrad_dplanes_rms" in n for n in names)     # (the tiles with both operands as planes + the step's optimizer tail on their loader waves)
         assert any("mid_bwd_kernel<false, false, true>" in n or "mid_bwd_kernelILb0ELb0ELb1E" in n for n in names), sorted(set(names))      # (... dr1 written as planes)

@@ -171,7 +171,7 @@ def test_producers_write_the_planes_of_what_they_write(dev):
     _lib.check(L.idl_mid_bwd_gather_planes(_p(z), _p(r2), _p(f), _p(inv), _p(G), 1, _p(dP0), _p(W3), _p(W2), _p(a1), mm, C, 1, 1e-3, _p(dlg), _p(dlat),
                                            _p(dr1), _p(p1), _p(p2), _p(p3), _p(pw3),
                                            _p(feats), n, F, n * F, _p(perm), _p(base), 0, 2 * n, B, _p(mean), _p(scale), _p(inv_scale),
-                                           _p(y), _p(yh), _p(yl), None, 3, 8, 8, 1, None, None, None, None, None, _stream()))
+                                           _p(y), _p(yh), _p(yl), None, 3, 8, 8, 1, None, None, None, None, _stream()))
     torch.cuda.synchronize()
     assert torch.equal(y, want) and xflag.item() == 0
     hi, lo, _, _ = _split(y, 0)
@@ -185,7 +185,7 @@ def test_producers_write_the_planes_of_what_they_write(dev):
 
     def bwd(G_, dP0_, planes):
         out = None if planes else torch.empty(mm, 512, device=dev)
-        tail = (_p(dh), _p(dl), _p(sc)) if planes else (None, None, None)
+        tail = (_p(dh), _p(dl), _p(sc), None) if planes else (None, None, None, None)
         _lib.check(L.idl_mid_bwd_gather_planes(_p(z), _p(r2), _p(f), _p(inv), _p(G_), 1, _p(dP0_), _p(W3), _p(W2), _p(a1), mm, C, 1, 1e-3, _p(dlg), _p(dlat),
                                                _p(out), _p(p1), _p(p2), _p(p3), _p(pw3), None, 0, 0, 0, None, None, 0, 0, 0, None, None, None,
                                                None, None, None, _p(dflag), 0, 0, 1, 1, *tail, _stream()))
@@ -474,7 +474,9 @@ def test_step_on_planes_with_200_output_units(dev, monkeypatch):
     assert abs(l1 - l0) <= 2e-6 * abs(l0), (l0, l1)
     assert ((g1 - g0).abs().max() / g0.abs().max()).item() < 1e-3 and ((g1 - g0).abs().mean() / g0.abs().max()).item() < 2e-6
     # (the step losses of this mode change sign inside an epoch and their sum nearly cancels: the bound is per step, on losses of ~0.3)
-    for a_, b_, tol in zip(sums["0"], sums["1"], (1e-4, 1e-3)):
+    # (round 6: the two forms also differ in the order the IIC joint's 512-row sums are formed -- its tiles ride in InfoNCE pass 1 in the plane form --,
+    #  a rounding the epoch amplifies like any other: 1.5e-4 a step measured in the first epoch)
+    for a_, b_, tol in zip(sums["0"], sums["1"], (3e-4, 1e-3)):
         assert np.isfinite(b_) and abs(b_ - a_) <= tol * nb, (sums,)
 
 

@@ -328,11 +328,33 @@ def k_sweep(din, args, dev, ks=(4, 5), reps=6):
         #  comparison with k = 6, and `bound` says what actually holds the kernel)
         atomics = (args.len - k + 1) + 2 * 0.015 * args.len * k * (P - 1)          # the count + an (old bin, new bin) pair per edit and window of every mimic view
         lds_floor_ms = din.n * atomics / (256 * 16 * 2.4e9) * 1e3                     # 16 a clock and CU: the instruction's issue rate
-        out[str(k)] = {"kernel": "vectorise3_kernel<%d>" % k, "bound": "lds", "ms_per_launch": ms, "ms_min": min(ts),
+        del feats
+        #  the WHOLE path at this k -- sites + vectorise + scaler fit + one epoch of the same NetLinear(4^k -> 512 -> 64 -> C) on the same
+        # 100 000 x 10 kbp: cfg4's shapes get a throughput figure, not only a vectorise stage.  At k = 5 (F = 1024) the step takes the two-plane
+        # products; at k = 4 (F = 256: cluster.py's default k) no plane kernel applies (F >= 1024) and the step is its latency-bound launches
+        import copy
+        a = copy.copy(args)
+        a.k, a.voters, a.exchange = k, 1, False
+        hp = HotPath(din, a, dev, 0, 1)
+        hp.step(seed=5000)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(2):
+            hp.step(seed=5001 + i)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 2
+        v = hp.validate()
+        whole = {"value": din.n / dt, "unit": "sequences/sec", "ms_per_pass": 1e3 * dt, "epoch_ms": hp.mean_ms("epoch", 1),
+                 "stage_ms": {kk: hp.mean_ms(kk, 1) for kk in ("edits", "vectorise", "stats", "epoch")},
+                 "step_form": "two-plane products" if getattr(hp.model._fused, "_planes", False) and F >= 1024 and F % 512 == 0 else "fp32 tiles / library GEMMs (F < 1024)",
+                 "epoch_loss_last_step": v.get("epoch_loss_last_step")}
+        del hp
+        torch.cuda.empty_cache()
+        feats = None
+        out[str(k)] = {"kernel": "vectorise3_kernel<%d>" % k, "bound": "lds", "ms_per_launch": ms, "ms_min": min(ts), "whole_path": whole,
                        "bytes_per_seq_algorithmic": b_vec, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                        "lds_atomics_per_seq": int(atomics), "lds_issue_floor_ms": lds_floor_ms, "frac_of_lds_issue_floor": lds_floor_ms / ms,
                        "sequences_per_sec_stage": din.n / (ms * 1e-3), "rows_checked": int(rows.numel())}
-        del feats
     return out
 
 

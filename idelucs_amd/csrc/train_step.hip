@@ -795,14 +795,21 @@ __device__ __forceinline__ void mid_bwd_body(const MidBwdArgs &a, int tile0, int
             // every global read of the row first, then arithmetic on registers and LDS only
             const int row = t0 + wv;
             const int prow = row < B ? row + B : row - B;
+            // (clamped, not predicated: the compiler puts a load under a condition into a branch of its own and drains every load in flight in
+            //  front of it -- two extra trips to memory at the head of this launch's longest chain)
             const bool cl = lane < C;
-            const float zp = cl ? a.z[(int64_t)prow * C + lane] : 0.f;
-            const float zc = cl ? a.z[(int64_t)row * C + lane] : 0.f;
+            const int lc = cl ? lane : 0;
+            const float zp_ = a.z[(int64_t)prow * C + lc], zc_ = a.z[(int64_t)row * C + lc];
             const float act = a.r2[(int64_t)row * H2 + lane];
             const float fr = a.f[(int64_t)row * H2 + lane], fp = a.f[(int64_t)prow * H2 + lane];
             float gp[8];                       // the first 8 partial products (idl_nce_fused_parts() = 8) are requested up front
+            if constexpr (!NCE) {
 #pragma unroll
-            for (int pp = 0; pp < 8; ++pp) gp[pp] = (!NCE && pp < a.g_parts) ? a.G[((int64_t)pp * m + row) * H2 + lane] : 0.f;
+                for (int pp = 0; pp < 8; ++pp) gp[pp] = a.G[((int64_t)(pp < a.g_parts ? pp : 0) * m + row) * H2 + lane];
+            }
+#pragma unroll
+            for (int pp = 0; pp < 8; ++pp) gp[pp] = (!NCE && pp < a.g_parts) ? gp[pp] : 0.f;
+            const float zp = cl ? zp_ : 0.f, zc = cl ? zc_ : 0.f;
             const float invr = a.inv[row];
             shz[wv][lane] = zp;
             __builtin_amdgcn_wave_barrier();

@@ -406,8 +406,8 @@ def plane_kernel_leg(dev, m, H, F, n=20, reps=5):
         V = torch.zeros_like(W); flag = torch.zeros(1, dtype=torch.int32, device=dev)
         hyper = torch.tensor([1e-3, 0.99, 1e-8, 0.01, 0.01], dtype=torch.float32, device=dev)
         fns = {"l1_planes_kernel": lambda: _lib.check(L.idl_l1_planes(p(wh), p(wl), F, p(xh), p(xl), F, m, H, F, p(part), st)),
-               "wgrad_dplanes_kernel": lambda: _lib.check(L.idl_wgrad_rmsprop_xplanes(None, p(dyh), p(dyl), p(sc), p(xh), p(xl), F, m, H, F, None, p(W), p(V), p(hyper),
-                                                                                       None, None, p(wh), p(wl), p(flag), st))}
+               "wgrad_dplanes_kernel": lambda: _lib.check(L.idl_wgrad_rmsprop_xplanes(p(dyh), p(dyl), p(sc), p(xh), p(xl), F, m, H, F, None, p(W), p(V), p(hyper),
+                                                                                       p(wh), p(wl), p(flag), st))}
         for name, fn in fns.items():
             for _ in range(3):
                 fn()

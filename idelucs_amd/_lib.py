@@ -85,7 +85,6 @@ SIGNATURES = {
                                        _vp, _i64, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
     "idl_wgrad_supported": (_int, [_int, _int, _int]),
     "idl_wgrad_rmsprop": (_int, [_vp, _vp, _int, _int, _int, _vp, _vp, _vp, _vp, _vp]),
-    "idl_wgrad_split_state_words": (_int, []),
     "idl_l1_fwd_supported": (_int, [_int, _int, _int]),
     "idl_l1_fwd_parts": (_int, []),
     "idl_l1_fwd": (_int, [_vp, _vp, _vp, _vp, _int, _int, _int, _c.c_uint64, _vp, _vp, _int, _vp, _vp]),
@@ -117,8 +116,8 @@ SIGNATURES = {
                                     _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _c.c_float, _c.c_float, _vp, _int,
                                     _int, _vp, _vp, _int, _int, _int, _int, _vp, _i64, _vp]),
     "idl_wgrad_xplanes_supported": (_int, [_int, _int, _int]),
-    "idl_wgrad_rmsprop_xplanes": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "idl_wgrad_xplanes_rms": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+    "idl_wgrad_rmsprop_xplanes": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "idl_wgrad_xplanes_rms": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp,
                                      _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _c.c_float, _c.c_float, _vp, _int,
                                      _int, _vp, _vp, _int, _int, _int, _int, _vp, _i64, _vp]),
     "idl_wgrad_rmsprop_planes": (_int, [_vp, _vp, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -1348,19 +1348,7 @@ __global__ __launch_bounds__(256) void reduce_rms_kernel(ReduceArgs r, RmsArgs a
 // b, in rmsprop_body's SPIN form (no s_barrier: the computing waves would not come).  The step counter and batch offset move at the
 // END of this launch (every workgroup read the counter when it started: all tiles are resident at once, one per CU; the launcher
 // refuses more tiles than CUs), so the next step's first launch adds up its partial sums alone (4.7 us instead of 9.4 with the tail).
-__global__ __launch_bounds__(wgp_dev::NT, 1) void wgrad_xplanes_rms_kernel(wgp_dev::XpArgs x, RmsArgs a, const float *hyper, int64_t *ctl, int64_t batch_advance,
-                                                                           int n_tail)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char wgp_rms_smem[];
-    auto tail = [&](int tix) {
-        if ((int)blockIdx.x < n_tail)
-            rmsprop_body<true, true>(a, hyper, ctl, batch_advance, 0, 0, idl_dev::GatherArgs{}, (int)blockIdx.x, tix,
-                                     (unsigned int *)(wgp_rms_smem + wgp_dev::LDS_BYTES) + 3);
-    };
-    wgp_dev::xplanes_body(x, wgp_rms_smem, tail);            // dr1 in fp32 (the step of n_clusters > 48: a library GEMM wrote it)
-}
-
-// ... and with dr1 as planes from mid_bwd (the step of n_clusters <= 48; wgrad_planes_device.h: dplanes_body, whose K-steps own v[200:247])
+// (wgrad_planes_device.h: dplanes_body, whose K-steps own v[200:247])
 __global__ __launch_bounds__(wgp_dev::NT, 1) __attribute__((amdgpu_num_vgpr(200))) void wgrad_dplanes_rms_kernel(wgp_dev::XpArgs x, RmsArgs a, const float *hyper,
                                                                                                                  int64_t *ctl, int64_t batch_advance, int n_tail)
 {
@@ -1444,13 +1432,13 @@ __global__ __launch_bounds__(wgp_dev::NT, 1) __attribute__((amdgpu_num_vgpr(200)
     extern __shared__ __attribute__((aligned(16))) unsigned char wgp_b_smem[];
     const XpRmsParams &p = *(const XpRmsParams *)(plans + (size_t)blockIdx.y * idl::PLAN_BYTES + idl::PLAN_PARAMS);
     wgp_dev::XpArgs x = p.x;
-    x.dy = uniform_ptr(x.dy); x.xh = uniform_ptr(x.xh); x.xl = uniform_ptr(x.xl); x.dyh = uniform_ptr(x.dyh); x.dyl = uniform_ptr(x.dyl);
+    x.xh = uniform_ptr(x.xh); x.xl = uniform_ptr(x.xl); x.dyh = uniform_ptr(x.dyh); x.dyl = uniform_ptr(x.dyl);
     auto tail = [&](int tix) {
         if ((int)blockIdx.x < p.n_tail)
             rmsprop_body<true, true>(p.a, p.hyper, p.ctl, p.batch_advance, 0, 0, idl_dev::GatherArgs{}, (int)blockIdx.x, tix,
                                      (unsigned int *)(wgp_b_smem + wgp_dev::LDS_BYTES) + 3);
     };
-    wgp_dev::dplanes_body(x, wgp_b_smem, tail);              // (recorded steps are of n_clusters <= 48 and m % 128 == 0: dr1 always arrives as planes; rmsprop_launch refuses another record)
+    wgp_dev::dplanes_body(x, wgp_b_smem, tail);
 }
 
 }  // namespace
@@ -1932,7 +1920,6 @@ static int rmsprop_launch(int count, float *const *params, const float *const *g
         if (const int rc = idl::device_info(&di); rc != IDL_OK) return rc;
         IDL_REQUIRE(nb_total + a.wg_tiles <= xp->tiles && xp->tiles <= di.cus, "wgrad_xplanes_rms: the tail's blocks need a tile each, and every tile its own CU");
         if (void *plan = idl::take_plan()) {      // recorded, not launched (idl_plan_begin)
-            IDL_REQUIRE(xp->dyh != nullptr, "wgrad_xplanes_rms: a recorded launch takes dy as planes");
             idl::PlanHead h{};
             h.kind = idl::PLAN_WGRAD_XPLANES; h.grid[0] = (unsigned)xp->tiles; h.grid[1] = 1; h.grid[2] = 1; h.block = wgp_dev::NT; h.lds = wgp_dev::LDS_BYTES + 16;
             memcpy(plan, &h, sizeof(h));
@@ -1944,15 +1931,10 @@ static int rmsprop_launch(int count, float *const *params, const float *const *g
         int dev = 0;
         IDL_HIP_TRY(hipGetDevice(&dev));
         if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-            IDL_HIP_TRY(hipFuncSetAttribute((const void *)wgrad_xplanes_rms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, wgp_dev::LDS_BYTES + 16));
             IDL_HIP_TRY(hipFuncSetAttribute((const void *)wgrad_dplanes_rms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, wgp_dev::LDS_BYTES + 16));
             attr_set[dev] = true;
         }
-        if (xp->dyh != nullptr)
-            hipLaunchKernelGGL(wgrad_dplanes_rms_kernel, dim3((unsigned)xp->tiles), dim3(wgp_dev::NT), wgp_dev::LDS_BYTES + 16, (hipStream_t)stream, *xp, a, hyper,
-                               ctl, batch_advance, nb_total + a.wg_tiles);
-        else
-        hipLaunchKernelGGL(wgrad_xplanes_rms_kernel, dim3((unsigned)xp->tiles), dim3(wgp_dev::NT), wgp_dev::LDS_BYTES + 16, (hipStream_t)stream, *xp, a, hyper,
+        hipLaunchKernelGGL(wgrad_dplanes_rms_kernel, dim3((unsigned)xp->tiles), dim3(wgp_dev::NT), wgp_dev::LDS_BYTES + 16, (hipStream_t)stream, *xp, a, hyper,
                            ctl, batch_advance, nb_total + a.wg_tiles);
         IDL_HIP_TRY(hipGetLastError());
         return IDL_OK;
@@ -2163,31 +2145,23 @@ int idl_reduce_parts_rms(float *part, int64_t slab_elems, const int64_t *step_co
 
 // idl_wgrad_rmsprop_xplanes (W updated, its planes written) with THIS step's optimizer tail carried by the tiles' loader waves (tail arguments as
 // idl_l1_fwd_rms; w1_index: the tensor the tiles update, left out of the tail).  Needs a CU per tile and no more tail blocks than tiles.
-int idl_wgrad_xplanes_rms(const float *dy, const void *dy_hi, const void *dy_lo, int *dy_scale, const void *x_hi, const void *x_lo, int ld_x, int m, int n_out,
-                          int n_in, float *grad, float *W, float *square_avg,
-                          unsigned long long *state, const int64_t *step_snapshot, void *w_hi, void *w_lo, int *overflow_flag,
+int idl_wgrad_xplanes_rms(const void *dy_hi, const void *dy_lo, int *dy_scale, const void *x_hi, const void *x_lo, int ld_x, int m, int n_out, int n_in, float *grad, float *W,
+                          float *square_avg, void *w_hi, void *w_lo, int *overflow_flag,
                           int count, float *const *params, const float *const *grads, const int32_t *grad_parts,
                           float *const *square_avg_all, const int64_t *sizes, const float *hyper, int64_t *ctl,
                           const float *loss_rows, int loss_m, float w_nce, float w_iic, float *out, int w1_index,
                           int wg_index, const float *wg_dy, const float *wg_x, int wg_x_transposed, int wg_m, int wg_n_out, int wg_n_in,
                           float *wg_grad, int64_t batch_advance, void *stream)
 {
-    IDL_REQUIRE(x_hi && x_lo && W && square_avg && hyper && ctl && w_hi && w_lo && overflow_flag, "wgrad_xplanes_rms: NULL buffer");
-    IDL_REQUIRE((dy_hi != nullptr) == (dy_lo != nullptr) && (dy_hi != nullptr) == (dy_scale != nullptr) && ((dy != nullptr && state != nullptr) || dy_hi != nullptr) &&
-                ((((uintptr_t)dy_hi) | ((uintptr_t)dy_lo)) & 15u) == 0 && (dy_hi == nullptr || m % wgp_dev::dpl::KC2 == 0),
-                "wgrad_xplanes_rms: dy in fp32 with the state words, or as both planes (16-byte aligned, m % 64 == 0) with the words of their scale");
-    IDL_REQUIRE(m % wgp_dev::KC == 0 && m / wgp_dev::KC >= 2 * wgp_dev::PF && n_out >= wgp_dev::TM && n_out % wgp_dev::TM == 0 && n_in >= wgp_dev::TN &&
-                n_in % wgp_dev::TN == 0 && (int64_t)m * (n_in + 1024) < (1ll << 29) && (int64_t)n_out * n_in < (1ll << 29),
-                "wgrad_xplanes_rms: m % 32 == 0, m >= 192, n_out % 64 == 0, n_in % 128 == 0");
+    IDL_REQUIRE(dy_hi && dy_lo && dy_scale && x_hi && x_lo && W && square_avg && hyper && ctl && w_hi && w_lo && overflow_flag, "wgrad_xplanes_rms: NULL buffer");
+    IDL_REQUIRE(idl_wgrad_xplanes_supported(m, n_out, n_in), "wgrad_xplanes_rms: m % 64 == 0, m >= 192, n_out % 64 == 0, n_in % 128 == 0");
     IDL_REQUIRE(ld_x >= n_in && ld_x <= n_in + 1024 && (ld_x & 7) == 0, "wgrad_xplanes_rms: n_in <= ld_x <= n_in + 1024, 8 | ld_x");
-    IDL_REQUIRE((((uintptr_t)dy | (uintptr_t)x_hi | (uintptr_t)x_lo | (uintptr_t)grad | (uintptr_t)W | (uintptr_t)square_avg) & 15u) == 0 &&
-                (((uintptr_t)state | (uintptr_t)w_hi | (uintptr_t)w_lo) & 7u) == 0, "wgrad_xplanes_rms: buffers 16-byte aligned, state and W's planes 8-byte");
+    IDL_REQUIRE((((uintptr_t)dy_hi | (uintptr_t)dy_lo | (uintptr_t)x_hi | (uintptr_t)x_lo | (uintptr_t)grad | (uintptr_t)W | (uintptr_t)square_avg) & 15u) == 0 &&
+                (((uintptr_t)w_hi | (uintptr_t)w_lo) & 7u) == 0, "wgrad_xplanes_rms: buffers 16-byte aligned, W's planes 8-byte");
     wgp_dev::XpArgs x{};
-    x.dy = dy; x.xh = (const uint16_t *)x_hi; x.xl = (const uint16_t *)x_lo; x.grad = grad; x.W = W; x.V = square_avg;
     x.dyh = (const uint16_t *)dy_hi; x.dyl = (const uint16_t *)dy_lo; x.dy_scale = dy_scale;
-    x.wh = (uint16_t *)w_hi; x.wl = (uint16_t *)w_lo; x.over = overflow_flag; x.hyper = hyper; x.state = state;
-    // (the launch number behind dr1's scale: from the snapshot the step's reduce launch took, not from the counter this launch's own tail moves)
-    x.ctl = step_snapshot != nullptr ? (const long long *)step_snapshot : (const long long *)ctl;
+    x.xh = (const uint16_t *)x_hi; x.xl = (const uint16_t *)x_lo; x.grad = grad; x.W = W; x.V = square_avg;
+    x.wh = (uint16_t *)w_hi; x.wl = (uint16_t *)w_lo; x.over = overflow_flag; x.hyper = hyper;
     x.m = m; x.n_out = n_out; x.n_in = n_in; x.ldx = ld_x;
     x.tiles_m = n_out / wgp_dev::TM; x.tiles = x.tiles_m * (n_in / wgp_dev::TN);
     static const int wgp_dbg = getenv("IDELUCS_WGP_DBG") ? atoi(getenv("IDELUCS_WGP_DBG")) : 0;      // (timing ablations; wgrad_planes_device.h)

@@ -9,13 +9,7 @@ namespace {
 
 using namespace wgp_dev;
 
-__global__ __launch_bounds__(NT, 1) void wgrad_xplanes_kernel(XpArgs a)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char wgp_smem[];
-    xplanes_body(a, wgp_smem, [](int) {});
-}
-
-// dy as planes too (dplanes_body): the compiler's allocator stops at v199, the K-steps' operand sets live above it
+// (the compiler's allocator stops at v199, the K-steps' operand sets live above it: wgrad_planes_device.h)
 __global__ __launch_bounds__(NT, 1) __attribute__((amdgpu_num_vgpr(200))) void wgrad_dplanes_kernel(XpArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char wgd_smem[];
@@ -24,34 +18,26 @@ __global__ __launch_bounds__(NT, 1) __attribute__((amdgpu_num_vgpr(200))) void w
 
 }  // namespace
 
-// 64-bit words of the state buffer that carries dy's scale from launch to launch (zero at first): 3 arrays of STATE_ARRAY used, 2 x STATE_SLOTS asked for
-extern "C" int idl_wgrad_split_state_words(void) { return 2 * wgp_dev::STATE_SLOTS; }
-
 extern "C" int idl_wgrad_xplanes_supported(int m, int n_out, int n_in)
 {
-    return (m % KC == 0 && m / KC >= 2 * PF && n_out >= TM && n_out % TM == 0 && n_in >= TN && n_in % TN == 0 &&
-            (int64_t)m * (n_in + 1024) < (1ll << 29) && (int64_t)n_out * n_in < (1ll << 29) && (n_out / TM) * (n_in / TN) <= STATE_ARRAY) ? 1 : 0;
+    return (m % dpl::KC2 == 0 && m / dpl::KC2 >= dpl::NS && n_out >= TM && n_out % TM == 0 && n_in >= TN && n_in % TN == 0 &&
+            (int64_t)m * (n_in + 1024) < (1ll << 29) && (int64_t)n_out * n_in < (1ll << 29) && (int64_t)m * n_out < (1ll << 30)) ? 1 : 0;
 }
 
-extern "C" int idl_wgrad_rmsprop_xplanes(const float *dy, const void *dy_hi, const void *dy_lo, int *dy_scale, const void *x_hi, const void *x_lo, int ld_x, int m,
-                                         int n_out, int n_in, float *grad, float *W,
-                                         float *square_avg, const float *hyper, const long long *ctl, unsigned long long *state, void *w_hi, void *w_lo,
-                                         int *overflow_flag, void *stream)
+extern "C" int idl_wgrad_rmsprop_xplanes(const void *dy_hi, const void *dy_lo, int *dy_scale, const void *x_hi, const void *x_lo, int ld_x, int m, int n_out, int n_in,
+                                         float *grad, float *W, float *square_avg, const float *hyper, void *w_hi, void *w_lo, int *overflow_flag, void *stream)
 {
-    IDL_REQUIRE(x_hi && x_lo && idl_wgrad_xplanes_supported(m, n_out, n_in), "wgrad_xplanes: m % 32 == 0, m >= 192, n_out % 64 == 0, n_in % 128 == 0");
-    IDL_REQUIRE((dy_hi != nullptr) == (dy_lo != nullptr) && (dy_hi != nullptr) == (dy_scale != nullptr) && ((dy != nullptr && state != nullptr) || dy_hi != nullptr) &&
-                ((((uintptr_t)dy_hi) | ((uintptr_t)dy_lo)) & 15u) == 0 && (dy_hi == nullptr || m % dpl::KC2 == 0),
-                "wgrad_xplanes: dy in fp32 with the state words, or as both planes (16-byte aligned, m % 64 == 0) with the words of their scale");
+    IDL_REQUIRE(dy_hi && dy_lo && dy_scale && x_hi && x_lo && idl_wgrad_xplanes_supported(m, n_out, n_in), "wgrad_xplanes: m % 64 == 0, m >= 192, n_out % 64 == 0, n_in % 128 == 0");
     IDL_REQUIRE(ld_x >= n_in && ld_x <= n_in + 1024 && (ld_x & 7) == 0, "wgrad_xplanes: n_in <= ld_x <= n_in + 1024, 8 | ld_x");
     IDL_REQUIRE((W != nullptr) == (square_avg != nullptr) && (W != nullptr || grad != nullptr), "wgrad_xplanes: give W and square_avg (fused update) and/or grad");
     IDL_REQUIRE(W == nullptr || hyper != nullptr, "wgrad_xplanes: hyper is needed for the fused update");
     IDL_REQUIRE((w_hi != nullptr) == (w_lo != nullptr) && (w_hi == nullptr || (W != nullptr && overflow_flag != nullptr)), "wgrad_xplanes: W's planes need both planes, W and the flag");
-    IDL_REQUIRE((((uintptr_t)dy | (uintptr_t)x_hi | (uintptr_t)x_lo | (uintptr_t)grad | (uintptr_t)W | (uintptr_t)square_avg) & 15u) == 0 &&
-                (((uintptr_t)state | (uintptr_t)w_hi | (uintptr_t)w_lo) & 7u) == 0, "wgrad_xplanes: buffers 16-byte aligned, state and W's planes 8-byte");
+    IDL_REQUIRE((((uintptr_t)dy_hi | (uintptr_t)dy_lo | (uintptr_t)x_hi | (uintptr_t)x_lo | (uintptr_t)grad | (uintptr_t)W | (uintptr_t)square_avg) & 15u) == 0 &&
+                (((uintptr_t)w_hi | (uintptr_t)w_lo) & 7u) == 0, "wgrad_xplanes: buffers 16-byte aligned, W's planes 8-byte");
     XpArgs a{};
     a.dyh = (const uint16_t *)dy_hi; a.dyl = (const uint16_t *)dy_lo; a.dy_scale = dy_scale;
-    a.dy = dy; a.xh = (const uint16_t *)x_hi; a.xl = (const uint16_t *)x_lo; a.grad = grad; a.W = W; a.V = square_avg;
-    a.wh = (uint16_t *)w_hi; a.wl = (uint16_t *)w_lo; a.over = overflow_flag; a.hyper = hyper; a.ctl = ctl; a.state = state;
+    a.xh = (const uint16_t *)x_hi; a.xl = (const uint16_t *)x_lo; a.grad = grad; a.W = W; a.V = square_avg;
+    a.wh = (uint16_t *)w_hi; a.wl = (uint16_t *)w_lo; a.over = overflow_flag; a.hyper = hyper;
     a.m = m; a.n_out = n_out; a.n_in = n_in; a.ldx = ld_x;
     a.tiles_m = n_out / TM; a.tiles = a.tiles_m * (n_in / TN);
     static const int wgp_dbg = getenv("IDELUCS_WGP_DBG") ? atoi(getenv("IDELUCS_WGP_DBG")) : 0;      // (timing ablations; wgrad_planes_device.h)
@@ -60,12 +46,10 @@ extern "C" int idl_wgrad_rmsprop_xplanes(const float *dy, const void *dy_hi, con
     int dev = 0;
     IDL_HIP_TRY(hipGetDevice(&dev));
     if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-        IDL_HIP_TRY(hipFuncSetAttribute((const void *)wgrad_xplanes_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + 16));
         IDL_HIP_TRY(hipFuncSetAttribute((const void *)wgrad_dplanes_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + 16));
         attr_set[dev] = true;
     }
-    if (a.dyh != nullptr) hipLaunchKernelGGL(wgrad_dplanes_kernel, dim3((unsigned)a.tiles), dim3(NT), LDS_BYTES + 16, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(wgrad_xplanes_kernel, dim3((unsigned)a.tiles), dim3(NT), LDS_BYTES + 16, (hipStream_t)stream, a);      // (+ 16: the exponent's word)
+    hipLaunchKernelGGL(wgrad_dplanes_kernel, dim3((unsigned)a.tiles), dim3(NT), LDS_BYTES + 16, (hipStream_t)stream, a);      // (+ 16: the tail's words)
     IDL_HIP_TRY(hipGetLastError());
     return IDL_OK;
 }

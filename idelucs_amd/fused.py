@@ -177,7 +177,6 @@ class FusedLinearTrainer:
         self._bufs = {}
         self._graphs = {}
         self._side = torch.cuda.Stream(device=self.dev)     # second branch of the step (see step_on_batch)
-        self._split_state = None
         # TEST HOOK (IDELUCS_TEST_COLD=1; tests/test_gpu_planes.py): a 512 MB fill in front of the step's middle and of each plane kernel, so that every load of
         # the hand-scheduled kernels comes from HBM instead of a warm L2/MALL -- a load consumed before its wait is right when it landed
         # early and wrong when it did not (DESIGN.md History, round 5), and only cold caches show that
@@ -331,7 +330,7 @@ class FusedLinearTrainer:
         # ... with the layer-1 product from two-plane operands (IDELUCS_PLANES=1)
         pl = (tm and self._planes and bool(_L.idl_l1_planes_supported(m, self.H1, self.F)) and next_from.n < 60_000_000)
         plw = pl and self._planes_wgrad and bool(_L.idl_wgrad_xplanes_supported(m, self.H1, self.F))
-        dpl = plw and m % 64 == 0              # ... with dr1 written as planes by mid_bwd: both operands of dW1 reach its tiles by LDS-DMA
+        dpl = plw                              # ... with dr1 written as planes by mid_bwd: both operands of dW1 reach its tiles by LDS-DMA (m % 128 == 0 here)
         # ... and the same two products in the step of n_clusters > 48 (the fine-grained mode's 200 output units: separate backward kernels, the
         # whole batch assembled by the mid-forward launch, activations NOT transposed): the layer-1 tiles with the operands' roles swapped
         # give part[8][m][512]; the dW1 kernel with the tail on its loader waves ends the step
@@ -540,7 +539,7 @@ class FusedLinearTrainer:
             st = next_from
             if not 48 < C <= 200:
                 torch.mm(bf.z, bf.P0, out=bf.dzs)
-            dplf = m % 64 == 0
+            dplf = True                        # (m % 128 == 0 in this form)
             chk(_L.idl_mid_bwd_gather_planes(_p(bf.z), _p(bf.r2), _p(bf.f), _p(bf.inv), _p(bf.G), bf.G.shape[0], _p(bf.P0), _p(self.W3), _p(self.W2),
                                              _p(r1), m, C, tr, nce_coef, _p(bf.dlogits), _p(bf.dlat), _p(bf.dr1), _p(gb1), _p(gb2), _p(gb3), None,
                                              _p(st.feats), st.n, st.f, st.n * st.f, _p(self._perm), _p(self.ctl[1:]), m // 2, st.n_pairs, m // 2,
@@ -580,8 +579,6 @@ class FusedLinearTrainer:
         if tm:      # the dW1 tiles end the step; everything else of the optimizer rides in the next step's layer-1 launch
             if plw:     # dW1 from the batch's planes on the fp16 matrix cores; the epilogue writes the updated W1 and its planes
                 wh, wl, flag = self._w1_planes
-                if self._split_state is None:
-                    self._split_state = torch.zeros(int(_L.idl_wgrad_split_state_words()), dtype=torch.int64, device=self.dev)
                 # (a tile per CU, and a tile for each of the tail's blocks: 128 dW2 tiles + at most 16 blocks for the small tensors)
                 if self._planes_tail_wgrad and self._planes_reduce_launch and 144 <= (self.H1 // 64) * (self.F // 128) <= self._cus:
                     # ... and THIS step's optimizer tail is run by the tiles' loader waves under the tiles' epilogue: nothing is pending
@@ -590,14 +587,14 @@ class FusedLinearTrainer:
                     wg = (2, _p(bf.dlat), _p(r1), 1, m, self.H2, self.H1, _p(self.grads[2]), m // 2, _stream())
                     if self._cold:
                         self._evict()
-                    chk(_L.idl_wgrad_xplanes_rms(_p(bf.dr1), *self._dy_planes_args(pb, dpl), _p(pb["xh"][xi]), _p(pb["xl"][xi]), self.F, m, self.H1, self.F,
+                    chk(_L.idl_wgrad_xplanes_rms(*self._dy_planes_args(pb), _p(pb["xh"][xi]), _p(pb["xl"][xi]), self.F, m, self.H1, self.F,
                                                  _p(gW1) if self._keep_w1_grad else None, _p(self.W1), _p(self.square_avg[0]),
-                                                 _p(self._split_state), _p(self._ctl_snap), _p(wh), _p(wl), _p(flag), *tail, 0, *wg))
+                                                 _p(wh), _p(wl), _p(flag), *tail, 0, *wg))
                     self._pending = None
                     return
-                chk(_L.idl_wgrad_rmsprop_xplanes(_p(bf.dr1), *self._dy_planes_args(pb, dpl), _p(pb["xh"][xi]), _p(pb["xl"][xi]), self.F, m, self.H1, self.F,
+                chk(_L.idl_wgrad_rmsprop_xplanes(*self._dy_planes_args(pb), _p(pb["xh"][xi]), _p(pb["xl"][xi]), self.F, m, self.H1, self.F,
                                                  _p(gW1) if self._keep_w1_grad else None, _p(self.W1), _p(self.square_avg[0]), _p(self.hyper),
-                                                 _p(self.ctl), _p(self._split_state), _p(wh), _p(wl), _p(flag), _stream()))
+                                                 _p(wh), _p(wl), _p(flag), _stream()))
             elif pl:    # ... and write the updated W1's planes for the next layer-1 product
                 wh, wl, flag = self._w1_planes
                 chk(_L.idl_wgrad_rmsprop_planes(_p(bf.dr1), _p(x), m, self.H1, self.F, _p(gW1) if self._keep_w1_grad else None, _p(self.W1),
@@ -612,16 +609,14 @@ class FusedLinearTrainer:
         if plf:     # dW1 from the batch's planes with RMSprop and W1's planes in the epilogue; the rest of the optimizer on the loader waves
             main.wait_stream(side)
             wh, wl, flag = self._w1_planes
-            if self._split_state is None:
-                self._split_state = torch.zeros(int(_L.idl_wgrad_split_state_words()), dtype=torch.int64, device=self.dev)
             tail = (len(self.params), self._pp, self._gp, self._parts, self._vp, self._sz, _p(self.hyper),
                     _p(self.ctl), _p(bf.loss_rows), m, 1.0 - self.weight, self.weight, _p(self.out))
             wg = (2, _p(bf.dlat), _p(r1), 0, m, self.H2, self.H1, _p(gW2), m // 2, _stream())
             if self._cold:
                 self._evict()
-            chk(_L.idl_wgrad_xplanes_rms(_p(bf.dr1), *self._dy_planes_args(pb, pb.get("dr1_as_planes", False)), _p(pb["xh"][xi]), _p(pb["xl"][xi]), self.F, m,
+            chk(_L.idl_wgrad_xplanes_rms(*self._dy_planes_args(pb), _p(pb["xh"][xi]), _p(pb["xl"][xi]), self.F, m,
                                          self.H1, self.F, _p(gW1) if self._keep_w1_grad else None, _p(self.W1), _p(self.square_avg[0]),
-                                         _p(self._split_state), _p(self._ctl_snap), _p(wh), _p(wl), _p(flag), *tail, 0, *wg))
+                                         _p(wh), _p(wl), _p(flag), *tail, 0, *wg))
             return
         w1_fusable = self._wgrad_fused and bool(_L.idl_wgrad_supported(m, self.H1, self.F))
         # the tiles ride at the head of the optimizer launch where that launch has the form below; else as a launch of their own
@@ -676,15 +671,13 @@ class FusedLinearTrainer:
         if self._w1_planes is None:
             self._w1_planes = (torch.empty(self.W1.shape, dtype=torch.int16, device=self.dev), torch.empty(self.W1.shape, dtype=torch.int16, device=self.dev),
                                torch.zeros(1, dtype=torch.int32, device=self.dev))
-        if self._split_state is None:
-            self._split_state = torch.zeros(int(_L.idl_wgrad_split_state_words()), dtype=torch.int64, device=self.dev)
         wh, wl, flag = self._w1_planes
         part = pb["part"][xi]
         r1 = part[0]
         gW1, gb1, gW2, gb2, gW3, gb3 = self.grads
         nce_coef = (1.0 - self.weight) / (m * TEMPERATURE)
         g2 = self._gsplit
-        dpl = m % 64 == 0
+        dpl = True
         self._k(_L.idl_l1_planes, _p(wh), _p(wl), self.F, _p(pb["xh"][xi]), _p(pb["xl"][xi]), self.F, m, self.H1, self.F, _p(part), _stream())
         self._k(_L.idl_reduce_parts_rms, _p(part), self.H1 * m, _p(self.ctl), _p(self._ctl_snap), 0, None, None, None, None, None, None, None, None, 0, 0.0, 0.0,
                 None, 0, -1, None, None, 0, 0, 0, 0, None, 0, _stream())
@@ -702,8 +695,8 @@ class FusedLinearTrainer:
         tail = (len(self.params), self._pp, self._gp, self._parts, self._vp, self._sz, _p(self.hyper),
                 _p(self.ctl), _p(bf.loss_rows), m, 1.0 - self.weight, self.weight, _p(self.out))
         wg = (2, _p(bf.dlat), _p(r1), 1, m, self.H2, self.H1, _p(gW2), m // 2, _stream())
-        self._k(_L.idl_wgrad_xplanes_rms, _p(bf.dr1), *self._dy_planes_args(pb, dpl), _p(pb["xh"][xi]), _p(pb["xl"][xi]), self.F, m, self.H1, self.F, None, _p(self.W1),
-                _p(self.square_avg[0]), _p(self._split_state), _p(self._ctl_snap), _p(wh), _p(wl), _p(flag), *tail, 0, *wg)
+        self._k(_L.idl_wgrad_xplanes_rms, *self._dy_planes_args(pb), _p(pb["xh"][xi]), _p(pb["xl"][xi]), self.F, m, self.H1, self.F, None, _p(self.W1),
+                _p(self.square_avg[0]), _p(wh), _p(wl), _p(flag), *tail, 0, *wg)
 
     def _dr1_planes_args(self, pb, on, dzs=None):
         """idl_mid_bwd_gather_planes' last arguments: dr1's planes and the words of their scale (or none of them: dr1 in fp32), and z dP0 as an
@@ -719,8 +712,8 @@ class FusedLinearTrainer:
             return bf.dr1
         return ((pb["dh"].view(torch.float16).double() + pb["dl"].view(torch.float16).double()) * 2.0 ** -int(self._dr1_scale[0].item())).float()
 
-    def _dy_planes_args(self, pb, on):
-        return (_p(pb["dh"]), _p(pb["dl"]), _p(self._dr1_scale)) if on else (None, None, None)
+    def _dy_planes_args(self, pb):
+        return (_p(pb["dh"]), _p(pb["dl"]), _p(self._dr1_scale))
 
     def _tail_launch(self, bf, xi, r1, l1=None, l1p=None, red=None):
         """The optimizer's tail of the step that ran on (bf, xi) with the activations r1: dW2 tiles + RMSprop on every tensor but W1 + step

@@ -38,8 +38,8 @@ def test_plane_kernels_have_no_scratch_and_fit_their_cu(tmp_path):
     spilled register set would be reloaded from scratch before its request has landed.  No scratch, and the LDS / register budget of one
     512-thread workgroup per CU (dynamic LDS is set by the launchers: 128 KB and 144 KB + the tail's 4 KB of static LDS)."""
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    want = {"planes.hip": ["l1_planes_kernel"], "wgrad_planes.hip": ["wgrad_xplanes_kernel", "wgrad_dplanes_kernel"],
-            "train_step.hip": ["wgrad_xplanes_rms_kernel", "wgrad_dplanes_rms_kernel", "wgrad_xplanes_rms_batched_kernel", "reduce_rms_kernel", "l1p_rms_kernel",
+    want = {"planes.hip": ["l1_planes_kernel"], "wgrad_planes.hip": ["wgrad_dplanes_kernel"],
+            "train_step.hip": ["wgrad_dplanes_rms_kernel", "wgrad_xplanes_rms_batched_kernel", "reduce_rms_kernel", "l1p_rms_kernel",
                                "mid_bwd_kernelILb0ELb0ELb1E", "mid_bwd_kernelILb0ELb0ELb0E"]}
     for fn, kernels in want.items():
         src = os.path.join(ROOT, "idelucs_amd", "csrc", fn)
@@ -57,47 +57,6 @@ def test_plane_kernels_have_no_scratch_and_fit_their_cu(tmp_path):
         assert set(seen) == set(kernels), (fn, seen)
         for k, (scratch, vgprs, lds) in seen.items():
             assert scratch == 0 and vgprs <= 256 and (lds <= 4096 or k.startswith("mid_bwd")), (k, scratch, vgprs, lds)      # (mid_bwd: a 1024-thread workgroup with 61 KB of static LDS)
-
-
-@pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="no hipcc")
-def test_the_weight_gradient_ring_is_out_of_the_compilers_sight(tmp_path):
-    """Round 5's loader race (wgrad_planes_device.h): the dr1 ring's requests target FIXED registers v[232:255] that the compiler must
-    never allocate or copy -- in the ISA of every kernel built from that body they appear only as the target of a
-    `global_load_dwordx4` and as the source of the `v_mov_b32`s that follow the `s_waitcnt vmcnt` of the same asm statement; nothing
-    else reads or writes them, and the loader asm never targets a compiler-allocated register."""
-    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    ring = re.compile(r"\bv(2(?:3[2-9]|4\d|5[0-5]))\b|v\[(2(?:3[2-9]|4\d|5[0-5])):")
-    for fn, kernels in (("wgrad_planes.hip", ["wgrad_xplanes_kernel"]), ("train_step.hip", ["wgrad_xplanes_rms_kernel"])):
-        src = os.path.join(ROOT, "idelucs_amd", "csrc", fn)
-        out = tmp_path / (fn + ".s")
-        r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-S", src, "-o", str(out)],
-                           capture_output=True, text=True, cwd=os.path.dirname(src))
-        assert r.returncode == 0, r.stderr[-2000:]
-        cur, seen = None, {}
-        lines = open(out).read().split("\n")
-        for no, line in enumerate(lines):
-            m = re.match(r"^(_Z\w+):", line)
-            if m:
-                cur = next((k for k in kernels if k + "E" in m.group(1)), None)
-                continue
-            if line.startswith(".Lfunc_end"):
-                cur = None
-            ins = line.split(";")[0].strip()
-            if cur is None or not ins or not ring.search(ins):
-                continue
-            seen.setdefault(cur, [0, 0])
-            if re.match(r"global_load_dwordx4 v\[2\d\d:2\d\d\], v\d+, s\[\d+:\d+\]$", ins):
-                seen[cur][0] += 1
-            elif re.match(r"v_mov_b32 v\d+, v2\d\d$", ins) and int(ins.split()[1].rstrip(",")[1:]) < 232:
-                # ... behind the wait of its asm statement: a waitcnt or another such v_mov directly in front
-                prev = lines[no - 1].split(";")[0].strip()
-                assert prev.startswith("s_waitcnt vmcnt(") or re.match(r"v_mov_b32 v\d+, v2\d\d$", prev), (cur, no, prev, ins)
-                seen[cur][1] += 1
-            else:
-                raise AssertionError("%s: the ring's registers in `%s` (line %d of %s)" % (cur, ins, no + 1, out))
-        assert set(seen) == set(kernels), (fn, seen)
-        for k, (loads, movs) in seen.items():
-            assert loads >= 6 and movs >= 24 and movs % 8 == 0, (k, loads, movs)
 
 
 @pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="no hipcc")

@@ -97,24 +97,17 @@ def main():
     flag = torch.zeros(1, dtype=torch.int32, device=dev)
     t_w = timed(lambda: _lib.check(L.idl_wgrad_rmsprop(p(dy), p(x), m, H, F, None, p(Wc), p(Vc), p(hyper), st())))
     t_wp = timed(lambda: _lib.check(L.idl_wgrad_rmsprop_planes(p(dy), p(x), m, H, F, None, p(Wc), p(Vc), p(hyper), p(wh), p(wl), p(flag), st())))
-    state = torch.zeros(L.idl_wgrad_split_state_words(), dtype=torch.int64, device=dev)
-    t_x = timed(lambda: _lib.check(L.idl_wgrad_rmsprop_xplanes(p(dy), None, None, None, p(xh), p(xl), F, m, H, F, None, p(Wc), p(Vc), p(hyper), None, p(state), p(wh), p(wl), p(flag), st())))
-    grad = torch.empty(H, F, device=dev)
-    t_xg = timed(lambda: _lib.check(L.idl_wgrad_rmsprop_xplanes(p(dy), None, None, None, p(xh), p(xl), F, m, H, F, p(grad), None, None, None, None, p(state), None, None, None, st())))
     dyh, dyl = h16(dy), h16(dy)
     kd = 9 - int(__import__("math").frexp(dy.abs().max().item())[1])
     _lib.check(L.idl_split_planes(p(dy), dy.numel(), kd, p(dyh), p(dyl), None, st()))
-    dexp = torch.zeros(int(L.idl_dr1_scale_words()), dtype=torch.int32, device=dev); dexp[0] = kd
-    t_d = timed(lambda: _lib.check(L.idl_wgrad_rmsprop_xplanes(None, p(dyh), p(dyl), p(dexp), p(xh), p(xl), F, m, H, F, None, p(Wc), p(Vc), p(hyper), None, None, p(wh), p(wl), p(flag), st())))
-    t_dg = timed(lambda: _lib.check(L.idl_wgrad_rmsprop_xplanes(None, p(dyh), p(dyl), p(dexp), p(xh), p(xl), F, m, H, F, p(grad), None, None, None, None, None, None, None, None, st())))
+    dsc = torch.zeros(int(L.idl_dr1_scale_words()), dtype=torch.int32, device=dev); dsc[0] = kd
+    grad = torch.empty(H, F, device=dev)
+    t_d = timed(lambda: _lib.check(L.idl_wgrad_rmsprop_xplanes(p(dyh), p(dyl), p(dsc), p(xh), p(xl), F, m, H, F, None, p(Wc), p(Vc), p(hyper), p(wh), p(wl), p(flag), st())))
+    t_dg = timed(lambda: _lib.check(L.idl_wgrad_rmsprop_xplanes(p(dyh), p(dyl), p(dsc), p(xh), p(xl), F, m, H, F, p(grad), None, None, None, None, None, None, st())))
     torch.cuda.synchronize()
     e_d = (grad.double() - dy.double().t() @ x.double()).abs().max().item() / (dy.double().t() @ x.double()).abs().max().item()
-    print(f"dW1 from dy's planes too (round 6): {t_d:.1f} us with the update, the gradient alone {t_dg:.1f} (error {e_d:.1e})")
-    _lib.check(L.idl_wgrad_rmsprop_xplanes(p(dy), None, None, None, p(xh), p(xl), F, m, H, F, p(grad), None, None, None, None, p(state), None, None, None, st()))
-    torch.cuda.synchronize()
-    e_g = (grad.double() - dy.double().t() @ x.double()).abs().max().item() / (dy.double().t() @ x.double()).abs().max().item()
-    print(f"dW1 tiles + RMSprop: {t_w:.1f} us; also writing W1's planes {t_wp:.1f}; from the batch's planes (fp16 matrix cores) {t_x:.1f}, its gradient alone {t_xg:.1f} "
-          f"(error {e_g:.1e} of the largest entry)")
+    print(f"dW1 tiles + RMSprop (fp32 tiles): {t_w:.1f} us; also writing W1's planes {t_wp:.1f}; from both operands' planes (fp16 matrix cores) {t_d:.1f}, its gradient alone {t_dg:.1f} "
+          f"(error {e_d:.1e} of the largest entry)")
     if "--no-epoch" in sys.argv:
         return
     epochs(dev, ("0", "1"))

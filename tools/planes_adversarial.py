@@ -66,7 +66,7 @@ def main():
         _lib.check(L.idl_split_planes(p(dy), dy.numel(), kd, p(dyh), p(dyl), p(flag), st()))
         sc = torch.zeros(int(L.idl_dr1_scale_words()), dtype=torch.int32, device=dev); sc[0] = kd
         gpl = torch.empty(H, F, device=dev)
-        _lib.check(L.idl_wgrad_rmsprop_xplanes(None, p(dyh), p(dyl), p(sc), p(xh), p(xl), F, m, H, F, p(gpl), None, None, None, None, None, None, None, None, st()))
+        _lib.check(L.idl_wgrad_rmsprop_xplanes(p(dyh), p(dyl), p(sc), p(xh), p(xl), F, m, H, F, p(gpl), None, None, None, None, None, None, st()))
         torch.cuda.synchronize()
         e_g = (gpl.double() - refg).abs().max().item() / s2
         rows.append((name, e_pl, e_lib, e_g, e_32, int(flag.item())))

@@ -132,7 +132,6 @@ SIGNATURES = {
     "idl_mst_prim_local": (_int, [_vp, _int, _vp, _i64, _int, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "idl_debug_prim_phases": (_int, [_vp]),
     "idl_debug_lazy_phases": (_int, [_vp]),
-    "idl_debug_split_gemm": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _vp]),
     "idl_mst_prim_lazy_workspace": (_i64, [_i64, _int]),
     "idl_mst_prim_lazy": (_int, [_vp, _vp, _vp, _i64, _int, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "idl_silhouette_sums": (_int, [_vp, _vp, _vp, _i64, _int, _int, _vp, _vp]),

@@ -1329,47 +1329,3 @@ def test_default_step_contains_no_library_gemm(dev, monkeypatch, planes, C):
         assert any("l1_rms_kernel" in n for n in names) and any("l1_fwd_kernel" in n for n in names), sorted(set(names))
         assert any("wgrad_q16_kernel" in n for n in names)
     assert not any("Cijk_" in n for n in names), [n for n in names if "Cijk_" in n][:3]
-
-
-def test_split_operand_products_on_the_16_bit_matrix_cores_are_fp32_grade():
-    """The probe behind DESIGN's "largest lever left" (csrc/probe_split.hip; not on the product path): the layer-1 product from
-    operands split into 16-bit planes -- three bf16 planes and six products, or two scaled fp16 planes and three -- accumulated in
-    fp32 is at least as close to the float64 product as the fp32 library GEMM (errors relative to the largest entry)."""
-    import ctypes
-    import sys
-    import torch
-    from conftest import ROOT
-    sys.path.insert(0, os.path.join(ROOT, "tools"))
-    import probe_split_mfma as P
-    from idelucs_amd import _lib
-    dev = torch.device("cuda")
-    g = torch.Generator(device="cpu"); g.manual_seed(11)
-    M, N, K, S = 256, 256, 2048, 8
-    a = torch.randn(M, K, generator=g).to(dev)
-    b = (torch.randn(N, K, generator=g) * (2.0 / K) ** 0.5).to(dev)
-    ref = a.double() @ b.double().t()
-    scale = ref.abs().max().item()
-    e_lib = ((a @ b.t()).double() - ref).abs().max().item() / scale
-    cpart = torch.empty(S, M, N, dtype=torch.float32, device=dev)
-    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-
-    def run(pa, pb, code):
-        _lib.check(_lib.lib.idl_debug_split_gemm(*(ctypes.c_void_p(t.data_ptr()) for t in pa), *(ctypes.c_void_p(t.data_ptr()) for t in pb),
-                                                 ctypes.c_void_p(cpart.data_ptr()), M, N, K, S, code, st))
-        torch.cuda.synchronize()
-        return cpart.double().sum(0)
-    pa, pb = P.split3(a), P.split3(b)
-    for code in (6, 16 + 6):                                  # both stagings of the bf16 form
-        err = (run(pa, pb, code) - ref).abs().max().item() / scale
-        assert err < 5e-7 and err <= e_lib, (code, err, e_lib)
-    assert (run(pa, pb, 16 + 1) - ref).abs().max().item() / scale > 1e-4       # (one product is plain bf16: the check can fail)
-    pa16, ka = P.split2_f16(a)
-    pb16, kb = P.split2_f16(b)
-    err = (run(pa16, pb16, 48 + 3) * 2.0 ** -(ka + kb) - ref).abs().max().item() / scale
-    assert err < 5e-7 and err <= e_lib, (err, e_lib)
-    # the weight gradient's form: operands [K][M], [K][N] as they lie, transposed LDS reads
-    at, bt = a.t().contiguous(), b.t().contiguous()
-    pat, kat = P.split2_f16(at)
-    pbt, kbt = P.split2_f16(bt)
-    err = (run(pat, pbt, 64 + 48 + 3) * 2.0 ** -(kat + kbt) - ref).abs().max().item() / scale
-    assert err < 5e-7 and err <= e_lib, (err, e_lib)

@@ -9,7 +9,7 @@
 // partial sums written as fp32 [S][M][N].  Four waves, each 64 x 64 = 2 x 2 blocks of v_mfma_f32_32x32x16_bf16; operands staged
 // through LDS by LDS-DMA (global_load_lds_dwordx4) two chunks of 32 k deep, the 16-byte slots of a 64-byte row swizzled on the
 // source side so that the fragment reads (ds_read_b128) are conflict-free.
-#include "common.h"
+#include "../idelucs_amd/csrc/common.h"
 
 namespace {
 

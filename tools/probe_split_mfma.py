@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""What the step's big fp32 products would cost on the bf16 matrix cores with three-way split operands (csrc/probe_split.hip):
+"""What the step's big fp32 products would cost on the bf16 matrix cores with three-way split operands (tools/probe_split.hip: a probe, built here with hipcc and linked against the product library; not part of it):
     python3 tools/probe_split_mfma.py
 C = A B^T at the layer-1 forward's shape (A = a standardised batch [1024, 4096], B = W1 [512, 4096]), operands split
 x = x0 + x1 + x2 into bf16 planes on the device beforehand, 6 / 3 / 1 of the split products on v_mfma_f32_32x32x16_bf16, fp32
@@ -9,8 +9,23 @@ import ctypes
 import os
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 import torch  # noqa: E402
+
+
+def build_probe():
+    """hipcc tools/probe_split.hip -> /tmp/libidelucs_probe_split.so (linked against libidelucs_hip.so for its error text), loaded with ctypes."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    csrc = os.path.join(ROOT, "idelucs_amd", "csrc")
+    out = "/tmp/libidelucs_probe_split.so"
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-shared", os.path.join(ROOT, "tools", "probe_split.hip"), "-o", out,
+                    "-I", os.path.join(ROOT, "include"), "-L", csrc, "-lidelucs_hip", "-Wl,-rpath," + csrc], check=True)
+    lib = ctypes.CDLL(out)
+    lib.idl_debug_split_gemm.restype = ctypes.c_int
+    return lib
 
 
 def split3(x):
@@ -52,6 +67,7 @@ def main():
     args = ap.parse_args()
     from idelucs_amd import _lib
     L = _lib.lib
+    PROBE = build_probe()
     dev = torch.device("cuda")
     g = torch.Generator(device="cpu"); g.manual_seed(3)
     if args.shape in ("fwd", "wgrad_t"):
@@ -74,7 +90,7 @@ def main():
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
     def run(products):
-        _lib.check(L.idl_debug_split_gemm(*(ctypes.c_void_p(t.data_ptr()) for t in pa), *(ctypes.c_void_p(t.data_ptr()) for t in pb),
+        _lib.check(PROBE.idl_debug_split_gemm(*(ctypes.c_void_p(t.data_ptr()) for t in pa), *(ctypes.c_void_p(t.data_ptr()) for t in pb),
                                           ctypes.c_void_p(cpart.data_ptr()), M, N, K, S, products, st))
 
     out = torch.empty(M, N, dtype=torch.float32, device=dev)

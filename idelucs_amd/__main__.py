@@ -135,7 +135,7 @@ def run(args):
     fig.savefig(os.path.join(out_dir, "training_plots.jpg"))
 
     if not use_hdbscan:
-        if os.environ.get("IDELUCS_ENSEMBLE", "device") == "sklearn":
+        if posthoc.OPTIONS["ensemble"] == "sklearn":
             y_pred, probabilities = posthoc.label_features(preds, args["n_clusters"])
         else:                                                      # same ensemble on the GPU
             y_pred, probabilities = posthoc.label_features_device(preds, args["n_clusters"], device=model.device, seed=args.get("seed", 0))

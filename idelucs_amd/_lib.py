@@ -7,6 +7,9 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
+# IDELUCS_DEV="name=value,name=value": developer / diagnostic settings for the variant tables of fused.py, posthoc.py and utils.py (VARIANTS / OPTIONS:
+# launch-sequence and algorithm variants that were measured and not adopted, kept for the tests and tools that compare them with the default)
+DEV = dict(kv.split("=", 1) for kv in os.environ.get("IDELUCS_DEV", "").split(",") if "=" in kv)
 LIB_PATH = os.environ.get("IDELUCS_LIB_PATH") or os.path.join(_HERE, "csrc", "libidelucs_hip.so")   # (override: A/B of two builds)
 
 IDL_FALLBACK = 1

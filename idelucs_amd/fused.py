@@ -46,6 +46,32 @@ def planes_default():
     return os.environ.get("IDELUCS_PLANES", "1") != "0" and not _PLANES_DISABLED
 
 
+# Launch-sequence variants kept because tests compare them with the default form (each was measured and not adopted: DESIGN, History).  They are
+# NOT environment switches (round 6: 27 of them used to be): a test sets an entry with monkeypatch.setitem(fused.VARIANTS, ...) before it builds a trainer.
+VARIANTS = {
+    "nce_fused": "1",        # 0: S = f f^T as a GEMM + row kernels instead of the fused InfoNCE passes
+    "dw3_partial": "1",      # 0: dW3 as a GEMM instead of stacked partials from the middle-backward launch (n_clusters <= 48)
+    "test_cold": "0",        # 1: a 512 MB fill in front of the hand-scheduled launches (tests/test_gpu_planes.py::test_cold_caches_*)
+    "planes_reduce": "launch",   # mid: mid_fwd adds the eight K-slice partial sums itself
+    "planes_fork": "0",      # 1: the pending tail on a second stream beside the layer-1 tiles
+    "lockstep_planes": "1",  # 0: a rank's voters in lockstep on batched fp32 library GEMMs
+    "planes_wgrad": "1",     # 0: dW1 on the fp32 tiles (writing W1's planes) beside the two-plane layer 1
+    "planes_tail": "wgrad",  # reduce: the optimizer tail beside the next step's partial sums instead of on the dW1 tiles' loader waves
+    "mid_fused": "1", "pipeline": "1", "dw2_inlaunch": "1", "overlap": "0", "early_gather": "1", "gather_split": "4", "transposed_l1": "1",
+    "l1_fused": "0",         # 1: bias / ReLU / Dropout / the K-split of Linear(512, 64) in the epilogue of own layer-1 tiles; bare: those tiles as a plain product
+    "l1_gather": "0", "nce_bwd_fused": "0", "joint_inlaunch": "1", "wgrad_fused": "1", "keep_w1_grad": "0", "steps_per_graph": "16",
+    "tail_l1": "1",          # 0 (fp32 form): the optimizer tail behind the dW1 tiles instead of riding in the next step's layer-1 launch
+}
+
+
+VARIANTS["fused"] = "1"      # 0: models.IID_model trains NetLinear + RMSprop through torch autograd instead of the fused explicit step
+VARIANTS.update({k: v for k, v in _lib.DEV.items() if k in VARIANTS})
+
+
+def _v(name):
+    return VARIANTS[name]
+
+
 def disable_planes():
     """From here on every trainer of this process runs the fp32 tiles (the data left the fp16 planes' range once: it will again)."""
     global _PLANES_DISABLED
@@ -80,12 +106,12 @@ class _Buffers:
         self.inv = torch.empty((m,), **f32)
         self.r2 = torch.empty((m, H2), **f32)
         self.z = torch.empty((m, C), **f32)
-        self.S = torch.empty((m, m) if not (_L.idl_nce_fused_workspace(m) > 0 and os.environ.get("IDELUCS_NCE_FUSED", "1") != "0") else (1, 1), **f32)
+        self.S = torch.empty((m, m) if not (_L.idl_nce_fused_workspace(m) > 0 and _v("nce_fused") != "0") else (1, 1), **f32)
         self.lse = torch.empty((m,), **f32)
         self.loss_rows = torch.empty((m,), **f32)
         self.nce_parts = _L.idl_nce_fused_parts()
         self.nce_ws_bytes = _L.idl_nce_fused_workspace(m)            # -1: shape not supported by the fused InfoNCE kernels
-        self.nce_fused = self.nce_ws_bytes > 0 and os.environ.get("IDELUCS_NCE_FUSED", "1") != "0"
+        self.nce_fused = self.nce_ws_bytes > 0 and _v("nce_fused") != "0"
         self.G = torch.empty((self.nce_parts if self.nce_fused else 1, m, H2), **f32)
         self.nce_ws = torch.empty(max(self.nce_ws_bytes, 4) // 4, **f32)
         self.P0 = torch.empty((C, C), **f32)
@@ -159,7 +185,7 @@ class FusedLinearTrainer:
         # bias gradients are kept as COL_PARTS stacked partial column sums, added up inside idl_rmsprop_step
         self.parts = [1 if p.dim() == 2 else _L.idl_col_sum_parts() for p in self.params]
         # the last layer's weight gradient (C x 64) is produced as partials by the bias-gradient launch when C <= 48
-        self._dw3_partial = self.C <= 48 and os.environ.get("IDELUCS_DW3_PARTIAL", "1") != "0"
+        self._dw3_partial = self.C <= 48 and _v("dw3_partial") != "0"
         if self._dw3_partial:
             self.parts[4] = _L.idl_col_sum_parts()
         self.grads = [torch.zeros((q,) + tuple(p.shape), dtype=p.dtype, device=p.device) if q > 1 else torch.zeros_like(p)
@@ -180,7 +206,7 @@ class FusedLinearTrainer:
         # TEST HOOK (IDELUCS_TEST_COLD=1; tests/test_gpu_planes.py): a 512 MB fill in front of the step's middle and of each plane kernel, so that every load of
         # the hand-scheduled kernels comes from HBM instead of a warm L2/MALL -- a load consumed before its wait is right when it landed
         # early and wrong when it did not (DESIGN.md History, round 5), and only cold caches show that
-        self._cold = os.environ.get("IDELUCS_TEST_COLD", "0") == "1"
+        self._cold = _v("test_cold") == "1"
         self._cold_buf = None
         # Round 5, default (IDELUCS_PLANES=0: the fp32 tiles below; csrc/planes.h): the two big products on the fp16 matrix cores from operands kept
         # as two fp16 planes (22 significand bits a factor, three products, fp32 accumulators: closer to a float64 product than an fp32 GEMM) --
@@ -188,18 +214,18 @@ class FusedLinearTrainer:
         # 100.6 us against 111.0 at cfg2 (tools/bench_planes.py).  Needs the default launch sequence of a single voter (tail-in-layer-1),
         # m % 128 == 0 and F % 512 == 0; any other step runs the fp32 tiles.
         self._planes = planes_default()
-        self._planes_reduce_launch = os.environ.get("IDELUCS_PLANES_REDUCE", "launch") != "mid"
-        self._planes_fork = os.environ.get("IDELUCS_PLANES_FORK", "0") == "1"
+        self._planes_reduce_launch = _v("planes_reduce") != "mid"
+        self._planes_fork = _v("planes_fork") == "1"
         # ... and the same for a rank's voters in lockstep (BatchedLinearTrainer; IDELUCS_LOCKSTEP_PLANES=0: their products as batched fp32
         # library GEMMs instead): the six launches of the two-plane step recorded per voter and run once for all of them, blockIdx.y = voter
         # -- the lone voters' steps bit for bit (tests/test_gpu_planes.py), 47.5 / 45.4 / 43.6 ms a voter-epoch in batches of 2 / 4 / 8
         # against 54.2 alone (fp32 GEMMs: 58.9 / 54.8 / 52.6)
-        self._planes_lockstep = os.environ.get("IDELUCS_LOCKSTEP_PLANES", "1") != "0"
+        self._planes_lockstep = _v("lockstep_planes") != "0"
         # ... and dW1 from the batch's planes too (csrc/wgrad_planes.hip); the assembling workgroups then write the planes ONLY
-        self._planes_wgrad = os.environ.get("IDELUCS_PLANES_WGRAD", "1") != "0"
+        self._planes_wgrad = _v("planes_wgrad") != "0"
         # ... whose loader waves run the step's optimizer tail under the tiles' epilogue (IDELUCS_PLANES_TAIL=reduce: the tail beside the
         # next step's partial sums instead, 9.4 us for that launch against 4.7)
-        self._planes_tail_wgrad = os.environ.get("IDELUCS_PLANES_TAIL", "wgrad") != "reduce"
+        self._planes_tail_wgrad = _v("planes_tail") != "reduce"
         self._cus = torch.cuda.get_device_properties(self.dev).multi_processor_count if self.dev.type == "cuda" else 0
         self._ctl_snap = torch.zeros(1, dtype=torch.int64, device=self.dev)       # the step counter as the step's reduce launch saw it (idl_wgrad_xplanes_rms)
         self._w1_planes = None                   # (W1 hi, W1 lo, overflow flag)
@@ -208,51 +234,51 @@ class FusedLinearTrainer:
         self._dr1_scale[1:2].fill_(int(_L.idl_planes_exponent(2)))
         self._w1_planes_fresh = False
         # the layers between the two big GEMMs as one 1024-thread MFMA kernel per direction (idl_mid_fwd / idl_mid_bwd)
-        self._mid_fused = self.H1 == 512 and os.environ.get("IDELUCS_MID_FUSED", "1") != "0"
-        self._pipeline = os.environ.get("IDELUCS_PIPELINE", "1") != "0"   # optimizer launch also assembles the next batch
+        self._mid_fused = self.H1 == 512 and _v("mid_fused") != "0"
+        self._pipeline = _v("pipeline") != "0"   # optimizer launch also assembles the next batch
         # dW2 = dlat^T r1 as 16 x 16 MFMA tiles inside the optimizer launch (idl_rmsprop_step_gather_wgrad) instead of a GEMM launch
-        self._dw2_inlaunch = self.H1 % 16 == 0 and os.environ.get("IDELUCS_DW2_INLAUNCH", "1") != "0"
-        self._overlap = os.environ.get("IDELUCS_OVERLAP", "0") != "0"   # measured: no gain inside a HIP graph on ROCm 7.2
+        self._dw2_inlaunch = self.H1 % 16 == 0 and _v("dw2_inlaunch") != "0"
+        self._overlap = _v("overlap") != "0"   # measured: no gain inside a HIP graph on ROCm 7.2
         # the NEXT batch is assembled by spare workgroups of the mid-forward / mid-backward launches into a second x buffer (instead
         # of by the optimizer launch, where it competed with RMSprop for HBM): needs the fused middle kernels and n_clusters <= 48
         self._early_gather = (self._pipeline and self._mid_fused and self.C <= 48 and self.F % 4 == 0
-                              and os.environ.get("IDELUCS_EARLY_GATHER", "1") != "0")
-        self._early_split = os.environ.get("IDELUCS_EARLY_GATHER", "1") != "2"       # 2: all of it in the mid-backward launch
+                              and _v("early_gather") != "0")
+        self._early_split = _v("early_gather") != "2"       # 2: all of it in the mid-backward launch
         # n_clusters > 48 (fine-grained mode, 200 outputs): the backward runs as separate kernels, so ALL of the next batch's tiles ride
         # in the mid-forward launch
         self._early_fwd = (self._pipeline and self._mid_fused and self.C > 48 and self.F % 4 == 0 and self._dw2_inlaunch
-                           and os.environ.get("IDELUCS_EARLY_GATHER", "1") != "0")
-        self._gsplit = min(max(int(os.environ.get("IDELUCS_GATHER_SPLIT", "4")), 0), 8)   # eighths of the tiles the mid-forward launch takes
+                           and _v("early_gather") != "0")
+        self._gsplit = min(max(int(_v("gather_split")), 0), 8)   # eighths of the tiles the mid-forward launch takes
         # layer-1 activations kept transposed ([512, m]) between the layer-1 product and its consumers
-        self._transposed_l1 = os.environ.get("IDELUCS_TRANSPOSED_L1", "1") != "0"
+        self._transposed_l1 = _v("transposed_l1") != "0"
         # OPT-IN (IDELUCS_L1_FUSED=1; measured, not adopted -- DESIGN 4.4): the layer-1 product on this package's own MFMA tiles with bias /
         # ReLU / Dropout and the K-split of Linear(512, 64) in its epilogue (csrc/l1_fwd.hip, idl_l1_fwd); the mid-forward launch is then
         # the head alone.  The bare product ties hipBLASLt (32.1-33.1 us against 32.8-33.7) and the head's own path shrinks from 8.9 to
         # 2.6 us, but that launch's LENGTH is set by the batch assembly riding in it (three dependent memory round trips, ~8-10 us),
         # which stays: 36.4 + 10.4 us against 32.8 + 11.0, the step 114.7 us against 111.8.
-        self._l1_fused = os.environ.get("IDELUCS_L1_FUSED", "0") == "1"
+        self._l1_fused = _v("l1_fused") == "1"
         # IDELUCS_L1_FUSED=bare: the same tiles as a plain product (no epilogue) in place of the library GEMM, mid_fwd unchanged
-        self._l1_bare = os.environ.get("IDELUCS_L1_FUSED", "0") == "bare"
+        self._l1_bare = _v("l1_fused") == "bare"
         # eighths of the next batch's tiles assembled by RIDER workgroups of that launch (default 0: beside fp32 MFMA waves, which hold
         # the vector issue port, the riders' arithmetic costs the tiles 9 us for the 7 us it saves the middle launches)
-        self._l1_gather = min(max(int(os.environ.get("IDELUCS_L1_GATHER", "0")), 0), 8)   # eighths of the next batch's tiles its riders assemble
+        self._l1_gather = min(max(int(_v("l1_gather")), 0), 8)   # eighths of the next batch's tiles its riders assemble
         # opt-in: InfoNCE pass 2 + IIC core inside the mid-backward launch (one boundary less, but the InfoNCE tiles then run on
         # the 64 CUs of that launch instead of 256: the fused launch takes 32.8 us against 9.5 + 13.5 -- measured +8 us per step)
-        self._nce_bwd_fused = os.environ.get("IDELUCS_NCE_BWD_FUSED", "0") != "0"
-        self._joint_inlaunch = os.environ.get("IDELUCS_JOINT_INLAUNCH", "1") != "0"   # IIC joint inside the InfoNCE pass-1 launch
+        self._nce_bwd_fused = _v("nce_bwd_fused") != "0"
+        self._joint_inlaunch = _v("joint_inlaunch") != "0"   # IIC joint inside the InfoNCE pass-1 launch
         # dW1 on this package's own MFMA tiles with RMSprop in their epilogue, as the head of the optimizer launch
         # (csrc/wgrad_device.h, idl_wgrad_rmsprop_step): one launch instead of hipBLASLt's GEMM + the optimizer launch, and the 8 MB
         # gradient never goes to memory.  IDELUCS_WGRAD_FUSED=0: hipBLASLt + optimizer launch; =2: the tiles as a launch of their own
-        self._wgrad_fused = os.environ.get("IDELUCS_WGRAD_FUSED", "1") != "0"
-        self._wgrad_own_launch = os.environ.get("IDELUCS_WGRAD_FUSED", "1") == "2"
-        self._keep_w1_grad = os.environ.get("IDELUCS_KEEP_W1_GRAD", "0") != "0"       # tests: also write dW1 to grads[0]
-        self._steps_per_graph = max(2, int(os.environ.get("IDELUCS_STEPS_PER_GRAPH", "16")) // 2 * 2)
+        self._wgrad_fused = _v("wgrad_fused") != "0"
+        self._wgrad_own_launch = _v("wgrad_fused") == "2"
+        self._keep_w1_grad = _v("keep_w1_grad") != "0"       # tests: also write dW1 to grads[0]
+        self._steps_per_graph = max(2, int(_v("steps_per_graph")) // 2 * 2)
         # Round 5 (IDELUCS_TAIL_L1, default on): the layer-1 product on this package's own tiles (idl_l1_fwd: no library build decides
         # its speed) and the optimizer's TAIL -- the dW2 tiles, the small tensors, step loss, step counter: 5.8 us behind the dW1 tiles
         # of the optimizer launch, where they cannot become resident beside a tile -- riding in the layer-1 launch of the NEXT step
         # (idl_l1_fwd_rms), where they have 30 us of slack.  A step then ends with the dW1 tiles alone; its tail is pending until the
         # next step's first launch, or flush_tail().  Only the default launch sequence of a single voter takes it.
-        self._tail_l1 = os.environ.get("IDELUCS_TAIL_L1", "1") != "0"
+        self._tail_l1 = _v("tail_l1") != "0"
         self._pending = None                     # (buffers, parity) of the step whose tail has not run yet
         self._perm = None
         n = len(self.params)

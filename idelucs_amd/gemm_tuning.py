@@ -25,6 +25,8 @@ _enabled = False
 _tuning = False
 
 
+DUMP_TO = None          # a path: maybe_enable() writes the tuned solutions there at exit
+
 def _unlink_quietly(path):
     try:
         os.unlink(path)
@@ -48,7 +50,7 @@ def maybe_enable(total_steps=None):
             _tuning = True
         return True
     # one result file per process (ranks of a multi-GPU job must not share one), seeded from the shipped solutions
-    dump = os.environ.get("IDELUCS_TUNABLEOP_DUMP")     # maintainers: write the tuned solutions there at exit (to refresh SEED_FILE)
+    dump = DUMP_TO                                        # maintainers (tools/): write the tuned solutions there at exit, to refresh SEED_FILE
     if dump:
         path = dump
         flags = os.O_WRONLY | os.O_CREAT | os.O_TRUNC | getattr(os, "O_NOFOLLOW", 0)

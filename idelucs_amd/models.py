@@ -39,6 +39,11 @@ def weights_init(m, generator=None):
         torch.nn.init.zeros_(m.bias)
 
 
+def _fused_on():
+    from . import fused
+    return fused.VARIANTS["fused"] != "0"
+
+
 class PlanesOverflow(RuntimeError):
     """An operand of the training step's two big products left the range of its fp16 planes (IID_model._check_planes)."""
 
@@ -100,7 +105,7 @@ class IID_model():
         # default configuration (NetLinear + RMSprop): explicit fused step replayed as a HIP graph
         self._fused = None
         self._use_fused = (args['model_size'] == 'linear' and args['optimizer'] == 'RMSprop'
-                           and args['n_clusters'] <= 256 and os.environ.get("IDELUCS_FUSED", "1") != "0")
+                           and args['n_clusters'] <= 256 and _fused_on())
 
     def _make_scheduler(self):
         if self.schedule == 'Plateau':                          # models.py:96-99

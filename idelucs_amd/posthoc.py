@@ -4,6 +4,22 @@ on the host with sklearn/scipy, as in the reference, on the outputs gathered fro
 """
 import os
 
+# Variants kept for the tests that compare them with the default path (not environment switches; a test sets an entry with monkeypatch.setitem)
+OPTIONS = {"knn": "",            # matrix | window: force one of the core-distance paths
+           "mst": "lazy",        # lazy | local | plain: which Prim
+           "mst_filter": "1",    # 0: no 8-bit lower bound in front of the exact distances
+           "silhouette": "",     # gemm: the float64 GEMM form instead of the one-pass kernel
+           "ensemble": "device"}  # sklearn: label_features on the host
+
+
+def _dev_options():
+    from . import _lib
+    OPTIONS.update({k: v for k, v in _lib.DEV.items() if k in OPTIONS})
+
+
+_dev_options()
+
+
 import numpy as np
 
 
@@ -155,7 +171,7 @@ def silhouette_score_device(data, labels, device=None, block=4096):
     if not 2 <= k <= n - 1:
         raise ValueError("Number of labels is %d. Valid values are 2 to n_samples - 1 (inclusive)" % k)      # sklearn's check
     lab = torch.from_numpy(inv.astype(np.int64)).to(dev)
-    if x.shape[1] == 64 and n >= SILHOUETTE_ONE_PASS_MIN and os.environ.get("IDELUCS_SILHOUETTE", "") != "gemm":
+    if x.shape[1] == 64 and n >= SILHOUETTE_ONE_PASS_MIN and OPTIONS["silhouette"] != "gemm":
         return float(_silhouette_one_pass(x, lab, k, dev).item() / n)
     onehot = torch.zeros((n, k), dtype=torch.float32, device=dev)
     onehot[torch.arange(n, device=dev), lab] = 1.0
@@ -479,7 +495,7 @@ def core_distances_device(x64, k, device, f32_exact=None, stats=None, order=None
     n = x64.shape[0]
     sq = (x64 * x64).sum(1)
     core = torch.empty(n, dtype=torch.float64, device=device)
-    mode = os.environ.get("IDELUCS_KNN", "")
+    mode = OPTIONS["knn"]
     if f32_exact is None:
         f32_exact = bool((x64.to(torch.float32).double() == x64).all())
     todo = None
@@ -575,7 +591,7 @@ def hdbscan_device(points, min_cluster_size, device=None, stats=None, core=None,
     f32_exact = bool(np.array_equal(pts.astype(np.float32).astype(np.float64), pts))
     import time
     t0 = time.time()
-    use_filter = d % 4 == 0 and d <= 64 and n >= MST_FILTER_MIN and os.environ.get("IDELUCS_MST_FILTER", "1") != "0"
+    use_filter = d % 4 == 0 and d <= 64 and n >= MST_FILTER_MIN and OPTIONS["mst_filter"] != "0"
     order = _spatial_order(x64) if use_filter else None
     if core is None:
         core = core_distances_device(x64, min(core_neighbour_rank(k), n), dev, f32_exact=f32_exact, stats=stats, order=order, shard=shard)
@@ -601,7 +617,7 @@ def hdbscan_device(points, min_cluster_size, device=None, stats=None, core=None,
         start = int(torch.nonzero(perm == 0)[0, 0])
         del xo
         n_groups = int(gid32[-1]) + 1
-        mode = os.environ.get("IDELUCS_MST", "lazy")
+        mode = OPTIONS["mst"]
         if mode == "lazy" and f32_exact and d == 64 and MST_LAZY_MIN <= n <= MST_LAZY_MAX and n_groups <= min(1024, -(-n // 256)):
             # groups of points may sleep while the tree grows elsewhere (idl_mst_prim_lazy): a ball around every group, the points row-major
             xo = x64[perm]
@@ -666,7 +682,7 @@ def core_distances_sharded(latent, device=None):
     pts = np.ascontiguousarray(latent, dtype=np.float64)
     x64 = torch.from_numpy(pts).to(dev)
     k = max(n // 100 + 1, 2)
-    use_filter = pts.shape[1] % 4 == 0 and pts.shape[1] <= 64 and n >= MST_FILTER_MIN and os.environ.get("IDELUCS_MST_FILTER", "1") != "0"
+    use_filter = pts.shape[1] % 4 == 0 and pts.shape[1] <= 64 and n >= MST_FILTER_MIN and OPTIONS["mst_filter"] != "0"
     # the memory order hdbscan_device will use (same seed, same groups) -- rank 0's, broadcast: it comes out of a float64 GEMM + argmin,
     # and two ranks whose libraries pick different kernels could place a boundary point in different groups.  Without
     # the filter the window pass builds its own order: the same broadcast

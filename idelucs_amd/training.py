@@ -50,7 +50,8 @@ def _leave_planes(lane_models, err):
 def plane_step_applies(model):
     """Whether a lone voter of this model trains with the two big products of its step on the fp16 matrix cores (fused.FusedLinearTrainer._planes:
     NetLinear, full batches of 2 x batch_sz rows with 128 | 2 batch_sz, 512 | F, F >= 1024)."""
-    if os.environ.get("IDELUCS_PLANES", "1") == "0" or not getattr(model, "_use_fused", False):
+    from . import fused
+    if not fused.planes_default() or not getattr(model, "_use_fused", False):
         return False
     try:
         lin1 = model.net.layers[0]
@@ -70,8 +71,8 @@ def voter_lanes(n_voters_here, model=None):
     fp32 library GEMMs (58.9 / 54.8 / 52.6 ms): a lone voter on planes then beats a batch of 2, and two voters train one after the other."""
     env = os.environ.get("IDELUCS_VOTER_LANES")
     lanes = max(1, min(int(env) if env is not None else 8, n_voters_here))
-    if (env is None and model is not None and lanes == 2 and plane_step_applies(model)
-            and os.environ.get("IDELUCS_LOCKSTEP_PLANES", "1") == "0"):
+    from . import fused
+    if env is None and model is not None and lanes == 2 and plane_step_applies(model) and fused.VARIANTS["lockstep_planes"] == "0":
         return 1
     return lanes
 
@@ -80,10 +81,10 @@ def can_batch(model):
     """Voters can be batched when the model runs the default fused launch sequence (NetLinear + RMSprop, n_clusters <= 48, full
     batches a multiple of 16 rows) and no scheduler reads the epoch loss on the host between epochs."""
     # (the CLI hands the scheduler over as the reference does, as a string: "None" unless Plateau / Triangle was asked for)
+    from . import fused
     return bool(model._use_fused and model.n_clusters <= 48 and model.batch_sz % 16 == 0
                 and model.schedule not in ('Plateau', 'Triangle')
-                and os.environ.get("IDELUCS_PIPELINE", "1") != "0" and os.environ.get("IDELUCS_EARLY_GATHER", "1") == "1"
-                and os.environ.get("IDELUCS_MID_FUSED", "1") != "0")
+                and fused.VARIANTS["pipeline"] != "0" and fused.VARIANTS["early_gather"] == "1" and fused.VARIANTS["mid_fused"] != "0")
 
 
 def train_voters(model, voters, n_epochs, n_voters=None, lanes=None, progress=True):

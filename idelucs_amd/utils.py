@@ -30,6 +30,12 @@ _CODE = np.full(256, 4, np.uint8)
 _CODE[[A, C, G, T]] = [0, 1, 2, 3]
 
 
+# Variants kept for the tests that compare them with the default path (not environment switches; a test sets an entry with monkeypatch.setitem)
+OPTIONS = {"mimic_slots": "1",       # 0: the exact two-call protocol of the site generator (count, scan, fill) instead of one pass into slots
+           "predict_counts": "1",    # 0: predict inputs through float64 rows instead of int32 counts
+           "one_pass": "1"}          # 0: the general three-pass FASTA reader instead of idl_fasta_parse_pack
+OPTIONS.update({k: v for k, v in _lib.DEV.items() if k in OPTIONS})
+
 def _default_rng_mode():
     return os.environ.get("IDELUCS_RNG", "philox")
 
@@ -452,7 +458,7 @@ def _philox_edits(dev_in, specs, seed, capacity=None, slots=None, sync=None):
     args = (_ptr(dev_in.lengths), dev_in.n, P, _ptr(p_ts), _ptr(p_tv), _ptr(n_rn), ctypes.c_uint64(seed & (2 ** 64 - 1)))
     forced = slots is True
     if slots is None:
-        slots = os.environ.get("IDELUCS_MIMIC_SLOTS", "1") != "0"
+        slots = OPTIONS["mimic_slots"] != "0"
     edits = None
     if slots and dev_in.n > 0:
         total = int(_L.idl_mimic_slots_capacity(dev_in.n, P, _ptr(p_ts), _ptr(p_tv), _ptr(n_rn), max_len))
@@ -646,7 +652,7 @@ def standardise(x, mean, scale, out=None):
 def counts_route_ok(k, reduce=False):
     """The predict inputs can be formed from int32 counts (idl_counts_stats / idl_counts_standardise) for plain k-mer rows of 4^k
     columns with 4^k / 4 a multiple of 64: k = 4..7.  IDELUCS_PREDICT_COUNTS=0: always the float64 rows."""
-    return (not reduce) and 4 <= k <= 7 and os.environ.get("IDELUCS_PREDICT_COUNTS", "1") != "0"
+    return (not reduce) and 4 <= k <= 7 and OPTIONS["predict_counts"] != "0"
 
 
 def predict_inputs_from_counts(din, k, rows=None, workspace=None):
@@ -845,7 +851,7 @@ def build_feature_store(sequence_file, n_mimics, k=6, reduce=False, rng=None, se
                 and reuse.k == k and reuse.reduce == reduce and reuse.feats.is_contiguous()):
             return reuse.feats
         return torch.empty((len(tfs), n, row), dtype=torch.float32, device=dev)
-    if streamed and rng == "philox" and fasta is None and os.environ.get("IDELUCS_ONE_PASS", "1") != "0":
+    if streamed and rng == "philox" and fasta is None and OPTIONS["one_pass"] != "0":
         import time
         timing = os.environ.get("IDELUCS_INGEST_TIMING") is not None
         q = [time.perf_counter()]
@@ -976,7 +982,7 @@ def predict_features(sequence_file, k=6, reduce=False, device=None, fasta=None, 
     every rank recomputes the cheap statistics locally -- bit-identical everywhere, no collective -- and embeds its shard)."""
     dev = _device(device)
     din = None
-    if fasta is None and os.environ.get("IDELUCS_ONE_PASS", "1") != "0":
+    if fasta is None and OPTIONS["one_pass"] != "0":
         din = _OnePassInput.create(sequence_file, dev)             # one pass over the file, copies in flight while parsing
         if din is not None:
             ff = din.ff

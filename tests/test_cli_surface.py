@@ -57,7 +57,7 @@ def test_lane_policy_of_a_ranks_voters(monkeypatch):
     from idelucs_amd import training
     monkeypatch.delenv("IDELUCS_VOTER_LANES", raising=False)
     monkeypatch.delenv("IDELUCS_PLANES", raising=False)
-    monkeypatch.delenv("IDELUCS_LOCKSTEP_PLANES", raising=False)
+    monkeypatch.setitem(__import__("idelucs_amd.fused", fromlist=["VARIANTS"]).VARIANTS, "lockstep_planes", "1")
 
     def model(F, batch_sz, fused=True, H1=512):
         net = types.SimpleNamespace(layers=[torch.nn.Linear(F, H1)])
@@ -67,7 +67,7 @@ def test_lane_policy_of_a_ranks_voters(monkeypatch):
     assert not training.plane_step_applies(model(256, 512)) and not training.plane_step_applies(model(4096, 48))
     assert not training.plane_step_applies(model(4096, 512, fused=False)) and not training.plane_step_applies(model(4096, 512, H1=256))
     assert [training.voter_lanes(n, cfg2) for n in (1, 2, 3, 4, 8, 11)] == [1, 2, 3, 4, 8, 8]
-    monkeypatch.setenv("IDELUCS_LOCKSTEP_PLANES", "0")
+    monkeypatch.setitem(__import__("idelucs_amd.fused", fromlist=["VARIANTS"]).VARIANTS, "lockstep_planes", "0")
     assert [training.voter_lanes(n, cfg2) for n in (1, 2, 3, 4, 8, 11)] == [1, 1, 3, 4, 8, 8]
     assert [training.voter_lanes(n, model(256, 512)) for n in (1, 2, 4, 8)] == [1, 2, 4, 8]        # k = 4: the fp32 step, lockstep pays
     assert [training.voter_lanes(n) for n in (1, 3, 9)] == [1, 3, 8]
@@ -312,7 +312,7 @@ def test_silhouette_in_one_pass_equals_sklearn(monkeypatch):
     lab = rng.integers(0, 9, 50000)
     x = centres[lab] + rng.normal(size=(50000, 64))
     one = posthoc.silhouette_score_device(x, lab)
-    monkeypatch.setenv("IDELUCS_SILHOUETTE", "gemm")
+    monkeypatch.setitem(__import__("idelucs_amd.posthoc", fromlist=["OPTIONS"]).OPTIONS, "silhouette", "gemm")
     two = posthoc.silhouette_score_device(x, lab)
     assert abs(one - two) < 2e-5, (one, two)
 

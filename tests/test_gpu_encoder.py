@@ -490,7 +490,7 @@ def test_batched_voters_take_the_own_layer1_tiles_too(dev, monkeypatch):
     import torch
     import torch.cuda.tunable as tunable
     from idelucs_amd.fused import FusedLinearTrainer, BatchedLinearTrainer
-    monkeypatch.setenv("IDELUCS_L1_FUSED", "1")
+    monkeypatch.setitem(__import__("idelucs_amd.fused", fromlist=["VARIANTS"]).VARIANTS, "l1_fused", "1")
     was_on = tunable.is_enabled()
     tunable.enable(False)
     try:
@@ -1258,8 +1258,8 @@ def test_tail_riding_in_the_layer1_launch_changes_no_bit(dev, monkeypatch, n, us
     out = []
     monkeypatch.setenv("IDELUCS_PLANES", "0")       # (the fp32 form of the step: the two-plane form has its own tests, test_gpu_planes.py)
     for tail, bare in (("1", "0"), ("0", "bare")):
-        monkeypatch.setenv("IDELUCS_TAIL_L1", tail)
-        monkeypatch.setenv("IDELUCS_L1_FUSED", bare)
+        monkeypatch.setitem(__import__("idelucs_amd.fused", fromlist=["VARIANTS"]).VARIANTS, "tail_l1", tail)
+        monkeypatch.setitem(__import__("idelucs_amd.fused", fromlist=["VARIANTS"]).VARIANTS, "l1_fused", bare)
         net = copy.deepcopy(net0)
         tr = FusedLinearTrainer(net, lr=1e-3, weight=0.25, lamb=2.8, seed=5)
         assert tr._tail_l1 == (tail == "1") and tr._l1_bare == (bare == "bare")
@@ -1274,7 +1274,7 @@ def test_tail_riding_in_the_layer1_launch_changes_no_bit(dev, monkeypatch, n, us
     for a, b in zip(pa + va, pb + vb):
         assert torch.equal(a, b)
     # a step taken alone (tests, callers outside run_epoch) is complete when it returns: nothing stays pending
-    monkeypatch.setenv("IDELUCS_TAIL_L1", "1"); monkeypatch.setenv("IDELUCS_L1_FUSED", "0")
+    monkeypatch.setitem(__import__("idelucs_amd.fused", fromlist=["VARIANTS"]).VARIANTS, "tail_l1", "1"); monkeypatch.setitem(__import__("idelucs_amd.fused", fromlist=["VARIANTS"]).VARIANTS, "l1_fused", "0")
     tr = FusedLinearTrainer(copy.deepcopy(net0), lr=1e-3, weight=0.25, lamb=2.8, seed=5)
     tr._perm = torch.randperm(store.n_pairs, device=dev)
     bf = tr.buffers(2 * B)

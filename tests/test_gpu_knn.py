@@ -46,9 +46,9 @@ def test_window_core_distances_are_the_kth_neighbour_distances(n, sample, offset
     if sample:
         monkeypatch.setattr(posthoc, "KNN_SAMPLE", sample)
     stats = {}
-    monkeypatch.setenv("IDELUCS_KNN", "window")
+    monkeypatch.setitem(__import__("idelucs_amd.posthoc", fromlist=["OPTIONS"]).OPTIONS, "knn", "window")
     got = posthoc.core_distances_device(xd, k, dev, stats=stats).cpu().numpy()
-    monkeypatch.setenv("IDELUCS_KNN", "matrix")
+    monkeypatch.setitem(__import__("idelucs_amd.posthoc", fromlist=["OPTIONS"]).OPTIONS, "knn", "matrix")
     ref = posthoc.core_distances_device(xd, k, dev).cpu().numpy()
     print(stats)
     assert stats["missed"] <= max(8, n // 2000), "the bracket misses far more rows than its 4.5 sigma promise"
@@ -68,9 +68,9 @@ def test_window_core_distances_with_duplicates_and_tiny_k(monkeypatch):
     xd = torch.from_numpy(x).to(dev)
     for k in (121, 2):
         stats = {}
-        monkeypatch.setenv("IDELUCS_KNN", "window")
+        monkeypatch.setitem(__import__("idelucs_amd.posthoc", fromlist=["OPTIONS"]).OPTIONS, "knn", "window")
         got = posthoc.core_distances_device(xd, k, dev, stats=stats).cpu().numpy()
-        monkeypatch.setenv("IDELUCS_KNN", "matrix")
+        monkeypatch.setitem(__import__("idelucs_amd.posthoc", fromlist=["OPTIONS"]).OPTIONS, "knn", "matrix")
         ref = posthoc.core_distances_device(xd, k, dev).cpu().numpy()
         print(k, stats)
         assert np.array_equal(got, ref)
@@ -82,9 +82,9 @@ def test_hdbscan_labels_do_not_depend_on_the_core_distance_path(monkeypatch):
     from idelucs_amd import posthoc
     x = _blobs(36000, seed=8)
     k = 36000 // 100 + 1
-    monkeypatch.setenv("IDELUCS_KNN", "window")
+    monkeypatch.setitem(__import__("idelucs_amd.posthoc", fromlist=["OPTIONS"]).OPTIONS, "knn", "window")
     l1, p1 = posthoc.hdbscan_device(x, k)
-    monkeypatch.setenv("IDELUCS_KNN", "matrix")
+    monkeypatch.setitem(__import__("idelucs_amd.posthoc", fromlist=["OPTIONS"]).OPTIONS, "knn", "matrix")
     l2, p2 = posthoc.hdbscan_device(x, k)
     assert np.array_equal(l1, l2) and np.array_equal(p1, p2)
 
@@ -107,7 +107,7 @@ def test_prim_with_the_8_bit_filter_builds_the_same_tree(monkeypatch, d, as_f32)
     k = 241
     with_filter, without = {}, {}
     l1, p1 = posthoc.hdbscan_device(x, k, stats=with_filter)
-    monkeypatch.setenv("IDELUCS_MST_FILTER", "0")
+    monkeypatch.setitem(__import__("idelucs_amd.posthoc", fromlist=["OPTIONS"]).OPTIONS, "mst_filter", "0")
     l2, p2 = posthoc.hdbscan_device(x, k, stats=without)
     a, b = with_filter["mst_edges"], without["mst_edges"]
     for f in ("current_node", "next_node", "distance"):
@@ -161,11 +161,11 @@ def test_lazy_prim_builds_the_same_tree(monkeypatch, kind):
     x = x.astype(np.float32).astype(np.float64)
     k = n // 100 + 1
     lazy, plain = {}, {}
-    monkeypatch.setenv("IDELUCS_MST", "lazy")
+    monkeypatch.setitem(__import__("idelucs_amd.posthoc", fromlist=["OPTIONS"]).OPTIONS, "mst", "lazy")
     l1, p1 = posthoc.hdbscan_device(x, k, stats=lazy)
     assert "prim_stalls" in lazy, "the lazy path did not run"
     print({kk: lazy[kk] for kk in ("prim_launches", "prim_stalls", "prim_censuses", "prim_s")})
-    monkeypatch.setenv("IDELUCS_MST", "local")
+    monkeypatch.setitem(__import__("idelucs_amd.posthoc", fromlist=["OPTIONS"]).OPTIONS, "mst", "local")
     l2, p2 = posthoc.hdbscan_device(x, k, stats=plain)
     a, b = lazy["mst_edges"], plain["mst_edges"]
     for f in ("current_node", "next_node", "distance"):
@@ -186,7 +186,7 @@ def test_core_distances_when_no_bracket_exists(monkeypatch):
     got = posthoc.core_distances_device(xd, k, dev).cpu().numpy()
     rows = np.arange(0, 5003, 500)
     assert np.array_equal(got[rows], _kth_by_definition(x, rows, k))
-    monkeypatch.setenv("IDELUCS_KNN", "window")
+    monkeypatch.setitem(__import__("idelucs_amd.posthoc", fromlist=["OPTIONS"]).OPTIONS, "knn", "window")
     with pytest.raises(ValueError):
         posthoc.core_distances_device(xd, k, dev)
 

@@ -305,9 +305,9 @@ def test_step_on_planes_trains_like_the_default_step(dev, monkeypatch, reduce):
     B = 512
     one, sums = {}, {}
     # the default (the sums as a launch, the tail on the dW1 kernel's loader waves) and the measured variants kept as switches
-    monkeypatch.setenv("IDELUCS_PLANES_REDUCE", "mid" if reduce == "mid" else "launch")
-    monkeypatch.setenv("IDELUCS_PLANES_TAIL", "reduce" if reduce == "tail_beside_the_sums" else "wgrad")
-    monkeypatch.setenv("IDELUCS_PLANES_WGRAD", "0" if reduce == "fp32_wgrad" else "1")
+    monkeypatch.setitem(__import__("idelucs_amd.fused", fromlist=["VARIANTS"]).VARIANTS, "planes_reduce", "mid" if reduce == "mid" else "launch")
+    monkeypatch.setitem(__import__("idelucs_amd.fused", fromlist=["VARIANTS"]).VARIANTS, "planes_tail", "reduce" if reduce == "tail_beside_the_sums" else "wgrad")
+    monkeypatch.setitem(__import__("idelucs_amd.fused", fromlist=["VARIANTS"]).VARIANTS, "planes_wgrad", "0" if reduce == "fp32_wgrad" else "1")
     for flag in ("0", "1"):
         monkeypatch.setenv("IDELUCS_PLANES", flag)
         tr = FusedLinearTrainer(copy.deepcopy(net0), lr=1e-3, weight=0.25, lamb=2.8, seed=5)
@@ -472,7 +472,7 @@ def test_lockstep_voters_on_planes_are_the_lone_voters(dev, monkeypatch, n, grap
     import test_gpu_encoder as E
     from idelucs_amd.fused import FusedLinearTrainer, BatchedLinearTrainer
     monkeypatch.setenv("IDELUCS_PLANES", "1")
-    monkeypatch.setenv("IDELUCS_LOCKSTEP_PLANES", "1")
+    monkeypatch.setitem(__import__("idelucs_amd.fused", fromlist=["VARIANTS"]).VARIANTS, "lockstep_planes", "1")
     bt = E._batched_like_single(dev, n, graph, copy, torch, FusedLinearTrainer, BatchedLinearTrainer, L=lanes)
     assert bt._planes_step and bt.L == lanes
     assert not any(t.planes_overflowed() for t in bt.trainers)
@@ -488,11 +488,11 @@ def test_cold_caches_leave_an_epoch_bit_identical(dev, monkeypatch, form):
     import test_gpu_encoder as E
     from idelucs_amd.fused import FusedLinearTrainer
     monkeypatch.setenv("IDELUCS_PLANES", "0" if form == "fp32" else "1")
-    monkeypatch.setenv("IDELUCS_PLANES_WGRAD", "0" if form == "planes_fp32_wgrad" else "1")
+    monkeypatch.setitem(__import__("idelucs_amd.fused", fromlist=["VARIANTS"]).VARIANTS, "planes_wgrad", "0" if form == "planes_fp32_wgrad" else "1")
     store, net0 = E._cfg2_store_and_net(dev, 4200, seed=4, C=200 if form == "planes_200_units" else 20)
     runs = []
     for cold in ("0", "1", "1", "1"):
-        monkeypatch.setenv("IDELUCS_TEST_COLD", cold)
+        monkeypatch.setitem(__import__("idelucs_amd.fused", fromlist=["VARIANTS"]).VARIANTS, "test_cold", cold)
         tr = FusedLinearTrainer(copy.deepcopy(net0), lr=1e-3, weight=0.25, lamb=2.8, seed=11)
         assert tr._cold == (cold == "1")
         tr.begin_voter(0)
@@ -511,8 +511,8 @@ def test_cold_caches_leave_lockstep_voters_the_lone_voters(dev, monkeypatch):
     import test_gpu_encoder as E
     from idelucs_amd.fused import FusedLinearTrainer, BatchedLinearTrainer
     monkeypatch.setenv("IDELUCS_PLANES", "1")
-    monkeypatch.setenv("IDELUCS_LOCKSTEP_PLANES", "1")
-    monkeypatch.setenv("IDELUCS_TEST_COLD", "1")
+    monkeypatch.setitem(__import__("idelucs_amd.fused", fromlist=["VARIANTS"]).VARIANTS, "lockstep_planes", "1")
+    monkeypatch.setitem(__import__("idelucs_amd.fused", fromlist=["VARIANTS"]).VARIANTS, "test_cold", "1")
     bt = E._batched_like_single(dev, 4200, False, copy, torch, FusedLinearTrainer, BatchedLinearTrainer)
     assert bt._planes_step and bt.trainers[0]._cold
 

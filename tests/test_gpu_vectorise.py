@@ -657,11 +657,11 @@ def test_predict_inputs_from_counts_equal_the_float64_route(tmp_path, k):
         assert torch.equal(tot.long(), counts.long().sum(1)) and torch.equal(m2, mean) and torch.equal(s2, scale)
     # through the product's entry (SequenceDataset's numbers are pinned to the reference golden elsewhere: test_predict... / seqdataset.npz)
     names, lengths, x = U.predict_features(os.path.join(DATA, "Influenza-A.fas"), k=k)
-    os.environ["IDELUCS_PREDICT_COUNTS"] = "0"
+    U.OPTIONS["predict_counts"] = "0"
     try:
         _, _, x_old = U.predict_features(os.path.join(DATA, "Influenza-A.fas"), k=k)
     finally:
-        del os.environ["IDELUCS_PREDICT_COUNTS"]
+        U.OPTIONS["predict_counts"] = "1"
     assert torch.equal(x, x_old)
 
 

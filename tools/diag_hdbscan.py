@@ -25,7 +25,7 @@ def main():
           f"{np.round(np.linalg.svd(x[rng.integers(0, n, 20000)] - x.mean(0), compute_uv=False)[:8], 2)}", flush=True)
     runs = [("default", {})]
     if "--compare" in sys.argv:
-        runs += [("IDELUCS_MST_FILTER=0", {"IDELUCS_MST_FILTER": "0"}), ("IDELUCS_KNN=matrix", {"IDELUCS_KNN": "matrix"})]
+        runs += [("IDELUCS_DEV=mst_filter=0", {"IDELUCS_DEV": "mst_filter=0"}), ("IDELUCS_DEV=knn=matrix", {"IDELUCS_DEV": "knn=matrix"})]
     ref = None
     for name, env in runs:
         os.environ.update(env)

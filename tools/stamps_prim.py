@@ -22,7 +22,7 @@ def main():
         fam = torch.randint(0, 8, (n,), generator=g)
         x = (centres[fam] + torch.randn(n, 64, generator=g) * 0.6).to(torch.float32).double().numpy()
     n = len(x)
-    for env in ({}, {"IDELUCS_MST_FILTER": "0"}):
+    for env in ({}, {"IDELUCS_DEV": "mst_filter=0"}):
         os.environ.update(env)
         out = (ctypes.c_ulonglong * 8)()
         _lib.check(_lib.lib.idl_debug_prim_phases(ctypes.cast(out, ctypes.c_void_p)))

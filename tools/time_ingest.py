@@ -85,11 +85,11 @@ def main():
             print(f"rep {rep}: " + ", ".join(f"{nm} {1e3 * (t[i + 1] - t[i]):.1f}" for i, nm in enumerate(names)) + " ms", flush=True)
             del feats, din, edits, edit_off, ff
             for one_pass in ("0", "1"):                             # the whole of build_feature_store(streamed=True), both readers
-                os.environ["IDELUCS_ONE_PASS"] = one_pass
+                U.OPTIONS["one_pass"] = one_pass
                 torch.cuda.synchronize(); q0 = time.perf_counter()
                 st = U.build_feature_store(path, 3, k=6, device=dev, streamed=True)
                 torch.cuda.synchronize(); q1 = time.perf_counter()
-                print(f"   build_feature_store(streamed) with IDELUCS_ONE_PASS={one_pass}: {1e3 * (q1 - q0):.1f} ms", flush=True)
+                print(f"   build_feature_store(streamed) with one_pass={one_pass}: {1e3 * (q1 - q0):.1f} ms", flush=True)
                 del st
     finally:
         os.unlink(path)

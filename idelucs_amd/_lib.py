@@ -75,10 +75,6 @@ SIGNATURES = {
     "idl_nce_fused": (_int, [_vp, _int, _c.c_float, _vp, _vp, _vp, _vp, _vp]),
     "idl_nce_fused_iic": (_int, [_vp, _int, _c.c_float, _vp, _vp, _vp, _vp, _vp, _int, _c.c_float, _c.c_float, _c.c_float, _vp, _vp, _vp]),
     "idl_nce_fused_iic_z": (_int, [_vp, _int, _c.c_float, _vp, _vp, _vp, _vp, _vp, _vp, _int, _c.c_float, _c.c_float, _c.c_float, _vp, _vp, _vp]),
-    "idl_nce_pass1_joint": (_int, [_vp, _int, _c.c_float, _vp, _vp, _vp, _int, _vp]),
-    "idl_nce_mid_bwd_gather": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _c.c_float, _vp, _c.c_float, _c.c_float, _c.c_float, _vp, _vp, _vp,
-                                      _vp, _vp, _vp, _int, _int, _int, _c.c_float, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
-                                      _vp, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _vp]),
     "idl_col_sum": (_int, [_vp, _int, _int, _vp, _vp]),
     "idl_relu_dropout_bwd_colsum": (_int, [_vp, _vp, _int, _int, _int, _vp, _vp]),
     "idl_col_sum_parts": (_int, []),
@@ -112,9 +108,6 @@ SIGNATURES = {
     "idl_l1_planes_parts": (_int, []),
     "idl_l1_planes_supported": (_int, [_int, _int, _int]),
     "idl_l1_planes": (_int, [_vp, _vp, _int, _vp, _vp, _int, _int, _int, _int, _vp, _vp]),
-    "idl_l1_planes_rms": (_int, [_vp, _vp, _vp, _vp, _int, _int, _vp,
-                                 _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _c.c_float, _c.c_float, _vp, _int,
-                                 _int, _vp, _vp, _int, _int, _int, _int, _vp, _i64, _vp]),
     "idl_reduce_parts_rms": (_int, [_vp, _i64, _vp, _vp,
                                     _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _c.c_float, _c.c_float, _vp, _int,
                                     _int, _vp, _vp, _int, _int, _int, _int, _vp, _i64, _vp]),

@@ -98,18 +98,6 @@ __device__ __forceinline__ void lds_barrier()
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 }
-// any(pred) over the workgroup through one LDS word per wave (flag: PRIM_NT / 64 ints; two barriers)
-__device__ __forceinline__ bool lds_block_any(bool pred, int *flag)
-{
-    const unsigned long long b = __ballot(pred);
-    if ((threadIdx.x & 63) == 0) flag[threadIdx.x >> 6] = b != 0ull;
-    lds_barrier();
-    bool any = false;
-#pragma unroll
-    for (int w = 0; w < PRIM_NT / 64; ++w) any |= flag[w] != 0;
-    lds_barrier();
-    return any;
-}
 
 // the same on the VALU alone (wave_ops.h: DPP inside the rows, permlane swaps across them -- a __shfl_xor butterfly over three 64-bit
 // values is 36 dependent trips through the LDS crossbar): the smallest weight of the wave first, then the smallest (number, position)
@@ -419,7 +407,7 @@ struct LazyState {
     long long cur_p, cur_o;    // the node added last: position, original number
     double cur_w, ema;         // its edge's weight; running mean of the recent weights
     int stalled, cand_par;     // 1: the winner could not be committed; which candidate buffer is valid
-    int fresh, pad;            // lazy_fold_kernel: 1 = no node has been added since the census (no sleeping group's bound has met one)
+    int fresh, pad;            // (unused since round 6)
 };
 
 struct LazyArgs {
@@ -994,1113 +982,12 @@ __global__ void lazy_init_kernel(PrimArgs a, LazyArgs z)
 }
 
 
-// ================================================================================================================ several nodes per launch
-// Round 5.  The lazy scan still pays one launch per tree node: 10^6 dependent 12 us launches.  Prim's order is a
-// chain -- node t + 1 is the argmin AFTER node t's update -- but often the chain can be read off in advance.  Let c_1, c_2, ... be
-// the best candidates of the last scan in ascending order (weight, then original number).  c_1 is the next node (when no sleeping
-// group could hold a better point: the stall rule).  c_i (i >= 2) is certain to follow c_1 .. c_{i-1} when
-//   (a) no AWAKE point j outside {c_1 .. c_i} can come to undercut it: whatever the nodes added meanwhile do to min_reach[j], it
-//       stays >= core[j] (mrd >= core[j]), and its old value was no better than c_i's; so  w_i < M_i = the smallest core distance
-//       among the awake points outside the tree other than c_1 .. c_i  suffices (c_i's own weight can only drop: it stays first);
-//   (b) no SLEEPING point can: the sleeping groups' bound after c_1 .. c_{i-1} is >= LB - max_j ||x_{c_j} - x_cur||, because the
-//       ball term of a new node c is >= the ball term of the node added last (cur: it is part of every bound since the census)
-//       less ||x_c - x_cur||;  so  w_i < LB - max_{j < i} ||x_{c_j} - x_cur||  suffices.  (Right after a census no node has met the
-//       bounds yet: one node per launch until one has.)
-// Both are STRICT, so ties never commit ahead.  On a latent of tight clusters the tree, once inside a cluster's core, takes the
-// remaining points nearly in the order of their core distances (min_reach = the point's own core distance, nothing left to
-// update): (a) and (b) hold for whole runs.  A launch is then a pair: lazy_reduce_kernel (one workgroup: the LZ_T best candidates
-// of all workgroups, the bounds, how many may be committed) and lazy_multi_kernel (commits them in order -- the edge of c_i is
-// its stored one or a better one through c_1 .. c_{i-1}, recomputed by the recording workgroup -- and scans all of them over the
-// awake points: every (point, node) pair that could change something gets its exact distance, then each point applies them in the
-// nodes' order with the scan's strict <).  Same tree, edge for edge (tests/test_gpu_knn.py::test_lazy_prim_builds_the_same_tree).
-constexpr int LZ_T = 8;                // nodes a launch may commit
-constexpr int LZ_W = 4;                // candidates a workgroup leaves, in order (a launch stops behind the LAST entry of a full list: the
-                                       // workgroup's next best is not known)
-constexpr int LZ_QCAP = 1024;          // (point, node) pairs a workgroup's exact-distance queue holds; beyond: the owner computes its own
-struct CandK { double w, core; int64_t j, p; };
-struct LazyDec {
-    int m, fresh;
-    long long cp[LZ_T], co[LZ_T]; double cw[LZ_T], cc[LZ_T];     // the nodes to commit: position, original number, weight, core distance
-    long long src[LZ_T];                                          // their stored sources (for the recording workgroup)
-    double xc[LZ_T][PRIM_FILTER_D];                               // their coordinates: the step reads them without waiting for cp
-};
-// lazy_fold_kernel's record of a workgroup: its best point, and what bounds everything else in it
-struct CandF { double w, core, w2, cmin; unsigned long long jp; double pad; };      // weight, its core distance; the second smallest weight; the smallest
-                                                                                  // core distance among the others; number << 32 | position (~0: none)
-constexpr int LF_T = 4;                // nodes a folded launch may commit (8: measured -- the work per node inside a launch costs what a launch costs; 218 681 launches of 42 us)
-struct LazyMulti {
-    CandK *cand[2];            // [grid * LZ_W] by candidate parity: each workgroup's LZ_W best, ascending
-    double *rest[2];           // [grid]: smallest core distance among the workgroup's awake outside points NOT among its LZ_W
-    LazyDec *dec;              // [2] by launch parity: what lazy_reduce_kernel decided for the launch (fresh: nothing added since the census)
-    int tmax;                  // <= LZ_T (IDELUCS_MST_MULTI)
-};
+// (Round 5's two multi-node variants of the lazy step -- lazy_reduce_kernel + lazy_multi_kernel: the decision in a launch of its own; lazy_fold_kernel: the
+//  decision inside the step -- were exact, measured no faster on BASELINE cfg5's latent (History) and opt-in; round 6 removed them.  One of them
+//  carried a correctness condition nobody had explained -- a build of lazy_fold_kernel that spilled 12 bytes a lane produced wrong records -- and a kernel with an
+//  unexplained condition does not ship.  `git log` has the 1 090 lines.)
 
-// wave-wide argmin of (w, j) with an index riding along; every lane gets the result.  On the VALU alone (wave_ops.h): the smallest
-// weight first, then the smallest (number, index) pair among the lanes that hold it, packed into one word -- numbers < 2^31 or
-// INT64_MAX ("nothing": index -1), indices >= 0.  (The __shfl_xor butterfly over the three values was ~350 wave instructions.)
-__device__ __forceinline__ void wave_argmin(double &bw, int64_t &bj, int &bi)
-{
-    const double wmin = idl_dev::wave_min_d(bw);
-    uint64_t key = (bw == wmin && bj != INT64_MAX) ? (((uint64_t)bj << 32) | (uint64_t)(uint32_t)bi) : ~0ull;
-    key = idl_dev::wave_min_u64(key);
-    bw = wmin;
-    bj = key == ~0ull ? INT64_MAX : (int64_t)(key >> 32);
-    bi = key == ~0ull ? -1 : (int)(uint32_t)key;
-}
-
-// One workgroup of 256 threads; thread t merges the (sorted) lists of workgroups 4 t .. 4 t + 3.  The tournament runs on ONE 64-bit
-// key per entry -- the weight's bit pattern (weights are >= 0: the order of the bits is the order of the values) -- kept in LDS, a
-// list's head a row number; equal weights (rare) are told apart by the original number in a second step.
-// wave-wide minimum of (k, bi), bi >= 0, lexicographic; every lane gets the result
-__device__ __forceinline__ void wave_min_u64(unsigned long long &k, int &bi)
-{
-    const unsigned long long kmin = idl_dev::wave_min_u64(k);
-    uint64_t ik = k == kmin ? (uint64_t)(uint32_t)bi : ~0ull;
-    ik = idl_dev::wave_min_u64(ik);
-    k = kmin; bi = (int)(uint32_t)ik;
-}
-
-__global__ __launch_bounds__(256) void lazy_reduce_kernel(PrimArgs a, LazyArgs z, LazyMulti u, int64_t launch, int grid)
-{
-    constexpr int NT = 256, LPT = 4, ROWS = LPT * LZ_W;      // lists per thread: grid <= 1024 = NT * LPT
-    __shared__ unsigned long long keyw[ROWS + 1][NT];        // row q * LZ_W + k: entry k of the thread's list q; the last row: +inf (an exhausted list)
-    __shared__ long long keyj[ROWS + 1][NT];
-    __shared__ CandK chosen[LZ_T];
-    __shared__ int cut[LZ_T];                                // 1: the entry was the last of a full list
-    __shared__ int wsel[NT / 64][LZ_T];                      // a wave's winners: entry numbers in the candidate buffer, -1: none
-    __shared__ double dup[LZ_T], red[NT / 64];
-    const int tid = threadIdx.x, par = (int)(launch & 1), G = z.n_groups;
-#ifdef IDL_PHASE_STAMPS
-    uint64_t last_ = __builtin_amdgcn_s_memrealtime();
-    const bool stamping = tid == 0;
-    const int kind_ = 2;
-#endif
-    const LazyState S = z.st[par];
-    LazyDec *D = &u.dec[par];
-    if (S.stalled || S.n_tree >= a.n) { if (tid == 0) D->m = 0; return; }
-    const CandK *pc = u.cand[S.cand_par];
-    const unsigned long long INF = 0x7FF0000000000000ull;
-    double umin_all = __builtin_inf();                       // smallest core distance among this thread's listed entries, by row
-    double ecore[ROWS];
-#pragma unroll
-    for (int q = 0; q < LPT; ++q) {
-        const int wg = tid * LPT + q;
-#pragma unroll
-        for (int k = 0; k < LZ_W; ++k) {
-            const CandK e = wg < grid ? pc[wg * LZ_W + k] : CandK{__builtin_inf(), __builtin_inf(), INT64_MAX, 0};
-            keyw[q * LZ_W + k][tid] = (unsigned long long)__double_as_longlong(e.w);
-            keyj[q * LZ_W + k][tid] = e.j;
-            ecore[q * LZ_W + k] = e.core;
-        }
-    }
-    keyw[ROWS][tid] = INF; keyj[ROWS][tid] = INT64_MAX;
-    (void)umin_all;
-    double lb = __builtin_inf(), rmin = __builtin_inf();
-    {       // (n_groups, grid <= 1024 = 4 per thread; every load of the four turns in flight at once, none behind a test)
-        int sl[4]; double mm[4], lp[4], rr[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int g = tid + t * NT;
-            const int gg = g < G ? g : 0, gw = g < grid ? g : 0;
-            sl[t] = z.asleep[gg]; mm[t] = z.minmr[gg]; lp[t] = z.lbp[par * G + gg]; rr[t] = u.rest[S.cand_par][gw];
-        }
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int g = tid + t * NT;
-            if (g < G && sl[t] == 1) lb = fmin(lb, fmin(mm[t], lp[t]));
-            if (g < grid) rmin = fmin(rmin, rr[t]);
-        }
-    }
-    auto block_min = [&](double v) {
-        v = idl_dev::wave_min_d(v);
-        if ((tid & 63) == 0) red[tid >> 6] = v;
-        __syncthreads();
-        const double r = fmin(fmin(red[0], red[1]), fmin(red[2], red[3]));
-        __syncthreads();
-        return r;
-    };
-    LZ_MARK(0);                                              // lists in LDS, bounds loaded
-    lb = block_min(lb);
-    rmin = block_min(rmin);
-    LZ_MARK(1);
-    // ---- every wave's tournament over its 256 lists: no barrier
-    const int T = u.tmax;
-    int head[LPT] = {0, 0, 0, 0};                            // a list's head: its row offset 0 .. LZ_W (LZ_W: exhausted)
-    for (int r = 0; r < T; ++r) {
-        unsigned long long kb = INF; int bi = 0x7FFFFFFF;
-#pragma unroll
-        for (int q = 0; q < LPT; ++q) {
-            const int row = head[q] < LZ_W ? q * LZ_W + head[q] : ROWS;
-            const unsigned long long kq = keyw[row][tid];
-            const int iq = ((tid & 63) * LPT + q) * LZ_W + head[q];
-            if (kq < kb || (kq == kb && iq < bi)) { kb = kq; bi = iq; }
-        }
-        unsigned long long km = kb; int bm = bi;
-        wave_min_u64(km, bm);
-        if (km >= INF) {                                     // nothing left in this wave
-            if ((tid & 63) == 0) for (int rr2 = r; rr2 < T; ++rr2) wsel[tid >> 6][rr2] = -1;
-            break;
-        }
-        // equal weights (two heads of one lane, or of several): the smallest original number among them goes first
-        int cnt = 0;
-#pragma unroll
-        for (int q = 0; q < LPT; ++q) {
-            const int row = head[q] < LZ_W ? q * LZ_W + head[q] : ROWS;
-            cnt += keyw[row][tid] == km ? 1 : 0;
-        }
-        int winner = bm;
-        if (__ballot(cnt >= 2) != 0ull || __popcll(__ballot(cnt >= 1)) > 1) {
-            long long jb = INT64_MAX; int ib = 0x7FFFFFFF;
-#pragma unroll
-            for (int q = 0; q < LPT; ++q) {
-                const int row = head[q] < LZ_W ? q * LZ_W + head[q] : ROWS;
-                if (keyw[row][tid] == km && keyj[row][tid] < jb) { jb = keyj[row][tid]; ib = ((tid & 63) * LPT + q) * LZ_W + head[q]; }
-            }
-            unsigned long long kj = (unsigned long long)jb; int bj2 = ib;      // (original numbers are >= 0)
-            wave_min_u64(kj, bj2);
-            winner = bj2;
-        }
-        if (winner / (LPT * LZ_W) == (tid & 63)) {
-            const int q = (winner / LZ_W) % LPT, k = winner % LZ_W;
-            wsel[tid >> 6][r] = (tid * LPT + q) * LZ_W + k;  // (the entry itself is fetched behind the tournament: no load inside it)
-#pragma unroll
-            for (int qq = 0; qq < LPT; ++qq) if (qq == q) head[qq] = k + 1;
-        }
-    }
-    __syncthreads();
-    LZ_MARK(2);                                              // the waves' tournaments
-    if (tid < (NT / 64) * LZ_T) {                            // 32 lanes: an entry each, ranked among the 4 T (empty entries by position)
-        __shared__ CandK mrg[(NT / 64) * LZ_T];
-        const int mw = tid / LZ_T, mr = tid % LZ_T;
-        const int idx = mr < T ? wsel[mw][mr] : -1;
-        const CandK me = idx >= 0 ? pc[idx] : CandK{__builtin_inf(), __builtin_inf(), INT64_MAX, 0};
-        mrg[tid] = me;                                       // (one wave: its LDS writes are seen by its own reads below)
-        __builtin_amdgcn_s_waitcnt(0xc07f);                  // lgkmcnt(0)
-        int rank = 0;
-        for (int k = 0; k < (NT / 64) * LZ_T; ++k) {
-            const CandK o = mrg[k];
-            if (k != tid && (better(o.w, o.j, me.w, me.j) || (o.w == me.w && o.j == me.j && k < tid))) ++rank;
-        }
-        // (a list of LZ_W finite entries is full: what follows its last entry in that workgroup is not listed)
-        if (rank < LZ_T) { chosen[rank] = me; cut[rank] = (idx >= 0 && idx % LZ_W == LZ_W - 1) ? 1 : 0; }
-    }
-    __syncthreads();
-    LZ_MARK(3);                                              // merged by rank
-    // the smallest core distance among the listed entries that were not chosen: everything strictly behind the T-th
-    double umin = __builtin_inf();
-    {
-        const double wT = chosen[T - 1].w; const int64_t jT = chosen[T - 1].j;
-#pragma unroll
-        for (int row = 0; row < ROWS; ++row) {
-            const double w = __longlong_as_double((long long)keyw[row][tid]);
-            if (better(wT, jT, w, keyj[row][tid])) umin = fmin(umin, ecore[row]);
-        }
-    }
-    umin = fmin(block_min(umin), rmin);
-    LZ_MARK(4);
-    // how far the candidates are from the node added last (an upper bound): each wave takes two.  Their coordinates and stored
-    // sources go into the record: the step reads them in its first trip instead of chasing the positions
-    __shared__ long long csrc[LZ_T];
-    for (int r = tid >> 6; r < T; r += NT / 64) {
-        const int l = tid & 63;
-        double d2 = 0.0, xr = 0.0;
-        const bool real = chosen[r].w < __builtin_inf();
-        if (real) {
-            xr = (double)z.xrow[chosen[r].p * PRIM_FILTER_D + l];
-            const double t = xr - (double)z.xrow[S.cur_p * PRIM_FILTER_D + l];
-            d2 = t * t;
-            if (l == 0) csrc[r] = a.source[chosen[r].p];
-        }
-        D->xc[r][l] = xr;
-        d2 = idl_dev::wave_sum_d(d2);                        // (any order: the bound keeps 1e-9 of slack)
-        if (l == 0) dup[r] = __dsqrt_rn(d2) * (1.0 + 1e-9) + 1e-300;
-    }
-    __syncthreads();
-    LZ_MARK(5);                                              // distances, coordinates, sources
-    if (tid == 0) {
-        int m = 0;
-        const int fresh = D->fresh;
-        if (chosen[0].w < lb) {                              // else: STALL, as the single-node step decides it
-            m = 1;
-            double dmax = dup[0];
-            for (int i = 1; i < T && !fresh && !cut[i - 1]; ++i) {
-                if (!(chosen[i].w < __builtin_inf())) break;
-                double mi = umin;                             // smallest core among the awake outside points other than c_0 .. c_i
-                for (int k = i + 1; k < T; ++k) mi = fmin(mi, chosen[k].core);
-                if (!(chosen[i].w < mi) || !(chosen[i].w < lb - dmax)) break;
-                m = i + 1;
-                dmax = fmax(dmax, dup[i]);
-            }
-        }
-        D->m = m;
-        for (int i = 0; i < LZ_T; ++i) {
-            const bool on = i < m;
-            D->cp[i] = on ? chosen[i].p : 0; D->co[i] = on ? chosen[i].j : 0; D->cw[i] = on ? chosen[i].w : 0.0; D->cc[i] = on ? chosen[i].core : 0.0;
-            D->src[i] = (on && i < T) ? csrc[i] : 0;
-        }
-        if (m == 0) { LazyState t = S; t.stalled = 1; z.st[par] = t; }      // the step launch behind this one falls through with it
-    }
-    LZ_MARK(6);
-#ifdef IDL_PHASE_STAMPS
-    if (stamping) atomicAdd(&lazy_phase_sum[2][7], 1ull);
-#endif
-}
-
-__global__ __launch_bounds__(PRIM_NT, 3) void lazy_multi_kernel(PrimArgs a, LazyArgs z, LazyMulti u, int64_t launch, int rescan)
-{
-    __shared__ double sw[PRIM_NT / 64];
-    __shared__ double xcs[LZ_T][PRIM_FILTER_D];              // the nodes of this launch
-    __shared__ float up[LZ_T][PRIM_RUNS][PRIM_FILTER_D];     // (x_node - lo_g) / scale_g for the group of each of the workgroup's runs
-    __shared__ double ccs[LZ_T];
-    __shared__ long long cps[LZ_T], cos_[LZ_T];
-    __shared__ int q_n;
-    __shared__ unsigned short q_item[LZ_QCAP / LZ_T];       // the queue: a point an item
-    __shared__ unsigned q_mask[LZ_QCAP / LZ_T];              // in: the nodes whose floor it passes; out: those whose exact distance was formed
-    __shared__ double q_val[LZ_QCAP];                        // [item][node]
-    __shared__ double pair_d[LZ_T * LZ_T];
-    __shared__ double cws[LZ_T];
-    __shared__ long long srcs[LZ_T];
-    static_assert(PRIM_NT == PRIM_SUB, "one sub-block per workgroup here");
-    const int tid = threadIdx.x;
-    const int64_t n = a.n;
-    const int G = z.n_groups;
-    const int par = (int)(launch & 1);
-#ifdef IDL_PHASE_STAMPS
-    uint64_t last_ = __builtin_amdgcn_s_memrealtime();
-    const bool stamping = tid == 0 && !rescan && (blockIdx.x == 0 || blockIdx.x % 61 == 7);
-    const int kind_ = blockIdx.x == 0 ? 0 : 1;
-#endif
-    // ---- trip 1: this workgroup's number and run flags (the list: lazy_list_kernel), the state of the walk, what the reduce decided
-    const int entry = z.wg_list[1 + blockIdx.x];
-    const LazyState S = z.st[par];
-    LazyState *nx = &z.st[par ^ 1];
-    const LazyDec *Dp = &u.dec[par];                         // (read field by field: a private copy of the record is registers a lane)
-    const int D_m = Dp->m, D_fresh = Dp->fresh;
-    const int wg = __builtin_amdgcn_readfirstlane(entry) & 0xFFFF, wg_mask = __builtin_amdgcn_readfirstlane(entry) >> 16;
-    const bool lead = wg == 0 && tid == 0;
-    const bool ball_duty = wg * (PRIM_NT / 64) < G;          // group g's bound: wave g % 4 of workgroup g / 4, as in lazy_step_kernel
-    const int ball_g = wg * (PRIM_NT / 64) + (tid >> 6);
-    const bool has_ball = ball_g < G;
-    if (S.stalled || S.n_tree >= n || (!rescan && D_m == 0)) {      // fall through: the state and the bounds are handed on unchanged
-        if (lead) { *nx = S; u.dec[par ^ 1].fresh = D_fresh; }
-        if (has_ball && (tid & 63) == 0) z.lbp[(par ^ 1) * G + ball_g] = z.lbp[par * G + ball_g];
-        return;
-    }
-    const int m = rescan ? 1 : D_m;                          // nodes scanned by this launch (a re-scan: the node added last, nothing committed)
-    const int64_t stride = (int64_t)z.full_grid * PRIM_NT;
-    const int64_t p0 = (int64_t)wg * PRIM_NT + tid;
-    bool run_on[PRIM_AHEAD];
-    bool any_on = false;
-#pragma unroll
-    for (int i = 0; i < PRIM_AHEAD; ++i) {
-        run_on[i] = ((wg_mask >> i) & 1) != 0;
-        any_on |= run_on[i];
-    }
-    CandK *cand_out = u.cand[S.cand_par ^ 1] + (int64_t)blockIdx.x * LZ_W;
-    double *rest_out = u.rest[S.cand_par ^ 1] + blockIdx.x;
-    auto leave_empty = [&]() {
-        if (tid < LZ_W) cand_out[tid] = CandK{__builtin_inf(), __builtin_inf(), INT64_MAX, 0};
-        if (tid == 0) *rest_out = __builtin_inf();
-    };
-    if (!any_on && !ball_duty && wg != 0) { leave_empty(); return; }
-    LZ_MARK(0);
-    // ---- trip 2, requests (lazy_step_kernel has the reasoning): 21 bytes of state a point, the nodes with their coordinates out of
-    // the record, the kept ball
-    double mr_a[PRIM_AHEAD], cj_a[PRIM_AHEAD];
-    int run_g[PRIM_AHEAD], pas_a[PRIM_AHEAD], o32[PRIM_AHEAD];
-    double run_scale[PRIM_AHEAD];
-#pragma unroll
-    for (int i = 0; i < PRIM_AHEAD; ++i) {
-        const int64_t first = (int64_t)wg * PRIM_NT + i * stride;
-        const int64_t p = p0 + i * stride;
-        mr_a[i] = -1.0; cj_a[i] = 0.0; run_g[i] = 0; pas_a[i] = 1; o32[i] = 0;
-        if (run_on[i]) {                                     // (uniform)
-            const int64_t pc = p < n ? p : first;
-            mr_a[i] = a.min_reach[pc];
-            cj_a[i] = a.core[pc];
-            pas_a[i] = z.pas[pc];
-            o32[i] = a.orig[pc];
-            run_g[i] = a.gid[first];
-        }
-    }
-    long long n_cp = -1, n_co = 0, n_src = 0;                // thread q < LZ_T: node q
-    double n_cc = 0.0, n_cw = 0.0;
-    if (tid < LZ_T && !rescan && tid < m) { n_cp = Dp->cp[tid]; n_co = Dp->co[tid]; n_cc = Dp->cc[tid]; n_cw = Dp->cw[tid]; n_src = Dp->src[tid]; }
-    if (tid < LZ_T && rescan && tid == 0) { n_cp = S.cur_p; n_co = S.cur_o; n_cc = a.core[S.cur_p]; }
-    double x_node[LZ_T * PRIM_FILTER_D / PRIM_NT];           // 2 coordinates a thread
-#pragma unroll
-    for (int t = 0; t < LZ_T * PRIM_FILTER_D / PRIM_NT; ++t) {
-        const int idx = tid + t * PRIM_NT;
-        x_node[t] = 0.0;
-        if (idx < m * PRIM_FILTER_D) x_node[t] = rescan ? (double)z.xrow[S.cur_p * PRIM_FILTER_D + (idx & 63)] : Dp->xc[idx >> 6][idx & 63];
-    }
-    double ball_c = 0.0, ball_lb = 0.0, ball_r = 0.0;
-    int ball_as = 0;
-    if (has_ball) {
-        ball_lb = z.lbp[par * G + ball_g];
-        ball_as = z.asleep[ball_g];
-        ball_c = z.gc[(int64_t)ball_g * PRIM_FILTER_D + (tid & 63)];
-        ball_r = z.gr[ball_g];
-    }
-    asm volatile("" ::: "memory");
-#define LZ_PIN(x) asm volatile("" : "+v"(x))
-#pragma unroll
-    for (int i = 0; i < PRIM_AHEAD; ++i) { LZ_PIN(mr_a[i]); LZ_PIN(cj_a[i]); LZ_PIN(run_g[i]); LZ_PIN(pas_a[i]); LZ_PIN(o32[i]); }
-    LZ_PIN(n_cp); LZ_PIN(n_co); LZ_PIN(n_cc); LZ_PIN(n_cw); LZ_PIN(n_src);
-#pragma unroll
-    for (int t = 0; t < LZ_T * PRIM_FILTER_D / PRIM_NT; ++t) LZ_PIN(x_node[t]);
-    LZ_PIN(ball_lb); LZ_PIN(ball_as); LZ_PIN(ball_c); LZ_PIN(ball_r);
-#undef LZ_PIN
-    LZ_MARK(1);
-    // ---- trip 2, answers
-    int64_t o_a[PRIM_AHEAD];
-    int my_run_g;
-    {
-        const int rr = tid >> 6;
-#pragma unroll
-        for (int i = 0; i < PRIM_AHEAD; ++i) {
-            const int64_t p = p0 + i * stride;
-            const bool on = run_on[i] && p < n;
-            if (!on || pas_a[i] != 0) mr_a[i] = -1.0;
-            if (!on) cj_a[i] = 0.0;
-            o_a[i] = on ? (int64_t)o32[i] : 0;
-            run_scale[i] = a.gscale[run_g[i]];
-        }
-        my_run_g = rr == 0 ? run_g[0] : rr == 1 ? run_g[1] : rr == 2 ? run_g[2] : run_g[3];
-    }
-    const double my_sc = a.gscale[my_run_g];
-    const float my_lo = a.glo[(int64_t)my_run_g * PRIM_FILTER_D + (tid & 63)];
-    if (tid < LZ_T) { cps[tid] = n_cp; cos_[tid] = n_co; ccs[tid] = n_cc; cws[tid] = n_cw; srcs[tid] = n_src; }
-    if (tid == 0) q_n = 0;
-#pragma unroll
-    for (int t = 0; t < LZ_T * PRIM_FILTER_D / PRIM_NT; ++t) {
-        const int idx = tid + t * PRIM_NT;
-        if (idx < m * PRIM_FILTER_D) xcs[idx >> 6][idx & 63] = x_node[t];
-    }
-    __syncthreads();
-    {       // one (run, feature) per thread, as in the single-node step; its box corner and scale are loaded once, the nodes loop in LDS
-        static_assert(PRIM_RUNS * 64 == PRIM_NT && PRIM_FILTER_D == 64 && PRIM_AHEAD == 4, "one (run, feature) per thread");
-        const int rr = tid >> 6, k = tid & 63;
-        for (int q = 0; q < m; ++q) up[q][rr][k] = (float)((xcs[q][k] - (double)my_lo) / my_sc);
-    }
-    LZ_MARK(2);                                              // nodes and boxes in LDS
-    // ---- the recording workgroup: the edges of the committed nodes, in order.  The edge of c_i is the one the scans so far left
-    // (its stored min_reach and source) unless one of c_0 .. c_{i-1} reaches it at a smaller mutual-reachability distance
-    if (wg == 0 && !rescan) {
-        for (int pr = tid; pr < m * m; pr += PRIM_NT) {
-            const int k = pr / m, i = pr % m;
-            double v = __builtin_inf();
-            if (k < i) {
-                double acc = 0.0;
-#pragma unroll 8
-                for (int f = 0; f < PRIM_FILTER_D; ++f) {
-                    // (the scan's arithmetic: the node as double, the point's float32 widened -- xcs holds exactly that; product and sum
-                    //  each rounded, in feature order)
-                    const double t = xcs[k][f] - xcs[i][f];
-                    acc = idl_dev::square_then_add(acc, t);
-                }
-                v = fmax(fmax(ccs[k], ccs[i]), __dsqrt_rn(acc));
-            }
-            pair_d[k * LZ_T + i] = v;
-        }
-        __syncthreads();
-        if (tid == 0) {
-            LazyState t = S;
-            for (int i = 0; i < m; ++i) {
-                double w = cws[i];
-                int64_t src = srcs[i];
-                for (int k = 0; k < i; ++k) if (pair_d[k * LZ_T + i] < w) { w = pair_d[k * LZ_T + i]; src = cos_[k]; }
-                a.mst_cur[t.n_tree - 1] = src; a.mst_next[t.n_tree - 1] = cos_[i]; a.mst_w[t.n_tree - 1] = w;
-                a.min_reach[cps[i]] = -1.0;
-                z.tree_p[t.n_tree] = cps[i];
-                t.n_tree += 1; t.cur_p = cps[i]; t.cur_o = cos_[i]; t.cur_w = w; t.ema = t.ema + (w - t.ema) * (1.0 / 64.0);
-            }
-            t.cand_par = S.cand_par ^ 1;
-            *nx = t;
-            u.dec[par ^ 1].fresh = 0;
-        }
-    } else if (lead) {                                       // a re-scan commits nothing
-        LazyState t = S;
-        t.cand_par = S.cand_par ^ 1;
-        *nx = t;
-        u.dec[par ^ 1].fresh = D_fresh;
-    }
-    // ---- the sleeping groups' bounds meet the new nodes (a group per wave)
-    if (has_ball) {
-        double lbv = ball_lb;
-        if (!rescan && ball_as == 1) {
-            for (int q = 0; q < m; ++q) {
-                const double t = xcs[q][tid & 63] - ball_c;
-                const double d2 = idl_dev::wave_sum_d(t * t);
-                const double b = __dsqrt_rn(d2) * (1.0 - 1e-12) - ball_r;
-                lbv = fmin(lbv, b > 0.0 ? b : 0.0);
-            }
-        }
-        if ((tid & 63) == 0) z.lbp[(par ^ 1) * G + ball_g] = lbv;
-    }
-    __syncthreads();
-    LZ_MARK(3);                                              // recorded, balls
-    if (!any_on) { leave_empty(); return; }
-    // ---- which (point, node) pairs could change something: the floor test first; for the points with such a pair -- trip 3 -- group,
-    // residual and codes, then the 8-bit bound
-    bool act[PRIM_AHEAD];
-    unsigned mask[PRIM_AHEAD];
-#pragma unroll
-    for (int i = 0; i < PRIM_AHEAD; ++i) {
-        const int64_t p = p0 + i * stride;
-        act[i] = mr_a[i] >= 0.0;
-        for (int q = 0; q < m; ++q) if (p == cps[q]) act[i] = false;        // committed in this launch (a re-scan: the node itself)
-        mask[i] = 0u;
-        if (!act[i]) continue;
-        for (int q = 0; q < m; ++q) if (fmax(ccs[q], cj_a[i]) < mr_a[i]) mask[i] |= 1u << q;
-    }
-    // ---- a point with such a pair is an ITEM of the workgroup's queue; a thread takes an item: trip 3, the point's group, residual and
-    // codes -> the 8-bit bound against each of its nodes; trip 4 (when a pair survives) its coordinates, ONCE for all its nodes -> the
-    // exact distances, in q_val[item][node].  (The first form kept the codes of a lane's four points in 64 registers and queued
-    // (point, node) pairs, each fetching the point again: 168 registers and 116 bytes of scratch, or two workgroups a CU.)  A point
-    // that does not fit the queue waits for the next round.
-    const float *xt = (const float *)a.xt;
-    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)xt, 0, 0xffffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t c_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.codes, 0, 0xffffffff, 0x00020000);
-    const int col_bytes = (int)n * 4;
-    constexpr int ITEMS = LZ_QCAP / LZ_T;                    // q_val rows of LZ_T
-    bool todo = false;
-#pragma unroll
-    for (int i = 0; i < PRIM_AHEAD; ++i) todo |= mask[i] != 0u;
-    while (__syncthreads_or(todo ? 1 : 0)) {                 // (inside a cluster's core nearly every launch skips this block)
-        int slot[PRIM_AHEAD];
-#pragma unroll
-        for (int i = 0; i < PRIM_AHEAD; ++i) {
-            slot[i] = -1;
-            if (!mask[i]) continue;
-            const int s_ = atomicAdd(&q_n, 1);
-            if (s_ < ITEMS) { slot[i] = s_; q_item[s_] = (unsigned short)(tid * PRIM_AHEAD + i); q_mask[s_] = mask[i]; }
-        }
-        __syncthreads();
-        const int qn = q_n < ITEMS ? q_n : ITEMS;
-        for (int s_ = tid; s_ < qn; s_ += PRIM_NT) {
-            const unsigned it = q_item[s_];
-            const int item = it & 1023, t_own = item / PRIM_AHEAD, i_own = item % PRIM_AHEAD;
-            unsigned mk = q_mask[s_];
-            const int64_t p = (int64_t)wg * PRIM_NT + t_own + i_own * stride;
-            const int64_t first = (int64_t)wg * PRIM_NT + i_own * stride;
-            const int gp = a.gid[p], gr = a.gid[first];
-            const float rsd = a.resid[p];
-            const double cjp = a.core[p], mrp = a.min_reach[p];
-            uint32_t cwd[PRIM_FILTER_D / 4];
-#pragma unroll
-            for (int k = 0; k < PRIM_FILTER_D / 4; ++k) cwd[k] = __builtin_amdgcn_raw_buffer_load_b32(c_rsrc, (uint32_t)p * 4u, k * (int)n * 4, 0);
-            if (gp == gr) {                                  // (else: a point of another group than its run's: no codes in this box)
-                const double sc = (double)(float)a.gscale[gr];
-                for (int q = 0; q < m; ++q) {
-                    if (!(mk >> q & 1u)) continue;
-                    float acc = 0.f;
-                    const float *uu = up[q][i_own];
-#pragma unroll
-                    for (int k = 0; k < PRIM_FILTER_D / 4; ++k) {
-                        const uint32_t w = cwd[k];
-                        const float t0 = uu[4 * k] - (float)(w & 255u), t1 = uu[4 * k + 1] - (float)((w >> 8) & 255u);
-                        const float t2 = uu[4 * k + 2] - (float)((w >> 16) & 255u), t3 = uu[4 * k + 3] - (float)(w >> 24);
-                        acc = fmaf(t0, t0, acc); acc = fmaf(t1, t1, acc); acc = fmaf(t2, t2, acc); acc = fmaf(t3, t3, acc);
-                    }
-                    const double lbq = sc * (double)sqrtf(acc) * (1.0 - 4e-5) - 0.01 * sc - (double)rsd;      // (prim_step_kernel has the reasoning)
-                    if (fmax(fmax(ccs[q], cjp), lbq) >= mrp) mk &= ~(1u << q);
-                }
-            }
-            if (mk != 0u) {
-                uint32_t v[64];
-#pragma unroll
-                for (int k = 0; k < 64; ++k) v[k] = __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, (uint32_t)p * 4u, k * col_bytes, 0);
-                for (int q = 0; q < m; ++q) {
-                    if (!(mk >> q & 1u)) continue;
-                    double acc = 0.0;
-#pragma unroll
-                    for (int k = 0; k < 64; ++k) {
-                        if ((k & 7) == 0) __builtin_amdgcn_sched_barrier(0);
-                        uint32_t vk = v[k];
-                        asm volatile("" : "+v"(vk));         // (widened here, every time: hoisted out of the loop over the nodes the 64 doubles are 128 registers)
-                        const double t = xcs[q][k] - (double)__uint_as_float(vk);
-                        acc = idl_dev::square_then_add(acc, t);
-                    }
-                    q_val[s_ * LZ_T + q] = fmax(fmax(ccs[q], cjp), __dsqrt_rn(acc));     // mrd(node q, point p)
-                }
-            }
-            q_mask[s_] = mk;
-        }
-        __syncthreads();
-        bool left = false;
-#pragma unroll
-        for (int i = 0; i < PRIM_AHEAD; ++i) {
-            if (!mask[i]) continue;
-            if (slot[i] < 0) { left = true; continue; }
-            const int64_t p = p0 + i * stride;
-            const unsigned mk = q_mask[slot[i]];
-            double mr = mr_a[i];
-            int64_t src = -1;
-            for (int q = 0; q < m; ++q) {
-                if (!(mk >> q & 1u)) continue;
-                const double v = q_val[slot[i] * LZ_T + q];
-                if (v < mr) { mr = v; src = cos_[q]; }
-            }
-            if (src >= 0) { a.min_reach[p] = mr; a.source[p] = src; mr_a[i] = mr; }
-            mask[i] = 0u;
-        }
-        __syncthreads();
-        if (tid == 0) q_n = 0;
-        todo = left;
-    }
-    LZ_MARK(4);                                              // floor tests, bounds, exact distances, applied
-    // ---- the workgroup's LZ_W best candidates in order: every wave picks its own LZ_W (no barrier), one wave merges the four
-    // lists by rank; then the smallest core distance among everything that is not listed
-    __shared__ CandK wl[PRIM_NT / 64][LZ_W];
-    __shared__ int64_t listed[LZ_W];
-    bool used[PRIM_AHEAD] = {false, false, false, false};
-    for (int r = 0; r < LZ_W; ++r) {
-        double bw = __builtin_inf(); int64_t bj = INT64_MAX; int bi = -1;
-#pragma unroll
-        for (int i = 0; i < PRIM_AHEAD; ++i) if (act[i] && !used[i] && better(mr_a[i], o_a[i], bw, bj)) { bw = mr_a[i]; bj = o_a[i]; bi = (tid & 63) * PRIM_AHEAD + i; }
-        wave_argmin(bw, bj, bi);
-        if (bi >= 0 && bi / PRIM_AHEAD == (tid & 63)) {
-#pragma unroll
-            for (int i = 0; i < PRIM_AHEAD; ++i) if (i == bi % PRIM_AHEAD) { used[i] = true; wl[tid >> 6][r] = CandK{mr_a[i], cj_a[i], o_a[i], p0 + i * stride}; }
-        }
-        if (bi < 0 && (tid & 63) == 0) wl[tid >> 6][r] = CandK{__builtin_inf(), __builtin_inf(), INT64_MAX, 0};
-    }
-    __syncthreads();
-    if (tid < (PRIM_NT / 64) * LZ_W) {                       // 16 lanes of wave 0: an entry each, ranked among the 16 (ties cannot be: j is unique)
-        const CandK me = wl[tid / LZ_W][tid % LZ_W];
-        int rank = 0;
-        for (int k = 0; k < (PRIM_NT / 64) * LZ_W; ++k) {
-            const CandK o = wl[k / LZ_W][k % LZ_W];
-            if (k != tid && (better(o.w, o.j, me.w, me.j) || (o.w == me.w && o.j == me.j && k < tid))) ++rank;     // (empty entries: by position)
-        }
-        if (rank < LZ_W) { cand_out[rank] = me; listed[rank] = me.w < __builtin_inf() ? me.p : -1; }
-    }
-    __syncthreads();
-    double rc = __builtin_inf();
-#pragma unroll
-    for (int i = 0; i < PRIM_AHEAD; ++i) {
-        const int64_t p = p0 + i * stride;
-        bool in_list = false;
-#pragma unroll
-        for (int k = 0; k < LZ_W; ++k) in_list |= listed[k] == p;
-        if (act[i] && !in_list) rc = fmin(rc, cj_a[i]);
-    }
-    rc = idl_dev::wave_min_d(rc);
-    if ((tid & 63) == 0) sw[tid >> 6] = rc;
-    __syncthreads();
-    if (tid == 0) *rest_out = fmin(fmin(sw[0], sw[1]), fmin(sw[2], sw[3]));
-    LZ_MARK(5);                                              // list and rest left
-#ifdef IDL_PHASE_STAMPS
-    if (stamping) { atomicAdd(&lazy_phase_sum[kind_][7], 1ull); atomicAdd(&lazy_phase_sum[kind_][11], (unsigned long long)m); }
-#endif
-}
-
-// ================================================================================================================ several nodes per launch, one launch
-// The decision of lazy_reduce_kernel INSIDE the step (round 5): every listed workgroup leaves ONE record -- its best point, the second
-// smallest weight among its other points (w2), the smallest core distance among its other points (cmin) -- and every workgroup of the
-// next launch works out the same chain c_0, c_1, ... from the same records: the candidates in order (weight, number), c_i (i >= 1)
-// following c_0 .. c_{i-1} when, all STRICTLY,
-//   w_i < min over all workgroups of w2            (no point that is not a workgroup's best comes first),
-//   w_i < min(cmin of all workgroups, the core distances of the bests not among c_0 .. c_i)      (condition (a) above),
-//   w_i < LB - max_{j < i} ||x_{c_j} - x_cur||     (condition (b) above), and a node has been added since the census.
-// No second launch, no single workgroup pulling every list through one CU; the price is lists of depth one.  The scan, the queue,
-// the recording workgroup and the bounds' update are lazy_multi_kernel's.  cand / rest of LazyMulti are not used: the records live
-// in the CandK buffers' storage (u.cand, viewed as CandF).
-__global__ __launch_bounds__(PRIM_NT, 3) void lazy_fold_kernel(PrimArgs a, LazyArgs z, LazyMulti u, int64_t launch, int rescan, int tmax)
-{
-    __shared__ double sw[PRIM_NT / 64];
-    __shared__ unsigned long long sk[PRIM_NT / 64];
-    __shared__ double sred[3][PRIM_NT / 64];
-    __shared__ double wl_w[PRIM_NT / 64][1], wl_c[PRIM_NT / 64][1], mg_w[LF_T], mg_c[LF_T];      // the waves' smallest records; the chain's candidates in order
-    __shared__ unsigned long long wl_k[PRIM_NT / 64][1], mg_k[LF_T];
-    __shared__ double th_w[64], th_c[64];                    // the records below theta
-    __shared__ unsigned long long th_k[64];
-    __shared__ int th_n;
-    __shared__ double xcs[LF_T][PRIM_FILTER_D];              // the nodes of this launch
-    __shared__ double xcur[PRIM_FILTER_D];                   // the node added last (condition (b))
-    __shared__ float up[LF_T][PRIM_RUNS][PRIM_FILTER_D];
-    __shared__ double ccs[LF_T], cws[LF_T], dup[LF_T];
-    __shared__ long long cps[LF_T], cos_[LF_T], srcs[LF_T];
-    __shared__ int q_n;
-    __shared__ int any_flag[PRIM_NT / 64];
-    __shared__ unsigned short q_pair[LZ_QCAP / LZ_T * LF_T];     // the queue: point | node << 10
-    __shared__ double q_val[LZ_QCAP / LZ_T * LF_T];              // the pair's mutual-reachability distance (inf: it changes nothing)
-    __shared__ double pair_d[LF_T * LF_T];
-    static_assert(PRIM_NT == PRIM_SUB, "one sub-block per workgroup here");
-    const int tid = threadIdx.x;
-    const int64_t n = a.n;
-    const int G = z.n_groups;
-    const int par = (int)(launch & 1);
-#ifdef IDL_PHASE_STAMPS
-    uint64_t last_ = __builtin_amdgcn_s_memrealtime();
-    const bool stamping = tid == 0 && !rescan && (blockIdx.x == 0 || blockIdx.x % 61 == 7);
-    const int kind_ = blockIdx.x == 0 ? 0 : 1;
-#endif
-    // ---- trip 1
-    const int entry = z.wg_list[1 + blockIdx.x];
-    const LazyState S = z.st[par];
-    LazyState *nx = &z.st[par ^ 1];
-    const int wg = __builtin_amdgcn_readfirstlane(entry) & 0xFFFF, wg_mask = __builtin_amdgcn_readfirstlane(entry) >> 16;
-    const bool lead = wg == 0 && tid == 0;
-    const int ball_g = wg * (PRIM_NT / 64) + (tid >> 6);
-    const bool has_ball = ball_g < G;
-    if (S.stalled || S.n_tree >= n) {                        // fall through: the state and the bounds are handed on unchanged
-        if (lead) *nx = S;
-        if (has_ball && (tid & 63) == 0) z.lbp[(par ^ 1) * G + ball_g] = z.lbp[par * G + ball_g];
-        return;
-    }
-    const int64_t stride = (int64_t)z.full_grid * PRIM_NT;
-    const int64_t p0 = (int64_t)wg * PRIM_NT + tid;
-    bool run_on[PRIM_AHEAD];
-    bool any_on = false;
-#pragma unroll
-    for (int i = 0; i < PRIM_AHEAD; ++i) {
-        run_on[i] = ((wg_mask >> i) & 1) != 0;
-        any_on |= run_on[i];
-    }
-    const CandF *rec_in = (const CandF *)u.cand[S.cand_par];
-    CandF *rec_out = (CandF *)u.cand[S.cand_par ^ 1] + blockIdx.x;
-    auto leave_empty = [&]() { if (tid == 0) *rec_out = CandF{__builtin_inf(), __builtin_inf(), __builtin_inf(), __builtin_inf(), ~0ull, 0.0}; };
-    LZ_MARK(0);
-    // ---- trip 2, requests
-    double mr_a[PRIM_AHEAD], cj_a[PRIM_AHEAD];
-    int run_g[PRIM_AHEAD], pas_a[PRIM_AHEAD], o32[PRIM_AHEAD];
-    double run_scale[PRIM_AHEAD];
-#pragma unroll
-    for (int i = 0; i < PRIM_AHEAD; ++i) {
-        const int64_t first = (int64_t)wg * PRIM_NT + i * stride;
-        const int64_t p = p0 + i * stride;
-        mr_a[i] = -1.0; cj_a[i] = 0.0; run_g[i] = 0; pas_a[i] = 1; o32[i] = 0;
-        if (run_on[i]) {                                     // (uniform)
-            const int64_t pc = p < n ? p : first;
-            mr_a[i] = a.min_reach[pc];
-            cj_a[i] = a.core[pc];
-            pas_a[i] = z.pas[pc];
-            o32[i] = a.orig[pc];
-            run_g[i] = a.gid[first];
-        }
-    }
-    constexpr int PRE = 4;                                   // records / group bounds a thread takes: 4 x 256 covers the largest grid
-    double r_w[PRE], r_core[PRE], r_w2[PRE], r_cmin[PRE];
-    unsigned long long r_jp[PRE];
-    int g_as[PRE];
-    double g_mm[PRE], g_lb[PRE];
-#pragma unroll
-    for (int it = 0; it < PRE; ++it) {
-        const int g = tid + it * PRIM_NT;
-        r_w[it] = __builtin_inf(); r_core[it] = __builtin_inf(); r_w2[it] = __builtin_inf(); r_cmin[it] = __builtin_inf(); r_jp[it] = ~0ull;
-        g_as[it] = 0; g_mm[it] = 0.0; g_lb[it] = 0.0;
-        if (!rescan) {
-            if (g < (int)gridDim.x) { const CandF c = rec_in[g]; r_w[it] = c.w; r_core[it] = c.core; r_w2[it] = c.w2; r_cmin[it] = c.cmin; r_jp[it] = c.jp; }
-            if (g < G) { g_as[it] = z.asleep[g]; g_mm[it] = z.minmr[g]; g_lb[it] = z.lbp[par * G + g]; }
-        }
-    }
-    double x_cur = 0.0;
-    if (tid < PRIM_FILTER_D) x_cur = (double)z.xrow[S.cur_p * PRIM_FILTER_D + tid];
-    double cc_cur = 0.0;
-    if (rescan && tid == 0) cc_cur = a.core[S.cur_p];
-    double ball_c = 0.0, ball_lb = 0.0, ball_r = 0.0;
-    int ball_as = 0;
-    if (has_ball) {
-        ball_lb = z.lbp[par * G + ball_g];
-        ball_as = z.asleep[ball_g];
-        ball_c = z.gc[(int64_t)ball_g * PRIM_FILTER_D + (tid & 63)];
-        ball_r = z.gr[ball_g];
-    }
-    asm volatile("" ::: "memory");
-#define LZ_PIN(x) asm volatile("" : "+v"(x))
-#pragma unroll
-    for (int i = 0; i < PRIM_AHEAD; ++i) { LZ_PIN(mr_a[i]); LZ_PIN(cj_a[i]); LZ_PIN(run_g[i]); LZ_PIN(pas_a[i]); LZ_PIN(o32[i]); }
-#pragma unroll
-    for (int it = 0; it < PRE; ++it) { LZ_PIN(r_w[it]); LZ_PIN(r_core[it]); LZ_PIN(r_w2[it]); LZ_PIN(r_cmin[it]); LZ_PIN(r_jp[it]); LZ_PIN(g_as[it]); LZ_PIN(g_mm[it]); LZ_PIN(g_lb[it]); }
-    LZ_PIN(x_cur); LZ_PIN(cc_cur); LZ_PIN(ball_lb); LZ_PIN(ball_as); LZ_PIN(ball_c); LZ_PIN(ball_r);
-#undef LZ_PIN
-    LZ_MARK(1);
-    // ---- trip 2, answers
-    int my_run_g;
-    {
-        const int rr = tid >> 6;
-#pragma unroll
-        for (int i = 0; i < PRIM_AHEAD; ++i) {
-            const int64_t p = p0 + i * stride;
-            const bool on = run_on[i] && p < n;
-            if (!on || pas_a[i] != 0) mr_a[i] = -1.0;
-            if (!on) cj_a[i] = 0.0;
-            if (!on) o32[i] = 0;
-            run_scale[i] = a.gscale[run_g[i]];
-        }
-        my_run_g = rr == 0 ? run_g[0] : rr == 1 ? run_g[1] : rr == 2 ? run_g[2] : run_g[3];
-    }
-    const double my_sc = a.gscale[my_run_g];
-    const float my_lo = a.glo[(int64_t)my_run_g * PRIM_FILTER_D + (tid & 63)];
-    if (tid < PRIM_FILTER_D) xcur[tid] = x_cur;
-    if (tid == 0) q_n = 0;
-    // ---- the chain: which nodes this launch commits (every workgroup, from the same records)
-    int k_found = 0;                                         // c_0 .. c_{k_found - 1}: in order, each below LB, below every w2 (from c_1 on)
-    double lb = __builtin_inf();
-    double core_unchosen = __builtin_inf();                  // the smallest core distance among the bests that are not chosen, and every cmin
-    if (rescan) {
-        if (tid == 0) { cps[0] = S.cur_p; cos_[0] = S.cur_o; ccs[0] = cc_cur; cws[0] = 0.0; srcs[0] = 0; }
-    } else {
-        // The chain's members lie below theta = min(LB, every w2): the records below it are FEW (they are collected through an LDS
-        // counter and ranked: three barriers, a handful of instructions); only when there are none (c_0 alone, if it is below LB) or
-        // more than TH_CAP (structureless data) do the waves run the selection rounds (eleven wave-wide reductions: 5.9 us).
-        constexpr int TH_CAP = 64;
-        double w2min = __builtin_inf(), cminmin = __builtin_inf();
-#pragma unroll
-        for (int it = 0; it < PRE; ++it) {
-            if (g_as[it] == 1) lb = fmin(lb, fmin(g_mm[it], g_lb[it]));
-            w2min = fmin(w2min, r_w2[it]); cminmin = fmin(cminmin, r_cmin[it]);
-        }
-        lb = idl_dev::wave_min_d(lb); w2min = idl_dev::wave_min_d(w2min); cminmin = idl_dev::wave_min_d(cminmin);
-        const int wv = tid >> 6;
-        if ((tid & 63) == 0) { sred[0][wv] = lb; sred[1][wv] = w2min; sred[2][wv] = cminmin; }
-        if (tid == 0) th_n = 0;
-        lds_barrier();
-        lb = fmin(fmin(sred[0][0], sred[0][1]), fmin(sred[0][2], sred[0][3]));
-        w2min = fmin(fmin(sred[1][0], sred[1][1]), fmin(sred[1][2], sred[1][3]));
-        cminmin = fmin(fmin(sred[2][0], sred[2][1]), fmin(sred[2][2], sred[2][3]));
-        const double theta = fmin(lb, w2min);
-        double cu = __builtin_inf();                         // smallest core distance among the records that are not listed
-        {
-            int cnt = 0;
-#pragma unroll
-            for (int it = 0; it < PRE; ++it) {
-                const bool below = r_jp[it] != ~0ull && r_w[it] < theta;
-                cnt += below ? 1 : 0;
-                if (!below) cu = fmin(cu, r_core[it]);
-            }
-            if (cnt) {
-                int at = atomicAdd(&th_n, cnt);
-#pragma unroll
-                for (int it = 0; it < PRE; ++it)
-                    if (r_jp[it] != ~0ull && r_w[it] < theta) { if (at < TH_CAP) { th_w[at] = r_w[it]; th_k[at] = r_jp[it]; th_c[at] = r_core[it]; } ++at; }
-            }
-        }
-        cu = idl_dev::wave_min_d(cu);
-        lds_barrier();                                     // (sred[0..2] have been read by everybody: the barrier above the reads... see below)
-        if ((tid & 63) == 0) sred[0][wv] = cu;
-        const int n_th = th_n;
-        lds_barrier();
-        cu = fmin(cminmin, fmin(fmin(sred[0][0], sred[0][1]), fmin(sred[0][2], sred[0][3])));
-        if (n_th >= 1 && n_th <= TH_CAP) {
-            // lane e < n_th of every wave holds entry e; LF_T rounds of the wave's smallest (weight, key) give the chain's candidates in
-            // order -- a full ranking (every entry against every other) was 2.9 us with the typical few dozen entries
-            const int e = tid & 63;
-            if (wv == 0) {                                   // (one wave: the other three leave their issue slots to the CU's other workgroup)
-                double me_w = __builtin_inf(), me_c = __builtin_inf(); unsigned long long me_k = ~0ull;
-                if (e < n_th) { me_w = th_w[e]; me_k = th_k[e]; me_c = th_c[e]; }
-                bool open_ = e < n_th;
-                for (int r = 0; r < LF_T; ++r) {
-                    const double wmin = idl_dev::wave_min_d(open_ ? me_w : __builtin_inf());
-                    unsigned long long key = (open_ && me_w == wmin) ? me_k : ~0ull;
-                    key = idl_dev::wave_min_u64(key);
-                    if (key == ~0ull) {                      // (uniform) nothing left
-                        if (e == 0) for (int r2 = r; r2 < LF_T; ++r2) { mg_w[r2] = __builtin_inf(); mg_k[r2] = ~0ull; mg_c[r2] = __builtin_inf(); }
-                        break;
-                    }
-                    if (open_ && me_k == key) { open_ = false; mg_w[r] = me_w; mg_k[r] = me_k; mg_c[r] = me_c; }
-                }
-                double cx = open_ ? me_c : __builtin_inf();  // listed, but behind the LF_T-th: unchosen
-                cx = idl_dev::wave_min_d(cx);
-                if (e == 0) sred[1][0] = cx;
-            }
-            lds_barrier();
-            cu = fmin(cu, sred[1][0]);
-        } else {
-            // none below theta (c_0 alone, if it is below LB: a stall otherwise, or a point that is no workgroup's best ties with it) or
-            // more than TH_CAP (structureless data right after a census): the smallest record, one node.  (The first form ran
-            // selection rounds here; their registers went to scratch at three workgroups a CU, and a build with that scratch gave
-            // wrong records -- not understood, avoided.)
-            double bw = __builtin_inf(); unsigned long long bk = ~0ull; double bc = __builtin_inf();
-#pragma unroll
-            for (int it = 0; it < PRE; ++it)
-                if (r_jp[it] != ~0ull && (r_w[it] < bw || (r_w[it] == bw && r_jp[it] < bk))) { bw = r_w[it]; bk = r_jp[it]; bc = r_core[it]; }
-            const double wmin = idl_dev::wave_min_d(bw);
-            unsigned long long key = (bw == wmin) ? bk : ~0ull;
-            key = idl_dev::wave_min_u64(key);
-            double core_w = (key != ~0ull && bk == key) ? bc : __builtin_inf();
-            core_w = idl_dev::wave_min_d(core_w);            // (the owner's value to every lane)
-            if ((tid & 63) == 0) { wl_w[wv][0] = key != ~0ull ? wmin : __builtin_inf(); wl_k[wv][0] = key; wl_c[wv][0] = core_w; }
-            lds_barrier();
-            if (tid == 0) {
-                int best = 0;
-                for (int v = 1; v < PRIM_NT / 64; ++v) if (wl_w[v][0] < wl_w[best][0] || (wl_w[v][0] == wl_w[best][0] && wl_k[v][0] < wl_k[best][0])) best = v;
-                mg_w[0] = wl_w[best][0]; mg_k[0] = wl_k[best][0]; mg_c[0] = wl_c[best][0];
-                for (int r = 1; r < LF_T; ++r) { mg_w[r] = __builtin_inf(); mg_k[r] = ~0ull; mg_c[r] = __builtin_inf(); }
-            }
-        }
-        lds_barrier();
-        const int T = S.fresh ? 1 : tmax;
-        for (int r = 0; r < T; ++r) {
-            const double w = mg_w[r]; const unsigned long long k = mg_k[r];
-            const bool ok = k != ~0ull && w < lb && (r == 0 || w < w2min);
-            if (!ok) break;
-            k_found = r + 1;
-        }
-        if (tid < LF_T) {
-            const bool on = tid < k_found;
-            cps[tid] = on ? (long long)(unsigned)(mg_k[tid] & 0xFFFFFFFFull) : -1; cos_[tid] = on ? (long long)(mg_k[tid] >> 32) : 0;
-            ccs[tid] = on ? mg_c[tid] : 0.0; cws[tid] = on ? mg_w[tid] : 0.0;
-        }
-        for (int r = k_found; r < LF_T; ++r) if (mg_k[r] != ~0ull) cu = fmin(cu, mg_c[r]);      // (merged, but not in the chain)
-        core_unchosen = cu;
-        if (k_found == 0) {                                  // STALL, as the single-node step decides it
-            if (lead) { *nx = S; nx->stalled = 1; }
-            if (has_ball && (tid & 63) == 0) z.lbp[(par ^ 1) * G + ball_g] = ball_lb;
-            return;
-        }
-    }
-    LZ_MARK(2);                                              // the chain's candidates
-    // ---- trip 3: the candidates' coordinates (and, for the recording workgroup, their stored sources)
-    const int k_nodes = rescan ? 1 : k_found;
-    lds_barrier();
-    {
-        const int f = tid & 63;
-        double xv[LF_T * PRIM_FILTER_D / PRIM_NT];
-#pragma unroll
-        for (int t = 0; t < LF_T * PRIM_FILTER_D / PRIM_NT; ++t) { const int q = (tid >> 6) + t * (PRIM_NT / 64); xv[t] = q < k_nodes ? (double)z.xrow[cps[q] * PRIM_FILTER_D + f] : 0.0; }
-        if (wg == 0 && !rescan && tid < k_nodes) srcs[tid] = a.source[cps[tid]];
-#pragma unroll
-        for (int t = 0; t < LF_T * PRIM_FILTER_D / PRIM_NT; ++t) { const int q = (tid >> 6) + t * (PRIM_NT / 64); if (q < k_nodes) xcs[q][f] = xv[t]; }
-    }
-    lds_barrier();
-    int m = 1;
-    if (!rescan) {
-        // how far each candidate is from the node added last (an upper bound): the waves take them in turn
-        for (int q = tid >> 6; q < k_nodes; q += PRIM_NT / 64) {
-            const int f = tid & 63;
-            const double t = xcs[q][f] - xcur[f];
-            const double d2 = idl_dev::wave_sum_d(t * t);
-            if (f == 0) dup[q] = __dsqrt_rn(d2) * (1.0 + 1e-9) + 1e-300;
-        }
-        lds_barrier();
-        double dmax = dup[0];
-        for (int i = 1; i < k_nodes; ++i) {
-            double mi = core_unchosen;                       // smallest core distance among the awake outside points other than c_0 .. c_i
-            for (int k = i + 1; k < k_nodes; ++k) mi = fmin(mi, ccs[k]);
-            if (!(cws[i] < mi) || !(cws[i] < lb - dmax)) break;
-            m = i + 1;
-            dmax = fmax(dmax, dup[i]);
-        }
-    }
-    LZ_MARK(3);                                              // their coordinates; how many go
-    {       // one (run, feature) per thread; its box corner and scale are loaded once, the nodes loop in LDS
-        static_assert(PRIM_RUNS * 64 == PRIM_NT && PRIM_FILTER_D == 64 && PRIM_AHEAD == 4, "one (run, feature) per thread");
-        const int rr = tid >> 6, k = tid & 63;
-        for (int q = 0; q < m; ++q) up[q][rr][k] = (float)((xcs[q][k] - (double)my_lo) / my_sc);
-    }
-    // ---- the recording workgroup: the edges of the committed nodes, in order (lazy_multi_kernel has the reasoning)
-    if (wg == 0 && !rescan) {
-        for (int pr = tid; pr < m * m; pr += PRIM_NT) {
-            const int k = pr / m, i = pr % m;
-            double v = __builtin_inf();
-            if (k < i) {
-                double acc = 0.0;
-#pragma unroll 8
-                for (int f = 0; f < PRIM_FILTER_D; ++f) {
-                    const double t = xcs[k][f] - xcs[i][f];
-                    acc = idl_dev::square_then_add(acc, t);
-                }
-                v = fmax(fmax(ccs[k], ccs[i]), __dsqrt_rn(acc));
-            }
-            pair_d[k * LF_T + i] = v;
-        }
-        lds_barrier();
-        if (tid < m) {                                       // lane i: the edge of c_i (its own pairs only: nothing sequential but the state)
-            const int i = tid;
-            double w = cws[i];
-            int64_t src = srcs[i];
-            for (int k = 0; k < i; ++k) if (pair_d[k * LF_T + i] < w) { w = pair_d[k * LF_T + i]; src = cos_[k]; }
-            const int64_t at = S.n_tree - 1 + i;
-            a.mst_cur[at] = src; a.mst_next[at] = cos_[i]; a.mst_w[at] = w;
-            a.min_reach[cps[i]] = -1.0;
-            z.tree_p[at + 1] = cps[i];
-            cws[i] = w;                                      // (the weight the edge was recorded with: the running mean below)
-        }
-        __builtin_amdgcn_wave_barrier();
-        if (tid == 0) {
-            LazyState t = S;
-            for (int i = 0; i < m; ++i) t.ema = t.ema + (cws[i] - t.ema) * (1.0 / 64.0);
-            t.n_tree = S.n_tree + m; t.cur_p = cps[m - 1]; t.cur_o = cos_[m - 1]; t.cur_w = cws[m - 1];
-            t.cand_par = S.cand_par ^ 1;
-            t.fresh = 0;
-            *nx = t;
-        }
-    } else if (lead) {                                       // a re-scan commits nothing
-        LazyState t = S;
-        t.cand_par = S.cand_par ^ 1;
-        t.fresh = 1;
-        *nx = t;
-    }
-    // ---- the sleeping groups' bounds meet the new nodes (a group per wave)
-    if (has_ball) {
-        double lbv = ball_lb;
-        if (!rescan && ball_as == 1) {
-            for (int q = 0; q < m; ++q) {
-                const double t = xcs[q][tid & 63] - ball_c;
-                const double d2 = idl_dev::wave_sum_d(t * t);
-                const double b = __dsqrt_rn(d2) * (1.0 - 1e-12) - ball_r;
-                lbv = fmin(lbv, b > 0.0 ? b : 0.0);
-            }
-        }
-        if ((tid & 63) == 0) z.lbp[(par ^ 1) * G + ball_g] = lbv;
-    }
-    lds_barrier();
-    LZ_MARK(4);                                              // boxes, recorded, balls
-    if (!any_on) { leave_empty(); return; }
-    // ---- which (point, node) pairs could change something: the floor test; the points with such a pair are the queue's items
-    bool act[PRIM_AHEAD];
-    unsigned mask[PRIM_AHEAD];
-    {
-        int cp_r[LF_T]; double cc_r[LF_T];                   // (once, into registers: the loops below were an LDS read per point and node)
-#pragma unroll
-        for (int q = 0; q < LF_T; ++q) { cp_r[q] = q < m ? (int)cps[q] : -1; cc_r[q] = q < m ? ccs[q] : __builtin_inf(); }
-#pragma unroll
-        for (int i = 0; i < PRIM_AHEAD; ++i) {
-            const int64_t p = p0 + i * stride;
-            act[i] = mr_a[i] >= 0.0;
-            mask[i] = 0u;
-#pragma unroll
-            for (int q = 0; q < LF_T; ++q) if ((int)p == cp_r[q]) act[i] = false; // committed in this launch (a re-scan: the node itself)
-#pragma unroll
-            for (int q = 0; q < LF_T; ++q) if (fmax(cc_r[q], cj_a[i]) < mr_a[i]) mask[i] |= 1u << q;       // (cc_r = inf beyond m: never)
-            if (!act[i]) mask[i] = 0u;
-        }
-    }
-    const float *xt = (const float *)a.xt;
-    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)xt, 0, 0xffffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t c_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.codes, 0, 0xffffffff, 0x00020000);
-    const int col_bytes = (int)n * 4;
-    // a (point, node) pair that passes the floor test is an ITEM of the workgroup's queue; a thread takes an item: the point's group,
-    // residual and codes -> the 8-bit bound; when it survives, the point's coordinates -> the exact distance (a dependent float64
-    // chain of 64 products and sums, 0.5 us: one per thread, side by side).  A point whose pairs do not fit waits for the next round.
-    constexpr int ITEMS = LZ_QCAP / LZ_T * LF_T;             // q_val's size
-    bool todo = false;
-#pragma unroll
-    for (int i = 0; i < PRIM_AHEAD; ++i) todo |= mask[i] != 0u;
-    while (lds_block_any(todo, any_flag)) {
-        int base[PRIM_AHEAD];
-        bool in_q[PRIM_AHEAD];
-#pragma unroll
-        for (int i = 0; i < PRIM_AHEAD; ++i) {
-            in_q[i] = false; base[i] = 0;
-            if (!mask[i]) continue;
-            const int cnt = __popc(mask[i]);
-            base[i] = atomicAdd(&q_n, cnt);
-            if (base[i] + cnt <= ITEMS) {
-                in_q[i] = true;
-                int s_ = base[i];
-                for (int q = 0; q < m; ++q) if (mask[i] >> q & 1u) q_pair[s_++] = (unsigned short)((tid * PRIM_AHEAD + i) | (q << 10));
-            } else {
-                for (int s_ = base[i]; s_ < ITEMS; ++s_) q_pair[s_] = 0xFFFFu;
-            }
-        }
-        lds_barrier();
-        LZ_MARK(8);
-        const int qn = q_n < ITEMS ? q_n : ITEMS;
-        for (int s_ = tid; s_ < qn; s_ += PRIM_NT) {
-            const unsigned it = q_pair[s_];
-            q_val[s_] = __builtin_inf();                     // (inf: the pair changes nothing)
-            if (it == 0xFFFFu) continue;
-            const int item = it & 1023, q = it >> 10, t_own = item / PRIM_AHEAD, i_own = item % PRIM_AHEAD;
-            const int64_t p = (int64_t)wg * PRIM_NT + t_own + i_own * stride;
-            const int64_t first = (int64_t)wg * PRIM_NT + i_own * stride;
-            const int gp = a.gid[p], gr = a.gid[first];
-            const float rsd = a.resid[p];
-            const double cjp = a.core[p], mrp = a.min_reach[p];
-            uint32_t cwd[PRIM_FILTER_D / 4];
-#pragma unroll
-            for (int k = 0; k < PRIM_FILTER_D / 4; ++k) cwd[k] = __builtin_amdgcn_raw_buffer_load_b32(c_rsrc, (uint32_t)p * 4u, k * (int)n * 4, 0);
-            bool live = true;
-            if (gp == gr) {
-                const double sc = (double)(float)a.gscale[gr];
-                float acc = 0.f;
-                const float *uu = up[q][i_own];
-#pragma unroll
-                for (int k = 0; k < PRIM_FILTER_D / 4; ++k) {
-                    const uint32_t w = cwd[k];
-                    const float t0 = uu[4 * k] - (float)(w & 255u), t1 = uu[4 * k + 1] - (float)((w >> 8) & 255u);
-                    const float t2 = uu[4 * k + 2] - (float)((w >> 16) & 255u), t3 = uu[4 * k + 3] - (float)(w >> 24);
-                    acc = fmaf(t0, t0, acc); acc = fmaf(t1, t1, acc); acc = fmaf(t2, t2, acc); acc = fmaf(t3, t3, acc);
-                }
-                const double lbq = sc * (double)sqrtf(acc) * (1.0 - 4e-5) - 0.01 * sc - (double)rsd;
-                if (fmax(fmax(ccs[q], cjp), lbq) >= mrp) live = false;
-            }
-            if (live) {
-                uint32_t v[64];
-#pragma unroll
-                for (int k = 0; k < 64; ++k) v[k] = __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, (uint32_t)p * 4u, k * col_bytes, 0);
-                double acc = 0.0;
-#pragma unroll
-                for (int k = 0; k < 64; ++k) {
-                    if ((k & 7) == 0) __builtin_amdgcn_sched_barrier(0);
-                    const double t = xcs[q][k] - (double)__uint_as_float(v[k]);
-                    acc = idl_dev::square_then_add(acc, t);
-                }
-                q_val[s_] = fmax(fmax(ccs[q], cjp), __dsqrt_rn(acc));       // mrd(node q, point p)
-            }
-        }
-        lds_barrier();
-        LZ_MARK(9);
-        bool left = false;
-#pragma unroll
-        for (int i = 0; i < PRIM_AHEAD; ++i) {
-            if (!mask[i]) continue;
-            if (!in_q[i]) { left = true; continue; }
-            const int64_t p = p0 + i * stride;
-            double mr = mr_a[i];
-            int64_t src = -1;
-            int s_ = base[i];
-            for (int q = 0; q < m; ++q) {
-                if (!(mask[i] >> q & 1u)) continue;
-                const double v = q_val[s_++];
-                if (v < mr) { mr = v; src = cos_[q]; }
-            }
-            if (src >= 0) { a.min_reach[p] = mr; a.source[p] = src; mr_a[i] = mr; }
-            mask[i] = 0u;
-        }
-        lds_barrier();
-        LZ_MARK(10);
-        if (tid == 0) q_n = 0;
-        todo = left;
-    }
-    LZ_MARK(5);                                              // floor tests, bounds, exact distances, applied
-    // ---- the workgroup's record: its best point (weight, then number), its core distance; the second smallest weight and the
-    // smallest core distance among the workgroup's other points
-    double bw = __builtin_inf(); int64_t bj = INT64_MAX, bp = 0;
-#pragma unroll
-    for (int i = 0; i < PRIM_AHEAD; ++i) if (act[i] && better(mr_a[i], (int64_t)o32[i], bw, bj)) { bw = mr_a[i]; bj = (int64_t)o32[i]; bp = p0 + i * stride; }
-    block_best_packed(bw, bj, bp, sw, sk);
-    double w2 = __builtin_inf(), cm = __builtin_inf(), cb = __builtin_inf();
-#pragma unroll
-    for (int i = 0; i < PRIM_AHEAD; ++i) {
-        const int64_t p = p0 + i * stride;
-        if (!act[i]) continue;
-        if (bj != INT64_MAX && p == bp) cb = cj_a[i];
-        else { w2 = fmin(w2, mr_a[i]); cm = fmin(cm, cj_a[i]); }
-    }
-    w2 = idl_dev::wave_min_d(w2); cm = idl_dev::wave_min_d(cm); cb = idl_dev::wave_min_d(cb);
-    if ((tid & 63) == 0) { sred[0][tid >> 6] = w2; sred[1][tid >> 6] = cm; sred[2][tid >> 6] = cb; }
-    lds_barrier();
-    if (tid == 0) {
-        CandF c;
-        c.w = bw;
-        c.core = fmin(fmin(sred[2][0], sred[2][1]), fmin(sred[2][2], sred[2][3]));
-        c.w2 = fmin(fmin(sred[0][0], sred[0][1]), fmin(sred[0][2], sred[0][3]));
-        c.cmin = fmin(fmin(sred[1][0], sred[1][1]), fmin(sred[1][2], sred[1][3]));
-        c.jp = bj == INT64_MAX ? ~0ull : (((unsigned long long)bj << 32) | (unsigned long long)(uint32_t)bp);
-        c.pad = 0.0;
-        *rec_out = c;
-    }
-    LZ_MARK(6);
-#ifdef IDL_PHASE_STAMPS
-    if (stamping) { atomicAdd(&lazy_phase_sum[kind_][7], 1ull); atomicAdd(&lazy_phase_sum[kind_][11], (unsigned long long)m); }
-#endif
-}
-
-struct LazyLayout { int64_t min_reach, source, cand0, cand1, candk0, candk1, rest0, rest1, dec, st, tree_p, run_asleep, pas, asleep, upto, minmr, lbp, gmin, galive, wg_list, total; };
+struct LazyLayout { int64_t min_reach, source, cand0, cand1, st, tree_p, run_asleep, pas, asleep, upto, minmr, lbp, gmin, galive, wg_list, total; };
 
 inline LazyLayout lazy_layout(int64_t n, int n_groups)
 {
@@ -2110,8 +997,6 @@ inline LazyLayout lazy_layout(int64_t n, int n_groups)
     auto take = [&](int64_t bytes) { const int64_t at = o; o += align256(bytes); return at; };
     l.min_reach = take(n * 8); l.source = take(n * 8);
     l.cand0 = take((int64_t)g * (int64_t)sizeof(Cand)); l.cand1 = take((int64_t)g * (int64_t)sizeof(Cand));
-    l.candk0 = take((int64_t)g * LZ_W * (int64_t)sizeof(CandK)); l.candk1 = take((int64_t)g * LZ_W * (int64_t)sizeof(CandK));
-    l.rest0 = take((int64_t)g * 8); l.rest1 = take((int64_t)g * 8); l.dec = take(2 * (int64_t)sizeof(LazyDec));
     l.st = take(2 * (int64_t)sizeof(LazyState)); l.tree_p = take(n * 8);
     l.run_asleep = take((n + 255) / 256); l.pas = take(n);
     l.asleep = take((int64_t)n_groups * 4); l.upto = take((int64_t)n_groups * 8); l.minmr = take((int64_t)n_groups * 8);
@@ -2221,42 +1106,7 @@ int idl_mst_prim_lazy(const void *xt, const float *xrow, const double *core, int
     int step_grid = grid;                                    // lazy_step_kernel's: the listed workgroups (lazy_list_kernel)
     const unsigned runs = (unsigned)((n + 255) / 256);
     hipLaunchKernelGGL(lazy_init_kernel, dim3(256), dim3(256), 0, st, a, z);
-    // several nodes per launch with the decision in a launch of its OWN: OPT-IN (IDELUCS_MST_MULTI = 2 .. 8; lazy_fold_kernel has it
-    // inside the step, opt-in as well; default: one node per launch).  Measured at 10^6 points (blobs /
-    // tight clusters; the same tree, edge for edge): 214 073 launch pairs instead of 1 002 049 launches -- 4.7 nodes a pair -- but a
-    // pair costs what 4.7 single steps cost: lazy_reduce_kernel 21.5 us (ONE workgroup: 5.6 to pull the lists of 520 workgroups
-    // through one CU, 6.1 for eight tournament rounds, 3.7 to merge by rank, 2.9 for the decision written by one lane) +
-    // lazy_multi_kernel 23-26 (the exact distances of a point against several nodes are dependent float64 chains; four rounds for the
-    // workgroup's list; the recording workgroup's serial edges) + two launch gaps, against 8.5 + one: 12.3-12.9 s against 10.9-12.2
-    // (stamps: tools/stamps_lazy.py with IDELUCS_MST_MULTI=8; profiles/r05_prim_stamps.txt).
-    const int multi_t = [] {       // (read at every call: the tests switch it inside one process)
-        const char *e = getenv("IDELUCS_MST_MULTI"); const int v = e ? atoi(e) : 0; return v < 2 ? 0 : (v > LZ_T ? LZ_T : v); }();
-    LazyMulti u{};
-    u.cand[0] = (CandK *)(w + l.candk0); u.cand[1] = (CandK *)(w + l.candk1);
-    u.rest[0] = (double *)(w + l.rest0); u.rest[1] = (double *)(w + l.rest1);
-    u.dec = (LazyDec *)(w + l.dec); u.tmax = multi_t;
-    const int one = 1;
-    auto set_fresh = [&](int par) { return hipMemcpyAsync(&u.dec[par].fresh, &one, sizeof(int), hipMemcpyHostToDevice, st); };
-    // the decision inside the step (lazy_fold_kernel): OPT-IN, IDELUCS_MST_FOLD = 1 .. 4 nodes a launch (default 0: the single-node step,
-    // lazy_step_kernel).  10^6 points of blobs / tight clusters, one box: 10.26-10.29 s against 11.54-11.63 (330 300 launches of ~28 us
-    // against 1 002 049 of ~10); on BASELINE cfg5's own latent 17.9 s against 14.2 (560 824 launches: 1.9 nodes a launch there).  The
-    // work per node inside a launch -- the chain's selection, boxes, pairs, record -- is instruction time on CUs that hold two
-    // workgroups, and costs two thirds of what a launch of its own costs; with LF_T = 8: 218 681 launches of 42 us.
-    const int fold_t = [] { const char *e = getenv("IDELUCS_MST_FOLD"); const int v = e ? atoi(e) : 0; return v < 1 ? 0 : (v > LF_T ? LF_T : v); }();
-    auto step = [&](int64_t ln, int rescan) {
-        if (fold_t && !multi_t) {
-            hipLaunchKernelGGL(lazy_fold_kernel, dim3(step_grid), dim3(PRIM_NT), 0, st, a, z, u, ln, rescan, fold_t);
-        } else if (multi_t) {
-            if (!rescan) hipLaunchKernelGGL(lazy_reduce_kernel, dim3(1), dim3(256), 0, st, a, z, u, ln, step_grid);
-            hipLaunchKernelGGL(lazy_multi_kernel, dim3(step_grid), dim3(PRIM_NT), 0, st, a, z, u, ln, rescan);
-        } else {
-            hipLaunchKernelGGL(lazy_step_kernel, dim3(step_grid), dim3(PRIM_NT), 0, st, a, z, ln, rescan);
-        }
-    };
-    if (multi_t) {
-        IDL_HIP_TRY(hipMemsetAsync(u.dec, 0, 2 * sizeof(LazyDec), st));
-        IDL_HIP_TRY(set_fresh(0)); IDL_HIP_TRY(set_fresh(1));
-    }
+    auto step = [&](int64_t ln, int rescan) { hipLaunchKernelGGL(lazy_step_kernel, dim3(step_grid), dim3(PRIM_NT), 0, st, a, z, ln, rescan); };
     auto relist = [&]() -> int {                             // the flags changed: the step's grid from the device's list
         hipLaunchKernelGGL(lazy_list_kernel, dim3(1), dim3(1024), 0, st, a, z);
         int L = 0;
@@ -2300,7 +1150,6 @@ int idl_mst_prim_lazy(const void *xt, const float *xrow, const double *core, int
         hipLaunchKernelGGL(lazy_flags_kernel, dim3(runs), dim3(256), 0, st, a, z);
         if (int rc = relist()) return rc;
         if (S.stalled) { S.stalled = 0; IDL_HIP_TRY(hipMemcpyAsync(z.st + (launch & 1), &S, sizeof(S), hipMemcpyHostToDevice, st)); IDL_HIP_TRY(hipStreamSynchronize(st)); }
-        if (multi_t) IDL_HIP_TRY(set_fresh((int)(launch & 1)));        // no node has met the new bounds yet: one node per launch until one has
         step(launch, 1); ++launch;   // candidates of the awake set
         last_census = S.n_tree;
     }

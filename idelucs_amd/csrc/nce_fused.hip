@@ -398,19 +398,6 @@ int idl_iic_joint(const float *z, int m, int C, float *P0, void *stream)
     return IDL_OK;
 }
 
-int idl_nce_pass1_joint(const float *f, int m, float temperature, void *workspace, const float *z, float *P0, int C, void *stream)
-{
-    IDL_REQUIRE(f && workspace && z && P0 && C >= 1 && C <= 48, "nce_pass1_joint: NULL buffer or n_clusters outside 1..48");
-    IDL_REQUIRE(m >= 32 && (m % 32) == 0 && m <= NCE_MAX_M && temperature > 0.f, "nce_pass1_joint: m must be a multiple of 32 in 32..2048, T > 0");
-    IDL_REQUIRE((((uintptr_t)f) & 15u) == 0, "f must be 16-byte aligned");
-    float *rowsum_part = (float *)workspace, *pos = rowsum_part + (size_t)NCE_SPLIT * m;
-    const dim3 grid1((unsigned)(m / 16 + 1), NCE_SPLIT);
-    hipLaunchKernelGGL(nce_pass1_kernel, grid1, dim3(256), 0, (hipStream_t)stream, f, m, 1.f / temperature, rowsum_part, pos,
-                       IicJob{P0, C, 0.f, 0.f, 0.f, nullptr, nullptr, z, 0});
-    IDL_HIP_TRY(hipGetLastError());
-    return IDL_OK;
-}
-
 int idl_nce_fused_iic_z(const float *f, int m, float temperature, float *lse, float *loss_rows, float *G_part, void *workspace,
                         const float *z, float *P0, int C, float lamb, float eps, float w_iic, float *iic_scratch, float *out, void *stream)
 {

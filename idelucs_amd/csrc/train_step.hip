@@ -658,11 +658,6 @@ struct MidBwdArgs {
     int64_t *ctl; int64_t batch_advance;
     int g_parts, m, C, train; float nce_coef;
     int act1_t;               // act1 is stored transposed, [512, m]
-    // fused InfoNCE pass 2 + IIC core (mid_bwd_kernel<true>): pass-1 results, the joint, where lse / loss rows / IIC go
-    const float *rowsum_part, *pos, *P0joint;
-    float *lse, *loss_rows, *out;
-    float inv_t, lamb, eps, w_iic;
-    int nce_split;
     // dr1 as two fp16 planes for the dW1 tiles' LDS-DMA (wgrad_planes_device.h: dplanes_body), in place of the fp32 tensor: the planes, the words of
     // their scale (planes.h: DR1_WORDS), the overflow flag
     uint16_t *dr1h, *dr1l;
@@ -673,16 +668,13 @@ struct MidBwdArgs {
 // (tile1 > tile0: the workgroups behind the COL_PARTS computing ones assemble tiles [tile0, tile1) of the NEXT batch into a
 // second x buffer, four 256-thread gather tiles of MID_GATHER_ROWS rows each -- this launch leaves three quarters of the CUs idle and is latency-bound, the gather is
 // pure streaming, and nothing in this step reads or writes what it touches.)
-// NCE = true (m == 16 * COL_PARTS, n_clusters <= 48): the launch starts one step earlier in the chain -- it is InfoNCE pass 2 as
-// well.  A workgroup owns 16 rows here exactly as there; with all 16 waves walking the column tiles (four each) the rows' G = (E +
-// E^T) f is complete inside the workgroup (partials added through LDS in a fixed order) and never goes to memory, and the IIC
-// core (400..2304 elements) is recomputed by every workgroup from the joint into LDS instead of being waited for.  One launch
-// boundary and the G / dP0 round trips disappear.
-template <bool NCE, bool BIG = false, bool DP = false>      // BIG: n_clusters > 48 (the per-row products then walk dP0 / W3 in memory); a separate instance, so that its
+// (Round 3's variant with InfoNCE pass 2 and the IIC core inside this launch -- 32.8 us against 9.5 + 13.5: the similarity tiles on this launch's 64 CUs -- was
+// removed in round 6: DESIGN, History.)
+template <bool BIG = false, bool DP = false>      // BIG: n_clusters > 48 (the per-row products then walk dP0 / W3 in memory); a separate instance, so that its
                                           // registers do not count against the n_clusters <= 48 one the training step runs.  DP: dr1 goes out as two fp16 planes
 __device__ __forceinline__ void mid_bwd_body(const MidBwdArgs &a, int tile0, int tile1, const idl_dev::GatherArgs &gth, const int bid)
 {
-    extern __shared__ float mid_dyn[];        // NCE: Gred[16 waves][16][64] | lse_all[m] | Ps[48 * 48]
+    extern __shared__ float mid_dyn[];        // BIG: W3 [C][64]
     if (bid >= COL_PARTS) {
         const int blk = tile0 + (bid - COL_PARTS) * 4 + (int)(threadIdx.x >> 8);
         if (blk < tile1) idl_dev::gather_tile<MID_GATHER_ROWS>(gth, (int64_t)blk, (int)(threadIdx.x & 255));
@@ -709,7 +701,7 @@ __device__ __forceinline__ void mid_bwd_body(const MidBwdArgs &a, int tile0, int
     if (DP && tid == 0) { s_dmx = 0u; s_dcnt = 0u; }
     unsigned int dmx = 0u;                       // the largest |dr1| this thread wrote, as its bit pattern (NaN and Inf order above every finite value)
     if (small) {
-        if (!NCE) for (int i = tid; i < C * C; i += 64 * MID_WAVES) sP[i] = a.dP0[i];
+        for (int i = tid; i < C * C; i += 64 * MID_WAVES) sP[i] = a.dP0[i];
         for (int i = tid; i < C * H2; i += 64 * MID_WAVES) sW3[i] = a.W3[i];
     } else {
         for (int i = tid; i < C * H2; i += 64 * MID_WAVES) mid_dyn[i] = a.W3[i];      // BIG: W3 (51 KB at 200 classes) in dynamic LDS -- read once per workgroup, not once per row
@@ -725,48 +717,6 @@ __device__ __forceinline__ void mid_bwd_body(const MidBwdArgs &a, int tile0, int
     }
     const float scale = a.train ? 2.f : 1.f;
     float cs1[2] = {0.f, 0.f}, s23 = 0.f, acc3[3] = {0.f, 0.f, 0.f};
-    float gsum_nce = 0.f;                     // NCE: ((E + E^T) f)[row r0 + wv][lane]
-    if (NCE) {
-        float *Gred = mid_dyn, *lse_all = mid_dyn + MID_WAVES * 16 * H2, *Ps = lse_all + m;
-        float rb[16];
-        nce_dev::load_rows(a.f, r0, l, q, rb);
-        for (int i = tid; i < m; i += 64 * MID_WAVES) {
-            float sm = 0.f;
-            for (int p = 0; p < a.nce_split; ++p) sm += a.rowsum_part[(int64_t)p * m + i];
-            lse_all[i] = __logf(sm);
-        }
-        iic_core_to_lds<64 * MID_WAVES>(a.P0joint, C, a.lamb, a.eps, a.w_iic, bid == 0 ? a.out : nullptr, sP, Ps);   // ends with a barrier
-        const int r = r0 + l;
-        const float lse_r = lse_all[r];
-        if (wv == 0 && q == 0) { a.lse[r] = lse_r; a.loss_rows[r] = lse_r - a.pos[r]; }
-        nce_dev::f32x4 g[4];
-#pragma unroll
-        for (int ct = 0; ct < 4; ++ct) g[ct] = nce_dev::f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int tc = wv; tc < m / 16; tc += MID_WAVES) {
-            const int j0 = tc * 16;
-            const nce_dev::f32x4 s = nce_dev::sim_tile(a.f, j0, rb, l, q);
-            float e[4];
-#pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {
-                const int j = j0 + 4 * q + gq;
-                const float x = s[gq] * a.inv_t;
-                e[gq] = (j == r) ? 0.f : __expf(x - lse_r) + __expf(x - lse_all[j]);
-            }
-#pragma unroll
-            for (int step = 0; step < 4; ++step) {
-                const float *frow = a.f + (int64_t)(j0 + 4 * q + step) * H2 + l;
-#pragma unroll
-                for (int ct = 0; ct < 4; ++ct) g[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(e[step], frow[16 * ct], g[ct], 0, 0, 0);
-            }
-        }
-#pragma unroll
-        for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) Gred[(wv * 16 + 4 * q + reg) * H2 + 16 * ct + l] = g[ct][reg];     // C/D: row = 4q + reg, col = l
-        __syncthreads();
-#pragma unroll
-        for (int w = 0; w < MID_WAVES; ++w) gsum_nce += Gred[(w * 16 + wv) * H2 + lane];      // this thread's own (row wv, column lane)
-    }
     for (int t0 = r0; t0 < r1; t0 += 16) {
         const int nr = (r1 - t0 < 16) ? r1 - t0 : 16;
         // the layer-1 activations this lane masks with in phase 2: requested now, needed after the head backward
@@ -803,12 +753,10 @@ __device__ __forceinline__ void mid_bwd_body(const MidBwdArgs &a, int tile0, int
             const float act = a.r2[(int64_t)row * H2 + lane];
             const float fr = a.f[(int64_t)row * H2 + lane], fp = a.f[(int64_t)prow * H2 + lane];
             float gp[8];                       // the first 8 partial products (idl_nce_fused_parts() = 8) are requested up front
-            if constexpr (!NCE) {
 #pragma unroll
-                for (int pp = 0; pp < 8; ++pp) gp[pp] = a.G[((int64_t)(pp < a.g_parts ? pp : 0) * m + row) * H2 + lane];
-            }
+            for (int pp = 0; pp < 8; ++pp) gp[pp] = a.G[((int64_t)(pp < a.g_parts ? pp : 0) * m + row) * H2 + lane];
 #pragma unroll
-            for (int pp = 0; pp < 8; ++pp) gp[pp] = (!NCE && pp < a.g_parts) ? gp[pp] : 0.f;
+            for (int pp = 0; pp < 8; ++pp) gp[pp] = pp < a.g_parts ? gp[pp] : 0.f;
             const float zp = cl ? zp_ : 0.f, zc = cl ? zc_ : 0.f;
             const float invr = a.inv[row];
             shz[wv][lane] = zp;
@@ -830,8 +778,7 @@ __device__ __forceinline__ void mid_bwd_body(const MidBwdArgs &a, int tile0, int
             float gsum = gp[0];
 #pragma unroll
             for (int pp = 1; pp < 8; ++pp) if (pp < a.g_parts) gsum += gp[pp];
-            if (!NCE) for (int pp = 8; pp < a.g_parts; ++pp) gsum += a.G[((int64_t)pp * m + row) * H2 + lane];
-            if (NCE) gsum = gsum_nce;
+            for (int pp = 8; pp < a.g_parts; ++pp) gsum += a.G[((int64_t)pp * m + row) * H2 + lane];
             const float df = a.nce_coef * (gsum - 2.f * fp);
             const float proj = wave_sum(fr * df);
             const float d = dl_cls + (df - fr * proj) * invr;
@@ -998,10 +945,10 @@ __device__ __forceinline__ void mid_bwd_body(const MidBwdArgs &a, int tile0, int
 struct MidBwdParams { MidBwdArgs a; int tile0, tile1; idl_dev::GatherArgs gth; };
 static_assert(sizeof(MidBwdParams) + idl::PLAN_PARAMS <= idl::PLAN_BYTES, "MidBwdParams does not fit a plan record");
 
-template <bool NCE, bool BIG = false, bool DP = false>
+template <bool BIG = false, bool DP = false>
 __global__ __launch_bounds__(64 * MID_WAVES) void mid_bwd_kernel(MidBwdArgs a, int tile0, int tile1, idl_dev::GatherArgs gth)
 {
-    mid_bwd_body<NCE, BIG, DP>(a, tile0, tile1, gth, (int)blockIdx.x);
+    mid_bwd_body<BIG, DP>(a, tile0, tile1, gth, (int)blockIdx.x);
 }
 
 // several voters in one launch, grid (voters, workgroups of one voter) as in mid_fwd_batched_kernel (n_clusters <= 48, separate
@@ -1009,7 +956,7 @@ __global__ __launch_bounds__(64 * MID_WAVES) void mid_bwd_kernel(MidBwdArgs a, i
 __global__ __launch_bounds__(64 * MID_WAVES) void mid_bwd_batched_kernel(const unsigned char *__restrict__ plans)
 {
     const MidBwdParams &p = *(const MidBwdParams *)(plans + (size_t)blockIdx.x * idl::PLAN_BYTES + idl::PLAN_PARAMS);
-    if (p.a.dr1h != nullptr) mid_bwd_body<false, false, true>(p.a, p.tile0, p.tile1, p.gth, (int)blockIdx.y);
+    if (p.a.dr1h != nullptr) mid_bwd_body<false, true>(p.a, p.tile0, p.tile1, p.gth, (int)blockIdx.y);
     else mid_bwd_body<false, false>(p.a, p.tile0, p.tile1, p.gth, (int)blockIdx.y);
 }
 
@@ -1295,16 +1242,6 @@ __global__ __launch_bounds__(l1_dev::THREADS, 4) void l1_rms_kernel(l1_dev::L1Ar
     rmsprop_body<false>(a, hyper, ctl, batch_advance, 0, 0, idl_dev::GatherArgs{}, (int)blockIdx.x - l.n_tiles, (int)threadIdx.x);
 }
 
-// The same with the layer-1 tiles of l1_planes_device.h (the product on the fp16 matrix cores from two-plane operands).  A tile
-// workgroup fills its CU (96 KB of LDS, eight waves): the riders start as tiles leave and end the launch behind them.
-__global__ __launch_bounds__(l1p_dev::THREADS, 1) void l1p_rms_kernel(l1p_dev::L1pArgs l, RmsArgs a, const float *hyper, int64_t *ctl, int64_t batch_advance)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char l1p_rms_smem[];
-    if ((int)blockIdx.x < l.n_tiles) { l1p_dev::l1p_body(l, (int)blockIdx.x, l1p_rms_smem); return; }
-    if (threadIdx.x >= RMS_THREADS) return;                  // (before any barrier: rmsprop_body is written for 256 threads)
-    rmsprop_body<false>(a, hyper, ctl, batch_advance, 0, 0, idl_dev::GatherArgs{}, (int)blockIdx.x - l.n_tiles, (int)threadIdx.x);
-}
-
 // The launch between the two-plane layer-1 tiles (idl_l1_planes) and mid_fwd: its first r.blocks workgroups add the KPARTS partial sums
 // part[p][i] in ascending p into part[0][i] (16-byte elements, all requests of a thread in flight before the first add) -- 16 MB read by
 // every CU at once instead of by mid_fwd's 64 workgroups -- and the workgroups behind them are the previous step's optimizer tail
@@ -1452,10 +1389,10 @@ static int launch_mid_bwd_big(const MidBwdArgs &a, unsigned grid, int t0, int t1
     int dev = 0;
     IDL_HIP_TRY(hipGetDevice(&dev));
     if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-        IDL_HIP_TRY(hipFuncSetAttribute((const void *)mid_bwd_kernel<false, true, DP>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * MAX_CPL * H2 * (int)sizeof(float)));
+        IDL_HIP_TRY(hipFuncSetAttribute((const void *)mid_bwd_kernel<true, DP>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * MAX_CPL * H2 * (int)sizeof(float)));
         attr_set[dev] = true;
     }
-    hipLaunchKernelGGL((mid_bwd_kernel<false, true, DP>), dim3(grid), dim3(64 * MID_WAVES), lds, (hipStream_t)stream, a, t0, t1, g);
+    hipLaunchKernelGGL((mid_bwd_kernel<true, DP>), dim3(grid), dim3(64 * MID_WAVES), lds, (hipStream_t)stream, a, t0, t1, g);
     IDL_HIP_TRY(hipGetLastError());
     return IDL_OK;
 }
@@ -1672,50 +1609,6 @@ int idl_mid_bwd(const float *z, const float *r2, const float *f, const float *in
     return IDL_OK;
 }
 
-int idl_nce_mid_bwd_gather(const float *z, const float *r2, const float *f, const float *inv, const void *nce_workspace, int nce_split,
-                           float temperature, const float *P0_joint, float lamb, float eps, float w_iic, float *lse, float *loss_rows,
-                           float *out, const float *W3, const float *W2, const float *act1, int m, int C, int train, float nce_coef,
-                           float *dlogits, float *dlat, float *dr1, float *partial1, float *partial2, float *partial3, float *dW3_partial,
-                           const float *feats, int64_t n, int64_t fdim, int64_t view_stride, const int64_t *pair_idx, const int64_t *base,
-                           int64_t base_add, int64_t n_pairs, int64_t batch, const double *mean, const double *scale,
-                           const double *inv_scale, float *y, int part, int part_end, int parts, int act1_transposed, void *stream)
-{
-    IDL_REQUIRE(parts >= 1 && part >= 0 && part <= part_end && part_end <= parts, "nce_mid_bwd_gather: need 0 <= part <= part_end <= parts");
-    IDL_REQUIRE(z && r2 && f && inv && nce_workspace && P0_joint && lse && loss_rows && out && W3 && W2 && act1 && dlogits && dlat && dr1 &&
-                partial1 && partial2 && partial3, "NULL buffer");
-    IDL_REQUIRE(m == 16 * COL_PARTS && C >= 1 && C <= 48 && nce_split >= 1 && nce_split <= 64 && temperature > 0.f,
-                "nce_mid_bwd_gather: m must be 1024 (16 rows per partial-sum chunk), n_clusters in 1..48");
-    IDL_REQUIRE((((uintptr_t)f) & 15u) == 0, "f must be 16-byte aligned");
-    MidBwdArgs a{};
-    a.z = z; a.r2 = r2; a.f = f; a.inv = inv; a.G = nullptr; a.dP0 = nullptr; a.W3 = W3; a.W2 = W2; a.act1 = act1;
-    a.dlogits = dlogits; a.dlat = dlat; a.dr1 = dr1; a.partial1 = partial1; a.partial2 = partial2; a.partial3 = partial3;
-    a.dW3_part = dW3_partial; a.ctl = nullptr; a.batch_advance = 0;
-    a.g_parts = 1; a.m = m; a.C = C; a.train = train; a.nce_coef = nce_coef; a.act1_t = act1_transposed ? 1 : 0;
-    a.rowsum_part = (const float *)nce_workspace; a.pos = a.rowsum_part + (size_t)nce_split * m; a.P0joint = P0_joint;
-    a.lse = lse; a.loss_rows = loss_rows; a.out = out; a.inv_t = 1.f / temperature; a.lamb = lamb; a.eps = eps; a.w_iic = w_iic;
-    a.nce_split = nce_split;
-    idl_dev::GatherArgs g{};
-    int64_t t0 = 0, t1 = 0;
-    if (feats != nullptr) {
-        IDL_REQUIRE(pair_idx && mean && scale && y && n >= 1 && fdim >= 4 && (fdim & 3) == 0 && batch >= 1 && n_pairs >= 0,
-                    "nce_mid_bwd_gather: bad gather arguments (4 | f)");
-        g = idl_dev::GatherArgs{feats, n, fdim, view_stride, pair_idx, base, batch, n_pairs, mean, scale, inv_scale, y, base_add};
-        const int64_t ng = idl_dev::gather_tiles<MID_GATHER_ROWS>(fdim, batch);
-        t0 = ng * part / parts; t1 = ng * part_end / parts;
-    }
-    const int lds = (MID_WAVES * 16 * H2 + m + 48 * 48) * 4;
-    static bool attr_set[64] = {};
-    int dev = 0;
-    IDL_HIP_TRY(hipGetDevice(&dev));
-    if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-        IDL_HIP_TRY(hipFuncSetAttribute((const void *)mid_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_set[dev] = true;
-    }
-    hipLaunchKernelGGL(mid_bwd_kernel<true>, dim3((unsigned)(COL_PARTS + (t1 - t0 + 3) / 4)), dim3(64 * MID_WAVES), lds, (hipStream_t)stream, a, (int)t0,
-                       (int)t1, g);
-    IDL_HIP_TRY(hipGetLastError());
-    return IDL_OK;
-}
 
 static int mid_bwd_gather_impl(const float *z, const float *r2, const float *f, const float *inv, const float *G, int g_parts, const float *dP0,
                        const float *W3, const float *W2, const float *act1, int m, int C, int train, float nce_coef, float *dlogits,
@@ -1762,7 +1655,7 @@ static int mid_bwd_gather_impl(const float *z, const float *r2, const float *f, 
     }
     if (C > 48) return dr1h != nullptr ? launch_mid_bwd_big<true>(a, (unsigned)(COL_PARTS + (t1 - t0 + 3) / 4), (int)t0, (int)t1, g, stream)
                                        : launch_mid_bwd_big<false>(a, (unsigned)(COL_PARTS + (t1 - t0 + 3) / 4), (int)t0, (int)t1, g, stream);
-    if (dr1h != nullptr) hipLaunchKernelGGL((mid_bwd_kernel<false, false, true>), dim3((unsigned)(COL_PARTS + (t1 - t0 + 3) / 4)), dim3(64 * MID_WAVES), 0, (hipStream_t)stream,
+    if (dr1h != nullptr) hipLaunchKernelGGL((mid_bwd_kernel<false, true>), dim3((unsigned)(COL_PARTS + (t1 - t0 + 3) / 4)), dim3(64 * MID_WAVES), 0, (hipStream_t)stream,
                                             a, (int)t0, (int)t1, g);
     else if (C <= 48) hipLaunchKernelGGL((mid_bwd_kernel<false, false>), dim3((unsigned)(COL_PARTS + (t1 - t0 + 3) / 4)), dim3(64 * MID_WAVES), 0, (hipStream_t)stream, a, (int)t0,
                                     (int)t1, g);
@@ -1870,7 +1763,7 @@ static int rmsprop_launch(int count, float *const *params, const float *const *g
                           void *stream, int wg_index = -1, const float *wg_dy = nullptr, const float *wg_x = nullptr, int wg_m = 0,
                           int wg_n_out = 0, int wg_n_in = 0, float *wg_grad = nullptr, int wg_x_transposed = 0,
                           const wg_dev::WgArgs *big = nullptr, int big_index = -1, const l1_dev::L1Args *l1 = nullptr, int skip_index = -1,
-                          const l1p_dev::L1pArgs *l1p = nullptr, const ReduceArgs *red = nullptr, const wgp_dev::XpArgs *xp = nullptr)
+                          const ReduceArgs *red = nullptr, const wgp_dev::XpArgs *xp = nullptr)
 {
     IDL_REQUIRE(count >= 1 && count <= 8 && params && grads && square_avg && sizes && hyper && ctl, "rmsprop_step: 1..8 tensors");
     RmsArgs a{};
@@ -1915,7 +1808,7 @@ static int rmsprop_launch(int count, float *const *params, const float *const *g
     for (int i = count; i <= 8; ++i) a.first[i] = nb_total;
     const int64_t extra = g.y != nullptr ? idl_dev::gather_blocks(g.f, g.batch) : 0;
     if (xp != nullptr) {                    // ... carried by the loader waves of the two-plane dW1 tiles (wgrad_xplanes_rms_kernel)
-        IDL_REQUIRE(big == nullptr && l1 == nullptr && l1p == nullptr && red == nullptr && extra == 0, "wgrad_xplanes_rms: no other tiles, no batch assembly");
+        IDL_REQUIRE(big == nullptr && l1 == nullptr && red == nullptr && extra == 0, "wgrad_xplanes_rms: no other tiles, no batch assembly");
         idl::DeviceInfo di;
         if (const int rc = idl::device_info(&di); rc != IDL_OK) return rc;
         IDL_REQUIRE(nb_total + a.wg_tiles <= xp->tiles && xp->tiles <= di.cus, "wgrad_xplanes_rms: the tail's blocks need a tile each, and every tile its own CU");
@@ -1940,23 +1833,9 @@ static int rmsprop_launch(int count, float *const *params, const float *const *g
         return IDL_OK;
     }
     if (red != nullptr) {                   // ... beside the workgroups that add up the two-plane layer-1 tiles' partial sums (reduce_rms_kernel)
-        IDL_REQUIRE(big == nullptr && l1 == nullptr && l1p == nullptr && extra == 0 && idl::take_plan() == nullptr, "reduce_parts_rms: no tiles, no batch assembly, not recordable");
+        IDL_REQUIRE(big == nullptr && l1 == nullptr && extra == 0 && idl::take_plan() == nullptr, "reduce_parts_rms: no tiles, no batch assembly, not recordable");
         hipLaunchKernelGGL(reduce_rms_kernel, dim3((unsigned)(red->blocks + nb_total + a.wg_tiles)), dim3(256), 0, (hipStream_t)stream, *red, a, hyper, ctl,
                            batch_advance, 1);
-        IDL_HIP_TRY(hipGetLastError());
-        return IDL_OK;
-    }
-    if (l1p != nullptr) {                   // ... behind the layer-1 tiles in their two-plane form (l1p_rms_kernel)
-        IDL_REQUIRE(big == nullptr && l1 == nullptr && extra == 0 && idl::take_plan() == nullptr, "l1_planes_rms: no dW1 tiles, no batch assembly, not recordable");
-        static bool attr_set[64] = {};
-        int dev = 0;
-        IDL_HIP_TRY(hipGetDevice(&dev));
-        if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-            IDL_HIP_TRY(hipFuncSetAttribute((const void *)l1p_rms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, l1p_dev::LDS_BYTES));
-            attr_set[dev] = true;
-        }
-        hipLaunchKernelGGL(l1p_rms_kernel, dim3((unsigned)(l1p->n_tiles + nb_total + a.wg_tiles)), dim3(l1p_dev::THREADS), l1p_dev::LDS_BYTES,
-                           (hipStream_t)stream, *l1p, a, hyper, ctl, batch_advance);
         IDL_HIP_TRY(hipGetLastError());
         return IDL_OK;
     }
@@ -2095,22 +1974,6 @@ int idl_l1_fwd_rms(const float *W1, const float *x, int m, int n_in, float *r1_t
                           stream, wg_index, wg_dy, wg_x, wg_m, wg_n_out, wg_n_in, wg_grad, wg_x_transposed, nullptr, -1, &l, w1_index);
 }
 
-// the layer-1 tiles from two-plane operands (idl_l1_planes) with the previous step's optimizer tail behind them; part: [8][n_hidden][m]
-int idl_l1_planes_rms(const void *w_hi, const void *w_lo, const void *x_hi, const void *x_lo, int m, int n_in, float *part,
-                      int count, float *const *params, const float *const *grads, const int32_t *grad_parts,
-                      float *const *square_avg, const int64_t *sizes, const float *hyper, int64_t *ctl,
-                      const float *loss_rows, int loss_m, float w_nce, float w_iic, float *out, int w1_index,
-                      int wg_index, const float *wg_dy, const float *wg_x, int wg_x_transposed, int wg_m, int wg_n_out, int wg_n_in,
-                      float *wg_grad, int64_t batch_advance, void *stream)
-{
-    IDL_REQUIRE(w_hi && w_lo && x_hi && x_lo && part && l1p_dev::supported(m, H1, n_in), "l1_planes_rms: Linear(n_in, 512), m % 128 == 0, n_in % 512 == 0, n_in >= 1024");
-    IDL_REQUIRE(((((uintptr_t)w_hi) | ((uintptr_t)w_lo) | ((uintptr_t)x_hi) | ((uintptr_t)x_lo) | ((uintptr_t)part)) & 15u) == 0, "l1_planes_rms: buffers must be 16-byte aligned");
-    const l1p_dev::L1pArgs l{(const uint16_t *)w_hi, (const uint16_t *)w_lo, (const uint16_t *)x_hi, (const uint16_t *)x_lo, part, m, H1, n_in,
-                             (H1 / l1p_dev::TM) * (m / l1p_dev::TN) * l1p_dev::KSPLIT, n_in, n_in, 0};
-    idl_dev::GatherArgs g{};
-    return rmsprop_launch(count, params, grads, grad_parts, square_avg, sizes, hyper, ctl, batch_advance, loss_rows, loss_m, w_nce, w_iic, out, g,
-                          stream, wg_index, wg_dy, wg_x, wg_m, wg_n_out, wg_n_in, wg_grad, wg_x_transposed, nullptr, -1, nullptr, w1_index, &l);
-}
 
 // part[p][i], p < idl_l1_planes_parts(), i < slab_elems (4 | slab_elems): part[0][i] = ((part[0][i] + part[1][i]) + ...) in ascending p.
 // With count >= 1: the previous step's optimizer tail in the same launch (arguments as idl_l1_fwd_rms); count == 0: the sums alone.
@@ -2140,7 +2003,7 @@ int idl_reduce_parts_rms(float *part, int64_t slab_elems, const int64_t *step_co
     }
     idl_dev::GatherArgs g{};
     return rmsprop_launch(count, params, grads, grad_parts, square_avg, sizes, hyper, ctl, batch_advance, loss_rows, loss_m, w_nce, w_iic, out, g,
-                          stream, wg_index, wg_dy, wg_x, wg_m, wg_n_out, wg_n_in, wg_grad, wg_x_transposed, nullptr, -1, nullptr, w1_index, nullptr, &r);
+                          stream, wg_index, wg_dy, wg_x, wg_m, wg_n_out, wg_n_in, wg_grad, wg_x_transposed, nullptr, -1, nullptr, w1_index, &r);
 }
 
 // idl_wgrad_rmsprop_xplanes (W updated, its planes written) with THIS step's optimizer tail carried by the tiles' loader waves (tail arguments as
@@ -2168,7 +2031,7 @@ int idl_wgrad_xplanes_rms(const void *dy_hi, const void *dy_lo, int *dy_scale, c
     x.dbg = wgp_dbg;
     idl_dev::GatherArgs g{};
     return rmsprop_launch(count, params, grads, grad_parts, square_avg_all, sizes, hyper, ctl, batch_advance, loss_rows, loss_m, w_nce, w_iic, out, g,
-                          stream, wg_index, wg_dy, wg_x, wg_m, wg_n_out, wg_n_in, wg_grad, wg_x_transposed, nullptr, -1, nullptr, w1_index, nullptr, nullptr, &x);
+                          stream, wg_index, wg_dy, wg_x, wg_m, wg_n_out, wg_n_in, wg_grad, wg_x_transposed, nullptr, -1, nullptr, w1_index, nullptr, &x);
 }
 
 int idl_debug_phase_stamps(int on)

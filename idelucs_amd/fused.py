@@ -52,14 +52,12 @@ VARIANTS = {
     "nce_fused": "1",        # 0: S = f f^T as a GEMM + row kernels instead of the fused InfoNCE passes
     "dw3_partial": "1",      # 0: dW3 as a GEMM instead of stacked partials from the middle-backward launch (n_clusters <= 48)
     "test_cold": "0",        # 1: a 512 MB fill in front of the hand-scheduled launches (tests/test_gpu_planes.py::test_cold_caches_*)
-    "planes_reduce": "launch",   # mid: mid_fwd adds the eight K-slice partial sums itself
-    "planes_fork": "0",      # 1: the pending tail on a second stream beside the layer-1 tiles
     "lockstep_planes": "1",  # 0: a rank's voters in lockstep on batched fp32 library GEMMs
     "planes_wgrad": "1",     # 0: dW1 on the fp32 tiles (writing W1's planes) beside the two-plane layer 1
     "planes_tail": "wgrad",  # reduce: the optimizer tail beside the next step's partial sums instead of on the dW1 tiles' loader waves
     "mid_fused": "1", "pipeline": "1", "dw2_inlaunch": "1", "overlap": "0", "early_gather": "1", "gather_split": "4", "transposed_l1": "1",
     "l1_fused": "0",         # 1: bias / ReLU / Dropout / the K-split of Linear(512, 64) in the epilogue of own layer-1 tiles; bare: those tiles as a plain product
-    "l1_gather": "0", "nce_bwd_fused": "0", "joint_inlaunch": "1", "wgrad_fused": "1", "keep_w1_grad": "0", "steps_per_graph": "16",
+    "l1_gather": "0", "joint_inlaunch": "1", "wgrad_fused": "1", "keep_w1_grad": "0", "steps_per_graph": "16",
     "tail_l1": "1",          # 0 (fp32 form): the optimizer tail behind the dW1 tiles instead of riding in the next step's layer-1 launch
 }
 
@@ -214,8 +212,7 @@ class FusedLinearTrainer:
         # 100.6 us against 111.0 at cfg2 (tools/bench_planes.py).  Needs the default launch sequence of a single voter (tail-in-layer-1),
         # m % 128 == 0 and F % 512 == 0; any other step runs the fp32 tiles.
         self._planes = planes_default()
-        self._planes_reduce_launch = _v("planes_reduce") != "mid"
-        self._planes_fork = _v("planes_fork") == "1"
+        self._planes_reduce_launch = True        # (round 6: the variant in which mid_fwd added the eight partial sums itself -- +8 us -- was removed)
         # ... and the same for a rank's voters in lockstep (BatchedLinearTrainer; IDELUCS_LOCKSTEP_PLANES=0: their products as batched fp32
         # library GEMMs instead): the six launches of the two-plane step recorded per voter and run once for all of them, blockIdx.y = voter
         # -- the lone voters' steps bit for bit (tests/test_gpu_planes.py), 47.5 / 45.4 / 43.6 ms a voter-epoch in batches of 2 / 4 / 8
@@ -264,7 +261,7 @@ class FusedLinearTrainer:
         self._l1_gather = min(max(int(_v("l1_gather")), 0), 8)   # eighths of the next batch's tiles its riders assemble
         # opt-in: InfoNCE pass 2 + IIC core inside the mid-backward launch (one boundary less, but the InfoNCE tiles then run on
         # the 64 CUs of that launch instead of 256: the fused launch takes 32.8 us against 9.5 + 13.5 -- measured +8 us per step)
-        self._nce_bwd_fused = _v("nce_bwd_fused") != "0"
+        self._nce_bwd_fused = False              # (round 6: InfoNCE pass 2 + the IIC core inside the mid-backward launch -- +8 us a step -- was removed)
         self._joint_inlaunch = _v("joint_inlaunch") != "0"   # IIC joint inside the InfoNCE pass-1 launch
         # dW1 on this package's own MFMA tiles with RMSprop in their epilogue, as the head of the optimizer launch
         # (csrc/wgrad_device.h, idl_wgrad_rmsprop_step): one launch instead of hipBLASLt's GEMM + the optimizer launch, and the 8 MB
@@ -388,16 +385,10 @@ class FusedLinearTrainer:
         # shares (eighths) of the next batch's assembly: [0, g1) riders of the layer-1 launch, [g1, g2) the mid-forward launch, [g2, 8) mid-backward
         g1 = self._l1_gather if l1 else 0
         g2 = max(g1, self._gsplit)
-        if pl and self._planes_reduce_launch:
-            # a1^T = W1 x^T as eight K-slice partial sums on the fp16 matrix cores (the tiles alone: five chunks resident, the whole LDS);
-            # then ONE launch that adds the eight up on every CU and, beside that, runs the previous step's optimizer tail
+        if pl:
+            # a1^T = W1 x^T as eight K-slice partial sums on the fp16 matrix cores, then ONE launch that adds the eight up on every CU (and, in the
+            # variant that keeps the tail off the dW1 tiles' loader waves, runs the previous step's optimizer tail beside that)
             wh, wl, _ = self._w1_planes
-            fork = self._planes_fork and self._pending is not None
-            if fork:        # the tail as a launch of its own on a second stream, beside the tiles (nothing it touches is read before mid_fwd)
-                self._side.wait_stream(main)
-                with torch.cuda.stream(self._side):
-                    pbf, pxi, pr1 = self._pending
-                    self._tail_launch(pbf, pxi, pr1)
             if self._cold:
                 self._evict()
             chk(_L.idl_l1_planes(_p(wh), _p(wl), self.F, _p(pb["xh"][xi]), _p(pb["xl"][xi]), self.F, m, self.H1, self.F, _p(pb["part"][xi]), _stream()))
@@ -407,17 +398,6 @@ class FusedLinearTrainer:
             else:
                 chk(_L.idl_reduce_parts_rms(_p(pb["part"][xi]), self.H1 * m, _p(self.ctl), _p(self._ctl_snap), 0, None, None, None, None, None, None, None, None, 0, 0.0, 0.0, None, 0,
                                             -1, None, None, 0, 0, 0, 0, None, 0, _stream()))
-            if fork:
-                main.wait_stream(self._side)
-        elif pl:    # ... or the tiles with the tail riding behind them, and mid_fwd adding the eight (IDELUCS_PLANES_REDUCE=mid)
-            wh, wl, _ = self._w1_planes
-            if self._pending is not None:
-                pbf, pxi, pr1 = self._pending
-                self._tail_launch(pbf, pxi, pr1, l1p=(wh, wl, pb["xh"][xi], pb["xl"][xi], m, pb["part"][xi]))
-            else:
-                if self._cold:
-                    self._evict()
-                chk(_L.idl_l1_planes(_p(wh), _p(wl), self.F, _p(pb["xh"][xi]), _p(pb["xl"][xi]), self.F, m, self.H1, self.F, _p(pb["part"][xi]), _stream()))
         elif tm:    # a1^T = W1 x^T on own tiles; the previous step's optimizer tail rides in the same launch
             if self._pending is not None:
                 pbf, pxi, pr1 = self._pending
@@ -447,7 +427,7 @@ class FusedLinearTrainer:
             self._evict()
         if pl:      # mid_fwd adds the eight partial sums; its spare workgroups assemble the first half of the next batch AND its planes
             st = next_from
-            chk(_L.idl_mid_fwd_gather_planes(_p(pb["part"][xi]), _p(self.b1), 1 if self._planes_reduce_launch else 3, _p(self.W2), _p(self.b2), _p(self.W3), _p(self.b3),
+            chk(_L.idl_mid_fwd_gather_planes(_p(pb["part"][xi]), _p(self.b1), 1, _p(self.W2), _p(self.b2), _p(self.W3), _p(self.b3),
                                              m, C, tr, self.seed, _p(self.ctl), _p(bf.f), _p(bf.inv), _p(bf.r2), _p(bf.z),
                                              _p(st.feats), st.n, st.f, st.n * st.f, _p(self._perm), _p(self.ctl[1:]), m // 2, st.n_pairs, m // 2,
                                              _p(st.mean), _p(st.scale), _p(st.inv_scale), None if plw else _p(bf.xs[1 - xi]), _p(pb["xh"][1 - xi]),
@@ -484,11 +464,7 @@ class FusedLinearTrainer:
             chk(_L.idl_head_fwd(_p(bf.lat), _p(self.W3), _p(self.b3), m, C, tr, self.seed, _p(self.ctl),
                                 _p(bf.f), _p(bf.inv), _p(bf.r2), _p(bf.z), _stream()))
         # ---- the two losses are independent: with the fused InfoNCE kernels the IIC core rides along as one extra workgroup
-        # InfoNCE pass 2 + IIC core inside the mid-backward launch (m = 1024: a workgroup owns the same 16 rows in both)
-        nce_bwd = (early and self._nce_bwd_fused and bf.nce_fused and C <= 48 and m == 1024 and not self._overlap and self._joint_inlaunch)
-        if nce_bwd:
-            chk(_L.idl_nce_pass1_joint(_p(bf.f), m, TEMPERATURE, _p(bf.nce_ws), _p(bf.z), _p(bf.P0), C, _stream()))
-        elif bf.nce_fused and C <= 48 and not self._overlap and self._joint_inlaunch:
+        if bf.nce_fused and C <= 48 and not self._overlap and self._joint_inlaunch:
             # the IIC workgroup of InfoNCE pass 1 forms the joint z1^T z2 itself (MFMA tiles) before the core
             self._k(_L.idl_nce_fused_iic_z, _p(bf.f), m, TEMPERATURE, _p(bf.lse), _p(bf.loss_rows), _p(bf.G), _p(bf.nce_ws), _p(bf.z),
                     _p(bf.P0), C, self.lamb, EPS, self.weight, _p(bf.iic_scratch), _p(self.out), _stream())
@@ -520,20 +496,7 @@ class FusedLinearTrainer:
         gW1, gb1, gW2, gb2, gW3, gb3 = self.grads
         adv_ctl = _p(self.ctl) if (next_from is not None and not early and not early_f) else None
         adv = batch_advance if (next_from is not None and not early and not early_f) else 0
-        if early and nce_bwd:
-            st = next_from
-            chk(_L.idl_nce_mid_bwd_gather(_p(bf.z), _p(bf.r2), _p(bf.f), _p(bf.inv), _p(bf.nce_ws), bf.nce_parts, TEMPERATURE, _p(bf.P0),
-                                          self.lamb, EPS, self.weight, _p(bf.lse), _p(bf.loss_rows), _p(self.out), _p(self.W3), _p(self.W2),
-                                          _p(r1), m, C, tr, nce_coef, _p(bf.dlogits), _p(bf.dlat), _p(bf.dr1), _p(gb1), _p(gb2), _p(gb3),
-                                          _p(gW3) if self._dw3_partial else None,
-                                          _p(st.feats), st.n, st.f, st.n * st.f, _p(self._perm), _p(self.ctl[1:]), m // 2, st.n_pairs, m // 2,
-                                          _p(st.mean), _p(st.scale), _p(st.inv_scale), _p(bf.xs[1 - xi]),
-                                          g2 if self._early_split else 0, 8, 8, 1 if tl else 0, _stream()))
-            if not self._dw3_partial:
-                torch.mm(bf.dlogits.t(), bf.r2, out=gW3)
-            if not self._dw2_inlaunch:
-                torch.mm(bf.dlat.t(), r1, out=gW2)
-        elif pl:
+        if pl:
             st = next_from
             chk(_L.idl_mid_bwd_gather_planes(_p(bf.z), _p(bf.r2), _p(bf.f), _p(bf.inv), _p(bf.G), bf.G.shape[0], _p(bf.P0), _p(self.W3), _p(self.W2),
                                              _p(r1), m, C, tr, nce_coef, _p(bf.dlogits), _p(bf.dlat), _p(bf.dr1), _p(gb1), _p(gb2), _p(gb3),
@@ -741,10 +704,10 @@ class FusedLinearTrainer:
     def _dy_planes_args(self, pb):
         return (_p(pb["dh"]), _p(pb["dl"]), _p(self._dr1_scale))
 
-    def _tail_launch(self, bf, xi, r1, l1=None, l1p=None, red=None):
+    def _tail_launch(self, bf, xi, r1, l1=None, red=None):
         """The optimizer's tail of the step that ran on (bf, xi) with the activations r1: dW2 tiles + RMSprop on every tensor but W1 + step
-        loss + step counter -- behind the layer-1 tiles of the next step (l1 = (x, m, r1T) of THAT step; l1p = its two-plane form's
-        (W1 hi, W1 lo, x hi, x lo, m, partial sums)), or as a launch of its own."""
+        loss + step counter -- behind the layer-1 tiles of the next step (l1 = (x, m, r1T) of THAT step), beside the workgroups that add up the next
+        step's layer-1 partial sums (red), or as a launch of its own."""
         m = bf.m
         tail = (len(self.params), self._pp, self._gp, self._parts, self._vp, self._sz, _p(self.hyper),
                 _p(self.ctl), _p(bf.loss_rows), m, 1.0 - self.weight, self.weight, _p(self.out))
@@ -752,9 +715,6 @@ class FusedLinearTrainer:
         if red is not None:       # beside the workgroups that add up the next step's layer-1 partial sums (red = (part, elements of a slab))
             part, slab = red
             _lib.check(_L.idl_reduce_parts_rms(_p(part), slab, None, None, *tail, 0, *wg))
-        elif l1p is not None:
-            wh, wl, xh, xl, m1, part = l1p
-            _lib.check(_L.idl_l1_planes_rms(_p(wh), _p(wl), _p(xh), _p(xl), m1, self.F, _p(part), *tail, 0, *wg))
         elif l1 is not None:
             x, m1, r1T = l1
             _lib.check(_L.idl_l1_fwd_rms(_p(self.W1), _p(x), m1, self.F, _p(r1T), *tail, 0, *wg))

@@ -11,10 +11,10 @@ from conftest import ROOT
 
 @pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="no hipcc")
 def test_prim_step_kernels_have_no_scratch(tmp_path):
-    """Round 5: a build of lazy_fold_kernel that spilled 12 bytes a lane to scratch (168 registers at three workgroups a CU)
-    produced wrong records -- trees that differ from sklearn's from the second edge on; the same source without the spill is exact.
-    Not understood (the step kernels pin loaded values with empty `asm volatile`s), so the condition is held by a test: the three
-    step kernels of idl_mst_prim_lazy compile without scratch."""
+    """The lazy Prim's step kernel pins its loaded values behind hand-placed waits (empty `asm volatile`s) and keeps ~136 registers at three workgroups
+    a CU: it must compile without scratch.  (Round 5 held two multi-node variants of it to the same condition after one of them, spilling 12 bytes a lane,
+    produced wrong trees for a reason nobody found; round 6 removed both variants -- measured no faster on cfg5's latent, opt-in -- rather than ship a kernel
+    with an unexplained correctness condition.)"""
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     src = os.path.join(ROOT, "idelucs_amd", "csrc", "mst.hip")
     r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-c", src, "-o", str(tmp_path / "mst.o"),
@@ -25,10 +25,10 @@ def test_prim_step_kernels_have_no_scratch(tmp_path):
     for b in blocks:
         name = b.split()[0]
         m = re.search(r"ScratchSize \[bytes/lane\]: (\d+)", b)
-        for k in ("lazy_step_kernel", "lazy_fold_kernel", "lazy_multi_kernel"):
+        for k in ("lazy_step_kernel",):
             if k in name and m:
                 seen[k] = int(m.group(1))
-    assert set(seen) == {"lazy_step_kernel", "lazy_fold_kernel", "lazy_multi_kernel"}, seen
+    assert set(seen) == {"lazy_step_kernel"}, seen
     assert all(v == 0 for v in seen.values()), seen
 
 
@@ -39,8 +39,8 @@ def test_plane_kernels_have_no_scratch_and_fit_their_cu(tmp_path):
     512-thread workgroup per CU (dynamic LDS is set by the launchers: 128 KB and 144 KB + the tail's 4 KB of static LDS)."""
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     want = {"planes.hip": ["l1_planes_kernel"], "wgrad_planes.hip": ["wgrad_dplanes_kernel"],
-            "train_step.hip": ["wgrad_dplanes_rms_kernel", "wgrad_xplanes_rms_batched_kernel", "reduce_rms_kernel", "l1p_rms_kernel",
-                               "mid_bwd_kernelILb0ELb0ELb1E", "mid_bwd_kernelILb0ELb0ELb0E"]}
+            "train_step.hip": ["wgrad_dplanes_rms_kernel", "wgrad_xplanes_rms_batched_kernel", "reduce_rms_kernel",
+                               "mid_bwd_kernelILb0ELb1E", "mid_bwd_kernelILb0ELb0E"]}
     for fn, kernels in want.items():
         src = os.path.join(ROOT, "idelucs_amd", "csrc", fn)
         r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-c", src, "-o", str(tmp_path / (fn + ".o")),

@@ -1012,7 +1012,7 @@ def test_opt_in_step_variants_agree_with_the_default(dev):
     # moves the weights (scale 3e-2) by >= 1e-2.  Bar: mean <= 1e-3, max <= 1e-2, epoch loss within 2e-3.
     variants = (dict(_l1_fused=True), dict(_l1_fused=True, _l1_gather=3), dict(_wgrad_fused=False), dict(_wgrad_own_launch=True), dict(_early_gather=False), dict(_transposed_l1=False),
                 dict(_dw2_inlaunch=False, _early_gather=False), dict(_joint_inlaunch=False), dict(_pipeline=False, _early_gather=False),
-                dict(_nce_bwd_fused=True), dict(_l1_fused=True, _joint_inlaunch=False))
+                dict(_l1_fused=True, _joint_inlaunch=False))
     for flags in variants:
         p, l = run(**flags)
         assert abs(l - ref_l) <= 2e-3 * abs(ref_l), (flags, l, ref_l)
@@ -1020,49 +1020,6 @@ def test_opt_in_step_variants_agree_with_the_default(dev):
             assert (a - b).abs().max().item() <= 1e-2 and (a - b).abs().mean().item() <= 1e-3, flags
     again, l2 = run()
     assert l2 == ref_l and all(torch.equal(a, b) for a, b in zip(again, ref_p)), "the default step is not deterministic"
-
-
-@pytest.mark.parametrize("C,train", [(20, 1), (5, 0), (48, 1)])
-def test_fused_nce_pass2_mid_backward_equals_separate_launches(dev, C, train):
-    """idl_nce_pass1_joint + idl_nce_mid_bwd_gather (InfoNCE pass 2 and the IIC core inside the mid-backward launch) ==
-    idl_nce_fused_iic_z + idl_mid_bwd_gather: lse, loss rows, IIC, dlogits, dlat, dr1 and every partial sum."""
-    import torch
-    from idelucs_amd import _lib
-    from idelucs_amd.fused import _p, _stream, EPS
-    L = _lib.lib
-    torch.manual_seed(11 + C)
-    m = 1024
-    parts = L.idl_col_sum_parts(); gp = L.idl_nce_fused_parts()
-    z = torch.softmax(torch.randn(m, C, device=dev), 1)
-    lat = torch.randn(m, 64, device=dev); nrm = lat.norm(dim=1); f = (lat / nrm[:, None]).contiguous(); inv = (1.0 / nrm).contiguous()
-    r2 = torch.relu(torch.randn(m, 64, device=dev)) * (torch.rand(m, 64, device=dev) > 0.5) * 2
-    W3 = torch.randn(C, 64, device=dev) * 0.2; W2 = torch.randn(64, 512, device=dev) * 0.06
-    act1 = (torch.relu(torch.randn(m, 512, device=dev)) * (torch.rand(m, 512, device=dev) > 0.5)).contiguous()
-    coef = 0.75 / (m * 0.85)
-    res = []
-    for fused in (False, True):
-        ws = torch.zeros(max(L.idl_nce_fused_workspace(m), 4) // 4, device=dev)
-        lse = torch.empty(m, device=dev); rows = torch.empty(m, device=dev); G = torch.zeros(gp, m, 64, device=dev)
-        P0 = torch.empty(C, C, device=dev); scr = torch.empty(C * C + 2 * C, device=dev); out = torch.zeros(4, device=dev)
-        dlg = torch.empty(m, C, device=dev); dlat = torch.empty(m, 64, device=dev); dr1 = torch.empty(m, 512, device=dev)
-        p1 = torch.empty(parts, 512, device=dev); p2 = torch.empty(parts, 64, device=dev); p3 = torch.empty(parts, C, device=dev)
-        w3 = torch.empty(parts, C, 64, device=dev)
-        nog = (None, 0, 0, 0, None, None, 0, 0, 0, None, None, None, None, 0, 1, 1, 0)
-        if fused:
-            _lib.check(L.idl_nce_pass1_joint(_p(f), m, 0.85, _p(ws), _p(z), _p(P0), C, _stream()))
-            _lib.check(L.idl_nce_mid_bwd_gather(_p(z), _p(r2), _p(f), _p(inv), _p(ws), gp, 0.85, _p(P0), 2.8, EPS, 0.25, _p(lse), _p(rows), _p(out),
-                                                _p(W3), _p(W2), _p(act1), m, C, train, coef, _p(dlg), _p(dlat), _p(dr1), _p(p1), _p(p2), _p(p3),
-                                                _p(w3), *nog, _stream()))
-        else:
-            _lib.check(L.idl_nce_fused_iic_z(_p(f), m, 0.85, _p(lse), _p(rows), _p(G), _p(ws), _p(z), _p(P0), C, 2.8, EPS, 0.25, _p(scr), _p(out),
-                                             _stream()))
-            _lib.check(L.idl_mid_bwd_gather(_p(z), _p(r2), _p(f), _p(inv), _p(G), gp, _p(P0), _p(W3), _p(W2), _p(act1), m, C, train, coef,
-                                            _p(dlg), _p(dlat), _p(dr1), _p(p1), _p(p2), _p(p3), _p(w3), *nog, _stream()))
-        torch.cuda.synchronize()
-        res.append((lse, rows, out[3:4].clone(), dlg, dlat, dr1, p1, p2, p3, w3))
-    names = ("lse", "loss_rows", "iic", "dlogits", "dlat", "dr1", "partial1", "partial2", "partial3", "dW3_part")
-    for nme, x, y in zip(names, res[0], res[1]):
-        assert torch.allclose(x, y, rtol=2e-4, atol=1e-6 * max(1.0, x.abs().max().item())), (nme, (x - y).abs().max().item())
 
 
 def test_batch_assembly_riding_in_the_middle_launches_is_the_gather(dev):
@@ -1319,12 +1276,12 @@ def test_default_step_contains_no_library_gemm(dev, monkeypatch, planes, C):
         pytest.skip("the profiler reported no device kernels on this box")
     if C > 48:      # (round 6) the step of the CLI's default mode -- 200 output units -- too: the middle backward in one launch, z dP0 and dW3 on own tiles
         assert any("l1_planes_kernel" in n for n in names) and any("wgrad_dplanes_rms" in n for n in names), sorted(set(names))
-        assert any("mid_bwd_kernel<false, true, true>" in n or "mid_bwd_kernelILb0ELb1ELb1E" in n for n in names), sorted(set(names))
+        assert any("mid_bwd_kernel<true, true>" in n or "mid_bwd_kernelILb1ELb1E" in n for n in names), sorted(set(names))
         assert any("iic_dz_kernel" in n for n in names) and any("at_b_kernel" in n for n in names) and not any("iic_joint_kernel" in n for n in names)
     elif planes == "1":
         assert any("l1_planes_kernel" in n for n in names) and any("reduce_rms_kernel" in n for n in names), sorted(set(names))
         assert any("wgrad_dplanes_rms" in n for n in names)     # (the tiles with both operands as planes + the step's optimizer tail on their loader waves)
-        assert any("mid_bwd_kernel<false, false, true>" in n or "mid_bwd_kernelILb0ELb0ELb1E" in n for n in names), sorted(set(names))      # (... dr1 written as planes)
+        assert any("mid_bwd_kernel<false, true>" in n or "mid_bwd_kernelILb0ELb1E" in n for n in names), sorted(set(names))      # (... dr1 written as planes)
     else:
         assert any("l1_rms_kernel" in n for n in names) and any("l1_fwd_kernel" in n for n in names), sorted(set(names))
         assert any("wgrad_q16_kernel" in n for n in names)

@@ -127,8 +127,7 @@ def test_filtered_prim_is_sklearns(monkeypatch):
     assert np.allclose(prob, ref.probabilities_, atol=1e-9)
 
 
-@pytest.mark.parametrize("kind", ["blobs", "tight", "duplicates", "uniform", "tight-multi", "duplicates-multi", "uniform-multi",
-                                  "blobs-fold", "tight-fold", "duplicates-fold", "uniform-fold"])
+@pytest.mark.parametrize("kind", ["blobs", "tight", "duplicates", "uniform"])
 def test_lazy_prim_builds_the_same_tree(monkeypatch, kind):
     """idl_mst_prim_lazy lets groups of points sleep while the tree grows elsewhere and has them catch up when the weight being
     added reaches their bound: the edges -- nodes, order, float64 weights -- are those of the scan that visits every point at
@@ -136,16 +135,6 @@ def test_lazy_prim_builds_the_same_tree(monkeypatch, kind):
     half of the points exact copies of others (runs of equal weights: ties go by the original number) and on structureless data
     (nobody can sleep)."""
     from idelucs_amd import posthoc
-    # round 5, both opt-in: several nodes per launch where they are certain to follow each other -- -fold: the decision inside the step
-    # (lazy_fold_kernel); -multi: in a launch of its own (lazy_reduce_kernel + lazy_multi_kernel).  Default: one node per launch
-    monkeypatch.delenv("IDELUCS_MST_MULTI", raising=False)
-    monkeypatch.delenv("IDELUCS_MST_FOLD", raising=False)
-    if kind.endswith("-multi"):
-        monkeypatch.setenv("IDELUCS_MST_MULTI", "8")
-        kind = kind[:-6]
-    elif kind.endswith("-fold"):
-        monkeypatch.setenv("IDELUCS_MST_FOLD", "4")
-        kind = kind[:-5]
     rng = np.random.default_rng(9)
     n = 70000
     if kind == "uniform":

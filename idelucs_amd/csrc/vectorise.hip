@@ -527,13 +527,18 @@ __global__ __launch_bounds__(64 * V2_WAVES, B16 ? 8 : 6) void vectorise2_kernel(
         const int64_t nslots = (L + 63) >> 6;
         const int64_t nsc = (nslots + SC - 1) / SC;
         if (a.redo != 0 && !redo_listed) {      // second pass without a list: only the sequences v3 left alone (the predicate of vectorise3_kernel's stage_next, restated)
-            int64_t te = 0;
+            int64_t te = 0, dmax = 0;
             if (a.edits != nullptr)
                 for (int v = 0; v < a.n_views; ++v) {
-                    const int64_t d = eo_end(a, (int64_t)v * a.n + s) - eo_begin(a, (int64_t)v * a.n + s);
-                    te += d < 0 ? 0 : (d > 0x3FFFFFF ? 0x3FFFFFF : d);
+                    int64_t d = eo_end(a, (int64_t)v * a.n + s) - eo_begin(a, (int64_t)v * a.n + s);
+                    d = d < 0 ? 0 : (d > 0x3FFFFFF ? 0x3FFFFFF : d);
+                    te += d;
+                    dmax = d > dmax ? d : dmax;
                 }
-            if (te <= (int64_t)a.ecap && te * K <= (int64_t)a.lcap && nslots >= 0 && nslots <= (int64_t)a.v3_sc && L >= 0 && L <= nslots * 64) continue;
+            // (redo == 2: the first pass was vectorise4_kernel, whose registers also bound a view's edits and the staged slots)
+            const bool first_did = a.redo == 2 ? (nslots <= 64 * 3 && te <= (int64_t)a.ecap)
+                                               : (te <= (int64_t)a.ecap && te * K <= (int64_t)a.lcap);
+            if (first_did && nslots >= 0 && nslots <= (int64_t)a.v3_sc && L >= 0 && L <= nslots * 64) continue;
         }
 
         for (int i = lane; i < T::HD / 4; i += NT) *(uint4 *)(hist + i * 4) = make_uint4(ivw, ivw, ivw, ivw);
@@ -1196,6 +1201,199 @@ __global__ __launch_bounds__(V3_NT, 8) void vectorise3_kernel(VecArgs a)
     }
 }
 
+// =====================================================================================================
+// v4 (round 6): ONE WAVEFRONT PER SEQUENCE for the small histograms, k = 4 and k = 5 (north_star's literal design).
+// v3's workgroup-per-sequence pipeline pays ~9 barriers and a DMA hand-over per sequence: at k = 6 they hide under 64 KB of row
+// stores, at k = 4 (a 1 KB row) they ARE the kernel -- 18.1 k cycles a sequence of which ~4 k barriers and 7 k the memory waves' DMA
+// issue, against 3.7 k if the LDS atomics were the bound.  Here a wave owns a sequence from its packed bases to its rows:
+//   * its slice of LDS holds the staged sequence (halo slot + ceil(L / 64) slots), the edits of all views, the histogram, and at k = 4 the
+//     2^RL per-lane copies the count goes to -- no list of (old bin, new bin) pairs: a view is undone by evaluating its edits again (V3<K, RL>'s helpers: the same count, edit
+//     evaluation, list entries and fold as v3, so the rows are v3's bit for bit);
+//   * no s_barrier anywhere: the LDS unit executes a wave's operations in order, a wave-level fence keeps the compiler's order;
+//   * the NEXT sequence's packed bases, mask and edits are requested (into registers) behind the count of the current one and written
+//     to LDS when the current one's last row is out: the trip to memory hides under the view phases;
+//   * a view: evaluate its edits (a lane per edit, K list entries each), apply, read the row out of LDS, convert (Markstein, as v3), store,
+//     undo from the list -- the last view is not undone (the next sequence's fold / clear rewrites the histogram).
+// Sequences are dealt round-robin over the launch's waves.  A sequence that does not fit the slice (v3's predicate: edits, pairs,
+// slots) is listed for the second pass on v2, as v3 does.
+// =====================================================================================================
+constexpr int V4_MAX_WAVES = 12;                // waves of a workgroup: as many as the slices of LDS allow (the launcher decides)
+constexpr int V4_SR = 3;                        // rounds of 64 slots a sequence may take (12 288 bases); longer inputs stay on v3 / v2
+constexpr int V4_FR = 10;                       // rounds of 64 edits (ALL views of a sequence, one after the other) prefetched into registers; more: second pass
+
+template <int K, int RL>
+__global__ __launch_bounds__(64 * V4_MAX_WAVES) void vectorise4_kernel(VecArgs a)
+{
+    using W = V3<K, RL>;
+    constexpr int F = W::F, HC = W::HC, RP = F / 256;
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int P = a.n_views, SC = a.v3_sc;
+    const int slice = (HC + (F + 4) + (SC + 1) * 6 + a.ecap + 3) & ~3;
+    uint32_t *copies = lds + (size_t)wv * slice, *hist = copies + HC, *cod = hist + F + 4, *msk = cod + (SC + 1) * 4, *E = msk + (SC + 1) * 2;
+    const uint32_t iv = (a.init == IDL_INIT_ONE) ? 1u : 0u;
+    const uint32_t garbage = ((uint32_t)F + (lane & 3)) << 2;
+    for (int i = lane; i < HC; i += 64) copies[i] = 0u;
+    if (lane < 4) cod[lane] = 0u;                            // the halo slot: no bases before the sequence
+    if (lane < 2) msk[lane] = 0xFFFFFFFFu;
+    // the sum over the wave without a trip through the LDS crossbar (six ds_bpermute in a row cost ~700 cycles, five times a sequence): rows of 16 by
+    // DPP (quad swaps, half-row mirror, row mirror), the four rows by readlane.  Every lane is active where this is called.
+    auto wave_sum = [](int v) {
+        v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);
+        v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);
+        v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true);
+        v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true);
+        return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
+    };
+    auto fence = []() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); };
+    // what a sequence brings: metadata (uniform), then its packed bases / mask / edits in registers until the slice is free
+    struct Meta { int64_t s, slot0, eb[V3_MAXV]; int L, nslots, ne[V3_MAXV], te, fast; };
+    struct Regs { uint4 c[V4_SR]; uint2 m[V4_SR]; uint32_t e[V4_FR]; };
+    // (sequences are dealt round-robin over all waves of the launch: a shared counter -- one returning atomic per sequence on ONE address -- serialised the
+    //  launch at ~12 ns a sequence: 1.2 ms for 100 000)
+    const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    int64_t next_s = (int64_t)blockIdx.x * (blockDim.x >> 6) + wv;
+    auto pull = [&](Meta &q) {
+        q.s = next_s < a.n ? next_s : a.n;
+        next_s += n_waves;
+        q.fast = 0; q.te = 0; q.L = 0; q.nslots = 0; q.slot0 = 0;
+        if (q.s >= a.n) return;
+        q.slot0 = a.slot_off[q.s];
+        const int64_t L = a.lengths[q.s];
+        const int64_t nslots = (L + 63) >> 6;
+        int64_t te = 0;
+#pragma unroll
+        for (int v = 0; v < V3_MAXV; ++v) {
+            q.eb[v] = 0; q.ne[v] = 0;
+            if (v < P && a.edits != nullptr) {
+                const int64_t b = eo_begin(a, (int64_t)v * a.n + q.s), e = eo_end(a, (int64_t)v * a.n + q.s);
+                const int64_t d = e - b < 0 ? 0 : (e - b > 0x3FFFFFF ? 0x3FFFFFF : e - b);
+                q.eb[v] = b; q.ne[v] = (int)d; te += d;
+            }
+        }
+        // (restated by vectorise2_kernel's second pass, redo == 2; the launcher keeps ecap <= 64 * V4_FR)
+        const bool ok = nslots <= (int64_t)SC && nslots <= 64 * V4_SR && L >= 0 && te <= (int64_t)a.ecap;
+        q.L = (int)L; q.nslots = (int)nslots; q.te = (int)te; q.fast = ok ? 1 : 0;
+    };
+    // (every load unconditional within its uniform branch, its index clamped: a load under a per-lane condition is put into a branch of its own and waited
+    //  for before the next is issued -- 35 dependent trips to memory a sequence in this lambda's first form)
+    auto request = [&](const Meta &q, Regs &r) {
+        if (!q.fast) return;
+        const int ns1 = q.nslots > 0 ? q.nslots - 1 : 0;
+#pragma unroll
+        for (int i = 0; i < V4_SR; ++i) {
+            const int slot = i * 64 + lane;
+            const int64_t g = q.slot0 + (slot < ns1 ? slot : ns1);
+            r.c[i] = a.codes[g]; r.m[i] = a.mask[g];
+        }
+        if (q.te > 0) {
+            // the edits of the views follow one another in the slice: flat index f -> (view, index in the view) by a chain of selects
+#pragma unroll
+            for (int j = 0; j < V4_FR; ++j) {
+                int f = j * 64 + lane;
+                f = f < q.te ? f : q.te - 1;
+                int64_t base = q.eb[0];
+                int start = 0, cum = q.ne[0];
+#pragma unroll
+                for (int v = 1; v < V3_MAXV; ++v) {
+                    const bool in = f >= cum;
+                    base = in ? q.eb[v] : base; start = in ? cum : start;
+                    cum += q.ne[v];
+                }
+                r.e[j] = a.edits[base + (f - start)];
+            }
+        }
+    };
+    auto deposit = [&](const Meta &q, const Regs &r) {       // registers -> the slice (the previous sequence is done with it)
+        if (!q.fast) return;
+#pragma unroll
+        for (int i = 0; i < V4_SR; ++i) {
+            const int slot = i * 64 + lane;
+            if (slot < q.nslots) { *(uint4 *)(cod + (slot + 1) * 4) = r.c[i]; *(uint2 *)(msk + (slot + 1) * 2) = r.m[i]; }
+        }
+#pragma unroll
+        for (int j = 0; j < V4_FR; ++j) { const int f = j * 64 + lane; if (f < q.te) E[f] = r.e[j]; }
+    };
+    Meta cur, nxt;
+    Regs rg;
+    pull(cur);
+    request(cur, rg);
+    while (cur.s < a.n) {
+        pull(nxt);                                           // (its loads are uniform and wanted only behind the count below)
+        if (!cur.fast) {                                     // the launcher's second pass (v2) takes this sequence
+            if (lane == 0) { const int slot = atomicAdd(a.redo_count, 1); if (slot < V3_REDO_CAP) ((int64_t *)(a.redo_count + 2))[slot] = cur.s; }
+            request(nxt, rg);
+            cur = nxt;
+            continue;
+        }
+        deposit(cur, rg);
+        if constexpr (RL == 0) { for (int i = lane; i < (F + 4) / 4; i += 64) *(uint4 *)(hist + i * 4) = make_uint4(iv, iv, iv, iv); }
+        fence();
+        // ---------------- the un-mutated sequence, counted once
+        const int windows = wave_sum((int)W::template count_all<64>(cod, msk, cur.nslots, RL ? copies : hist, lane));
+        request(nxt, rg);                                    // the next sequence's trip to memory hides under the views of this one
+        if constexpr (RL > 0) { for (int b = lane; b < F; b += 64) W::fold_copies(copies, hist, b, iv); }
+        fence();
+        // the un-mutated histogram stays in registers (four bins a lane and 256): a view is undone by writing it back -- RP conflict-free stores
+        // instead of the view's atomics a second time
+        uint4 h0[RP];
+#pragma unroll
+        for (int j = 0; j < RP; ++j) h0[j] = *(const uint4 *)(hist + (lane + 64 * j) * 4);
+        // ---------------- the views: apply, row out, restore
+        int eo = 0;
+#pragma unroll 1
+        for (int vi = 0; vi < P; ++vi) {
+            int ne = 0;                                       // (a select chain: a run-time index would put the array into scratch)
+#pragma unroll
+            for (int v = 0; v < V3_MAXV; ++v) ne = v == vi ? cur.ne[v] : ne;
+            const uint32_t *Ev = E + eo;
+            int dwt = 0;
+            for (int e0 = 0; e0 < ne; e0 += 64) {
+                const int ei = e0 + lane;
+                if (ei < ne) {
+                    uint32_t pr[K];
+                    dwt += W::edit_eval(Ev, ne, ei, cur.L - 1, cod, msk, garbage, pr);
+#pragma unroll
+                    for (int t = 0; t < K; ++t) W::move(hist, pr[t], 1u);
+                }
+            }
+            uint4 h[RP];
+            int64_t S = (int64_t)windows + (iv ? (int64_t)F : 0);
+            if (ne > 0) {
+                fence();
+                S += (int64_t)wave_sum(dwt);
+#pragma unroll
+                for (int j = 0; j < RP; ++j) h[j] = *(const uint4 *)(hist + (lane + 64 * j) * 4);
+                if (vi + 1 < P) {                            // (the LDS unit takes a wave's operations in order: the stores follow the loads)
+#pragma unroll
+                    for (int j = 0; j < RP; ++j) *(uint4 *)(hist + (lane + 64 * j) * 4) = h0[j];
+                    fence();
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < RP; ++j) h[j] = h0[j];
+            }
+            float *dst = (float *)a.out + ((int64_t)vi * a.view_stride + cur.s * (int64_t)F) + lane * 4;
+            if (a.out_kind == IDL_OUT_COUNTS_I32) {
+#pragma unroll
+                for (int j = 0; j < RP; ++j) *(uint4 *)((uint32_t *)dst + j * 256) = h[j];
+            } else {
+                // S <= max_len + 4^k < 2^24 (the launcher bounds max_len): the Markstein form equals float32(float64 division), as in v3
+                const float Sf = (float)S, rS = 1.0f / Sf;
+#pragma unroll
+                for (int j = 0; j < RP; ++j) {
+                    const float c0 = (float)h[j].x, c1 = (float)h[j].y, c2 = (float)h[j].z, c3 = (float)h[j].w;
+                    const float q0 = c0 * rS, q1 = c1 * rS, q2 = c2 * rS, q3 = c3 * rS;
+                    *(float4 *)(dst + j * 256) = make_float4(fmaf(fmaf(-q0, Sf, c0), rS, q0), fmaf(fmaf(-q1, Sf, c1), rS, q1),
+                                                             fmaf(fmaf(-q2, Sf, c2), rS, q2), fmaf(fmaf(-q3, Sf, c3), rS, q3));
+                }
+            }
+            eo += ne;
+        }
+        cur = nxt;
+    }
+}
+
 // collapse a host-provided histogram (idl_kmer_rev_comp): one wave, counts modified in place like utils.py:216-217
 template <int K>
 __global__ __launch_bounds__(64) void collapse_kernel(int32_t *counts, int32_t *out)
@@ -1350,10 +1548,74 @@ int launch_vectorise3_rl(const VecArgs &a_in, const idl::DeviceInfo &di, hipStre
     return IDL_OK;
 }
 
+// v4 takes what v3 takes at k = 4 / 5 when every sequence fits its wave's slice of LDS (<= 12 288 bases); IDELUCS_VEC=3 keeps v3 (the cross-check tests)
+template <int K, int RL>
+int launch_vectorise4(const VecArgs &a_in, const idl::DeviceInfo &di, hipStream_t st, bool *done)
+{
+    VecArgs a = a_in;
+    int want = 4;
+    if (const char *e = getenv("IDELUCS_VEC")) want = atoi(e);
+    if (want != 4 || a.mode != IDL_MODE_KMER || a.init == IDL_INIT_FROM_OUT || a.out_kind == IDL_OUT_FREQ_F64 || a.n_views > V3_MAXV || a.max_len <= 0 ||
+        a.max_len > 64 * 64 * V4_SR || a.n > 0x7F000000ll)
+        return IDL_OK;
+    using W = V3<K, RL>;
+    a.v3_sc = (int)((a.max_len + 63) / 64);
+    a.sc_slots = a.v3_sc;
+    int ec = a.edits == nullptr ? 0 : (((int)(a.max_len * 35 / 1000) + 64) * a.n_views / 4 + 7) & ~7;      // edits of all views: 3.5 % of the bases + slack for four views, scaled
+    if (ec > 64 * V4_FR) ec = 64 * V4_FR;
+    if (const char *e = getenv("IDELUCS_V3_EC")) { const int t = atoi(e); if (t >= 0 && t <= 64 * V4_FR) ec = t & ~7; }
+    a.ecap = ec; a.lcap = 0;
+    const int slice = (W::HC + (W::F + 4) + (a.v3_sc + 1) * 6 + ec + 3) & ~3;
+    // as many waves a workgroup as its CU's LDS holds slices (one workgroup per CU: nothing is shared between the waves but the CU)
+    int waves = (di.lds_per_cu - 2048) / (slice * 4);
+    if (waves > V4_MAX_WAVES) waves = V4_MAX_WAVES;
+    if (const char *e = getenv("IDELUCS_V4_WAVES")) { const int t = atoi(e); if (t >= 1 && t <= waves) waves = t; }
+    if (waves < 4) return IDL_OK;                            // (long sequences: v3 / v2)
+    const size_t lds = (size_t)slice * 4 * waves;
+    if ((int)lds > di.max_dyn_lds) return IDL_OK;
+    const void *fn = (const void *)vectorise4_kernel<K, RL>;
+    if (lds > 64 * 1024) IDL_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int per_cu = 1, lc = 0;
+    int64_t grid = (int64_t)di.cus * per_cu;
+    if (grid * waves > a.n) grid = (a.n + waves - 1) / waves;
+    a.redo_count = redo_counter(st);
+    if (a.redo_count == nullptr) { idl::set_error("cannot allocate the v3 hand-over word"); return IDL_ERR_HIP; }
+    IDL_HIP_TRY(hipMemsetAsync(a.redo_count, 0, 2 * sizeof(int), st));
+    if (getenv("IDELUCS_DEBUG"))
+        fprintf(stderr, "[idl] vectorise k=%d v4 (a wave per sequence) lds=%zu B a workgroup of %d waves (copies %d, staged slots %d, edits %d, pairs %d) -> %d workgroups/CU\n",
+                K, lds, waves, 1 << RL, a.v3_sc, ec, lc, per_cu);
+    hipLaunchKernelGGL((vectorise4_kernel<K, RL>), dim3((unsigned)grid), dim3(64 * waves), lds, st, a);
+    IDL_HIP_TRY(hipGetLastError());
+    {       // second pass: v2 on the sequences v4 left alone; exits at once when there are none
+        VecArgs b = a;
+        b.redo = 2;
+        b.sc_slots = 160;
+        const size_t lds2 = (size_t)((1 << (2 * K)) + 4 + (b.sc_slots + 1) * 6 + V2_EDIT_CAP + V2_LIST_CAP + 2 * V2_WAVES + 4 * b.n_views) * 4;
+        int64_t g2 = (int64_t)di.cus * 4;
+        if (g2 > a.n) g2 = a.n;
+        hipLaunchKernelGGL((vectorise2_kernel<K, false>), dim3((unsigned)g2), dim3(64 * V2_WAVES), lds2, st, b);
+        IDL_HIP_TRY(hipGetLastError());
+    }
+    *done = true;
+    return IDL_OK;
+}
+
 template <int K>
 int launch_vectorise3(const VecArgs &a_in, const idl::DeviceInfo &di, hipStream_t st, bool *done)
 {
     *done = false;
+    if constexpr (K == 4 || K == 5) {
+        int rc;
+        if constexpr (K == 4) {
+            // copies of the histogram a wave counts into: 4 -- measured at 100 000 x 10 kbp, 4 views, one box (gpurun_out r06): no edits / philox edits
+            // 0.351 / 0.649 ms with 4, 0.349 / 0.738 with 8, 0.453 / 1.025 with 16 (fewer waves fit); v3 on the same box: 0.621 / 0.725
+            int rl = 2;
+            if (const char *e = getenv("IDELUCS_V4_COPIES")) { const int t = atoi(e); rl = t == 16 ? 4 : (t == 8 ? 3 : (t == 1 ? 0 : 2)); }
+            rc = rl == 4 ? launch_vectorise4<K, 4>(a_in, di, st, done) : (rl == 2 ? launch_vectorise4<K, 2>(a_in, di, st, done) :
+                 (rl == 0 ? launch_vectorise4<K, 0>(a_in, di, st, done) : launch_vectorise4<K, 3>(a_in, di, st, done)));
+        } else rc = launch_vectorise4<K, 0>(a_in, di, st, done);
+        if (rc != IDL_OK || *done) return rc;
+    }
     if constexpr (K == 4) {
         // copies of the histogram the count goes to: 16 by default -- measured at 100 000 x 10 kbp, 4 views (gpurun_out/r05_e): 0.708 ms
         // with 16 (four workgroups per CU), 0.714 with 8, 0.844 with 32 (conflict-free, but 41 KB of LDS: three per CU); v2: 1.393

@@ -405,12 +405,22 @@ def test_full_size_v1_v2_v3_kernels_agree_bitwise(gpu, monkeypatch, k):
     specs = [t.spec() for t in U.mimic_transforms(3)]
     edits, edit_off = U._philox_edits(din, specs, 11)
     outs = {}
-    for which in ("3", "2", "1"):
+    for which in ("4", "3", "2", "1"):                        # (4: round 6's wave-per-sequence kernel, the default at k = 4 / 5; it does not take k = 6: v3 runs)
         monkeypatch.setenv("IDELUCS_VEC", which)
         outs[which] = (U._vectorise(din, k, _lib.MODE_KMER, _lib.INIT_ONE, _lib.OUT_FREQ_F32, 4, edits, edit_off).clone(),
                        U._vectorise(din, k, _lib.MODE_KMER, _lib.INIT_ZERO, _lib.OUT_COUNTS_I32, 4, edits, edit_off).clone())
-    assert torch.equal(outs["1"][1], outs["2"][1]) and torch.equal(outs["1"][1], outs["3"][1])
-    assert torch.equal(outs["1"][0], outs["2"][0]) and torch.equal(outs["1"][0], outs["3"][0])
+    assert torch.equal(outs["1"][1], outs["2"][1]) and torch.equal(outs["1"][1], outs["3"][1]) and torch.equal(outs["1"][1], outs["4"][1])
+    assert torch.equal(outs["1"][0], outs["2"][0]) and torch.equal(outs["1"][0], outs["3"][0]) and torch.equal(outs["1"][0], outs["4"][0])
+    if k in (4, 5):     # ... also when its tables take only some of the sequences (the rest: the second pass on v2), and with other numbers of histogram copies
+        for ec, lc in (("0", "0"), ("320", "1800")):
+            monkeypatch.setenv("IDELUCS_VEC", "4"); monkeypatch.setenv("IDELUCS_V3_EC", ec); monkeypatch.setenv("IDELUCS_V3_LC", lc)
+            assert torch.equal(U._vectorise(din, k, _lib.MODE_KMER, _lib.INIT_ONE, _lib.OUT_FREQ_F32, 4, edits, edit_off), outs["1"][0]), (ec, lc)
+        monkeypatch.delenv("IDELUCS_V3_EC"); monkeypatch.delenv("IDELUCS_V3_LC")
+        if k == 4:
+            for copies in ("16", "8", "1"):
+                monkeypatch.setenv("IDELUCS_VEC", "4"); monkeypatch.setenv("IDELUCS_V4_COPIES", copies)
+                assert torch.equal(U._vectorise(din, k, _lib.MODE_KMER, _lib.INIT_ZERO, _lib.OUT_COUNTS_I32, 4, edits, edit_off), outs["1"][1]), copies
+            monkeypatch.delenv("IDELUCS_V4_COPIES")
     if k == 4:      # round 5: the count goes to 16 copies of the 4^4-bin histogram (lane l adds to copy l mod 16); 32 and 8 copies: the same rows
         for copies in ("32", "8"):
             monkeypatch.setenv("IDELUCS_VEC", "3"); monkeypatch.setenv("IDELUCS_V3_COPIES", copies)

@@ -24,6 +24,17 @@
 
 namespace {
 
+// Diagnostic phase stamps of the two InfoNCE passes (`make STAMPS=1`, tools/stamps_mid.py: modes 3 and 4 of idl_debug_phase_stamps); compiled out otherwise
+#ifdef IDL_PHASE_STAMPS
+__device__ uint64_t *nce_phase_stamps = nullptr;
+__device__ int nce_phase_mode = 0;
+#define NCE_PHASE_BUF(mode) ((nce_phase_mode == (mode) && nce_phase_stamps != nullptr && blockIdx.y == 0 && blockIdx.x < 64) ? nce_phase_stamps + 8 * blockIdx.x : nullptr)
+#define NCE_PHASE_STAMP(buf, slot) do { if ((buf) != nullptr && threadIdx.x == 0) (buf)[(slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define NCE_PHASE_BUF(mode) nullptr
+#define NCE_PHASE_STAMP(buf, slot) do { (void)(buf); } while (0)
+#endif
+
 constexpr int NCE_SPLIT = 8;     // column quarters -> (m/16) * 4 workgroups
 constexpr int NCE_MAX_M = 2048;  // rows (2 * batch) whose lse fit the LDS table
 
@@ -90,6 +101,8 @@ __device__ __forceinline__ void nce_pass1_body(const float *f, int m, float inv_
         return;
     }
     __shared__ float sh[4][16];
+    uint64_t *const stp = NCE_PHASE_BUF(3);
+    NCE_PHASE_STAMP(stp, 0);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, l = lane & 15, q = lane >> 4;
     const int r0 = blockIdx.x * 16, ntiles = m / 16;
     const int t0 = (int)((int64_t)blockIdx.y * ntiles / NCE_SPLIT), t1 = (int)((int64_t)(blockIdx.y + 1) * ntiles / NCE_SPLIT);
@@ -115,10 +128,13 @@ __device__ __forceinline__ void nce_pass1_body(const float *f, int m, float inv_
     }
     if (t < t1) fold(sim_tile(f, t * 16, rb, l, q), t);
     // this lane holds the partial of row r over its j's (q, reg); add the four q groups, then the four waves
+    NCE_PHASE_STAMP(stp, 1);                     // (wave 0: its tiles' loads arrived, products and exponentials done)
     sum = idl_dev::add_xor32(idl_dev::add_xor16(sum));
     if (q == 0) sh[wv][l] = sum;
     __syncthreads();
+    NCE_PHASE_STAMP(stp, 2);
     if (threadIdx.x < 16) rowsum_part[(int64_t)blockIdx.y * m + r0 + threadIdx.x] = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+    NCE_PHASE_STAMP(stp, 3);
 }
 
 // pass 2: lse / loss rows, and the partial products G_part[NCE_SPLIT][m][64]
@@ -133,6 +149,8 @@ __device__ __forceinline__ void nce_pass2_body(const float *f, int m, float inv_
     __shared__ float red[4][16][64];     // per-wave G tiles [row][c]
     __shared__ float lse_col[NCE_MAX_M / NCE_SPLIT + 16];   // lse of the columns this workgroup visits (for E^T) ...
     __shared__ float lse_own[16];                            // ... and of its own 16 rows
+    uint64_t *const stp = NCE_PHASE_BUF(4);
+    NCE_PHASE_STAMP(stp, 0);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, l = lane & 15, q = lane >> 4;
     const int r0 = blockIdx.x * 16, ntiles = m / 16;
     const int t0 = (int)((int64_t)blockIdx.y * ntiles / NCE_SPLIT), t1 = (int)((int64_t)(blockIdx.y + 1) * ntiles / NCE_SPLIT);
@@ -149,6 +167,7 @@ __device__ __forceinline__ void nce_pass2_body(const float *f, int m, float inv_
     load_rows(f, r0, l, q, rb);
     const int r = r0 + l;
     __syncthreads();
+    NCE_PHASE_STAMP(stp, 1);                     // (the partial row sums read, their logarithms in LDS)
     const float lse_r = lse_own[l];
     if (blockIdx.y == 0 && wv == 0 && q == 0) { lse[r] = lse_r; loss_rows[r] = lse_r - pos[r]; }
     f32x4 g[4];                           // G[r = 4q+reg][c = 16*ct + l] for ct = 0..3
@@ -199,17 +218,20 @@ __device__ __forceinline__ void nce_pass2_body(const float *f, int m, float inv_
             for (int ct = 0; ct < 4; ++ct) g[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(e[step], frow[16 * ct], g[ct], 0, 0, 0);
         }
     }
+    NCE_PHASE_STAMP(stp, 2);                     // (wave 0: both products of its tiles)
     // C/D layout of g[ct]: row = 4q + reg, col = l  ->  add the four waves through LDS, write [16][64]
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) red[wv][4 * q + reg][16 * ct + l] = g[ct][reg];
     __syncthreads();
+    NCE_PHASE_STAMP(stp, 3);
     float *dst = G_part + ((int64_t)blockIdx.y * m + r0) * 64;
     for (int i = threadIdx.x; i < 16 * 64; i += 256) {
         const int rr = i >> 6, c = i & 63;
         dst[i] = (red[0][rr][c] + red[1][rr][c]) + (red[2][rr][c] + red[3][rr][c]);
     }
+    NCE_PHASE_STAMP(stp, 4);
 }
 
 __global__ __launch_bounds__(256) void nce_pass1_kernel(const float *f, int m, float inv_t, float *rowsum_part, float *pos, IicJob iic)
@@ -337,6 +359,15 @@ int64_t idl_nce_fused_workspace(int m)
 }
 
 int idl_nce_fused_parts(void) { return NCE_SPLIT; }
+
+#ifdef IDL_PHASE_STAMPS
+int nce_set_phase_stamps(uint64_t *st, int on)      // (train_step.hip: idl_debug_phase_stamps)
+{
+    IDL_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(nce_phase_stamps), &st, sizeof(st)));
+    IDL_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(nce_phase_mode), &on, sizeof(on)));
+    return IDL_OK;
+}
+#endif
 
 static int nce_launch(const float *f, int m, float temperature, float *lse, float *loss_rows, float *G_part, void *workspace,
                       const IicJob &iic, void *stream)

@@ -2034,6 +2034,10 @@ int idl_wgrad_xplanes_rms(const void *dy_hi, const void *dy_lo, int *dy_scale, c
                           stream, wg_index, wg_dy, wg_x, wg_m, wg_n_out, wg_n_in, wg_grad, wg_x_transposed, nullptr, -1, nullptr, w1_index, nullptr, &x);
 }
 
+#ifdef IDL_PHASE_STAMPS
+int nce_set_phase_stamps(uint64_t *st, int on);
+#endif
+
 int idl_debug_phase_stamps(int on)
 {
 #ifdef IDL_PHASE_STAMPS
@@ -2043,6 +2047,7 @@ int idl_debug_phase_stamps(int on)
     if (st != nullptr) IDL_HIP_TRY(hipMemset(st, 0, 1024 * 4 * sizeof(uint64_t)));
     IDL_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(idl_phase_stamps), &st, sizeof(st)));
     IDL_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(idl_phase_mode), &on, sizeof(on)));
+    { const int rc = nce_set_phase_stamps(st, on); if (rc != IDL_OK) return rc; }      // (modes 3, 4: the InfoNCE passes, nce_fused.hip)
     g_phase_mode_host = on;
     return IDL_OK;
 #else

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Diagnostic: phase marks inside the two middle kernels of the training step (workgroups 0..63), in microseconds from the
+"""Diagnostic: phase marks inside the four middle kernels of the training step (workgroups 0..63), in microseconds from the
 kernel's first workgroup start.   IDELUCS_STAMPS=1 python tools/stamps_mid.py"""
 import os, sys, ctypes
 os.environ["IDELUCS_STAMPS"] = "1"
@@ -19,17 +19,22 @@ tr = FusedLinearTrainer(net, 1e-3, 0.25, 2.8, seed=3)
 names = {1: ["start", "loads in, relu/dropout done (wave 0)", "MFMA + partials written", "barrier 1", "row sums, f/r2 stored, R2t (2 barriers)",
              "logits MFMA + barrier", "end"],
          2: ["start", "prologue requests issued (wave 0)", "barrier: sP / sW3 staged", "head backward of the row", "barrier",
-             "dr1 MFMA + stores issued", "end"]}
-for mode in (1, 2):
+             "dr1 MFMA + stores issued", "end"],
+         3: ["start", "tiles' products + exponentials (wave 0)", "barrier: the four waves' sums", "partial row sums stored = end"],
+         4: ["start", "partial row sums read, logarithms in LDS (barrier)", "both products of its tiles (wave 0)", "barrier: the four waves' G tiles",
+             "G_part stored = end"]}
+kern = {1: "mid_fwd", 2: "mid_bwd", 3: "nce_pass1 (workgroups (x < 64, y = 0))", 4: "nce_pass2 (workgroups (x < 64, y = 0))"}
+for mode in (1, 2, 3, 4):
     _lib.check(_lib.lib.idl_debug_phase_stamps(mode))
     tr.run_epoch(store, B, use_graph=False)
     torch.cuda.synchronize()
     out = np.zeros((1024, 4), np.uint64)
     _lib.check(_lib.lib.idl_debug_stamps(out.ctypes.data_as(ctypes.c_void_p)))
     st = out.reshape(-1)[:64 * 8].reshape(64, 8).astype(np.int64)
+    st = st[np.abs(st[:, 0] - np.median(st[:, 0])) < 100000]      # (the epoch's last, partial batch has fewer workgroups: the others' marks are one step older)
     t0 = st[:, 0].min()
     us = (st - t0) * 0.01
-    print(f"== {'mid_fwd' if mode == 1 else 'mid_bwd'}: marks (median / max over 64 workgroups, us after the first workgroup's start)")
+    print(f"== {kern[mode]}: marks (median / max over the workgroups of the last full step, us after the first workgroup's start)")
     for i, nm in enumerate(names[mode]):
         print(f"   {i} {nm:55s} {np.median(us[:, i]):6.2f} {us[:, i].max():6.2f}")
 _lib.check(_lib.lib.idl_debug_phase_stamps(0))

@@ -1221,11 +1221,15 @@ constexpr int V4_MAX_WAVES = 12;                // waves of a workgroup: as many
 constexpr int V4_SR = 3;                        // rounds of 64 slots a sequence may take (12 288 bases); longer inputs stay on v3 / v2
 constexpr int V4_FR = 10;                       // rounds of 64 edits (ALL views of a sequence, one after the other) prefetched into registers; more: second pass
 
-template <int K, int RL>
+// OM ("other modes"): the CGR and canonical rows (reference utils.py:279-317, 208-221 -- round 6) as epilogues over the finished histogram, in an
+// instance of their own so that their registers (a lane's 4^k / 64 collapsed bins) do not count against the plain rows'.
+template <int K, int RL, bool OM = false>
 __global__ __launch_bounds__(64 * V4_MAX_WAVES) void vectorise4_kernel(VecArgs a)
 {
     using W = V3<K, RL>;
     constexpr int F = W::F, HC = W::HC, RP = F / 256;
+    constexpr int ROW_CANON = (K % 2 == 0) ? (F + (1 << K)) / 2 : F / 2;
+    const int64_t row_len = (OM && a.mode == IDL_MODE_CANONICAL) ? ROW_CANON : F;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int P = a.n_views, SC = a.v3_sc;
@@ -1359,33 +1363,75 @@ __global__ __launch_bounds__(64 * V4_MAX_WAVES) void vectorise4_kernel(VecArgs a
             }
             uint4 h[RP];
             int64_t S = (int64_t)windows + (iv ? (int64_t)F : 0);
-            if (ne > 0) {
-                fence();
-                S += (int64_t)wave_sum(dwt);
+            if (ne > 0) { fence(); S += (int64_t)wave_sum(dwt); }
+            const int64_t row = (int64_t)vi * a.view_stride + cur.s * row_len;
+            bool stored = false;
+            if constexpr (OM) {
+                if (a.mode == IDL_MODE_CANONICAL) {
+                    // utils.py:208-221: for every k-mer b <= rc(b), ascending: int32((c[b] + c[rc]) * 0.5) -- truncating, palindromes keep their count --, the row
+                    // normalised by ITS OWN sum (utils.py:246-250).  A lane takes bins lane, lane + 64, ...; ranks from a running ballot, as in v2.
+                    // (two walks over the bins -- the sum, then the rows -- instead of a lane's 4^k / 64 collapsed bins in registers: 16 at k = 5, where they spilled)
+                    int part = 0;
+#pragma unroll 4
+                    for (int t = 0; t < F / 64; ++t) {
+                        const uint32_t b = 64u * t + lane, rc = revcomp<K>(b);
+                        if (b <= rc) part += (int32_t)(hist[b] + hist[rc]) / 2;
+                    }
+                    const int Sc = wave_sum(part);
+                    const float Sf = (float)Sc, rS = 1.0f / Sf;
+                    int rank0 = 0;
+#pragma unroll 4
+                    for (int t = 0; t < F / 64; ++t) {
+                        const uint32_t b = 64u * t + lane, rc = revcomp<K>(b);
+                        const bool cn = b <= rc;
+                        const uint64_t bal = __ballot(cn);
+                        if (cn) {
+                            const uint32_t val = (uint32_t)((int32_t)(hist[b] + hist[rc]) / 2);
+                            const int64_t o = row + rank0 + __popcll(bal & ((1ull << lane) - 1ull));
+                            if (a.out_kind == IDL_OUT_COUNTS_I32) ((uint32_t *)a.out)[o] = val;
+                            else { const float c = (float)val, q = c * rS; ((float *)a.out)[o] = fmaf(fmaf(-q, Sf, c), rS, q); }     // (Sc < 2^24: == float32(float64 division))
+                        }
+                        rank0 += __popcll(bal);
+                    }
+                    stored = true;
+                } else if (a.mode == IDL_MODE_CGR) {
+                    // the histogram is kept in k-mer order; a CGR row is stored in pixel order (kmers.pyx:53-123 through cgr_pixel_to_kmer)
 #pragma unroll
-                for (int j = 0; j < RP; ++j) h[j] = *(const uint4 *)(hist + (lane + 64 * j) * 4);
-                if (vi + 1 < P) {                            // (the LDS unit takes a wave's operations in order: the stores follow the loads)
-#pragma unroll
-                    for (int j = 0; j < RP; ++j) *(uint4 *)(hist + (lane + 64 * j) * 4) = h0[j];
-                    fence();
+                    for (int j = 0; j < RP; ++j) {
+                        const uint32_t i0 = (uint32_t)(lane + 64 * j) * 4u;
+                        h[j] = make_uint4(hist[cgr_pixel_to_kmer<K>(i0)], hist[cgr_pixel_to_kmer<K>(i0 + 1)], hist[cgr_pixel_to_kmer<K>(i0 + 2)], hist[cgr_pixel_to_kmer<K>(i0 + 3)]);
+                    }
                 }
-            } else {
-#pragma unroll
-                for (int j = 0; j < RP; ++j) h[j] = h0[j];
             }
-            float *dst = (float *)a.out + ((int64_t)vi * a.view_stride + cur.s * (int64_t)F) + lane * 4;
-            if (a.out_kind == IDL_OUT_COUNTS_I32) {
+            if (!OM || a.mode == IDL_MODE_KMER) {
+                if (ne > 0) {
 #pragma unroll
-                for (int j = 0; j < RP; ++j) *(uint4 *)((uint32_t *)dst + j * 256) = h[j];
-            } else {
-                // S <= max_len + 4^k < 2^24 (the launcher bounds max_len): the Markstein form equals float32(float64 division), as in v3
-                const float Sf = (float)S, rS = 1.0f / Sf;
+                    for (int j = 0; j < RP; ++j) h[j] = *(const uint4 *)(hist + (lane + 64 * j) * 4);
+                } else {
 #pragma unroll
-                for (int j = 0; j < RP; ++j) {
-                    const float c0 = (float)h[j].x, c1 = (float)h[j].y, c2 = (float)h[j].z, c3 = (float)h[j].w;
-                    const float q0 = c0 * rS, q1 = c1 * rS, q2 = c2 * rS, q3 = c3 * rS;
-                    *(float4 *)(dst + j * 256) = make_float4(fmaf(fmaf(-q0, Sf, c0), rS, q0), fmaf(fmaf(-q1, Sf, c1), rS, q1),
-                                                             fmaf(fmaf(-q2, Sf, c2), rS, q2), fmaf(fmaf(-q3, Sf, c3), rS, q3));
+                    for (int j = 0; j < RP; ++j) h[j] = h0[j];
+                }
+            }
+            if (ne > 0 && vi + 1 < P) {                      // (the LDS unit takes a wave's operations in order: the stores follow the loads)
+#pragma unroll
+                for (int j = 0; j < RP; ++j) *(uint4 *)(hist + (lane + 64 * j) * 4) = h0[j];
+                fence();
+            }
+            if (!stored) {
+                float *dst = (float *)a.out + row + lane * 4;
+                if (a.out_kind == IDL_OUT_COUNTS_I32) {
+#pragma unroll
+                    for (int j = 0; j < RP; ++j) *(uint4 *)((uint32_t *)dst + j * 256) = h[j];
+                } else {
+                    // S <= max_len + 4^k < 2^24 (the launcher bounds max_len): the Markstein form equals float32(float64 division), as in v3
+                    const float Sf = (float)S, rS = 1.0f / Sf;
+#pragma unroll
+                    for (int j = 0; j < RP; ++j) {
+                        const float c0 = (float)h[j].x, c1 = (float)h[j].y, c2 = (float)h[j].z, c3 = (float)h[j].w;
+                        const float q0 = c0 * rS, q1 = c1 * rS, q2 = c2 * rS, q3 = c3 * rS;
+                        *(float4 *)(dst + j * 256) = make_float4(fmaf(fmaf(-q0, Sf, c0), rS, q0), fmaf(fmaf(-q1, Sf, c1), rS, q1),
+                                                                 fmaf(fmaf(-q2, Sf, c2), rS, q2), fmaf(fmaf(-q3, Sf, c3), rS, q3));
+                    }
                 }
             }
             eo += ne;
@@ -1555,7 +1601,8 @@ int launch_vectorise4(const VecArgs &a_in, const idl::DeviceInfo &di, hipStream_
     VecArgs a = a_in;
     int want = 4;
     if (const char *e = getenv("IDELUCS_VEC")) want = atoi(e);
-    if (want != 4 || a.mode != IDL_MODE_KMER || a.init == IDL_INIT_FROM_OUT || a.out_kind == IDL_OUT_FREQ_F64 || a.n_views > V3_MAXV || a.max_len <= 0 ||
+    const bool om = a.mode == IDL_MODE_CGR || a.mode == IDL_MODE_CANONICAL;
+    if (want != 4 || (a.mode != IDL_MODE_KMER && !om) || a.init == IDL_INIT_FROM_OUT || a.out_kind == IDL_OUT_FREQ_F64 || a.n_views > V3_MAXV || a.max_len <= 0 ||
         a.max_len > 64 * 64 * V4_SR || a.n > 0x7F000000ll)
         return IDL_OK;
     using W = V3<K, RL>;
@@ -1573,7 +1620,7 @@ int launch_vectorise4(const VecArgs &a_in, const idl::DeviceInfo &di, hipStream_
     if (waves < 4) return IDL_OK;                            // (long sequences: v3 / v2)
     const size_t lds = (size_t)slice * 4 * waves;
     if ((int)lds > di.max_dyn_lds) return IDL_OK;
-    const void *fn = (const void *)vectorise4_kernel<K, RL>;
+    const void *fn = om ? (const void *)vectorise4_kernel<K, RL, true> : (const void *)vectorise4_kernel<K, RL, false>;
     if (lds > 64 * 1024) IDL_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int per_cu = 1, lc = 0;
     int64_t grid = (int64_t)di.cus * per_cu;
@@ -1584,7 +1631,8 @@ int launch_vectorise4(const VecArgs &a_in, const idl::DeviceInfo &di, hipStream_
     if (getenv("IDELUCS_DEBUG"))
         fprintf(stderr, "[idl] vectorise k=%d v4 (a wave per sequence) lds=%zu B a workgroup of %d waves (copies %d, staged slots %d, edits %d, pairs %d) -> %d workgroups/CU\n",
                 K, lds, waves, 1 << RL, a.v3_sc, ec, lc, per_cu);
-    hipLaunchKernelGGL((vectorise4_kernel<K, RL>), dim3((unsigned)grid), dim3(64 * waves), lds, st, a);
+    if (om) hipLaunchKernelGGL((vectorise4_kernel<K, RL, true>), dim3((unsigned)grid), dim3(64 * waves), lds, st, a);
+    else hipLaunchKernelGGL((vectorise4_kernel<K, RL, false>), dim3((unsigned)grid), dim3(64 * waves), lds, st, a);
     IDL_HIP_TRY(hipGetLastError());
     {       // second pass: v2 on the sequences v4 left alone; exits at once when there are none
         VecArgs b = a;

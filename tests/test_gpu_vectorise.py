@@ -388,6 +388,36 @@ def test_cfg2_full_size_store_properties(gpu):
     assert int(counts[P - 1, n - 1].sum()) >= L - (k - 1) - 20 * k
 
 
+@pytest.mark.parametrize("k", [5, 4])
+def test_cgr_and_canonical_rows_of_the_wave_per_sequence_kernel_are_v2s(gpu, monkeypatch, k):
+    """Round 6: the CGR permutation (kmers.pyx:53-123) and the canonical collapse with its truncating halve and own normalisation
+    (utils.py:208-221, 246-250) as epilogues of vectorise4_kernel (k = 4, 5: a wavefront owns the finished histogram) -- bit for bit the rows of the delta-view
+    kernel v2 (the checker the oracle tests hold), counts and float32 frequencies, 20 000 x 10 kbp x 4 views with device-drawn mimic edits; also when some
+    sequences go to the second pass."""
+    import torch
+    from idelucs_amd import _lib, utils as U
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_vectorise", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "bench_vectorise.py"))
+    bv = importlib.util.module_from_spec(spec); spec.loader.exec_module(bv)
+    dev = torch.device("cuda")
+    din = bv.synth_input(20000, 10000, dev)
+    edits, edit_off = U._philox_edits(din, [t.spec() for t in U.mimic_transforms(3)], 13)
+    for mode in (_lib.MODE_CGR, _lib.MODE_CANONICAL):
+        outs = {}
+        for which in ("2", "4"):
+            monkeypatch.setenv("IDELUCS_VEC", which)
+            outs[which] = (U._vectorise(din, k, mode, _lib.INIT_ONE, _lib.OUT_FREQ_F32, 4, edits, edit_off).clone(),
+                           U._vectorise(din, k, mode, _lib.INIT_ZERO, _lib.OUT_COUNTS_I32, 4, edits, edit_off).clone(),
+                           U._vectorise(din, k, mode, _lib.INIT_ONE, _lib.OUT_FREQ_F32).clone())
+        for a_, b_ in zip(outs["2"], outs["4"]):
+            assert a_.shape == b_.shape and torch.equal(a_, b_), (mode, k)
+        assert outs["4"][0].shape[-1] == int(_lib.lib.idl_row_len(mode, k))
+        assert float(outs["4"][0][1:].sum(-1).sub(1).abs().max()) < 1e-5 and not torch.equal(outs["4"][0][0], outs["4"][0][1])
+        monkeypatch.setenv("IDELUCS_VEC", "4"); monkeypatch.setenv("IDELUCS_V3_EC", "320")
+        assert torch.equal(U._vectorise(din, k, mode, _lib.INIT_ONE, _lib.OUT_FREQ_F32, 4, edits, edit_off), outs["2"][0]), (mode, k)
+        monkeypatch.delenv("IDELUCS_V3_EC")
+
+
 @pytest.mark.parametrize("k", [6, 5, 4])
 def test_full_size_v1_v2_v3_kernels_agree_bitwise(gpu, monkeypatch, k):
     """cfg2-shaped batch (20 000 x 10 kbp, 4 views, device-drawn mimic edits): the single-pass kernel (v1: full recount per

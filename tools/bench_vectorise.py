@@ -65,6 +65,11 @@ def main():
               f"{a.n / mn * 1e3:,.0f} seq/s")
     mn, av = timeit(lambda: U._vectorise(din, a.k, _lib.MODE_KMER, _lib.INIT_ZERO, _lib.OUT_COUNTS_I32, 1, None, None, out.view(torch.int32)[:1]), a.reps)
     print(f"vectorise i32 x1 view                 min {mn:8.3f} ms  avg {av:8.3f} ms  -> {a.n * ((a.len + 3) // 4 + F * 4) / mn / 1e6:8.1f} GB/s")
+    for mname, mode in (("cgr", _lib.MODE_CGR), ("canonical", _lib.MODE_CANONICAL)):       # (k = 4, 5: vectorise4_kernel's epilogues; otherwise the delta-view kernel v2)
+        rl = int(_lib.lib.idl_row_len(mode, a.k))
+        o2 = out.view(-1)[:a.views * a.n * rl].view(a.views, a.n, rl)
+        mn, av = timeit(lambda: U._vectorise(din, a.k, mode, _lib.INIT_ONE, _lib.OUT_FREQ_F32, a.views, edits, edit_off, o2), a.reps)
+        print(f"vectorise {mname:9s} f32 x{a.views} views [philox edits] min {mn:8.3f} ms  avg {av:8.3f} ms")
     mn, av = timeit(lambda: U.col_stats(out[0]), a.reps)
     print(f"col_stats (one pass over view 0)        min {mn:8.3f} ms  avg {av:8.3f} ms  -> {2 * a.n * F * 4 / mn / 1e6:8.1f} GB/s")
     mean, scale = U.col_stats(out[0])

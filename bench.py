@@ -43,7 +43,7 @@ import torch.distributed as dist
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 matrix peak (v_mfma_f32_32x32x2_f32)
 MFMA_F16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense fp16 / bf16 matrix peak (v_mfma_f32_32x32x16_f16; the 2:1-sparsity figure is twice that)
-PMC_PROFILE = "r05_t_vectorise_pmc_k6.json"     # profiles/: FETCH_SIZE / WRITE_SIZE passes of the vectoriser at cfg2
+PMC_PROFILE = "r06_vectorise_pmc_k6.json"     # profiles/: FETCH_SIZE / WRITE_SIZE passes of the vectoriser at cfg2
 
 
 def synth_packed(n, L, dev, seed=12345, n_rate=0.0):
@@ -351,7 +351,7 @@ def k_sweep(din, args, dev, ks=(4, 5), reps=6):
         del hp
         torch.cuda.empty_cache()
         feats = None
-        out[str(k)] = {"kernel": "vectorise3_kernel<%d>" % k, "bound": "lds", "ms_per_launch": ms, "ms_min": min(ts), "whole_path": whole,
+        out[str(k)] = {"kernel": "vectorise4_kernel<%d> (a wavefront per sequence)" % k, "bound": "lds", "ms_per_launch": ms, "ms_min": min(ts), "whole_path": whole,
                        "bytes_per_seq_algorithmic": b_vec, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                        "lds_atomics_per_seq": int(atomics), "lds_issue_floor_ms": lds_floor_ms, "frac_of_lds_issue_floor": lds_floor_ms / ms,
                        "sequences_per_sec_stage": din.n / (ms * 1e-3), "rows_checked": int(rows.numel())}

@@ -7,6 +7,7 @@
 //   idelucs/utils.py:26-51               check_sequence (header checks, translate, delete, validate)
 // and produces the packed slot layout documented in include/idelucs_hip.h.
 #include <stdint.h>
+#include "dev_env.h"
 #include <stdlib.h>
 #include <string.h>
 
@@ -173,7 +174,7 @@ int n_threads()
 
 size_t par_min_bytes()                  // files smaller than this are handled by one thread
 {
-    if (const char *e = getenv("IDELUCS_PAR_MIN")) return (size_t)atoll(e);
+    if (const char *e = idl::dev_env("par_min")) return (size_t)atoll(e);
     return (size_t)1 << 22;
 }
 
@@ -184,7 +185,7 @@ size_t par_min_bytes()                  // files smaller than this are handled b
 // node; with the file on the other node than the GPU, ingest-to-features 14.4 ms beside the GPU and 10.8 beside the FILE -- reads
 // across the socket link cost, posted writes hardly.  The threads of a job that copies to a device are therefore bound, for the
 // job, to the node of the file's pages (file_numa_node below) and, when the file does not say, to the device's node (workers
-// keep the binding, the caller's own is restored).  IDELUCS_NUMA=off switches it off, =device ignores the file, =<node> forces a node.
+// keep the binding, the caller's own is restored).  IDELUCS_DEV=numa=off switches it off, =device ignores the file, =<node> forces a node.
 struct CpuBind {
     cpu_set_t set;                      // the node's CPUs open to this process
     std::vector<cpu_set_t> per_thread;  // thread i of a job: the hardware threads of ONE core, cores dealt round-robin over the node's L3 domains
@@ -203,7 +204,7 @@ int first_cpu_of_list(const char *path)      // first number of a sysfs cpu list
     return v;
 }
 
-// OPT-IN (IDELUCS_NUMA_PIN=1): one core per reader thread, spread over the L3 domains, instead of the node's whole CPU set for every
+// OPT-IN (IDELUCS_DEV=numa_pin=1): one core per reader thread, spread over the L3 domains, instead of the node's whole CPU set for every
 // thread.  Built because the pool's threads, woken where they last ran, finished between 4.6 and 8.7 ms where freshly created ones
 // took 4.8 .. 6.1; measured on three boxes (gpurun_out/r05_c..e, kept as profiles/r05_ingest_ab.txt): the pinned threads do finish
 // closer together (9.1 .. 11.9 against 5.4 .. 12.1 ms) but the LAST one no earlier, and every job starts 1.3 ms late -- a thread
@@ -211,7 +212,7 @@ int first_cpu_of_list(const char *path)      // first number of a sysfs cpu list
 // idle CPU of the node.  Ingest-to-features 14.5 / 11.8 / 16.3 ms pinned against 13.5 / 11.6 / 16.3 node-wide: node-wide is the default.
 void spread_over_cores(CpuBind *b)
 {
-    const char *e = getenv("IDELUCS_NUMA_PIN");
+    const char *e = idl::dev_env("numa_pin");
     if (!(e && atoi(e) == 1)) return;
     struct Core { int l3, first; cpu_set_t cpus; };
     std::vector<Core> cores;
@@ -271,11 +272,11 @@ bool parse_cpulist(const char *path, cpu_set_t *out)
 CpuBind bind_for_device(int dev, int want_threads, int file_node = -1)
 {
     CpuBind b;
-    const char *env = getenv("IDELUCS_NUMA");
+    const char *env = idl::dev_env("numa");
     if (env && (strcmp(env, "off") == 0 || strcmp(env, "-1") == 0)) return b;
     int node = -1;
     if (env && *env >= '0' && *env <= '9') node = atoi(env);
-    else if (file_node >= 0 && !(env && strcmp(env, "device") == 0)) node = file_node;      // beside the file (IDELUCS_NUMA=device: beside the GPU)
+    else if (file_node >= 0 && !(env && strcmp(env, "device") == 0)) node = file_node;      // beside the file (IDELUCS_DEV=numa=device: beside the GPU)
     else {
         char id[64] = {0};
         if (dev < 0 || hipDeviceGetPCIBusId(id, (int)sizeof(id) - 1, dev) != hipSuccess) return b;
@@ -297,7 +298,7 @@ CpuBind bind_for_device(int dev, int want_threads, int file_node = -1)
     // too few CPUs of that node are open to this process (a cpuset on the other socket): leave the threads where they are
     if (CPU_COUNT(&b.set) == 0 || (CPU_COUNT(&b.set) < CPU_COUNT(&mine) && CPU_COUNT(&b.set) * 2 < want_threads)) return b;
     b.node = node;
-    const char *pin = getenv("IDELUCS_NUMA_PIN");
+    const char *pin = idl::dev_env("numa_pin");
     if (CPU_EQUAL(&b.set, &mine) && !(pin && atoi(pin) == 1)) return b;     // already there (one node, or an outer binding): leave the threads alone
     b.on = true;
     spread_over_cores(&b);
@@ -430,9 +431,9 @@ template <typename F>
 void parallel_for(int nt, F &&fn, const CpuBind *bind = nullptr)       // fn(thread index)
 {
     if (nt <= 1) { fn(0); return; }
-    static const bool pooled = [] { const char *e = getenv("IDELUCS_READER_POOL"); return !(e && atoi(e) == 0); }();
+    static const bool pooled = [] { const char *e = idl::dev_env("reader_pool"); return !(e && atoi(e) == 0); }();
     if (pooled) { ReaderPool::get().run(nt, fn, bind); return; }
-    // IDELUCS_READER_POOL=0: a thread per call and index (round 4's form, kept for A/B runs); new threads inherit the caller's CPUs
+    // IDELUCS_DEV=reader_pool=0: a thread per call and index (round 4's form, kept for A/B runs); new threads inherit the caller's CPUs
     cpu_set_t before;
     const bool rebind = bind != nullptr && bind->on && sched_getaffinity(0, sizeof(before), &before) == 0 &&
                         sched_setaffinity(0, sizeof(cpu_set_t), &bind->set) == 0;
@@ -584,7 +585,7 @@ __attribute__((target("avx512f,avx512bw"))) inline bool pack64_avx512(const uint
 
 // memchr(p, '\n', n) for the one-pass reader's long sequence lines, with a software prefetch ahead of the scan: the hardware
 // prefetchers stop at every 4 KB page, so a thread streaming a mapping of the page cache takes one full memory latency per page
-// (IDELUCS_PREFETCH = bytes ahead, default 2048; 0 = plain memchr).  The scan is the first touch of the line; the packer behind
+// (IDELUCS_DEV=prefetch = bytes ahead, default 2048; 0 = plain memchr).  The scan is the first touch of the line; the packer behind
 // it reads the cache.
 __attribute__((target("avx512f,avx512bw"))) inline const uint8_t *find_nl_avx512(const uint8_t *p, size_t n, size_t ahead)
 {
@@ -599,7 +600,7 @@ __attribute__((target("avx512f,avx512bw"))) inline const uint8_t *find_nl_avx512
 }
 inline const uint8_t *find_nl(const uint8_t *p, size_t n)
 {
-    static const size_t ahead = [] { const char *e = getenv("IDELUCS_PREFETCH"); const long v = e ? atol(e) : 2048; return (size_t)(v < 0 ? 0 : (v > 65536 ? 65536 : v)); }();
+    static const size_t ahead = [] { const char *e = idl::dev_env("prefetch"); const long v = e ? atol(e) : 2048; return (size_t)(v < 0 ? 0 : (v > 65536 ? 65536 : v)); }();
     if (ahead != 0 && n >= 256 && host_has_avx512()) return find_nl_avx512(p, n, ahead);
     return (const uint8_t *)memchr(p, '\n', n);
 }
@@ -1042,11 +1043,11 @@ int idl_fasta_parse_pack(const char *path, uint8_t *codes, uint8_t *mask, int64_
     const bool timing = getenv("IDELUCS_INGEST_TIMING") != nullptr;
     auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_0 = now();
-    // The file is cut into SLICES (IDELUCS_SLICES per thread, default 4) that the threads take from a counter: the threads of a
+    // The file is cut into SLICES (IDELUCS_DEV=slices per thread, default 4) that the threads take from a counter: the threads of a
     // shared host do not run at one speed (a core's other hardware thread busy, a time slice lost: with one slice per thread they
     // finished between 5.4 and 7.6 ms), and the call ends with its slowest.  A slice owns the records whose header line starts in
     // it and its own region of the arenas, as a thread did.
-    const int per_thread = [] { const char *e = getenv("IDELUCS_SLICES"); const int v = e ? atoi(e) : 4; return v >= 1 && v <= 64 ? v : 4; }();
+    const int per_thread = [] { const char *e = idl::dev_env("slices"); const int v = e ? atoi(e) : 4; return v >= 1 && v <= 64 ? v : 4; }();
     const int ns = nt > 1 ? nt * per_thread : 1;
     std::vector<FastOut> outs((size_t)ns);
     std::vector<double> th_begin((size_t)nt, 0.0), th_end((size_t)nt, 0.0);
@@ -1054,15 +1055,15 @@ int idl_fasta_parse_pack(const char *path, uint8_t *codes, uint8_t *mask, int64_
     // A thread sends what it has packed while it goes on parsing; what is still unsent when it finishes is the copy TAIL every
     // later stage waits for.  Round 4 cut a region into 3 equal pieces: the last third of everything (125 MB at cfg2) left when the
     // parsing was over, 2.6 ms at the link's 48 GB/s (IDELUCS_INGEST_TIMING=2: threads joined 8.0 ms, copies drained 10.6).  The
-    // pieces now shrink -- cuts at 45 / 75 / 92 % of the region's expected slots, the rest at the end (IDELUCS_COPY_SCHED="45,75,92")
+    // pieces now shrink -- cuts at 45 / 75 / 92 % of the region's expected slots, the rest at the end (IDELUCS_DEV=copy_sched="45,75,92")
     // -- for the same number of calls as four equal pieces: every hipMemcpyAsync takes the stream's lock and ~15 us of host time
     // (8 equal pieces 14.6 ms against 12.3-12.8 for 2-4, 16 pieces 18.9: round 4).  A piece is at most 6 MB (big files: more
-    // pieces) and, but for the last, at least 384 KB.  IDELUCS_COPY_DIV=<d> keeps round 4's d equal pieces for A/B runs.
+    // pieces) and, but for the last, at least 384 KB.  IDELUCS_DEV=copy_div=<d> keeps round 4's d equal pieces for A/B runs.
     const int64_t region_slots = (int64_t)(size / 64) / ns + 1;
-    const int copy_div = [] { const char *e = getenv("IDELUCS_COPY_DIV"); const int d = e ? atoi(e) : 0; return d >= 1 && d <= 64 ? d : 0; }();
+    const int copy_div = [] { const char *e = idl::dev_env("copy_div"); const int d = e ? atoi(e) : 0; return d >= 1 && d <= 64 ? d : 0; }();
     const std::vector<int> sched = [] {
         std::vector<int> v;
-        const char *e = getenv("IDELUCS_COPY_SCHED");
+        const char *e = idl::dev_env("copy_sched");
         for (const char *p = e ? e : "45,75,92"; *p;) {       // (of a thread's share; with several slices per thread: of each slice, first cut only)
             char *q = nullptr;
             const long x = strtol(p, &q, 10);
@@ -1078,17 +1079,17 @@ int idl_fasta_parse_pack(const char *path, uint8_t *codes, uint8_t *mask, int64_
     // first (a rank of a multi-GPU job is bound to another one, and dev_codes / stream belong to it)
     int caller_dev = -1;
     if (dev_codes != nullptr && hipGetDevice(&caller_dev) != hipSuccess) caller_dev = -1;
-    g_last_file_node = (nt > 1 && caller_dev >= 0 && !getenv("IDELUCS_NUMA")) ? file_numa_node(buf, size) : -1;
+    g_last_file_node = (nt > 1 && caller_dev >= 0 && !idl::dev_env("numa")) ? file_numa_node(buf, size) : -1;
     CpuBind bind = (nt > 1 && caller_dev >= 0) ? bind_for_device(caller_dev, nt, g_last_file_node) : CpuBind();
     if (g_last_file_node >= 0 && bind.node != g_last_file_node) bind = bind_for_device(caller_dev, nt);       // (too few CPUs open there: the device's node)
     g_last_bind_node = bind.node;
-    const bool sparse_mask = [] { const char *e = getenv("IDELUCS_SPARSE_MASK"); return !(e && atoi(e) == 0); }();
-    // copy streams: the caller's, and IDELUCS_COPY_STREAMS - 1 more of this library's own (thread t copies on stream t mod count;
+    const bool sparse_mask = [] { const char *e = idl::dev_env("sparse_mask"); return !(e && atoi(e) == 0); }();
+    // copy streams: the caller's, and IDELUCS_DEV=copy_streams - 1 more of this library's own (thread t copies on stream t mod count;
     // they start behind whatever the caller's stream holds and the caller's stream waits for them at the end)
     std::vector<hipStream_t> streams(1, (hipStream_t)stream);
     CopyStreams *cs = nullptr;
     if (dev_codes != nullptr && nt > 1 && caller_dev >= 0) {
-        const int want = [] { const char *e = getenv("IDELUCS_COPY_STREAMS"); const int v = e ? atoi(e) : 1; return v >= 1 && v <= 8 ? v : 1; }();
+        const int want = [] { const char *e = idl::dev_env("copy_streams"); const int v = e ? atoi(e) : 1; return v >= 1 && v <= 8 ? v : 1; }();
         cs = want > 1 ? copy_streams(caller_dev, want - 1) : nullptr;
         if (cs != nullptr) {
             if (hipEventRecord(cs->start, (hipStream_t)stream) != hipSuccess) cs = nullptr;

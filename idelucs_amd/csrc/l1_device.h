@@ -67,7 +67,7 @@ __device__ __forceinline__ void mma_step(const Frag &f, f32x4_t &c0, f32x4_t &c1
     }
 }
 
-// DBG (a diagnostic, IDELUCS_L1_DEBUG, wrong results): 1 = no DMA inside the main loop (barriers stay); 2 = no barrier and no DMA inside
+// DBG (a diagnostic, IDELUCS_DEV=l1_debug, wrong results): 1 = no DMA inside the main loop (barriers stay); 2 = no barrier and no DMA inside
 // the main loop; 3 = as 2 and no LDS reads either (the MFMA stream alone)
 template <bool EPILOGUE, int DBG = 0>
 __device__ __forceinline__ void l1_fwd_body(const L1Args &a, const int bid_in, unsigned char *smem)

@@ -25,6 +25,7 @@
 // fp32 MFMA runs at the vector rate (64 FLOP/clk/SIMD): 2048 x 32 = 65 536 matrix-pipe cycles per wave, 27.4 us at the
 // 2.39 GHz the chip holds under this stream (profiles/r04_mfma_clock.txt); everything else has to hide in that shadow.
 #include <stdlib.h>
+#include "dev_env.h"
 #include <string.h>
 
 #include "l1_device.h"
@@ -108,7 +109,7 @@ static int l1_launch(const float *W1, const float *x, const float *b1, const flo
         memcpy((unsigned char *)plan + idl::PLAN_PARAMS, &a, sizeof(a));
         return IDL_OK;
     }
-    static const int dbg = [] { const char *e = getenv("IDELUCS_L1_DEBUG"); return e != nullptr ? atoi(e) : 0; }();
+    static const int dbg = [] { const char *e = idl::dev_env("l1_debug"); return e != nullptr ? atoi(e) : 0; }();
     if (!epi && dbg == 1) hipLaunchKernelGGL((l1_fwd_kernel<false, 1>), grid, block, LDS_BYTES, (hipStream_t)stream, a);
     else if (!epi && dbg == 2) hipLaunchKernelGGL((l1_fwd_kernel<false, 2>), grid, block, LDS_BYTES, (hipStream_t)stream, a);
     else if (!epi && dbg == 3) hipLaunchKernelGGL((l1_fwd_kernel<false, 3>), grid, block, LDS_BYTES, (hipStream_t)stream, a);

@@ -1,6 +1,6 @@
 // l1_planes_device.h -- the layer-1 forward product a1^T = W1 x^T on the fp16 MATRIX CORES from operands kept as two fp16 planes
 // (planes.h): the device side, shared by planes.hip (idl_l1_planes: the step's first launch) and train_step.hip (the same tiles with the
-// previous step's optimizer tail riding behind them, idl_l1_planes_rms: a measured variant, IDELUCS_PLANES_REDUCE=mid).
+// previous step's optimizer tail riding behind them, idl_l1_planes_rms: a measured variant, IDELUCS_DEV=planes_reduce=mid).
 //
 // Reference: Linear(F,512) of idelucs/PytorchUtils.py:38-45, called for both views of a batch at idelucs/models.py:124-125.  The fp32
 // tiles of l1_device.h sit on the fp32 matrix pipe's floor (27.4 us at 512 x 1024 x 4096; 33.6 measured); the fp16 pipe is sixteen
@@ -46,7 +46,7 @@ struct L1pArgs {
     float *part;                   // [KSPLIT][n_out][m]
     int m, n_out, K, n_tiles;      // n_tiles = (n_out / 128) (m / 128) KSPLIT
     int ldw, ldx;                  // elements between two rows of W1's / the batch's planes (>= K, multiples of 8)
-    int dbg;                       // diagnostics (IDELUCS_L1P_DBG; wrong results): 1 no DMA, 4 no stores of the partial sums
+    int dbg;                       // diagnostics (IDELUCS_DEV=l1p_dbg; wrong results): 1 no DMA, 4 no stores of the partial sums
 };
 
 __host__ __device__ inline bool supported(int m, int n_out, int K)

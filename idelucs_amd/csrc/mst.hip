@@ -33,6 +33,7 @@
 // distance, which would have changed nothing -- the tree is the same, edge for edge.  Ties are broken on the points' ORIGINAL
 // numbers (`orig`), as sklearn's scan over j would.
 #include <stdio.h>
+#include "dev_env.h"
 #include <stdlib.h>
 #include <string.h>
 
@@ -1120,9 +1121,9 @@ int idl_mst_prim_lazy(const void *xt, const float *xrow, const double *core, int
     if (int rc = relist()) return rc;
     step(launch, 1); ++launch;       // the first scan: cur = the start
     // the steps are queued in chunks; after each the host looks at the state: done, stalled, or time for a census
-    static const int chunk = getenv("IDELUCS_MST_CHUNK") ? atoi(getenv("IDELUCS_MST_CHUNK")) : 512;
-    static const int64_t census_every = getenv("IDELUCS_MST_CENSUS") ? atoll(getenv("IDELUCS_MST_CENSUS")) : 16384;
-    static const bool sleep_on = !(getenv("IDELUCS_MST_SLEEP") && atoi(getenv("IDELUCS_MST_SLEEP")) == 0);
+    static const int chunk = idl::dev_env("mst_chunk") ? atoi(idl::dev_env("mst_chunk")) : 512;
+    static const int64_t census_every = idl::dev_env("mst_census") ? atoll(idl::dev_env("mst_census")) : 16384;
+    static const bool sleep_on = !(idl::dev_env("mst_sleep") && atoi(idl::dev_env("mst_sleep")) == 0);
     int64_t last_census = 0, last_stall_at = -1000000, quick = 0, no_sleep_until = 0;
     LazyState S{};
     for (;;) {
@@ -1139,7 +1140,7 @@ int idl_mst_prim_lazy(const void *xt, const float *xrow, const double *core, int
             last_stall_at = S.n_tree;
         }
         ++censuses;
-        static const bool dbg = getenv("IDELUCS_MST_DEBUG") != nullptr;
+        static const bool dbg = idl::dev_env("mst_debug") != nullptr;
         if (dbg && (censuses < 60 || censuses % 100 == 0))
             fprintf(stderr, "[idl] lazy prim: census %lld at launch %lld: n_tree %lld stalled %d cur_w %.6g ema %.6g quick %lld no_sleep_until %lld\n",
                     (long long)censuses, (long long)launch, (long long)S.n_tree, S.stalled, S.cur_w, S.ema, (long long)quick, (long long)no_sleep_until);

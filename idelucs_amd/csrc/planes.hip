@@ -2,6 +2,7 @@
 // planes: W1 when an epoch begins, the first batch of an epoch, tests) and idl_l1_planes (the layer-1 forward tiles of
 // l1_planes_device.h: the first launch of the two-plane step).
 #include <stdlib.h>
+#include "dev_env.h"
 #include <string.h>
 
 #include "common.h"
@@ -61,7 +62,7 @@ int idl_l1_planes(const void *w_hi, const void *w_lo, int ld_w, const void *x_hi
     IDL_REQUIRE(w_hi && w_lo && x_hi && x_lo && part && l1p_dev::supported(m, n_out, n_in),
                 "l1_planes: m % 128 == 0, n_out % 128 == 0, n_in % 512 == 0, n_in >= 1024");
     IDL_REQUIRE(((((uintptr_t)w_hi) | ((uintptr_t)w_lo) | ((uintptr_t)x_hi) | ((uintptr_t)x_lo) | ((uintptr_t)part)) & 15u) == 0, "l1_planes: buffers must be 16-byte aligned");
-    static const int l1p_dbg = getenv("IDELUCS_L1P_DBG") ? atoi(getenv("IDELUCS_L1P_DBG")) : 0;      // (timing ablations; l1_planes_device.h)
+    static const int l1p_dbg = idl::dev_env("l1p_dbg") ? atoi(idl::dev_env("l1p_dbg")) : 0;      // (timing ablations; l1_planes_device.h)
     l1p_dev::L1pArgs a{(const uint16_t *)w_hi, (const uint16_t *)w_lo, (const uint16_t *)x_hi, (const uint16_t *)x_lo, part, m, n_out, n_in,
                        (n_out / l1p_dev::TM) * (m / l1p_dev::TN) * l1p_dev::KSPLIT, ld_w, ld_x, l1p_dbg};
     if (void *plan = idl::take_plan()) {          // recorded, not launched (idl_plan_begin): several voters in one launch, train_step.hip

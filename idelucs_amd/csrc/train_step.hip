@@ -20,6 +20,7 @@
 // host involvement:  ctl[0] = optimizer-step counter, ctl[1] = offset of the next batch in the
 // shuffled pair list.
 #include <stdlib.h>
+#include "dev_env.h"
 #include <string.h>
 
 #include "common.h"
@@ -1191,7 +1192,7 @@ __global__ __launch_bounds__(256) void rmsprop_kernel(RmsArgs a, const float *hy
 // the optimizer launch as before (the small tensors, the dW2 tiles, step loss, step counter) and run beside them -- a tile
 // workgroup is one wave per SIMD, so both fit a CU.  One launch, one boundary and the 8 MB gradient's round trip fewer than
 // hipBLASLt's GEMM followed by rmsprop_kernel.
-template <bool STAMPS = false, bool SKIP_TILES = false>      // STAMPS (IDELUCS_STAMPS=1, a diagnostic): every workgroup leaves {start, end, hardware id, XCC id | shader cycles << 8} in `stamps`
+template <bool STAMPS = false, bool SKIP_TILES = false>      // STAMPS (IDELUCS_DEV=stamps=1, a diagnostic): every workgroup leaves {start, end, hardware id, XCC id | shader cycles << 8} in `stamps`
 __global__ __launch_bounds__(wg_dev::THREADS) void wgrad_rmsprop_kernel(wg_dev::WgArgs w, RmsArgs a, const float *hyper, int64_t *ctl,
                                                             int64_t batch_advance, int n_gather, idl_dev::GatherArgs g, uint64_t *stamps)
 {
@@ -1742,11 +1743,11 @@ int idl_bias_grads(float *dx1, const float *act1, int n1, float *partial1, const
     return launch_col_jobs(jobs, 3, stream);
 }
 
-// IDELUCS_STAMPS=1: a device buffer of 1024 x 4 uint64 the stamped kernels write to (idl_debug_stamps copies it out)
+// IDELUCS_DEV=stamps=1: a device buffer of 1024 x 4 uint64 the stamped kernels write to (idl_debug_stamps copies it out)
 static uint64_t *stamp_buffer()
 {
     static uint64_t *buf = [] {
-        const char *e = getenv("IDELUCS_STAMPS");
+        const char *e = idl::dev_env("stamps");
         uint64_t *p = nullptr;
         if (e != nullptr && e[0] == '1' && hipMalloc((void **)&p, 1024 * 4 * sizeof(uint64_t)) == hipSuccess) (void)hipMemset(p, 0, 1024 * 4 * sizeof(uint64_t));
         else p = nullptr;
@@ -1871,7 +1872,7 @@ static int rmsprop_launch(int count, float *const *params, const float *const *g
     }
     if (big != nullptr) {
         const dim3 grid((unsigned)(big->tiles + nb_total + extra + a.wg_tiles));
-        static const bool skip = [] { const char *e = getenv("IDELUCS_STAMPS_SKIP_TILES"); return e != nullptr && e[0] == '1'; }();
+        static const bool skip = [] { const char *e = idl::dev_env("stamps_skip_tiles"); return e != nullptr && e[0] == '1'; }();
         static bool attr_set[64] = {};
         int dev = 0;
         IDL_HIP_TRY(hipGetDevice(&dev));
@@ -1967,7 +1968,7 @@ int idl_l1_fwd_rms(const float *W1, const float *x, int m, int n_in, float *r1_t
     IDL_REQUIRE(W1 && x && r1_transposed && idl_l1_fwd_supported(m, l1_dev::H1, n_in), "l1_fwd_rms: Linear(n_in, 512), m % 32 == 0, n_in % 64 == 0, n_in >= 192");
     IDL_REQUIRE((((uintptr_t)W1 | (uintptr_t)x | (uintptr_t)r1_transposed) & 15u) == 0, "l1_fwd_rms: buffers must be 16-byte aligned");
     const int n_tiles = (l1_dev::H1 / l1_dev::TH) * (m / l1_dev::TR);
-    static const int prio = [] { const char *e = getenv("IDELUCS_L1_PRIO"); return e ? atoi(e) : 0; }();     // (A/B knob: measured)
+    static const int prio = [] { const char *e = idl::dev_env("l1_prio"); return e ? atoi(e) : 0; }();     // (A/B knob: measured)
     const l1_dev::L1Args l{W1, x, nullptr, nullptr, r1_transposed, nullptr, nullptr, 0, m, n_in, 0, 1, n_tiles, 0, 0, idl_dev::GatherArgs{}, prio};
     idl_dev::GatherArgs g{};
     return rmsprop_launch(count, params, grads, grad_parts, square_avg, sizes, hyper, ctl, batch_advance, loss_rows, loss_m, w_nce, w_iic, out, g,
@@ -2027,7 +2028,7 @@ int idl_wgrad_xplanes_rms(const void *dy_hi, const void *dy_lo, int *dy_scale, c
     x.wh = (uint16_t *)w_hi; x.wl = (uint16_t *)w_lo; x.over = overflow_flag; x.hyper = hyper;
     x.m = m; x.n_out = n_out; x.n_in = n_in; x.ldx = ld_x;
     x.tiles_m = n_out / wgp_dev::TM; x.tiles = x.tiles_m * (n_in / wgp_dev::TN);
-    static const int wgp_dbg = getenv("IDELUCS_WGP_DBG") ? atoi(getenv("IDELUCS_WGP_DBG")) : 0;      // (timing ablations; wgrad_planes_device.h)
+    static const int wgp_dbg = idl::dev_env("wgp_dbg") ? atoi(idl::dev_env("wgp_dbg")) : 0;      // (timing ablations; wgrad_planes_device.h)
     x.dbg = wgp_dbg;
     idl_dev::GatherArgs g{};
     return rmsprop_launch(count, params, grads, grad_parts, square_avg_all, sizes, hyper, ctl, batch_advance, loss_rows, loss_m, w_nce, w_iic, out, g,
@@ -2042,7 +2043,7 @@ int idl_debug_phase_stamps(int on)
 {
 #ifdef IDL_PHASE_STAMPS
     uint64_t *st = on ? stamp_buffer() : nullptr;
-    IDL_REQUIRE(!on || st != nullptr, "debug stamps are off (IDELUCS_STAMPS=1 before the first launch)");
+    IDL_REQUIRE(!on || st != nullptr, "debug stamps are off (IDELUCS_DEV=stamps=1 before the first launch)");
     IDL_HIP_TRY(hipDeviceSynchronize());
     if (st != nullptr) IDL_HIP_TRY(hipMemset(st, 0, 1024 * 4 * sizeof(uint64_t)));
     IDL_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(idl_phase_stamps), &st, sizeof(st)));
@@ -2060,7 +2061,7 @@ int idl_debug_stamps(uint64_t *host_out)
 {
     IDL_REQUIRE(host_out != nullptr, "NULL buffer");
     uint64_t *st = stamp_buffer();
-    IDL_REQUIRE(st != nullptr, "debug stamps are off (IDELUCS_STAMPS=1 before the first launch)");
+    IDL_REQUIRE(st != nullptr, "debug stamps are off (IDELUCS_DEV=stamps=1 before the first launch)");
     IDL_HIP_TRY(hipDeviceSynchronize());
     IDL_HIP_TRY(hipMemcpy(host_out, st, 1024 * 4 * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return IDL_OK;

@@ -17,6 +17,7 @@
 //   idelucs/utils.py:242-250 ones-init, counts / sum(counts)
 //   idelucs/utils.py:54-135  transforms   -> substitution edits (XOR on 2-bit codes / set-N)
 #include <stdlib.h>
+#include "dev_env.h"
 
 #include <map>
 #include <mutex>
@@ -45,8 +46,8 @@ struct VecArgs {
     int redo, v3_sc; //   (a sequence is v3's iff its edits fit ecap, its pairs lcap and its slots v3_sc)
     int chunk;       // v3: consecutive sequences per workgroup and round (chunks are dealt round-robin over the workgroups)
     int ecap, lcap;  // v3: LDS capacity for the staged edits of all views / for the recorded (edit, window) pairs
-    unsigned long long *dbg;   // diagnostic (IDELUCS_VEC_DBG): per-workgroup cycle sums of the phases
-    int ablate;      // diagnostic builds only (IDELUCS_VEC_ABLATE): 1 no row stores, 2 no H0 count, 4 no deltas, 8 raw epilogue
+    unsigned long long *dbg;   // diagnostic (IDELUCS_DEV=vec_dbg): per-workgroup cycle sums of the phases
+    int ablate;      // diagnostic builds only (IDELUCS_DEV=vec_ablate): 1 no row stores, 2 no H0 count, 4 no deltas, 8 raw epilogue
 };
 
 // first / one-past-last edit of item it = view * n + sequence, in either layout of edit_off
@@ -1503,7 +1504,7 @@ int *redo_counter(hipStream_t st)
 template <int K, int RL>
 int launch_vectorise3_k(VecArgs &a, const idl::DeviceInfo &di, hipStream_t st, size_t lds, int per_cu)
 {
-    const bool dbg = getenv("IDELUCS_VEC_DBG") != nullptr;
+    const bool dbg = idl::dev_env("vec_dbg") != nullptr;
     const void *fn = dbg ? (const void *)vectorise3_kernel<K, true, RL> : (const void *)vectorise3_kernel<K, false, RL>;
     if (lds > 64 * 1024) IDL_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int64_t grid = (int64_t)di.cus * per_cu;
@@ -1553,13 +1554,13 @@ int launch_vectorise3_rl(const VecArgs &a_in, const idl::DeviceInfo &di, hipStre
         constexpr int HW = V3<K, RL>::HD;                          // histogram words (k = 4: the copies + the histogram proper)
         VecArgs a = a_in;
         int want = 3;
-        if (const char *e = getenv("IDELUCS_VEC")) want = atoi(e);
+        if (const char *e = idl::dev_env("vec")) want = atoi(e);
         if (want != 3 || a.mode != IDL_MODE_KMER || a.init == IDL_INIT_FROM_OUT || a.out_kind == IDL_OUT_FREQ_F64 ||
             a.n_views > V3_MAXV || a.max_len <= 0 || a.max_len > 64 * 2048 || a.n > 0x7F000000ll)
             return IDL_OK;
         a.sc_slots = (int)((a.max_len + 63) / 64);
         // LDS tables for the edits of all views and their K windows each: at least 3.5 % of the bases + slack, and whatever else
-        // fits at four workgroups per CU (an edit costs 2 + K words: two staging sets and the list); IDELUCS_V3_EC / _LC override
+        // fits at four workgroups per CU (an edit costs 2 + K words: two staging sets and the list); IDELUCS_DEV=v3_ec / _LC override
         int ec = (int)(a.max_len * 35 / 1000) + 64, lc;
         {
             const int fixed = HW + 2 * (a.sc_slots + 1) * 6 + 3 * V3_META + 2 * V3_VTAB + 16 + 4;
@@ -1568,22 +1569,22 @@ int launch_vectorise3_rl(const VecArgs &a_in, const idl::DeviceInfo &di, hipStre
             const int fit = ((di.lds_per_cu / wgs - 1024) / 4 - fixed) / (2 + K);
             if (fit > ec) ec = fit > 4096 ? 4096 : fit;
         }
-        if (const char *e = getenv("IDELUCS_V3_EC")) { const int t = atoi(e); if (t >= 0 && t <= 16384) ec = t; }
+        if (const char *e = idl::dev_env("v3_ec")) { const int t = atoi(e); if (t >= 0 && t <= 16384) ec = t; }
         ec &= ~7;
         lc = ec * K;
-        if (const char *e = getenv("IDELUCS_V3_LC")) { const int t = atoi(e); if (t >= 0 && t <= 65536) lc = t; }
+        if (const char *e = idl::dev_env("v3_lc")) { const int t = atoi(e); if (t >= 0 && t <= 65536) lc = t; }
         if (a.edits == nullptr) { ec = 0; lc = 0; }
         a.ecap = ec; a.lcap = lc;
         a.chunk = 2;
-        if (const char *e = getenv("IDELUCS_V3_CHUNK")) { const int t = atoi(e); if (t >= 1 && t <= 4096) a.chunk = t; }
-        if (const char *e = getenv("IDELUCS_VEC_ABLATE")) a.ablate = atoi(e);
+        if (const char *e = idl::dev_env("v3_chunk")) { const int t = atoi(e); if (t >= 1 && t <= 4096) a.chunk = t; }
+        if (const char *e = idl::dev_env("vec_ablate")) a.ablate = atoi(e);
         const size_t lds = (size_t)(HW + 2 * ((a.sc_slots + 1) * 6 + ec) + lc + 3 * V3_META + 2 * V3_VTAB + 16 + 4) * 4;
         if ((int)lds > di.max_dyn_lds || lds > 80 * 1024) return IDL_OK;                 // (fewer than two workgroups per CU: v2's chunked staging is the better fit)
         // workgroups per CU by LDS, with 1 KB of slack each (measured: five 32 032-byte workgroups do NOT become resident
         // together although 5 x 32 032 < 160 KB and the occupancy query says 5 -- the fifth ran after the others)
         int per_cu = (int)((size_t)di.lds_per_cu / (lds + 1024));
         if (per_cu > 4) per_cu = 4;                   // 8 waves per workgroup, <= 64 registers: 32 waves per CU
-        if (const char *e = getenv("IDELUCS_WG_PER_CU")) { const int t = atoi(e); if (t >= 1 && t <= 32) per_cu = t; }
+        if (const char *e = idl::dev_env("wg_per_cu")) { const int t = atoi(e); if (t >= 1 && t <= 32) per_cu = t; }
         if (per_cu < 1) per_cu = 1;
         if (getenv("IDELUCS_DEBUG"))
             fprintf(stderr, "[idl] vectorise k=%d v3 lds=%zu B (histogram copies %d, staged slots %d, edits %d, pairs %d) -> %d workgroups/CU\n", K, lds, 1 << RL, a.sc_slots, ec, lc, per_cu);
@@ -1594,13 +1595,13 @@ int launch_vectorise3_rl(const VecArgs &a_in, const idl::DeviceInfo &di, hipStre
     return IDL_OK;
 }
 
-// v4 takes what v3 takes at k = 4 / 5 when every sequence fits its wave's slice of LDS (<= 12 288 bases); IDELUCS_VEC=3 keeps v3 (the cross-check tests)
+// v4 takes what v3 takes at k = 4 / 5 when every sequence fits its wave's slice of LDS (<= 12 288 bases); IDELUCS_DEV=vec=3 keeps v3 (the cross-check tests)
 template <int K, int RL>
 int launch_vectorise4(const VecArgs &a_in, const idl::DeviceInfo &di, hipStream_t st, bool *done)
 {
     VecArgs a = a_in;
     int want = 4;
-    if (const char *e = getenv("IDELUCS_VEC")) want = atoi(e);
+    if (const char *e = idl::dev_env("vec")) want = atoi(e);
     const bool om = a.mode == IDL_MODE_CGR || a.mode == IDL_MODE_CANONICAL;
     if (want != 4 || (a.mode != IDL_MODE_KMER && !om) || a.init == IDL_INIT_FROM_OUT || a.out_kind == IDL_OUT_FREQ_F64 || a.n_views > V3_MAXV || a.max_len <= 0 ||
         a.max_len > 64 * 64 * V4_SR || a.n > 0x7F000000ll)
@@ -1610,13 +1611,13 @@ int launch_vectorise4(const VecArgs &a_in, const idl::DeviceInfo &di, hipStream_
     a.sc_slots = a.v3_sc;
     int ec = a.edits == nullptr ? 0 : (((int)(a.max_len * 35 / 1000) + 64) * a.n_views / 4 + 7) & ~7;      // edits of all views: 3.5 % of the bases + slack for four views, scaled
     if (ec > 64 * V4_FR) ec = 64 * V4_FR;
-    if (const char *e = getenv("IDELUCS_V3_EC")) { const int t = atoi(e); if (t >= 0 && t <= 64 * V4_FR) ec = t & ~7; }
+    if (const char *e = idl::dev_env("v3_ec")) { const int t = atoi(e); if (t >= 0 && t <= 64 * V4_FR) ec = t & ~7; }
     a.ecap = ec; a.lcap = 0;
     const int slice = (W::HC + (W::F + 4) + (a.v3_sc + 1) * 6 + ec + 3) & ~3;
     // as many waves a workgroup as its CU's LDS holds slices (one workgroup per CU: nothing is shared between the waves but the CU)
     int waves = (di.lds_per_cu - 2048) / (slice * 4);
     if (waves > V4_MAX_WAVES) waves = V4_MAX_WAVES;
-    if (const char *e = getenv("IDELUCS_V4_WAVES")) { const int t = atoi(e); if (t >= 1 && t <= waves) waves = t; }
+    if (const char *e = idl::dev_env("v4_waves")) { const int t = atoi(e); if (t >= 1 && t <= waves) waves = t; }
     if (waves < 4) return IDL_OK;                            // (long sequences: v3 / v2)
     const size_t lds = (size_t)slice * 4 * waves;
     if ((int)lds > di.max_dyn_lds) return IDL_OK;
@@ -1658,7 +1659,7 @@ int launch_vectorise3(const VecArgs &a_in, const idl::DeviceInfo &di, hipStream_
             // copies of the histogram a wave counts into: 4 -- measured at 100 000 x 10 kbp, 4 views, one box (gpurun_out r06): no edits / philox edits
             // 0.351 / 0.649 ms with 4, 0.349 / 0.738 with 8, 0.453 / 1.025 with 16 (fewer waves fit); v3 on the same box: 0.621 / 0.725
             int rl = 2;
-            if (const char *e = getenv("IDELUCS_V4_COPIES")) { const int t = atoi(e); rl = t == 16 ? 4 : (t == 8 ? 3 : (t == 1 ? 0 : 2)); }
+            if (const char *e = idl::dev_env("v4_copies")) { const int t = atoi(e); rl = t == 16 ? 4 : (t == 8 ? 3 : (t == 1 ? 0 : 2)); }
             rc = rl == 4 ? launch_vectorise4<K, 4>(a_in, di, st, done) : (rl == 2 ? launch_vectorise4<K, 2>(a_in, di, st, done) :
                  (rl == 0 ? launch_vectorise4<K, 0>(a_in, di, st, done) : launch_vectorise4<K, 3>(a_in, di, st, done)));
         } else rc = launch_vectorise4<K, 0>(a_in, di, st, done);
@@ -1668,7 +1669,7 @@ int launch_vectorise3(const VecArgs &a_in, const idl::DeviceInfo &di, hipStream_
         // copies of the histogram the count goes to: 16 by default -- measured at 100 000 x 10 kbp, 4 views (gpurun_out/r05_e): 0.708 ms
         // with 16 (four workgroups per CU), 0.714 with 8, 0.844 with 32 (conflict-free, but 41 KB of LDS: three per CU); v2: 1.393
         int rl = 4;
-        if (const char *e = getenv("IDELUCS_V3_COPIES")) { const int t = atoi(e); rl = t == 32 ? 5 : (t == 8 ? 3 : 4); }
+        if (const char *e = idl::dev_env("v3_copies")) { const int t = atoi(e); rl = t == 32 ? 5 : (t == 8 ? 3 : 4); }
         if (rl == 5) return launch_vectorise3_rl<K, 5>(a_in, di, st, done);
         if (rl == 4) return launch_vectorise3_rl<K, 4>(a_in, di, st, done);
         return launch_vectorise3_rl<K, 3>(a_in, di, st, done);
@@ -1691,16 +1692,16 @@ int launch_vectorise(const VecArgs &a_in, const idl::DeviceInfo &di, hipStream_t
     }
     VecArgs a = a_in;
     bool v1 = (a.init == IDL_INIT_FROM_OUT);            // accumulate-on-top needs a per-view start: single-pass kernel
-    if (const char *e = getenv("IDELUCS_VEC")) { if (atoi(e) == 1) v1 = true; }   // force the v1 kernel (cross-check tests)
+    if (const char *e = idl::dev_env("vec")) { if (atoi(e) == 1) v1 = true; }   // force the v1 kernel (cross-check tests)
     int sc = 160;                                       // 10240 bases staged at a time (cfg2's 10 kbp in one super-chunk)
-    if (const char *e = getenv("IDELUCS_SC_SLOTS")) { const int t = atoi(e); if (t >= 1 && t <= 4096) sc = t; }
+    if (const char *e = idl::dev_env("sc_slots")) { const int t = atoi(e); if (t >= 1 && t <= 4096) sc = t; }
     a.sc_slots = sc;
-    if (const char *e = getenv("IDELUCS_VEC_ABLATE")) a.ablate = atoi(e);
+    if (const char *e = idl::dev_env("vec_ablate")) a.ablate = atoi(e);
     // 16-bit bins are possible while no count can reach 65536 (count <= max_len + 1).  Measured on MI355X (cfg2): 8
     // workgroups/CU with 16-bit bins (64 VGPRs, 80 B/lane of spill) run 2.16 ms, 6 workgroups/CU with 32-bit bins
-    // (79 VGPRs) 1.98 ms -- so 32-bit is the default and 16-bit an opt-in experiment (IDELUCS_BINS=16).
+    // (79 VGPRs) 1.98 ms -- so 32-bit is the default and 16-bit an opt-in experiment (IDELUCS_DEV=bins=16).
     bool b16 = false;
-    if (const char *e = getenv("IDELUCS_BINS")) b16 = atoi(e) == 16 && !v1 && a.max_len > 0 && a.max_len <= 65000;
+    if (const char *e = idl::dev_env("bins")) b16 = atoi(e) == 16 && !v1 && a.max_len > 0 && a.max_len <= 65000;
     const int hd = b16 ? (F / 2 + 4) & ~3 : F + 4;
     const size_t lds = v1 ? (size_t)(F + STAGE_DWORDS) * 4
                           : (size_t)(hd + (sc + 1) * 6 + V2_EDIT_CAP + V2_LIST_CAP + 2 * V2_WAVES + 4 * a.n_views) * 4;
@@ -1713,7 +1714,7 @@ int launch_vectorise(const VecArgs &a_in, const idl::DeviceInfo &di, hipStream_t
     if (lds > 64 * 1024) IDL_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int per_cu = 0;
     IDL_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, v1 ? 64 : 64 * V2_WAVES, lds));
-    if (const char *e = getenv("IDELUCS_WG_PER_CU")) { const int t = atoi(e); if (t >= 1 && t <= 32) per_cu = t; }
+    if (const char *e = idl::dev_env("wg_per_cu")) { const int t = atoi(e); if (t >= 1 && t <= 32) per_cu = t; }
     if (per_cu > 16) per_cu = 16;
     if (per_cu < 1) per_cu = 1;
     if (getenv("IDELUCS_DEBUG"))

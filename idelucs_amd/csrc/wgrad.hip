@@ -3,6 +3,7 @@
 // (idl_wgrad_rmsprop_step, train_step.hip); this entry point serves tests, tools/bench_wgrad.py and callers that want the
 // gradient alone.
 #include <stdlib.h>
+#include "dev_env.h"
 #include <string.h>
 
 #include "common.h"
@@ -63,7 +64,7 @@ static int wgrad_launch(const float *dy, const float *x, int m, int n_out, int n
     a.hyper = hyper; a.m = m;
     a.tiles_m = n_out / wg_dev::TM;
     a.tiles = a.tiles_m * (n_in / wg_dev::TN);
-    static const bool noload = [] { const char *e = getenv("IDELUCS_WGRAD_KERNEL"); return e != nullptr && strcmp(e, "noload") == 0; }();
+    static const bool noload = [] { const char *e = idl::dev_env("wgrad_kernel"); return e != nullptr && strcmp(e, "noload") == 0; }();
     if (const int rc = raise_lds_limit(); rc != IDL_OK) return rc;
     const dim3 grid((unsigned)a.tiles), block(wg_dev::THREADS);
     if (noload) hipLaunchKernelGGL((wgrad_q16_kernel<1>), grid, block, wg_dev::IMG_BYTES, (hipStream_t)stream, a);   // diagnostic

@@ -1,6 +1,7 @@
 // wgrad_planes.hip -- idl_wgrad_rmsprop_xplanes: the kernel of wgrad_planes_device.h as a launch of its own (tests, tools/bench_planes.py; in the
 // step it carries the optimizer tail: train_step.hip, idl_wgrad_xplanes_rms).
 #include <stdlib.h>
+#include "dev_env.h"
 
 #include "common.h"
 #include "wgrad_planes_device.h"
@@ -40,7 +41,7 @@ extern "C" int idl_wgrad_rmsprop_xplanes(const void *dy_hi, const void *dy_lo, i
     a.wh = (uint16_t *)w_hi; a.wl = (uint16_t *)w_lo; a.over = overflow_flag; a.hyper = hyper;
     a.m = m; a.n_out = n_out; a.n_in = n_in; a.ldx = ld_x;
     a.tiles_m = n_out / TM; a.tiles = a.tiles_m * (n_in / TN);
-    static const int wgp_dbg = getenv("IDELUCS_WGP_DBG") ? atoi(getenv("IDELUCS_WGP_DBG")) : 0;      // (timing ablations; wgrad_planes_device.h)
+    static const int wgp_dbg = idl::dev_env("wgp_dbg") ? atoi(idl::dev_env("wgp_dbg")) : 0;      // (timing ablations; wgrad_planes_device.h)
     a.dbg = wgp_dbg;
     static bool attr_set[64] = {};
     int dev = 0;

@@ -42,7 +42,7 @@ struct XpArgs {
     int *over;
     const float *hyper;
     int m, n_out, n_in, ldx, tiles_m, tiles;
-    int dbg;                               // diagnostics (IDELUCS_WGP_DBG; wrong results): 8 no epilogue
+    int dbg;                               // diagnostics (IDELUCS_DEV=wgp_dbg; wrong results): 8 no epilogue
 };
 
 __device__ __forceinline__ int swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }      // cdna_hip_programming.md T10 (b)

@@ -144,7 +144,7 @@ def _planes_of(bf, F):
 
 
 def _lat_part_of(bf):
-    """idl_l1_fwd's partial sums of r1 W2^T per 64-unit tile of the hidden layer (the opt-in IDELUCS_L1_FUSED=1 path only)."""
+    """idl_l1_fwd's partial sums of r1 W2^T per 64-unit tile of the hidden layer (the opt-in IDELUCS_DEV=l1_fused=1 path only)."""
     if bf._lat_part is None:
         m, H2, dev = bf._dims
         bf._lat_part = torch.empty((_L.idl_l1_fwd_parts(), m, H2), dtype=torch.float32, device=dev)
@@ -201,7 +201,7 @@ class FusedLinearTrainer:
         self._bufs = {}
         self._graphs = {}
         self._side = torch.cuda.Stream(device=self.dev)     # second branch of the step (see step_on_batch)
-        # TEST HOOK (IDELUCS_TEST_COLD=1; tests/test_gpu_planes.py): a 512 MB fill in front of the step's middle and of each plane kernel, so that every load of
+        # TEST HOOK (IDELUCS_DEV=test_cold=1; tests/test_gpu_planes.py): a 512 MB fill in front of the step's middle and of each plane kernel, so that every load of
         # the hand-scheduled kernels comes from HBM instead of a warm L2/MALL -- a load consumed before its wait is right when it landed
         # early and wrong when it did not (DESIGN.md History, round 5), and only cold caches show that
         self._cold = _v("test_cold") == "1"
@@ -213,14 +213,14 @@ class FusedLinearTrainer:
         # m % 128 == 0 and F % 512 == 0; any other step runs the fp32 tiles.
         self._planes = planes_default()
         self._planes_reduce_launch = True        # (round 6: the variant in which mid_fwd added the eight partial sums itself -- +8 us -- was removed)
-        # ... and the same for a rank's voters in lockstep (BatchedLinearTrainer; IDELUCS_LOCKSTEP_PLANES=0: their products as batched fp32
+        # ... and the same for a rank's voters in lockstep (BatchedLinearTrainer; IDELUCS_DEV=lockstep_planes=0: their products as batched fp32
         # library GEMMs instead): the six launches of the two-plane step recorded per voter and run once for all of them, blockIdx.y = voter
         # -- the lone voters' steps bit for bit (tests/test_gpu_planes.py), 47.5 / 45.4 / 43.6 ms a voter-epoch in batches of 2 / 4 / 8
         # against 54.2 alone (fp32 GEMMs: 58.9 / 54.8 / 52.6)
         self._planes_lockstep = _v("lockstep_planes") != "0"
         # ... and dW1 from the batch's planes too (csrc/wgrad_planes.hip); the assembling workgroups then write the planes ONLY
         self._planes_wgrad = _v("planes_wgrad") != "0"
-        # ... whose loader waves run the step's optimizer tail under the tiles' epilogue (IDELUCS_PLANES_TAIL=reduce: the tail beside the
+        # ... whose loader waves run the step's optimizer tail under the tiles' epilogue (IDELUCS_DEV=planes_tail=reduce: the tail beside the
         # next step's partial sums instead, 9.4 us for that launch against 4.7)
         self._planes_tail_wgrad = _v("planes_tail") != "reduce"
         self._cus = torch.cuda.get_device_properties(self.dev).multi_processor_count if self.dev.type == "cuda" else 0
@@ -248,13 +248,13 @@ class FusedLinearTrainer:
         self._gsplit = min(max(int(_v("gather_split")), 0), 8)   # eighths of the tiles the mid-forward launch takes
         # layer-1 activations kept transposed ([512, m]) between the layer-1 product and its consumers
         self._transposed_l1 = _v("transposed_l1") != "0"
-        # OPT-IN (IDELUCS_L1_FUSED=1; measured, not adopted -- DESIGN 4.4): the layer-1 product on this package's own MFMA tiles with bias /
+        # OPT-IN (IDELUCS_DEV=l1_fused=1; measured, not adopted -- DESIGN 4.4): the layer-1 product on this package's own MFMA tiles with bias /
         # ReLU / Dropout and the K-split of Linear(512, 64) in its epilogue (csrc/l1_fwd.hip, idl_l1_fwd); the mid-forward launch is then
         # the head alone.  The bare product ties hipBLASLt (32.1-33.1 us against 32.8-33.7) and the head's own path shrinks from 8.9 to
         # 2.6 us, but that launch's LENGTH is set by the batch assembly riding in it (three dependent memory round trips, ~8-10 us),
         # which stays: 36.4 + 10.4 us against 32.8 + 11.0, the step 114.7 us against 111.8.
         self._l1_fused = _v("l1_fused") == "1"
-        # IDELUCS_L1_FUSED=bare: the same tiles as a plain product (no epilogue) in place of the library GEMM, mid_fwd unchanged
+        # IDELUCS_DEV=l1_fused=bare: the same tiles as a plain product (no epilogue) in place of the library GEMM, mid_fwd unchanged
         self._l1_bare = _v("l1_fused") == "bare"
         # eighths of the next batch's tiles assembled by RIDER workgroups of that launch (default 0: beside fp32 MFMA waves, which hold
         # the vector issue port, the riders' arithmetic costs the tiles 9 us for the 7 us it saves the middle launches)
@@ -265,12 +265,12 @@ class FusedLinearTrainer:
         self._joint_inlaunch = _v("joint_inlaunch") != "0"   # IIC joint inside the InfoNCE pass-1 launch
         # dW1 on this package's own MFMA tiles with RMSprop in their epilogue, as the head of the optimizer launch
         # (csrc/wgrad_device.h, idl_wgrad_rmsprop_step): one launch instead of hipBLASLt's GEMM + the optimizer launch, and the 8 MB
-        # gradient never goes to memory.  IDELUCS_WGRAD_FUSED=0: hipBLASLt + optimizer launch; =2: the tiles as a launch of their own
+        # gradient never goes to memory.  IDELUCS_DEV=wgrad_fused=0: hipBLASLt + optimizer launch; =2: the tiles as a launch of their own
         self._wgrad_fused = _v("wgrad_fused") != "0"
         self._wgrad_own_launch = _v("wgrad_fused") == "2"
         self._keep_w1_grad = _v("keep_w1_grad") != "0"       # tests: also write dW1 to grads[0]
         self._steps_per_graph = max(2, int(_v("steps_per_graph")) // 2 * 2)
-        # Round 5 (IDELUCS_TAIL_L1, default on): the layer-1 product on this package's own tiles (idl_l1_fwd: no library build decides
+        # Round 5 (IDELUCS_DEV=tail_l1, default on): the layer-1 product on this package's own tiles (idl_l1_fwd: no library build decides
         # its speed) and the optimizer's TAIL -- the dW2 tiles, the small tensors, step loss, step counter: 5.8 us behind the dW1 tiles
         # of the optimizer launch, where they cannot become resident beside a tile -- riding in the layer-1 launch of the NEXT step
         # (idl_l1_fwd_rms), where they have 30 us of slack.  A step then ends with the dW1 tiles alone; its tail is pending until the

@@ -159,7 +159,7 @@ SILHOUETTE_ONE_PASS_MIN = 4096   # points from which 64-dimensional data take th
 def silhouette_score_device(data, labels, device=None, block=4096):
     """sklearn.metrics.silhouette_score(data, labels) (euclidean, mean over all samples) on the GPU.  64-dimensional data (the
     latent) from SILHOUETTE_ONE_PASS_MIN points: one pass over all pairs on the fp32 matrix cores that adds every point's distances
-    up per cluster in registers (_silhouette_one_pass; 10^6 points: 2 s).  Otherwise ($IDELUCS_SILHOUETTE=gemm forces it): for a
+    up per cluster in registers (_silhouette_one_pass; 10^6 points: 2 s).  Otherwise ($IDELUCS_DEV=silhouette=gemm forces it): for a
     block of rows the distances to every point come from one GEMM (||x||^2 + ||y||^2 - 2 x.y, clamped, square-rooted) and their
     per-cluster sums from a second GEMM with the one-hot label matrix (10 s at 10^6 points: five elementwise passes over 4 TB).
     float64 from the per-cluster sums on; agrees with sklearn to ~1e-6 (tests/test_cli_surface.py)."""
@@ -487,7 +487,7 @@ def core_distances_device(x64, k, device, f32_exact=None, stats=None, order=None
     """Distance of every point to its k-th nearest neighbour, itself included (sklearn _hdbscan_prims: NearestNeighbors(
     n_neighbors=k).kneighbors(X)[:, -1]).  From KNN_WINDOW_MIN points of 64 float32-exact coordinates (the latent of the
     reference's networks) the one-pass window kernels; else, and for the rows their bracket missed, the float64 Gram-form matrix
-    in row blocks (_core_distances_rows).  $IDELUCS_KNN = matrix | window forces one.
+    in row blocks (_core_distances_rows).  $IDELUCS_DEV=knn = matrix | window forces one.
     shard = (rank, world) (every rank of the group must call, with the same points): the window path's rows are split over the
     ranks and the result all-reduced (_core_distances_window); the few rows the brackets missed, and the matrix path, are computed
     by every rank for itself -- the same values everywhere."""
@@ -502,7 +502,7 @@ def core_distances_device(x64, k, device, f32_exact=None, stats=None, order=None
     if mode != "matrix" and f32_exact and x64.shape[1] == 64 and (n >= KNN_WINDOW_MIN or mode == "window"):
         todo = _core_distances_window(x64, k, device, core, stats=stats, order=order, shard=shard)
         if todo is None and mode == "window":
-            raise ValueError("core_distances_device: no bracket for this k / n (IDELUCS_KNN=window)")
+            raise ValueError("core_distances_device: no bracket for this k / n (IDELUCS_DEV=knn=window)")
     if todo is None:
         _core_distances_rows(x64, sq, None, k, device, core)
     elif todo.numel():

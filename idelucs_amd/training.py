@@ -67,7 +67,7 @@ def voter_lanes(n_voters_here, model=None):
     One training step is a handful of launches, most of them latency-bound; batched, each launch serves every voter of the batch
     (fused.BatchedLinearTrainer: blockIdx.y = voter), the two big products included when the step takes them from fp16 planes
     (plane_step_applies).  Default: all of a rank's voters, up to 8: at cfg2 a voter-epoch costs 54.2 ms alone and 47.5 / 45.4 / 43.6 ms in
-    lockstep batches of 2 / 4 / 8 (bench.py: predicted_fixed_job).  With IDELUCS_LOCKSTEP_PLANES=0 a batch runs the products as batched
+    lockstep batches of 2 / 4 / 8 (bench.py: predicted_fixed_job).  With IDELUCS_DEV=lockstep_planes=0 a batch runs the products as batched
     fp32 library GEMMs (58.9 / 54.8 / 52.6 ms): a lone voter on planes then beats a batch of 2, and two voters train one after the other."""
     env = os.environ.get("IDELUCS_VOTER_LANES")
     lanes = max(1, min(int(env) if env is not None else 8, n_voters_here))
@@ -116,7 +116,7 @@ def train_voters(model, voters, n_epochs, n_voters=None, lanes=None, progress=Tr
             lane_models = [model.lane() for _ in wave]
             try:
                 batched = BatchedLinearTrainer([m.net for m in lane_models], model.lr, model.weight, model.l, seed=model.seed)
-            except ValueError:       # an opt-in launch variant (IDELUCS_OVERLAP, IDELUCS_WGRAD_FUSED, ...) the batched step does not take
+            except ValueError:       # an opt-in launch variant (IDELUCS_DEV=overlap, IDELUCS_DEV=wgrad_fused, ...) the batched step does not take
                 for v in voters[w:]:
                     out[v] = train_voter(model, n_epochs, v, n_voters, progress)
                 return out

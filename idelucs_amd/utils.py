@@ -432,7 +432,7 @@ def _slots_budget(dev_in, p_ts, p_tv, n_rn, max_len):
 
 def _philox_edits(dev_in, specs, seed, capacity=None, slots=None, sync=None):
     """Device-drawn mimic sites -> (edits, edit_off) on device.
-    Default (slots; IDELUCS_MIMIC_SLOTS=0 turns it off; slots=True forces it; otherwise only while the slot buffer stays within
+    Default (slots; IDELUCS_DEV=mimic_slots=0 turns it off; slots=True forces it; otherwise only while the slot buffer stays within
     _slots_budget -- one long record among many short ones goes to the exact protocol): ONE pass (idl_mimic_edits_slots) into fixed per-item slots sized on the
     host from the longest sequence; edit_off is then the [n_views * n, 2] array of (begin, end) _vectorise understands.  An item
     that outgrows its slot (expected sites + 10 sigma + 32) raises a device flag: with sync (the default without a capacity)
@@ -651,7 +651,7 @@ def standardise(x, mean, scale, out=None):
 
 def counts_route_ok(k, reduce=False):
     """The predict inputs can be formed from int32 counts (idl_counts_stats / idl_counts_standardise) for plain k-mer rows of 4^k
-    columns with 4^k / 4 a multiple of 64: k = 4..7.  IDELUCS_PREDICT_COUNTS=0: always the float64 rows."""
+    columns with 4^k / 4 a multiple of 64: k = 4..7.  IDELUCS_DEV=predict_counts=0: always the float64 rows."""
     return (not reduce) and 4 <= k <= 7 and OPTIONS["predict_counts"] != "0"
 
 

@@ -2,6 +2,7 @@
 against (a) the golden vectors generated from the real reference and (b) the CPU oracle on seeded
 random inputs.  Integer/byte results must be bit-exact."""
 import json
+from conftest import dev_env
 import os
 import random
 
@@ -146,9 +147,9 @@ def test_random_batches_with_edits_vs_oracle(gpu, monkeypatch, sc_slots, bins):
     exercised on small inputs."""
     import torch
     if sc_slots is not None:
-        monkeypatch.setenv("IDELUCS_SC_SLOTS", sc_slots)
+        dev_env(monkeypatch, sc_slots=sc_slots)
     if bins is not None:
-        monkeypatch.setenv("IDELUCS_BINS", bins)          # opt-in 16-bit LDS bins (default: 32-bit)
+        dev_env(monkeypatch, bins=bins)          # opt-in 16-bit LDS bins (default: 32-bit)
     from idelucs_amd import _lib, utils as U
     rng = np.random.default_rng(2024)
     seqs = _random_batch(rng, 40, 0, 300) + _random_batch(rng, 12, 3900, 4300) + _random_batch(rng, 6, 8000, 13000, 0.0) \
@@ -191,7 +192,7 @@ def test_adversarial_edits_at_boundaries(gpu, monkeypatch, sc_slots, long_seq):
     import torch
     from idelucs_amd import _lib, utils as U
     if sc_slots is not None:
-        monkeypatch.setenv("IDELUCS_SC_SLOTS", sc_slots)
+        dev_env(monkeypatch, sc_slots=sc_slots)
     rng = np.random.default_rng(77)
     seqs = _random_batch(rng, 6, 380, 400, 0.01) + _random_batch(rng, 2, 64, 64, 0.0) + _random_batch(rng, 2, 128, 129, 0.0) \
         + _random_batch(rng, 2, 17000, 17010, 0.001)
@@ -405,7 +406,7 @@ def test_cgr_and_canonical_rows_of_the_wave_per_sequence_kernel_are_v2s(gpu, mon
     for mode in (_lib.MODE_CGR, _lib.MODE_CANONICAL):
         outs = {}
         for which in ("2", "4"):
-            monkeypatch.setenv("IDELUCS_VEC", which)
+            dev_env(monkeypatch, vec=which)
             outs[which] = (U._vectorise(din, k, mode, _lib.INIT_ONE, _lib.OUT_FREQ_F32, 4, edits, edit_off).clone(),
                            U._vectorise(din, k, mode, _lib.INIT_ZERO, _lib.OUT_COUNTS_I32, 4, edits, edit_off).clone(),
                            U._vectorise(din, k, mode, _lib.INIT_ONE, _lib.OUT_FREQ_F32).clone())
@@ -413,9 +414,9 @@ def test_cgr_and_canonical_rows_of_the_wave_per_sequence_kernel_are_v2s(gpu, mon
             assert a_.shape == b_.shape and torch.equal(a_, b_), (mode, k)
         assert outs["4"][0].shape[-1] == int(_lib.lib.idl_row_len(mode, k))
         assert float(outs["4"][0][1:].sum(-1).sub(1).abs().max()) < 1e-5 and not torch.equal(outs["4"][0][0], outs["4"][0][1])
-        monkeypatch.setenv("IDELUCS_VEC", "4"); monkeypatch.setenv("IDELUCS_V3_EC", "320")
+        dev_env(monkeypatch, vec="4"); dev_env(monkeypatch, v3_ec="320")
         assert torch.equal(U._vectorise(din, k, mode, _lib.INIT_ONE, _lib.OUT_FREQ_F32, 4, edits, edit_off), outs["2"][0]), (mode, k)
-        monkeypatch.delenv("IDELUCS_V3_EC")
+        dev_env(monkeypatch, v3_ec=None)
 
 
 @pytest.mark.parametrize("k", [6, 5, 4])
@@ -436,33 +437,33 @@ def test_full_size_v1_v2_v3_kernels_agree_bitwise(gpu, monkeypatch, k):
     edits, edit_off = U._philox_edits(din, specs, 11)
     outs = {}
     for which in ("4", "3", "2", "1"):                        # (4: round 6's wave-per-sequence kernel, the default at k = 4 / 5; it does not take k = 6: v3 runs)
-        monkeypatch.setenv("IDELUCS_VEC", which)
+        dev_env(monkeypatch, vec=which)
         outs[which] = (U._vectorise(din, k, _lib.MODE_KMER, _lib.INIT_ONE, _lib.OUT_FREQ_F32, 4, edits, edit_off).clone(),
                        U._vectorise(din, k, _lib.MODE_KMER, _lib.INIT_ZERO, _lib.OUT_COUNTS_I32, 4, edits, edit_off).clone())
     assert torch.equal(outs["1"][1], outs["2"][1]) and torch.equal(outs["1"][1], outs["3"][1]) and torch.equal(outs["1"][1], outs["4"][1])
     assert torch.equal(outs["1"][0], outs["2"][0]) and torch.equal(outs["1"][0], outs["3"][0]) and torch.equal(outs["1"][0], outs["4"][0])
     if k in (4, 5):     # ... also when its tables take only some of the sequences (the rest: the second pass on v2), and with other numbers of histogram copies
         for ec, lc in (("0", "0"), ("320", "1800")):
-            monkeypatch.setenv("IDELUCS_VEC", "4"); monkeypatch.setenv("IDELUCS_V3_EC", ec); monkeypatch.setenv("IDELUCS_V3_LC", lc)
+            dev_env(monkeypatch, vec="4"); dev_env(monkeypatch, v3_ec=ec); dev_env(monkeypatch, v3_lc=lc)
             assert torch.equal(U._vectorise(din, k, _lib.MODE_KMER, _lib.INIT_ONE, _lib.OUT_FREQ_F32, 4, edits, edit_off), outs["1"][0]), (ec, lc)
-        monkeypatch.delenv("IDELUCS_V3_EC"); monkeypatch.delenv("IDELUCS_V3_LC")
+        dev_env(monkeypatch, v3_ec=None); dev_env(monkeypatch, v3_lc=None)
         if k == 4:
             for copies in ("16", "8", "1"):
-                monkeypatch.setenv("IDELUCS_VEC", "4"); monkeypatch.setenv("IDELUCS_V4_COPIES", copies)
+                dev_env(monkeypatch, vec="4"); dev_env(monkeypatch, v4_copies=copies)
                 assert torch.equal(U._vectorise(din, k, _lib.MODE_KMER, _lib.INIT_ZERO, _lib.OUT_COUNTS_I32, 4, edits, edit_off), outs["1"][1]), copies
-            monkeypatch.delenv("IDELUCS_V4_COPIES")
+            dev_env(monkeypatch, v4_copies=None)
     if k == 4:      # round 5: the count goes to 16 copies of the 4^4-bin histogram (lane l adds to copy l mod 16); 32 and 8 copies: the same rows
         for copies in ("32", "8"):
-            monkeypatch.setenv("IDELUCS_VEC", "3"); monkeypatch.setenv("IDELUCS_V3_COPIES", copies)
+            dev_env(monkeypatch, vec="3"); dev_env(monkeypatch, v3_copies=copies)
             assert torch.equal(U._vectorise(din, k, _lib.MODE_KMER, _lib.INIT_ONE, _lib.OUT_FREQ_F32, 4, edits, edit_off), outs["1"][0]), copies
             assert torch.equal(U._vectorise(din, k, _lib.MODE_KMER, _lib.INIT_ZERO, _lib.OUT_COUNTS_I32, 4, edits, edit_off), outs["1"][1]), copies
-        monkeypatch.delenv("IDELUCS_V3_COPIES")
+        dev_env(monkeypatch, v3_copies=None)
     # sequences whose edits / pairs do not fit v3's LDS tables are left to a second pass on the v2 kernel: same bits
     # (tables for no / half / nearly all of the sequences: the second pass scans, or walks the short list v3 left it)
     for ec, lc in (("0", "0"), ("320", "1800"), ("512", "1920"), ("448", "2304")):
-        monkeypatch.setenv("IDELUCS_VEC", "3"); monkeypatch.setenv("IDELUCS_V3_EC", ec); monkeypatch.setenv("IDELUCS_V3_LC", lc)
+        dev_env(monkeypatch, vec="3"); dev_env(monkeypatch, v3_ec=ec); dev_env(monkeypatch, v3_lc=lc)
         assert torch.equal(U._vectorise(din, k, _lib.MODE_KMER, _lib.INIT_ONE, _lib.OUT_FREQ_F32, 4, edits, edit_off), outs["1"][0]), (ec, lc)
-    monkeypatch.delenv("IDELUCS_V3_EC"); monkeypatch.delenv("IDELUCS_V3_LC")
+    dev_env(monkeypatch, v3_ec=None); dev_env(monkeypatch, v3_lc=None)
     c = outs["2"][1]
     assert not torch.equal(c[0], c[1]) and int(c[3].sum(1).min()) >= 10000 - (k - 1) - 20 * k       # the views differ; Random_N kills <= 20*k windows
 
@@ -621,7 +622,7 @@ def test_variant_n_synthetic_input_vs_oracle(gpu, monkeypatch):
     edits, edit_off = U._philox_edits(din, [t.spec() for t in U.mimic_transforms(P - 1)], 3)
     outs = {}
     for ver in ("1", "2", "3"):
-        monkeypatch.setenv("IDELUCS_VEC", ver)
+        dev_env(monkeypatch, vec=ver)
         outs[ver] = U._vectorise(din, k, _lib.MODE_KMER, _lib.INIT_ONE, _lib.OUT_FREQ_F32, P, edits, edit_off)
     assert torch.equal(outs["1"], outs["2"]) and torch.equal(outs["1"], outs["3"])
     assert torch.allclose(outs["3"].double().sum(2), torch.ones((P, n), dtype=torch.float64, device=dev), atol=1e-6)
@@ -713,9 +714,9 @@ def test_one_pass_ingest_device_image_with_sparse_mask(gpu, tmp_path, monkeypatc
     and the feature store built from it is the one built with every mask copied."""
     import torch
     from idelucs_amd import _lib, utils as U
-    monkeypatch.setenv("IDELUCS_PAR_MIN", "0")
+    dev_env(monkeypatch, par_min="0")
     monkeypatch.setenv("IDELUCS_THREADS", "6")
-    monkeypatch.setenv("IDELUCS_COPY_STREAMS", streams)
+    dev_env(monkeypatch, copy_streams=streams)
     rng = np.random.default_rng(5)
     fn = str(tmp_path / "mix.fas")
     with open(fn, "wb") as f:                      # long clean stretches (pieces without an N), a few records with N runs / IUPAC, short and empty ones
@@ -729,7 +730,7 @@ def test_one_pass_ingest_device_image_with_sparse_mask(gpu, tmp_path, monkeypatc
     whole = U.FastaFile(fn)
     images = {}
     for sparse in ("1", "0"):
-        monkeypatch.setenv("IDELUCS_SPARSE_MASK", sparse)
+        dev_env(monkeypatch, sparse_mask=sparse)
         U.release_ingest_buffers()
         din = U._OnePassInput.create(fn, dev)
         assert din is not None

@@ -2,6 +2,7 @@
 symbol, the FASTA reader / check_sequence / packer agree with the golden vectors and the oracle.
 No compute entry point is called here (there is no GPU in this tier)."""
 import ctypes
+from conftest import dev_env
 import json
 import os
 import re
@@ -172,7 +173,7 @@ def test_threaded_reader_equals_oracle(tmp_path, monkeypatch, threads):
     """The parallel reader (forced on for small files) reproduces the reference's sequential state machine:
     wrapped lines, CRLF, padded lines, comments, lower case / IUPAC / gaps, empty records."""
     monkeypatch.setenv("IDELUCS_THREADS", threads)
-    monkeypatch.setenv("IDELUCS_PAR_MIN", "0")
+    dev_env(monkeypatch, par_min="0")
     rng = np.random.default_rng(int(threads))
     p = str(tmp_path / "r.fas")
     _random_fasta(p, rng, 300)
@@ -231,7 +232,7 @@ def test_reader_quirks_match_reference_state_machine(tmp_path, monkeypatch, cont
     for threads, par_min in (("1", None), ("4", "0")):
         monkeypatch.setenv("IDELUCS_THREADS", threads)
         if par_min is not None:
-            monkeypatch.setenv("IDELUCS_PAR_MIN", par_min)
+            dev_env(monkeypatch, par_min=par_min)
         ff = U.FastaFile(str(p), keep_bytes=True)
         assert ff.names == [r[0] for r in want], (threads, ff.names)
         assert [bytes(ff.record(i)) for i in range(ff.n)] == [bytes(r[1]) for r in want]
@@ -239,7 +240,7 @@ def test_reader_quirks_match_reference_state_machine(tmp_path, monkeypatch, cont
 
 def test_first_error_in_file_order_wins(tmp_path, monkeypatch):
     monkeypatch.setenv("IDELUCS_THREADS", "6")
-    monkeypatch.setenv("IDELUCS_PAR_MIN", "0")
+    dev_env(monkeypatch, par_min="0")
     body = b"".join(b">r%d\nACGTACGTAC\n" % i for i in range(200))
     bad = body.replace(b">r150\nACGT", b">r150\nAC!T").replace(b">r40\nACGT", b">r40\nAZGT").replace(b">r90\n", b">r\t90\n")
     p = tmp_path / "e.fas"
@@ -257,7 +258,7 @@ def test_ranged_packing_equals_whole_file_export(tmp_path, monkeypatch, threads)
     """idl_fasta_pack_range (the streamed ingest: record chunks packed into the whole-file buffers at their slot offsets)
     gives the same bytes as idl_fasta_export, whatever the chunking, also on Influenza-A."""
     monkeypatch.setenv("IDELUCS_THREADS", threads)
-    monkeypatch.setenv("IDELUCS_PAR_MIN", "0")
+    dev_env(monkeypatch, par_min="0")
     rng = np.random.default_rng(5)
     fn = str(tmp_path / "r.fas")
     _random_fasta(fn, rng, 41)
@@ -299,7 +300,7 @@ def test_one_pass_reader_equals_general_reader(tmp_path, monkeypatch, threads):
     lengths and packed bytes of the general reader, record by record, at the slots it reports -- wrapped lines, CRLF, padded lines,
     comments, lower case / IUPAC / gaps, empty records, Influenza-A; and records of any one thread sit back to back."""
     monkeypatch.setenv("IDELUCS_THREADS", threads)
-    monkeypatch.setenv("IDELUCS_PAR_MIN", "0")
+    dev_env(monkeypatch, par_min="0")
     rng = np.random.default_rng(40 + int(threads))
     fn = str(tmp_path / "r.fas")
     _random_fasta(fn, rng, 300)
@@ -331,7 +332,7 @@ def test_one_pass_reader_leaves_rolling_layouts_to_the_general_reader(tmp_path, 
     p.write_bytes(content)
     for threads in ("1", "4"):
         monkeypatch.setenv("IDELUCS_THREADS", threads)
-        monkeypatch.setenv("IDELUCS_PAR_MIN", "0")
+        dev_env(monkeypatch, par_min="0")
         assert _one_pass(str(p)) is None
 
 
@@ -346,7 +347,7 @@ def test_one_pass_reader_on_small_layouts(tmp_path, monkeypatch, content):
     want = list(O.fasta_records(str(p)))
     for threads in ("1", "4"):
         monkeypatch.setenv("IDELUCS_THREADS", threads)
-        monkeypatch.setenv("IDELUCS_PAR_MIN", "0")
+        dev_env(monkeypatch, par_min="0")
         got = _one_pass(str(p))
         assert got is not None
         ff, codes, mask = got
@@ -360,7 +361,7 @@ def test_one_pass_reader_on_small_layouts(tmp_path, monkeypatch, content):
 def test_one_pass_reader_errors_and_full_regions(tmp_path, monkeypatch):
     """Same first-error-in-file-order rule and messages as the general reader; a region that runs out of slots is a fallback."""
     monkeypatch.setenv("IDELUCS_THREADS", "6")
-    monkeypatch.setenv("IDELUCS_PAR_MIN", "0")
+    dev_env(monkeypatch, par_min="0")
     body = b"".join(b">r%d\nACGTACGTAC\n" % i for i in range(200))
     bad = body.replace(b">r150\nACGT", b">r150\nAC!T").replace(b">r40\nACGT", b">r40\nAZGT").replace(b">r90\n", b">r\t90\n")
     p = tmp_path / "e.fas"
@@ -381,7 +382,7 @@ def test_kept_mapping_never_serves_a_rewritten_file(tmp_path, monkeypatch):
     """The readers keep the mapping of the last file after its handles close.  A file rewritten in place (same path, same size,
     same inode) must be read anew: the key holds the modification time; idl_ingest_release drops the mapping."""
     monkeypatch.setenv("IDELUCS_THREADS", "2")
-    monkeypatch.setenv("IDELUCS_PAR_MIN", "0")
+    dev_env(monkeypatch, par_min="0")
     p = tmp_path / "m.fas"
     p.write_bytes(b">a\nACGTACGT\n>b\nGGGGCCCC\n")
     first = U.FastaFile(str(p), keep_bytes=True)
@@ -441,17 +442,17 @@ def test_reader_thread_default_follows_quota_and_ranks():
 
 
 def test_reader_cpu_plan_one_core_per_thread(monkeypatch):
-    """Round 5: a device job's reader threads are bound to the NUMA node of the device; with IDELUCS_NUMA_PIN=1 one core each, cores
-    dealt over the L3 domains (idl_ingest_cpu_plan reports the placement without changing anything).  Here, without a device: IDELUCS_NUMA=<node>
+    """Round 5: a device job's reader threads are bound to the NUMA node of the device; with IDELUCS_DEV=numa_pin=1 one core each, cores
+    dealt over the L3 domains (idl_ingest_cpu_plan reports the placement without changing anything).  Here, without a device: IDELUCS_DEV=numa=<node>
     names the node; every thread's set is a non-empty part of this process's CPUs, and as many threads as the node has cores get
-    cores of their own; IDELUCS_NUMA=off plans nothing."""
+    cores of their own; IDELUCS_DEV=numa=off plans nothing."""
     if not os.path.isdir("/sys/devices/system/node/node0"):
         pytest.skip("no NUMA topology in sysfs")
     mine = os.sched_getaffinity(0)
     nt = 12
     first = np.full(nt, -2, np.int32); count = np.zeros(nt, np.int32)
-    monkeypatch.setenv("IDELUCS_NUMA", "0")
-    monkeypatch.setenv("IDELUCS_NUMA_PIN", "1")
+    dev_env(monkeypatch, numa="0")
+    dev_env(monkeypatch, numa_pin="1")
     node = _lib.lib.idl_ingest_cpu_plan(-1, nt, U._ptr(first), U._ptr(count))
     if node < 0:
         pytest.skip("node 0 holds none of this process's CPUs")
@@ -463,16 +464,16 @@ def test_reader_cpu_plan_one_core_per_thread(monkeypatch):
     n_cores = len({open(f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list").read().strip() for c in mine
                    if os.path.exists(f"/sys/devices/system/node/node0/cpu{c}")})
     assert len(cores) == min(nt, n_cores)
-    monkeypatch.setenv("IDELUCS_NUMA_PIN", "0")                  # (the default) the node's whole set for everybody, or nothing to do at all
+    dev_env(monkeypatch, numa_pin="0")                  # (the default) the node's whole set for everybody, or nothing to do at all
     assert _lib.lib.idl_ingest_cpu_plan(-1, nt, U._ptr(first), U._ptr(count)) == 0 and len(set(count.tolist())) == 1
-    monkeypatch.setenv("IDELUCS_NUMA", "off")
+    dev_env(monkeypatch, numa="off")
     assert _lib.lib.idl_ingest_cpu_plan(-1, nt, U._ptr(first), U._ptr(count)) == -1 and np.all(count == 0)
 
 
 def test_reader_pool_is_reused_and_survives_fork(tmp_path, monkeypatch):
     """Round 5: the reader's threads persist between calls.  Jobs of different widths follow each other, and a forked child
     (whose parent's pool threads do not exist there) reads with a pool of its own."""
-    monkeypatch.setenv("IDELUCS_PAR_MIN", "0")
+    dev_env(monkeypatch, par_min="0")
     rng = np.random.default_rng(77)
     fn = str(tmp_path / "p.fas")
     _random_fasta(fn, rng, 200)
@@ -511,7 +512,7 @@ def test_arena_meta_and_deferred_names(tmp_path, monkeypatch):
     """Round 5: idl_fasta_arena_meta hands out lengths, arena slots and the length range right after the one pass; the names come
     later (FastaFile.from_handle(meta=...): on first use or at close()) and are the general reader's."""
     monkeypatch.setenv("IDELUCS_THREADS", "4")
-    monkeypatch.setenv("IDELUCS_PAR_MIN", "0")
+    dev_env(monkeypatch, par_min="0")
     for path in (os.path.join(DATA, "Influenza-A.fas"),):
         whole = U.FastaFile(path)
         size = os.path.getsize(path)

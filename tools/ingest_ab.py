@@ -2,7 +2,7 @@
 """A/B runs of T_e2e's host stage: utils.build_feature_store(streamed=True) on the synthetic cfg2 FASTA (100 000 x 10 kbp, tmpfs)
 under a list of environment settings, one child process per setting (most knobs are read once per process), with the reader's
 own timeline (IDELUCS_INGEST_TIMING) of the best repetition.
-   python tools/ingest_ab.py "IDELUCS_NUMA=off" "IDELUCS_READER_POOL=0" "IDELUCS_COPY_DIV=4" ...      (each argument: VAR=VAL[;VAR=VAL...]; "" = defaults)"""
+   python tools/ingest_ab.py "IDELUCS_DEV=numa=off" "IDELUCS_DEV=reader_pool=0" "IDELUCS_DEV=copy_div=4" ...      (each argument: VAR=VAL[;VAR=VAL...]; "" = defaults)"""
 import os
 import subprocess
 import sys

@@ -8,7 +8,7 @@ after >= 2 s of back-to-back launches, median over waves.  Arms:
   B  the same on all-zero operands (what an 'uninitialised registers' probe measures: round 3's 31.3 us figure)
   C  the product's loop (operands streamed through the register ring) -- random data
   D  arm C launched right behind the hipBLASLt layer-1 GEMM (the clock in the library kernel's neighbourhood)
-  E  inside the real training step: the stamped optimizer launch (IDELUCS_STAMPS=1), whole-workgroup clock of the dW1 tiles
+  E  inside the real training step: the stamped optimizer launch (IDELUCS_DEV=stamps=1), whole-workgroup clock of the dW1 tiles
 Prints a table; `python tools/mfma_clock.py > profiles/r04_mfma_clock.txt`."""
 import ctypes
 import os
@@ -17,7 +17,7 @@ import sys
 import threading
 import time
 
-os.environ["IDELUCS_STAMPS"] = "1"
+os.environ["IDELUCS_DEV"] = ",".join(x for x in (os.environ.get("IDELUCS_DEV", ""), "stamps=1") if x)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch

@@ -25,6 +25,7 @@ for f in glob.glob(out + "/g*/**/*counter_collection.csv", recursive=True):
         k = r["Kernel_Name"]
         K = __import__("os").environ.get("IDELUCS_ABLATE_K", "6")
         if "vectorise3_kernel" in k: k = f"vectorise3_kernel<{K}>"
+        elif "vectorise4_kernel" in k: k = f"vectorise4_kernel<{K}> (round 6: a wavefront per sequence, k = 4 / 5)"
         elif "vectorise2_kernel" in k: k = f"vectorise2_kernel<{K},false> (second pass: exits at once when v3 left nothing)"
         else: continue
         agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
@@ -36,11 +37,11 @@ for k, cs in agg.items():
 open(out + "/summary.txt", "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
 K = int(__import__("os").environ.get("IDELUCS_ABLATE_K", "6"))
-k3 = agg.get(f"vectorise3_kernel<{K}>", {})
+k3 = agg.get(f"vectorise3_kernel<{K}>", {}) or agg.get(f"vectorise4_kernel<{K}> (round 6: a wavefront per sequence, k = 4 / 5)", {})
 if js and "FETCH_SIZE" in k3 and "WRITE_SIZE" in k3:
     f, w = sum(k3["FETCH_SIZE"]) / len(k3["FETCH_SIZE"]), sum(k3["WRITE_SIZE"]) / len(k3["WRITE_SIZE"])
     alg = 100000 * (2500 + 4 * 4 ** K * 4) / 1e9
-    json.dump({"kernel": f"vectorise3_kernel<{K}>", "workload": f"cfg2's input: 100000 x 10000 bp, k={K}, 4 views, device-drawn edits (tools/ablate_vectorise.py 0)",
+    json.dump({"kernel": f"vectorise3_kernel<{K}>" if K >= 6 else f"vectorise4_kernel<{K}>", "workload": f"cfg2's input: 100000 x 10000 bp, k={K}, 4 views, device-drawn edits (tools/ablate_vectorise.py 0)",
                "algorithmic_gb_per_launch": round(alg, 4),
                "WRITE_SIZE_KB": w, "FETCH_SIZE_KB": f,
                "traffic_gb_per_launch": round((w + 2 * f) * 1024 / 1e9, 3),

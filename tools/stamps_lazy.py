@@ -25,9 +25,9 @@ def main():
     posthoc.hdbscan_device(x, n // 100 + 1, stats=stats)
     _lib.check(_lib.lib.idl_debug_lazy_phases(ctypes.cast(out, ctypes.c_void_p)))
     o = np.array(list(out), dtype=np.float64).reshape(3, 12)
-    multi = int(os.environ.get("IDELUCS_MST_MULTI", "0") or 0) >= 2
+    multi = False        # (the multi-node and fold variants of the lazy step left the library in round 6)
     names = ["run flags", "trip 2 answered", "decided", "node + boxes + ball", "bounds, queue", "exact distances", "candidate left"]
-    fold = int(os.environ.get("IDELUCS_MST_FOLD", "0") or 0) >= 1 and not multi
+    fold = False
     if fold:
         names = ["trip 1", "trip 2 answered", "chain's candidates", "coordinates, how many go", "boxes, recorded, balls", "floor, bounds, exact, applied", "record left"]
     if multi:       # lazy_multi_kernel (kinds 0, 1) and lazy_reduce_kernel (kind 2) have marks of their own

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Diagnostic: phase marks inside the four middle kernels of the training step (workgroups 0..63), in microseconds from the
-kernel's first workgroup start.   IDELUCS_STAMPS=1 python tools/stamps_mid.py"""
+kernel's first workgroup start.   IDELUCS_DEV=stamps=1 python tools/stamps_mid.py"""
 import os, sys, ctypes
-os.environ["IDELUCS_STAMPS"] = "1"
+os.environ["IDELUCS_DEV"] = ",".join(x for x in (os.environ.get("IDELUCS_DEV", ""), "stamps=1") if x)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from idelucs_amd import _lib, utils as U, models

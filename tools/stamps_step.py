@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Diagnostic: where and when the workgroups of the optimizer launch (dW1 tiles + the rest) run.
-   IDELUCS_STAMPS=1 python tools/stamps_step.py"""
+   IDELUCS_DEV=stamps=1 python tools/stamps_step.py"""
 import os, sys, ctypes
-os.environ["IDELUCS_STAMPS"] = "1"
+os.environ["IDELUCS_DEV"] = ",".join(x for x in (os.environ.get("IDELUCS_DEV", ""), "stamps=1") if x)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from idelucs_amd import _lib, utils as U, models

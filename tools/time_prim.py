@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Prim's stage of posthoc.hdbscan_device alone, on planted blobs or tight clusters in 64 dimensions, with the launch statistics of
-the lazy form:   python tools/time_prim.py [--n 1000000] [--tight]      (IDELUCS_MST_MULTI=1: one node per launch)"""
+the lazy form:   python tools/time_prim.py [--n 1000000] [--tight]"""
 import argparse
 import os
 import sys

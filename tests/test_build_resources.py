@@ -115,3 +115,82 @@ def test_the_weight_gradient_operand_sets_are_out_of_the_compilers_sight(tmp_pat
         assert set(seen) == set(kernels), (fn, seen)
         for k, (reads, mfmas) in seen.items():
             assert reads == 5 * 12 and mfmas == 4 * 6, (k, reads, mfmas)
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="no hipcc")
+def test_no_lds_read_leaves_a_hand_scheduled_k_step_in_flight(tmp_path):
+    """VERDICT r5 #4a.  The rule of the hand-scheduled K-steps (l1_planes_device.h: L1P_STEP, wgrad_planes_device.h: WGD_STEP_*): a step is ONE asm statement from
+    its first MFMA to the `s_waitcnt lgkmcnt(0)` that retires the LDS reads issued inside it, so no register is in flight at any point the compiler schedules
+    around.  Read off the ISA by BASIC BLOCK (labels and branches cut them): in every block that holds an fp16 MFMA, LDS operations retire in order (`s_waitcnt
+    lgkmcnt(N)` leaves the last N outstanding); no instruction touches the destination of a read that is still out, and no such block ends with a read outstanding."""
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    reg = re.compile(r"\bv(\d+)\b|v\[(\d+):(\d+)\]")
+
+    def regs(text):
+        out = set()
+        for m in reg.finditer(text):
+            if m.group(1) is not None:
+                out.add(int(m.group(1)))
+            else:
+                out.update(range(int(m.group(2)), int(m.group(3)) + 1))
+        return out
+
+    for fn, kernels in (("planes.hip", ["l1_planes_kernel"]), ("train_step.hip", ["l1_planes_batched_kernel", "wgrad_dplanes_rms_kernel", "wgrad_xplanes_rms_batched_kernel"]),
+                        ("wgrad_planes.hip", ["wgrad_dplanes_kernel"])):
+        src = os.path.join(ROOT, "idelucs_amd", "csrc", fn)
+        out = tmp_path / (fn + ".s")
+        r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-S", src, "-o", str(out)],
+                           capture_output=True, text=True, cwd=os.path.dirname(src))
+        assert r.returncode == 0, r.stderr[-2000:]
+        # basic blocks of the kernels
+        blocks, cur, blk = {}, None, None
+        for no, line in enumerate(open(out).read().split("\n")):
+            m = re.match(r"^(_Z\w+):", line)
+            if m:
+                cur = next((k for k in kernels if k + "E" in m.group(1)), None)
+                blk = []
+                if cur is not None:
+                    blocks.setdefault(cur, []).append(blk)
+                continue
+            if line.startswith(".Lfunc_end"):
+                cur = None
+            if cur is None:
+                continue
+            if re.match(r"^\.LBB\w+:", line):
+                blk = []
+                blocks[cur].append(blk)
+                continue
+            ins = line.split(";")[0].strip()
+            if not ins or ins.startswith("."):
+                continue
+            blk.append((no + 1, ins))
+            if ins.startswith(("s_cbranch", "s_branch", "s_endpgm", "s_setpc")):
+                blk = []
+                blocks[cur].append(blk)
+        assert set(blocks) == set(kernels), (fn, sorted(blocks))
+        for k, bl in blocks.items():
+            checked = 0
+            for b in bl:
+                if not any(i.startswith("v_mfma_f32_32x32x16_f16") for _, i in b):
+                    continue
+                fifo = []            # LDS operations outstanding, oldest first: the destination registers of a read, an empty set for a write / atomic
+                for no, ins in b:
+                    ops = ins.split(None, 1)
+                    args = [a_.strip() for a_ in ops[1].split(",")] if len(ops) > 1 else []
+                    flying = set().union(*fifo) if fifo else set()
+                    if ops[0].startswith("ds_read"):
+                        assert not (regs(args[1]) & flying), (k, no, ins)
+                        fifo.append(regs(args[0]))
+                        checked += 1
+                    elif ops[0].startswith("ds_"):
+                        assert not (regs(ins) & flying), (k, no, ins)
+                        fifo.append(set())
+                    elif ops[0] == "s_waitcnt":
+                        m = re.search(r"lgkmcnt\((\d+)\)", ins)
+                        if m:
+                            n = int(m.group(1))
+                            fifo = fifo[len(fifo) - n:] if n and n < len(fifo) else ([] if n == 0 else fifo)
+                    else:
+                        assert not (regs(ins) & flying), "%s: `%s` touches a register an LDS read has in flight (line %d of %s)" % (k, ins, no, out)
+                assert not any(fifo), "%s: a block with fp16 MFMAs ends with LDS reads outstanding (line %d of %s)" % (k, b[-1][0], out)
+            assert checked >= 24, (k, checked)

@@ -152,9 +152,8 @@ constexpr int MID_GATHER_ROWS = 4;   // rows per 256-thread gather tile when the
 
 // PRE: the layer-1 product came from idl_l1_fwd (l1_fwd.hip), whose epilogue already applied bias / ReLU / Dropout and formed
 // lat = r1 W2^T as 8 partial sums: `a1` then points at lat_part[8][m][64] and this kernel is the head only.
-// KPARTS (with TIN): the layer-1 product came from idl_l1_planes* as KPARTS partial sums over K slices, a1 = part[KPARTS][512][m]: added up
-// here in ascending order (the same sum wherever it runs); r1 is written over part[0], which the backward then reads as the activations.
-template <bool TIN, bool PRE = false, int KPARTS = 1>       // TIN: a1 is stored transposed, [512, m] (the orientation hipBLASLt runs the layer-1 product fastest in)
+// (Round 5's variant that added idl_l1_planes' eight K-slice partial sums up HERE -- 16 MB read by 64 workgroups: +8 us -- left in round 6: idl_reduce_parts_rms does it on every CU.)
+template <bool TIN, bool PRE = false>       // TIN: a1 is stored transposed, [512, m] (the orientation hipBLASLt runs the layer-1 product fastest in)
 __device__ __forceinline__ void mid_fwd_body(float *__restrict__ a1, const float *__restrict__ b1, const float *__restrict__ W2,
                                                                   const float *__restrict__ b2, const float *__restrict__ W3,
                                                                   const float *__restrict__ b3, int m, int C, int train, uint64_t seed,
@@ -190,11 +189,7 @@ __device__ __forceinline__ void mid_fwd_body(float *__restrict__ a1, const float
             bw[ct][0] = wsrc[0]; bw[ct][1] = wsrc[1];
         }
     };
-    // KPARTS > 1: a lane's 8 elements are KPARTS x 8 four-byte reads, and the launch has 128 registers a lane (1024-thread workgroups): the
-    // first trip brings slabs 0 .. KP1 with everything small, the second the rest of the slabs with the W2 fragments (32 registers)
-    constexpr int KP1 = KPARTS > 1 ? (KPARTS > 6 ? 5 : KPARTS - 1) : 0;
-    const int64_t slab = (int64_t)H1 * m;
-    float t8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, u8[KP1 > 0 ? KP1 : 1][8];
+    float t8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float pre[8];                                // PRE: row r0 + wv's eight partial sums of lat, column `lane`
     if constexpr (PRE) {
 #pragma unroll
@@ -203,19 +198,12 @@ __device__ __forceinline__ void mid_fwd_body(float *__restrict__ a1, const float
         if (TIN) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) t8[i] = srcT[(int64_t)i * m];
-            if constexpr (KPARTS > 1) {
-#pragma unroll
-                for (int p = 0; p < KP1; ++p)
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) u8[p][i] = srcT[(1 + p) * slab + (int64_t)i * m];
-            } else {
-                av[0] = make_float4(t8[0], t8[1], t8[2], t8[3]); av[1] = make_float4(t8[4], t8[5], t8[6], t8[7]);
-            }
+            av[0] = make_float4(t8[0], t8[1], t8[2], t8[3]); av[1] = make_float4(t8[4], t8[5], t8[6], t8[7]);
         } else {
             av[0] = src[0]; av[1] = src[1];
         }
         if (b1 != nullptr) { bb[0] = *(const float4 *)(b1 + k0); bb[1] = *(const float4 *)(b1 + k0 + 4); }
-        if constexpr (KPARTS == 1) load_bw();
+        load_bw();
     }
     const int nct = (C + 15) / 16;               // column tiles of the logits; wave wv < nct owns tile wv
     float4 w3f[4];                               // B[k = 16 q + s][c = l] = W3[16 wv + l][16 q + s]
@@ -229,26 +217,6 @@ __device__ __forceinline__ void mid_fwd_body(float *__restrict__ a1, const float
     }
     const float b2v = b2[lane];
     const uint32_t step = (uint32_t)ctl[0];
-    if constexpr (!PRE && TIN && KPARTS > 1) {   // the second trip (slabs in ascending order: the same sum wherever it runs)
-#pragma unroll
-        for (int p = 0; p < KP1; ++p)
-#pragma unroll
-            for (int i = 0; i < 8; ++i) t8[i] += u8[p][i];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(t8[i]) : : "memory");      // (the requests below stay below)
-        constexpr int KP2 = KPARTS - 1 - KP1;
-        float v8[KP2 > 0 ? KP2 : 1][8];
-#pragma unroll
-        for (int p = 0; p < KP2; ++p)
-#pragma unroll
-            for (int i = 0; i < 8; ++i) v8[p][i] = srcT[(1 + KP1 + p) * slab + (int64_t)i * m];
-        load_bw();
-#pragma unroll
-        for (int p = 0; p < KP2; ++p)
-#pragma unroll
-            for (int i = 0; i < 8; ++i) t8[i] += v8[p][i];
-        av[0] = make_float4(t8[0], t8[1], t8[2], t8[3]); av[1] = make_float4(t8[4], t8[5], t8[6], t8[7]);
-    }
     if constexpr (!PRE) {
     // ---- ReLU + Dropout of layer 1, in place
     float a[8];
@@ -364,7 +332,7 @@ struct MidFwdParams {
 };
 static_assert(sizeof(MidFwdParams) + idl::PLAN_PARAMS <= idl::PLAN_BYTES, "MidFwdParams does not fit a plan record");
 
-template <bool TIN, bool PRE = false, int KPARTS = 1>
+template <bool TIN, bool PRE = false>
 __global__ __launch_bounds__(64 * MID_WAVES) void mid_fwd_kernel(float *__restrict__ a1, const float *__restrict__ b1, const float *__restrict__ W2,
                                                                   const float *__restrict__ b2, const float *__restrict__ W3,
                                                                   const float *__restrict__ b3, int m, int C, int train, uint64_t seed,
@@ -372,7 +340,7 @@ __global__ __launch_bounds__(64 * MID_WAVES) void mid_fwd_kernel(float *__restri
                                                                   float *__restrict__ inv, float *__restrict__ r2, float *__restrict__ z,
                                                                   int n_rows_wg, int tile0, int tile1, idl_dev::GatherArgs gth)
 {
-    mid_fwd_body<TIN, PRE, KPARTS>(a1, b1, W2, b2, W3, b3, m, C, train, seed, ctl, f, inv, r2, z, n_rows_wg, tile0, tile1, gth, (int)blockIdx.x);
+    mid_fwd_body<TIN, PRE>(a1, b1, W2, b2, W3, b3, m, C, train, seed, ctl, f, inv, r2, z, n_rows_wg, tile0, tile1, gth, (int)blockIdx.x);
 }
 
 // the same for several voters in one launch: the grid is (voters, workgroups of one voter) -- the VOTER index runs fastest, so the
@@ -1446,8 +1414,8 @@ static int mid_fwd_gather_impl(float *a1, const float *b1, int a1_transposed, co
     IDL_REQUIRE((((uintptr_t)a1 | (uintptr_t)W2 | (uintptr_t)W3) & 15u) == 0, "a1 / W2 / W3 must be 16-byte aligned");
     IDL_REQUIRE(parts >= 1 && part >= 0 && part <= part_end && part_end <= parts, "mid_fwd_gather: need 0 <= part <= part_end <= parts");
     IDL_REQUIRE(b1 == nullptr || (((uintptr_t)b1) & 15u) == 0, "mid_fwd_gather: b1 must be 16-byte aligned");
-    IDL_REQUIRE(a1_transposed >= 0 && a1_transposed <= 3 && (a1_transposed != 2 || b1 == nullptr),
-                "mid_fwd_gather: a1_transposed is 0, 1, 2 (a1 = idl_l1_fwd's lat partials, no b1) or 3 (a1 = idl_l1_planes' K-slice partial sums [8][512][m])");
+    IDL_REQUIRE(a1_transposed >= 0 && a1_transposed <= 2 && (a1_transposed != 2 || b1 == nullptr),
+                "mid_fwd_gather: a1_transposed is 0, 1 or 2 (a1 = idl_l1_fwd's lat partials, no b1)");
     IDL_REQUIRE((yh != nullptr) == (yl != nullptr) && (yh == nullptr || (feats != nullptr && ((((uintptr_t)yh) | ((uintptr_t)yl)) & 7u) == 0)),
                 "mid_fwd_gather: both planes of the next batch (8-byte aligned) or neither; planes need the batch assembly");
     idl_dev::GatherArgs g{};
@@ -1461,7 +1429,6 @@ static int mid_fwd_gather_impl(float *a1, const float *b1, int a1_transposed, co
     }
     const dim3 grid((unsigned)(m / 16 + (t1 - t0 + 3) / 4));
     if (void *plan = idl::take_plan()) {          // recorded, not launched (idl_plan_begin)
-        IDL_REQUIRE(a1_transposed != 3, "mid_fwd_gather: the partial-sum form cannot be recorded");
         idl::PlanHead h{};
         h.kind = idl::PLAN_MID_FWD; h.variant = a1_transposed; /* 0 row-major, 1 transposed, 2 lat partials (head only) */ h.grid[0] = grid.x; h.grid[1] = 1; h.grid[2] = 1; h.block = 64 * MID_WAVES;
         memcpy(plan, &h, sizeof(h));
@@ -1469,9 +1436,7 @@ static int mid_fwd_gather_impl(float *a1, const float *b1, int a1_transposed, co
         memcpy((unsigned char *)plan + idl::PLAN_PARAMS, &p, sizeof(p));
         return IDL_OK;
     }
-    if (a1_transposed == 3) hipLaunchKernelGGL((mid_fwd_kernel<true, false, l1p_dev::KSPLIT>), grid, dim3(64 * MID_WAVES), 0, (hipStream_t)stream, a1, b1, W2, b2, W3, b3,
-                                               m, C, train, seed, ctl, f, inv, r2, z, m / 16, (int)t0, (int)t1, g);
-    else if (a1_transposed == 2) hipLaunchKernelGGL((mid_fwd_kernel<false, true>), grid, dim3(64 * MID_WAVES), 0, (hipStream_t)stream, a1, b1, W2, b2, W3, b3,
+    if (a1_transposed == 2) hipLaunchKernelGGL((mid_fwd_kernel<false, true>), grid, dim3(64 * MID_WAVES), 0, (hipStream_t)stream, a1, b1, W2, b2, W3, b3,
                                                m, C, train, seed, ctl, f, inv, r2, z, m / 16, (int)t0, (int)t1, g);
     else if (a1_transposed) hipLaunchKernelGGL(mid_fwd_kernel<true>, grid, dim3(64 * MID_WAVES), 0, (hipStream_t)stream, a1, b1, W2, b2, W3, b3,
                                           m, C, train, seed, ctl, f, inv, r2, z, m / 16, (int)t0, (int)t1, g);

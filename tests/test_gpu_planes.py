@@ -85,44 +85,6 @@ def test_layer1_product_from_planes_is_closer_to_float64_than_the_fp32_gemm(dev,
     assert L.idl_l1_planes(_p(wh), _p(wl), F, _p(xh), _p(xl), F, m + 1, H, F, _p(part), _stream()) != 0
 
 
-@pytest.mark.parametrize("m,C,train", [(1024, 20, 1), (128, 5, 0)])
-def test_mid_forward_adds_the_partial_sums_in_order(dev, m, C, train):
-    """idl_mid_fwd_gather with a1_transposed = 3 on part[8][512][m] gives bit for bit what a1_transposed = 1 gives on the slabs added in
-    ascending order, and leaves the same activations in slab 0."""
-    import torch
-    from idelucs_amd import _lib
-    L = _lib.lib
-    g = torch.Generator(device="cpu"); g.manual_seed(9)
-    H1, H2 = 512, 64
-    part = (torch.randn(8, H1, m, generator=g) * 0.3).to(dev)
-    summed = part[0].clone()
-    for p in range(1, 8):
-        summed += part[p]
-    b1 = (torch.randn(H1, generator=g) * 0.1).to(dev)
-    W2 = (torch.randn(H2, H1, generator=g) / H1 ** 0.5).to(dev); b2 = (torch.randn(H2, generator=g) * 0.1).to(dev)
-    W3 = (torch.randn(C, H2, generator=g) / 8).to(dev); b3 = (torch.randn(C, generator=g) * 0.1).to(dev)
-    ctl = torch.tensor([7, 0], dtype=torch.int64, device=dev)
-    outs = []
-    for variant, buf in ((1, summed), (3, part)):
-        f = torch.empty(m, H2, device=dev); inv = torch.empty(m, device=dev); r2 = torch.empty(m, H2, device=dev); z = torch.empty(m, C, device=dev)
-        _lib.check(L.idl_mid_fwd_gather(_p(buf), _p(b1), variant, _p(W2), _p(b2), _p(W3), _p(b3), m, C, train, ctypes.c_uint64(11), _p(ctl),
-                                        _p(f), _p(inv), _p(r2), _p(z), None, 0, 0, 0, None, None, 0, 0, 0, None, None, None, None, 0, 0, 1, _stream()))
-        torch.cuda.synchronize()
-        outs.append((f, inv, r2, z, buf[0].clone() if variant == 3 else buf.clone()))
-    for a, b in zip(*outs):
-        assert torch.equal(a, b)
-    # the launch that adds the slabs up on every CU (idl_reduce_parts_rms without a tail): the same sums in slab 0, the other slabs untouched
-    part2 = (torch.randn(8, H1, m, generator=g) * 0.3).to(dev)
-    want = part2[0].clone()
-    for p in range(1, 8):
-        want += part2[p]
-    keep = part2[1:].clone()
-    _lib.check(L.idl_reduce_parts_rms(_p(part2), H1 * m, None, None, 0, None, None, None, None, None, None, None, None, 0, 0.0, 0.0, None, 0,
-                                      -1, None, None, 0, 0, 0, 0, None, 0, _stream()))
-    torch.cuda.synchronize()
-    assert torch.equal(part2[0], want) and torch.equal(part2[1:], keep)
-
-
 def test_producers_write_the_planes_of_what_they_write(dev):
     """The dW1 tiles' epilogue (idl_wgrad_rmsprop_planes) leaves W1 exactly as idl_wgrad_rmsprop does, with planes that are idl_split_planes of
     it; the batch-assembling workgroups of idl_mid_*_gather_planes leave the batch idl_gather_pairs_at assembles, with its planes."""
@@ -161,7 +123,7 @@ def test_producers_write_the_planes_of_what_they_write(dev):
     W3 = (torch.randn(C, H2, generator=g) / 8).to(dev); b3 = torch.zeros(C, device=dev)
     ctl = torch.zeros(2, dtype=torch.int64, device=dev)
     f = torch.empty(mm, H2, device=dev); inv = torch.empty(mm, device=dev); r2 = torch.empty(mm, H2, device=dev); z = torch.empty(mm, C, device=dev)
-    _lib.check(L.idl_mid_fwd_gather_planes(_p(a1), _p(b1), 3, _p(W2), _p(b2), _p(W3), _p(b3), mm, C, 1, ctypes.c_uint64(3), _p(ctl), _p(f), _p(inv), _p(r2), _p(z),
+    _lib.check(L.idl_mid_fwd_gather_planes(_p(a1), _p(b1), 1, _p(W2), _p(b2), _p(W3), _p(b3), mm, C, 1, ctypes.c_uint64(3), _p(ctl), _p(f), _p(inv), _p(r2), _p(z),
                                            _p(feats), n, F, n * F, _p(perm), _p(base), 0, 2 * n, B, _p(mean), _p(scale), _p(inv_scale),
                                            _p(y), _p(yh), _p(yl), _p(xflag), 0, 3, 8, _stream()))
     G = torch.randn(1, mm, H2, generator=g).to(dev) * 1e-2; dP0 = torch.randn(C, C, generator=g).to(dev) * 1e-2
@@ -228,7 +190,7 @@ def test_producers_write_the_planes_of_what_they_write(dev):
     # a column whose originals barely vary: the standardised entries leave the planes' range, are clamped there, and the flag says so
     scale2 = scale.clone(); scale2[7] = 1e-9
     inv2 = 1.0 / scale2
-    _lib.check(L.idl_mid_fwd_gather_planes(_p(a1), _p(b1), 3, _p(W2), _p(b2), _p(W3), _p(b3), mm, C, 1, ctypes.c_uint64(3), _p(ctl), _p(f), _p(inv), _p(r2), _p(z),
+    _lib.check(L.idl_mid_fwd_gather_planes(_p(a1), _p(b1), 1, _p(W2), _p(b2), _p(W3), _p(b3), mm, C, 1, ctypes.c_uint64(3), _p(ctl), _p(f), _p(inv), _p(r2), _p(z),
                                            _p(feats), n, F, n * F, _p(perm), _p(base), 0, 2 * n, B, _p(mean), _p(scale2), _p(inv2),
                                            None, _p(yh), _p(yl), _p(xflag), 0, 8, 8, _stream()))
     torch.cuda.synchronize()

@@ -85,10 +85,7 @@ SIGNATURES = {
     "idl_wgrad_supported": (_int, [_int, _int, _int]),
     "idl_wgrad_rmsprop": (_int, [_vp, _vp, _int, _int, _int, _vp, _vp, _vp, _vp, _vp]),
     "idl_l1_fwd_supported": (_int, [_int, _int, _int]),
-    "idl_l1_fwd_parts": (_int, []),
-    "idl_l1_fwd": (_int, [_vp, _vp, _vp, _vp, _int, _int, _int, _c.c_uint64, _vp, _vp, _int, _vp, _vp]),
-    "idl_l1_fwd_gather": (_int, [_vp, _vp, _vp, _vp, _int, _int, _int, _c.c_uint64, _vp, _vp, _int, _vp,
-                                 _vp, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _int, _int, _int, _vp]),
+    "idl_l1_fwd": (_int, [_vp, _vp, _int, _int, _vp, _vp]),
     "idl_debug_wgrad_clock": (_int, [_vp, _vp, _int, _int, _int, _vp, _int, _vp, _vp]),
     "idl_rmsprop_step_gather_wgrad": (_int, [_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _c.c_float, _c.c_float, _vp,
                                              _vp, _i64, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _vp, _vp,

@@ -38,7 +38,6 @@ static_assert(sizeof(PlanHead) <= PLAN_PARAMS, "plan header does not fit");
 void *take_plan();
 // the batched launches of the other translation units
 int nce_plan_launch(const PlanHead &h, const void *dev_plans, int n_voters, hipStream_t stream);
-int l1_plan_launch(const PlanHead &h, const void *dev_plans, int n_voters, hipStream_t stream);
 
 }  // namespace idl
 

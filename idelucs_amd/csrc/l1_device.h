@@ -22,23 +22,15 @@ constexpr int NP = 4;                      // loader waves (24 DMA instructions 
 constexpr int THREADS = 256 + 64 * NP;
 static_assert(16 % NP == 0 && 8 % NP == 0, "a loader takes whole instructions of A and of B");
 
+// (Round 4's form with bias / ReLU / Dropout / the K-split of Linear(512, 64) in these tiles' epilogue and batch-assembly riders behind them -- measured 114.7 us a
+//  step against 111.8, kept opt-in for two rounds -- left the library in round 6: the tiles are the fp32 form's plain product a1^T = W1 x^T.)
 struct L1Args {
     const float *W1, *x;        // [512, K], [m, K]
-    const float *b1, *W2;       // [512], [64, 512]
-    float *r1;                  // Dropout(ReLU(W1 x^T + b1)): [512, m] (r1_transposed) or [m, 512]
-    float *lat_part;            // [8][m][64]
-    const int64_t *ctl;         // ctl[0]: the step counter (dropout stream)
-    uint64_t seed;
-    int m, K, train, r1_transposed;
-    // riders: workgroups behind the tiles assemble tiles [tile0, tile1) of the NEXT batch (idl_dev::gather_tile: 4 rows x 1024 columns
-    // each) -- HBM is idle while the tiles stream their operands out of L2, and a rider (4 streaming waves, no LDS use) fits beside
-    // a tile workgroup on every CU
-    int n_tiles, tile0, tile1;
-    idl_dev::GatherArgs gth;
-    int prio;                   // > 0: the computing waves raise their priority to it (riders of another kind share the CU: train_step.hip's l1_rms_kernel)
+    float *r1;                  // a1^T = W1 x^T: [512, m]
+    int m, K;
+    int n_tiles;
+    int prio;                   // > 0: the computing waves raise their priority to it (riders share the CU: train_step.hip's l1_rms_kernel)
 };
-constexpr int RIDER_ROWS = 4;              // == train_step.hip's MID_GATHER_ROWS: the shares of a batch are counted in these tiles
-constexpr int RIDER_TILES = 4;             // gather tiles per rider workgroup (two per 256 threads, one after the other)
 
 // LDS-DMA: 64 lanes x 16 bytes -> LDS bytes [lds_byte, lds_byte + 1024), lane-linear; source = sbase + voff (per lane)
 __device__ __forceinline__ void dma16(uint32_t voff, const void *sbase, uint32_t lds_byte)
@@ -69,16 +61,11 @@ __device__ __forceinline__ void mma_step(const Frag &f, f32x4_t &c0, f32x4_t &c1
 
 // DBG (a diagnostic, IDELUCS_DEV=l1_debug, wrong results): 1 = no DMA inside the main loop (barriers stay); 2 = no barrier and no DMA inside
 // the main loop; 3 = as 2 and no LDS reads either (the MFMA stream alone)
-template <bool EPILOGUE, int DBG = 0>
+template <int DBG = 0>
 __device__ __forceinline__ void l1_fwd_body(const L1Args &a, const int bid_in, unsigned char *smem)
 {
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    if (bid_in >= a.n_tiles) {               // a rider
-        const int first = a.tile0 + (bid_in - a.n_tiles) * RIDER_TILES + (tid >> 8) * (RIDER_TILES / 2);
-#pragma unroll 1
-        for (int t = first; t < first + RIDER_TILES / 2 && t < a.tile1; ++t) idl_dev::gather_tile<RIDER_ROWS>(a.gth, (int64_t)t, tid & 255);
-        return;
-    }
+    if (bid_in >= a.n_tiles) return;
     const int l = lane & 15, q = lane >> 4, wh = (wv >> 1) & 1, wr = wv & 1;
     // ---- tile of this workgroup.  Workgroups go to the 8 XCDs round-robin: the 32 of an XCD take 4 h-tiles x (n_rt / 4) row-tiles, so
     // an XCD's L2 streams 256 rows of W1 and m / 4 rows of x (8 MB at cfg2, all 32 tiles in K-lockstep) instead of all 24 MB
@@ -135,20 +122,6 @@ __device__ __forceinline__ void l1_fwd_body(const L1Args &a, const int bid_in, u
     if (a.prio == 1) __builtin_amdgcn_s_setprio(1);
     else if (a.prio == 2) __builtin_amdgcn_s_setprio(2);
     else if (a.prio >= 3) __builtin_amdgcn_s_setprio(3);
-    // ---- things the epilogue needs, requested before the loop
-    f32x4_t bias[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-    f32x4_t w2f[4][2];
-    uint32_t step = 0;
-    if (EPILOGUE) {
-#pragma unroll
-        for (int hb = 0; hb < 2; ++hb) {
-            const int hb0 = h0 + 32 * wh + 16 * hb + 4 * q;
-            bias[hb] = *(const f32x4_t *)(a.b1 + hb0);
-#pragma unroll
-            for (int cb = 0; cb < 4; ++cb) w2f[cb][hb] = *(const f32x4_t *)(a.W2 + (int64_t)(16 * cb + l) * H1 + hb0);
-        }
-        step = (uint32_t)a.ctl[0];
-    }
     // ---- fragment reads: row 32 wh + 16 hb + l of A, row 16 wr + l of B; slot (4 t + q) ^ l.  fp32 MFMA holds the SIMD's vector issue
     // for its whole 32 cycles, so every VALU instruction between two MFMAs is a bubble in the matrix pipe (this loop's second
     // form computed its LDS addresses per step: 5 v_add + 3 ds_read cost 72 cycles per 256-cycle step, 38.1 us against the MFMA
@@ -213,61 +186,13 @@ __device__ __forceinline__ void l1_fwd_body(const L1Args &a, const int bid_in, u
             if (c == nc) break;
         }
     }
-    if (!EPILOGUE) {                                         // the bare product (tools/bench_l1_fwd.py): a1^T = W1 x^T, no bias
-#pragma unroll
-        for (int hb = 0; hb < 2; ++hb) {
-            const f32x4_t v = hb ? c1 : c0;
-            const int hb0 = h0 + 32 * wh + 16 * hb + 4 * q, r = r0 + 16 * wr + l;
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) a.r1[(int64_t)(hb0 + reg) * a.m + r] = v[reg];
-        }
-        return;
-    }
-    // ---- epilogue: bias, ReLU, Dropout; r1 to memory; this tile's share of lat
-    const int r = r0 + 16 * wr + l;
-    f32x4_t v[2] = {c0, c1};
-    f32x4_t lat[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    // a1^T = W1 x^T, no bias (the mid-forward launch adds it)
 #pragma unroll
     for (int hb = 0; hb < 2; ++hb) {
-        const int hb0 = h0 + 32 * wh + 16 * hb + 4 * q;
-        float s[4] = {1.f, 1.f, 1.f, 1.f};
-        if (a.train) {
-            const int64_t idx4 = ((int64_t)r * H1 + hb0) >> 2;
-            const idl_dev::U4 p = idl_dev::philox((uint32_t)idx4, 1u, step, (uint32_t)(idx4 >> 32), (uint32_t)a.seed, (uint32_t)(a.seed >> 32));
-            s[0] = (p.x >> 31) ? 2.f : 0.f; s[1] = (p.y >> 31) ? 2.f : 0.f; s[2] = (p.z >> 31) ? 2.f : 0.f; s[3] = (p.w >> 31) ? 2.f : 0.f;
-        }
+        const f32x4_t v = hb ? c1 : c0;
+        const int hb0 = h0 + 32 * wh + 16 * hb + 4 * q, r = r0 + 16 * wr + l;
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-            const float t = v[hb][reg] + bias[hb][reg];
-            v[hb][reg] = t > 0.f ? t * s[reg] : 0.f;
-        }
-        if (a.r1_transposed) {
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) a.r1[(int64_t)(hb0 + reg) * a.m + r] = v[hb][reg];
-        } else *(f32x4_t *)(a.r1 + (int64_t)r * H1 + hb0) = v[hb];
-#pragma unroll
-        for (int cb = 0; cb < 4; ++cb)
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg)
-                lat[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[hb][reg], w2f[cb][hb][reg], lat[cb], 0, 0, 0);
-    }
-    // the two halves of the tile's hidden units (wh) are added through LDS (the stages are dead: every wave is past its last read)
-    __syncthreads();
-    float *red = (float *)smem;                              // [wr][16 values][64 lanes]
-    if (wh == 1) {
-#pragma unroll
-        for (int cb = 0; cb < 4; ++cb)
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) red[(wr * 16 + cb * 4 + reg) * 64 + lane] = lat[cb][reg];
-    }
-    __syncthreads();
-    if (wh == 0) {
-        float *dst = a.lat_part + ((int64_t)ht * a.m + r0 + 16 * wr) * H2;
-#pragma unroll
-        for (int cb = 0; cb < 4; ++cb)
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg)      // C/D layout: row 4 q + reg (batch row), column l (latent unit 16 cb + l)
-                dst[(4 * q + reg) * H2 + 16 * cb + l] = lat[cb][reg] + red[(wr * 16 + cb * 4 + reg) * 64 + lane];
+        for (int reg = 0; reg < 4; ++reg) a.r1[(int64_t)(hb0 + reg) * a.m + r] = v[reg];
     }
 }
 

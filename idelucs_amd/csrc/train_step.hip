@@ -150,10 +150,8 @@ constexpr int H1 = 512;
 constexpr int MID_WAVES = 16;
 constexpr int MID_GATHER_ROWS = 4;   // rows per 256-thread gather tile when the batch assembly rides in mid_fwd / mid_bwd
 
-// PRE: the layer-1 product came from idl_l1_fwd (l1_fwd.hip), whose epilogue already applied bias / ReLU / Dropout and formed
-// lat = r1 W2^T as 8 partial sums: `a1` then points at lat_part[8][m][64] and this kernel is the head only.
 // (Round 5's variant that added idl_l1_planes' eight K-slice partial sums up HERE -- 16 MB read by 64 workgroups: +8 us -- left in round 6: idl_reduce_parts_rms does it on every CU.)
-template <bool TIN, bool PRE = false>       // TIN: a1 is stored transposed, [512, m] (the orientation hipBLASLt runs the layer-1 product fastest in)
+template <bool TIN>       // TIN: a1 is stored transposed, [512, m] (the orientation hipBLASLt runs the layer-1 product fastest in)
 __device__ __forceinline__ void mid_fwd_body(float *__restrict__ a1, const float *__restrict__ b1, const float *__restrict__ W2,
                                                                   const float *__restrict__ b2, const float *__restrict__ W3,
                                                                   const float *__restrict__ b3, int m, int C, int train, uint64_t seed,
@@ -190,21 +188,15 @@ __device__ __forceinline__ void mid_fwd_body(float *__restrict__ a1, const float
         }
     };
     float t8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    float pre[8];                                // PRE: row r0 + wv's eight partial sums of lat, column `lane`
-    if constexpr (PRE) {
+    if (TIN) {
 #pragma unroll
-        for (int p = 0; p < 8; ++p) pre[p] = a1[((int64_t)p * m + r0 + wv) * H2 + lane];
+        for (int i = 0; i < 8; ++i) t8[i] = srcT[(int64_t)i * m];
+        av[0] = make_float4(t8[0], t8[1], t8[2], t8[3]); av[1] = make_float4(t8[4], t8[5], t8[6], t8[7]);
     } else {
-        if (TIN) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) t8[i] = srcT[(int64_t)i * m];
-            av[0] = make_float4(t8[0], t8[1], t8[2], t8[3]); av[1] = make_float4(t8[4], t8[5], t8[6], t8[7]);
-        } else {
-            av[0] = src[0]; av[1] = src[1];
-        }
-        if (b1 != nullptr) { bb[0] = *(const float4 *)(b1 + k0); bb[1] = *(const float4 *)(b1 + k0 + 4); }
-        load_bw();
+        av[0] = src[0]; av[1] = src[1];
     }
+    if (b1 != nullptr) { bb[0] = *(const float4 *)(b1 + k0); bb[1] = *(const float4 *)(b1 + k0 + 4); }
+    load_bw();
     const int nct = (C + 15) / 16;               // column tiles of the logits; wave wv < nct owns tile wv
     float4 w3f[4];                               // B[k = 16 q + s][c = l] = W3[16 wv + l][16 q + s]
     float b3v = 0.f;
@@ -217,7 +209,7 @@ __device__ __forceinline__ void mid_fwd_body(float *__restrict__ a1, const float
     }
     const float b2v = b2[lane];
     const uint32_t step = (uint32_t)ctl[0];
-    if constexpr (!PRE) {
+    {
     // ---- ReLU + Dropout of layer 1, in place
     float a[8];
 #pragma unroll
@@ -260,13 +252,8 @@ __device__ __forceinline__ void mid_fwd_body(float *__restrict__ a1, const float
     // ---- wave wv owns row wv of the tile: add the 16 K-slices and the bias; normalise; ReLU + Dropout of the latent
     const int row = r0 + wv, cs = (lane + 16 * (wv >> 2)) & 63;
     float x = b2v;
-    if constexpr (PRE) {
 #pragma unroll
-        for (int p = 0; p < 8; ++p) x += pre[p];             // h-tiles in ascending order: the same sum wherever it runs
-    } else {
-#pragma unroll
-        for (int w = 0; w < MID_WAVES; ++w) x += part[w][wv][cs];
-    }
+    for (int w = 0; w < MID_WAVES; ++w) x += part[w][wv][cs];
     const float nrm = fmaxf(sqrtf(wave_sum(x * x)), 1e-12f);       // F.normalize(dim=1), eps 1e-12
     float sc = 1.f;
     if (train) {                                 // as head_row
@@ -332,7 +319,7 @@ struct MidFwdParams {
 };
 static_assert(sizeof(MidFwdParams) + idl::PLAN_PARAMS <= idl::PLAN_BYTES, "MidFwdParams does not fit a plan record");
 
-template <bool TIN, bool PRE = false>
+template <bool TIN>
 __global__ __launch_bounds__(64 * MID_WAVES) void mid_fwd_kernel(float *__restrict__ a1, const float *__restrict__ b1, const float *__restrict__ W2,
                                                                   const float *__restrict__ b2, const float *__restrict__ W3,
                                                                   const float *__restrict__ b3, int m, int C, int train, uint64_t seed,
@@ -340,18 +327,18 @@ __global__ __launch_bounds__(64 * MID_WAVES) void mid_fwd_kernel(float *__restri
                                                                   float *__restrict__ inv, float *__restrict__ r2, float *__restrict__ z,
                                                                   int n_rows_wg, int tile0, int tile1, idl_dev::GatherArgs gth)
 {
-    mid_fwd_body<TIN, PRE>(a1, b1, W2, b2, W3, b3, m, C, train, seed, ctl, f, inv, r2, z, n_rows_wg, tile0, tile1, gth, (int)blockIdx.x);
+    mid_fwd_body<TIN>(a1, b1, W2, b2, W3, b3, m, C, train, seed, ctl, f, inv, r2, z, n_rows_wg, tile0, tile1, gth, (int)blockIdx.x);
 }
 
 // the same for several voters in one launch: the grid is (voters, workgroups of one voter) -- the VOTER index runs fastest, so the
 // computing workgroups of every voter are dispatched before anybody's batch-assembly workgroups (a workgroup of this kernel fills a
 // CU: voter by voter, the second half of the voters would wait behind the first half's streaming workgroups); each voter takes its
 // arguments from its plan record (common.h)
-template <bool TIN, bool PRE = false>
+template <bool TIN>
 __global__ __launch_bounds__(64 * MID_WAVES) void mid_fwd_batched_kernel(const unsigned char *__restrict__ plans)
 {
     const MidFwdParams &p = *(const MidFwdParams *)(plans + (size_t)blockIdx.x * idl::PLAN_BYTES + idl::PLAN_PARAMS);
-    mid_fwd_body<TIN, PRE>(p.a1, p.b1, p.W2, p.b2, p.W3, p.b3, p.m, p.C, p.train, p.seed, p.ctl, p.f, p.inv, p.r2, p.z, p.n_rows_wg, p.tile0, p.tile1, p.gth,
+    mid_fwd_body<TIN>(p.a1, p.b1, p.W2, p.b2, p.W3, p.b3, p.m, p.C, p.train, p.seed, p.ctl, p.f, p.inv, p.r2, p.z, p.n_rows_wg, p.tile0, p.tile1, p.gth,
                       (int)blockIdx.y);
 }
 
@@ -1206,7 +1193,7 @@ __global__ __launch_bounds__(wg_dev::THREADS) void wgrad_rmsprop_kernel(wg_dev::
 __global__ __launch_bounds__(l1_dev::THREADS, 4) void l1_rms_kernel(l1_dev::L1Args l, RmsArgs a, const float *hyper, int64_t *ctl, int64_t batch_advance)
 {
     extern __shared__ __attribute__((aligned(1024))) unsigned char l1_rms_smem[];
-    if ((int)blockIdx.x < l.n_tiles) { l1_dev::l1_fwd_body<false, 0>(l, (int)blockIdx.x, l1_rms_smem); return; }
+    if ((int)blockIdx.x < l.n_tiles) { l1_dev::l1_fwd_body<0>(l, (int)blockIdx.x, l1_rms_smem); return; }
     if (threadIdx.x >= RMS_THREADS) return;                  // (before any barrier: rmsprop_body is written for 256 threads)
     rmsprop_body<false>(a, hyper, ctl, batch_advance, 0, 0, idl_dev::GatherArgs{}, (int)blockIdx.x - l.n_tiles, (int)threadIdx.x);
 }
@@ -1414,8 +1401,7 @@ static int mid_fwd_gather_impl(float *a1, const float *b1, int a1_transposed, co
     IDL_REQUIRE((((uintptr_t)a1 | (uintptr_t)W2 | (uintptr_t)W3) & 15u) == 0, "a1 / W2 / W3 must be 16-byte aligned");
     IDL_REQUIRE(parts >= 1 && part >= 0 && part <= part_end && part_end <= parts, "mid_fwd_gather: need 0 <= part <= part_end <= parts");
     IDL_REQUIRE(b1 == nullptr || (((uintptr_t)b1) & 15u) == 0, "mid_fwd_gather: b1 must be 16-byte aligned");
-    IDL_REQUIRE(a1_transposed >= 0 && a1_transposed <= 2 && (a1_transposed != 2 || b1 == nullptr),
-                "mid_fwd_gather: a1_transposed is 0, 1 or 2 (a1 = idl_l1_fwd's lat partials, no b1)");
+    IDL_REQUIRE(a1_transposed == 0 || a1_transposed == 1, "mid_fwd_gather: a1_transposed is 0 or 1");
     IDL_REQUIRE((yh != nullptr) == (yl != nullptr) && (yh == nullptr || (feats != nullptr && ((((uintptr_t)yh) | ((uintptr_t)yl)) & 7u) == 0)),
                 "mid_fwd_gather: both planes of the next batch (8-byte aligned) or neither; planes need the batch assembly");
     idl_dev::GatherArgs g{};
@@ -1430,15 +1416,13 @@ static int mid_fwd_gather_impl(float *a1, const float *b1, int a1_transposed, co
     const dim3 grid((unsigned)(m / 16 + (t1 - t0 + 3) / 4));
     if (void *plan = idl::take_plan()) {          // recorded, not launched (idl_plan_begin)
         idl::PlanHead h{};
-        h.kind = idl::PLAN_MID_FWD; h.variant = a1_transposed; /* 0 row-major, 1 transposed, 2 lat partials (head only) */ h.grid[0] = grid.x; h.grid[1] = 1; h.grid[2] = 1; h.block = 64 * MID_WAVES;
+        h.kind = idl::PLAN_MID_FWD; h.variant = a1_transposed; /* 0 row-major, 1 transposed */ h.grid[0] = grid.x; h.grid[1] = 1; h.grid[2] = 1; h.block = 64 * MID_WAVES;
         memcpy(plan, &h, sizeof(h));
         const MidFwdParams p{a1, b1, W2, b2, W3, b3, m, C, train, seed, ctl, f, inv, r2, z, m / 16, (int)t0, (int)t1, g};
         memcpy((unsigned char *)plan + idl::PLAN_PARAMS, &p, sizeof(p));
         return IDL_OK;
     }
-    if (a1_transposed == 2) hipLaunchKernelGGL((mid_fwd_kernel<false, true>), grid, dim3(64 * MID_WAVES), 0, (hipStream_t)stream, a1, b1, W2, b2, W3, b3,
-                                               m, C, train, seed, ctl, f, inv, r2, z, m / 16, (int)t0, (int)t1, g);
-    else if (a1_transposed) hipLaunchKernelGGL(mid_fwd_kernel<true>, grid, dim3(64 * MID_WAVES), 0, (hipStream_t)stream, a1, b1, W2, b2, W3, b3,
+    if (a1_transposed) hipLaunchKernelGGL(mid_fwd_kernel<true>, grid, dim3(64 * MID_WAVES), 0, (hipStream_t)stream, a1, b1, W2, b2, W3, b3,
                                           m, C, train, seed, ctl, f, inv, r2, z, m / 16, (int)t0, (int)t1, g);
     else hipLaunchKernelGGL(mid_fwd_kernel<false>, grid, dim3(64 * MID_WAVES), 0, (hipStream_t)stream, a1, b1, W2, b2, W3, b3,
                             m, C, train, seed, ctl, f, inv, r2, z, m / 16, (int)t0, (int)t1, g);
@@ -1934,7 +1918,7 @@ int idl_l1_fwd_rms(const float *W1, const float *x, int m, int n_in, float *r1_t
     IDL_REQUIRE((((uintptr_t)W1 | (uintptr_t)x | (uintptr_t)r1_transposed) & 15u) == 0, "l1_fwd_rms: buffers must be 16-byte aligned");
     const int n_tiles = (l1_dev::H1 / l1_dev::TH) * (m / l1_dev::TR);
     static const int prio = [] { const char *e = idl::dev_env("l1_prio"); return e ? atoi(e) : 0; }();     // (A/B knob: measured)
-    const l1_dev::L1Args l{W1, x, nullptr, nullptr, r1_transposed, nullptr, nullptr, 0, m, n_in, 0, 1, n_tiles, 0, 0, idl_dev::GatherArgs{}, prio};
+    const l1_dev::L1Args l{W1, x, r1_transposed, m, n_in, n_tiles, prio};
     idl_dev::GatherArgs g{};
     return rmsprop_launch(count, params, grads, grad_parts, square_avg, sizes, hyper, ctl, batch_advance, loss_rows, loss_m, w_nce, w_iic, out, g,
                           stream, wg_index, wg_dy, wg_x, wg_m, wg_n_out, wg_n_in, wg_grad, wg_x_transposed, nullptr, -1, &l, w1_index);
@@ -2044,12 +2028,9 @@ int idl_plan_launch(const void *host_plans, const void *dev_plans, int n_voters,
     const hipStream_t st = (hipStream_t)stream;
     switch (h.kind) {
     case idl::PLAN_MID_FWD:
-        if (h.variant == 2) hipLaunchKernelGGL((mid_fwd_batched_kernel<false, true>), dim3((unsigned)n_voters, h.grid[0]), dim3(h.block), 0, st, dp);
-        else if (h.variant) hipLaunchKernelGGL(mid_fwd_batched_kernel<true>, dim3((unsigned)n_voters, h.grid[0]), dim3(h.block), 0, st, dp);
+        if (h.variant) hipLaunchKernelGGL(mid_fwd_batched_kernel<true>, dim3((unsigned)n_voters, h.grid[0]), dim3(h.block), 0, st, dp);
         else hipLaunchKernelGGL(mid_fwd_batched_kernel<false>, dim3((unsigned)n_voters, h.grid[0]), dim3(h.block), 0, st, dp);
         break;
-    case idl::PLAN_L1_FWD:
-        return idl::l1_plan_launch(h, dev_plans, n_voters, st);
     case idl::PLAN_MID_BWD:
         hipLaunchKernelGGL(mid_bwd_batched_kernel, dim3((unsigned)n_voters, h.grid[0]), dim3(h.block), 0, st, dp);
         break;

@@ -56,8 +56,8 @@ VARIANTS = {
     "planes_wgrad": "1",     # 0: dW1 on the fp32 tiles (writing W1's planes) beside the two-plane layer 1
     "planes_tail": "wgrad",  # reduce: the optimizer tail beside the next step's partial sums instead of on the dW1 tiles' loader waves
     "mid_fused": "1", "pipeline": "1", "dw2_inlaunch": "1", "overlap": "0", "early_gather": "1", "gather_split": "4", "transposed_l1": "1",
-    "l1_fused": "0",         # 1: bias / ReLU / Dropout / the K-split of Linear(512, 64) in the epilogue of own layer-1 tiles; bare: those tiles as a plain product
-    "l1_gather": "0", "joint_inlaunch": "1", "wgrad_fused": "1", "keep_w1_grad": "0", "steps_per_graph": "16",
+    "l1_fused": "0",         # bare: the fp32 form's own layer-1 tiles as a plain product without the riding tail (the comparison of test_tail_riding_*)
+    "joint_inlaunch": "1", "wgrad_fused": "1", "keep_w1_grad": "0", "steps_per_graph": "16",
     "tail_l1": "1",          # 0 (fp32 form): the optimizer tail behind the dW1 tiles instead of riding in the next step's layer-1 launch
 }
 
@@ -98,7 +98,6 @@ class _Buffers:
         self._r1_other = None
         self._H1 = H1
         self.lat = torch.empty((m, H2), **f32)
-        self._lat_part = None                         # idl_l1_fwd with its epilogue (opt-in): made on first use
         self._dims = (m, H2, dev)
         self.f = torch.empty((m, H2), **f32)
         self.inv = torch.empty((m,), **f32)
@@ -141,14 +140,6 @@ def _planes_of(bf, F):
                       "valid": [False, False],          # valid[i]: xh[i] / xl[i] hold the planes of the batch in bf.xs[i]
                       "x32": [True, True]}              # x32[i]: bf.xs[i] itself holds that batch (False: it was assembled as planes only)
     return bf._planes
-
-
-def _lat_part_of(bf):
-    """idl_l1_fwd's partial sums of r1 W2^T per 64-unit tile of the hidden layer (the opt-in IDELUCS_DEV=l1_fused=1 path only)."""
-    if bf._lat_part is None:
-        m, H2, dev = bf._dims
-        bf._lat_part = torch.empty((_L.idl_l1_fwd_parts(), m, H2), dtype=torch.float32, device=dev)
-    return bf._lat_part
 
 
 class _Recorder:
@@ -248,17 +239,10 @@ class FusedLinearTrainer:
         self._gsplit = min(max(int(_v("gather_split")), 0), 8)   # eighths of the tiles the mid-forward launch takes
         # layer-1 activations kept transposed ([512, m]) between the layer-1 product and its consumers
         self._transposed_l1 = _v("transposed_l1") != "0"
-        # OPT-IN (IDELUCS_DEV=l1_fused=1; measured, not adopted -- DESIGN 4.4): the layer-1 product on this package's own MFMA tiles with bias /
-        # ReLU / Dropout and the K-split of Linear(512, 64) in its epilogue (csrc/l1_fwd.hip, idl_l1_fwd); the mid-forward launch is then
-        # the head alone.  The bare product ties hipBLASLt (32.1-33.1 us against 32.8-33.7) and the head's own path shrinks from 8.9 to
-        # 2.6 us, but that launch's LENGTH is set by the batch assembly riding in it (three dependent memory round trips, ~8-10 us),
-        # which stays: 36.4 + 10.4 us against 32.8 + 11.0, the step 114.7 us against 111.8.
-        self._l1_fused = _v("l1_fused") == "1"
-        # IDELUCS_DEV=l1_fused=bare: the same tiles as a plain product (no epilogue) in place of the library GEMM, mid_fwd unchanged
+        # IDELUCS_DEV=l1_fused=bare: the fp32 form's own layer-1 tiles as a plain product (no riding tail) in place of the library GEMM, mid_fwd unchanged.
+        # (Round 4's variant with bias / ReLU / Dropout and the K-split of Linear(512, 64) in those tiles' epilogue -- 114.7 us a step against 111.8: the
+        #  mid-forward launch is as long as the batch assembly riding in it, not as its head -- left the library in round 6: DESIGN, History.)
         self._l1_bare = _v("l1_fused") == "bare"
-        # eighths of the next batch's tiles assembled by RIDER workgroups of that launch (default 0: beside fp32 MFMA waves, which hold
-        # the vector issue port, the riders' arithmetic costs the tiles 9 us for the 7 us it saves the middle launches)
-        self._l1_gather = min(max(int(_v("l1_gather")), 0), 8)   # eighths of the next batch's tiles its riders assemble
         # opt-in: InfoNCE pass 2 + IIC core inside the mid-backward launch (one boundary less, but the InfoNCE tiles then run on
         # the 64 CUs of that launch instead of 256: the fused launch takes 32.8 us against 9.5 + 13.5 -- measured +8 us per step)
         self._nce_bwd_fused = False              # (round 6: InfoNCE pass 2 + the IIC core inside the mid-backward launch -- +8 us a step -- was removed)
@@ -338,13 +322,13 @@ class FusedLinearTrainer:
         early = next_from is not None and self._early_gather and m % 16 == 0   # next batch -> bf.xs[1 - xi] by the mid launches
         early_f = next_from is not None and self._early_fwd and m % 16 == 0    # ... by the mid-forward launch alone
         if (self._rec is not None and self._planes and self._planes_lockstep and tl and early and self._early_split and not self._nce_bwd_fused
-                and not self._l1_fused and not self._l1_bare and self._wgrad_fused and not self._wgrad_own_launch and not self._overlap
+                and not self._l1_bare and self._wgrad_fused and not self._wgrad_own_launch and not self._overlap
                 and self._joint_inlaunch and self._dw3_partial and bf.nce_fused and C <= 48
                 and bool(_L.idl_l1_planes_supported(m, self.H1, self.F)) and bool(_L.idl_wgrad_xplanes_supported(m, self.H1, self.F))
                 and 144 <= (self.H1 // 64) * (self.F // 128) <= self._cus and next_from.n < 60_000_000):
             return self._record_planes_step(bf, tr, next_from, xi)
         # tail-in-layer-1: own layer-1 tiles, the dW1 tiles as the step's last launch, the rest of the optimizer in the NEXT layer-1 launch
-        tm = (self._tail_l1 and tl and early and self._early_split and self._rec is None and not self._l1_fused and not self._l1_bare
+        tm = (self._tail_l1 and tl and early and self._early_split and self._rec is None and not self._l1_bare
               and not self._nce_bwd_fused and self._wgrad_fused and not self._wgrad_own_launch and not self._shared_buffers
               and self._dw2_inlaunch and not self._overlap
               and bool(_L.idl_l1_fwd_supported(m, self.H1, self.F)) and bool(_L.idl_wgrad_supported(m, self.H1, self.F)))
@@ -381,10 +365,9 @@ class FusedLinearTrainer:
         main = torch.cuda.current_stream()
         side = self._side if self._overlap else main
         # ---- forward
-        l1 = tl and self._l1_fused and early and self._early_split and bool(_L.idl_l1_fwd_supported(m, self.H1, self.F))
-        # shares (eighths) of the next batch's assembly: [0, g1) riders of the layer-1 launch, [g1, g2) the mid-forward launch, [g2, 8) mid-backward
-        g1 = self._l1_gather if l1 else 0
-        g2 = max(g1, self._gsplit)
+        # shares (eighths) of the next batch's assembly: [0, g2) the mid-forward launch, [g2, 8) mid-backward
+        g1 = 0
+        g2 = self._gsplit
         if pl:
             # a1^T = W1 x^T as eight K-slice partial sums on the fp16 matrix cores, then ONE launch that adds the eight up on every CU (and, in the
             # variant that keeps the tail off the dW1 tiles' loader waves, runs the previous step's optimizer tail beside that)
@@ -403,7 +386,7 @@ class FusedLinearTrainer:
                 pbf, pxi, pr1 = self._pending
                 self._tail_launch(pbf, pxi, pr1, l1=(x, m, r1T))
             else:
-                chk(_L.idl_l1_fwd(_p(self.W1), _p(x), None, None, m, self.F, 0, 0, None, _p(r1T), 1, None, _stream()))
+                chk(_L.idl_l1_fwd(_p(self.W1), _p(x), m, self.F, _p(r1T), _stream()))
         elif plf:   # a1 = x W1^T as eight K-slice partial sums [8][m][512] (the tiles of idl_l1_planes with the operands' roles swapped), then their sum
             wh, wl, _ = self._w1_planes
             if self._cold:
@@ -411,14 +394,8 @@ class FusedLinearTrainer:
             chk(_L.idl_l1_planes(_p(pb["xh"][xi]), _p(pb["xl"][xi]), self.F, _p(wh), _p(wl), self.F, self.H1, m, self.F, _p(pb["part"][xi]), _stream()))
             chk(_L.idl_reduce_parts_rms(_p(pb["part"][xi]), self.H1 * m, _p(self.ctl), _p(self._ctl_snap), 0, None, None, None, None, None, None, None, None, 0, 0.0, 0.0, None, 0,
                                         -1, None, None, 0, 0, 0, 0, None, 0, _stream()))
-        elif l1:    # own tiles: r1^T = Dropout(ReLU(W1 x^T + b1)) and the partial sums of lat = r1 W2^T straight from the accumulators
-            st = next_from      # ... with shares [0, g1) of the next batch's tiles assembled by riders of the same launch (HBM is idle under it)
-            self._k(_L.idl_l1_fwd_gather, _p(self.W1), _p(x), _p(self.b1), _p(self.W2), m, self.F, tr, self.seed, _p(self.ctl), _p(r1), 1,
-                    _p(_lat_part_of(bf)),
-                    _p(st.feats), st.n, st.f, st.n * st.f, _p(self._perm), _p(self.ctl[1:]), m // 2, st.n_pairs, m // 2,
-                    _p(st.mean), _p(st.scale), _p(st.inv_scale), _p(bf.xs[1 - xi]), 0, self._l1_gather, 8, _stream())
         elif tl and self._l1_bare and self._rec is None and bool(_L.idl_l1_fwd_supported(m, self.H1, self.F)):
-            chk(_L.idl_l1_fwd(_p(self.W1), _p(x), None, None, m, self.F, 0, 0, None, _p(r1), 1, None, _stream()))
+            chk(_L.idl_l1_fwd(_p(self.W1), _p(x), m, self.F, _p(r1), _stream()))
         elif tl:    # a1^T = W1 x^T: the orientation hipBLASLt runs this product fastest in; mid_fwd adds the bias
             self._mm(self.W1, x.t(), r1T)
         else:
@@ -434,8 +411,8 @@ class FusedLinearTrainer:
                                              _p(pb["xl"][1 - xi]), _p(self._w1_planes[2]), g1, g2, 8, _stream()))
         elif early and self._early_split:         # ... and the first half of the next batch's tiles in its spare workgroups
             st = next_from
-            self._k(_L.idl_mid_fwd_gather, _p(_lat_part_of(bf)) if l1 else _p(r1), _p(self.b1) if (tl and not l1) else None,
-                    2 if l1 else (1 if tl else 0), _p(self.W2), _p(self.b2), _p(self.W3), _p(self.b3),
+            self._k(_L.idl_mid_fwd_gather, _p(r1), _p(self.b1) if tl else None,
+                    1 if tl else 0, _p(self.W2), _p(self.b2), _p(self.W3), _p(self.b3),
                     m, C, tr, self.seed, _p(self.ctl),
                     _p(bf.f), _p(bf.inv), _p(bf.r2), _p(bf.z),
                     _p(st.feats), st.n, st.f, st.n * st.f, _p(self._perm), _p(self.ctl[1:]), m // 2, st.n_pairs, m // 2,
@@ -900,7 +877,6 @@ class BatchedLinearTrainer:
         self._programs = {}
         self._graphs = {}
         self._w1_in_launch = False
-        self._l1_in_launch = False
         self._planes_step = False
 
     def drop_planes(self):
@@ -934,13 +910,12 @@ class BatchedLinearTrainer:
                         t.step_on_batch(t.buffers(m), train=True, batch_advance=m // 2, next_from=store, xi=xi)
                     finally:
                         rec, t._rec = t._rec, None
-                    # 4 kernel launches + the two big products as batched GEMMs; a product on own tiles is a recorded launch instead:
-                    # the layer-1 forward (idl_l1_fwd) in front, dW1 at the head of the optimizer launch
-                    if (len(rec.plans), rec.mms) not in ((4, 2), (4, 1), (5, 1), (5, 0), (6, 0)):
+                    # the two-plane step: six recorded launches, no library GEMM; the fp32 form: 4 kernel launches + the two big products as batched
+                    # GEMMs (dW1 on own tiles at the head of the optimizer launch is a recorded launch instead: one GEMM)
+                    if (len(rec.plans), rec.mms) not in ((4, 2), (4, 1), (6, 0)):
                         raise RuntimeError("the recorded step is not the default launch sequence")
-                    self._planes_step = len(rec.plans) == 6          # the two-plane step: six recorded launches, no library GEMM
-                    self._l1_in_launch = len(rec.plans) == 5
-                    self._w1_in_launch = rec.mms == (0 if self._l1_in_launch else 1)
+                    self._planes_step = len(rec.plans) == 6
+                    self._w1_in_launch = rec.mms == 1
                     recs.append(rec.plans)
                 ops = []
                 for k in range(len(recs[0])):
@@ -962,12 +937,8 @@ class BatchedLinearTrainer:
                 _lib.check(_L.idl_plan_launch(ctypes.c_void_p(ops[k][0].data_ptr()), _p(ops[k][1]), L, _stream()))
             return
         k0 = 0
-        if self._l1_in_launch:                                                           # every voter's layer-1 tiles + epilogue: one launch
-            _lib.check(_L.idl_plan_launch(ctypes.c_void_p(ops[0][0].data_ptr()), _p(ops[0][1]), L, _stream()))
-            k0 = 1
-        else:
-            r1T = st['r1'].view(L, self._H1, -1)
-            torch.bmm(self.W1s, st['xs'][xi].transpose(1, 2), out=r1T)                    # a1^T = W1 x^T per voter
+        r1T = st['r1'].view(L, self._H1, -1)
+        torch.bmm(self.W1s, st['xs'][xi].transpose(1, 2), out=r1T)                        # a1^T = W1 x^T per voter
         for k in (k0, k0 + 1, k0 + 2):                                                   # mid_fwd, InfoNCE passes, mid_bwd
             _lib.check(_L.idl_plan_launch(ctypes.c_void_p(ops[k][0].data_ptr()), _p(ops[k][1]), L, _stream()))
         if not self._w1_in_launch:

@@ -83,7 +83,7 @@ def main():
         t_pad = timed(lambda: _lib.check(L.idl_l1_planes(p(pw), p(pl_), F + pad, p(px), p(py), F + pad, m, H, F, p(part), st())))
         torch.cuda.synchronize()
         print(f"   pitch {F} + {pad} elements: {t_pad:.1f} us (error {(part.double().sum(0) - ref).abs().max().item() / scale:.1e})")
-    t_32 = timed(lambda: _lib.check(L.idl_l1_fwd(p(W), p(x), None, None, m, F, 0, 0, None, p(r1T), 1, None, st())))
+    t_32 = timed(lambda: _lib.check(L.idl_l1_fwd(p(W), p(x), m, F, p(r1T), st())))
     t_sx = timed(lambda: _lib.check(L.idl_split_planes(p(x), x.numel(), 3, p(xh), p(xl), None, st())))
     torch.cuda.synchronize()
     e_pl = (part.double().sum(0) - ref).abs().max().item() / scale

@@ -1,12 +1,12 @@
 // l1_planes_device.h -- the layer-1 forward product a1^T = W1 x^T on the fp16 MATRIX CORES from operands kept as two fp16 planes
-// (planes.h): the device side, shared by planes.hip (idl_l1_planes: the step's first launch) and train_step.hip (the same tiles with the
-// previous step's optimizer tail riding behind them, idl_l1_planes_rms: a measured variant, IDELUCS_DEV=planes_reduce=mid).
+// (planes.h): the device side, shared by planes.hip (idl_l1_planes: the step's first launch) and train_step.hip (l1_planes_batched_kernel: a rank's
+// voters in lockstep).
 //
 // Reference: Linear(F,512) of idelucs/PytorchUtils.py:38-45, called for both views of a batch at idelucs/models.py:124-125.  The fp32
 // tiles of l1_device.h sit on the fp32 matrix pipe's floor (27.4 us at 512 x 1024 x 4096; 33.6 measured); the fp16 pipe is sixteen
 // times faster, and with BOTH operands split in two planes the three products w0 x0 + w0 x1 + w1 x0 carry 22 significand bits per
-// factor -- measured against a float64 product the sum is closer than the fp32 library GEMM (the probe: csrc/probe_split.hip,
-// profiles/r05_probe_split_mfma.txt; tests/test_gpu_encoder.py).  What is left is data movement: 4 bytes an element, as fp32.
+// factor -- measured against a float64 product the sum is closer than the fp32 library GEMM on the step's dense sums (the probe: tools/probe_split.hip,
+// profiles/r05_probe_split_mfma.txt; tests/test_gpu_planes.py, profiles/r06_planes_adversarial.txt).  What is left is data movement: 4 bytes an element, as fp32.
 //
 // 128 x 128 tiles of a1^T with an 8-way split of K, ONE K SLICE PER XCD (workgroups go to the XCDs round-robin: slice = blockIdx % 8, so an
 // XCD's L2 streams one eighth of both operands; whole-K tiles of 64 x 32 would pull 600 MB a launch out of L2).  Four LOADER waves bring
@@ -16,8 +16,10 @@
 // partial sums go out as part[8][512][m] fp32 (scaled back by 2^-(W_EXP + X_EXP)); idl_reduce_parts_rms adds the eight in a fixed order.
 // The operands' roles are symmetric: called with the batch's planes as "W1" and W1's as the "batch" the same tiles give part[8][m][512]
 // (the step of n_clusters > 48, whose activations are not transposed).
-// WHERE IT STANDS: 18.5-19.8 us in the step; what it moves out of L2 (134 MB at the ~10 TB/s this access pattern gets: 13.4 us) + 3.8 us of
-// partial-sum stores + launch; computing alone 6.4 us, MFMA pipe busy 0.20.
+// WHERE IT STANDS (round 6): 15.3 us in the step (round 5: 18.5-19.8).  The loaders alone, free-running, stream the launch's 134 MB out of L2 in 4 us (33 TB/s; 13 us
+// without the K-slice-per-XCD mapping); computing alone 6.4 us; together 11 + 3.8 us of partial-sum stores + launch: per K-step the LDS serves 32 KB of fragment reads and
+// 16 KB of DMA writes (384 clocks at 128 B a clock) beside 384 clocks of MFMAs per SIMD -- two pipes at equal load that a one-step look-ahead keeps ~half busy (MFMA 0.23).
+// Four chunks of 32 k resident instead of two of 64 k: 17.9 us (not a latency pipeline); DESIGN 4.4 and History.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

@@ -1340,10 +1340,14 @@ __global__ __launch_bounds__(64 * V4_MAX_WAVES) void vectorise4_kernel(VecArgs a
         if constexpr (RL > 0) { for (int b = lane; b < F; b += 64) W::fold_copies(copies, hist, b, iv); }
         fence();
         // the un-mutated histogram stays in registers (four bins a lane and 256): a view is undone by writing it back -- RP conflict-free stores
-        // instead of the view's atomics a second time
-        uint4 h0[RP];
+        // instead of the view's atomics a second time.  (k = 6, the CGR / canonical instance only: 64 registers would hold it; there a view is undone by
+        // evaluating its edits again with the other sign, and the rows leave piece by piece.)
+        constexpr bool KEEP = RP <= 4;
+        uint4 h0[KEEP ? RP : 1];
+        if constexpr (KEEP) {
 #pragma unroll
-        for (int j = 0; j < RP; ++j) h0[j] = *(const uint4 *)(hist + (lane + 64 * j) * 4);
+            for (int j = 0; j < RP; ++j) h0[j] = *(const uint4 *)(hist + (lane + 64 * j) * 4);
+        }
         // ---------------- the views: apply, row out, restore
         int eo = 0;
 #pragma unroll 1
@@ -1362,7 +1366,7 @@ __global__ __launch_bounds__(64 * V4_MAX_WAVES) void vectorise4_kernel(VecArgs a
                     for (int t = 0; t < K; ++t) W::move(hist, pr[t], 1u);
                 }
             }
-            uint4 h[RP];
+            uint4 h[KEEP ? RP : 1];
             int64_t S = (int64_t)windows + (iv ? (int64_t)F : 0);
             if (ne > 0) { fence(); S += (int64_t)wave_sum(dwt); }
             const int64_t row = (int64_t)vi * a.view_stride + cur.s * row_len;
@@ -1397,28 +1401,60 @@ __global__ __launch_bounds__(64 * V4_MAX_WAVES) void vectorise4_kernel(VecArgs a
                     stored = true;
                 } else if (a.mode == IDL_MODE_CGR) {
                     // the histogram is kept in k-mer order; a CGR row is stored in pixel order (kmers.pyx:53-123 through cgr_pixel_to_kmer)
+                    if constexpr (KEEP) {
 #pragma unroll
-                    for (int j = 0; j < RP; ++j) {
-                        const uint32_t i0 = (uint32_t)(lane + 64 * j) * 4u;
-                        h[j] = make_uint4(hist[cgr_pixel_to_kmer<K>(i0)], hist[cgr_pixel_to_kmer<K>(i0 + 1)], hist[cgr_pixel_to_kmer<K>(i0 + 2)], hist[cgr_pixel_to_kmer<K>(i0 + 3)]);
+                        for (int j = 0; j < RP; ++j) {
+                            const uint32_t i0 = (uint32_t)(lane + 64 * j) * 4u;
+                            h[j] = make_uint4(hist[cgr_pixel_to_kmer<K>(i0)], hist[cgr_pixel_to_kmer<K>(i0 + 1)], hist[cgr_pixel_to_kmer<K>(i0 + 2)], hist[cgr_pixel_to_kmer<K>(i0 + 3)]);
+                        }
+                    } else {
+                        const float Sf = (float)S, rS = 1.0f / Sf;
+                        float *dst = (float *)a.out + row + lane * 4;
+#pragma unroll 4
+                        for (int j = 0; j < RP; ++j) {
+                            const uint32_t i0 = (uint32_t)(lane + 64 * j) * 4u;
+                            const uint4 hh = make_uint4(hist[cgr_pixel_to_kmer<K>(i0)], hist[cgr_pixel_to_kmer<K>(i0 + 1)], hist[cgr_pixel_to_kmer<K>(i0 + 2)], hist[cgr_pixel_to_kmer<K>(i0 + 3)]);
+                            if (a.out_kind == IDL_OUT_COUNTS_I32) *(uint4 *)((uint32_t *)dst + j * 256) = hh;
+                            else {
+                                const float c0 = (float)hh.x, c1 = (float)hh.y, c2 = (float)hh.z, c3 = (float)hh.w;
+                                const float q0 = c0 * rS, q1 = c1 * rS, q2 = c2 * rS, q3 = c3 * rS;
+                                *(float4 *)(dst + j * 256) = make_float4(fmaf(fmaf(-q0, Sf, c0), rS, q0), fmaf(fmaf(-q1, Sf, c1), rS, q1),
+                                                                         fmaf(fmaf(-q2, Sf, c2), rS, q2), fmaf(fmaf(-q3, Sf, c3), rS, q3));
+                            }
+                        }
+                        stored = true;
                     }
                 }
             }
-            if (!OM || a.mode == IDL_MODE_KMER) {
-                if (ne > 0) {
+            if constexpr (KEEP) {
+                if (!OM || a.mode == IDL_MODE_KMER) {
+                    if (ne > 0) {
 #pragma unroll
-                    for (int j = 0; j < RP; ++j) h[j] = *(const uint4 *)(hist + (lane + 64 * j) * 4);
-                } else {
+                        for (int j = 0; j < RP; ++j) h[j] = *(const uint4 *)(hist + (lane + 64 * j) * 4);
+                    } else {
 #pragma unroll
-                    for (int j = 0; j < RP; ++j) h[j] = h0[j];
+                        for (int j = 0; j < RP; ++j) h[j] = h0[j];
+                    }
                 }
-            }
-            if (ne > 0 && vi + 1 < P) {                      // (the LDS unit takes a wave's operations in order: the stores follow the loads)
+                if (ne > 0 && vi + 1 < P) {                  // (the LDS unit takes a wave's operations in order: the stores follow the loads)
 #pragma unroll
-                for (int j = 0; j < RP; ++j) *(uint4 *)(hist + (lane + 64 * j) * 4) = h0[j];
+                    for (int j = 0; j < RP; ++j) *(uint4 *)(hist + (lane + 64 * j) * 4) = h0[j];
+                    fence();
+                }
+            } else if (ne > 0 && vi + 1 < P) {               // k = 6: back to the un-mutated histogram by the same pairs with the other sign
+                fence();
+                for (int e0 = 0; e0 < ne; e0 += 64) {
+                    const int ei = e0 + lane;
+                    if (ei < ne) {
+                        uint32_t pr[K];
+                        (void)W::edit_eval(Ev, ne, ei, cur.L - 1, cod, msk, garbage, pr);
+#pragma unroll
+                        for (int t = 0; t < K; ++t) W::move(hist, pr[t], 0xFFFFFFFFu);
+                    }
+                }
                 fence();
             }
-            if (!stored) {
+            if (KEEP && !stored) {
                 float *dst = (float *)a.out + row + lane * 4;
                 if (a.out_kind == IDL_OUT_COUNTS_I32) {
 #pragma unroll
@@ -1603,6 +1639,9 @@ int launch_vectorise4(const VecArgs &a_in, const idl::DeviceInfo &di, hipStream_
     int want = 4;
     if (const char *e = idl::dev_env("vec")) want = atoi(e);
     const bool om = a.mode == IDL_MODE_CGR || a.mode == IDL_MODE_CANONICAL;
+    if (K == 6 && !om) return IDL_OK;                        // (plain rows at k = 6 are v3's: bound by the write stream there)
+    // (k = 6, CGR / canonical: 2.29 / 4.99 ms at 100 000 x 10 kbp x 4 views against v2's 3.05 / 7.53 -- the collapse reads hist[rc(b)] for 64 consecutive b, a COLUMN of the
+    //  histogram seen as 64 x 64: one bank; a padded histogram pitch would free it, at the price of every helper that takes a bin's byte offset as bin * 4)
     if (want != 4 || (a.mode != IDL_MODE_KMER && !om) || a.init == IDL_INIT_FROM_OUT || a.out_kind == IDL_OUT_FREQ_F64 || a.n_views > V3_MAXV || a.max_len <= 0 ||
         a.max_len > 64 * 64 * V4_SR || a.n > 0x7F000000ll)
         return IDL_OK;
@@ -1621,7 +1660,7 @@ int launch_vectorise4(const VecArgs &a_in, const idl::DeviceInfo &di, hipStream_
     if (waves < 4) return IDL_OK;                            // (long sequences: v3 / v2)
     const size_t lds = (size_t)slice * 4 * waves;
     if ((int)lds > di.max_dyn_lds) return IDL_OK;
-    const void *fn = om ? (const void *)vectorise4_kernel<K, RL, true> : (const void *)vectorise4_kernel<K, RL, false>;
+    const void *fn = (om || K == 6) ? (const void *)vectorise4_kernel<K, RL, true> : (const void *)vectorise4_kernel<K, RL, K == 6>;
     if (lds > 64 * 1024) IDL_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int per_cu = 1, lc = 0;
     int64_t grid = (int64_t)di.cus * per_cu;
@@ -1632,8 +1671,8 @@ int launch_vectorise4(const VecArgs &a_in, const idl::DeviceInfo &di, hipStream_
     if (getenv("IDELUCS_DEBUG"))
         fprintf(stderr, "[idl] vectorise k=%d v4 (a wave per sequence) lds=%zu B a workgroup of %d waves (copies %d, staged slots %d, edits %d, pairs %d) -> %d workgroups/CU\n",
                 K, lds, waves, 1 << RL, a.v3_sc, ec, lc, per_cu);
-    if (om) hipLaunchKernelGGL((vectorise4_kernel<K, RL, true>), dim3((unsigned)grid), dim3(64 * waves), lds, st, a);
-    else hipLaunchKernelGGL((vectorise4_kernel<K, RL, false>), dim3((unsigned)grid), dim3(64 * waves), lds, st, a);
+    if (om || K == 6) hipLaunchKernelGGL((vectorise4_kernel<K, RL, true>), dim3((unsigned)grid), dim3(64 * waves), lds, st, a);
+    else hipLaunchKernelGGL((vectorise4_kernel<K, RL, K == 6>), dim3((unsigned)grid), dim3(64 * waves), lds, st, a);
     IDL_HIP_TRY(hipGetLastError());
     {       // second pass: v2 on the sequences v4 left alone; exits at once when there are none
         VecArgs b = a;
@@ -1653,7 +1692,7 @@ template <int K>
 int launch_vectorise3(const VecArgs &a_in, const idl::DeviceInfo &di, hipStream_t st, bool *done)
 {
     *done = false;
-    if constexpr (K == 4 || K == 5) {
+    if constexpr (K == 4 || K == 5 || K == 6) {
         int rc;
         if constexpr (K == 4) {
             // copies of the histogram a wave counts into: 4 -- measured at 100 000 x 10 kbp, 4 views, one box (gpurun_out r06): no edits / philox edits

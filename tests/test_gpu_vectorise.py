@@ -389,10 +389,10 @@ def test_cfg2_full_size_store_properties(gpu):
     assert int(counts[P - 1, n - 1].sum()) >= L - (k - 1) - 20 * k
 
 
-@pytest.mark.parametrize("k", [5, 4])
+@pytest.mark.parametrize("k", [6, 5, 4])
 def test_cgr_and_canonical_rows_of_the_wave_per_sequence_kernel_are_v2s(gpu, monkeypatch, k):
     """Round 6: the CGR permutation (kmers.pyx:53-123) and the canonical collapse with its truncating halve and own normalisation
-    (utils.py:208-221, 246-250) as epilogues of vectorise4_kernel (k = 4, 5: a wavefront owns the finished histogram) -- bit for bit the rows of the delta-view
+    (utils.py:208-221, 246-250) as epilogues of vectorise4_kernel (k = 4, 5, 6: a wavefront owns the finished histogram; k = 6 -- the reference's default k, model_size='small' -- in the instance that undoes a view by its edits) -- bit for bit the rows of the delta-view
     kernel v2 (the checker the oracle tests hold), counts and float32 frequencies, 20 000 x 10 kbp x 4 views with device-drawn mimic edits; also when some
     sequences go to the second pass."""
     import torch

@@ -329,6 +329,8 @@ def k_sweep(din, args, dev, ks=(4, 5), reps=6):
         atomics = (args.len - k + 1) + 2 * 0.015 * args.len * k * (P - 1)          # the count + an (old bin, new bin) pair per edit and window of every mimic view
         lds_floor_ms = din.n * atomics / (256 * 16 * 2.4e9) * 1e3                     # 16 a clock and CU: the instruction's issue rate
         del feats
+        #  the canonical rows of model_size='small' (reverse-complement collapse, utils.py:208-221) at this k, on the same kernel's epilogue
+        can_ms = _canonical_ms(din, k, P, edits, edit_off, dev, reps)
         #  the WHOLE path at this k -- sites + vectorise + scaler fit + one epoch of the same NetLinear(4^k -> 512 -> 64 -> C) on the same
         # 100 000 x 10 kbp: cfg4's shapes get a throughput figure, not only a vectorise stage.  At k = 5 (F = 1024) the step takes the two-plane
         # products; at k = 4 (F = 256: cluster.py's default k) no plane kernel applies (F >= 1024) and the step is its latency-bound launches
@@ -354,8 +356,28 @@ def k_sweep(din, args, dev, ks=(4, 5), reps=6):
         out[str(k)] = {"kernel": "vectorise4_kernel<%d> (a wavefront per sequence)" % k, "bound": "lds", "ms_per_launch": ms, "ms_min": min(ts), "whole_path": whole,
                        "bytes_per_seq_algorithmic": b_vec, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                        "lds_atomics_per_seq": int(atomics), "lds_issue_floor_ms": lds_floor_ms, "frac_of_lds_issue_floor": lds_floor_ms / ms,
-                       "sequences_per_sec_stage": din.n / (ms * 1e-3), "rows_checked": int(rows.numel())}
+                       "sequences_per_sec_stage": din.n / (ms * 1e-3), "rows_checked": int(rows.numel()),
+                       "canonical_rows_ms_per_launch": can_ms}
+    # k = 6 (the reference's default k): the canonical rows alone -- the plain rows are `roofline`'s kernel
+    out["6"] = {"kernel": "vectorise4_kernel<6> (canonical rows: a wavefront per sequence; plain rows at k = 6 are `roofline`)",
+                "canonical_rows_ms_per_launch": _canonical_ms(din, 6, P, edits, edit_off, dev, reps)}
     return out
+
+
+def _canonical_ms(din, k, P, edits, edit_off, dev, reps):
+    from idelucs_amd import _lib, utils as U
+    rl = int(_lib.lib.idl_row_len(_lib.MODE_CANONICAL, k))
+    rows = torch.empty((P, din.n, rl), dtype=torch.float32, device=dev)
+    run = lambda: U._vectorise(din, k, _lib.MODE_CANONICAL, _lib.INIT_ONE, _lib.OUT_FREQ_F32, P, edits, edit_off, rows)
+    run(); torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record(); run(); e.record(); torch.cuda.synchronize()
+        ts.append(s.elapsed_time(e))
+    sums = rows[:, ::max(din.n // 1024, 1)].double().sum(2)
+    assert torch.allclose(sums, torch.ones_like(sums), atol=1e-6)
+    return sum(ts) / len(ts)
 
 
 def lanes_epoch_ms(din, args, dev, rank, world, voters):

@@ -194,3 +194,22 @@ def test_no_lds_read_leaves_a_hand_scheduled_k_step_in_flight(tmp_path):
                         assert not (regs(ins) & flying), "%s: `%s` touches a register an LDS read has in flight (line %d of %s)" % (k, ins, no, out)
                 assert not any(fifo), "%s: a block with fp16 MFMAs ends with LDS reads outstanding (line %d of %s)" % (k, b[-1][0], out)
             assert checked >= 24, (k, checked)
+
+
+def test_the_one_developer_variable_is_parsed_by_name(tmp_path):
+    """csrc/dev_env.h: IDELUCS_DEV="name=value,name=value" -- a key is matched whole (vec is not vec_ablate), a bare name reads as "1", a missing one as NULL,
+    the value is re-read at every use; the Python side (idelucs_amd/_lib.py: DEV) splits the same string the same way."""
+    gxx = shutil.which("g++")
+    if gxx is None:
+        pytest.skip("no g++")
+    src = tmp_path / "t.cpp"
+    src.write_text('#include <cstdio>\n#include "dev_env.h"\nint main(int argc, char **argv) { for (int i = 1; i < argc; ++i) { const char *v = idl::dev_env(argv[i]); '
+                   'printf("%s=%s\\n", argv[i], v ? v : "<null>"); } return 0; }\n')
+    exe = tmp_path / "t"
+    r = subprocess.run([gxx, "-std=c++17", "-I", os.path.join(ROOT, "idelucs_amd", "csrc"), str(src), "-o", str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    env = dict(os.environ, IDELUCS_DEV="vec_ablate=3,vec=4,stamps,v3_ec=320,numa=off")
+    out = subprocess.run([str(exe), "vec", "vec_ablate", "stamps", "v3_ec", "v3", "numa", "missing", "ec"], capture_output=True, text=True, env=env).stdout.split()
+    assert out == ["vec=4", "vec_ablate=3", "stamps=1", "v3_ec=320", "v3=<null>", "numa=off", "missing=<null>", "ec=<null>"], out
+    env.pop("IDELUCS_DEV")
+    assert subprocess.run([str(exe), "vec"], capture_output=True, text=True, env=env).stdout.split() == ["vec=<null>"]

@@ -47,6 +47,7 @@ SIGNATURES = {
     "idl_fasta_parse_pack": (_int, [_c.c_char_p, _vp, _vp, _i64, _vp, _vp, _vp, _c.POINTER(_vp)]),
     "idl_fasta_arena_slots": (_int, [_vp, _vp]),
     "idl_fasta_arena_meta": (_int, [_vp, _vp, _vp, _pi64, _pi64]),
+    "idl_fasta_names_high": (_int, [_vp]),
     "idl_fasta_arena_mask_flags": (_i64, [_vp, _vp]),
     "idl_mask_from_lengths": (_int, [_vp, _vp, _vp, _vp, _i64, _vp]),
     "idl_ingest_release": (None, []),

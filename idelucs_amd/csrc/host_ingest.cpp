@@ -755,6 +755,7 @@ struct idl_fasta {
     std::vector<Rec> recs;
     int check = 1;
     int64_t total_bases = 0, total_slots = 0, names_bytes = 0;
+    int names_high = -1;           // 1: some header byte is >= 0x80 (the decoded-name checks apply), 0: all ASCII, -1: this reader did not look
     std::vector<int64_t> arena_slot;      // idl_fasta_parse_pack: first slot of every record in the caller's arenas (+ the end)
     std::vector<int64_t> lengths;         // idl_fasta_parse_pack: cleaned lengths, ready for idl_fasta_arena_meta
     std::vector<uint8_t> mask_sent;       // idl_fasta_parse_pack with device arenas: 1 = the record's invalid-mask was copied there
@@ -1237,7 +1238,7 @@ int idl_fasta_parse_pack(const char *path, uint8_t *codes, uint8_t *mask, int64_
     int64_t last_end = 0;
     for (const FastOut &o : outs) if (!o.recs.empty()) last_end = o.slot.back();
     f->arena_slot[n] = last_end;
-    struct Part { int64_t bases = 0, slots = 0, names = 0, lo = INT64_MAX, hi = 0, unsent = 0; };
+    struct Part { int64_t bases = 0, slots = 0, names = 0, lo = INT64_MAX, hi = 0, unsent = 0; unsigned high = 0; };
     std::vector<Part> parts((size_t)ns);
     parallel_for(n >= 4096 ? nt : 1, [&](int t0) {
         for (int t = t0; t < ns; t += (n >= 4096 ? nt : 1)) {
@@ -1253,16 +1254,20 @@ int idl_fasta_parse_pack(const char *path, uint8_t *codes, uint8_t *mask, int64_
                 f->mask_sent[at + i] = ms;
                 p.unsent += ms ? 0 : 1;
                 p.bases += r.len; p.slots += (r.len + 63) / 64; p.names += (int64_t)(r.id_e - r.id_b);
+                for (size_t j = r.id_b; j < r.id_e; ++j) p.high |= buf[j];      // (a non-ASCII header: the caller validates the decoded names at once)
                 p.lo = std::min(p.lo, r.len); p.hi = std::max(p.hi, r.len);
             }
         }
     });
     int64_t lo = INT64_MAX;
+    unsigned high = 0;
     for (const Part &p : parts) {
         f->total_bases += p.bases; f->total_slots += p.slots; f->names_bytes += p.names; f->n_mask_unsent += p.unsent;
+        high |= p.high;
         lo = std::min(lo, p.lo); f->max_len = std::max(f->max_len, p.hi);
     }
     f->min_len = n ? lo : 0;
+    f->names_high = (high & 0x80u) ? 1 : 0;
     if (timing) fprintf(stderr, "idl_fasta_parse_pack: one pass %.1f ms (%d threads, %zu records)\n", now() - t_0, nt, n);
     *out = f;
     return IDL_OK;
@@ -1303,6 +1308,8 @@ void idl_ingest_release(void)
     { std::lock_guard<std::mutex> lk(g_map_mu); m.swap(g_map); g_map_key = MapKey{}; }
     if (m && m.use_count() == 1) m->unmap_inline = true;          // nobody else reads it: unmapped before this returns
 }
+
+int idl_fasta_names_high(const idl_fasta *f) { return f ? f->names_high : -1; }
 
 int idl_fasta_sizes(const idl_fasta *f, int64_t *n_records, int64_t *total_bases, int64_t *total_slots,
                     int64_t *names_bytes)

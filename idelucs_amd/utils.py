@@ -95,7 +95,8 @@ class FastaFile:
         """A FastaFile over an idl_fasta handle the caller opened (idl_fasta_parse_pack: arena = True -> slot_off are the records'
         first slots in the caller's arenas); the handle is closed.
         meta = (lengths, slot_off) already read out with idl_fasta_arena_meta (the one-pass ingest: they go to the device first):
-        the names are then exported on first use or at close() -- off the path between the file and the first kernel."""
+        the names are then exported on first use or at close() -- off the path between the file and the first kernel; a file with a non-ASCII header byte
+        (idl_fasta_names_high) exports and validates them here (invalid UTF-8 / a unicode space heading a name fail when the file is read)."""
         obj = cls.__new__(cls)
         if arena and meta is not None:
             n, tb, ts, nb = (ctypes.c_int64() for _ in range(4))
@@ -106,6 +107,8 @@ class FastaFile:
             obj._names_raw = obj._name_off = obj._names = None
             obj._names_bytes, obj._check = nb.value, True
             obj._h = h
+            if int(_L.idl_fasta_names_high(h)) != 0:      # a non-ASCII header (rare): the checks on the decoded names run now, as the reference's do while it reads
+                obj._export_names()
             return obj
         arena_slots = None
         if arena:

@@ -561,3 +561,46 @@ def test_file_page_node_probe(tmp_path):
     assert _lib.lib.idl_ingest_probe_file_node(os.fsencode(str(small))) == -1
     assert _lib.lib.idl_ingest_probe_file_node(os.fsencode(str(tmp_path / "nope"))) == -1
     assert _lib.lib.idl_ingest_file_node() in [-1] + nodes
+
+
+def test_non_ascii_headers_are_checked_when_the_file_is_read(tmp_path, monkeypatch):
+    """in the one-pass ingest the names stay in the handle until somebody asks for them -- but the two checks of the reference that need DECODED
+    names (invalid UTF-8; a unicode space as a header's first character, which `line[1:].strip()` semantics of idelucs/utils.py:26-51 reject) must fail
+    when the file is read, not when the CLI writes its TSV after training.  idl_fasta_names_high says whether any header byte is >= 0x80; FastaFile.from_handle(meta=...)
+    then exports and validates at once.  ASCII files keep the deferral (names exported on first use)."""
+    monkeypatch.setenv("IDELUCS_THREADS", "4")
+    dev_env(monkeypatch, par_min="0")
+
+    def open_deferred(content):
+        p = tmp_path / "u.fas"
+        p.write_bytes(content)
+        size = os.path.getsize(p)
+        cap = size // 48 + 4096 * U.ingest_threads() + 1024
+        codes = np.zeros(cap * 16, np.uint8); mask = np.zeros(cap * 8, np.uint8)
+        h = ctypes.c_void_p()
+        _lib.check(_lib.lib.idl_fasta_parse_pack(os.fsencode(str(p)), U._ptr(codes), U._ptr(mask), cap, None, None, None, ctypes.byref(h)))
+        n = ctypes.c_int64()
+        _lib.check(_lib.lib.idl_fasta_sizes(h, ctypes.byref(n), None, None, None))
+        lengths = np.empty(n.value, np.int64); slot_off = np.empty(n.value + 1, np.int64)
+        lo, hi = ctypes.c_int64(), ctypes.c_int64()
+        _lib.check(_lib.lib.idl_fasta_arena_meta(h, U._ptr(lengths), U._ptr(slot_off), ctypes.byref(lo), ctypes.byref(hi)))
+        high = int(_lib.lib.idl_fasta_names_high(h))
+        return high, (lambda: U.FastaFile.from_handle(h, arena=True, meta=(lengths, slot_off)))
+
+    body = b"".join(b">r%d\nACGTACGTAC\n" % i for i in range(50))
+    high, make = open_deferred(body)
+    ff = make()
+    assert high == 0 and ff._names_raw is None                  # ASCII: deferred
+    assert ff.names[:2] == ["r0", "r1"]
+    high, make = open_deferred(body.replace(b">r7\n", ">r7é\n".encode()))
+    ff = make()
+    assert high == 1 and ff._names_raw is not None and ff.names[7] == "r7é"      # valid non-ASCII: read out at once, accepted
+    high, make = open_deferred(body.replace(b">r9\n", "> r9\n".encode()))       # an EM SPACE heads the name
+    assert high == 1
+    with pytest.raises(ValueError) as e:
+        make()
+    assert str(e.value) == "Bad character in sequence header"
+    high, make = open_deferred(body.replace(b">r11\n", b">r11\xff\xfe\n"))
+    assert high == 1
+    with pytest.raises((UnicodeDecodeError, ValueError)):
+        make()

@@ -1640,10 +1640,10 @@ int launch_vectorise4(const VecArgs &a_in, const idl::DeviceInfo &di, hipStream_
     if (const char *e = idl::dev_env("vec")) want = atoi(e);
     const bool om = a.mode == IDL_MODE_CGR || a.mode == IDL_MODE_CANONICAL;
     if (K == 6 && !om) return IDL_OK;                        // (plain rows at k = 6 are v3's: bound by the write stream there)
-    // (k = 6, CGR / canonical: 2.29 / 4.99 ms at 100 000 x 10 kbp x 4 views against v2's 3.05 / 7.53.  The collapse is INSTRUCTION-bound -- 4096 bins x 4 views a sequence walked by
-    //  one wave, ~40 VALU instructions a bin and walk: ~120 k cycles a sequence and SIMD --, not bank-bound: summing the pairs in place in a skewed, conflict-free order (lane l of
+    // (k = 6, CGR / canonical: 2.29 / 4.99 ms at 100 000 x 10 kbp x 4 views against v2's 3.05 / 7.53.  The collapse is latency-bound -- 4096 bins x 4 views a sequence walked by
+    //  one wave in 64 turns, twice --, not bank- or instruction-bound: summing the pairs in place in a skewed, conflict-free order (lane l of
     //  turn t takes b = l | ((l + t) mod 64) << 6) and restoring them by a third walk was built and measured: 6.0 ms at k = 6, no change at k = 4 / 5; rc(b) from per-lane and per-turn
-    //  halves would halve the instructions: not built)
+    //  halves (no bit reversal in the loop) measured too: 5.1 ms -- a walk costs ~1.3 ms whatever its body: 64 dependent turns of LDS latency at two waves a SIMD)
     if (want != 4 || (a.mode != IDL_MODE_KMER && !om) || a.init == IDL_INIT_FROM_OUT || a.out_kind == IDL_OUT_FREQ_F64 || a.n_views > V3_MAXV || a.max_len <= 0 ||
         a.max_len > 64 * 64 * V4_SR || a.n > 0x7F000000ll)
         return IDL_OK;
